@@ -1,0 +1,195 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (imported from /root/reference).
+
+Run in the authoring container only (the reference does not travel to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The fixtures pin the oracle (oracle/ppo_numpy.py, oracle/gae_scan.c, oracle/torch_port.py) to the
+reference's real outputs on seeded inputs; tests/test_oracle_golden.py re-checks them everywhere.
+Nothing from the reference is copied: only its *outputs* on our inputs are stored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch as th
+
+REF = os.environ.get("ERL_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+class ScriptedVecEnv:
+    """Linear toy env whose terminal/truncate flags come from a seeded script (so both occur)."""
+
+    def __init__(self, num_envs, state_dim, action_dim, seed):
+        g = th.Generator().manual_seed(seed)
+        self.num_envs, self.state_dim, self.action_dim = num_envs, state_dim, action_dim
+        self.ws = 0.9 * th.eye(state_dim) + 0.05 * th.randn(state_dim, state_dim, generator=g)
+        self.wa = 0.1 * th.randn(action_dim, state_dim, generator=g)
+        self.g = g
+        self.state = th.randn(num_envs, state_dim, generator=g)
+
+    def reset(self):
+        return self.state.clone(), {}
+
+    def step(self, action):
+        s = self.state @ self.ws + action @ self.wa
+        reward = -(s * s).mean(1) - 0.01 * (action * action).mean(1)
+        u = th.rand(self.num_envs, generator=self.g)
+        terminal = u < 0.10
+        truncate = (u >= 0.10) & (u < 0.22)
+        done = terminal | truncate
+        fresh = th.randn(self.num_envs, self.state_dim, generator=self.g)
+        s = th.where(done[:, None], fresh, s)
+        self.state = s
+        return s.clone(), reward, terminal, truncate, {}
+
+
+def np32(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def net_arrays(prefix, net):
+    out = {}
+    for k, v in net.state_dict().items():
+        out[f"{prefix}.{k}"] = np32(v)
+    return out
+
+
+def make_ppo(tag, *, N, S, A, H, net_dims, batch_size, repeat_times, use_v_trace, seed):
+    sys.path.insert(0, REF)
+    from elegantrl.agents import AgentPPO
+    from elegantrl.train.config import Config
+
+    th.manual_seed(seed)
+    args = Config(AgentPPO, None, {"env_name": "scripted", "num_envs": N, "max_step": 100,
+                                   "state_dim": S, "action_dim": A, "if_discrete": False})
+    args.net_dims = list(net_dims)
+    args.horizon_len, args.batch_size, args.repeat_times = H, batch_size, repeat_times
+    args.learning_rate = 1e-3
+    args.gamma = 0.99
+    args.reward_scale = 0.5
+    args.if_use_v_trace = use_v_trace
+    agent = AgentPPO(args.net_dims, S, A, gpu_id=-1, args=args)
+    with th.no_grad():  # non-trivial normalisation buffers and action std
+        for net in (agent.act, agent.cri):
+            net.state_avg[:] = 0.1 * th.randn(S)
+            net.state_std[:] = 1.0 + 0.2 * th.rand(S)
+        agent.act.action_std_log[:] = -0.3 + 0.1 * th.randn(1, A)
+
+    env = ScriptedVecEnv(N, S, A, seed + 1)
+    agent.last_state = env.reset()[0]
+    first_state = np32(agent.last_state)
+
+    th.set_grad_enabled(False)
+    g = {}
+    g.update(net_arrays("act0", agent.act))
+    g.update(net_arrays("cri0", agent.cri))
+
+    # --- rollout: record the policy mean so eps can be recovered ---
+    means = []
+    orig_get_action = agent.act.get_action
+
+    def recording_get_action(state):
+        means.append(agent.act.net(agent.act.state_norm(state)).clone())
+        return orig_get_action(state)
+
+    agent.act.get_action = recording_get_action
+    items = agent.explore_env(env, H)
+    agent.act.get_action = orig_get_action
+    states, actions, logprobs, rewards, undones, unmasks = items
+    mean = th.stack(means)
+    std = agent.act.action_std_log.exp()
+    eps = ((actions.double() - mean.double()) / std.double())
+    g.update(first_state=first_state, states=np32(states), actions=np32(actions), logprobs=np32(logprobs),
+             rewards=np32(rewards), undones=np32(undones), unmasks=np32(unmasks),
+             eps=eps.numpy().copy(), action_mean=np32(mean), last_state=np32(agent.last_state))
+
+    # --- value pre-pass + GAE on clones (get_advantages mutates rewards/undones) ---
+    values = agent.cri(states).squeeze(-1)
+    r2, u2 = rewards.clone(), undones.clone()
+    adv = agent.get_advantages(states, r2, u2, unmasks, values)
+    next_value = agent.cri(agent.last_state).squeeze(-1)
+    adv_norm = (adv - adv.mean()) / (adv[::4, ::4].std() + 1e-5)
+    g.update(values=np32(values), next_value=np32(next_value), advantages=np32(adv),
+             rewards_after=np32(r2), undones_after=np32(u2), reward_sums=np32(adv + values),
+             advantages_norm=np32(adv_norm))
+
+    # --- update_net with recorded minibatch ids ---
+    ids_log = []
+    orig_randint = th.randint
+
+    def recording_randint(*a, **k):
+        out = orig_randint(*a, **k)
+        ids_log.append(out.clone())
+        return out
+
+    th.randint = recording_randint
+    th.set_grad_enabled(True)
+    objs = agent.update_net([t.clone() for t in items])
+    th.set_grad_enabled(False)
+    th.randint = orig_randint
+    g.update(net_arrays("act1", agent.act))
+    g.update(net_arrays("cri1", agent.cri))
+    g.update(ids=np.stack([np32(i) for i in ids_log]).astype(np.int64),
+             objs=np.array([float(o) for o in objs], dtype=np.float64),
+             hyper=np.array([args.gamma, agent.lambda_gae_adv, agent.ratio_clip, float(agent.lambda_entropy),
+                             args.learning_rate, args.clip_grad_norm, args.reward_scale], dtype=np.float64),
+             dims=np.array([N, S, A, H, batch_size, len(ids_log), int(use_v_trace), *net_dims], dtype=np.int64))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"ppo_{tag}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, {k: v.shape for k, v in g.items() if k in ("states", "ids", "advantages")})
+
+
+def make_replay():
+    sys.path.insert(0, REF)
+    from elegantrl.train.replay_buffer import ReplayBuffer
+
+    th.manual_seed(7)
+    max_size, S, A, num_seqs = 20, 3, 2, 2
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=-1, num_seqs=num_seqs)
+    buf.states.zero_(); buf.actions.zero_(); buf.rewards.zero_(); buf.undones.zero_(); buf.unmasks.zero_()
+    adds = [7, 7, 6, 5, 9, 20, 3]   # 7+7+6 lands exactly on max_size (edge A12); 20 == max_size
+    g = {"adds": np.array(adds), "dims": np.array([max_size, S, A, num_seqs])}
+    orig_randint = th.randint
+    for k, add in enumerate(adds):
+        items = (th.randn(add, num_seqs, S), th.randn(add, num_seqs, A), th.randn(add, num_seqs),
+                 th.rand(add, num_seqs) > 0.2, th.rand(add, num_seqs) > 0.1)
+        buf.update(items)
+        for name, t in zip(("states", "actions", "rewards", "undones", "unmasks"), items):
+            g[f"in{k}_{name}"] = np32(t)
+        g[f"cursor{k}"] = np.array([buf.p, buf.cur_size, int(buf.if_full), buf.add_size])
+        for name in ("states", "actions", "rewards", "undones", "unmasks"):
+            g[f"buf{k}_{name}"] = np32(getattr(buf, name))
+        log = []
+
+        def rec(*a, **kw):
+            out = orig_randint(*a, **kw)
+            log.append(out.clone())
+            return out
+
+        th.randint = rec
+        out = buf.sample(16)
+        th.randint = orig_randint
+        g[f"ids{k}"] = np32(log[0]).astype(np.int64)
+        g[f"ids0_{k}"] = np32(buf.ids0).astype(np.int64)
+        g[f"ids1_{k}"] = np32(buf.ids1).astype(np.int64)
+        for name, t in zip(("state", "action", "reward", "undone", "unmask", "next_state"), out):
+            g[f"out{k}_{name}"] = np32(t)
+    path = os.path.join(OUT, "replay_ring.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), f"reference not mounted at {REF}"
+    make_ppo("small_vtrace", N=8, S=6, A=2, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0,
+             use_v_trace=True, seed=11)
+    make_ppo("small_alt", N=8, S=6, A=2, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0,
+             use_v_trace=False, seed=12)
+    make_ppo("mid_vtrace", N=40, S=17, A=5, H=20, net_dims=(128, 128), batch_size=64, repeat_times=6.4,
+             use_v_trace=True, seed=13)
+    make_replay()

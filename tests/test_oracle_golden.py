@@ -1,0 +1,129 @@
+"""Pin the numpy oracle to the reference's real outputs (tests/golden, made by oracle/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import ppo_numpy as O
+from tests.helpers import PPO_GOLDENS, dims, hyper, load, mlp_from
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_rollout_action_logprob(name):
+    g = load(name)
+    actor = mlp_from(g, "act0")
+    H = dims(g)["H"]
+    for t in range(H):
+        a, lp = O.actor_sample(g["states"][t], actor, g["eps"][t].astype(np.float32))
+        np.testing.assert_allclose(a, g["actions"][t], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(lp, g["logprobs"][t], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_values(name):
+    g = load(name)
+    critic = mlp_from(g, "cri0")
+    v = O.critic_value(g["states"], critic)
+    np.testing.assert_allclose(v, g["values"], rtol=1e-5, atol=2e-6)
+    nv = O.critic_value(g["last_state"], critic)
+    np.testing.assert_allclose(nv, g["next_value"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_gae_matches_reference(name):
+    g = load(name)
+    hp, d = hyper(g), dims(g)
+    adv, r2, u2 = O.gae_scan(g["rewards"], g["undones"], g["unmasks"], g["values"], g["next_value"],
+                             hp["gamma"], hp["lam"], use_v_trace=d["vtrace"])
+    assert (~g["unmasks"]).any(), "fixture must exercise the truncation fix-up"
+    assert (~g["undones"]).any()
+    np.testing.assert_array_equal(u2, g["undones_after"])
+    np.testing.assert_allclose(r2, g["rewards_after"], rtol=0, atol=2e-6)
+    # the reference re-runs the critic on the truncated rows; everything else is the same op order
+    np.testing.assert_allclose(adv, g["advantages"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(O.reward_sums(adv, g["values"]), g["reward_sums"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(O.adv_normalize(g["advantages"]), g["advantages_norm"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_gae_fp64_bounds_fp32(name):
+    g = load(name)
+    hp, d = hyper(g), dims(g)
+    adv64, _, _ = O.gae_scan(g["rewards"].astype(np.float64), g["undones"], g["unmasks"],
+                             g["values"].astype(np.float64), g["next_value"].astype(np.float64),
+                             hp["gamma"], hp["lam"], use_v_trace=d["vtrace"])
+    np.testing.assert_allclose(adv64, g["advantages"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_update_net_weights_and_objectives(name):
+    """Full minibatch loop (gather -> objectives -> manual backward -> clip -> Adam) vs the reference's
+    autograd + torch.optim.Adam, on the reference's own recorded randint ids."""
+    g = load(name)
+    hp, d = hyper(g), dims(g)
+    actor, critic = mlp_from(g, "act0"), mlp_from(g, "cri0")
+    buf = (g["states"], g["actions"], g["unmasks"], g["logprobs"], g["advantages_norm"], g["reward_sums"])
+    sa, sc = O.AdamState(), O.AdamState()
+    objs = []
+    for ids in g["ids"]:
+        objs.append(O.ppo_minibatch_step(buf, ids, actor, critic, sa, sc, lr=hp["lr"], max_norm=hp["max_norm"],
+                                         ratio_clip=hp["ratio_clip"], lambda_entropy=hp["lambda_entropy"]))
+    objs = np.array(objs, dtype=np.float64).mean(axis=0)
+    np.testing.assert_allclose(objs, g["objs"], rtol=2e-4, atol=2e-6)
+    ref_a, ref_c = mlp_from(g, "act1"), mlp_from(g, "cri1")
+    for mine, ref in ((actor, ref_a), (critic, ref_c)):
+        for p, q in zip(mine.trainable(), ref.trainable()):
+            np.testing.assert_allclose(p, q, rtol=0, atol=5e-6)  # measured <= 1.3e-6
+    moved = sum(float(np.abs(p - q).sum()) for p, q in zip(mlp_from(g, "act0").trainable(), ref_a.trainable()))
+    assert moved > 0
+
+
+def test_replay_ring_cursors_indices_and_rows():
+    g = load("replay_ring.npz")
+    max_size, S, A, num_seqs = [int(x) for x in g["dims"]]
+    ring = O.Ring(max_size, S, A, num_seqs)
+    for k, add in enumerate(g["adds"]):
+        items = tuple(g[f"in{k}_{n}"] for n in ("states", "actions", "rewards", "undones", "unmasks"))
+        ring.update(items)
+        assert [ring.p, ring.cur_size, int(ring.if_full), ring.add_size] == list(g[f"cursor{k}"])
+        for n in ("states", "actions", "rewards", "undones", "unmasks"):
+            np.testing.assert_array_equal(getattr(ring, n), g[f"buf{k}_{n}"])
+        out, (i0, i1) = ring.sample(g[f"ids{k}"])
+        np.testing.assert_array_equal(i0, g[f"ids0_{k}"])
+        np.testing.assert_array_equal(i1, g[f"ids1_{k}"])
+        for arr, n in zip(out, ("state", "action", "reward", "undone", "unmask", "next_state")):
+            np.testing.assert_array_equal(arr, g[f"out{k}_{n}"])
+    assert list(g["cursor2"][:3]) == [max_size, max_size, 0]  # lands exactly on max_size: not yet "full"
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_c_oracle_gae_bitwise_equals_numpy_and_matches_reference(name):
+    from oracle import c_oracle
+    g = load(name)
+    hp, d = hyper(g), dims(g)
+    adv_c, ret_c, r_c, u_c = c_oracle.gae(g["rewards"], g["undones"], g["unmasks"], g["values"], g["next_value"],
+                                          hp["gamma"], hp["lam"], use_v_trace=d["vtrace"])
+    adv_n, r_n, u_n = O.gae_scan(g["rewards"], g["undones"], g["unmasks"], g["values"], g["next_value"],
+                                 hp["gamma"], hp["lam"], use_v_trace=d["vtrace"])
+    np.testing.assert_array_equal(adv_c, adv_n)           # same op order, no contraction: bit-identical
+    np.testing.assert_array_equal(ret_c, adv_n + g["values"])
+    np.testing.assert_array_equal(r_c, r_n)
+    np.testing.assert_array_equal(u_c, u_n)
+    np.testing.assert_allclose(adv_c, g["advantages"], rtol=0, atol=1e-5)
+
+
+def test_c_oracle_cols_variant_equals_plain():
+    from oracle import c_oracle
+    rng = np.random.default_rng(0)
+    H, N = 37, 133
+    r = rng.standard_normal((H, N), dtype=np.float32)
+    v = rng.standard_normal((H, N), dtype=np.float32)
+    u = rng.random((H, N)) < 0.95
+    m = rng.random((H, N)) < 0.97
+    nv = rng.standard_normal(N, dtype=np.float32)
+    adv, ret, r2, u2 = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95)
+    rr, uu, mm = r.copy(), u.astype(np.uint8), m.astype(np.uint8)
+    a2, t2 = np.empty_like(r), np.empty_like(r)
+    c_oracle.gae_cols_inplace(rr, uu, mm, v, nv, a2, t2, 0, 70, 0.99, 0.95)
+    c_oracle.gae_cols_inplace(rr, uu, mm, v, nv, a2, t2, 70, N, 0.99, 0.95)
+    np.testing.assert_array_equal(a2, adv)
+    np.testing.assert_array_equal(t2, ret)
+    np.testing.assert_array_equal(rr, r2)
