@@ -1,0 +1,7 @@
+"""elegantrl_amd -- MI355X-native (gfx950) hot path for an ElegantRL-compatible vectorised actor-learner.
+
+Same Python surface as `elegantrl` for the path named in BASELINE.json (train_agent / Config / AgentBase /
+AgentPPO / ReplayBuffer); the arithmetic runs in hand-written HIP kernels behind the C ABI in
+include/erl_hip.h (elegantrl_amd/lib/liberl_hip.so).  No CPU fallback, no CUDA shims.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,123 @@
+"""ctypes binding of liberl_hip.so (the C ABI declared in include/erl_hip.h).
+
+This is the only way the package reaches the GPU kernels.  There is NO CPU or PyTorch fallback:
+if the shared library is missing, or a kernel reports an error, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from typing import Optional
+
+import torch as th
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liberl_hip.so")
+
+# flags mirrored from include/erl_hip.h
+GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
+GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
+MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
+ABI_VERSION = 1
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "erl_abi_version": (c_int, []),
+    "erl_last_error_string": (c_char_p, []),
+    "erl_device_info": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "erl_gae_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "erl_gae_scan_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_float, c_float, c_int, _P, _P, c_int64, _P]),
+    "erl_adv_stats_f32": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P]),
+    "erl_adv_normalize_f32": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
+    "erl_split_ids_i64": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
+    "erl_ppo_gather_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P, c_int64,
+                                   _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "erl_replay_write_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int, c_int,
+                                     c_int64, c_int64, _P]),
+    "erl_replay_sample_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64,
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "erl_mlp_param_count": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "erl_value_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P]),
+    "erl_rollout_step_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_uint64, c_uint64,
+                                     _P, _P, _P, _P, _P]),
+    "erl_ppo_slab_stride": (c_int64, [c_int, c_int, c_int, c_int]),
+    "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
+                                 c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, _P, c_int, _P]),
+    "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),
+    "erl_clip_adam_f32": (c_int, [_P, _P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, _P, c_int32, c_float,
+                                  c_float, c_float, c_float, c_float, c_float, _P]),
+    "erl_synenv_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_uint64, _P]),
+    "erl_pendulum_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_uint64, _P]),
+    "erl_selftest_mfma": (c_int, [POINTER(c_float)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load liberl_hip.so once; fail loudly if it is absent (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                f"{LIB_PATH} not found: build it with `make -C elegantrl_amd/csrc` (or __graft_entry__.build()). "
+                "elegantrl_amd has no CPU/PyTorch fallback for its kernels.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if handle.erl_abi_version() != ABI_VERSION:
+            raise HipExtensionError(f"liberl_hip.so ABI {handle.erl_abi_version()} != binding ABI {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().erl_last_error_string()
+        raise HipExtensionError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream (kernels are ordered with torch ops on that stream)."""
+    return th.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[th.Tensor], dtype: Optional[th.dtype] = None) -> Optional[int]:
+    """Raw device pointer of a contiguous CUDA(HIP) tensor; None passes NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipExtensionError("elegantrl_amd kernels need tensors on a HIP device (no CPU path); got a CPU tensor")
+    if not t.is_contiguous():
+        raise HipExtensionError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise HipExtensionError(f"expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def flag_ptr(t: th.Tensor) -> int:
+    """bool/uint8 flags are passed as bytes."""
+    if t.dtype not in (th.bool, th.uint8):
+        raise HipExtensionError(f"flag tensor must be bool/uint8, got {t.dtype}")
+    return ptr(t)
+
+
+def device_info():
+    cu, lds = c_int(0), c_int(0)
+    check(lib().erl_device_info(ctypes.byref(cu), ctypes.byref(lds)), "erl_device_info")
+    return cu.value, lds.value
+
+
+def selftest_mfma() -> float:
+    err = c_float(0)
+    check(lib().erl_selftest_mfma(ctypes.byref(err)), "erl_selftest_mfma")
+    return float(err.value)

@@ -1,0 +1,116 @@
+// Shared host/device helpers for liberl_hip.so (gfx950 / CDNA4 only: wave = 64, no portability layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/erl_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+void erl_set_error(const char *fmt, ...);
+
+#define ERL_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            erl_set_error(__VA_ARGS__);        \
+            return ERL_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+static inline int erl_hip_status(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return ERL_OK;
+    erl_set_error("%s: %s", what, hipGetErrorString(e));
+    return -(1000 + (int)e);
+}
+
+#define ERL_LAUNCH_CHECK(what) return erl_hip_status(hipGetLastError(), what)
+
+static inline int64_t erl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// device: wave / block reductions (wave64)
+// ---------------------------------------------------------------------------------------------
+#define ERL_WAVE 64
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, ERL_WAVE);
+    return v;
+}
+
+// sum over the whole block; result valid in every thread. `scratch` holds >= blockDim.x/64 T's.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();  // protect scratch reuse
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    T t = 0;
+    for (int w = 0; w < nw; ++w) t += scratch[w];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device: Philox4x32-10 counter RNG + Box-Muller (production noise for K1 and env resets)
+// ---------------------------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+// two uniforms in (0,1] -> two independent N(0,1)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &n0, float &n1)
+{
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.28318530717958647692f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// i-th N(0,1) of the stream (seed, counter, env): dims are consumed 4 per Philox call.
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t counter, uint32_t env, uint32_t dim)
+{
+    const Philox4 p = philox4x32_10(env, dim >> 2, (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    float n0, n1;
+    if ((dim & 2) == 0) box_muller(p.x, p.y, n0, n1);
+    else box_muller(p.z, p.w, n0, n1);
+    return (dim & 1) ? n1 : n0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device: exact-erf GELU (nn.GELU default) and its derivative
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return x * (0.5f * (1.0f + erff(x * 0.70710678118654752440f))); }
+
+__device__ __forceinline__ void gelu_and_grad(float x, float &y, float &g)
+{
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
+    y = x * cdf;
+    g = cdf + x * pdf;
+}

@@ -1,0 +1,208 @@
+// K5: PPO minibatch index decomposition + gather; K8/K9: replay ring write / sample.  gfx950.
+// All HBM-bound byte/index work: flat element mapping so that reads inside a gathered row and all
+// writes are coalesced; indices are int64 and bit-exact (ids % L, ids // L; the reference's th.fmod /
+// th.div(rounding_mode='floor') on non-negative ids).
+#include "erl_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void split_ids_kernel(const int64_t *__restrict__ ids, int64_t B, int64_t L,
+                                                        int64_t *__restrict__ ids0, int64_t *__restrict__ ids1)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const int64_t id = ids[i];
+    const int64_t q = id / L;
+    if (ids0) ids0[i] = id - q * L;
+    if (ids1) ids1[i] = q;
+}
+
+// One "virtual row" per sample of width W = S + A + 4 columns:
+//   [0,S) state | [S,S+A) action | S+A: unmask | +1: logprob | +2: advantage | +3: reward_sum
+// source element = x[(t*N + n) * dim + c] with t = id % H, n = id // H   (AgentPPO.py:179-187)
+__global__ __launch_bounds__(256) void ppo_gather_kernel(const float *__restrict__ states, const float *__restrict__ actions,
+                                                         const uint8_t *__restrict__ unmasks,
+                                                         const float *__restrict__ logprobs,
+                                                         const float *__restrict__ advantages,
+                                                         const float *__restrict__ reward_sums, int64_t H, int64_t N,
+                                                         int S, int A, const int64_t *__restrict__ ids, int64_t B,
+                                                         float *__restrict__ o_state, float *__restrict__ o_action,
+                                                         uint8_t *__restrict__ o_unmask, float *__restrict__ o_logprob,
+                                                         float *__restrict__ o_adv, float *__restrict__ o_ret,
+                                                         int64_t *__restrict__ o_ids0, int64_t *__restrict__ o_ids1)
+{
+    const int W = S + A + 4;
+    const int64_t total = B * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / W;
+        const int c = (int)(e - b * W);
+        const int64_t id = ids[b];
+        const int64_t n = id / H, t = id - n * H;
+        const int64_t row = t * N + n;
+        if (c < S) {
+            if (o_state) o_state[b * S + c] = states[row * S + c];
+        } else if (c < S + A) {
+            if (o_action) o_action[b * A + (c - S)] = actions[row * A + (c - S)];
+        } else {
+            switch (c - S - A) {
+            case 0:
+                if (o_unmask) o_unmask[b] = unmasks[row];
+                if (o_ids0) o_ids0[b] = t;
+                if (o_ids1) o_ids1[b] = n;
+                break;
+            case 1: if (o_logprob) o_logprob[b] = logprobs[row]; break;
+            case 2: if (o_adv) o_adv[b] = advantages[row]; break;
+            default: if (o_ret) o_ret[b] = reward_sums[row]; break;
+            }
+        }
+    }
+}
+
+// Ring write: virtual row of width W = S + A + 3 per (time row i, sequence q);
+// destination time row = (p + i) mod max_size  (replay_buffer.py:86-105).
+template <bool FLAG_F32>
+__global__ __launch_bounds__(256) void replay_write_kernel(float *__restrict__ b_states, float *__restrict__ b_actions,
+                                                           float *__restrict__ b_rewards, float *__restrict__ b_undones,
+                                                           float *__restrict__ b_unmasks, const float *__restrict__ states,
+                                                           const float *__restrict__ actions,
+                                                           const float *__restrict__ rewards, const void *__restrict__ undones,
+                                                           const void *__restrict__ unmasks, int64_t max_size,
+                                                           int64_t num_seqs, int S, int A, int64_t p, int64_t add)
+{
+    const int W = S + A + 3;
+    const int64_t rows = add * num_seqs, total = rows * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / W;
+        const int c = (int)(e - r * W);
+        const int64_t i = r / num_seqs, q = r - i * num_seqs;
+        int64_t ti = p + i;
+        if (ti >= max_size) ti -= max_size;
+        const int64_t d = ti * num_seqs + q;
+        if (c < S) b_states[d * S + c] = states[r * S + c];
+        else if (c < S + A) b_actions[d * A + (c - S)] = actions[r * A + (c - S)];
+        else if (c == S + A) b_rewards[d] = rewards[r];
+        else if (c == S + A + 1)
+            b_undones[d] = FLAG_F32 ? ((const float *)undones)[r] : (((const uint8_t *)undones)[r] ? 1.f : 0.f);
+        else
+            b_unmasks[d] = FLAG_F32 ? ((const float *)unmasks)[r] : (((const uint8_t *)unmasks)[r] ? 1.f : 0.f);
+    }
+}
+
+// Sample: virtual row of width W = 2S + A + 3:
+//   [0,S) state | [S,S+A) action | reward | undone | unmask | [S+A+3, 2S+A+3) next_state = states[t+1, n]
+__global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restrict__ b_states,
+                                                            const float *__restrict__ b_actions,
+                                                            const float *__restrict__ b_rewards,
+                                                            const float *__restrict__ b_undones,
+                                                            const float *__restrict__ b_unmasks, int64_t num_seqs, int S,
+                                                            int A, const int64_t *__restrict__ ids, int64_t B,
+                                                            int64_t sample_len, float *__restrict__ o_state,
+                                                            float *__restrict__ o_action, float *__restrict__ o_reward,
+                                                            float *__restrict__ o_undone, float *__restrict__ o_unmask,
+                                                            float *__restrict__ o_next, int64_t *__restrict__ o_ids0,
+                                                            int64_t *__restrict__ o_ids1)
+{
+    const int W = 2 * S + A + 3;
+    const int64_t total = B * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / W;
+        const int c = (int)(e - b * W);
+        const int64_t id = ids[b];
+        const int64_t n = id / sample_len, t = id - n * sample_len;
+        const int64_t row = t * num_seqs + n;
+        if (c < S) {
+            o_state[b * S + c] = b_states[row * S + c];
+        } else if (c < S + A) {
+            o_action[b * A + (c - S)] = b_actions[row * A + (c - S)];
+        } else if (c < S + A + 3) {
+            const int k = c - S - A;
+            if (k == 0) {
+                o_reward[b] = b_rewards[row];
+                if (o_ids0) o_ids0[b] = t;
+                if (o_ids1) o_ids1[b] = n;
+            } else if (k == 1) o_undone[b] = b_undones[row];
+            else o_unmask[b] = b_unmasks[row];
+        } else {
+            const int cs = c - S - A - 3;
+            o_next[b * S + cs] = b_states[(row + num_seqs) * S + cs];
+        }
+    }
+}
+
+inline int grid_for(int64_t total)
+{
+    int64_t g = erl_cdiv(total, 256);
+    if (g > 256 * 8) g = 256 * 8;  // grid-stride beyond 8 blocks per CU
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int erl_split_ids_i64(const int64_t *ids, int64_t B, int64_t sample_len, int64_t *ids0, int64_t *ids1, void *stream)
+{
+    ERL_REQUIRE(ids && B >= 0 && sample_len >= 1, "erl_split_ids_i64: bad argument");
+    if (B == 0) return ERL_OK;
+    hipLaunchKernelGGL(split_ids_kernel, dim3((unsigned)erl_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, ids, B,
+                       sample_len, ids0, ids1);
+    ERL_LAUNCH_CHECK("erl_split_ids_i64");
+}
+
+extern "C" int erl_ppo_gather_f32(const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
+                                  const float *advantages, const float *reward_sums, int64_t H, int64_t N, int S, int A,
+                                  const int64_t *ids, int64_t B, float *out_state, float *out_action, uint8_t *out_unmask,
+                                  float *out_logprob, float *out_advantage, float *out_reward_sum, int64_t *out_ids0,
+                                  int64_t *out_ids1, void *stream)
+{
+    ERL_REQUIRE(ids && H >= 1 && N >= 1 && S >= 1 && A >= 1 && B >= 0, "erl_ppo_gather_f32: bad shape");
+    ERL_REQUIRE((!out_state || states) && (!out_action || actions) && (!out_unmask || unmasks) &&
+                    (!out_logprob || logprobs) && (!out_advantage || advantages) && (!out_reward_sum || reward_sums),
+                "erl_ppo_gather_f32: output requested without its source tensor");
+    if (B == 0) return ERL_OK;
+    hipLaunchKernelGGL(ppo_gather_kernel, dim3(grid_for(B * (S + A + 4))), dim3(256), 0, (hipStream_t)stream, states, actions,
+                       unmasks, logprobs, advantages, reward_sums, H, N, S, A, ids, B, out_state, out_action, out_unmask,
+                       out_logprob, out_advantage, out_reward_sum, out_ids0, out_ids1);
+    ERL_LAUNCH_CHECK("erl_ppo_gather_f32");
+}
+
+extern "C" int erl_replay_write_f32(float *buf_states, float *buf_actions, float *buf_rewards, float *buf_undones,
+                                    float *buf_unmasks, const float *states, const float *actions, const float *rewards,
+                                    const void *undones, const void *unmasks, int flag_is_f32, int64_t max_size,
+                                    int64_t num_seqs, int S, int A, int64_t p, int64_t add, void *stream)
+{
+    ERL_REQUIRE(buf_states && buf_actions && buf_rewards && buf_undones && buf_unmasks && states && actions && rewards &&
+                    undones && unmasks,
+                "erl_replay_write_f32: NULL tensor");
+    ERL_REQUIRE(max_size >= 1 && num_seqs >= 1 && S >= 1 && A >= 1, "erl_replay_write_f32: bad shape");
+    ERL_REQUIRE(add >= 0 && add <= max_size && p >= 0 && p <= max_size, "erl_replay_write_f32: add=%lld p=%lld max_size=%lld",
+                (long long)add, (long long)p, (long long)max_size);
+    if (add == 0) return ERL_OK;
+    const int g = grid_for(add * num_seqs * (S + A + 3));
+    if (flag_is_f32)
+        hipLaunchKernelGGL((replay_write_kernel<true>), dim3(g), dim3(256), 0, (hipStream_t)stream, buf_states, buf_actions,
+                           buf_rewards, buf_undones, buf_unmasks, states, actions, rewards, undones, unmasks, max_size, num_seqs,
+                           S, A, p, add);
+    else
+        hipLaunchKernelGGL((replay_write_kernel<false>), dim3(g), dim3(256), 0, (hipStream_t)stream, buf_states, buf_actions,
+                           buf_rewards, buf_undones, buf_unmasks, states, actions, rewards, undones, unmasks, max_size, num_seqs,
+                           S, A, p, add);
+    ERL_LAUNCH_CHECK("erl_replay_write_f32");
+}
+
+extern "C" int erl_replay_sample_f32(const float *buf_states, const float *buf_actions, const float *buf_rewards,
+                                     const float *buf_undones, const float *buf_unmasks, int64_t max_size, int64_t num_seqs,
+                                     int S, int A, const int64_t *ids, int64_t B, int64_t sample_len, float *out_state,
+                                     float *out_action, float *out_reward, float *out_undone, float *out_unmask,
+                                     float *out_next_state, int64_t *out_ids0, int64_t *out_ids1, void *stream)
+{
+    ERL_REQUIRE(buf_states && buf_actions && buf_rewards && buf_undones && buf_unmasks && ids, "erl_replay_sample_f32: NULL tensor");
+    ERL_REQUIRE(out_state && out_action && out_reward && out_undone && out_unmask && out_next_state,
+                "erl_replay_sample_f32: NULL output");
+    ERL_REQUIRE(sample_len >= 1 && sample_len < max_size + 0 && num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0,
+                "erl_replay_sample_f32: bad shape (sample_len=%lld max_size=%lld)", (long long)sample_len, (long long)max_size);
+    if (B == 0) return ERL_OK;
+    hipLaunchKernelGGL(replay_sample_kernel, dim3(grid_for(B * (2 * S + A + 3))), dim3(256), 0, (hipStream_t)stream, buf_states,
+                       buf_actions, buf_rewards, buf_undones, buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state,
+                       out_action, out_reward, out_undone, out_unmask, out_next_state, out_ids0, out_ids1);
+    ERL_LAUNCH_CHECK("erl_replay_sample_f32");
+}

@@ -1,0 +1,256 @@
+"""Tensor-level wrappers of the C ABI (include/erl_hip.h).  One function per kernel entry point.
+
+All tensors must live on a HIP device; outputs are allocated with torch (the library itself never
+allocates).  Every wrapper raises `HipExtensionError` on failure -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch as th
+
+from . import _hip
+from ._hip import check, flag_ptr, lib, ptr, stream_ptr
+
+TEN = th.Tensor
+_ALGO = {"auto": _hip.GAE_ALGO_AUTO, "exact": _hip.GAE_ALGO_EXACT, "chunked": _hip.GAE_ALGO_CHUNKED,
+         "lookback": _hip.GAE_ALGO_LOOKBACK}
+
+_workspaces = {}
+
+
+def _workspace(device: th.device, nbytes: int) -> TEN:
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = th.empty(max(nbytes, 1 << 22), dtype=th.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 / K4
+# ------------------------------------------------------------------------------------------------
+def gae_scan(rewards: TEN, undones: TEN, unmasks: TEN, values: TEN, next_value: TEN, gamma: float, lam: float, *,
+             use_v_trace: bool = True, mutate: bool = True, algo: str = "auto", with_ret: bool = True,
+             stats: Optional[TEN] = None, adv: Optional[TEN] = None, ret: Optional[TEN] = None):
+    """AgentPPO.get_advantages (+ reward_sums).  Returns (advantages, reward_sums or None).
+    With mutate=True `rewards`/`undones` receive the truncation fix-up in place, like the reference."""
+    H, N = rewards.shape
+    assert undones.shape == unmasks.shape == values.shape == (H, N) and next_value.shape == (N,)
+    adv = th.empty_like(values) if adv is None else adv
+    if with_ret and ret is None:
+        ret = th.empty_like(values)
+    flags = (_hip.GAE_VTRACE if use_v_trace else 0) | (_hip.GAE_MUTATE if mutate else 0) | _ALGO[algo]
+    if stats is not None:
+        assert stats.dtype == th.float64 and stats.numel() >= 5
+        flags |= _hip.GAE_STATS
+    nbytes = lib().erl_gae_workspace_bytes(H, N)
+    ws = _workspace(rewards.device, nbytes)
+    check(lib().erl_gae_scan_f32(ptr(rewards, th.float32), flag_ptr(undones), flag_ptr(unmasks), ptr(values, th.float32),
+                                 ptr(next_value, th.float32), ptr(adv, th.float32), ptr(ret if with_ret else None),
+                                 H, N, gamma, lam, flags, ptr(stats), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_gae_scan_f32")
+    return adv, (ret if with_ret else None)
+
+
+def adv_stats(adv: TEN, stats: Optional[TEN] = None) -> TEN:
+    """Raw sums for AgentPPO.py:149 -> float64[5] = (sum, H*N, sum_sub, sumsq_sub, count_sub)."""
+    H, N = adv.shape
+    stats = th.empty(8, dtype=th.float64, device=adv.device) if stats is None else stats
+    ws = _workspace(adv.device, lib().erl_gae_workspace_bytes(H, N))
+    check(lib().erl_adv_stats_f32(ptr(adv, th.float32), H, N, ptr(stats, th.float64), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_adv_stats_f32")
+    return stats
+
+
+def adv_normalize(adv: TEN, stats: TEN, out: Optional[TEN] = None) -> TEN:
+    H, N = adv.shape
+    out = th.empty_like(adv) if out is None else out
+    check(lib().erl_adv_normalize_f32(ptr(adv, th.float32), ptr(out, th.float32), H, N, ptr(stats, th.float64), stream_ptr()),
+          "erl_adv_normalize_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K5
+# ------------------------------------------------------------------------------------------------
+def split_ids(ids: TEN, sample_len: int) -> Tuple[TEN, TEN]:
+    ids0, ids1 = th.empty_like(ids), th.empty_like(ids)
+    check(lib().erl_split_ids_i64(ptr(ids, th.int64), ids.numel(), sample_len, ptr(ids0), ptr(ids1), stream_ptr()),
+          "erl_split_ids_i64")
+    return ids0, ids1
+
+
+def ppo_gather(states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN, ids: TEN):
+    """x[ids % H, ids // H] for the six PPO buffers (AgentPPO.py:178-187) + the index pair."""
+    H, N, S = states.shape
+    A = actions.shape[2]
+    B = ids.numel()
+    dev = states.device
+    o_s = th.empty((B, S), dtype=th.float32, device=dev)
+    o_a = th.empty((B, A), dtype=th.float32, device=dev)
+    o_u = th.empty((B,), dtype=th.bool, device=dev)
+    o_l, o_ad, o_r = (th.empty((B,), dtype=th.float32, device=dev) for _ in range(3))
+    i0, i1 = th.empty_like(ids), th.empty_like(ids)
+    check(lib().erl_ppo_gather_f32(ptr(states, th.float32), ptr(actions, th.float32), flag_ptr(unmasks), ptr(logprobs, th.float32),
+                                   ptr(advantages, th.float32), ptr(reward_sums, th.float32), H, N, S, A, ptr(ids, th.int64), B,
+                                   ptr(o_s), ptr(o_a), ptr(o_u), ptr(o_l), ptr(o_ad), ptr(o_r), ptr(i0), ptr(i1), stream_ptr()),
+          "erl_ppo_gather_f32")
+    return (o_s, o_a, o_u, o_l, o_ad, o_r), (i0, i1)
+
+
+# ------------------------------------------------------------------------------------------------
+# K8 / K9
+# ------------------------------------------------------------------------------------------------
+def replay_write(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undones: TEN, buf_unmasks: TEN,
+                 items: Sequence[TEN], p: int) -> None:
+    states, actions, rewards, undones, unmasks = items
+    max_size, num_seqs, S = buf_states.shape
+    A = buf_actions.shape[2]
+    add = rewards.shape[0]
+    assert states.shape == (add, num_seqs, S) and actions.shape == (add, num_seqs, A)
+    is_f32 = undones.dtype == th.float32
+    assert unmasks.dtype == undones.dtype and (is_f32 or undones.dtype in (th.bool, th.uint8))
+    check(lib().erl_replay_write_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.float32), ptr(buf_rewards, th.float32),
+                                     ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), ptr(states, th.float32),
+                                     ptr(actions, th.float32), ptr(rewards, th.float32), ptr(undones), ptr(unmasks), int(is_f32),
+                                     max_size, num_seqs, S, A, p, add, stream_ptr()),
+          "erl_replay_write_f32")
+
+
+def replay_sample(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undones: TEN, buf_unmasks: TEN, ids: TEN,
+                  sample_len: int):
+    max_size, num_seqs, S = buf_states.shape
+    A = buf_actions.shape[2]
+    B = ids.numel()
+    dev = buf_states.device
+    o_s = th.empty((B, S), dtype=th.float32, device=dev)
+    o_n = th.empty((B, S), dtype=th.float32, device=dev)
+    o_a = th.empty((B, A), dtype=th.float32, device=dev)
+    o_r, o_ud, o_um = (th.empty((B,), dtype=th.float32, device=dev) for _ in range(3))
+    i0, i1 = th.empty_like(ids), th.empty_like(ids)
+    check(lib().erl_replay_sample_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.float32), ptr(buf_rewards, th.float32),
+                                      ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), max_size, num_seqs, S, A,
+                                      ptr(ids, th.int64), B, sample_len, ptr(o_s), ptr(o_a), ptr(o_r), ptr(o_ud), ptr(o_um),
+                                      ptr(o_n), ptr(i0), ptr(i1), stream_ptr()),
+          "erl_replay_sample_f32")
+    return (o_s, o_a, o_r, o_ud, o_um, o_n), (i0, i1)
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP kernels (K1, K2, K6, K7)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class MlpSpec:
+    """Shape of a 2-hidden-layer build_mlp([S, h1, h2, out]) network in one flat fp32 buffer
+    (W1,b1,W2,b2,W3,b3[,action_std_log]); see include/erl_hip.h."""
+    S: int
+    h1: int
+    h2: int
+    out: int
+    with_std_log: bool
+
+    @property
+    def count(self) -> int:
+        n = lib().erl_mlp_param_count(self.S, self.h1, self.h2, self.out, int(self.with_std_log))
+        if n < 0:
+            raise _hip.HipExtensionError(
+                f"unsupported network for the fused HIP kernels: state_dim={self.S} net_dims=[{self.h1},{self.h2}] "
+                f"out={self.out} (need 2 hidden layers, multiples of 32 and <= {_hip.MAX_HIDDEN}; state_dim <= "
+                f"{_hip.MAX_STATE_DIM}; action_dim <= {_hip.MAX_ACTION_DIM})")
+        return n
+
+    def slices(self):
+        """(name, offset, shape) in flat order."""
+        out, o = [], 0
+        for name, shape in (("net.0.weight", (self.h1, self.S)), ("net.0.bias", (self.h1,)),
+                            ("net.2.weight", (self.h2, self.h1)), ("net.2.bias", (self.h2,)),
+                            ("net.4.weight", (self.out, self.h2)), ("net.4.bias", (self.out,))):
+            n = 1
+            for s in shape:
+                n *= s
+            out.append((name, o, shape))
+            o += n
+        if self.with_std_log:
+            out.append(("action_std_log", o, (1, self.out)))
+        return out
+
+
+def value_forward(params: TEN, spec: MlpSpec, state_avg: TEN, state_std: TEN, states: TEN, out: Optional[TEN] = None) -> TEN:
+    """CriticPPO(states).squeeze(-1) for states (..., S)."""
+    rows = states.numel() // spec.S
+    out = th.empty(states.shape[:-1], dtype=th.float32, device=states.device) if out is None else out
+    check(lib().erl_value_forward_f32(ptr(params, th.float32), ptr(state_avg, th.float32), ptr(state_std, th.float32), spec.S,
+                                      spec.h1, spec.h2, ptr(states, th.float32), rows, ptr(out, th.float32), stream_ptr()),
+          "erl_value_forward_f32")
+    return out
+
+
+def rollout_step(params: TEN, spec: MlpSpec, state_avg: TEN, state_std: TEN, state: TEN, *, noise: Optional[TEN] = None,
+                 seed: int = 0, counter: int = 0, out_state: Optional[TEN] = None, out_action: Optional[TEN] = None,
+                 out_logprob: Optional[TEN] = None, out_env_action: Optional[TEN] = None) -> None:
+    N = state.shape[0]
+    check(lib().erl_rollout_step_f32(ptr(params, th.float32), ptr(state_avg, th.float32), ptr(state_std, th.float32), spec.S,
+                                     spec.h1, spec.h2, spec.out, ptr(state, th.float32), N, ptr(noise), seed & (2 ** 64 - 1),
+                                     counter & (2 ** 64 - 1), ptr(out_state), ptr(out_action), ptr(out_logprob),
+                                     ptr(out_env_action), stream_ptr()),
+          "erl_rollout_step_f32")
+
+
+def ppo_slab_stride(S: int, h1: int, h2: int, A: int) -> int:
+    return lib().erl_ppo_slab_stride(S, h1, h2, A)
+
+
+def ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int, h1: int,
+             h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
+             ids: TEN, ratio_clip: float, lambda_entropy: float, inv_batch: float, slabs: TEN, n_slabs: int) -> None:
+    H, N = states.shape[0], states.shape[1]
+    check(lib().erl_ppo_step_f32(ptr(actor_params, th.float32), ptr(critic_params, th.float32), ptr(act_avg), ptr(act_std),
+                                 ptr(cri_avg), ptr(cri_std), S, h1, h2, A, ptr(states, th.float32), ptr(actions, th.float32),
+                                 flag_ptr(unmasks), ptr(logprobs, th.float32), ptr(advantages, th.float32),
+                                 ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), ids.numel(), ratio_clip,
+                                 lambda_entropy, inv_batch, ptr(slabs, th.float32), n_slabs, stream_ptr()),
+          "erl_ppo_step_f32")
+
+
+def grad_reduce(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN) -> None:
+    check(lib().erl_grad_reduce_f32(ptr(slabs, th.float32), n_slabs, stride, ptr(flat_grad, th.float32), stream_ptr()),
+          "erl_grad_reduce_f32")
+
+
+def clip_adam(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, groups: Sequence[Tuple[int, int]], step: int, lr: float,
+              max_norm: float, grad_scale: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
+              step_base: Optional[TEN] = None) -> None:
+    n = len(groups)
+    off = (ctypes.c_int64 * n)(*[g[0] for g in groups])
+    ln = (ctypes.c_int64 * n)(*[g[1] for g in groups])
+    check(lib().erl_clip_adam_f32(ptr(params, th.float32), ptr(grads, th.float32), ptr(exp_avg, th.float32),
+                                  ptr(exp_avg_sq, th.float32), off, ln, n, ptr(step_base), step, lr, betas[0], betas[1], eps,
+                                  max_norm, grad_scale, stream_ptr()),
+          "erl_clip_adam_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# environments
+# ------------------------------------------------------------------------------------------------
+def synenv_step(state: TEN, action: TEN, Ws: TEN, Wa: TEN, step_count: TEN, episode: TEN, reward: TEN, terminal: TEN,
+                truncate: TEN, max_step: int, seed: int) -> None:
+    N, S = state.shape
+    A = action.shape[1]
+    check(lib().erl_synenv_step_f32(ptr(state, th.float32), ptr(action, th.float32), ptr(Ws, th.float32), ptr(Wa, th.float32),
+                                    ptr(step_count, th.int32), ptr(episode, th.int32), ptr(reward, th.float32),
+                                    flag_ptr(terminal), flag_ptr(truncate), N, S, A, max_step, seed & (2 ** 64 - 1),
+                                    stream_ptr()),
+          "erl_synenv_step_f32")
+
+
+def pendulum_step(phys: TEN, obs: TEN, action: TEN, step_count: TEN, episode: TEN, reward: TEN, terminal: TEN, truncate: TEN,
+                  max_step: int, seed: int) -> None:
+    N = phys.shape[0]
+    check(lib().erl_pendulum_step_f32(ptr(phys, th.float32), ptr(obs, th.float32), ptr(action, th.float32),
+                                      ptr(step_count, th.int32), ptr(episode, th.int32), ptr(reward, th.float32),
+                                      flag_ptr(terminal), flag_ptr(truncate), N, max_step, seed & (2 ** 64 - 1), stream_ptr()),
+          "erl_pendulum_step_f32")

@@ -1,0 +1,199 @@
+/* erl_hip.h -- C ABI of liberl_hip.so: the MI355X (gfx950) hot path of an ElegantRL-compatible
+ * vectorised actor-learner.
+ *
+ * The reference (AI4Finance-Foundation/ElegantRL) is 100% Python/PyTorch and has no FFI of its own; the
+ * seam this library sits behind is the Python class protocol driven by elegantrl/train/run.py
+ * (SURVEY.md section 8b).  Each entry point below names the reference lines whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer would add under elegantrl/agents and
+ * elegantrl/train.
+ *
+ * Conventions
+ *  - plain C types only: raw device pointers, sizes, scalars, an opaque hipStream_t passed as void*.
+ *  - every tensor is caller-allocated, caller-owned device memory (torch tensors in practice); the
+ *    library never allocates or frees device memory and keeps no state besides a last-error string.
+ *  - all work is enqueued on `stream`; nothing synchronises the host.
+ *  - layout at the seam is the reference's: time-major (H, N, .) row-major contiguous, fp32 values,
+ *    1-byte flags (torch.bool), int64 indices.
+ *  - return value: 0 = ok; ERL_EINVAL (-1) = bad argument; -(1000 + hipError_t) = HIP runtime error.
+ *    erl_last_error_string() describes the most recent failure on the calling thread.
+ */
+#ifndef ERL_HIP_H
+#define ERL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ERL_ABI_VERSION 1
+#define ERL_API __attribute__((visibility("default")))
+#define ERL_OK 0
+#define ERL_EINVAL (-1)
+
+/* limits of the fused MLP kernels (2 hidden layers, as Config.net_dims = [128, 128]) */
+#define ERL_MAX_STATE_DIM 128
+#define ERL_MAX_HIDDEN 128
+#define ERL_MAX_ACTION_DIM 16
+
+ERL_API int erl_abi_version(void);
+ERL_API const char *erl_last_error_string(void);
+/* number of compute units / max LDS per workgroup of the current device (needs a GPU). */
+ERL_API int erl_device_info(int *num_cu, int *lds_bytes_per_block);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  GAE / lambda-return backward scan.
+ * Replaces AgentPPO.get_advantages (elegantrl/agents/AgentPPO.py:207-232; the north star's
+ * `get_reward_sum_gae`) plus `reward_sums = advantages + values` (:146).
+ *   trunc = !unmask: r += V(s_t) (= values at that element), undone = 0            (:211-214)
+ *   m = undone*gamma; v-trace branch (:223-227) or the alternative branch (:228-231)
+ * rewards/values/adv/ret: (H, N) f32; undones/unmasks: (H, N) u8; next_value: (N,) = cri(last_state).
+ * `ret` may be NULL.  With ERL_GAE_MUTATE the truncation fix-up is written back into
+ * rewards/undones exactly like the reference does to its caller's tensors.
+ * With ERL_GAE_STATS the kernel also leaves the raw sums needed by K4 in stats[0..4]
+ * (see erl_adv_stats_f32).  `workspace` must hold erl_gae_workspace_bytes(H, N) bytes.
+ * Algorithmic HBM traffic: 18 B per (t, n) element (14 B without ret).
+ * ------------------------------------------------------------------------------------------- */
+#define ERL_GAE_VTRACE 0x1      /* if_use_v_trace=True branch (the reference default) */
+#define ERL_GAE_MUTATE 0x2      /* write the truncation fix-up back into rewards / undones */
+#define ERL_GAE_STATS 0x4       /* also produce adv statistics (stats must be non-NULL) */
+#define ERL_GAE_ALGO_AUTO 0x00
+#define ERL_GAE_ALGO_EXACT 0x10    /* one thread per env, reference op order, bit-exact vs the oracle */
+#define ERL_GAE_ALGO_CHUNKED 0x20  /* time-parallel two-pass affine scan (within 1e-5) */
+#define ERL_GAE_ALGO_LOOKBACK 0x30 /* time-parallel single-pass scan, decoupled look-back (within 1e-5) */
+#define ERL_GAE_ALGO_MASK 0xF0
+ERL_API int64_t erl_gae_workspace_bytes(int64_t H, int64_t N);
+ERL_API int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
+                     const float *next_value, float *adv, float *ret, int64_t H, int64_t N, float gamma,
+                     float lam, int flags, double *stats, void *workspace, int64_t workspace_bytes,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  advantage normalisation.  Replaces AgentPPO.py:149:
+ *       adv = (adv - adv.mean()) / (adv[::4, ::4].std() + 1e-5)      (unbiased std of the subsample)
+ * erl_adv_stats_f32 writes raw sums so that data-parallel ranks can all-reduce them first:
+ *   stats[0] = sum(adv)  stats[1] = H*N  stats[2] = sum(sub)  stats[3] = sum(sub^2)  stats[4] = count(sub)
+ * erl_adv_normalize_f32 turns the sums into mean/std on the device and writes (adv-mean)/(std+1e-5).
+ * `out` may alias `adv`.  workspace: erl_gae_workspace_bytes(H, N) bytes.
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int erl_adv_stats_f32(const float *adv, int64_t H, int64_t N, double *stats, void *workspace,
+                      int64_t workspace_bytes, void *stream);
+ERL_API int erl_adv_normalize_f32(const float *adv, float *out, int64_t H, int64_t N, const double *stats,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  minibatch index decomposition + gather.  Replaces AgentPPO.update_objectives' sampling
+ * (AgentPPO.py:178-187):  ids0 = ids % H (time row), ids1 = ids // H (env column)  -- bit-exact --
+ * then x[ids0, ids1] for states, actions, unmasks, logprobs, advantages, reward_sums.
+ * Any out_* pointer may be NULL to skip that output.
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int erl_split_ids_i64(const int64_t *ids, int64_t B, int64_t sample_len, int64_t *ids0, int64_t *ids1,
+                      void *stream);
+ERL_API int erl_ppo_gather_f32(const float *states, const float *actions, const uint8_t *unmasks,
+                       const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
+                       int64_t N, int S, int A, const int64_t *ids, int64_t B, float *out_state,
+                       float *out_action, uint8_t *out_unmask, float *out_logprob, float *out_advantage,
+                       float *out_reward_sum, int64_t *out_ids0, int64_t *out_ids1, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  replay ring write.  Replaces ReplayBuffer.update's tensor copies
+ * (elegantrl/train/replay_buffer.py:86-105): `add` time rows are appended at row `p`, wrapping at
+ * max_size (rows [p, max_size) then [0, p+add-max_size)).  The cursor arithmetic (p, cur_size, if_full)
+ * stays on the host in the Python class.  Flags arrive as torch.bool (flag_is_f32 = 0) or float32
+ * (flag_is_f32 = 1) and are stored as float32 like the reference's buffers (:57-58).
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int erl_replay_write_f32(float *buf_states, float *buf_actions, float *buf_rewards, float *buf_undones,
+                         float *buf_unmasks, const float *states, const float *actions, const float *rewards,
+                         const void *undones, const void *unmasks, int flag_is_f32, int64_t max_size,
+                         int64_t num_seqs, int S, int A, int64_t p, int64_t add, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9  replay sample.  Replaces ReplayBuffer.sample (replay_buffer.py:120-134) given the drawn ids:
+ *   ids0 = ids % sample_len, ids1 = ids // sample_len (sample_len = cur_size - 1), bit-exact;
+ *   returns states/actions/rewards/undones/unmasks[ids0, ids1] and next_state = states[ids0 + 1, ids1].
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int erl_replay_sample_f32(const float *buf_states, const float *buf_actions, const float *buf_rewards,
+                          const float *buf_undones, const float *buf_unmasks, int64_t max_size,
+                          int64_t num_seqs, int S, int A, const int64_t *ids, int64_t B, int64_t sample_len,
+                          float *out_state, float *out_action, float *out_reward, float *out_undone,
+                          float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MLP parameter block used by K1/K2/K6/K7: one flat fp32 buffer per network, laid out as
+ *   W1[h1][S] b1[h1] W2[h2][h1] b2[h2] W3[out][h2] b3[out] (+ action_std_log[A] for the actor)
+ * i.e. nn.Linear.weight/.bias of build_mlp([S, h1, h2, out]) (elegantrl/agents/AgentBase.py:345-360)
+ * in order; the Python side makes the nn.Module parameters views of this buffer.  state_avg /
+ * state_std are the (S,) normalisation buffers of ActorPPO/CriticPPO (AgentPPO.py:357-361, :432-441).
+ * Activation is exact-erf GELU.  Constraints: h1, h2 multiples of 32 and <= ERL_MAX_HIDDEN,
+ * S <= ERL_MAX_STATE_DIM, A <= ERL_MAX_ACTION_DIM.
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int64_t erl_mlp_param_count(int S, int h1, int h2, int out, int with_std_log);
+
+/* K2  value pre-pass: values[i] = CriticPPO(states[i]) for `rows` states (AgentPPO.py:141-143, :219-220). */
+ERL_API int erl_value_forward_f32(const float *critic_params, const float *state_avg, const float *state_std, int S,
+                          int h1, int h2, const float *states, int64_t rows, float *values, void *stream);
+
+/* K1  one vectorised rollout step = ActorPPO.get_action + the three buffer stores
+ * (AgentPPO.py:113-119, :368-376):  a = mean + exp(std_log)*eps,  logprob = Normal.log_prob(a).sum(1),
+ * out_state_row <- state, out_action_row <- a (pre-tanh), out_logprob_row <- logprob,
+ * out_action_env <- tanh(a) (convert_action_for_env, :388-390).  eps comes from `noise` (N, A) when
+ * non-NULL (tests), otherwise from Philox4x32-10 keyed by (seed, counter, env, action-dim). */
+ERL_API int erl_rollout_step_f32(const float *actor_params, const float *state_avg, const float *state_std, int S,
+                         int h1, int h2, int A, const float *state, int64_t N, const float *noise,
+                         uint64_t seed, uint64_t counter, float *out_state_row, float *out_action_row,
+                         float *out_logprob_row, float *out_action_env, void *stream);
+
+/* K6  one PPO minibatch: gather (K5 indices) + critic fwd/bwd + actor fwd/bwd, both networks in one
+ * launch.  Replaces AgentPPO.update_objectives up to (not including) the two optimizer steps
+ * (AgentPPO.py:173-204) and ActorPPO.get_logprob_entropy (:378-386):
+ *   obj_critic = mean((cri(s) - reward_sum)^2 * unmask)
+ *   ratio = exp(logp_new - logp_old); surrogate = adv*ratio*where(adv > 0, 1-clip, 1+clip)
+ *   actor loss = -(mean(surrogate*unmask) - lambda_entropy*mean(entropy*unmask))
+ * Gradients are left as per-workgroup partial sums in `slabs` (n_slabs x erl_ppo_slab_stride floats),
+ * to be summed by erl_grad_reduce_f32.  inv_batch = 1/B (or 1/(B*world) under data parallelism).
+ * Slab / flat-gradient layout: [actor grads (Pa)] [critic grads (Pc)] [obj_critic, obj_surrogate,
+ * obj_entropy, 0] where Pa/Pc = erl_mlp_param_count(...). */
+ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
+ERL_API int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg,
+                     const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2,
+                     int A, const float *states, const float *actions, const uint8_t *unmasks,
+                     const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
+                     int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
+                     float inv_batch, float *slabs, int n_slabs, void *stream);
+ERL_API int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, void *stream);
+
+/* K7  optimizer_backward's tail (elegantrl/agents/AgentBase.py:246-248) for up to 4 parameter groups in
+ * one launch: per group, global-L2-norm clip (clip_grad_norm_: coef = min(1, max_norm/(norm+1e-6)))
+ * then torch.optim.Adam defaults (betas 0.9/0.999, eps 1e-8).  Group g covers
+ * [group_off[g], group_off[g] + group_len[g]) of the flat params/grads/m/v buffers (host arrays).
+ * grad_scale multiplies every gradient first (1/world_size after an all-reduce SUM).
+ * step = (step_base ? *step_base : 0) + step_offset is the 1-based Adam step of this call. */
+ERL_API int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                      const int64_t *group_off, const int64_t *group_len, int n_groups, const int32_t *step_base,
+                      int32_t step_offset, float lr, float beta1, float beta2, float eps, float max_norm,
+                      float grad_scale, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GPU-resident synthetic environments for measurement; they implement the
+ * env protocol of elegantrl (step -> state, reward, terminal, truncate; auto-reset).
+ * ------------------------------------------------------------------------------------------- */
+/* SynVecEnv: s' = s*Ws + a*Wa; reward = -mean(s'^2) - 0.01*mean(a^2); terminal = max|s'| > 10;
+ * truncate = step_count >= max_step && !terminal; done rows reset to N(0,1) (Philox by seed/env/episode). */
+ERL_API int erl_synenv_step_f32(float *state, const float *action, const float *Ws, const float *Wa,
+                        int32_t *step_count, int32_t *episode, float *reward, uint8_t *terminal,
+                        uint8_t *truncate, int64_t N, int S, int A, int max_step, uint64_t seed, void *stream);
+/* Pendulum-v1 dynamics with elegantrl/envs/CustomGymEnv.py:24-44 scaling (action*2, reward*0.5).
+ * phys: (N, 2) = (theta, theta_dot); obs out: (N, 3) = (cos, sin, theta_dot). 200-step truncation. */
+ERL_API int erl_pendulum_step_f32(float *phys, float *obs, const float *action, int32_t *step_count, int32_t *episode,
+                          float *reward, uint8_t *terminal, uint8_t *truncate, int64_t N, int max_step,
+                          uint64_t seed, void *stream);
+
+/* self-test of the MFMA tile helpers against scalar code; returns 0 and writes max |err| to *max_err
+ * (host pointer).  Needs a GPU. */
+ERL_API int erl_selftest_mfma(float *max_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ERL_HIP_H */

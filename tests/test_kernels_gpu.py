@@ -1,0 +1,444 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+
+Bars (BASELINE.json north_star / SURVEY.md 8c): indices and gathered rows bit-exact; advantages and
+returns within 1e-5 * max(1, |ref|) fp32 (bit-exact in ERL_GAE_ALGO_EXACT mode); MLP / loss / gradient
+math within rtol 1e-4 of the fp32 oracle (MFMA accumulation order differs from torch's GEMM).
+"""
+import numpy as np
+import pytest
+import torch as th
+
+from oracle import c_oracle
+from oracle import ppo_numpy as O
+from tests.helpers import PPO_GOLDENS, dims, hyper, load, mlp_from
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from elegantrl_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return th.device("cuda:0")
+
+
+def cu(a, dev, dtype=None):
+    t = th.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def rel_close(x, ref, tol):
+    x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(x - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= tol, f"max rel err {err.max():.3e} > {tol:.1e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def gae_inputs(H, N, seed, p_done=0.01, p_trunc=0.005):
+    rng = np.random.default_rng(seed)
+    r = rng.standard_normal((H, N), dtype=np.float32)
+    v = rng.standard_normal((H, N), dtype=np.float32)
+    u = rng.random((H, N)) >= p_done
+    m = rng.random((H, N)) >= p_trunc
+    nv = rng.standard_normal(N, dtype=np.float32)
+    return r, u, m, v, nv
+
+
+def flat_params(net: O.Mlp):
+    return np.concatenate([p.reshape(-1) for p in net.trainable()]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_mfma_tile_mapping():
+    from elegantrl_amd import _hip
+    assert _hip.selftest_mfma() < 1e-5
+
+
+@pytest.mark.parametrize("H,N", [(32, 4096), (1, 64), (7, 1), (33, 130), (200, 4096), (5, 1000)])
+@pytest.mark.parametrize("vtrace", [True, False])
+def test_gae_exact_is_bitwise_equal_to_oracle(ops, dev, H, N, vtrace):
+    r, u, m, v, nv = gae_inputs(H, N, seed=H * 1000 + N, p_done=0.05, p_trunc=0.03)
+    adv_o, ret_o, r_o, u_o = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=vtrace)
+    tr, tu, tm, tv, tnv = cu(r, dev), cu(u, dev), cu(m, dev), cu(v, dev), cu(nv, dev)
+    adv, ret = ops.gae_scan(tr, tu, tm, tv, tnv, 0.99, 0.95, use_v_trace=vtrace, mutate=True, algo="exact")
+    np.testing.assert_array_equal(adv.cpu().numpy(), adv_o)
+    np.testing.assert_array_equal(ret.cpu().numpy(), ret_o)
+    np.testing.assert_array_equal(tr.cpu().numpy(), r_o)     # in-place truncation fix-up, like the reference
+    np.testing.assert_array_equal(tu.cpu().numpy(), u_o)
+
+
+def test_gae_exact_edge_rows(ops, dev):
+    H, N = 16, 128
+    r, u, m, v, nv = gae_inputs(H, N, seed=3)
+    u[:, :32] = False          # every step terminal
+    m[:, 32:64] = False        # every step truncated
+    u[:, 64:96] = True
+    m[:, 64:96] = True         # never done
+    adv_o, ret_o, _, _ = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95)
+    adv, ret = ops.gae_scan(cu(r, dev), cu(u, dev), cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, algo="exact")
+    np.testing.assert_array_equal(adv.cpu().numpy(), adv_o)
+    np.testing.assert_array_equal(ret.cpu().numpy(), ret_o)
+
+
+@pytest.mark.parametrize("H,N", [(256, 1000), (513, 260), (128, 4096), (1024, 512), (40, 77), (9, 64)])
+@pytest.mark.parametrize("vtrace", [True, False])
+def test_gae_chunked_within_1e5(ops, dev, H, N, vtrace):
+    r, u, m, v, nv = gae_inputs(H, N, seed=H + N)
+    adv_o, ret_o, r_o, u_o = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=vtrace)
+    tr, tu = cu(r, dev), cu(u, dev)
+    adv, ret = ops.gae_scan(tr, tu, cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, use_v_trace=vtrace, algo="chunked")
+    rel_close(adv.cpu().numpy(), adv_o, 1e-5)
+    rel_close(ret.cpu().numpy(), ret_o, 1e-5)
+    np.testing.assert_array_equal(tu.cpu().numpy(), u_o)
+    np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
+
+
+def test_gae_full_size_property_linearity(ops, dev):
+    """BASELINE size (2048 x 4096, 151 MB): with no terminal/truncation GAE is linear in (r, v, next_v);
+    check adv(x + y) == adv(x) + adv(y) and agreement of the exact and chunked algorithms."""
+    H, N = 2048, 4096
+    g = th.Generator(device=dev).manual_seed(0)
+    ones = th.ones((H, N), dtype=th.bool, device=dev)
+
+    def run(r, v, nv, algo):
+        return ops.gae_scan(r.clone(), ones.clone(), ones, v, nv, 0.99, 0.95, algo=algo)[0]
+
+    r1, v1 = th.randn((H, N), device=dev, generator=g), th.randn((H, N), device=dev, generator=g)
+    r2, v2 = th.randn((H, N), device=dev, generator=g), th.randn((H, N), device=dev, generator=g)
+    n1, n2 = th.randn(N, device=dev, generator=g), th.randn(N, device=dev, generator=g)
+    a1, a2, a12 = run(r1, v1, n1, "chunked"), run(r2, v2, n2, "chunked"), run(r1 + r2, v1 + v2, n1 + n2, "chunked")
+    assert (a12 - (a1 + a2)).abs().max().item() < 2e-4
+    e1 = run(r1, v1, n1, "exact")
+    err = ((a1 - e1).abs() / e1.abs().clamp_min(1.0)).max().item()
+    assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_gae_on_reference_golden(ops, dev, name):
+    g = load(name)
+    hp, d = hyper(g), dims(g)
+    tr, tu = cu(g["rewards"], dev), cu(g["undones"], dev)
+    adv, ret = ops.gae_scan(tr, tu, cu(g["unmasks"], dev), cu(g["values"], dev), cu(g["next_value"], dev), hp["gamma"],
+                            hp["lam"], use_v_trace=d["vtrace"], algo="exact")
+    rel_close(adv.cpu().numpy(), g["advantages"], 1e-5)
+    rel_close(ret.cpu().numpy(), g["reward_sums"], 1e-5)
+    np.testing.assert_array_equal(tu.cpu().numpy(), g["undones_after"])
+
+
+@pytest.mark.parametrize("H,N", [(32, 4096), (12, 8), (33, 130), (200, 1024)])
+@pytest.mark.parametrize("algo", ["exact", "chunked"])
+def test_adv_stats_and_normalize(ops, dev, H, N, algo):
+    r, u, m, v, nv = gae_inputs(H, N, seed=5)
+    stats = th.zeros(8, dtype=th.float64, device=dev)
+    adv, _ = ops.gae_scan(cu(r, dev), cu(u, dev), cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, algo=algo, stats=stats)
+    adv_np = adv.cpu().numpy()
+    s = stats.cpu().numpy()
+    sub = adv_np[::4, ::4].astype(np.float64)
+    np.testing.assert_allclose(s[0], adv_np.astype(np.float64).sum(), rtol=1e-9, atol=1e-6)
+    assert s[1] == H * N and s[4] == sub.size
+    np.testing.assert_allclose(s[2], sub.sum(), rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(s[3], (sub * sub).sum(), rtol=1e-9)
+    s2 = ops.adv_stats(adv).cpu().numpy()
+    np.testing.assert_allclose(s2[:5], s[:5], rtol=1e-9, atol=1e-6)
+    out = ops.adv_normalize(adv, stats)
+    rel_close(out.cpu().numpy(), O.adv_normalize(adv_np), 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,N,S,A,B", [(32, 4096, 64, 8, 16384), (12, 8, 6, 2, 16), (7, 13, 3, 1, 100)])
+def test_ppo_gather_bit_exact(ops, dev, H, N, S, A, B):
+    rng = np.random.default_rng(1)
+    states = rng.standard_normal((H, N, S), dtype=np.float32)
+    actions = rng.standard_normal((H, N, A), dtype=np.float32)
+    um = rng.random((H, N)) > 0.1
+    lp, adv, rs = (rng.standard_normal((H, N), dtype=np.float32) for _ in range(3))
+    ids = rng.integers(0, H * N, size=B).astype(np.int64)
+    ids[:3] = [0, H * N - 1, H]                                   # extremes
+    (o_s, o_a, o_u, o_l, o_ad, o_r), (i0, i1) = ops.ppo_gather(cu(states, dev), cu(actions, dev), cu(um, dev), cu(lp, dev),
+                                                             cu(adv, dev), cu(rs, dev), cu(ids, dev))
+    r0, r1 = O.split_ids(ids, H)
+    np.testing.assert_array_equal(i0.cpu().numpy(), r0)
+    np.testing.assert_array_equal(i1.cpu().numpy(), r1)
+    s0, s1 = ops.split_ids(cu(ids, dev), H)
+    np.testing.assert_array_equal(s0.cpu().numpy(), r0)
+    np.testing.assert_array_equal(s1.cpu().numpy(), r1)
+    np.testing.assert_array_equal(o_s.cpu().numpy(), states[r0, r1])
+    np.testing.assert_array_equal(o_a.cpu().numpy(), actions[r0, r1])
+    np.testing.assert_array_equal(o_u.cpu().numpy(), um[r0, r1])
+    np.testing.assert_array_equal(o_l.cpu().numpy(), lp[r0, r1])
+    np.testing.assert_array_equal(o_ad.cpu().numpy(), adv[r0, r1])
+    np.testing.assert_array_equal(o_r.cpu().numpy(), rs[r0, r1])
+
+
+def test_replay_ring_against_reference_golden(ops, dev):
+    g = load("replay_ring.npz")
+    max_size, S, A, num_seqs = [int(x) for x in g["dims"]]
+    bs = th.zeros((max_size, num_seqs, S), device=dev)
+    ba = th.zeros((max_size, num_seqs, A), device=dev)
+    br, bu, bm = (th.zeros((max_size, num_seqs), device=dev) for _ in range(3))
+    p = 0
+    ring = O.Ring(max_size, S, A, num_seqs)
+    for k, add in enumerate(g["adds"]):
+        items_np = tuple(g[f"in{k}_{n}"] for n in ("states", "actions", "rewards", "undones", "unmasks"))
+        ops.replay_write(bs, ba, br, bu, bm, [cu(x, dev) for x in items_np], p)
+        ring.update(items_np)
+        p = ring.p
+        for t, n in zip((bs, ba, br, bu, bm), ("states", "actions", "rewards", "undones", "unmasks")):
+            np.testing.assert_array_equal(t.cpu().numpy(), g[f"buf{k}_{n}"])
+        out, (i0, i1) = ops.replay_sample(bs, ba, br, bu, bm, cu(g[f"ids{k}"], dev), ring.cur_size - 1)
+        np.testing.assert_array_equal(i0.cpu().numpy(), g[f"ids0_{k}"])
+        np.testing.assert_array_equal(i1.cpu().numpy(), g[f"ids1_{k}"])
+        for t, n in zip(out, ("state", "action", "reward", "undone", "unmask", "next_state")):
+            np.testing.assert_array_equal(t.cpu().numpy(), g[f"out{k}_{n}"])
+
+
+def test_replay_large_random_vs_oracle(ops, dev):
+    rng = np.random.default_rng(2)
+    max_size, S, A, num_seqs = 1000, 11, 3, 4
+    ring = O.Ring(max_size, S, A, num_seqs)
+    bs = th.zeros((max_size, num_seqs, S), device=dev)
+    ba = th.zeros((max_size, num_seqs, A), device=dev)
+    br, bu, bm = (th.zeros((max_size, num_seqs), device=dev) for _ in range(3))
+    for add in (300, 512, 188, 1, 999, 1000):
+        items = (rng.standard_normal((add, num_seqs, S), dtype=np.float32), rng.standard_normal((add, num_seqs, A), dtype=np.float32),
+                 rng.standard_normal((add, num_seqs), dtype=np.float32), (rng.random((add, num_seqs)) > 0.1).astype(np.float32),
+                 (rng.random((add, num_seqs)) > 0.1).astype(np.float32))
+        ops.replay_write(bs, ba, br, bu, bm, [cu(x, dev) for x in items], ring.p)
+        ring.update(items)
+        np.testing.assert_array_equal(bs.cpu().numpy(), ring.states)
+        np.testing.assert_array_equal(bu.cpu().numpy(), ring.undones)
+        ids = rng.integers(0, (ring.cur_size - 1) * num_seqs, size=4096).astype(np.int64)
+        out, (i0, i1) = ops.replay_sample(bs, ba, br, bu, bm, cu(ids, dev), ring.cur_size - 1)
+        ref, (r0, r1) = ring.sample(ids)
+        np.testing.assert_array_equal(i0.cpu().numpy(), r0)
+        np.testing.assert_array_equal(i1.cpu().numpy(), r1)
+        for t, x in zip(out, ref):
+            np.testing.assert_array_equal(t.cpu().numpy(), x)
+
+
+# ------------------------------------------------------------------------------------------------
+def random_net(rng, S, h1, h2, out, with_std):
+    def lin(o, i):
+        return (rng.standard_normal((o, i)) / np.sqrt(i)).astype(np.float32), (0.1 * rng.standard_normal(o)).astype(np.float32)
+    (w1, b1), (w2, b2), (w3, b3) = lin(h1, S), lin(h2, h1), lin(out, h2)
+    return O.Mlp([w1, w2, w3], [b1, b2, b3], (0.1 * rng.standard_normal(S)).astype(np.float32),
+                 (1.0 + 0.2 * rng.random(S)).astype(np.float32),
+                 (-0.3 + 0.1 * rng.standard_normal(out)).astype(np.float32) if with_std else None)
+
+
+MLP_SHAPES = [(64, 128, 128, 8), (60, 128, 128, 8), (3, 128, 64, 1), (17, 128, 128, 5), (6, 64, 32, 2), (128, 32, 96, 16)]
+
+
+@pytest.mark.parametrize("S,h1,h2,A", MLP_SHAPES)
+@pytest.mark.parametrize("rows", [1, 64, 1000])
+def test_value_forward(ops, dev, S, h1, h2, A, rows):
+    rng = np.random.default_rng(S + rows)
+    net = random_net(rng, S, h1, h2, 1, False)
+    x = rng.standard_normal((rows, S), dtype=np.float32)
+    spec = ops.MlpSpec(S, h1, h2, 1, False)
+    v = ops.value_forward(cu(flat_params(net), dev), spec, cu(net.state_avg, dev), cu(net.state_std, dev), cu(x, dev))
+    ref = O.critic_value(x.astype(np.float64), net.astype(np.float64))
+    np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("S,h1,h2,A", MLP_SHAPES)
+@pytest.mark.parametrize("N", [4096, 37])
+def test_rollout_step_injected_noise(ops, dev, S, h1, h2, A, N):
+    rng = np.random.default_rng(S * 7 + N)
+    net = random_net(rng, S, h1, h2, A, True)
+    x = rng.standard_normal((N, S), dtype=np.float32)
+    eps = rng.standard_normal((N, A), dtype=np.float32)
+    spec = ops.MlpSpec(S, h1, h2, A, True)
+    o_s, o_a, o_e = th.zeros((N, S), device=dev), th.zeros((N, A), device=dev), th.zeros((N, A), device=dev)
+    o_l = th.zeros(N, device=dev)
+    ops.rollout_step(cu(flat_params(net), dev), spec, cu(net.state_avg, dev), cu(net.state_std, dev), cu(x, dev),
+                     noise=cu(eps, dev), out_state=o_s, out_action=o_a, out_logprob=o_l, out_env_action=o_e)
+    a_ref, lp_ref = O.actor_sample(x.astype(np.float64), net.astype(np.float64), eps.astype(np.float64))
+    np.testing.assert_array_equal(o_s.cpu().numpy(), x)
+    np.testing.assert_allclose(o_a.cpu().numpy(), a_ref, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(o_l.cpu().numpy(), lp_ref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(o_e.cpu().numpy(), np.tanh(a_ref), rtol=1e-4, atol=2e-5)
+
+
+def test_rollout_step_philox_noise_is_standard_normal_and_deterministic(ops, dev):
+    S, h1, h2, A, N = 64, 128, 128, 8, 4096
+    rng = np.random.default_rng(0)
+    net = random_net(rng, S, h1, h2, A, True)
+    net.action_std_log[:] = 0.0
+    spec = ops.MlpSpec(S, h1, h2, A, True)
+    P, avg, sd = cu(flat_params(net), dev), cu(net.state_avg, dev), cu(net.state_std, dev)
+    x = cu(rng.standard_normal((N, S), dtype=np.float32), dev)
+
+    def run(counter):
+        o_a, o_l = th.zeros((N, A), device=dev), th.zeros(N, device=dev)
+        ops.rollout_step(P, spec, avg, sd, x, seed=123, counter=counter, out_action=o_a, out_logprob=o_l)
+        return o_a.cpu().numpy(), o_l.cpu().numpy()
+
+    a0, l0 = run(5)
+    a0b, _ = run(5)
+    a1, _ = run(6)
+    np.testing.assert_array_equal(a0, a0b)
+    mean = O.actor_mean(x.cpu().numpy(), net)
+    eps0, eps1 = a0 - mean, a1 - mean      # std = 1
+    assert abs(eps0.mean()) < 0.02 and abs(eps0.std() - 1.0) < 0.02
+    assert abs(np.corrcoef(eps0.ravel(), eps1.ravel())[0, 1]) < 0.02
+    assert abs(np.corrcoef(eps0[:, 0], eps0[:, 1])[0, 1]) < 0.06
+    np.testing.assert_allclose(l0, O.gaussian_logprob(a0, mean, net.action_std_log), rtol=1e-4, atol=1e-4)
+
+
+def ppo_case(rng, H, N, S, A, B):
+    states = rng.standard_normal((H, N, S), dtype=np.float32)
+    actions = rng.standard_normal((H, N, A), dtype=np.float32) * 0.7
+    um = rng.random((H, N)) > 0.1
+    lp = (-1.0 * A + 0.3 * rng.standard_normal((H, N))).astype(np.float32)
+    adv = rng.standard_normal((H, N), dtype=np.float32)
+    rs = rng.standard_normal((H, N), dtype=np.float32)
+    ids = rng.integers(0, H * N, size=B).astype(np.int64)
+    return states, actions, um, lp, adv, rs, ids
+
+
+def oracle_flat_grads(buf, ids, actor, critic, clip, lam_ent, dt):
+    states, actions, um, lp, adv, rs = buf
+    H = states.shape[0]
+    i0, i1 = O.split_ids(ids, H)
+    s, a = states[i0, i1].astype(dt), actions[i0, i1].astype(dt)
+    oc, gw, gb = O.critic_objective(s, rs[i0, i1].astype(dt), um[i0, i1], critic.astype(dt))
+    gc = np.concatenate([x.reshape(-1) for pair in zip(gw, gb) for x in pair])
+    os_, oe, gw, gb, gsl = O.actor_objective(s, a, lp[i0, i1].astype(dt), adv[i0, i1].astype(dt), um[i0, i1], actor.astype(dt),
+                                             clip, lam_ent)
+    ga = np.concatenate([x.reshape(-1) for pair in zip(gw, gb) for x in pair] + [gsl.reshape(-1)])
+    return ga, gc, np.array([oc, os_, oe], dtype=np.float64)
+
+
+@pytest.mark.parametrize("S,h1,h2,A", MLP_SHAPES)
+@pytest.mark.parametrize("B,n_slabs", [(64, 1), (200, 2), (1024, 16), (1000, 3)])
+def test_ppo_step_gradients(ops, dev, S, h1, h2, A, B, n_slabs):
+    rng = np.random.default_rng(S + B)
+    H, N = 9, 50
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = buf_ids[:6], buf_ids[6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    stride = ops.ppo_slab_stride(S, h1, h2, A)
+    Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
+    assert stride == Pa + Pc + 4
+    slabs = th.full((n_slabs, stride), float("nan"), device=dev)
+    flat = th.zeros(stride, device=dev)
+    ops.ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                 cu(critic.state_avg, dev), cu(critic.state_std, dev), S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev),
+                 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    ops.grad_reduce(slabs, n_slabs, stride, flat)
+    got = flat.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all(), "a slab slot was left unwritten"
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64)
+    for name, g, ref in (("actor", got[:Pa], ga), ("critic", got[Pa:Pa + Pc], gc)):
+        scale = np.abs(ref).max()
+        err = np.abs(g - ref).max()
+        assert err <= 1e-4 * scale + 1e-7, f"{name} grad err {err:.3e} (scale {scale:.3e})"
+    np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
+
+
+def test_clip_adam_matches_oracle(ops, dev):
+    rng = np.random.default_rng(9)
+    n_a, n_c = 25872, 24961
+    p = rng.standard_normal(n_a + n_c).astype(np.float32)
+    P, M1, M2 = cu(p, dev), th.zeros(n_a + n_c, device=dev), th.zeros(n_a + n_c, device=dev)
+    pa, pc = [p[:n_a].copy()], [p[n_a:].copy()]
+    sa, sc = O.AdamState(), O.AdamState()
+    for step in range(1, 6):
+        scale = 10.0 if step % 2 else 0.01                 # exercise both clipped and unclipped
+        g = (scale * rng.standard_normal(n_a + n_c) / 100).astype(np.float32)
+        ops.clip_adam(P, cu(g, dev), M1, M2, [(0, n_a), (n_a, n_c)], step, 1e-3, 3.0)
+        O.optimizer_backward(pa, [g[:n_a]], sa, 1e-3, 3.0)
+        O.optimizer_backward(pc, [g[n_a:]], sc, 1e-3, 3.0)
+        np.testing.assert_allclose(P.cpu().numpy(), np.concatenate([pa[0], pc[0]]), rtol=0, atol=2e-6)
+
+
+def test_clip_adam_grad_scale_equals_prescaled(ops, dev):
+    rng = np.random.default_rng(10)
+    n = 5000
+    p = rng.standard_normal(n).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    P1, P2 = cu(p, dev), cu(p, dev)
+    z = lambda: th.zeros(n, device=dev)
+    ops.clip_adam(P1, cu(g, dev), z(), z(), [(0, n)], 1, 1e-3, 3.0, grad_scale=0.125)
+    ops.clip_adam(P2, cu(g * np.float32(0.125), dev), z(), z(), [(0, n)], 1, 1e-3, 3.0)
+    np.testing.assert_array_equal(P1.cpu().numpy(), P2.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_update_loop_on_reference_golden(ops, dev, name):
+    """gather + fwd/bwd + reduce + clip + Adam for every recorded minibatch of the reference run."""
+    g = load(name)
+    hp, d = hyper(g), dims(g)
+    S, A, h1, h2, B = d["S"], d["A"], d["h1"], d["h2"], d["B"]
+    a0, c0 = mlp_from(g, "act0"), mlp_from(g, "cri0")
+    Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
+    P = cu(np.concatenate([flat_params(a0), flat_params(c0)]), dev)
+    M1, M2 = th.zeros_like(P), th.zeros_like(P)
+    stride = Pa + Pc + 4
+    slabs, flat = th.zeros((1, stride), device=dev), th.zeros(stride, device=dev)
+    buf = [cu(g[k], dev) for k in ("states", "actions", "unmasks", "logprobs", "advantages_norm", "reward_sums")]
+    logs = []
+    for step, ids in enumerate(g["ids"], start=1):
+        ops.ppo_step(P[:Pa], P[Pa:], cu(a0.state_avg, dev), cu(a0.state_std, dev), cu(c0.state_avg, dev), cu(c0.state_std, dev),
+                     S, h1, h2, A, *buf, cu(ids, dev), hp["ratio_clip"], hp["lambda_entropy"], 1.0 / B, slabs, 1)
+        ops.grad_reduce(slabs, 1, stride, flat)
+        logs.append(flat[Pa + Pc:Pa + Pc + 3].cpu().numpy().astype(np.float64))
+        ops.clip_adam(P, flat, M1, M2, [(0, Pa), (Pa, Pc)], step, hp["lr"], hp["max_norm"])
+    np.testing.assert_allclose(np.mean(logs, axis=0), g["objs"], rtol=2e-4, atol=2e-6)
+    ref = np.concatenate([flat_params(mlp_from(g, "act1")), flat_params(mlp_from(g, "cri1"))])
+    np.testing.assert_allclose(P.cpu().numpy(), ref, rtol=0, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_synenv_step_matches_formula(ops, dev):
+    rng = np.random.default_rng(4)
+    N, S, A = 1000, 64, 8
+    s = rng.standard_normal((N, S), dtype=np.float32)
+    s[:5] *= 30.0                                             # force terminals
+    a = np.tanh(rng.standard_normal((N, A), dtype=np.float32))
+    Ws = (0.9 * np.eye(S) + 0.05 * rng.standard_normal((S, S))).astype(np.float32)
+    Wa = (0.1 * rng.standard_normal((A, S))).astype(np.float32)
+    sc = np.zeros(N, np.int32)
+    sc[10:20] = 99                                            # will truncate at max_step = 100
+    ts, tsc, tep = cu(s, dev), cu(sc, dev), th.zeros(N, dtype=th.int32, device=dev)
+    rew, term, trunc = th.zeros(N, device=dev), th.zeros(N, dtype=th.bool, device=dev), th.zeros(N, dtype=th.bool, device=dev)
+    ops.synenv_step(ts, cu(a, dev), cu(Ws, dev), cu(Wa, dev), tsc, tep, rew, term, trunc, 100, 7)
+    s2 = s.astype(np.float64) @ Ws + a.astype(np.float64) @ Wa
+    np.testing.assert_allclose(rew.cpu().numpy(), -(s2 ** 2).mean(1) - 0.01 * (a.astype(np.float64) ** 2).mean(1), rtol=1e-4, atol=1e-5)
+    t_ref = np.abs(s2).max(1) > 10
+    np.testing.assert_array_equal(term.cpu().numpy(), t_ref)
+    tr_ref = (sc + 1 >= 100) & ~t_ref
+    np.testing.assert_array_equal(trunc.cpu().numpy(), tr_ref)
+    done = t_ref | tr_ref
+    assert done[:5].all() and done[10:20].all()
+    out = ts.cpu().numpy()
+    np.testing.assert_allclose(out[~done], s2[~done], rtol=1e-4, atol=1e-5)
+    assert abs(out[done].mean()) < 0.2 and 0.7 < out[done].std() < 1.3     # fresh N(0,1) rows
+    np.testing.assert_array_equal(tsc.cpu().numpy(), np.where(done, 0, sc + 1))
+    np.testing.assert_array_equal(tep.cpu().numpy(), done.astype(np.int32))
+
+
+def test_pendulum_step_matches_gym_formula(ops, dev):
+    rng = np.random.default_rng(6)
+    N = 512
+    phys = np.stack([rng.uniform(-np.pi, np.pi, N), rng.uniform(-8, 8, N)], 1).astype(np.float32)
+    act = rng.uniform(-1.5, 1.5, (N, 1)).astype(np.float32)
+    tp, obs = cu(phys, dev), th.zeros((N, 3), device=dev)
+    sc, ep = th.zeros(N, dtype=th.int32, device=dev), th.zeros(N, dtype=th.int32, device=dev)
+    rew, term, trunc = th.zeros(N, device=dev), th.zeros(N, dtype=th.bool, device=dev), th.zeros(N, dtype=th.bool, device=dev)
+    ops.pendulum_step(tp, obs, cu(act, dev), sc, ep, rew, term, trunc, 200, 0)
+    th_, thd = phys[:, 0].astype(np.float64), phys[:, 1].astype(np.float64)
+    u = np.clip(2.0 * act[:, 0].astype(np.float64), -2, 2)
+    ang = ((th_ + np.pi) % (2 * np.pi)) - np.pi
+    cost = ang ** 2 + 0.1 * thd ** 2 + 0.001 * u ** 2
+    nthd = np.clip(thd + (3 * 10.0 / 2 * np.sin(th_) + 3.0 * u) * 0.05, -8, 8)
+    nth = th_ + nthd * 0.05
+    np.testing.assert_allclose(rew.cpu().numpy(), -0.5 * cost, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(obs.cpu().numpy(), np.stack([np.cos(nth), np.sin(nth), nthd], 1), rtol=1e-4, atol=1e-4)
+    assert not term.any().item() and not trunc.any().item()
