@@ -1,0 +1,174 @@
+"""`AgentBase`: constructor contract, attributes and checkpoint format of elegantrl/agents/AgentBase.py,
+plus the flat-parameter plumbing the HIP kernels need.
+
+What is kept from the reference (it is the API run.py / Evaluator drive):
+ctor `(net_dims, state_dim, action_dim, gpu_id, args)`, the hyper-parameter attributes read from
+`Config`, `explore_env` dispatch (:70-74), settable `act` / `last_state`, `save_or_load_agent`
+(:280-297, whole-object `th.save` files), `explore_rate` (run.py:126 needs it) and the torch-module
+builders `build_mlp` / `layer_init_with_orthogonal` (:345-365).
+
+What is new: `FlatNet` makes an actor/critic's trainable parameters views into one flat fp32 buffer laid
+out as include/erl_hip.h describes, so kernels read/write weights in place while the objects stay
+ordinary picklable `nn.Module`s.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch as th
+from torch import nn
+
+from ..train.config import Config
+
+TEN = th.Tensor
+
+
+def build_mlp(dims: List[int], activation=None, if_raw_out: bool = True) -> nn.Sequential:
+    """Linear -> GELU -> ... -> Linear (no activation after the last layer when if_raw_out)."""
+    act = nn.GELU if activation is None else activation
+    layers: list = []
+    for d_in, d_out in zip(dims[:-1], dims[1:]):
+        layers += [nn.Linear(d_in, d_out), act()]
+    if if_raw_out:
+        layers.pop()
+    return nn.Sequential(*layers)
+
+
+def layer_init_with_orthogonal(layer, std: float = 1.0, bias_const: float = 1e-6):
+    th.nn.init.orthogonal_(layer.weight, std)
+    th.nn.init.constant_(layer.bias, bias_const)
+
+
+class FlatNet:
+    """Binds an `nn.Module` with sub-module `net` = build_mlp([S, h1, h2, out]) (and optionally
+    `action_std_log`) to a slice of a flat fp32 parameter buffer.  After `bind`, each trainable
+    parameter's `.data` is a view into the slice, in the order W1,b1,W2,b2,W3,b3[,action_std_log]."""
+
+    def __init__(self, module: nn.Module, spec, flat_slice: TEN):
+        self.module = module
+        self.spec = spec
+        self.flat = flat_slice
+        self.bind(module)
+
+    def _named(self, module):
+        sd = dict(module.named_parameters())
+        return [(name, sd[name], off, shape) for name, off, shape in self.spec.slices()]
+
+    def bind(self, module: nn.Module) -> None:
+        """copy the module's current values into the flat slice and re-point the parameters at it."""
+        self.module = module
+        with th.no_grad():
+            for name, p, off, shape in self._named(module):
+                assert tuple(p.shape) == tuple(shape), f"{name}: {tuple(p.shape)} != {shape}"
+                view = self.flat[off:off + p.numel()].view(shape)
+                view.copy_(p.data.to(self.flat.device, th.float32))
+                p.data = view
+
+    def is_bound(self, module: nn.Module) -> bool:
+        if module is not self.module:
+            return False
+        name, p, off, _ = self._named(module)[0]
+        return p.data_ptr() == self.flat.data_ptr() + 4 * off
+
+
+class AgentBase:
+    """Hyper-parameter capture + the generic pieces shared by the agents."""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
+        args = Config() if args is None else args
+        self.if_discrete: bool = args.if_discrete
+        self.if_off_policy: bool = args.if_off_policy
+        self.net_dims = net_dims
+        self.state_dim = state_dim
+        self.action_dim = action_dim
+
+        self.gamma = args.gamma
+        self.max_step = args.max_step
+        self.num_envs = args.num_envs
+        self.batch_size = args.batch_size
+        self.repeat_times = args.repeat_times
+        self.reward_scale = args.reward_scale
+        self.learning_rate = args.learning_rate
+        self.clip_grad_norm = args.clip_grad_norm
+        self.soft_update_tau = args.soft_update_tau
+        self.state_value_tau = args.state_value_tau
+        self.buffer_init_size = args.buffer_init_size
+
+        self.explore_noise_std = getattr(args, "explore_noise_std", 0.05)
+        self.explore_rate = getattr(args, "explore_rate", 1.0)  # read by run.py:126 in the single-process loop
+        self.last_state: Optional[TEN] = None
+        self.device = th.device(f"cuda:{gpu_id}" if (th.cuda.is_available() and gpu_id >= 0) else "cpu")
+
+        self._act = None
+        self.cri = None
+        self.act_target = None
+        self.cri_target = None
+        self.act_optimizer = None
+        self.cri_optimizer = None
+
+        self.criterion = getattr(args, "criterion", th.nn.MSELoss(reduction="none"))
+        self.if_vec_env = self.num_envs > 1
+        self.if_use_per = getattr(args, "if_use_per", None)
+        self.lambda_fit_cum_r = getattr(args, "lambda_fit_cum_r", 0.0)
+
+        self.save_attr_names = {"act", "act_target", "act_optimizer", "cri", "cri_target", "cri_optimizer"}
+
+        # data-parallel context (one process per GPU; see elegantrl_amd/parallel.py)
+        self.world_size = int(getattr(args, "world_size", 1))
+        self.rank = int(getattr(args, "rank", 0))
+        seed = getattr(args, "random_seed", None)
+        self.rng_seed = (int(seed) if seed is not None else max(0, gpu_id)) * 1000003 + 7919 * self.rank
+        self.rng_counter = 0
+
+    # `act` is settable (run.py:404-407 replaces it with the learner's copy); subclasses re-bind kernels
+    @property
+    def act(self):
+        return self._act
+
+    @act.setter
+    def act(self, module):
+        self._act = module
+        self._on_act_replaced()
+
+    def _on_act_replaced(self):
+        pass
+
+    def explore_env(self, env, horizon_len: int) -> Tuple[TEN, ...]:
+        if self.if_vec_env:
+            return self._explore_vec_env(env=env, horizon_len=horizon_len)
+        return self._explore_one_env(env=env, horizon_len=horizon_len)
+
+    # spellings used by older releases / the north star
+    def explore_vec_env(self, env, horizon_len: int):
+        return self._explore_vec_env(env=env, horizon_len=horizon_len)
+
+    def explore_one_env(self, env, horizon_len: int):
+        return self._explore_one_env(env=env, horizon_len=horizon_len)
+
+    def _explore_vec_env(self, env, horizon_len: int):
+        raise NotImplementedError
+
+    def _explore_one_env(self, env, horizon_len: int):
+        raise NotImplementedError
+
+    def update_net(self, buffer):
+        raise NotImplementedError
+
+    @staticmethod
+    def soft_update(target_net: nn.Module, current_net: nn.Module, tau: float):
+        with th.no_grad():
+            for tar, cur in zip(target_net.parameters(), current_net.parameters()):
+                tar.data.mul_(1.0 - tau).add_(cur.data, alpha=tau)
+
+    def save_or_load_agent(self, cwd: str, if_save: bool):
+        """whole-object checkpoint files `{cwd}/{attr}.pth`, as AgentBase.py:280-297."""
+        assert self.save_attr_names.issuperset({"act", "act_optimizer"})
+        for attr_name in self.save_attr_names:
+            path = f"{cwd}/{attr_name}.pth"
+            obj = getattr(self, attr_name, None)
+            if if_save:
+                if obj is not None:
+                    th.save(obj, path)
+            elif os.path.isfile(path):
+                setattr(self, attr_name, th.load(path, map_location=self.device, weights_only=False))

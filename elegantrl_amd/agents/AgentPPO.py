@@ -1,0 +1,335 @@
+"""`AgentPPO` on the HIP hot path: vectorised rollout (K1), value pre-pass (K2), GAE scan (K3), advantage
+normalisation (K4), fused gather + PPO objective forward/backward (K5/K6) and clip + Adam (K7).
+
+Drop-in for elegantrl/agents/AgentPPO.py (AgentPPO :12-232, ActorPPO :348-390, CriticPPO :425-441): same
+constructor, same `explore_env` / `update_net` / `get_advantages` / `explore_action` signatures and
+returned shapes/dtypes, same objective (including its quirks: sign-dependent "clip" scale :199,
+penalised entropy :203-204, `[::4, ::4]` std :149, `update_times = int(H * repeat_times / batch_size)`
+:159) -- the arithmetic itself runs in liberl_hip.so.  There is no PyTorch fallback for these methods:
+without a HIP device / the extension they raise.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch as th
+from torch import nn
+
+from .. import _hip
+from ..train.config import Config
+from .AgentBase import AgentBase, FlatNet, build_mlp, layer_init_with_orthogonal
+
+TEN = th.Tensor
+
+
+class ActorPPO(nn.Module):
+    """Gaussian policy head: same parameters/buffers and torch-side methods as the reference so that the
+    Evaluator's `actor(state)`, `th.save(actor)` and user code keep working; the training path does not
+    call these methods (it uses the fused kernels on the flat parameter buffer)."""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int):
+        super().__init__()
+        self.net = build_mlp(dims=[state_dim, *net_dims, action_dim])
+        layer_init_with_orthogonal(self.net[-1], std=0.1)
+        self.action_std_log = nn.Parameter(th.zeros((1, action_dim)), requires_grad=True)
+        self.ActionDist = th.distributions.normal.Normal
+        self.state_avg = nn.Parameter(th.zeros((state_dim,)), requires_grad=False)
+        self.state_std = nn.Parameter(th.ones((state_dim,)), requires_grad=False)
+
+    def state_norm(self, state: TEN) -> TEN:
+        return (state - self.state_avg) / (self.state_std + 1e-4)
+
+    def forward(self, state: TEN) -> TEN:
+        return self.convert_action_for_env(self.net(self.state_norm(state)))
+
+    def get_action(self, state: TEN) -> Tuple[TEN, TEN]:
+        dist = self.ActionDist(self.net(self.state_norm(state)), self.action_std_log.exp())
+        action = dist.sample()
+        return action, dist.log_prob(action).sum(1)
+
+    def get_logprob_entropy(self, state: TEN, action: TEN) -> Tuple[TEN, TEN]:
+        dist = self.ActionDist(self.net(self.state_norm(state)), self.action_std_log.exp())
+        return dist.log_prob(action).sum(1), dist.entropy().sum(1)
+
+    @staticmethod
+    def convert_action_for_env(action: TEN) -> TEN:
+        return action.tanh()
+
+
+class CriticPPO(nn.Module):
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int):
+        super().__init__()
+        assert isinstance(action_dim, int)
+        self.net = build_mlp(dims=[state_dim, *net_dims, 1])
+        layer_init_with_orthogonal(self.net[-1], std=0.5)
+        self.state_avg = nn.Parameter(th.zeros((state_dim,)), requires_grad=False)
+        self.state_std = nn.Parameter(th.ones((state_dim,)), requires_grad=False)
+
+    def state_norm(self, state: TEN) -> TEN:
+        return (state - self.state_avg) / (self.state_std + 1e-4)
+
+    def forward(self, state: TEN) -> TEN:
+        return self.net(self.state_norm(state))
+
+
+class FlatAdam:
+    """Adam state of one network as views into the agent's flat moment buffers (picklable; takes the place
+    of the reference's `th.optim.Adam` objects in `save_or_load_agent`)."""
+
+    def __init__(self, exp_avg: TEN, exp_avg_sq: TEN, lr: float):
+        self.exp_avg, self.exp_avg_sq, self.lr = exp_avg, exp_avg_sq, lr
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8}]
+
+
+class AgentPPO(AgentBase):
+    """PPO + GAE, reference-form objective, HIP kernels."""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
+        args = Config() if args is None else args
+        super().__init__(net_dims, state_dim, action_dim, gpu_id, args)
+        self.if_off_policy = False
+        if self.if_discrete:
+            raise NotImplementedError("AgentDiscretePPO is a 'next' row (SURVEY.md 8f); the HIP path is continuous PPO")
+        if len(net_dims) != 2:
+            raise _hip.HipExtensionError(f"the fused HIP MLP kernels support exactly 2 hidden layers, got net_dims={net_dims}")
+
+        self.ratio_clip = getattr(args, "ratio_clip", 0.25)
+        self.lambda_gae_adv = getattr(args, "lambda_gae_adv", 0.95)
+        self.lambda_entropy_value = float(getattr(args, "lambda_entropy", 0.001))
+        self.lambda_entropy = th.tensor(self.lambda_entropy_value, dtype=th.float32, device=self.device)
+        # the reference reads `if_use_v_trace`; its Config sets `if_use_vtrace` (never consumed): accept both
+        self.if_use_v_trace = getattr(args, "if_use_v_trace", getattr(args, "if_use_vtrace", True))
+        self.gae_algo = getattr(args, "gae_algo", "auto")
+
+        from .. import ops  # deferred: importing the package must work without the built extension
+        h1, h2 = net_dims
+        self._spec_a = ops.MlpSpec(state_dim, h1, h2, action_dim, True)
+        self._spec_c = ops.MlpSpec(state_dim, h1, h2, 1, False)
+        self._Pa, self._Pc = self._spec_a.count, self._spec_c.count    # raises for unsupported shapes
+        self._stride = self._Pa + self._Pc + 4
+        f32 = dict(dtype=th.float32, device=self.device)
+        self._flat = th.zeros(self._Pa + self._Pc, **f32)
+        self._exp_avg = th.zeros_like(self._flat)
+        self._exp_avg_sq = th.zeros_like(self._flat)
+        self._adam_step = 0
+
+        act = ActorPPO(net_dims=net_dims, state_dim=state_dim, action_dim=action_dim).to(self.device)
+        cri = CriticPPO(net_dims=net_dims, state_dim=state_dim, action_dim=action_dim).to(self.device)
+        self._flat_a = FlatNet(act, self._spec_a, self._flat[:self._Pa])
+        self._flat_c = FlatNet(cri, self._spec_c, self._flat[self._Pa:])
+        self._act = act
+        self.cri = cri
+        self.act_optimizer = FlatAdam(self._exp_avg[:self._Pa], self._exp_avg_sq[:self._Pa], self.learning_rate)
+        self.cri_optimizer = FlatAdam(self._exp_avg[self._Pa:], self._exp_avg_sq[self._Pa:], self.learning_rate)
+
+        self._slabs = None
+        self._grads = None
+        self._stats = None
+        self._env_action = None
+
+    # ---- keeping the kernels' view of the weights in sync with whatever module is installed ----------
+    def _on_act_replaced(self):
+        if getattr(self, "_flat_a", None) is not None and self._act is not None and not self._flat_a.is_bound(self._act):
+            self._act = self._act.to(self.device)
+            self._flat_a.bind(self._act)
+
+    def _sync_modules(self):
+        if not self._flat_a.is_bound(self._act):
+            self._flat_a.bind(self._act)
+        if not self._flat_c.is_bound(self.cri):
+            self._flat_c.bind(self.cri)
+
+    def _require_gpu(self, what: str):
+        if self.device.type != "cuda":
+            raise _hip.HipExtensionError(f"AgentPPO.{what} runs on the HIP kernels only; no GPU is visible "
+                                         f"(device={self.device}) and there is no CPU fallback")
+
+    # ---- rollout: AgentPPO.py:87-133 -----------------------------------------------------------------
+    def explore_action(self, state: TEN, noise: Optional[TEN] = None) -> Tuple[TEN, TEN]:
+        """(pre-tanh action, logprob) for a batch of states, through the K1 kernel."""
+        from .. import ops
+        self._require_gpu("explore_action")
+        self._sync_modules()
+        state = state.contiguous()
+        n = state.shape[0]
+        action = th.empty((n, self.action_dim), dtype=th.float32, device=self.device)
+        logprob = th.empty((n,), dtype=th.float32, device=self.device)
+        ops.rollout_step(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
+                         noise=noise, seed=self.rng_seed, counter=self.rng_counter, out_action=action, out_logprob=logprob)
+        self.rng_counter += 1
+        return action, logprob
+
+    def _explore_vec_env(self, env, horizon_len: int, if_random: bool = False, noise: Optional[TEN] = None):
+        """H batched steps -> (states, actions, logprobs, rewards, undones, unmasks), time-major.
+        `noise` (H, N, A) injects the N(0,1) draws (tests); otherwise Philox keyed by (seed, step, env)."""
+        from .. import ops
+        self._require_gpu("explore_env")
+        self._sync_modules()
+        H, N, S, A = horizon_len, self.num_envs, self.state_dim, self.action_dim
+        dev = self.device
+        states = th.zeros((H, N, S), dtype=th.float32, device=dev)
+        actions = th.zeros((H, N, A), dtype=th.float32, device=dev)
+        logprobs = th.zeros((H, N), dtype=th.float32, device=dev)
+        rewards = th.zeros((H, N), dtype=th.float32, device=dev)
+        terminals = th.zeros((H, N), dtype=th.bool, device=dev)
+        truncates = th.zeros((H, N), dtype=th.bool, device=dev)
+        if self._env_action is None or self._env_action.shape != (N, A):
+            self._env_action = th.empty((N, A), dtype=th.float32, device=dev)
+        env_action = self._env_action
+        P, spec = self._flat_a.flat, self._spec_a
+        avg, std = self._act.state_avg.data, self._act.state_std.data
+        native = hasattr(env, "step_into")
+
+        state = self.last_state
+        assert state.shape == (N, S), f"last_state {tuple(state.shape)} != {(N, S)}"
+        state = state.to(dev, th.float32).contiguous()
+        for t in range(H):
+            ops.rollout_step(P, spec, avg, std, state, noise=None if noise is None else noise[t], seed=self.rng_seed,
+                             counter=self.rng_counter, out_state=states[t], out_action=actions[t],
+                             out_logprob=logprobs[t], out_env_action=env_action)
+            self.rng_counter += 1
+            if native:     # GPU-resident env writes its outputs straight into row t (no copies, no host sync)
+                state = env.step_into(env_action, rewards[t], terminals[t], truncates[t])
+            else:          # any env honouring the reference protocol (device tensors, auto-reset)
+                state, reward, terminal, truncate, _ = env.step(env_action)
+                state = state.to(dev, th.float32).contiguous()
+                rewards[t] = reward
+                terminals[t] = terminal
+                truncates[t] = truncate
+        self.last_state = state.clone() if native else state
+        rewards *= self.reward_scale
+        undones = th.logical_not(terminals)
+        unmasks = th.logical_not(truncates)
+        return states, actions, logprobs, rewards, undones, unmasks
+
+    def _explore_one_env(self, env, horizon_len: int, if_random: bool = False):
+        """single (numpy, non-vectorised) env: AgentPPO.py:34-85; the policy still runs on the GPU."""
+        from .. import ops
+        self._require_gpu("explore_env")
+        self._sync_modules()
+        H, S, A, dev = horizon_len, self.state_dim, self.action_dim, self.device
+        states = th.zeros((H, 1, S), dtype=th.float32, device=dev)
+        actions = th.zeros((H, 1, A), dtype=th.float32, device=dev)
+        logprobs = th.zeros((H, 1), dtype=th.float32, device=dev)
+        rewards = th.zeros((H, 1), dtype=th.float32, device=dev)
+        terminals = th.zeros((H, 1), dtype=th.bool, device=dev)
+        truncates = th.zeros((H, 1), dtype=th.bool, device=dev)
+        env_action = th.empty((1, A), dtype=th.float32, device=dev)
+        state = self.last_state.to(dev, th.float32).reshape(1, S).contiguous()
+        for t in range(H):
+            ops.rollout_step(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
+                             seed=self.rng_seed, counter=self.rng_counter, out_state=states[t], out_action=actions[t],
+                             out_logprob=logprobs[t], out_env_action=env_action)
+            self.rng_counter += 1
+            ary_state, reward, terminal, truncate, _ = env.step(env_action[0].cpu().numpy())
+            if terminal or truncate:
+                ary_state, _ = env.reset()
+            state = th.as_tensor(ary_state, dtype=th.float32, device=dev).reshape(1, S)
+            rewards[t, 0] = float(reward)
+            terminals[t, 0] = bool(terminal)
+            truncates[t, 0] = bool(truncate)
+        self.last_state = state
+        rewards *= self.reward_scale
+        return states, actions, logprobs, rewards, th.logical_not(terminals), th.logical_not(truncates)
+
+    # ---- GAE: AgentPPO.py:207-232 ---------------------------------------------------------------------
+    def get_values(self, states: TEN) -> TEN:
+        """cri(states).squeeze(-1) for states (..., S) (the value pre-pass of :141-143, in one launch)."""
+        from .. import ops
+        self._require_gpu("get_values")
+        self._sync_modules()
+        return ops.value_forward(self._flat_c.flat, self._spec_c, self.cri.state_avg.data, self.cri.state_std.data,
+                                 states.contiguous())
+
+    def get_advantages(self, states: TEN, rewards: TEN, undones: TEN, unmasks: TEN, values: TEN) -> TEN:
+        """Same signature and side effects as the reference: returns `advantages` (H, N) and applies the
+        truncation fix-up to the caller's `rewards` / `undones` in place."""
+        adv, _ = self._gae(rewards, undones, unmasks, values, with_ret=False)
+        return adv
+
+    get_reward_sum_gae = get_advantages   # older spelling used by the north star / stale tests
+
+    def _gae(self, rewards, undones, unmasks, values, with_ret=True, stats=None):
+        from .. import ops
+        self._require_gpu("get_advantages")
+        next_value = self.get_values(self.last_state.to(self.device, th.float32))
+        return ops.gae_scan(rewards, undones, unmasks, values, next_value, float(self.gamma), float(self.lambda_gae_adv),
+                            use_v_trace=bool(self.if_use_v_trace), mutate=True, algo=self.gae_algo, with_ret=with_ret,
+                            stats=stats)
+
+    # ---- update: AgentPPO.py:135-205 ------------------------------------------------------------------
+    def update_net(self, buffer, ids: Optional[TEN] = None) -> Tuple[float, float, float]:
+        """One PPO update on the rollout `buffer`; returns (obj_critic, obj_surrogate, obj_entropy) means.
+        `ids` (update_times, batch_size) int64 injects the minibatch indices (tests); otherwise they are drawn
+        with th.randint(H*N, ...) like the reference."""
+        from .. import ops, parallel
+        self._require_gpu("update_net")
+        self._sync_modules()
+        states, actions, logprobs, rewards, undones, unmasks = buffer
+        H, N = rewards.shape
+        dev = self.device
+        if self._stats is None:
+            self._stats = th.zeros(8, dtype=th.float64, device=dev)
+
+        values = self.get_values(states)                                              # (H, N)
+        advantages, reward_sums = self._gae(rewards, undones, unmasks, values, stats=self._stats)
+        if self.world_size > 1:                                                       # one normalisation for the whole job
+            parallel.all_reduce_sum(self._stats)
+        advantages = ops.adv_normalize(advantages, self._stats, out=advantages)
+        assert logprobs.shape == advantages.shape == reward_sums.shape == (H, N)
+
+        B = int(self.batch_size)
+        update_times = int(H * self.repeat_times / B)
+        assert update_times >= 1
+        if ids is None:
+            ids = th.randint(H * N, size=(update_times, B), device=dev)
+        assert ids.shape == (update_times, B) and ids.dtype == th.int64
+        n_slabs = self._n_slabs(B)
+        if self._slabs is None or self._slabs.shape[0] != n_slabs:
+            self._slabs = th.empty((n_slabs, self._stride), dtype=th.float32, device=dev)
+        if self._grads is None or self._grads.shape[0] < update_times:
+            self._grads = th.empty((update_times, self._stride), dtype=th.float32, device=dev)
+        a, c = self._act, self.cri
+        groups = [(0, self._Pa), (self._Pa, self._Pc)]
+        inv_batch = 1.0 / B
+        grad_scale = 1.0 / self.world_size
+        h1, h2 = self.net_dims
+        for k in range(update_times):
+            ops.ppo_step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
+                         c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
+                         advantages, reward_sums, ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch,
+                         self._slabs, n_slabs)
+            g = self._grads[k]
+            ops.grad_reduce(self._slabs, n_slabs, self._stride, g)
+            if self.world_size > 1:
+                parallel.all_reduce_sum(g)                                             # RCCL over xGMI
+            self._adam_step += 1
+            ops.clip_adam(self._flat, g, self._exp_avg, self._exp_avg_sq, groups, self._adam_step, float(self.learning_rate),
+                          float(self.clip_grad_norm), grad_scale=grad_scale)
+        self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
+        logs = self._grads[:update_times, self._Pa + self._Pc:self._Pa + self._Pc + 3].mean(dim=0) * grad_scale
+        obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())           # the only host sync of update_net
+        return obj_critic, obj_actor, obj_entropy
+
+    def _n_slabs(self, batch_size: int) -> int:
+        tiles = (batch_size + 63) // 64
+        try:
+            cus = _hip.device_info()[0]
+        except Exception:
+            cus = 256
+        return max(1, min(tiles, cus // 2))
+
+    # ---- running state normalisation: AgentPPO.py:234-249 (never called by the reference's loops) -----
+    def update_avg_std_for_normalization(self, states: TEN):
+        tau = self.state_value_tau
+        if tau == 0:
+            return
+        state_avg = states.mean(dim=0, keepdim=True)
+        state_std = states.std(dim=0, keepdim=True)
+        with th.no_grad():
+            self.act.state_avg[:] = self.act.state_avg * (1 - tau) + state_avg * tau
+            self.act.state_std[:] = (self.act.state_std * (1 - tau) + state_std * tau).clamp_min(1e-4)
+            self.cri.state_avg[:] = self.act.state_avg
+            self.cri.state_std[:] = self.act.state_std

@@ -1,0 +1,118 @@
+"""Off-policy `ReplayBuffer` on the HIP ring-write / sample kernels (K8 / K9).
+
+Same constructor, attributes and cursor behaviour as elegantrl/train/replay_buffer.py:11-134; the
+cursor arithmetic (p, cur_size, if_full, add_size) is host-side integer code and reproduces the
+reference bit for bit (including landing exactly on max_size, Appendix A12 of SURVEY.md).  The tensor
+traffic goes through erl_replay_write_f32 / erl_replay_sample_f32.  Prioritised replay (SumTree) is a
+"next" row of SURVEY.md section 8f and raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch as th
+
+from .config import Config
+
+TEN = th.Tensor
+
+
+class ReplayBuffer:
+    def __init__(self, max_size: int, state_dim: int, action_dim: int, gpu_id: int = 0, num_seqs: int = 1,
+                 if_use_per: bool = False, if_discrete: bool = False, args: Optional[Config] = None):
+        if if_use_per:
+            raise NotImplementedError("prioritised replay (per-sequence SumTree) is not part of the HIP hot path yet")
+        if if_discrete:
+            raise NotImplementedError("discrete-action replay (uint8 actions) is not part of the HIP hot path yet")
+        self.p = 0                 # write cursor (time row)
+        self.if_full = False
+        self.cur_size = 0
+        self.add_size = 0
+        self.max_size = int(max_size)
+        self.num_seqs = int(num_seqs)
+        self.device = th.device(f"cuda:{gpu_id}" if (th.cuda.is_available() and gpu_id >= 0) else "cpu")
+        f32 = dict(dtype=th.float32, device=self.device)
+        self.states = th.empty((self.max_size, self.num_seqs, state_dim), **f32)
+        self.actions = th.empty((self.max_size, self.num_seqs, action_dim), **f32)
+        self.rewards = th.empty((self.max_size, self.num_seqs), **f32)
+        self.undones = th.empty((self.max_size, self.num_seqs), **f32)   # float flags, as in the reference
+        self.unmasks = th.empty((self.max_size, self.num_seqs), **f32)
+        self.cum_rewards = th.empty_like(self.rewards)
+        self.ids0 = th.tensor((), dtype=th.long, device=self.device)
+        self.ids1 = th.tensor((), dtype=th.long, device=self.device)
+        self.if_use_per = False
+        self.sum_trees = None
+        self.per_alpha = None
+        self.per_beta = None
+
+    # ---- cursor arithmetic: replay_buffer.py:84-118 -------------------------------------------
+    def _advance(self, add_size: int) -> int:
+        """update p / if_full / cur_size for `add_size` new time rows; returns the row the write starts at."""
+        assert 0 < add_size <= self.max_size, f"add_size={add_size} must be in (0, max_size={self.max_size}]"
+        self.add_size = add_size
+        start = self.p
+        p = self.p + add_size
+        if p > self.max_size:      # strictly greater: landing exactly on max_size is not "full" yet
+            self.if_full = True
+            p -= self.max_size
+        self.p = p
+        self.cur_size = self.max_size if self.if_full else self.p
+        return start
+
+    def update(self, items: Tuple[TEN, ...]):
+        from .. import ops
+        states, actions, rewards, undones, unmasks = items
+        start = self._advance(rewards.shape[0])
+        ops.replay_write(self.states, self.actions, self.rewards, self.undones, self.unmasks,
+                         (states.contiguous(), actions.contiguous(), rewards.contiguous(), undones.contiguous(),
+                          unmasks.contiguous()), start)
+
+    def sample(self, batch_size: int, ids: Optional[TEN] = None) -> Tuple[TEN, TEN, TEN, TEN, TEN, TEN]:
+        """(state, action, reward, undone, unmask, next_state) for ids drawn like the reference
+        (th.randint(sample_len * num_seqs, (batch_size,))); `ids` can be injected for tests."""
+        from .. import ops
+        sample_len = self.cur_size - 1
+        if ids is None:
+            ids = th.randint(sample_len * self.num_seqs, size=(batch_size,), requires_grad=False, device=self.device)
+        out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
+                                                        ids, sample_len)
+        return out
+
+    def sample_for_per(self, batch_size: int):
+        raise NotImplementedError("prioritised replay is not part of the HIP hot path yet")
+
+    def td_error_update_for_per(self, is_indices: TEN, td_error: TEN):
+        raise NotImplementedError("prioritised replay is not part of the HIP hot path yet")
+
+    # ---- persistence: replay_buffer.py:181-211 (same file names and unrolled order) --------------
+    def save_or_load_history(self, cwd: str, if_save: bool):
+        named = ((self.states, "states"), (self.actions, "actions"), (self.rewards, "rewards"), (self.undones, "undones"))
+        if if_save:
+            for item, name in named:
+                if self.cur_size == self.p:
+                    buf_item = item[:self.cur_size]
+                else:
+                    buf_item = th.vstack((item[self.p:self.cur_size], item[0:self.p]))
+                path = f"{cwd}/replay_buffer_{name}.pth"
+                print(f"| buffer.save_or_load_history(): Save {path}", flush=True)
+                th.save(buf_item, path)
+        elif all(os.path.isfile(f"{cwd}/replay_buffer_{name}.pth") for _, name in named):
+            sizes = []
+            for item, name in named:
+                path = f"{cwd}/replay_buffer_{name}.pth"
+                print(f"| buffer.save_or_load_history(): Load {path}", flush=True)
+                buf_item = th.load(path, map_location=self.device)
+                item[:buf_item.shape[0]] = buf_item
+                sizes.append(buf_item.shape[0])
+            assert all(s == sizes[0] for s in sizes)
+            self.cur_size = self.p = sizes[0]
+            self.if_full = self.cur_size == self.max_size
+
+    def update_cum_rewards(self, get_cumulative_rewards):
+        if self.p >= self.add_size:
+            p1, p0 = self.p, self.p - self.add_size
+        else:
+            p1 = self.max_size
+            p0 = p1 - self.add_size
+        self.cum_rewards[p0:p1, :] = get_cumulative_rewards(rewards=self.rewards[p0:p1, :], undones=self.undones[p0:p1, :])
