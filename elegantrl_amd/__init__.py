@@ -5,3 +5,7 @@ AgentPPO / ReplayBuffer); the arithmetic runs in hand-written HIP kernels behind
 include/erl_hip.h (elegantrl_amd/lib/liberl_hip.so).  No CPU fallback, no CUDA shims.
 """
 __version__ = "0.1.0"
+
+from .train.config import Config, get_gym_env_args  # noqa: E402
+from .train.run import (train_agent, train_agent_multiprocessing,  # noqa: E402
+                        train_agent_multiprocessing_multi_gpu, train_agent_single_process)

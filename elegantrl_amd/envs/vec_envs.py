@@ -1,0 +1,96 @@
+"""GPU-resident vectorised environments implementing the reference's env protocol
+(reset() -> (state, info); step(action) -> (state, reward, terminal, truncate, info); auto-reset;
+attributes env_name, num_envs, max_step, state_dim, action_dim, if_discrete -- elegantrl/train/config.py:134-135,
+elegantrl/envs/PointChasingEnv.py:84-182 as the in-tree exemplar).
+
+They additionally expose `step_into(action, reward_row, terminal_row, truncate_row) -> state`, which lets the
+rollout write step outputs straight into row t of its time-major buffers (no copies, no host sync).
+The dynamics run in erl_synenv_step_f32 / erl_pendulum_step_f32 (elegantrl_amd/csrc/envs.hip).
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import torch as th
+
+TEN = th.Tensor
+
+
+class _GpuVecEnv:
+    env_name = "GpuVecEnv"
+    if_discrete = False
+
+    def __init__(self, num_envs: int, state_dim: int, action_dim: int, max_step: int, gpu_id: int, seed: int):
+        if not th.cuda.is_available() or gpu_id < 0:
+            raise RuntimeError(f"{type(self).__name__} is GPU resident (HIP kernels); no device available for gpu_id={gpu_id}")
+        self.device = th.device(f"cuda:{gpu_id}")
+        self.num_envs, self.state_dim, self.action_dim, self.max_step = num_envs, state_dim, action_dim, max_step
+        self.seed = int(seed)
+        dev = self.device
+        self.step_count = th.zeros(num_envs, dtype=th.int32, device=dev)
+        self.episode = th.zeros(num_envs, dtype=th.int32, device=dev)
+        self._reward = th.zeros(num_envs, dtype=th.float32, device=dev)
+        self._terminal = th.zeros(num_envs, dtype=th.bool, device=dev)
+        self._truncate = th.zeros(num_envs, dtype=th.bool, device=dev)
+
+    def step(self, action: TEN) -> Tuple[TEN, TEN, TEN, TEN, dict]:
+        state = self.step_into(action.contiguous(), self._reward, self._terminal, self._truncate)
+        return state.clone(), self._reward.clone(), self._terminal.clone(), self._truncate.clone(), {}
+
+    def close(self):
+        pass
+
+
+class SynVecEnv(_GpuVecEnv):
+    """Synthetic continuous-control workload of SURVEY.md 8d: s' = s Ws + a Wa with Ws = 0.9 I + 0.05 G1,
+    Wa = 0.1 G2 (G ~ N(0,1), torch.Generator().manual_seed(0)); reward = -mean(s'^2) - 0.01 mean(a^2);
+    terminal = max|s'| > 10; truncate at max_step; done rows reset to N(0,1)."""
+    env_name = "SynVecEnv"
+
+    def __init__(self, num_envs: int = 4096, state_dim: int = 64, action_dim: int = 8, max_step: int = 1000,
+                 gpu_id: int = 0, seed: int = 0, **_):
+        super().__init__(num_envs, state_dim, action_dim, max_step, gpu_id, seed)
+        g = th.Generator().manual_seed(0)
+        self.Ws = (0.9 * th.eye(state_dim) + 0.05 * th.randn(state_dim, state_dim, generator=g)).to(self.device).contiguous()
+        self.Wa = (0.1 * th.randn(action_dim, state_dim, generator=g)).to(self.device).contiguous()
+        self.state = th.zeros((num_envs, state_dim), dtype=th.float32, device=self.device)
+
+    def reset(self) -> Tuple[TEN, dict]:
+        g = th.Generator(device=self.device).manual_seed(self.seed)
+        self.state = th.randn((self.num_envs, self.state_dim), device=self.device, generator=g)
+        self.step_count.zero_()
+        self.episode.zero_()
+        return self.state.clone(), {}
+
+    def step_into(self, action: TEN, reward_row: TEN, terminal_row: TEN, truncate_row: TEN) -> TEN:
+        from .. import ops
+        ops.synenv_step(self.state, action, self.Ws, self.Wa, self.step_count, self.episode, reward_row, terminal_row,
+                        truncate_row, self.max_step, self.seed)
+        return self.state
+
+
+class PendulumVecEnv(_GpuVecEnv):
+    """Pendulum-v1 (g=10, m=l=1, dt=0.05, 200-step truncation) behind the reference wrapper's scaling
+    (elegantrl/envs/CustomGymEnv.py:42-44: torque = 2*action, reward = 0.5*gym reward)."""
+    env_name = "Pendulum-v1"
+
+    def __init__(self, num_envs: int = 4096, max_step: int = 200, gpu_id: int = 0, seed: int = 0, **_):
+        super().__init__(num_envs, 3, 1, max_step, gpu_id, seed)
+        self.phys = th.zeros((num_envs, 2), dtype=th.float32, device=self.device)
+        self.state = th.zeros((num_envs, 3), dtype=th.float32, device=self.device)
+
+    def reset(self) -> Tuple[TEN, dict]:
+        g = th.Generator(device=self.device).manual_seed(self.seed)
+        u = th.rand((self.num_envs, 2), device=self.device, generator=g) * 2 - 1
+        self.phys = th.stack((u[:, 0] * math.pi, u[:, 1]), dim=1).contiguous()
+        self.state = th.stack((self.phys[:, 0].cos(), self.phys[:, 0].sin(), self.phys[:, 1]), dim=1).contiguous()
+        self.step_count.zero_()
+        self.episode.zero_()
+        return self.state.clone(), {}
+
+    def step_into(self, action: TEN, reward_row: TEN, terminal_row: TEN, truncate_row: TEN) -> TEN:
+        from .. import ops
+        ops.pendulum_step(self.phys, self.state, action, self.step_count, self.episode, reward_row, terminal_row,
+                          truncate_row, self.max_step, self.seed)
+        return self.state

@@ -1,0 +1,223 @@
+"""GPU tests of the drop-in classes (AgentPPO / ReplayBuffer / train_agent) against the reference-generated
+golden fixtures and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+from oracle import ppo_numpy as O
+from tests.helpers import PPO_GOLDENS, dims, hyper, load, mlp_from
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class PlaybackVecEnv:
+    """Replays the transitions recorded from the reference run (so the rollout sees identical inputs)."""
+
+    def __init__(self, g, reward_scale):
+        self.g, self.t, self.scale = g, 0, reward_scale
+        self.num_envs = g["states"].shape[1]
+
+    def reset(self):
+        return th.from_numpy(self.g["states"][0]).to(DEV), {}
+
+    def step(self, action):
+        g, t = self.g, self.t
+        H = g["states"].shape[0]
+        nxt = g["states"][t + 1] if t + 1 < H else g["last_state"]
+        self.t += 1
+        self.last_action = action.clone()
+        return (th.from_numpy(nxt).to(DEV), th.from_numpy(g["rewards"][t] / np.float32(self.scale)).to(DEV),
+                th.from_numpy(~g["undones"][t]).to(DEV), th.from_numpy(~g["unmasks"][t]).to(DEV), {})
+
+
+def make_agent(g):
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.train import Config
+    hp, d = hyper(g), dims(g)
+    args = Config(AgentPPO, None, {"env_name": "golden", "num_envs": d["N"], "max_step": 100, "state_dim": d["S"],
+                                   "action_dim": d["A"], "if_discrete": False})
+    args.net_dims = [d["h1"], d["h2"]]
+    args.horizon_len, args.batch_size = d["H"], d["B"]
+    args.repeat_times = d["n_upd"] * d["B"] / d["H"]
+    args.learning_rate, args.gamma, args.reward_scale = hp["lr"], hp["gamma"], hp["reward_scale"]
+    args.clip_grad_norm = hp["max_norm"]
+    args.if_use_v_trace = d["vtrace"]
+    args.lambda_gae_adv, args.ratio_clip, args.lambda_entropy = hp["lam"], hp["ratio_clip"], hp["lambda_entropy"]
+    agent = AgentPPO(args.net_dims, d["S"], d["A"], gpu_id=0, args=args)
+    with th.no_grad():
+        for net, prefix in ((agent.act, "act0"), (agent.cri, "cri0")):
+            sd = {k[len(prefix) + 1:]: th.from_numpy(v) for k, v in g.items() if k.startswith(prefix + ".")}
+            net.load_state_dict(sd)
+    return agent, args
+
+
+def flat_of(net):
+    return np.concatenate([p.reshape(-1) for p in net.trainable()])
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_explore_env_reproduces_reference_rollout(name):
+    g = load(name)
+    agent, args = make_agent(g)
+    env = PlaybackVecEnv(g, args.reward_scale)
+    agent.last_state = env.reset()[0]
+    noise = th.from_numpy(g["eps"].astype(np.float32)).to(DEV)
+    items = agent._explore_vec_env(env, args.horizon_len, noise=noise)
+    states, actions, logprobs, rewards, undones, unmasks = items
+    assert undones.dtype == th.bool and unmasks.dtype == th.bool and states.shape == g["states"].shape
+    np.testing.assert_array_equal(states.cpu().numpy(), g["states"])
+    np.testing.assert_allclose(actions.cpu().numpy(), g["actions"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(logprobs.cpu().numpy(), g["logprobs"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(rewards.cpu().numpy(), g["rewards"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(undones.cpu().numpy(), g["undones"])
+    np.testing.assert_array_equal(unmasks.cpu().numpy(), g["unmasks"])
+    np.testing.assert_array_equal(agent.last_state.cpu().numpy(), g["last_state"])
+    np.testing.assert_allclose(env.last_action.cpu().numpy(), np.tanh(g["actions"][-1]), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_get_advantages_matches_reference_and_mutates_like_it(name):
+    g = load(name)
+    agent, _ = make_agent(g)
+    agent.last_state = th.from_numpy(g["last_state"]).to(DEV)
+    states = th.from_numpy(g["states"]).to(DEV)
+    values = agent.get_values(states)
+    np.testing.assert_allclose(values.cpu().numpy(), g["values"], rtol=1e-4, atol=2e-5)
+    r, u = th.from_numpy(g["rewards"]).to(DEV), th.from_numpy(g["undones"]).to(DEV)
+    adv = agent.get_advantages(states, r, u, th.from_numpy(g["unmasks"]).to(DEV), th.from_numpy(g["values"]).to(DEV))
+    x, ref = adv.cpu().numpy(), g["advantages"]
+    assert (np.abs(x - ref) / np.maximum(1, np.abs(ref))).max() <= 1e-5          # the north star's bar
+    np.testing.assert_array_equal(u.cpu().numpy(), g["undones_after"])
+    np.testing.assert_allclose(r.cpu().numpy(), g["rewards_after"], rtol=0, atol=2e-5)
+    assert agent.get_reward_sum_gae.__func__ is agent.get_advantages.__func__
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_update_net_matches_reference_weights_and_objectives(name):
+    g = load(name)
+    agent, _ = make_agent(g)
+    agent.last_state = th.from_numpy(g["last_state"]).to(DEV)
+    buf = [th.from_numpy(g[k]).to(DEV) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
+    objs = agent.update_net(buf, ids=th.from_numpy(g["ids"]).to(DEV))
+    np.testing.assert_allclose(np.array(objs), g["objs"], rtol=5e-4, atol=5e-6)
+    for net, prefix in ((agent.act, "act1"), (agent.cri, "cri1")):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"{prefix}.{k}"], rtol=0, atol=3e-5, err_msg=f"{prefix}.{k}")
+    moved = np.abs(agent.act.net[0].weight.detach().cpu().numpy() - g["act0.net.0.weight"]).max()
+    assert moved > 1e-4
+
+
+def test_c4_iteration_against_oracle():
+    """BASELINE config 4 shapes (4096 envs, obs 64, act 8, H=32, B=16384): one rollout + 2 minibatches,
+    checked end to end against the fp64 oracle driven with the same noise and ids."""
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config
+    N, S, A, H, B = 4096, 64, 8, 32, 16384
+    args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 1000, "state_dim": S,
+                                        "action_dim": A, "if_discrete": False})
+    args.horizon_len, args.batch_size, args.repeat_times = H, B, 2 * B / H
+    args.learning_rate = 1e-3
+    th.manual_seed(0)
+    agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
+    env = SynVecEnv(N, S, A, max_step=5, gpu_id=0, seed=3)            # short episodes: truncations occur in H=32
+    agent.last_state = env.reset()[0]
+    first = agent.last_state.clone()
+    g = th.Generator(device=DEV).manual_seed(1)
+    noise = th.randn((H, N, A), device=DEV, generator=g)
+    items = agent._explore_vec_env(env, H, noise=noise)
+    states, actions, logprobs, rewards, undones, unmasks = [x.clone() for x in items]
+    assert (~unmasks).any() and th.equal(states[0], first)
+
+    def to_mlp(net, with_std):
+        ws = [net.net[i].weight.detach().cpu().numpy().astype(np.float64) for i in (0, 2, 4)]
+        bs = [net.net[i].bias.detach().cpu().numpy().astype(np.float64) for i in (0, 2, 4)]
+        return O.Mlp(ws, bs, net.state_avg.detach().cpu().numpy().astype(np.float64),
+                     net.state_std.detach().cpu().numpy().astype(np.float64),
+                     net.action_std_log.detach().cpu().numpy().reshape(-1).astype(np.float64) if with_std else None)
+
+    actor, critic = to_mlp(agent.act, True), to_mlp(agent.cri, False)
+    s_np = states.cpu().numpy().astype(np.float64)
+    for t in (0, H - 1):
+        a_ref, lp_ref = O.actor_sample(s_np[t], actor, noise[t].cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(actions[t].cpu().numpy(), a_ref, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(logprobs[t].cpu().numpy(), lp_ref, rtol=1e-4, atol=1e-4)
+
+    ids = th.randint(H * N, (2, B), device=DEV, generator=g)
+    objs = agent.update_net(list(items), ids=ids)
+    # oracle: same pipeline in fp64
+    v = O.critic_value(s_np, critic)
+    nv = O.critic_value(agent.last_state.cpu().numpy().astype(np.float64), critic)
+    adv, _, _ = O.gae_scan(rewards.cpu().numpy().astype(np.float64), undones.cpu().numpy(), unmasks.cpu().numpy(), v, nv,
+                           args.gamma, 0.95)
+    buf = (s_np, actions.cpu().numpy().astype(np.float64), unmasks.cpu().numpy(), logprobs.cpu().numpy().astype(np.float64),
+           O.adv_normalize(adv), O.reward_sums(adv, v))
+    sa, sc = O.AdamState(), O.AdamState()
+    ref = np.mean([O.ppo_minibatch_step(buf, i.cpu().numpy(), actor, critic, sa, sc, lr=args.learning_rate, max_norm=3.0,
+                                        ratio_clip=0.25, lambda_entropy=0.001) for i in ids], axis=0)
+    np.testing.assert_allclose(np.array(objs), ref, rtol=2e-4, atol=2e-6)
+    got_a = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in (agent.act.net[0].weight, agent.act.net[4].weight)])
+    ref_a = np.concatenate([actor.weights[0].reshape(-1), actor.weights[2].reshape(-1)])
+    np.testing.assert_allclose(got_a, ref_a, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(agent.cri.net[2].weight.detach().cpu().numpy(), critic.weights[1], rtol=0, atol=2e-5)
+
+
+def test_act_setter_rebinds_kernel_weights():
+    import copy
+    g = load(PPO_GOLDENS[0])
+    agent, _ = make_agent(g)
+    other = copy.deepcopy(agent.act).cpu()
+    with th.no_grad():
+        other.net[0].weight.add_(1.0)
+    agent.act = other                                   # what run.py:404-407 does with the learner's actor
+    assert agent.act.net[0].weight.is_cuda and agent._flat_a.is_bound(agent.act)
+    state = th.from_numpy(g["states"][0]).to(DEV)
+    a, lp = agent.explore_action(state, noise=th.zeros((state.shape[0], agent.action_dim), device=DEV))
+    ref = O.actor_mean(g["states"][0], O.Mlp([p.detach().cpu().numpy() for p in (other.net[0].weight, other.net[2].weight, other.net[4].weight)],
+                                             [p.detach().cpu().numpy() for p in (other.net[0].bias, other.net[2].bias, other.net[4].bias)],
+                                             other.state_avg.detach().cpu().numpy(), other.state_std.detach().cpu().numpy(),
+                                             other.action_std_log.detach().cpu().numpy().reshape(-1)))
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+
+
+def test_replay_buffer_class_matches_reference_golden():
+    from elegantrl_amd.train import ReplayBuffer
+    g = load("replay_ring.npz")
+    max_size, S, A, num_seqs = [int(x) for x in g["dims"]]
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=num_seqs)
+    for t in (buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks):
+        t.zero_()
+    for k in range(len(g["adds"])):
+        buf.update(tuple(th.from_numpy(g[f"in{k}_{n}"]).to(DEV) for n in ("states", "actions", "rewards", "undones", "unmasks")))
+        assert [buf.p, buf.cur_size, int(buf.if_full), buf.add_size] == list(g[f"cursor{k}"])
+        out = buf.sample(16, ids=th.from_numpy(g[f"ids{k}"]).to(DEV))
+        np.testing.assert_array_equal(buf.ids0.cpu().numpy(), g[f"ids0_{k}"])
+        np.testing.assert_array_equal(buf.ids1.cpu().numpy(), g[f"ids1_{k}"])
+        for t, n in zip(out, ("state", "action", "reward", "undone", "unmask", "next_state")):
+            np.testing.assert_array_equal(t.cpu().numpy(), g[f"out{k}_{n}"])
+    out = buf.sample(8)                                  # production path draws its own ids
+    assert out[0].shape == (8, S) and int(buf.ids0.max()) < buf.cur_size - 1
+
+
+def test_train_agent_pendulum_smoke(tmp_path):
+    from elegantrl_amd import train_agent
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.envs import PendulumVecEnv
+    from elegantrl_amd.train import Config
+    args = Config(AgentPPO, PendulumVecEnv, {"env_name": "Pendulum-v1", "num_envs": 256, "max_step": 200, "state_dim": 3,
+                                             "action_dim": 1, "if_discrete": False})
+    args.net_dims = [128, 64]
+    args.horizon_len, args.batch_size, args.repeat_times = 64, 1024, 64.0
+    args.gamma, args.reward_scale, args.learning_rate = 0.97, 2 ** -2, 4e-4
+    args.break_step, args.eval_per_step, args.eval_times = 64 * 6, 64 * 3, 4
+    args.cwd, args.gpu_id, args.random_seed = str(tmp_path / "run"), 0, 0
+    train_agent(args, if_single_process=True)
+    files = os.listdir(args.cwd)
+    assert "act.pth" in files and "cri.pth" in files and "recorder.npy" in files
+    rec = np.load(os.path.join(args.cwd, "recorder.npy"))
+    assert np.isfinite(rec).all() and rec.shape[1] >= 7
+    actor = th.load(os.path.join(args.cwd, "act.pth"), weights_only=False)
+    assert actor(th.zeros((2, 3), device=DEV)).shape == (2, 1)

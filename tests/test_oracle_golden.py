@@ -127,3 +127,50 @@ def test_c_oracle_cols_variant_equals_plain():
     np.testing.assert_array_equal(a2, adv)
     np.testing.assert_array_equal(t2, ret)
     np.testing.assert_array_equal(rr, r2)
+
+
+def _port_from_golden(g):
+    import torch as th
+    from oracle.torch_port import TorchPortPPO
+    hp, d = hyper(g), dims(g)
+    port = TorchPortPPO(d["S"], d["A"], (d["h1"], d["h2"]), lr=hp["lr"], gamma=hp["gamma"], lam=hp["lam"],
+                        ratio_clip=hp["ratio_clip"], lambda_entropy=hp["lambda_entropy"], max_norm=hp["max_norm"],
+                        reward_scale=hp["reward_scale"], use_v_trace=d["vtrace"])
+    for net, prefix in ((port.actor, "act0"), (port.critic, "cri0")):
+        net.load_state_dict({k[len(prefix) + 1:]: th.from_numpy(v) for k, v in g.items() if k.startswith(prefix + ".")})
+    port.last_state = th.from_numpy(g["last_state"])
+    return port
+
+
+@pytest.mark.parametrize("name", PPO_GOLDENS)
+def test_torch_port_update_matches_reference(name):
+    """the torch CPU port (bench.py's cpu_baseline) reproduces the reference's update_net on recorded ids."""
+    import torch as th
+    g = load(name)
+    d = dims(g)
+    port = _port_from_golden(g)
+    buf = [th.from_numpy(g[k]).clone() for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
+    objs = port.update(buf, d["B"], d["n_upd"], ids=th.from_numpy(g["ids"]))
+    np.testing.assert_allclose(np.array(objs), g["objs"], rtol=1e-5, atol=1e-7)
+    for net, prefix in ((port.actor, "act1"), (port.critic, "cri1")):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f"{prefix}.{k}"], rtol=0, atol=1e-6, err_msg=k)
+    np.testing.assert_array_equal(buf[4].numpy(), g["undones_after"])      # in-place side effect kept
+
+
+def test_torch_port_rollout_shapes_and_env_rules():
+    import torch as th
+    from oracle.torch_port import TorchPortPPO, TorchSynEnv
+    th.manual_seed(0)
+    env = TorchSynEnv(num_envs=64, state_dim=8, action_dim=2, max_step=5, seed=1)
+    port = TorchPortPPO(8, 2, (32, 32))
+    port.last_state = env.reset()
+    s, a, lp, r, ud, um = port.explore(env, 12)
+    assert s.shape == (12, 64, 8) and a.shape == (12, 64, 2) and lp.shape == r.shape == (12, 64)
+    assert ud.dtype == th.bool and um.dtype == th.bool and (~um).any()       # truncation every 5 steps
+    a_ref, lp_ref = O.actor_sample(s[3].numpy(), O.Mlp([port.actor.net[i].weight.detach().numpy() for i in (0, 2, 4)],
+                                                      [port.actor.net[i].bias.detach().numpy() for i in (0, 2, 4)],
+                                                      np.zeros(8, np.float32), np.ones(8, np.float32), np.zeros(2, np.float32)),
+                                   np.zeros((64, 2), np.float32))
+    mean = a_ref                                                             # eps = 0 -> action == mean
+    np.testing.assert_allclose(lp[3].numpy(), O.gaussian_logprob(a[3].numpy(), mean, np.zeros(2, np.float32)), rtol=1e-5, atol=1e-5)
