@@ -97,11 +97,42 @@ def gae_sweep(ops, dev):
     return out
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """cores this process may actually run on: affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports
+    the whole host and oversubscribing OpenMP threads onto a small quota makes torch-CPU orders of magnitude slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_subprocess(iters: int, timeout_s: int = 240):
+    """run the CPU leg in its own process (fresh OpenMP pool, hard timeout) and parse its JSON line."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-iters", str(iters)],
+                             capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "unit": "env-steps/s", "kind": "port", "error": (out.stderr or "no output")[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "env-steps/s", "kind": "port", "error": f"timed out after {timeout_s}s"}
+
+
 def cpu_baseline(iters=2):
     """oracle/torch_port.py on the host cores, same workload shape (bounded sample: 1 warm-up + `iters` iterations)."""
     from oracle.torch_port import TorchPortPPO, TorchSynEnv
     th.manual_seed(0)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     th.set_num_threads(cores)
     env = TorchSynEnv(N_ENVS, STATE_DIM, ACTION_DIM, 1000, seed=0)
     port = TorchPortPPO(STATE_DIM, ACTION_DIM, tuple(NET_DIMS))
@@ -130,7 +161,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gae-sweep", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     opt = ap.parse_args()
+    if opt.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(opt.cpu_iters)), flush=True)
+        return
 
     from elegantrl_amd import ops, parallel
     from elegantrl_amd.agents import AgentPPO
@@ -163,8 +198,10 @@ def main():
         items = agent.explore_env(env, HORIZON)
         return agent.update_net(list(items))
 
+    log(f"rank {rank}/{world}: agent + env ready, warm-up x{opt.warmup}")
     for _ in range(opt.warmup):
         step()
+    log("timed region")
     t_ppo.enabled = t_gae.enabled = True
     parallel.barrier()
     th.cuda.synchronize()
@@ -176,6 +213,7 @@ def main():
     elapsed = parallel.all_reduce_max_float(time.perf_counter() - t0, device=dev)
     t_ppo.enabled = t_gae.enabled = False
 
+    log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
     if rank != 0:
         return
     env_steps = world * N_ENVS * HORIZON * opt.steps
@@ -200,9 +238,12 @@ def main():
         "objectives_last": [round(float(x), 6) for x in objs],
     }
     if not opt.no_gae_sweep:
+        log("GAE size sweep")
         line["roofline_gae"]["sweep"] = gae_sweep(ops, dev)
     if world == 1 and not opt.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(opt.cpu_iters)
+        log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
+        line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters)
+    log("done")
     print(json.dumps(line), flush=True)
 
 
