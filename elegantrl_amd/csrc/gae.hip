@@ -376,6 +376,14 @@ inline int pick_chunk_len(int64_t H, int64_t N, int vec)
 
 }  // namespace
 
+// gae_lookback.hip
+bool erl_gae_lookback_usable(const float *rewards, const uint8_t *undones, const uint8_t *unmasks, const float *values,
+                             const float *next_value, const float *adv, const float *ret, int64_t N);
+int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
+                            const float *next_value, float *adv, float *ret, int64_t H, int64_t N, float gamma, float lam,
+                            bool vtrace, bool mutate, bool want_stats, void *workspace, int64_t workspace_bytes,
+                            double **partials, int *nparts, hipStream_t stream);
+
 extern "C" int64_t erl_gae_workspace_bytes(int64_t H, int64_t N)
 {
     if (H < 0 || N < 0) return 0;
@@ -395,14 +403,21 @@ extern "C" int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t 
     ERL_REQUIRE(!want_stats || stats, "erl_gae_scan_f32: ERL_GAE_STATS needs stats");
     ERL_REQUIRE(workspace && workspace_bytes >= erl_gae_workspace_bytes(H, N), "erl_gae_scan_f32: workspace too small");
     int algo = flags & ERL_GAE_ALGO_MASK;
-    if (algo == ERL_GAE_ALGO_AUTO) algo = (H * N <= (1LL << 20) || H < 16) ? ERL_GAE_ALGO_EXACT : ERL_GAE_ALGO_CHUNKED;
-    if (algo == ERL_GAE_ALGO_LOOKBACK) algo = ERL_GAE_ALGO_CHUNKED;  // single-pass variant: see gae_lookback.hip (later)
+    const bool lb_ok = H >= 4 && erl_gae_lookback_usable(rewards, undones, unmasks, values, next_value, adv, ret, N);
+    // AUTO: short horizons are launch-latency sized -> the bit-exact lane-per-env scan; otherwise the single-pass scan
+    if (algo == ERL_GAE_ALGO_AUTO)
+        algo = (H < 64) ? ERL_GAE_ALGO_EXACT : (lb_ok ? ERL_GAE_ALGO_LOOKBACK : ERL_GAE_ALGO_CHUNKED);
+    if (algo == ERL_GAE_ALGO_LOOKBACK && !lb_ok) algo = ERL_GAE_ALGO_CHUNKED;  // needs N % 4 == 0 and 16-byte aligned rows
 
     // workspace: [agg float2 K*N][partials double 3*nblk]
     char *ws = (char *)workspace;
     int nparts = 0;
     double *partials = nullptr;
-    if (algo == ERL_GAE_ALGO_EXACT) {
+    if (algo == ERL_GAE_ALGO_LOOKBACK) {
+        int rc = erl_gae_lookback_launch(rewards, undones, unmasks, values, next_value, adv, ret, H, N, gamma, lam, vtrace,
+                                         mutate, want_stats, workspace, workspace_bytes, &partials, &nparts, stream);
+        if (rc) return rc;
+    } else if (algo == ERL_GAE_ALGO_EXACT) {
         const int nblk = (int)erl_cdiv(N, 64);
         partials = (double *)ws;
         nparts = nblk;

@@ -1,0 +1,337 @@
+// K3, single-pass time-parallel variant ("LOOKBACK"): 18 B of HBM traffic per (t, n) element -- every input is
+// read exactly once, every output written once.  gfx950.
+//
+// Reference semantics: elegantrl/agents/AgentPPO.py:207-232 (get_advantages) + :146 (reward_sums); the
+// recurrence is the affine map  adv_t = delta_t + c_t * adv_{t+1}  documented in gae.hip.
+//
+// Decomposition.  A workgroup of W waves owns a slab of T = W * L time steps x 256 envs (lane = 4 consecutive
+// envs -> one 16-byte load per row and tensor, a wave reads 1 KiB row segments).  Wave w holds its L rows in
+// registers (the chunk never goes back to memory between the two local passes):
+//   pass 1   per wave: fold the L steps into the chunk's affine map (A, P); stash delta_t in place of r_t
+//   LDS      waves exchange their maps; wave w composes the maps of the waves later in time (< w)
+//   global   the slab's map is published as ONE 8-byte granule per env {A, P} (P in [0, 1]); the carry into the
+//            slab is obtained by walking the later slabs' granules (decoupled look-back): a granule is either
+//            not-ready (all-ones sentinel), an aggregate {A, P >= 0} or an inclusive value {adv, -1}
+//   pass 2   per wave: replay the L steps from registers with the true carry, write adv / ret (+ statistics)
+// Slabs are handed out through an atomic ticket in launch order, latest time first, so every slab a workgroup
+// waits for belongs to a workgroup that is already running (forward progress without co-residency).
+// Granules are written/read with 8-byte agent-scope atomics (sc1 write-through stores / L1-bypassing loads):
+// self-validating, so no fences are needed (MI355X_MICROARCH.md, handoff-1to1 / R2 granules).
+#include "erl_common.h"
+
+namespace {
+
+constexpr int LB_MAX_WAVES = 16;
+constexpr uint32_t LB_SENTINEL = 0xFFFFFFFFu;  // bit pattern of P for "not ready" (a NaN; real P is in [0, 1] or -1)
+
+struct LbArgs {
+    float *rewards;
+    uint8_t *undones;
+    const uint8_t *unmasks;
+    const float *values, *next_value;
+    float *adv, *ret;
+    int H, N, G, K;            // G env groups of 256, K time slabs of T steps
+    float gamma, lam;
+    int vtrace, mutate;
+    uint32_t *ticket;          // preset to 0xFFFFFFFF
+    unsigned long long *slots; // [K][N] granules, preset to all-ones
+    double *partials;          // [gridDim.x][3]
+};
+
+__device__ __forceinline__ unsigned long long pack_granule(float a, float p)
+{
+    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(p) << 32);
+}
+
+template <int L, bool STATS>
+__global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookback_kernel(LbArgs g)
+{
+    __shared__ float2 s_agg[LB_MAX_WAVES][256];
+    __shared__ float s_carry[256];
+    __shared__ double s_red[3][LB_MAX_WAVES];
+    __shared__ uint32_t s_ticket;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(g.ticket, 1u) + 1u;   // 0xFFFFFFFF + 1 wraps to ticket 0
+    __syncthreads();
+    const int ticket = (int)s_ticket;
+    const int kk = ticket / g.G, grp = ticket - kk * g.G;             // kk = 0 is the latest slab in time
+    const int T = W * L;
+    const int n0 = grp * 256 + lane * 4;
+    const bool live = n0 < g.N;
+    const int t_top = g.H - kk * T - w * L - 1;                       // this wave's latest step; steps t_top - j
+    const size_t N = (size_t)g.N;
+    const float gl = g.gamma * g.lam;
+
+    // ---- issue every load of the chunk up front (they do not depend on the recurrence)
+    float4 r[L], v[L];
+    uint32_t ud4[L], um4[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int t = t_top - j;
+        if (live && t >= 0) {
+            const size_t i = (size_t)t * N + n0;
+            r[j] = *reinterpret_cast<const float4 *>(g.rewards + i);
+            v[j] = *reinterpret_cast<const float4 *>(g.values + i);
+            ud4[j] = *reinterpret_cast<const uint32_t *>(g.undones + i);
+            um4[j] = *reinterpret_cast<const uint32_t *>(g.unmasks + i);
+        } else {
+            r[j] = v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ud4[j] = 0u;
+            um4[j] = 0x01010101u;
+        }
+    }
+    float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);                      // value following the chunk's latest step
+    if (live && t_top >= 0) {
+        if (t_top + 1 == g.H) { if (g.vtrace) vn = *reinterpret_cast<const float4 *>(g.next_value + n0); }
+        else vn = *reinterpret_cast<const float4 *>(g.values + (size_t)(t_top + 1) * N + n0);
+    }
+
+    // ---- pass 1: chunk -> affine map (A, P); r[j] <- delta, cmask bit <- "chain continues"
+    float A[4] = {0.f, 0.f, 0.f, 0.f}, P[4] = {1.f, 1.f, 1.f, 1.f};
+    float vnext[4] = {vn.x, vn.y, vn.z, vn.w};
+    uint32_t cmask[(L * 4 + 31) / 32];
+#pragma unroll
+    for (int q = 0; q < (L * 4 + 31) / 32; ++q) cmask[q] = 0u;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const float ro[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        float dl[4];
+        bool fix = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bool ud = ((ud4[j] >> (8 * e)) & 0xFFu) != 0u;
+            const bool um = ((um4[j] >> (8 * e)) & 0xFFu) != 0u;
+            float rr = ro[e];
+            if (!um) {  // truncated: bootstrap with V(s_t) and cut the chain (AgentPPO.py:211-214)
+                rr += vv[e];
+                ud = false;
+                fix = true;
+            }
+            const float m = ud ? g.gamma : 0.f, c = ud ? gl : 0.f;
+            dl[e] = (rr + m * vnext[e]) - vv[e];
+            A[e] = dl[e] + c * A[e];
+            P[e] = c * P[e];
+            vnext[e] = vv[e];
+            if (ud) cmask[(j * 4 + e) >> 5] |= 1u << ((j * 4 + e) & 31);
+        }
+        if (fix && g.mutate) {   // rare (truncations): write the fix-up back like the reference does to its caller
+            const size_t i = (size_t)(t_top - j) * N + n0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (((um4[j] >> (8 * e)) & 0xFFu) == 0u) {
+                    g.rewards[i + e] = ro[e] + vv[e];
+                    g.undones[i + e] = 0;
+                }
+        }
+        r[j] = make_float4(dl[0], dl[1], dl[2], dl[3]);   // pass 2 only needs delta
+    }
+
+    // ---- exchange the waves' maps through LDS
+    {
+        float4 *dst = reinterpret_cast<float4 *>(&s_agg[w][lane * 4]);
+        dst[0] = make_float4(A[0], P[0], A[1], P[1]);
+        dst[1] = make_float4(A[2], P[2], A[3], P[3]);
+    }
+    __syncthreads();
+    // map from the slab's incoming carry to this wave's incoming carry: compose waves 0 .. w-1 (latest first)
+    float cA[4] = {0.f, 0.f, 0.f, 0.f}, cP[4] = {1.f, 1.f, 1.f, 1.f};
+    for (int u = 0; u < w; ++u) {
+        const float4 *src = reinterpret_cast<const float4 *>(&s_agg[u][lane * 4]);
+        const float4 x = src[0], y = src[1];
+        const float a_[4] = {x.x, x.z, y.x, y.z}, p_[4] = {x.y, x.w, y.y, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cA[e] = a_[e] + p_[e] * cA[e];
+            cP[e] = p_[e] * cP[e];
+        }
+    }
+
+    // ---- the earliest wave owns the slab's total map: publish it, look back, publish the inclusive value
+    if (w == W - 1) {
+        float sA[4], sP[4], carry[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sA[e] = A[e] + P[e] * cA[e];
+            sP[e] = P[e] * cP[e];
+            carry[e] = 0.f;
+        }
+        unsigned long long *mine = g.slots + (size_t)kk * N + n0;
+        const bool has_reader = kk + 1 < g.K;
+        if (live && has_reader) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                __hip_atomic_store(mine + e, pack_granule(sA[e], sP[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (live && kk > 0) {
+            float accA[4] = {0.f, 0.f, 0.f, 0.f}, accP[4] = {1.f, 1.f, 1.f, 1.f};
+            uint32_t open = 0xFu;   // envs whose carry still depends on later slabs
+            for (int j = kk - 1; j >= 0 && open; --j) {
+                const unsigned long long *src = g.slots + (size_t)j * N + n0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!(open & (1u << e))) continue;
+                    unsigned long long gr;
+                    uint32_t spins = 0;
+                    do {
+                        gr = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)(gr >> 32) != LB_SENTINEL) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    } while (++spins < (1u << 22));   // bounded: a lost predecessor yields NaN outputs, not a hang
+                    const float ga = __uint_as_float((uint32_t)gr), gp = __uint_as_float((uint32_t)(gr >> 32));
+                    if (gp < 0.f) {                 // inclusive value of slab j: adv at its earliest step
+                        accA[e] += accP[e] * ga;
+                        open &= ~(1u << e);
+                    } else {                        // aggregate (NaN sentinel after a timeout poisons accA)
+                        accA[e] += accP[e] * ga;
+                        accP[e] *= gp;
+                        if (accP[e] == 0.f) open &= ~(1u << e);   // an episode boundary cuts the chain
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) carry[e] = accA[e];
+        }
+        if (live && has_reader) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                __hip_atomic_store(mine + e, pack_granule(sA[e] + sP[e] * carry[e], -1.f), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *reinterpret_cast<float4 *>(&s_carry[lane * 4]) = make_float4(carry[0], carry[1], carry[2], carry[3]);
+    }
+    __syncthreads();
+
+    // ---- pass 2: replay from registers with the true carry
+    float a[4];
+    {
+        const float4 c4 = *reinterpret_cast<const float4 *>(&s_carry[lane * 4]);
+        const float cin[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = cA[e] + cP[e] * cin[e];
+    }
+    double s_all = 0, s_sub = 0, q_sub = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int t = t_top - j;
+        const float dd[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool cont = (cmask[(j * 4 + e) >> 5] >> ((j * 4 + e) & 31)) & 1u;
+            a[e] = dd[e] + (cont ? gl : 0.f) * a[e];
+            o[e] = a[e];
+        }
+        if (live && t >= 0) {
+            const size_t i = (size_t)t * N + n0;
+            *reinterpret_cast<float4 *>(g.adv + i) = make_float4(o[0], o[1], o[2], o[3]);
+            if (g.ret)
+                *reinterpret_cast<float4 *>(g.ret + i) = make_float4(o[0] + vv[0], o[1] + vv[1], o[2] + vv[2], o[3] + vv[3]);
+            if (STATS) {
+                s_all += ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
+                if ((t & 3) == 0) {   // n0 is a multiple of 4: env n0 is the only [::4] column of this lane
+                    s_sub += o[0];
+                    q_sub += (double)o[0] * o[0];
+                }
+            }
+        }
+    }
+    if (STATS) {
+        const double w0 = wave_sum(s_all), w1 = wave_sum(s_sub), w2 = wave_sum(q_sub);
+        if (lane == 0) {
+            s_red[0][w] = w0;
+            s_red[1][w] = w1;
+            s_red[2][w] = w2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double s = 0;
+            for (int u = 0; u < W; ++u) s += s_red[threadIdx.x][u];
+            g.partials[(size_t)blockIdx.x * 3 + threadIdx.x] = s;
+        }
+    }
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+// Shape heuristics (overridable for sweeps with ERL_GAE_LB_L in {2,4,8,16} and ERL_GAE_LB_W in 1..16).
+void erl_gae_lookback_pick(int64_t H, int64_t N, int *L, int *W)
+{
+    (void)N;
+    int l, w;
+    // measured on MI355X (tools/gae_sweep.py, profiles/gae_sweep_r01.json): slabs of 128 steps once H is large,
+    // short slabs (more workgroups) for short horizons
+    if (H >= 4096) { l = 16; w = 8; }
+    else if (H >= 512) { l = 8; w = 16; }
+    else if (H >= 64) { l = 4; w = 8; }
+    else { l = 4; w = 2; }
+    l = env_int("ERL_GAE_LB_L", l);
+    w = env_int("ERL_GAE_LB_W", w);
+    if (l != 2 && l != 4 && l != 8 && l != 16) l = 8;
+    if (w < 1) w = 1;
+    if (w > LB_MAX_WAVES) w = LB_MAX_WAVES;
+    if (l >= 16 && w > 8) w = 8;   // the L = 16 instantiation is compiled for <= 512 threads (256 VGPRs)
+    *L = l;
+    *W = w;
+}
+
+bool erl_gae_lookback_usable(const float *rewards, const uint8_t *undones, const uint8_t *unmasks, const float *values,
+                             const float *next_value, const float *adv, const float *ret, int64_t N)
+{
+    const uintptr_t f = reinterpret_cast<uintptr_t>(rewards) | reinterpret_cast<uintptr_t>(values) |
+                        reinterpret_cast<uintptr_t>(next_value) | reinterpret_cast<uintptr_t>(adv) | reinterpret_cast<uintptr_t>(ret);
+    const uintptr_t b = reinterpret_cast<uintptr_t>(undones) | reinterpret_cast<uintptr_t>(unmasks);
+    return (N % 4 == 0) && (f % 16 == 0) && (b % 4 == 0);
+}
+
+// Enqueues memset + kernel.  workspace layout: [ticket: 256 B][slots: K*N*8 B][partials: nblk*24 B].
+// Returns the number of statistics partials (blocks) through *nparts and their location through *partials.
+int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
+                            const float *next_value, float *adv, float *ret, int64_t H, int64_t N, float gamma, float lam,
+                            bool vtrace, bool mutate, bool want_stats, void *workspace, int64_t workspace_bytes,
+                            double **partials, int *nparts, hipStream_t stream)
+{
+    int L, W;
+    erl_gae_lookback_pick(H, N, &L, &W);
+    const int64_t T = (int64_t)L * W;
+    const int64_t K = erl_cdiv(H, T), G = erl_cdiv(N, 256);
+    ERL_REQUIRE(K * G < (1LL << 30), "erl_gae_scan_f32: lookback grid too large");
+    const size_t slot_bytes = ((size_t)K * N * 8 + 255) & ~(size_t)255;
+    const size_t need = 256 + slot_bytes + (size_t)(K * G) * 24;
+    ERL_REQUIRE((int64_t)need <= workspace_bytes, "erl_gae_scan_f32: workspace too small for the lookback scan");
+    char *ws = (char *)workspace;
+    LbArgs g;
+    g.rewards = rewards; g.undones = undones; g.unmasks = unmasks; g.values = values; g.next_value = next_value;
+    g.adv = adv; g.ret = ret;
+    g.H = (int)H; g.N = (int)N; g.G = (int)G; g.K = (int)K;
+    g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
+    g.ticket = (uint32_t *)ws;
+    g.slots = (unsigned long long *)(ws + 256);
+    g.partials = (double *)(ws + 256 + slot_bytes);
+    *partials = g.partials;
+    *nparts = (int)(K * G);
+    int rc = erl_hip_status(hipMemsetAsync(ws, 0xFF, 256 + (K > 1 ? slot_bytes : 0), stream), "hipMemsetAsync(lookback slots)");
+    if (rc) return rc;
+    const dim3 grid((unsigned)(K * G)), block(W * 64);
+#define LB_LAUNCH(LL)                                                                                  \
+    do {                                                                                               \
+        if (want_stats) hipLaunchKernelGGL((gae_lookback_kernel<LL, true>), grid, block, 0, stream, g); \
+        else hipLaunchKernelGGL((gae_lookback_kernel<LL, false>), grid, block, 0, stream, g);           \
+    } while (0)
+    switch (L) {
+        case 2: LB_LAUNCH(2); break;
+        case 4: LB_LAUNCH(4); break;
+        case 8: LB_LAUNCH(8); break;
+        default: LB_LAUNCH(16); break;
+    }
+#undef LB_LAUNCH
+    return erl_hip_status(hipGetLastError(), "gae_lookback_kernel launch");
+}

@@ -98,6 +98,45 @@ def test_gae_chunked_within_1e5(ops, dev, H, N, vtrace):
     np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("H,N", [(256, 1000), (513, 260), (128, 4096), (1024, 512), (40, 76), (9, 64), (4, 4), (2048, 256)])
+@pytest.mark.parametrize("vtrace", [True, False])
+def test_gae_lookback_within_1e5(ops, dev, H, N, vtrace):
+    """single-pass decoupled look-back scan (N % 4 == 0): same bar as the chunked scan, plus the in-place
+    truncation fix-up of rewards / undones."""
+    r, u, m, v, nv = gae_inputs(H, N, seed=H + N)
+    adv_o, ret_o, r_o, u_o = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=vtrace)
+    tr, tu = cu(r, dev), cu(u, dev)
+    adv, ret = ops.gae_scan(tr, tu, cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, use_v_trace=vtrace, algo="lookback")
+    rel_close(adv.cpu().numpy(), adv_o, 1e-5)
+    rel_close(ret.cpu().numpy(), ret_o, 1e-5)
+    np.testing.assert_array_equal(tu.cpu().numpy(), u_o)
+    np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("L,W", [(2, 1), (4, 3), (8, 16), (16, 8), (4, 16)])
+def test_gae_lookback_every_tiling(ops, dev, L, W, monkeypatch):
+    """every (steps per lane, waves per workgroup) instantiation, long undone chains (no episode ends) so that the
+    carry really crosses every slab boundary; repeated to catch ordering races in the look-back."""
+    monkeypatch.setenv("ERL_GAE_LB_L", str(L))
+    monkeypatch.setenv("ERL_GAE_LB_W", str(W))
+    H, N = 777, 1028
+    r, u, m, v, nv = gae_inputs(H, N, seed=L * 100 + W, p_done=0.0005, p_trunc=0.0005)
+    adv_o, ret_o, _, _ = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=True)
+    tm, tv, tnv = cu(m, dev), cu(v, dev), cu(nv, dev)
+    for _ in range(5):
+        adv, ret = ops.gae_scan(cu(r, dev), cu(u, dev), tm, tv, tnv, 0.99, 0.95, algo="lookback")
+        rel_close(adv.cpu().numpy(), adv_o, 1e-5)
+        rel_close(ret.cpu().numpy(), ret_o, 1e-5)
+
+
+def test_gae_lookback_misaligned_falls_back(ops, dev):
+    """N % 4 != 0 cannot use 16-byte rows: the entry point silently uses the chunked scan (same tolerance)."""
+    r, u, m, v, nv = gae_inputs(64, 77, seed=3)
+    adv_o, _, _, _ = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=True)
+    adv, _ = ops.gae_scan(cu(r, dev), cu(u, dev), cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, algo="lookback")
+    rel_close(adv.cpu().numpy(), adv_o, 1e-5)
+
+
 def test_gae_full_size_property_linearity(ops, dev):
     """BASELINE size (2048 x 4096, 151 MB): with no terminal/truncation GAE is linear in (r, v, next_v);
     check adv(x + y) == adv(x) + adv(y) and agreement of the exact and chunked algorithms."""
@@ -116,6 +155,10 @@ def test_gae_full_size_property_linearity(ops, dev):
     e1 = run(r1, v1, n1, "exact")
     err = ((a1 - e1).abs() / e1.abs().clamp_min(1.0)).max().item()
     assert err <= 1e-5, err
+    l1, l12 = run(r1, v1, n1, "lookback"), run(r1 + r2, v1 + v2, n1 + n2, "lookback")
+    err = ((l1 - e1).abs() / e1.abs().clamp_min(1.0)).max().item()
+    assert err <= 1e-5, err
+    assert (l12 - (l1 + run(r2, v2, n2, "lookback"))).abs().max().item() < 2e-4
 
 
 @pytest.mark.parametrize("name", PPO_GOLDENS)
@@ -131,7 +174,7 @@ def test_gae_on_reference_golden(ops, dev, name):
 
 
 @pytest.mark.parametrize("H,N", [(32, 4096), (12, 8), (33, 130), (200, 1024)])
-@pytest.mark.parametrize("algo", ["exact", "chunked"])
+@pytest.mark.parametrize("algo", ["exact", "chunked", "lookback"])
 def test_adv_stats_and_normalize(ops, dev, H, N, algo):
     r, u, m, v, nv = gae_inputs(H, N, seed=5)
     stats = th.zeros(8, dtype=th.float64, device=dev)
