@@ -11,7 +11,7 @@ fwd/bwd, gradient reduce, [RCCL all-reduce when N > 1], clip + Adam).  Inputs ar
 one per GPU (weak scaling).  Rank 0 prints ONE JSON line.
 
 Besides the throughput the line carries
-  roofline      dominant kernel of the timed region (ppo_step_kernel, fp32 MFMA bound), timed with HIP events
+  roofline      dominant kernel of the timed region (ppo_step2_kernel, fp32 MFMA bound), timed with HIP events
                 around every launch inside the timed region
   roofline_gae  the GAE scan (HBM bound; the metric's second half): in-loop launches + a size sweep run after
                 the timed region (the in-loop 32 x 4096 problem is 2.4 MB, i.e. launch-latency sized)
@@ -227,7 +227,7 @@ def main():
                                "horizon 32, 40 minibatches x 16384, net [128,128], fp32",
                    "envs_per_gpu": N_ENVS, "horizon": HORIZON, "batch": BATCH, "update_times": UPDATE_TIMES,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
-        "roofline": {"kernel": "ppo_step_kernel", "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
+        "roofline": {"kernel": "ppo_step2_kernel", "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": None, "flops_per_launch": flops, "avg_launch_us": round(ppo_s * 1e6, 2),
                      "launches_timed": len(t_ppo.pairs)},

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liberl_hip.so")
 GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P = c_void_p
 _SIGNATURES = {
@@ -43,6 +43,7 @@ _SIGNATURES = {
     "erl_rollout_step_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_uint64, c_uint64,
                                      _P, _P, _P, _P, _P]),
     "erl_ppo_slab_stride": (c_int64, [c_int, c_int, c_int, c_int]),
+    "erl_ppo_num_slabs": (c_int, [c_int64]),
     "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, _P, c_int, _P]),
     "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),

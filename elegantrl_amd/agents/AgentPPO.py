@@ -314,12 +314,8 @@ class AgentPPO(AgentBase):
         return obj_critic, obj_actor, obj_entropy
 
     def _n_slabs(self, batch_size: int) -> int:
-        tiles = (batch_size + 63) // 64
-        try:
-            cus = _hip.device_info()[0]
-        except Exception:
-            cus = 256
-        return max(1, min(tiles, cus // 2))
+        from .. import ops
+        return ops.ppo_num_slabs(batch_size)
 
     # ---- running state normalisation: AgentPPO.py:234-249 (never called by the reference's loops) -----
     def update_avg_std_for_normalization(self, states: TEN):

@@ -1,4 +1,4 @@
-// K2 value pre-pass, K1 rollout step, K6 fused PPO minibatch forward+backward.  gfx950 / fp32 MFMA.
+// K2 value pre-pass, K1 rollout step, slab reduction of K6 (the PPO minibatch kernel itself: ppo_step.hip).  gfx950 / fp32 MFMA.
 // Building blocks and the LDS/MFMA formulation are documented in mlp_tiles.h.
 #include "mlp_tiles.h"
 
@@ -114,214 +114,6 @@ __global__ __launch_bounds__(NW * 64) void rollout_step_kernel(const float *__re
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K6: PPO minibatch.  grid = (n_slabs, 2): blockIdx.y = 0 actor, 1 critic.  M = 64 rows per tile,
-// 8 waves.  LDS: R0 [max(Sc,h2)][LD] (XT, then H2T, then XT again) | H1T | G1T | G2T | YT[16] | TMP[16]
-// | rowdata[6][M].  Weight-gradient accumulators stay in registers across the block's row tiles.
-// ---------------------------------------------------------------------------------------------
-constexpr int PPO_M = 64, PPO_NW = 8, PPO_LD = PPO_M + 1;
-
-__host__ __device__ inline size_t ppo_lds_floats(const MlpDims &d)
-{
-    const int r0 = d.Sc() > d.h2 ? d.Sc() : d.h2;
-    return (size_t)(r0 + 2 * d.h1 + d.h2 + 32) * PPO_LD + 6 * PPO_M;
-}
-
-struct PpoArgs {
-    const float *P[2];    // actor, critic flat params
-    const float *avg[2];
-    const float *sd[2];
-    const float *states, *actions, *logprobs, *advantages, *reward_sums;
-    const uint8_t *unmasks;
-    const int64_t *ids;
-    int64_t H, N, B;
-    int S, h1, h2, A;
-    float ratio_clip, lambda_entropy, inv_batch;
-    float *slabs;
-    int64_t stride, Pa, Pc;
-};
-
-__global__ __launch_bounds__(PPO_NW * 64) void ppo_step_kernel(PpoArgs g)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int M = PPO_M, NW = PPO_NW, LD = PPO_LD;
-    const int net = blockIdx.y;  // 0 actor, 1 critic
-    const bool is_actor = net == 0;
-    MlpDims d{g.S, g.h1, g.h2, is_actor ? g.A : 1};
-    const float *P = g.P[net];
-    const int Sc = d.Sc(), r0rows = Sc > d.h2 ? Sc : d.h2;
-    float *R0 = smem, *H1T = R0 + r0rows * LD, *G1T = H1T + d.h1 * LD, *G2T = G1T + d.h1 * LD, *YT = G2T + d.h2 * LD,
-          *TMP = YT + 16 * LD, *rowd = TMP + 16 * LD;
-    float *r_um = rowd, *r_a = rowd + M, *r_b = rowd + 2 * M;  // um | (ret) or (logp_old, adv)
-    int64_t *r_row = reinterpret_cast<int64_t *>(rowd + 4 * M);  // 8-byte aligned: (.. + 32)*65 + 4*64 floats is even
-
-    const int tid = threadIdx.x;
-    const int A = d.out;
-    const float *std_log = P + d.oStd();
-
-    f32x16 accW2[2], accW1[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        accW2[j] = f32x16{0};
-        accW1[j] = f32x16{0};
-    }
-    float accW3[4] = {0.f, 0.f, 0.f, 0.f};   // dW3[a][i] for e = tid + j*512 over out*h2 (<= 16*128)
-    float acc_db1 = 0.f, acc_db2 = 0.f, acc_db3 = 0.f, acc_dsl = 0.f;
-    float loss0 = 0.f, loss1 = 0.f;           // critic: sum diff^2 um | actor: sum surr um, sum um
-
-    const int64_t ntiles = (g.B + M - 1) / M;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t b0 = tile * M;
-        const int valid = (int)min((int64_t)M, g.B - b0);
-        // ---- row bookkeeping: id -> (t = id % H, n = id // H) -> state row t*N + n   (AgentPPO.py:179-187)
-        if (tid < M) {
-            float um = 0.f, xa = 0.f, xb = 0.f;
-            int64_t row = 0;
-            if (tid < valid) {
-                const int64_t id = g.ids[b0 + tid];
-                const int64_t n = id / g.H, t = id - n * g.H;
-                row = t * g.N + n;
-                um = g.unmasks[row] ? 1.f : 0.f;
-                if (is_actor) {
-                    xa = g.logprobs[row];
-                    xb = g.advantages[row];
-                } else {
-                    xa = g.reward_sums[row];
-                }
-            }
-            r_um[tid] = um;
-            r_a[tid] = xa;
-            r_b[tid] = xb;
-            r_row[tid] = row;
-        }
-        __syncthreads();
-        gather_states<M>(R0, Sc, d.S, g.states, g.avg[net], g.sd[net], valid, [&](int m) { return r_row[m]; }, nullptr, 0);
-        __syncthreads();
-        layer_forward<M, NW, true, true, 8>(P + d.oW1(), P + d.ob1(), d.h1, d.S, R0, H1T, G1T);
-        __syncthreads();
-        float *H2T = R0;  // XT is dead until the dW1 step
-        layer_forward<M, NW, true, true, 8>(P + d.oW2(), P + d.ob2(), d.h2, d.h1, H1T, H2T, G2T);
-        __syncthreads();
-        output_layer<M>(P + d.oW3(), P + d.ob3(), A, d.h2, H2T, YT);
-        __syncthreads();
-        // ---- objective and dL/dY (one thread per row), AgentPPO.py:189-204
-        if (tid < M) {
-            const int m = tid;
-            const float um = r_um[m];
-            if (!is_actor) {
-                const float diff = YT[m] - r_a[m];
-                loss0 += diff * diff * um;
-                YT[m] = 2.f * diff * um * g.inv_batch;  // d mean((v-ret)^2 um) / dv
-            } else {
-                const int64_t row = r_row[m];
-                float lp = 0.f;
-                for (int a = 0; a < A; ++a) {
-                    const float sdv = expf(std_log[a]), var = sdv * sdv;
-                    const float act = (m < valid) ? g.actions[row * A + a] : 0.f;
-                    const float diff = act - YT[a * LD + m];
-                    lp += -(diff * diff) / (2.f * var) - logf(sdv) - kLogSqrt2Pi;
-                    TMP[a * LD + m] = diff;
-                }
-                const float adv = r_b[m];
-                const float ratio = expf(lp - r_a[m]);
-                const float w = adv > 0.f ? 1.f - g.ratio_clip : 1.f + g.ratio_clip;
-                const float surr = adv * ratio * w;     // reference-form "clip" (:199)
-                loss0 += surr * um;
-                loss1 += um;
-                const float dlp = -(surr * um) * g.inv_batch;  // d(-mean(surr um))/dlogp_new
-                const float ent_term = g.lambda_entropy * um * g.inv_batch;
-                for (int a = 0; a < A; ++a) {
-                    const float sdv = expf(std_log[a]), var = sdv * sdv;
-                    const float diff = TMP[a * LD + m];
-                    YT[a * LD + m] = dlp * (diff / var);                          // dL/dmean
-                    TMP[a * LD + m] = dlp * (diff * diff / var - 1.f) + ent_term;  // dL/dstd_log, per row
-                }
-            }
-        }
-        __syncthreads();
-        // ---- output layer backward (vector ALU): dW3, db3, dstd_log, dZ2T = (W3^T dY) * GELU'(z2)
-        {
-            const float *W3 = P + d.oW3();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = tid + j * (NW * 64);
-                if (e < A * d.h2) {
-                    const int a = e / d.h2, i = e - a * d.h2;
-                    float s = 0.f;
-                    for (int m = 0; m < M; ++m) s = fmaf(YT[a * LD + m], H2T[i * LD + m], s);
-                    accW3[j] += s;
-                }
-            }
-            if (tid < A) {
-                float s = 0.f, q = 0.f;
-                for (int m = 0; m < M; ++m) {
-                    s += YT[tid * LD + m];
-                    if (is_actor) q += TMP[tid * LD + m];
-                }
-                acc_db3 += s;
-                acc_dsl += q;
-            }
-            for (int e = tid; e < d.h2 * M; e += NW * 64) {
-                const int i = e / M, m = e - i * M;
-                float s = 0.f;
-                for (int a = 0; a < A; ++a) s = fmaf(W3[a * d.h2 + i], YT[a * LD + m], s);
-                G2T[i * LD + m] *= s;
-            }
-        }
-        __syncthreads();
-        // ---- layer 2 backward: dW2 += dZ2 H1^T, db2, dZ1T = (W2^T dZ2) * GELU'(z1); then XT is re-gathered
-        weight_grad_accumulate<M, NW, 2>(accW2, d.h2, d.h1, G2T, H1T);
-        if (tid < d.h2) {
-            float s = 0.f;
-            for (int m = 0; m < M; ++m) s += G2T[tid * LD + m];
-            acc_db2 += s;
-        }
-        layer_backward_input<M, NW, 8>(P + d.oW2(), d.h2, d.h1, G2T, G1T);
-        gather_states<M>(R0, Sc, d.S, g.states, g.avg[net], g.sd[net], valid, [&](int m) { return r_row[m]; }, nullptr, 0);
-        __syncthreads();
-        // ---- layer 1 backward: dW1 += dZ1 X^T, db1
-        weight_grad_accumulate<M, NW, 2>(accW1, d.h1, Sc, G1T, R0);
-        if (tid < d.h1) {
-            float s = 0.f;
-            for (int m = 0; m < M; ++m) s += G1T[tid * LD + m];
-            acc_db1 += s;
-        }
-        __syncthreads();
-    }
-
-    // ---- write this block's partial gradient slab
-    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (is_actor ? 0 : g.Pa);
-    store_weight_grad<NW, 2>(accW1, d.h1, Sc, d.S, slab + d.oW1());
-    store_weight_grad<NW, 2>(accW2, d.h2, d.h1, d.h1, slab + d.oW2());
-    if (tid < d.h1) slab[d.ob1() + tid] = acc_db1;
-    if (tid < d.h2) slab[d.ob2() + tid] = acc_db2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = tid + j * (NW * 64);
-        if (e < A * d.h2) slab[d.oW3() + e] = accW3[j];
-    }
-    if (tid < A) {
-        slab[d.ob3() + tid] = acc_db3;
-        if (is_actor) slab[d.oStd() + tid] = acc_dsl;
-    }
-    // objective partial sums (already scaled by 1/B so that the slab reduction yields the means)
-    __shared__ float red[NW];
-    const float t0 = block_sum(loss0, red);
-    const float t1 = block_sum(loss1, red);
-    if (tid == 0) {
-        float *logs = g.slabs + (size_t)blockIdx.x * g.stride + g.Pa + g.Pc;
-        if (is_actor) {
-            float ent = 0.f;
-            for (int a = 0; a < A; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));  // 0.5 + 0.5 log(2 pi) + log(std)
-            logs[1] = t0 * g.inv_batch;
-            logs[2] = ent * t1 * g.inv_batch;
-        } else {
-            logs[0] = t0 * g.inv_batch;
-            logs[3] = 0.f;
-        }
-    }
-}
-
 // sum the per-block slabs into the flat gradient (deterministic order)
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int64_t stride,
                                                           float *__restrict__ flat)
@@ -382,12 +174,6 @@ extern "C" int64_t erl_mlp_param_count(int S, int h1, int h2, int out, int with_
     return MlpDims{S, h1, h2, out}.count(with_std_log != 0);
 }
 
-extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
-{
-    if (!dims_ok(S, h1, h2, A)) return -1;
-    return MlpDims{S, h1, h2, A}.count(true) + MlpDims{S, h1, h2, 1}.count(false) + 4;
-}
-
 extern "C" int erl_value_forward_f32(const float *critic_params, const float *state_avg, const float *state_std, int S, int h1,
                                      int h2, const float *states, int64_t rows, float *values, void *stream)
 {
@@ -426,39 +212,6 @@ extern "C" int erl_rollout_step_f32(const float *actor_params, const float *stat
                        state_std, d, state, N, noise, seed, counter, out_state_row, out_action_row, out_logprob_row,
                        out_action_env);
     ERL_LAUNCH_CHECK("erl_rollout_step_f32");
-}
-
-extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
-                                const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
-                                const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
-                                const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
-                                float lambda_entropy, float inv_batch, float *slabs, int n_slabs, void *stream)
-{
-    ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions && unmasks &&
-                    logprobs && advantages && reward_sums && ids && slabs,
-                "erl_ppo_step_f32: NULL tensor");
-    ERL_REQUIRE(dims_ok(S, h1, h2, A), "erl_ppo_step_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
-    ERL_REQUIRE(H >= 1 && N >= 1 && B >= 1 && n_slabs >= 1, "erl_ppo_step_f32: bad shape");
-    ERL_REQUIRE(n_slabs <= erl_cdiv(B, PPO_M), "erl_ppo_step_f32: n_slabs=%d exceeds the %lld row tiles", n_slabs,
-                (long long)erl_cdiv(B, PPO_M));
-    PpoArgs g;
-    g.P[0] = actor_params; g.P[1] = critic_params;
-    g.avg[0] = act_avg; g.avg[1] = cri_avg;
-    g.sd[0] = act_std; g.sd[1] = cri_std;
-    g.states = states; g.actions = actions; g.logprobs = logprobs; g.advantages = advantages; g.reward_sums = reward_sums;
-    g.unmasks = unmasks; g.ids = ids;
-    g.H = H; g.N = N; g.B = B;
-    g.S = S; g.h1 = h1; g.h2 = h2; g.A = A;
-    g.ratio_clip = ratio_clip; g.lambda_entropy = lambda_entropy; g.inv_batch = inv_batch;
-    g.slabs = slabs;
-    g.Pa = MlpDims{S, h1, h2, A}.count(true);
-    g.Pc = MlpDims{S, h1, h2, 1}.count(false);
-    g.stride = g.Pa + g.Pc + 4;
-    const size_t lds = ppo_lds_floats(MlpDims{S, h1, h2, A}) * sizeof(float);
-    int rc = set_lds(ppo_step_kernel, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(ppo_step_kernel, dim3(n_slabs, 2), dim3(PPO_NW * 64), lds, (hipStream_t)stream, g);
-    ERL_LAUNCH_CHECK("erl_ppo_step_f32");
 }
 
 extern "C" int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, void *stream)

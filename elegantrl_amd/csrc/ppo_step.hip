@@ -1,0 +1,692 @@
+// K6: one PPO minibatch (gather + actor & critic forward + objective + full backward), gfx950 fp32 MFMA.
+//
+// Replaces AgentPPO.update_objectives up to the optimizer steps (elegantrl/agents/AgentPPO.py:173-204) and
+// ActorPPO.get_logprob_entropy (:378-386).  grid = (ceil(B / 128), 2): blockIdx.y = 0 actor, 1 critic; a workgroup
+// of 8 waves owns 128 samples and writes ONE gradient slab (no accumulation across workgroups here; the slabs are
+// summed in a fixed order by erl_grad_reduce_f32 -> deterministic).
+//
+// Register-chained transposed formulation.  Wave w owns 16 samples; every layer is computed transposed,
+//     outT (feat x 16 samples) = W (feat x K) . inT (K x 16 samples),
+// on v_mfma_f32_16x16x4_f32 (exact fp32): A = 16 weight rows x 4 k, B = 4 k x 16 samples, and the result tile
+// leaves lane (m = lane & 15, q = lane >> 4) holding features 16 t + 4 q + r (r = 0..3) of sample m.  The K loop of
+// the NEXT layer is ordered so that step (t, r) consumes k = 16 t + 4 q + r from lane group q: that is exactly
+// the register the lane already holds, so activations never leave the register file between layers (no LDS
+// round trip, no barrier), and the matching A operand is one 16-byte read W[row][16 t + 4 q .. + 3] per 4 MFMAs.
+// The same holds for the backward-input chain (dZ2 -> dZ1) with W3^T / W2^T as A operands.  All three weight
+// matrices and the biases are copied into LDS once per workgroup (zero padded to the tile grid; row stride
+// 4 * odd floats: conflict-free ds_read_b128 along k for the forward pass, conflict-free ds_read_b32 along the
+// transposed direction for the backward pass), so the compute phases never wait on L2 / HBM latency.
+//
+// Weight gradients need the sample dimension as the MFMA K dimension, i.e. the transpose of what the lanes hold:
+// the 8 waves stage their tiles feature-major in LDS (T[feature][sample], LD = 129: conflict-free ds_read_b32 along
+// features, 2-way (free) ds_write_b32) and split the dW output tiles (v_mfma_f32_32x32x2_f32, K = 128 samples).
+// Seven workgroup barriers (LDS-only, no vector-memory drain) in total; all control flow in the hot instantiations is compile-time (tile counts are
+// template parameters, out-of-range loads are clamped + selected instead of branched).
+#include "mlp_tiles.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int PB = 128;        // samples per workgroup
+constexpr int PLD = PB + 1;    // leading dimension of the staged feature-major tiles
+constexpr int PNW = 8;
+#ifndef PCH
+#define PCH 2          // k-tiles (of 16) per software-pipelined weight chunk: 2 x PCH x 4 VGPRs of operand buffer
+#endif
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+
+struct Dims {
+    int S, h1, h2, out;
+    __host__ __device__ int64_t oW1() const { return 0; }
+    __host__ __device__ int64_t ob1() const { return (int64_t)h1 * S; }
+    __host__ __device__ int64_t oW2() const { return ob1() + h1; }
+    __host__ __device__ int64_t ob2() const { return oW2() + (int64_t)h2 * h1; }
+    __host__ __device__ int64_t oW3() const { return ob2() + h2; }
+    __host__ __device__ int64_t ob3() const { return oW3() + (int64_t)out * h2; }
+    __host__ __device__ int64_t oStd() const { return ob3() + out; }
+    __host__ __device__ int64_t count(bool with_std) const { return oStd() + (with_std ? out : 0); }
+};
+
+struct Ppo2Args {
+    const float *P[2];    // actor, critic flat params
+    const float *avg[2];
+    const float *sd[2];
+    const float *states, *actions, *logprobs, *advantages, *reward_sums;
+    const uint8_t *unmasks;
+    const int64_t *ids;
+    int64_t H, N, B;
+    int S, h1, h2, A;
+    float ratio_clip, lambda_entropy, inv_batch;
+    float *slabs;
+    int64_t stride, Pa, Pc;
+    long long *prof;      // ERL_PROFILE builds only: [net][wave][32] s_memtime stamps of workgroup 0
+};
+
+#ifdef ERL_PROFILE
+#define PROF(i)                                                                                   \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if (g.prof && blockIdx.x == 0 && lane == 0) g.prof[(net * PNW + wave) * 32 + (i)] = (long long)t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define PROF(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the vector-memory
+// counter, so in-flight global loads (prefetches) and the gradient-slab stores keep streaming across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// exact-erf GELU and its derivative.  erf through Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, the size of an fp32
+// ulp of the result), sharing exp(-z^2/2) with the Gaussian density of the derivative: ~20 VALU ops instead of ~70.
+__device__ __forceinline__ void gelu_and_grad_fast(float z, float &y, float &gd)
+{
+    const float x = fabsf(z) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    const float u = __expf(-(x * x));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    p *= t;
+    const float erfa = fmaf(-p, u, 1.0f);
+    const float cdf = 0.5f * (1.0f + copysignf(erfa, z));
+    y = z * cdf;
+    gd = fmaf(z * u, 0.39894228040143267794f, cdf);
+}
+
+// 4 consecutive floats row[k0 .. k0+3] of a row of length K, zeros beyond K.  Branch-free: the address is clamped
+// into the row and the result selected, so the loads can be hoisted and pipelined freely.
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float *__restrict__ row, int k0, int K)
+{
+    if (VEC) {   // K % 4 == 0 and 16-byte aligned rows: a 4-group is either fully inside or fully outside
+        const int kc = min(k0, K - 4);
+        const float4 v = *reinterpret_cast<const float4 *>(row + kc);
+        return k0 < K ? v : zero4();
+    }
+    float x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float v = row[min(k0 + c, K - 1)];
+        x[c] = (k0 + c < K) ? v : 0.f;
+    }
+    return make_float4(x[0], x[1], x[2], x[3]);
+}
+
+// row stride of an LDS weight copy with `cols` columns: the smallest 4 * odd >= cols + 1 (see the file header)
+__host__ __device__ constexpr int lds_ld(int cols) { return 4 * (2 * ((cols + 7) / 8) + 1); }
+
+// cooperative copy of a row-major [rows][cols] matrix into LDS [rows_pad][ld], zero padded, in two halves so that
+// the global round trip overlaps other work: copy_load issues up to MAXV float4 loads per thread (rows_pad *
+// cols_pad / 4 <= MAXV * 512), copy_store writes them to LDS.
+template <bool VEC, int MAXV>
+__device__ __forceinline__ void copy_load(float4 (&v)[MAXV], const float *__restrict__ src, int rows, int cols, int rows_pad,
+                                          int cols_pad, int tid)
+{
+    const int vpr = cols_pad >> 2, total = rows_pad * vpr;   // cols_pad % 4 == 0
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int e = min(tid + u * (PNW * 64), total - 1);
+        const int i = e / vpr, j4 = e - i * vpr;
+        v[u] = load4<VEC>(src + (size_t)min(i, rows - 1) * cols, 4 * j4, cols);
+        if (i >= rows) v[u] = zero4();
+    }
+}
+
+template <int MAXV>
+__device__ __forceinline__ void copy_store(const float4 (&v)[MAXV], float *dst, int ld, int rows_pad, int cols_pad, int tid)
+{
+    const int vpr = cols_pad >> 2, total = rows_pad * vpr;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int e = tid + u * (PNW * 64);
+        if (e < total) {
+            const int i = e / vpr, j4 = e - i * vpr;
+            *reinterpret_cast<float4 *>(dst + i * ld + 4 * j4) = v[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward layer on registers:  out[ot] (16 features x 16 samples) = act( W[16 ot .. +15][:] . in + bias )
+// W, bias: zero-padded LDS copies (row stride ldw).  KT = k-tiles of the input (compile time; 0 = use `kt`).
+// Weight chunks of 4 k-tiles (16 VGPRs) are software-pipelined one chunk ahead of the MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+template <bool ACT, int KT, bool KEEPG = true>
+__device__ __forceinline__ void forward_layer(const float *W, int ldw, const float *bias, int kt_rt, int nout,
+                                              const f32x4 (&in)[8], f32x4 (&outH)[8], f32x4 (&outG)[8], int l15, int q)
+{
+    constexpr int NCH = KT ? (KT + PCH - 1) / PCH : 8 / PCH;           // chunks per output tile
+    constexpr int NC = 8 * NCH;
+    const int kt = KT ? KT : kt_rt;
+    float4 wq[2][PCH];
+    auto issue = [&](int c, float4(&dst)[PCH]) {
+        const int ot = c / NCH, th = c % NCH;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j) {
+            const int t = PCH * th + j;
+            if (ot < nout && t < kt) dst[j] = *reinterpret_cast<const float4 *>(W + (16 * ot + l15) * ldw + 16 * t + 4 * q);
+        }
+    };
+    issue(0, wq[0]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ot = c / NCH, th = c % NCH;
+        if (c + 1 < NC) issue(c + 1, wq[(c + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ot < nout) {
+            if (th == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < PCH; ++j) {
+                const int t = PCH * th + j;
+                if (t < kt) {
+                    const float4 wv = wq[c & 1][j];
+                    acc = mfma16(wv.x, in[t][0], acc);
+                    acc = mfma16(wv.y, in[t][1], acc);
+                    acc = mfma16(wv.z, in[t][2], acc);
+                    acc = mfma16(wv.w, in[t][3], acc);
+                }
+            }
+            if (th == NCH - 1) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(bias + 16 * ot + 4 * q);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = acc[r] + bb[r];
+                    if (ACT) {
+                        float y, gd;
+                        gelu_and_grad_fast(z, y, gd);
+                        outH[ot][r] = y;
+                        if (KEEPG) outG[ot][r] = gd;
+                    } else {
+                        outH[ot][r] = z;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward through a layer's input on registers:  g[jt] <- gate[jt] * ( W^T . dz ),  W = zero-padded LDS copy
+// [16 kt][ldw] (A operand = W^T: lane (j, q) supplies W[16 t + 4 q + r][16 jt + j], four ds_read_b32 per k-tile).
+// gate = GELU'(z_in).  RECOMP = false: gate is what `g` holds on entry (kept from the forward pass).
+// RECOMP = true: the forward pass did not keep it (32 VGPRs less for the whole forward chain); the layer's
+// pre-activation tile z = Win[16 jt ..][:] . xin + bin is recomputed here (NSX k-tiles, 4 NSX extra MFMAs per tile).
+// ---------------------------------------------------------------------------------------------------------
+template <int KT, bool RECOMP, int NSX>
+__device__ __forceinline__ void backward_input(const float *W, int ldw, int kt_rt, int nin, const f32x4 (&dz)[8], f32x4 (&g)[8],
+                                               const float *Win, int ldin, const float *bin, const f32x4 (&xin)[8], int l15,
+                                               int q)
+{
+    constexpr int NCH = KT ? (KT + PCH - 1) / PCH : 8 / PCH;
+    constexpr int NC = 8 * NCH;
+    constexpr int NX = RECOMP ? NSX : 1;
+    const int kt = KT ? KT : kt_rt;
+    float4 wq[2][PCH];
+    float4 wx[NX];
+    auto issue = [&](int c, float4(&dst)[PCH]) {
+        const int jt = c / NCH, th = c % NCH;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j) {
+            const int t = PCH * th + j;
+            if (jt < nin && t < kt) {
+                const float *p = W + (16 * t + 4 * q) * ldw + 16 * jt + l15;
+                dst[j] = make_float4(p[0], p[ldw], p[2 * ldw], p[3 * ldw]);
+            }
+        }
+    };
+    issue(0, wq[0]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int jt = c / NCH, th = c % NCH;
+        if (c + 1 < NC) issue(c + 1, wq[(c + 1) & 1]);
+        if (RECOMP && th == 0 && jt < nin) {   // this tile's rows of the input layer's weights (used in the epilogue)
+#pragma unroll
+            for (int t = 0; t < NX; ++t) wx[t] = *reinterpret_cast<const float4 *>(Win + (16 * jt + l15) * ldin + 16 * t + 4 * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (jt < nin) {
+            if (th == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < PCH; ++j) {
+                const int t = PCH * th + j;
+                if (t < kt) {
+                    const float4 wv = wq[c & 1][j];
+                    acc = mfma16(wv.x, dz[t][0], acc);
+                    acc = mfma16(wv.y, dz[t][1], acc);
+                    acc = mfma16(wv.z, dz[t][2], acc);
+                    acc = mfma16(wv.w, dz[t][3], acc);
+                }
+            }
+            if (th == NCH - 1) {
+                if (RECOMP) {
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < NX; ++t) {
+                        z = mfma16(wx[t].x, xin[t][0], z);
+                        z = mfma16(wx[t].y, xin[t][1], z);
+                        z = mfma16(wx[t].z, xin[t][2], z);
+                        z = mfma16(wx[t].w, xin[t][3], z);
+                    }
+                    const float4 b4 = *reinterpret_cast<const float4 *>(bin + 16 * jt + 4 * q);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y, gd;
+                        gelu_and_grad_fast(z[r] + bb[r], y, gd);
+                        g[jt][r] = gd * acc[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[jt][r] *= acc[r];
+                }
+            }
+        }
+    }
+}
+
+// stage a register-resident activation (D layout) feature-major into LDS: T[feature][16 w + m]
+__device__ __forceinline__ void stage(float *T, const f32x4 (&a)[8], int nt, int col, int q)
+{
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(16 * t + 4 * q + r) * PLD + col] = a[t][r];
+        }
+}
+
+// dW (nA32*32 x nB32*32) = TA . TB^T over the 128 staged samples; output tiles split over the 8 waves.
+__device__ __forceinline__ void weight_grad(const float *TA, int nA32, const float *TB, int nB32, float *__restrict__ dW,
+                                            int ldw, int cols_real, int wave, int lane)
+{
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntiles = nA32 * nB32;
+    for (int tile = wave; tile < ntiles; tile += PNW) {
+        const int it = tile / nB32, jt = tile - it * nB32;
+        const float *a = TA + (32 * it + l31) * PLD + hi;
+        const float *b = TB + (32 * jt + l31) * PLD + hi;
+        f32x16 acc = {0};
+#pragma unroll 16
+        for (int s = 0; s < PB / 2; ++s) acc = mfma32(a[2 * s], b[2 * s], acc);
+        const int i = 32 * jt + l31;
+        if (i < cols_real) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW[(size_t)(32 * it + crow(r, hi)) * ldw + i] = acc[r];
+        }
+    }
+}
+
+// bias gradient: out[f] = sum over the 128 staged samples of T[f][:]; wave w reduces features 16 w .. 16 w + 15
+__device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__restrict__ out, int wave, int lane)
+{
+    for (int f0 = 16 * wave; f0 < nfeat; f0 += 16 * PNW) {
+        const int f = f0 + (lane & 15), p = lane >> 4;
+        const float *src = T + f * PLD + 32 * p;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            s0 += src[k];
+            s1 += src[k + 1];
+        }
+        float s = s0 + s1;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (p == 0 && f < nfeat) out[f] = s;
+    }
+}
+
+// LDS pool (floats): [RA: W2 copy, later staged tiles][RB: W1 copy, later staged tiles][RC: dY^T][RW3: W3 copy]
+//                    [s_bias: b1 | b2 | b3(16)][s_part: 8*16][s_red: 16]
+constexpr int kRFloats = 128 * 132 + 64;  // >= 128 * lds_ld(128), >= 128 * PLD, >= 128 * lds_ld(64) + 64 * PLD (W1 copy | X^T)
+constexpr int kRCFloats = 16 * PLD;
+constexpr int kRW3Floats = 16 * 132;
+constexpr int kBiasFloats = 128 + 128 + 16;
+constexpr size_t kPpoLdsBytes = (size_t)(2 * kRFloats + kRCFloats + kRW3Floats + kBiasFloats + PNW * 16 + 16) * sizeof(float);
+
+template <bool ACTOR, int NS_, int N1_, int N2_, bool VEC>
+__device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int net = ACTOR ? 0 : 1;
+    const Dims d{g.S, g.h1, g.h2, ACTOR ? g.A : 1};
+    const int S = d.S, h1 = N1_ ? 16 * N1_ : d.h1, h2 = N2_ ? 16 * N2_ : d.h2, OUT = d.out;
+    const int ns = NS_ ? NS_ : (S + 15) >> 4, n1 = N1_ ? N1_ : h1 >> 4, n2 = N2_ ? N2_ : h2 >> 4;
+    const float *P = g.P[net];
+    const float *std_log = P + d.oStd();
+
+    float *RA = smem;                      // W2 copy [h2][ld2], later staged tiles [128][PLD]
+    float *RB = RA + kRFloats;             // W1 copy [h1][ld1], later staged tiles [128][PLD]
+    float *RC = RB + kRFloats;             // [16][PLD]   dY^T
+    float *RW3 = RC + kRCFloats;           // W3 copy [16][ld3] (rows >= OUT are zero)
+    float *s_b1 = RW3 + kRW3Floats, *s_b2 = s_b1 + 128, *s_b3 = s_b2 + 128;
+    float *s_part = s_b3 + 16;             // [8 waves][16]  per-wave dstd_log partials
+    float *s_red = s_part + PNW * 16;      // [16] block_sum scratch
+    const int ld1 = lds_ld(16 * ns), ld2 = lds_ld(h1), ld3 = lds_ld(h2);
+
+    PROF(0);
+    // ---- prologue: two global round trips.  Trip 1: the sample id and the weight/bias copies.
+    const int col = 16 * wave + l15;                       // sample slot inside the workgroup
+    const int64_t bidx = (int64_t)blockIdx.x * PB + col;
+    const bool valid = bidx < g.B;
+    const int64_t id = g.ids[valid ? bidx : 0];
+    float4 c2[8], c1[8], c3[1];
+    copy_load<VEC, 8>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
+    copy_load<VEC, 8>(c1, P + d.oW1(), h1, S, h1, 16 * ns, tid);
+    copy_load<VEC, 1>(c3, P + d.oW3(), OUT, h2, 16, h2, tid);
+    float bias_pre = 0.f;                                  // b1 | b2 | b3 (one element per thread 0..271)
+    if (tid < 128) bias_pre = (tid < h1) ? P[d.ob1() + tid] : 0.f;
+    else if (tid < 256) bias_pre = (tid - 128 < h2) ? P[d.ob2() + tid - 128] : 0.f;
+    else if (tid < 272) bias_pre = (tid - 256 < OUT) ? P[d.ob3() + tid - 256] : 0.f;
+
+    // ---- trip 2: id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
+    const int64_t n_ = id / g.H, t_ = id - n_ * g.H;
+    const int64_t row = valid ? t_ * g.N + n_ : 0;
+    // this sample's raw state slice, features 16 t + 4 q + r; normalised by norm_x (AgentPPO.py:360-361)
+    const float *srow = g.states + row * S;
+    const float *avg = g.avg[net], *sdv = g.sd[net];
+    auto load_x_raw = [&](float4(&R)[8]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < ns) R[t] = load4<VEC>(srow, 16 * t + 4 * q, S);
+    };
+    auto norm_x = [&](const float4(&R)[8], f32x4(&X)[8]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < ns) {
+                const int k0 = 16 * t + 4 * q;
+                const float4 a4 = load4<VEC>(avg, k0, S), s4 = load4<VEC>(sdv, k0, S);
+                const float rr[4] = {R[t].x, R[t].y, R[t].z, R[t].w}, aa[4] = {a4.x, a4.y, a4.z, a4.w},
+                            ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xn = (rr[r] - aa[r]) / (ss[r] + 1e-4f);
+                    X[t][r] = (valid && k0 + r < S) ? xn : 0.f;
+                }
+            }
+        }
+    };
+    float4 XR[8];
+    load_x_raw(XR);
+
+    // ---- publish the LDS copies (zero padded to the tile grid), visible after barrier (0)
+    copy_store<8>(c2, RA, ld2, h2, h1, tid);
+    copy_store<8>(c1, RB, ld1, h1, 16 * ns, tid);
+    copy_store<1>(c3, RW3, ld3, 16, h2, tid);
+    if (tid < 272) s_b1[tid] = bias_pre;                   // s_b1 | s_b2 | s_b3 are contiguous
+
+    // X^T for dW1 lives next to the W1 copy when both fit (S <= 64): staged once, here, from the registers
+    constexpr bool EARLY_X = NS_ != 0 && NS_ <= 4;
+    float *RX = EARLY_X ? RB + 128 * lds_ld(64) : RB;
+    f32x4 H1[8], G1[8], H2[8], G2[8];
+    f32x4 X[8];
+    norm_x(XR, X);
+    if (EARLY_X) stage(RX, X, ns, col, q);
+    PROF(1);
+    lds_barrier();                                                   // (0) weight copies visible
+    PROF(2);
+    forward_layer<true, NS_, !EARLY_X>(RB, ld1, s_b1, ns, n1, X, H1, G1, l15, q);   // EARLY_X: GELU'(z1) is recomputed
+    PROF(3);
+    forward_layer<true, N1_>(RA, ld2, s_b2, n1, n2, H1, H2, G2, l15, q);
+    PROF(4);
+    // per-sample scalars: issued here (L2 / MALL hits by now), consumed after the output layer
+    const float um = (valid && g.unmasks[row]) ? 1.f : 0.f;
+    const float xa = ACTOR ? g.logprobs[row] : g.reward_sums[row];
+    const float xb = ACTOR ? g.advantages[row] : 0.f;
+    float act_pre[4] = {0.f, 0.f, 0.f, 0.f}, sl_pre[4] = {0.f, 0.f, 0.f, 0.f};   // this lane's actions a = 4 q + r (actor)
+    if (ACTOR) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ac = min(4 * q + r, OUT - 1);
+            act_pre[r] = g.actions[row * OUT + ac];
+            sl_pre[r] = std_log[ac];
+        }
+    }
+    f32x4 Y[8], dummy[8];
+    forward_layer<false, N2_>(RW3, ld3, s_b3, n2, 1, H2, Y, dummy, l15, q);
+    PROF(5);
+
+    // ---- objective and dL/dY for this lane's outputs a = 4 q + r   (AgentPPO.py:189-204)
+    f32x4 dY[8];
+    float loss0 = 0.f, loss1 = 0.f;
+    float dsl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!ACTOR) {
+        const float diff = Y[0][0] - xa;                  // only (q = 0, r = 0) is the value head
+        const bool head = q == 0;
+        loss0 = head ? diff * diff * um : 0.f;
+        dY[0] = f32x4{head ? 2.f * diff * um * g.inv_batch : 0.f, 0.f, 0.f, 0.f};
+    } else {
+        float diffv[4], varv[4];
+        float lp = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * q + r;
+            const float sl = sl_pre[r], sd_ = expf(sl);
+            const float diff = act_pre[r] - Y[0][r];
+            const bool on = a < OUT;
+            varv[r] = sd_ * sd_;
+            diffv[r] = on ? diff : 0.f;
+            const float term = -(diff * diff) / (2.f * varv[r]) - logf(sd_) - kLogSqrt2Pi;
+            lp += on ? term : 0.f;
+        }
+        lp += __shfl_xor(lp, 16, 64);
+        lp += __shfl_xor(lp, 32, 64);
+        const float adv = xb;
+        const float ratio = expf(lp - xa);
+        const float wclip = adv > 0.f ? 1.f - g.ratio_clip : 1.f + g.ratio_clip;
+        const float surr = valid ? adv * ratio * wclip : 0.f;   // reference-form "clip" (:199); padding rows contribute 0
+        if (q == 0) {
+            loss0 = surr * um;
+            loss1 = um;
+        }
+        const float dlp = -(surr * um) * g.inv_batch;      // d(-mean(surr um)) / dlogp_new
+        const float ent_term = g.lambda_entropy * um * g.inv_batch;
+        f32x4 dy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool on = 4 * q + r < OUT;
+            dy[r] = on ? dlp * (diffv[r] / varv[r]) : 0.f;                                     // dL/dmean
+            dsl[r] = on ? dlp * (diffv[r] * diffv[r] / varv[r] - 1.f) + ent_term : 0.f;        // dL/dstd_log, this sample
+        }
+        dY[0] = dy;
+    }
+
+    // ---- per-wave dstd_log partials
+    if (ACTOR) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = dsl[r];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            if (l15 == 0) s_part[wave * 16 + 4 * q + r] = s;
+        }
+    }
+    // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 16 outputs: one k-tile);  dZ1 = (W2^T dZ2) * GELU'(z1)
+    PROF(6);
+    backward_input<1, false, 1>(RW3, ld3, 1, n2, dY, G2, nullptr, 0, nullptr, dY, l15, q);   // G2 now holds dZ2
+    if (EARLY_X) {                                                  // X back from its LDS staging (16 ds_read_b32)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < ns) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[t][r] = RX[(16 * t + 4 * q + r) * PLD + col];
+            }
+    }
+    backward_input<N2_, EARLY_X, (NS_ ? NS_ : 1)>(RA, ld2, n2, n1, G2, G1, RB, ld1, s_b1, X, l15, q);   // G1 now holds dZ1
+    PROF(7);
+    lds_barrier();                                                   // (1) every wave is done with the weight copies
+    PROF(8);
+    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
+
+    // ---- layer 1: dW1 = dZ1^T . X, db1;  (dY^T is staged alongside for the output layer)
+    stage(RA, G1, n1, col, q);                                      // dZ1^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) RC[(4 * q + r) * PLD + col] = dY[0][r];
+    if (!EARLY_X) {                                                 // generic shapes: re-gather X now (the W1 copy is dead)
+        load_x_raw(XR);
+        norm_x(XR, X);
+        stage(RX, X, ns, col, q);
+    }
+    lds_barrier();                                                   // (2)
+    PROF(9);
+    weight_grad(RA, h1 >> 5, RX, (S + 31) >> 5, slab + d.oW1(), S, S, wave, lane);
+    bias_grad(RA, h1, slab + d.ob1(), wave, lane);
+    if (wave == 0) {
+        bias_grad(RC, OUT, slab + d.ob3(), 0, lane);
+        if (ACTOR && lane < OUT) {
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < PNW; ++u) s += s_part[u * 16 + lane];
+            slab[d.oStd() + lane] = s;
+        }
+    }
+    PROF(10);
+    lds_barrier();                                                   // (3) dZ1^T, X^T consumed
+
+    // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 MFMA, one 16-column tile per wave
+    stage(RA, H2, n2, col, q);                                      // H2^T
+    stage(RB, H1, n1, col, q);                                      // H1^T (for dW2)
+    lds_barrier();                                                   // (4)
+    PROF(11);
+    for (int it = wave; it < n2; it += PNW) {
+        const float *a = RC + l15 * PLD + q;                        // A[row a][k = sample]
+        const float *b = RA + (16 * it + l15) * PLD + q;            // B[k = sample][col i]
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int s = 0; s < PB / 4; ++s) acc = mfma16(a[4 * s], b[4 * s], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a_ = 4 * q + r;
+            if (a_ < OUT) slab[d.oW3() + (size_t)a_ * h2 + 16 * it + l15] = acc[r];
+        }
+    }
+    lds_barrier();                                                   // (5) H2^T consumed
+    stage(RA, G2, n2, col, q);                                      // dZ2^T
+    lds_barrier();                                                   // (6)
+    PROF(12);
+
+    // ---- layer 2: dW2 = dZ2^T . H1, db2
+    weight_grad(RA, h2 >> 5, RB, h1 >> 5, slab + d.oW2(), h1, h1, wave, lane);
+    bias_grad(RA, h2, slab + d.ob2(), wave, lane);
+    PROF(13);
+
+    // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
+    const float t0 = block_sum(loss0, s_red);
+    const float t1 = block_sum(loss1, s_red);
+    if (tid == 0) {
+        float *logs = g.slabs + (size_t)blockIdx.x * g.stride + g.Pa + g.Pc;
+        if (ACTOR) {
+            float ent = 0.f;
+            for (int a = 0; a < OUT; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));  // 0.5 + 0.5 log(2 pi) + log(std)
+            logs[1] = t0 * g.inv_batch;
+            logs[2] = ent * t1 * g.inv_batch;
+        } else {
+            logs[0] = t0 * g.inv_batch;
+            logs[3] = 0.f;
+        }
+    }
+}
+
+template <int NS_, int N1_, int N2_, bool VEC>
+__global__ __launch_bounds__(PNW * 64) void ppo_step2_kernel(Ppo2Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.y == 0) ppo_block<true, NS_, N1_, N2_, VEC>(g, smem);
+    else ppo_block<false, NS_, N1_, N2_, VEC>(g, smem);
+}
+
+bool dims_ok2(int S, int h1, int h2, int out)
+{
+    return S >= 1 && S <= ERL_MAX_STATE_DIM && h1 >= 32 && h1 <= ERL_MAX_HIDDEN && (h1 % 32) == 0 && h2 >= 32 &&
+           h2 <= ERL_MAX_HIDDEN && (h2 % 32) == 0 && out >= 1 && out <= ERL_MAX_ACTION_DIM;
+}
+
+template <int NS_, int N1_, int N2_, bool VEC>
+int launch(const Ppo2Args &g, int n_slabs, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = erl_hip_status(hipFuncSetAttribute((const void *)ppo_step2_kernel<NS_, N1_, N2_, VEC>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPpoLdsBytes),
+                                "hipFuncSetAttribute(ppo_step2_kernel)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ppo_step2_kernel<NS_, N1_, N2_, VEC>), dim3(n_slabs, 2), dim3(PNW * 64), kPpoLdsBytes, stream, g);
+    return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");
+}
+
+long long *g_ppo_prof = nullptr;
+
+}  // namespace
+
+#ifdef ERL_PROFILE
+// profiling builds only (make EXTRA=-DERL_PROFILE): device buffer of 2 * 8 * 32 int64 cycle stamps
+extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile(long long *dev_buf) { g_ppo_prof = dev_buf; }
+#endif
+
+extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
+{
+    if (!dims_ok2(S, h1, h2, A)) return -1;
+    return Dims{S, h1, h2, A}.count(true) + Dims{S, h1, h2, 1}.count(false) + 4;
+}
+
+extern "C" int erl_ppo_num_slabs(int64_t B) { return B >= 1 && B < (1LL << 37) ? (int)erl_cdiv(B, PB) : -1; }
+
+extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
+                                const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
+                                const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
+                                const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
+                                float lambda_entropy, float inv_batch, float *slabs, int n_slabs, void *stream)
+{
+    ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions && unmasks &&
+                    logprobs && advantages && reward_sums && ids && slabs,
+                "erl_ppo_step_f32: NULL tensor");
+    ERL_REQUIRE(dims_ok2(S, h1, h2, A), "erl_ppo_step_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
+    ERL_REQUIRE(H >= 1 && N >= 1 && B >= 1, "erl_ppo_step_f32: bad shape");
+    ERL_REQUIRE(n_slabs == erl_ppo_num_slabs(B), "erl_ppo_step_f32: n_slabs=%d, expected erl_ppo_num_slabs(B=%lld)=%d", n_slabs,
+                (long long)B, erl_ppo_num_slabs(B));
+    Ppo2Args g;
+    g.P[0] = actor_params; g.P[1] = critic_params;
+    g.avg[0] = act_avg; g.avg[1] = cri_avg;
+    g.sd[0] = act_std; g.sd[1] = cri_std;
+    g.states = states; g.actions = actions; g.logprobs = logprobs; g.advantages = advantages; g.reward_sums = reward_sums;
+    g.unmasks = unmasks; g.ids = ids;
+    g.H = H; g.N = N; g.B = B;
+    g.S = S; g.h1 = h1; g.h2 = h2; g.A = A;
+    g.ratio_clip = ratio_clip; g.lambda_entropy = lambda_entropy; g.inv_batch = inv_batch;
+    g.slabs = slabs;
+    g.Pa = Dims{S, h1, h2, A}.count(true);
+    g.Pc = Dims{S, h1, h2, 1}.count(false);
+    g.stride = g.Pa + g.Pc + 4;
+    g.prof = g_ppo_prof;
+    // 16-byte vector path: every row / parameter block / normalisation vector must be 16-byte aligned
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states) && al(act_avg) && al(act_std) &&
+                     al(cri_avg) && al(cri_std);
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = (S + 15) / 16;
+    if (vec && ns == 4 && h1 == 128 && h2 == 128) return launch<4, 8, 8, true>(g, n_slabs, st);   // configs 4 / 5
+    if (vec) return launch<0, 0, 0, true>(g, n_slabs, st);
+    return launch<0, 0, 0, false>(g, n_slabs, st);
+}

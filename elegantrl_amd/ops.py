@@ -204,6 +204,11 @@ def ppo_slab_stride(S: int, h1: int, h2: int, A: int) -> int:
     return lib().erl_ppo_slab_stride(S, h1, h2, A)
 
 
+def ppo_num_slabs(batch_size: int) -> int:
+    """number of per-workgroup gradient slabs erl_ppo_step_f32 writes for a minibatch of `batch_size` samples."""
+    return lib().erl_ppo_num_slabs(batch_size)
+
+
 def ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int, h1: int,
              h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
              ids: TEN, ratio_clip: float, lambda_entropy: float, inv_batch: float, slabs: TEN, n_slabs: int) -> None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 1
+#define ERL_ABI_VERSION 2
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -150,11 +150,13 @@ ERL_API int erl_rollout_step_f32(const float *actor_params, const float *state_a
  *   obj_critic = mean((cri(s) - reward_sum)^2 * unmask)
  *   ratio = exp(logp_new - logp_old); surrogate = adv*ratio*where(adv > 0, 1-clip, 1+clip)
  *   actor loss = -(mean(surrogate*unmask) - lambda_entropy*mean(entropy*unmask))
- * Gradients are left as per-workgroup partial sums in `slabs` (n_slabs x erl_ppo_slab_stride floats),
- * to be summed by erl_grad_reduce_f32.  inv_batch = 1/B (or 1/(B*world) under data parallelism).
+ * Every workgroup owns 128 samples and leaves its gradient as one partial sum in `slabs`
+ * (n_slabs x erl_ppo_slab_stride floats, n_slabs == erl_ppo_num_slabs(B) = ceil(B / 128)), to be summed in a
+ * fixed order by erl_grad_reduce_f32.  inv_batch = 1/B (1/(B*world) is folded into K7 under data parallelism).
  * Slab / flat-gradient layout: [actor grads (Pa)] [critic grads (Pc)] [obj_critic, obj_surrogate,
  * obj_entropy, 0] where Pa/Pc = erl_mlp_param_count(...). */
 ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
+ERL_API int erl_ppo_num_slabs(int64_t B);
 ERL_API int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg,
                      const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2,
                      int A, const float *states, const float *actions, const uint8_t *unmasks,

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at the BASELINE config-4 shapes (HIP events, best of 3 x 20 launches).
+Run on the GPU box:  python tools/kernel_bench.py"""
+import json
+import os
+import sys
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from elegantrl_amd import ops  # noqa: E402
+
+dev = th.device("cuda:0")
+N, S, A, H, B, h1, h2 = 4096, 64, 8, 32, 16384, 128, 128
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    th.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        th.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e-3 / iters)
+    return best * 1e6
+
+
+def main():
+    g = th.Generator(device=dev).manual_seed(0)
+    sa, sc = ops.MlpSpec(S, h1, h2, A, True), ops.MlpSpec(S, h1, h2, 1, False)
+    Pa, Pc = sa.count, sc.count
+    flat = th.randn(Pa + Pc, device=dev, generator=g) * 0.05
+    avg, std = th.zeros(S, device=dev), th.ones(S, device=dev)
+    states = th.randn((H, N, S), device=dev, generator=g)
+    actions = th.randn((H, N, A), device=dev, generator=g)
+    logprobs = th.randn((H, N), device=dev, generator=g) - 8
+    adv = th.randn((H, N), device=dev, generator=g)
+    ret = th.randn((H, N), device=dev, generator=g)
+    um = th.rand((H, N), device=dev, generator=g) < 0.995
+    ids = th.randint(H * N, (B,), device=dev, generator=g)
+    stride = ops.ppo_slab_stride(S, h1, h2, A)
+    n_slabs = ops.ppo_num_slabs(B)
+    slabs = th.empty((n_slabs, stride), device=dev)
+    grads = th.empty(stride, device=dev)
+    m1, m2 = th.zeros_like(flat), th.zeros_like(flat)
+    out = {}
+    out["ppo_step"] = timeit(lambda: ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs,
+                                                   adv, ret, ids, 0.25, 0.001, 1.0 / B, slabs, n_slabs))
+    out["grad_reduce"] = timeit(lambda: ops.grad_reduce(slabs, n_slabs, stride, grads))
+    out["clip_adam"] = timeit(lambda: ops.clip_adam(flat.clone(), grads, m1, m2, [(0, Pa), (Pa, Pc)], 5, 6e-5, 3.0))
+    state = th.randn((N, S), device=dev, generator=g)
+    env_a = th.empty((N, A), device=dev)
+    out["rollout_step"] = timeit(lambda: ops.rollout_step(flat[:Pa], sa, avg, std, state, seed=1, counter=2, out_state=states[0],
+                                                           out_action=actions[0], out_logprob=logprobs[0], out_env_action=env_a))
+    vals = th.empty((H, N), device=dev)
+    out["value_forward_HxN"] = timeit(lambda: ops.value_forward(flat[Pa:], sc, avg, std, states, out=vals))
+    out["value_forward_N"] = timeit(lambda: ops.value_forward(flat[Pa:], sc, avg, std, state))
+    flops = 2 * (S * h1 + h1 * h2) * 2 + 2 * (h1 * h2) + 0  # rough; the bench uses its own formula
+    out = {k: round(v, 2) for k, v in out.items()}
+    print(json.dumps(out))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/kernel_bench.json", "w"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Phase-level cycle breakdown of the K6 PPO minibatch kernel (needs the ERL_PROFILE build:
+   make -C elegantrl_amd/csrc EXTRA=-DERL_PROFILE OUT=../lib/liberl_hip_prof.so OBJDIR=build_prof).
+   Run on the GPU box:  python tools/ppo_phase_profile.py"""
+import ctypes
+import os
+import sys
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from elegantrl_amd import _hip  # noqa: E402
+
+_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "liberl_hip_prof.so")
+from elegantrl_amd import ops  # noqa: E402
+
+dev = th.device("cuda:0")
+N, S, A, H, B, h1, h2 = 4096, 64, 8, 32, 16384, 128, 128
+NAMES = ["prologue (2 global trips, copies, norm_x)", "barrier0", "L1 fwd", "L2 fwd", "out layer", "objective + dstd partials",
+         "dZ2 + dZ1", "barrier1 (wave skew)", "stage dZ1/dY + barrier2", "dW1 + db1 + db3", "barrier3 + stage H2/H1 + barrier4",
+         "dW3 + barrier5 + stage dZ2 + barrier6", "dW2 + db2", "loss reduce + logs"]
+NP = 15
+
+def main():
+    lib = _hip.lib()
+    lib.erl_debug_set_ppo_profile.argtypes = [ctypes.c_void_p]
+    lib.erl_debug_set_ppo_profile.restype = None
+    g = th.Generator(device=dev).manual_seed(0)
+    sa, sc = ops.MlpSpec(S, h1, h2, A, True), ops.MlpSpec(S, h1, h2, 1, False)
+    Pa, Pc = sa.count, sc.count
+    flat = th.randn(Pa + Pc, device=dev, generator=g) * 0.05
+    avg, std = th.zeros(S, device=dev), th.ones(S, device=dev)
+    states = th.randn((H, N, S), device=dev, generator=g)
+    actions = th.randn((H, N, A), device=dev, generator=g)
+    logprobs = th.randn((H, N), device=dev, generator=g) - 8
+    adv = th.randn((H, N), device=dev, generator=g)
+    ret = th.randn((H, N), device=dev, generator=g)
+    um = th.rand((H, N), device=dev, generator=g) < 0.995
+    ids = th.randint(H * N, (B,), device=dev, generator=g)
+    stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
+    slabs = th.empty((n_slabs, stride), device=dev)
+    prof = th.zeros(2 * 8 * 32, dtype=th.int64, device=dev)
+    lib.erl_debug_set_ppo_profile(prof.data_ptr())
+    run = lambda: ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,  # noqa: E731
+                               ids, 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    for _ in range(5):
+        run()
+    th.cuda.synchronize()
+    p = prof.cpu().view(2, 8, 32)[:, :, :NP]
+    for net, name in enumerate(("actor", "critic")):
+        d = (p[net, :, 1:] - p[net, :, :-1]).double()
+        tot = (p[net, :, NP - 1] - p[net, :, 0]).double()
+        print(f"--- {name}: total cycles per wave min/mean/max = {tot.min():.0f} / {tot.mean():.0f} / {tot.max():.0f}")
+        for i, nm in enumerate(NAMES[:NP - 1]):
+            print(f"  {nm:36s} mean {d[:, i].mean():9.0f}  min {d[:, i].min():9.0f}  max {d[:, i].max():9.0f}  ({100 * d[:, i].mean() / tot.mean():5.1f} %)")
+
+
+if __name__ == "__main__":
+    main()
