@@ -17,16 +17,30 @@ struct AdamGroups {
 __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ params, const float *__restrict__ grads,
                                                          float *__restrict__ m1, float *__restrict__ m2, AdamGroups gr,
                                                          const int32_t *__restrict__ step_base, int32_t step_offset, float lr,
-                                                         float beta1, float beta2, float eps, float max_norm, float grad_scale)
+                                                         float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                                                         float host_step_size, float host_bc2_sqrt)
 {
     __shared__ double scratch[16];
     const int gi = blockIdx.y;
     const int64_t off = gr.off[gi], len = gr.len[gi];
     const float *g = grads + off;
     double ss = 0.0;
-    for (int64_t i = threadIdx.x; i < len; i += 1024) {
-        const float x = g[i] * grad_scale;
-        ss += (double)x * x;
+    {   // all loads of a thread are issued before the first use (one L2 round trip instead of one per element)
+        constexpr int U = 8;
+        for (int64_t i0 = threadIdx.x; i0 < len; i0 += (int64_t)U * 1024) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * 1024;
+                x[u] = g[i < len ? i : len - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * 1024;
+                const float xs = x[u] * grad_scale;
+                if (i < len) ss += (double)xs * xs;
+            }
+        }
     }
     ss = block_sum(ss, scratch);
     const float total_norm = (float)sqrt(ss);
@@ -34,11 +48,14 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ par
     coef = coef > 1.f ? 1.f : coef;
     const float gmul = grad_scale * coef;
 
-    const int step = (step_base ? *step_base : 0) + step_offset;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    float step_size = host_step_size, bc2_sqrt = host_bc2_sqrt;   // computed on the host when the step is a host value
+    if (step_base) {
+        const int step = *step_base + step_offset;
+        const double bc1 = 1.0 - pow((double)beta1, (double)step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step);
+        step_size = (float)((double)lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
 
     const int64_t per = (len + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < len) ? lo + per : len;
@@ -73,7 +90,14 @@ extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_a
     int bx = (int)erl_cdiv(longest, 4096);
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (!step_base) {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step_offset), bc2 = 1.0 - pow((double)beta2, (double)step_offset);
+        step_size = (float)((double)lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
     hipLaunchKernelGGL(clip_adam_kernel, dim3(bx, n_groups), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                       gr, step_base, step_offset, lr, beta1, beta2, eps, max_norm, grad_scale);
+                       gr, step_base, step_offset, lr, beta1, beta2, eps, max_norm, grad_scale, step_size, bc2_sqrt);
     ERL_LAUNCH_CHECK("erl_clip_adam_f32");
 }
+

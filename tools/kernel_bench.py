@@ -52,7 +52,8 @@ def main():
     out["ppo_step"] = timeit(lambda: ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs,
                                                    adv, ret, ids, 0.25, 0.001, 1.0 / B, slabs, n_slabs))
     out["grad_reduce"] = timeit(lambda: ops.grad_reduce(slabs, n_slabs, stride, grads))
-    out["clip_adam"] = timeit(lambda: ops.clip_adam(flat.clone(), grads, m1, m2, [(0, Pa), (Pa, Pc)], 5, 6e-5, 3.0))
+    p_adam = flat.clone()
+    out["clip_adam"] = timeit(lambda: ops.clip_adam(p_adam, grads, m1, m2, [(0, Pa), (Pa, Pc)], 5, 6e-5, 3.0))
     state = th.randn((N, S), device=dev, generator=g)
     env_a = th.empty((N, A), device=dev)
     out["rollout_step"] = timeit(lambda: ops.rollout_step(flat[:Pa], sa, avg, std, state, seed=1, counter=2, out_state=states[0],
