@@ -1,117 +1,198 @@
-// K2 value pre-pass, K1 rollout step, slab reduction of K6 (the PPO minibatch kernel itself: ppo_step.hip).  gfx950 / fp32 MFMA.
-// Building blocks and the LDS/MFMA formulation are documented in mlp_tiles.h.
-#include "mlp_tiles.h"
+// K1 rollout step and K2 value pre-pass on the register-chained MLP (mlp_chain.h), slab reduction of K6, MFMA self-test.
+// gfx950 / fp32 MFMA.
+//
+// K1  one vectorised rollout step = ActorPPO.get_action + the three buffer stores + convert_action_for_env
+//     (elegantrl/agents/AgentPPO.py:113-119, :368-376, :388-390).  A wave owns 16 envs; 4 waves per workgroup share
+//     the LDS copies of W1 / W2 / W3.  Lane (m, q) ends up with the policy means of actions a = 4 q + r, samples
+//     them (injected eps or Philox4x32-10 + Box-Muller), stores the pre-tanh action, tanh(action) for the env and
+//     the log-prob (cross-lane sum over q).
+// K2  value pre-pass: persistent workgroups of 8 waves; a wave walks 16-row tiles with the next tile's state rows
+//     prefetched under the current tile's MFMAs  (AgentPPO.py:141-143, :219-220, :435-441).
+#include "mlp_chain.h"
 
 namespace {
 
-struct MlpDims {
+constexpr float kLogSqrt2PiF = 0.91893853320467274178f;  // log(sqrt(2 pi))
+
+// LDS pool of the forward kernels (floats): [W2 copy 128 x 132][W1 copy 128 x 132][W3 copy 16 x 132][b1 | b2 | b3]
+constexpr int kFwdW = 128 * 132;
+constexpr int kFwdW3 = 16 * 132;
+constexpr size_t kFwdLdsBytes = (size_t)(2 * kFwdW + kFwdW3 + 128 + 128 + 16) * sizeof(float);
+
+struct FwdArgs {
+    const float *P, *avg, *sd;
     int S, h1, h2, out;
-    __host__ __device__ int Sc() const { return (S + 31) & ~31; }
-    __host__ __device__ int64_t oW1() const { return 0; }
-    __host__ __device__ int64_t ob1() const { return (int64_t)h1 * S; }
-    __host__ __device__ int64_t oW2() const { return ob1() + h1; }
-    __host__ __device__ int64_t ob2() const { return oW2() + (int64_t)h2 * h1; }
-    __host__ __device__ int64_t oW3() const { return ob2() + h2; }
-    __host__ __device__ int64_t ob3() const { return oW3() + (int64_t)out * h2; }
-    __host__ __device__ int64_t oStd() const { return ob3() + out; }
-    __host__ __device__ int64_t count(bool with_std) const { return oStd() + (with_std ? out : 0); }
+    const float *states;      // (rows, S)
+    int64_t rows;
+    // K2
+    float *values;
+    // K1
+    const float *noise;
+    uint64_t seed, counter;
+    float *o_state, *o_action, *o_logprob, *o_env;
 };
 
-bool dims_ok(int S, int h1, int h2, int out)
+// copies W1 / W2 / W3 / biases of one network into LDS (zero padded to the tile grid) and barriers
+template <bool VEC, int NW>
+__device__ __forceinline__ void load_network(const FwdArgs &g, const Dims &d, int ns, float *W2c, float *W1c, float *W3c, float *sb,
+                                             int tid)
 {
-    return S >= 1 && S <= ERL_MAX_STATE_DIM && h1 >= 32 && h1 <= ERL_MAX_HIDDEN && (h1 % 32) == 0 && h2 >= 32 &&
-           h2 <= ERL_MAX_HIDDEN && (h2 % 32) == 0 && out >= 1 && out <= ERL_MAX_ACTION_DIM;
-}
-
-constexpr float kLogSqrt2Pi = 0.91893853320467274178f;  // log(sqrt(2 pi))
-
-// ---------------------------------------------------------------------------------------------
-// forward-only kernels (K2: critic values, K1: actor rollout step)
-// LDS: XT [Sc][LD] | H1T [h1][LD] | H2T [h2][LD] | YT [16][LD] | ACT [16][LD]
-// ---------------------------------------------------------------------------------------------
-template <int M>
-__host__ __device__ inline size_t fwd_lds_floats(const MlpDims &d)
-{
-    return (size_t)(d.Sc() + d.h1 + d.h2 + 32) * (M + 1);
-}
-
-template <int M, int NW>
-__global__ __launch_bounds__(NW * 64) void value_forward_kernel(const float *__restrict__ P, const float *__restrict__ avg,
-                                                                const float *__restrict__ sd, MlpDims d,
-                                                                const float *__restrict__ states, int64_t rows,
-                                                                float *__restrict__ values)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LD = M + 1;
-    float *XT = smem, *H1T = XT + d.Sc() * LD, *H2T = H1T + d.h1 * LD, *YT = H2T + d.h2 * LD;
-    const int64_t ntiles = (rows + M - 1) / M;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * M;
-        const int valid = (int)min((int64_t)M, rows - row0);
-        gather_states<M>(XT, d.Sc(), d.S, states, avg, sd, valid, [&](int m) { return row0 + m; }, nullptr, 0);
-        __syncthreads();
-        layer_forward<M, NW, true, false>(P + d.oW1(), P + d.ob1(), d.h1, d.S, XT, H1T, nullptr);
-        __syncthreads();
-        layer_forward<M, NW, true, false>(P + d.oW2(), P + d.ob2(), d.h2, d.h1, H1T, H2T, nullptr);
-        __syncthreads();
-        output_layer<M>(P + d.oW3(), P + d.ob3(), 1, d.h2, H2T, YT);
-        __syncthreads();
-        if ((int)threadIdx.x < valid) values[row0 + threadIdx.x] = YT[threadIdx.x];
-        __syncthreads();
+    constexpr int NT = NW * 64;
+    constexpr int MV = 8 * 512 / NT;     // float4 per thread for a 128 x 128 matrix
+    const int ld1 = lds_ld(16 * ns), ld2 = lds_ld(d.h1), ld3 = lds_ld(d.h2);
+    float4 c2[MV], c1[MV], c3[(512 + NT - 1) / NT];
+    copy_load<VEC, MV, NT>(c2, g.P + d.oW2(), d.h2, d.h1, d.h2, d.h1, tid);
+    copy_load<VEC, MV, NT>(c1, g.P + d.oW1(), d.h1, d.S, d.h1, 16 * ns, tid);
+    copy_load<VEC, (512 + NT - 1) / NT, NT>(c3, g.P + d.oW3(), d.out, d.h2, 16, d.h2, tid);
+    for (int i = tid; i < 272; i += NT) {
+        float b = 0.f;
+        if (i < 128) b = (i < d.h1) ? g.P[d.ob1() + i] : 0.f;
+        else if (i < 256) b = (i - 128 < d.h2) ? g.P[d.ob2() + i - 128] : 0.f;
+        else b = (i - 256 < d.out) ? g.P[d.ob3() + i - 256] : 0.f;
+        sb[i] = b;
     }
+    copy_store<MV, NT>(c2, W2c, ld2, d.h2, d.h1, tid);
+    copy_store<MV, NT>(c1, W1c, ld1, d.h1, 16 * ns, tid);
+    copy_store<(512 + NT - 1) / NT, NT>(c3, W3c, ld3, 16, d.h2, tid);
 }
 
-template <int M, int NW>
-__global__ __launch_bounds__(NW * 64) void rollout_step_kernel(const float *__restrict__ P, const float *__restrict__ avg,
-                                                               const float *__restrict__ sd, MlpDims d,
-                                                               const float *__restrict__ state, int64_t N,
-                                                               const float *__restrict__ noise, uint64_t seed,
-                                                               uint64_t counter, float *__restrict__ o_state,
-                                                               float *__restrict__ o_action, float *__restrict__ o_logprob,
-                                                               float *__restrict__ o_env)
+template <bool VEC>
+__device__ __forceinline__ void load_rows_raw(float4 (&R)[8], const float *__restrict__ srow, int ns, int S, int q)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LD = M + 1;
-    float *XT = smem, *H1T = XT + d.Sc() * LD, *H2T = H1T + d.h1 * LD, *YT = H2T + d.h2 * LD, *ACT = YT + 16 * LD;
-    const int A = d.out;
-    const float *std_log = P + d.oStd();
-    const int64_t ntiles = (N + M - 1) / M;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * M;
-        const int valid = (int)min((int64_t)M, N - row0);
-        gather_states<M>(XT, d.Sc(), d.S, state, avg, sd, valid, [&](int m) { return row0 + m; }, o_state, row0);
-        __syncthreads();
-        layer_forward<M, NW, true, false>(P + d.oW1(), P + d.ob1(), d.h1, d.S, XT, H1T, nullptr);
-        __syncthreads();
-        layer_forward<M, NW, true, false>(P + d.oW2(), P + d.ob2(), d.h2, d.h1, H1T, H2T, nullptr);
-        __syncthreads();
-        output_layer<M>(P + d.oW3(), P + d.ob3(), A, d.h2, H2T, YT);
-        __syncthreads();
-        // sample: a = mean + std * eps  (torch.normal(mean, std));  element order (row, a) so that the
-        // global reads of `noise` and the writes of the action rows are coalesced.
-        for (int e = threadIdx.x; e < valid * A; e += blockDim.x) {
-            const int m = e / A, a = e - m * A;
-            const int64_t row = row0 + m;
-            const float eps = noise ? noise[row * A + a] : philox_normal(seed, counter, (uint32_t)row, (uint32_t)a);
-            const float sdv = expf(std_log[a]);
-            const float act = YT[a * LD + m] + sdv * eps;
-            ACT[a * LD + m] = act;
-            if (o_action) o_action[row * A + a] = act;
-            if (o_env) o_env[row * A + a] = tanhf(act);
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < valid && o_logprob) {
-            const int m = threadIdx.x;
-            float lp = 0.f;
-            for (int a = 0; a < A; ++a) {  // Normal.log_prob: -(x-mu)^2/(2 var) - log(std) - log(sqrt(2 pi))
-                const float sl = std_log[a], sdv = expf(sl), var = sdv * sdv;
-                const float diff = ACT[a * LD + m] - YT[a * LD + m];
-                lp += -(diff * diff) / (2.f * var) - logf(sdv) - kLogSqrt2Pi;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < ns) R[t] = load4<VEC>(srow, 16 * t + 4 * q, S);
+}
+
+template <bool VEC>
+__device__ __forceinline__ void normalise_rows(const float4 (&R)[8], f32x4 (&X)[8], const float *__restrict__ avg,
+                                               const float *__restrict__ sd, int ns, int S, int q, bool valid)
+{
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t < ns) {
+            const int k0 = 16 * t + 4 * q;
+            const float4 a4 = load4<VEC>(avg, k0, S), s4 = load4<VEC>(sd, k0, S);
+            const float rr[4] = {R[t].x, R[t].y, R[t].z, R[t].w}, aa[4] = {a4.x, a4.y, a4.z, a4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xn = (rr[r] - aa[r]) / (ss[r] + 1e-4f);   // (s - avg) / (std + 1e-4), AgentPPO.py:360-361
+                X[t][r] = (valid && k0 + r < S) ? xn : 0.f;
             }
-            o_logprob[row0 + m] = lp;
         }
-        __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2
+// ---------------------------------------------------------------------------------------------------------
+template <int NS_, int N1_, int N2_, bool VEC>
+__global__ __launch_bounds__(512) void value_forward2_kernel(FwdArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const Dims d{g.S, N1_ ? 16 * N1_ : g.h1, N2_ ? 16 * N2_ : g.h2, 1};
+    const int S = d.S, ns = NS_ ? NS_ : (S + 15) >> 4, n1 = d.h1 >> 4, n2 = d.h2 >> 4;
+    float *W2c = smem, *W1c = W2c + kFwdW, *W3c = W1c + kFwdW, *sb = W3c + kFwdW3;
+    const int ld1 = lds_ld(16 * ns), ld2 = lds_ld(d.h1), ld3 = lds_ld(d.h2);
+
+    const int64_t ntiles = (g.rows + 15) / 16;
+    int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    float4 XR[8];
+    {
+        const int64_t row = min(tile * 16 + l15, g.rows - 1);
+        load_rows_raw<VEC>(XR, g.states + row * S, ns, S, q);
+    }
+    load_network<VEC, NW>(g, d, ns, W2c, W1c, W3c, sb, tid);
+    lds_barrier();
+    for (; tile < ntiles; tile += tstep) {
+        const int64_t row = tile * 16 + l15;
+        const bool valid = row < g.rows;
+        f32x4 X[8], H1[8], H2[8], Y[8], dummy[8];
+        normalise_rows<VEC>(XR, X, g.avg, g.sd, ns, S, q, valid);
+        if (tile + tstep < ntiles) {   // prefetch the next tile's rows under this tile's MFMAs
+            const int64_t nrow = min((tile + tstep) * 16 + l15, g.rows - 1);
+            load_rows_raw<VEC>(XR, g.states + nrow * S, ns, S, q);
+        }
+        forward_layer<true, NS_, false>(W1c, ld1, sb, ns, n1, X, H1, dummy, l15, q);
+        forward_layer<true, N1_, false>(W2c, ld2, sb + 128, n1, n2, H1, H2, dummy, l15, q);
+        forward_layer<false, N2_>(W3c, ld3, sb + 256, n2, 1, H2, Y, dummy, l15, q);
+        if (valid && q == 0) g.values[row] = Y[0][0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------------------------------------
+template <int NS_, int N1_, int N2_, bool VEC>
+__global__ __launch_bounds__(256) void rollout_step2_kernel(FwdArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const Dims d{g.S, N1_ ? 16 * N1_ : g.h1, N2_ ? 16 * N2_ : g.h2, g.out};
+    const int S = d.S, A = d.out, ns = NS_ ? NS_ : (S + 15) >> 4, n1 = d.h1 >> 4, n2 = d.h2 >> 4;
+    float *W2c = smem, *W1c = W2c + kFwdW, *W3c = W1c + kFwdW, *sb = W3c + kFwdW3;
+    const int ld1 = lds_ld(16 * ns), ld2 = lds_ld(d.h1), ld3 = lds_ld(d.h2);
+    const float *std_log = g.P + d.oStd();
+
+    const int64_t env = ((int64_t)blockIdx.x * NW + wave) * 16 + l15;
+    const bool valid = env < g.rows;
+    const int64_t row = valid ? env : g.rows - 1;
+    float4 XR[8];
+    load_rows_raw<VEC>(XR, g.states + row * S, ns, S, q);
+    // this lane's action slots a = 4 q + r: noise and std
+    float eps[4], sl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a = 4 * q + r, ac = min(a, A - 1);
+        sl[r] = std_log[ac];
+        eps[r] = g.noise ? g.noise[row * A + ac] : philox_normal(g.seed, g.counter, (uint32_t)row, (uint32_t)ac);
+    }
+    load_network<VEC, NW>(g, d, ns, W2c, W1c, W3c, sb, tid);
+    if (g.o_state && valid) {   // states[t] = state: raw rows, the lane's 4-float groups
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < ns) {
+                const int k0 = 16 * t + 4 * q;
+                float *dst = g.o_state + row * S + k0;
+                if (VEC) { if (k0 < S) *reinterpret_cast<float4 *>(dst) = XR[t]; }
+                else {
+                    const float xr[4] = {XR[t].x, XR[t].y, XR[t].z, XR[t].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (k0 + c < S) dst[c] = xr[c];
+                }
+            }
+        }
+    }
+    f32x4 X[8], H1[8], H2[8], Y[8], dummy[8];
+    normalise_rows<VEC>(XR, X, g.avg, g.sd, ns, S, q, valid);
+    lds_barrier();
+    forward_layer<true, NS_, false>(W1c, ld1, sb, ns, n1, X, H1, dummy, l15, q);
+    forward_layer<true, N1_, false>(W2c, ld2, sb + 128, n1, n2, H1, H2, dummy, l15, q);
+    forward_layer<false, N2_>(W3c, ld3, sb + 256, n2, 1, H2, Y, dummy, l15, q);
+
+    // sample: a = mean + std * eps (torch.normal(mean, std)); Normal.log_prob summed over the action dims
+    float lp = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a = 4 * q + r;
+        const bool on = a < A;
+        const float sdv = expf(sl[r]), var = sdv * sdv;
+        const float act = Y[0][r] + sdv * eps[r];
+        const float diff = act - Y[0][r];
+        const float term = -(diff * diff) / (2.f * var) - logf(sdv) - kLogSqrt2PiF;
+        lp += on ? term : 0.f;
+        if (on && valid) {
+            if (g.o_action) g.o_action[row * A + a] = act;
+            if (g.o_env) g.o_env[row * A + a] = tanhf(act);   // convert_action_for_env
+        }
+    }
+    lp += __shfl_xor(lp, 16, 64);
+    lp += __shfl_xor(lp, 32, 64);
+    if (valid && q == 0 && g.o_logprob) g.o_logprob[row] = lp;
 }
 
 // sum the per-workgroup slabs into the flat gradient.  Deterministic: element e is summed by 4 threads (slab
@@ -152,13 +233,6 @@ __global__ void selftest_kernel(const float *A, const float *B, int K, float *C)
     for (int r = 0; r < 16; ++r) C[crow(r, hi) * 32 + l31] = acc[r];
 }
 
-template <typename Kern>
-int set_lds(Kern kern, size_t bytes)
-{
-    if (bytes <= 64 * 1024) return ERL_OK;
-    return erl_hip_status(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
-                          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-}
 
 int num_cus()
 {
@@ -172,30 +246,57 @@ int num_cus()
     return cus;
 }
 
+template <typename Kern>
+int prep_lds(Kern kern, bool *done)
+{
+    if (*done) return ERL_OK;
+    int rc = erl_hip_status(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLdsBytes),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (!rc) *done = true;
+    return rc;
+}
+
+bool vec_ok(const FwdArgs &g)
+{
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return (g.S % 4 == 0) && al(g.P) && al(g.states) && al(g.avg) && al(g.sd) && (!g.o_state || al(g.o_state));
+}
+
 }  // namespace
 
 extern "C" int64_t erl_mlp_param_count(int S, int h1, int h2, int out, int with_std_log)
 {
-    if (!dims_ok(S, h1, h2, out)) return -1;
-    return MlpDims{S, h1, h2, out}.count(with_std_log != 0);
+    if (!mlp_dims_ok(S, h1, h2, out)) return -1;
+    return Dims{S, h1, h2, out}.count(with_std_log != 0);
 }
 
 extern "C" int erl_value_forward_f32(const float *critic_params, const float *state_avg, const float *state_std, int S, int h1,
                                      int h2, const float *states, int64_t rows, float *values, void *stream)
 {
     ERL_REQUIRE(critic_params && state_avg && state_std && states && values, "erl_value_forward_f32: NULL tensor");
-    ERL_REQUIRE(dims_ok(S, h1, h2, 1), "erl_value_forward_f32: unsupported dims S=%d net=[%d,%d]", S, h1, h2);
+    ERL_REQUIRE(mlp_dims_ok(S, h1, h2, 1), "erl_value_forward_f32: unsupported dims S=%d net=[%d,%d]", S, h1, h2);
     ERL_REQUIRE(rows >= 0, "erl_value_forward_f32: rows < 0");
     if (rows == 0) return ERL_OK;
-    MlpDims d{S, h1, h2, 1};
-    constexpr int M = 64, NW = 8;
-    const size_t lds = fwd_lds_floats<M>(d) * sizeof(float);
-    int rc = set_lds(value_forward_kernel<M, NW>, lds);
-    if (rc) return rc;
-    int64_t tiles = erl_cdiv(rows, M);
-    const int grid = (int)(tiles < num_cus() ? tiles : num_cus());
-    hipLaunchKernelGGL((value_forward_kernel<M, NW>), dim3(grid), dim3(NW * 64), lds, (hipStream_t)stream, critic_params,
-                       state_avg, state_std, d, states, rows, values);
+    FwdArgs g{};
+    g.P = critic_params; g.avg = state_avg; g.sd = state_std;
+    g.S = S; g.h1 = h1; g.h2 = h2; g.out = 1;
+    g.states = states; g.rows = rows; g.values = values;
+    const int64_t tiles = erl_cdiv(rows, 16);
+    const int64_t want = erl_cdiv(tiles, 8);
+    const int grid = (int)(want < num_cus() ? want : num_cus());
+    const bool vec = vec_ok(g);
+    const int ns = (S + 15) / 16;
+    static bool d0 = false, d1 = false, d2 = false;
+    int rc;
+#define VF_LAUNCH(K, FLAG)                                                                        \
+    do {                                                                                          \
+        if ((rc = prep_lds(K, &FLAG))) return rc;                                                 \
+        hipLaunchKernelGGL(K, dim3(grid), dim3(512), kFwdLdsBytes, (hipStream_t)stream, g);       \
+    } while (0)
+    if (vec && ns == 4 && h1 == 128 && h2 == 128) VF_LAUNCH((value_forward2_kernel<4, 8, 8, true>), d0);
+    else if (vec) VF_LAUNCH((value_forward2_kernel<0, 0, 0, true>), d1);
+    else VF_LAUNCH((value_forward2_kernel<0, 0, 0, false>), d2);
+#undef VF_LAUNCH
     ERL_LAUNCH_CHECK("erl_value_forward_f32");
 }
 
@@ -205,20 +306,32 @@ extern "C" int erl_rollout_step_f32(const float *actor_params, const float *stat
                                     float *out_action_env, void *stream)
 {
     ERL_REQUIRE(actor_params && state_avg && state_std && state, "erl_rollout_step_f32: NULL tensor");
-    ERL_REQUIRE(dims_ok(S, h1, h2, A), "erl_rollout_step_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
+    ERL_REQUIRE(mlp_dims_ok(S, h1, h2, A), "erl_rollout_step_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
     ERL_REQUIRE(N >= 1, "erl_rollout_step_f32: N < 1");
-    MlpDims d{S, h1, h2, A};
-    constexpr int M = 32, NW = 4;
-    const size_t lds = fwd_lds_floats<M>(d) * sizeof(float);
-    int rc = set_lds(rollout_step_kernel<M, NW>, lds);
-    if (rc) return rc;
-    int64_t tiles = erl_cdiv(N, M);
-    const int grid = (int)(tiles < 2 * num_cus() ? tiles : 2 * num_cus());
-    hipLaunchKernelGGL((rollout_step_kernel<M, NW>), dim3(grid), dim3(NW * 64), lds, (hipStream_t)stream, actor_params, state_avg,
-                       state_std, d, state, N, noise, seed, counter, out_state_row, out_action_row, out_logprob_row,
-                       out_action_env);
+    FwdArgs g{};
+    g.P = actor_params; g.avg = state_avg; g.sd = state_std;
+    g.S = S; g.h1 = h1; g.h2 = h2; g.out = A;
+    g.states = state; g.rows = N;
+    g.noise = noise; g.seed = seed; g.counter = counter;
+    g.o_state = out_state_row; g.o_action = out_action_row; g.o_logprob = out_logprob_row; g.o_env = out_action_env;
+    const int grid = (int)erl_cdiv(N, 64);
+    const bool vec = vec_ok(g);
+    const int ns = (S + 15) / 16;
+    static bool d0 = false, d1 = false, d2 = false;
+    int rc;
+#define RS_LAUNCH(K, FLAG)                                                                        \
+    do {                                                                                          \
+        if ((rc = prep_lds(K, &FLAG))) return rc;                                                 \
+        hipLaunchKernelGGL(K, dim3(grid), dim3(256), kFwdLdsBytes, (hipStream_t)stream, g);       \
+    } while (0)
+    if (vec && ns == 4 && h1 == 128 && h2 == 128) RS_LAUNCH((rollout_step2_kernel<4, 8, 8, true>), d0);
+    else if (vec) RS_LAUNCH((rollout_step2_kernel<0, 0, 0, true>), d1);
+    else RS_LAUNCH((rollout_step2_kernel<0, 0, 0, false>), d2);
+#undef RS_LAUNCH
     ERL_LAUNCH_CHECK("erl_rollout_step_f32");
 }
+
+
 
 extern "C" int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, void *stream)
 {
