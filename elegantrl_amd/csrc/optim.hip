@@ -87,7 +87,7 @@ extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_a
         ERL_REQUIRE(gr.off[i] >= 0 && gr.len[i] >= 0, "erl_clip_adam_f32: negative group bounds");
         if (gr.len[i] > longest) longest = gr.len[i];
     }
-    int bx = (int)erl_cdiv(longest, 4096);
+    int bx = (int)erl_cdiv(longest, 1024);   // one element per thread in the Adam phase (latency bound: no serial loop)
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
     float step_size = 0.f, bc2_sqrt = 1.f;

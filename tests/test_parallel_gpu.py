@@ -1,0 +1,70 @@
+"""Data-parallel AgentPPO end to end on the real kernels: two ranks share the one GPU of the test box (RCCL refuses
+two ranks per device, so the collective backend here is gloo on CUDA tensors; the code path in AgentPPO /
+parallel.py is the one the 8-GPU run takes with backend "nccl").  Checks: identical initial weights after the
+broadcast, the job-wide advantage statistics, one flat-gradient all-reduce per minibatch, and that both ranks hold
+bit-identical weights after two iterations although they rolled out different env shards."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch as th
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from elegantrl_amd import parallel
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config
+    parallel.init_from_env(backend="gloo")
+    th.cuda.set_device(0)
+    N, S, A, H, B = 256, 64, 8, 16, 1024
+    args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
+                                        "if_discrete": False})
+    args.horizon_len, args.batch_size, args.repeat_times = H, B, 3 * B / H
+    args.learning_rate, args.random_seed = 1e-3, 5
+    args.world_size, args.rank, args.gpu_id = world, rank, 0
+    th.manual_seed(100 + rank)                                  # ranks start from DIFFERENT weights on purpose
+    agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
+    parallel.broadcast_(agent._flat)
+    w0 = agent._flat.clone()
+    env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=7919 * rank)
+    agent.last_state = env.reset()[0]
+    logs = []
+    for _ in range(2):
+        items = agent.explore_env(env, H)
+        logs.append(agent.update_net(list(items)))
+    np.save(os.path.join(out_dir, f"w0_{rank}.npy"), w0.cpu().numpy())
+    np.save(os.path.join(out_dir, f"w_{rank}.npy"), agent._flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"stats_{rank}.npy"), agent._stats.cpu().numpy())
+    np.save(os.path.join(out_dir, f"rew_{rank}.npy"), items[3].cpu().numpy())
+    np.save(os.path.join(out_dir, f"logs_{rank}.npy"), np.array(logs))
+    parallel.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_agent_stays_in_lockstep(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ld = lambda n: [np.load(tmp_path / f"{n}_{r}.npy") for r in range(world)]   # noqa: E731
+    w0, w, stats, rew, logs = ld("w0"), ld("w"), ld("stats"), ld("rew"), ld("logs")
+    np.testing.assert_array_equal(w0[0], w0[1])                       # broadcast
+    assert not np.array_equal(rew[0], rew[1])                         # different env shards were rolled out
+    np.testing.assert_array_equal(stats[0], stats[1])                 # job-wide advantage sums
+    assert stats[0][1] == 2 * 16 * 256                                # counts add up over both shards
+    assert not np.array_equal(w[0], w0[0])                            # training moved the weights ...
+    np.testing.assert_array_equal(w[0], w[1])                         # ... identically on both ranks
+    np.testing.assert_allclose(logs[0], logs[1], rtol=1e-6)           # logged objectives are global means
+    assert np.isfinite(w[0]).all() and np.isfinite(logs[0]).all()
