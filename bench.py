@@ -97,6 +97,19 @@ def gae_sweep(ops, dev):
     return out
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); None when the file does not carry the kernel."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        for name, v in prof["kernels"].items():
+            if name.startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -190,8 +203,9 @@ def main():
     env = SynVecEnv(N_ENVS, STATE_DIM, ACTION_DIM, max_step=1000, gpu_id=local_rank, seed=7919 * rank)
     agent.last_state = env.reset()[0]
 
+    from elegantrl_amd import _hip
     t_ppo, t_gae = EventTimer(), EventTimer()
-    ops.ppo_step = t_ppo.wrap(ops.ppo_step)
+    ops.ppo_step = t_ppo.wrap(ops.ppo_step)      # N > 1: the minibatch loop runs in Python (all-reduce in the middle)
     ops.gae_scan = t_gae.wrap(ops.gae_scan)
 
     def step():
@@ -203,6 +217,7 @@ def main():
         step()
     log("timed region")
     t_ppo.enabled = t_gae.enabled = True
+    _hip.k6_timing_enable(True)                  # N = 1: the loop runs inside erl_ppo_update_f32, which records the events
     parallel.barrier()
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -212,13 +227,19 @@ def main():
     parallel.barrier()
     elapsed = parallel.all_reduce_max_float(time.perf_counter() - t0, device=dev)
     t_ppo.enabled = t_gae.enabled = False
+    _hip.k6_timing_enable(False)
+    k6_seconds, k6_launches = _hip.k6_timing_read()
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
     if rank != 0:
         return
     env_steps = world * N_ENVS * HORIZON * opt.steps
     flops = ppo_flops_per_sample(STATE_DIM, *NET_DIMS, ACTION_DIM) * BATCH
-    ppo_s, gae_s = t_ppo.mean_seconds(), t_gae.mean_seconds()
+    if k6_launches:
+        ppo_s, n_k6 = k6_seconds / k6_launches, k6_launches
+    else:
+        ppo_s, n_k6 = t_ppo.mean_seconds(), len(t_ppo.pairs)
+    gae_s = t_gae.mean_seconds()
     line = {
         "metric": "env_steps_per_sec_ppo_4096envs_obs64", "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
@@ -229,8 +250,8 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         "roofline": {"kernel": "ppo_step2_kernel", "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     "traffic": None, "flops_per_launch": flops, "avg_launch_us": round(ppo_s * 1e6, 2),
-                     "launches_timed": len(t_ppo.pairs)},
+                     "traffic": pmc_traffic("ppo_step2_kernel"), "flops_per_launch": flops,
+                     "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6},
         "roofline_gae": {"kernel": "gae_exact_kernel (in-loop 32x4096)", "bound": "hbm",
                          "achieved": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -239,7 +260,12 @@ def main():
     }
     if not opt.no_gae_sweep:
         log("GAE size sweep")
-        line["roofline_gae"]["sweep"] = gae_sweep(ops, dev)
+        sweep = gae_sweep(ops, dev)
+        line["roofline_gae"]["sweep"] = sweep
+        big = next(x for x in sweep if (x["H"], x["N"]) == (2048, 4096))
+        line["roofline_gae"]["at_2048x4096"] = {"kernel": "gae_lookback_kernel (+ slot memset)", "achieved": big["GBps"],
+                                                "frac": big["frac"], "us": big["us"], "bytes_per_launch": big["bytes"],
+                                                "traffic": pmc_traffic("gae_lookback_kernel")}
     if world == 1 and not opt.no_cpu_baseline:
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
         line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters)

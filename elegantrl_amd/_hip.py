@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liberl_hip.so")
 GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P = c_void_p
 _SIGNATURES = {
@@ -49,6 +49,11 @@ _SIGNATURES = {
     "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),
     "erl_clip_adam_f32": (c_int, [_P, _P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, _P, c_int32, c_float,
                                   c_float, c_float, c_float, c_float, c_float, _P]),
+    "erl_ppo_update_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
+                                   _P, c_int64, c_int, c_float, c_float, _P, _P, c_int32, c_float, c_float, c_float, c_float, c_float,
+                                   _P]),
+    "erl_k6_timing_enable": (None, [c_int]),
+    "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_synenv_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_uint64, _P]),
     "erl_pendulum_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_uint64, _P]),
     "erl_selftest_mfma": (c_int, [POINTER(c_float)]),
@@ -116,6 +121,17 @@ def device_info():
     cu, lds = c_int(0), c_int(0)
     check(lib().erl_device_info(ctypes.byref(cu), ctypes.byref(lds)), "erl_device_info")
     return cu.value, lds.value
+
+
+def k6_timing_enable(on: bool) -> None:
+    lib().erl_k6_timing_enable(int(on))
+
+
+def k6_timing_read():
+    """(seconds summed over the K6 launches recorded since the last read, number of launches)."""
+    ms, n = ctypes.c_double(0), c_int(0)
+    check(lib().erl_k6_timing_read(ctypes.byref(ms), ctypes.byref(n)), "erl_k6_timing_read")
+    return ms.value * 1e-3, n.value
 
 
 def selftest_mfma() -> float:

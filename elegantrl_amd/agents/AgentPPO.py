@@ -185,19 +185,43 @@ class AgentPPO(AgentBase):
         state = self.last_state
         assert state.shape == (N, S), f"last_state {tuple(state.shape)} != {(N, S)}"
         state = state.to(dev, th.float32).contiguous()
-        for t in range(H):
-            ops.rollout_step(P, spec, avg, std, state, noise=None if noise is None else noise[t], seed=self.rng_seed,
-                             counter=self.rng_counter, out_state=states[t], out_action=actions[t],
-                             out_logprob=logprobs[t], out_env_action=env_action)
-            self.rng_counter += 1
-            if native:     # GPU-resident env writes its outputs straight into row t (no copies, no host sync)
-                state = env.step_into(env_action, rewards[t], terminals[t], truncates[t])
-            else:          # any env honouring the reference protocol (device tensors, auto-reset)
-                state, reward, terminal, truncate, _ = env.step(env_action)
-                state = state.to(dev, th.float32).contiguous()
-                rewards[t] = reward
-                terminals[t] = terminal
-                truncates[t] = truncate
+        if hasattr(env, "raw_stepper") and state.data_ptr() != env.state.data_ptr():
+            env.state.copy_(state)                 # the env owns the live state buffer; keep it authoritative
+        if hasattr(env, "raw_stepper"):
+            # GPU-resident env: both launches of a step go straight to the C ABI on raw pointers (no tensor views, no
+            # per-call argument checks on the interpreter's launch path)
+            fn = _hip.lib().erl_rollout_step_f32
+            env_step = env.raw_stepper()
+            sp = _hip.stream_ptr()
+            pP, pavg, pstd, pst, pea = (_hip.ptr(x, th.float32) for x in (P, avg, std, env.state, env_action))
+            p_s, p_a, p_l, p_r = states.data_ptr(), actions.data_ptr(), logprobs.data_ptr(), rewards.data_ptr()
+            p_te, p_tr = terminals.data_ptr(), truncates.data_ptr()
+            p_n = None if noise is None else _hip.ptr(noise.contiguous(), th.float32)
+            h1, h2 = spec.h1, spec.h2
+            seed = self.rng_seed & (2 ** 64 - 1)
+            for t in range(H):
+                rc = fn(pP, pavg, pstd, S, h1, h2, A, pst, N, None if p_n is None else p_n + 4 * t * N * A, seed,
+                        self.rng_counter & (2 ** 64 - 1), p_s + 4 * t * N * S, p_a + 4 * t * N * A, p_l + 4 * t * N, pea, sp)
+                if rc:
+                    _hip.check(rc, "erl_rollout_step_f32")
+                self.rng_counter += 1
+                env_step(pea, p_r + 4 * t * N, p_te + t * N, p_tr + t * N, sp)
+            state = env.state
+            native = True
+        else:
+            for t in range(H):
+                ops.rollout_step(P, spec, avg, std, state, noise=None if noise is None else noise[t], seed=self.rng_seed,
+                                 counter=self.rng_counter, out_state=states[t], out_action=actions[t],
+                                 out_logprob=logprobs[t], out_env_action=env_action)
+                self.rng_counter += 1
+                if native:     # GPU-resident env writes its outputs straight into row t (no copies, no host sync)
+                    state = env.step_into(env_action, rewards[t], terminals[t], truncates[t])
+                else:          # any env honouring the reference protocol (device tensors, auto-reset)
+                    state, reward, terminal, truncate, _ = env.step(env_action)
+                    state = state.to(dev, th.float32).contiguous()
+                    rewards[t] = reward
+                    terminals[t] = terminal
+                    truncates[t] = truncate
         self.last_state = state.clone() if native else state
         rewards *= self.reward_scale
         undones = th.logical_not(terminals)
@@ -296,18 +320,24 @@ class AgentPPO(AgentBase):
         inv_batch = 1.0 / B
         grad_scale = 1.0 / self.world_size
         h1, h2 = self.net_dims
-        for k in range(update_times):
-            ops.ppo_step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
-                         c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
-                         advantages, reward_sums, ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch,
-                         self._slabs, n_slabs)
-            g = self._grads[k]
-            ops.grad_reduce(self._slabs, n_slabs, self._stride, g)
-            if self.world_size > 1:
+        if self.world_size == 1:        # the whole minibatch loop is enqueued by one C call (no interpreter on the launch path)
+            ops.ppo_update(self._flat, self._exp_avg, self._exp_avg_sq, a.state_avg.data, a.state_std.data, c.state_avg.data,
+                           c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
+                           advantages, reward_sums, ids, float(self.ratio_clip), self.lambda_entropy_value, self._slabs,
+                           self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm))
+            self._adam_step += update_times
+        else:                           # data parallel: the gradient all-reduce sits between slab reduction and optimiser
+            for k in range(update_times):
+                ops.ppo_step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
+                             c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
+                             advantages, reward_sums, ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch,
+                             self._slabs, n_slabs)
+                g = self._grads[k]
+                ops.grad_reduce(self._slabs, n_slabs, self._stride, g)
                 parallel.all_reduce_sum(g)                                             # RCCL over xGMI
-            self._adam_step += 1
-            ops.clip_adam(self._flat, g, self._exp_avg, self._exp_avg_sq, groups, self._adam_step, float(self.learning_rate),
-                          float(self.clip_grad_norm), grad_scale=grad_scale)
+                self._adam_step += 1
+                ops.clip_adam(self._flat, g, self._exp_avg, self._exp_avg_sq, groups, self._adam_step, float(self.learning_rate),
+                              float(self.clip_grad_norm), grad_scale=grad_scale)
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
         logs = self._grads[:update_times, self._Pa + self._Pc:self._Pa + self._Pc + 3].mean(dim=0) * grad_scale
         obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())           # the only host sync of update_net

@@ -30,3 +30,74 @@ extern "C" int erl_device_info(int *num_cu, int *lds_bytes_per_block)
     if (lds_bytes_per_block) *lds_bytes_per_block = (int)prop.maxSharedMemoryPerMultiProcessor;
     return ERL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Host-side batching: one C call enqueues a whole PPO update (update_times x [K6, slab reduce, clip + Adam]) so
+// that the Python interpreter is off the launch path (about 3 us per launch from here instead of about 10 from
+// ctypes).  Single-process path only: under data parallelism the gradient all-reduce sits between the slab
+// reduction and the optimiser step and the loop stays in Python.
+// ---------------------------------------------------------------------------------------------------------
+// optional per-launch timing of K6 inside erl_ppo_update_f32 (measurement hook for bench.py: HIP events on the launch
+// stream around every K6 launch; off by default).  The event pairs are kept until erl_k6_timing_read() drains them.
+#include <vector>
+static bool g_k6_timing = false;
+static std::vector<hipEvent_t> g_k6_events;
+
+extern "C" void erl_k6_timing_enable(int on) { g_k6_timing = on != 0; }
+
+// waits for the recorded events, returns the summed K6 time in milliseconds and the number of launches, and clears.
+extern "C" int erl_k6_timing_read(double *total_ms, int *launches)
+{
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < g_k6_events.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_k6_events[i + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_k6_events[i], g_k6_events[i + 1]) == hipSuccess) {
+            tot += ms;
+            ++n;
+        }
+        (void)hipEventDestroy(g_k6_events[i]);
+        (void)hipEventDestroy(g_k6_events[i + 1]);
+    }
+    g_k6_events.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return ERL_OK;
+}
+
+extern "C" int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg, const float *act_std,
+                                  const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
+                                  const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
+                                  const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
+                                  int update_times, float ratio_clip, float lambda_entropy, float *slabs, float *grads,
+                                  int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, void *stream)
+{
+    ERL_REQUIRE(flat_params && exp_avg && exp_avg_sq && ids && slabs && grads, "erl_ppo_update_f32: NULL tensor");
+    ERL_REQUIRE(update_times >= 1 && first_step >= 1 && B >= 1, "erl_ppo_update_f32: bad argument");
+    const int64_t Pa = erl_mlp_param_count(S, h1, h2, A, 1), Pc = erl_mlp_param_count(S, h1, h2, 1, 0);
+    ERL_REQUIRE(Pa > 0 && Pc > 0, "erl_ppo_update_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
+    const int64_t stride = Pa + Pc + 4;
+    const int n_slabs = erl_ppo_num_slabs(B);
+    const int64_t off[2] = {0, Pa}, len[2] = {Pa, Pc};
+    for (int k = 0; k < update_times; ++k) {
+        float *g = grads + (size_t)k * stride;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_k6_timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+            (void)hipEventRecord(e0, (hipStream_t)stream);
+        int rc = erl_ppo_step_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
+                                  unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
+                                  lambda_entropy, 1.0f / (float)B, slabs, n_slabs, stream);
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, (hipStream_t)stream);
+            g_k6_events.push_back(e0);
+            g_k6_events.push_back(e1);
+        }
+        if (rc) return rc;
+        if ((rc = erl_grad_reduce_f32(slabs, n_slabs, stride, g, stream))) return rc;
+        if ((rc = erl_clip_adam_f32(flat_params, g, exp_avg, exp_avg_sq, off, len, 2, nullptr, first_step + k, lr, beta1, beta2, eps,
+                                    max_norm, 1.0f, stream)))
+            return rc;
+    }
+    return ERL_OK;
+}

@@ -69,6 +69,20 @@ class SynVecEnv(_GpuVecEnv):
                         truncate_row, self.max_step, self.seed)
         return self.state
 
+    def raw_stepper(self):
+        """`step(action_ptr, reward_ptr, terminal_ptr, truncate_ptr, stream)` on raw device pointers (the rollout's
+        per-step fast path: no tensor views, no argument checks); the state lives in `self.state` (fixed address)."""
+        from .. import _hip
+        fn = _hip.lib().erl_synenv_step_f32
+        st, ws, wa, sc, ep = (t.data_ptr() for t in (self.state, self.Ws, self.Wa, self.step_count, self.episode))
+        n, s, a, ms, seed = self.num_envs, self.state_dim, self.action_dim, self.max_step, self.seed & (2 ** 64 - 1)
+
+        def step(action_ptr, reward_ptr, terminal_ptr, truncate_ptr, stream):
+            rc = fn(st, action_ptr, ws, wa, sc, ep, reward_ptr, terminal_ptr, truncate_ptr, n, s, a, ms, seed, stream)
+            if rc:
+                _hip.check(rc, "erl_synenv_step_f32")
+        return step
+
 
 class PendulumVecEnv(_GpuVecEnv):
     """Pendulum-v1 (g=10, m=l=1, dt=0.05, 200-step truncation) behind the reference wrapper's scaling
@@ -94,3 +108,15 @@ class PendulumVecEnv(_GpuVecEnv):
         ops.pendulum_step(self.phys, self.state, action, self.step_count, self.episode, reward_row, terminal_row,
                           truncate_row, self.max_step, self.seed)
         return self.state
+
+    def raw_stepper(self):
+        from .. import _hip
+        fn = _hip.lib().erl_pendulum_step_f32
+        ph, ob, sc, ep = (t.data_ptr() for t in (self.phys, self.state, self.step_count, self.episode))
+        n, ms, seed = self.num_envs, self.max_step, self.seed & (2 ** 64 - 1)
+
+        def step(action_ptr, reward_ptr, terminal_ptr, truncate_ptr, stream):
+            rc = fn(ph, ob, action_ptr, sc, ep, reward_ptr, terminal_ptr, truncate_ptr, n, ms, seed, stream)
+            if rc:
+                _hip.check(rc, "erl_pendulum_step_f32")
+        return step

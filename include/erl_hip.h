@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 2
+#define ERL_ABI_VERSION 3
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -175,6 +175,24 @@ ERL_API int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg,
                       const int64_t *group_off, const int64_t *group_len, int n_groups, const int32_t *step_base,
                       int32_t step_offset, float lr, float beta1, float beta2, float eps, float max_norm,
                       float grad_scale, void *stream);
+
+/* Whole PPO update in one call (single-process path): for k in [0, update_times):
+ *   erl_ppo_step_f32(ids + k*B) -> erl_grad_reduce_f32 -> grads[k] -> erl_clip_adam_f32(step = first_step + k).
+ * Replaces the minibatch loop of AgentPPO.update_net (AgentPPO.py:158-167).  flat_params / exp_avg / exp_avg_sq hold
+ * [actor (Pa) | critic (Pc)]; grads: (update_times, erl_ppo_slab_stride) -- row k keeps minibatch k's summed gradient
+ * and its three objective values in the tail; slabs: (erl_ppo_num_slabs(B), erl_ppo_slab_stride) scratch. */
+ERL_API int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg,
+                       const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
+                       const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
+                       const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
+                       int64_t B, int update_times, float ratio_clip, float lambda_entropy, float *slabs,
+                       float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
+                       float max_norm, void *stream);
+
+/* measurement hook: when enabled, erl_ppo_update_f32 brackets every K6 launch with HIP events on the launch stream;
+ * erl_k6_timing_read waits for them, returns the summed time (ms) and the launch count, and clears the list. */
+ERL_API void erl_k6_timing_enable(int on);
+ERL_API int erl_k6_timing_read(double *total_ms, int *launches);
 
 /* ---------------------------------------------------------------------------------------------
  * GPU-resident synthetic environments for measurement; they implement the
