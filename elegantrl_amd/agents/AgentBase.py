@@ -146,14 +146,86 @@ class AgentBase:
     def explore_one_env(self, env, horizon_len: int):
         return self._explore_one_env(env=env, horizon_len=horizon_len)
 
-    def _explore_vec_env(self, env, horizon_len: int):
+    # ---- off-policy defaults (overridden by the on-policy agents): AgentBase.py:76-189 of the reference ----------
+    def explore_action(self, state: TEN) -> TEN:
+        return self.act.get_action(state)
+
+    def _explore_vec_env(self, env, horizon_len: int, noise: Optional[TEN] = None) -> Tuple[TEN, ...]:
+        """off-policy vectorised rollout -> (states, actions, rewards, undones, unmasks), time-major (H, N, .); the
+        already-squashed action is both stored and sent to the env (AgentBase.py:130-170).  GPU-resident envs write
+        reward / terminal / truncate straight into row t (`step_into`)."""
+        H, N, dev = horizon_len, self.num_envs, self.device
+        states = th.zeros((H, N, self.state_dim), dtype=th.float32, device=dev)
+        actions = th.zeros((H, N, self.action_dim), dtype=th.float32, device=dev)
+        rewards = th.zeros((H, N), dtype=th.float32, device=dev)
+        terminals = th.zeros((H, N), dtype=th.bool, device=dev)
+        truncates = th.zeros((H, N), dtype=th.bool, device=dev)
+        native = hasattr(env, "step_into")
+        state = self.last_state.to(dev, th.float32)
+        assert state.shape == (N, self.state_dim)
+        for t in range(H):
+            action = self.explore_action(state) if noise is None else self.explore_action(state, noise[t])
+            states[t] = state
+            actions[t] = action
+            if native:
+                state = env.step_into(action.contiguous(), rewards[t], terminals[t], truncates[t])
+            else:
+                state, reward, terminal, truncate, _ = env.step(action)
+                state = state.to(dev, th.float32)
+                rewards[t] = reward
+                terminals[t] = terminal
+                truncates[t] = truncate
+        self.last_state = state.clone() if native else state
+        rewards *= self.reward_scale
+        return states, actions, rewards, th.logical_not(terminals), th.logical_not(truncates)
+
+    def _explore_one_env(self, env, horizon_len: int) -> Tuple[TEN, ...]:
+        """single numpy env (AgentBase.py:76-128): same 5-tuple with a middle dimension of 1."""
+        H, dev = horizon_len, self.device
+        states = th.zeros((H, 1, self.state_dim), dtype=th.float32, device=dev)
+        actions = th.zeros((H, 1, self.action_dim), dtype=th.float32, device=dev)
+        rewards = th.zeros((H, 1), dtype=th.float32, device=dev)
+        terminals = th.zeros((H, 1), dtype=th.bool, device=dev)
+        truncates = th.zeros((H, 1), dtype=th.bool, device=dev)
+        state = self.last_state.to(dev, th.float32).reshape(1, self.state_dim)
+        for t in range(H):
+            action = self.explore_action(state)
+            states[t], actions[t] = state, action
+            ary_state, reward, terminal, truncate, _ = env.step(action[0].detach().cpu().numpy())
+            if terminal or truncate:
+                ary_state, _ = env.reset()
+            state = th.as_tensor(ary_state, dtype=th.float32, device=dev).reshape(1, self.state_dim)
+            rewards[t, 0], terminals[t, 0], truncates[t, 0] = float(reward), bool(terminal), bool(truncate)
+        self.last_state = state
+        rewards *= self.reward_scale
+        return states, actions, rewards, th.logical_not(terminals), th.logical_not(truncates)
+
+    def update_net(self, buffer) -> Tuple[float, ...]:
+        """off-policy update loop (AgentBase.py:172-189): `update_times = int(cur_size * repeat_times / batch_size)` steps of
+        `update_objectives`, each drawing one minibatch through ReplayBuffer.sample (HIP K9)."""
+        import numpy as np
+        objs_critic, objs_actor = [], []
+        if self.lambda_fit_cum_r != 0:
+            buffer.update_cum_rewards(get_cumulative_rewards=self.get_cumulative_rewards)
+        th.set_grad_enabled(True)
+        update_times = int(buffer.cur_size * self.repeat_times / self.batch_size)
+        for update_t in range(update_times):
+            obj_critic, obj_actor = self.update_objectives(buffer=buffer, update_t=update_t)
+            objs_critic.append(obj_critic)
+            if isinstance(obj_actor, float):
+                objs_actor.append(obj_actor)
+        th.set_grad_enabled(False)
+        return (float(np.nanmean(objs_critic)) if objs_critic else 0.0, float(np.nanmean(objs_actor)) if objs_actor else 0.0)
+
+    def update_objectives(self, buffer, update_t: int) -> Tuple[float, float]:
         raise NotImplementedError
 
-    def _explore_one_env(self, env, horizon_len: int):
-        raise NotImplementedError
-
-    def update_net(self, buffer):
-        raise NotImplementedError
+    def optimizer_backward(self, optimizer, objective: TEN):
+        """zero_grad, backward, global-norm clip of the optimiser's first param group, step (AgentBase.py:239-248)."""
+        optimizer.zero_grad()
+        objective.backward()
+        th.nn.utils.clip_grad_norm_(parameters=optimizer.param_groups[0]["params"], max_norm=self.clip_grad_norm)
+        optimizer.step()
 
     @staticmethod
     def soft_update(target_net: nn.Module, current_net: nn.Module, tau: float):

@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) void replay_write_kernel(float *__restrict__ b
 
 // Sample: virtual row of width W = 2S + A + 3:
 //   [0,S) state | [S,S+A) action | reward | undone | unmask | [S+A+3, 2S+A+3) next_state = states[t+1, n]
+// A workgroup owns RS_SAMPLES samples: their ring rows are resolved once (one 64-bit division per sample, results in
+// LDS and in ids0/ids1), then all 256 threads stream the RS_SAMPLES x W output elements with 32-bit index math.
+constexpr int RS_SAMPLES = 128;
+
 __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restrict__ b_states,
                                                             const float *__restrict__ b_actions,
                                                             const float *__restrict__ b_rewards,
@@ -102,29 +106,36 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restr
                                                             float *__restrict__ o_next, int64_t *__restrict__ o_ids0,
                                                             int64_t *__restrict__ o_ids1)
 {
+    __shared__ int64_t s_row[RS_SAMPLES];
     const int W = 2 * S + A + 3;
-    const int64_t total = B * W;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t b = e / W;
-        const int c = (int)(e - b * W);
-        const int64_t id = ids[b];
-        const int64_t n = id / sample_len, t = id - n * sample_len;
-        const int64_t row = t * num_seqs + n;
-        if (c < S) {
-            o_state[b * S + c] = b_states[row * S + c];
-        } else if (c < S + A) {
-            o_action[b * A + (c - S)] = b_actions[row * A + (c - S)];
-        } else if (c < S + A + 3) {
-            const int k = c - S - A;
-            if (k == 0) {
-                o_reward[b] = b_rewards[row];
-                if (o_ids0) o_ids0[b] = t;
-                if (o_ids1) o_ids1[b] = n;
-            } else if (k == 1) o_undone[b] = b_undones[row];
-            else o_unmask[b] = b_unmasks[row];
-        } else {
-            const int cs = c - S - A - 3;
-            o_next[b * S + cs] = b_states[(row + num_seqs) * S + cs];
+    for (int64_t b0 = (int64_t)blockIdx.x * RS_SAMPLES; b0 < B; b0 += (int64_t)gridDim.x * RS_SAMPLES) {
+        const int nb = (int)min((int64_t)RS_SAMPLES, B - b0);
+        __syncthreads();   // s_row reuse
+        if ((int)threadIdx.x < nb) {
+            const int64_t id = ids[b0 + threadIdx.x];
+            const int64_t n = id / sample_len, t = id - n * sample_len;   // ids0 = ids % L, ids1 = ids // L  (:124-125)
+            s_row[threadIdx.x] = t * num_seqs + n;
+            if (o_ids0) o_ids0[b0 + threadIdx.x] = t;
+            if (o_ids1) o_ids1[b0 + threadIdx.x] = n;
+        }
+        __syncthreads();
+        const int total = nb * W;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int bl = e / W, c = e - bl * W;
+            const int64_t row = s_row[bl], b = b0 + bl;
+            if (c < S) {
+                o_state[b * S + c] = b_states[row * S + c];
+            } else if (c < S + A) {
+                o_action[b * A + (c - S)] = b_actions[row * A + (c - S)];
+            } else if (c < S + A + 3) {
+                const int k = c - S - A;
+                if (k == 0) o_reward[b] = b_rewards[row];
+                else if (k == 1) o_undone[b] = b_undones[row];
+                else o_unmask[b] = b_unmasks[row];
+            } else {
+                const int cs = c - S - A - 3;
+                o_next[b * S + cs] = b_states[(row + num_seqs) * S + cs];
+            }
         }
     }
 }
@@ -201,7 +212,7 @@ extern "C" int erl_replay_sample_f32(const float *buf_states, const float *buf_a
     ERL_REQUIRE(sample_len >= 1 && sample_len < max_size + 0 && num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0,
                 "erl_replay_sample_f32: bad shape (sample_len=%lld max_size=%lld)", (long long)sample_len, (long long)max_size);
     if (B == 0) return ERL_OK;
-    hipLaunchKernelGGL(replay_sample_kernel, dim3(grid_for(B * (2 * S + A + 3))), dim3(256), 0, (hipStream_t)stream, buf_states,
+    hipLaunchKernelGGL(replay_sample_kernel, dim3(grid_for(erl_cdiv(B, RS_SAMPLES) * 256)), dim3(256), 0, (hipStream_t)stream, buf_states,
                        buf_actions, buf_rewards, buf_undones, buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state,
                        out_action, out_reward, out_undone, out_unmask, out_next_state, out_ids0, out_ids1);
     ERL_LAUNCH_CHECK("erl_replay_sample_f32");

@@ -123,21 +123,25 @@ def replay_write(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undone
 
 def replay_sample(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undones: TEN, buf_unmasks: TEN, ids: TEN,
                   sample_len: int):
+    """ReplayBuffer.sample given the drawn ids: ((state, action, reward, undone, unmask, next_state), (ids0, ids1)).
+    The six outputs are views of ONE allocation (and the two index vectors of another): two allocator calls per
+    sample instead of eight keep the interpreter off the critical path at small batch sizes."""
     max_size, num_seqs, S = buf_states.shape
     A = buf_actions.shape[2]
     B = ids.numel()
     dev = buf_states.device
-    o_s = th.empty((B, S), dtype=th.float32, device=dev)
-    o_n = th.empty((B, S), dtype=th.float32, device=dev)
-    o_a = th.empty((B, A), dtype=th.float32, device=dev)
-    o_r, o_ud, o_um = (th.empty((B,), dtype=th.float32, device=dev) for _ in range(3))
-    i0, i1 = th.empty_like(ids), th.empty_like(ids)
+    flat = th.empty(B * (2 * S + A + 3), dtype=th.float32, device=dev)
+    o_s, o_n, o_a, o_r, o_ud, o_um = th.split(flat, [B * S, B * S, B * A, B, B, B])
+    o_s, o_n, o_a = o_s.view(B, S), o_n.view(B, S), o_a.view(B, A)
+    i01 = th.empty((2, B), dtype=th.int64, device=dev)
+    base, ib = flat.data_ptr(), i01.data_ptr()
     check(lib().erl_replay_sample_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.float32), ptr(buf_rewards, th.float32),
                                       ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), max_size, num_seqs, S, A,
-                                      ptr(ids, th.int64), B, sample_len, ptr(o_s), ptr(o_a), ptr(o_r), ptr(o_ud), ptr(o_um),
-                                      ptr(o_n), ptr(i0), ptr(i1), stream_ptr()),
+                                      ptr(ids, th.int64), B, sample_len, base, base + 8 * B * S, base + 4 * B * (2 * S + A),
+                                      base + 4 * B * (2 * S + A + 1), base + 4 * B * (2 * S + A + 2), base + 4 * B * S,
+                                      ib, ib + 8 * B, stream_ptr()),
           "erl_replay_sample_f32")
-    return (o_s, o_a, o_r, o_ud, o_um, o_n), (i0, i1)
+    return (o_s, o_a, o_r, o_ud, o_um, o_n), (i01[0], i01[1])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -184,6 +184,86 @@ def make_replay():
     print("wrote", path)
 
 
+def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed):
+    """Run the reference's AgentSAC.update_objectives on a seeded ring; record every random draw it makes
+    (minibatch ids via th.randint, the two rsample() noise tensors per step via th.distributions.Normal.rsample) so the
+    same step can be replayed elsewhere with injected draws.  Also records the off-policy rollout contract
+    (AgentBase._explore_vec_env): stored action == action sent to the env == tanh(mean + std * eps)."""
+    sys.path.insert(0, REF)
+    from elegantrl.agents import AgentSAC
+    from elegantrl.train.config import Config
+    from elegantrl.train.replay_buffer import ReplayBuffer
+
+    th.manual_seed(seed)
+    args = Config(AgentSAC, None, {"env_name": "scripted", "num_envs": N, "max_step": 100,
+                                   "state_dim": S, "action_dim": A, "if_discrete": False})
+    args.net_dims = list(net_dims)
+    args.batch_size, args.learning_rate, args.gamma, args.reward_scale = batch_size, 1e-3, 0.98, 0.5
+    args.soft_update_tau = 5e-3
+    agent = AgentSAC(args.net_dims, S, A, gpu_id=-1, args=args)
+    g = {}
+    g.update(net_arrays("act0", agent.act))
+    g.update(net_arrays("cri0", agent.cri))
+    g["alpha_log0"] = np32(agent.alpha_log)
+
+    # --- record rsample draws ---
+    Normal = th.distributions.normal.Normal
+    orig_rsample = Normal.rsample
+    eps_log = []
+
+    def rec_rsample(self, sample_shape=th.Size()):
+        eps = th.randn(self.loc.shape)
+        eps_log.append(eps.clone())
+        return self.loc + eps * self.scale
+
+    Normal.rsample = rec_rsample
+
+    # --- off-policy rollout through the reference's loop ---
+    env = ScriptedVecEnv(N, S, A, seed + 1)
+    agent.last_state = env.reset()[0]
+    g["first_state"] = np32(agent.last_state)
+    th.set_grad_enabled(False)
+    items = agent.explore_env(env, rows)
+    states, actions, rewards, undones, unmasks = items
+    g.update(ro_states=np32(states), ro_actions=np32(actions), ro_rewards=np32(rewards), ro_undones=np32(undones),
+             ro_unmasks=np32(unmasks), ro_eps=np.stack([np32(e) for e in eps_log]), ro_last_state=np32(agent.last_state))
+    eps_log.clear()
+
+    buf = ReplayBuffer(max_size=rows + 5, state_dim=S, action_dim=A, gpu_id=-1, num_seqs=N)
+    buf.update(items)
+
+    # --- n_updates SAC steps with recorded ids / noise ---
+    ids_log = []
+    orig_randint = th.randint
+
+    def rec_randint(*a, **k):
+        out = orig_randint(*a, **k)
+        ids_log.append(out.clone())
+        return out
+
+    th.randint = rec_randint
+    th.set_grad_enabled(True)
+    objs = []
+    for t in range(n_updates):
+        objs.append(agent.update_objectives(buf, t))
+        g.update(net_arrays(f"act{t + 1}", agent.act))
+        g.update(net_arrays(f"cri{t + 1}", agent.cri))
+        g.update(net_arrays(f"crit{t + 1}", agent.cri_target))
+        g[f"alpha_log{t + 1}"] = np32(agent.alpha_log)
+    th.set_grad_enabled(False)
+    th.randint = orig_randint
+    Normal.rsample = orig_rsample
+    assert len(eps_log) == 2 * n_updates and len(ids_log) == n_updates
+    g.update(ids=np.stack([np32(i) for i in ids_log]).astype(np.int64), eps_next=np.stack([np32(e) for e in eps_log[0::2]]),
+             eps_cur=np.stack([np32(e) for e in eps_log[1::2]]), objs=np.array(objs, dtype=np.float64),
+             hyper=np.array([args.gamma, args.learning_rate, args.clip_grad_norm, args.reward_scale, args.soft_update_tau,
+                             agent.target_entropy], dtype=np.float64),
+             dims=np.array([N, S, A, rows, batch_size, n_updates, agent.num_ensembles, *net_dims], dtype=np.int64))
+    path = os.path.join(OUT, f"sac_{tag}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, "objs", objs)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"reference not mounted at {REF}"
     make_ppo("small_vtrace", N=8, S=6, A=2, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0,
@@ -193,3 +273,4 @@ if __name__ == "__main__":
     make_ppo("mid_vtrace", N=40, S=17, A=5, H=20, net_dims=(128, 128), batch_size=64, repeat_times=6.4,
              use_v_trace=True, seed=13)
     make_replay()
+    make_sac("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=21)

@@ -264,6 +264,40 @@ def test_replay_large_random_vs_oracle(ops, dev):
             np.testing.assert_array_equal(t.cpu().numpy(), x)
 
 
+@pytest.mark.parametrize("num_seqs,max_size", [(1, 1_000_000), (64, 15_625)])
+def test_replay_full_size_config3(ops, dev, num_seqs, max_size):
+    """BASELINE config 3 ring (1e6 transitions, Hopper-shaped S=11, A=3): size-independent properties.
+    (1) index split bit-exact vs integer arithmetic; (2) every sampled row equals the ring row it names (torch advanced
+    indexing on the same device buffers) incl. next_state = states[ids0 + 1]; (3) a wrapped write lands in
+    [p, max_size) + [0, p'), leaves every other row untouched, and casts bool flags to 0/1 floats."""
+    S, A, B = 11, 3, 4096
+    g = th.Generator(device=dev).manual_seed(3)
+    bs = th.randn((max_size, num_seqs, S), device=dev, generator=g)
+    ba = th.randn((max_size, num_seqs, A), device=dev, generator=g)
+    br = th.randn((max_size, num_seqs), device=dev, generator=g)
+    bu = (th.rand((max_size, num_seqs), device=dev, generator=g) > 0.1).float()
+    bm = (th.rand((max_size, num_seqs), device=dev, generator=g) > 0.1).float()
+    sample_len = max_size - 1                                    # full ring
+    ids = th.randint(sample_len * num_seqs, (B,), device=dev, generator=g)
+    ids[0], ids[1] = 0, sample_len * num_seqs - 1                # extremes
+    out, (i0, i1) = ops.replay_sample(bs, ba, br, bu, bm, ids, sample_len)
+    assert th.equal(i0, ids % sample_len) and th.equal(i1, ids // sample_len)
+    for got, buf in zip(out[:5], (bs, ba, br, bu, bm)):
+        assert th.equal(got, buf[i0, i1])
+    assert th.equal(out[5], bs[i0 + 1, i1])
+    # wrapped append of 1000 rows starting 300 rows before the end
+    add, p = 1000, max_size - 300
+    items = [th.randn((add, num_seqs, S), device=dev, generator=g), th.randn((add, num_seqs, A), device=dev, generator=g),
+             th.randn((add, num_seqs), device=dev, generator=g), th.rand((add, num_seqs), device=dev, generator=g) > 0.5,
+             th.rand((add, num_seqs), device=dev, generator=g) > 0.5]
+    before = bs.clone()
+    ops.replay_write(bs, ba, br, bu, bm, items, p)
+    assert th.equal(bs[p:], items[0][:300]) and th.equal(bs[:700], items[0][300:])
+    assert th.equal(bs[700:p], before[700:p])
+    assert th.equal(bu[p:], items[3][:300].float()) and th.equal(bm[:700], items[4][300:].float())
+    assert th.equal(br[:700], items[2][300:])
+
+
 # ------------------------------------------------------------------------------------------------
 def random_net(rng, S, h1, h2, out, with_std):
     def lin(o, i):

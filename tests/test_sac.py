@@ -1,0 +1,121 @@
+"""Off-policy half of the hot path: AgentSAC's rollout / update loop on the HIP replay
+kernels, pinned to tests/golden/sac_small.npz -- outputs of the reference's own AgentSAC (oracle/make_golden.py:make_sac)
+with every random draw (minibatch ids, both rsample() noises per step) recorded so the steps can be replayed."""
+import numpy as np
+import pytest
+import torch as th
+
+from tests.helpers import load
+
+
+def _load_nets(g, tag, act, cri):
+    act.load_state_dict({k[len(f"act{tag}."):]: th.from_numpy(v) for k, v in g.items() if k.startswith(f"act{tag}.")})
+    cri.load_state_dict({k[len(f"cri{tag}."):]: th.from_numpy(v) for k, v in g.items() if k.startswith(f"cri{tag}.")})
+
+
+def test_actor_critic_modules_match_reference_rollout_on_cpu():
+    """module-level math on CPU: stored action == tanh(mean + std * eps) for the recorded eps (AgentSAC.py:179-185)."""
+    from elegantrl_amd.agents.AgentSAC import ActorSAC, CriticEnsemble
+    g = load("sac_small.npz")
+    N, S, A, rows, B, n_upd, n_ens, h1, h2 = [int(x) for x in g["dims"]]
+    act, cri = ActorSAC([h1, h2], S, A), CriticEnsemble([h1, h2], S, A, n_ens)
+    _load_nets(g, 0, act, cri)
+    with th.no_grad():
+        a = act.get_action(th.from_numpy(g["ro_states"][0]), th.from_numpy(g["ro_eps"][0]))
+        np.testing.assert_allclose(a.numpy(), g["ro_actions"][0], rtol=1e-5, atol=1e-6)
+        q = cri.get_q_values(th.from_numpy(g["ro_states"][3]), th.from_numpy(g["ro_actions"][3]))
+        assert q.shape == (N, n_ens)
+        np.testing.assert_allclose(cri(th.from_numpy(g["ro_states"][3]), th.from_numpy(g["ro_actions"][3])).numpy(),
+                                   q.mean(1, keepdim=True).numpy(), rtol=1e-6)
+
+
+class _ReplayEnv:
+    """replays the recorded env transitions of the golden rollout (device tensors, the reference's 5-tuple protocol)."""
+
+    def __init__(self, g, dev):
+        self.g, self.dev, self.t = g, dev, 0
+        self.num_envs = g["ro_states"].shape[1]
+
+    def step(self, action):
+        g, t = self.g, self.t
+        nxt = g["ro_states"][t + 1] if t + 1 < g["ro_states"].shape[0] else g["ro_last_state"]
+        self.t += 1
+        reward = th.from_numpy(g["ro_rewards"][t] / 0.5).to(self.dev)          # un-scale (reward_scale = 0.5)
+        return (th.from_numpy(nxt).to(self.dev), reward, th.from_numpy(~g["ro_undones"][t]).to(self.dev),
+                th.from_numpy(~g["ro_unmasks"][t]).to(self.dev), {})
+
+
+@pytest.mark.gpu
+def test_sac_rollout_and_updates_replay_the_reference():
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.train import Config, ReplayBuffer
+    g = load("sac_small.npz")
+    N, S, A, rows, B, n_upd, n_ens, h1, h2 = [int(x) for x in g["dims"]]
+    gamma, lr, max_norm, reward_scale, tau, target_entropy = [float(x) for x in g["hyper"]]
+    dev = th.device("cuda:0")
+    args = Config(AgentSAC, None, {"env_name": "scripted", "num_envs": N, "max_step": 100, "state_dim": S, "action_dim": A,
+                                   "if_discrete": False})
+    assert args.if_off_policy
+    args.net_dims = [h1, h2]
+    args.batch_size, args.learning_rate, args.gamma, args.reward_scale, args.soft_update_tau = B, lr, gamma, reward_scale, tau
+    args.clip_grad_norm = max_norm
+    agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    assert abs(agent.target_entropy - target_entropy) < 1e-12
+    _load_nets(g, 0, agent.act, agent.cri)
+    agent.cri_target.load_state_dict(agent.cri.state_dict())
+    with th.no_grad():
+        agent.alpha_log[:] = th.from_numpy(g["alpha_log0"]).to(dev)
+
+    # ---- row 2b: off-policy rollout (stored action = squashed action, rewards scaled, flags inverted)
+    agent.last_state = th.from_numpy(g["first_state"]).to(dev)
+    th.set_grad_enabled(False)
+    items = agent._explore_vec_env(_ReplayEnv(g, dev), rows, noise=th.from_numpy(g["ro_eps"]).to(dev))
+    for got, name in zip(items, ("ro_states", "ro_actions", "ro_rewards", "ro_undones", "ro_unmasks")):
+        if got.dtype == th.bool:
+            np.testing.assert_array_equal(got.cpu().numpy(), g[name])
+        else:
+            np.testing.assert_allclose(got.cpu().numpy(), g[name], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(agent.last_state.cpu().numpy(), g["ro_last_state"], rtol=0, atol=0)
+
+    # ---- rows 13-16: ring write (K8), sample (K9), update_objectives
+    buf = ReplayBuffer(max_size=rows + 5, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N)
+    buf.update(tuple(th.from_numpy(g[n]).to(dev) for n in ("ro_states", "ro_actions", "ro_rewards", "ro_undones", "ro_unmasks")))
+    assert (buf.p, buf.cur_size, buf.if_full) == (rows, rows, False)
+    th.set_grad_enabled(True)
+    for t in range(n_upd):
+        oc, oa = agent.update_objectives(buf, t, ids=th.from_numpy(g["ids"][t]).to(dev),
+                                         noises=(th.from_numpy(g["eps_next"][t]).to(dev), th.from_numpy(g["eps_cur"][t]).to(dev)))
+        np.testing.assert_allclose([oc, oa], g["objs"][t], rtol=2e-4, atol=2e-6)
+        for prefix, net in ((f"act{t + 1}", agent.act), (f"cri{t + 1}", agent.cri), (f"crit{t + 1}", agent.cri_target)):
+            for k, v in net.state_dict().items():
+                np.testing.assert_allclose(v.cpu().numpy(), g[f"{prefix}.{k}"], rtol=0, atol=3e-5, err_msg=f"{prefix}.{k}")
+        np.testing.assert_allclose(agent.alpha_log.detach().cpu().numpy(), g[f"alpha_log{t + 1}"], rtol=0, atol=1e-5)
+    th.set_grad_enabled(False)
+
+
+@pytest.mark.gpu
+def test_sac_update_net_loop_on_hopper_shaped_ring():
+    """config-3 shapes end to end: GPU-resident synthetic env (S=11, A=3) -> off-policy rollout -> ring -> update_net."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config, ReplayBuffer
+    N, S, A, H = 64, 11, 3, 32
+    args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
+                                        "if_discrete": False})
+    args.net_dims, args.batch_size, args.repeat_times = [64, 64], 256, 16.0   # update_times = int(cur_size * 16 / 256)
+    th.manual_seed(0)
+    agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=3)
+    agent.last_state = env.reset()[0]
+    buf = ReplayBuffer(max_size=1000, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N)
+    th.set_grad_enabled(False)
+    w0 = [p.detach().clone() for p in agent.act.parameters()]
+    for _ in range(2):
+        items = agent.explore_env(env, H)
+        assert [tuple(x.shape) for x in items] == [(H, N, S), (H, N, A), (H, N), (H, N), (H, N)]
+        assert items[1].abs().max() <= 1.0 and items[3].dtype == th.bool
+        buf.update(items)
+        oc, oa = agent.update_net(buf)
+        assert np.isfinite([oc, oa]).all()
+    assert buf.cur_size == 2 * H and int(buf.cur_size * args.repeat_times / args.batch_size) == 4
+    assert any(not th.equal(a, b) for a, b in zip(w0, agent.act.parameters()))

@@ -62,6 +62,17 @@ def main():
     out["value_forward_HxN"] = timeit(lambda: ops.value_forward(flat[Pa:], sc, avg, std, states, out=vals))
     out["value_forward_N"] = timeit(lambda: ops.value_forward(flat[Pa:], sc, avg, std, state))
     flops = 2 * (S * h1 + h1 * h2) * 2 + 2 * (h1 * h2) + 0  # rough; the bench uses its own formula
+    # config 3 replay ring: 1e6 x (S=11, A=3), num_seqs 1
+    M, S3, A3 = 1_000_000, 11, 3
+    rs, ra = th.randn((M, 1, S3), device=dev, generator=g), th.randn((M, 1, A3), device=dev, generator=g)
+    rr, ru, rm = (th.rand((M, 1), device=dev, generator=g) for _ in range(3))
+    for Bq in (256, 4096, 65536, 1048576):
+        rid = th.randint(M - 1, (Bq,), device=dev, generator=g)
+        out[f"replay_sample_B{Bq}"] = timeit(lambda: ops.replay_sample(rs, ra, rr, ru, rm, rid, M - 1))
+    add = 4096
+    items = [th.randn((add, 1, S3), device=dev), th.randn((add, 1, A3), device=dev), th.randn((add, 1), device=dev),
+             th.rand((add, 1), device=dev) > 0.5, th.rand((add, 1), device=dev) > 0.5]
+    out["replay_write_4096rows"] = timeit(lambda: ops.replay_write(rs, ra, rr, ru, rm, items, M - 1000))
     out = {k: round(v, 2) for k, v in out.items()}
     print(json.dumps(out))
     os.makedirs("gpurun_out", exist_ok=True)
