@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "liberl_hip.so")
 GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
-ABI_VERSION = 3
+MAX_LAYERS, MAXN_WIDTH = 6, 4096
+ABI_VERSION = 4
 
 _P = c_void_p
 _SIGNATURES = {
@@ -52,6 +53,13 @@ _SIGNATURES = {
     "erl_ppo_update_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
                                    _P, c_int64, c_int, c_float, c_float, _P, _P, c_int32, c_float, c_float, c_float, c_float, c_float,
                                    _P]),
+    "erl_mlpn_param_count": (c_int64, [POINTER(c_int), c_int, c_int]),
+    "erl_mlpn_workspace_bytes": (c_int64, [POINTER(c_int), c_int, c_int64, c_int]),
+    "erl_mlpn_value_forward_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, _P, c_int64, _P]),
+    "erl_mlpn_rollout_step_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P, _P,
+                                          _P, c_int64, _P]),
+    "erl_mlpn_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P,
+                                      c_int64, c_float, c_float, c_float, _P, _P, c_int64, _P]),
     "erl_k6_timing_enable": (None, [c_int]),
     "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_synenv_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_uint64, _P]),

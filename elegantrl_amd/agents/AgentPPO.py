@@ -92,8 +92,10 @@ class AgentPPO(AgentBase):
         self.if_off_policy = False
         if self.if_discrete:
             raise NotImplementedError("AgentDiscretePPO is a 'next' row (SURVEY.md 8f); the HIP path is continuous PPO")
-        if len(net_dims) != 2:
-            raise _hip.HipExtensionError(f"the fused HIP MLP kernels support exactly 2 hidden layers, got net_dims={net_dims}")
+        # fused register-chained kernels: 2 hidden layers of width 32..128 (multiples of 32); every other build_mlp()
+        # shape (the reference's demos go up to (256, 128, 128)) takes the layered generic path (erl_mlpn_*)
+        self._fused = (len(net_dims) == 2 and all(32 <= d <= _hip.MAX_HIDDEN and d % 32 == 0 for d in net_dims)
+                       and state_dim <= _hip.MAX_STATE_DIM and action_dim <= _hip.MAX_ACTION_DIM)
 
         self.ratio_clip = getattr(args, "ratio_clip", 0.25)
         self.lambda_gae_adv = getattr(args, "lambda_gae_adv", 0.95)
@@ -104,9 +106,13 @@ class AgentPPO(AgentBase):
         self.gae_algo = getattr(args, "gae_algo", "auto")
 
         from .. import ops  # deferred: importing the package must work without the built extension
-        h1, h2 = net_dims
-        self._spec_a = ops.MlpSpec(state_dim, h1, h2, action_dim, True)
-        self._spec_c = ops.MlpSpec(state_dim, h1, h2, 1, False)
+        if self._fused:
+            h1, h2 = net_dims
+            self._spec_a = ops.MlpSpec(state_dim, h1, h2, action_dim, True)
+            self._spec_c = ops.MlpSpec(state_dim, h1, h2, 1, False)
+        else:
+            self._spec_a = ops.MlpSpecN([state_dim, *net_dims, action_dim], True)
+            self._spec_c = ops.MlpSpecN([state_dim, *net_dims, 1], False)
         self._Pa, self._Pc = self._spec_a.count, self._spec_c.count    # raises for unsupported shapes
         self._stride = self._Pa + self._Pc + 4
         f32 = dict(dtype=th.float32, device=self.device)
@@ -156,8 +162,9 @@ class AgentPPO(AgentBase):
         n = state.shape[0]
         action = th.empty((n, self.action_dim), dtype=th.float32, device=self.device)
         logprob = th.empty((n,), dtype=th.float32, device=self.device)
-        ops.rollout_step(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
-                         noise=noise, seed=self.rng_seed, counter=self.rng_counter, out_action=action, out_logprob=logprob)
+        step = ops.rollout_step if self._fused else ops.mlpn_rollout_step
+        step(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
+             noise=noise, seed=self.rng_seed, counter=self.rng_counter, out_action=action, out_logprob=logprob)
         self.rng_counter += 1
         return action, logprob
 
@@ -187,7 +194,8 @@ class AgentPPO(AgentBase):
         state = state.to(dev, th.float32).contiguous()
         if hasattr(env, "raw_stepper") and state.data_ptr() != env.state.data_ptr():
             env.state.copy_(state)                 # the env owns the live state buffer; keep it authoritative
-        if hasattr(env, "raw_stepper"):
+        rollout_step = ops.rollout_step if self._fused else ops.mlpn_rollout_step
+        if hasattr(env, "raw_stepper") and self._fused:
             # GPU-resident env: both launches of a step go straight to the C ABI on raw pointers (no tensor views, no
             # per-call argument checks on the interpreter's launch path)
             fn = _hip.lib().erl_rollout_step_f32
@@ -210,9 +218,9 @@ class AgentPPO(AgentBase):
             native = True
         else:
             for t in range(H):
-                ops.rollout_step(P, spec, avg, std, state, noise=None if noise is None else noise[t], seed=self.rng_seed,
-                                 counter=self.rng_counter, out_state=states[t], out_action=actions[t],
-                                 out_logprob=logprobs[t], out_env_action=env_action)
+                rollout_step(P, spec, avg, std, state, noise=None if noise is None else noise[t], seed=self.rng_seed,
+                             counter=self.rng_counter, out_state=states[t], out_action=actions[t],
+                             out_logprob=logprobs[t], out_env_action=env_action)
                 self.rng_counter += 1
                 if native:     # GPU-resident env writes its outputs straight into row t (no copies, no host sync)
                     state = env.step_into(env_action, rewards[t], terminals[t], truncates[t])
@@ -243,9 +251,10 @@ class AgentPPO(AgentBase):
         env_action = th.empty((1, A), dtype=th.float32, device=dev)
         state = self.last_state.to(dev, th.float32).reshape(1, S).contiguous()
         for t in range(H):
-            ops.rollout_step(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
-                             seed=self.rng_seed, counter=self.rng_counter, out_state=states[t], out_action=actions[t],
-                             out_logprob=logprobs[t], out_env_action=env_action)
+            (ops.rollout_step if self._fused else ops.mlpn_rollout_step)(
+                self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
+                seed=self.rng_seed, counter=self.rng_counter, out_state=states[t], out_action=actions[t],
+                out_logprob=logprobs[t], out_env_action=env_action)
             self.rng_counter += 1
             ary_state, reward, terminal, truncate, _ = env.step(env_action[0].cpu().numpy())
             if terminal or truncate:
@@ -264,8 +273,8 @@ class AgentPPO(AgentBase):
         from .. import ops
         self._require_gpu("get_values")
         self._sync_modules()
-        return ops.value_forward(self._flat_c.flat, self._spec_c, self.cri.state_avg.data, self.cri.state_std.data,
-                                 states.contiguous())
+        fwd = ops.value_forward if self._fused else ops.mlpn_value_forward
+        return fwd(self._flat_c.flat, self._spec_c, self.cri.state_avg.data, self.cri.state_std.data, states.contiguous())
 
     def get_advantages(self, states: TEN, rewards: TEN, undones: TEN, unmasks: TEN, values: TEN) -> TEN:
         """Same signature and side effects as the reference: returns `advantages` (H, N) and applies the
@@ -310,8 +319,8 @@ class AgentPPO(AgentBase):
         if ids is None:
             ids = th.randint(H * N, size=(update_times, B), device=dev)
         assert ids.shape == (update_times, B) and ids.dtype == th.int64
-        n_slabs = self._n_slabs(B)
-        if self._slabs is None or self._slabs.shape[0] != n_slabs:
+        n_slabs = self._n_slabs(B) if self._fused else 0
+        if self._fused and (self._slabs is None or self._slabs.shape[0] != n_slabs):
             self._slabs = th.empty((n_slabs, self._stride), dtype=th.float32, device=dev)
         if self._grads is None or self._grads.shape[0] < update_times:
             self._grads = th.empty((update_times, self._stride), dtype=th.float32, device=dev)
@@ -319,6 +328,21 @@ class AgentPPO(AgentBase):
         groups = [(0, self._Pa), (self._Pa, self._Pc)]
         inv_batch = 1.0 / B
         grad_scale = 1.0 / self.world_size
+        if not self._fused:             # generic-shape networks: layered path, summed gradient written directly
+            for k in range(update_times):
+                g = self._grads[k]
+                ops.mlpn_ppo_step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
+                                  c.state_std.data, self._spec_a, states, actions, unmasks, logprobs, advantages, reward_sums,
+                                  ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch, g)
+                if self.world_size > 1:
+                    parallel.all_reduce_sum(g)
+                self._adam_step += 1
+                ops.clip_adam(self._flat, g, self._exp_avg, self._exp_avg_sq, groups, self._adam_step, float(self.learning_rate),
+                              float(self.clip_grad_norm), grad_scale=grad_scale)
+            self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
+            logs = self._grads[:update_times, self._Pa + self._Pc:self._Pa + self._Pc + 3].mean(dim=0) * grad_scale
+            obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())
+            return obj_critic, obj_actor, obj_entropy
         h1, h2 = self.net_dims
         if self.world_size == 1:        # the whole minibatch loop is enqueued by one C call (no interpreter on the launch path)
             ops.ppo_update(self._flat, self._exp_avg, self._exp_avg_sq, a.state_avg.data, a.state_std.data, c.state_avg.data,

@@ -260,6 +260,85 @@ def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, ac
 
 
 # ------------------------------------------------------------------------------------------------
+# generic-shape MLP path (any depth / width): erl_mlpn_*
+# ------------------------------------------------------------------------------------------------
+class MlpSpecN:
+    """build_mlp([S, d1, ..., dL, out]) of any depth in one flat fp32 buffer (W1 b1 ... Wout bout [action_std_log])."""
+
+    def __init__(self, dims: Sequence[int], with_std_log: bool):
+        self.dims = [int(d) for d in dims]
+        self.with_std_log = bool(with_std_log)
+        self.S, self.out = self.dims[0], self.dims[-1]
+        self._c = (ctypes.c_int * len(self.dims))(*self.dims)
+
+    @property
+    def cdims(self):
+        return self._c, len(self.dims)
+
+    @property
+    def count(self) -> int:
+        n = lib().erl_mlpn_param_count(self._c, len(self.dims), int(self.with_std_log))
+        if n < 0:
+            raise _hip.HipExtensionError(f"unsupported network dims {self.dims}: at most {_hip.MAX_LAYERS} hidden layers of width "
+                                         f"<= {_hip.MAXN_WIDTH}")
+        return n
+
+    def slices(self):
+        out, o = [], 0
+        for i, (d_in, d_out) in enumerate(zip(self.dims[:-1], self.dims[1:])):
+            out.append((f"net.{2 * i}.weight", o, (d_out, d_in)))
+            o += d_out * d_in
+            out.append((f"net.{2 * i}.bias", o, (d_out,)))
+            o += d_out
+        if self.with_std_log:
+            out.append(("action_std_log", o, (1, self.out)))
+        return out
+
+    def workspace_bytes(self, rows: int, training: bool) -> int:
+        return lib().erl_mlpn_workspace_bytes(self._c, len(self.dims), rows, int(training))
+
+
+def mlpn_value_forward(params: TEN, spec: MlpSpecN, state_avg: TEN, state_std: TEN, states: TEN, out: Optional[TEN] = None) -> TEN:
+    rows = states.numel() // spec.S
+    out = th.empty(states.shape[:-1], dtype=th.float32, device=states.device) if out is None else out
+    ws = _workspace(states.device, spec.workspace_bytes(max(rows, 1), False))
+    c, n = spec.cdims
+    check(lib().erl_mlpn_value_forward_f32(ptr(params, th.float32), ptr(state_avg, th.float32), ptr(state_std, th.float32), c, n,
+                                           ptr(states, th.float32), rows, ptr(out, th.float32), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_mlpn_value_forward_f32")
+    return out
+
+
+def mlpn_rollout_step(params: TEN, spec: MlpSpecN, state_avg: TEN, state_std: TEN, state: TEN, *, noise: Optional[TEN] = None,
+                      seed: int = 0, counter: int = 0, out_state: Optional[TEN] = None, out_action: Optional[TEN] = None,
+                      out_logprob: Optional[TEN] = None, out_env_action: Optional[TEN] = None) -> None:
+    N = state.shape[0]
+    ws = _workspace(state.device, spec.workspace_bytes(N, False))
+    c, n = spec.cdims
+    check(lib().erl_mlpn_rollout_step_f32(ptr(params, th.float32), ptr(state_avg, th.float32), ptr(state_std, th.float32), c, n,
+                                          ptr(state, th.float32), N, ptr(noise), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1),
+                                          ptr(out_state), ptr(out_action), ptr(out_logprob), ptr(out_env_action), ptr(ws),
+                                          ws.numel(), stream_ptr()),
+          "erl_mlpn_rollout_step_f32")
+
+
+def mlpn_ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, spec: MlpSpecN,
+                  states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN, ids: TEN,
+                  ratio_clip: float, lambda_entropy: float, inv_batch: float, flat_grad: TEN) -> None:
+    """one PPO minibatch for networks of any depth; `flat_grad` receives [actor | critic | 3 objectives, 0]."""
+    H, N = states.shape[0], states.shape[1]
+    B = ids.numel()
+    ws = _workspace(states.device, spec.workspace_bytes(B, True))
+    c, n = spec.cdims
+    check(lib().erl_mlpn_ppo_step_f32(ptr(actor_params, th.float32), ptr(critic_params, th.float32), ptr(act_avg), ptr(act_std),
+                                      ptr(cri_avg), ptr(cri_std), c, n, ptr(states, th.float32), ptr(actions, th.float32),
+                                      flag_ptr(unmasks), ptr(logprobs, th.float32), ptr(advantages, th.float32),
+                                      ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), B, ratio_clip, lambda_entropy,
+                                      inv_batch, ptr(flat_grad, th.float32), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_mlpn_ppo_step_f32")
+
+
+# ------------------------------------------------------------------------------------------------
 # environments
 # ------------------------------------------------------------------------------------------------
 def synenv_step(state: TEN, action: TEN, Ws: TEN, Wa: TEN, step_count: TEN, episode: TEN, reward: TEN, terminal: TEN,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 3
+#define ERL_ABI_VERSION 4
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -35,6 +35,9 @@ extern "C" {
 #define ERL_MAX_STATE_DIM 128
 #define ERL_MAX_HIDDEN 128
 #define ERL_MAX_ACTION_DIM 16
+/* limits of the generic-shape path (erl_mlpn_*): hidden layers / layer width */
+#define ERL_MAX_LAYERS 6
+#define ERL_MAXN_WIDTH 4096
 
 ERL_API int erl_abi_version(void);
 ERL_API const char *erl_last_error_string(void);
@@ -188,6 +191,33 @@ ERL_API int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp_av
                        int64_t B, int update_times, float ratio_clip, float lambda_entropy, float *slabs,
                        float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
                        float max_norm, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic-shape path: build_mlp([S, d1, ..., dL, out]) with ANY number (<= ERL_MAX_LAYERS) and width of hidden layers
+ * (elegantrl/agents/AgentBase.py:345-360; the reference's demos use (256, 128), (256, 128, 64), (256, 128, 128)).
+ * dims = [S, d1, ..., dL, out], n_dims = L + 2.  Parameter block: W1 b1 ... WL bL Wout bout (+ action_std_log).
+ * Dense layers are rocBLAS sgemm calls (fp32, atomics off), the rest is hand-written HIP; activations live in
+ * `workspace` (erl_mlpn_workspace_bytes(dims, n_dims, rows, training)).  Same arithmetic as K1 / K2 / K6:
+ *   erl_mlpn_value_forward_f32  = erl_value_forward_f32,  erl_mlpn_rollout_step_f32 = erl_rollout_step_f32,
+ *   erl_mlpn_ppo_step_f32       = erl_ppo_step_f32 + erl_grad_reduce_f32 (writes the summed gradient
+ *                                 [actor | critic | obj_critic, obj_surrogate, obj_entropy, 0] straight to flat_grad).
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int64_t erl_mlpn_param_count(const int *dims, int n_dims, int with_std_log);
+ERL_API int64_t erl_mlpn_workspace_bytes(const int *dims, int n_dims, int64_t rows, int training);
+ERL_API int erl_mlpn_value_forward_f32(const float *params, const float *state_avg, const float *state_std, const int *dims,
+                               int n_dims, const float *states, int64_t rows, float *values, void *workspace,
+                               int64_t workspace_bytes, void *stream);
+ERL_API int erl_mlpn_rollout_step_f32(const float *actor_params, const float *state_avg, const float *state_std,
+                              const int *dims, int n_dims, const float *state, int64_t N, const float *noise,
+                              uint64_t seed, uint64_t counter, float *out_state_row, float *out_action_row,
+                              float *out_logprob_row, float *out_action_env, void *workspace,
+                              int64_t workspace_bytes, void *stream);
+ERL_API int erl_mlpn_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg,
+                          const float *act_std, const float *cri_avg, const float *cri_std, const int *actor_dims,
+                          int n_dims, const float *states, const float *actions, const uint8_t *unmasks,
+                          const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
+                          int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
+                          float inv_batch, float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* measurement hook: when enabled, erl_ppo_update_f32 brackets every K6 launch with HIP events on the launch stream;
  * erl_k6_timing_read waits for them, returns the summed time (ms) and the launch count, and clears the list. */
