@@ -187,6 +187,7 @@ def main():
 
     rank, world, local_rank = parallel.init_from_env()
     assert world == opt.gpus, f"--gpus {opt.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
+    local_rank = local_rank % th.cuda.device_count()
     th.cuda.set_device(local_rank)
     dev = th.device(f"cuda:{local_rank}")
 
@@ -204,8 +205,7 @@ def main():
     agent.last_state = env.reset()[0]
 
     from elegantrl_amd import _hip
-    t_ppo, t_gae = EventTimer(), EventTimer()
-    ops.ppo_step = t_ppo.wrap(ops.ppo_step)      # N > 1: the minibatch loop runs in Python (all-reduce in the middle)
+    t_gae = EventTimer()
     ops.gae_scan = t_gae.wrap(ops.gae_scan)
 
     def step():
@@ -216,8 +216,8 @@ def main():
     for _ in range(opt.warmup):
         step()
     log("timed region")
-    t_ppo.enabled = t_gae.enabled = True
-    _hip.k6_timing_enable(True)                  # N = 1: the loop runs inside erl_ppo_update_f32, which records the events
+    t_gae.enabled = True
+    _hip.k6_timing_enable(True)                  # erl_ppo_step_f32 brackets every K6 launch with HIP events on its stream
     parallel.barrier()
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -226,7 +226,7 @@ def main():
     th.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.all_reduce_max_float(time.perf_counter() - t0, device=dev)
-    t_ppo.enabled = t_gae.enabled = False
+    t_gae.enabled = False
     _hip.k6_timing_enable(False)
     k6_seconds, k6_launches = _hip.k6_timing_read()
 
@@ -235,10 +235,7 @@ def main():
         return
     env_steps = world * N_ENVS * HORIZON * opt.steps
     flops = ppo_flops_per_sample(STATE_DIM, *NET_DIMS, ACTION_DIM) * BATCH
-    if k6_launches:
-        ppo_s, n_k6 = k6_seconds / k6_launches, k6_launches
-    else:
-        ppo_s, n_k6 = t_ppo.mean_seconds(), len(t_ppo.pairs)
+    ppo_s, n_k6 = k6_seconds / max(1, k6_launches), k6_launches
     gae_s = t_gae.mean_seconds()
     line = {
         "metric": "env_steps_per_sec_ppo_4096envs_obs64", "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",

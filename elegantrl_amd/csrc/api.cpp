@@ -37,11 +37,31 @@ extern "C" int erl_device_info(int *num_cu, int *lds_bytes_per_block)
 // ctypes).  Single-process path only: under data parallelism the gradient all-reduce sits between the slab
 // reduction and the optimiser step and the loop stays in Python.
 // ---------------------------------------------------------------------------------------------------------
-// optional per-launch timing of K6 inside erl_ppo_update_f32 (measurement hook for bench.py: HIP events on the launch
-// stream around every K6 launch; off by default).  The event pairs are kept until erl_k6_timing_read() drains them.
+// optional per-launch timing of K6 (measurement hook for bench.py: erl_ppo_step_f32 brackets its launch with HIP events
+// on the launch stream; off by default).  The event pairs are kept until erl_k6_timing_read() drains them.
 #include <vector>
 static bool g_k6_timing = false;
 static std::vector<hipEvent_t> g_k6_events;
+static hipEvent_t g_k6_open = nullptr;
+
+// called by erl_ppo_step_f32 right before (which = 0) and right after (which = 1) it enqueues K6
+void erl_k6_timing_mark(hipStream_t stream, int which)
+{
+    if (!g_k6_timing) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, stream);
+    if (which == 0) {
+        if (g_k6_open) (void)hipEventDestroy(g_k6_open);
+        g_k6_open = e;
+    } else if (g_k6_open) {
+        g_k6_events.push_back(g_k6_open);
+        g_k6_events.push_back(e);
+        g_k6_open = nullptr;
+    } else {
+        (void)hipEventDestroy(e);
+    }
+}
 
 extern "C" void erl_k6_timing_enable(int on) { g_k6_timing = on != 0; }
 
@@ -82,17 +102,9 @@ extern "C" int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp
     const int64_t off[2] = {0, Pa}, len[2] = {Pa, Pc};
     for (int k = 0; k < update_times; ++k) {
         float *g = grads + (size_t)k * stride;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_k6_timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
-            (void)hipEventRecord(e0, (hipStream_t)stream);
         int rc = erl_ppo_step_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
                                   unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
                                   lambda_entropy, 1.0f / (float)B, slabs, n_slabs, stream);
-        if (e0 && e1) {
-            (void)hipEventRecord(e1, (hipStream_t)stream);
-            g_k6_events.push_back(e0);
-            g_k6_events.push_back(e1);
-        }
         if (rc) return rc;
         if ((rc = erl_grad_reduce_f32(slabs, n_slabs, stride, g, stream))) return rc;
         if ((rc = erl_clip_adam_f32(flat_params, g, exp_avg, exp_avg_sq, off, len, 2, nullptr, first_step + k, lr, beta1, beta2, eps,

@@ -477,6 +477,8 @@ long long *g_ppo_prof = nullptr;
 
 }  // namespace
 
+void erl_k6_timing_mark(hipStream_t stream, int which);   // api.cpp (measurement hook, no-op unless enabled)
+
 #ifdef ERL_PROFILE
 // profiling builds only (make EXTRA=-DERL_PROFILE): device buffer of 2 * 8 * 32 int64 cycle stamps
 extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile(long long *dev_buf) { g_ppo_prof = dev_buf; }
@@ -523,7 +525,11 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
                      al(cri_avg) && al(cri_std);
     hipStream_t st = (hipStream_t)stream;
     const int ns = (S + 15) / 16;
-    if (vec && ns == 4 && h1 == 128 && h2 == 128) return launch<4, 8, 8, true>(g, n_slabs, st);   // configs 4 / 5
-    if (vec) return launch<0, 0, 0, true>(g, n_slabs, st);
-    return launch<0, 0, 0, false>(g, n_slabs, st);
+    erl_k6_timing_mark(st, 0);
+    int rc;
+    if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);   // configs 4 / 5
+    else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
+    else rc = launch<0, 0, 0, false>(g, n_slabs, st);
+    erl_k6_timing_mark(st, 1);
+    return rc;
 }

@@ -28,9 +28,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if th.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend is None:   # "nccl" IS RCCL on ROCm; ERL_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+            backend = os.environ.get("ERL_DIST_BACKEND") or ("nccl" if th.cuda.is_available() else "gloo")
+        if th.cuda.is_available():
+            local_rank = local_rank % th.cuda.device_count()
             th.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank

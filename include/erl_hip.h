@@ -219,7 +219,7 @@ ERL_API int erl_mlpn_ppo_step_f32(const float *actor_params, const float *critic
                           int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
                           float inv_batch, float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream);
 
-/* measurement hook: when enabled, erl_ppo_update_f32 brackets every K6 launch with HIP events on the launch stream;
+/* measurement hook: when enabled, erl_ppo_step_f32 brackets its K6 launch with HIP events on the launch stream;
  * erl_k6_timing_read waits for them, returns the summed time (ms) and the launch count, and clears the list. */
 ERL_API void erl_k6_timing_enable(int on);
 ERL_API int erl_k6_timing_read(double *total_ms, int *launches);
