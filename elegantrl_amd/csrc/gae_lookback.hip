@@ -9,20 +9,26 @@
 // registers (the chunk never goes back to memory between the two local passes):
 //   pass 1   per wave: fold the L steps into the chunk's affine map (A, P); stash delta_t in place of r_t
 //   LDS      waves exchange their maps; wave w composes the maps of the waves later in time (< w)
-//   global   the slab's map is published as ONE 8-byte granule per env {A, P} (P in [0, 1]); the carry into the
-//            slab is obtained by walking the later slabs' granules (decoupled look-back): a granule is either
-//            not-ready (all-ones sentinel), an aggregate {A, P >= 0} or an inclusive value {adv, -1}
+//   global   the slab's map is published as ONE 8-byte granule per env {A, tag}; tag = launch nonce << 2 | state.  A
+//            slab's P is two-valued (every c_t is 0 or gamma*lambda: P = 0 if the chain is cut inside the slab, else
+//            the full-slab product every workgroup can recompute bit-identically), so the state says which:
+//            AGG_ZERO / AGG_FULL / PREFIX (inclusive value); a tag with another nonce means "not ready".  The carry
+//            into the slab is obtained by walking the later slabs' granules (decoupled look-back).
 //   pass 2   per wave: replay the L steps from registers with the true carry, write adv / ret (+ statistics)
 // Slabs are handed out through an atomic ticket in launch order, latest time first, so every slab a workgroup
 // waits for belongs to a workgroup that is already running (forward progress without co-residency).
 // Granules are written/read with 8-byte agent-scope atomics (sc1 write-through stores / L1-bypassing loads):
 // self-validating, so no fences are needed (MI355X_MICROARCH.md, handoff-1to1 / R2 granules).
+// The granule table and the ticket counter live in a small library-owned device buffer that only this kernel ever
+// writes (allocated on first use, one per device): the per-launch nonce makes every older granule read as "not
+// ready", so nothing has to be cleared between launches (a memset + its launch gap cost ~25 % at 151 MB).  Problems
+// whose table exceeds that buffer, or calls on a second stream, use the caller's workspace with a memset instead.
 #include "erl_common.h"
 
 namespace {
 
 constexpr int LB_MAX_WAVES = 16;
-constexpr uint32_t LB_SENTINEL = 0xFFFFFFFFu;  // bit pattern of P for "not ready" (a NaN; real P is in [0, 1] or -1)
+constexpr uint32_t LB_AGG_ZERO = 1u, LB_AGG_FULL = 2u, LB_PREFIX = 3u;   // granule states (0 never appears with a live nonce)
 
 struct LbArgs {
     float *rewards;
@@ -33,14 +39,15 @@ struct LbArgs {
     int H, N, G, K;            // G env groups of 256, K time slabs of T steps
     float gamma, lam;
     int vtrace, mutate;
-    uint32_t *ticket;          // preset to 0xFFFFFFFF
-    unsigned long long *slots; // [K][N] granules, preset to all-ones
+    uint32_t *ticket;          // monotonically increasing across launches; this launch's tickets start at ticket_base
+    uint32_t ticket_base, nonce;
+    unsigned long long *slots; // [K][N] granules {A, nonce << 2 | state}
     double *partials;          // [gridDim.x][3]
 };
 
-__device__ __forceinline__ unsigned long long pack_granule(float a, float p)
+__device__ __forceinline__ unsigned long long pack_granule(float a, uint32_t tag)
 {
-    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(p) << 32);
+    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)tag << 32);
 }
 
 template <int L, bool STATS>
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
     __shared__ uint32_t s_ticket;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(g.ticket, 1u) + 1u;   // 0xFFFFFFFF + 1 wraps to ticket 0
+    if (threadIdx.x == 0) s_ticket = atomicAdd(g.ticket, 1u) - g.ticket_base;   // wrap-safe: tickets of this launch are 0 .. grid-1
     __syncthreads();
     const int ticket = (int)s_ticket;
     const int kk = ticket / g.G, grp = ticket - kk * g.G;             // kk = 0 is the latest slab in time
@@ -157,12 +164,24 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
             sP[e] = P[e] * cP[e];
             carry[e] = 0.f;
         }
+        // product of a full slab with no cut, composed exactly like sP above (bit-identical in every workgroup)
+        float p_full;
+        {
+            float pw = 1.f;
+#pragma unroll
+            for (int j = 0; j < L; ++j) pw = gl * pw;
+            float cp = 1.f;
+            for (int u = 0; u < W - 1; ++u) cp = pw * cp;
+            p_full = pw * cp;
+        }
+        const uint32_t tagbase = g.nonce << 2;
         unsigned long long *mine = g.slots + (size_t)kk * N + n0;
         const bool has_reader = kk + 1 < g.K;
         if (live && has_reader) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                __hip_atomic_store(mine + e, pack_granule(sA[e], sP[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + e, pack_granule(sA[e], tagbase | (sP[e] == 0.f ? LB_AGG_ZERO : LB_AGG_FULL)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (live && kk > 0) {
             float accA[4] = {0.f, 0.f, 0.f, 0.f}, accP[4] = {1.f, 1.f, 1.f, 1.f};
@@ -174,20 +193,18 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
                     if (!(open & (1u << e))) continue;
                     unsigned long long gr;
                     uint32_t spins = 0;
+                    bool ready;
                     do {
                         gr = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t)(gr >> 32) != LB_SENTINEL) break;
+                        ready = ((uint32_t)(gr >> 34)) == g.nonce;
+                        if (ready) break;
                         __builtin_amdgcn_s_sleep(2);
                     } while (++spins < (1u << 22));   // bounded: a lost predecessor yields NaN outputs, not a hang
-                    const float ga = __uint_as_float((uint32_t)gr), gp = __uint_as_float((uint32_t)(gr >> 32));
-                    if (gp < 0.f) {                 // inclusive value of slab j: adv at its earliest step
-                        accA[e] += accP[e] * ga;
-                        open &= ~(1u << e);
-                    } else {                        // aggregate (NaN sentinel after a timeout poisons accA)
-                        accA[e] += accP[e] * ga;
-                        accP[e] *= gp;
-                        if (accP[e] == 0.f) open &= ~(1u << e);   // an episode boundary cuts the chain
-                    }
+                    const float ga = ready ? __uint_as_float((uint32_t)gr) : __uint_as_float(0x7FC00000u);
+                    const uint32_t state = (uint32_t)(gr >> 32) & 3u;
+                    accA[e] += accP[e] * ga;
+                    if (state == LB_AGG_FULL && ready) accP[e] *= p_full;   // the chain runs through slab j: keep walking
+                    else open &= ~(1u << e);                                 // inclusive value, or an episode boundary cut it
                 }
             }
 #pragma unroll
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
         if (live && has_reader) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                __hip_atomic_store(mine + e, pack_granule(sA[e] + sP[e] * carry[e], -1.f), __ATOMIC_RELAXED,
+                __hip_atomic_store(mine + e, pack_granule(sA[e] + sP[e] * carry[e], tagbase | LB_PREFIX), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
         *reinterpret_cast<float4 *>(&s_carry[lane * 4]) = make_float4(carry[0], carry[1], carry[2], carry[3]);
@@ -292,7 +309,18 @@ bool erl_gae_lookback_usable(const float *rewards, const uint8_t *undones, const
     return (N % 4 == 0) && (f % 16 == 0) && (b % 4 == 0);
 }
 
-// Enqueues memset + kernel.  workspace layout: [ticket: 256 B][slots: K*N*8 B][partials: nblk*24 B].
+// Library-owned look-back table (one per device): [ticket counter: 256 B][granules].  Only gae_lookback_kernel writes
+// it; stale granules carry older nonces.  Allocated (and zeroed) on first use.
+constexpr size_t kLbTableBytes = 256 + ((size_t)8 << 20);   // 8 MiB of granules: K * N <= 1M (e.g. 2048 x 65536 at T = 128)
+struct LbTable {
+    char *ptr = nullptr;
+    uint32_t nonce = 1, ticket_base = 0;
+    hipStream_t stream = nullptr;
+    bool used = false;
+};
+static LbTable g_lb_table[32];
+
+// Enqueues [memset +] kernel.  workspace layout (fallback path): [ticket: 256 B][slots: K*N*8 B][partials: nblk*24 B].
 // Returns the number of statistics partials (blocks) through *nparts and their location through *partials.
 int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
                             const float *next_value, float *adv, float *ret, int64_t H, int64_t N, float gamma, float lam,
@@ -313,13 +341,46 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     g.adv = adv; g.ret = ret;
     g.H = (int)H; g.N = (int)N; g.G = (int)G; g.K = (int)K;
     g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
-    g.ticket = (uint32_t *)ws;
-    g.slots = (unsigned long long *)(ws + 256);
     g.partials = (double *)(ws + 256 + slot_bytes);
     *partials = g.partials;
     *nparts = (int)(K * G);
-    int rc = erl_hip_status(hipMemsetAsync(ws, 0xFF, 256 + (K > 1 ? slot_bytes : 0), stream), "hipMemsetAsync(lookback slots)");
-    if (rc) return rc;
+
+    // fast path: the library-owned table (no clearing); fallback: the caller's workspace, cleared by a memset
+    LbTable *tab = nullptr;
+    int dev = -1;
+    if (!getenv("ERL_GAE_LB_NO_TABLE") && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32 && 256 + slot_bytes <= kLbTableBytes) {
+        LbTable &t = g_lb_table[dev];
+        if (!t.ptr) {
+            void *p = nullptr;
+            if (hipMalloc(&p, kLbTableBytes) == hipSuccess) {
+                if (hipMemset(p, 0, kLbTableBytes) == hipSuccess) t.ptr = (char *)p;
+                else (void)hipFree(p);
+            }
+            (void)hipGetLastError();
+        }
+        if (t.ptr && (!t.used || t.stream == stream)) {   // launches on the table must be ordered by ONE stream
+            t.used = true;
+            t.stream = stream;
+            tab = &t;
+        }
+    }
+    if (tab) {
+        g.ticket = (uint32_t *)tab->ptr;
+        g.slots = (unsigned long long *)(tab->ptr + 256);
+        g.ticket_base = tab->ticket_base;
+        g.nonce = tab->nonce;
+        tab->ticket_base += (uint32_t)(K * G);
+        if (++tab->nonce >= (1u << 30)) {   // nonce space exhausted: clear behind this launch and start over
+            tab->nonce = 1;
+        }
+    } else {
+        g.ticket = (uint32_t *)ws;
+        g.slots = (unsigned long long *)(ws + 256);
+        g.ticket_base = 0;
+        g.nonce = 1;
+        int rc = erl_hip_status(hipMemsetAsync(ws, 0, 256 + (K > 1 ? slot_bytes : 0), stream), "hipMemsetAsync(lookback slots)");
+        if (rc) return rc;
+    }
     const dim3 grid((unsigned)(K * G)), block(W * 64);
 #define LB_LAUNCH(LL)                                                                                  \
     do {                                                                                               \
@@ -333,5 +394,9 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
         default: LB_LAUNCH(16); break;
     }
 #undef LB_LAUNCH
+    if (tab && tab->nonce == 1 && tab->ticket_base != 0) {   // just wrapped: zero the table behind the launch
+        (void)hipMemsetAsync(tab->ptr, 0, kLbTableBytes, stream);
+        tab->ticket_base = 0;
+    }
     return erl_hip_status(hipGetLastError(), "gae_lookback_kernel launch");
 }

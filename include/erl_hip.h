@@ -9,8 +9,9 @@
  *
  * Conventions
  *  - plain C types only: raw device pointers, sizes, scalars, an opaque hipStream_t passed as void*.
- *  - every tensor is caller-allocated, caller-owned device memory (torch tensors in practice); the
- *    library never allocates or frees device memory and keeps no state besides a last-error string.
+ *  - every tensor is caller-allocated, caller-owned device memory (torch tensors in practice).  The library
+ *    itself owns only: a last-error string, a rocBLAS handle (generic-shape path), and one 8 MiB per-device
+ *    look-back table for the single-pass GAE scan (allocated on first use; see ERL_GAE_ALGO_LOOKBACK).
  *  - all work is enqueued on `stream`; nothing synchronises the host.
  *  - layout at the seam is the reference's: time-major (H, N, .) row-major contiguous, fp32 values,
  *    1-byte flags (torch.bool), int64 indices.
@@ -63,7 +64,9 @@ ERL_API int erl_device_info(int *num_cu, int *lds_bytes_per_block);
 #define ERL_GAE_ALGO_AUTO 0x00
 #define ERL_GAE_ALGO_EXACT 0x10    /* one thread per env, reference op order, bit-exact vs the oracle */
 #define ERL_GAE_ALGO_CHUNKED 0x20  /* time-parallel two-pass affine scan (within 1e-5) */
-#define ERL_GAE_ALGO_LOOKBACK 0x30 /* time-parallel single-pass scan, decoupled look-back (within 1e-5) */
+#define ERL_GAE_ALGO_LOOKBACK 0x30 /* time-parallel single-pass scan, decoupled look-back (within 1e-5); its granule table
+                                      lives in a library-owned buffer (nonce-tagged, never cleared) when it fits, else in
+                                      `workspace` behind a memset */
 #define ERL_GAE_ALGO_MASK 0xF0
 ERL_API int64_t erl_gae_workspace_bytes(int64_t H, int64_t N);
 ERL_API int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
