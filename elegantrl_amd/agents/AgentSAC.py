@@ -1,15 +1,16 @@
-"""`AgentSAC` for the off-policy half of the hot path (BASELINE config 3): the rollout loop feeding `ReplayBuffer.update`
-(reference `AgentBase._explore_vec_env`, elegantrl/agents/AgentBase.py:130-170) and the update loop around
-`ReplayBuffer.sample` (`AgentBase.update_net` :172-189 + `AgentSAC.update_objectives`, elegantrl/agents/AgentSAC.py:42-86).
+"""`AgentSAC` on the HIP path (BASELINE config 3): off-policy rollout feeding `ReplayBuffer.update` (reference
+`AgentBase._explore_vec_env`, elegantrl/agents/AgentBase.py:130-170), and the update loop around `ReplayBuffer.sample`
+(`AgentBase.update_net` :172-189 + `AgentSAC.update_objectives`, elegantrl/agents/AgentSAC.py:42-86).
 
-What runs where: the ring write and the sample path (index split + six gathers incl. next-state) are the HIP kernels K8 /
-K9 behind `ReplayBuffer`; the SAC *update math* (tanh-Gaussian actor, critic ensemble, temperature, soft update, three
-Adam steps) is SURVEY.md section 8f row f1 ("next") and is still expressed with torch modules/autograd on the device -- it
-is pinned to the reference by tests/golden/sac_*.npz so that the HIP version that replaces it has its oracle ready.
+Everything numerical runs in liberl_hip.so: ring write / sample are K8 / K9, the exploration action is
+`erl_sac_explore_action_f32` and the whole update step after the sample -- tanh-Gaussian actor, critic ensemble, target
+min, temperature, soft update, three clip + Adam steps -- is ONE `erl_sac_update_f32` call (csrc/sac.hip).  The
+`nn.Module`s below only describe the parameter layout (their tensors are views into the flat blocks the kernels
+read/write) and serve the Evaluator's `actor(state)` / checkpoints.  No torch fallback for the update math: the torch
+restatement lives in oracle/sac_torch.py as test infrastructure.
 
-Networks and objectives restate the reference, quirks included: `log_prob` is evaluated at the MEAN of the Gaussian
-(AgentSAC.py:197), the tanh correction uses `log(1 - tanh(a)^2 + 1e-6)` (:198), the actor is trained against the TARGET
-critic ensemble's mean (:83), `alpha_log` is clamped to [-16, 2] after its own step (:80-81).
+Quirks of the reference are reproduced (see csrc/sac.hip): log-prob evaluated at the Gaussian MEAN (:197), tanh correction
+`log(1 - tanh^2 + 1e-6)` (:198), actor trained against the TARGET ensemble mean (:83), alpha clamped after its own step.
 """
 from __future__ import annotations
 
@@ -17,11 +18,13 @@ import math
 from copy import deepcopy
 from typing import List, Optional, Tuple
 
+import numpy as np
 import torch as th
 from torch import nn
 
+from .. import _hip
 from ..train.config import Config
-from .AgentBase import AgentBase, build_mlp, layer_init_with_orthogonal
+from .AgentBase import AgentBase, FlatNet, build_mlp, layer_init_with_orthogonal
 
 TEN = th.Tensor
 
@@ -79,6 +82,25 @@ class CriticEnsemble(nn.Module):
         return self.get_q_values(state, action).mean(dim=-1, keepdim=True)
 
 
+
+class _Slices:
+    def __init__(self, slices):
+        self._s = slices
+
+    def slices(self):
+        return self._s
+
+
+class _FlatAdamState:
+    """Adam moments of one parameter block as flat tensors (what `save_or_load_agent` stores for the optimisers)."""
+
+    def __init__(self, numel: int, lr: float, device):
+        self.exp_avg = th.zeros(numel, dtype=th.float32, device=device)
+        self.exp_avg_sq = th.zeros(numel, dtype=th.float32, device=device)
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8}]
+
+
 class AgentSAC(AgentBase):
     def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
         args = Config() if args is None else args
@@ -86,51 +108,83 @@ class AgentSAC(AgentBase):
         self.if_off_policy = True
         if self.if_discrete:
             raise NotImplementedError("SAC is a continuous-action agent")
+        if self.device.type != "cuda":
+            raise _hip.HipExtensionError("AgentSAC runs on the HIP kernels only; no GPU is visible and there is no CPU fallback")
+        from .. import ops
         self.num_ensembles = getattr(args, "num_ensembles", 4)
-        self._act = ActorSAC(net_dims, state_dim, action_dim).to(self.device)
-        self.cri = CriticEnsemble(net_dims, state_dim, action_dim, num_ensembles=self.num_ensembles).to(self.device)
-        self.cri_target = deepcopy(self.cri)
-        self.act_optimizer = th.optim.Adam(self._act.parameters(), self.learning_rate)
-        self.cri_optimizer = th.optim.Adam(self.cri.parameters(), self.learning_rate)
-        self.alpha_log = th.tensor((-1,), dtype=th.float32, requires_grad=True, device=self.device)
-        self.alpha_optim = th.optim.Adam((self.alpha_log,), lr=self.learning_rate)
+        self._spec = ops.SacSpec(state_dim, action_dim, net_dims, self.num_ensembles)
+        dev, f32 = self.device, th.float32
+        self._actor_flat = th.zeros(self._spec.actor_count, dtype=f32, device=dev)
+        self._critic_flat = th.zeros(self._spec.critic_count, dtype=f32, device=dev)
+        self._target_flat = th.zeros(self._spec.critic_count, dtype=f32, device=dev)
+        act = ActorSAC(net_dims, state_dim, action_dim).to(dev)
+        cri = CriticEnsemble(net_dims, state_dim, action_dim, num_ensembles=self.num_ensembles).to(dev)
+        cri_target = deepcopy(cri)
+        self._bind_a = FlatNet(act, _Slices(self._spec.actor_slices()), self._actor_flat)
+        self._bind_c = FlatNet(cri, _Slices(self._spec.critic_slices()), self._critic_flat)
+        self._bind_t = FlatNet(cri_target, _Slices(self._spec.critic_slices()), self._target_flat)
+        self._act, self.cri, self.cri_target = act, cri, cri_target
+        self.act_optimizer = _FlatAdamState(self._spec.actor_count, self.learning_rate, dev)
+        self.cri_optimizer = _FlatAdamState(self._spec.critic_count, self.learning_rate, dev)
+        self.alpha_optim = _FlatAdamState(1, self.learning_rate, dev)
+        self.alpha_log = th.full((1,), -1.0, dtype=f32, device=dev)
         self.target_entropy = math.log(action_dim)               # np.log(action_dim), as the reference (:31)
+        self._step = 0
+        self._objs = th.zeros(2, dtype=f32, device=dev)
+
+    def _on_act_replaced(self):
+        if getattr(self, "_bind_a", None) is not None and self._act is not None and not self._bind_a.is_bound(self._act):
+            self._act = self._act.to(self.device)
+            self._bind_a.bind(self._act)
+
+    def _sync_modules(self):
+        for bind, mod in ((self._bind_a, self._act), (self._bind_c, self.cri), (self._bind_t, self.cri_target)):
+            if not bind.is_bound(mod):
+                bind.bind(mod)
 
     def explore_action(self, state: TEN, noise: Optional[TEN] = None) -> TEN:
-        return self._act.get_action(state, noise)
+        from .. import ops
+        self._sync_modules()
+        action = ops.sac_explore_action(self._spec, self._actor_flat, state.contiguous(), noise=noise, seed=self.rng_seed,
+                                        counter=self.rng_counter)
+        self.rng_counter += 1
+        return action
+
+    def _update_on_batch(self, batch, objs_out: TEN, noises=None):
+        from .. import ops
+        self._step += 1
+        ops.sac_update(self._spec, self._actor_flat, self._critic_flat, self._target_flat, self.alpha_log,
+                       (self.act_optimizer.exp_avg, self.act_optimizer.exp_avg_sq, self.cri_optimizer.exp_avg,
+                        self.cri_optimizer.exp_avg_sq, self.alpha_optim.exp_avg, self.alpha_optim.exp_avg_sq),
+                       batch, self._step, gamma=float(self.gamma), target_entropy=float(self.target_entropy),
+                       tau=float(self.soft_update_tau), lr=float(self.learning_rate), max_norm=float(self.clip_grad_norm),
+                       objs_out=objs_out, noises=noises, seed=self.rng_seed + 1, counter=self._step)
+        self.act_optimizer.step_count = self.cri_optimizer.step_count = self.alpha_optim.step_count = self._step
 
     def update_objectives(self, buffer, update_t: int, ids: Optional[TEN] = None,
                           noises: Optional[Tuple[TEN, TEN]] = None) -> Tuple[float, float]:
-        """one SAC step.  `ids` / `noises` = (eps for next_state, eps for state) inject the random draws (tests)."""
+        """one SAC step (AgentSAC.py:42-86).  `ids` / `noises` = (eps for next_state, eps for state) inject the random draws."""
         assert isinstance(update_t, int)
         if self.if_use_per:
             raise NotImplementedError("prioritised replay is SURVEY.md 8f row f2")
-        n_next, n_cur = (None, None) if noises is None else noises
-        with th.no_grad():
-            state, action, reward, undone, unmask, next_state = buffer.sample(self.batch_size, ids=ids)   # HIP K9
-            next_action, next_logprob = self._act.get_action_logprob(next_state, n_next)
-            next_q = th.min(self.cri_target.get_q_values(next_state, next_action), dim=1)[0]
-            alpha = self.alpha_log.exp()
-            q_label = reward + undone * self.gamma * (next_q - next_logprob * alpha)
-
-        q_values = self.cri.get_q_values(state, action)
-        q_labels = q_label.view((-1, 1)).repeat(1, q_values.shape[1])
-        td_error = self.criterion(q_values, q_labels).mean(dim=1) * unmask
-        obj_critic = td_error.mean()
         if self.lambda_fit_cum_r:
-            cum_r = buffer.cum_rewards[buffer.ids0, buffer.ids1].detach().mean().repeat(q_values.shape[1])
-            obj_critic = obj_critic + self.criterion(cum_r, q_values.mean(dim=0)).mean() * self.lambda_fit_cum_r
-        self.optimizer_backward(self.cri_optimizer, obj_critic)
-        self.soft_update(self.cri_target, self.cri, self.soft_update_tau)
+            raise NotImplementedError("lambda_fit_cum_r != 0 is not part of the HIP SAC step yet")
+        self._sync_modules()
+        batch = buffer.sample(self.batch_size, ids=ids)                                   # HIP K9
+        self._update_on_batch(batch, self._objs, noises)
+        oc, oa = self._objs.cpu().tolist()
+        return oc, oa
 
-        action_pg, logprob = self._act.get_action_logprob(state, n_cur)
-        obj_alpha = (self.alpha_log * (self.target_entropy - logprob).detach()).mean()
-        self.optimizer_backward(self.alpha_optim, obj_alpha)
-
-        alpha = self.alpha_log.exp().detach()
-        with th.no_grad():
-            self.alpha_log[:] = self.alpha_log.clamp(-16, 2)
-        q_value_pg = self.cri_target(state, action_pg).mean()
-        obj_actor = (q_value_pg - logprob * alpha).mean()
-        self.optimizer_backward(self.act_optimizer, -obj_actor)
-        return obj_critic.item(), obj_actor.item()
+    def update_net(self, buffer) -> Tuple[float, float]:
+        """AgentBase.update_net (:172-189) with ONE host sync: the per-step objectives stay on the device until the end."""
+        if self.if_use_per or self.lambda_fit_cum_r:
+            return super().update_net(buffer)
+        self._sync_modules()
+        update_times = int(buffer.cur_size * self.repeat_times / self.batch_size)
+        if update_times < 1:
+            return 0.0, 0.0
+        objs = th.zeros((update_times, 2), dtype=th.float32, device=self.device)
+        for t in range(update_times):
+            self._update_on_batch(buffer.sample(self.batch_size), objs[t])
+        o = objs.cpu().numpy()
+        return float(np.nanmean(o[:, 0])), float(np.nanmean(o[:, 1]))

@@ -1,0 +1,306 @@
+// Shared pieces of the layered (rocBLAS GEMM + HIP epilogue) paths: erl_mlpn_* (mlpn.hip) and erl_sac_* (sac.hip).
+#pragma once
+#include <rocblas/rocblas.h>
+
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int MAXL = ERL_MAX_LAYERS;      // hidden layers
+constexpr float kLogSqrt2PiN = 0.91893853320467274178f;
+
+struct NetDims {
+    int n;                 // number of dense layers = hidden + 1
+    int d[MAXL + 2];       // d[0] = S, d[1..n-1] hidden, d[n] = out
+    int64_t oW[MAXL + 1], ob[MAXL + 1], oStd, count;
+};
+
+bool make_dims(const int *dims, int n_dims, bool with_std, NetDims *nd)
+{
+    if (!dims || n_dims < 2 || n_dims > MAXL + 2) return false;
+    nd->n = n_dims - 1;
+    int64_t o = 0;
+    for (int i = 0; i < n_dims; ++i) {
+        if (dims[i] < 1 || dims[i] > ERL_MAXN_WIDTH) return false;
+        nd->d[i] = dims[i];
+    }
+    for (int l = 0; l < nd->n; ++l) {
+        nd->oW[l] = o;
+        o += (int64_t)dims[l + 1] * dims[l];
+        nd->ob[l] = o;
+        o += dims[l + 1];
+    }
+    nd->oStd = o;
+    nd->count = o + (with_std ? dims[n_dims - 1] : 0);
+    return true;
+}
+
+}  // namespace
+int erl_blas(hipStream_t stream, rocblas_handle *h);   // mlpn.hip: the library's one rocBLAS handle, bound to `stream`
+namespace {
+inline int blas(hipStream_t stream, rocblas_handle *h) { return erl_blas(stream, h); }
+
+#define RB(call)                                                           \
+    do {                                                                   \
+        rocblas_status st_ = (call);                                       \
+        if (st_ != rocblas_status_success) {                               \
+            erl_set_error("%s -> rocblas status %d", #call, (int)st_);     \
+            return -2;                                                     \
+        }                                                                  \
+    } while (0)
+
+// row-major Z[M][N] = X[M][K] . W[N][K]^T
+int gemm_fwd(rocblas_handle h, const float *X, const float *W, float *Z, int M, int N, int K)
+{
+    const float one = 1.f, zero = 0.f;
+    RB(rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, W, K, X, K, &zero, Z, N));
+    return 0;
+}
+// row-major dX[M][K] = dZ[M][N] . W[N][K]
+int gemm_dx(rocblas_handle h, const float *dZ, const float *W, float *dX, int M, int N, int K)
+{
+    const float one = 1.f, zero = 0.f;
+    RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, K, M, N, &one, W, K, dZ, N, &zero, dX, K));
+    return 0;
+}
+// row-major dX[M][K] += dZ[M][N] . W[N][K]   (accumulating variant: ensemble decoders summing into one encoder gradient)
+int gemm_dx_acc(rocblas_handle h, const float *dZ, const float *W, float *dX, int M, int N, int K)
+{
+    const float one = 1.f;
+    RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, K, M, N, &one, W, K, dZ, N, &one, dX, K));
+    return 0;
+}
+// row-major dW[N][K] = dZ[M][N]^T . X[M][K]
+int gemm_dw(rocblas_handle h, const float *dZ, const float *X, float *dW, int M, int N, int K)
+{
+    const float one = 1.f, zero = 0.f;
+    RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, N, M, &one, X, K, dZ, N, &zero, dW, K));
+    return 0;
+}
+// db[N] = column sums of dZ[M][N]
+int colsum(rocblas_handle h, const float *dZ, const float *ones, float *db, int M, int N)
+{
+    const float one = 1.f, zero = 0.f;
+    RB(rocblas_sgemv(h, rocblas_operation_none, N, M, &one, dZ, N, ones, 1, &zero, db, 1));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// hand-written pieces
+// ---------------------------------------------------------------------------------------------------------
+// X[b][:] = (states[row(b)][:] - avg) / (std + 1e-4); row(b) = b (ids == NULL) or (id % H) * N + id // H
+__global__ __launch_bounds__(256) void gather_norm_kernel(const float *__restrict__ states, const float *__restrict__ avg,
+                                                          const float *__restrict__ sd, const int64_t *__restrict__ ids,
+                                                          int64_t H, int64_t N, int S, int64_t rows, float *__restrict__ X,
+                                                          float *__restrict__ raw_copy)
+{
+    const int64_t total = rows * S;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / S;
+        const int c = (int)(e - b * S);
+        int64_t row = b;
+        if (ids) {
+            const int64_t id = ids[b];
+            const int64_t n = id / H, t = id - n * H;
+            row = t * N + n;
+        }
+        const float raw = states[row * S + c];
+        if (raw_copy) raw_copy[e] = raw;
+        X[e] = (raw - avg[c]) / (sd[c] + 1e-4f);
+    }
+}
+
+// in place: Z <- GELU(Z + b); optionally G <- GELU'(Z + b)
+__global__ __launch_bounds__(256) void bias_gelu_kernel(float *__restrict__ Z, float *__restrict__ G, const float *__restrict__ bias,
+                                                        int width, int64_t total)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % width);
+        float y, gd;
+        gelu_and_grad_fast(Z[e] + bias[c], y, gd);
+        Z[e] = y;
+        if (G) G[e] = gd;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_kernel(float *__restrict__ Z, const float *__restrict__ bias, int width, int64_t total)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) Z[e] += bias[e % width];
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(float *__restrict__ dH, const float *__restrict__ G, int64_t total)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) dH[e] *= G[e];
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ p, float v, int64_t total)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) p[e] = v;
+}
+
+// rollout sampling: a = mean + std * eps, log-prob, tanh (AgentPPO.py:368-376, :388-390); one thread per env
+__global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ Y, const float *__restrict__ std_log, int A,
+                                                     int64_t N, const float *__restrict__ noise, uint64_t seed, uint64_t counter,
+                                                     float *__restrict__ o_action, float *__restrict__ o_logprob,
+                                                     float *__restrict__ o_env)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float lp = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float eps = noise ? noise[n * A + a] : philox_normal(seed, counter, (uint32_t)n, (uint32_t)a);
+        const float sdv = expf(std_log[a]), var = sdv * sdv;
+        const float mean = Y[n * A + a];
+        const float act = mean + sdv * eps;
+        const float diff = act - mean;
+        lp += -(diff * diff) / (2.f * var) - logf(sdv) - kLogSqrt2PiN;
+        if (o_action) o_action[n * A + a] = act;
+        if (o_env) o_env[n * A + a] = tanhf(act);
+    }
+    if (o_logprob) o_logprob[n] = lp;
+}
+
+// PPO objective on gathered rows (AgentPPO.py:189-204).  ACTOR: Y holds the means (B, A) on entry and dL/dmean on exit;
+// DSL (B, A) receives the per-row dL/dstd_log terms.  CRITIC: Y (B, 1) holds values on entry, dL/dv on exit.
+// Per-block partial sums of the logged objectives go to part[block][2].
+template <bool ACTOR>
+__global__ __launch_bounds__(256) void objective_kernel(float *__restrict__ Y, float *__restrict__ DSL, const int64_t *__restrict__ ids,
+                                                        int64_t H, int64_t N, int A, int64_t B, const float *__restrict__ actions,
+                                                        const uint8_t *__restrict__ unmasks, const float *__restrict__ xa_src,
+                                                        const float *__restrict__ xb_src, const float *__restrict__ std_log,
+                                                        float ratio_clip, float lambda_entropy, float inv_batch,
+                                                        float *__restrict__ part)
+{
+    __shared__ float red[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float l0 = 0.f, l1 = 0.f;
+    if (b < B) {
+        const int64_t id = ids[b];
+        const int64_t n = id / H, t = id - n * H;
+        const int64_t row = t * N + n;
+        const float um = unmasks[row] ? 1.f : 0.f;
+        if (!ACTOR) {
+            const float diff = Y[b] - xa_src[row];
+            l0 = diff * diff * um;
+            Y[b] = 2.f * diff * um * inv_batch;
+        } else {
+            float lp = 0.f;
+            for (int a = 0; a < A; ++a) {
+                const float sdv = expf(std_log[a]), var = sdv * sdv;
+                const float diff = actions[row * A + a] - Y[b * A + a];
+                lp += -(diff * diff) / (2.f * var) - logf(sdv) - kLogSqrt2PiN;
+            }
+            const float adv = xb_src[row];
+            const float ratio = expf(lp - xa_src[row]);
+            const float w = adv > 0.f ? 1.f - ratio_clip : 1.f + ratio_clip;
+            const float surr = adv * ratio * w;
+            l0 = surr * um;
+            l1 = um;
+            const float dlp = -(surr * um) * inv_batch;
+            const float ent_term = lambda_entropy * um * inv_batch;
+            for (int a = 0; a < A; ++a) {
+                const float sdv = expf(std_log[a]), var = sdv * sdv;
+                const float diff = actions[row * A + a] - Y[b * A + a];
+                Y[b * A + a] = dlp * (diff / var);
+                DSL[b * A + a] = dlp * (diff * diff / var - 1.f) + ent_term;
+            }
+        }
+    }
+    const float t0 = block_sum(l0, red), t1 = block_sum(l1, red);
+    if (threadIdx.x == 0) {
+        part[(size_t)blockIdx.x * 2 + 0] = t0;
+        part[(size_t)blockIdx.x * 2 + 1] = t1;
+    }
+}
+
+// logs: fold the per-block partials in a fixed order
+__global__ void fold_logs_kernel(const float *__restrict__ part, int nparts, const float *__restrict__ std_log, int A, float inv_batch,
+                                 int is_actor, float *__restrict__ logs)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        s0 += part[2 * i];
+        s1 += part[2 * i + 1];
+    }
+    if (is_actor) {
+        float ent = 0.f;
+        for (int a = 0; a < A; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));
+        logs[1] = s0 * inv_batch;
+        logs[2] = ent * s1 * inv_batch;
+    } else {
+        logs[0] = s0 * inv_batch;
+        logs[3] = 0.f;
+    }
+}
+
+inline int grid1d(int64_t total)
+{
+    int64_t g = erl_cdiv(total, 256);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+struct Ws {
+    char *base;
+    int64_t used, cap;
+    float *take(int64_t floats)
+    {
+        float *p = (float *)(base + used);
+        used += ((floats * 4 + 255) / 256) * 256;
+        return used <= cap ? p : nullptr;
+    }
+};
+
+int64_t ws_floats_forward(const NetDims &nd, int64_t rows)
+{
+    int64_t f = rows * nd.d[0] + 64;
+    for (int l = 1; l <= nd.n; ++l) f += rows * nd.d[l] + 64;
+    return f;
+}
+
+// forward pass into workspace buffers; act[l] = activation after layer l (act[0] = X), keep_g: store GELU' per hidden layer
+int forward(rocblas_handle h, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float **act, float **gd)
+{
+    for (int l = 0; l < nd.n; ++l) {
+        const int K = nd.d[l], Nw = nd.d[l + 1];
+        int rc = gemm_fwd(h, act[l], P + nd.oW[l], act[l + 1], (int)rows, Nw, K);
+        if (rc) return rc;
+        const int64_t total = rows * Nw;
+        if (l + 1 < nd.n)
+            hipLaunchKernelGGL(bias_gelu_kernel, dim3(grid1d(total)), dim3(256), 0, s, act[l + 1], gd ? gd[l + 1] : nullptr, P + nd.ob[l],
+                               Nw, total);
+        else
+            hipLaunchKernelGGL(bias_kernel, dim3(grid1d(total)), dim3(256), 0, s, act[l + 1], P + nd.ob[l], Nw, total);
+    }
+    return 0;
+}
+
+
+// backward through an MLP whose forward was run by forward(): dZ = dL/d(output).  Writes weight / bias gradients into
+// G (same layout as the parameter block) when G != nullptr, and dL/d(input) into dX0 when dX0 != nullptr
+// (accumulating into it when acc_dx0).  tmpA / tmpB: two scratch buffers of rows * max-width floats.
+int backward(rocblas_handle h, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float *const *act, float *const *gd,
+             const float *dZ, float *G, const float *ones, float *dX0, bool acc_dx0, float *tmpA, float *tmpB)
+{
+    int rc;
+    for (int l = nd.n - 1; l >= 0; --l) {
+        const int K = nd.d[l], Nw = nd.d[l + 1];
+        if (G) {
+            if ((rc = gemm_dw(h, dZ, act[l], G + nd.oW[l], (int)rows, Nw, K))) return rc;
+            if ((rc = colsum(h, dZ, ones, G + nd.ob[l], (int)rows, Nw))) return rc;
+        }
+        if (l > 0) {
+            float *dH = (dZ == tmpA) ? tmpB : tmpA;
+            if ((rc = gemm_dx(h, dZ, P + nd.oW[l], dH, (int)rows, Nw, K))) return rc;
+            hipLaunchKernelGGL(mul_kernel, dim3(grid1d(rows * K)), dim3(256), 0, s, dH, gd[l], rows * K);
+            dZ = dH;
+        } else if (dX0) {
+            if ((rc = (acc_dx0 ? gemm_dx_acc : gemm_dx)(h, dZ, P + nd.oW[0], dX0, (int)rows, Nw, K))) return rc;
+        }
+    }
+    return 0;
+}
+
+}  // namespace

@@ -1,0 +1,389 @@
+// SAC update step: the consumer on the other side of ReplayBuffer.sample.  gfx950.
+//
+// Replaces AgentSAC.update_objectives (elegantrl/agents/AgentSAC.py:42-86) after the sample: tanh-Gaussian actor
+// (ActorSAC :167-199), critic ensemble with a shared (state, action) encoder (CriticEnsemble :243-259), temperature
+// update, soft target update (AgentBase.py:270-278) and the three clip + Adam steps (AgentBase.py:239-248).  Quirks are
+// reproduced: Normal.log_prob is evaluated at the MEAN (:197), tanh correction log(1 - tanh^2 + 1e-6) (:198), the actor is
+// trained against the TARGET ensemble's mean (:83), alpha is read after its own Adam step and only then clamped (:79-81).
+//
+// Batches are small (256..1024 rows): the step is launch-latency bound, so the win over ~300 ATen dispatches is that
+// ONE C call enqueues everything.  Dense layers are rocBLAS sgemm (fp32, atomics off), the rest is hand-written HIP.
+//
+// Parameter blocks (flat fp32):
+//   actor   build_mlp([S, h0..hL-1]) with GELU after every layer, then Linear(hL-1, 2A):  W b ... Whead bhead
+//   critic  encoder Linear(S + A, h0) (no activation), then E decoders build_mlp([h0, h1, .., hL-1, 1]):  We be | dec0 | dec1 ...
+#include "mlpn_common.h"
+
+extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
+                                 const int64_t *group_len, int n_groups, const int32_t *step_base, int32_t step_offset, float lr,
+                                 float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream);
+
+namespace {
+
+constexpr int MAXE = 16;
+constexpr float kLogSqrt2PiS = 0.91893853320467274178f;
+
+struct SacDims {
+    int S, A, E, L;
+    NetDims actor, enc, dec;
+    int64_t Pa, Pc;
+};
+
+bool make_sac_dims(int S, int A, const int *hidden, int n_hidden, int E, SacDims *d)
+{
+    if (S < 1 || A < 1 || !hidden || n_hidden < 1 || n_hidden > MAXL || E < 1 || E > MAXE) return false;
+    int dims[MAXL + 2];
+    dims[0] = S;
+    for (int i = 0; i < n_hidden; ++i) dims[i + 1] = hidden[i];
+    dims[n_hidden + 1] = 2 * A;
+    if (!make_dims(dims, n_hidden + 2, false, &d->actor)) return false;
+    int e[2] = {S + A, hidden[0]};
+    if (!make_dims(e, 2, false, &d->enc)) return false;
+    int dd[MAXL + 2];
+    for (int i = 0; i < n_hidden; ++i) dd[i] = hidden[i];
+    dd[n_hidden] = 1;
+    if (!make_dims(dd, n_hidden + 1, false, &d->dec)) return false;
+    d->S = S; d->A = A; d->E = E; d->L = n_hidden;
+    d->Pa = d->actor.count;
+    d->Pc = d->enc.count + (int64_t)E * d->dec.count;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void concat_kernel(const float *__restrict__ s, const float *__restrict__ a, int S, int A, int64_t B,
+                                                     float *__restrict__ out)
+{
+    const int W = S + A;
+    const int64_t total = B * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / W;
+        const int c = (int)(e - b * W);
+        out[e] = c < S ? s[b * S + c] : a[b * A + (c - S)];
+    }
+}
+
+// ActorSAC.get_action_logprob head: Y (B, 2A) = [mean | log_std] -> tanh action, log-prob; keeps eps for the backward
+__global__ __launch_bounds__(256) void head_forward_kernel(const float *__restrict__ Y, const float *__restrict__ noise, uint64_t seed,
+                                                           uint64_t counter, int A, int64_t B, float *__restrict__ act_t,
+                                                           float *__restrict__ logprob, float *__restrict__ eps_out)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float lp = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float mean = Y[b * 2 * A + a], ls = Y[b * 2 * A + A + a];
+        const float lsc = fminf(fmaxf(ls, -16.f), 2.f);
+        const float sd = expf(lsc);
+        const float eps = noise ? noise[b * A + a] : philox_normal(seed, counter, (uint32_t)b, (uint32_t)a);
+        const float t = tanhf(mean + sd * eps);
+        act_t[b * A + a] = t;
+        if (eps_out) eps_out[b * A + a] = eps;
+        lp += (-logf(sd) - kLogSqrt2PiS) - logf(-(t * t) + 1.000001f);
+    }
+    logprob[b] = lp;
+}
+
+// q_label = reward + undone * gamma * (min_e q_target - next_logprob * alpha)     (AgentSAC.py:52-55)
+__global__ __launch_bounds__(256) void q_label_kernel(const float *__restrict__ qt, int E, int64_t B, const float *__restrict__ reward,
+                                                      const float *__restrict__ undone, const float *__restrict__ next_lp,
+                                                      const float *__restrict__ alpha_log, float gamma, float *__restrict__ label)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float m = qt[b];
+    for (int e = 1; e < E; ++e) m = fminf(m, qt[(size_t)e * B + b]);
+    const float alpha = expf(alpha_log[0]);
+    label[b] = reward[b] + (undone[b] * gamma) * (m - next_lp[b] * alpha);
+}
+
+// critic objective: td = mean_e (q - label)^2 * unmask; obj = mean_b td; dq[e][b] = 2 (q - label) unmask / (E B)
+__global__ __launch_bounds__(256) void critic_loss_kernel(const float *__restrict__ q, const float *__restrict__ label,
+                                                          const float *__restrict__ unmask, int E, int64_t B, float *__restrict__ dq,
+                                                          float *__restrict__ part)
+{
+    __shared__ float red[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float td = 0.f;
+    if (b < B) {
+        const float l = label[b], um = unmask[b];
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) {
+            const float diff = q[(size_t)e * B + b] - l;
+            s += diff * diff;
+            dq[(size_t)e * B + b] = 2.f * diff * um / ((float)E * (float)B);
+        }
+        td = (s / (float)E) * um;
+    }
+    const float t = block_sum(td, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// single-block deterministic reductions of small vectors:  out = scale * sum_i x[i] (+ bias)
+__global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, int64_t n, float scale, float bias, float *__restrict__ out)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = t * scale + bias;
+}
+
+__global__ __launch_bounds__(256) void fillk_kernel(float *__restrict__ p, float v, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
+// actor objective value and dL/d(head output) for L = -(mean q_pg - alpha * mean logprob)   (AgentSAC.py:74-85)
+//   action = tanh(u), u = mean + std eps, std = exp(clamp(ls, -16, 2));  logprob = sum_a [-log std - c - log(1 - t^2 + 1e-6)]
+__global__ __launch_bounds__(256) void head_backward_kernel(const float *__restrict__ Y, const float *__restrict__ act_t,
+                                                            const float *__restrict__ eps, const float *__restrict__ dA,
+                                                            const float *__restrict__ alpha_log, int A, int64_t B,
+                                                            float *__restrict__ dY)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float alpha = expf(alpha_log[0]);
+    const float dlp = alpha / (float)B;                 // dL/dlogprob_b
+    for (int a = 0; a < A; ++a) {
+        const float ls = Y[b * 2 * A + A + a];
+        const float lsc = fminf(fmaxf(ls, -16.f), 2.f);
+        const float sd = expf(lsc);
+        const float t = act_t[b * A + a];
+        const float one_m = 1.f - t * t;
+        const float du = dA[b * A + a] * one_m + dlp * (2.f * t * one_m / (one_m + 1e-6f));
+        const bool inside = ls >= -16.f && ls <= 2.f;   // clamp passes its gradient inside [min, max]
+        dY[b * 2 * A + a] = du;
+        dY[b * 2 * A + A + a] = inside ? du * sd * eps[b * A + a] - dlp : 0.f;
+    }
+}
+
+// obj_actor = mean_b mean_e q_pg - alpha * mean_b logprob
+__global__ __launch_bounds__(256) void actor_obj_kernel(const float *__restrict__ qpg, int E, int64_t B, const float *__restrict__ lp,
+                                                        const float *__restrict__ alpha_log, float *__restrict__ out)
+{
+    __shared__ float red[4];
+    float sq = 0.f, sl = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)E * B; i += 256) sq += qpg[i];
+    for (int64_t i = threadIdx.x; i < B; i += 256) sl += lp[i];
+    const float tq = block_sum(sq, red), tl = block_sum(sl, red);
+    if (threadIdx.x == 0) out[0] = tq / ((float)E * (float)B) - expf(alpha_log[0]) * (tl / (float)B);
+}
+
+__global__ __launch_bounds__(256) void soft_update_kernel(float *__restrict__ tar, const float *__restrict__ cur, float tau, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        tar[i] = __fadd_rn(__fmul_rn(cur[i], tau), __fmul_rn(tar[i], 1.0f - tau));   // cur * tau + tar * (1 - tau)
+}
+
+__global__ void clamp_alpha_kernel(float *alpha_log)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) alpha_log[0] = fminf(fmaxf(alpha_log[0], -16.f), 2.f);
+}
+
+struct CriticWs {
+    float *enc;                       // (B, h0)
+    float *act[MAXE][MAXL + 2];       // decoder activations; act[e][0] = enc
+    float *gd[MAXE][MAXL + 2];
+    float *q;                         // [E][B]
+};
+
+int64_t critic_ws_floats(const SacDims &d, int64_t B)
+{
+    int64_t f = B * d.enc.d[1] + 64 + (int64_t)d.E * B + 64;
+    for (int l = 1; l < d.dec.n; ++l) f += (int64_t)d.E * 2 * (B * d.dec.d[l] + 64);
+    return f;
+}
+
+bool carve_critic(Ws &ws, const SacDims &d, int64_t B, CriticWs *c)
+{
+    c->enc = ws.take(B * d.enc.d[1]);
+    c->q = ws.take((int64_t)d.E * B);
+    for (int e = 0; e < d.E; ++e) {
+        c->act[e][0] = c->enc;
+        c->gd[e][0] = nullptr;
+        for (int l = 1; l < d.dec.n; ++l) {
+            c->act[e][l] = ws.take(B * d.dec.d[l]);
+            c->gd[e][l] = ws.take(B * d.dec.d[l]);
+        }
+        c->act[e][d.dec.n] = c->q + (size_t)e * B;   // (B, 1) output column of decoder e
+        c->gd[e][d.dec.n] = nullptr;
+    }
+    return c->act[d.E - 1][d.dec.n - 1] != nullptr && c->q != nullptr;
+}
+
+int critic_forward(rocblas_handle h, hipStream_t s, const SacDims &d, const float *P, int64_t B, float *xa, CriticWs &c, bool keep)
+{
+    float *ea[2] = {xa, c.enc};
+    int rc = forward(h, s, d.enc, P, B, ea, nullptr);      // one raw linear layer
+    if (rc) return rc;
+    for (int e = 0; e < d.E; ++e)
+        if ((rc = forward(h, s, d.dec, P + d.enc.count + (int64_t)e * d.dec.count, B, c.act[e], keep ? c.gd[e] : nullptr))) return rc;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int erl_sac_param_counts(int S, int A, const int *hidden, int n_hidden, int E, int64_t *actor_count, int64_t *critic_count)
+{
+    SacDims d;
+    ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, E, &d), "erl_sac_param_counts: unsupported dims");
+    if (actor_count) *actor_count = d.Pa;
+    if (critic_count) *critic_count = d.Pc;
+    return ERL_OK;
+}
+
+extern "C" int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int n_hidden, int E, int64_t B)
+{
+    SacDims d;
+    if (!make_sac_dims(S, A, hidden, n_hidden, E, &d) || B < 1) return -1;
+    int maxd = S + A;
+    for (int i = 0; i < n_hidden; ++i) maxd = hidden[i] > maxd ? hidden[i] : maxd;
+    maxd = 2 * A > maxd ? 2 * A : maxd;
+    int64_t f = 0;
+    f += 2 * (B * (S + A) + 64);                                     // xa, dxa
+    for (int l = 0; l <= d.actor.n; ++l) f += 2 * (B * d.actor.d[l] + 64);   // actor activations + GELU'
+    f += critic_ws_floats(d, B);
+    f += 4 * (B * A + 64) + 6 * (B + 64) + (int64_t)d.E * B + 64;    // actions, eps, dA, t | logprobs, label, ones, ... | dq
+    f += 3 * (B * maxd + 64) + B * 2 * A + 64;                       // tmpA, tmpB, dEnc, dHead
+    f += d.Pa + d.Pc + 64 + 1024;                                     // gradients, partials
+    return f * 4 + 8192;
+}
+
+extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
+                                  float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
+                                  const int *hidden, int n_hidden, int E, const float *state, const float *action,
+                                  const float *reward, const float *undone, const float *unmask, const float *next_state, int64_t B,
+                                  const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
+                                  float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                                  int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    ERL_REQUIRE(actor_params && critic_params && target_params && alpha_log && actor_m && actor_v && critic_m && critic_v && alpha_m &&
+                    alpha_v && state && action && reward && undone && unmask && next_state && objs_out && workspace,
+                "erl_sac_update_f32: NULL tensor");
+    SacDims d;
+    ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, E, &d), "erl_sac_update_f32: unsupported dims");
+    ERL_REQUIRE(B >= 1 && B < (1LL << 24) && step >= 1, "erl_sac_update_f32: bad argument");
+    ERL_REQUIRE(workspace_bytes >= erl_sac_workspace_bytes(S, A, hidden, n_hidden, E, B), "erl_sac_update_f32: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    rocblas_handle h;
+    int rc = blas(s, &h);
+    if (rc) return rc;
+
+    Ws ws{(char *)workspace, 0, workspace_bytes};
+    int maxd = S + A;
+    for (int i = 0; i < n_hidden; ++i) maxd = hidden[i] > maxd ? hidden[i] : maxd;
+    maxd = 2 * A > maxd ? 2 * A : maxd;
+    float *xa = ws.take(B * (S + A)), *dxa = ws.take(B * (S + A));
+    float *aact[MAXL + 2], *agd[MAXL + 2];
+    for (int l = 0; l <= d.actor.n; ++l) {
+        aact[l] = ws.take(B * d.actor.d[l]);
+        agd[l] = (l >= 1 && l < d.actor.n) ? ws.take(B * d.actor.d[l]) : nullptr;
+    }
+    CriticWs cw;
+    ERL_REQUIRE(carve_critic(ws, d, B, &cw), "erl_sac_update_f32: workspace layout");
+    float *act_t = ws.take(B * A), *eps_used = ws.take(B * A), *dAct = ws.take(B * A);
+    float *lp_next = ws.take(B), *lp_cur = ws.take(B), *label = ws.take(B), *ones = ws.take(B);
+    float *dq = ws.take((int64_t)E * B);
+    float *tmpA = ws.take(B * maxd), *tmpB = ws.take(B * maxd), *dEnc = ws.take(B * d.enc.d[1]);
+    float *dHead = ws.take(B * 2 * A);
+    float *g_actor = ws.take(d.Pa), *g_critic = ws.take(d.Pc), *g_alpha = ws.take(4);
+    const int nparts = (int)erl_cdiv(B, 256);
+    float *part = ws.take(nparts);
+    ERL_REQUIRE(part != nullptr, "erl_sac_update_f32: workspace layout (tail)");
+    const dim3 rows_grid((unsigned)erl_cdiv(B, 256)), blk(256);
+
+    hipLaunchKernelGGL(fillk_kernel, dim3(grid1d(B)), blk, 0, s, ones, 1.0f, B);
+
+    // ---- (1) targets: next action / log-prob from the actor, min over the TARGET ensemble          (:50-55)
+    (void)hipMemcpyAsync(aact[0], next_state, (size_t)B * S * 4, hipMemcpyDeviceToDevice, s);
+    if ((rc = forward(h, s, d.actor, actor_params, B, aact, nullptr))) return rc;
+    hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_next, seed, 2 * counter, A, B, act_t, lp_next,
+                       (float *)nullptr);
+    hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, next_state, act_t, S, A, B, xa);
+    if ((rc = critic_forward(h, s, d, target_params, B, xa, cw, false))) return rc;
+    hipLaunchKernelGGL(q_label_kernel, rows_grid, blk, 0, s, cw.q, E, B, reward, undone, lp_next, alpha_log, gamma, label);
+
+    // ---- (2) critic objective, backward, clip + Adam, soft target update                          (:57-70)
+    hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, state, action, S, A, B, xa);
+    if ((rc = critic_forward(h, s, d, critic_params, B, xa, cw, true))) return rc;
+    hipLaunchKernelGGL(critic_loss_kernel, rows_grid, blk, 0, s, cw.q, label, unmask, E, B, dq, part);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, part, (int64_t)nparts, 1.0f / (float)B, 0.f, objs_out);
+    for (int e = 0; e < E; ++e) {
+        float *Gdec = g_critic + d.enc.count + (int64_t)e * d.dec.count;
+        if ((rc = backward(h, s, d.dec, critic_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
+                           Gdec, ones, dEnc, e > 0, tmpA, tmpB)))
+            return rc;
+    }
+    {   // encoder: one raw linear layer, input xa
+        float *ea[2] = {xa, cw.enc};
+        if ((rc = backward(h, s, d.enc, critic_params, B, ea, nullptr, dEnc, g_critic, ones, nullptr, false, tmpA, tmpB))) return rc;
+    }
+    {
+        const int64_t off = 0, len = d.Pc;
+        if ((rc = erl_clip_adam_f32(critic_params, g_critic, critic_m, critic_v, &off, &len, 1, nullptr, step, lr, beta1, beta2, eps_adam,
+                                    max_norm, 1.0f, stream)))
+            return rc;
+    }
+    hipLaunchKernelGGL(soft_update_kernel, dim3(grid1d(d.Pc)), blk, 0, s, target_params, critic_params, tau, d.Pc);
+
+    // ---- (3) policy-gradient sample, temperature step                                              (:72-81)
+    (void)hipMemcpyAsync(aact[0], state, (size_t)B * S * 4, hipMemcpyDeviceToDevice, s);
+    if ((rc = forward(h, s, d.actor, actor_params, B, aact, agd))) return rc;
+    hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_cur, seed, 2 * counter + 1, A, B, act_t, lp_cur,
+                       eps_used);
+    // obj_alpha = mean(alpha_log * (target_entropy - logprob)):  d/dalpha_log = target_entropy - mean(logprob)
+    hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, lp_cur, B, -1.0f / (float)B, target_entropy, g_alpha);
+    {
+        const int64_t off = 0, len = 1;
+        if ((rc = erl_clip_adam_f32(alpha_log, g_alpha, alpha_m, alpha_v, &off, &len, 1, nullptr, step, lr, beta1, beta2, eps_adam, max_norm,
+                                    1.0f, stream)))
+            return rc;
+    }
+
+    // ---- (4) actor objective against the TARGET ensemble's mean, backward into the action, head, actor   (:82-85)
+    hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, state, act_t, S, A, B, xa);
+    if ((rc = critic_forward(h, s, d, target_params, B, xa, cw, true))) return rc;
+    hipLaunchKernelGGL(actor_obj_kernel, dim3(1), blk, 0, s, cw.q, E, B, lp_cur, alpha_log, objs_out + 1);
+    hipLaunchKernelGGL(fillk_kernel, dim3(grid1d((int64_t)E * B)), blk, 0, s, dq, -1.0f / ((float)E * (float)B), (int64_t)E * B);
+    for (int e = 0; e < E; ++e)
+        if ((rc = backward(h, s, d.dec, target_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
+                           nullptr, ones, dEnc, e > 0, tmpA, tmpB)))
+            return rc;
+    if ((rc = gemm_dx(h, dEnc, target_params, dxa, (int)B, d.enc.d[1], S + A))) return rc;      // dL/d[state | action]
+    // action columns of dxa -> contiguous (B, A)
+    (void)hipMemcpy2DAsync(dAct, (size_t)A * 4, dxa + S, (size_t)(S + A) * 4, (size_t)A * 4, (size_t)B, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dAct, alpha_log, A, B, dHead);
+    hipLaunchKernelGGL(clamp_alpha_kernel, dim3(1), dim3(64), 0, s, alpha_log);                  // after alpha was read (:80-81)
+    if ((rc = backward(h, s, d.actor, actor_params, B, aact, agd, dHead, g_actor, ones, nullptr, false, tmpA, tmpB))) return rc;
+    {
+        const int64_t off = 0, len = d.Pa;
+        if ((rc = erl_clip_adam_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, nullptr, step, lr, beta1, beta2, eps_adam,
+                                    max_norm, 1.0f, stream)))
+            return rc;
+    }
+    ERL_LAUNCH_CHECK("erl_sac_update_f32");
+}
+
+// ActorSAC.get_action for the off-policy rollout (AgentSAC.py:179-185): action = tanh(mean + std * eps)
+extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden, const float *state,
+                                          int64_t N, const float *noise, uint64_t seed, uint64_t counter, float *action_out,
+                                          void *workspace, int64_t workspace_bytes, void *stream)
+{
+    ERL_REQUIRE(actor_params && state && action_out && workspace, "erl_sac_explore_action_f32: NULL tensor");
+    SacDims d;
+    ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, 1, &d), "erl_sac_explore_action_f32: unsupported dims");
+    ERL_REQUIRE(N >= 1 && N < (1LL << 31), "erl_sac_explore_action_f32: bad N");
+    hipStream_t s = (hipStream_t)stream;
+    rocblas_handle h;
+    int rc = blas(s, &h);
+    if (rc) return rc;
+    Ws ws{(char *)workspace, 0, workspace_bytes};
+    float *aact[MAXL + 2];
+    aact[0] = const_cast<float *>(state);
+    for (int l = 1; l <= d.actor.n; ++l) aact[l] = ws.take(N * d.actor.d[l]);
+    float *lp = ws.take(N);
+    ERL_REQUIRE(lp != nullptr, "erl_sac_explore_action_f32: workspace too small");
+    if ((rc = forward(h, s, d.actor, actor_params, N, aact, nullptr))) return rc;
+    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, aact[d.actor.n], noise, seed, counter, A, N,
+                       action_out, lp, (float *)nullptr);
+    ERL_LAUNCH_CHECK("erl_sac_explore_action_f32");
+}

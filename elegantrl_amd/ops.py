@@ -339,6 +339,76 @@ def mlpn_ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: 
 
 
 # ------------------------------------------------------------------------------------------------
+# SAC (erl_sac_*)
+# ------------------------------------------------------------------------------------------------
+class SacSpec:
+    """shapes of ActorSAC / CriticEnsemble as flat fp32 blocks (include/erl_hip.h)."""
+
+    def __init__(self, S: int, A: int, hidden: Sequence[int], num_ensembles: int):
+        self.S, self.A, self.hidden, self.E = int(S), int(A), [int(h) for h in hidden], int(num_ensembles)
+        self._c = (ctypes.c_int * len(self.hidden))(*self.hidden)
+        pa, pc = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().erl_sac_param_counts(self.S, self.A, self._c, len(self.hidden), self.E, ctypes.byref(pa), ctypes.byref(pc)),
+              "erl_sac_param_counts")
+        self.actor_count, self.critic_count = pa.value, pc.value
+
+    def actor_slices(self):
+        """(parameter name in ActorSAC, offset, shape) in flat order."""
+        out, o, dims = [], 0, [self.S, *self.hidden]
+        for i, (d_in, d_out) in enumerate(zip(dims[:-1], dims[1:])):
+            out += [(f"net_s.{2 * i}.weight", o, (d_out, d_in)), (f"net_s.{2 * i}.bias", o + d_out * d_in, (d_out,))]
+            o += d_out * d_in + d_out
+        d_in, d_out = self.hidden[-1], 2 * self.A
+        out += [("net_a.0.weight", o, (d_out, d_in)), ("net_a.0.bias", o + d_out * d_in, (d_out,))]
+        return out
+
+    def critic_slices(self):
+        out, o = [], 0
+        d_in, d_out = self.S + self.A, self.hidden[0]
+        out += [("encoder_sa.0.weight", o, (d_out, d_in)), ("encoder_sa.0.bias", o + d_out * d_in, (d_out,))]
+        o += d_out * d_in + d_out
+        dims = [*self.hidden, 1]
+        for e in range(self.E):
+            for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+                out += [(f"decoder_q{e:02}.{2 * i}.weight", o, (b, a)), (f"decoder_q{e:02}.{2 * i}.bias", o + b * a, (b,))]
+                o += b * a + b
+        return out
+
+    def workspace_bytes(self, B: int) -> int:
+        return lib().erl_sac_workspace_bytes(self.S, self.A, self._c, len(self.hidden), self.E, B)
+
+
+def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: TEN, moments: Sequence[TEN], batch: Sequence[TEN],
+               step: int, *, gamma: float, target_entropy: float, tau: float, lr: float, max_norm: float, objs_out: TEN,
+               noises: Optional[Tuple[TEN, TEN]] = None, seed: int = 0, counter: int = 0, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """one AgentSAC.update_objectives step after the sample; `moments` = (actor_m, actor_v, critic_m, critic_v, alpha_m,
+    alpha_v); `batch` = (state, action, reward, undone, unmask, next_state); objs_out: float32[2] on the device."""
+    state, action, reward, undone, unmask, next_state = batch
+    B = state.shape[0]
+    ws = _workspace(state.device, spec.workspace_bytes(B))
+    n_next, n_cur = (None, None) if noises is None else noises
+    f32 = th.float32
+    check(lib().erl_sac_update_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
+                                   spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ptr(state, f32), ptr(action, f32),
+                                   ptr(reward, f32), ptr(undone, f32), ptr(unmask, f32), ptr(next_state, f32), B, ptr(n_next),
+                                   ptr(n_cur), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), gamma, target_entropy, tau, lr, betas[0],
+                                   betas[1], eps, max_norm, step, ptr(objs_out, f32), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_sac_update_f32")
+
+
+def sac_explore_action(spec: SacSpec, actor: TEN, state: TEN, *, noise: Optional[TEN] = None, seed: int = 0, counter: int = 0,
+                       out: Optional[TEN] = None) -> TEN:
+    N = state.shape[0]
+    out = th.empty((N, spec.A), dtype=th.float32, device=state.device) if out is None else out
+    ws = _workspace(state.device, spec.workspace_bytes(N))
+    check(lib().erl_sac_explore_action_f32(ptr(actor, th.float32), spec.S, spec.A, spec._c, len(spec.hidden), ptr(state, th.float32), N,
+                                           ptr(noise), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), ptr(out, th.float32), ptr(ws),
+                                           ws.numel(), stream_ptr()),
+          "erl_sac_explore_action_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # environments
 # ------------------------------------------------------------------------------------------------
 def synenv_step(state: TEN, action: TEN, Ws: TEN, Wa: TEN, step_count: TEN, episode: TEN, reward: TEN, terminal: TEN,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 4
+#define ERL_ABI_VERSION 5
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -221,6 +221,32 @@ ERL_API int erl_mlpn_ppo_step_f32(const float *actor_params, const float *critic
                           const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
                           int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
                           float inv_batch, float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SAC: everything AgentSAC.update_objectives does after ReplayBuffer.sample
+ * (elegantrl/agents/AgentSAC.py:50-86) in ONE call: target computation with the tanh-Gaussian actor (:167-199) and the
+ * TARGET critic ensemble (:243-259), critic step + soft update (AgentBase.py:270-278), temperature step, actor step --
+ * three clip + Adam steps (AgentBase.py:239-248).  hidden = net_dims (n_hidden <= ERL_MAX_LAYERS), E = num_ensembles.
+ * Parameter blocks: actor = build_mlp([S, *hidden]) (GELU after every layer) + Linear(hidden[-1], 2A);
+ * critic/target = Linear(S + A, hidden[0]) | E x build_mlp([*hidden, 1]).  The batch tensors are what
+ * erl_replay_sample_f32 returned (B rows).  eps_next / eps_cur (B, A) inject the two rsample() draws (tests); NULL ->
+ * Philox keyed by (seed, counter).  objs_out: device float[2] = (obj_critic, obj_actor).  step = 1-based Adam step.
+ * erl_sac_explore_action_f32 = ActorSAC.get_action (:179-185) for the off-policy rollout.
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int erl_sac_param_counts(int S, int A, const int *hidden, int n_hidden, int E, int64_t *actor_count,
+                         int64_t *critic_count);
+ERL_API int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int n_hidden, int E, int64_t B);
+ERL_API int erl_sac_update_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log,
+                       float *actor_m, float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v,
+                       int S, int A, const int *hidden, int n_hidden, int E, const float *state, const float *action,
+                       const float *reward, const float *undone, const float *unmask, const float *next_state,
+                       int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
+                       float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam,
+                       float max_norm, int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes,
+                       void *stream);
+ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
+                               const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
+                               float *action_out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* measurement hook: when enabled, erl_ppo_step_f32 brackets its K6 launch with HIP events on the launch stream;
  * erl_k6_timing_read waits for them, returns the summed time (ms) and the launch count, and clears the list. */

@@ -1,0 +1,133 @@
+"""torch (CPU) restatement of the reference's SAC update step.  ORACLE / TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Restates elegantrl/agents/AgentSAC.py:42-86 (update_objectives), :167-199 (ActorSAC), :243-259 (CriticEnsemble),
+elegantrl/agents/AgentBase.py:239-248 (optimizer_backward), :270-278 (soft_update) with every random draw injectable.
+Pinned by tests/test_sac.py::test_torch_restatement_replays_the_reference against tests/golden/sac_small.npz (outputs of
+the reference's own AgentSAC, oracle/make_golden.py:make_sac); the HIP implementation (csrc/sac.hip) is then checked
+against the same fixture.
+"""
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+from typing import List, Optional, Tuple
+
+import torch as th
+from torch import nn
+
+TEN = th.Tensor
+
+
+def build_mlp(dims: List[int], if_raw_out: bool = True) -> nn.Sequential:
+    layers: list = []
+    for d_in, d_out in zip(dims[:-1], dims[1:]):
+        layers += [nn.Linear(d_in, d_out), nn.GELU()]
+    if if_raw_out:
+        layers.pop()
+    return nn.Sequential(*layers)
+
+
+def layer_init_with_orthogonal(layer, std: float = 1.0, bias_const: float = 1e-6):
+    th.nn.init.orthogonal_(layer.weight, std)
+    th.nn.init.constant_(layer.bias, bias_const)
+
+
+class ActorSAC(nn.Module):
+    """state -> encoder MLP (GELU after every layer) -> linear head -> (mean, log_std); action = tanh(mean + std * eps)."""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int):
+        super().__init__()
+        self.state_dim, self.action_dim = state_dim, action_dim
+        self.net_s = build_mlp(dims=[state_dim, *net_dims], if_raw_out=False)
+        self.net_a = build_mlp(dims=[net_dims[-1], action_dim * 2])
+        layer_init_with_orthogonal(self.net_a[-1], std=0.1)
+
+    def _head(self, state: TEN) -> Tuple[TEN, TEN]:
+        mean, log_std = self.net_a(self.net_s(state)).chunk(2, dim=1)
+        return mean, log_std.clamp(-16, 2).exp()
+
+    def forward(self, state: TEN) -> TEN:
+        return self.net_a(self.net_s(state))[:, :self.action_dim].tanh()
+
+    def get_action(self, state: TEN, noise: Optional[TEN] = None) -> TEN:
+        mean, std = self._head(state)
+        eps = th.randn_like(mean) if noise is None else noise
+        return (mean + std * eps).tanh()                       # Normal(mean, std).rsample().tanh()
+
+    def get_action_logprob(self, state: TEN, noise: Optional[TEN] = None) -> Tuple[TEN, TEN]:
+        mean, std = self._head(state)
+        eps = th.randn_like(mean) if noise is None else noise
+        action_tanh = (mean + std * eps).tanh()
+        logprob = -std.log() - math.log(math.sqrt(2 * math.pi))          # Normal.log_prob evaluated at the mean (:197)
+        logprob = logprob - (-action_tanh.pow(2) + 1.000001).log()       # tanh correction (:198)
+        return action_tanh, logprob.sum(1)
+
+
+class CriticEnsemble(nn.Module):
+    """shared (state, action) encoder layer + `num_ensembles` independent Q decoders; forward = ensemble mean."""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, num_ensembles: int = 4):
+        super().__init__()
+        self.state_dim, self.action_dim = state_dim, action_dim
+        self.encoder_sa = build_mlp(dims=[state_dim + action_dim, net_dims[0]])
+        self.decoder_qs = []
+        for i in range(num_ensembles):
+            dec = build_mlp(dims=[*net_dims, 1])
+            layer_init_with_orthogonal(dec[-1], std=0.5)
+            self.decoder_qs.append(dec)
+            setattr(self, f"decoder_q{i:02}", dec)              # registers the parameters under the reference's names
+
+    def get_q_values(self, state: TEN, action: TEN) -> TEN:
+        enc = self.encoder_sa(th.cat((state, action), dim=1))
+        return th.cat([dec(enc) for dec in self.decoder_qs], dim=-1)
+
+    def forward(self, state: TEN, action: TEN) -> TEN:
+        return self.get_q_values(state, action).mean(dim=-1, keepdim=True)
+
+
+
+class SacStepper:
+    """holds actor / critic / target / alpha and their Adam optimisers; `step` = one update_objectives on a given batch."""
+
+    def __init__(self, net_dims, state_dim, action_dim, num_ensembles, lr, gamma, tau, max_norm):
+        self.act = ActorSAC(list(net_dims), state_dim, action_dim)
+        self.cri = CriticEnsemble(list(net_dims), state_dim, action_dim, num_ensembles)
+        self.cri_target = deepcopy(self.cri)
+        self.alpha_log = th.tensor((-1,), dtype=th.float32, requires_grad=True)
+        self.gamma, self.tau, self.max_norm = gamma, tau, max_norm
+        self.target_entropy = math.log(action_dim)
+        self.lr = lr
+        self.reset_optimizers()
+
+    def reset_optimizers(self):
+        self.act_opt = th.optim.Adam(self.act.parameters(), self.lr)
+        self.cri_opt = th.optim.Adam(self.cri.parameters(), self.lr)
+        self.alpha_opt = th.optim.Adam((self.alpha_log,), lr=self.lr)
+
+    def _opt(self, opt, obj):
+        opt.zero_grad()
+        obj.backward()
+        th.nn.utils.clip_grad_norm_(parameters=opt.param_groups[0]["params"], max_norm=self.max_norm)
+        opt.step()
+
+    def step(self, batch, eps_next: TEN, eps_cur: TEN) -> Tuple[float, float]:
+        state, action, reward, undone, unmask, next_state = batch
+        with th.no_grad():
+            next_action, next_logprob = self.act.get_action_logprob(next_state, eps_next)
+            next_q = th.min(self.cri_target.get_q_values(next_state, next_action), dim=1)[0]
+            q_label = reward + undone * self.gamma * (next_q - next_logprob * self.alpha_log.exp())
+        q_values = self.cri.get_q_values(state, action)
+        td = ((q_values - q_label.view(-1, 1)) ** 2).mean(dim=1) * unmask
+        obj_critic = td.mean()
+        self._opt(self.cri_opt, obj_critic)
+        with th.no_grad():
+            for tar, cur in zip(self.cri_target.parameters(), self.cri.parameters()):
+                tar.data.copy_(cur.data * self.tau + tar.data * (1.0 - self.tau))
+        action_pg, logprob = self.act.get_action_logprob(state, eps_cur)
+        self._opt(self.alpha_opt, (self.alpha_log * (self.target_entropy - logprob).detach()).mean())
+        alpha = self.alpha_log.exp().detach()
+        with th.no_grad():
+            self.alpha_log[:] = self.alpha_log.clamp(-16, 2)
+        obj_actor = (self.cri_target(state, action_pg).mean() - logprob * alpha).mean()
+        self._opt(self.act_opt, -obj_actor)
+        return obj_critic.item(), obj_actor.item()

@@ -13,6 +13,34 @@ def _load_nets(g, tag, act, cri):
     cri.load_state_dict({k[len(f"cri{tag}."):]: th.from_numpy(v) for k, v in g.items() if k.startswith(f"cri{tag}.")})
 
 
+def test_torch_restatement_replays_the_reference():
+    """oracle/sac_torch.py (CPU) against the reference-generated golden: objectives, actor, critics, target and alpha after
+    each of the 3 recorded update steps."""
+    from oracle.sac_torch import SacStepper
+    g = load("sac_small.npz")
+    N, S, A, rows, B, n_upd, n_ens, h1, h2 = [int(x) for x in g["dims"]]
+    gamma, lr, max_norm, reward_scale, tau, target_entropy = [float(x) for x in g["hyper"]]
+    st = SacStepper([h1, h2], S, A, n_ens, lr, gamma, tau, max_norm)
+    _load_nets(g, 0, st.act, st.cri)
+    st.cri_target.load_state_dict(st.cri.state_dict())
+    with th.no_grad():
+        st.alpha_log[:] = th.from_numpy(g["alpha_log0"])
+    st.reset_optimizers()
+    ring = {k: th.from_numpy(g[f"ro_{k}"]) for k in ("states", "actions", "rewards", "undones", "unmasks")}
+    L = rows - 1
+    for t in range(n_upd):
+        ids = th.from_numpy(g["ids"][t])
+        i0, i1 = ids % L, ids // L
+        batch = (ring["states"][i0, i1], ring["actions"][i0, i1], ring["rewards"][i0, i1], ring["undones"][i0, i1].float(),
+                 ring["unmasks"][i0, i1].float(), ring["states"][i0 + 1, i1])
+        oc, oa = st.step(batch, th.from_numpy(g["eps_next"][t]), th.from_numpy(g["eps_cur"][t]))
+        np.testing.assert_allclose([oc, oa], g["objs"][t], rtol=1e-5, atol=1e-7)
+        for prefix, net in ((f"act{t + 1}", st.act), (f"cri{t + 1}", st.cri), (f"crit{t + 1}", st.cri_target)):
+            for k, v in net.state_dict().items():
+                np.testing.assert_allclose(v.numpy(), g[f"{prefix}.{k}"], rtol=0, atol=2e-6, err_msg=f"{prefix}.{k}")
+        np.testing.assert_allclose(st.alpha_log.detach().numpy(), g[f"alpha_log{t + 1}"], rtol=0, atol=1e-6)
+
+
 def test_actor_critic_modules_match_reference_rollout_on_cpu():
     """module-level math on CPU: stored action == tanh(mean + std * eps) for the recorded eps (AgentSAC.py:179-185)."""
     from elegantrl_amd.agents.AgentSAC import ActorSAC, CriticEnsemble

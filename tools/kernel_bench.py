@@ -73,6 +73,18 @@ def main():
     items = [th.randn((add, 1, S3), device=dev), th.randn((add, 1, A3), device=dev), th.randn((add, 1), device=dev),
              th.rand((add, 1), device=dev) > 0.5, th.rand((add, 1), device=dev) > 0.5]
     out["replay_write_4096rows"] = timeit(lambda: ops.replay_write(rs, ra, rr, ru, rm, items, M - 1000))
+    # SAC update step (config 3 shapes): one erl_sac_update_f32 call
+    for tag, hid, Bq in (("64x32_B256", [64, 32], 256), ("256x256_B256", [256, 256], 256), ("256x256_B1024", [256, 256], 1024)):
+        spec = ops.SacSpec(S3, A3, hid, 4)
+        pa = th.randn(spec.actor_count, device=dev, generator=g) * 0.1
+        pc = th.randn(spec.critic_count, device=dev, generator=g) * 0.1
+        pt, al = pc.clone(), th.full((1,), -1.0, device=dev)
+        mom = [th.zeros_like(pa), th.zeros_like(pa), th.zeros_like(pc), th.zeros_like(pc), th.zeros(1, device=dev), th.zeros(1, device=dev)]
+        rid = th.randint(M - 1, (Bq,), device=dev, generator=g)
+        batch, _ = ops.replay_sample(rs, ra, rr, ru, rm, rid, M - 1)
+        objs = th.zeros(2, device=dev)
+        out[f"sac_update_{tag}"] = timeit(lambda: ops.sac_update(spec, pa, pc, pt, al, mom, batch, 3, gamma=0.99, target_entropy=1.1,
+                                                                  tau=5e-3, lr=1e-4, max_norm=3.0, objs_out=objs), iters=10)
     out = {k: round(v, 2) for k, v in out.items()}
     print(json.dumps(out))
     os.makedirs("gpurun_out", exist_ok=True)
