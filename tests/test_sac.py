@@ -147,3 +147,30 @@ def test_sac_update_net_loop_on_hopper_shaped_ring():
         assert np.isfinite([oc, oa]).all()
     assert buf.cur_size == 2 * H and int(buf.cur_size * args.repeat_times / args.batch_size) == 4
     assert any(not th.equal(a, b) for a, b in zip(w0, agent.act.parameters()))
+
+
+@pytest.mark.gpu
+def test_train_agent_sac_pendulum_learns(tmp_path):
+    """config-3 style loop through train_agent: off-policy rollout -> ring -> erl_sac_update_f32; files like the reference's
+    run.py writes them, and the policy improves on Pendulum (a few thousand SAC steps)."""
+    import os
+    from elegantrl_amd import train_agent
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import PendulumVecEnv
+    from elegantrl_amd.train import Config
+    args = Config(AgentSAC, PendulumVecEnv, {"env_name": "Pendulum-v1", "num_envs": 64, "max_step": 200, "state_dim": 3,
+                                             "action_dim": 1, "if_discrete": False})
+    args.net_dims = [128, 64]
+    args.horizon_len, args.batch_size, args.repeat_times = 25, 256, 256.0 / 25 * 2   # ~2 SAC steps per collected row-block... cur_size based
+    args.buffer_size = 20_000
+    args.gamma, args.reward_scale, args.learning_rate = 0.97, 2 ** -2, 3e-4
+    args.break_step, args.eval_per_step, args.eval_times = 25 * 60, 25 * 20, 8
+    args.cwd, args.gpu_id, args.random_seed = str(tmp_path / "run"), 0, 0
+    train_agent(args, if_single_process=True)
+    files = os.listdir(args.cwd)
+    assert "act.pth" in files and "cri.pth" in files and "cri_target.pth" in files and "recorder.npy" in files
+    rec = np.load(os.path.join(args.cwd, "recorder.npy"))
+    assert np.isfinite(rec[:, :4]).all()
+    assert rec[-1, 1] > rec[0, 1] + 50, f"no learning progress: first eval {rec[0, 1]:.1f}, last {rec[-1, 1]:.1f}"
+    actor = th.load(os.path.join(args.cwd, "act.pth"), weights_only=False)
+    assert actor(th.zeros((2, 3), device="cuda:0")).shape == (2, 1)
