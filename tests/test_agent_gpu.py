@@ -110,13 +110,14 @@ def test_update_net_matches_reference_weights_and_objectives(name):
     assert moved > 1e-4
 
 
-def test_c4_iteration_against_oracle():
-    """BASELINE config 4 shapes (4096 envs, obs 64, act 8, H=32, B=16384): one rollout + 2 minibatches,
-    checked end to end against the fp64 oracle driven with the same noise and ids."""
+@pytest.mark.parametrize("N,S", [(4096, 64), (8192, 60)], ids=["config4", "config5-ant-shaped"])
+def test_c4_iteration_against_oracle(N, S):
+    """BASELINE config 4 (4096 envs, obs 64) and config 5 (Ant-shaped: 8192 envs, obs 60) shapes, act 8, H=32, B=16384:
+    one rollout + 2 minibatches, checked end to end against the fp64 oracle driven with the same noise and ids."""
     from elegantrl_amd.agents import AgentPPO
     from elegantrl_amd.envs import SynVecEnv
     from elegantrl_amd.train import Config
-    N, S, A, H, B = 4096, 64, 8, 32, 16384
+    A, H, B = 8, 32, 16384
     args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 1000, "state_dim": S,
                                         "action_dim": A, "if_discrete": False})
     args.horizon_len, args.batch_size, args.repeat_times = H, B, 2 * B / H
