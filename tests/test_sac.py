@@ -174,3 +174,49 @@ def test_train_agent_sac_pendulum_learns(tmp_path):
     assert rec[-1, 1] > rec[0, 1] + 50, f"no learning progress: first eval {rec[0, 1]:.1f}, last {rec[-1, 1]:.1f}"
     actor = th.load(os.path.join(args.cwd, "act.pth"), weights_only=False)
     assert actor(th.zeros((2, 3), device="cuda:0")).shape == (2, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,A,hidden,E,B", [(5, 1, (32,), 1, 37), (11, 3, (256, 256), 4, 256), (17, 6, (64, 48, 32), 2, 130),
+                                           (3, 1, (128, 64), 4, 64)])
+def test_sac_update_matches_torch_restatement_on_other_shapes(S, A, hidden, E, B):
+    """erl_sac_update_f32 vs oracle/sac_torch.py (itself pinned to the reference golden) on random batches for network
+    shapes the golden does not cover: 1..3 hidden layers, 1..4 ensembles, scalar actions, the demos' [256, 256]."""
+    from elegantrl_amd import ops
+    from oracle.sac_torch import SacStepper
+    dev = th.device("cuda:0")
+    th.manual_seed(S * 100 + E)
+    st = SacStepper(list(hidden), S, A, E, lr=1e-3, gamma=0.97, tau=5e-3, max_norm=3.0)
+    with th.no_grad():                                          # make target != critic and log_std span the clamp range
+        for p in st.cri_target.parameters():
+            p.add_(0.05 * th.randn_like(p))
+        st.act.net_a[0].bias[A:] = th.linspace(-18.0, 3.0, A) if A > 1 else th.tensor([0.3])
+    spec = ops.SacSpec(S, A, hidden, E)
+
+    def flat(module, slices):
+        sd = dict(module.named_parameters())
+        return th.cat([sd[name].detach().reshape(-1) for name, _, _ in slices]).to(dev).contiguous()
+
+    pa, pc, pt = flat(st.act, spec.actor_slices()), flat(st.cri, spec.critic_slices()), flat(st.cri_target, spec.critic_slices())
+    assert pa.numel() == spec.actor_count and pc.numel() == spec.critic_count
+    alpha = st.alpha_log.detach().clone().to(dev)
+    mom = [th.zeros_like(pa), th.zeros_like(pa), th.zeros_like(pc), th.zeros_like(pc), th.zeros(1, device=dev), th.zeros(1, device=dev)]
+    objs = th.zeros(2, device=dev)
+    for step in range(1, 4):
+        batch = (th.randn(B, S), th.randn(B, A).tanh(), th.randn(B), (th.rand(B) > 0.1).float(), (th.rand(B) > 0.1).float(),
+                 th.randn(B, S))
+        e_next, e_cur = th.randn(B, A), th.randn(B, A)
+        ref = st.step(batch, e_next, e_cur)
+        ops.sac_update(spec, pa, pc, pt, alpha, mom, [x.to(dev).contiguous() for x in batch], step, gamma=0.97,
+                       target_entropy=st.target_entropy, tau=5e-3, lr=1e-3, max_norm=3.0, objs_out=objs,
+                       noises=(e_next.to(dev), e_cur.to(dev)))
+        np.testing.assert_allclose(objs.cpu().numpy(), ref, rtol=3e-4, atol=3e-6)
+        # Adam turns a gradient g into a step lr * g / (|g| + 1e-8): for the handful of weights whose gradient is at the
+        # fp32 noise floor (|g| ~ 1e-9, summation order of rocBLAS vs torch) the step can differ by up to lr per update.
+        # Bar: >= 99.5 % of every block within 5e-5, no element further than the accumulated Adam step bound.
+        for got, module, slices in ((pa, st.act, spec.actor_slices()), (pc, st.cri, spec.critic_slices()),
+                                    (pt, st.cri_target, spec.critic_slices())):
+            diff = np.abs(got.cpu().numpy() - flat(module, slices).cpu().numpy())
+            assert (diff <= 5e-5).mean() >= 0.995, f"{(diff > 5e-5).mean():.4%} of the block is off"
+            assert diff.max() <= 2.2 * step * 1e-3
+        np.testing.assert_allclose(alpha.cpu().numpy(), st.alpha_log.detach().numpy(), rtol=0, atol=1e-5)
