@@ -51,8 +51,11 @@ extern "C" int64_t erl_mlpn_workspace_bytes(const int *dims, int n_dims, int64_t
         for (int l = 1; l < nd.n; ++l) f += rows * nd.d[l] + 64;      // GELU'
         f += 2 * (rows * maxd + 64);                                  // dH ping-pong
         f += rows * nd.d[nd.n] + 64;                                  // DSL
-        f += rows + 64;                                               // ones
+        f += colsum_scratch_floats(rows, maxd) + 64;                  // bias-gradient partials
         f += 2 * (erl_cdiv(rows, 256) + 64);                          // loss partials
+        int64_t nk = 1;
+        for (int l = 0; l < nd.n; ++l) nk = (int64_t)nd.d[l] * nd.d[l + 1] > nk ? (int64_t)nd.d[l] * nd.d[l + 1] : nk;
+        f += dw_scratch_floats(rows, nk) + 64;                        // per-chunk dW partials
     }
     return f * 4 + 4096;
 }
@@ -146,12 +149,14 @@ extern "C" int erl_mlpn_ppo_step_f32(const float *actor_params, const float *cri
         for (int l = 1; l < nd.n; ++l) gd[l] = ws.take(B * nd.d[l]);
         float *dA = ws.take(B * maxd), *dB = ws.take(B * maxd);
         float *dsl = ws.take(B * nd.d[nd.n]);
-        float *ones = ws.take(B);
+        float *cs_scr = ws.take(colsum_scratch_floats(B, maxd));
         const int nparts = (int)erl_cdiv(B, 256);
         float *part = ws.take(2 * (int64_t)nparts);
-        ERL_REQUIRE(part != nullptr, "erl_mlpn_ppo_step_f32: workspace too small (need erl_mlpn_workspace_bytes(dims, rows = B, training = 1))");
+        int64_t nk = 1;
+        for (int l = 0; l < nd.n; ++l) nk = (int64_t)nd.d[l] * nd.d[l + 1] > nk ? (int64_t)nd.d[l] * nd.d[l + 1] : nk;
+        float *dw_scr = dw_scratch_floats(B, nk) ? ws.take(dw_scratch_floats(B, nk)) : nullptr;
+        ERL_REQUIRE(part != nullptr && (dw_scr != nullptr || !dw_scratch_floats(B, nk)), "erl_mlpn_ppo_step_f32: workspace too small (need erl_mlpn_workspace_bytes(dims, rows = B, training = 1))");
 
-        hipLaunchKernelGGL(fill_kernel, dim3(grid1d(B)), dim3(256), 0, s, ones, 1.0f, B);
         hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(B * nd.d[0])), dim3(256), 0, s, states, net == 0 ? act_avg : cri_avg,
                            net == 0 ? act_std : cri_std, ids, H, N, nd.d[0], B, act[0], (float *)nullptr);
         if ((rc = forward(h, s, nd, P, B, act, gd))) return rc;
@@ -164,10 +169,10 @@ extern "C" int erl_mlpn_ppo_step_f32(const float *actor_params, const float *cri
                                unmasks, reward_sums, (const float *)nullptr, (const float *)nullptr, ratio_clip, lambda_entropy,
                                inv_batch, part);
         hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, s, part, nparts, P + nd.oStd, A, inv_batch, net == 0 ? 1 : 0, logs);
-        if (net == 0 && (rc = colsum(h, dsl, ones, G + nd.oStd, (int)B, A))) return rc;     // dL/dstd_log
+        if (net == 0 && (rc = colsum(s, dsl, cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
 
         // backward: dZ of the output layer is Y (dL/dY); walk the layers down
-        if ((rc = backward(h, s, nd, P, B, act, gd, Y, G, ones, nullptr, false, dA, dB))) return rc;
+        if ((rc = backward(h, s, nd, P, B, act, gd, Y, G, cs_scr, nullptr, false, dA, dB, dw_scr))) return rc;
     }
     ERL_LAUNCH_CHECK("erl_mlpn_ppo_step_f32");
 }

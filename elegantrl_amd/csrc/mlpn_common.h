@@ -77,13 +77,70 @@ int gemm_dw(rocblas_handle h, const float *dZ, const float *X, float *dW, int M,
     RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, N, M, &one, X, K, dZ, N, &zero, dW, K));
     return 0;
 }
-// db[N] = column sums of dZ[M][N]
-int colsum(rocblas_handle h, const float *dZ, const float *ones, float *db, int M, int N)
+// sum `n_slabs` partial results of `stride` floats each (fixed order -> deterministic); defined in mlp.hip
+extern "C" int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, void *stream);
+
+// dW for tall batches: rocBLAS will not split the M (sample) reduction across workgroups with atomics off, so one
+// 128 x 128 output tile would walk all 16 384 rows on a handful of CUs.  Instead: a strided-batched GEMM over chunks of
+// DW_CHUNK rows writes one partial dW per chunk into `scratch`, and the partials are summed in a fixed order.
+constexpr int DW_CHUNK = 256;
+inline int64_t dw_scratch_floats(int64_t M, int64_t NK) { return M >= 4 * DW_CHUNK ? ((M + DW_CHUNK - 1) / DW_CHUNK) * NK : 0; }
+
+int gemm_dw_split(rocblas_handle h, hipStream_t s, const float *dZ, const float *X, float *dW, int M, int N, int K, float *scratch)
 {
+    if (!scratch || M < 4 * DW_CHUNK) return gemm_dw(h, dZ, X, dW, M, N, K);
     const float one = 1.f, zero = 0.f;
-    RB(rocblas_sgemv(h, rocblas_operation_none, N, M, &one, dZ, N, ones, 1, &zero, db, 1));
+    const int full = M / DW_CHUNK, rem = M - full * DW_CHUNK;
+    const int64_t NK = (int64_t)N * K;
+    RB(rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, K, N, DW_CHUNK, &one, X, K,
+                                     (rocblas_stride)DW_CHUNK * K, dZ, N, (rocblas_stride)DW_CHUNK * N, &zero, scratch, K,
+                                     (rocblas_stride)NK, full));
+    if (rem)
+        RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, N, rem, &one, X + (size_t)full * DW_CHUNK * K, K,
+                         dZ + (size_t)full * DW_CHUNK * N, N, &zero, scratch + (size_t)full * NK, K));
+    return erl_grad_reduce_f32(scratch, full + (rem ? 1 : 0), NK, dW, (void *)s);
+}
+
+// db[N] = column sums of dZ[M][N] (row-major): each block sums a slice of rows into its own partial (threads along the
+// columns: coalesced), a fixed-order fold finishes.  (rocBLAS gemv on a 128 x 16384 matrix took 127 us; this is ~5.)
+constexpr int CS_ROWS = 128;   // rows per block
+constexpr int CS_MAX_PART = 1024;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ dZ, int M, int N, float *__restrict__ part)
+{
+    const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            s0 += dZ[(size_t)r * N + c];
+            s1 += dZ[(size_t)(r + 1) * N + c];
+            s2 += dZ[(size_t)(r + 2) * N + c];
+            s3 += dZ[(size_t)(r + 3) * N + c];
+        }
+        for (; r < r1; ++r) s0 += dZ[(size_t)r * N + c];
+        part[(size_t)blockIdx.x * N + c] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float *__restrict__ part, int nparts, int N, float *__restrict__ db)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * N + c];
+    db[c] = s;
+}
+
+// `part`: scratch of ceil(M / CS_ROWS) * N floats
+int colsum(hipStream_t s, const float *dZ, float *part, float *db, int M, int N)
+{
+    const int nparts = (M + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nparts), dim3(256), 0, s, dZ, M, N, part);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, nparts, N, db);
     return 0;
 }
+inline int64_t colsum_scratch_floats(int64_t M, int64_t maxN) { return ((M + CS_ROWS - 1) / CS_ROWS) * maxN; }
 
 // ---------------------------------------------------------------------------------------------------------
 // hand-written pieces
@@ -280,16 +337,18 @@ int forward(rocblas_handle h, hipStream_t s, const NetDims &nd, const float *P, 
 
 // backward through an MLP whose forward was run by forward(): dZ = dL/d(output).  Writes weight / bias gradients into
 // G (same layout as the parameter block) when G != nullptr, and dL/d(input) into dX0 when dX0 != nullptr
-// (accumulating into it when acc_dx0).  tmpA / tmpB: two scratch buffers of rows * max-width floats.
+// (accumulating into it when acc_dx0).  tmpA / tmpB: two scratch buffers of rows * max-width floats; cs_scratch:
+// colsum_scratch_floats(rows, max width) floats for the bias gradients.
 int backward(rocblas_handle h, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float *const *act, float *const *gd,
-             const float *dZ, float *G, const float *ones, float *dX0, bool acc_dx0, float *tmpA, float *tmpB)
+             const float *dZ, float *G, float *cs_scratch, float *dX0, bool acc_dx0, float *tmpA, float *tmpB,
+             float *dw_scratch = nullptr)
 {
     int rc;
     for (int l = nd.n - 1; l >= 0; --l) {
         const int K = nd.d[l], Nw = nd.d[l + 1];
         if (G) {
-            if ((rc = gemm_dw(h, dZ, act[l], G + nd.oW[l], (int)rows, Nw, K))) return rc;
-            if ((rc = colsum(h, dZ, ones, G + nd.ob[l], (int)rows, Nw))) return rc;
+            if ((rc = gemm_dw_split(h, s, dZ, act[l], G + nd.oW[l], (int)rows, Nw, K, dw_scratch))) return rc;
+            if ((rc = colsum(s, dZ, cs_scratch, G + nd.ob[l], (int)rows, Nw))) return rc;
         }
         if (l > 0) {
             float *dH = (dZ == tmpA) ? tmpB : tmpA;

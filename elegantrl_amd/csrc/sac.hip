@@ -242,7 +242,8 @@ extern "C" int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int 
     f += 2 * (B * (S + A) + 64);                                     // xa, dxa
     for (int l = 0; l <= d.actor.n; ++l) f += 2 * (B * d.actor.d[l] + 64);   // actor activations + GELU'
     f += critic_ws_floats(d, B);
-    f += 4 * (B * A + 64) + 6 * (B + 64) + (int64_t)d.E * B + 64;    // actions, eps, dA, t | logprobs, label, ones, ... | dq
+    f += 4 * (B * A + 64) + 6 * (B + 64) + (int64_t)d.E * B + 64;    // actions, eps, dA, t | logprobs, label, ... | dq
+    f += colsum_scratch_floats(B, maxd) + 64;                        // bias-gradient partials
     f += 3 * (B * maxd + 64) + B * 2 * A + 64;                       // tmpA, tmpB, dEnc, dHead
     f += d.Pa + d.Pc + 64 + 1024;                                     // gradients, partials
     return f * 4 + 8192;
@@ -281,7 +282,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     CriticWs cw;
     ERL_REQUIRE(carve_critic(ws, d, B, &cw), "erl_sac_update_f32: workspace layout");
     float *act_t = ws.take(B * A), *eps_used = ws.take(B * A), *dAct = ws.take(B * A);
-    float *lp_next = ws.take(B), *lp_cur = ws.take(B), *label = ws.take(B), *ones = ws.take(B);
+    float *lp_next = ws.take(B), *lp_cur = ws.take(B), *label = ws.take(B), *cs_scr = ws.take(colsum_scratch_floats(B, maxd));   // bias-gradient partials
     float *dq = ws.take((int64_t)E * B);
     float *tmpA = ws.take(B * maxd), *tmpB = ws.take(B * maxd), *dEnc = ws.take(B * d.enc.d[1]);
     float *dHead = ws.take(B * 2 * A);
@@ -290,8 +291,6 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     float *part = ws.take(nparts);
     ERL_REQUIRE(part != nullptr, "erl_sac_update_f32: workspace layout (tail)");
     const dim3 rows_grid((unsigned)erl_cdiv(B, 256)), blk(256);
-
-    hipLaunchKernelGGL(fillk_kernel, dim3(grid1d(B)), blk, 0, s, ones, 1.0f, B);
 
     // ---- (1) targets: next action / log-prob from the actor, min over the TARGET ensemble          (:50-55)
     (void)hipMemcpyAsync(aact[0], next_state, (size_t)B * S * 4, hipMemcpyDeviceToDevice, s);
@@ -310,12 +309,12 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     for (int e = 0; e < E; ++e) {
         float *Gdec = g_critic + d.enc.count + (int64_t)e * d.dec.count;
         if ((rc = backward(h, s, d.dec, critic_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
-                           Gdec, ones, dEnc, e > 0, tmpA, tmpB)))
+                           Gdec, cs_scr, dEnc, e > 0, tmpA, tmpB)))
             return rc;
     }
     {   // encoder: one raw linear layer, input xa
         float *ea[2] = {xa, cw.enc};
-        if ((rc = backward(h, s, d.enc, critic_params, B, ea, nullptr, dEnc, g_critic, ones, nullptr, false, tmpA, tmpB))) return rc;
+        if ((rc = backward(h, s, d.enc, critic_params, B, ea, nullptr, dEnc, g_critic, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
     }
     {
         const int64_t off = 0, len = d.Pc;
@@ -346,14 +345,14 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     hipLaunchKernelGGL(fillk_kernel, dim3(grid1d((int64_t)E * B)), blk, 0, s, dq, -1.0f / ((float)E * (float)B), (int64_t)E * B);
     for (int e = 0; e < E; ++e)
         if ((rc = backward(h, s, d.dec, target_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
-                           nullptr, ones, dEnc, e > 0, tmpA, tmpB)))
+                           nullptr, cs_scr, dEnc, e > 0, tmpA, tmpB)))
             return rc;
     if ((rc = gemm_dx(h, dEnc, target_params, dxa, (int)B, d.enc.d[1], S + A))) return rc;      // dL/d[state | action]
     // action columns of dxa -> contiguous (B, A)
     (void)hipMemcpy2DAsync(dAct, (size_t)A * 4, dxa + S, (size_t)(S + A) * 4, (size_t)A * 4, (size_t)B, hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dAct, alpha_log, A, B, dHead);
     hipLaunchKernelGGL(clamp_alpha_kernel, dim3(1), dim3(64), 0, s, alpha_log);                  // after alpha was read (:80-81)
-    if ((rc = backward(h, s, d.actor, actor_params, B, aact, agd, dHead, g_actor, ones, nullptr, false, tmpA, tmpB))) return rc;
+    if ((rc = backward(h, s, d.actor, actor_params, B, aact, agd, dHead, g_actor, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
     {
         const int64_t off = 0, len = d.Pa;
         if ((rc = erl_clip_adam_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, nullptr, step, lr, beta1, beta2, eps_adam,

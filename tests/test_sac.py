@@ -17,6 +17,7 @@ def test_torch_restatement_replays_the_reference():
     """oracle/sac_torch.py (CPU) against the reference-generated golden: objectives, actor, critics, target and alpha after
     each of the 3 recorded update steps."""
     from oracle.sac_torch import SacStepper
+    th.set_grad_enabled(True)
     g = load("sac_small.npz")
     N, S, A, rows, B, n_upd, n_ens, h1, h2 = [int(x) for x in g["dims"]]
     gamma, lr, max_norm, reward_scale, tau, target_entropy = [float(x) for x in g["hyper"]]
@@ -185,6 +186,7 @@ def test_sac_update_matches_torch_restatement_on_other_shapes(S, A, hidden, E, B
     from elegantrl_amd import ops
     from oracle.sac_torch import SacStepper
     dev = th.device("cuda:0")
+    th.set_grad_enabled(True)                                   # train_agent() (previous test) leaves autograd switched off
     th.manual_seed(S * 100 + E)
     st = SacStepper(list(hidden), S, A, E, lr=1e-3, gamma=0.97, tau=5e-3, max_norm=3.0)
     with th.no_grad():                                          # make target != critic and log_std span the clamp range

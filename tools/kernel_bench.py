@@ -73,6 +73,15 @@ def main():
     items = [th.randn((add, 1, S3), device=dev), th.randn((add, 1, A3), device=dev), th.randn((add, 1), device=dev),
              th.rand((add, 1), device=dev) > 0.5, th.rand((add, 1), device=dev) > 0.5]
     out["replay_write_4096rows"] = timeit(lambda: ops.replay_write(rs, ra, rr, ru, rm, items, M - 1000))
+    # generic-shape path (rocBLAS GEMMs + HIP) on the config-4 buffers
+    for tag, hid in (("128x128", [128, 128]), ("256x128", [256, 128]), ("256x128x64", [256, 128, 64])):
+        spn = ops.MlpSpecN([S, *hid, A], True)
+        pcn = ops.MlpSpecN([S, *hid, 1], False).count
+        fl = th.randn(spn.count + pcn, device=dev, generator=g) * 0.05
+        gout = th.empty(spn.count + pcn + 4, device=dev)
+        out[f"mlpn_ppo_step_{tag}"] = timeit(lambda: ops.mlpn_ppo_step(fl[:spn.count], fl[spn.count:], avg, std, avg, std, spn, states,
+                                                                       actions, um, logprobs, adv, ret, ids, 0.25, 0.001, 1.0 / B, gout),
+                                             iters=10)
     # SAC update step (config 3 shapes): one erl_sac_update_f32 call
     for tag, hid, Bq in (("64x32_B256", [64, 32], 256), ("256x256_B256", [256, 256], 256), ("256x256_B1024", [256, 256], 1024)):
         spec = ops.SacSpec(S3, A3, hid, 4)
