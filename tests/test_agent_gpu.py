@@ -222,3 +222,23 @@ def test_train_agent_pendulum_smoke(tmp_path):
     assert np.isfinite(rec).all() and rec.shape[1] >= 7
     actor = th.load(os.path.join(args.cwd, "act.pth"), weights_only=False)
     assert actor(th.zeros((2, 3), device=DEV)).shape == (2, 1)
+
+
+def test_train_agent_ppo_pendulum_learns(tmp_path):
+    """the whole loop on the HIP kernels learns: PPO on 1024 GPU-resident Pendulum envs (config-2 hyper-parameters) lifts the
+    evaluated return from about -1200..-600 (random policy) to better than -400 within 60 iterations (~2 s)."""
+    from elegantrl_amd import train_agent
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.envs import PendulumVecEnv
+    from elegantrl_amd.train import Config
+    args = Config(AgentPPO, PendulumVecEnv, {"env_name": "Pendulum-v1", "num_envs": 1024, "max_step": 200, "state_dim": 3,
+                                             "action_dim": 1, "if_discrete": False})
+    args.net_dims = [128, 64]
+    args.horizon_len, args.batch_size, args.repeat_times = 200, 4096, 4096 * 16 / 200
+    args.gamma, args.reward_scale, args.learning_rate = 0.97, 2 ** -2, 4e-4
+    args.break_step, args.eval_per_step, args.eval_times = 200 * 60, 200 * 10, 8
+    args.cwd, args.gpu_id, args.random_seed = str(tmp_path / "run"), 0, 0
+    train_agent(args, if_single_process=True)
+    rec = np.load(os.path.join(args.cwd, "recorder.npy"))
+    assert np.isfinite(rec[:, :4]).all()
+    assert rec[:, 1].max() > -400.0, f"PPO did not learn Pendulum: evaluated returns {np.round(rec[:, 1], 1).tolist()}"
