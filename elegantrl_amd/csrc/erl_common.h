@@ -101,16 +101,3 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t counter, 
     else box_muller(p.z, p.w, n0, n1);
     return (dim & 1) ? n1 : n0;
 }
-
-// ---------------------------------------------------------------------------------------------
-// device: exact-erf GELU (nn.GELU default) and its derivative
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return x * (0.5f * (1.0f + erff(x * 0.70710678118654752440f))); }
-
-__device__ __forceinline__ void gelu_and_grad(float x, float &y, float &g)
-{
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
-    y = x * cdf;
-    g = cdf + x * pdf;
-}

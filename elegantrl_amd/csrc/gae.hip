@@ -12,10 +12,10 @@
 //  * CHUNKED : grid = env-groups x time-chunks.  Pass A reduces every chunk to its affine map
 //              (A_k, P_k); pass B folds the later chunks' maps into the carry, re-scans its chunk and
 //              writes adv/ret (+ statistics partials).  Reassociation error <= ~1e-6 at default gamma.
-//  * LOOKBACK: single pass (18 B/elem of HBM traffic): chunk data stays in registers while the
-//              chunk's affine map is published with an agent-scope 8-byte store and later chunks'
-//              maps are polled (dispatch order guarantees forward progress: later time-chunks get
-//              lower block ids).
+//  * LOOKBACK: single pass (18 B/elem of HBM traffic), gae_lookback.hip: chunk data stays in registers while
+//              the slab's affine map is published as a nonce-tagged 8-byte granule and later slabs' granules
+//              are walked (decoupled look-back; slabs are handed out by an atomic ticket, latest time first,
+//              so a slab only waits for workgroups that are already running).  AUTO picks it for H >= 64.
 #include "erl_common.h"
 
 #pragma clang fp contract(off)
