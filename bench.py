@@ -272,3 +272,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    from elegantrl_amd import parallel as _parallel
+    _parallel.shutdown()      # every rank: barrier -> RCCL communicator -> process group (rank 0 has printed its line by now)

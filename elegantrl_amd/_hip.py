@@ -20,7 +20,8 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 5
+ABI_VERSION = 6
+COMM_ID_BYTES = 128
 
 _P = c_void_p
 _SIGNATURES = {
@@ -53,6 +54,14 @@ _SIGNATURES = {
     "erl_ppo_update_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
                                    _P, c_int64, c_int, c_float, c_float, _P, _P, c_int32, c_float, c_float, c_float, c_float, c_float,
                                    _P]),
+    "erl_comm_unique_id": (c_int, [_P]),
+    "erl_comm_init": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    "erl_comm_destroy": (c_int, [_P]),
+    "erl_comm_world_size": (c_int, [_P]),
+    "erl_comm_allreduce_sum_f32": (c_int, [_P, _P, c_int64, _P]),
+    "erl_ppo_update_dp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
+                                      _P, c_int64, c_int, c_float, c_float, _P, _P, c_int32, c_float, c_float, c_float, c_float,
+                                      c_float, _P, _P]),
     "erl_mlpn_param_count": (c_int64, [POINTER(c_int), c_int, c_int]),
     "erl_mlpn_workspace_bytes": (c_int64, [POINTER(c_int), c_int, c_int64, c_int]),
     "erl_mlpn_value_forward_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, _P, c_int64, _P]),

@@ -176,12 +176,13 @@ class AgentPPO(AgentBase):
         self._sync_modules()
         H, N, S, A = horizon_len, self.num_envs, self.state_dim, self.action_dim
         dev = self.device
-        states = th.zeros((H, N, S), dtype=th.float32, device=dev)
-        actions = th.zeros((H, N, A), dtype=th.float32, device=dev)
-        logprobs = th.zeros((H, N), dtype=th.float32, device=dev)
-        rewards = th.zeros((H, N), dtype=th.float32, device=dev)
-        terminals = th.zeros((H, N), dtype=th.bool, device=dev)
-        truncates = th.zeros((H, N), dtype=th.bool, device=dev)
+        # every element of the six buffers is written by the rollout below (row t by step t): no zero-fill launches
+        states = th.empty((H, N, S), dtype=th.float32, device=dev)
+        actions = th.empty((H, N, A), dtype=th.float32, device=dev)
+        logprobs = th.empty((H, N), dtype=th.float32, device=dev)
+        rewards = th.empty((H, N), dtype=th.float32, device=dev)
+        terminals = th.empty((H, N), dtype=th.bool, device=dev)
+        truncates = th.empty((H, N), dtype=th.bool, device=dev)
         if self._env_action is None or self._env_action.shape != (N, A):
             self._env_action = th.empty((N, A), dtype=th.float32, device=dev)
         env_action = self._env_action
@@ -231,7 +232,8 @@ class AgentPPO(AgentBase):
                     terminals[t] = terminal
                     truncates[t] = truncate
         self.last_state = state.clone() if native else state
-        rewards *= self.reward_scale
+        if self.reward_scale != 1.0:
+            rewards *= self.reward_scale
         undones = th.logical_not(terminals)
         unmasks = th.logical_not(truncates)
         return states, actions, logprobs, rewards, undones, unmasks
@@ -328,13 +330,17 @@ class AgentPPO(AgentBase):
         groups = [(0, self._Pa), (self._Pa, self._Pc)]
         inv_batch = 1.0 / B
         grad_scale = 1.0 / self.world_size
+        dp = self.world_size > 1 or parallel.force_dp()
+        comm = parallel.gradient_comm() if dp else None       # library-owned RCCL communicator (None: torch.distributed)
         if not self._fused:             # generic-shape networks: layered path, summed gradient written directly
             for k in range(update_times):
                 g = self._grads[k]
                 ops.mlpn_ppo_step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
                                   c.state_std.data, self._spec_a, states, actions, unmasks, logprobs, advantages, reward_sums,
                                   ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch, g)
-                if self.world_size > 1:
+                if comm is not None:
+                    comm.all_reduce_sum(g)
+                elif dp:
                     parallel.all_reduce_sum(g)
                 self._adam_step += 1
                 ops.clip_adam(self._flat, g, self._exp_avg, self._exp_avg_sq, groups, self._adam_step, float(self.learning_rate),
@@ -344,13 +350,14 @@ class AgentPPO(AgentBase):
             obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())
             return obj_critic, obj_actor, obj_entropy
         h1, h2 = self.net_dims
-        if self.world_size == 1:        # the whole minibatch loop is enqueued by one C call (no interpreter on the launch path)
+        if not dp or comm is not None:  # the whole minibatch loop is enqueued by one C call (no interpreter on the launch
+            # path); data-parallel ranks pass the library's RCCL communicator and the all-reduce rides the same stream
             ops.ppo_update(self._flat, self._exp_avg, self._exp_avg_sq, a.state_avg.data, a.state_std.data, c.state_avg.data,
                            c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
                            advantages, reward_sums, ids, float(self.ratio_clip), self.lambda_entropy_value, self._slabs,
-                           self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm))
+                           self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm), comm=comm)
             self._adam_step += update_times
-        else:                           # data parallel: the gradient all-reduce sits between slab reduction and optimiser
+        else:                           # data parallel through torch.distributed (gloo tests, ERL_DP_COLLECTIVE=torch)
             # raw pointers + direct C-ABI calls: the interpreter spends ~3 us per launch instead of ~10 (ptr checks, views)
             L, sp = _hip.lib(), _hip.stream_ptr()
             pf = _hip.ptr(self._flat, th.float32)
@@ -371,7 +378,7 @@ class AgentPPO(AgentBase):
                 rc = rc or L.erl_grad_reduce_f32(p_slabs, n_slabs, stride, p_g + 4 * k * stride, sp)
                 if rc:
                     _hip.check(rc, "erl_ppo_step_f32 / erl_grad_reduce_f32")
-                parallel.all_reduce_sum(self._grads[k])                                # RCCL over xGMI
+                parallel.all_reduce_sum(self._grads[k])
                 self._adam_step += 1
                 rc = L.erl_clip_adam_f32(pf, p_g + 4 * k * stride, p_m1, p_m2, off, ln, 2, None, self._adam_step, lr, 0.9, 0.999,
                                          1e-8, max_norm, grad_scale, sp)

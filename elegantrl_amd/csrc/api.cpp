@@ -93,23 +93,7 @@ extern "C" int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp
                                   int update_times, float ratio_clip, float lambda_entropy, float *slabs, float *grads,
                                   int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, void *stream)
 {
-    ERL_REQUIRE(flat_params && exp_avg && exp_avg_sq && ids && slabs && grads, "erl_ppo_update_f32: NULL tensor");
-    ERL_REQUIRE(update_times >= 1 && first_step >= 1 && B >= 1, "erl_ppo_update_f32: bad argument");
-    const int64_t Pa = erl_mlp_param_count(S, h1, h2, A, 1), Pc = erl_mlp_param_count(S, h1, h2, 1, 0);
-    ERL_REQUIRE(Pa > 0 && Pc > 0, "erl_ppo_update_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
-    const int64_t stride = Pa + Pc + 4;
-    const int n_slabs = erl_ppo_num_slabs(B);
-    const int64_t off[2] = {0, Pa}, len[2] = {Pa, Pc};
-    for (int k = 0; k < update_times; ++k) {
-        float *g = grads + (size_t)k * stride;
-        int rc = erl_ppo_step_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
-                                  unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
-                                  lambda_entropy, 1.0f / (float)B, slabs, n_slabs, stream);
-        if (rc) return rc;
-        if ((rc = erl_grad_reduce_f32(slabs, n_slabs, stride, g, stream))) return rc;
-        if ((rc = erl_clip_adam_f32(flat_params, g, exp_avg, exp_avg_sq, off, len, 2, nullptr, first_step + k, lr, beta1, beta2, eps,
-                                    max_norm, 1.0f, stream)))
-            return rc;
-    }
-    return ERL_OK;
+    return erl_ppo_update_dp_f32(flat_params, exp_avg, exp_avg_sq, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
+                                 unmasks, logprobs, advantages, reward_sums, H, N, ids, B, update_times, ratio_clip, lambda_entropy,
+                                 slabs, grads, first_step, lr, beta1, beta2, eps, max_norm, /*comm=*/nullptr, stream);
 }

@@ -1,0 +1,141 @@
+// The one exchange step of the path: a SUM all-reduce of the flat actor+critic gradient per minibatch,
+// enqueued by RCCL on the SAME stream as the kernels either side of it -- no second stream, no event hand-offs, and
+// (through erl_ppo_update_dp_f32) no interpreter between ppo_step, grad_reduce, the collective and clip_adam.
+//
+// RCCL is bound at run time (dlopen of the librccl.so.1 already mapped by PyTorch when there is one), so the library
+// loads and every single-GPU entry point works on a box without RCCL; the comm entry points then fail loudly.
+#include "erl_common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names)          // prefer the copy PyTorch already mapped: one RCCL per process
+            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!r.handle)
+            for (const char *n : names)
+                if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!r.handle) return;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+    });
+    return r;
+}
+
+int rccl_status(ncclResult_t e, const char *what)
+{
+    if (e == ncclSuccess) return ERL_OK;
+    erl_set_error("%s: %s", what, rccl().GetErrorString(e));
+    return -(2000 + (int)e);
+}
+
+#define ERL_NEED_RCCL(what) ERL_REQUIRE(rccl().ok, what ": librccl.so.1 could not be loaded or lacks the nccl* symbols")
+
+struct Comm {
+    ncclComm_t nccl;
+    int rank, world;
+};
+
+} // namespace
+
+extern "C" int erl_comm_unique_id(uint8_t *out_id)
+{
+    ERL_REQUIRE(out_id, "erl_comm_unique_id: NULL output");
+    ERL_NEED_RCCL("erl_comm_unique_id");
+    ncclUniqueId id;
+    int rc = rccl_status(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    if (rc) return rc;
+    static_assert(sizeof(id) == ERL_COMM_ID_BYTES, "RCCL unique id size changed");
+    memcpy(out_id, &id, sizeof(id));
+    return ERL_OK;
+}
+
+extern "C" int erl_comm_init(const uint8_t *id_bytes, int rank, int world_size, void **out_comm)
+{
+    ERL_REQUIRE(id_bytes && out_comm, "erl_comm_init: NULL argument");
+    ERL_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "erl_comm_init: rank %d not in [0, %d)", rank, world_size);
+    ERL_NEED_RCCL("erl_comm_init");
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    ncclComm_t c = nullptr;
+    int rc = rccl_status(rccl().CommInitRank(&c, world_size, id, rank), "ncclCommInitRank");   // binds hipGetDevice()'s GPU
+    if (rc) return rc;
+    *out_comm = new Comm{c, rank, world_size};
+    return ERL_OK;
+}
+
+extern "C" int erl_comm_destroy(void *comm)
+{
+    if (!comm) return ERL_OK;
+    Comm *c = (Comm *)comm;
+    int rc = rccl().ok ? rccl_status(rccl().CommDestroy(c->nccl), "ncclCommDestroy") : ERL_OK;
+    delete c;
+    return rc;
+}
+
+extern "C" int erl_comm_world_size(void *comm) { return comm ? ((Comm *)comm)->world : 1; }
+
+extern "C" int erl_comm_allreduce_sum_f32(void *comm, float *buf, int64_t count, void *stream)
+{
+    ERL_REQUIRE(comm && buf && count >= 0, "erl_comm_allreduce_sum_f32: bad argument");
+    if (count == 0) return ERL_OK;
+    Comm *c = (Comm *)comm;
+    return rccl_status(rccl().AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->nccl, (hipStream_t)stream),
+                       "ncclAllReduce");
+}
+
+extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg, const float *act_std,
+                                     const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
+                                     const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
+                                     const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
+                                     int update_times, float ratio_clip, float lambda_entropy, float *slabs, float *grads,
+                                     int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, void *comm,
+                                     void *stream)
+{
+    ERL_REQUIRE(flat_params && exp_avg && exp_avg_sq && ids && slabs && grads, "erl_ppo_update_dp_f32: NULL tensor");
+    ERL_REQUIRE(update_times >= 1 && first_step >= 1 && B >= 1, "erl_ppo_update_dp_f32: bad argument");
+    const int64_t Pa = erl_mlp_param_count(S, h1, h2, A, 1), Pc = erl_mlp_param_count(S, h1, h2, 1, 0);
+    ERL_REQUIRE(Pa > 0 && Pc > 0, "erl_ppo_update_dp_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
+    const int64_t stride = Pa + Pc + 4;
+    const int n_slabs = erl_ppo_num_slabs(B);
+    const int64_t off[2] = {0, Pa}, len[2] = {Pa, Pc};
+    const int world = erl_comm_world_size(comm);
+    const float grad_scale = 1.0f / (float)world;          // SUM over ranks -> mean, folded into the optimiser
+    for (int k = 0; k < update_times; ++k) {
+        float *g = grads + (size_t)k * stride;
+        int rc = erl_ppo_step_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
+                                  unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
+                                  lambda_entropy, 1.0f / (float)B, slabs, n_slabs, stream);
+        if (rc) return rc;
+        if ((rc = erl_grad_reduce_f32(slabs, n_slabs, stride, g, stream))) return rc;
+        if (comm && (rc = erl_comm_allreduce_sum_f32(comm, g, stride, stream))) return rc;   // gradient + the 3 logged objectives
+        if ((rc = erl_clip_adam_f32(flat_params, g, exp_avg, exp_avg_sq, off, len, 2, nullptr, first_step + k, lr, beta1, beta2, eps,
+                                    max_norm, grad_scale, stream)))
+            return rc;
+    }
+    return ERL_OK;
+}

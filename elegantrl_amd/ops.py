@@ -245,18 +245,20 @@ def clip_adam(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, groups: Se
 def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int,
                h1: int, h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
                ids: TEN, ratio_clip: float, lambda_entropy: float, slabs: TEN, grads: TEN, first_step: int, lr: float,
-               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
-    """the whole minibatch loop of AgentPPO.update_net in one C call (single-process path); ids: (update_times, B)."""
+               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8, comm=None) -> None:
+    """the whole minibatch loop of AgentPPO.update_net in one C call; ids: (update_times, B).  `comm` (a
+    parallel.RcclComm) puts the gradient all-reduce inside the loop, on the same stream (data-parallel ranks)."""
     H, N = states.shape[0], states.shape[1]
     update_times, B = ids.shape
     assert grads.shape[0] >= update_times and slabs.shape[0] == ppo_num_slabs(B)
-    check(lib().erl_ppo_update_f32(ptr(flat_params, th.float32), ptr(exp_avg, th.float32), ptr(exp_avg_sq, th.float32), ptr(act_avg),
-                                   ptr(act_std), ptr(cri_avg), ptr(cri_std), S, h1, h2, A, ptr(states, th.float32),
-                                   ptr(actions, th.float32), flag_ptr(unmasks), ptr(logprobs, th.float32),
-                                   ptr(advantages, th.float32), ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), B,
-                                   update_times, ratio_clip, lambda_entropy, ptr(slabs, th.float32), ptr(grads, th.float32),
-                                   first_step, lr, betas[0], betas[1], eps, max_norm, stream_ptr()),
-          "erl_ppo_update_f32")
+    check(lib().erl_ppo_update_dp_f32(ptr(flat_params, th.float32), ptr(exp_avg, th.float32), ptr(exp_avg_sq, th.float32),
+                                      ptr(act_avg), ptr(act_std), ptr(cri_avg), ptr(cri_std), S, h1, h2, A, ptr(states, th.float32),
+                                      ptr(actions, th.float32), flag_ptr(unmasks), ptr(logprobs, th.float32),
+                                      ptr(advantages, th.float32), ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), B,
+                                      update_times, ratio_clip, lambda_entropy, ptr(slabs, th.float32), ptr(grads, th.float32),
+                                      first_step, lr, betas[0], betas[1], eps, max_norm, None if comm is None else comm.handle,
+                                      stream_ptr()),
+          "erl_ppo_update_dp_f32")
 
 
 # ------------------------------------------------------------------------------------------------

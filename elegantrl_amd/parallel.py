@@ -15,8 +15,13 @@ import torch as th
 import torch.distributed as dist
 
 
+def force_dp() -> bool:
+    """ERL_FORCE_DP=1: run the data-parallel code path even with one rank (measures its overhead on a 1-GPU box)."""
+    return os.environ.get("ERL_FORCE_DP") == "1"
+
+
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dp())
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
@@ -25,7 +30,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_dp()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:   # "nccl" IS RCCL on ROCm; ERL_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
@@ -35,6 +40,103 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
             th.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+class RcclComm:
+    """RCCL communicator owned by liberl_hip.so (erl_comm_*): the gradient all-reduce is enqueued on the SAME stream as
+    the kernels either side of it, from inside the C loop.  torch.distributed stays the control plane: it carries the
+    128-byte unique id to the ranks and the all-ranks agreement that the communicator came up everywhere."""
+
+    def __init__(self, handle: int, rank: int, world: int):
+        self.handle, self.rank, self.world = handle, rank, world
+
+    @classmethod
+    def create(cls) -> Optional["RcclComm"]:
+        """Collective over the default process group (or a 1-rank communicator when there is none).  Returns None --
+        on EVERY rank -- unless every rank got its communicator, so the ranks can never disagree about the path."""
+        import ctypes
+        from . import _hip
+        L = _hip.lib()
+        distributed = is_distributed()
+        rank = dist.get_rank() if distributed else 0
+        world = dist.get_world_size() if distributed else 1
+        ident = (ctypes.c_uint8 * _hip.COMM_ID_BYTES)()
+        ok = 1
+        if rank == 0 and L.erl_comm_unique_id(ident) != 0:
+            ok = 0
+        if distributed:
+            box = [bytes(ident) if ok else None]
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                return None
+            ident = (ctypes.c_uint8 * _hip.COMM_ID_BYTES).from_buffer_copy(box[0])
+        elif not ok:
+            return None
+        out = ctypes.c_void_p(None)
+        ok = int(L.erl_comm_init(ident, rank, world, ctypes.byref(out)) == 0 and bool(out.value))
+        if distributed:
+            flag = th.tensor([ok], dtype=th.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            all_ok = int(flag.item())
+        else:
+            all_ok = ok
+        if not all_ok:
+            if ok:
+                L.erl_comm_destroy(out)
+            return None
+        return cls(out.value, rank, world)
+
+    def all_reduce_sum(self, t: th.Tensor) -> th.Tensor:
+        from . import _hip
+        _hip.check(_hip.lib().erl_comm_allreduce_sum_f32(self.handle, _hip.ptr(t, th.float32), t.numel(), _hip.stream_ptr()),
+                   "erl_comm_allreduce_sum_f32")
+        return t
+
+    def close(self):
+        if self.handle:
+            from . import _hip
+            th.cuda.synchronize()
+            _hip.lib().erl_comm_destroy(self.handle)
+            self.handle = None
+
+
+_grad_comm: Optional[RcclComm] = None
+_grad_comm_tried = False
+
+
+def gradient_comm() -> Optional[RcclComm]:
+    """The job's RCCL communicator for the per-minibatch gradient exchange; None means "use torch.distributed"
+    (CPU/gloo runs, ERL_DP_COLLECTIVE=torch, or RCCL did not come up on every rank).  ERL_FORCE_DP=1 builds a 1-rank
+    communicator without a process group (measures the data-parallel loop on one GPU)."""
+    global _grad_comm, _grad_comm_tried
+    if _grad_comm_tried:
+        return _grad_comm
+    _grad_comm_tried = True
+    if os.environ.get("ERL_DP_COLLECTIVE", "rccl") != "rccl" or not th.cuda.is_available():
+        return None
+    if is_distributed():
+        if dist.get_backend() != "nccl":        # several ranks on one GPU (gloo tests): RCCL cannot span duplicates
+            return None
+    elif not force_dp():
+        return None
+    _grad_comm = RcclComm.create()
+    return _grad_comm
+
+
+def shutdown() -> None:
+    """Orderly end of a data-parallel job, called by every rank: drain the GPU, meet at a barrier, destroy the library's
+    RCCL communicator (an intra-node collective in RCCL, hence the barrier first), then the process group."""
+    global _grad_comm, _grad_comm_tried
+    up = dist.is_available() and dist.is_initialized()
+    if th.cuda.is_available() and (up or _grad_comm is not None):
+        th.cuda.synchronize()
+    if up:
+        _barrier()
+    if _grad_comm is not None:
+        _grad_comm.close()
+    _grad_comm, _grad_comm_tried = None, False
+    if up:
+        dist.destroy_process_group()
 
 
 def all_reduce_sum(t: th.Tensor) -> th.Tensor:
@@ -65,6 +167,13 @@ def shard_range(total: int, rank: int, world: int) -> range:
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
+def _barrier():
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[th.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
 def barrier():
     if is_distributed():
-        dist.barrier()
+        _barrier()

@@ -114,6 +114,7 @@ def _dp_worker(local_rank: int, args: Config, gpu_ids, port: int):
     if local_rank != 0:
         args.if_remove = False
     train_agent_single_process(args)
+    parallel.shutdown()
 
 
 def train_agent_multiprocessing_multi_gpu(args: Config):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 5
+#define ERL_ABI_VERSION 6
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -194,6 +194,33 @@ ERL_API int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp_av
                        int64_t B, int update_times, float ratio_clip, float lambda_entropy, float *slabs,
                        float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
                        float max_norm, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data-parallel exchange: one process per GPU, env shards one per rank, and ONE collective on the path --
+ * the SUM all-reduce of the flat [actor | critic | 3 logged objectives] gradient row (203 KB at config 4) per minibatch,
+ * enqueued by RCCL on the caller's stream between erl_grad_reduce_f32 and erl_clip_adam_f32.  The reference has no
+ * collective here (its multi-GPU mode ships rollout data through host pipes, elegantrl/train/run.py:305-320).
+ * RCCL is bound with dlopen at first use; without it these entry points return an error and everything else works.
+ *   rank 0: erl_comm_unique_id(id) -> ship the ERL_COMM_ID_BYTES to every rank out of band (torch.distributed store)
+ *   all   : erl_comm_init(id, rank, world, &comm)   (collective; binds the calling thread's current HIP device)
+ * The communicator is library-owned state behind an opaque handle; destroy it before process exit. */
+#define ERL_COMM_ID_BYTES 128
+ERL_API int erl_comm_unique_id(uint8_t *out_id);
+ERL_API int erl_comm_init(const uint8_t *id_bytes, int rank, int world_size, void **out_comm);
+ERL_API int erl_comm_destroy(void *comm);
+ERL_API int erl_comm_world_size(void *comm);
+ERL_API int erl_comm_allreduce_sum_f32(void *comm, float *buf, int64_t count, void *stream);
+
+/* erl_ppo_update_f32 with the gradient all-reduce in the loop: ppo_step -> grad_reduce -> all-reduce(grads[k]) ->
+ * clip_adam(grad_scale = 1/world).  comm == NULL degenerates to the single-process loop.  Every rank must call it with
+ * the same update_times; ids are this rank's own minibatch indices into its own rollout shard. */
+ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg,
+                          const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
+                          const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
+                          const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
+                          int64_t B, int update_times, float ratio_clip, float lambda_entropy, float *slabs,
+                          float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
+                          float max_norm, void *comm, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic-shape path: build_mlp([S, d1, ..., dL, out]) with ANY number (<= ERL_MAX_LAYERS) and width of hidden layers

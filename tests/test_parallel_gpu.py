@@ -68,3 +68,64 @@ def test_two_rank_agent_stays_in_lockstep(tmp_path):
     np.testing.assert_array_equal(w[0], w[1])                         # ... identically on both ranks
     np.testing.assert_allclose(logs[0], logs[1], rtol=1e-6)           # logged objectives are global means
     assert np.isfinite(w[0]).all() and np.isfinite(logs[0]).all()
+
+
+# ---- the library-owned RCCL communicator (erl_comm_*) on one rank --------------------------------------------------
+_DP_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch as th
+from elegantrl_amd import parallel
+from elegantrl_amd.agents import AgentPPO
+from elegantrl_amd.envs import SynVecEnv
+from elegantrl_amd.train import Config
+rank, world, _ = parallel.init_from_env()
+N, S, A, H, B = 256, 64, 8, 16, 1024
+args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
+                                    "if_discrete": False})
+args.horizon_len, args.batch_size, args.repeat_times = H, B, 3 * B / H
+args.learning_rate, args.random_seed = 1e-3, 5
+args.world_size, args.rank, args.gpu_id = world, rank, 0
+th.manual_seed(3)
+args.net_dims = [int(x) for x in os.environ["ERL_TEST_NET"].split(",")]
+agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
+env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=11)
+agent.last_state = env.reset()[0]
+logs = [agent.update_net(list(agent.explore_env(env, H))) for _ in range(2)]
+comm = parallel.gradient_comm() if parallel.force_dp() else None
+if comm is not None:                      # the collective on its own: SUM over one rank is the identity, on torch's stream
+    x = th.randn(50837, device="cuda")
+    y = comm.all_reduce_sum(x.clone())
+    assert th.equal(x, y)
+np.savez(sys.argv[1], w=agent._flat.cpu().numpy(), logs=np.array(logs), used_comm=comm is not None,
+         pg=parallel.dist.is_initialized())
+"""
+
+
+def _run_dp_script(tmp_path, name, **env):
+    import subprocess
+    import sys
+    out = tmp_path / f"{name}.npz"
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", **env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DP_SCRIPT, str(out)], env=e, cwd=root, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return np.load(out)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("net", ["128,128", "96,64,32"], ids=["fused", "generic"])
+def test_rccl_comm_one_rank_matches_single_process(tmp_path, net):
+    """ERL_FORCE_DP=1 drives the data-parallel branch of update_net with one rank: (a) through the library's RCCL
+    communicator inside erl_ppo_update_dp_f32 (unique id carried by the nccl process group), (b) through
+    torch.distributed's all_reduce.  Both must leave exactly the weights of the plain single-process loop."""
+    plain = _run_dp_script(tmp_path, "plain", ERL_TEST_NET=net)
+    rccl = _run_dp_script(tmp_path, "rccl", ERL_TEST_NET=net, ERL_FORCE_DP="1")
+    torch_pg = _run_dp_script(tmp_path, "torch", ERL_TEST_NET=net, ERL_FORCE_DP="1", ERL_DP_COLLECTIVE="torch")
+    assert not plain["used_comm"] and not plain["pg"]
+    assert rccl["used_comm"] and rccl["pg"], "RCCL communicator did not come up on the GPU box"
+    assert not torch_pg["used_comm"] and torch_pg["pg"]
+    np.testing.assert_array_equal(plain["w"], rccl["w"])
+    np.testing.assert_array_equal(plain["w"], torch_pg["w"])
+    np.testing.assert_array_equal(plain["logs"], rccl["logs"])
+    np.testing.assert_array_equal(plain["logs"], torch_pg["logs"])
