@@ -13,6 +13,7 @@
 namespace {
 
 constexpr float kLogSqrt2PiF = 0.91893853320467274178f;  // log(sqrt(2 pi))
+constexpr int64_t kSplitMaxEnvs = 16384;
 
 // LDS pool of the forward kernels (floats): [W2 copy 128 x 132][W1 copy 128 x 132][W3 copy 16 x 132][b1 | b2 | b3]
 constexpr int kFwdW = 128 * 132;
@@ -30,7 +31,22 @@ struct FwdArgs {
     const float *noise;
     uint64_t seed, counter;
     float *o_state, *o_action, *o_logprob, *o_env;
+    long long *prof;          // ERL_PROFILE builds only: [wave][16] s_memtime stamps of workgroup 0 (rollout_split_kernel)
 };
+
+#ifdef ERL_PROFILE
+long long *g_fwd_prof = nullptr;
+#define RPROF(i)                                                                                  \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if (g.prof && blockIdx.x == 0 && lane == 0) g.prof[wave * 16 + (i)] = (long long)t_;      \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define RPROF(i) do { } while (0)
+#endif
 
 // copies W1 / W2 / W3 / biases of one network into LDS (zero padded to the tile grid) and barriers
 template <bool VEC, int NW>
@@ -195,6 +211,176 @@ __global__ __launch_bounds__(256) void rollout_step2_kernel(FwdArgs g)
     if (valid && q == 0 && g.o_logprob) g.o_logprob[row] = lp;
 }
 
+// tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2 |x|) in (0, 1]: no overflow, no cancellation in 1 + e;
+// 1 - e loses nothing below |x| ~ 1e-4 that the result's own fp32 ulp would show (abs err < 2e-7).
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    const float e = __expf(-2.f * fabsf(x));
+    return copysignf(__fdividef(1.f - e, 1.f + e), x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1, latency form (N of a few thousand envs: one 16-env tile per workgroup fills the chip, and the step is a
+// dependent chain, so what counts is the length of that chain, not throughput).  The 8 waves of a workgroup split
+// the OUTPUT features of each layer: wave w owns feature tile w (rows 16 w .. 16 w + 15 of W1 and of W2) and reads
+// exactly those weight rows straight from L2 into registers as MFMA A operands -- all of them, together with the
+// state tile, in ONE round trip issued before anything else; no LDS weight image, no staging barrier.
+//   L1: 16 x 16 tile of H1^T per wave (ns x 4 MFMAs on two accumulators)  -> LDS image T1[sample][feature] -> barrier
+//   L2: every wave reads all of H1 back as B operands (8 ds_read_b128), n1 x 4 MFMAs -> its H2^T tile in registers
+//   out: the wave's H2 tile IS the k-slice 16 w .. 16 w + 15 of the output layer: 4 MFMAs give a partial Y^T;
+//        the 8 partials meet in LDS, wave 0 adds them in a fixed order and does the sampling / log-prob / stores.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSplitLd = 132;   // T1 row stride (floats): 16-byte aligned rows, consecutive samples 4 banks apart
+
+template <int NS_, int N1_, int N2_, bool VEC>
+__global__ __launch_bounds__(512) void rollout_split_kernel(FwdArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float T1[16 * kSplitLd];
+    __shared__ __attribute__((aligned(16))) float PS[8 * 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const Dims d{g.S, N1_ ? 16 * N1_ : g.h1, N2_ ? 16 * N2_ : g.h2, g.out};
+    const int S = d.S, A = d.out, ns = NS_ ? NS_ : (S + 15) >> 4, n1 = d.h1 >> 4, n2 = d.h2 >> 4;
+    const bool on1 = wave < n1, on2 = wave < n2;
+    const float *std_log = g.P + d.oStd();
+
+    const int64_t env = (int64_t)blockIdx.x * 16 + l15;
+    const bool valid = env < g.rows;
+    const int64_t row = valid ? env : g.rows - 1;
+
+    RPROF(0);
+    // ---- every global load of the step, issued back to back ----
+    float4 XR[8], w1[8], w2[8];
+    load_rows_raw<VEC>(XR, g.states + row * S, ns, S, q);
+    {
+        const float *r1 = g.P + d.oW1() + (size_t)min(16 * wave + l15, d.h1 - 1) * S;
+        const float *r2 = g.P + d.oW2() + (size_t)min(16 * wave + l15, d.h2 - 1) * d.h1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < ns) w1[t] = load4<VEC>(r1, 16 * t + 4 * q, S);
+            if (t < n1) w2[t] = load4<VEC>(r2, 16 * t + 4 * q, d.h1);
+        }
+    }
+    const int kt = min(wave, n2 - 1);                      // this wave's k-tile of the output layer
+    float4 w3 = load4<VEC>(g.P + d.oW3() + (size_t)min(l15, A - 1) * d.h2, 16 * kt + 4 * q, d.h2);
+    if (l15 >= A || !on2) w3 = zero4();
+    const float4 b1 = load4<VEC>(g.P + d.ob1(), 16 * min(wave, n1 - 1) + 4 * q, d.h1);
+    const float4 b2 = load4<VEC>(g.P + d.ob2(), 16 * kt + 4 * q, d.h2);
+    float eps[4], sl[4], b3[4];
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * q + r, ac = min(a, A - 1);
+            sl[r] = std_log[ac];
+            b3[r] = g.P[d.ob3() + ac];
+            eps[r] = g.noise ? g.noise[row * A + ac] : philox_normal(g.seed, g.counter, (uint32_t)row, (uint32_t)ac);
+        }
+    }
+    if (wave == 7 && g.o_state && valid) {   // states[t] = state: raw rows, the lane's 4-float groups
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < ns) {
+                const int k0 = 16 * t + 4 * q;
+                float *dst = g.o_state + row * S + k0;
+                if (VEC) { if (k0 < S) *reinterpret_cast<float4 *>(dst) = XR[t]; }
+                else {
+                    const float xr[4] = {XR[t].x, XR[t].y, XR[t].z, XR[t].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (k0 + c < S) dst[c] = xr[c];
+                }
+            }
+        }
+    }
+    RPROF(1);
+    f32x4 X[8];
+    normalise_rows<VEC>(XR, X, g.avg, g.sd, ns, S, q, valid);
+    RPROF(2);
+
+    // ---- L1: this wave's feature tile of H1^T ----
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t < ns) {
+            a0 = mfma16(w1[t].x, X[t][0], a0);
+            a1 = mfma16(w1[t].y, X[t][1], a1);
+            a0 = mfma16(w1[t].z, X[t][2], a0);
+            a1 = mfma16(w1[t].w, X[t][3], a1);
+        }
+    }
+    if (on1) {
+        const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+        float h[4], gd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
+        *reinterpret_cast<float4 *>(T1 + l15 * kSplitLd + 16 * wave + 4 * q) = make_float4(h[0], h[1], h[2], h[3]);
+    }
+    RPROF(3);
+    lds_barrier();
+    RPROF(4);
+
+    // ---- L2: all of H1 back as B operands, this wave's feature tile of H2^T stays in registers ----
+    a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t < n1) {
+            const float4 hv = *reinterpret_cast<const float4 *>(T1 + l15 * kSplitLd + 16 * t + 4 * q);
+            a0 = mfma16(w2[t].x, hv.x, a0);
+            a1 = mfma16(w2[t].y, hv.y, a1);
+            a0 = mfma16(w2[t].z, hv.z, a0);
+            a1 = mfma16(w2[t].w, hv.w, a1);
+        }
+    }
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
+        float h[4], gd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
+        // ---- output layer, k-slice 16 w + 4 q + r: the B operand is the tile just computed ----
+        part = mfma16(w3.x, h[0], part);
+        part = mfma16(w3.y, h[1], part);
+        part = mfma16(w3.z, h[2], part);
+        part = mfma16(w3.w, h[3], part);
+    }
+    *reinterpret_cast<float4 *>(PS + (wave * 64 + lane) * 4) =
+        on2 ? make_float4(part[0], part[1], part[2], part[3]) : zero4();
+    RPROF(5);
+    lds_barrier();
+    RPROF(6);
+    if (wave != 0) return;
+
+    float Y[4];
+    {
+        float4 p[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) p[w] = *reinterpret_cast<const float4 *>(PS + (w * 64 + lane) * 4);
+        Y[0] = ((p[0].x + p[1].x) + (p[2].x + p[3].x)) + ((p[4].x + p[5].x) + (p[6].x + p[7].x)) + b3[0];
+        Y[1] = ((p[0].y + p[1].y) + (p[2].y + p[3].y)) + ((p[4].y + p[5].y) + (p[6].y + p[7].y)) + b3[1];
+        Y[2] = ((p[0].z + p[1].z) + (p[2].z + p[3].z)) + ((p[4].z + p[5].z) + (p[6].z + p[7].z)) + b3[2];
+        Y[3] = ((p[0].w + p[1].w) + (p[2].w + p[3].w)) + ((p[4].w + p[5].w) + (p[6].w + p[7].w)) + b3[3];
+    }
+    // sample: a = mean + std * eps (torch.normal(mean, std)); Normal.log_prob summed over the action dims
+    float lp = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a = 4 * q + r;
+        const bool on = a < A;
+        const float sdv = expf(sl[r]), var = sdv * sdv;
+        const float act = Y[r] + sdv * eps[r];
+        const float diff = act - Y[r];
+        const float term = -(diff * diff) / (2.f * var) - sl[r] - kLogSqrt2PiF;      // log(exp(std_log)) = std_log
+        lp += on ? term : 0.f;
+        if (on && valid) {
+            if (g.o_action) g.o_action[row * A + a] = act;
+            if (g.o_env) g.o_env[row * A + a] = fast_tanh(act);   // convert_action_for_env
+        }
+    }
+    lp += __shfl_xor(lp, 16, 64);
+    lp += __shfl_xor(lp, 32, 64);
+    if (valid && q == 0 && g.o_logprob) g.o_logprob[row] = lp;
+    RPROF(7);
+}
+
 // sum the per-workgroup slabs into the flat gradient.  Deterministic: element e is summed by 4 threads (slab
 // quarter p = threadIdx.x / 64 takes slabs k = p (mod 4)... in ascending order, 8 loads in flight), combined in a
 // fixed order through LDS.  Latency bound (26 MB, 128 strided rows): the split buys 4x the loads in flight.
@@ -314,9 +500,26 @@ extern "C" int erl_rollout_step_f32(const float *actor_params, const float *stat
     g.states = state; g.rows = N;
     g.noise = noise; g.seed = seed; g.counter = counter;
     g.o_state = out_state_row; g.o_action = out_action_row; g.o_logprob = out_logprob_row; g.o_env = out_action_env;
-    const int grid = (int)erl_cdiv(N, 64);
+#ifdef ERL_PROFILE
+    g.prof = g_fwd_prof;
+#endif
     const bool vec = vec_ok(g);
     const int ns = (S + 15) / 16;
+    // up to kSplitMaxEnvs envs the step is latency bound: one 16-env tile per workgroup, output features split over
+    // the waves (rollout_split_kernel).  Beyond that the weight re-reads (one network per tile) outweigh the shorter
+    // chain and the throughput form (4 tiles per workgroup behind one LDS weight image) takes over.
+    static const int split_mode = [] { const char *e = getenv("ERL_ROLLOUT_SPLIT"); return e ? atoi(e) : -1; }();
+    if (split_mode == 1 || (split_mode != 0 && N <= kSplitMaxEnvs)) {
+        const unsigned sgrid = (unsigned)erl_cdiv(N, 16);
+        if (vec && ns == 4 && h1 == 128 && h2 == 128)
+            hipLaunchKernelGGL((rollout_split_kernel<4, 8, 8, true>), dim3(sgrid), dim3(512), 0, (hipStream_t)stream, g);
+        else if (vec)
+            hipLaunchKernelGGL((rollout_split_kernel<0, 0, 0, true>), dim3(sgrid), dim3(512), 0, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL((rollout_split_kernel<0, 0, 0, false>), dim3(sgrid), dim3(512), 0, (hipStream_t)stream, g);
+        ERL_LAUNCH_CHECK("erl_rollout_step_f32");
+    }
+    const int grid = (int)erl_cdiv(N, 64);
     static bool d0 = false, d1 = false, d2 = false;
     int rc;
 #define RS_LAUNCH(K, FLAG)                                                                        \
@@ -332,6 +535,11 @@ extern "C" int erl_rollout_step_f32(const float *actor_params, const float *stat
 }
 
 
+
+#ifdef ERL_PROFILE
+// profiling builds only (make EXTRA=-DERL_PROFILE): device buffer of 8 * 16 int64 cycle stamps
+extern "C" __attribute__((visibility("default"))) void erl_debug_set_rollout_profile(long long *dev_buf) { g_fwd_prof = dev_buf; }
+#endif
 
 extern "C" int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, void *stream)
 {

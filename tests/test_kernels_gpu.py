@@ -324,7 +324,7 @@ def test_value_forward(ops, dev, S, h1, h2, A, rows):
 
 
 @pytest.mark.parametrize("S,h1,h2,A", MLP_SHAPES)
-@pytest.mark.parametrize("N", [4096, 37])
+@pytest.mark.parametrize("N", [4096, 37, 16384 + 21])     # <= 16384 envs: latency form (split), above: throughput form
 def test_rollout_step_injected_noise(ops, dev, S, h1, h2, A, N):
     rng = np.random.default_rng(S * 7 + N)
     net = random_net(rng, S, h1, h2, A, True)
