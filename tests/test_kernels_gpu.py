@@ -476,9 +476,10 @@ def test_update_loop_on_reference_golden(ops, dev, name):
 
 
 # ------------------------------------------------------------------------------------------------
-def test_synenv_step_matches_formula(ops, dev):
+@pytest.mark.parametrize("N,S,A", [(1000, 64, 8), (4096, 64, 8), (777, 60, 8), (50, 11, 3), (300, 128, 16), (200, 64, 20)])
+def test_synenv_step_matches_formula(ops, dev, N, S, A):
+    """A <= 16: 16-env MFMA tiles (synenv_tile_kernel); A = 20: the one-wave-per-env form."""
     rng = np.random.default_rng(4)
-    N, S, A = 1000, 64, 8
     s = rng.standard_normal((N, S), dtype=np.float32)
     s[:5] *= 30.0                                             # force terminals
     a = np.tanh(rng.standard_normal((N, A), dtype=np.float32))
