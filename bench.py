@@ -141,7 +141,7 @@ def cpu_baseline_subprocess(iters: int, timeout_s: int = 240):
         return {"value": None, "unit": "env-steps/s", "kind": "port", "error": f"timed out after {timeout_s}s"}
 
 
-def cpu_baseline(iters=2):
+def cpu_baseline(iters=12):
     """oracle/torch_port.py on the host cores, same workload shape (bounded sample: 1 warm-up + `iters` iterations)."""
     from oracle.torch_port import TorchPortPPO, TorchSynEnv
     th.manual_seed(0)
@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gae-sweep", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=12)   # ~10-15 s of host work on 16 cores
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     opt = ap.parse_args()
     if opt.cpu_baseline_only:
