@@ -13,7 +13,8 @@ from typing import Optional
 import torch as th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liberl_hip.so")
+# ERL_HIP_LIB selects another build of the same library (profiling / A-B builds); it is still this HIP library or nothing
+LIB_PATH = os.environ.get("ERL_HIP_LIB") or os.path.join(_HERE, "lib", "liberl_hip.so")
 
 # flags mirrored from include/erl_hip.h
 GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4

@@ -27,7 +27,14 @@
 namespace {
 
 constexpr int PB = 128;        // samples per workgroup
-constexpr int PLD = PB + 1;    // leading dimension of the staged feature-major tiles
+#ifdef ERL_K6_B32              // previous staging layout (A/B builds only): odd stride, one ds_read_b32 per operand
+constexpr int PLD = PB + 1;
+#else
+// leading dimension of the staged feature-major tiles T[feature][sample]: 16-byte aligned rows, consecutive rows 16
+// bytes apart modulo the 128-byte bank span => 8 consecutive rows form one conflict-free ds_read_b128 wavefront slice,
+// and a transposing ds_write_b32 of a D-layout tile lands 2 lanes per bank (the minimum for 64 lanes).
+constexpr int PLD = PB + 4;
+#endif
 constexpr int PNW = 8;
 constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
 
@@ -161,8 +168,22 @@ __device__ __forceinline__ void weight_grad(const float *TA, int nA32, const flo
         const float *a = TA + (32 * it + l31) * PLD + hi;
         const float *b = TB + (32 * jt + l31) * PLD + hi;
         f32x16 acc = {0};
+#ifdef ERL_K6_B32
 #pragma unroll 16
         for (int s = 0; s < PB / 2; ++s) acc = mfma32(a[2 * s], b[2 * s], acc);
+#else
+        // the sum over samples is order-free: lane half `hi` takes samples 8 j + 4 hi + {0..3} of every group of 8, so
+        // one 16-byte read per operand feeds four MFMAs (k-pair of step s' = samples 8 j + s' and 8 j + 4 + s')
+        const float *a4 = a + 3 * hi, *b4 = b + 3 * hi;             // a + hi + 3 hi = row + 4 hi
+#pragma unroll 8
+        for (int j = 0; j < PB / 8; ++j) {
+            const float4 av = *reinterpret_cast<const float4 *>(a4 + 8 * j), bv = *reinterpret_cast<const float4 *>(b4 + 8 * j);
+            acc = mfma32(av.x, bv.x, acc);
+            acc = mfma32(av.y, bv.y, acc);
+            acc = mfma32(av.z, bv.z, acc);
+            acc = mfma32(av.w, bv.w, acc);
+        }
+#endif
         const int i = 32 * jt + l31;
         if (i < cols_real) {
 #pragma unroll
@@ -178,11 +199,20 @@ __device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__re
         const int f = f0 + (lane & 15), p = lane >> 4;
         const float *src = T + f * PLD + 32 * p;
         float s0 = 0.f, s1 = 0.f;
+#ifdef ERL_K6_B32
 #pragma unroll
         for (int k = 0; k < 32; k += 2) {
             s0 += src[k];
             s1 += src[k + 1];
         }
+#else
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + k);
+            s0 += v.x + v.z;
+            s1 += v.y + v.w;
+        }
+#endif
         float s = s0 + s1;
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
@@ -192,7 +222,9 @@ __device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__re
 
 // LDS pool (floats): [RA: W2 copy, later staged tiles][RB: W1 copy, later staged tiles][RC: dY^T][RW3: W3 copy]
 //                    [s_bias: b1 | b2 | b3(16)][s_part: 8*16][s_red: 16]
-constexpr int kRFloats = 128 * 132 + 64;  // >= 128 * lds_ld(128), >= 128 * PLD, >= 128 * lds_ld(64) + 64 * PLD (W1 copy | X^T)
+constexpr int kRFloats = 128 * 68 + 64 * PLD > 128 * 132 ? 128 * 68 + 64 * PLD : 128 * 132;
+static_assert(kRFloats >= 128 * PLD && kRFloats % 4 == 0, "staged tiles must fit the weight-copy regions");
+// >= 128 * lds_ld(128) (W2 copy), >= 128 * PLD (staged tile), >= 128 * lds_ld(64) + 64 * PLD (W1 copy | X^T, tuned shape)
 constexpr int kRCFloats = 16 * PLD;
 constexpr int kRW3Floats = 16 * 132;
 constexpr int kBiasFloats = 128 + 128 + 16;
@@ -273,6 +305,19 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     // X^T for dW1 lives next to the W1 copy when both fit (S <= 64): staged once, here, from the registers
     constexpr bool EARLY_X = NS_ != 0 && NS_ <= 4;
     float *RX = EARLY_X ? RB + 128 * lds_ld(64) : RB;
+    // GELU'(z1) is needed again only at the very end of the chain (dZ1).  Holding it in registers across the whole
+    // forward pass pushes the live set past 256 VGPRs (spill reloads cost 10-20k cycles each); recomputing it there costs
+    // 128 MFMAs + ~650 VALU ops per wave.  The tuned shape parks it in memory instead: this workgroup's own gradient
+    // slab is dead until the weight-gradient phases, so each lane writes its 8 float4 there right after L1 and reads
+    // the same 8 float4 back before dZ1 (64 KB per workgroup, same lane, same address: no synchronisation; the slab
+    // is at least 16384 + 3 floats long for this shape).
+#ifdef ERL_K6_RECOMP
+    constexpr bool GMEM = false;
+#else
+    constexpr bool GMEM = EARLY_X && N1_ == 8;
+#endif
+    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
+    float *gscr = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(slab) + 15) & ~static_cast<uintptr_t>(15)) + 4 * tid;
     f32x4 H1[8], G1[8], H2[8], G2[8];
     f32x4 X[8];
     norm_x(XR, X);
@@ -280,7 +325,11 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     PROF(1);
     lds_barrier();                                                   // (0) weight copies visible
     PROF(2);
-    forward_layer<true, NS_, !EARLY_X>(RB, ld1, s_b1, ns, n1, X, H1, G1, l15, q);   // EARLY_X: GELU'(z1) is recomputed
+    forward_layer<true, NS_, (!EARLY_X || GMEM)>(RB, ld1, s_b1, ns, n1, X, H1, G1, l15, q);
+    if (GMEM) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4 *>(gscr + t * (4 * PNW * 64)) = G1[t];
+    }
     PROF(3);
     forward_layer<true, N1_>(RA, ld2, s_b2, n1, n2, H1, H2, G2, l15, q);
     PROF(4);
@@ -299,6 +348,12 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     }
     f32x4 Y[8], dummy[8];
     forward_layer<false, N2_>(RW3, ld3, s_b3, n2, 1, H2, Y, dummy, l15, q);
+    if (GMEM) {   // GELU'(z1) back from the slab; the laundered pointer keeps the compiler from forwarding the stores
+        const float *gl = gscr;
+        asm volatile("" : "+v"(gl));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) G1[t] = *reinterpret_cast<const f32x4 *>(gl + t * (4 * PNW * 64));
+    }
     PROF(5);
 
     // ---- objective and dL/dY for this lane's outputs a = 4 q + r   (AgentPPO.py:189-204)
@@ -361,7 +416,7 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 16 outputs: one k-tile);  dZ1 = (W2^T dZ2) * GELU'(z1)
     PROF(6);
     backward_input<1, false, 1>(RW3, ld3, 1, n2, dY, G2, nullptr, 0, nullptr, dY, l15, q);   // G2 now holds dZ2
-    if (EARLY_X) {                                                  // X back from its LDS staging (16 ds_read_b32)
+    if (EARLY_X && !GMEM) {                                         // X back from its LDS staging (16 ds_read_b32)
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             if (t < ns) {
@@ -369,11 +424,10 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
                 for (int r = 0; r < 4; ++r) X[t][r] = RX[(16 * t + 4 * q + r) * PLD + col];
             }
     }
-    backward_input<N2_, EARLY_X, (NS_ ? NS_ : 1)>(RA, ld2, n2, n1, G2, G1, RB, ld1, s_b1, X, l15, q);   // G1 now holds dZ1
+    backward_input<N2_, (EARLY_X && !GMEM), (NS_ ? NS_ : 1)>(RA, ld2, n2, n1, G2, G1, RB, ld1, s_b1, X, l15, q);   // G1 <- dZ1
     PROF(7);
     lds_barrier();                                                   // (1) every wave is done with the weight copies
     PROF(8);
-    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
 
     // ---- layer 1: dW1 = dZ1^T . X, db1;  (dY^T is staged alongside for the output layer)
     stage(RA, G1, n1, col, q);                                      // dZ1^T
@@ -406,11 +460,24 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     lds_barrier();                                                   // (4)
     PROF(11);
     for (int it = wave; it < n2; it += PNW) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifdef ERL_K6_B32
         const float *a = RC + l15 * PLD + q;                        // A[row a][k = sample]
         const float *b = RA + (16 * it + l15) * PLD + q;            // B[k = sample][col i]
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int s = 0; s < PB / 4; ++s) acc = mfma16(a[4 * s], b[4 * s], acc);
+#else
+        const float *a = RC + l15 * PLD + 4 * q;                    // lane group q: samples 16 j + 4 q + {0..3}
+        const float *b = RA + (16 * it + l15) * PLD + 4 * q;
+#pragma unroll
+        for (int j = 0; j < PB / 16; ++j) {
+            const float4 av = *reinterpret_cast<const float4 *>(a + 16 * j), bv = *reinterpret_cast<const float4 *>(b + 16 * j);
+            acc = mfma16(av.x, bv.x, acc);
+            acc = mfma16(av.y, bv.y, acc);
+            acc = mfma16(av.z, bv.z, acc);
+            acc = mfma16(av.w, bv.w, acc);
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int a_ = 4 * q + r;
