@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 counter-collection CSVs (one --pmc pass per file) into per-kernel, per-dispatch averages.
+   python tools/pmc_summarise.py out.json pass1/p_counter_collection.csv pass2/p_counter_collection.csv ...
+Rows of one (dispatch, counter) -- one per XCD / dimension instance -- are summed, then averaged over the dispatches of
+the kernel.  FETCH_SIZE / WRITE_SIZE (KB) are turned into HBM bytes with the gfx950 correction of MI355X_MICROARCH.md
+(FETCH_SIZE counts 128-byte read requests as 64 bytes: x2; WRITE_SIZE as reported)."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    m = re.search(r"(\w+_kernel)", name)
+    return m.group(1) if m else name[:60]
+
+
+def main():
+    out_path, files = sys.argv[1], sys.argv[2:]
+    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # kernel -> counter -> dispatch -> value
+    dur = defaultdict(dict)
+    for f in files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                k = short(row["Kernel_Name"])
+                did = (f, row["Dispatch_Id"])
+                per[k][row["Counter_Name"]][did] += float(row["Counter_Value"])
+                if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                    dur[k][did] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3
+    res = {}
+    for k, counters in per.items():
+        e = {c: round(sum(v.values()) / len(v), 1) for c, v in sorted(counters.items())}
+        e["dispatches"] = max(len(v) for v in counters.values())
+        if dur[k]:
+            e["avg_duration_us"] = round(sum(dur[k].values()) / len(dur[k]), 2)
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_read_bytes"] = int(e["FETCH_SIZE"] * 1024 * 2)
+            e["hbm_write_bytes"] = int(e["WRITE_SIZE"] * 1024)
+            e["hbm_bytes_per_launch"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "avg_duration_us" in e:
+            # the counter sums busy cycles over all SIMDs (256 CUs x 4); gfx950 engine clock 2.4 GHz
+            e["mfma_busy_cycles_per_simd"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024, 1)
+            e["mfma_busy_frac_of_kernel_time_at_2.4GHz"] = round(e["mfma_busy_cycles_per_simd"] / (e["avg_duration_us"] * 2400), 3)
+        res[k] = e
+    json.dump({"note": "rocprofv3 --kernel-trace --pmc <one counter set per pass>; per-dispatch averages, summed over XCDs "
+                       "(tools/pmc_summarise.py)", "kernels": res}, open(out_path, "w"), indent=1)
+    print(json.dumps(res, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@ N, S, A, H, B, h1, h2 = 4096, 64, 8, 32, 16384, 128, 128
 NAMES = ["prologue (2 global trips, copies, norm_x)", "barrier0", "L1 fwd", "L2 fwd", "out layer", "objective + dstd partials",
          "dZ2 + dZ1", "barrier1 (wave skew)", "stage dZ1/dY + barrier2", "dW1 + db1 + db3", "barrier3 + stage H2/H1 + barrier4",
          "dW3 + barrier5 + stage dZ2 + barrier6", "dW2 + db2", "loss reduce + logs"]
-NP = 15
+NP = 14
 
 def main():
     lib = _hip.lib()
