@@ -27,14 +27,10 @@
 namespace {
 
 constexpr int PB = 128;        // samples per workgroup
-#ifdef ERL_K6_B32              // previous staging layout (A/B builds only): odd stride, one ds_read_b32 per operand
-constexpr int PLD = PB + 1;
-#else
 // leading dimension of the staged feature-major tiles T[feature][sample]: 16-byte aligned rows, consecutive rows 16
 // bytes apart modulo the 128-byte bank span => 8 consecutive rows form one conflict-free ds_read_b128 wavefront slice,
 // and a transposing ds_write_b32 of a D-layout tile lands 2 lanes per bank (the minimum for 64 lanes).
 constexpr int PLD = PB + 4;
-#endif
 constexpr int PNW = 8;
 constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
 
@@ -67,23 +63,18 @@ struct Ppo2Args {
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
-// backward through a layer's input on registers:  g[jt] <- gate[jt] * ( W^T . dz ),  W = zero-padded LDS copy
+// backward through a layer's input on registers:  g[jt] <- g[jt] * ( W^T . dz ),  W = zero-padded LDS copy
 // [16 kt][ldw] (A operand = W^T: lane (j, q) supplies W[16 t + 4 q + r][16 jt + j], four ds_read_b32 per k-tile).
-// gate = GELU'(z_in).  RECOMP = false: gate is what `g` holds on entry (kept from the forward pass).
-// RECOMP = true: the forward pass did not keep it (32 VGPRs less for the whole forward chain); the layer's
-// pre-activation tile z = Win[16 jt ..][:] . xin + bin is recomputed here (NSX k-tiles, 4 NSX extra MFMAs per tile).
+// On entry g holds the gate GELU'(z_in) (kept in registers from the forward pass, or read back from the slab).
 // ---------------------------------------------------------------------------------------------------------
-template <int KT, bool RECOMP, int NSX>
+template <int KT>
 __device__ __forceinline__ void backward_input(const float *W, int ldw, int kt_rt, int nin, const f32x4 (&dz)[8], f32x4 (&g)[8],
-                                               const float *Win, int ldin, const float *bin, const f32x4 (&xin)[8], int l15,
-                                               int q)
+                                               int l15, int q)
 {
     constexpr int NCH = KT ? (KT + PCH - 1) / PCH : 8 / PCH;
     constexpr int NC = 8 * NCH;
-    constexpr int NX = RECOMP ? NSX : 1;
     const int kt = KT ? KT : kt_rt;
     float4 wq[2][PCH];
-    float4 wx[NX];
     auto issue = [&](int c, float4(&dst)[PCH]) {
         const int jt = c / NCH, th = c % NCH;
 #pragma unroll
@@ -101,10 +92,6 @@ __device__ __forceinline__ void backward_input(const float *W, int ldw, int kt_r
     for (int c = 0; c < NC; ++c) {
         const int jt = c / NCH, th = c % NCH;
         if (c + 1 < NC) issue(c + 1, wq[(c + 1) & 1]);
-        if (RECOMP && th == 0 && jt < nin) {   // this tile's rows of the input layer's weights (used in the epilogue)
-#pragma unroll
-            for (int t = 0; t < NX; ++t) wx[t] = *reinterpret_cast<const float4 *>(Win + (16 * jt + l15) * ldin + 16 * t + 4 * q);
-        }
         __builtin_amdgcn_sched_barrier(0);
         if (jt < nin) {
             if (th == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -120,27 +107,8 @@ __device__ __forceinline__ void backward_input(const float *W, int ldw, int kt_r
                 }
             }
             if (th == NCH - 1) {
-                if (RECOMP) {
-                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < NX; ++t) {
-                        z = mfma16(wx[t].x, xin[t][0], z);
-                        z = mfma16(wx[t].y, xin[t][1], z);
-                        z = mfma16(wx[t].z, xin[t][2], z);
-                        z = mfma16(wx[t].w, xin[t][3], z);
-                    }
-                    const float4 b4 = *reinterpret_cast<const float4 *>(bin + 16 * jt + 4 * q);
-                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float y, gd;
-                        gelu_and_grad_fast(z[r] + bb[r], y, gd);
-                        g[jt][r] = gd * acc[r];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) g[jt][r] *= acc[r];
-                }
+                for (int r = 0; r < 4; ++r) g[jt][r] *= acc[r];
             }
         }
     }
@@ -168,10 +136,6 @@ __device__ __forceinline__ void weight_grad(const float *TA, int nA32, const flo
         const float *a = TA + (32 * it + l31) * PLD + hi;
         const float *b = TB + (32 * jt + l31) * PLD + hi;
         f32x16 acc = {0};
-#ifdef ERL_K6_B32
-#pragma unroll 16
-        for (int s = 0; s < PB / 2; ++s) acc = mfma32(a[2 * s], b[2 * s], acc);
-#else
         // the sum over samples is order-free: lane half `hi` takes samples 8 j + 4 hi + {0..3} of every group of 8, so
         // one 16-byte read per operand feeds four MFMAs (k-pair of step s' = samples 8 j + s' and 8 j + 4 + s')
         const float *a4 = a + 3 * hi, *b4 = b + 3 * hi;             // a + hi + 3 hi = row + 4 hi
@@ -183,7 +147,6 @@ __device__ __forceinline__ void weight_grad(const float *TA, int nA32, const flo
             acc = mfma32(av.z, bv.z, acc);
             acc = mfma32(av.w, bv.w, acc);
         }
-#endif
         const int i = 32 * jt + l31;
         if (i < cols_real) {
 #pragma unroll
@@ -199,20 +162,12 @@ __device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__re
         const int f = f0 + (lane & 15), p = lane >> 4;
         const float *src = T + f * PLD + 32 * p;
         float s0 = 0.f, s1 = 0.f;
-#ifdef ERL_K6_B32
-#pragma unroll
-        for (int k = 0; k < 32; k += 2) {
-            s0 += src[k];
-            s1 += src[k + 1];
-        }
-#else
 #pragma unroll
         for (int k = 0; k < 32; k += 4) {
             const float4 v = *reinterpret_cast<const float4 *>(src + k);
             s0 += v.x + v.z;
             s1 += v.y + v.w;
         }
-#endif
         float s = s0 + s1;
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
@@ -311,11 +266,8 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     // slab is dead until the weight-gradient phases, so each lane writes its 8 float4 there right after L1 and reads
     // the same 8 float4 back before dZ1 (64 KB per workgroup, same lane, same address: no synchronisation; the slab
     // is at least 16384 + 3 floats long for this shape).
-#ifdef ERL_K6_RECOMP
-    constexpr bool GMEM = false;
-#else
     constexpr bool GMEM = EARLY_X && N1_ == 8;
-#endif
+    static_assert(GMEM || !EARLY_X, "the tuned instantiation parks GELU'(z1) in the slab; generic shapes keep it in registers");
     float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
     float *gscr = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(slab) + 15) & ~static_cast<uintptr_t>(15)) + 4 * tid;
     f32x4 H1[8], G1[8], H2[8], G2[8];
@@ -415,16 +367,8 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     }
     // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 16 outputs: one k-tile);  dZ1 = (W2^T dZ2) * GELU'(z1)
     PROF(6);
-    backward_input<1, false, 1>(RW3, ld3, 1, n2, dY, G2, nullptr, 0, nullptr, dY, l15, q);   // G2 now holds dZ2
-    if (EARLY_X && !GMEM) {                                         // X back from its LDS staging (16 ds_read_b32)
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-            if (t < ns) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[t][r] = RX[(16 * t + 4 * q + r) * PLD + col];
-            }
-    }
-    backward_input<N2_, (EARLY_X && !GMEM), (NS_ ? NS_ : 1)>(RA, ld2, n2, n1, G2, G1, RB, ld1, s_b1, X, l15, q);   // G1 <- dZ1
+    backward_input<1>(RW3, ld3, 1, n2, dY, G2, l15, q);            // G2 (the gate) <- dZ2
+    backward_input<N2_>(RA, ld2, n2, n1, G2, G1, l15, q);          // G1 (the gate) <- dZ1
     PROF(7);
     lds_barrier();                                                   // (1) every wave is done with the weight copies
     PROF(8);
@@ -461,12 +405,6 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     PROF(11);
     for (int it = wave; it < n2; it += PNW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#ifdef ERL_K6_B32
-        const float *a = RC + l15 * PLD + q;                        // A[row a][k = sample]
-        const float *b = RA + (16 * it + l15) * PLD + q;            // B[k = sample][col i]
-#pragma unroll 8
-        for (int s = 0; s < PB / 4; ++s) acc = mfma16(a[4 * s], b[4 * s], acc);
-#else
         const float *a = RC + l15 * PLD + 4 * q;                    // lane group q: samples 16 j + 4 q + {0..3}
         const float *b = RA + (16 * it + l15) * PLD + 4 * q;
 #pragma unroll
@@ -477,7 +415,6 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
             acc = mfma16(av.z, bv.z, acc);
             acc = mfma16(av.w, bv.w, acc);
         }
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int a_ = 4 * q + r;
