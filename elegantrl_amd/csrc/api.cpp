@@ -34,8 +34,8 @@ extern "C" int erl_device_info(int *num_cu, int *lds_bytes_per_block)
 // ---------------------------------------------------------------------------------------------------------
 // Host-side batching: one C call enqueues a whole PPO update (update_times x [K6, slab reduce, clip + Adam]) so
 // that the Python interpreter is off the launch path (about 3 us per launch from here instead of about 10 from
-// ctypes).  Single-process path only: under data parallelism the gradient all-reduce sits between the slab
-// reduction and the optimiser step and the loop stays in Python.
+// ctypes).  The loop itself lives in comm.cpp (erl_ppo_update_dp_f32): under data parallelism the gradient all-reduce
+// sits between the slab reduction and the optimiser step, issued by RCCL on the same stream.
 // ---------------------------------------------------------------------------------------------------------
 // optional per-launch timing of K6 (measurement hook for bench.py: erl_ppo_step_f32 brackets its launch with HIP events
 // on the launch stream; off by default).  The event pairs are kept until erl_k6_timing_read() drains them.
