@@ -24,9 +24,16 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ par
     const int gi = blockIdx.y;
     const int64_t off = gr.off[gi], len = gr.len[gi];
     const float *g = grads + off;
+    // this thread's element of the Adam phase: its four loads ride the same round trip as the norm's
+    const int64_t per = (len + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < len) ? lo + per : len;
+    const int64_t ie = lo + threadIdx.x;
+    const bool own = ie < hi && per <= 1024;          // per > 1024 (very long groups): the loop at the end re-reads
+    float e_g = 0.f, e_m1 = 0.f, e_m2 = 0.f, e_p = 0.f;
+    if (own) { e_g = g[ie]; e_m1 = m1[off + ie]; e_m2 = m2[off + ie]; e_p = params[off + ie]; }
     double ss = 0.0;
-    {   // all loads of a thread are issued before the first use (one L2 round trip instead of one per element)
-        constexpr int U = 8;
+    {   // every load of the thread is issued before the first use: ONE L2 round trip for groups up to 32 Ki elements
+        constexpr int U = 32;
         for (int64_t i0 = threadIdx.x; i0 < len; i0 += (int64_t)U * 1024) {
             float x[U];
 #pragma unroll
@@ -57,16 +64,19 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ par
         bc2_sqrt = (float)sqrt(bc2);
     }
 
-    const int64_t per = (len + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < len) ? lo + per : len;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        const float gx = g[i] * gmul;
-        const float a = m1[off + i] * beta1 + (1.f - beta1) * gx;          // exp_avg.lerp_(grad, 1 - beta1)
-        const float b = m2[off + i] * beta2 + (1.f - beta2) * (gx * gx);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    auto adam = [&](int64_t i, float graw, float m1v, float m2v, float pv) {
+        const float gx = graw * gmul;
+        const float a = m1v * beta1 + (1.f - beta1) * gx;          // exp_avg.lerp_(grad, 1 - beta1)
+        const float b = m2v * beta2 + (1.f - beta2) * (gx * gx);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
         m1[off + i] = a;
         m2[off + i] = b;
         const float denom = sqrtf(b) / bc2_sqrt + eps;
-        params[off + i] -= step_size * (a / denom);
+        params[off + i] = pv - step_size * (a / denom);
+    };
+    if (per <= 1024) {
+        if (own) adam(ie, e_g, e_m1, e_m2, e_p);
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) adam(i, g[i], m1[off + i], m2[off + i], params[off + i]);
     }
 }
 

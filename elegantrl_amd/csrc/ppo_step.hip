@@ -222,7 +222,15 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     else if (tid < 272) bias_pre = (tid - 256 < OUT) ? P[d.ob3() + tid - 256] : 0.f;
 
     // ---- trip 2: id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
-    const int64_t n_ = id / g.H, t_ = id - n_ * g.H;
+    int64_t n_, t_;
+    if (g.H * g.N <= 0x7fffffffLL) {       // uniform branch: ids < H N fit 32 bits, a 32-bit divide is ~4x shorter and it sits
+        const uint32_t i32 = (uint32_t)id, h32 = (uint32_t)g.H, n32 = i32 / h32;   // between the two dependent round trips
+        n_ = n32;
+        t_ = i32 - n32 * h32;
+    } else {
+        n_ = id / g.H;
+        t_ = id - n_ * g.H;
+    }
     const int64_t row = valid ? t_ * g.N + n_ : 0;
     // this sample's raw state slice, features 16 t + 4 q + r; normalised by norm_x (AgentPPO.py:360-361)
     const float *srow = g.states + row * S;
