@@ -21,7 +21,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 6
+ABI_VERSION = 7
 COMM_ID_BYTES = 128
 
 _P = c_void_p
@@ -70,6 +70,10 @@ _SIGNATURES = {
                                           _P, c_int64, _P]),
     "erl_mlpn_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P,
                                       c_int64, c_float, c_float, c_float, _P, _P, c_int64, _P]),
+    "erl_mlpn_rollout_step_discrete_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P,
+                                                   _P, _P, _P, c_int64, _P]),
+    "erl_mlpn_ppo_step_discrete_f32": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, _P, _P, _P, c_int64,
+                                               c_int64, _P, c_int64, c_float, c_float, c_float, _P, _P, c_int64, _P]),
     "erl_sac_param_counts": (c_int, [c_int, c_int, POINTER(c_int), c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "erl_sac_workspace_bytes": (c_int64, [c_int, c_int, POINTER(c_int), c_int, c_int, c_int64]),
     "erl_sac_update_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int] + [_P] * 6 + [c_int64, _P, _P, c_uint64,

@@ -57,6 +57,32 @@ class ActorPPO(nn.Module):
         return action.tanh()
 
 
+class ActorDiscretePPO(ActorPPO):
+    """Categorical policy head (elegantrl/agents/AgentPPO.py:393-422): `net` emits logits; `forward` is the greedy action
+    the Evaluator uses.  `action_std_log` is inherited but unused, exactly as in the reference (keeps state_dicts alike)."""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int):
+        super().__init__(net_dims=net_dims, state_dim=state_dim, action_dim=action_dim)
+        self.ActionDist = th.distributions.Categorical
+        self.soft_max = nn.Softmax(dim=-1)
+
+    def forward(self, state: TEN) -> TEN:
+        return self.net(self.state_norm(state)).argmax(dim=1)
+
+    def get_action(self, state: TEN) -> Tuple[TEN, TEN]:
+        dist = self.ActionDist(self.soft_max(self.net(self.state_norm(state))))
+        action = dist.sample()
+        return action, dist.log_prob(action)
+
+    def get_logprob_entropy(self, state: TEN, action: TEN) -> Tuple[TEN, TEN]:
+        dist = self.ActionDist(self.soft_max(self.net(self.state_norm(state))))
+        return dist.log_prob(action), dist.entropy()
+
+    @staticmethod
+    def convert_action_for_env(action: TEN) -> TEN:
+        return action.long()
+
+
 class CriticPPO(nn.Module):
     def __init__(self, net_dims: List[int], state_dim: int, action_dim: int):
         super().__init__()
@@ -85,16 +111,20 @@ class FlatAdam:
 
 class AgentPPO(AgentBase):
     """PPO + GAE, reference-form objective, HIP kernels."""
+    _discrete = False            # AgentDiscretePPO: categorical head on the layered path
+    _actor_class = ActorPPO
 
     def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
         args = Config() if args is None else args
         super().__init__(net_dims, state_dim, action_dim, gpu_id, args)
         self.if_off_policy = False
-        if self.if_discrete:
-            raise NotImplementedError("AgentDiscretePPO is a 'next' row (SURVEY.md 8f); the HIP path is continuous PPO")
+        if bool(self.if_discrete) != self._discrete:
+            raise ValueError(f"{type(self).__name__} with if_discrete={self.if_discrete}: use "
+                             f"{'AgentDiscretePPO' if self.if_discrete else 'AgentPPO'}")
         # fused register-chained kernels: 2 hidden layers of width 32..128 (multiples of 32); every other build_mlp()
         # shape (the reference's demos go up to (256, 128, 128)) takes the layered generic path (erl_mlpn_*)
-        self._fused = (len(net_dims) == 2 and all(32 <= d <= _hip.MAX_HIDDEN and d % 32 == 0 for d in net_dims)
+        self._fused = (not self._discrete and len(net_dims) == 2
+                       and all(32 <= d <= _hip.MAX_HIDDEN and d % 32 == 0 for d in net_dims)
                        and state_dim <= _hip.MAX_STATE_DIM and action_dim <= _hip.MAX_ACTION_DIM)
 
         self.ratio_clip = getattr(args, "ratio_clip", 0.25)
@@ -111,7 +141,7 @@ class AgentPPO(AgentBase):
             self._spec_a = ops.MlpSpec(state_dim, h1, h2, action_dim, True)
             self._spec_c = ops.MlpSpec(state_dim, h1, h2, 1, False)
         else:
-            self._spec_a = ops.MlpSpecN([state_dim, *net_dims, action_dim], True)
+            self._spec_a = ops.MlpSpecN([state_dim, *net_dims, action_dim], not self._discrete)
             self._spec_c = ops.MlpSpecN([state_dim, *net_dims, 1], False)
         self._Pa, self._Pc = self._spec_a.count, self._spec_c.count    # raises for unsupported shapes
         self._stride = self._Pa + self._Pc + 4
@@ -121,7 +151,7 @@ class AgentPPO(AgentBase):
         self._exp_avg_sq = th.zeros_like(self._flat)
         self._adam_step = 0
 
-        act = ActorPPO(net_dims=net_dims, state_dim=state_dim, action_dim=action_dim).to(self.device)
+        act = self._actor_class(net_dims=net_dims, state_dim=state_dim, action_dim=action_dim).to(self.device)
         cri = CriticPPO(net_dims=net_dims, state_dim=state_dim, action_dim=action_dim).to(self.device)
         self._flat_a = FlatNet(act, self._spec_a, self._flat[:self._Pa])
         self._flat_c = FlatNet(cri, self._spec_c, self._flat[self._Pa:])
@@ -335,7 +365,8 @@ class AgentPPO(AgentBase):
         if not self._fused:             # generic-shape networks: layered path, summed gradient written directly
             for k in range(update_times):
                 g = self._grads[k]
-                ops.mlpn_ppo_step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
+                step = ops.mlpn_ppo_step_discrete if self._discrete else ops.mlpn_ppo_step
+                step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
                                   c.state_std.data, self._spec_a, states, actions, unmasks, logprobs, advantages, reward_sums,
                                   ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch, g)
                 if comm is not None:
@@ -405,3 +436,96 @@ class AgentPPO(AgentBase):
             self.act.state_std[:] = (self.act.state_std * (1 - tau) + state_std * tau).clamp_min(1e-4)
             self.cri.state_avg[:] = self.act.state_avg
             self.cri.state_std[:] = self.act.state_std
+
+
+class AgentDiscretePPO(AgentPPO):
+    """PPO with a categorical policy (elegantrl/agents/AgentPPO.py:305-320, ActorDiscretePPO :393-422) on the layered
+    path: logits from rocBLAS GEMMs + HIP epilogues, inverse-CDF sampling / log-prob and the clipped-scale objective
+    with its state-dependent entropy in hand-written kernels (erl_mlpn_rollout_step_discrete_f32,
+    erl_mlpn_ppo_step_discrete_f32).  Rollout dtypes as the reference: actions (H, N) int32, env receives int64."""
+    _discrete = True
+    _actor_class = ActorDiscretePPO
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
+        args = Config() if args is None else args
+        super().__init__(net_dims, state_dim, action_dim, gpu_id, args)
+        self.lambda_entropy_value = float(getattr(args, "lambda_entropy", 0.01))          # AgentPPO.py:318
+        self.lambda_entropy = th.tensor(self.lambda_entropy_value, dtype=th.float32, device=self.device)
+
+    def explore_action(self, state: TEN, uniform: Optional[TEN] = None) -> Tuple[TEN, TEN]:
+        """(action int32 (n,), logprob (n,)); `uniform` (n,) injects the U[0,1) draws (tests)."""
+        from .. import ops
+        self._require_gpu("explore_action")
+        self._sync_modules()
+        state = state.contiguous()
+        n = state.shape[0]
+        action = th.empty((n,), dtype=th.int32, device=self.device)
+        logprob = th.empty((n,), dtype=th.float32, device=self.device)
+        ops.mlpn_rollout_step_discrete(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
+                                       uniform=uniform, seed=self.rng_seed, counter=self.rng_counter, out_action=action,
+                                       out_logprob=logprob)
+        self.rng_counter += 1
+        return action, logprob
+
+    def _explore_vec_env(self, env, horizon_len: int, if_random: bool = False, noise: Optional[TEN] = None):
+        """H batched steps -> (states, actions int32 (H, N), logprobs, rewards, undones, unmasks); `noise` (H, N) injects
+        the uniform draws."""
+        from .. import ops
+        self._require_gpu("explore_env")
+        self._sync_modules()
+        H, N, S, dev = horizon_len, self.num_envs, self.state_dim, self.device
+        states = th.empty((H, N, S), dtype=th.float32, device=dev)
+        actions = th.empty((H, N), dtype=th.int32, device=dev)
+        logprobs = th.empty((H, N), dtype=th.float32, device=dev)
+        rewards = th.empty((H, N), dtype=th.float32, device=dev)
+        terminals = th.empty((H, N), dtype=th.bool, device=dev)
+        truncates = th.empty((H, N), dtype=th.bool, device=dev)
+        env_action = th.empty((N,), dtype=th.int64, device=dev)
+        state = self.last_state
+        assert state.shape == (N, S), f"last_state {tuple(state.shape)} != {(N, S)}"
+        state = state.to(dev, th.float32).contiguous()
+        for t in range(H):
+            ops.mlpn_rollout_step_discrete(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
+                                           uniform=None if noise is None else noise[t].contiguous(), seed=self.rng_seed,
+                                           counter=self.rng_counter, out_state=states[t], out_action=actions[t],
+                                           out_logprob=logprobs[t], out_env_action=env_action)
+            self.rng_counter += 1
+            state, reward, terminal, truncate, _ = env.step(env_action)
+            state = state.to(dev, th.float32).contiguous()
+            rewards[t] = reward
+            terminals[t] = terminal
+            truncates[t] = truncate
+        self.last_state = state
+        if self.reward_scale != 1.0:
+            rewards *= self.reward_scale
+        return states, actions, logprobs, rewards, th.logical_not(terminals), th.logical_not(truncates)
+
+    def _explore_one_env(self, env, horizon_len: int, if_random: bool = False):
+        """single (numpy) env, AgentPPO.py:34-85 with if_discrete: actions (H, 1) int32, env.step gets a python int."""
+        from .. import ops
+        self._require_gpu("explore_env")
+        self._sync_modules()
+        H, S, dev = horizon_len, self.state_dim, self.device
+        states = th.zeros((H, 1, S), dtype=th.float32, device=dev)
+        actions = th.zeros((H, 1), dtype=th.int32, device=dev)
+        logprobs = th.zeros((H, 1), dtype=th.float32, device=dev)
+        rewards = th.zeros((H, 1), dtype=th.float32, device=dev)
+        terminals = th.zeros((H, 1), dtype=th.bool, device=dev)
+        truncates = th.zeros((H, 1), dtype=th.bool, device=dev)
+        env_action = th.empty((1,), dtype=th.int64, device=dev)
+        state = self.last_state.to(dev, th.float32).reshape(1, S).contiguous()
+        for t in range(H):
+            ops.mlpn_rollout_step_discrete(self._flat_a.flat, self._spec_a, self._act.state_avg.data, self._act.state_std.data, state,
+                                           seed=self.rng_seed, counter=self.rng_counter, out_state=states[t], out_action=actions[t],
+                                           out_logprob=logprobs[t], out_env_action=env_action)
+            self.rng_counter += 1
+            ary_state, reward, terminal, truncate, _ = env.step(int(env_action[0].item()))
+            if terminal or truncate:
+                ary_state, _ = env.reset()
+            state = th.as_tensor(ary_state, dtype=th.float32, device=dev).reshape(1, S)
+            rewards[t, 0] = float(reward)
+            terminals[t, 0] = bool(terminal)
+            truncates[t, 0] = bool(truncate)
+        self.last_state = state
+        rewards *= self.reward_scale
+        return states, actions, logprobs, rewards, th.logical_not(terminals), th.logical_not(truncates)

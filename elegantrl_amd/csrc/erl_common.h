@@ -91,6 +91,14 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &n0, fl
     n1 = r * s;
 }
 
+// one U[0,1) of the stream (seed, counter, env) -- the categorical draw of the discrete policy (24-bit mantissa)
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t counter, uint32_t env)
+{
+    const Philox4 p = philox4x32_10(env, 0x5eedu, (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    return (float)(p.x >> 8) * (1.0f / 16777216.0f);
+}
+
 // i-th N(0,1) of the stream (seed, counter, env): dims are consumed 4 per Philox call.
 __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t counter, uint32_t env, uint32_t dim)
 {

@@ -84,15 +84,19 @@ extern "C" int erl_mlpn_value_forward_f32(const float *params, const float *stat
     ERL_LAUNCH_CHECK("erl_mlpn_value_forward_f32");
 }
 
-extern "C" int erl_mlpn_rollout_step_f32(const float *actor_params, const float *state_avg, const float *state_std, const int *dims,
-                                         int n_dims, const float *state, int64_t N, const float *noise, uint64_t seed,
-                                         uint64_t counter, float *out_state_row, float *out_action_row, float *out_logprob_row,
-                                         float *out_action_env, void *workspace, int64_t workspace_bytes, void *stream)
+namespace {
+
+// shared by the Gaussian and the categorical rollout step: normalise (+ store the raw state row), forward, sample
+int rollout_impl(const char *what, bool discrete, const float *actor_params, const float *state_avg, const float *state_std,
+                 const int *dims, int n_dims, const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
+                 float *out_state_row, void *out_action_row, float *out_logprob_row, void *out_action_env, void *workspace,
+                 int64_t workspace_bytes, void *stream)
 {
     NetDims nd;
-    ERL_REQUIRE(actor_params && state_avg && state_std && state && workspace, "erl_mlpn_rollout_step_f32: NULL tensor");
-    ERL_REQUIRE(make_dims(dims, n_dims, true, &nd), "erl_mlpn_rollout_step_f32: bad dims");
-    ERL_REQUIRE(N >= 1 && N < (1LL << 31), "erl_mlpn_rollout_step_f32: bad N");
+    ERL_REQUIRE(actor_params && state_avg && state_std && state && workspace, "%s: NULL tensor", what);
+    ERL_REQUIRE(make_dims(dims, n_dims, !discrete, &nd), "%s: bad dims", what);
+    ERL_REQUIRE(!discrete || nd.d[nd.n] <= kMaxDiscrete, "%s: action_dim > %d", what, kMaxDiscrete);
+    ERL_REQUIRE(N >= 1 && N < (1LL << 31), "%s: bad N", what);
     hipStream_t s = (hipStream_t)stream;
     rocblas_handle h;
     int rc = blas(s, &h);
@@ -100,33 +104,64 @@ extern "C" int erl_mlpn_rollout_step_f32(const float *actor_params, const float 
     Ws ws{(char *)workspace, 0, workspace_bytes};
     float *act[MAXL + 2];
     for (int l = 0; l <= nd.n; ++l) act[l] = ws.take(N * nd.d[l]);
-    ERL_REQUIRE(act[nd.n] != nullptr, "erl_mlpn_rollout_step_f32: workspace too small");
+    ERL_REQUIRE(act[nd.n] != nullptr, "%s: workspace too small", what);
     hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(N * nd.d[0])), dim3(256), 0, s, state, state_avg, state_std,
                        (const int64_t *)nullptr, (int64_t)1, (int64_t)1, nd.d[0], N, act[0], out_state_row);
     if ((rc = forward(h, s, nd, actor_params, N, act, nullptr))) return rc;
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, act[nd.n], actor_params + nd.oStd, nd.d[nd.n], N,
-                       noise, seed, counter, out_action_row, out_logprob_row, out_action_env);
-    ERL_LAUNCH_CHECK("erl_mlpn_rollout_step_f32");
+    if (discrete)
+        hipLaunchKernelGGL(sample_categorical_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, act[nd.n], nd.d[nd.n], N, noise,
+                           seed, counter, (int32_t *)out_action_row, out_logprob_row, (int64_t *)out_action_env);
+    else
+        hipLaunchKernelGGL(sample_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, act[nd.n], actor_params + nd.oStd,
+                           nd.d[nd.n], N, noise, seed, counter, (float *)out_action_row, out_logprob_row, (float *)out_action_env);
+    return erl_hip_status(hipGetLastError(), what);
+}
+
+}  // namespace
+
+extern "C" int erl_mlpn_rollout_step_f32(const float *actor_params, const float *state_avg, const float *state_std, const int *dims,
+                                         int n_dims, const float *state, int64_t N, const float *noise, uint64_t seed,
+                                         uint64_t counter, float *out_state_row, float *out_action_row, float *out_logprob_row,
+                                         float *out_action_env, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return rollout_impl("erl_mlpn_rollout_step_f32", false, actor_params, state_avg, state_std, dims, n_dims, state, N, noise, seed,
+                        counter, out_state_row, out_action_row, out_logprob_row, out_action_env, workspace, workspace_bytes, stream);
+}
+
+extern "C" int erl_mlpn_rollout_step_discrete_f32(const float *actor_params, const float *state_avg, const float *state_std,
+                                                  const int *dims, int n_dims, const float *state, int64_t N, const float *uniform,
+                                                  uint64_t seed, uint64_t counter, float *out_state_row, int32_t *out_action_row,
+                                                  float *out_logprob_row, int64_t *out_action_env, void *workspace,
+                                                  int64_t workspace_bytes, void *stream)
+{
+    return rollout_impl("erl_mlpn_rollout_step_discrete_f32", true, actor_params, state_avg, state_std, dims, n_dims, state, N, uniform,
+                        seed, counter, out_state_row, out_action_row, out_logprob_row, out_action_env, workspace, workspace_bytes,
+                        stream);
 }
 
 // One PPO minibatch for networks of any depth: writes the summed gradient [actor | critic | logs(4)] to flat_grad.
-extern "C" int erl_mlpn_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
-                                     const float *cri_avg, const float *cri_std, const int *actor_dims, int n_dims,
-                                     const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
-                                     const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
-                                     int64_t B, float ratio_clip, float lambda_entropy, float inv_batch, float *flat_grad,
-                                     void *workspace, int64_t workspace_bytes, void *stream)
+namespace {
+
+int ppo_step_impl(const char *what, bool discrete, const float *actor_params, const float *critic_params, const float *act_avg,
+                  const float *act_std, const float *cri_avg, const float *cri_std, const int *actor_dims, int n_dims,
+                  const float *states, const void *actions_any, const uint8_t *unmasks, const float *logprobs,
+                  const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
+                  float ratio_clip, float lambda_entropy, float inv_batch, float *flat_grad, void *workspace,
+                  int64_t workspace_bytes, void *stream)
 {
-    ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions && unmasks &&
+    const float *actions = discrete ? nullptr : (const float *)actions_any;
+    const int32_t *actions_i = discrete ? (const int32_t *)actions_any : nullptr;
+    ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions_any && unmasks &&
                     logprobs && advantages && reward_sums && ids && flat_grad && workspace,
-                "erl_mlpn_ppo_step_f32: NULL tensor");
+                "%s: NULL tensor", what);
     NetDims na, nc;
-    ERL_REQUIRE(make_dims(actor_dims, n_dims, true, &na), "erl_mlpn_ppo_step_f32: bad dims");
+    ERL_REQUIRE(make_dims(actor_dims, n_dims, !discrete, &na), "%s: bad dims", what);
+    ERL_REQUIRE(!discrete || na.d[na.n] <= kMaxDiscrete, "%s: action_dim > %d", what, kMaxDiscrete);
     int cdims[MAXL + 2];
     for (int i = 0; i < n_dims; ++i) cdims[i] = actor_dims[i];
     cdims[n_dims - 1] = 1;
-    ERL_REQUIRE(make_dims(cdims, n_dims, false, &nc), "erl_mlpn_ppo_step_f32: bad dims");
-    ERL_REQUIRE(H >= 1 && N >= 1 && B >= 1 && B < (1LL << 31), "erl_mlpn_ppo_step_f32: bad shape");
+    ERL_REQUIRE(make_dims(cdims, n_dims, false, &nc), "%s: bad dims", what);
+    ERL_REQUIRE(H >= 1 && N >= 1 && B >= 1 && B < (1LL << 31), "%s: bad shape", what);
     hipStream_t s = (hipStream_t)stream;
     rocblas_handle h;
     int rc = blas(s, &h);
@@ -155,24 +190,54 @@ extern "C" int erl_mlpn_ppo_step_f32(const float *actor_params, const float *cri
         int64_t nk = 1;
         for (int l = 0; l < nd.n; ++l) nk = (int64_t)nd.d[l] * nd.d[l + 1] > nk ? (int64_t)nd.d[l] * nd.d[l + 1] : nk;
         float *dw_scr = dw_scratch_floats(B, nk) ? ws.take(dw_scratch_floats(B, nk)) : nullptr;
-        ERL_REQUIRE(part != nullptr && (dw_scr != nullptr || !dw_scratch_floats(B, nk)), "erl_mlpn_ppo_step_f32: workspace too small (need erl_mlpn_workspace_bytes(dims, rows = B, training = 1))");
+        ERL_REQUIRE(part != nullptr && (dw_scr != nullptr || !dw_scratch_floats(B, nk)), "%s: workspace too small (need erl_mlpn_workspace_bytes(dims, rows = B, training = 1))", what);
 
         hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(B * nd.d[0])), dim3(256), 0, s, states, net == 0 ? act_avg : cri_avg,
                            net == 0 ? act_std : cri_std, ids, H, N, nd.d[0], B, act[0], (float *)nullptr);
         if ((rc = forward(h, s, nd, P, B, act, gd))) return rc;
         float *Y = act[nd.n];
-        if (net == 0)
+        if (net == 0 && discrete)
+            hipLaunchKernelGGL(objective_discrete_kernel, dim3(nparts), dim3(256), 0, s, Y, ids, H, N, A, B, actions_i, unmasks, logprobs,
+                               advantages, ratio_clip, lambda_entropy, inv_batch, part);
+        else if (net == 0)
             hipLaunchKernelGGL((objective_kernel<true>), dim3(nparts), dim3(256), 0, s, Y, dsl, ids, H, N, A, B, actions, unmasks, logprobs,
                                advantages, P + nd.oStd, ratio_clip, lambda_entropy, inv_batch, part);
         else
             hipLaunchKernelGGL((objective_kernel<false>), dim3(nparts), dim3(256), 0, s, Y, (float *)nullptr, ids, H, N, 1, B, actions,
                                unmasks, reward_sums, (const float *)nullptr, (const float *)nullptr, ratio_clip, lambda_entropy,
                                inv_batch, part);
-        hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, s, part, nparts, P + nd.oStd, A, inv_batch, net == 0 ? 1 : 0, logs);
-        if (net == 0 && (rc = colsum(s, dsl, cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
+        hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, s, part, nparts, P + nd.oStd, A, inv_batch,
+                           net == 0 ? (discrete ? 2 : 1) : 0, logs);
+        if (net == 0 && !discrete && (rc = colsum(s, dsl, cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
 
         // backward: dZ of the output layer is Y (dL/dY); walk the layers down
         if ((rc = backward(h, s, nd, P, B, act, gd, Y, G, cs_scr, nullptr, false, dA, dB, dw_scr))) return rc;
     }
-    ERL_LAUNCH_CHECK("erl_mlpn_ppo_step_f32");
+    return erl_hip_status(hipGetLastError(), what);
+}
+
+}  // namespace
+
+extern "C" int erl_mlpn_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
+                                     const float *cri_avg, const float *cri_std, const int *actor_dims, int n_dims,
+                                     const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
+                                     const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
+                                     int64_t B, float ratio_clip, float lambda_entropy, float inv_batch, float *flat_grad,
+                                     void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return ppo_step_impl("erl_mlpn_ppo_step_f32", false, actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, actor_dims,
+                         n_dims, states, actions, unmasks, logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy,
+                         inv_batch, flat_grad, workspace, workspace_bytes, stream);
+}
+
+extern "C" int erl_mlpn_ppo_step_discrete_f32(const float *actor_params, const float *critic_params, const float *act_avg,
+                                              const float *act_std, const float *cri_avg, const float *cri_std, const int *actor_dims,
+                                              int n_dims, const float *states, const int32_t *actions, const uint8_t *unmasks,
+                                              const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
+                                              int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
+                                              float inv_batch, float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return ppo_step_impl("erl_mlpn_ppo_step_discrete_f32", true, actor_params, critic_params, act_avg, act_std, cri_avg, cri_std,
+                         actor_dims, n_dims, states, actions, unmasks, logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip,
+                         lambda_entropy, inv_batch, flat_grad, workspace, workspace_bytes, stream);
 }

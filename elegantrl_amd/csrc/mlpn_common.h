@@ -270,7 +270,98 @@ __global__ __launch_bounds__(256) void objective_kernel(float *__restrict__ Y, f
     }
 }
 
-// logs: fold the per-block partials in a fixed order
+// ---- discrete policy (ActorDiscretePPO, elegantrl/agents/AgentPPO.py:393-422) ------------------------------------
+// torch.distributions.Categorical(probs = softmax(z)) works on logits = log(clamp(p, eps, 1 - eps)) with
+// eps = float32 machine epsilon: log_prob(a) = logits[a], entropy = -sum p logits; the clamp has zero gradient outside.
+constexpr int kMaxDiscrete = 64;             // action_dim of the discrete path
+constexpr float kCatEps = 1.1920928955078125e-07f;
+
+__device__ __forceinline__ void softmax_row(const float *__restrict__ z, int A, float *p)
+{
+    float mx = z[0];
+    for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
+    float sum = 0.f;
+    for (int a = 0; a < A; ++a) { p[a] = expf(z[a] - mx); sum += p[a]; }
+    const float inv = 1.f / sum;
+    for (int a = 0; a < A; ++a) p[a] *= inv;
+}
+
+// rollout sampling: inverse-CDF draw from softmax(logits) with u in [0, 1) (injected or Philox), log-prob of the draw
+__global__ __launch_bounds__(256) void sample_categorical_kernel(const float *__restrict__ Y, int A, int64_t N,
+                                                                 const float *__restrict__ uniform, uint64_t seed, uint64_t counter,
+                                                                 int32_t *__restrict__ o_action, float *__restrict__ o_logprob,
+                                                                 int64_t *__restrict__ o_env)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float p[kMaxDiscrete];
+    softmax_row(Y + n * A, A, p);
+    const float u = uniform ? uniform[n] : philox_uniform(seed, counter, (uint32_t)n);
+    int act = A - 1;
+    float c = 0.f;
+    for (int a = 0; a < A; ++a) {
+        c += p[a];
+        if (u < c) { act = a; break; }
+    }
+    if (o_action) o_action[n] = act;
+    if (o_env) o_env[n] = act;                                      // convert_action_for_env: action.long()
+    if (o_logprob) o_logprob[n] = logf(fminf(fmaxf(p[act], kCatEps), 1.f - kCatEps));
+}
+
+// PPO objective of the discrete actor on gathered rows (AgentPPO.py:189-204 with get_logprob_entropy of :413-418):
+// Y (B, A) holds the logits on entry and dL/dlogits on exit; part[block] = (sum surr * unmask, sum entropy * unmask).
+__global__ __launch_bounds__(256) void objective_discrete_kernel(float *__restrict__ Y, const int64_t *__restrict__ ids, int64_t H,
+                                                                 int64_t N, int A, int64_t B, const int32_t *__restrict__ actions,
+                                                                 const uint8_t *__restrict__ unmasks, const float *__restrict__ logp_old,
+                                                                 const float *__restrict__ advantages, float ratio_clip,
+                                                                 float lambda_entropy, float inv_batch, float *__restrict__ part)
+{
+    __shared__ float red[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float l0 = 0.f, l1 = 0.f;
+    if (b < B) {
+        const int64_t id = ids[b];
+        const int64_t n = id / H, t = id - n * H;
+        const int64_t row = t * N + n;
+        const float um = unmasks[row] ? 1.f : 0.f;
+        float p[kMaxDiscrete];
+        float *z = Y + b * A;
+        softmax_row(z, A, p);
+        int act = actions[row];
+        act = act < 0 ? 0 : (act >= A ? A - 1 : act);
+        float ent = 0.f, ph = 0.f;                                  // entropy, sum_k p_k h_k with h_k = dH/dp_k
+        for (int a = 0; a < A; ++a) {
+            const bool inside = p[a] > kCatEps && p[a] < 1.f - kCatEps;
+            const float L = logf(fminf(fmaxf(p[a], kCatEps), 1.f - kCatEps));
+            ent -= p[a] * L;
+            ph += p[a] * -(L + (inside ? 1.f : 0.f));
+        }
+        const bool a_inside = p[act] > kCatEps && p[act] < 1.f - kCatEps;
+        const float lp = logf(fminf(fmaxf(p[act], kCatEps), 1.f - kCatEps));
+        const float adv = advantages[row];
+        const float ratio = expf(lp - logp_old[row]);
+        const float w = adv > 0.f ? 1.f - ratio_clip : 1.f + ratio_clip;
+        const float surr = adv * ratio * w;
+        l0 = surr * um;
+        l1 = ent * um;
+        // loss = -(mean(surr um) - lambda mean(ent um)):  dL/dlp = -surr um / B,  dL/dent = lambda um / B
+        const float dlp = a_inside ? -(surr * um) * inv_batch : 0.f;
+        const float dent = lambda_entropy * um * inv_batch;
+        for (int a = 0; a < A; ++a) {
+            const bool inside = p[a] > kCatEps && p[a] < 1.f - kCatEps;
+            const float L = logf(fminf(fmaxf(p[a], kCatEps), 1.f - kCatEps));
+            const float h = -(L + (inside ? 1.f : 0.f));
+            z[a] = dlp * ((a == act ? 1.f : 0.f) - p[a]) + dent * p[a] * (h - ph);
+        }
+    }
+    const float t0 = block_sum(l0, red), t1 = block_sum(l1, red);
+    if (threadIdx.x == 0) {
+        part[(size_t)blockIdx.x * 2 + 0] = t0;
+        part[(size_t)blockIdx.x * 2 + 1] = t1;
+    }
+}
+
+// logs: fold the per-block partials in a fixed order (is_actor: 1 = Gaussian head, 2 = categorical head)
 __global__ void fold_logs_kernel(const float *__restrict__ part, int nparts, const float *__restrict__ std_log, int A, float inv_batch,
                                  int is_actor, float *__restrict__ logs)
 {
@@ -280,7 +371,10 @@ __global__ void fold_logs_kernel(const float *__restrict__ part, int nparts, con
         s0 += part[2 * i];
         s1 += part[2 * i + 1];
     }
-    if (is_actor) {
+    if (is_actor == 2) {
+        logs[1] = s0 * inv_batch;
+        logs[2] = s1 * inv_batch;
+    } else if (is_actor) {
         float ent = 0.f;
         for (int a = 0; a < A; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));
         logs[1] = s0 * inv_batch;

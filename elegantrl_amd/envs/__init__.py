@@ -1,1 +1,1 @@
-from .vec_envs import PendulumVecEnv, SynVecEnv
+from .vec_envs import CartPoleVecEnv, PendulumVecEnv, SynVecEnv

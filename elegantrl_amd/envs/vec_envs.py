@@ -120,3 +120,45 @@ class PendulumVecEnv(_GpuVecEnv):
             if rc:
                 _hip.check(rc, "erl_pendulum_step_f32")
         return step
+
+
+class CartPoleVecEnv:
+    """CartPole-v1 for N envs, written with plain torch ops on device tensors: an exemplar of "any env honouring the
+    reference's vector protocol" for the discrete agents (action (N,) int64, auto-reset, 5-tuple).  gymnasium's physics:
+    gravity 9.8, cart 1.0 kg, pole 0.1 kg, half-length 0.5 m, force 10 N, dt 0.02 s (Euler), terminal when |x| > 2.4 or
+    |theta| > 12 degrees, reward 1 per step, truncation at max_step (500)."""
+    env_name = "CartPole-v1"
+    if_discrete = True
+
+    def __init__(self, num_envs: int = 1024, max_step: int = 500, gpu_id: int = 0, seed: int = 0, **_):
+        self.device = th.device(f"cuda:{gpu_id}" if (th.cuda.is_available() and gpu_id >= 0) else "cpu")
+        self.num_envs, self.state_dim, self.action_dim, self.max_step = num_envs, 4, 2, max_step
+        self.gen = th.Generator(device=self.device).manual_seed(int(seed))
+        self.state = th.zeros((num_envs, 4), dtype=th.float32, device=self.device)
+        self.step_count = th.zeros(num_envs, dtype=th.int32, device=self.device)
+
+    def _fresh(self, n: int) -> TEN:
+        return th.rand((n, 4), device=self.device, generator=self.gen) * 0.1 - 0.05
+
+    def reset(self) -> Tuple[TEN, dict]:
+        self.state = self._fresh(self.num_envs)
+        self.step_count.zero_()
+        return self.state.clone(), {}
+
+    def step(self, action: TEN) -> Tuple[TEN, TEN, TEN, TEN, dict]:
+        x, x_dot, theta, theta_dot = self.state.unbind(dim=1)
+        force = th.where(action.to(self.device).reshape(-1) == 1, 10.0, -10.0).to(th.float32)
+        cos, sin = theta.cos(), theta.sin()
+        temp = (force + 0.05 * theta_dot * theta_dot * sin) / 1.1                       # polemass_length = 0.05, total mass 1.1
+        theta_acc = (9.8 * sin - cos * temp) / (0.5 * (4.0 / 3.0 - 0.1 * cos * cos / 1.1))
+        x_acc = temp - 0.05 * theta_acc * cos / 1.1
+        state = th.stack((x + 0.02 * x_dot, x_dot + 0.02 * x_acc, theta + 0.02 * theta_dot, theta_dot + 0.02 * theta_acc), dim=1)
+        self.step_count += 1
+        terminal = (state[:, 0].abs() > 2.4) | (state[:, 2].abs() > 12 * 2 * math.pi / 360)
+        truncate = (self.step_count >= self.max_step) & ~terminal
+        done = terminal | truncate
+        reward = th.ones(self.num_envs, dtype=th.float32, device=self.device)
+        state = th.where(done[:, None], self._fresh(self.num_envs), state)
+        self.step_count = th.where(done, th.zeros_like(self.step_count), self.step_count)
+        self.state = state
+        return state.clone(), reward, terminal, truncate, {}

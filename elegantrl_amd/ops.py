@@ -340,6 +340,39 @@ def mlpn_ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: 
           "erl_mlpn_ppo_step_f32")
 
 
+def mlpn_rollout_step_discrete(params: TEN, spec: MlpSpecN, state_avg: TEN, state_std: TEN, state: TEN, *,
+                               uniform: Optional[TEN] = None, seed: int = 0, counter: int = 0, out_state: Optional[TEN] = None,
+                               out_action: Optional[TEN] = None, out_logprob: Optional[TEN] = None,
+                               out_env_action: Optional[TEN] = None) -> None:
+    """one rollout step of the categorical policy: out_action (N,) int32, out_logprob (N,), out_env_action (N,) int64."""
+    N = state.shape[0]
+    ws = _workspace(state.device, spec.workspace_bytes(N, False))
+    c, n = spec.cdims
+    check(lib().erl_mlpn_rollout_step_discrete_f32(ptr(params, th.float32), ptr(state_avg, th.float32), ptr(state_std, th.float32), c, n,
+                                                   ptr(state, th.float32), N, ptr(uniform, th.float32) if uniform is not None else None,
+                                                   seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), ptr(out_state),
+                                                   ptr(out_action, th.int32) if out_action is not None else None, ptr(out_logprob),
+                                                   ptr(out_env_action, th.int64) if out_env_action is not None else None, ptr(ws),
+                                                   ws.numel(), stream_ptr()),
+          "erl_mlpn_rollout_step_discrete_f32")
+
+
+def mlpn_ppo_step_discrete(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN,
+                           spec: MlpSpecN, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
+                           ids: TEN, ratio_clip: float, lambda_entropy: float, inv_batch: float, flat_grad: TEN) -> None:
+    """one PPO minibatch of the categorical policy; actions (H, N) int32."""
+    H, N = states.shape[0], states.shape[1]
+    B = ids.numel()
+    ws = _workspace(states.device, spec.workspace_bytes(B, True))
+    c, n = spec.cdims
+    check(lib().erl_mlpn_ppo_step_discrete_f32(ptr(actor_params, th.float32), ptr(critic_params, th.float32), ptr(act_avg), ptr(act_std),
+                                               ptr(cri_avg), ptr(cri_std), c, n, ptr(states, th.float32), ptr(actions, th.int32),
+                                               flag_ptr(unmasks), ptr(logprobs, th.float32), ptr(advantages, th.float32),
+                                               ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), B, ratio_clip, lambda_entropy,
+                                               inv_batch, ptr(flat_grad, th.float32), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_mlpn_ppo_step_discrete_f32")
+
+
 # ------------------------------------------------------------------------------------------------
 # SAC (erl_sac_*)
 # ------------------------------------------------------------------------------------------------

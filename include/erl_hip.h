@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 6
+#define ERL_ABI_VERSION 7
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -248,6 +248,26 @@ ERL_API int erl_mlpn_ppo_step_f32(const float *actor_params, const float *critic
                           const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
                           int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
                           float inv_batch, float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Discrete-action sibling (AgentDiscretePPO / ActorDiscretePPO, elegantrl/agents/AgentPPO.py:305-320, :393-422): the actor
+ * block has no action_std_log (erl_mlpn_param_count(dims, n_dims, 0)), dims[n_dims-1] = number of actions (<= 64).
+ * Rollout: a ~ Categorical(softmax(logits)) by inverse CDF with one U[0,1) per env (`uniform` (N) injected, or
+ * Philox4x32-10 keyed by (seed, counter, env)); stores the action as int32 (the reference's rollout dtype,
+ * AgentPPO.py:103), its log-prob, and the int64 copy that goes to env.step (convert_action_for_env, :420-422).
+ * Update: actions (H, N) int32; log-prob / entropy as torch.distributions.Categorical(probs) computes them
+ * (logits = log(clamp(p, eps, 1 - eps))); the entropy is state dependent here, so its gradient flows into the network. */
+#define ERL_MAX_DISCRETE_ACTIONS 64
+ERL_API int erl_mlpn_rollout_step_discrete_f32(const float *actor_params, const float *state_avg, const float *state_std,
+                              const int *dims, int n_dims, const float *state, int64_t N, const float *uniform,
+                              uint64_t seed, uint64_t counter, float *out_state_row, int32_t *out_action_row,
+                              float *out_logprob_row, int64_t *out_action_env, void *workspace,
+                              int64_t workspace_bytes, void *stream);
+ERL_API int erl_mlpn_ppo_step_discrete_f32(const float *actor_params, const float *critic_params, const float *act_avg,
+                          const float *act_std, const float *cri_avg, const float *cri_std, const int *actor_dims,
+                          int n_dims, const float *states, const int32_t *actions, const uint8_t *unmasks,
+                          const float *logprobs, const float *advantages, const float *reward_sums, int64_t H, int64_t N,
+                          const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy, float inv_batch,
+                          float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SAC: everything AgentSAC.update_objectives does after ReplayBuffer.sample

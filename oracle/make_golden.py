@@ -144,6 +144,92 @@ def make_ppo(tag, *, N, S, A, H, net_dims, batch_size, repeat_times, use_v_trace
     print("wrote", path, {k: v.shape for k, v in g.items() if k in ("states", "ids", "advantages")})
 
 
+class ScriptedDiscreteVecEnv(ScriptedVecEnv):
+    """the same toy dynamics driven by a discrete action (one row of wa per action index, int64 as the reference's
+    convert_action_for_env produces)."""
+
+    def step(self, action):
+        assert action.dtype == th.int64 and action.shape == (self.num_envs,)
+        s = self.state @ self.ws + self.wa[action]
+        reward = -(s * s).mean(1)
+        u = th.rand(self.num_envs, generator=self.g)
+        terminal = u < 0.10
+        truncate = (u >= 0.10) & (u < 0.22)
+        fresh = th.randn(self.num_envs, self.state_dim, generator=self.g)
+        s = th.where((terminal | truncate)[:, None], fresh, s)
+        self.state = s
+        return s.clone(), reward, terminal, truncate, {}
+
+
+def make_ppo_discrete(tag, *, N, S, A, H, net_dims, batch_size, repeat_times, seed):
+    """reference AgentDiscretePPO: rollout (actions int32, log-probs, logits recorded) and one update_net with recorded ids."""
+    sys.path.insert(0, REF)
+    from elegantrl.agents import AgentDiscretePPO
+    from elegantrl.train.config import Config
+
+    th.manual_seed(seed)
+    args = Config(AgentDiscretePPO, None, {"env_name": "scripted", "num_envs": N, "max_step": 100, "state_dim": S, "action_dim": A,
+                                           "if_discrete": True})
+    args.net_dims = list(net_dims)
+    args.horizon_len, args.batch_size, args.repeat_times = H, batch_size, repeat_times
+    args.learning_rate, args.gamma, args.reward_scale = 1e-3, 0.99, 0.5
+    agent = AgentDiscretePPO(args.net_dims, S, A, gpu_id=-1, args=args)
+    with th.no_grad():
+        for net in (agent.act, agent.cri):
+            net.state_avg[:] = 0.1 * th.randn(S)
+            net.state_std[:] = 1.0 + 0.2 * th.rand(S)
+        agent.act.net[-1].weight *= 8.0           # spread the logits so the policy is far from uniform
+    env = ScriptedDiscreteVecEnv(N, S, A, seed + 1)
+    agent.last_state = env.reset()[0]
+    th.set_grad_enabled(False)
+    g = {}
+    g.update(net_arrays("act0", agent.act))
+    g.update(net_arrays("cri0", agent.cri))
+    g.update(first_state=np32(agent.last_state))
+    logits = []
+    orig_get_action = agent.act.get_action
+
+    def recording_get_action(state):
+        logits.append(agent.act.net(agent.act.state_norm(state)).clone())
+        return orig_get_action(state)
+
+    agent.act.get_action = recording_get_action
+    items = agent.explore_env(env, H)
+    agent.act.get_action = orig_get_action
+    states, actions, logprobs, rewards, undones, unmasks = items
+    assert actions.dtype == th.int32 and actions.shape == (H, N)
+    g.update(states=np32(states), actions=np32(actions), logprobs=np32(logprobs), rewards=np32(rewards), undones=np32(undones),
+             unmasks=np32(unmasks), logits=np32(th.stack(logits)), last_state=np32(agent.last_state))
+    values = agent.cri(states).squeeze(-1)
+    r2, u2 = rewards.clone(), undones.clone()
+    adv = agent.get_advantages(states, r2, u2, unmasks, values)
+    g.update(values=np32(values), advantages=np32(adv), reward_sums=np32(adv + values),
+             advantages_norm=np32((adv - adv.mean()) / (adv[::4, ::4].std() + 1e-5)))
+    ids_log = []
+    orig_randint = th.randint
+
+    def recording_randint(*a, **k):
+        out = orig_randint(*a, **k)
+        ids_log.append(out.clone())
+        return out
+
+    th.randint = recording_randint
+    th.set_grad_enabled(True)
+    objs = agent.update_net([t.clone() for t in items])
+    th.set_grad_enabled(False)
+    th.randint = orig_randint
+    g.update(net_arrays("act1", agent.act))
+    g.update(net_arrays("cri1", agent.cri))
+    g.update(ids=np.stack([np32(i) for i in ids_log]).astype(np.int64), objs=np.array([float(o) for o in objs], dtype=np.float64),
+             hyper=np.array([args.gamma, agent.lambda_gae_adv, agent.ratio_clip, float(agent.lambda_entropy), args.learning_rate,
+                             args.clip_grad_norm, args.reward_scale], dtype=np.float64),
+             dims=np.array([N, S, A, H, batch_size, len(ids_log), 1, *net_dims], dtype=np.int64))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"ppo_discrete_{tag}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, {k: v.shape for k, v in g.items() if k in ("states", "ids", "actions")}, "objs", objs)
+
+
 def make_replay():
     sys.path.insert(0, REF)
     from elegantrl.train.replay_buffer import ReplayBuffer
@@ -274,3 +360,4 @@ if __name__ == "__main__":
              use_v_trace=True, seed=13)
     make_replay()
     make_sac("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=21)
+    make_ppo_discrete("small", N=8, S=6, A=4, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0, seed=31)

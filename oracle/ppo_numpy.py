@@ -251,6 +251,74 @@ def actor_objective(state, action, logprob_old, advantage, unmask, actor: Mlp,
 
 
 # --------------------------------------------------------------------------------------
+# Discrete policy: ActorDiscretePPO (AgentPPO.py:393-422) through torch.distributions.Categorical(probs)
+# --------------------------------------------------------------------------------------
+_CAT_EPS = float(np.finfo(np.float32).eps)      # Categorical clamps probs to [eps, 1 - eps] before the log (fp32 policy)
+
+
+def softmax(z: np.ndarray) -> np.ndarray:
+    e = np.exp(z - z.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def categorical_logits(p: np.ndarray) -> np.ndarray:
+    """torch/distributions/utils.py probs_to_logits: log(clamp(p, eps, 1 - eps))."""
+    dt = p.dtype
+    return np.log(np.clip(p, dt.type(_CAT_EPS), dt.type(1.0 - _CAT_EPS)))
+
+
+def categorical_sample(state: np.ndarray, actor: Mlp, u: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """get_action (AgentPPO.py:405-411) with the draw made explicit: inverse CDF of softmax(net(state)) at u in [0, 1)
+    (first index whose running sum exceeds u, last index otherwise); log-prob of the drawn action."""
+    p = softmax(actor_mean(state, actor))
+    c = np.cumsum(p, axis=1)
+    act = np.minimum((c <= u[:, None]).sum(axis=1), p.shape[1] - 1).astype(np.int32)
+    return act, categorical_logits(p)[np.arange(p.shape[0]), act]
+
+
+def actor_objective_discrete(state, action, logprob_old, advantage, unmask, actor: Mlp, ratio_clip: float, lambda_entropy: float):
+    """AgentPPO.update_objectives (:193-204) with ActorDiscretePPO.get_logprob_entropy (:413-418):
+    log_prob = logits[a], entropy = -sum p * logits (state dependent: its gradient reaches the network).
+    Returns (obj_surrogate, obj_entropy, grads_w, grads_b) of the minimised loss."""
+    dt = state.dtype
+    B, um = state.shape[0], unmask.astype(dt)
+    z, cache = actor_mean(state, actor, keep=True)
+    p = softmax(z)
+    L = categorical_logits(p)
+    inside = ((p > dt.type(_CAT_EPS)) & (p < dt.type(1.0 - _CAT_EPS))).astype(dt)     # clamp passes no gradient outside
+    rows = np.arange(B)
+    a = action.astype(np.int64)
+    new_lp = L[rows, a]
+    ent = -(p * L).sum(axis=1)
+    ratio = np.exp(new_lp - logprob_old)
+    w = np.where(advantage > 0, dt.type(1.0 - ratio_clip), dt.type(1.0 + ratio_clip)).astype(dt)
+    surrogate = advantage * ratio * w
+    obj_s, obj_e = (surrogate * um).mean(), (ent * um).mean()
+    dlp = -(surrogate * um) / dt.type(B) * inside[rows, a]
+    dent = dt.type(lambda_entropy) * um / dt.type(B)
+    onehot = np.zeros_like(p)
+    onehot[rows, a] = 1
+    h = -(L + inside)                                                                  # dH/dp_k
+    dz = dlp[:, None] * (onehot - p) + dent[:, None] * p * (h - (p * h).sum(axis=1, keepdims=True))
+    gw, gb = mlp_backward(dz.astype(dt), actor, cache)
+    return obj_s, obj_e, gw, gb
+
+
+def ppo_minibatch_step_discrete(buf, ids, actor: Mlp, critic: Mlp, st_a: "AdamState", st_c: "AdamState", *, lr: float,
+                                max_norm: float, ratio_clip: float, lambda_entropy: float):
+    """ppo_minibatch_step for the discrete agent: actions (H, N) int32."""
+    states, actions, unmasks, logprobs, advantages, rsums = buf
+    i0, i1 = split_ids(ids, states.shape[0])
+    s, a = states[i0, i1], actions[i0, i1]
+    um, lp, adv, rs = unmasks[i0, i1], logprobs[i0, i1], advantages[i0, i1], rsums[i0, i1]
+    obj_c, gw, gb = critic_objective(s, rs, um, critic)
+    optimizer_backward(critic.trainable(), [x for pair in zip(gw, gb) for x in pair], st_c, lr, max_norm)
+    obj_s, obj_e, gw, gb = actor_objective_discrete(s, a, lp, adv, um, actor, ratio_clip, lambda_entropy)
+    optimizer_backward(actor.trainable(), [x for pair in zip(gw, gb) for x in pair], st_a, lr, max_norm)
+    return obj_c, obj_s, obj_e
+
+
+# --------------------------------------------------------------------------------------
 # optimizer_backward: AgentBase.py:239-248 (clip_grad_norm_(max_norm) then Adam.step)
 # --------------------------------------------------------------------------------------
 def clip_coef(grads: Sequence[np.ndarray], max_norm: float) -> float:

@@ -174,3 +174,47 @@ def test_torch_port_rollout_shapes_and_env_rules():
                                    np.zeros((64, 2), np.float32))
     mean = a_ref                                                             # eps = 0 -> action == mean
     np.testing.assert_allclose(lp[3].numpy(), O.gaussian_logprob(a[3].numpy(), mean, np.zeros(2, np.float32)), rtol=1e-5, atol=1e-5)
+
+
+# ---- discrete policy (AgentDiscretePPO / ActorDiscretePPO), fixture ppo_discrete_small.npz ---------------------------
+def _discrete_actor(g, prefix):
+    a = mlp_from(g, prefix)
+    a.action_std_log = None          # ActorDiscretePPO inherits the parameter but never uses it (its grad stays None)
+    return a
+
+
+def test_discrete_logprob_and_sampling_rule():
+    g = load("ppo_discrete_small.npz")
+    actor = _discrete_actor(g, "act0")
+    H, N, A = g["actions"].shape[0], g["actions"].shape[1], g["logits"].shape[-1]
+    for t in range(H):
+        z = O.actor_mean(g["states"][t], actor)
+        np.testing.assert_allclose(z, g["logits"][t], rtol=1e-5, atol=1e-5)
+        L = O.categorical_logits(O.softmax(z))
+        np.testing.assert_allclose(L[np.arange(N), g["actions"][t]], g["logprobs"][t], rtol=1e-5, atol=1e-5)   # dist.log_prob
+    # the inverse-CDF draw: u just below / above a cumulative boundary picks the two neighbouring actions
+    p = O.softmax(O.actor_mean(g["states"][0], actor))
+    c = np.cumsum(p, axis=1)
+    for k in range(A - 1):
+        lo, _ = O.categorical_sample(g["states"][0], actor, (c[:, k] - 1e-6).astype(np.float32))
+        hi, _ = O.categorical_sample(g["states"][0], actor, (c[:, k] + 1e-6).astype(np.float32))
+        assert (lo <= k).all() and (hi >= k + 1).all()
+    a, lp = O.categorical_sample(g["states"][0], actor, np.full(N, 0.999999, np.float32))
+    assert a.max() <= A - 1 and np.isfinite(lp).all()
+
+
+def test_discrete_update_net_weights_and_objectives():
+    """the reference's AgentDiscretePPO.update_net on its own recorded ids: manual softmax / entropy backward vs autograd."""
+    g = load("ppo_discrete_small.npz")
+    hp = hyper(g)
+    actor, critic = _discrete_actor(g, "act0"), mlp_from(g, "cri0")
+    buf = (g["states"], g["actions"], g["unmasks"], g["logprobs"], g["advantages_norm"], g["reward_sums"])
+    sa, sc = O.AdamState(), O.AdamState()
+    objs = [O.ppo_minibatch_step_discrete(buf, ids, actor, critic, sa, sc, lr=hp["lr"], max_norm=hp["max_norm"],
+                                          ratio_clip=hp["ratio_clip"], lambda_entropy=hp["lambda_entropy"]) for ids in g["ids"]]
+    np.testing.assert_allclose(np.array(objs, dtype=np.float64).mean(axis=0), g["objs"], rtol=2e-4, atol=2e-6)
+    ref_a, ref_c = _discrete_actor(g, "act1"), mlp_from(g, "cri1")
+    for mine, ref in ((actor, ref_a), (critic, ref_c)):
+        for p, q in zip(mine.trainable(), ref.trainable()):
+            np.testing.assert_allclose(p, q, rtol=0, atol=5e-6)
+    assert sum(float(np.abs(p - q).sum()) for p, q in zip(_discrete_actor(g, "act0").trainable(), ref_a.trainable())) > 0
