@@ -1,0 +1,271 @@
+// fp32 MFMA GEMMs of the layered path (any build_mlp shape), with the epilogues that used to be separate launches.
+// gfx950, v_mfma_f32_32x32x2_f32 (exact fp32).  One kernel template covers the three contractions of a dense layer:
+//
+//   forward   Y[m][n]  = act( sum_k X[m][k]  W[n][k] + b[n] )           A = X  (RC)   B = W  (RC)   epilogue BIAS / BIAS_GELU
+//   backward  dH[m][c] = ( sum_n dZ[m][n] W[n][c] ) * GELU'[m][c]        A = dZ (RC)   B = W  (OC)   epilogue MUL / STORE / ACC
+//   weights   dW[n][c] = sum_m dZ[m][n] X[m][c],  db[n] = sum_m dZ[m][n] A = dZ (OC)   B = X  (OC)   epilogue PARTIAL
+//
+// C[i][j] = sum_k A(i, k) B(j, k).  An operand is "RC" when its reduction index is the contiguous one in memory
+// (elem(i, k) = P[i ld + k]) and "OC" when its output index is (elem(i, k) = P[k ld + i]).  A workgroup of 4 waves
+// owns a 64 x 64 tile of C (each wave one 32 x 32 accumulator); the reduction advances in chunks of 16 through LDS
+// tiles stored reduction-major (T[k][i], row stride 68), so an MFMA operand read is 32 consecutive floats per lane
+// half; the next chunk's global loads are in flight under the current chunk's MFMAs.  Shapes are arbitrary: loads are
+// clamped and masked, stores bounds-checked.  The weight-gradient contraction runs over the batch (tens of thousands
+// of rows) into a small output: it is split over blockIdx.z in chunks of rows, each split writes its own partial
+// (fixed-order sum afterwards: deterministic), and the workgroups of the first column tile also emit the row sums of
+// A -- the bias gradient -- from the LDS tiles they already hold.
+#pragma once
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int GT = 64;    // C tile edge
+constexpr int GK = 16;    // reduction chunk
+constexpr int GLD = 68;   // LDS row stride (floats)
+constexpr int GD = 4;     // chunks of global loads in flight per workgroup
+
+enum { OP_RC = 0, OP_OC = 1 };
+enum { EPI_STORE = 0, EPI_ACC, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL, EPI_PARTIAL };
+
+struct GemmArgs {
+    const float *A, *B;
+    int lda, ldb;
+    int M, N, K;              // C is M x N; K = reduction length
+    float *C;
+    int ldc;
+    const float *bias;        // BIAS / BIAS_GELU: [N]
+    float *G;                 // BIAS_GELU: GELU'(z) out, same layout as C (may be NULL); MUL: gate in
+    int kchunk;               // PARTIAL: reduction rows per blockIdx.z
+    int64_t c_split;          // PARTIAL: floats between consecutive partial C's
+    float *rowsum;            // PARTIAL: sum_k A(i, k) of the split (may be NULL)
+    int64_t rs_split;         // PARTIAL: floats between consecutive partial row-sum vectors
+};
+
+template <int OP>
+__device__ __forceinline__ void tile_load(float (&r)[4], const float *__restrict__ P, int ld, int i0, int imax, int k0, int kmax, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u;
+        const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
+        const int gi = i0 + i, gk = k0 + k;
+        const bool ok = gi < imax && gk < kmax;
+        const size_t off = !ok ? 0 : (OP == OP_RC ? (size_t)gi * ld + gk : (size_t)gk * ld + gi);
+        const float v = P[off];
+        r[u] = ok ? v : 0.f;
+    }
+}
+
+template <int OP>
+__device__ __forceinline__ void tile_store(const float (&r)[4], float *T, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u;
+        const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
+        T[k * GLD + i] = r[u];
+    }
+}
+
+template <int AOP, int BOP, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
+{
+    __shared__ float As[GK * GLD], Bs[GK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    int kb = 0, ke = g.K;
+    if (EPI == EPI_PARTIAL) {
+        kb = blockIdx.z * g.kchunk;
+        ke = min(g.K, kb + g.kchunk);
+    }
+    const bool want_rs = EPI == EPI_PARTIAL && g.rowsum != nullptr && blockIdx.x == 0;
+    // GD chunks of global loads stay in flight: a lone workgroup (small batches: 16 workgroups on the whole chip) would
+    // otherwise pay one full memory round trip per 16-deep chunk; with 4 chunks ahead the trip hides under ~2k cycles of MFMAs
+    float ra[GD][4], rb[GD][4], rsum = 0.f;
+    f32x16 acc = {0};
+#pragma unroll
+    for (int d = 0; d < GD; ++d) {
+        tile_load<AOP>(ra[d], g.A, g.lda, i0, g.M, kb + d * GK, ke, tid);
+        tile_load<BOP>(rb[d], g.B, g.ldb, j0, g.N, kb + d * GK, ke, tid);
+    }
+    for (int base = kb; base < ke; base += GD * GK) {
+#pragma unroll
+        for (int d = 0; d < GD; ++d) {
+            const int k0 = base + d * GK;
+            if (k0 < ke) {                                     // uniform
+                __syncthreads();                               // the previous chunk's operand reads are done
+                tile_store<AOP>(ra[d], As, tid);
+                tile_store<BOP>(rb[d], Bs, tid);
+                __syncthreads();
+                if (k0 + GD * GK < ke) {                       // refill this slot with the chunk GD ahead
+                    tile_load<AOP>(ra[d], g.A, g.lda, i0, g.M, k0 + GD * GK, ke, tid);
+                    tile_load<BOP>(rb[d], g.B, g.ldb, j0, g.N, k0 + GD * GK, ke, tid);
+                }
+                const float *a = As + hi * GLD + 32 * wm + l31, *b = Bs + hi * GLD + 32 * wn + l31;
+#pragma unroll
+                for (int s = 0; s < GK / 2; ++s) acc = mfma32(a[2 * s * GLD], b[2 * s * GLD], acc);
+                if (want_rs && tid < GT) {
+#pragma unroll
+                    for (int k = 0; k < GK; ++k) rsum += As[k * GLD + tid];
+                }
+            }
+        }
+    }
+
+    const int j = j0 + 32 * wn + l31;
+    float *C = g.C + (EPI == EPI_PARTIAL ? (size_t)blockIdx.z * g.c_split : 0);
+    if (j < g.N) {
+        const float bj = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? g.bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + 32 * wm + crow(r, hi);
+            if (i < g.M) {
+                const size_t o = (size_t)i * g.ldc + j;
+                const float v = acc[r];
+                if (EPI == EPI_STORE || EPI == EPI_PARTIAL) C[o] = v;
+                else if (EPI == EPI_ACC) C[o] += v;
+                else if (EPI == EPI_BIAS) C[o] = v + bj;
+                else if (EPI == EPI_MUL) C[o] = v * g.G[o];
+                else {
+                    float y, gd;
+                    gelu_and_grad_fast(v + bj, y, gd);
+                    C[o] = y;
+                    if (g.G) g.G[o] = gd;
+                }
+            }
+        }
+    }
+    if (want_rs && tid < GT && i0 + tid < g.M) g.rowsum[(size_t)blockIdx.z * g.rs_split + i0 + tid] = rsum;
+}
+
+// Small outputs (the off-policy agents' batches of a few hundred rows: 16 tiles of 64 x 64 would leave 240 CUs idle and
+// each of the 16 walk the whole reduction): a workgroup owns a 32 x 32 tile and its 4 waves split the REDUCTION -- every
+// step stages 64 reduction indices, wave w takes rows 16 w .. 16 w + 15 of the staged tiles -- and the four partial
+// accumulators meet in LDS in a fixed order (deterministic), wave w finishing accumulator rows 4 w .. 4 w + 3.
+constexpr int ST = 32, SK = 64, SLD = 33;   // odd stride: staging stores and operand reads both land 2 lanes per bank
+
+template <int OP>
+__device__ __forceinline__ void small_load(float (&r)[8], const float *__restrict__ P, int ld, int i0, int imax, int k0, int kmax, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + 256 * u;
+        const int i = OP == OP_RC ? e >> 6 : e & 31, k = OP == OP_RC ? e & 63 : e >> 5;
+        const int gi = i0 + i, gk = k0 + k;
+        const bool ok = gi < imax && gk < kmax;
+        const size_t off = !ok ? 0 : (OP == OP_RC ? (size_t)gi * ld + gk : (size_t)gk * ld + gi);
+        const float v = P[off];
+        r[u] = ok ? v : 0.f;
+    }
+}
+
+template <int OP>
+__device__ __forceinline__ void small_store(const float (&r)[8], float *T, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + 256 * u;
+        const int i = OP == OP_RC ? e >> 6 : e & 31, k = OP == OP_RC ? e & 63 : e >> 5;
+        T[k * SLD + i] = r[u];
+    }
+}
+
+template <int AOP, int BOP, int EPI>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g)
+{
+    __shared__ float As[SK * SLD], Bs[SK * SLD];
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int i0 = blockIdx.y * ST, j0 = blockIdx.x * ST;
+    int kb = 0, ke = g.K;
+    if (EPI == EPI_PARTIAL) {
+        kb = blockIdx.z * g.kchunk;
+        ke = min(g.K, kb + g.kchunk);
+    }
+    const bool want_rs = EPI == EPI_PARTIAL && g.rowsum != nullptr && blockIdx.x == 0;
+    float ra[8], rb[8], rsum = 0.f;
+    f32x16 acc = {0};
+    small_load<AOP>(ra, g.A, g.lda, i0, g.M, kb, ke, tid);
+    small_load<BOP>(rb, g.B, g.ldb, j0, g.N, kb, ke, tid);
+    for (int k0 = kb; k0 < ke; k0 += SK) {
+        __syncthreads();
+        small_store<AOP>(ra, As, tid);
+        small_store<BOP>(rb, Bs, tid);
+        __syncthreads();
+        if (k0 + SK < ke) {
+            small_load<AOP>(ra, g.A, g.lda, i0, g.M, k0 + SK, ke, tid);
+            small_load<BOP>(rb, g.B, g.ldb, j0, g.N, k0 + SK, ke, tid);
+        }
+        const float *a = As + (16 * wave + hi) * SLD + l31, *b = Bs + (16 * wave + hi) * SLD + l31;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = mfma32(a[2 * s * SLD], b[2 * s * SLD], acc);
+        if (want_rs && tid < ST) {
+#pragma unroll 16
+            for (int k = 0; k < SK; ++k) rsum += As[k * SLD + tid];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+
+    const int j = j0 + l31;
+    float *C = g.C + (EPI == EPI_PARTIAL ? (size_t)blockIdx.z * g.c_split : 0);
+    if (j < g.N) {
+        const float bj = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? g.bias[j] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * wave + q;
+            const int i = i0 + crow(r, hi);
+            if (i < g.M) {
+                const float v = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+                const size_t o = (size_t)i * g.ldc + j;
+                if (EPI == EPI_STORE || EPI == EPI_PARTIAL) C[o] = v;
+                else if (EPI == EPI_ACC) C[o] += v;
+                else if (EPI == EPI_BIAS) C[o] = v + bj;
+                else if (EPI == EPI_MUL) C[o] = v * g.G[o];
+                else {
+                    float y, gd;
+                    gelu_and_grad_fast(v + bj, y, gd);
+                    C[o] = y;
+                    if (g.G) g.G[o] = gd;
+                }
+            }
+        }
+    }
+    if (want_rs && tid < ST && i0 + tid < g.M) g.rowsum[(size_t)blockIdx.z * g.rs_split + i0 + tid] = rsum;
+}
+
+template <int AOP, int BOP, int EPI>
+int gemm_launch(hipStream_t s, const GemmArgs &g, int splits, const char *what)
+{
+    const int64_t tiles64 = erl_cdiv(g.N, GT) * erl_cdiv(g.M, GT) * splits;
+    if (tiles64 < 128) {       // fewer 64 x 64 tiles than half the CUs: 32 x 32 tiles with the reduction split over the waves
+        const dim3 grid((unsigned)erl_cdiv(g.N, ST), (unsigned)erl_cdiv(g.M, ST), (unsigned)splits);
+        hipLaunchKernelGGL((gemm_small_kernel<AOP, BOP, EPI>), grid, dim3(256), 0, s, g);
+    } else {
+        const dim3 grid((unsigned)erl_cdiv(g.N, GT), (unsigned)erl_cdiv(g.M, GT), (unsigned)splits);
+        hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI>), grid, dim3(256), 0, s, g);
+    }
+    return erl_hip_status(hipGetLastError(), what);
+}
+
+// Y[rows][Nw] = act(X[rows][K] . W[Nw][K]^T + b);  gelu: hidden layer (G receives GELU' when not NULL)
+int dense_forward(hipStream_t s, const float *X, const float *W, const float *b, float *Y, float *G, int rows, int Nw, int K, bool gelu)
+{
+    GemmArgs g{};
+    g.A = X; g.lda = K; g.B = W; g.ldb = K; g.M = rows; g.N = Nw; g.K = K; g.C = Y; g.ldc = Nw; g.bias = b; g.G = G;
+    return gelu ? gemm_launch<OP_RC, OP_RC, EPI_BIAS_GELU>(s, g, 1, "dense_forward") : gemm_launch<OP_RC, OP_RC, EPI_BIAS>(s, g, 1, "dense_forward");
+}
+
+// dX[rows][K] (=, +=, or = gate *) dZ[rows][Nw] . W[Nw][K]
+int dense_backward_input(hipStream_t s, const float *dZ, const float *W, float *dX, const float *gate, bool accumulate, int rows, int Nw,
+                         int K)
+{
+    GemmArgs g{};
+    g.A = dZ; g.lda = Nw; g.B = W; g.ldb = K; g.M = rows; g.N = K; g.K = Nw; g.C = dX; g.ldc = K; g.G = const_cast<float *>(gate);
+    if (gate) return gemm_launch<OP_RC, OP_OC, EPI_MUL>(s, g, 1, "dense_backward_input");
+    return accumulate ? gemm_launch<OP_RC, OP_OC, EPI_ACC>(s, g, 1, "dense_backward_input")
+                      : gemm_launch<OP_RC, OP_OC, EPI_STORE>(s, g, 1, "dense_backward_input");
+}
+
+}  // namespace

@@ -2,7 +2,7 @@
 #pragma once
 #include <rocblas/rocblas.h>
 
-#include "mlp_chain.h"
+#include "gemm_tiles.h"
 
 namespace {
 
@@ -411,46 +411,60 @@ int64_t ws_floats_forward(const NetDims &nd, int64_t rows)
     return f;
 }
 
-// forward pass into workspace buffers; act[l] = activation after layer l (act[0] = X), keep_g: store GELU' per hidden layer
-int forward(rocblas_handle h, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float **act, float **gd)
+// forward pass into workspace buffers; act[l] = activation after layer l (act[0] = X), gd: store GELU' per hidden layer.
+// One launch per dense layer (bias and GELU are the GEMM's epilogue).
+int forward(rocblas_handle, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float **act, float **gd)
 {
     for (int l = 0; l < nd.n; ++l) {
-        const int K = nd.d[l], Nw = nd.d[l + 1];
-        int rc = gemm_fwd(h, act[l], P + nd.oW[l], act[l + 1], (int)rows, Nw, K);
+        const bool hidden = l + 1 < nd.n;
+        int rc = dense_forward(s, act[l], P + nd.oW[l], P + nd.ob[l], act[l + 1], hidden && gd ? gd[l + 1] : nullptr, (int)rows,
+                               nd.d[l + 1], nd.d[l], hidden);
         if (rc) return rc;
-        const int64_t total = rows * Nw;
-        if (l + 1 < nd.n)
-            hipLaunchKernelGGL(bias_gelu_kernel, dim3(grid1d(total)), dim3(256), 0, s, act[l + 1], gd ? gd[l + 1] : nullptr, P + nd.ob[l],
-                               Nw, total);
-        else
-            hipLaunchKernelGGL(bias_kernel, dim3(grid1d(total)), dim3(256), 0, s, act[l + 1], P + nd.ob[l], Nw, total);
     }
     return 0;
 }
 
 
+// dW[Nw][K] = dZ^T . X and db[Nw] = column sums of dZ, one launch: the reduction over the `rows` samples is split in
+// chunks of DW_CHUNK rows over blockIdx.z when scratch is available; each split writes its own partial (dW partials to
+// dw_scratch, db partials to cs_scratch) and the partials are summed in a fixed order (deterministic).
+int dense_weight_grad(hipStream_t s, const float *dZ, const float *X, float *dW, float *db, int rows, int Nw, int K, float *dw_scratch,
+                      float *cs_scratch)
+{
+    GemmArgs g{};
+    g.A = dZ; g.lda = Nw; g.B = X; g.ldb = K; g.M = Nw; g.N = K; g.K = rows; g.ldc = K;
+    const bool split = dw_scratch && cs_scratch && rows >= 4 * DW_CHUNK;
+    const int nsplit = split ? (int)erl_cdiv(rows, DW_CHUNK) : 1;
+    g.kchunk = split ? DW_CHUNK : rows;
+    g.C = split ? dw_scratch : dW;
+    g.c_split = (int64_t)Nw * K;
+    g.rowsum = split ? cs_scratch : db;
+    g.rs_split = Nw;
+    int rc = gemm_launch<OP_OC, OP_OC, EPI_PARTIAL>(s, g, nsplit, "dense_weight_grad");
+    if (rc || !split) return rc;
+    if ((rc = erl_grad_reduce_f32(dw_scratch, nsplit, (int64_t)Nw * K, dW, (void *)s))) return rc;
+    return erl_grad_reduce_f32(cs_scratch, nsplit, Nw, db, (void *)s);
+}
+
 // backward through an MLP whose forward was run by forward(): dZ = dL/d(output).  Writes weight / bias gradients into
 // G (same layout as the parameter block) when G != nullptr, and dL/d(input) into dX0 when dX0 != nullptr
 // (accumulating into it when acc_dx0).  tmpA / tmpB: two scratch buffers of rows * max-width floats; cs_scratch:
-// colsum_scratch_floats(rows, max width) floats for the bias gradients.
-int backward(rocblas_handle h, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float *const *act, float *const *gd,
+// colsum_scratch_floats(rows, max width) floats (bias-gradient partials); dw_scratch: dw_scratch_floats(rows, max W).
+// Per layer: one launch for dW + db (+ two fixed-order sums when the batch is split), one for dX with GELU' applied.
+int backward(rocblas_handle, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float *const *act, float *const *gd,
              const float *dZ, float *G, float *cs_scratch, float *dX0, bool acc_dx0, float *tmpA, float *tmpB,
              float *dw_scratch = nullptr)
 {
     int rc;
     for (int l = nd.n - 1; l >= 0; --l) {
         const int K = nd.d[l], Nw = nd.d[l + 1];
-        if (G) {
-            if ((rc = gemm_dw_split(h, s, dZ, act[l], G + nd.oW[l], (int)rows, Nw, K, dw_scratch))) return rc;
-            if ((rc = colsum(s, dZ, cs_scratch, G + nd.ob[l], (int)rows, Nw))) return rc;
-        }
+        if (G && (rc = dense_weight_grad(s, dZ, act[l], G + nd.oW[l], G + nd.ob[l], (int)rows, Nw, K, dw_scratch, cs_scratch))) return rc;
         if (l > 0) {
             float *dH = (dZ == tmpA) ? tmpB : tmpA;
-            if ((rc = gemm_dx(h, dZ, P + nd.oW[l], dH, (int)rows, Nw, K))) return rc;
-            hipLaunchKernelGGL(mul_kernel, dim3(grid1d(rows * K)), dim3(256), 0, s, dH, gd[l], rows * K);
+            if ((rc = dense_backward_input(s, dZ, P + nd.oW[l], dH, gd[l], false, (int)rows, Nw, K))) return rc;
             dZ = dH;
         } else if (dX0) {
-            if ((rc = (acc_dx0 ? gemm_dx_acc : gemm_dx)(h, dZ, P + nd.oW[0], dX0, (int)rows, Nw, K))) return rc;
+            if ((rc = dense_backward_input(s, dZ, P + nd.oW[0], dX0, nullptr, acc_dx0, (int)rows, Nw, K))) return rc;
         }
     }
     return 0;

@@ -347,7 +347,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
         if ((rc = backward(h, s, d.dec, target_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
                            nullptr, cs_scr, dEnc, e > 0, tmpA, tmpB)))
             return rc;
-    if ((rc = gemm_dx(h, dEnc, target_params, dxa, (int)B, d.enc.d[1], S + A))) return rc;      // dL/d[state | action]
+    if ((rc = dense_backward_input(s, dEnc, target_params, dxa, nullptr, false, (int)B, d.enc.d[1], S + A))) return rc;   // dL/d[state | action]
     // action columns of dxa -> contiguous (B, A)
     (void)hipMemcpy2DAsync(dAct, (size_t)A * 4, dxa + S, (size_t)(S + A) * 4, (size_t)A * 4, (size_t)B, hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dAct, alpha_log, A, B, dHead);
