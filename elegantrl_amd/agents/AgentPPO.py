@@ -440,7 +440,7 @@ class AgentPPO(AgentBase):
 
 class AgentDiscretePPO(AgentPPO):
     """PPO with a categorical policy (elegantrl/agents/AgentPPO.py:305-320, ActorDiscretePPO :393-422) on the layered
-    path: logits from rocBLAS GEMMs + HIP epilogues, inverse-CDF sampling / log-prob and the clipped-scale objective
+    path: logits from the layered path's MFMA GEMMs, inverse-CDF sampling / log-prob and the clipped-scale objective
     with its state-dependent entropy in hand-written kernels (erl_mlpn_rollout_step_discrete_f32,
     erl_mlpn_ppo_step_discrete_f32).  Rollout dtypes as the reference: actions (H, N) int32, env receives int64."""
     _discrete = True

@@ -4,34 +4,14 @@
 // default Config.net_dims = [128, 128] and its Pendulum demos.  Reference demos also use (256, 128), (256, 128, 64),
 // (256, 128, 128) (examples/demo_A2C_PPO.py:117,171,224): those shapes take this layered path, so that
 // AgentPPO.explore_env / update_net stay drop-in for every build_mlp() the reference can construct
-// (elegantrl/agents/AgentBase.py:345-360).  Dense layers are plain library GEMMs (rocBLAS sgemm, fp32, atomics
-// off => deterministic); everything around them is hand-written HIP: gather + normalise, bias + exact-erf GELU (+ its
-// derivative), the PPO objective with its analytic dL/dY, Gaussian sampling / log-prob for the rollout.
+// (elegantrl/agents/AgentBase.py:345-360).  Dense layers are the fp32 MFMA GEMMs of gemm_tiles.h (bias, exact-erf
+// GELU and its derivative, the backward gate and the bias gradient are their epilogues; fixed-order reductions =>
+// deterministic); around them: gather + normalise, the PPO objective with its analytic dL/dY, sampling / log-prob.
 // Activations live in a caller-provided workspace (row-major [rows][width]).
 //
 // Parameter block (one flat fp32 buffer per network, same convention as the fused kernels):
 //   W1[d1][d0] b1[d1] ... WL[dL][dL-1] bL[dL] Wout[out][dL] bout[out] (+ action_std_log[out] for the actor)
 #include "mlpn_common.h"
-
-static rocblas_handle g_handle = nullptr;
-
-int erl_blas(hipStream_t stream, rocblas_handle *h)
-{
-    if (!g_handle) {
-        if (rocblas_create_handle(&g_handle) != rocblas_status_success) {
-            erl_set_error("rocblas_create_handle failed");
-            return -2;
-        }
-        rocblas_set_atomics_mode(g_handle, rocblas_atomics_not_allowed);   // deterministic reductions
-        rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
-    }
-    if (rocblas_set_stream(g_handle, stream) != rocblas_status_success) {
-        erl_set_error("rocblas_set_stream failed");
-        return -2;
-    }
-    *h = g_handle;
-    return 0;
-}
 
 extern "C" int64_t erl_mlpn_param_count(const int *dims, int n_dims, int with_std_log)
 {
@@ -70,9 +50,7 @@ extern "C" int erl_mlpn_value_forward_f32(const float *params, const float *stat
     if (rows == 0) return ERL_OK;
     ERL_REQUIRE(rows > 0 && rows < (1LL << 31), "erl_mlpn_value_forward_f32: bad rows");
     hipStream_t s = (hipStream_t)stream;
-    rocblas_handle h;
-    int rc = blas(s, &h);
-    if (rc) return rc;
+    int rc;
     Ws ws{(char *)workspace, 0, workspace_bytes};
     float *act[MAXL + 2];
     for (int l = 0; l < nd.n; ++l) act[l] = ws.take(rows * nd.d[l]);
@@ -80,7 +58,7 @@ extern "C" int erl_mlpn_value_forward_f32(const float *params, const float *stat
     ERL_REQUIRE(act[nd.n - 1] != nullptr, "erl_mlpn_value_forward_f32: workspace too small");
     hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(rows * nd.d[0])), dim3(256), 0, s, states, state_avg, state_std,
                        (const int64_t *)nullptr, (int64_t)1, (int64_t)1, nd.d[0], rows, act[0], (float *)nullptr);
-    if ((rc = forward(h, s, nd, params, rows, act, nullptr))) return rc;
+    if ((rc = forward(s, nd, params, rows, act, nullptr))) return rc;
     ERL_LAUNCH_CHECK("erl_mlpn_value_forward_f32");
 }
 
@@ -98,16 +76,14 @@ int rollout_impl(const char *what, bool discrete, const float *actor_params, con
     ERL_REQUIRE(!discrete || nd.d[nd.n] <= kMaxDiscrete, "%s: action_dim > %d", what, kMaxDiscrete);
     ERL_REQUIRE(N >= 1 && N < (1LL << 31), "%s: bad N", what);
     hipStream_t s = (hipStream_t)stream;
-    rocblas_handle h;
-    int rc = blas(s, &h);
-    if (rc) return rc;
+    int rc;
     Ws ws{(char *)workspace, 0, workspace_bytes};
     float *act[MAXL + 2];
     for (int l = 0; l <= nd.n; ++l) act[l] = ws.take(N * nd.d[l]);
     ERL_REQUIRE(act[nd.n] != nullptr, "%s: workspace too small", what);
     hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(N * nd.d[0])), dim3(256), 0, s, state, state_avg, state_std,
                        (const int64_t *)nullptr, (int64_t)1, (int64_t)1, nd.d[0], N, act[0], out_state_row);
-    if ((rc = forward(h, s, nd, actor_params, N, act, nullptr))) return rc;
+    if ((rc = forward(s, nd, actor_params, N, act, nullptr))) return rc;
     if (discrete)
         hipLaunchKernelGGL(sample_categorical_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, act[nd.n], nd.d[nd.n], N, noise,
                            seed, counter, (int32_t *)out_action_row, out_logprob_row, (int64_t *)out_action_env);
@@ -163,9 +139,7 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
     ERL_REQUIRE(make_dims(cdims, n_dims, false, &nc), "%s: bad dims", what);
     ERL_REQUIRE(H >= 1 && N >= 1 && B >= 1 && B < (1LL << 31), "%s: bad shape", what);
     hipStream_t s = (hipStream_t)stream;
-    rocblas_handle h;
-    int rc = blas(s, &h);
-    if (rc) return rc;
+    int rc;
     const int A = na.d[na.n];
     float *logs = flat_grad + na.count + nc.count;
 
@@ -194,7 +168,7 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
 
         hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(B * nd.d[0])), dim3(256), 0, s, states, net == 0 ? act_avg : cri_avg,
                            net == 0 ? act_std : cri_std, ids, H, N, nd.d[0], B, act[0], (float *)nullptr);
-        if ((rc = forward(h, s, nd, P, B, act, gd))) return rc;
+        if ((rc = forward(s, nd, P, B, act, gd))) return rc;
         float *Y = act[nd.n];
         if (net == 0 && discrete)
             hipLaunchKernelGGL(objective_discrete_kernel, dim3(nparts), dim3(256), 0, s, Y, ids, H, N, A, B, actions_i, unmasks, logprobs,
@@ -211,7 +185,7 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
         if (net == 0 && !discrete && (rc = colsum(s, dsl, cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
 
         // backward: dZ of the output layer is Y (dL/dY); walk the layers down
-        if ((rc = backward(h, s, nd, P, B, act, gd, Y, G, cs_scr, nullptr, false, dA, dB, dw_scr))) return rc;
+        if ((rc = backward(s, nd, P, B, act, gd, Y, G, cs_scr, nullptr, false, dA, dB, dw_scr))) return rc;
     }
     return erl_hip_status(hipGetLastError(), what);
 }

@@ -1,6 +1,6 @@
-// Shared pieces of the layered (rocBLAS GEMM + HIP epilogue) paths: erl_mlpn_* (mlpn.hip) and erl_sac_* (sac.hip).
+// Shared pieces of the layered paths (own fp32 MFMA GEMMs with fused epilogues, gemm_tiles.h): erl_mlpn_* (mlpn.hip) and
+// erl_sac_* (sac.hip).
 #pragma once
-#include <rocblas/rocblas.h>
 
 #include "gemm_tiles.h"
 
@@ -35,74 +35,16 @@ bool make_dims(const int *dims, int n_dims, bool with_std, NetDims *nd)
     return true;
 }
 
-}  // namespace
-int erl_blas(hipStream_t stream, rocblas_handle *h);   // mlpn.hip: the library's one rocBLAS handle, bound to `stream`
-namespace {
-inline int blas(hipStream_t stream, rocblas_handle *h) { return erl_blas(stream, h); }
 
-#define RB(call)                                                           \
-    do {                                                                   \
-        rocblas_status st_ = (call);                                       \
-        if (st_ != rocblas_status_success) {                               \
-            erl_set_error("%s -> rocblas status %d", #call, (int)st_);     \
-            return -2;                                                     \
-        }                                                                  \
-    } while (0)
-
-// row-major Z[M][N] = X[M][K] . W[N][K]^T
-int gemm_fwd(rocblas_handle h, const float *X, const float *W, float *Z, int M, int N, int K)
-{
-    const float one = 1.f, zero = 0.f;
-    RB(rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, W, K, X, K, &zero, Z, N));
-    return 0;
-}
-// row-major dX[M][K] = dZ[M][N] . W[N][K]
-int gemm_dx(rocblas_handle h, const float *dZ, const float *W, float *dX, int M, int N, int K)
-{
-    const float one = 1.f, zero = 0.f;
-    RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, K, M, N, &one, W, K, dZ, N, &zero, dX, K));
-    return 0;
-}
-// row-major dX[M][K] += dZ[M][N] . W[N][K]   (accumulating variant: ensemble decoders summing into one encoder gradient)
-int gemm_dx_acc(rocblas_handle h, const float *dZ, const float *W, float *dX, int M, int N, int K)
-{
-    const float one = 1.f;
-    RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, K, M, N, &one, W, K, dZ, N, &one, dX, K));
-    return 0;
-}
-// row-major dW[N][K] = dZ[M][N]^T . X[M][K]
-int gemm_dw(rocblas_handle h, const float *dZ, const float *X, float *dW, int M, int N, int K)
-{
-    const float one = 1.f, zero = 0.f;
-    RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, N, M, &one, X, K, dZ, N, &zero, dW, K));
-    return 0;
-}
 // sum `n_slabs` partial results of `stride` floats each (fixed order -> deterministic); defined in mlp.hip
 extern "C" int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, void *stream);
 
-// dW for tall batches: rocBLAS will not split the M (sample) reduction across workgroups with atomics off, so one
-// 128 x 128 output tile would walk all 16 384 rows on a handful of CUs.  Instead: a strided-batched GEMM over chunks of
-// DW_CHUNK rows writes one partial dW per chunk into `scratch`, and the partials are summed in a fixed order.
+// the weight-gradient contraction is split over chunks of DW_CHUNK batch rows when the batch is at least 4 chunks tall
 constexpr int DW_CHUNK = 256;
 inline int64_t dw_scratch_floats(int64_t M, int64_t NK) { return M >= 4 * DW_CHUNK ? ((M + DW_CHUNK - 1) / DW_CHUNK) * NK : 0; }
 
-int gemm_dw_split(rocblas_handle h, hipStream_t s, const float *dZ, const float *X, float *dW, int M, int N, int K, float *scratch)
-{
-    if (!scratch || M < 4 * DW_CHUNK) return gemm_dw(h, dZ, X, dW, M, N, K);
-    const float one = 1.f, zero = 0.f;
-    const int full = M / DW_CHUNK, rem = M - full * DW_CHUNK;
-    const int64_t NK = (int64_t)N * K;
-    RB(rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, K, N, DW_CHUNK, &one, X, K,
-                                     (rocblas_stride)DW_CHUNK * K, dZ, N, (rocblas_stride)DW_CHUNK * N, &zero, scratch, K,
-                                     (rocblas_stride)NK, full));
-    if (rem)
-        RB(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, N, rem, &one, X + (size_t)full * DW_CHUNK * K, K,
-                         dZ + (size_t)full * DW_CHUNK * N, N, &zero, scratch + (size_t)full * NK, K));
-    return erl_grad_reduce_f32(scratch, full + (rem ? 1 : 0), NK, dW, (void *)s);
-}
-
 // db[N] = column sums of dZ[M][N] (row-major): each block sums a slice of rows into its own partial (threads along the
-// columns: coalesced), a fixed-order fold finishes.  (rocBLAS gemv on a 128 x 16384 matrix took 127 us; this is ~5.)
+// columns: coalesced), a fixed-order fold finishes.  (used for dL/dstd_log; the layers' bias gradients come out of the weight-gradient GEMM.)
 constexpr int CS_ROWS = 128;   // rows per block
 constexpr int CS_MAX_PART = 1024;
 
@@ -165,29 +107,6 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(const float *__restric
         if (raw_copy) raw_copy[e] = raw;
         X[e] = (raw - avg[c]) / (sd[c] + 1e-4f);
     }
-}
-
-// in place: Z <- GELU(Z + b); optionally G <- GELU'(Z + b)
-__global__ __launch_bounds__(256) void bias_gelu_kernel(float *__restrict__ Z, float *__restrict__ G, const float *__restrict__ bias,
-                                                        int width, int64_t total)
-{
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % width);
-        float y, gd;
-        gelu_and_grad_fast(Z[e] + bias[c], y, gd);
-        Z[e] = y;
-        if (G) G[e] = gd;
-    }
-}
-
-__global__ __launch_bounds__(256) void bias_kernel(float *__restrict__ Z, const float *__restrict__ bias, int width, int64_t total)
-{
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) Z[e] += bias[e % width];
-}
-
-__global__ __launch_bounds__(256) void mul_kernel(float *__restrict__ dH, const float *__restrict__ G, int64_t total)
-{
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) dH[e] *= G[e];
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ p, float v, int64_t total)
@@ -413,7 +332,7 @@ int64_t ws_floats_forward(const NetDims &nd, int64_t rows)
 
 // forward pass into workspace buffers; act[l] = activation after layer l (act[0] = X), gd: store GELU' per hidden layer.
 // One launch per dense layer (bias and GELU are the GEMM's epilogue).
-int forward(rocblas_handle, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float **act, float **gd)
+int forward(hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float **act, float **gd)
 {
     for (int l = 0; l < nd.n; ++l) {
         const bool hidden = l + 1 < nd.n;
@@ -451,7 +370,7 @@ int dense_weight_grad(hipStream_t s, const float *dZ, const float *X, float *dW,
 // (accumulating into it when acc_dx0).  tmpA / tmpB: two scratch buffers of rows * max-width floats; cs_scratch:
 // colsum_scratch_floats(rows, max width) floats (bias-gradient partials); dw_scratch: dw_scratch_floats(rows, max W).
 // Per layer: one launch for dW + db (+ two fixed-order sums when the batch is split), one for dX with GELU' applied.
-int backward(rocblas_handle, hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float *const *act, float *const *gd,
+int backward(hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float *const *act, float *const *gd,
              const float *dZ, float *G, float *cs_scratch, float *dX0, bool acc_dx0, float *tmpA, float *tmpB,
              float *dw_scratch = nullptr)
 {

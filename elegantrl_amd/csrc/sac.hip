@@ -7,7 +7,7 @@
 // trained against the TARGET ensemble's mean (:83), alpha is read after its own Adam step and only then clamped (:79-81).
 //
 // Batches are small (256..1024 rows): the step is launch-latency bound, so the win over ~300 ATen dispatches is that
-// ONE C call enqueues everything.  Dense layers are rocBLAS sgemm (fp32, atomics off), the rest is hand-written HIP.
+// ONE C call enqueues everything.  Dense layers are the layered path's own fp32 MFMA GEMMs (gemm_tiles.h).
 //
 // Parameter blocks (flat fp32):
 //   actor   build_mlp([S, h0..hL-1]) with GELU after every layer, then Linear(hL-1, 2A):  W b ... Whead bhead
@@ -210,13 +210,13 @@ bool carve_critic(Ws &ws, const SacDims &d, int64_t B, CriticWs *c)
     return c->act[d.E - 1][d.dec.n - 1] != nullptr && c->q != nullptr;
 }
 
-int critic_forward(rocblas_handle h, hipStream_t s, const SacDims &d, const float *P, int64_t B, float *xa, CriticWs &c, bool keep)
+int critic_forward(hipStream_t s, const SacDims &d, const float *P, int64_t B, float *xa, CriticWs &c, bool keep)
 {
     float *ea[2] = {xa, c.enc};
-    int rc = forward(h, s, d.enc, P, B, ea, nullptr);      // one raw linear layer
+    int rc = forward(s, d.enc, P, B, ea, nullptr);      // one raw linear layer
     if (rc) return rc;
     for (int e = 0; e < d.E; ++e)
-        if ((rc = forward(h, s, d.dec, P + d.enc.count + (int64_t)e * d.dec.count, B, c.act[e], keep ? c.gd[e] : nullptr))) return rc;
+        if ((rc = forward(s, d.dec, P + d.enc.count + (int64_t)e * d.dec.count, B, c.act[e], keep ? c.gd[e] : nullptr))) return rc;
     return 0;
 }
 
@@ -265,9 +265,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     ERL_REQUIRE(B >= 1 && B < (1LL << 24) && step >= 1, "erl_sac_update_f32: bad argument");
     ERL_REQUIRE(workspace_bytes >= erl_sac_workspace_bytes(S, A, hidden, n_hidden, E, B), "erl_sac_update_f32: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    rocblas_handle h;
-    int rc = blas(s, &h);
-    if (rc) return rc;
+    int rc;
 
     Ws ws{(char *)workspace, 0, workspace_bytes};
     int maxd = S + A;
@@ -294,27 +292,27 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
 
     // ---- (1) targets: next action / log-prob from the actor, min over the TARGET ensemble          (:50-55)
     (void)hipMemcpyAsync(aact[0], next_state, (size_t)B * S * 4, hipMemcpyDeviceToDevice, s);
-    if ((rc = forward(h, s, d.actor, actor_params, B, aact, nullptr))) return rc;
+    if ((rc = forward(s, d.actor, actor_params, B, aact, nullptr))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_next, seed, 2 * counter, A, B, act_t, lp_next,
                        (float *)nullptr);
     hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, next_state, act_t, S, A, B, xa);
-    if ((rc = critic_forward(h, s, d, target_params, B, xa, cw, false))) return rc;
+    if ((rc = critic_forward(s, d, target_params, B, xa, cw, false))) return rc;
     hipLaunchKernelGGL(q_label_kernel, rows_grid, blk, 0, s, cw.q, E, B, reward, undone, lp_next, alpha_log, gamma, label);
 
     // ---- (2) critic objective, backward, clip + Adam, soft target update                          (:57-70)
     hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, state, action, S, A, B, xa);
-    if ((rc = critic_forward(h, s, d, critic_params, B, xa, cw, true))) return rc;
+    if ((rc = critic_forward(s, d, critic_params, B, xa, cw, true))) return rc;
     hipLaunchKernelGGL(critic_loss_kernel, rows_grid, blk, 0, s, cw.q, label, unmask, E, B, dq, part);
     hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, part, (int64_t)nparts, 1.0f / (float)B, 0.f, objs_out);
     for (int e = 0; e < E; ++e) {
         float *Gdec = g_critic + d.enc.count + (int64_t)e * d.dec.count;
-        if ((rc = backward(h, s, d.dec, critic_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
+        if ((rc = backward(s, d.dec, critic_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
                            Gdec, cs_scr, dEnc, e > 0, tmpA, tmpB)))
             return rc;
     }
     {   // encoder: one raw linear layer, input xa
         float *ea[2] = {xa, cw.enc};
-        if ((rc = backward(h, s, d.enc, critic_params, B, ea, nullptr, dEnc, g_critic, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
+        if ((rc = backward(s, d.enc, critic_params, B, ea, nullptr, dEnc, g_critic, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
     }
     {
         const int64_t off = 0, len = d.Pc;
@@ -326,7 +324,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
 
     // ---- (3) policy-gradient sample, temperature step                                              (:72-81)
     (void)hipMemcpyAsync(aact[0], state, (size_t)B * S * 4, hipMemcpyDeviceToDevice, s);
-    if ((rc = forward(h, s, d.actor, actor_params, B, aact, agd))) return rc;
+    if ((rc = forward(s, d.actor, actor_params, B, aact, agd))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_cur, seed, 2 * counter + 1, A, B, act_t, lp_cur,
                        eps_used);
     // obj_alpha = mean(alpha_log * (target_entropy - logprob)):  d/dalpha_log = target_entropy - mean(logprob)
@@ -340,11 +338,11 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
 
     // ---- (4) actor objective against the TARGET ensemble's mean, backward into the action, head, actor   (:82-85)
     hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, state, act_t, S, A, B, xa);
-    if ((rc = critic_forward(h, s, d, target_params, B, xa, cw, true))) return rc;
+    if ((rc = critic_forward(s, d, target_params, B, xa, cw, true))) return rc;
     hipLaunchKernelGGL(actor_obj_kernel, dim3(1), blk, 0, s, cw.q, E, B, lp_cur, alpha_log, objs_out + 1);
     hipLaunchKernelGGL(fillk_kernel, dim3(grid1d((int64_t)E * B)), blk, 0, s, dq, -1.0f / ((float)E * (float)B), (int64_t)E * B);
     for (int e = 0; e < E; ++e)
-        if ((rc = backward(h, s, d.dec, target_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
+        if ((rc = backward(s, d.dec, target_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
                            nullptr, cs_scr, dEnc, e > 0, tmpA, tmpB)))
             return rc;
     if ((rc = dense_backward_input(s, dEnc, target_params, dxa, nullptr, false, (int)B, d.enc.d[1], S + A))) return rc;   // dL/d[state | action]
@@ -352,7 +350,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     (void)hipMemcpy2DAsync(dAct, (size_t)A * 4, dxa + S, (size_t)(S + A) * 4, (size_t)A * 4, (size_t)B, hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dAct, alpha_log, A, B, dHead);
     hipLaunchKernelGGL(clamp_alpha_kernel, dim3(1), dim3(64), 0, s, alpha_log);                  // after alpha was read (:80-81)
-    if ((rc = backward(h, s, d.actor, actor_params, B, aact, agd, dHead, g_actor, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
+    if ((rc = backward(s, d.actor, actor_params, B, aact, agd, dHead, g_actor, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
     {
         const int64_t off = 0, len = d.Pa;
         if ((rc = erl_clip_adam_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, nullptr, step, lr, beta1, beta2, eps_adam,
@@ -372,16 +370,14 @@ extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int 
     ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, 1, &d), "erl_sac_explore_action_f32: unsupported dims");
     ERL_REQUIRE(N >= 1 && N < (1LL << 31), "erl_sac_explore_action_f32: bad N");
     hipStream_t s = (hipStream_t)stream;
-    rocblas_handle h;
-    int rc = blas(s, &h);
-    if (rc) return rc;
+    int rc;
     Ws ws{(char *)workspace, 0, workspace_bytes};
     float *aact[MAXL + 2];
     aact[0] = const_cast<float *>(state);
     for (int l = 1; l <= d.actor.n; ++l) aact[l] = ws.take(N * d.actor.d[l]);
     float *lp = ws.take(N);
     ERL_REQUIRE(lp != nullptr, "erl_sac_explore_action_f32: workspace too small");
-    if ((rc = forward(h, s, d.actor, actor_params, N, aact, nullptr))) return rc;
+    if ((rc = forward(s, d.actor, actor_params, N, aact, nullptr))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, aact[d.actor.n], noise, seed, counter, A, N,
                        action_out, lp, (float *)nullptr);
     ERL_LAUNCH_CHECK("erl_sac_explore_action_f32");

@@ -10,7 +10,7 @@
  * Conventions
  *  - plain C types only: raw device pointers, sizes, scalars, an opaque hipStream_t passed as void*.
  *  - every tensor is caller-allocated, caller-owned device memory (torch tensors in practice).  The library
- *    itself owns only: a last-error string, a rocBLAS handle (generic-shape path), and one 8 MiB per-device
+ *    itself owns only: a last-error string, an RCCL communicator behind erl_comm_* handles, and one 8 MiB per-device
  *    look-back table for the single-pass GAE scan (allocated on first use; see ERL_GAE_ALGO_LOOKBACK).
  *  - all work is enqueued on `stream`; nothing synchronises the host.
  *  - layout at the seam is the reference's: time-major (H, N, .) row-major contiguous, fp32 values,
@@ -226,7 +226,7 @@ ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp
  * Generic-shape path: build_mlp([S, d1, ..., dL, out]) with ANY number (<= ERL_MAX_LAYERS) and width of hidden layers
  * (elegantrl/agents/AgentBase.py:345-360; the reference's demos use (256, 128), (256, 128, 64), (256, 128, 128)).
  * dims = [S, d1, ..., dL, out], n_dims = L + 2.  Parameter block: W1 b1 ... WL bL Wout bout (+ action_std_log).
- * Dense layers are rocBLAS sgemm calls (fp32, atomics off), the rest is hand-written HIP; activations live in
+ * Dense layers are the library's own fp32 MFMA GEMMs with fused bias / GELU / gate epilogues; activations live in
  * `workspace` (erl_mlpn_workspace_bytes(dims, n_dims, rows, training)).  Same arithmetic as K1 / K2 / K6:
  *   erl_mlpn_value_forward_f32  = erl_value_forward_f32,  erl_mlpn_rollout_step_f32 = erl_rollout_step_f32,
  *   erl_mlpn_ppo_step_f32       = erl_ppo_step_f32 + erl_grad_reduce_f32 (writes the summed gradient

@@ -1,4 +1,4 @@
-"""Generic-shape MLP path (erl_mlpn_*: any depth / width; rocBLAS GEMMs + hand-written HIP around them) against the
+"""Generic-shape MLP path (erl_mlpn_*: any depth / width; own MFMA GEMMs with fused epilogues) against the
 depth-generic numpy oracle, and AgentPPO end to end on the reference's larger demo shapes (256, 128) / (256, 128, 64)
 (examples/demo_A2C_PPO.py:117,171).  Same bars as the fused kernels: rtol 1e-4 vs the fp32 oracle."""
 import numpy as np

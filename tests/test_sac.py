@@ -214,7 +214,7 @@ def test_sac_update_matches_torch_restatement_on_other_shapes(S, A, hidden, E, B
                        noises=(e_next.to(dev), e_cur.to(dev)))
         np.testing.assert_allclose(objs.cpu().numpy(), ref, rtol=3e-4, atol=3e-6)
         # Adam turns a gradient g into a step lr * g / (|g| + 1e-8): for the handful of weights whose gradient is at the
-        # fp32 noise floor (|g| ~ 1e-9, summation order of rocBLAS vs torch) the step can differ by up to lr per update.
+        # fp32 noise floor (|g| ~ 1e-9, summation order of the MFMA GEMMs vs torch) the step can differ by up to lr per update.
         # Bar: >= 99.5 % of every block within 5e-5, no element further than the accumulated Adam step bound.
         for got, module, slices in ((pa, st.act, spec.actor_slices()), (pc, st.cri, spec.critic_slices()),
                                     (pt, st.cri_target, spec.critic_slices())):

@@ -73,7 +73,7 @@ def main():
     items = [th.randn((add, 1, S3), device=dev), th.randn((add, 1, A3), device=dev), th.randn((add, 1), device=dev),
              th.rand((add, 1), device=dev) > 0.5, th.rand((add, 1), device=dev) > 0.5]
     out["replay_write_4096rows"] = timeit(lambda: ops.replay_write(rs, ra, rr, ru, rm, items, M - 1000))
-    # generic-shape path (rocBLAS GEMMs + HIP) on the config-4 buffers
+    # generic-shape path (own MFMA GEMMs) on the config-4 buffers
     for tag, hid in (("128x128", [128, 128]), ("256x128", [256, 128]), ("256x128x64", [256, 128, 64])):
         spn = ops.MlpSpecN([S, *hid, A], True)
         pcn = ops.MlpSpecN([S, *hid, 1], False).count
