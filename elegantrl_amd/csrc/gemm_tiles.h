@@ -41,33 +41,52 @@ struct GemmArgs {
     int64_t rs_split;         // PARTIAL: floats between consecutive partial row-sum vectors
 };
 
-template <int OP>
+// A thread's four elements of a 64 x 16 operand tile.  VEC (16-byte aligned base, ld % 4 == 0 and the contiguous extent a
+// multiple of 4): one 16-byte load along the contiguous index; otherwise four clamped scalar loads.
+template <int OP, bool VEC>
 __device__ __forceinline__ void tile_load(float (&r)[4], const float *__restrict__ P, int ld, int i0, int imax, int k0, int kmax, int tid)
 {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = tid + 256 * u;
-        const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
+    if (VEC) {
+        const int i = OP == OP_RC ? tid >> 2 : (tid & 15) * 4, k = OP == OP_RC ? (tid & 3) * 4 : tid >> 4;
         const int gi = i0 + i, gk = k0 + k;
-        const bool ok = gi < imax && gk < kmax;
+        const bool ok = gi < imax && gk < kmax;      // the extent along the vector is a multiple of 4: all four or none
         const size_t off = !ok ? 0 : (OP == OP_RC ? (size_t)gi * ld + gk : (size_t)gk * ld + gi);
-        const float v = P[off];
-        r[u] = ok ? v : 0.f;
+        const float4 v = *reinterpret_cast<const float4 *>(P + off);
+        r[0] = ok ? v.x : 0.f; r[1] = ok ? v.y : 0.f; r[2] = ok ? v.z : 0.f; r[3] = ok ? v.w : 0.f;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
+            const int gi = i0 + i, gk = k0 + k;
+            const bool ok = gi < imax && gk < kmax;
+            const size_t off = !ok ? 0 : (OP == OP_RC ? (size_t)gi * ld + gk : (size_t)gk * ld + gi);
+            const float v = P[off];
+            r[u] = ok ? v : 0.f;
+        }
     }
 }
 
-template <int OP>
+template <int OP, bool VEC>
 __device__ __forceinline__ void tile_store(const float (&r)[4], float *T, int tid)
 {
+    if (VEC && OP == OP_OC) {
+        *reinterpret_cast<float4 *>(T + (tid >> 4) * GLD + (tid & 15) * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    } else if (VEC) {
+        const int i = tid >> 2, k = (tid & 3) * 4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = tid + 256 * u;
-        const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
-        T[k * GLD + i] = r[u];
+        for (int c = 0; c < 4; ++c) T[(k + c) * GLD + i] = r[c];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
+            T[k * GLD + i] = r[u];
+        }
     }
 }
 
-template <int AOP, int BOP, int EPI>
+template <int AOP, int BOP, int EPI, bool VA, bool VB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
 {
     __shared__ float As[GK * GLD], Bs[GK * GLD];
@@ -85,8 +104,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
     f32x16 acc = {0};
 #pragma unroll
     for (int d = 0; d < GD; ++d) {
-        tile_load<AOP>(ra[d], g.A, g.lda, i0, g.M, kb + d * GK, ke, tid);
-        tile_load<BOP>(rb[d], g.B, g.ldb, j0, g.N, kb + d * GK, ke, tid);
+        tile_load<AOP, VA>(ra[d], g.A, g.lda, i0, g.M, kb + d * GK, ke, tid);
+        tile_load<BOP, VB>(rb[d], g.B, g.ldb, j0, g.N, kb + d * GK, ke, tid);
     }
     for (int base = kb; base < ke; base += GD * GK) {
 #pragma unroll
@@ -94,12 +113,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
             const int k0 = base + d * GK;
             if (k0 < ke) {                                     // uniform
                 __syncthreads();                               // the previous chunk's operand reads are done
-                tile_store<AOP>(ra[d], As, tid);
-                tile_store<BOP>(rb[d], Bs, tid);
+                tile_store<AOP, VA>(ra[d], As, tid);
+                tile_store<BOP, VB>(rb[d], Bs, tid);
                 __syncthreads();
                 if (k0 + GD * GK < ke) {                       // refill this slot with the chunk GD ahead
-                    tile_load<AOP>(ra[d], g.A, g.lda, i0, g.M, k0 + GD * GK, ke, tid);
-                    tile_load<BOP>(rb[d], g.B, g.ldb, j0, g.N, k0 + GD * GK, ke, tid);
+                    tile_load<AOP, VA>(ra[d], g.A, g.lda, i0, g.M, k0 + GD * GK, ke, tid);
+                    tile_load<BOP, VB>(rb[d], g.B, g.ldb, j0, g.N, k0 + GD * GK, ke, tid);
                 }
                 const float *a = As + hi * GLD + 32 * wm + l31, *b = Bs + hi * GLD + 32 * wn + l31;
 #pragma unroll
@@ -244,7 +263,14 @@ int gemm_launch(hipStream_t s, const GemmArgs &g, int splits, const char *what)
         hipLaunchKernelGGL((gemm_small_kernel<AOP, BOP, EPI>), grid, dim3(256), 0, s, g);
     } else {
         const dim3 grid((unsigned)erl_cdiv(g.N, GT), (unsigned)erl_cdiv(g.M, GT), (unsigned)splits);
-        hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI>), grid, dim3(256), 0, s, g);
+        auto vec_ok = [](int op, const float *P, int ld, int outs, int red) {
+            return (reinterpret_cast<uintptr_t>(P) & 15) == 0 && ld % 4 == 0 && (op == OP_RC ? red : outs) % 4 == 0;
+        };
+        const bool va = vec_ok(AOP, g.A, g.lda, g.M, g.K), vb = vec_ok(BOP, g.B, g.ldb, g.N, g.K);
+        if (va && vb) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, true, true>), grid, dim3(256), 0, s, g);
+        else if (va) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, true, false>), grid, dim3(256), 0, s, g);
+        else if (vb) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, false, false>), grid, dim3(256), 0, s, g);
     }
     return erl_hip_status(hipGetLastError(), what);
 }
