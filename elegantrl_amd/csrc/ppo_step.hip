@@ -18,10 +18,13 @@
 // transposed direction for the backward pass), so the compute phases never wait on L2 / HBM latency.
 //
 // Weight gradients need the sample dimension as the MFMA K dimension, i.e. the transpose of what the lanes hold:
-// the 8 waves stage their tiles feature-major in LDS (T[feature][sample], LD = 129: conflict-free ds_read_b32 along
-// features, 2-way (free) ds_write_b32) and split the dW output tiles (v_mfma_f32_32x32x2_f32, K = 128 samples).
-// Seven workgroup barriers (LDS-only, no vector-memory drain) in total; all control flow in the hot instantiations is compile-time (tile counts are
-// template parameters, out-of-range loads are clamped + selected instead of branched).
+// the 8 waves stage their tiles feature-major in LDS (T[feature][sample], row stride PLD = 132) and split the dW output
+// tiles (v_mfma_f32_32x32x2_f32, K = 128 samples; the sum over samples is order-free, so each lane half reads four
+// consecutive samples with one ds_read_b128 per operand and feeds four MFMAs).  GELU'(z1), needed again only by the last
+// step of the chain, is parked in the workgroup's own still-dead gradient slab instead of occupying 32 VGPRs across the
+// whole forward pass.  Seven workgroup barriers (LDS-only, no vector-memory drain) in total; all control flow in the hot
+// instantiation is compile-time (tile counts are template parameters, out-of-range loads are clamped + selected instead
+// of branched).
 #include "mlp_chain.h"
 
 namespace {
