@@ -132,3 +132,34 @@ def test_two_rank_gloo_data_parallel_equals_single_rank(tmp_path):
         _apply(actor, critic, _flat_grads(buf, ids, actor, critic, inv_batch=1.0 / B), st_a, st_c)
     single = np.concatenate([p.reshape(-1) for p in actor.trainable() + critic.trainable()])
     np.testing.assert_allclose(r0, single, rtol=1e-10, atol=1e-12)
+
+
+def test_gradient_comm_is_none_without_a_gpu_and_shutdown_is_idempotent(monkeypatch):
+    """no HIP device -> the library's RCCL communicator is never attempted (the exchange stays in torch.distributed), and
+    parallel.shutdown() is a no-op outside a process group, callable twice."""
+    from elegantrl_amd import parallel
+    monkeypatch.setattr(parallel, "_grad_comm", None)
+    monkeypatch.setattr(parallel, "_grad_comm_tried", False)
+    if not th.cuda.is_available():
+        assert parallel.gradient_comm() is None
+        monkeypatch.setenv("ERL_FORCE_DP", "1")
+        monkeypatch.setattr(parallel, "_grad_comm_tried", False)
+        assert parallel.gradient_comm() is None
+    parallel.shutdown()
+    parallel.shutdown()
+    assert parallel._grad_comm is None and not parallel._grad_comm_tried
+
+
+def test_unique_id_comes_from_rccl_without_a_gpu():
+    """erl_comm_unique_id only needs librccl (bound with dlopen): 128 opaque bytes, different on every call."""
+    import ctypes
+    from elegantrl_amd import _hip
+    L = _hip.lib()
+    a, b = (ctypes.c_uint8 * _hip.COMM_ID_BYTES)(), (ctypes.c_uint8 * _hip.COMM_ID_BYTES)()
+    rc = L.erl_comm_unique_id(a)
+    if rc != 0:
+        pytest.skip("librccl not loadable here: " + L.erl_last_error_string().decode())
+    assert L.erl_comm_unique_id(b) == 0
+    assert bytes(a) != bytes(b) and any(bytes(a))
+    assert L.erl_comm_world_size(None) == 1
+    assert L.erl_comm_allreduce_sum_f32(None, None, 4, None) != 0 and b"bad argument" in L.erl_last_error_string()
