@@ -89,7 +89,7 @@ def discrete_case(rng, H, N, S, A, B):
 
 
 @pytest.mark.parametrize("S,hidden,A", SHAPES)
-@pytest.mark.parametrize("B", [64, 1000])
+@pytest.mark.parametrize("B", [64, 1000, 1300])
 def test_ppo_step_discrete_gradients(ops, S, hidden, A, B):
     rng = np.random.default_rng(S + B + A)
     H, N = 9, 50

@@ -83,7 +83,7 @@ def test_mlpn_rollout_step(ops, dev, S, hidden, A):
 
 
 @pytest.mark.parametrize("S,hidden,A", NET_SHAPES)
-@pytest.mark.parametrize("B", [64, 1000])
+@pytest.mark.parametrize("B", [64, 1000, 2321])      # 2321 = 9 chunks of 256 rows + 17: the split weight-gradient reduction
 def test_mlpn_ppo_step_gradients(ops, dev, S, hidden, A, B):
     rng = np.random.default_rng(S + B)
     H, N = 9, 50
