@@ -12,7 +12,6 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
-import numpy as np
 import torch as th
 from torch import nn
 

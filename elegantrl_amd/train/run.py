@@ -11,7 +11,6 @@ from __future__ import annotations
 import os
 import time
 
-import numpy as np
 import torch as th
 
 from .. import parallel

@@ -12,7 +12,6 @@ Pinned by tests/test_oracle_golden.py::test_torch_port_* against tests/golden/pp
 """
 from __future__ import annotations
 
-import math
 from typing import List, Optional, Tuple
 
 import torch as th
