@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gae-sweep", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=12)   # ~10-15 s of host work on 16 cores
+    ap.add_argument("--k6-sample", type=int, default=16,
+                    help="bracket every n-th K6 launch with HIP events (0 = none): each bracket costs ~3 us of stream time")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     opt = ap.parse_args()
     if opt.cpu_baseline_only:
@@ -217,7 +219,7 @@ def main():
         step()
     log("timed region")
     t_gae.enabled = True
-    _hip.k6_timing_enable(True)                  # erl_ppo_step_f32 brackets every K6 launch with HIP events on its stream
+    _hip.k6_timing_enable(opt.k6_sample)         # erl_ppo_step_f32 brackets every n-th K6 launch with HIP events on its stream
     parallel.barrier()
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -235,7 +237,7 @@ def main():
         return
     env_steps = world * N_ENVS * HORIZON * opt.steps
     flops = ppo_flops_per_sample(STATE_DIM, *NET_DIMS, ACTION_DIM) * BATCH
-    ppo_s, n_k6 = k6_seconds / max(1, k6_launches), k6_launches
+    ppo_s, n_k6 = (k6_seconds / k6_launches if k6_launches else float("nan")), k6_launches
     gae_s = t_gae.mean_seconds()
     line = {
         "metric": "env_steps_per_sec_ppo_4096envs_obs64", "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",

@@ -151,8 +151,9 @@ def device_info():
     return cu.value, lds.value
 
 
-def k6_timing_enable(on: bool) -> None:
-    lib().erl_k6_timing_enable(int(on))
+def k6_timing_enable(every_nth: int) -> None:
+    """bracket every n-th K6 launch with HIP events on its stream (0 / False = off, 1 / True = every launch)."""
+    lib().erl_k6_timing_enable(int(every_nth))
 
 
 def k6_timing_read():

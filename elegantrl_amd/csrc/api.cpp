@@ -40,7 +40,9 @@ extern "C" int erl_device_info(int *num_cu, int *lds_bytes_per_block)
 // optional per-launch timing of K6 (measurement hook for bench.py: erl_ppo_step_f32 brackets its launch with HIP events
 // on the launch stream; off by default).  The event pairs are kept until erl_k6_timing_read() drains them.
 #include <vector>
-static bool g_k6_timing = false;
+static int g_k6_timing = 0;              // 0 = off, n = bracket every n-th launch
+static long g_k6_launch = 0;
+static bool g_k6_skip = false;
 static std::vector<hipEvent_t> g_k6_events;
 static hipEvent_t g_k6_open = nullptr;
 
@@ -48,6 +50,8 @@ static hipEvent_t g_k6_open = nullptr;
 void erl_k6_timing_mark(hipStream_t stream, int which)
 {
     if (!g_k6_timing) return;
+    if (which == 0) g_k6_skip = (g_k6_launch++ % g_k6_timing) != 0;
+    if (g_k6_skip) return;
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, stream);
@@ -63,7 +67,7 @@ void erl_k6_timing_mark(hipStream_t stream, int which)
     }
 }
 
-extern "C" void erl_k6_timing_enable(int on) { g_k6_timing = on != 0; }
+extern "C" void erl_k6_timing_enable(int every_nth) { g_k6_timing = every_nth > 0 ? every_nth : 0; g_k6_launch = 0; }
 
 // waits for the recorded events, returns the summed K6 time in milliseconds and the number of launches, and clears.
 extern "C" int erl_k6_timing_read(double *total_ms, int *launches)

@@ -295,9 +295,10 @@ ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, 
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
                                float *action_out, void *workspace, int64_t workspace_bytes, void *stream);
 
-/* measurement hook: when enabled, erl_ppo_step_f32 brackets its K6 launch with HIP events on the launch stream;
- * erl_k6_timing_read waits for them, returns the summed time (ms) and the launch count, and clears the list. */
-ERL_API void erl_k6_timing_enable(int on);
+/* measurement hook: every_nth > 0 makes erl_ppo_step_f32 bracket every n-th K6 launch with HIP events on the launch
+ * stream (1 = every launch, 0 = off); erl_k6_timing_read waits for them, returns the summed time (ms) and the number of
+ * bracketed launches, and clears the list. */
+ERL_API void erl_k6_timing_enable(int every_nth);
 ERL_API int erl_k6_timing_read(double *total_ms, int *launches);
 
 /* ---------------------------------------------------------------------------------------------
