@@ -6,6 +6,7 @@ if the shared library is missing, or a kernel reports an error, a RuntimeError i
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 from typing import Optional
@@ -21,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 7
+ABI_VERSION = 8
 COMM_ID_BYTES = 128
 
 _P = c_void_p
@@ -32,6 +33,8 @@ _SIGNATURES = {
     "erl_device_info": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "erl_gae_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "erl_gae_scan_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_float, c_float, c_int, _P, _P, c_int64, _P]),
+    "erl_async_fault_count": (c_int, [c_int]),
+    "erl_cum_rewards_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, _P]),
     "erl_adv_stats_f32": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P]),
     "erl_adv_normalize_f32": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "erl_split_ids_i64": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
@@ -121,16 +124,34 @@ def check(rc: int, what: str) -> None:
 
 
 def stream_ptr() -> int:
-    """hipStream_t of torch's current stream (kernels are ordered with torch ops on that stream)."""
+    """hipStream_t of torch's current stream ON THE CURRENT DEVICE (kernels are ordered with torch ops on that stream).
+    The C ABI launches on the calling thread's current HIP device, so every tensor handed to it must live there: `ptr`
+    enforces it, and the agents / buffers / envs enter their own device first (`on_device`)."""
     return th.cuda.current_stream().cuda_stream
 
 
+def on_device(method):
+    """run a method of an object with a `.device` attribute with that device current (`args.gpu_id` != 0 in a single
+    process: the library's launches, its stream lookup and its library-owned buffers all follow the current device)."""
+    @functools.wraps(method)
+    def inner(self, *a, **k):
+        dev = getattr(self, "device", None)
+        if dev is None or dev.type != "cuda" or dev.index is None or dev.index == th.cuda.current_device():
+            return method(self, *a, **k)
+        with th.cuda.device(dev):
+            return method(self, *a, **k)
+    return inner
+
+
 def ptr(t: Optional[th.Tensor], dtype: Optional[th.dtype] = None) -> Optional[int]:
-    """Raw device pointer of a contiguous CUDA(HIP) tensor; None passes NULL."""
+    """Raw device pointer of a contiguous CUDA(HIP) tensor on the current device; None passes NULL."""
     if t is None:
         return None
     if not t.is_cuda:
         raise HipExtensionError("elegantrl_amd kernels need tensors on a HIP device (no CPU path); got a CPU tensor")
+    if t.device.index != th.cuda.current_device():
+        raise HipExtensionError(f"tensor lives on {t.device} but the current HIP device is cuda:{th.cuda.current_device()}: "
+                                "kernels launch on the current device (enter `th.cuda.device(...)` / use the agent's methods)")
     if not t.is_contiguous():
         raise HipExtensionError("tensor must be contiguous")
     if dtype is not None and t.dtype != dtype:
@@ -143,6 +164,15 @@ def flag_ptr(t: th.Tensor) -> int:
     if t.dtype not in (th.bool, th.uint8):
         raise HipExtensionError(f"flag tensor must be bool/uint8, got {t.dtype}")
     return ptr(t)
+
+
+def check_async_faults() -> None:
+    """raise if a kernel recorded a device-side fault since the last check (call after a stream synchronisation; reads a
+    pinned host word, no GPU work): today the look-back GAE scan's bounded wait (csrc/gae_lookback.hip)."""
+    n = lib().erl_async_fault_count(1)
+    if n:
+        msg = lib().erl_last_error_string()
+        raise HipExtensionError(f"device-side fault ({n}): {msg.decode() if msg else '?'}")
 
 
 def device_info():

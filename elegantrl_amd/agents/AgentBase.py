@@ -19,6 +19,7 @@ from typing import List, Optional, Tuple
 import torch as th
 from torch import nn
 
+from .. import _hip
 from ..train.config import Config
 
 TEN = th.Tensor
@@ -134,7 +135,10 @@ class AgentBase:
     def _on_act_replaced(self):
         pass
 
-    def explore_env(self, env, horizon_len: int) -> Tuple[TEN, ...]:
+    @_hip.on_device
+    def explore_env(self, env, horizon_len: int, if_random: bool = False) -> Tuple[TEN, ...]:
+        """AgentBase.py:70-74.  `if_random` is accepted for signature parity with the PPO rollout of the reference
+        (AgentPPO.py:87), which never reads it either."""
         if self.if_vec_env:
             return self._explore_vec_env(env=env, horizon_len=horizon_len)
         return self._explore_one_env(env=env, horizon_len=horizon_len)
@@ -200,6 +204,7 @@ class AgentBase:
         rewards *= self.reward_scale
         return states, actions, rewards, th.logical_not(terminals), th.logical_not(truncates)
 
+    @_hip.on_device
     def update_net(self, buffer) -> Tuple[float, ...]:
         """off-policy update loop (AgentBase.py:172-189): `update_times = int(cur_size * repeat_times / batch_size)` steps of
         `update_objectives`, each drawing one minibatch through ReplayBuffer.sample (HIP K9)."""
@@ -219,6 +224,22 @@ class AgentBase:
 
     def update_objectives(self, buffer, update_t: int) -> Tuple[float, float]:
         raise NotImplementedError
+
+    @_hip.on_device
+    def get_cumulative_rewards(self, rewards: TEN, undones: TEN) -> TEN:
+        """n-step discounted return of the newest `add_size` rows of the replay buffer (AgentBase.py:226-237), bootstrapped
+        with `cri_target(last_state, act_target(last_state))`; the backward scan runs in erl_cum_rewards_f32 (bit-exact op
+        order).  Agents without a target actor (the reference's AgentSAC leaves `act_target = None` and would raise
+        'NoneType is not callable' here) bootstrap with the current actor instead."""
+        from .. import ops
+        if self.device.type != "cuda":
+            raise _hip.HipExtensionError("get_cumulative_rewards runs on the HIP kernels only; no GPU is visible")
+        last_state = self.last_state.to(self.device, th.float32)
+        actor = self.act_target if self.act_target is not None else self.act
+        critic = self.cri_target if self.cri_target is not None else self.cri
+        with th.no_grad():
+            next_value = critic(last_state, actor(last_state)).detach().reshape(-1).to(th.float32).contiguous()
+        return ops.cum_rewards(rewards.contiguous(), undones.to(th.float32).contiguous(), next_value, float(self.gamma))
 
     def optimizer_backward(self, optimizer, objective: TEN):
         """zero_grad, backward, global-norm clip of the optimiser's first param group, step (AgentBase.py:239-248)."""

@@ -164,6 +164,36 @@ class AgentPPO(AgentBase):
         self._stats = None
         self._env_action = None
 
+    # ---- checkpoints: AgentBase.save_or_load_agent (AgentBase.py:280-297) + the flat Adam state ------
+    def save_or_load_agent(self, cwd: str, if_save: bool):
+        """The reference pickles `th.optim.Adam` objects and gets moments + step back on load.  Here the optimiser files hold
+        `FlatAdam` views of the flat moment buffers; on load their tensors are fresh copies, so they are copied back into
+        the buffers the kernels use, the step counter (Adam bias correction) is restored and the views are re-created."""
+        if if_save:
+            self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
+        super().save_or_load_agent(cwd, if_save)
+        if if_save:
+            return
+        steps = []
+        for name, lo, n in (("act_optimizer", 0, self._Pa), ("cri_optimizer", self._Pa, self._Pc)):
+            opt = getattr(self, name, None)
+            m1, m2 = self._exp_avg[lo:lo + n], self._exp_avg_sq[lo:lo + n]
+            if isinstance(opt, FlatAdam) and opt.exp_avg.numel() == n:
+                if opt.exp_avg.data_ptr() != m1.data_ptr():
+                    m1.copy_(opt.exp_avg.to(self.device, th.float32))
+                    m2.copy_(opt.exp_avg_sq.to(self.device, th.float32))
+                steps.append(int(opt.step_count))
+            fresh = FlatAdam(m1, m2, self.learning_rate)
+            fresh.step_count = steps[-1] if steps else self._adam_step
+            setattr(self, name, fresh)
+        if steps:
+            self._adam_step = max(steps)
+            self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
+        if self.cri is not None:
+            self.cri = self.cri.to(self.device)
+        self._on_act_replaced()
+        self._sync_modules()
+
     # ---- keeping the kernels' view of the weights in sync with whatever module is installed ----------
     def _on_act_replaced(self):
         if getattr(self, "_flat_a", None) is not None and self._act is not None and not self._flat_a.is_bound(self._act):
@@ -182,6 +212,7 @@ class AgentPPO(AgentBase):
                                          f"(device={self.device}) and there is no CPU fallback")
 
     # ---- rollout: AgentPPO.py:87-133 -----------------------------------------------------------------
+    @_hip.on_device
     def explore_action(self, state: TEN, noise: Optional[TEN] = None) -> Tuple[TEN, TEN]:
         """(pre-tanh action, logprob) for a batch of states, through the K1 kernel."""
         from .. import ops
@@ -197,6 +228,7 @@ class AgentPPO(AgentBase):
         self.rng_counter += 1
         return action, logprob
 
+    @_hip.on_device
     def _explore_vec_env(self, env, horizon_len: int, if_random: bool = False, noise: Optional[TEN] = None):
         """H batched steps -> (states, actions, logprobs, rewards, undones, unmasks), time-major.
         `noise` (H, N, A) injects the N(0,1) draws (tests); otherwise Philox keyed by (seed, step, env)."""
@@ -234,7 +266,8 @@ class AgentPPO(AgentBase):
             pP, pavg, pstd, pst, pea = (_hip.ptr(x, th.float32) for x in (P, avg, std, env.state, env_action))
             p_s, p_a, p_l, p_r = states.data_ptr(), actions.data_ptr(), logprobs.data_ptr(), rewards.data_ptr()
             p_te, p_tr = terminals.data_ptr(), truncates.data_ptr()
-            p_n = None if noise is None else _hip.ptr(noise.contiguous(), th.float32)
+            noise = None if noise is None else noise.contiguous()      # keep the (possibly fresh) contiguous copy alive for all H launches
+            p_n = None if noise is None else _hip.ptr(noise, th.float32)
             h1, h2 = spec.h1, spec.h2
             seed = self.rng_seed & (2 ** 64 - 1)
             for t in range(H):
@@ -267,6 +300,7 @@ class AgentPPO(AgentBase):
         unmasks = th.logical_not(truncates)
         return states, actions, logprobs, rewards, undones, unmasks
 
+    @_hip.on_device
     def _explore_one_env(self, env, horizon_len: int, if_random: bool = False):
         """single (numpy, non-vectorised) env: AgentPPO.py:34-85; the policy still runs on the GPU."""
         from .. import ops
@@ -299,6 +333,7 @@ class AgentPPO(AgentBase):
         return states, actions, logprobs, rewards, th.logical_not(terminals), th.logical_not(truncates)
 
     # ---- GAE: AgentPPO.py:207-232 ---------------------------------------------------------------------
+    @_hip.on_device
     def get_values(self, states: TEN) -> TEN:
         """cri(states).squeeze(-1) for states (..., S) (the value pre-pass of :141-143, in one launch)."""
         from .. import ops
@@ -307,6 +342,7 @@ class AgentPPO(AgentBase):
         fwd = ops.value_forward if self._fused else ops.mlpn_value_forward
         return fwd(self._flat_c.flat, self._spec_c, self.cri.state_avg.data, self.cri.state_std.data, states.contiguous())
 
+    @_hip.on_device
     def get_advantages(self, states: TEN, rewards: TEN, undones: TEN, unmasks: TEN, values: TEN) -> TEN:
         """Same signature and side effects as the reference: returns `advantages` (H, N) and applies the
         truncation fix-up to the caller's `rewards` / `undones` in place."""
@@ -324,6 +360,7 @@ class AgentPPO(AgentBase):
                             stats=stats)
 
     # ---- update: AgentPPO.py:135-205 ------------------------------------------------------------------
+    @_hip.on_device
     def update_net(self, buffer, ids: Optional[TEN] = None) -> Tuple[float, float, float]:
         """One PPO update on the rollout `buffer`; returns (obj_critic, obj_surrogate, obj_entropy) means.
         `ids` (update_times, batch_size) int64 injects the minibatch indices (tests); otherwise they are drawn
@@ -378,6 +415,7 @@ class AgentPPO(AgentBase):
             self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
             logs = self._grads[:update_times, self._Pa + self._Pc:self._Pa + self._Pc + 3].mean(dim=0) * grad_scale
             obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())
+            _hip.check_async_faults()          # the stream is drained: a lost look-back predecessor (NaN advantages) raises here
             return obj_critic, obj_actor, obj_entropy
         h1, h2 = self.net_dims
         if not dp or comm is not None:  # the whole minibatch loop is enqueued by one C call (no interpreter on the launch
@@ -417,6 +455,7 @@ class AgentPPO(AgentBase):
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
         logs = self._grads[:update_times, self._Pa + self._Pc:self._Pa + self._Pc + 3].mean(dim=0) * grad_scale
         obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())           # the only host sync of update_net
+        _hip.check_async_faults()              # the stream is drained: a lost look-back predecessor (NaN advantages) raises here
         return obj_critic, obj_actor, obj_entropy
 
     def _n_slabs(self, batch_size: int) -> int:
@@ -451,6 +490,7 @@ class AgentDiscretePPO(AgentPPO):
         self.lambda_entropy_value = float(getattr(args, "lambda_entropy", 0.01))          # AgentPPO.py:318
         self.lambda_entropy = th.tensor(self.lambda_entropy_value, dtype=th.float32, device=self.device)
 
+    @_hip.on_device
     def explore_action(self, state: TEN, uniform: Optional[TEN] = None) -> Tuple[TEN, TEN]:
         """(action int32 (n,), logprob (n,)); `uniform` (n,) injects the U[0,1) draws (tests)."""
         from .. import ops
@@ -466,6 +506,7 @@ class AgentDiscretePPO(AgentPPO):
         self.rng_counter += 1
         return action, logprob
 
+    @_hip.on_device
     def _explore_vec_env(self, env, horizon_len: int, if_random: bool = False, noise: Optional[TEN] = None):
         """H batched steps -> (states, actions int32 (H, N), logprobs, rewards, undones, unmasks); `noise` (H, N) injects
         the uniform draws."""
@@ -499,6 +540,7 @@ class AgentDiscretePPO(AgentPPO):
             rewards *= self.reward_scale
         return states, actions, logprobs, rewards, th.logical_not(terminals), th.logical_not(truncates)
 
+    @_hip.on_device
     def _explore_one_env(self, env, horizon_len: int, if_random: bool = False):
         """single (numpy) env, AgentPPO.py:34-85 with if_discrete: actions (H, 1) int32, env.step gets a python int."""
         from .. import ops

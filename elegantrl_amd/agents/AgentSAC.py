@@ -131,6 +131,7 @@ class AgentSAC(AgentBase):
         self.target_entropy = math.log(action_dim)               # np.log(action_dim), as the reference (:31)
         self._step = 0
         self._objs = th.zeros(2, dtype=f32, device=dev)
+        self.save_attr_names = self.save_attr_names | {"alpha_log", "alpha_optim"}
 
     def _on_act_replaced(self):
         if getattr(self, "_bind_a", None) is not None and self._act is not None and not self._bind_a.is_bound(self._act):
@@ -142,6 +143,29 @@ class AgentSAC(AgentBase):
             if not bind.is_bound(mod):
                 bind.bind(mod)
 
+    def save_or_load_agent(self, cwd: str, if_save: bool):
+        """AgentBase.save_or_load_agent plus what a resumed SAC run needs beyond the reference's file set: the temperature
+        and its optimiser state (`alpha_log`, `alpha_optim`), the Adam step (bias correction) and the Philox counters."""
+        if if_save:
+            for opt in (self.act_optimizer, self.cri_optimizer, self.alpha_optim):
+                opt.step_count = self._step
+                opt.rng_counter = self.rng_counter
+        super().save_or_load_agent(cwd, if_save)
+        if not if_save:
+            self.alpha_log = self.alpha_log.to(self.device, th.float32).contiguous()
+            for opt in (self.act_optimizer, self.cri_optimizer, self.alpha_optim):
+                opt.exp_avg = opt.exp_avg.to(self.device, th.float32).contiguous()
+                opt.exp_avg_sq = opt.exp_avg_sq.to(self.device, th.float32).contiguous()
+            self._step = int(self.act_optimizer.step_count)
+            self.rng_counter = int(getattr(self.act_optimizer, "rng_counter", self.rng_counter))
+            if self.cri is not None:
+                self.cri = self.cri.to(self.device)
+            if self.cri_target is not None:
+                self.cri_target = self.cri_target.to(self.device)
+            self._on_act_replaced()
+            self._sync_modules()
+
+    @_hip.on_device
     def explore_action(self, state: TEN, noise: Optional[TEN] = None) -> TEN:
         from .. import ops
         self._sync_modules()
@@ -161,6 +185,7 @@ class AgentSAC(AgentBase):
                        objs_out=objs_out, noises=noises, seed=self.rng_seed + 1, counter=self._step)
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self.alpha_optim.step_count = self._step
 
+    @_hip.on_device
     def update_objectives(self, buffer, update_t: int, ids: Optional[TEN] = None,
                           noises: Optional[Tuple[TEN, TEN]] = None) -> Tuple[float, float]:
         """one SAC step (AgentSAC.py:42-86).  `ids` / `noises` = (eps for next_state, eps for state) inject the random draws."""
@@ -175,6 +200,7 @@ class AgentSAC(AgentBase):
         oc, oa = self._objs.cpu().tolist()
         return oc, oa
 
+    @_hip.on_device
     def update_net(self, buffer) -> Tuple[float, float]:
         """AgentBase.update_net (:172-189) with ONE host sync: the per-step objectives stay on the device until the end."""
         if self.if_use_per or self.lambda_fit_cum_r:

@@ -362,6 +362,41 @@ __global__ __launch_bounds__(256) void adv_normalize_kernel(const float *__restr
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// n-step discounted return of the off-policy agents (AgentBase.get_cumulative_rewards, AgentBase.py:226-237):
+//   masks = undones * gamma;  for t = H-1 .. 0:  cum[t] = next_value = rewards[t] + masks[t] * next_value
+// One lane per sequence, the reference's op order with every product / sum rounded separately (this file is built
+// with fp contraction off): bit-identical to the chain of ATen ops.  It is K3's recurrence with lambda = 1 and no
+// value term; U steps of loads are issued together ahead of the dependent chain.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cum_rewards_kernel(const float *__restrict__ rewards, const float *__restrict__ undones,
+                                                         const float *__restrict__ next_value, float *__restrict__ out, int H,
+                                                         int N, float gamma)
+{
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    float nv = next_value[n];
+    constexpr int U = 8;
+    for (int tb = H - 1; tb >= 0; tb -= U) {
+        float r[U], u[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = tb - j;
+            if (t >= 0) {
+                r[j] = rewards[(size_t)t * N + n];
+                u[j] = undones[(size_t)t * N + n];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = tb - j;
+            if (t < 0) break;
+            nv = add_rn(r[j], mul_rn(mul_rn(u[j], gamma), nv));
+            out[(size_t)t * N + n] = nv;
+        }
+    }
+}
+
 inline int pick_chunk_len(int64_t H, int64_t N, int vec)
 {
     // Pass B folds the (K - k - 1) later chunk maps per lane: that term is O(K^2 N), the chunk re-scan
@@ -459,6 +494,17 @@ extern "C" int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t 
     if (want_stats)
         hipLaunchKernelGGL(adv_stats_fold_kernel, dim3(1), dim3(256), 0, stream, partials, nparts, (int)H, (int)N, stats);
     ERL_LAUNCH_CHECK("erl_gae_scan_f32");
+}
+
+extern "C" int erl_cum_rewards_f32(const float *rewards, const float *undones, const float *next_value, float *cum_rewards,
+                                   int64_t H, int64_t N, float gamma, void *stream)
+{
+    ERL_REQUIRE(rewards && undones && next_value && cum_rewards, "erl_cum_rewards_f32: NULL tensor");
+    ERL_REQUIRE(H >= 1 && N >= 1 && N < (1LL << 31) && H < (1LL << 31), "erl_cum_rewards_f32: bad shape H=%lld N=%lld",
+                (long long)H, (long long)N);
+    hipLaunchKernelGGL(cum_rewards_kernel, dim3((unsigned)erl_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, rewards, undones,
+                       next_value, cum_rewards, (int)H, (int)N, gamma);
+    ERL_LAUNCH_CHECK("erl_cum_rewards_f32");
 }
 
 extern "C" int erl_adv_stats_f32(const float *adv, int64_t H, int64_t N, double *stats, void *workspace,

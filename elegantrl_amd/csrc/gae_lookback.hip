@@ -43,6 +43,9 @@ struct LbArgs {
     uint32_t ticket_base, nonce;
     unsigned long long *slots; // [K][N] granules {A, nonce << 2 | state}
     double *partials;          // [gridDim.x][3]
+    uint32_t *fault;           // host-mapped counter of look-back spin timeouts (erl_async_fault_count); may be NULL
+    uint32_t spin_limit;       // polls per granule before a predecessor is declared lost
+    uint32_t publish_nonce;    // == nonce; ERL_GAE_LB_FAULT=1 (tests) publishes under a foreign nonce so readers time out
 };
 
 __device__ __forceinline__ unsigned long long pack_granule(float a, uint32_t tag)
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
             for (int u = 0; u < W - 1; ++u) cp = pw * cp;
             p_full = pw * cp;
         }
-        const uint32_t tagbase = g.nonce << 2;
+        const uint32_t tagbase = g.publish_nonce << 2;
         unsigned long long *mine = g.slots + (size_t)kk * N + n0;
         const bool has_reader = kk + 1 < g.K;
         if (live && has_reader) {
@@ -199,7 +202,9 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
                         ready = ((uint32_t)(gr >> 34)) == g.nonce;
                         if (ready) break;
                         __builtin_amdgcn_s_sleep(2);
-                    } while (++spins < (1u << 22));   // bounded: a lost predecessor yields NaN outputs, not a hang
+                    } while (++spins < g.spin_limit);   // bounded: a lost predecessor poisons this env's outputs with NaN AND
+                    // is counted in the host-visible fault word (erl_async_fault_count -> the caller raises), never a hang
+                    if (!ready && g.fault) __hip_atomic_fetch_add(g.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const float ga = ready ? __uint_as_float((uint32_t)gr) : __uint_as_float(0x7FC00000u);
                     const uint32_t state = (uint32_t)(gr >> 32) & 3u;
                     accA[e] += accP[e] * ga;
@@ -320,6 +325,38 @@ struct LbTable {
 };
 static LbTable g_lb_table[32];
 
+// Device-side faults that cannot be returned by the (asynchronous) launch call are counted in ONE pinned, host-mapped
+// word: the kernel bumps it with a system-scope atomic, the host reads it without touching the GPU once the stream has
+// been synchronised (erl_async_fault_count).  Allocated on first use; NULL when pinned memory is unavailable.
+static uint32_t *g_fault_host = nullptr, *g_fault_dev = nullptr;
+static uint32_t *fault_word()
+{
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            g_fault_host = (uint32_t *)h;
+            g_fault_dev = (uint32_t *)d;
+            *g_fault_host = 0u;
+        } else {
+            if (h) (void)hipHostFree(h);
+            (void)hipGetLastError();
+        }
+    }
+    return g_fault_dev;
+}
+
+extern "C" int erl_async_fault_count(int reset)
+{
+    if (!g_fault_host) return 0;
+    const uint32_t n = __atomic_load_n(g_fault_host, __ATOMIC_ACQUIRE);
+    if (reset && n) __atomic_store_n(g_fault_host, 0u, __ATOMIC_RELEASE);
+    if (n) erl_set_error("gae_lookback_kernel: %u look-back wait(s) timed out (a predecessor slab never published); the affected "
+                         "advantages are NaN", n);
+    return (int)(n > 0x7fffffffu ? 0x7fffffffu : n);
+}
+
 // Enqueues [memset +] kernel.  workspace layout (fallback path): [ticket: 256 B][slots: K*N*8 B][partials: nblk*24 B].
 // Returns the number of statistics partials (blocks) through *nparts and their location through *partials.
 int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
@@ -342,6 +379,11 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     g.H = (int)H; g.N = (int)N; g.G = (int)G; g.K = (int)K;
     g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
     g.partials = (double *)(ws + 256 + slot_bytes);
+    g.fault = fault_word();
+    {
+        const int lim = env_int("ERL_GAE_LB_SPIN", 1 << 22);
+        g.spin_limit = lim > 0 ? (uint32_t)lim : 1u;
+    }
     *partials = g.partials;
     *nparts = (int)(K * G);
 
@@ -381,6 +423,7 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
         int rc = erl_hip_status(hipMemsetAsync(ws, 0, 256 + (K > 1 ? slot_bytes : 0), stream), "hipMemsetAsync(lookback slots)");
         if (rc) return rc;
     }
+    g.publish_nonce = env_int("ERL_GAE_LB_FAULT", 0) ? (g.nonce ^ 0x15555555u) & 0x3fffffffu : g.nonce;
     const dim3 grid((unsigned)(K * G)), block(W * 64);
 #define LB_LAUNCH(LL)                                                                                  \
     do {                                                                                               \

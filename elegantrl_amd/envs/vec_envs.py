@@ -14,6 +14,8 @@ from typing import Tuple
 
 import torch as th
 
+from .. import _hip
+
 TEN = th.Tensor
 
 
@@ -34,6 +36,7 @@ class _GpuVecEnv:
         self._terminal = th.zeros(num_envs, dtype=th.bool, device=dev)
         self._truncate = th.zeros(num_envs, dtype=th.bool, device=dev)
 
+    @_hip.on_device
     def step(self, action: TEN) -> Tuple[TEN, TEN, TEN, TEN, dict]:
         state = self.step_into(action.contiguous(), self._reward, self._terminal, self._truncate)
         return state.clone(), self._reward.clone(), self._terminal.clone(), self._truncate.clone(), {}

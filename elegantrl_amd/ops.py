@@ -56,6 +56,17 @@ def gae_scan(rewards: TEN, undones: TEN, unmasks: TEN, values: TEN, next_value: 
     return adv, (ret if with_ret else None)
 
 
+def cum_rewards(rewards: TEN, undones: TEN, next_value: TEN, gamma: float, out: Optional[TEN] = None) -> TEN:
+    """AgentBase.get_cumulative_rewards' backward scan (AgentBase.py:226-237): rewards / undones (H, N) f32, next_value (N,)."""
+    H, N = rewards.shape
+    assert undones.shape == (H, N) and next_value.numel() == N
+    out = th.empty_like(rewards) if out is None else out
+    check(lib().erl_cum_rewards_f32(ptr(rewards, th.float32), ptr(undones, th.float32), ptr(next_value, th.float32),
+                                    ptr(out, th.float32), H, N, gamma, stream_ptr()),
+          "erl_cum_rewards_f32")
+    return out
+
+
 def adv_stats(adv: TEN, stats: Optional[TEN] = None) -> TEN:
     """Raw sums for AgentPPO.py:149 -> float64[5] = (sum, H*N, sum_sub, sumsq_sub, count_sub)."""
     H, N = adv.shape
@@ -300,14 +311,28 @@ class MlpSpecN:
         return lib().erl_mlpn_workspace_bytes(self._c, len(self.dims), rows, int(training))
 
 
+_MLPN_VALUE_WS_BYTES = 256 << 20     # activation workspace cap of the layered value pre-pass
+
+
 def mlpn_value_forward(params: TEN, spec: MlpSpecN, state_avg: TEN, state_std: TEN, states: TEN, out: Optional[TEN] = None) -> TEN:
+    """CriticPPO(states).squeeze(-1) on the layered path.  The pass is cut into row chunks whose activations fit a fixed
+    256 MiB workspace (the reference chunks this pre-pass too, `bs = 2 ** 10 // num_envs` time rows, AgentPPO.py:141-143:
+    H x N x sum(dims) floats at 2048 x 4096 would be ~15 GB in one piece)."""
     rows = states.numel() // spec.S
     out = th.empty(states.shape[:-1], dtype=th.float32, device=states.device) if out is None else out
-    ws = _workspace(states.device, spec.workspace_bytes(max(rows, 1), False))
+    per_row = max(1, spec.workspace_bytes(4096, False) // 4096)
+    chunk = max(4096, (_MLPN_VALUE_WS_BYTES // per_row) // 4096 * 4096)
     c, n = spec.cdims
-    check(lib().erl_mlpn_value_forward_f32(ptr(params, th.float32), ptr(state_avg, th.float32), ptr(state_std, th.float32), c, n,
-                                           ptr(states, th.float32), rows, ptr(out, th.float32), ptr(ws), ws.numel(), stream_ptr()),
-          "erl_mlpn_value_forward_f32")
+    s2, o1 = states.reshape(-1, spec.S), out.reshape(-1)
+    for r0 in range(0, max(rows, 1), chunk):
+        nr = min(chunk, rows - r0)
+        if nr <= 0:
+            break
+        ws = _workspace(states.device, spec.workspace_bytes(nr, False))
+        check(lib().erl_mlpn_value_forward_f32(ptr(params, th.float32), ptr(state_avg, th.float32), ptr(state_std, th.float32), c, n,
+                                               ptr(s2, th.float32) + 4 * r0 * spec.S, nr, ptr(o1, th.float32) + 4 * r0, ptr(ws),
+                                               ws.numel(), stream_ptr()),
+              "erl_mlpn_value_forward_f32")
     return out
 
 

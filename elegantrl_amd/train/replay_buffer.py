@@ -13,6 +13,7 @@ from typing import Optional, Tuple
 
 import torch as th
 
+from .. import _hip
 from .config import Config
 
 TEN = th.Tensor
@@ -60,6 +61,7 @@ class ReplayBuffer:
         self.cur_size = self.max_size if self.if_full else self.p
         return start
 
+    @_hip.on_device
     def update(self, items: Tuple[TEN, ...]):
         from .. import ops
         states, actions, rewards, undones, unmasks = items
@@ -68,6 +70,7 @@ class ReplayBuffer:
                          (states.contiguous(), actions.contiguous(), rewards.contiguous(), undones.contiguous(),
                           unmasks.contiguous()), start)
 
+    @_hip.on_device
     def sample(self, batch_size: int, ids: Optional[TEN] = None) -> Tuple[TEN, TEN, TEN, TEN, TEN, TEN]:
         """(state, action, reward, undone, unmask, next_state) for ids drawn like the reference
         (th.randint(sample_len * num_seqs, (batch_size,))); `ids` can be injected for tests."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 7
+#define ERL_ABI_VERSION 8
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -73,6 +73,20 @@ ERL_API int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t *un
                      const float *next_value, float *adv, float *ret, int64_t H, int64_t N, float gamma,
                      float lam, int flags, double *stats, void *workspace, int64_t workspace_bytes,
                      void *stream);
+
+/* Device-side faults that an asynchronous launch cannot return (today: a look-back wait of ERL_GAE_ALGO_LOOKBACK that
+ * timed out because a predecessor slab never published -- the affected advantages are NaN) are counted in a pinned,
+ * host-mapped word.  Call after the stream has been synchronised: returns the number of faults since the last reset
+ * (0 = none), describes them in erl_last_error_string(), and clears the counter when `reset` != 0.  Costs no GPU work. */
+ERL_API int erl_async_fault_count(int reset);
+
+/* n-step discounted return for the off-policy agents.  Replaces AgentBase.get_cumulative_rewards' scan
+ * (elegantrl/agents/AgentBase.py:226-237):  masks = undones * gamma;
+ *   for t = H-1 .. 0:  cum_rewards[t] = next_value = rewards[t] + masks[t] * next_value        (bit-exact op order)
+ * rewards / undones / cum_rewards: (H, N) f32 (the replay buffer's float flags, replay_buffer.py:57); next_value: (N,)
+ * = cri_target(last_state, act_target(last_state)), computed by the caller. */
+ERL_API int erl_cum_rewards_f32(const float *rewards, const float *undones, const float *next_value, float *cum_rewards,
+                        int64_t H, int64_t N, float gamma, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  advantage normalisation.  Replaces AgentPPO.py:149:

@@ -350,8 +350,61 @@ def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed):
     print("wrote", path, "objs", objs)
 
 
+def make_cum_rewards():
+    """reference AgentBase.get_cumulative_rewards (elegantrl/agents/AgentBase.py:226-237) through AgentTD3 (which owns
+    act_target / cri_target), called the way AgentBase.update_net does: via ReplayBuffer.update_cum_rewards (both the
+    contiguous and the `p < add_size` branch, replay_buffer.py:213-223)."""
+    sys.path.insert(0, REF)
+    from elegantrl.agents.AgentTD3 import AgentTD3
+    from elegantrl.train.config import Config
+    from elegantrl.train.replay_buffer import ReplayBuffer
+
+    th.manual_seed(41)
+    N, S, A, max_size = 6, 5, 2, 24
+    args = Config(AgentTD3, None, {"env_name": "x", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
+                                   "if_discrete": False})
+    args.gamma = 0.985
+    agent = AgentTD3((32, 32), S, A, gpu_id=-1, args=args)
+    # As written the reference function cannot run with its own critics: they return (N, 1), and `rewards[t] + masks[t] *
+    # next_value` then broadcasts to (N, N) and the assignment raises (executed here: RuntimeError expand [6, 6] -> [6]).
+    # The fixture is generated with the critic's output squeezed to (N,) -- the evident intent -- and nothing else changed.
+    twin = agent.cri_target
+    agent.cri_target = lambda s, a: twin(s, a).squeeze(-1)
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=-1, num_seqs=N)
+    for t in (buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks, buf.cum_rewards):
+        t.zero_()
+    g = {"dims": np.array([N, S, A, max_size]), "gamma": np.array([args.gamma])}
+    adds = [10, 9, 11, 7]          # 10 + 9 = 19; +11 wraps to p = 6 (< add_size: the p1 = max_size branch); +7 -> p = 13
+    g["adds"] = np.array(adds)
+    with th.no_grad():
+        for k, add in enumerate(adds):
+            items = (th.randn(add, N, S), th.randn(add, N, A).tanh(), th.randn(add, N), th.rand(add, N) > 0.15,
+                     th.rand(add, N) > 0.1)
+            buf.update(items)
+            agent.last_state = th.randn(N, S)
+            nv = agent.cri_target(agent.last_state, agent.act_target(agent.last_state))
+            buf.update_cum_rewards(get_cumulative_rewards=agent.get_cumulative_rewards)
+            g[f"rewards{k}"], g[f"undones{k}"] = np32(buf.rewards), np32(buf.undones)
+            g[f"next_value{k}"] = np32(nv).reshape(-1)
+            g[f"cursor{k}"] = np.array([buf.p, buf.cur_size, int(buf.if_full), buf.add_size])
+            g[f"cum_rewards{k}"] = np32(buf.cum_rewards)
+            # the function on its own, on the slice update_cum_rewards hands it
+            p1 = buf.p if buf.p >= buf.add_size else buf.max_size
+            p0 = p1 - buf.add_size
+            g[f"slice{k}"] = np.array([p0, p1])
+            g[f"direct{k}"] = np32(agent.get_cumulative_rewards(rewards=buf.rewards[p0:p1], undones=buf.undones[p0:p1]))
+    path = os.path.join(OUT, "cum_rewards.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"reference not mounted at {REF}"
+    only = sys.argv[1:]
+    if only:                       # regenerate selected fixtures only: python oracle/make_golden.py cum_rewards ...
+        for name in only:
+            globals()[f"make_{name}"]()
+        sys.exit(0)
     make_ppo("small_vtrace", N=8, S=6, A=2, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0,
              use_v_trace=True, seed=11)
     make_ppo("small_alt", N=8, S=6, A=2, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0,
@@ -361,3 +414,4 @@ if __name__ == "__main__":
     make_replay()
     make_sac("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=21)
     make_ppo_discrete("small", N=8, S=6, A=4, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0, seed=31)
+    make_cum_rewards()

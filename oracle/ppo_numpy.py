@@ -380,6 +380,27 @@ def ppo_minibatch_step(buf, ids, actor: Mlp, critic: Mlp, st_a: AdamState, st_c:
 
 
 # --------------------------------------------------------------------------------------
+# n-step discounted return of the off-policy agents: elegantrl/agents/AgentBase.py:226-237
+# --------------------------------------------------------------------------------------
+def cum_rewards(rewards: np.ndarray, undones: np.ndarray, next_value: np.ndarray, gamma: float) -> np.ndarray:
+    """masks = undones * gamma (:229); for t = H-1 .. 0: cum[t] = next_value = rewards[t] + masks[t] * next_value (:235-236).
+    dtype-generic; with float32 inputs every product / sum rounds separately like the reference's ATen ops."""
+    dt = rewards.dtype
+    masks = undones.astype(dt) * dt.type(gamma)
+    out = np.empty_like(rewards)
+    nv = next_value.astype(dt).reshape(-1)
+    for t in range(rewards.shape[0] - 1, -1, -1):
+        out[t] = nv = rewards[t] + masks[t] * nv
+    return out
+
+
+def cum_rewards_slice(p: int, add_size: int, max_size: int) -> Tuple[int, int]:
+    """rows ReplayBuffer.update_cum_rewards hands to get_cumulative_rewards (elegantrl/train/replay_buffer.py:213-223)."""
+    p1 = p if p >= add_size else max_size
+    return p1 - add_size, p1
+
+
+# --------------------------------------------------------------------------------------
 # Off-policy ring buffer: elegantrl/train/replay_buffer.py:11-134
 # --------------------------------------------------------------------------------------
 class Ring:

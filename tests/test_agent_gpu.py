@@ -166,6 +166,75 @@ def test_c4_iteration_against_oracle(N, S):
     np.testing.assert_allclose(agent.cri.net[2].weight.detach().cpu().numpy(), critic.weights[1], rtol=0, atol=2e-5)
 
 
+def test_checkpoint_resume_restores_adam_state(tmp_path):
+    """save_or_load_agent(if_save=False) must continue exactly where the saved run stopped: weights, Adam moments and the
+    Adam step (bias correction).  An interrupted run (2 updates, save, fresh agent, load, 2 updates) ends with weights
+    bit-identical to the uninterrupted run (4 updates on the same minibatches); without the restored moments it does not."""
+    g = load("ppo_mid_vtrace.npz")
+    d = dims(g)
+    buf = lambda: [th.from_numpy(g[k]).to(DEV) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]  # noqa: E731
+    gen = th.Generator(device=DEV).manual_seed(9)
+    ids = [th.randint(d["H"] * d["N"], tuple(g["ids"].shape), device=DEV, generator=gen) for _ in range(4)]
+    last = th.from_numpy(g["last_state"]).to(DEV)
+
+    a, _ = make_agent(g)
+    a.last_state = last
+    for k in range(4):
+        a.update_net(buf(), ids=ids[k])
+
+    b, _ = make_agent(g)
+    b.last_state = last
+    for k in range(2):
+        b.update_net(buf(), ids=ids[k])
+    b.save_or_load_agent(str(tmp_path), if_save=True)
+    assert sorted(os.listdir(tmp_path)) == ["act.pth", "act_optimizer.pth", "cri.pth", "cri_optimizer.pth"]
+
+    c, _ = make_agent(g)                       # fresh process stand-in: golden initial weights, zero moments, step 0
+    c.save_or_load_agent(str(tmp_path), if_save=False)
+    c.last_state = last
+    assert c._adam_step == b._adam_step == 2 * g["ids"].shape[0]
+    assert th.equal(c._flat, b._flat) and th.equal(c._exp_avg, b._exp_avg) and th.equal(c._exp_avg_sq, b._exp_avg_sq)
+    assert c.act_optimizer.exp_avg.data_ptr() == c._exp_avg.data_ptr()            # the views alias the live buffers again
+    for k in range(2, 4):
+        c.update_net(buf(), ids=ids[k])
+    assert th.equal(c._flat, a._flat) and th.equal(c._exp_avg_sq, a._exp_avg_sq)
+    c.save_or_load_agent(str(tmp_path), if_save=True)                              # and the next save is not stale
+    saved = th.load(os.path.join(tmp_path, "act_optimizer.pth"), weights_only=False)
+    assert saved.step_count == c._adam_step and th.equal(saved.exp_avg.to(DEV), c._exp_avg[:c._Pa])
+
+
+def test_off_policy_cumulative_rewards_through_the_buffer():
+    """AgentBase.get_cumulative_rewards via ReplayBuffer.update_cum_rewards (AgentBase.py:226-237, replay_buffer.py:213-223)
+    on the SAC agent: the scan kernel bootstrapped with cri_target(last_state, act(last_state)) equals the fp32 numpy
+    restatement bit for bit on the rows the reference's slice rule selects."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.train import Config, ReplayBuffer
+    N, S, A, max_size = 6, 5, 2, 24
+    args = Config(AgentSAC, None, {"env_name": "x", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
+                                   "if_discrete": False})
+    args.net_dims, args.gamma = [32, 32], 0.985
+    th.manual_seed(4)
+    agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N)
+    buf.cum_rewards.zero_()
+    gen = th.Generator(device=DEV).manual_seed(1)
+    r = lambda *s: th.randn(*s, device=DEV, generator=gen)  # noqa: E731
+    for add in (10, 9, 11, 7):
+        buf.update((r(add, N, S), r(add, N, A).tanh(), r(add, N), th.rand(add, N, device=DEV, generator=gen) > 0.15,
+                    th.rand(add, N, device=DEV, generator=gen) > 0.1))
+        agent.last_state = r(N, S)
+        before = buf.cum_rewards.clone()
+        buf.update_cum_rewards(get_cumulative_rewards=agent.get_cumulative_rewards)
+        with th.no_grad():
+            nv = agent.cri_target(agent.last_state, agent.act(agent.last_state)).reshape(-1)
+        p0, p1 = O.cum_rewards_slice(buf.p, buf.add_size, max_size)
+        ref = O.cum_rewards(buf.rewards[p0:p1].cpu().numpy(), buf.undones[p0:p1].cpu().numpy(), nv.cpu().numpy(), args.gamma)
+        np.testing.assert_array_equal(buf.cum_rewards[p0:p1].cpu().numpy(), ref)
+        keep = np.ones(max_size, bool)
+        keep[p0:p1] = False
+        np.testing.assert_array_equal(buf.cum_rewards.cpu().numpy()[keep], before.cpu().numpy()[keep])
+
+
 def test_act_setter_rebinds_kernel_weights():
     import copy
     g = load(PPO_GOLDENS[0])

@@ -113,6 +113,71 @@ def test_gae_lookback_within_1e5(ops, dev, H, N, vtrace):
     np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("H,N", [(2048, 4096), (200, 4096), (32, 32768)], ids=["baseline-2048x4096", "config2-200x4096", "32x32768"])
+@pytest.mark.parametrize("vtrace", [True, False])
+def test_gae_lookback_at_baseline_sizes_against_c_oracle(ops, dev, H, N, vtrace):
+    """the metric's own sizes (SURVEY.md 8d sweep; 2048 x 4096 = 151 MB) checked DIRECTLY against oracle/gae_scan.c, not
+    against another kernel of this library: |x - ref| <= 1e-5 max(1, |ref|) (north star), flags bit-exact."""
+    r, u, m, v, nv = gae_inputs(H, N, seed=H * 7 + N)
+    adv_o, ret_o, r_o, u_o = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=vtrace)
+    tr, tu = cu(r, dev), cu(u, dev)
+    adv, ret = ops.gae_scan(tr, tu, cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, use_v_trace=vtrace, algo="lookback")
+    rel_close(adv.cpu().numpy(), adv_o, 1e-5)
+    rel_close(ret.cpu().numpy(), ret_o, 1e-5)
+    np.testing.assert_array_equal(tu.cpu().numpy(), u_o)
+    np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
+    th.cuda.synchronize()
+    from elegantrl_amd import _hip
+    _hip.check_async_faults()                                  # no look-back wait timed out
+
+
+def test_gae_lookback_timeout_is_reported_not_silent(ops, dev, monkeypatch):
+    """a predecessor slab that never publishes (fault injection: granules written under a foreign nonce) makes the bounded
+    look-back wait expire: the affected advantages are NaN AND the fault reaches the host through the ABI
+    (erl_async_fault_count / _hip.check_async_faults), which AgentPPO.update_net checks at its host sync."""
+    from elegantrl_amd import _hip
+    th.cuda.synchronize()
+    assert _hip.lib().erl_async_fault_count(1) >= 0            # start clean
+    r, u, m, v, nv = gae_inputs(512, 256, seed=5, p_done=0.0, p_trunc=0.0)
+    args = (cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95)
+    monkeypatch.setenv("ERL_GAE_LB_FAULT", "1")
+    monkeypatch.setenv("ERL_GAE_LB_SPIN", "64")
+    adv, _ = ops.gae_scan(cu(r, dev), cu(u, dev), *args, algo="lookback")
+    th.cuda.synchronize()
+    assert th.isnan(adv).any()
+    with pytest.raises(_hip.HipExtensionError, match="look-back"):
+        _hip.check_async_faults()
+    _hip.check_async_faults()                                  # the counter was cleared by the failing check
+    monkeypatch.delenv("ERL_GAE_LB_FAULT")
+    monkeypatch.delenv("ERL_GAE_LB_SPIN")
+    adv, _ = ops.gae_scan(cu(r, dev), cu(u, dev), *args, algo="lookback")
+    th.cuda.synchronize()
+    assert not th.isnan(adv).any()
+    _hip.check_async_faults()
+
+
+def test_cum_rewards_reference_golden_bitwise(ops, dev):
+    """erl_cum_rewards_f32 against the returns the reference's AgentBase.get_cumulative_rewards produced (4 appends through
+    ReplayBuffer.update_cum_rewards, one of them the p < add_size branch): bit-exact."""
+    g = load("cum_rewards.npz")
+    gamma = float(g["gamma"][0])
+    for k in range(len(g["adds"])):
+        p0, p1 = [int(x) for x in g[f"slice{k}"]]
+        out = ops.cum_rewards(cu(g[f"rewards{k}"][p0:p1], dev), cu(g[f"undones{k}"][p0:p1], dev), cu(g[f"next_value{k}"], dev), gamma)
+        np.testing.assert_array_equal(out.cpu().numpy(), g[f"direct{k}"])
+
+
+@pytest.mark.parametrize("H,N", [(512, 64), (1, 1), (37, 130), (4096, 4), (9, 1000)])
+def test_cum_rewards_matches_numpy_restatement_bitwise(ops, dev, H, N):
+    rng = np.random.default_rng(H + N)
+    r = rng.standard_normal((H, N), dtype=np.float32)
+    u = (rng.random((H, N)) > 0.05).astype(np.float32)
+    nv = rng.standard_normal(N, dtype=np.float32)
+    ref = O.cum_rewards(r, u, nv, 0.97)
+    out = ops.cum_rewards(cu(r, dev), cu(u, dev), cu(nv, dev), 0.97)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("L,W", [(2, 1), (4, 3), (8, 16), (16, 8), (4, 16)])
 def test_gae_lookback_every_tiling(ops, dev, L, W, monkeypatch):
     """every (steps per lane, waves per workgroup) instantiation, long undone chains (no episode ends) so that the

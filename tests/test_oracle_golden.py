@@ -94,6 +94,24 @@ def test_replay_ring_cursors_indices_and_rows():
     assert list(g["cursor2"][:3]) == [max_size, max_size, 0]  # lands exactly on max_size: not yet "full"
 
 
+def test_cum_rewards_matches_reference_bitwise():
+    """AgentBase.get_cumulative_rewards run through ReplayBuffer.update_cum_rewards by the reference (4 appends, one wrapping
+    with p < add_size): the fp32 numpy restatement reproduces the recorded returns bit for bit, and the slice rule too."""
+    g = load("cum_rewards.npz")
+    N, S, A, max_size = [int(x) for x in g["dims"]]
+    gamma = float(g["gamma"][0])
+    cum = np.zeros((max_size, N), np.float32)
+    for k in range(len(g["adds"])):
+        p, cur, full, add = [int(x) for x in g[f"cursor{k}"]]
+        p0, p1 = O.cum_rewards_slice(p, add, max_size)
+        assert [p0, p1] == list(g[f"slice{k}"])
+        out = O.cum_rewards(g[f"rewards{k}"][p0:p1], g[f"undones{k}"][p0:p1], g[f"next_value{k}"], gamma)
+        np.testing.assert_array_equal(out, g[f"direct{k}"])
+        cum[p0:p1] = out
+        np.testing.assert_array_equal(cum, g[f"cum_rewards{k}"])
+    assert list(g["slice2"]) == [max_size - 11, max_size]      # the p < add_size branch was exercised
+
+
 @pytest.mark.parametrize("name", PPO_GOLDENS)
 def test_c_oracle_gae_bitwise_equals_numpy_and_matches_reference(name):
     from oracle import c_oracle

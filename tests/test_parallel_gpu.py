@@ -20,25 +20,27 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False):
+    gpu = rank if one_gpu_per_rank else 0
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(gpu), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from elegantrl_amd import parallel
     from elegantrl_amd.agents import AgentPPO
     from elegantrl_amd.envs import SynVecEnv
     from elegantrl_amd.train import Config
-    parallel.init_from_env(backend="gloo")
-    th.cuda.set_device(0)
+    parallel.init_from_env(backend=backend)
+    th.cuda.set_device(gpu)
     N, S, A, H, B = 256, 64, 8, 16, 1024
     args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
                                         "if_discrete": False})
     args.horizon_len, args.batch_size, args.repeat_times = H, B, 3 * B / H
     args.learning_rate, args.random_seed = 1e-3, 5
-    args.world_size, args.rank, args.gpu_id = world, rank, 0
+    args.world_size, args.rank, args.gpu_id = world, rank, gpu
     th.manual_seed(100 + rank)                                  # ranks start from DIFFERENT weights on purpose
-    agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
+    agent = AgentPPO(args.net_dims, S, A, gpu_id=gpu, args=args)
     parallel.broadcast_(agent._flat)
     w0 = agent._flat.clone()
-    env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=7919 * rank)
+    env = SynVecEnv(N, S, A, max_step=50, gpu_id=gpu, seed=7919 * rank)
     agent.last_state = env.reset()[0]
     logs = []
     for _ in range(2):
@@ -49,9 +51,10 @@ def _worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, f"stats_{rank}.npy"), agent._stats.cpu().numpy())
     np.save(os.path.join(out_dir, f"rew_{rank}.npy"), items[3].cpu().numpy())
     np.save(os.path.join(out_dir, f"logs_{rank}.npy"), np.array(logs))
+    comm = parallel.gradient_comm()
+    np.save(os.path.join(out_dir, f"comm_{rank}.npy"), np.array([comm is not None, comm.world if comm is not None else 0]))
     parallel.barrier()
-    import torch.distributed as dist
-    dist.destroy_process_group()
+    parallel.shutdown()
 
 
 @pytest.mark.timeout(600)
@@ -68,6 +71,29 @@ def test_two_rank_agent_stays_in_lockstep(tmp_path):
     np.testing.assert_array_equal(w[0], w[1])                         # ... identically on both ranks
     np.testing.assert_allclose(logs[0], logs[1], rtol=1e-6)           # logged objectives are global means
     assert np.isfinite(w[0]).all() and np.isfinite(logs[0]).all()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(th.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rank_rccl_one_gpu_per_rank(tmp_path):
+    """The multi-GPU path as the 8-GPU run takes it: backend "nccl" (= RCCL over xGMI), one GPU per rank, the library's own
+    communicator (erl_comm_init with world > 1) issuing the gradient all-reduce from inside erl_ppo_update_dp_f32.  Ranks
+    end bit-identical to each other AND to the gloo route on the same two GPUs (a two-term sum is order-free, so any
+    all-reduce algorithm yields the same bits)."""
+    world = 2
+    (tmp_path / "rccl").mkdir()
+    (tmp_path / "gloo").mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / "rccl"), "nccl", True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / "gloo"), "gloo", True), nprocs=world, join=True)
+    ld = lambda d, n: [np.load(tmp_path / d / f"{n}_{r}.npy") for r in range(world)]   # noqa: E731
+    comm = ld("rccl", "comm")
+    assert all(c[0] == 1 and c[1] == world for c in comm), "the library RCCL communicator did not come up with world = 2"
+    assert all(c[0] == 0 for c in ld("gloo", "comm"))
+    w, wg = ld("rccl", "w"), ld("gloo", "w")
+    np.testing.assert_array_equal(w[0], w[1])                         # ranks in lockstep over RCCL
+    np.testing.assert_array_equal(w[0], wg[0])                        # RCCL route == torch.distributed/gloo route
+    np.testing.assert_array_equal(ld("rccl", "stats")[0], ld("gloo", "stats")[0])
+    assert not np.array_equal(w[0], ld("rccl", "w0")[0]) and np.isfinite(w[0]).all()
 
 
 # ---- the library-owned RCCL communicator (erl_comm_*) on one rank --------------------------------------------------
