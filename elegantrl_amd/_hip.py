@@ -48,6 +48,11 @@ _SIGNATURES = {
     "erl_value_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     "erl_rollout_step_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_uint64, c_uint64,
                                      _P, _P, _P, _P, _P]),
+    "erl_rollout_fused_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "erl_rollout_synenv_f32": (c_int, [_P] * 6 + [c_int] * 4 + [_P] * 5 + [c_int, c_uint64, c_int64, c_int64, _P, c_uint64, c_uint64,
+                                       c_float] + [_P] * 9),
+    "erl_rollout_pendulum_f32": (c_int, [_P] * 6 + [c_int] * 2 + [_P] * 4 + [c_int, c_uint64, c_int64, c_int64, _P, c_uint64,
+                                         c_uint64, c_float] + [_P] * 9),
     "erl_ppo_slab_stride": (c_int64, [c_int, c_int, c_int, c_int]),
     "erl_ppo_num_slabs": (c_int, [c_int64]),
     "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,

@@ -163,6 +163,13 @@ class AgentPPO(AgentBase):
         self._grads = None
         self._stats = None
         self._env_action = None
+        # GPU-resident envs that expose `fused_rollout` get the whole horizon in ONE launch (csrc/rollout_fused.hip), which
+        # also leaves the critic's values of the visited states for update_net; ERL_FUSED_ROLLOUT=0 / args.fused_rollout=False
+        # keep the per-step launches (A/B runs, parity tests)
+        import os
+        self.fused_rollout = bool(getattr(args, "fused_rollout", os.environ.get("ERL_FUSED_ROLLOUT", "1") != "0"))
+        self._rollout_cache = None
+        self._norm_version = 0
 
     # ---- checkpoints: AgentBase.save_or_load_agent (AgentBase.py:280-297) + the flat Adam state ------
     def save_or_load_agent(self, cwd: str, if_save: bool):
@@ -256,6 +263,23 @@ class AgentPPO(AgentBase):
         state = state.to(dev, th.float32).contiguous()
         if hasattr(env, "raw_stepper") and state.data_ptr() != env.state.data_ptr():
             env.state.copy_(state)                 # the env owns the live state buffer; keep it authoritative
+        self._rollout_cache = None
+        if (self.fused_rollout and self._fused and hasattr(env, "fused_rollout") and getattr(env, "num_envs", None) == N
+                and getattr(env, "device", None) == dev
+                and _hip.lib().erl_rollout_fused_supported(S, self.net_dims[0], self.net_dims[1], A)):
+            # one persistent launch for all H steps: policy, env, buffer rows, reward scaling, flag inversion AND the critic's
+            # values of every visited state + cri(last_state) (update_net's pre-pass, AgentPPO.py:141-143, :219-220)
+            undones = th.empty((H, N), dtype=th.bool, device=dev)
+            unmasks = th.empty((H, N), dtype=th.bool, device=dev)
+            values = th.empty((H, N), dtype=th.float32, device=dev)
+            next_value = th.empty((N,), dtype=th.float32, device=dev)
+            noise = None if noise is None else noise.contiguous()
+            env.fused_rollout(self, H, noise, (states, actions, logprobs, rewards, undones, unmasks), values, next_value)
+            self.rng_counter += H
+            self.last_state = env.state.clone()
+            self._rollout_cache = dict(states=states, values=values, next_value=next_value, last_state=self.last_state,
+                                       key=self._value_cache_key(states, self.last_state))
+            return states, actions, logprobs, rewards, undones, unmasks
         rollout_step = ops.rollout_step if self._fused else ops.mlpn_rollout_step
         if hasattr(env, "raw_stepper") and self._fused:
             # GPU-resident env: both launches of a step go straight to the C ABI on raw pointers (no tensor views, no
@@ -351,10 +375,27 @@ class AgentPPO(AgentBase):
 
     get_reward_sum_gae = get_advantages   # older spelling used by the north star / stale tests
 
-    def _gae(self, rewards, undones, unmasks, values, with_ret=True, stats=None):
+    def _value_cache_key(self, states: TEN, last_state: TEN):
+        """what the values left by the fused rollout depend on: the very tensors, the critic's weights (Adam step, in-place
+        torch edits of the flat block, the module object) and the normalisation vectors."""
+        return (states.data_ptr(), states._version, tuple(states.shape), last_state.data_ptr(), last_state._version,
+                self._adam_step, self._flat._version, id(self.cri), self._norm_version,
+                sum(p._version for p in self.cri.parameters()))      # in-place edits / load_state_dict of the critic
+
+    def _cached_values(self, states: TEN):
+        """(values, next_value) computed by the fused rollout for exactly this buffer and this critic, else None."""
+        c = self._rollout_cache
+        if c is None or states is not c["states"] or self.last_state is not c["last_state"]:
+            return None
+        if not self._flat_c.is_bound(self.cri) or c["key"] != self._value_cache_key(states, self.last_state):
+            return None
+        return c["values"], c["next_value"]
+
+    def _gae(self, rewards, undones, unmasks, values, with_ret=True, stats=None, next_value=None):
         from .. import ops
         self._require_gpu("get_advantages")
-        next_value = self.get_values(self.last_state.to(self.device, th.float32))
+        if next_value is None:
+            next_value = self.get_values(self.last_state.to(self.device, th.float32))
         return ops.gae_scan(rewards, undones, unmasks, values, next_value, float(self.gamma), float(self.lambda_gae_adv),
                             use_v_trace=bool(self.if_use_v_trace), mutate=True, algo=self.gae_algo, with_ret=with_ret,
                             stats=stats)
@@ -374,8 +415,13 @@ class AgentPPO(AgentBase):
         if self._stats is None:
             self._stats = th.zeros(8, dtype=th.float64, device=dev)
 
-        values = self.get_values(states)                                              # (H, N)
-        advantages, reward_sums = self._gae(rewards, undones, unmasks, values, stats=self._stats)
+        cached = self._cached_values(states)
+        if cached is not None:                                                        # left by the fused rollout (same critic)
+            values, next_value = cached
+            self._rollout_cache = None                                                # the GAE below mutates rewards / undones
+        else:
+            values, next_value = self.get_values(states), None                        # (H, N)
+        advantages, reward_sums = self._gae(rewards, undones, unmasks, values, stats=self._stats, next_value=next_value)
         if self.world_size > 1:                                                       # one normalisation for the whole job
             parallel.all_reduce_sum(self._stats)
         advantages = ops.adv_normalize(advantages, self._stats, out=advantages)
@@ -467,6 +513,7 @@ class AgentPPO(AgentBase):
         tau = self.state_value_tau
         if tau == 0:
             return
+        self._norm_version += 1
         state_avg = states.mean(dim=0, keepdim=True)
         state_std = states.std(dim=0, keepdim=True)
         with th.no_grad():

@@ -12,7 +12,6 @@
 
 namespace {
 
-constexpr float kLogSqrt2PiF = 0.91893853320467274178f;  // log(sqrt(2 pi))
 constexpr int64_t kSplitMaxEnvs = 16384;
 
 // LDS pool of the forward kernels (floats): [W2 copy 128 x 132][W1 copy 128 x 132][W3 copy 16 x 132][b1 | b2 | b3]
@@ -209,14 +208,6 @@ __global__ __launch_bounds__(256) void rollout_step2_kernel(FwdArgs g)
     lp += __shfl_xor(lp, 16, 64);
     lp += __shfl_xor(lp, 32, 64);
     if (valid && q == 0 && g.o_logprob) g.o_logprob[row] = lp;
-}
-
-// tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2 |x|) in (0, 1]: no overflow, no cancellation in 1 + e;
-// 1 - e loses nothing below |x| ~ 1e-4 that the result's own fp32 ulp would show (abs err < 2e-7).
-__device__ __forceinline__ float fast_tanh(float x)
-{
-    const float e = __expf(-2.f * fabsf(x));
-    return copysignf(__fdividef(1.f - e, 1.f + e), x);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -46,6 +46,16 @@ __device__ __forceinline__ void lds_barrier()
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+constexpr float kLogSqrt2PiF = 0.91893853320467274178f;  // log(sqrt(2 pi))
+
+// tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2 |x|) in (0, 1]: no overflow, no cancellation in 1 + e;
+// 1 - e loses nothing below |x| ~ 1e-4 that the result's own fp32 ulp would show (abs err < 2e-7).
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    const float e = __expf(-2.f * fabsf(x));
+    return copysignf(__fdividef(1.f - e, 1.f + e), x);
+}
+
 // exact-erf GELU and its derivative.  erf through Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, the size of an fp32
 // ulp of the result), sharing exp(-z^2/2) with the Gaussian density of the derivative: ~20 VALU ops instead of ~70.
 __device__ __forceinline__ void gelu_and_grad_fast(float z, float &y, float &gd)

@@ -1,0 +1,612 @@
+// Persistent H-step rollout for device-resident environments: ONE launch per AgentPPO.explore_env.  gfx950 / fp32 MFMA.
+//
+// Replaces the whole loop of AgentPPO._explore_vec_env (elegantrl/agents/AgentPPO.py:87-129): for t in range(H):
+// ActorPPO.get_action (:368-376), the three buffer stores (:115-117), convert_action_for_env (:388-390), env.step, the
+// reward / flag stores (:121-123); then `rewards *= reward_scale` and the two logical_not (:126-128).  It also evaluates
+// CriticPPO (:435-441) on every state it visits -- the value pre-pass of update_net (:141-143) and the bootstrap value
+// cri(last_state) (:219-220) -- so that update_net finds them ready (same critic weights: nothing trains during a rollout).
+//
+// Envs are independent, so a workgroup (8 waves) owns a 16-env tile for all H steps; nothing crosses workgroups and there
+// is no launch, no weight re-read and no HBM round trip between steps:
+//   * wave w holds rows 16 w .. 16 w + 15 of W2 of BOTH networks (the big operand: 2 x 32 VGPRs) and its k-slice of the
+//     output layers in registers as MFMA A operands for the whole rollout (v_mfma_f32_16x16x4_f32; the layout of the
+//     latency-form step kernel, mlp.hip rollout_split_kernel); the W1 images and -- SynVecEnv -- Ws^T / Wa^T sit in LDS
+//     (one conflict-free ds_read_b128 per 4 MFMAs), loaded once per launch;
+//   * the state tile lives in LDS (XS); per step: L1 of both nets -> H1 tiles to LDS -> barrier -> L2 + output-layer
+//     partials -> LDS -> barrier -> waves < ceil(S/16) finish the policy head in registers (action, log-prob, tanh) and
+//     step the env on the matrix cores, wave 7 finishes the value, waves 4..7 draw the next step's N(0,1) (injected or
+//     Philox4x32-10) -> barrier -> done flags, auto-reset, new state tile -> barrier.  Four LDS-only barriers per step; the
+//     per-step chain is MFMA-bound (~100 kFLOP per env-step);
+//   * every buffer row is written straight from the kernel: states / actions (pre-tanh) / logprobs / rewards (already
+//     multiplied by reward_scale) / undones = !terminal / unmasks = !truncate / values, time-major (H, N, .).
+// The arithmetic of a step is instruction-for-instruction that of erl_rollout_step_f32's latency form followed by
+// erl_synenv_step_f32's tile form (or erl_pendulum_step_f32), so the six rollout buffers are bit-identical to the per-step
+// path under the same Philox keys / injected noise (tests/test_rollout_fused_gpu.py).
+#include <type_traits>
+
+#include "erl_common.h"
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int RF_NSM = 4;      // state k-tiles of 16 held per lane: state_dim <= 64
+constexpr int RF_XLD = 68;     // row stride of the state tile XS[16][.]
+constexpr int RF_TLD = 132;    // row stride of the H1 tiles (as kSplitLd in mlp.hip)
+
+struct RfArgs {
+    const float *Pa, *Pc;                          // actor / critic flat parameter blocks (include/erl_hip.h)
+    const float *avg_a, *std_a, *avg_c, *std_c;
+    int S, h1, h2, A;
+    int64_t N;
+    int H;
+    const float *noise;                            // (H, N, A) or NULL
+    uint64_t seed, counter0;
+    float reward_scale;
+    float *o_states, *o_actions, *o_logprobs, *o_rewards;
+    uint8_t *o_undones, *o_unmasks;
+    float *o_values, *o_next_value;                // may be NULL
+    // environment
+    float *env_state;                              // (N, S) live state (SynVecEnv.state / PendulumVecEnv.state = obs)
+    float *phys;                                   // Pendulum: (N, 2) theta, theta_dot
+    const float *Ws, *Wa;                          // SynVecEnv
+    int32_t *step_count, *episode;
+    int max_step;
+    uint64_t env_seed;
+    long long *prof;                               // ERL_PROFILE builds only: [wave][16] s_memtime stamps of workgroup 0, step 5
+};
+
+#ifdef ERL_PROFILE
+long long *g_rf_prof = nullptr;
+#define RFPROF(i)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if (g.prof && blockIdx.x == 0 && lane == 0 && t == 5) g.prof[wave * 16 + (i)] = (long long)t_;  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define RFPROF(i) do { } while (0)
+#endif
+
+enum { ENV_SYN = 0, ENV_PENDULUM = 1 };
+
+constexpr int RF_WLD = 68;     // row stride of the LDS operand images (W1 rows, Ws^T rows): 16-byte rows, 4 banks apart
+// dynamic LDS layout (floats)
+constexpr int RF_O_XS = 0;                              // [16][RF_XLD]   state tile
+constexpr int RF_O_XA = RF_O_XS + 16 * RF_XLD;          // [16][RF_XLD]   state tile normalised for the actor
+constexpr int RF_O_XC = RF_O_XA + 16 * RF_XLD;          // [16][RF_XLD]   ... for the critic
+constexpr int RF_O_NRM = RF_O_XC + 16 * RF_XLD;         // [4][64]        avg_a | den_a | avg_c | den_c  (den = std + 1e-4)
+constexpr int RF_O_T1A = RF_O_NRM + 4 * 64;             // [16][RF_TLD]   actor H1 tile
+constexpr int RF_O_T1C = RF_O_T1A + 16 * RF_TLD;        // [16][RF_TLD]   critic H1 tile
+constexpr int RF_O_PSA = RF_O_T1C + 16 * RF_TLD;        // [8][64][4]     actor output-layer partials
+constexpr int RF_O_PSC = RF_O_PSA + 8 * 64 * 4;         // [8][16]        critic output-layer partials
+constexpr int RF_O_EPS = RF_O_PSC + 8 * 16;             // [2][16][16]    N(0,1) draws of step t (t & 1) and t + 1, produced a step ahead
+constexpr int RF_O_RED = RF_O_EPS + 2 * 16 * 16;        // [8][16][2]     env reductions
+constexpr int RF_O_W1A = RF_O_RED + 8 * 16 * 2;         // [128][RF_WLD]  actor W1 (rows >= h1 / cols >= S zero)
+constexpr int RF_O_W1C = RF_O_W1A + 128 * RF_WLD;       // [128][RF_WLD]  critic W1
+constexpr int RF_O_WST = RF_O_W1C + 128 * RF_WLD;       // [64][RF_WLD]   Ws^T: WST[j][k] = Ws[k][j]
+constexpr int RF_O_WAT = RF_O_WST + 64 * RF_WLD;        // [64][16]       Wa^T
+constexpr int RF_FLOATS = RF_O_WAT + 64 * 16;
+constexpr size_t kRfLdsBytes = (size_t)RF_FLOATS * sizeof(float);
+
+// NS_ / N1_ / N2_: k-tiles of the state / hidden layers as compile-time constants for the tuned shapes (0 = read them from
+// the arguments): with them the step body is straight-line code between barriers, which lets the scheduler interleave the
+// LDS operand reads, the divisions of the normalisation and the GELUs with the MFMA chains.
+template <int ENV, bool VEC, int NS_, int N1_, int N2_>
+__global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *XS = smem + RF_O_XS, *XA = smem + RF_O_XA, *XC = smem + RF_O_XC, *NRM = smem + RF_O_NRM, *T1A = smem + RF_O_T1A, *T1C = smem + RF_O_T1C, *PSA = smem + RF_O_PSA;
+    float *PSC = smem + RF_O_PSC, *EPS = smem + RF_O_EPS, *RED = smem + RF_O_RED;
+    float *W1A = smem + RF_O_W1A, *W1C = smem + RF_O_W1C, *WST = smem + RF_O_WST, *WAT = smem + RF_O_WAT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const Dims da{g.S, g.h1, g.h2, g.A}, dc{g.S, g.h1, g.h2, 1};
+    const int S = g.S, A = g.A, ns = NS_ ? NS_ : (S + 15) >> 4, n1 = N1_ ? N1_ : g.h1 >> 4, n2 = N2_ ? N2_ : g.h2 >> 4;
+    const bool on1 = wave < n1, on2 = wave < n2;
+    const int64_t env0 = (int64_t)blockIdx.x * 16;
+    const int64_t env = env0 + l15;
+    const bool valid = env < g.N;
+    const int64_t row = valid ? env : g.N - 1;          // rows past N replay env N - 1 (never stored)
+    const int H = g.H;
+    const size_t N = (size_t)g.N;
+
+    // ---- state tile (raw, and normalised for either network: (s - avg) / (std + 1e-4), AgentPPO.py:360-361, :440-441) and
+    // the normalisation constants into LDS; columns >= S stay 0 for the whole rollout.  The normalised tiles are written by
+    // whoever produces a state (here, then the env waves): 8 divides per producing lane per step instead of 32 per lane in
+    // every one of the 8 waves that consume the tile as an MFMA B operand.
+    for (int e = tid; e < 16 * 64; e += 512) {
+        const int i = e >> 6, k = e & 63, kc = min(k, S - 1);
+        const int64_t r_ = min(env0 + i, g.N - 1);
+        const float x = g.env_state[r_ * S + kc];
+        XS[i * RF_XLD + k] = (k < S) ? x : 0.f;
+        XA[i * RF_XLD + k] = (k < S) ? (x - g.avg_a[kc]) / (g.std_a[kc] + 1e-4f) : 0.f;
+        XC[i * RF_XLD + k] = (k < S) ? (x - g.avg_c[kc]) / (g.std_c[kc] + 1e-4f) : 0.f;
+    }
+    if (tid < 256) {
+        const int which = tid >> 6, k = tid & 63, kc = min(k, S - 1);
+        float v;
+        if (which == 0) v = g.avg_a[kc];
+        else if (which == 1) v = g.std_a[kc] + 1e-4f;
+        else if (which == 2) v = g.avg_c[kc];
+        else v = g.std_c[kc] + 1e-4f;
+        if (k >= S) v = (which & 1) ? 1.f : 0.f;
+        NRM[tid] = v;
+    }
+    // W1 images of both networks, rows clamped like the step kernel's register loads, columns >= S zero
+    for (int e = tid; e < 128 * 64; e += 512) {
+        const int i = e >> 6, k = e & 63;
+        const size_t src = (size_t)min(i, g.h1 - 1) * S + min(k, S - 1);
+        W1A[i * RF_WLD + k] = (k < S) ? g.Pa[da.oW1() + src] : 0.f;
+        W1C[i * RF_WLD + k] = (k < S) ? g.Pc[dc.oW1() + src] : 0.f;
+    }
+    if (ENV == ENV_SYN) {
+        for (int e = tid; e < 64 * 64; e += 512) {           // WST[j][k] = Ws[k][j]  (coalesced along j)
+            const int k = e >> 6, jj = e & 63;
+            WST[jj * RF_WLD + k] = (k < S && jj < S) ? g.Ws[(size_t)k * S + jj] : 0.f;
+        }
+        for (int e = tid; e < 16 * 64; e += 512) {
+            const int k = e >> 6, jj = e & 63;
+            WAT[jj * 16 + k] = (k < A && jj < S) ? g.Wa[(size_t)k * S + jj] : 0.f;
+        }
+    }
+
+    // ---- the wave's rows of W2 of both networks, held in registers for the whole rollout
+    float4 w2a[8], w2c[8];
+    {
+        const float *ra2 = g.Pa + da.oW2() + (size_t)min(16 * wave + l15, da.h2 - 1) * da.h1;
+        const float *rc2 = g.Pc + dc.oW2() + (size_t)min(16 * wave + l15, dc.h2 - 1) * dc.h1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            w2a[t] = (t < n1) ? load4<VEC>(ra2, 16 * t + 4 * q, da.h1) : zero4();
+            w2c[t] = (t < n1) ? load4<VEC>(rc2, 16 * t + 4 * q, dc.h1) : zero4();
+        }
+    }
+    const float *w1a_row = W1A + (16 * wave + l15) * RF_WLD + 4 * q, *w1c_row = W1C + (16 * wave + l15) * RF_WLD + 4 * q;
+    const int kt = min(wave, n2 - 1);                      // this wave's k-tile of the output layers
+    float4 w3a = load4<VEC>(g.Pa + da.oW3() + (size_t)min(l15, A - 1) * da.h2, 16 * kt + 4 * q, da.h2);
+    if (l15 >= A || !on2) w3a = zero4();
+    float4 w3c = load4<VEC>(g.Pc + dc.oW3(), 16 * kt + 4 * q, dc.h2);
+    if (l15 >= 1 || !on2) w3c = zero4();
+    const float4 b1a = load4<VEC>(g.Pa + da.ob1(), 16 * min(wave, n1 - 1) + 4 * q, da.h1);
+    const float4 b2a = load4<VEC>(g.Pa + da.ob2(), 16 * kt + 4 * q, da.h2);
+    const float4 b1c = load4<VEC>(g.Pc + dc.ob1(), 16 * min(wave, n1 - 1) + 4 * q, dc.h1);
+    const float4 b2c = load4<VEC>(g.Pc + dc.ob2(), 16 * kt + 4 * q, dc.h2);
+    float sl[4], b3a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ac = min(4 * q + r, A - 1);
+        sl[r] = g.Pa[da.oStd() + ac];
+        b3a[r] = g.Pa[da.ob3() + ac];
+    }
+    const float b3c = g.Pc[dc.ob3()];
+
+    // ---- the environment's per-lane constants
+    const int nt = (ENV == ENV_SYN) ? ns : 1;                // waves that step the environment (<= 4: state_dim <= 64)
+    const float *wst_row = WST + ((16 * wave + l15) & 63) * RF_WLD + 4 * q, *wat_row = WAT + ((16 * wave + l15) & 63) * 16 + 4 * q;
+    int sc = g.step_count[row], ep = g.episode[row];
+    float th = 0.f, thdot = 0.f;
+    if (ENV == ENV_PENDULUM) { th = g.phys[2 * row]; thdot = g.phys[2 * row + 1]; }
+
+    // The N(0,1) draws of step t are produced one step ahead by waves 4..7 (idle while waves < nt step the environment):
+    // wave 4 + r, lane (m, q) owns eps[m][4 q + r] -- injected noise[t] or Philox4x32-10 + Box-Muller keyed by
+    // (seed, counter0 + t, env, action-dim) -- so the ~600-cycle draw never sits on the step's dependent chain.
+    auto draw = [&](int t) {
+        if (wave >= 4 && t < H) {
+            const int r = wave - 4, ac = min(4 * q + r, A - 1);
+            const float e = g.noise ? g.noise[((size_t)t * N + row) * A + ac]
+                                    : philox_normal(g.seed, g.counter0 + (uint64_t)t, (uint32_t)row, (uint32_t)ac);
+            EPS[(t & 1) * 256 + l15 * 16 + 4 * q + r] = e;
+        }
+    };
+    draw(0);
+    __syncthreads();
+
+    // one step; LAST = the extra pass after the horizon that only evaluates the critic on the final state (bootstrap value).
+    // Compile-time so that the H regular steps carry no `last` branches between their MFMA groups.
+    auto step = [&](int t, auto last_c) {
+        constexpr bool last = decltype(last_c)::value;
+        // ================= phase 0: state tile -> registers; states[t]; layer 1 of both networks =================
+        RFPROF(0);
+        float4 R[RF_NSM];                    // raw state: B operand of the env step (waves < nt), states[t] (wave 7)
+        if (!last && (wave < nt || wave == 7)) {
+#pragma unroll
+            for (int tt = 0; tt < RF_NSM; ++tt)
+                R[tt] = (tt < ns) ? *reinterpret_cast<const float4 *>(XS + l15 * RF_XLD + 16 * tt + 4 * q) : zero4();
+        }
+        if (wave == 7 && !last && valid) {   // states[t] = state (AgentPPO.py:115)
+            float *dst0 = g.o_states + ((size_t)t * N + row) * S;
+#pragma unroll
+            for (int tt = 0; tt < RF_NSM; ++tt) {
+                if (tt < ns) {
+                    const int k0 = 16 * tt + 4 * q;
+                    if (VEC) { if (k0 < S) *reinterpret_cast<float4 *>(dst0 + k0) = R[tt]; }
+                    else {
+                        const float xr[4] = {R[tt].x, R[tt].y, R[tt].z, R[tt].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (k0 + c < S) dst0[k0 + c] = xr[c];
+                    }
+                }
+            }
+        }
+        {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tt = 0; tt < RF_NSM; ++tt) {
+                if (tt < ns) {
+                    if (!last) {
+                        const float4 xa = *reinterpret_cast<const float4 *>(XA + l15 * RF_XLD + 16 * tt + 4 * q);
+                        const float4 w1 = *reinterpret_cast<const float4 *>(w1a_row + 16 * tt);
+                        a0 = mfma16(w1.x, xa.x, a0);
+                        a1 = mfma16(w1.y, xa.y, a1);
+                        a0 = mfma16(w1.z, xa.z, a0);
+                        a1 = mfma16(w1.w, xa.w, a1);
+                    }
+                    const float4 xc = *reinterpret_cast<const float4 *>(XC + l15 * RF_XLD + 16 * tt + 4 * q);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(w1c_row + 16 * tt);
+                    c0 = mfma16(w1.x, xc.x, c0);
+                    c1 = mfma16(w1.y, xc.y, c1);
+                    c0 = mfma16(w1.z, xc.z, c0);
+                    c1 = mfma16(w1.w, xc.w, c1);
+                }
+            }
+            if (on1) {
+                float h[4], gd;
+                if (!last) {
+                    const float bb[4] = {b1a.x, b1a.y, b1a.z, b1a.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
+                    *reinterpret_cast<float4 *>(T1A + l15 * RF_TLD + 16 * wave + 4 * q) = make_float4(h[0], h[1], h[2], h[3]);
+                }
+                const float bc[4] = {b1c.x, b1c.y, b1c.z, b1c.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gelu_and_grad_fast((c0[r] + c1[r]) + bc[r], h[r], gd);
+                *reinterpret_cast<float4 *>(T1C + l15 * RF_TLD + 16 * wave + 4 * q) = make_float4(h[0], h[1], h[2], h[3]);
+            }
+        }
+        RFPROF(1);
+        lds_barrier();                                                                               // (1) H1 tiles
+        RFPROF(2);
+
+        // ================= phase 1: layer 2 + the output-layer partials of this wave's k-slice =================
+        {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                if (tt < n1) {
+                    if (!last) {
+                        const float4 hv = *reinterpret_cast<const float4 *>(T1A + l15 * RF_TLD + 16 * tt + 4 * q);
+                        a0 = mfma16(w2a[tt].x, hv.x, a0);
+                        a1 = mfma16(w2a[tt].y, hv.y, a1);
+                        a0 = mfma16(w2a[tt].z, hv.z, a0);
+                        a1 = mfma16(w2a[tt].w, hv.w, a1);
+                    }
+                    const float4 hc = *reinterpret_cast<const float4 *>(T1C + l15 * RF_TLD + 16 * tt + 4 * q);
+                    c0 = mfma16(w2c[tt].x, hc.x, c0);
+                    c1 = mfma16(w2c[tt].y, hc.y, c1);
+                    c0 = mfma16(w2c[tt].z, hc.z, c0);
+                    c1 = mfma16(w2c[tt].w, hc.w, c1);
+                }
+            }
+            float h[4], gd;
+            if (!last) {
+                const float bb[4] = {b2a.x, b2a.y, b2a.z, b2a.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
+                f32x4 part = {0.f, 0.f, 0.f, 0.f};
+                part = mfma16(w3a.x, h[0], part);
+                part = mfma16(w3a.y, h[1], part);
+                part = mfma16(w3a.z, h[2], part);
+                part = mfma16(w3a.w, h[3], part);
+                *reinterpret_cast<float4 *>(PSA + (wave * 64 + lane) * 4) =
+                    on2 ? make_float4(part[0], part[1], part[2], part[3]) : zero4();
+            }
+            const float bc[4] = {b2c.x, b2c.y, b2c.z, b2c.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast((c0[r] + c1[r]) + bc[r], h[r], gd);
+            f32x4 pc = {0.f, 0.f, 0.f, 0.f};
+            pc = mfma16(w3c.x, h[0], pc);
+            pc = mfma16(w3c.y, h[1], pc);
+            pc = mfma16(w3c.z, h[2], pc);
+            pc = mfma16(w3c.w, h[3], pc);
+            if (q == 0) PSC[wave * 16 + l15] = on2 ? pc[0] : 0.f;
+        }
+        RFPROF(3);
+        lds_barrier();                                                                               // (2) partials
+        RFPROF(4);
+
+        // ================= phase 2: value (wave 7); policy head + environment step (waves < nt); next draws (waves 4..7) ====
+        if (wave == 7) {
+            float p[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) p[w] = PSC[w * 16 + l15];
+            const float v = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + b3c;
+            if (valid && q == 0) {
+                if (last) { if (g.o_next_value) g.o_next_value[row] = v; }
+                else if (g.o_values) g.o_values[(size_t)t * N + row] = v;
+            }
+        }
+        if (last) return;
+        draw(t + 1);
+        float out[4] = {0.f, 0.f, 0.f, 0.f}, a2 = 0.f, pend_cost = 0.f;
+        const int j0 = 16 * wave + 4 * q;
+        if (wave < nt) {
+            // every env wave finishes the policy head for its own lanes (same fixed-order sum, same draws: bit-identical in
+            // all of them), so tanh(action) reaches the env's MFMA B operand -- k = 4 q + r -- without an LDS round trip
+            float Y[4];
+            {
+                float4 p[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) p[w] = *reinterpret_cast<const float4 *>(PSA + (w * 64 + lane) * 4);
+                Y[0] = ((p[0].x + p[1].x) + (p[2].x + p[3].x)) + ((p[4].x + p[5].x) + (p[6].x + p[7].x)) + b3a[0];
+                Y[1] = ((p[0].y + p[1].y) + (p[2].y + p[3].y)) + ((p[4].y + p[5].y) + (p[6].y + p[7].y)) + b3a[1];
+                Y[2] = ((p[0].z + p[1].z) + (p[2].z + p[3].z)) + ((p[4].z + p[5].z) + (p[6].z + p[7].z)) + b3a[2];
+                Y[3] = ((p[0].w + p[1].w) + (p[2].w + p[3].w)) + ((p[4].w + p[5].w) + (p[6].w + p[7].w)) + b3a[3];
+            }
+            const float4 e4 = *reinterpret_cast<const float4 *>(EPS + (t & 1) * 256 + l15 * 16 + 4 * q);
+            const float eps[4] = {e4.x, e4.y, e4.z, e4.w};
+            // a = mean + std * eps (torch.normal(mean, std)); Normal.log_prob summed over the action dims (:373-376)
+            float lp = 0.f, te[4], act[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool on = 4 * q + r < A;
+                const float sdv = expf(sl[r]), var = sdv * sdv;
+                act[r] = Y[r] + sdv * eps[r];
+                const float diff = act[r] - Y[r];
+                const float term = -(diff * diff) / (2.f * var) - sl[r] - kLogSqrt2PiF;
+                lp += on ? term : 0.f;
+                te[r] = on ? fast_tanh(act[r]) : 0.f;                       // convert_action_for_env (:388-390)
+            }
+            if (wave == 0) {
+                lp += __shfl_xor(lp, 16, 64);
+                lp += __shfl_xor(lp, 32, 64);
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * q + r < A) g.o_actions[((size_t)t * N + row) * A + 4 * q + r] = act[r];
+                    if (q == 0) g.o_logprobs[(size_t)t * N + row] = lp;
+                }
+            }
+            if (ENV == ENV_SYN) {
+                // s' = s Ws + a Wa on the matrix cores: wave w < nt owns features 16 w .. 16 w + 15 (envs.hip synenv_tile_kernel)
+                a2 = (te[0] * te[0] + te[1] * te[1]) + (te[2] * te[2] + te[3] * te[3]);
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                const float4 wb = *reinterpret_cast<const float4 *>(wat_row);
+                c0 = mfma16(wb.x, te[0], c0);
+                c1 = mfma16(wb.y, te[1], c1);
+                c0 = mfma16(wb.z, te[2], c0);
+                c1 = mfma16(wb.w, te[3], c1);
+#pragma unroll
+                for (int tt = 0; tt < RF_NSM; ++tt) {
+                    if (tt < ns) {
+                        const float4 wa = *reinterpret_cast<const float4 *>(wst_row + 16 * tt);
+                        c0 = mfma16(wa.x, R[tt].x, c0);
+                        c1 = mfma16(wa.y, R[tt].y, c1);
+                        c0 = mfma16(wa.z, R[tt].z, c0);
+                        c1 = mfma16(wa.w, R[tt].w, c1);
+                    }
+                }
+                float sq = 0.f, mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    out[r] = c0[r] + c1[r];
+                    if (j0 + r < S) {
+                        sq += out[r] * out[r];
+                        mx = fmaxf(mx, fabsf(out[r]));
+                    }
+                }
+                {   // three independent cross-lane reductions issued together (each hop is an LDS-latency ds_bpermute)
+                    const float a2x = __shfl_xor(a2, 16, 64), sqx = __shfl_xor(sq, 16, 64), mxx = __shfl_xor(mx, 16, 64);
+                    a2 += a2x; sq += sqx; mx = fmaxf(mx, mxx);
+                    const float a2y = __shfl_xor(a2, 32, 64), sqy = __shfl_xor(sq, 32, 64), mxy = __shfl_xor(mx, 32, 64);
+                    a2 += a2y; sq += sqy; mx = fmaxf(mx, mxy);
+                }
+                if (q == 0) { RED[(wave * 16 + l15) * 2] = sq; RED[(wave * 16 + l15) * 2 + 1] = mx; }
+            } else {
+                // Pendulum-v1 behind the reference wrapper's scaling (envs.hip pendulum_step_kernel); lanes q > 0 mirror q = 0
+                const float PI = 3.14159265358979323846f;
+                const float a_env = __shfl(te[0], l15, 64);              // action 0 lives in lane group q = 0
+                float u = 2.f * a_env;
+                u = fminf(fmaxf(u, -2.f), 2.f);
+                const float two_pi = 2.f * PI;
+                float ang = fmodf(th + PI, two_pi);
+                if (ang < 0.f) ang += two_pi;
+                ang -= PI;
+                pend_cost = ang * ang + 0.1f * thdot * thdot + 0.001f * u * u;
+                float nthdot = thdot + (3.f * 10.f / 2.f * sinf(th) + 3.f * u) * 0.05f;
+                nthdot = fminf(fmaxf(nthdot, -8.f), 8.f);
+                out[0] = th + nthdot * 0.05f;                              // new theta
+                out[1] = nthdot;
+            }
+        }
+        RFPROF(5);
+        lds_barrier();                                                                               // (3) env reductions
+        RFPROF(6);
+        if (wave < nt) {
+            if (ENV == ENV_SYN) {
+                float sq = 0.f, mx = 0.f;
+                for (int w = 0; w < nt; ++w) { sq += RED[(w * 16 + l15) * 2]; mx = fmaxf(mx, RED[(w * 16 + l15) * 2 + 1]); }
+                const int sc1 = sc + 1;
+                const bool term = mx > 10.f;
+                const bool trunc = (sc1 >= g.max_step) && !term;
+                const bool done = term || trunc;
+                if (j0 < S) {
+                    if (done) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            out[r] = philox_normal(g.env_seed, (uint64_t)(ep + 1), (uint32_t)row, (uint32_t)(j0 + r));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (j0 + r >= S) out[r] = 0.f;
+                    *reinterpret_cast<float4 *>(XS + l15 * RF_XLD + j0) = make_float4(out[0], out[1], out[2], out[3]);
+                    const float4 aa = *reinterpret_cast<const float4 *>(NRM + j0), ad = *reinterpret_cast<const float4 *>(NRM + 64 + j0);
+                    const float4 ca = *reinterpret_cast<const float4 *>(NRM + 128 + j0), cd = *reinterpret_cast<const float4 *>(NRM + 192 + j0);
+                    *reinterpret_cast<float4 *>(XA + l15 * RF_XLD + j0) =
+                        make_float4((out[0] - aa.x) / ad.x, (out[1] - aa.y) / ad.y, (out[2] - aa.z) / ad.z, (out[3] - aa.w) / ad.w);
+                    *reinterpret_cast<float4 *>(XC + l15 * RF_XLD + j0) =
+                        make_float4((out[0] - ca.x) / cd.x, (out[1] - ca.y) / cd.y, (out[2] - ca.z) / cd.z, (out[3] - ca.w) / cd.w);
+                }
+                if (valid && wave == 0 && q == 0) {
+                    const float rew = -(sq / (float)S) - 0.01f * (a2 / (float)A);
+                    g.o_rewards[(size_t)t * N + row] = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;   // rewards *= reward_scale (:126)
+                    g.o_undones[(size_t)t * N + row] = term ? 0 : 1;                                          // logical_not (:127-128)
+                    g.o_unmasks[(size_t)t * N + row] = trunc ? 0 : 1;
+                }
+                sc = done ? 0 : sc1;
+                if (done) ep = ep + 1;
+            } else {
+                const float PI = 3.14159265358979323846f;
+                float nth = out[0], nthdot = out[1];
+                const int sc1 = sc + 1;
+                const bool trunc = sc1 >= g.max_step;
+                if (trunc) {       // reset: theta ~ U(-pi, pi), theta_dot ~ U(-1, 1)
+                    ep = ep + 1;
+                    const Philox4 p = philox4x32_10((uint32_t)row, 0u, (uint32_t)ep, 0x50454e44u, (uint32_t)g.env_seed,
+                                                    (uint32_t)(g.env_seed >> 32));
+                    nth = ((float)(p.x >> 8) * (1.f / 16777216.f) * 2.f - 1.f) * PI;
+                    nthdot = (float)(p.y >> 8) * (1.f / 16777216.f) * 2.f - 1.f;
+                }
+                th = nth;
+                thdot = nthdot;
+                sc = trunc ? 0 : sc1;
+                if (q == 0) {
+                    const float ob[3] = {cosf(nth), sinf(nth), nthdot};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        XS[l15 * RF_XLD + k] = ob[k];
+                        XA[l15 * RF_XLD + k] = (ob[k] - NRM[k]) / NRM[64 + k];
+                        XC[l15 * RF_XLD + k] = (ob[k] - NRM[128 + k]) / NRM[192 + k];
+                    }
+                    if (valid) {
+                        const float rew = -0.5f * pend_cost;
+                        g.o_rewards[(size_t)t * N + row] = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;
+                        g.o_undones[(size_t)t * N + row] = 1;
+                        g.o_unmasks[(size_t)t * N + row] = trunc ? 0 : 1;
+                    }
+                }
+            }
+        }
+        RFPROF(7);
+        lds_barrier();                                                                               // (4) new state tile visible
+        RFPROF(8);
+    };
+    for (int t = 0; t < H; ++t) step(t, std::false_type{});
+    step(H, std::true_type{});
+
+    // ---- hand the environment back: live state, counters (the per-step kernels keep them in global memory)
+    for (int e = tid; e < 16 * 64; e += 512) {
+        const int i = e >> 6, k = e & 63;
+        if (env0 + i < g.N && k < S) g.env_state[(env0 + i) * S + k] = XS[i * RF_XLD + k];
+    }
+    if (wave == 0 && q == 0 && valid) {
+        g.step_count[row] = sc;
+        g.episode[row] = ep;
+        if (ENV == ENV_PENDULUM) { g.phys[2 * row] = th; g.phys[2 * row + 1] = thdot; }
+    }
+}
+
+bool rf_dims_ok(int S, int h1, int h2, int A)
+{
+    return mlp_dims_ok(S, h1, h2, A) && S <= 16 * RF_NSM;
+}
+
+int rf_launch(RfArgs &g, int env_kind, hipStream_t stream)
+{
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = (g.S % 4 == 0) && al(g.Pa) && al(g.Pc) && al(g.o_states);
+    const dim3 grid((unsigned)erl_cdiv(g.N, 16)), block(512);
+    static bool attr[6] = {false, false, false, false, false, false};
+#define RF_LAUNCH(E, V, A_, B_, C_, SLOT)                                                                                  \
+    do {                                                                                                                   \
+        if (!attr[SLOT]) {                                                                                                 \
+            int rc = erl_hip_status(hipFuncSetAttribute((const void *)rollout_fused_kernel<E, V, A_, B_, C_>,              \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRfLdsBytes),     \
+                                    "hipFuncSetAttribute(rollout_fused_kernel)");                                          \
+            if (rc) return rc;                                                                                             \
+            attr[SLOT] = true;                                                                                             \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((rollout_fused_kernel<E, V, A_, B_, C_>), grid, block, kRfLdsBytes, stream, g);                 \
+    } while (0)
+    const int ns = (g.S + 15) / 16;
+    if (env_kind == ENV_SYN) {
+        if (vec && ns == 4 && g.h1 == 128 && g.h2 == 128) RF_LAUNCH(ENV_SYN, true, 4, 8, 8, 0);      // configs 4 / 5
+        else if (vec) RF_LAUNCH(ENV_SYN, true, 0, 0, 0, 1);
+        else RF_LAUNCH(ENV_SYN, false, 0, 0, 0, 2);
+    } else {
+        if (g.h1 == 128 && g.h2 == 64) RF_LAUNCH(ENV_PENDULUM, false, 1, 8, 4, 3);                    // config 2
+        else RF_LAUNCH(ENV_PENDULUM, false, 0, 0, 0, 4);
+    }
+#undef RF_LAUNCH
+    return erl_hip_status(hipGetLastError(), "rollout_fused_kernel launch");
+}
+
+int rf_fill(RfArgs &g, const char *what, const float *actor_params, const float *critic_params, const float *act_avg,
+            const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, int64_t N, int64_t H,
+            const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states, float *out_actions,
+            float *out_logprobs, float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks, float *out_values,
+            float *out_next_value)
+{
+    ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std, "%s: NULL network tensor", what);
+    ERL_REQUIRE(out_states && out_actions && out_logprobs && out_rewards && out_undones && out_unmasks, "%s: NULL rollout buffer", what);
+    ERL_REQUIRE(rf_dims_ok(S, h1, h2, A), "%s: unsupported dims S=%d net=[%d,%d] A=%d (fused rollout: state_dim <= %d, 2 hidden "
+                "layers of 32..128 in steps of 32, action_dim <= 16)", what, S, h1, h2, A, 16 * RF_NSM);
+    ERL_REQUIRE(N >= 1 && H >= 1 && H < (1LL << 30), "%s: bad shape N=%lld H=%lld", what, (long long)N, (long long)H);
+    g.Pa = actor_params; g.Pc = critic_params;
+    g.avg_a = act_avg; g.std_a = act_std; g.avg_c = cri_avg; g.std_c = cri_std;
+    g.S = S; g.h1 = h1; g.h2 = h2; g.A = A; g.N = N; g.H = (int)H;
+    g.noise = noise; g.seed = seed; g.counter0 = counter0; g.reward_scale = reward_scale;
+    g.o_states = out_states; g.o_actions = out_actions; g.o_logprobs = out_logprobs; g.o_rewards = out_rewards;
+    g.o_undones = out_undones; g.o_unmasks = out_unmasks; g.o_values = out_values; g.o_next_value = out_next_value;
+#ifdef ERL_PROFILE
+    g.prof = g_rf_prof;
+#endif
+    return ERL_OK;
+}
+
+}  // namespace
+
+#ifdef ERL_PROFILE
+// profiling builds only (make EXTRA=-DERL_PROFILE): device buffer of 8 * 16 int64 cycle stamps
+extern "C" __attribute__((visibility("default"))) void erl_debug_set_rollout_fused_profile(long long *dev_buf) { g_rf_prof = dev_buf; }
+#endif
+
+extern "C" int erl_rollout_fused_supported(int S, int h1, int h2, int A) { return rf_dims_ok(S, h1, h2, A) ? 1 : 0; }
+
+extern "C" int erl_rollout_synenv_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
+                                      const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, float *env_state,
+                                      const float *Ws, const float *Wa, int32_t *step_count, int32_t *episode, int max_step,
+                                      uint64_t env_seed, int64_t N, int64_t H, const float *noise, uint64_t seed, uint64_t counter0,
+                                      float reward_scale, float *out_states, float *out_actions, float *out_logprobs,
+                                      float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks, float *out_values,
+                                      float *out_next_value, void *stream)
+{
+    RfArgs g{};
+    int rc = rf_fill(g, "erl_rollout_synenv_f32", actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, N, H,
+                     noise, seed, counter0, reward_scale, out_states, out_actions, out_logprobs, out_rewards, out_undones, out_unmasks,
+                     out_values, out_next_value);
+    if (rc) return rc;
+    ERL_REQUIRE(env_state && Ws && Wa && step_count && episode && max_step >= 1, "erl_rollout_synenv_f32: bad environment argument");
+    g.env_state = env_state; g.Ws = Ws; g.Wa = Wa; g.step_count = step_count; g.episode = episode;
+    g.max_step = max_step; g.env_seed = env_seed;
+    return rf_launch(g, ENV_SYN, (hipStream_t)stream);
+}
+
+extern "C" int erl_rollout_pendulum_f32(const float *actor_params, const float *critic_params, const float *act_avg,
+                                        const float *act_std, const float *cri_avg, const float *cri_std, int h1, int h2, float *phys,
+                                        float *obs, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N,
+                                        int64_t H, const float *noise, uint64_t seed, uint64_t counter0, float reward_scale,
+                                        float *out_states, float *out_actions, float *out_logprobs, float *out_rewards,
+                                        uint8_t *out_undones, uint8_t *out_unmasks, float *out_values, float *out_next_value,
+                                        void *stream)
+{
+    RfArgs g{};
+    int rc = rf_fill(g, "erl_rollout_pendulum_f32", actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, 3, h1, h2, 1, N, H,
+                     noise, seed, counter0, reward_scale, out_states, out_actions, out_logprobs, out_rewards, out_undones, out_unmasks,
+                     out_values, out_next_value);
+    if (rc) return rc;
+    ERL_REQUIRE(phys && obs && step_count && episode && max_step >= 1, "erl_rollout_pendulum_f32: bad environment argument");
+    g.env_state = obs; g.phys = phys; g.step_count = step_count; g.episode = episode;
+    g.max_step = max_step; g.env_seed = env_seed;
+    return rf_launch(g, ENV_PENDULUM, (hipStream_t)stream);
+}

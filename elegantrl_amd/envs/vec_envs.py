@@ -87,6 +87,24 @@ class SynVecEnv(_GpuVecEnv):
         return step
 
 
+    def fused_rollout(self, agent, horizon_len: int, noise, bufs, values, next_value) -> None:
+        """all `horizon_len` steps of AgentPPO._explore_vec_env in ONE launch (erl_rollout_synenv_f32); `bufs` = (states,
+        actions, logprobs, rewards, undones, unmasks) time-major, written in place; the env's state / counters advance."""
+        from .. import _hip
+        p, f32 = _hip.ptr, th.float32
+        a, c = agent._act, agent.cri
+        states, actions, logprobs, rewards, undones, unmasks = bufs
+        h1, h2 = agent.net_dims
+        _hip.check(_hip.lib().erl_rollout_synenv_f32(
+            p(agent._flat_a.flat, f32), p(agent._flat_c.flat, f32), p(a.state_avg.data, f32), p(a.state_std.data, f32),
+            p(c.state_avg.data, f32), p(c.state_std.data, f32), self.state_dim, h1, h2, self.action_dim, p(self.state, f32),
+            p(self.Ws, f32), p(self.Wa, f32), p(self.step_count, th.int32), p(self.episode, th.int32), self.max_step,
+            self.seed & (2 ** 64 - 1), self.num_envs, horizon_len, p(noise, f32), agent.rng_seed & (2 ** 64 - 1),
+            agent.rng_counter & (2 ** 64 - 1), float(agent.reward_scale), p(states, f32), p(actions, f32), p(logprobs, f32),
+            p(rewards, f32), _hip.flag_ptr(undones), _hip.flag_ptr(unmasks), p(values, f32), p(next_value, f32),
+            _hip.stream_ptr()), "erl_rollout_synenv_f32")
+
+
 class PendulumVecEnv(_GpuVecEnv):
     """Pendulum-v1 (g=10, m=l=1, dt=0.05, 200-step truncation) behind the reference wrapper's scaling
     (elegantrl/envs/CustomGymEnv.py:42-44: torque = 2*action, reward = 0.5*gym reward)."""
@@ -123,6 +141,23 @@ class PendulumVecEnv(_GpuVecEnv):
             if rc:
                 _hip.check(rc, "erl_pendulum_step_f32")
         return step
+
+
+    def fused_rollout(self, agent, horizon_len: int, noise, bufs, values, next_value) -> None:
+        """all `horizon_len` steps of AgentPPO._explore_vec_env in ONE launch (erl_rollout_pendulum_f32)."""
+        from .. import _hip
+        p, f32 = _hip.ptr, th.float32
+        a, c = agent._act, agent.cri
+        states, actions, logprobs, rewards, undones, unmasks = bufs
+        h1, h2 = agent.net_dims
+        _hip.check(_hip.lib().erl_rollout_pendulum_f32(
+            p(agent._flat_a.flat, f32), p(agent._flat_c.flat, f32), p(a.state_avg.data, f32), p(a.state_std.data, f32),
+            p(c.state_avg.data, f32), p(c.state_std.data, f32), h1, h2, p(self.phys, f32), p(self.state, f32),
+            p(self.step_count, th.int32), p(self.episode, th.int32), self.max_step, self.seed & (2 ** 64 - 1), self.num_envs,
+            horizon_len, p(noise, f32), agent.rng_seed & (2 ** 64 - 1), agent.rng_counter & (2 ** 64 - 1),
+            float(agent.reward_scale), p(states, f32), p(actions, f32), p(logprobs, f32), p(rewards, f32),
+            _hip.flag_ptr(undones), _hip.flag_ptr(unmasks), p(values, f32), p(next_value, f32), _hip.stream_ptr()),
+            "erl_rollout_pendulum_f32")
 
 
 class CartPoleVecEnv:

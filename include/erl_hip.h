@@ -164,6 +164,33 @@ ERL_API int erl_rollout_step_f32(const float *actor_params, const float *state_a
                          uint64_t seed, uint64_t counter, float *out_state_row, float *out_action_row,
                          float *out_logprob_row, float *out_action_env, void *stream);
 
+/* K1+K2 fused over a whole horizon, for the GPU-resident environments below: ONE launch runs all H steps of
+ * AgentPPO._explore_vec_env (elegantrl/agents/AgentPPO.py:87-129) -- get_action, the buffer stores, tanh, env.step, the
+ * reward / flag stores, `rewards *= reward_scale`, `undones = ~terminals`, `unmasks = ~truncates` (:126-128) -- and
+ * evaluates CriticPPO on every visited state: out_values (H, N) is update_net's value pre-pass (:141-143) and
+ * out_next_value (N) the bootstrap cri(last_state) (:219-220); both may be NULL.  A workgroup owns 16 envs for all H
+ * steps (weights in registers / LDS for the whole rollout, state tile in LDS).  Step t draws its noise from
+ * noise[t] ((H, N, A), tests) or Philox keyed by (seed, counter0 + t, env, action-dim) -- the keys H successive
+ * erl_rollout_step_f32 calls would use -- and every step's arithmetic is that of erl_rollout_step_f32 (N <= 16384 form) +
+ * erl_synenv_step_f32 / erl_pendulum_step_f32, so the six rollout buffers come out bit-identical to the per-step path.
+ * The env's live state / counters are read at entry and written back at exit.  Needs erl_rollout_fused_supported(...):
+ * state_dim <= 64 on top of the K1 constraints. */
+ERL_API int erl_rollout_fused_supported(int S, int h1, int h2, int A);
+ERL_API int erl_rollout_synenv_f32(const float *actor_params, const float *critic_params, const float *act_avg,
+                           const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
+                           float *env_state, const float *Ws, const float *Wa, int32_t *step_count, int32_t *episode,
+                           int max_step, uint64_t env_seed, int64_t N, int64_t H, const float *noise, uint64_t seed,
+                           uint64_t counter0, float reward_scale, float *out_states, float *out_actions,
+                           float *out_logprobs, float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks,
+                           float *out_values, float *out_next_value, void *stream);
+ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *critic_params, const float *act_avg,
+                             const float *act_std, const float *cri_avg, const float *cri_std, int h1, int h2, float *phys,
+                             float *obs, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N,
+                             int64_t H, const float *noise, uint64_t seed, uint64_t counter0, float reward_scale,
+                             float *out_states, float *out_actions, float *out_logprobs, float *out_rewards,
+                             uint8_t *out_undones, uint8_t *out_unmasks, float *out_values, float *out_next_value,
+                             void *stream);
+
 /* K6  one PPO minibatch: gather (K5 indices) + critic fwd/bwd + actor fwd/bwd, both networks in one
  * launch.  Replaces AgentPPO.update_objectives up to (not including) the two optimizer steps
  * (AgentPPO.py:173-204) and ActorPPO.get_logprob_entropy (:378-386):
