@@ -1,0 +1,132 @@
+// K6 (one PPO minibatch) -- pieces shared by the two kernels behind erl_ppo_step_f32:
+//   ppo_step.hip      8 waves x 16 samples, v_mfma_f32_16x16x4_f32 chain (any S <= 128, h1, h2 <= 128)
+//   ppo_step_w4.hip   4 waves x 32 samples, v_mfma_f32_32x32x2_f32 chain, one wave per SIMD with the whole activation
+//                     set in the 512-entry register file (S <= 64, net [128,128], A <= 8: BASELINE configs 4 / 5)
+// Both write the same gradient slabs (one per 128 samples and network) and the same objective partial sums.
+#pragma once
+#include "mlp_chain.h"
+
+struct Ppo2Args {
+    const float *P[2];    // actor, critic flat params
+    const float *avg[2];
+    const float *sd[2];
+    const float *states, *actions, *logprobs, *advantages, *reward_sums;
+    const uint8_t *unmasks;
+    const int64_t *ids;
+    int64_t H, N, B;
+    int S, h1, h2, A;
+    float ratio_clip, lambda_entropy, inv_batch;
+    int canonical;        // 0: the reference's sign-dependent scale (AgentPPO.py:199); 1: min(r A, clamp(r) A)
+    float *slabs;
+    int64_t stride, Pa, Pc;
+    long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup 0
+};
+
+namespace {
+
+constexpr int PB = 128;        // samples per workgroup
+// leading dimension of the staged feature-major tiles T[feature][sample]: 16-byte aligned rows, consecutive rows 16
+// bytes apart modulo the 128-byte bank span => 8 consecutive rows form one conflict-free ds_read_b128 wavefront slice,
+// and a transposing ds_write_b32 of a D-layout tile lands 2 lanes per bank (the minimum for 64 lanes).
+constexpr int PLD = PB + 4;
+
+#ifdef ERL_PROFILE
+#define PROF(i)                                                                                   \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if (g.prof && blockIdx.x == 0 && lane == 0) g.prof[(net * 8 + wave) * 32 + (i)] = (long long)t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+// the same stamp without draining the vector-memory counter (loads that are meant to stay in flight across it)
+#define PROF_NV(i)                                                                                \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if (g.prof && blockIdx.x == 0 && lane == 0) g.prof[(net * 8 + wave) * 32 + (i)] = (long long)t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define PROF(i) do { } while (0)
+#define PROF_NV(i) do { } while (0)
+#endif
+
+// dW (nA32*32 x nB32*32) = TA . TB^T over the 128 staged samples; output tiles split over the NW waves.
+template <int NW>
+__device__ __forceinline__ void weight_grad(const float *TA, int nA32, const float *TB, int nB32, float *__restrict__ dW,
+                                            int ldw, int cols_real, int wave, int lane)
+{
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntiles = nA32 * nB32;
+    for (int tile = wave; tile < ntiles; tile += NW) {
+        const int it = tile / nB32, jt = tile - it * nB32;
+        const float *a = TA + (32 * it + l31) * PLD + hi;
+        const float *b = TB + (32 * jt + l31) * PLD + hi;
+        f32x16 acc = {0};
+        // the sum over samples is order-free: lane half `hi` takes samples 8 j + 4 hi + {0..3} of every group of 8, so
+        // one 16-byte read per operand feeds four MFMAs (k-pair of step s' = samples 8 j + s' and 8 j + 4 + s')
+        const float *a4 = a + 3 * hi, *b4 = b + 3 * hi;             // a + hi + 3 hi = row + 4 hi
+#pragma unroll 8
+        for (int j = 0; j < PB / 8; ++j) {
+            const float4 av = *reinterpret_cast<const float4 *>(a4 + 8 * j), bv = *reinterpret_cast<const float4 *>(b4 + 8 * j);
+            acc = mfma32(av.x, bv.x, acc);
+            acc = mfma32(av.y, bv.y, acc);
+            acc = mfma32(av.z, bv.z, acc);
+            acc = mfma32(av.w, bv.w, acc);
+        }
+        const int i = 32 * jt + l31;
+        if (i < cols_real) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW[(size_t)(32 * it + crow(r, hi)) * ldw + i] = acc[r];
+        }
+    }
+}
+
+// bias gradient: out[f] = sum over the 128 staged samples of T[f][:]; wave w reduces features 16 w .. 16 w + 15 (+ 16 NW ...)
+template <int NW>
+__device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__restrict__ out, int wave, int lane)
+{
+    for (int f0 = 16 * wave; f0 < nfeat; f0 += 16 * NW) {
+        const int f = f0 + (lane & 15), p = lane >> 4;
+        const float *src = T + f * PLD + 32 * p;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + k);
+            s0 += v.x + v.z;
+            s1 += v.y + v.w;
+        }
+        float s = s0 + s1;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (p == 0 && f < nfeat) out[f] = s;
+    }
+}
+
+// the surrogate of one sample and its derivative with respect to the new log-prob.
+//   reference form (AgentPPO.py:199):  surr = adv ratio (adv > 0 ? 1 - clip : 1 + clip)         d surr / d logp = surr
+//   canonical (helloworld/helloworld_PPO_single_file.py:337-339):  surr = min(adv ratio, adv clamp(ratio, 1 - clip, 1 + clip))
+//                                                                  d surr / d logp = adv ratio where the unclipped branch is taken
+__device__ __forceinline__ void ppo_surrogate(float adv, float ratio, float clip, int canonical, float &surr, float &dsurr)
+{
+    if (!canonical) {
+        const float w = adv > 0.f ? 1.f - clip : 1.f + clip;
+        surr = adv * ratio * w;
+        dsurr = surr;
+    } else {
+        const float s1 = adv * ratio;
+        const float s2 = adv * fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+        const bool first = s1 <= s2;                  // torch.min: ties take either branch; the unclipped one keeps the gradient
+        surr = first ? s1 : s2;
+        const bool inside = ratio >= 1.f - clip && ratio <= 1.f + clip;   // clamp passes the gradient inside the interval
+        dsurr = first ? s1 : (inside ? s1 : 0.f);
+    }
+}
+
+}  // namespace
+
+// ppo_step_w4.hip
+bool erl_ppo_w4_supported(int S, int h1, int h2, int A);
+int erl_ppo_w4_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);

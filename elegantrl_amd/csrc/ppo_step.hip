@@ -25,45 +25,14 @@
 // whole forward pass.  Seven workgroup barriers (LDS-only, no vector-memory drain) in total; all control flow in the hot
 // instantiation is compile-time (tile counts are template parameters, out-of-range loads are clamped + selected instead
 // of branched).
-#include "mlp_chain.h"
+#include <stdlib.h>
+
+#include "ppo_step.h"
 
 namespace {
 
-constexpr int PB = 128;        // samples per workgroup
-// leading dimension of the staged feature-major tiles T[feature][sample]: 16-byte aligned rows, consecutive rows 16
-// bytes apart modulo the 128-byte bank span => 8 consecutive rows form one conflict-free ds_read_b128 wavefront slice,
-// and a transposing ds_write_b32 of a D-layout tile lands 2 lanes per bank (the minimum for 64 lanes).
-constexpr int PLD = PB + 4;
 constexpr int PNW = 8;
 constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
-
-struct Ppo2Args {
-    const float *P[2];    // actor, critic flat params
-    const float *avg[2];
-    const float *sd[2];
-    const float *states, *actions, *logprobs, *advantages, *reward_sums;
-    const uint8_t *unmasks;
-    const int64_t *ids;
-    int64_t H, N, B;
-    int S, h1, h2, A;
-    float ratio_clip, lambda_entropy, inv_batch;
-    float *slabs;
-    int64_t stride, Pa, Pc;
-    long long *prof;      // ERL_PROFILE builds only: [net][wave][32] s_memtime stamps of workgroup 0
-};
-
-#ifdef ERL_PROFILE
-#define PROF(i)                                                                                   \
-    do {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        unsigned long long t_;                                                                    \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-        if (g.prof && blockIdx.x == 0 && lane == 0) g.prof[(net * PNW + wave) * 32 + (i)] = (long long)t_; \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    } while (0)
-#else
-#define PROF(i) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // backward through a layer's input on registers:  g[jt] <- g[jt] * ( W^T . dz ),  W = zero-padded LDS copy
@@ -126,56 +95,6 @@ __device__ __forceinline__ void stage(float *T, const f32x4 (&a)[8], int nt, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[(16 * t + 4 * q + r) * PLD + col] = a[t][r];
         }
-}
-
-// dW (nA32*32 x nB32*32) = TA . TB^T over the 128 staged samples; output tiles split over the 8 waves.
-__device__ __forceinline__ void weight_grad(const float *TA, int nA32, const float *TB, int nB32, float *__restrict__ dW,
-                                            int ldw, int cols_real, int wave, int lane)
-{
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int ntiles = nA32 * nB32;
-    for (int tile = wave; tile < ntiles; tile += PNW) {
-        const int it = tile / nB32, jt = tile - it * nB32;
-        const float *a = TA + (32 * it + l31) * PLD + hi;
-        const float *b = TB + (32 * jt + l31) * PLD + hi;
-        f32x16 acc = {0};
-        // the sum over samples is order-free: lane half `hi` takes samples 8 j + 4 hi + {0..3} of every group of 8, so
-        // one 16-byte read per operand feeds four MFMAs (k-pair of step s' = samples 8 j + s' and 8 j + 4 + s')
-        const float *a4 = a + 3 * hi, *b4 = b + 3 * hi;             // a + hi + 3 hi = row + 4 hi
-#pragma unroll 8
-        for (int j = 0; j < PB / 8; ++j) {
-            const float4 av = *reinterpret_cast<const float4 *>(a4 + 8 * j), bv = *reinterpret_cast<const float4 *>(b4 + 8 * j);
-            acc = mfma32(av.x, bv.x, acc);
-            acc = mfma32(av.y, bv.y, acc);
-            acc = mfma32(av.z, bv.z, acc);
-            acc = mfma32(av.w, bv.w, acc);
-        }
-        const int i = 32 * jt + l31;
-        if (i < cols_real) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dW[(size_t)(32 * it + crow(r, hi)) * ldw + i] = acc[r];
-        }
-    }
-}
-
-// bias gradient: out[f] = sum over the 128 staged samples of T[f][:]; wave w reduces features 16 w .. 16 w + 15
-__device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__restrict__ out, int wave, int lane)
-{
-    for (int f0 = 16 * wave; f0 < nfeat; f0 += 16 * PNW) {
-        const int f = f0 + (lane & 15), p = lane >> 4;
-        const float *src = T + f * PLD + 32 * p;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; k += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(src + k);
-            s0 += v.x + v.z;
-            s1 += v.y + v.w;
-        }
-        float s = s0 + s1;
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (p == 0 && f < nfeat) out[f] = s;
-    }
 }
 
 // LDS pool (floats): [RA: W2 copy, later staged tiles][RB: W1 copy, later staged tiles][RC: dY^T][RW3: W3 copy]
@@ -344,15 +263,16 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
         }
         lp += __shfl_xor(lp, 16, 64);
         lp += __shfl_xor(lp, 32, 64);
-        const float adv = xb;
         const float ratio = expf(lp - xa);
-        const float wclip = adv > 0.f ? 1.f - g.ratio_clip : 1.f + g.ratio_clip;
-        const float surr = valid ? adv * ratio * wclip : 0.f;   // reference-form "clip" (:199); padding rows contribute 0
+        float surr, dsurr;
+        ppo_surrogate(xb, ratio, g.ratio_clip, g.canonical, surr, dsurr);
+        surr = valid ? surr : 0.f;                              // padding rows contribute 0
+        dsurr = valid ? dsurr : 0.f;
         if (q == 0) {
             loss0 = surr * um;
             loss1 = um;
         }
-        const float dlp = -(surr * um) * g.inv_batch;      // d(-mean(surr um)) / dlogp_new
+        const float dlp = -(dsurr * um) * g.inv_batch;     // d(-mean(surr um)) / dlogp_new
         const float ent_term = g.lambda_entropy * um * g.inv_batch;
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -395,10 +315,10 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     }
     lds_barrier();                                                   // (2)
     PROF(9);
-    weight_grad(RA, h1 >> 5, RX, (S + 31) >> 5, slab + d.oW1(), S, S, wave, lane);
-    bias_grad(RA, h1, slab + d.ob1(), wave, lane);
+    weight_grad<PNW>(RA, h1 >> 5, RX, (S + 31) >> 5, slab + d.oW1(), S, S, wave, lane);
+    bias_grad<PNW>(RA, h1, slab + d.ob1(), wave, lane);
     if (wave == 0) {
-        bias_grad(RC, OUT, slab + d.ob3(), 0, lane);
+        bias_grad<PNW>(RC, OUT, slab + d.ob3(), 0, lane);
         if (ACTOR && lane < OUT) {
             float s = 0.f;
 #pragma unroll
@@ -438,8 +358,8 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     PROF(12);
 
     // ---- layer 2: dW2 = dZ2^T . H1, db2
-    weight_grad(RA, h2 >> 5, RB, h1 >> 5, slab + d.oW2(), h1, h1, wave, lane);
-    bias_grad(RA, h2, slab + d.ob2(), wave, lane);
+    weight_grad<PNW>(RA, h2 >> 5, RB, h1 >> 5, slab + d.oW2(), h1, h1, wave, lane);
+    bias_grad<PNW>(RA, h2, slab + d.ob2(), wave, lane);
     PROF(13);
 
     // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
@@ -529,6 +449,7 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     g.H = H; g.N = N; g.B = B;
     g.S = S; g.h1 = h1; g.h2 = h2; g.A = A;
     g.ratio_clip = ratio_clip; g.lambda_entropy = lambda_entropy; g.inv_batch = inv_batch;
+    g.canonical = 0;
     g.slabs = slabs;
     g.Pa = Dims{S, h1, h2, A}.count(true);
     g.Pc = Dims{S, h1, h2, 1}.count(false);
@@ -542,7 +463,11 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     const int ns = (S + 15) / 16;
     erl_k6_timing_mark(st, 0);
     int rc;
-    if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);   // configs 4 / 5
+    // K6 form: 0 = automatic (one-wave-per-SIMD 32x32x2 kernel where its shape class applies), 8 = always the 8-wave
+    // 16x16x4 kernel (A/B measurements: ERL_K6_FORM=8)
+    static const int form = [] { const char *e = getenv("ERL_K6_FORM"); return e ? atoi(e) : 0; }();
+    if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 4 / 5
+    else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
     else rc = launch<0, 0, 0, false>(g, n_slabs, st);
     erl_k6_timing_mark(st, 1);

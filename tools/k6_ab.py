@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""K6 (erl_ppo_step_f32) alone at the BASELINE config-4 minibatch (B = 16384, S = 64, A = 8, net [128,128]):
+HIP-event time per launch over back-to-back launches.  A/B the two kernel forms on the same box:
+    ERL_K6_FORM=8 python tools/k6_ab.py ; python tools/k6_ab.py"""
+import json
+import os
+import sys
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from elegantrl_amd import ops  # noqa: E402
+
+dev = th.device("cuda:0")
+N, S, A, H, B, h1, h2 = 4096, int(os.environ.get("K6_S", 64)), 8, 32, 16384, 128, 128
+
+
+def main():
+    g = th.Generator(device=dev).manual_seed(0)
+    sa, sc = ops.MlpSpec(S, h1, h2, A, True), ops.MlpSpec(S, h1, h2, 1, False)
+    Pa = sa.count
+    flat = th.randn(Pa + sc.count, device=dev, generator=g) * 0.05
+    avg, std = th.zeros(S, device=dev), th.ones(S, device=dev)
+    states = th.randn((H, N, S), device=dev, generator=g)
+    actions = th.randn((H, N, A), device=dev, generator=g)
+    logprobs = th.randn((H, N), device=dev, generator=g) - 8
+    adv = th.randn((H, N), device=dev, generator=g)
+    ret = th.randn((H, N), device=dev, generator=g)
+    um = th.rand((H, N), device=dev, generator=g) < 0.995
+    ids = th.randint(H * N, (B,), device=dev, generator=g)
+    stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
+    slabs = th.empty((n_slabs, stride), device=dev)
+    run = lambda: ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,  # noqa: E731
+                               ids, 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    for _ in range(10):
+        run()
+    th.cuda.synchronize()
+    best, tot = 1e9, []
+    for _ in range(5):
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            run()
+        e1.record()
+        th.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e3 / 50
+        tot.append(round(t, 2))
+        best = min(best, t)
+    flops = 2 * B * sum(3 * (S * h1 + h1 * h2 + h2 * o) - 2 * S * h1 for o in (A, 1))
+    print(json.dumps({"form": os.environ.get("ERL_K6_FORM", "auto"), "S": S, "us": tot, "best_us": round(best, 2),
+                      "checksum": float(slabs.double().sum())}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+// Micro-benchmark: what one wave alone on its SIMD pays per v_mfma_f32_32x32x2_f32 (64-cycle fp32 MFMA) depending on
+// what sits between consecutive MFMAs.  256 threads = 4 waves, one per SIMD, one workgroup per CU (LDS-limited), whole
+// chip busy.  Prints s_memtime ticks per MFMA for each instruction pattern (hand-placed in inline asm: the compiler
+// cannot reorder it).  Background for the instruction-stream rules of ppo_step_w4.hip.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_issue_bench tools/mfma_issue_bench.hip && tools/bin/mfma_issue_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define M0 "v_mfma_f32_32x32x2_f32 %[c0], %[a], %[b], %[c0]\n\t"
+#define M1 "v_mfma_f32_32x32x2_f32 %[c1], %[a], %[b], %[c1]\n\t"
+#define VI "v_fma_f32 %[x], %[z], %[z], %[x]\n\t"          /* independent-ish VALU (accumulates into %4) */
+#define VJ "v_fma_f32 %[y], %[z], %[z], %[y]\n\t"
+#define VD "v_fma_f32 %[x], %[x], %[z], %[z]\n\t"          /* dependent chain through %4 */
+#define VX "v_exp_f32 %[y], %[z]\n\t"                  /* transcendental */
+#define NOP "s_nop 0\n\t"
+#define R4(x) x x x x
+#define R8(x) R4(x) R4(x)
+
+// MODE: see names[] in main
+template <int MODE>
+__global__ __launch_bounds__(256) void k(long long *out, float *sink, int reps)
+{
+    extern __shared__ __attribute__((aligned(16))) float T[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc0 = {0}, acc1 = {0};
+    float a = 1.0f + lane * 1e-3f, b = 0.5f, x = 0.1f, y = 0.2f, z = 1e-3f * lane;
+    for (int i = threadIdx.x; i < 8192; i += 256) T[i] = (float)i;
+    __syncthreads();
+    const unsigned lds_off = 16u * lane;       // byte offset inside the dynamic LDS block (it starts at 0)
+    f32x4 l0 = {0, 0, 0, 0}, l1 = {0, 0, 0, 0};
+    float wv = 3.f;
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < reps; ++it) {
+        if (MODE == 0)        // 16 dependent MFMAs, one chain
+            asm volatile(R8(M0) R8(M0) : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b));
+        else if (MODE == 1)   // two alternating chains
+            asm volatile(R8(M0 M1) : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b));
+        else if (MODE == 2)   // one chain, 1 s_nop between dependent MFMAs
+            asm volatile(R8(M0 NOP) R8(M0 NOP) : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b));
+        else if (MODE == 3)   // one chain, 4 independent VALU between dependent MFMAs
+            asm volatile(R8(M0 VI VJ VI VJ) R8(M0 VI VJ VI VJ) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 4)   // two chains, 4 independent VALU per gap
+            asm volatile(R8(M0 VI VJ VI VJ M1 VI VJ VI VJ) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 5)   // two chains, 8 independent VALU per gap
+            asm volatile(R8(M0 R4(VI VJ) M1 R4(VI VJ)) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 6)   // two chains, 12 independent VALU per gap
+            asm volatile(R8(M0 R4(VI VJ VI) M1 R4(VI VJ VI)) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 7)   // two chains, 16 independent VALU per gap
+            asm volatile(R8(M0 R8(VI VJ) M1 R8(VI VJ)) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 8)   // two chains, 8 DEPENDENT VALU per gap
+            asm volatile(R8(M0 R8(VD) M1 R8(VD)) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 9)   // two chains, 6 independent VALU + 2 transcendentals per gap
+            asm volatile(R8(M0 VI VJ VI VX VI VJ VI VX M1 VI VJ VI VX VI VJ VI VX) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 10)  // two chains, accumulators in VGPRs instead of AGPRs
+            asm volatile(R8(M0 M1) : [c0] "+v"(acc0), [c1] "+v"(acc1) : [a] "v"(a), [b] "v"(b));
+        else if (MODE == 11) {  // two chains, two ds_read_b128 + a wait per 8 MFMAs (the layer loop's operand traffic)
+            asm volatile("ds_read_b128 %[l0], %[p]\n\tds_read_b128 %[l1], %[p] offset:2048\n\t" R4(M0 M1) "s_waitcnt lgkmcnt(0)\n\t"
+                         "ds_read_b128 %[l0], %[p] offset:4096\n\tds_read_b128 %[l1], %[p] offset:6144\n\t" R4(M0 M1) "s_waitcnt lgkmcnt(0)\n\t"
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1), [l0] "=&v"(l0), [l1] "=&v"(l1) : [a] "v"(a), [b] "v"(b), [p] "v"(lds_off));
+        } else if (MODE == 12)  // two chains, 8 ds_read_b32 per 8 MFMAs
+            asm volatile(R8(M0 "ds_read_b32 %[x], %[p]\n\t" M1 "s_waitcnt lgkmcnt(4)\n\t") : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "=&v"(x) : [a] "v"(a), [b] "v"(b), [p] "v"(lds_off));
+        else if (MODE == 13)  // two chains, 1 s_nop per gap
+            asm volatile(R8(M0 NOP M1 NOP) : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b));
+        else if (MODE == 14)  // two chains, v_accvgpr_read + write (of another AGPR) per gap
+            asm volatile(R8(M0 "v_accvgpr_read_b32 %[x], %[w]\n\tv_accvgpr_write_b32 %[w], %[x]\n\t" M1 "v_accvgpr_read_b32 %[y], %[w]\n\tv_accvgpr_write_b32 %[w], %[y]\n\t")
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y), [w] "+a"(wv) : [a] "v"(a), [b] "v"(b));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (lane == 0 && blockIdx.x == 0) out[wave] = (long long)(t1 - t0);
+    float s = x + y + l0[0] + l1[1] + wv;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+template <int MODE>
+void run(const char *name)
+{
+    long long *d; float *s;
+    hipMalloc(&d, 64); hipMalloc(&s, 4096);
+    const int reps = 200;
+    const size_t lds = 100 * 1024;   // one workgroup per CU
+    hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int i = 0; i < 3; ++i) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(256), lds, 0, d, s, reps);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    long long h[4];
+    hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
+    const double per = (double)h[0] / (reps * 16.0);
+    printf("%-62s %7.1f ticks / MFMA   (kernel %.1f us => %.2f GHz if ticks are shader cycles)\n", name, per, ms * 1e3,
+           (double)h[0] / (ms * 1e-3) * 1e-9);
+    hipFree(d); hipFree(s);
+}
+
+int main()
+{
+    run<0>("0  one chain (dependent, back-to-back)");
+    run<1>("1  two alternating chains");
+    run<2>("2  one chain + 1 s_nop between dependent MFMAs");
+    run<3>("3  one chain + 4 indep VALU between dependent MFMAs");
+    run<4>("4  two chains + 4 indep VALU per gap");
+    run<5>("5  two chains + 8 indep VALU per gap");
+    run<6>("6  two chains + 12 indep VALU per gap");
+    run<7>("7  two chains + 16 indep VALU per gap");
+    run<8>("8  two chains + 8 DEPENDENT VALU per gap");
+    run<9>("9  two chains + 6 VALU + 2 v_exp per gap");
+    run<10>("10 two chains, accumulators in arch VGPRs");
+    run<11>("11 two chains + 2 ds_read_b128 + wait per 8 MFMAs");
+    run<12>("12 two chains + ds_read_b32 per 2 MFMAs");
+    run<13>("13 two chains + 1 s_nop per gap");
+    run<14>("14 two chains + accvgpr read+write per gap");
+    return 0;
+}

@@ -47,6 +47,8 @@ def main():
         run()
     th.cuda.synchronize()
     p = prof.cpu().view(2, 8, 32)[:, :, :NP]
+    p = p[:, (p[0, :, 0] != 0)]                        # the 4-wave form stamps waves 0..3 only
+    print(f"{p.shape[1]} waves per workgroup")
     for net, name in enumerate(("actor", "critic")):
         d = (p[net, :, 1:] - p[net, :, :-1]).double()
         tot = (p[net, :, NP - 1] - p[net, :, 0]).double()
