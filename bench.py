@@ -98,10 +98,10 @@ def gae_sweep(ops, dev):
 
 
 def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: separate --pmc
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json: separate --pmc
     FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); None when the file does not carry the kernel."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         for name, v in prof["kernels"].items():
             if name.startswith(kernel_prefix):
                 return v["hbm_bytes_per_launch"]
@@ -247,9 +247,9 @@ def main():
                                "horizon 32, 40 minibatches x 16384, net [128,128], fp32",
                    "envs_per_gpu": N_ENVS, "horizon": HORIZON, "batch": BATCH, "update_times": UPDATE_TIMES,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
-        "roofline": {"kernel": "ppo_step2_kernel", "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
+        "roofline": {"kernel": "ppo_step_w4_kernel", "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     "traffic": pmc_traffic("ppo_step2_kernel"), "flops_per_launch": flops,
+                     "traffic": pmc_traffic("ppo_step_w4_kernel"), "flops_per_launch": flops,
                      "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6},
         "roofline_gae": {"kernel": "gae_exact_kernel (in-loop 32x4096)", "bound": "hbm",
                          "achieved": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -19,7 +19,8 @@ struct Ppo2Args {
     int canonical;        // 0: the reference's sign-dependent scale (AgentPPO.py:199); 1: min(r A, clamp(r) A)
     float *slabs;
     int64_t stride, Pa, Pc;
-    long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup 0
+    long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
+    int prof_block;
 };
 
 namespace {
@@ -36,7 +37,7 @@ constexpr int PLD = PB + 4;
         __builtin_amdgcn_sched_barrier(0);                                                        \
         unsigned long long t_;                                                                    \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-        if (g.prof && blockIdx.x == 0 && lane == 0) g.prof[(net * 8 + wave) * 32 + (i)] = (long long)t_; \
+        if (g.prof && (int)blockIdx.x == g.prof_block && lane == 0) g.prof[(net * 8 + wave) * 32 + (i)] = (long long)t_; \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
 // the same stamp without draining the vector-memory counter (loads that are meant to stay in flight across it)
@@ -45,7 +46,7 @@ constexpr int PLD = PB + 4;
         __builtin_amdgcn_sched_barrier(0);                                                        \
         unsigned long long t_;                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-        if (g.prof && blockIdx.x == 0 && lane == 0) g.prof[(net * 8 + wave) * 32 + (i)] = (long long)t_; \
+        if (g.prof && (int)blockIdx.x == g.prof_block && lane == 0) g.prof[(net * 8 + wave) * 32 + (i)] = (long long)t_; \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
 #else

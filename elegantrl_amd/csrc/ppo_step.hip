@@ -409,6 +409,7 @@ int launch(const Ppo2Args &g, int n_slabs, hipStream_t stream)
 }
 
 long long *g_ppo_prof = nullptr;
+int g_ppo_prof_block = 0;
 
 }  // namespace
 
@@ -417,6 +418,7 @@ void erl_k6_timing_mark(hipStream_t stream, int which);   // api.cpp (measuremen
 #ifdef ERL_PROFILE
 // profiling builds only (make EXTRA=-DERL_PROFILE): device buffer of 2 * 8 * 32 int64 cycle stamps
 extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile(long long *dev_buf) { g_ppo_prof = dev_buf; }
+extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile_block(int b) { g_ppo_prof_block = b; }
 #endif
 
 extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
@@ -455,6 +457,7 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     g.Pc = Dims{S, h1, h2, 1}.count(false);
     g.stride = g.Pa + g.Pc + 4;
     g.prof = g_ppo_prof;
+    g.prof_block = g_ppo_prof_block;
     // 16-byte vector path: every row / parameter block / normalisation vector must be 16-byte aligned
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states) && al(act_avg) && al(act_std) &&
@@ -466,7 +469,7 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     // K6 form: 0 = automatic (one-wave-per-SIMD 32x32x2 kernel where its shape class applies), 8 = always the 8-wave
     // 16x16x4 kernel (A/B measurements: ERL_K6_FORM=8)
     static const int form = [] { const char *e = getenv("ERL_K6_FORM"); return e ? atoi(e) : 0; }();
-    if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 4 / 5
+    if (form != 8 && vec && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 4 / 5
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
     else rc = launch<0, 0, 0, false>(g, n_slabs, st);

@@ -5,33 +5,39 @@
 // ActorPPO.get_logprob_entropy (:378-386), like ppo_step.hip, and writes the same slabs.  What differs is the mapping:
 //
 //   * grid = (ceil(B / 128), 2 nets), 256 threads: FOUR waves, one per SIMD, each owning 32 samples.  A wave alone on
-//     its SIMD has the whole 512-entry register file (256 arch + 256 acc VGPRs): X, H1, GELU'(z1), H2, GELU'(z2) of its
-//     32 samples (288 registers per lane) stay in registers from the gather to the last weight gradient -- nothing is
+//     its SIMD has the whole 512-entry register file (256 arch + 256 acc VGPRs): H1, GELU'(z1), H2, GELU'(z2) of its 32
+//     samples (256 registers per lane) stay in registers from the first layer to the last weight gradient -- nothing is
 //     parked in memory (the 8-wave kernel round-trips GELU'(z1) through its slab: 33.6 MB per launch at B = 16384).
-//   * every layer is computed transposed on v_mfma_f32_32x32x2_f32 (64 cycles per SIMD, dependent-accumulate latency
-//     64: a single accumulator chain keeps the pipe full, which the 16x16x4 shape -- 32-cycle issue, 40-cycle dependent
-//     latency -- cannot do without a second wave):
+//   * every layer is computed transposed on v_mfma_f32_32x32x2_f32:
 //         outT (32 features x 32 samples) += W (32 rows x 2 k) . inT (2 k x 32 samples).
 //     The result tile leaves lane (m = lane & 31, hi = lane >> 5) holding features 8 g + 4 hi + j (acc[4 g + j]) of
 //     sample m.  The next layer walks its reduction index in the order (tile, g, j) and pairs k = 8 g + j (lane half 0)
 //     with k = 8 g + 4 + j (lane half 1): the B operand of step (g, j) is then exactly acc[4 g + j] of the previous
 //     layer -- the register chain of ppo_step.hip in the 32x32 layout -- and the A operand of four consecutive steps is
 //     one 16-byte LDS read W[row][32 T + 8 g + 4 hi .. + 3].  Half the LDS operand traffic of the 16x16x4 form.
-//   * the two instruction streams a SIMD used to interleave (two waves) are one stream here: the GELU epilogue of an
-//     output tile is issued between the MFMAs of the next tile by the compiler's scheduler (every layer is one fully
-//     unrolled basic block).
+//
+// What bounds it (tools/mfma_issue_bench.hip, profiles/r02_mfma_issue_bench.txt): the fp32 MFMA runs on the vector
+// ALUs -- a wave's VALU instructions do NOT overlap its fp32 MFMAs, each one adds its 4 cycles (transcendentals 8) to the
+// 64 of an MFMA, while LDS reads, waits and s_nops between MFMAs are free and dependent MFMAs issue back to back.  So the
+// kernel's time is (MFMA count x 64 + VALU count x 4) cycles plus whatever latency is exposed, and the design rules are:
+// no padded MFMA work (the 8-row output layer is 256 packed FMAs, not a 32-row MFMA tile), as few VALU instructions as
+// possible (packed-fp32 GELU, normalisation folded into one packed FMA per two elements, biases loaded straight into the
+// accumulators by ds_read), operands prefetched one group ahead, and fences (sched_barrier) that keep the compiler from
+// hoisting a whole unrolled layer's operand reads into registers.
 //
 // Weight gradients are the same staged scheme as ppo_step.hip (T[feature][sample] tiles in LDS, 32x32x2 tiles, K = 128
 // samples, output tiles split over the waves).
 #include "ppo_step.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int QNW = 4;           // waves per workgroup
 constexpr int QNT = QNW * 64;
 
-// LDS pool (floats): [RA: W2 copy, later staged tiles][RB: W1 copy | X^T, later staged tiles][RC: dY^T][RW3: W3 copy]
-//                    [s_bias: b1 | b2 | b3(16)][s_part: 4*16][s_red: 16]
+// LDS pool (floats): [RA: X sample-major, then W2 copy, later staged tiles][RB: W1 copy | X^T, later staged tiles]
+//                    [RC: dY^T][RW3: W3 copy][s_bias: b1 | b2 | b3(16)][s_part: 4*16][s_red: 16]
 constexpr int kQR = 128 * 68 + 64 * PLD;                  // >= 128 * PLD
 static_assert(kQR >= 128 * PLD && kQR % 4 == 0, "staged tiles must fit the weight-copy regions");
 constexpr int kQRC = 16 * PLD;
@@ -40,253 +46,196 @@ constexpr int kQBias = 128 + 128 + 16;
 constexpr size_t kW4LdsBytes = (size_t)(2 * kQR + kQRC + kQRW3 + kQBias + QNW * 16 + 16) * sizeof(float);
 static_assert(kW4LdsBytes <= 160 * 1024, "LDS budget");
 
-// ---------------------------------------------------------------------------------------------------------
-// Instruction-stream control.  One wave per SIMD: whatever has to hide under the MFMAs must sit BETWEEN them in program
-// order (an in-order wave stalls at the next dependent MFMA).  Two rules shape every MFMA phase of this kernel:
-//   1. An MFMA that accumulates into the register its predecessor wrote only issues back-to-back when NOTHING sits
-//      between the two (accumulator forwarding); one VALU op, s_waitcnt or s_nop in between costs ~40 cycles (measured:
-//      the first version of this kernel ran its layers at 60-65 % of the MFMA rate with the epilogue ops between
-//      dependent MFMAs).  So every reduction is split over TWO accumulator chains that alternate instruction by
-//      instruction (chain 0: even reduction groups, chain 1: odd groups, summed at the end): consecutive MFMAs are
-//      independent, and each 64-cycle gap can hide ~12 other instructions.
-//   2. The compiler must neither hoist all the operand reads of an unrolled layer (that alone overflowed the 512-entry
-//      register file) nor sink the epilogues behind the MFMA chain: every "super-group" (two 16-byte A-operand reads
-//      issued one super-group ahead, eight alternating MFMAs, a share of the previous output tile's epilogue) is fenced
-//      by sched_barrier, ordered inside by sched_group_barrier, and epilogue results are pinned (ERL_PIN) because LLVM's
-//      IR-level code sinking moves pure arithmetic across sched_barrier towards its first use.
-// ---------------------------------------------------------------------------------------------------------
-#define ERL_PIN1(a) asm volatile("" : "+v"(a))
-#define ERL_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#define ERL_SGB_DSREAD(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
-#define ERL_SGB_MFMA_VALU(nv)                                \
-    do {                                                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
-        __builtin_amdgcn_sched_group_barrier(0x002, (nv), 0); \
-    } while (0)
-#define ERL_SGB_8X(nv)                                                                                     \
-    do {                                                                                                   \
-        ERL_SGB_MFMA_VALU(nv); ERL_SGB_MFMA_VALU(nv); ERL_SGB_MFMA_VALU(nv); ERL_SGB_MFMA_VALU(nv);        \
-        ERL_SGB_MFMA_VALU(nv); ERL_SGB_MFMA_VALU(nv); ERL_SGB_MFMA_VALU(nv); ERL_SGB_MFMA_VALU(nv);        \
-    } while (0)
+// LLVM's IR-level code sinking moves pure arithmetic (an epilogue whose result is first used a few basic blocks later)
+// across sched_barrier towards its first use; an empty volatile asm that "modifies" the value keeps it where it is written.
+#define ERL_PIN4(a, b) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y))
 
-// the two partial accumulators of an output tile whose epilogue is still to be done (z = a0 + a1, bias inside a0)
-struct Pend {
-    f32x16 a0, a1;
-};
+// exact-erf GELU and its derivative for two elements at once on packed fp32 (v_pk_fma_f32: two FMAs per lane and issue
+// slot).  erf through Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) like gelu_and_grad_fast; the scalings are folded into
+// the constants so that exp(-z^2 / 2) is ONE v_exp_f32 (2^x) of -(c |z|)^2, c = sqrt(log2(e) / 2), and the cdf comes out
+// of half-scaled coefficients as 0.5 + copysign(0.5 erf(|z| / sqrt 2), z).  16 plain + 4 transcendental ops per pair.
+__device__ __forceinline__ void gelu2(f32x2 z, f32x2 &y, f32x2 &gd)
+{
+    constexpr float kC = 0.84932180028801904272f;              // sqrt(log2(e) / 2)
+    constexpr float kP = 0.3275911f * 0.70710678118654752440f / kC;   // A&S p, for the rescaled argument
+    const f32x2 xa = {fabsf(z.x) * kC, fabsf(z.y) * kC};
+    const f32x2 den = xa * kP + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f32x2 w = -(xa * xa);
+    const f32x2 u = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};   // exp(-z^2 / 2)
+    f32x2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+    p = t * p + (0.5f * 1.421413741f);
+    p = t * p + (0.5f * -0.284496736f);
+    p = t * p + (0.5f * 0.254829592f);
+    p = p * t;
+    const f32x2 h = 0.5f - p * u;                              // 0.5 erf(|z| / sqrt 2)
+    const f32x2 hs = {copysignf(h.x, z.x), copysignf(h.y, z.y)};
+    const f32x2 cdf = hs + 0.5f;
+    y = z * cdf;
+    gd = (z * u) * 0.39894228040143267794f + cdf;
+}
 
-// bias of output tile To in the D layout: element e <-> feature 32 To + 8 (e >> 2) + 4 hi + (e & 3).
-// HEAD16: the bias vector has 16 entries only (output layer): elements 4.. are padding rows and start from 0.
-template <bool HEAD16>
+// bias of output tile To in the D layout, loaded straight into an accumulator: element e <-> feature
+// 32 To + 8 (e >> 2) + 4 hi + (e & 3)
 __device__ __forceinline__ void load_bias16(const float *bias, int To, int hi, f32x16 &pb)
 {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        if (HEAD16 && gq > 0) {
-            pb[4 * gq + 0] = 0.f; pb[4 * gq + 1] = 0.f; pb[4 * gq + 2] = 0.f; pb[4 * gq + 3] = 0.f;
-        } else {
-            const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * To + 8 * gq + 4 * hi);
-            pb[4 * gq + 0] = b4.x; pb[4 * gq + 1] = b4.y; pb[4 * gq + 2] = b4.z; pb[4 * gq + 3] = b4.w;
-        }
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * To + 8 * gq + 4 * hi);
+        pb[4 * gq + 0] = b4.x; pb[4 * gq + 1] = b4.y; pb[4 * gq + 2] = b4.z; pb[4 * gq + 3] = b4.w;
+    }
+}
+
+// The same for two pairs, written step by step for both: the dependent packed-FMA chains of the two pairs alternate in
+// program order, which fills the wait state gfx950 needs between a packed op and its consumer (hipcc otherwise pads
+// every dependent pair with an s_nop: 4 cycles each, ~10 per pair; it does not interleave two gelu2 calls by itself).
+__device__ __forceinline__ void gelu4(f32x2 za, f32x2 zb, f32x2 &ya, f32x2 &ga, f32x2 &yb, f32x2 &gb)
+{
+    constexpr float kC = 0.84932180028801904272f;
+    constexpr float kP = 0.3275911f * 0.70710678118654752440f / kC;
+    const f32x2 xa = {fabsf(za.x) * kC, fabsf(za.y) * kC};
+    const f32x2 xb = {fabsf(zb.x) * kC, fabsf(zb.y) * kC};
+    const f32x2 da = xa * kP + 1.0f;
+    const f32x2 db = xb * kP + 1.0f;
+    const f32x2 wa = -(xa * xa);
+    const f32x2 wb = -(xb * xb);
+    const f32x2 ta = {__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
+    const f32x2 tb = {__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+    const f32x2 ua = {__builtin_amdgcn_exp2f(wa.x), __builtin_amdgcn_exp2f(wa.y)};
+    const f32x2 ub = {__builtin_amdgcn_exp2f(wb.x), __builtin_amdgcn_exp2f(wb.y)};
+    f32x2 pa = ta * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+    f32x2 pb = tb * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+    pa = ta * pa + (0.5f * 1.421413741f);
+    pb = tb * pb + (0.5f * 1.421413741f);
+    pa = ta * pa + (0.5f * -0.284496736f);
+    pb = tb * pb + (0.5f * -0.284496736f);
+    pa = ta * pa + (0.5f * 0.254829592f);
+    pb = tb * pb + (0.5f * 0.254829592f);
+    pa = pa * ta;
+    pb = pb * tb;
+    const f32x2 zua = za * ua;
+    const f32x2 zub = zb * ub;
+    const f32x2 ha = 0.5f - pa * ua;
+    const f32x2 hb = 0.5f - pb * ub;
+    const f32x2 sa = {copysignf(ha.x, za.x), copysignf(ha.y, za.y)};
+    const f32x2 sb = {copysignf(hb.x, zb.x), copysignf(hb.y, zb.y)};
+    const f32x2 ca = sa + 0.5f;
+    const f32x2 cb = sb + 0.5f;
+    ya = za * ca;
+    yb = zb * cb;
+    ga = zua * 0.39894228040143267794f + ca;
+    gb = zub * 0.39894228040143267794f + cb;
+}
+
+__device__ __forceinline__ void gelu_tile(const f32x16 &acc, f32x16 &H, f32x16 &G)
+{
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+        f32x2 y0, g0, y1, g1;
+        gelu4(f32x2{acc[e], acc[e + 1]}, f32x2{acc[e + 2], acc[e + 3]}, y0, g0, y1, g1);
+        ERL_PIN4(y0, g0);
+        ERL_PIN4(y1, g1);
+        H[e] = y0.x; H[e + 1] = y0.y; H[e + 2] = y1.x; H[e + 3] = y1.y;
+        G[e] = g0.x; G[e + 1] = g0.y; G[e + 2] = g1.x; G[e + 3] = g1.y;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// forward layer on registers: out[To] (32 features x 32 samples) = GELU( bias + W[32 To .. + 31][:] . in ), To < NOUT.
+// forward layer on registers: out[To] (32 features x 32 samples) = GELU( bias + W[32 To .. + 31][:] . in ), To = 0..3.
 // W, bias: zero-padded LDS copies (row stride ldw = 4 * odd floats: the 16-byte reads of 16 consecutive rows hit 16
-// distinct 16-byte bank groups); `arow` = this lane's row inside a 32-row tile.  KT = input tiles of 32.
-// Software pipeline across tiles AND layers: the GELU epilogue of tile To rides in the super-groups of tile To + 1; the
-// last tile's accumulators are handed to the caller (`pout`), whose next layer finishes them (`pin`, PEND_IN) during
-// the first super-groups of its own first output tile -- that tile consumes the pending input tile KT - 1 last.
+// distinct 16-byte bank groups).  KT = input tiles of 32.  One group = one 16-byte A read (issued a group ahead) + four
+// MFMAs; the accumulator starts from the bias (read a tile ahead); the GELU epilogue of tile To sits after the first
+// group of tile To + 1, when its accumulator has long been written back.
 // ---------------------------------------------------------------------------------------------------------
-template <int KT, bool PEND_IN, int NOUT, bool HEAD16>
-__device__ __forceinline__ void fwd32(const float *W, int ldw, const float *bias, int arow, f32x16 (&in)[KT], f32x16 (&inG)[KT],
-                                      const Pend &pin, f32x16 (&outH)[4], f32x16 (&outG)[4], Pend &pout, int hi)
+template <int KT>
+__device__ __forceinline__ void fwd32(const float *W, int ldw, const float *bias, const f32x16 (&in)[KT], f32x16 (&outH)[4],
+                                      f32x16 (&outG)[4], int m, int hi)
 {
-    constexpr int NS = 2 * KT, NC = NOUT * NS;                 // super-groups per output tile / in total
-    constexpr int EPS = (16 + NS - 1) / NS;                    // epilogue elements of the previous tile per super-group
-    constexpr int NPS = NS > 2 ? NS - 2 : 1;                   // the pending tile is consumed by the last two super-groups
-    constexpr int PPS = (16 + NPS - 1) / NPS;                  // pending-input elements per super-group
-    constexpr int NV = (24 * ((PEND_IN && PPS > EPS) || NOUT == 1 ? PPS : EPS) + 7) / 8;   // VALU slots per MFMA gap
-    const float *wbase = W + arow * ldw + 4 * hi;
-    float4 wq[2][2];
-    auto issue = [&](int c, float4(&dst)[2]) {
-        const int To = c / NS, s = c % NS;
-        const float *p = wbase + 32 * To * ldw + 16 * s;
-        dst[0] = *reinterpret_cast<const float4 *>(p);
-        dst[1] = *reinterpret_cast<const float4 *>(p + 8);
+    constexpr int NG = 4 * KT, NC = 4 * NG;
+    const float *wbase = W + m * ldw + 4 * hi;
+    float4 wq[2];
+    auto issue = [&](int c, float4 &dst) {
+        const int To = c / NG, gi = c % NG;
+        dst = *reinterpret_cast<const float4 *>(wbase + 32 * To * ldw + 8 * gi);
     };
     issue(0, wq[0]);
-    f32x16 nb;
-    load_bias16<HEAD16>(bias, 0, hi, nb);
-    f32x16 acc0 = {0}, acc1 = {0}, p0 = {0}, p1 = {0};
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int To = c / NS, s = c % NS;
-        const int Ti0 = (2 * s) >> 2, g0 = (2 * s) & 3, Ti1 = (2 * s + 1) >> 2, g1 = (2 * s + 1) & 3;
+    f32x16 acc, nb, prev;
+    load_bias16(bias, 0, hi, nb);
+    auto group = [&](int To, int gi) {
+        const int c = To * NG + gi, Ti = gi >> 2, gq = gi & 3;
         if (c + 1 < NC) issue(c + 1, wq[(c + 1) & 1]);
-        if (s == 0) {
-            acc0 = nb;
-            acc1 = f32x16{0};
-        }
-        const float4 a0 = wq[c & 1][0], a1 = wq[c & 1][1];
-        acc0 = mfma32(a0.x, in[Ti0][4 * g0 + 0], acc0);
-        acc1 = mfma32(a1.x, in[Ti1][4 * g1 + 0], acc1);
-        acc0 = mfma32(a0.y, in[Ti0][4 * g0 + 1], acc0);
-        acc1 = mfma32(a1.y, in[Ti1][4 * g1 + 1], acc1);
-        acc0 = mfma32(a0.z, in[Ti0][4 * g0 + 2], acc0);
-        acc1 = mfma32(a1.z, in[Ti1][4 * g1 + 2], acc1);
-        acc0 = mfma32(a0.w, in[Ti0][4 * g0 + 3], acc0);
-        acc1 = mfma32(a1.w, in[Ti1][4 * g1 + 3], acc1);
-        if (To > 0) {                                          // epilogue share of tile To - 1
-#pragma unroll
-            for (int u = 0; u < EPS; ++u) {
-                const int e = s * EPS + u;
-                if (e < 16) {
-                    float y, gd;
-                    gelu_and_grad_fast(p0[e] + p1[e], y, gd);
-                    ERL_PIN2(y, gd);
-                    outH[To - 1][e] = y;
-                    outG[To - 1][e] = gd;
-                }
-            }
-        } else if (PEND_IN && s < NPS) {                       // the producer layer's last tile
-#pragma unroll
-            for (int u = 0; u < PPS; ++u) {
-                const int e = s * PPS + u;
-                if (e < 16) {
-                    float y, gd;
-                    gelu_and_grad_fast(pin.a0[e] + pin.a1[e], y, gd);
-                    ERL_PIN2(y, gd);
-                    in[KT - 1][e] = y;
-                    inG[KT - 1][e] = gd;
-                }
-            }
-        }
-        if (s == NS - 1 && To + 1 < NOUT) load_bias16<HEAD16>(bias, To + 1, hi, nb);
-        ERL_SGB_DSREAD(2);
-        ERL_SGB_8X(NV);
+        const float4 a = wq[c & 1];
+        acc = mfma32(a.x, in[Ti][4 * gq + 0], acc);
+        acc = mfma32(a.y, in[Ti][4 * gq + 1], acc);
+        acc = mfma32(a.z, in[Ti][4 * gq + 2], acc);
+        acc = mfma32(a.w, in[Ti][4 * gq + 3], acc);
         __builtin_amdgcn_sched_barrier(0);
-        if (s == NS - 1) {
-            p0 = acc0;
-            p1 = acc1;
-        }
-    }
-    pout.a0 = p0;
-    pout.a1 = p1;
-}
-
-// finish a pending tile outside any MFMA phase (S <= 32: the next layer is too short to hide it)
-__device__ __forceinline__ void finish_pend(const Pend &p, f32x16 &H, f32x16 &G)
-{
+    };
+    // (nested loops: one flat loop with the epilogue inside exceeds LLVM's pragma-unroll size limit and is left rolled,
+    // which demotes every register array to scratch)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float y, gd;
-        gelu_and_grad_fast(p.a0[e] + p.a1[e], y, gd);
-        H[e] = y;
-        G[e] = gd;
+    for (int To = 0; To < 4; ++To) {
+        acc = nb;
+        group(To, 0);
+        if (To + 1 < 4) load_bias16(bias, To + 1, hi, nb);
+        if (To > 0) {
+            gelu_tile(prev, outH[To - 1], outG[To - 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int gi = 1; gi < NG; ++gi) group(To, gi);
+        prev = acc;
     }
+    gelu_tile(prev, outH[3], outG[3]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // backward through a layer's input on registers:  gate[To] <- gate[To] * ( W^T . dz ),  W = LDS copy [32 KT rows][ldw]
 // (A operand = W^T: lane (i, hi) supplies W[8 gi + 4 hi + j][32 To + i] for reduction group gi, four ds_read_b32 per
-// group, issued one super-group ahead; two alternating accumulator chains; the gate multiplies of tile To ride in the
-// first super-group of tile To + 1).
+// group, issued one group ahead; the gate multiplies of tile To sit after the first group of tile To + 1).
 // ---------------------------------------------------------------------------------------------------------
 template <int KT>
 __device__ __forceinline__ void bwd32(const float *W, int ldw, const f32x16 (&dz)[KT], f32x16 (&gate)[4], int m, int hi)
 {
-    constexpr int NS = 2 * KT, NC = 4 * NS;
+    constexpr int NG = 4 * KT, NC = 4 * NG;
     const float *wbase = W + (4 * hi) * ldw + m;
-    float wq[2][8];
-    auto issue = [&](int c, float(&dst)[8]) {
-        const int To = c / NS, s = c % NS;
-        const float *p = wbase + (16 * s) * ldw + 32 * To;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            dst[u] = p[u * ldw];
-            dst[4 + u] = p[(8 + u) * ldw];
-        }
+    float wq[2][4];
+    auto issue = [&](int c, float(&dst)[4]) {
+        const int To = c / NG, gi = c % NG;
+        const float *p = wbase + (8 * gi) * ldw + 32 * To;
+        dst[0] = p[0]; dst[1] = p[ldw]; dst[2] = p[2 * ldw]; dst[3] = p[3 * ldw];
     };
     issue(0, wq[0]);
-    f32x16 acc0 = {0}, acc1 = {0}, p0 = {0}, p1 = {0};
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int To = c / NS, s = c % NS;
-        const int Tk0 = (2 * s) >> 2, g0 = (2 * s) & 3, Tk1 = (2 * s + 1) >> 2, g1 = (2 * s + 1) & 3;
+    f32x16 acc = {0}, prev = {0};
+    auto group = [&](int To, int gi) {
+        const int c = To * NG + gi, Tk = gi >> 2, gq = gi & 3;
         if (c + 1 < NC) issue(c + 1, wq[(c + 1) & 1]);
-        if (s == 0) {
-            acc0 = f32x16{0};
-            acc1 = f32x16{0};
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc0 = mfma32(wq[c & 1][j], dz[Tk0][4 * g0 + j], acc0);
-            acc1 = mfma32(wq[c & 1][4 + j], dz[Tk1][4 * g1 + j], acc1);
-        }
-        if (To > 0 && s == 0) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = gate[To - 1][e] * (p0[e] + p1[e]);
-                ERL_PIN1(v);
-                gate[To - 1][e] = v;
-            }
-        }
-        ERL_SGB_DSREAD(8);
-        ERL_SGB_8X(4);
+        acc = mfma32(wq[c & 1][0], dz[Tk][4 * gq + 0], acc);
+        acc = mfma32(wq[c & 1][1], dz[Tk][4 * gq + 1], acc);
+        acc = mfma32(wq[c & 1][2], dz[Tk][4 * gq + 2], acc);
+        acc = mfma32(wq[c & 1][3], dz[Tk][4 * gq + 3], acc);
         __builtin_amdgcn_sched_barrier(0);
-        if (s == NS - 1) {
-            p0 = acc0;
-            p1 = acc1;
-        }
-    }
+    };
 #pragma unroll
-    for (int e = 0; e < 16; ++e) gate[3][e] *= p0[e] + p1[e];
-}
-
-// dW (nA32*32 x nB32*32) = TA . TB^T over the 128 staged samples, output tiles split over the waves.  The sum over
-// samples is order-free: lane half `hi` takes samples 8 j + 4 hi + {0..3} of every group of 8 (one 16-byte read per
-// operand feeds four MFMAs), even groups feed accumulator chain 0 and odd groups chain 1 (alternating, see rule 1).
-__device__ __forceinline__ void weight_grad_w4(const float *TA, int nA32, const float *TB, int nB32, float *__restrict__ dW,
-                                               int ldw, int cols_real, int wave, int lane)
-{
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int ntiles = nA32 * nB32;
-    for (int tile = wave; tile < ntiles; tile += QNW) {
-        const int it = tile / nB32, jt = tile - it * nB32;
-        const float *a4 = TA + (32 * it + l31) * PLD + 4 * hi;
-        const float *b4 = TB + (32 * jt + l31) * PLD + 4 * hi;
-        f32x16 acc0 = {0}, acc1 = {0};
-        float4 av[2][2], bv[2][2];
-        auto issue = [&](int pr, float4(&a)[2], float4(&b)[2]) {
-            a[0] = *reinterpret_cast<const float4 *>(a4 + 16 * pr);
-            b[0] = *reinterpret_cast<const float4 *>(b4 + 16 * pr);
-            a[1] = *reinterpret_cast<const float4 *>(a4 + 16 * pr + 8);
-            b[1] = *reinterpret_cast<const float4 *>(b4 + 16 * pr + 8);
-        };
-        issue(0, av[0], bv[0]);
+    for (int To = 0; To < 4; ++To) {
+        acc = f32x16{0};
+        group(To, 0);
+        if (To > 0) {
 #pragma unroll
-        for (int pr = 0; pr < PB / 16; ++pr) {
-            if (pr + 1 < PB / 16) issue(pr + 1, av[(pr + 1) & 1], bv[(pr + 1) & 1]);
-            const float4 x0 = av[pr & 1][0], y0 = bv[pr & 1][0], x1 = av[pr & 1][1], y1 = bv[pr & 1][1];
-            acc0 = mfma32(x0.x, y0.x, acc0);
-            acc1 = mfma32(x1.x, y1.x, acc1);
-            acc0 = mfma32(x0.y, y0.y, acc0);
-            acc1 = mfma32(x1.y, y1.y, acc1);
-            acc0 = mfma32(x0.z, y0.z, acc0);
-            acc1 = mfma32(x1.z, y1.z, acc1);
-            acc0 = mfma32(x0.w, y0.w, acc0);
-            acc1 = mfma32(x1.w, y1.w, acc1);
-            ERL_SGB_DSREAD(4);
-            ERL_SGB_8X(1);
+            for (int e = 0; e < 16; e += 2) {
+                f32x2 v = f32x2{gate[To - 1][e], gate[To - 1][e + 1]} * f32x2{prev[e], prev[e + 1]};
+                asm volatile("" : "+v"(v.x), "+v"(v.y));
+                gate[To - 1][e] = v.x;
+                gate[To - 1][e + 1] = v.y;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const int i = 32 * jt + l31;
-        if (i < cols_real) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dW[(size_t)(32 * it + crow(r, hi)) * ldw + i] = acc0[r] + acc1[r];
-        }
+        for (int gi = 1; gi < NG; ++gi) group(To, gi);
+        prev = acc;
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gate[3][e] *= prev[e];
 }
 
 // stage a register-resident activation (32x32 D layout) feature-major into LDS: T[feature][sample col]
@@ -297,6 +246,95 @@ __device__ __forceinline__ void stage32(float *T, const f32x16 (&a)[NT_], int co
     for (int t = 0; t < NT_; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[(32 * t + crow(r, hi)) * PLD + col] = a[t][r];
+    }
+}
+
+// dW (nA32*32 x nB32*32) = TA . TB^T over the 128 staged samples, output tiles split over the waves.  The sum over
+// samples is order-free: lane half `hi` takes samples 8 j + 4 hi + {0..3} of every group of 8 (one 16-byte read per
+// operand feeds four MFMAs); operands are read one group ahead.
+__device__ __forceinline__ void weight_grad_w4(const float *TA, int nA32, const float *TB, int nB32, float *__restrict__ dW,
+                                               int ldw, int cols_real, int wave, int lane)
+{
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntiles = nA32 * nB32;
+    for (int tile = wave; tile < ntiles; tile += QNW) {
+        const int it = tile / nB32, jt = tile - it * nB32;
+        const float *a4 = TA + (32 * it + l31) * PLD + 4 * hi;
+        const float *b4 = TB + (32 * jt + l31) * PLD + 4 * hi;
+        f32x16 acc = {0};
+        float4 av[2], bv[2];
+        av[0] = *reinterpret_cast<const float4 *>(a4);
+        bv[0] = *reinterpret_cast<const float4 *>(b4);
+#pragma unroll
+        for (int j = 0; j < PB / 8; ++j) {
+            if (j + 1 < PB / 8) {
+                av[(j + 1) & 1] = *reinterpret_cast<const float4 *>(a4 + 8 * (j + 1));
+                bv[(j + 1) & 1] = *reinterpret_cast<const float4 *>(b4 + 8 * (j + 1));
+            }
+            const float4 x = av[j & 1], y = bv[j & 1];
+            acc = mfma32(x.x, y.x, acc);
+            acc = mfma32(x.y, y.y, acc);
+            acc = mfma32(x.z, y.z, acc);
+            acc = mfma32(x.w, y.w, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int i = 32 * jt + l31;
+        if (i < cols_real) {
+            float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * ldw] = acc[r];
+        }
+    }
+}
+
+// copy_load for a matrix that fills its padded tile exactly (rows x COLS, COLS % 4 == 0, 16-byte aligned): no clamps, no
+// selects -- one address and immediate offsets (the generic copy_load spends ~14 VALU instructions per 16-byte load)
+template <int MAXV, int COLS>
+__device__ __forceinline__ void copy_load_full(float4 (&v)[MAXV], const float *__restrict__ src, int tid)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(src) + tid;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) v[u] = p[u * QNT];
+}
+
+// LDS-DMA copy (global_load_lds_dwordx4: memory -> LDS without passing through registers) of a row-major [rows][128] fp32
+// matrix into its padded LDS image [NROWS_PAD][132].  The image is a sequence of 16-byte units, 33 per row (32 data + 1
+// pad); one wave instruction fills 64 consecutive units (LDS address = uniform base + 16 lane), every lane fetching the
+// unit's own source address -- pad units fetch a neighbour, rows >= `rows` are left alone (the caller has zeroed them).
+// Completion is tracked by the issuing wave's vmcnt.
+template <int NROWS_PAD>
+__device__ __forceinline__ void dma_copy128(const float *__restrict__ src, int rows, float *dst, int wave, int lane)
+{
+    constexpr int UNITS = NROWS_PAD * 33, NK = (UNITS + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < (NK + QNW - 1) / QNW; ++i) {
+        const int k = wave + QNW * i;                       // wave-uniform
+        if (k < NK) {
+            const int u = 64 * k + lane;
+            const int row = (u * 1986) >> 16, cu = u - 33 * row;     // u / 33 for u < 4224
+            if (u < UNITS && row < rows) __builtin_amdgcn_global_load_lds(src + row * 128 + 4 * min(cu, 31), dst + 256 * k, 16, 0, 0);
+        }
+    }
+}
+
+// row sums of the 16-row tile RC: rows a < OUT are db3, rows 8 + a are the std_log gradient (actor)
+__device__ __forceinline__ void bias_grad_head(const float *T, int OUT, float *__restrict__ db3, float *__restrict__ dstd, int lane)
+{
+    const int f = lane & 15, p = lane >> 4;
+    const float *src = T + f * PLD + 32 * p;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + k);
+        s0 += v.x + v.z;
+        s1 += v.y + v.w;
+    }
+    float s = s0 + s1;
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (p == 0) {
+        if (f < OUT) db3[f] = s;
+        else if (dstd && f >= 8 && f - 8 < OUT) dstd[f - 8] = s;
     }
 }
 
@@ -312,7 +350,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     const float *P = g.P[net];
     const float *std_log = P + d.oStd();
 
-    float *RA = smem;                      // W2 copy [128][ld2], later staged tiles [128][PLD]
+    float *RA = smem;                      // X sample-major [128][XLD], then W2 copy [128][ld2], later staged tiles [128][PLD]
     float *RB = RA + kQR;                  // W1 copy [128][ld1] | X^T [32 KX][PLD], later staged tiles
     float *RC = RB + kQR;                  // [16][PLD]   dY^T
     float *RW3 = RC + kQRC;                // W3 copy [16][ld3] (rows >= OUT are zero)
@@ -320,6 +358,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     float *s_part = s_b3 + 16;             // [4 waves][16]  per-wave dstd_log partials
     float *s_red = s_part + QNW * 16;      // [16] block_sum scratch
     constexpr int ld1 = lds_ld(32 * KX), ld2 = lds_ld(128), ld3 = lds_ld(128);
+    constexpr int XLD = 32 * KX + 4;       // sample-major X rows: 16-byte aligned, 16 consecutive rows on 16 distinct bank groups
     float *RX = RB + 128 * lds_ld(64);
 
     PROF(0);
@@ -329,10 +368,15 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
     float4 c1[4 * KX];
-    copy_load<VEC, 4 * KX, QNT>(c1, P + d.oW1(), h1, S, h1, 32 * KX, tid);
-    float bias_pre = (tid < 128) ? P[d.ob1() + tid] : P[d.ob2() + tid - 128];
+    if (VEC && S == 32 * KX) copy_load_full<4 * KX, 32 * KX>(c1, P + d.oW1(), tid);      // uniform branch
+    else copy_load<VEC, 4 * KX, QNT>(c1, P + d.oW1(), h1, S, h1, 32 * KX, tid);
+    const float bias_pre = (tid < 128) ? P[d.ob1() + tid] : P[d.ob2() + tid - 128];
     float b3_pre = 0.f;
     if (tid < 16) b3_pre = (tid < OUT) ? P[d.ob3() + tid] : 0.f;
+    // this lane's normalisation constants: it gathers the 16-byte chunk xc of EVERY row it loads (see below)
+    const int xr = lane >> 4, xc = lane & 15;
+    const float *avg = g.avg[net], *sdv = g.sd[net];
+    const float4 a4 = load4<VEC>(avg, 4 * xc, S), s4 = load4<VEC>(sdv, 4 * xc, S);
 
     // ---- trip 2: id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
     int64_t n_, t_;
@@ -344,13 +388,20 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
         n_ = id / g.H;
         t_ = id - n_ * g.H;
     }
-    const int64_t row = valid ? t_ * g.N + n_ : 0;
-    const float *srow = g.states + row * S;
-    const float *avg = g.avg[net], *sdv = g.sd[net];
-    // this sample's raw state slice, features 32 T + 8 g + 4 hi + j
-    float4 XR[4 * KX];
+    const int64_t row = valid ? t_ * g.N + n_ : 0;          // padding slots read row 0 (finite data) and carry zero weight
+    // The state rows are gathered COALESCED: lane (xr = lane >> 4, xc = lane & 15) loads chunk xc (16 bytes) of the rows of
+    // samples 4 i + xr, i = 0..7 -- 16 lanes cover one 256-byte row -- whose row numbers sit in lanes 4 i + xr (ds_bpermute).
+    float4 XR[8];
+    {
+        const int rlo = (int)(uint32_t)row, rhi = (int)(row >> 32);
 #pragma unroll
-    for (int t = 0; t < 4 * KX; ++t) XR[t] = load4<VEC>(srow, 8 * t + 4 * hi, S);
+        for (int i = 0; i < 8; ++i) {
+            const int src = 4 * (4 * i + xr);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, rlo), hi32 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, rhi);
+            const int64_t r_i = (int64_t)(((uint64_t)hi32 << 32) | lo);
+            XR[i] = load4<VEC>(g.states + r_i * S, 4 * xc, S);
+        }
+    }
     // per-sample scalars (consumed after the output layer)
     const float um = (valid && g.unmasks[row]) ? 1.f : 0.f;
     const float xa = ACTOR ? g.logprobs[row] : g.reward_sums[row];
@@ -364,46 +415,102 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
             sl_pre[j] = std_log[ac];
         }
     }
-    // ---- W2, W3 ride behind: they are not needed before the second layer
-    float4 c2[16], c3[2];
-    copy_load<VEC, 16, QNT>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
-    copy_load<VEC, 2, QNT>(c3, P + d.oW3(), OUT, h2, 16, h2, tid);
-
-    // ---- publish the W1 copy, the biases and X^T (zero padded to the tile grid), visible after barrier (0a)
+    // ---- publish the W1 copy and the biases (zero padded to the tile grid), visible after barrier (0a)
     copy_store<4 * KX, QNT>(c1, RB, ld1, h1, 32 * KX, tid);
     s_b1[tid] = bias_pre;                                   // s_b1 | s_b2 contiguous
     if (tid < 16) s_b3[tid] = b3_pre;
-    f32x16 X[KX];
 #pragma unroll
-    for (int t = 0; t < 4 * KX; ++t) {                      // (x - avg) / (std + 1e-4)   (AgentPPO.py:360-361)
-        const int k0 = 8 * t + 4 * hi;
-        const float4 a4 = load4<VEC>(avg, k0, S), s4 = load4<VEC>(sdv, k0, S);
-        const float rr[4] = {XR[t].x, XR[t].y, XR[t].z, XR[t].w}, aa[4] = {a4.x, a4.y, a4.z, a4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+    for (int e = tid; e < kQRW3 / 4; e += QNT) reinterpret_cast<float4 *>(RW3)[e] = zero4();   // rows >= OUT of the W3 copy stay zero
+    // ---- normalise, (x - avg) / (std + 1e-4) (AgentPPO.py:360-361) as x * r + (-avg r), r = 1 / (std + 1e-4): one packed
+    // FMA per two elements; write the rows sample-major (for this wave's own B operands) and feature-major (X^T for dW1)
+    {
+        const f32x2 r01 = {__builtin_amdgcn_rcpf(s4.x + 1e-4f), __builtin_amdgcn_rcpf(s4.y + 1e-4f)};
+        const f32x2 r23 = {__builtin_amdgcn_rcpf(s4.z + 1e-4f), __builtin_amdgcn_rcpf(s4.w + 1e-4f)};
+        const f32x2 n01 = -(f32x2{a4.x, a4.y} * r01), n23 = -(f32x2{a4.z, a4.w} * r23);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xn = (rr[j] - aa[j]) / (ss[j] + 1e-4f);
-            X[t >> 2][4 * (t & 3) + j] = (valid && k0 + j < S) ? xn : 0.f;
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 x01 = f32x2{XR[i].x, XR[i].y} * r01 + n01, x23 = f32x2{XR[i].z, XR[i].w} * r23 + n23;
+            const int sc = 32 * wave + 4 * i + xr;
+            if (4 * xc < 32 * KX) {
+                *reinterpret_cast<float4 *>(RA + sc * XLD + 4 * xc) = make_float4(x01.x, x01.y, x23.x, x23.y);
+                float *t = RX + (4 * xc) * PLD + sc;
+                t[0] = x01.x; t[PLD] = x01.y; t[2 * PLD] = x23.x; t[3 * PLD] = x23.y;
+            }
         }
     }
-    stage32<KX>(RX, X, col, hi);
-    PROF_NV(1);
-    lds_barrier();                                                   // (0a) W1 copy, biases visible
-    PROF_NV(2);
-    f32x16 H1[4], G1[4], H2[4], G2[4];
-    Pend pend1, pend2, pendY;
-    fwd32<KX, false, 4, false>(RB, ld1, s_b1, m, X, X, pend1, H1, G1, pend1, hi);          // H1[3] left pending
-    PROF_NV(3);
-    copy_store<16, QNT>(c2, RA, ld2, h2, h1, tid);
-    copy_store<2, QNT>(c3, RW3, ld3, 16, h2, tid);
-    lds_barrier();                                                   // (0b) W2, W3 copies visible
-    fwd32<4, true, 4, false>(RA, ld2, s_b2, m, H1, G1, pend1, H2, G2, pend2, hi);           // finishes H1[3]; H2[3] pending
-    PROF(4);
-    // ---- output layer: one 32-row tile whose rows >= A are zero (lanes m >= 16 read row 15 of the 16-row copy, which is
-    // zero because A <= 8); finishes H2[3] on the way.  No activation: Y = a0 + a1, outputs a = 4 hi + j in elements 0..3.
-    fwd32<4, true, 1, true>(RW3, ld3, s_b3, m < 16 ? m : 15, H2, G2, pend2, H2, G2, pendY, hi);
-    float Y[4];
+    // this wave's own rows back as B operands (same wave: LDS executes a wave's accesses in order, no barrier needed)
+    f32x16 X[KX];
+    {
+        const float *xs = RA + col * XLD + 4 * hi;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Y[j] = pendY.a0[j] + pendY.a1[j];
+        for (int t = 0; t < 4 * KX; ++t) {
+            const float4 v = *reinterpret_cast<const float4 *>(xs + 8 * t);
+            X[t >> 2][4 * (t & 3) + 0] = v.x; X[t >> 2][4 * (t & 3) + 1] = v.y;
+            X[t >> 2][4 * (t & 3) + 2] = v.z; X[t >> 2][4 * (t & 3) + 3] = v.w;
+        }
+    }
+    PROF_NV(1);
+    lds_barrier();                                                   // (0a) W1 copy, biases visible; X rows consumed
+    PROF_NV(2);
+    // ---- W2, W3 are not needed before the second layer: requested only now, so that the prologue's burst (every CU pulls
+    // its 32 KB of W1 and 32 KB of gathered rows at once, ~11 B/clk per CU) is not stretched by another 68 KB; they
+    // stream in under the first layer's MFMAs, by LDS-DMA: held in registers they would need 72 VGPRs across the first layer
+    // (hipcc spilled them to scratch, waiting for every load first)
+    dma_copy128<128>(P + d.oW2(), 128, RA, wave, lane);
+    dma_copy128<16>(P + d.oW3(), OUT, RW3, wave, lane);
+    f32x16 H1[4], G1[4], H2[4], G2[4];
+    fwd32<KX>(RB, ld1, s_b1, X, H1, G1, m, hi);
+    PROF_NV(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's share of the W2 / W3 copies has landed
+    lds_barrier();                                                   // (0b) W2, W3 copies visible
+    fwd32<4>(RA, ld2, s_b2, H1, H2, G2, m, hi);
+    PROF(4);
+    // ---- output layer on the vector ALUs: A <= 8 rows would fill a quarter of a 32-row MFMA tile, and the fp32 MFMA runs
+    // at the packed-FMA rate anyway.  Each lane reduces its own 64 features of H2 against the rows of W3 (broadcast
+    // 16-byte LDS reads), the two lane halves meet through v_permlane32_swap, which also leaves outputs a = 4 hi + j of
+    // sample m in lane (m, hi) -- the layout the objective and the dZ2 MFMAs want.
+    float Y[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        constexpr int NR = ACTOR ? 8 : 1;
+        f32x2 yp[NR];
+#pragma unroll
+        for (int a = 0; a < NR; ++a) yp[a] = f32x2{0.f, 0.f};
+        // batches of four 16-byte reads (one row a, one tile T), issued one batch ahead of the eight packed FMAs that
+        // consume them: with a single wave per SIMD an un-prefetched LDS read costs its whole latency
+        const float *w3 = RW3 + 4 * hi;
+        float4 wq[2][4];
+        auto issue = [&](int bt, float4(&dst)[4]) {
+            const int T = bt / NR, a = bt % NR;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) dst[gq] = *reinterpret_cast<const float4 *>(w3 + a * ld3 + 32 * T + 8 * gq);
+        };
+        issue(0, wq[0]);
+#pragma unroll
+        for (int bt = 0; bt < 4 * NR; ++bt) {
+            const int T = bt / NR, a = bt % NR;
+            if (bt + 1 < 4 * NR) issue(bt + 1, wq[(bt + 1) & 1]);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 w = wq[bt & 1][gq];
+                yp[a] = f32x2{w.x, w.y} * f32x2{H2[T][4 * gq + 0], H2[T][4 * gq + 1]} + yp[a];
+                yp[a] = f32x2{w.z, w.w} * f32x2{H2[T][4 * gq + 2], H2[T][4 * gq + 3]} + yp[a];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 b4 = *reinterpret_cast<const float4 *>(s_b3 + 4 * hi);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+        if (ACTOR) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = yp[j].x + yp[j].y, hi_ = yp[NR > 4 ? 4 + j : j].x + yp[NR > 4 ? 4 + j : j].y;
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
+                Y[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) + bb[j];   // lanes < 32: output j; lanes >= 32: output 4 + j
+            }
+        } else {
+            const float s = yp[0].x + yp[0].y;
+            Y[0] = s + __shfl_xor(s, 32, 64) + bb[0];
+        }
+    }
     PROF(5);
 
     // ---- objective and dL/dY for this lane's outputs a = 4 hi + j   (AgentPPO.py:189-204)
@@ -411,7 +518,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     float loss0 = 0.f, loss1 = 0.f;
     float dsl[4] = {0.f, 0.f, 0.f, 0.f};
     if (!ACTOR) {
-        const float diff = Y[0] - xa;                  // only (hi = 0, j = 0) is the value head
+        const float diff = Y[0] - xa;                     // only (hi = 0, j = 0) is the value head
         const bool head = hi == 0;
         loss0 = head ? diff * diff * um : 0.f;
         dY[0] = head ? 2.f * diff * um * g.inv_batch : 0.f;
@@ -452,19 +559,6 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
         }
     }
 
-    // ---- per-wave dstd_log partials (sum over the wave's 32 samples)
-    if (ACTOR) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = dsl[j];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 8, 64);
-            s += __shfl_xor(s, 16, 64);
-            if (m == 0) s_part[wave * 16 + 4 * hi + j] = s;
-        }
-    }
     // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 8 outputs: four k-pairs);  dZ1 = (W2^T dZ2) * GELU'(z1)
     PROF(6);
     {
@@ -474,16 +568,13 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
 #pragma unroll
             for (int j = 0; j < 4; ++j) w3[To][j] = RW3[(4 * hi + j) * ld3 + 32 * To + m];
         }
-        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                               // four independent chains, interleaved
-#pragma unroll
-            for (int To = 0; To < 4; ++To) acc[To] = mfma32(w3[To][j], dY[j], acc[To]);
-        }
 #pragma unroll
         for (int To = 0; To < 4; ++To) {
+            f32x16 acc = {0};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) G2[To][r] *= acc[To][r];
+            for (int j = 0; j < 4; ++j) acc = mfma32(w3[To][j], dY[j], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G2[To][r] *= acc[r];
         }
     }
     bwd32<4>(RA, ld2, G2, G1, m, hi);                               // G1 (the gate) <- dZ1
@@ -497,21 +588,14 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         RC[(4 * hi + j) * PLD + col] = dY[j];
-        RC[(8 + 4 * hi + j) * PLD + col] = 0.f;
+        RC[(8 + 4 * hi + j) * PLD + col] = dsl[j];       // rows 8..15: per-sample dL/dstd_log (zero for the critic); their row sums
+                                                         // are the std_log gradient, and dW3 never stores product rows >= A
     }
     lds_barrier();                                                   // (2)
     PROF(9);
     weight_grad_w4(RA, 4, RX, (S + 31) >> 5, slab + d.oW1(), S, S, wave, lane);
     bias_grad<QNW>(RA, h1, slab + d.ob1(), wave, lane);
-    if (wave == 0) {
-        bias_grad<QNW>(RC, OUT, slab + d.ob3(), 0, lane);
-        if (ACTOR && lane < OUT) {
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < QNW; ++u) s += s_part[u * 16 + lane];
-            slab[d.oStd() + lane] = s;
-        }
-    }
+    if (wave == 0) bias_grad_head(RC, OUT, slab + d.ob3(), ACTOR ? slab + d.oStd() : nullptr, lane);
     PROF(10);
     lds_barrier();                                                   // (3) dZ1^T, X^T consumed
 
@@ -523,23 +607,17 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     {
         const int l15 = lane & 15, q = lane >> 4;
         for (int it = wave; it < 8; it += QNW) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float *a = RC + l15 * PLD + 4 * q;                    // lane group q: samples 16 j + 4 q + {0..3}
             const float *b = RA + (16 * it + l15) * PLD + 4 * q;
 #pragma unroll
-            for (int j = 0; j < PB / 16; j += 2) {                      // two alternating chains (16x16x4: 40-cycle dependent latency)
+            for (int j = 0; j < PB / 16; ++j) {
                 const float4 av = *reinterpret_cast<const float4 *>(a + 16 * j), bv = *reinterpret_cast<const float4 *>(b + 16 * j);
-                const float4 aw = *reinterpret_cast<const float4 *>(a + 16 * j + 16), bw = *reinterpret_cast<const float4 *>(b + 16 * j + 16);
                 acc = mfma16(av.x, bv.x, acc);
-                acc1 = mfma16(aw.x, bw.x, acc1);
                 acc = mfma16(av.y, bv.y, acc);
-                acc1 = mfma16(aw.y, bw.y, acc1);
                 acc = mfma16(av.z, bv.z, acc);
-                acc1 = mfma16(aw.z, bw.z, acc1);
                 acc = mfma16(av.w, bv.w, acc);
-                acc1 = mfma16(aw.w, bw.w, acc1);
             }
-            acc += acc1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a_ = 4 * q + r;
@@ -601,8 +679,13 @@ int launch_w4(const Ppo2Args &g, int n_slabs, hipStream_t stream)
 
 bool erl_ppo_w4_supported(int S, int h1, int h2, int A) { return S >= 1 && S <= 64 && h1 == 128 && h2 == 128 && A >= 1 && A <= 8; }
 
+// `vec`: every row / parameter block / normalisation vector is 16-byte aligned and S % 4 == 0 (the LDS-DMA weight copies
+// and the 16-byte gathers need it); other inputs take the 8-wave kernel
 int erl_ppo_w4_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream)
 {
-    if (g.S > 32) return vec ? launch_w4<2, true>(g, n_slabs, stream) : launch_w4<2, false>(g, n_slabs, stream);
-    return vec ? launch_w4<1, true>(g, n_slabs, stream) : launch_w4<1, false>(g, n_slabs, stream);
+    if (!vec) {
+        erl_set_error("erl_ppo_w4_launch: unaligned input");
+        return ERL_EINVAL;
+    }
+    return g.S > 32 ? launch_w4<2, true>(g, n_slabs, stream) : launch_w4<1, true>(g, n_slabs, stream);
 }

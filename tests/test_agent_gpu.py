@@ -309,6 +309,7 @@ def test_train_agent_ppo_pendulum_learns(tmp_path):
     args.gamma, args.reward_scale, args.learning_rate = 0.97, 2 ** -2, 4e-4
     args.break_step, args.eval_per_step, args.eval_times = 200 * 100, 200 * 10, 8
     args.cwd, args.gpu_id, args.random_seed = str(tmp_path / "run"), 0, 1
+    args.gae_algo = "exact"    # fixed association: the run is then reproducible bit for bit (the look-back scan is not)
     train_agent(args, if_single_process=True)
     rec = np.load(os.path.join(args.cwd, "recorder.npy"))
     assert np.isfinite(rec[:, :4]).all()

@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void k(long long *out, float *sink, int reps)
     __syncthreads();
     const unsigned lds_off = 16u * lane;       // byte offset inside the dynamic LDS block (it starts at 0)
     f32x4 l0 = {0, 0, 0, 0}, l1 = {0, 0, 0, 0};
-    float wv = 3.f;
+    float wv = 3.f, wv2 = 4.f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 pk0 = {x, y}, pk1 = {y, x}, pk2 = {1.0f, 0.999f};
+    const unsigned bc_off = 16u * (lane >> 5);
     unsigned long long t0, t1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < reps; ++it) {
@@ -68,10 +71,38 @@ __global__ __launch_bounds__(256) void k(long long *out, float *sink, int reps)
         else if (MODE == 14)  // two chains, v_accvgpr_read + write (of another AGPR) per gap
             asm volatile(R8(M0 "v_accvgpr_read_b32 %[x], %[w]\n\tv_accvgpr_write_b32 %[w], %[x]\n\t" M1 "v_accvgpr_read_b32 %[y], %[w]\n\tv_accvgpr_write_b32 %[w], %[y]\n\t")
                          : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y), [w] "+a"(wv) : [a] "v"(a), [b] "v"(b));
+        else if (MODE == 20)  // VALU only: 16 v_fma_f32 on two independent registers
+            asm volatile(R8(VI VJ) : [x] "+v"(x), [y] "+v"(y) : [z] "v"(z));
+        else if (MODE == 21)  // 16 dependent v_fma_f32
+            asm volatile(R8(VD VD) : [x] "+v"(x) : [z] "v"(z));
+        else if (MODE == 22)  // 16 v_pk_fma_f32 on two independent register pairs
+            asm volatile(R8("v_pk_fma_f32 %[p], %[r], %[r], %[p]\n\tv_pk_fma_f32 %[q], %[r], %[r], %[q]\n\t") : [p] "+v"(pk0), [q] "+v"(pk1) : [r] "v"(pk2));
+        else if (MODE == 23)  // 16 dependent v_pk_fma_f32 with the s_nop hipcc puts between them
+            asm volatile(R8("v_pk_fma_f32 %[p], %[p], %[r], %[r]\n\ts_nop 0\n\tv_pk_fma_f32 %[p], %[p], %[r], %[r]\n\ts_nop 0\n\t") : [p] "+v"(pk0) : [r] "v"(pk2));
+        else if (MODE == 24)  // 16 dependent v_pk_fma_f32, no s_nop (timing only)
+            asm volatile(R8("v_pk_fma_f32 %[p], %[p], %[r], %[r]\n\tv_pk_fma_f32 %[p], %[p], %[r], %[r]\n\t") : [p] "+v"(pk0) : [r] "v"(pk2));
+        else if (MODE == 25)  // 16 v_exp_f32 (independent sources)
+            asm volatile(R8("v_exp_f32 %[x], %[z]\n\tv_exp_f32 %[y], %[z]\n\t") : [x] "+v"(x), [y] "+v"(y) : [z] "v"(z));
+        else if (MODE == 26)  // 16 v_rcp_f32
+            asm volatile(R8("v_rcp_f32 %[x], %[z]\n\tv_rcp_f32 %[y], %[z]\n\t") : [x] "+v"(x), [y] "+v"(y) : [z] "v"(z));
+        else if (MODE == 27)  // 16 v_accvgpr_write_b32 (two AGPRs)
+            asm volatile(R8("v_accvgpr_write_b32 %[w], %[z]\n\tv_accvgpr_write_b32 %[w2], %[z]\n\t") : [w] "+a"(wv), [w2] "+a"(wv2) : [z] "v"(z));
+        else if (MODE == 28)  // 16 v_accvgpr_read_b32
+            asm volatile(R8("v_accvgpr_read_b32 %[x], %[w]\n\tv_accvgpr_read_b32 %[y], %[w2]\n\t") : [x] "+v"(x), [y] "+v"(y), [w] "+a"(wv), [w2] "+a"(wv2));
+        else if (MODE == 29)  // 16 v_bfi_b32
+            asm volatile(R8("v_bfi_b32 %[x], %[z], %[x], %[y]\n\tv_bfi_b32 %[y], %[z], %[y], %[x]\n\t") : [x] "+v"(x), [y] "+v"(y) : [z] "v"(z));
+        else if (MODE == 30)  // 16 independent v_fma with 16 s_nop 0 interleaved
+            asm volatile(R8(VI NOP VJ NOP) : [x] "+v"(x), [y] "+v"(y) : [z] "v"(z));
+        else if (MODE == 31)  // 16 v_mov_b32
+            asm volatile(R8("v_mov_b32 %[x], %[z]\n\tv_mov_b32 %[y], %[z]\n\t") : [x] "+v"(x), [y] "+v"(y) : [z] "v"(z));
+        else if (MODE == 32)  // 8 x (ds_read_b128 broadcast-per-half + wait)
+            asm volatile(R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") : [l0] "=&v"(l0) : [p] "v"(bc_off));
+        else if (MODE == 33)  // 16 x (ds_read_b128 distinct addresses + wait)
+            asm volatile(R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") : [l0] "=&v"(l0) : [p] "v"(lds_off));
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     if (lane == 0 && blockIdx.x == 0) out[wave] = (long long)(t1 - t0);
-    float s = x + y + l0[0] + l1[1] + wv;
+    float s = x + y + l0[0] + l1[1] + wv + wv2 + pk0.x + pk1.y;
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
     if (s == 12345.678f) sink[threadIdx.x] = s;
 }
@@ -118,5 +149,20 @@ int main()
     run<12>("12 two chains + ds_read_b32 per 2 MFMAs");
     run<13>("13 two chains + 1 s_nop per gap");
     run<14>("14 two chains + accvgpr read+write per gap");
+    printf("--- VALU only: ticks per 16 instructions are (ticks / 'MFMA') x 1, i.e. per instruction = value / 16 ...\n");
+    run<20>("20 16 v_fma_f32, two independent accumulators      [per 16]");
+    run<21>("21 16 v_fma_f32, one dependent chain               [per 16]");
+    run<22>("22 16 v_pk_fma_f32, two independent                [per 16]");
+    run<23>("23 16 v_pk_fma_f32 dependent + s_nop 0 each        [per 16]");
+    run<24>("24 16 v_pk_fma_f32 dependent, no s_nop             [per 16]");
+    run<25>("25 16 v_exp_f32                                    [per 16]");
+    run<26>("26 16 v_rcp_f32                                    [per 16]");
+    run<27>("27 16 v_accvgpr_write_b32                          [per 16]");
+    run<28>("28 16 v_accvgpr_read_b32                           [per 16]");
+    run<29>("29 16 v_bfi_b32 (dependent pair)                   [per 16]");
+    run<30>("30 16 v_fma_f32 + 16 s_nop 0                       [per 16]");
+    run<31>("31 16 v_mov_b32                                    [per 16]");
+    run<32>("32 16 x (ds_read_b128 half-broadcast + wait)       [per 16]");
+    run<33>("33 16 x (ds_read_b128 distinct + wait)             [per 16]");
     return 0;
 }

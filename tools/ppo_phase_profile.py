@@ -43,9 +43,28 @@ def main():
     lib.erl_debug_set_ppo_profile(prof.data_ptr())
     run = lambda: ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,  # noqa: E731
                                ids, 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    lib.erl_debug_set_ppo_profile_block.argtypes = [ctypes.c_int]
+    lib.erl_debug_set_ppo_profile_block.restype = None
+    for blk in (1, 37, 64, 127):                      # are the workgroups alike?  (total cycles, wave 0 of each net)
+        lib.erl_debug_set_ppo_profile_block(blk)
+        prof.zero_()
+        for _ in range(3):
+            run()
+        th.cuda.synchronize()
+        q = prof.cpu().view(2, 8, 32)
+        print(f"workgroup {blk:3d}: actor {int(q[0, 0, NP - 1] - q[0, 0, 0])} cycles, critic {int(q[1, 0, NP - 1] - q[1, 0, 0])} cycles; "
+              f"start skew vs critic {int(q[1, 0, 0] - q[0, 0, 0])}")
+    lib.erl_debug_set_ppo_profile_block(0)
+    prof.zero_()
+    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
     for _ in range(5):
         run()
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
     th.cuda.synchronize()
+    print(f"wall time per launch of this (instrumented) build: {e0.elapsed_time(e1) * 50:.1f} us")
     p = prof.cpu().view(2, 8, 32)[:, :, :NP]
     p = p[:, (p[0, :, 0] != 0)]                        # the 4-wave form stamps waves 0..3 only
     print(f"{p.shape[1]} waves per workgroup")
