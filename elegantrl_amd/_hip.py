@@ -22,7 +22,8 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 8
+ABI_VERSION = 9
+PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 COMM_ID_BYTES = 128
 
 _P = c_void_p
@@ -56,28 +57,28 @@ _SIGNATURES = {
     "erl_ppo_slab_stride": (c_int64, [c_int, c_int, c_int, c_int]),
     "erl_ppo_num_slabs": (c_int, [c_int64]),
     "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
-                                 c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, _P, c_int, _P]),
+                                 c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, c_int, _P, c_int, _P]),
     "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),
     "erl_clip_adam_f32": (c_int, [_P, _P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, _P, c_int32, c_float,
                                   c_float, c_float, c_float, c_float, c_float, _P]),
     "erl_ppo_update_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
-                                   _P, c_int64, c_int, c_float, c_float, _P, _P, c_int32, c_float, c_float, c_float, c_float, c_float,
-                                   _P]),
+                                   _P, c_int64, c_int, c_float, c_float, c_int, _P, _P, c_int32, c_float, c_float, c_float, c_float,
+                                   c_float, _P]),
     "erl_comm_unique_id": (c_int, [_P]),
     "erl_comm_init": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
     "erl_comm_destroy": (c_int, [_P]),
     "erl_comm_world_size": (c_int, [_P]),
     "erl_comm_allreduce_sum_f32": (c_int, [_P, _P, c_int64, _P]),
     "erl_ppo_update_dp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
-                                      _P, c_int64, c_int, c_float, c_float, _P, _P, c_int32, c_float, c_float, c_float, c_float,
-                                      c_float, _P, _P]),
+                                      _P, c_int64, c_int, c_float, c_float, c_int, _P, _P, c_int32, c_float, c_float, c_float,
+                                      c_float, c_float, _P, _P]),
     "erl_mlpn_param_count": (c_int64, [POINTER(c_int), c_int, c_int]),
     "erl_mlpn_workspace_bytes": (c_int64, [POINTER(c_int), c_int, c_int64, c_int]),
     "erl_mlpn_value_forward_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, _P, c_int64, _P]),
     "erl_mlpn_rollout_step_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P, _P,
                                           _P, c_int64, _P]),
     "erl_mlpn_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P,
-                                      c_int64, c_float, c_float, c_float, _P, _P, c_int64, _P]),
+                                      c_int64, c_float, c_float, c_float, c_int, _P, _P, c_int64, _P]),
     "erl_mlpn_rollout_step_discrete_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P,
                                                    _P, _P, _P, c_int64, _P]),
     "erl_mlpn_ppo_step_discrete_f32": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, _P, _P, _P, c_int64,

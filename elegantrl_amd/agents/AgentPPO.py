@@ -133,6 +133,10 @@ class AgentPPO(AgentBase):
         # the reference reads `if_use_v_trace`; its Config sets `if_use_vtrace` (never consumed): accept both
         self.if_use_v_trace = getattr(args, "if_use_v_trace", getattr(args, "if_use_vtrace", True))
         self.gae_algo = getattr(args, "gae_algo", "auto")
+        # which actor objective the kernels differentiate: the reference's sign-dependent scale (AgentPPO.py:199, default) or,
+        # with args.canonical_ppo = True, the textbook min(r A, clamp(r, 1 - clip, 1 + clip) A) of
+        # helloworld/helloworld_PPO_single_file.py:337-339
+        self._objective = _hip.PPO_OBJ_CANONICAL if getattr(args, "canonical_ppo", False) else _hip.PPO_OBJ_REFERENCE
 
         from .. import ops  # deferred: importing the package must work without the built extension
         if self._fused:
@@ -448,9 +452,10 @@ class AgentPPO(AgentBase):
             for k in range(update_times):
                 g = self._grads[k]
                 step = ops.mlpn_ppo_step_discrete if self._discrete else ops.mlpn_ppo_step
+                extra = {} if self._discrete else {"objective": self._objective}
                 step(self._flat_a.flat, self._flat_c.flat, a.state_avg.data, a.state_std.data, c.state_avg.data,
-                                  c.state_std.data, self._spec_a, states, actions, unmasks, logprobs, advantages, reward_sums,
-                                  ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch, g)
+                     c.state_std.data, self._spec_a, states, actions, unmasks, logprobs, advantages, reward_sums,
+                     ids[k], float(self.ratio_clip), self.lambda_entropy_value, inv_batch, g, **extra)
                 if comm is not None:
                     comm.all_reduce_sum(g)
                 elif dp:
@@ -469,7 +474,8 @@ class AgentPPO(AgentBase):
             ops.ppo_update(self._flat, self._exp_avg, self._exp_avg_sq, a.state_avg.data, a.state_std.data, c.state_avg.data,
                            c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
                            advantages, reward_sums, ids, float(self.ratio_clip), self.lambda_entropy_value, self._slabs,
-                           self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm), comm=comm)
+                           self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm), comm=comm,
+                           objective=self._objective)
             self._adam_step += update_times
         else:                           # data parallel through torch.distributed (gloo tests, ERL_DP_COLLECTIVE=torch)
             # raw pointers + direct C-ABI calls: the interpreter spends ~3 us per launch instead of ~10 (ptr checks, views)
@@ -488,7 +494,8 @@ class AgentPPO(AgentBase):
             lr, max_norm, stride = float(self.learning_rate), float(self.clip_grad_norm), self._stride
             for k in range(update_times):
                 rc = L.erl_ppo_step_f32(pf, pf + 4 * self._Pa, p_avg_a, p_std_a, p_avg_c, p_std_c, S_, h1, h2, A_, p_s, p_ac, p_um,
-                                        p_lp, p_adv, p_rs, H, N, p_ids + 8 * k * B, B, clip, lam_e, inv_batch, p_slabs, n_slabs, sp)
+                                        p_lp, p_adv, p_rs, H, N, p_ids + 8 * k * B, B, clip, lam_e, inv_batch, self._objective, p_slabs,
+                                        n_slabs, sp)
                 rc = rc or L.erl_grad_reduce_f32(p_slabs, n_slabs, stride, p_g + 4 * k * stride, sp)
                 if rc:
                     _hip.check(rc, "erl_ppo_step_f32 / erl_grad_reduce_f32")
@@ -521,6 +528,31 @@ class AgentPPO(AgentBase):
             self.act.state_std[:] = (self.act.state_std * (1 - tau) + state_std * tau).clamp_min(1e-4)
             self.cri.state_avg[:] = self.act.state_avg
             self.cri.state_std[:] = self.act.state_std
+
+
+class AgentA2C(AgentPPO):
+    """A2C (elegantrl/agents/AgentPPO.py:252-303): AgentPPO's rollout, GAE and advantage normalisation, minibatches of whole
+    TIME ROWS (`indices = randint(buffer_size)`, :289) and the un-clipped objective `mean(advantage * new_logprob)` (:301)
+    without unmask and without an entropy term; `update_net` returns (obj_critic, obj_actor, 0).
+
+    Like the reference's this agent is for ONE environment: with `num_envs > 1` the reference's `states[indices]` keeps the
+    env axis, `cri(state).squeeze(1)` no longer squeezes and `criterion(value, reward_sum)` broadcasts (B, N, 1) against
+    (B, N) -- the class only produces the intended objective for `num_envs == 1`, so that is what is supported here (a
+    ValueError otherwise).  With one env the reference's `get_logprob_entropy(...).sum(1)` sums over the env axis (size 1)
+    instead of the action axis, so `new_logprob` is per action dimension and the mean runs over (batch, action_dim): the
+    objective is mean_B(adv * logp) / action_dim -- reproduced (ERL_PPO_OBJ_A2C, csrc/ppo_objective.h)."""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
+        super().__init__(net_dims, state_dim, action_dim, gpu_id, args)
+        if self.num_envs != 1:
+            raise ValueError("AgentA2C follows the reference's time-row minibatches, which are only well formed for num_envs == 1 "
+                             "(elegantrl/agents/AgentPPO.py:289-303); use AgentPPO for vectorised envs")
+        self._objective = _hip.PPO_OBJ_A2C
+
+    def update_net(self, buffer, ids: Optional[TEN] = None) -> Tuple[float, float, float]:
+        """`ids`, if given, are the time indices (update_times, batch_size) in [0, horizon_len)."""
+        obj_critic, obj_actor, _ = super().update_net(buffer, ids=ids)      # H * N == H: ids are time rows, env 0
+        return obj_critic, obj_actor, 0
 
 
 class AgentDiscretePPO(AgentPPO):

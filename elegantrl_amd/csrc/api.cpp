@@ -94,10 +94,10 @@ extern "C" int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp
                                   const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
                                   const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                                   const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
-                                  int update_times, float ratio_clip, float lambda_entropy, float *slabs, float *grads,
+                                  int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs, float *grads,
                                   int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, void *stream)
 {
     return erl_ppo_update_dp_f32(flat_params, exp_avg, exp_avg_sq, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
                                  unmasks, logprobs, advantages, reward_sums, H, N, ids, B, update_times, ratio_clip, lambda_entropy,
-                                 slabs, grads, first_step, lr, beta1, beta2, eps, max_norm, /*comm=*/nullptr, stream);
+                                 objective, slabs, grads, first_step, lr, beta1, beta2, eps, max_norm, /*comm=*/nullptr, stream);
 }

@@ -112,7 +112,7 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
                                      const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
                                      const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                                      const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
-                                     int update_times, float ratio_clip, float lambda_entropy, float *slabs, float *grads,
+                                     int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs, float *grads,
                                      int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, void *comm,
                                      void *stream)
 {
@@ -129,7 +129,7 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
         float *g = grads + (size_t)k * stride;
         int rc = erl_ppo_step_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
                                   unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
-                                  lambda_entropy, 1.0f / (float)B, slabs, n_slabs, stream);
+                                  lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, stream);
         if (rc) return rc;
         if ((rc = erl_grad_reduce_f32(slabs, n_slabs, stride, g, stream))) return rc;
         if (comm && (rc = erl_comm_allreduce_sum_f32(comm, g, stride, stream))) return rc;   // gradient + the 3 logged objectives

@@ -122,7 +122,7 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
                   const float *act_std, const float *cri_avg, const float *cri_std, const int *actor_dims, int n_dims,
                   const float *states, const void *actions_any, const uint8_t *unmasks, const float *logprobs,
                   const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
-                  float ratio_clip, float lambda_entropy, float inv_batch, float *flat_grad, void *workspace,
+                  float ratio_clip, float lambda_entropy, float inv_batch, int objective, float *flat_grad, void *workspace,
                   int64_t workspace_bytes, void *stream)
 {
     const float *actions = discrete ? nullptr : (const float *)actions_any;
@@ -175,11 +175,11 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
                                advantages, ratio_clip, lambda_entropy, inv_batch, part);
         else if (net == 0)
             hipLaunchKernelGGL((objective_kernel<true>), dim3(nparts), dim3(256), 0, s, Y, dsl, ids, H, N, A, B, actions, unmasks, logprobs,
-                               advantages, P + nd.oStd, ratio_clip, lambda_entropy, inv_batch, part);
+                               advantages, P + nd.oStd, ratio_clip, lambda_entropy, inv_batch, objective, part);
         else
             hipLaunchKernelGGL((objective_kernel<false>), dim3(nparts), dim3(256), 0, s, Y, (float *)nullptr, ids, H, N, 1, B, actions,
                                unmasks, reward_sums, (const float *)nullptr, (const float *)nullptr, ratio_clip, lambda_entropy,
-                               inv_batch, part);
+                               inv_batch, objective, part);
         hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, s, part, nparts, P + nd.oStd, A, inv_batch,
                            net == 0 ? (discrete ? 2 : 1) : 0, logs);
         if (net == 0 && !discrete && (rc = colsum(s, dsl, cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
@@ -196,12 +196,14 @@ extern "C" int erl_mlpn_ppo_step_f32(const float *actor_params, const float *cri
                                      const float *cri_avg, const float *cri_std, const int *actor_dims, int n_dims,
                                      const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
                                      const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
-                                     int64_t B, float ratio_clip, float lambda_entropy, float inv_batch, float *flat_grad,
-                                     void *workspace, int64_t workspace_bytes, void *stream)
+                                     int64_t B, float ratio_clip, float lambda_entropy, float inv_batch, int objective,
+                                     float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream)
 {
+    ERL_REQUIRE(objective >= ERL_PPO_OBJ_REFERENCE && objective <= ERL_PPO_OBJ_A2C, "erl_mlpn_ppo_step_f32: unknown objective %d",
+                objective);
     return ppo_step_impl("erl_mlpn_ppo_step_f32", false, actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, actor_dims,
                          n_dims, states, actions, unmasks, logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy,
-                         inv_batch, flat_grad, workspace, workspace_bytes, stream);
+                         inv_batch, objective, flat_grad, workspace, workspace_bytes, stream);
 }
 
 extern "C" int erl_mlpn_ppo_step_discrete_f32(const float *actor_params, const float *critic_params, const float *act_avg,
@@ -213,5 +215,5 @@ extern "C" int erl_mlpn_ppo_step_discrete_f32(const float *actor_params, const f
 {
     return ppo_step_impl("erl_mlpn_ppo_step_discrete_f32", true, actor_params, critic_params, act_avg, act_std, cri_avg, cri_std,
                          actor_dims, n_dims, states, actions, unmasks, logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip,
-                         lambda_entropy, inv_batch, flat_grad, workspace, workspace_bytes, stream);
+                         lambda_entropy, inv_batch, ERL_PPO_OBJ_REFERENCE, flat_grad, workspace, workspace_bytes, stream);
 }

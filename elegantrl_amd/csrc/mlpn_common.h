@@ -3,6 +3,7 @@
 #pragma once
 
 #include "gemm_tiles.h"
+#include "ppo_objective.h"
 
 namespace {
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void objective_kernel(float *__restrict__ Y, f
                                                         int64_t H, int64_t N, int A, int64_t B, const float *__restrict__ actions,
                                                         const uint8_t *__restrict__ unmasks, const float *__restrict__ xa_src,
                                                         const float *__restrict__ xb_src, const float *__restrict__ std_log,
-                                                        float ratio_clip, float lambda_entropy, float inv_batch,
+                                                        float ratio_clip, float lambda_entropy, float inv_batch, int objective,
                                                         float *__restrict__ part)
 {
     __shared__ float red[4];
@@ -166,14 +167,11 @@ __global__ __launch_bounds__(256) void objective_kernel(float *__restrict__ Y, f
                 const float diff = actions[row * A + a] - Y[b * A + a];
                 lp += -(diff * diff) / (2.f * var) - logf(sdv) - kLogSqrt2PiN;
             }
-            const float adv = xb_src[row];
-            const float ratio = expf(lp - xa_src[row]);
-            const float w = adv > 0.f ? 1.f - ratio_clip : 1.f + ratio_clip;
-            const float surr = adv * ratio * w;
-            l0 = surr * um;
-            l1 = um;
-            const float dlp = -(surr * um) * inv_batch;
-            const float ent_term = lambda_entropy * um * inv_batch;
+            const PpoActorTerms o = ppo_actor_terms(objective, xb_src[row], lp, xa_src[row], ratio_clip, lambda_entropy, um, A, false);
+            l0 = o.logged;
+            l1 = o.ent_mask;
+            const float dlp = o.dlp * inv_batch;
+            const float ent_term = o.ent_w * inv_batch;
             for (int a = 0; a < A; ++a) {
                 const float sdv = expf(std_log[a]), var = sdv * sdv;
                 const float diff = actions[row * A + a] - Y[b * A + a];

@@ -5,6 +5,7 @@
 // Both write the same gradient slabs (one per 128 samples and network) and the same objective partial sums.
 #pragma once
 #include "mlp_chain.h"
+#include "ppo_objective.h"
 
 struct Ppo2Args {
     const float *P[2];    // actor, critic flat params
@@ -16,7 +17,7 @@ struct Ppo2Args {
     int64_t H, N, B;
     int S, h1, h2, A;
     float ratio_clip, lambda_entropy, inv_batch;
-    int canonical;        // 0: the reference's sign-dependent scale (AgentPPO.py:199); 1: min(r A, clamp(r) A)
+    int objective;        // ERL_PPO_OBJ_* (ppo_objective.h)
     float *slabs;
     int64_t stride, Pa, Pc;
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
@@ -103,26 +104,6 @@ __device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__re
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         if (p == 0 && f < nfeat) out[f] = s;
-    }
-}
-
-// the surrogate of one sample and its derivative with respect to the new log-prob.
-//   reference form (AgentPPO.py:199):  surr = adv ratio (adv > 0 ? 1 - clip : 1 + clip)         d surr / d logp = surr
-//   canonical (helloworld/helloworld_PPO_single_file.py:337-339):  surr = min(adv ratio, adv clamp(ratio, 1 - clip, 1 + clip))
-//                                                                  d surr / d logp = adv ratio where the unclipped branch is taken
-__device__ __forceinline__ void ppo_surrogate(float adv, float ratio, float clip, int canonical, float &surr, float &dsurr)
-{
-    if (!canonical) {
-        const float w = adv > 0.f ? 1.f - clip : 1.f + clip;
-        surr = adv * ratio * w;
-        dsurr = surr;
-    } else {
-        const float s1 = adv * ratio;
-        const float s2 = adv * fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
-        const bool first = s1 <= s2;                  // torch.min: ties take either branch; the unclipped one keeps the gradient
-        surr = first ? s1 : s2;
-        const bool inside = ratio >= 1.f - clip && ratio <= 1.f + clip;   // clamp passes the gradient inside the interval
-        dsurr = first ? s1 : (inside ? s1 : 0.f);
     }
 }
 

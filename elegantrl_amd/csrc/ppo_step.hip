@@ -263,17 +263,13 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
         }
         lp += __shfl_xor(lp, 16, 64);
         lp += __shfl_xor(lp, 32, 64);
-        const float ratio = expf(lp - xa);
-        float surr, dsurr;
-        ppo_surrogate(xb, ratio, g.ratio_clip, g.canonical, surr, dsurr);
-        surr = valid ? surr : 0.f;                              // padding rows contribute 0
-        dsurr = valid ? dsurr : 0.f;
+        const PpoActorTerms o = ppo_actor_terms(g.objective, xb, lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, false);
         if (q == 0) {
-            loss0 = surr * um;
-            loss1 = um;
+            loss0 = valid ? o.logged : 0.f;                    // padding rows contribute 0
+            loss1 = valid ? o.ent_mask : 0.f;
         }
-        const float dlp = -(dsurr * um) * g.inv_batch;     // d(-mean(surr um)) / dlogp_new
-        const float ent_term = g.lambda_entropy * um * g.inv_batch;
+        const float dlp = (valid ? o.dlp : 0.f) * g.inv_batch;  // d loss / dlogp_new
+        const float ent_term = (valid ? o.ent_w : 0.f) * g.inv_batch;
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -433,13 +429,14 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
                                 const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
                                 const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                                 const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
-                                float lambda_entropy, float inv_batch, float *slabs, int n_slabs, void *stream)
+                                float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, void *stream)
 {
     ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions && unmasks &&
                     logprobs && advantages && reward_sums && ids && slabs,
                 "erl_ppo_step_f32: NULL tensor");
     ERL_REQUIRE(dims_ok2(S, h1, h2, A), "erl_ppo_step_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
     ERL_REQUIRE(H >= 1 && N >= 1 && B >= 1, "erl_ppo_step_f32: bad shape");
+    ERL_REQUIRE(objective >= ERL_PPO_OBJ_REFERENCE && objective <= ERL_PPO_OBJ_A2C, "erl_ppo_step_f32: unknown objective %d", objective);
     ERL_REQUIRE(n_slabs == erl_ppo_num_slabs(B), "erl_ppo_step_f32: n_slabs=%d, expected erl_ppo_num_slabs(B=%lld)=%d", n_slabs,
                 (long long)B, erl_ppo_num_slabs(B));
     Ppo2Args g;
@@ -451,7 +448,7 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     g.H = H; g.N = N; g.B = B;
     g.S = S; g.h1 = h1; g.h2 = h2; g.A = A;
     g.ratio_clip = ratio_clip; g.lambda_entropy = lambda_entropy; g.inv_batch = inv_batch;
-    g.canonical = 0;
+    g.objective = objective;
     g.slabs = slabs;
     g.Pa = Dims{S, h1, h2, A}.count(true);
     g.Pc = Dims{S, h1, h2, 1}.count(false);

@@ -540,17 +540,13 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
             lp += on ? term : 0.f;
         }
         lp += __shfl_xor(lp, 32, 64);
-        const float ratio = __expf(lp - xa);
-        float surr, dsurr;
-        ppo_surrogate(xb, ratio, g.ratio_clip, g.canonical, surr, dsurr);
-        surr = valid ? surr : 0.f;                          // padding rows contribute 0
-        dsurr = valid ? dsurr : 0.f;
+        const PpoActorTerms o = ppo_actor_terms(g.objective, xb, lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, true);
         if (hi == 0) {
-            loss0 = surr * um;
-            loss1 = um;
+            loss0 = valid ? o.logged : 0.f;                     // padding rows contribute 0
+            loss1 = valid ? o.ent_mask : 0.f;
         }
-        const float dlp = -(dsurr * um) * g.inv_batch;      // d(-mean(surr um)) / dlogp_new
-        const float ent_term = g.lambda_entropy * um * g.inv_batch;
+        const float dlp = (valid ? o.dlp : 0.f) * g.inv_batch;  // d loss / dlogp_new
+        const float ent_term = (valid ? o.ent_w : 0.f) * g.inv_batch;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool on = 4 * hi + j < OUT;

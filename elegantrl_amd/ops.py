@@ -226,13 +226,15 @@ def ppo_num_slabs(batch_size: int) -> int:
 
 def ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int, h1: int,
              h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
-             ids: TEN, ratio_clip: float, lambda_entropy: float, inv_batch: float, slabs: TEN, n_slabs: int) -> None:
+             ids: TEN, ratio_clip: float, lambda_entropy: float, inv_batch: float, slabs: TEN, n_slabs: int,
+             objective: int = 0) -> None:
+    """`objective`: _hip.PPO_OBJ_REFERENCE (AgentPPO.py:199) / PPO_OBJ_CANONICAL (textbook clip) / PPO_OBJ_A2C (AgentPPO.py:296-303)"""
     H, N = states.shape[0], states.shape[1]
     check(lib().erl_ppo_step_f32(ptr(actor_params, th.float32), ptr(critic_params, th.float32), ptr(act_avg), ptr(act_std),
                                  ptr(cri_avg), ptr(cri_std), S, h1, h2, A, ptr(states, th.float32), ptr(actions, th.float32),
                                  flag_ptr(unmasks), ptr(logprobs, th.float32), ptr(advantages, th.float32),
                                  ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), ids.numel(), ratio_clip,
-                                 lambda_entropy, inv_batch, ptr(slabs, th.float32), n_slabs, stream_ptr()),
+                                 lambda_entropy, inv_batch, int(objective), ptr(slabs, th.float32), n_slabs, stream_ptr()),
           "erl_ppo_step_f32")
 
 
@@ -256,7 +258,7 @@ def clip_adam(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, groups: Se
 def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int,
                h1: int, h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
                ids: TEN, ratio_clip: float, lambda_entropy: float, slabs: TEN, grads: TEN, first_step: int, lr: float,
-               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8, comm=None) -> None:
+               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8, comm=None, objective: int = 0) -> None:
     """the whole minibatch loop of AgentPPO.update_net in one C call; ids: (update_times, B).  `comm` (a
     parallel.RcclComm) puts the gradient all-reduce inside the loop, on the same stream (data-parallel ranks)."""
     H, N = states.shape[0], states.shape[1]
@@ -266,7 +268,8 @@ def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, ac
                                       ptr(act_avg), ptr(act_std), ptr(cri_avg), ptr(cri_std), S, h1, h2, A, ptr(states, th.float32),
                                       ptr(actions, th.float32), flag_ptr(unmasks), ptr(logprobs, th.float32),
                                       ptr(advantages, th.float32), ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), B,
-                                      update_times, ratio_clip, lambda_entropy, ptr(slabs, th.float32), ptr(grads, th.float32),
+                                      update_times, ratio_clip, lambda_entropy, int(objective), ptr(slabs, th.float32),
+                                      ptr(grads, th.float32),
                                       first_step, lr, betas[0], betas[1], eps, max_norm, None if comm is None else comm.handle,
                                       stream_ptr()),
           "erl_ppo_update_dp_f32")
@@ -351,7 +354,7 @@ def mlpn_rollout_step(params: TEN, spec: MlpSpecN, state_avg: TEN, state_std: TE
 
 def mlpn_ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, spec: MlpSpecN,
                   states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN, ids: TEN,
-                  ratio_clip: float, lambda_entropy: float, inv_batch: float, flat_grad: TEN) -> None:
+                  ratio_clip: float, lambda_entropy: float, inv_batch: float, flat_grad: TEN, objective: int = 0) -> None:
     """one PPO minibatch for networks of any depth; `flat_grad` receives [actor | critic | 3 objectives, 0]."""
     H, N = states.shape[0], states.shape[1]
     B = ids.numel()
@@ -361,7 +364,7 @@ def mlpn_ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: 
                                       ptr(cri_avg), ptr(cri_std), c, n, ptr(states, th.float32), ptr(actions, th.float32),
                                       flag_ptr(unmasks), ptr(logprobs, th.float32), ptr(advantages, th.float32),
                                       ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), B, ratio_clip, lambda_entropy,
-                                      inv_batch, ptr(flat_grad, th.float32), ptr(ws), ws.numel(), stream_ptr()),
+                                      inv_batch, int(objective), ptr(flat_grad, th.float32), ptr(ws), ws.numel(), stream_ptr()),
           "erl_mlpn_ppo_step_f32")
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 8
+#define ERL_ABI_VERSION 9
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -202,6 +202,10 @@ ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *cri
  * fixed order by erl_grad_reduce_f32.  inv_batch = 1/B (1/(B*world) is folded into K7 under data parallelism).
  * Slab / flat-gradient layout: [actor grads (Pa)] [critic grads (Pc)] [obj_critic, obj_surrogate,
  * obj_entropy, 0] where Pa/Pc = erl_mlp_param_count(...). */
+/* `objective` of the PPO minibatch entry points: which actor objective is differentiated (csrc/ppo_objective.h) */
+#define ERL_PPO_OBJ_REFERENCE 0   /* AgentPPO.py:199   surrogate = adv*ratio*where(adv > 0, 1-clip, 1+clip) */
+#define ERL_PPO_OBJ_CANONICAL 1   /* helloworld_PPO_single_file.py:337-339   min(adv*ratio, adv*clamp(ratio, 1-clip, 1+clip)) */
+#define ERL_PPO_OBJ_A2C 2         /* AgentA2C.update_objectives (AgentPPO.py:296-303)   mean(adv * logp_a), no clip / mask / entropy */
 ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
 ERL_API int erl_ppo_num_slabs(int64_t B);
 ERL_API int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg,
@@ -209,7 +213,7 @@ ERL_API int erl_ppo_step_f32(const float *actor_params, const float *critic_para
                      int A, const float *states, const float *actions, const uint8_t *unmasks,
                      const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
                      int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
-                     float inv_batch, float *slabs, int n_slabs, void *stream);
+                     float inv_batch, int objective, float *slabs, int n_slabs, void *stream);
 ERL_API int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, void *stream);
 
 /* K7  optimizer_backward's tail (elegantrl/agents/AgentBase.py:246-248) for up to 4 parameter groups in
@@ -232,7 +236,7 @@ ERL_API int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp_av
                        const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
                        const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
                        const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
-                       int64_t B, int update_times, float ratio_clip, float lambda_entropy, float *slabs,
+                       int64_t B, int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs,
                        float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
                        float max_norm, void *stream);
 
@@ -259,7 +263,7 @@ ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp
                           const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
                           const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
                           const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
-                          int64_t B, int update_times, float ratio_clip, float lambda_entropy, float *slabs,
+                          int64_t B, int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs,
                           float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
                           float max_norm, void *comm, void *stream);
 
@@ -288,7 +292,8 @@ ERL_API int erl_mlpn_ppo_step_f32(const float *actor_params, const float *critic
                           int n_dims, const float *states, const float *actions, const uint8_t *unmasks,
                           const float *logprobs, const float *advantages, const float *reward_sums, int64_t H,
                           int64_t N, const int64_t *ids, int64_t B, float ratio_clip, float lambda_entropy,
-                          float inv_batch, float *flat_grad, void *workspace, int64_t workspace_bytes, void *stream);
+                          float inv_batch, int objective, float *flat_grad, void *workspace, int64_t workspace_bytes,
+                          void *stream);
 
 /* Discrete-action sibling (AgentDiscretePPO / ActorDiscretePPO, elegantrl/agents/AgentPPO.py:305-320, :393-422): the actor
  * block has no action_std_log (erl_mlpn_param_count(dims, n_dims, 0)), dims[n_dims-1] = number of actions (<= 64).

@@ -350,6 +350,66 @@ def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed):
     print("wrote", path, "objs", objs)
 
 
+def make_a2c(tag, *, S, A, H, net_dims, batch_size, repeat_times, seed):
+    """reference AgentA2C (elegantrl/agents/AgentPPO.py:252-303) on a one-env buffer (the only shape its time-row minibatches
+    are well formed for): update_net with recorded time indices; weights before / after and the returned objectives."""
+    sys.path.insert(0, REF)
+    from elegantrl.agents.AgentPPO import AgentA2C
+    from elegantrl.train.config import Config
+
+    th.manual_seed(seed)
+    args = Config(AgentA2C, None, {"env_name": "scripted", "num_envs": 1, "max_step": 100, "state_dim": S, "action_dim": A,
+                                   "if_discrete": False})
+    args.net_dims = list(net_dims)
+    args.horizon_len, args.batch_size, args.repeat_times = H, batch_size, repeat_times
+    args.learning_rate, args.gamma, args.reward_scale = 1e-3, 0.98, 1.0
+    agent = AgentA2C(args.net_dims, S, A, gpu_id=-1, args=args)
+    with th.no_grad():
+        for net in (agent.act, agent.cri):
+            net.state_avg[:] = 0.1 * th.randn(S)
+            net.state_std[:] = 1.0 + 0.2 * th.rand(S)
+        agent.act.action_std_log[:] = -0.3 + 0.1 * th.randn(1, A)
+    g = {}
+    g.update(net_arrays("act0", agent.act))
+    g.update(net_arrays("cri0", agent.cri))
+    states = th.randn(H, 1, S)
+    actions = th.randn(H, 1, A)
+    logprobs = -1.0 * A + 0.3 * th.randn(H, 1)
+    rewards = th.randn(H, 1)
+    undones = th.rand(H, 1) > 0.1
+    unmasks = th.rand(H, 1) > 0.12
+    undones = undones & unmasks | (~unmasks & False)       # a truncated step is an episode end as well
+    agent.last_state = th.randn(1, S)
+    g.update(states=np32(states), actions=np32(actions), logprobs=np32(logprobs), rewards=np32(rewards), undones=np32(undones),
+             unmasks=np32(unmasks), last_state=np32(agent.last_state))
+    th.set_grad_enabled(False)
+    values = agent.cri(states).squeeze(-1)
+    r2, u2 = rewards.clone(), undones.clone()
+    adv = agent.get_advantages(states, r2, u2, unmasks, values)
+    g.update(values=np32(values), advantages=np32(adv), reward_sums=np32(adv + values),
+             advantages_norm=np32((adv - adv.mean()) / (adv[::4, ::4].std() + 1e-5)))
+    ids_log = []
+    orig_randint = th.randint
+
+    def recording_randint(*a, **k):
+        out = orig_randint(*a, **k)
+        ids_log.append(out.clone())
+        return out
+
+    th.randint = recording_randint
+    objs = agent.update_net((states.clone(), actions.clone(), logprobs.clone(), rewards.clone(), undones.clone(), unmasks.clone()))
+    th.set_grad_enabled(False)
+    th.randint = orig_randint
+    g.update(net_arrays("act1", agent.act))
+    g.update(net_arrays("cri1", agent.cri))
+    g.update(ids=np.stack([np32(i) for i in ids_log]).astype(np.int64), objs=np.array([float(o) for o in objs], dtype=np.float64),
+             hyper=np.array([args.gamma, agent.lambda_gae_adv, args.learning_rate, args.clip_grad_norm], dtype=np.float64),
+             dims=np.array([1, S, A, H, batch_size, len(ids_log), *net_dims], dtype=np.int64))
+    path = os.path.join(OUT, f"a2c_{tag}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, {k: v.shape for k, v in g.items() if k in ("states", "ids", "advantages")}, "objs", objs)
+
+
 def make_cum_rewards():
     """reference AgentBase.get_cumulative_rewards (elegantrl/agents/AgentBase.py:226-237) through AgentTD3 (which owns
     act_target / cri_target), called the way AgentBase.update_net does: via ReplayBuffer.update_cum_rewards (both the
@@ -403,7 +463,11 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     if only:                       # regenerate selected fixtures only: python oracle/make_golden.py cum_rewards ...
         for name in only:
-            globals()[f"make_{name}"]()
+            if name == "a2c":
+                make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)
+                make_a2c("mid", S=64, A=8, H=48, net_dims=(128, 128), batch_size=32, repeat_times=2.0, seed=42)
+            else:
+                globals()[f"make_{name}"]()
         sys.exit(0)
     make_ppo("small_vtrace", N=8, S=6, A=2, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0,
              use_v_trace=True, seed=11)
@@ -415,3 +479,5 @@ if __name__ == "__main__":
     make_sac("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=21)
     make_ppo_discrete("small", N=8, S=6, A=4, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0, seed=31)
     make_cum_rewards()
+    make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)
+    make_a2c("mid", S=64, A=8, H=48, net_dims=(128, 128), batch_size=32, repeat_times=2.0, seed=42)

@@ -219,12 +219,17 @@ def critic_objective(state, reward_sum, unmask, critic: Mlp):
 
 
 def actor_objective(state, action, logprob_old, advantage, unmask, actor: Mlp,
-                    ratio_clip: float, lambda_entropy: float):
-    """Reference-form PPO objective (AgentPPO.py:193-204):
-        ratio = exp(new_logprob - old_logprob)
-        surrogate = adv * ratio * where(adv > 0, 1 - clip, 1 + clip)
-        minimise -( mean(surrogate*unmask) - lambda_entropy * mean(entropy*unmask) )
-    Returns (obj_surrogate, obj_entropy, grads_w, grads_b, grad_std_log) of the *minimised* loss.
+                    ratio_clip: float, lambda_entropy: float, objective: str = "reference"):
+    """The actor objective of one minibatch and its gradients.  `objective`:
+      "reference"  AgentPPO.py:193-204:  ratio = exp(new_logprob - old_logprob);
+                   surrogate = adv * ratio * where(adv > 0, 1 - clip, 1 + clip);
+                   minimise -( mean(surrogate*unmask) - lambda_entropy * mean(entropy*unmask) )
+      "canonical"  the same loss around the textbook surrogate of helloworld/helloworld_PPO_single_file.py:337-339,
+                   min(adv * ratio, adv * clamp(ratio, 1 - clip, 1 + clip))   (torch.min / clamp sub-gradients)
+      "a2c"        AgentA2C.update_objectives (AgentPPO.py:296-303) for one env: new_logprob is per ACTION DIMENSION (the
+                   reference's .sum(1) runs over the env axis of size 1), obj = mean over (batch, action dims) of
+                   adv * logp_a, minimise -obj; no unmask, no entropy term (obj_entropy reported as 0)
+    Returns (obj_actor, obj_entropy, grads_w, grads_b, grad_std_log) of the *minimised* loss.
     """
     dt = state.dtype
     B = state.shape[0]
@@ -235,14 +240,31 @@ def actor_objective(state, action, logprob_old, advantage, unmask, actor: Mlp,
     var = std * std
     new_lp = gaussian_logprob(action, mean, std_log)
     ent = gaussian_entropy(std_log, B)
+    diff = action - mean
+    if objective == "a2c":
+        A = action.shape[1]
+        obj_s = (advantage * new_lp).mean() / dt.type(A)
+        dlp = -advantage / dt.type(B * A)
+        dmean = dlp[:, None] * (diff / var)
+        dstd_log = (dlp[:, None] * (diff * diff / var - dt.type(1.0))).sum(axis=0)
+        gw, gb = mlp_backward(dmean, actor, cache)
+        return obj_s, dt.type(0.0), gw, gb, dstd_log.astype(dt)
     ratio = np.exp(new_lp - logprob_old)
-    w = np.where(advantage > 0, dt.type(1.0 - ratio_clip), dt.type(1.0 + ratio_clip)).astype(dt)
-    surrogate = advantage * ratio * w
+    if objective == "canonical":
+        lo, hi = dt.type(1.0 - ratio_clip), dt.type(1.0 + ratio_clip)
+        s1 = advantage * ratio
+        s2 = advantage * np.clip(ratio, lo, hi)
+        surrogate = np.minimum(s1, s2)
+        inside = (ratio >= lo) & (ratio <= hi)
+        dsurr = np.where((s1 <= s2) | inside, s1, dt.type(0.0))     # d surrogate / d new_logprob
+    else:
+        w = np.where(advantage > 0, dt.type(1.0 - ratio_clip), dt.type(1.0 + ratio_clip)).astype(dt)
+        surrogate = advantage * ratio * w
+        dsurr = surrogate
     obj_s = (surrogate * um).mean()
     obj_e = (ent * um).mean()
     # loss = -(obj_s - lambda*obj_e)
-    dlp = -(surrogate * um) / dt.type(B)                 # dloss/dnew_logprob
-    diff = action - mean
+    dlp = -(dsurr * um) / dt.type(B)                     # dloss/dnew_logprob
     dmean = dlp[:, None] * (diff / var)
     dstd_log = (dlp[:, None] * (diff * diff / var - dt.type(1.0))).sum(axis=0)
     dstd_log = dstd_log + dt.type(lambda_entropy) * um.mean()
@@ -362,8 +384,9 @@ def optimizer_backward(params, grads, st: AdamState, lr: float, max_norm: float)
 
 
 def ppo_minibatch_step(buf, ids, actor: Mlp, critic: Mlp, st_a: AdamState, st_c: AdamState, *,
-                       lr: float, max_norm: float, ratio_clip: float, lambda_entropy: float):
-    """One update_objectives call (AgentPPO.py:173-205) on explicit ``ids``.
+                       lr: float, max_norm: float, ratio_clip: float, lambda_entropy: float, objective: str = "reference"):
+    """One update_objectives call (AgentPPO.py:173-205; AgentA2C's :286-303 with objective="a2c", whose ids are time rows
+    of a one-env buffer) on explicit ``ids``.
     buf = (states(H,N,S), actions(H,N,A), unmasks(H,N) bool, logprobs, advantages, reward_sums)."""
     states, actions, unmasks, logprobs, advantages, rsums = buf
     H = states.shape[0]
@@ -373,7 +396,7 @@ def ppo_minibatch_step(buf, ids, actor: Mlp, critic: Mlp, st_a: AdamState, st_c:
     obj_c, gw, gb = critic_objective(s, rs, um, critic)
     g = [x for pair in zip(gw, gb) for x in pair]
     optimizer_backward(critic.trainable(), g, st_c, lr, max_norm)
-    obj_s, obj_e, gw, gb, gsl = actor_objective(s, a, lp, adv, um, actor, ratio_clip, lambda_entropy)
+    obj_s, obj_e, gw, gb, gsl = actor_objective(s, a, lp, adv, um, actor, ratio_clip, lambda_entropy, objective)
     g = [x for pair in zip(gw, gb) for x in pair] + [gsl]
     optimizer_backward(actor.trainable(), g, st_a, lr, max_norm)
     return obj_c, obj_s, obj_e

@@ -58,7 +58,7 @@ def test_errors_are_reported_not_swallowed():
     L = _hip.lib()
     rc = L.erl_split_ids_i64(None, 4, 0, None, None, None)
     assert rc == -1 and b"erl_split_ids_i64" in L.erl_last_error_string()
-    rc = L.erl_ppo_step_f32(*([None] * 6), 64, 128, 128, 8, *([None] * 6), 32, 4096, None, 16384, 0.25, 0.001, 1.0, None, 128, None)
+    rc = L.erl_ppo_step_f32(*([None] * 6), 64, 128, 128, 8, *([None] * 6), 32, 4096, None, 16384, 0.25, 0.001, 1.0, 0, None, 128, None)
     assert rc == -1 and b"NULL" in L.erl_last_error_string()
 
 

@@ -110,6 +110,58 @@ def test_update_net_matches_reference_weights_and_objectives(name):
     assert moved > 1e-4
 
 
+@pytest.mark.parametrize("name", ["a2c_small.npz", "a2c_mid.npz"])
+def test_a2c_update_net_matches_reference(name):
+    """AgentA2C.update_net against the reference's own AgentA2C run (tests/golden/a2c_*.npz, oracle/make_golden.py:make_a2c):
+    one env, time-row minibatches on the recorded indices; `mid` is the [128, 128] / S = 64 shape of the fused kernels."""
+    from elegantrl_amd.agents import AgentA2C
+    from elegantrl_amd.train import Config
+    g = load(name)
+    _, S, A, H, B, n_upd, h1, h2 = (int(x) for x in g["dims"])
+    gamma, lam, lr, max_norm = (float(x) for x in g["hyper"])
+    args = Config(AgentA2C, None, {"env_name": "scripted", "num_envs": 1, "max_step": 100, "state_dim": S, "action_dim": A,
+                                   "if_discrete": False})
+    args.net_dims = [h1, h2]
+    args.horizon_len, args.batch_size, args.repeat_times = H, B, n_upd * B / H
+    args.learning_rate, args.gamma, args.clip_grad_norm, args.lambda_gae_adv = lr, gamma, max_norm, lam
+    agent = AgentA2C(args.net_dims, S, A, gpu_id=0, args=args)
+    for net, prefix in ((agent.act, "act0"), (agent.cri, "cri0")):
+        net.load_state_dict({k: th.from_numpy(g[f"{prefix}.{k}"]) for k in net.state_dict()})
+    agent.last_state = th.from_numpy(g["last_state"]).to(DEV)
+    buf = [th.from_numpy(g[k]).to(DEV) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
+    objs = agent.update_net(buf, ids=th.from_numpy(g["ids"]).to(DEV))
+    assert objs[2] == 0
+    np.testing.assert_allclose(np.array(objs[:2]), g["objs"][:2], rtol=5e-4, atol=5e-6)
+    for net, prefix in ((agent.act, "act1"), (agent.cri, "cri1")):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"{prefix}.{k}"], rtol=0, atol=3e-5, err_msg=f"{prefix}.{k}")
+    with pytest.raises(ValueError):
+        AgentA2C(args.net_dims, S, A, gpu_id=0,
+                 args=Config(AgentA2C, None, {"env_name": "x", "num_envs": 4, "max_step": 9, "state_dim": S, "action_dim": A,
+                                              "if_discrete": False}))
+
+
+def test_canonical_ppo_flag_changes_the_objective_only():
+    """args.canonical_ppo = True selects ERL_PPO_OBJ_CANONICAL: same rollout, same critic update, different actor update."""
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.train import Config
+    g = load(PPO_GOLDENS[2])
+    res = []
+    for canonical in (False, True):
+        agent, _ = make_agent(g)
+        agent._objective = 1 if canonical else 0
+        agent.last_state = th.from_numpy(g["last_state"]).to(DEV)
+        buf = [th.from_numpy(g[k]).to(DEV) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
+        lp = buf[2] + 0.5 * th.randn(buf[2].shape, device=DEV, generator=th.Generator(device=DEV).manual_seed(0))
+        buf[2] = lp
+        agent.update_net(buf, ids=th.from_numpy(g["ids"]).to(DEV))
+        res.append((agent.act.net[0].weight.detach().clone(), agent.cri.net[0].weight.detach().clone()))
+    assert th.equal(res[0][1], res[1][1]) and not th.equal(res[0][0], res[1][0])
+    args = Config(AgentPPO, None, {"env_name": "x", "num_envs": 4, "max_step": 9, "state_dim": 6, "action_dim": 2, "if_discrete": False})
+    args.canonical_ppo = True
+    assert AgentPPO([64, 32], 6, 2, gpu_id=0, args=args)._objective == 1
+
+
 @pytest.mark.parametrize("N,S", [(4096, 64), (8192, 60)], ids=["config4", "config5-ant-shaped"])
 def test_c4_iteration_against_oracle(N, S):
     """BASELINE config 4 (4096 envs, obs 64) and config 5 (Ant-shaped: 8192 envs, obs 60) shapes, act 8, H=32, B=16384:

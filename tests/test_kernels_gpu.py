@@ -444,7 +444,7 @@ def ppo_case(rng, H, N, S, A, B):
     return states, actions, um, lp, adv, rs, ids
 
 
-def oracle_flat_grads(buf, ids, actor, critic, clip, lam_ent, dt):
+def oracle_flat_grads(buf, ids, actor, critic, clip, lam_ent, dt, objective="reference"):
     states, actions, um, lp, adv, rs = buf
     H = states.shape[0]
     i0, i1 = O.split_ids(ids, H)
@@ -452,7 +452,7 @@ def oracle_flat_grads(buf, ids, actor, critic, clip, lam_ent, dt):
     oc, gw, gb = O.critic_objective(s, rs[i0, i1].astype(dt), um[i0, i1], critic.astype(dt))
     gc = np.concatenate([x.reshape(-1) for pair in zip(gw, gb) for x in pair])
     os_, oe, gw, gb, gsl = O.actor_objective(s, a, lp[i0, i1].astype(dt), adv[i0, i1].astype(dt), um[i0, i1], actor.astype(dt),
-                                             clip, lam_ent)
+                                             clip, lam_ent, objective)
     ga = np.concatenate([x.reshape(-1) for pair in zip(gw, gb) for x in pair] + [gsl.reshape(-1)])
     return ga, gc, np.array([oc, os_, oe], dtype=np.float64)
 
@@ -483,6 +483,38 @@ def test_ppo_step_gradients(ops, dev, S, h1, h2, A, B):
         scale = np.abs(ref).max()
         err = np.abs(g - ref).max()
         assert err <= 1e-4 * scale + 1e-7, f"{name} grad err {err:.3e} (scale {scale:.3e})"
+    np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
+
+
+OBJECTIVES = {"canonical": 1, "a2c": 2}
+
+
+@pytest.mark.parametrize("S,h1,h2,A", [(64, 128, 128, 8), (17, 128, 128, 5), (6, 64, 32, 2)],
+                         ids=["one-wave-per-SIMD kernel", "8-wave kernel", "8-wave kernel, small net"])
+@pytest.mark.parametrize("objective", list(OBJECTIVES))
+def test_ppo_step_objective_forms(ops, dev, S, h1, h2, A, objective):
+    """the textbook clipped surrogate (SURVEY App. A1 / helloworld_PPO_single_file.py:337-339) and AgentA2C's un-clipped
+    objective (AgentPPO.py:296-303) through both K6 kernels, against the fp64 restatement (itself checked against torch
+    autograd of the quoted expressions and, for A2C, against the reference's own run: tests/test_oracle_golden.py)."""
+    rng = np.random.default_rng(S + len(objective))
+    B, H, N = 300, 9, 50
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = list(buf_ids[:6]), buf_ids[6]
+    buf[3] = (buf[3] + 0.5 * rng.standard_normal(buf[3].shape)).astype(np.float32)     # ratios on both sides of the clip
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
+    Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
+    slabs = th.full((n_slabs, stride), float("nan"), device=dev)
+    flat = th.zeros(stride, device=dev)
+    ops.ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                 cu(critic.state_avg, dev), cu(critic.state_std, dev), S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev),
+                 0.25, 0.001, 1.0 / B, slabs, n_slabs, objective=OBJECTIVES[objective])
+    ops.grad_reduce(slabs, n_slabs, stride, flat)
+    got = flat.cpu().numpy().astype(np.float64)
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64, objective)
+    for name, g, ref in (("actor", got[:Pa], ga), ("critic", got[Pa:Pa + Pc], gc)):
+        scale = np.abs(ref).max()
+        assert np.abs(g - ref).max() <= 1e-4 * scale + 1e-7, f"{name} grad err {np.abs(g - ref).max():.3e} (scale {scale:.3e})"
     np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
 
 

@@ -105,6 +105,29 @@ def test_mlpn_ppo_step_gradients(ops, dev, S, hidden, A, B):
     np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("objective,code", [("canonical", 1), ("a2c", 2)])
+def test_mlpn_ppo_step_objective_forms(ops, dev, objective, code):
+    """the layered path's objective kernel with the textbook clip and AgentA2C's objective (csrc/ppo_objective.h)."""
+    rng = np.random.default_rng(len(objective))
+    S, hidden, A, B, H, N = 11, [256, 128, 64], 3, 200, 9, 50
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = list(buf_ids[:6]), buf_ids[6]
+    buf[3] = (buf[3] + 0.5 * rng.standard_normal(buf[3].shape)).astype(np.float32)
+    actor, critic = random_net_n(rng, [S, *hidden, A], True), random_net_n(rng, [S, *hidden, 1], False)
+    spec = ops.MlpSpecN([S, *hidden, A], True)
+    Pa, Pc = spec.count, ops.MlpSpecN([S, *hidden, 1], False).count
+    flat = th.full((Pa + Pc + 4,), float("nan"), device=dev)
+    ops.mlpn_ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                      cu(critic.state_avg, dev), cu(critic.state_std, dev), spec, *[cu(x, dev) for x in buf], cu(ids, dev), 0.25, 0.001,
+                      1.0 / B, flat, objective=code)
+    got = flat.cpu().numpy().astype(np.float64)
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64, objective)
+    for name, g, ref in (("actor", got[:Pa], ga), ("critic", got[Pa:Pa + Pc], gc)):
+        scale = np.abs(ref).max()
+        assert np.abs(g - ref).max() <= 1e-4 * scale + 1e-7, f"{name} grad err {np.abs(g - ref).max():.3e} (scale {scale:.3e})"
+    np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
+
+
 def test_mlpn_agrees_with_fused_kernels_on_a_fused_shape(ops, dev):
     """on [128, 128] both paths exist: same gradient within fp32 summation-order noise."""
     rng = np.random.default_rng(3)

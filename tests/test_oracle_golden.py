@@ -236,3 +236,76 @@ def test_discrete_update_net_weights_and_objectives():
         for p, q in zip(mine.trainable(), ref.trainable()):
             np.testing.assert_allclose(p, q, rtol=0, atol=5e-6)
     assert sum(float(np.abs(p - q).sum()) for p, q in zip(_discrete_actor(g, "act0").trainable(), ref_a.trainable())) > 0
+
+
+# ---- PPO siblings: AgentA2C (reference golden) and the objective forms (torch autograd of the quoted expressions) ----------
+@pytest.mark.parametrize("name", ["a2c_small.npz", "a2c_mid.npz"])
+def test_a2c_update_net_weights_and_objectives(name):
+    """AgentA2C.update_net (elegantrl/agents/AgentPPO.py:256-303) on a one-env buffer, replayed by the numpy restatement on the
+    reference's recorded time indices: GAE + normalisation as AgentPPO, then the un-clipped objective per minibatch."""
+    g = load(name)
+    gamma, lam, lr, max_norm = (float(x) for x in g["hyper"])
+    actor, critic = mlp_from(g, "act0"), mlp_from(g, "cri0")
+    v = O.critic_value(g["states"], critic)
+    nv = O.critic_value(g["last_state"], critic)
+    np.testing.assert_allclose(v, g["values"], rtol=1e-5, atol=1e-6)
+    adv, _, _ = O.gae_scan(g["rewards"].copy(), g["undones"].copy(), g["unmasks"], g["values"], nv, gamma, lam)
+    np.testing.assert_allclose(adv, g["advantages"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(O.adv_normalize(g["advantages"]), g["advantages_norm"], rtol=1e-5, atol=1e-5)
+    buf = (g["states"], g["actions"], g["unmasks"], g["logprobs"], g["advantages_norm"], g["reward_sums"])
+    sa, sc = O.AdamState(), O.AdamState()
+    objs = [O.ppo_minibatch_step(buf, ids, actor, critic, sa, sc, lr=lr, max_norm=max_norm, ratio_clip=0.25, lambda_entropy=0.0,
+                                 objective="a2c") for ids in g["ids"]]
+    objs = np.array(objs, dtype=np.float64).mean(axis=0)
+    np.testing.assert_allclose(objs[:2], g["objs"][:2], rtol=2e-4, atol=2e-6)
+    assert g["objs"][2] == 0 and objs[2] == 0
+    for mine, ref in ((actor, mlp_from(g, "act1")), (critic, mlp_from(g, "cri1"))):
+        for p, q in zip(mine.trainable(), ref.trainable()):
+            np.testing.assert_allclose(p, q, rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("objective", ["reference", "canonical", "a2c"])
+def test_actor_objective_forms_against_torch_autograd(objective):
+    """the three actor objectives of oracle/ppo_numpy.actor_objective (= csrc/ppo_objective.h) against torch autograd of the
+    expressions they quote: AgentPPO.py:196-204, helloworld_PPO_single_file.py:337-339 (inside the same loss), AgentPPO.py:301."""
+    import torch as th
+    rng = np.random.default_rng(5)
+    B, S, A, h1, h2, clip, lam = 96, 7, 3, 32, 32, 0.25, 0.01
+    ws = [rng.standard_normal(s) * 0.3 for s in ((h1, S), (h2, h1), (A, h2))]
+    bs = [rng.standard_normal(n) * 0.1 for n in (h1, h2, A)]
+    actor = O.Mlp(ws, bs, rng.standard_normal(S) * 0.1, 1 + 0.2 * rng.random(S), rng.standard_normal(A) * 0.2 - 0.3)
+    s, a = rng.standard_normal((B, S)), rng.standard_normal((B, A))
+    adv, um = rng.standard_normal(B), rng.random(B) > 0.2
+    mean0 = O.actor_mean(s, actor)
+    lp_old = O.gaussian_logprob(a, mean0, actor.action_std_log) + 0.4 * rng.standard_normal(B)    # ratios on both sides of the clip
+    obj_s, obj_e, gw, gb, gsl = O.actor_objective(s, a, lp_old, adv, um, actor, clip, lam, objective)
+
+    t = lambda x: th.tensor(np.asarray(x), dtype=th.float64)  # noqa: E731
+    W = [t(w).requires_grad_() for w in ws]
+    Bv = [t(b).requires_grad_() for b in bs]
+    sl = t(actor.action_std_log).requires_grad_()
+    x = (t(s) - t(actor.state_avg)) / (t(actor.state_std) + 1e-4)
+    h = th.nn.functional.gelu(x @ W[0].T + Bv[0])
+    h = th.nn.functional.gelu(h @ W[1].T + Bv[1])
+    mu = h @ W[2].T + Bv[2]
+    dist = th.distributions.Normal(mu, sl.exp())
+    logp_a = dist.log_prob(t(a))                       # (B, A)
+    ent = dist.entropy().sum(1)
+    tum, tadv = t(um.astype(np.float64)), t(adv)
+    if objective == "a2c":
+        obj = (tadv[:, None] * logp_a).mean()          # AgentPPO.py:301 with new_logprob of shape (B, A)
+        loss, ref_e = -obj, 0.0
+    else:
+        ratio = (logp_a.sum(1) - t(lp_old)).exp()
+        if objective == "canonical":
+            surr = th.min(tadv * ratio, tadv * ratio.clamp(1 - clip, 1 + clip))
+        else:
+            surr = tadv * ratio * th.where(tadv > 0, 1 - clip, 1 + clip)
+        obj = (surr * tum).mean()
+        ref_e = (ent * tum).mean()
+        loss = -(obj - ref_e * lam)
+        ref_e = float(ref_e.detach())
+    loss.backward()
+    assert abs(float(obj) - obj_s) <= 1e-10 * max(1, abs(float(obj))) and abs(ref_e - obj_e) <= 1e-10
+    for mine, ref in zip(list(gw) + list(gb) + [gsl], W + Bv + [sl]):
+        np.testing.assert_allclose(mine, ref.grad.numpy().reshape(mine.shape), rtol=1e-9, atol=1e-12)
