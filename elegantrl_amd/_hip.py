@@ -45,6 +45,10 @@ _SIGNATURES = {
                                      c_int64, c_int64, _P]),
     "erl_replay_sample_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64,
                                       _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "erl_replay_write_discrete_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int, c_int64,
+                                              c_int64, _P]),
+    "erl_replay_sample_discrete_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, c_int64,
+                                               _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "erl_mlp_param_count": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "erl_value_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     "erl_rollout_step_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_uint64, c_uint64,

@@ -211,6 +211,6 @@ class AgentSAC(AgentBase):
             return 0.0, 0.0
         objs = th.zeros((update_times, 2), dtype=th.float32, device=self.device)
         for t in range(update_times):
-            self._update_on_batch(buffer.sample(self.batch_size), objs[t])
+            self._update_on_batch(buffer.sample(self.batch_size, reuse=True), objs[t])   # the batch is consumed before the next draw
         o = objs.cpu().numpy()
         return float(np.nanmean(o[:, 0])), float(np.nanmean(o[:, 1]))

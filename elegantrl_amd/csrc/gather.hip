@@ -60,11 +60,13 @@ __global__ __launch_bounds__(256) void ppo_gather_kernel(const float *__restrict
 
 // Ring write: virtual row of width W = S + A + 3 per (time row i, sequence q);
 // destination time row = (p + i) mod max_size  (replay_buffer.py:86-105).
-template <bool FLAG_F32>
-__global__ __launch_bounds__(256) void replay_write_kernel(float *__restrict__ b_states, float *__restrict__ b_actions,
+// ACT_U8: discrete actions -- (add, num_seqs) int32 in, (max_size, num_seqs) uint8 stored (replay_buffer.py:53-54; the
+// assignment of an int32 row into the uint8 buffer keeps the low byte), one column instead of A.
+template <bool FLAG_F32, bool ACT_U8>
+__global__ __launch_bounds__(256) void replay_write_kernel(float *__restrict__ b_states, void *__restrict__ b_actions,
                                                            float *__restrict__ b_rewards, float *__restrict__ b_undones,
                                                            float *__restrict__ b_unmasks, const float *__restrict__ states,
-                                                           const float *__restrict__ actions,
+                                                           const void *__restrict__ actions,
                                                            const float *__restrict__ rewards, const void *__restrict__ undones,
                                                            const void *__restrict__ unmasks, int64_t max_size,
                                                            int64_t num_seqs, int S, int A, int64_t p, int64_t add)
@@ -79,7 +81,10 @@ __global__ __launch_bounds__(256) void replay_write_kernel(float *__restrict__ b
         if (ti >= max_size) ti -= max_size;
         const int64_t d = ti * num_seqs + q;
         if (c < S) b_states[d * S + c] = states[r * S + c];
-        else if (c < S + A) b_actions[d * A + (c - S)] = actions[r * A + (c - S)];
+        else if (c < S + A) {
+            if (ACT_U8) ((uint8_t *)b_actions)[d] = (uint8_t)((const int32_t *)actions)[r];
+            else ((float *)b_actions)[d * A + (c - S)] = ((const float *)actions)[r * A + (c - S)];
+        }
         else if (c == S + A) b_rewards[d] = rewards[r];
         else if (c == S + A + 1)
             b_undones[d] = FLAG_F32 ? ((const float *)undones)[r] : (((const uint8_t *)undones)[r] ? 1.f : 0.f);
@@ -94,14 +99,15 @@ __global__ __launch_bounds__(256) void replay_write_kernel(float *__restrict__ b
 // LDS and in ids0/ids1), then all 256 threads stream the RS_SAMPLES x W output elements with 32-bit index math.
 constexpr int RS_SAMPLES = 128;
 
+template <bool ACT_U8>
 __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restrict__ b_states,
-                                                            const float *__restrict__ b_actions,
+                                                            const void *__restrict__ b_actions,
                                                             const float *__restrict__ b_rewards,
                                                             const float *__restrict__ b_undones,
                                                             const float *__restrict__ b_unmasks, int64_t num_seqs, int S,
                                                             int A, const int64_t *__restrict__ ids, int64_t B,
                                                             int64_t sample_len, float *__restrict__ o_state,
-                                                            float *__restrict__ o_action, float *__restrict__ o_reward,
+                                                            void *__restrict__ o_action, float *__restrict__ o_reward,
                                                             float *__restrict__ o_undone, float *__restrict__ o_unmask,
                                                             float *__restrict__ o_next, int64_t *__restrict__ o_ids0,
                                                             int64_t *__restrict__ o_ids1)
@@ -126,7 +132,8 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restr
             if (c < S) {
                 o_state[b * S + c] = b_states[row * S + c];
             } else if (c < S + A) {
-                o_action[b * A + (c - S)] = b_actions[row * A + (c - S)];
+                if (ACT_U8) ((uint8_t *)o_action)[b] = ((const uint8_t *)b_actions)[row];
+                else ((float *)o_action)[b * A + (c - S)] = ((const float *)b_actions)[row * A + (c - S)];
             } else if (c < S + A + 3) {
                 const int k = c - S - A;
                 if (k == 0) o_reward[b] = b_rewards[row];
@@ -176,28 +183,75 @@ extern "C" int erl_ppo_gather_f32(const float *states, const float *actions, con
     ERL_LAUNCH_CHECK("erl_ppo_gather_f32");
 }
 
+namespace {
+
+int replay_write_impl(const char *what, bool act_u8, float *buf_states, void *buf_actions, float *buf_rewards, float *buf_undones,
+                      float *buf_unmasks, const float *states, const void *actions, const float *rewards, const void *undones,
+                      const void *unmasks, int flag_is_f32, int64_t max_size, int64_t num_seqs, int S, int A, int64_t p, int64_t add,
+                      void *stream)
+{
+    ERL_REQUIRE(buf_states && buf_actions && buf_rewards && buf_undones && buf_unmasks && states && actions && rewards && undones &&
+                    unmasks,
+                "%s: NULL tensor", what);
+    ERL_REQUIRE(max_size >= 1 && num_seqs >= 1 && S >= 1 && A >= 1, "%s: bad shape", what);
+    ERL_REQUIRE(add >= 0 && add <= max_size && p >= 0 && p <= max_size, "%s: add=%lld p=%lld max_size=%lld", what, (long long)add,
+                (long long)p, (long long)max_size);
+    if (add == 0) return ERL_OK;
+    const int g = grid_for(add * num_seqs * (S + A + 3));
+    hipStream_t st = (hipStream_t)stream;
+#define ERL_RW(F, U)                                                                                                            \
+    hipLaunchKernelGGL((replay_write_kernel<F, U>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones, \
+                       buf_unmasks, states, actions, rewards, undones, unmasks, max_size, num_seqs, S, A, p, add)
+    if (flag_is_f32 && act_u8) ERL_RW(true, true);
+    else if (flag_is_f32) ERL_RW(true, false);
+    else if (act_u8) ERL_RW(false, true);
+    else ERL_RW(false, false);
+#undef ERL_RW
+    return erl_hip_status(hipGetLastError(), what);
+}
+
+int replay_sample_impl(const char *what, bool act_u8, const float *buf_states, const void *buf_actions, const float *buf_rewards,
+                       const float *buf_undones, const float *buf_unmasks, int64_t max_size, int64_t num_seqs, int S, int A,
+                       const int64_t *ids, int64_t B, int64_t sample_len, float *out_state, void *out_action, float *out_reward,
+                       float *out_undone, float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1,
+                       void *stream)
+{
+    ERL_REQUIRE(buf_states && buf_actions && buf_rewards && buf_undones && buf_unmasks && ids, "%s: NULL tensor", what);
+    ERL_REQUIRE(out_state && out_action && out_reward && out_undone && out_unmask && out_next_state, "%s: NULL output", what);
+    ERL_REQUIRE(num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0 && sample_len >= 1 && sample_len < max_size,
+                "%s: bad shape (sample_len=%lld max_size=%lld)", what, (long long)sample_len, (long long)max_size);
+    if (B == 0) return ERL_OK;
+    const int g = grid_for(erl_cdiv(B, RS_SAMPLES) * 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (act_u8)
+        hipLaunchKernelGGL((replay_sample_kernel<true>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones,
+                           buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone, out_unmask,
+                           out_next_state, out_ids0, out_ids1);
+    else
+        hipLaunchKernelGGL((replay_sample_kernel<false>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones,
+                           buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone, out_unmask,
+                           out_next_state, out_ids0, out_ids1);
+    return erl_hip_status(hipGetLastError(), what);
+}
+
+}  // namespace
+
 extern "C" int erl_replay_write_f32(float *buf_states, float *buf_actions, float *buf_rewards, float *buf_undones,
                                     float *buf_unmasks, const float *states, const float *actions, const float *rewards,
                                     const void *undones, const void *unmasks, int flag_is_f32, int64_t max_size,
                                     int64_t num_seqs, int S, int A, int64_t p, int64_t add, void *stream)
 {
-    ERL_REQUIRE(buf_states && buf_actions && buf_rewards && buf_undones && buf_unmasks && states && actions && rewards &&
-                    undones && unmasks,
-                "erl_replay_write_f32: NULL tensor");
-    ERL_REQUIRE(max_size >= 1 && num_seqs >= 1 && S >= 1 && A >= 1, "erl_replay_write_f32: bad shape");
-    ERL_REQUIRE(add >= 0 && add <= max_size && p >= 0 && p <= max_size, "erl_replay_write_f32: add=%lld p=%lld max_size=%lld",
-                (long long)add, (long long)p, (long long)max_size);
-    if (add == 0) return ERL_OK;
-    const int g = grid_for(add * num_seqs * (S + A + 3));
-    if (flag_is_f32)
-        hipLaunchKernelGGL((replay_write_kernel<true>), dim3(g), dim3(256), 0, (hipStream_t)stream, buf_states, buf_actions,
-                           buf_rewards, buf_undones, buf_unmasks, states, actions, rewards, undones, unmasks, max_size, num_seqs,
-                           S, A, p, add);
-    else
-        hipLaunchKernelGGL((replay_write_kernel<false>), dim3(g), dim3(256), 0, (hipStream_t)stream, buf_states, buf_actions,
-                           buf_rewards, buf_undones, buf_unmasks, states, actions, rewards, undones, unmasks, max_size, num_seqs,
-                           S, A, p, add);
-    ERL_LAUNCH_CHECK("erl_replay_write_f32");
+    return replay_write_impl("erl_replay_write_f32", false, buf_states, buf_actions, buf_rewards, buf_undones, buf_unmasks, states,
+                             actions, rewards, undones, unmasks, flag_is_f32, max_size, num_seqs, S, A, p, add, stream);
+}
+
+extern "C" int erl_replay_write_discrete_f32(float *buf_states, uint8_t *buf_actions, float *buf_rewards, float *buf_undones,
+                                             float *buf_unmasks, const float *states, const int32_t *actions, const float *rewards,
+                                             const void *undones, const void *unmasks, int flag_is_f32, int64_t max_size,
+                                             int64_t num_seqs, int S, int64_t p, int64_t add, void *stream)
+{
+    return replay_write_impl("erl_replay_write_discrete_f32", true, buf_states, buf_actions, buf_rewards, buf_undones, buf_unmasks,
+                             states, actions, rewards, undones, unmasks, flag_is_f32, max_size, num_seqs, S, 1, p, add, stream);
 }
 
 extern "C" int erl_replay_sample_f32(const float *buf_states, const float *buf_actions, const float *buf_rewards,
@@ -206,14 +260,19 @@ extern "C" int erl_replay_sample_f32(const float *buf_states, const float *buf_a
                                      float *out_action, float *out_reward, float *out_undone, float *out_unmask,
                                      float *out_next_state, int64_t *out_ids0, int64_t *out_ids1, void *stream)
 {
-    ERL_REQUIRE(buf_states && buf_actions && buf_rewards && buf_undones && buf_unmasks && ids, "erl_replay_sample_f32: NULL tensor");
-    ERL_REQUIRE(out_state && out_action && out_reward && out_undone && out_unmask && out_next_state,
-                "erl_replay_sample_f32: NULL output");
-    ERL_REQUIRE(sample_len >= 1 && sample_len < max_size + 0 && num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0,
-                "erl_replay_sample_f32: bad shape (sample_len=%lld max_size=%lld)", (long long)sample_len, (long long)max_size);
-    if (B == 0) return ERL_OK;
-    hipLaunchKernelGGL(replay_sample_kernel, dim3(grid_for(erl_cdiv(B, RS_SAMPLES) * 256)), dim3(256), 0, (hipStream_t)stream, buf_states,
-                       buf_actions, buf_rewards, buf_undones, buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state,
-                       out_action, out_reward, out_undone, out_unmask, out_next_state, out_ids0, out_ids1);
-    ERL_LAUNCH_CHECK("erl_replay_sample_f32");
+    return replay_sample_impl("erl_replay_sample_f32", false, buf_states, buf_actions, buf_rewards, buf_undones, buf_unmasks,
+                              max_size, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone,
+                              out_unmask, out_next_state, out_ids0, out_ids1, stream);
+}
+
+extern "C" int erl_replay_sample_discrete_f32(const float *buf_states, const uint8_t *buf_actions, const float *buf_rewards,
+                                              const float *buf_undones, const float *buf_unmasks, int64_t max_size,
+                                              int64_t num_seqs, int S, const int64_t *ids, int64_t B, int64_t sample_len,
+                                              float *out_state, uint8_t *out_action, float *out_reward, float *out_undone,
+                                              float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1,
+                                              void *stream)
+{
+    return replay_sample_impl("erl_replay_sample_discrete_f32", true, buf_states, buf_actions, buf_rewards, buf_undones,
+                              buf_unmasks, max_size, num_seqs, S, 1, ids, B, sample_len, out_state, out_action, out_reward,
+                              out_undone, out_unmask, out_next_state, out_ids0, out_ids1, stream);
 }

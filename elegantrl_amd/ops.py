@@ -118,13 +118,23 @@ def ppo_gather(states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantage
 # ------------------------------------------------------------------------------------------------
 def replay_write(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undones: TEN, buf_unmasks: TEN,
                  items: Sequence[TEN], p: int) -> None:
+    """ring append (ReplayBuffer.update).  A uint8 `buf_actions` (max_size, num_seqs) is a discrete-action ring: `actions`
+    arrive as (add, num_seqs) int32 (AgentBase.py:146) and their low byte is stored (replay_buffer.py:53-54)."""
     states, actions, rewards, undones, unmasks = items
     max_size, num_seqs, S = buf_states.shape
-    A = buf_actions.shape[2]
     add = rewards.shape[0]
-    assert states.shape == (add, num_seqs, S) and actions.shape == (add, num_seqs, A)
     is_f32 = undones.dtype == th.float32
     assert unmasks.dtype == undones.dtype and (is_f32 or undones.dtype in (th.bool, th.uint8))
+    if buf_actions.dtype == th.uint8:
+        assert states.shape == (add, num_seqs, S) and actions.shape == (add, num_seqs) and buf_actions.shape == (max_size, num_seqs)
+        check(lib().erl_replay_write_discrete_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.uint8), ptr(buf_rewards, th.float32),
+                                                  ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), ptr(states, th.float32),
+                                                  ptr(actions, th.int32), ptr(rewards, th.float32), ptr(undones), ptr(unmasks),
+                                                  int(is_f32), max_size, num_seqs, S, p, add, stream_ptr()),
+              "erl_replay_write_discrete_f32")
+        return
+    A = buf_actions.shape[2]
+    assert states.shape == (add, num_seqs, S) and actions.shape == (add, num_seqs, A)
     check(lib().erl_replay_write_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.float32), ptr(buf_rewards, th.float32),
                                      ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), ptr(states, th.float32),
                                      ptr(actions, th.float32), ptr(rewards, th.float32), ptr(undones), ptr(unmasks), int(is_f32),
@@ -132,27 +142,52 @@ def replay_write(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undone
           "erl_replay_write_f32")
 
 
+class ReplayStage:
+    """the output block of ReplayBuffer.sample for one batch size -- ONE fp32 allocation viewed as state / next_state / action /
+    reward / undone / unmask, one int64 (2, B) for ids0 / ids1 and, for a discrete ring, a (B,) uint8 action vector -- with
+    its raw addresses computed once.  A buffer that reuses its stage (ReplayBuffer.sample(..., reuse=True), the off-policy
+    update loop) samples without touching the allocator or building views: at batch 256 that was most of the call."""
+
+    def __init__(self, B: int, S: int, A: int, discrete: bool, device):
+        self.B, self.discrete = B, discrete
+        A_f = 0 if discrete else A
+        self.flat = th.empty(B * (2 * S + A_f + 3), dtype=th.float32, device=device)
+        o_s, o_n, o_a, o_r, o_ud, o_um = th.split(self.flat, [B * S, B * S, B * A_f, B, B, B])
+        self.act_u8 = th.empty(B, dtype=th.uint8, device=device) if discrete else None
+        self.i01 = th.empty((2, B), dtype=th.int64, device=device)
+        self.out = (o_s.view(B, S), self.act_u8 if discrete else o_a.view(B, A), o_r, o_ud, o_um, o_n.view(B, S))
+        self.ids = (self.i01[0], self.i01[1])
+        base, ib = self.flat.data_ptr(), self.i01.data_ptr()
+        self.p_state, self.p_next = base, base + 4 * B * S
+        self.p_action = self.act_u8.data_ptr() if discrete else base + 8 * B * S
+        self.p_reward = base + 4 * B * (2 * S + A_f)
+        self.p_undone, self.p_unmask = self.p_reward + 4 * B, self.p_reward + 8 * B
+        self.p_ids0, self.p_ids1 = ib, ib + 8 * B
+
+
 def replay_sample(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undones: TEN, buf_unmasks: TEN, ids: TEN,
-                  sample_len: int):
+                  sample_len: int, stage: Optional[ReplayStage] = None):
     """ReplayBuffer.sample given the drawn ids: ((state, action, reward, undone, unmask, next_state), (ids0, ids1)).
-    The six outputs are views of ONE allocation (and the two index vectors of another): two allocator calls per
-    sample instead of eight keep the interpreter off the critical path at small batch sizes."""
+    The six outputs are views of ONE allocation (and the two index vectors of another); pass a ReplayStage to reuse it."""
     max_size, num_seqs, S = buf_states.shape
-    A = buf_actions.shape[2]
+    discrete = buf_actions.dtype == th.uint8
+    A = 1 if discrete else buf_actions.shape[2]
     B = ids.numel()
-    dev = buf_states.device
-    flat = th.empty(B * (2 * S + A + 3), dtype=th.float32, device=dev)
-    o_s, o_n, o_a, o_r, o_ud, o_um = th.split(flat, [B * S, B * S, B * A, B, B, B])
-    o_s, o_n, o_a = o_s.view(B, S), o_n.view(B, S), o_a.view(B, A)
-    i01 = th.empty((2, B), dtype=th.int64, device=dev)
-    base, ib = flat.data_ptr(), i01.data_ptr()
-    check(lib().erl_replay_sample_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.float32), ptr(buf_rewards, th.float32),
-                                      ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), max_size, num_seqs, S, A,
-                                      ptr(ids, th.int64), B, sample_len, base, base + 8 * B * S, base + 4 * B * (2 * S + A),
-                                      base + 4 * B * (2 * S + A + 1), base + 4 * B * (2 * S + A + 2), base + 4 * B * S,
-                                      ib, ib + 8 * B, stream_ptr()),
-          "erl_replay_sample_f32")
-    return (o_s, o_a, o_r, o_ud, o_um, o_n), (i01[0], i01[1])
+    st = stage if stage is not None else ReplayStage(B, S, A, discrete, buf_states.device)
+    assert st.B == B and st.discrete == discrete
+    if discrete:
+        check(lib().erl_replay_sample_discrete_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.uint8), ptr(buf_rewards, th.float32),
+                                                   ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), max_size, num_seqs, S,
+                                                   ptr(ids, th.int64), B, sample_len, st.p_state, st.p_action, st.p_reward,
+                                                   st.p_undone, st.p_unmask, st.p_next, st.p_ids0, st.p_ids1, stream_ptr()),
+              "erl_replay_sample_discrete_f32")
+    else:
+        check(lib().erl_replay_sample_f32(ptr(buf_states, th.float32), ptr(buf_actions, th.float32), ptr(buf_rewards, th.float32),
+                                          ptr(buf_undones, th.float32), ptr(buf_unmasks, th.float32), max_size, num_seqs, S, A,
+                                          ptr(ids, th.int64), B, sample_len, st.p_state, st.p_action, st.p_reward, st.p_undone,
+                                          st.p_unmask, st.p_next, st.p_ids0, st.p_ids1, stream_ptr()),
+              "erl_replay_sample_f32")
+    return st.out, st.ids
 
 
 # ------------------------------------------------------------------------------------------------

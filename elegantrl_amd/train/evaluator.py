@@ -70,10 +70,11 @@ class Evaluator:
             self.save_training_curve_jpg()
 
     def get_cumulative_rewards_and_step(self, actor) -> TEN:
-        if getattr(self.env, "num_envs", 1) == 1:
+        if getattr(self.env, "num_envs", 1) == 1:                                  # evaluator.py:145-148
             out = [get_rewards_and_steps(self.env, actor) for _ in range(self.eval_times)]
             return th.tensor(out, dtype=th.float32)
-        return get_cumulative_rewards_and_step_from_vec_env(self.env, actor)
+        rounds = max(1, self.eval_times // self.env.num_envs)                       # evaluator.py:150-155
+        return th.cat([get_cumulative_rewards_and_step_from_vec_env(self.env, actor) for _ in range(rounds)], dim=0)
 
     def save_or_load_recoder(self, if_save: bool):
         if if_save:
@@ -106,7 +107,7 @@ class Evaluator:
 
 
 def get_rewards_and_steps(env, actor, if_render: bool = False) -> tuple:
-    """one episode of a single (numpy) env with the deterministic policy `actor(state)`."""
+    """one episode of a single (numpy) env with the deterministic policy `actor(state)` (evaluator.py:161-198)."""
     device = next(actor.parameters()).device
     max_step = env.max_step
     state, _ = env.reset()
@@ -116,26 +117,37 @@ def get_rewards_and_steps(env, actor, if_render: bool = False) -> tuple:
         action = actor(ten).detach().cpu().numpy()[0]
         state, reward, terminated, truncated, _ = env.step(action)
         cumulative += reward
+        if if_render:
+            env.render()
         if terminated or truncated:
             break
-    cumulative = getattr(env, "cumulative_rewards", cumulative)
+    cumulative = getattr(getattr(env, "unwrapped", env), "cumulative_returns", cumulative)
     return cumulative, episode_steps + 1
 
 
 def get_cumulative_rewards_and_step_from_vec_env(env, actor) -> TEN:
-    """first-episode return and length of every sub-env of a device-resident vectorised env -> (num_envs, 2)."""
+    """(return, length) of EVERY episode the sub-envs complete within `max_step` steps of the deterministic policy, as the
+    reference counts them (evaluator.py:201-238): the rollout runs on the env's device without host round trips, the reward
+    and done planes come to the host once, episodes still open at the end are dropped, and an env that exposes
+    `cumulative_returns` reports that (with length max_step) instead.  -> (n_episodes, 2) float32 on the CPU."""
     device = next(actor.parameters()).device
     n, max_step = env.num_envs, env.max_step
     state, _ = env.reset()
-    returns = th.zeros(n, dtype=th.float32, device=device)
-    steps = th.zeros(n, dtype=th.float32, device=device)
-    alive = th.ones(n, dtype=th.bool, device=device)
+    rewards = th.empty((max_step, n), dtype=th.float32, device=device)
+    dones = th.empty((max_step, n), dtype=th.bool, device=device)
     with th.no_grad():
-        for _ in range(max_step):
+        for t in range(max_step):
             state, reward, terminal, truncate, _ = env.step(actor(state.to(device)))
-            returns += reward * alive
-            steps += alive
-            alive &= ~(terminal | truncate)
-            if not bool(alive.any()):
-                break
-    return th.stack((returns, steps), dim=1).cpu()
+            rewards[t] = reward
+            dones[t] = th.logical_or(terminal, truncate)
+    if hasattr(env, "cumulative_returns"):
+        ret = th.as_tensor(env.cumulative_returns, dtype=th.float32).reshape(-1).cpu()
+        return th.stack((ret, th.full_like(ret, float(max_step))), dim=1)
+    r, d = rewards.cpu().numpy().astype(np.float64), dones.cpu().numpy()
+    cs = np.vstack((np.zeros((1, n)), np.cumsum(r, axis=0)))      # cs[t] = sum of the first t rewards (exact enough in fp64)
+    out = []
+    for i in range(n):
+        ends = np.flatnonzero(d[:, i]) + 1
+        starts = np.concatenate(([0], ends[:-1]))
+        out.extend(zip(cs[ends, i] - cs[starts, i], ends - starts))
+    return th.tensor(out, dtype=th.float32).reshape(-1, 2)

@@ -3,8 +3,9 @@
 Same constructor, attributes and cursor behaviour as elegantrl/train/replay_buffer.py:11-134; the
 cursor arithmetic (p, cur_size, if_full, add_size) is host-side integer code and reproduces the
 reference bit for bit (including landing exactly on max_size, Appendix A12 of SURVEY.md).  The tensor
-traffic goes through erl_replay_write_f32 / erl_replay_sample_f32.  Prioritised replay (SumTree) is a
-"next" row of SURVEY.md section 8f and raises NotImplementedError.
+traffic goes through erl_replay_write_f32 / erl_replay_sample_f32 (uint8 action rings of discrete agents:
+erl_replay_*_discrete_f32).  Prioritised replay (SumTree) is a "next" row of SURVEY.md section 8f and raises
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -24,8 +25,7 @@ class ReplayBuffer:
                  if_use_per: bool = False, if_discrete: bool = False, args: Optional[Config] = None):
         if if_use_per:
             raise NotImplementedError("prioritised replay (per-sequence SumTree) is not part of the HIP hot path yet")
-        if if_discrete:
-            raise NotImplementedError("discrete-action replay (uint8 actions) is not part of the HIP hot path yet")
+        assert (action_dim < 256) or (not if_discrete)       # replay_buffer.py:50: a discrete action must fit a byte
         self.p = 0                 # write cursor (time row)
         self.if_full = False
         self.cur_size = 0
@@ -35,7 +35,10 @@ class ReplayBuffer:
         self.device = th.device(f"cuda:{gpu_id}" if (th.cuda.is_available() and gpu_id >= 0) else "cpu")
         f32 = dict(dtype=th.float32, device=self.device)
         self.states = th.empty((self.max_size, self.num_seqs, state_dim), **f32)
-        self.actions = th.empty((self.max_size, self.num_seqs, action_dim), **f32)
+        self.if_discrete = bool(if_discrete)
+        self.actions = (th.empty((self.max_size, self.num_seqs), dtype=th.uint8, device=self.device) if if_discrete
+                        else th.empty((self.max_size, self.num_seqs, action_dim), **f32))          # replay_buffer.py:52-54
+        self._stage = None
         self.rewards = th.empty((self.max_size, self.num_seqs), **f32)
         self.undones = th.empty((self.max_size, self.num_seqs), **f32)   # float flags, as in the reference
         self.unmasks = th.empty((self.max_size, self.num_seqs), **f32)
@@ -71,15 +74,25 @@ class ReplayBuffer:
                           unmasks.contiguous()), start)
 
     @_hip.on_device
-    def sample(self, batch_size: int, ids: Optional[TEN] = None) -> Tuple[TEN, TEN, TEN, TEN, TEN, TEN]:
+    def sample(self, batch_size: int, ids: Optional[TEN] = None, reuse: bool = False) -> Tuple[TEN, TEN, TEN, TEN, TEN, TEN]:
         """(state, action, reward, undone, unmask, next_state) for ids drawn like the reference
-        (th.randint(sample_len * num_seqs, (batch_size,))); `ids` can be injected for tests."""
+        (th.randint(sample_len * num_seqs, (batch_size,))); `ids` can be injected for tests.
+        reuse=True writes into a buffer-owned staging block that the NEXT reuse=True call overwrites (no allocator call, no
+        view construction per sample) -- for loops that consume a batch before drawing the next, like the off-policy
+        update_net; the default returns fresh tensors like the reference."""
         from .. import ops
         sample_len = self.cur_size - 1
         if ids is None:
             ids = th.randint(sample_len * self.num_seqs, size=(batch_size,), requires_grad=False, device=self.device)
+        stage = None
+        if reuse:
+            B = ids.numel()
+            if self._stage is None or self._stage.B != B:
+                self._stage = ops.ReplayStage(B, self.states.shape[2], 1 if self.if_discrete else self.actions.shape[2],
+                                              self.if_discrete, self.device)
+            stage = self._stage
         out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
-                                                        ids, sample_len)
+                                                        ids, sample_len, stage=stage)
         return out
 
     def sample_for_per(self, batch_size: int):

@@ -126,6 +126,13 @@ ERL_API int erl_replay_write_f32(float *buf_states, float *buf_actions, float *b
                          float *buf_unmasks, const float *states, const float *actions, const float *rewards,
                          const void *undones, const void *unmasks, int flag_is_f32, int64_t max_size,
                          int64_t num_seqs, int S, int A, int64_t p, int64_t add, void *stream);
+/* discrete actions (if_discrete=True, replay_buffer.py:53-54): `actions` (add, num_seqs) int32 as the off-policy rollout
+ * produces them (AgentBase.py:146), stored as uint8 in `buf_actions` (max_size, num_seqs) -- the low byte, like torch's
+ * assignment of an int32 tensor into a uint8 one */
+ERL_API int erl_replay_write_discrete_f32(float *buf_states, uint8_t *buf_actions, float *buf_rewards, float *buf_undones,
+                                  float *buf_unmasks, const float *states, const int32_t *actions, const float *rewards,
+                                  const void *undones, const void *unmasks, int flag_is_f32, int64_t max_size,
+                                  int64_t num_seqs, int S, int64_t p, int64_t add, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9  replay sample.  Replaces ReplayBuffer.sample (replay_buffer.py:120-134) given the drawn ids:
@@ -138,6 +145,13 @@ ERL_API int erl_replay_sample_f32(const float *buf_states, const float *buf_acti
                           float *out_state, float *out_action, float *out_reward, float *out_undone,
                           float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1,
                           void *stream);
+/* the same for the uint8 action buffer of a discrete-action ring: out_action is (B,) uint8 */
+ERL_API int erl_replay_sample_discrete_f32(const float *buf_states, const uint8_t *buf_actions, const float *buf_rewards,
+                                   const float *buf_undones, const float *buf_unmasks, int64_t max_size,
+                                   int64_t num_seqs, int S, const int64_t *ids, int64_t B, int64_t sample_len,
+                                   float *out_state, uint8_t *out_action, float *out_reward, float *out_undone,
+                                   float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1,
+                                   void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MLP parameter block used by K1/K2/K6/K7: one flat fp32 buffer per network, laid out as

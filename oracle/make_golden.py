@@ -270,6 +270,50 @@ def make_replay():
     print("wrote", path)
 
 
+def make_replay_discrete():
+    """reference ReplayBuffer(if_discrete=True): uint8 action ring fed with (add, num_seqs) int32 actions (AgentBase.py:146),
+    same cursor schedule as make_replay (wrap-around, landing exactly on max_size)."""
+    sys.path.insert(0, REF)
+    from elegantrl.train.replay_buffer import ReplayBuffer
+
+    th.manual_seed(8)
+    max_size, S, n_actions, num_seqs = 20, 3, 6, 2
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=1, gpu_id=-1, num_seqs=num_seqs, if_discrete=True)
+    assert buf.actions.dtype == th.uint8 and buf.actions.shape == (max_size, num_seqs)
+    buf.states.zero_(); buf.actions.zero_(); buf.rewards.zero_(); buf.undones.zero_(); buf.unmasks.zero_()
+    adds = [7, 7, 6, 5, 9, 20, 3]
+    g = {"adds": np.array(adds), "dims": np.array([max_size, S, n_actions, num_seqs])}
+    orig_randint = th.randint
+    for k, add in enumerate(adds):
+        items = (th.randn(add, num_seqs, S), orig_randint(n_actions, (add, num_seqs), dtype=th.int32), th.randn(add, num_seqs),
+                 th.rand(add, num_seqs) > 0.2, th.rand(add, num_seqs) > 0.1)
+        buf.update(items)
+        for name, t in zip(("states", "actions", "rewards", "undones", "unmasks"), items):
+            g[f"in{k}_{name}"] = np32(t)
+        g[f"cursor{k}"] = np.array([buf.p, buf.cur_size, int(buf.if_full), buf.add_size])
+        for name in ("states", "actions", "rewards", "undones", "unmasks"):
+            g[f"buf{k}_{name}"] = np32(getattr(buf, name))
+        log = []
+
+        def rec(*a, **kw):
+            out = orig_randint(*a, **kw)
+            log.append(out.clone())
+            return out
+
+        th.randint = rec
+        out = buf.sample(16)
+        th.randint = orig_randint
+        g[f"ids{k}"] = np32(log[0]).astype(np.int64)
+        g[f"ids0_{k}"] = np32(buf.ids0).astype(np.int64)
+        g[f"ids1_{k}"] = np32(buf.ids1).astype(np.int64)
+        for name, t in zip(("state", "action", "reward", "undone", "unmask", "next_state"), out):
+            g[f"out{k}_{name}"] = np32(t)
+        assert out[1].dtype == th.uint8 and out[1].shape == (16,)
+    path = os.path.join(OUT, "replay_ring_discrete.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path)
+
+
 def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed):
     """Run the reference's AgentSAC.update_objectives on a seeded ring; record every random draw it makes
     (minibatch ids via th.randint, the two rsample() noise tensors per step via th.distributions.Normal.rsample) so the
@@ -458,6 +502,34 @@ def make_cum_rewards():
     print("wrote", path)
 
 
+def make_evaluator():
+    """the reference's Evaluator (elegantrl/train/evaluator.py:12-155) driven with a toy single env and a toy vectorised env
+    (tests/helpers.py) through a fixed schedule of evaluate_and_save calls: the files it leaves in cwd and recorder.npy."""
+    import tempfile
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from elegantrl.train.config import Config
+    from elegantrl.train.evaluator import Evaluator
+    from tests.helpers import EVAL_SCHEDULE, ToyActor, ToySingleEnv, ToyVecEnv
+    g = {}
+    for tag, env, over_write in (("single", ToySingleEnv(), False), ("vec", ToyVecEnv(6), False), ("vec_overwrite", ToyVecEnv(6), True)):
+        args = Config()
+        args.gpu_id, args.eval_times, args.eval_per_step, args.eval_record_step = 0, 4 if tag == "single" else 12, 150, 0
+        args.save_gap, args.if_keep_save, args.if_over_write = 2, True, over_write
+        actor = ToyActor.build(env.state_dim, env.action_dim)
+        with tempfile.TemporaryDirectory() as cwd, th.no_grad():
+            ev = Evaluator(cwd=cwd, env=env, args=args)
+            for steps, exp_r, log in EVAL_SCHEDULE:
+                ev.evaluate_and_save(actor, steps, exp_r, log)
+            ev.save_or_load_recoder(if_save=True)
+            g[f"{tag}_files"] = np.array(sorted(os.listdir(cwd)))
+            g[f"{tag}_recorder"] = np.load(f"{cwd}/recorder.npy")
+        print(tag, list(g[f"{tag}_files"]), g[f"{tag}_recorder"].shape)
+    path = os.path.join(OUT, "evaluator_format.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"reference not mounted at {REF}"
     only = sys.argv[1:]
@@ -476,8 +548,10 @@ if __name__ == "__main__":
     make_ppo("mid_vtrace", N=40, S=17, A=5, H=20, net_dims=(128, 128), batch_size=64, repeat_times=6.4,
              use_v_trace=True, seed=13)
     make_replay()
+    make_replay_discrete()
     make_sac("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=21)
     make_ppo_discrete("small", N=8, S=6, A=4, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0, seed=31)
     make_cum_rewards()
     make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)
     make_a2c("mid", S=64, A=8, H=48, net_dims=(128, 128), batch_size=32, repeat_times=2.0, seed=42)
+    make_evaluator()

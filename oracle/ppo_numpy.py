@@ -429,7 +429,7 @@ def cum_rewards_slice(p: int, add_size: int, max_size: int) -> Tuple[int, int]:
 class Ring:
     """ReplayBuffer.__init__/update/sample restated on numpy (non-PER path)."""
 
-    def __init__(self, max_size: int, state_dim: int, action_dim: int, num_seqs: int = 1):
+    def __init__(self, max_size: int, state_dim: int, action_dim: int, num_seqs: int = 1, if_discrete: bool = False):
         self.p = 0
         self.if_full = False
         self.cur_size = 0
@@ -438,7 +438,8 @@ class Ring:
         self.num_seqs = num_seqs
         f = np.float32
         self.states = np.zeros((max_size, num_seqs, state_dim), f)
-        self.actions = np.zeros((max_size, num_seqs, action_dim), f)
+        # discrete agents: one uint8 per transition (replay_buffer.py:53-54); int32 actions are narrowed on assignment
+        self.actions = np.zeros((max_size, num_seqs), np.uint8) if if_discrete else np.zeros((max_size, num_seqs, action_dim), f)
         self.rewards = np.zeros((max_size, num_seqs), f)
         self.undones = np.zeros((max_size, num_seqs), f)   # floats, unlike the on-policy bools (:57-58)
         self.unmasks = np.zeros((max_size, num_seqs), f)

@@ -283,14 +283,17 @@ def test_ppo_gather_bit_exact(ops, dev, H, N, S, A, B):
     np.testing.assert_array_equal(o_r.cpu().numpy(), rs[r0, r1])
 
 
-def test_replay_ring_against_reference_golden(ops, dev):
-    g = load("replay_ring.npz")
+@pytest.mark.parametrize("name", ["replay_ring.npz", "replay_ring_discrete.npz"])
+def test_replay_ring_against_reference_golden(ops, dev, name):
+    """K8 / K9 against the reference's own ReplayBuffer run, continuous and discrete (uint8 action ring, int32 actions in)."""
+    g = load(name)
+    discrete = "discrete" in name
     max_size, S, A, num_seqs = [int(x) for x in g["dims"]]
     bs = th.zeros((max_size, num_seqs, S), device=dev)
-    ba = th.zeros((max_size, num_seqs, A), device=dev)
+    ba = th.zeros((max_size, num_seqs), dtype=th.uint8, device=dev) if discrete else th.zeros((max_size, num_seqs, A), device=dev)
     br, bu, bm = (th.zeros((max_size, num_seqs), device=dev) for _ in range(3))
     p = 0
-    ring = O.Ring(max_size, S, A, num_seqs)
+    ring = O.Ring(max_size, S, A, num_seqs, if_discrete=discrete)
     for k, add in enumerate(g["adds"]):
         items_np = tuple(g[f"in{k}_{n}"] for n in ("states", "actions", "rewards", "undones", "unmasks"))
         ops.replay_write(bs, ba, br, bu, bm, [cu(x, dev) for x in items_np], p)
@@ -303,6 +306,30 @@ def test_replay_ring_against_reference_golden(ops, dev):
         np.testing.assert_array_equal(i1.cpu().numpy(), g[f"ids1_{k}"])
         for t, n in zip(out, ("state", "action", "reward", "undone", "unmask", "next_state")):
             np.testing.assert_array_equal(t.cpu().numpy(), g[f"out{k}_{n}"])
+            assert t.dtype == (th.uint8 if discrete and n == "action" else th.float32)
+
+
+def test_replay_buffer_class_discrete_and_reused_stage(dev):
+    """ReplayBuffer(if_discrete=True) end to end on the reference golden, and sample(reuse=True): same values, same storage."""
+    from elegantrl_amd.train import ReplayBuffer
+    g = load("replay_ring_discrete.npz")
+    max_size, S, _, num_seqs = [int(x) for x in g["dims"]]
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=1, gpu_id=0, num_seqs=num_seqs, if_discrete=True)
+    for t in (buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks):
+        t.zero_()
+    assert buf.actions.dtype == th.uint8 and buf.actions.shape == (max_size, num_seqs)
+    ptrs = set()
+    for k, add in enumerate(g["adds"]):
+        buf.update(tuple(cu(g[f"in{k}_{n}"], dev) for n in ("states", "actions", "rewards", "undones", "unmasks")))
+        assert [buf.p, buf.cur_size, int(buf.if_full), buf.add_size] == list(g[f"cursor{k}"])
+        np.testing.assert_array_equal(buf.actions.cpu().numpy(), g[f"buf{k}_actions"])
+        for reuse in (False, True):
+            out = buf.sample(16, ids=cu(g[f"ids{k}"], dev), reuse=reuse)
+            for t, n in zip(out, ("state", "action", "reward", "undone", "unmask", "next_state")):
+                np.testing.assert_array_equal(t.cpu().numpy(), g[f"out{k}_{n}"])
+            np.testing.assert_array_equal(buf.ids0.cpu().numpy(), g[f"ids0_{k}"])
+        ptrs.add(out[0].data_ptr())
+    assert len(ptrs) == 1                     # the reused stage is one allocation for the whole run
 
 
 def test_replay_large_random_vs_oracle(ops, dev):

@@ -76,10 +76,11 @@ def test_update_net_weights_and_objectives(name):
     assert moved > 0
 
 
-def test_replay_ring_cursors_indices_and_rows():
-    g = load("replay_ring.npz")
+@pytest.mark.parametrize("name", ["replay_ring.npz", "replay_ring_discrete.npz"])
+def test_replay_ring_cursors_indices_and_rows(name):
+    g = load(name)
     max_size, S, A, num_seqs = [int(x) for x in g["dims"]]
-    ring = O.Ring(max_size, S, A, num_seqs)
+    ring = O.Ring(max_size, S, A, num_seqs, if_discrete="discrete" in name)
     for k, add in enumerate(g["adds"]):
         items = tuple(g[f"in{k}_{n}"] for n in ("states", "actions", "rewards", "undones", "unmasks"))
         ring.update(items)
