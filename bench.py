@@ -34,8 +34,33 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
-# BASELINE config 4
+# BASELINE configs (SURVEY.md section 8 header / 8d).  c4 = configs[3] is the metric's configuration and the default; the
+# others are run with --config and recorded under profiles/ (same JSON schema, the workload named in config.workload).
+PPO_CONFIGS = {
+    "c4": dict(metric="env_steps_per_sec_ppo_4096envs_obs64", env="syn", N=4096, S=64, A=8, H=32, B=16384, update_times=40,
+               net_dims=[128, 128], hyper={},
+               workload="BASELINE configs[3]: AgentPPO, synthetic VecEnv obs_dim=64 act_dim=8, 4096 envs/GPU, horizon 32, "
+                        "40 minibatches x 16384, net [128,128], fp32"),
+    "c5": dict(metric="env_steps_per_sec_ppo_ant_shaped_8192envs", env="syn", N=8192, S=60, A=8, H=32, B=16384, update_times=80,
+               net_dims=[128, 128], hyper=dict(learning_rate=5e-4, lambda_entropy=0.0, reward_scale=0.01),
+               workload="BASELINE configs[4]: AgentPPO, Isaac-Gym-Ant-shaped synthetic VecEnv obs_dim=60 act_dim=8, 8192 envs/GPU, "
+                        "horizon 32, batch 16384, 5 passes = 80 minibatches, lr 5e-4, entropy 0 (examples/plan_Isaac_Gym.py:36-64), "
+                        "net [128,128], fp32"),
+    "c2": dict(metric="env_steps_per_sec_ppo_pendulum_4096envs", env="pendulum", N=4096, S=3, A=1, H=200, B=16384, update_times=40,
+               net_dims=[128, 64], hyper=dict(gamma=0.97, reward_scale=0.25, learning_rate=4e-4),
+               workload="BASELINE configs[1]: AgentPPO, GPU-resident vectorised Pendulum-v1, 4096 envs, horizon 200, "
+                        "40 minibatches x 16384, net [128,64], fp32"),
+}
 N_ENVS, STATE_DIM, ACTION_DIM, HORIZON, BATCH, UPDATE_TIMES, NET_DIMS = 4096, 64, 8, 32, 16384, 40, [128, 128]
+
+
+def select_config(name: str):
+    """point the module-level workload constants at one of the PPO configs"""
+    global N_ENVS, STATE_DIM, ACTION_DIM, HORIZON, BATCH, UPDATE_TIMES, NET_DIMS
+    c = PPO_CONFIGS[name]
+    N_ENVS, STATE_DIM, ACTION_DIM, HORIZON, BATCH, UPDATE_TIMES, NET_DIMS = (c["N"], c["S"], c["A"], c["H"], c["B"],
+                                                                              c["update_times"], list(c["net_dims"]))
+    return c
 
 
 def ppo_flops_per_sample(S, h1, h2, A):
@@ -127,11 +152,12 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline_subprocess(iters: int, timeout_s: int = 240):
+def cpu_baseline_subprocess(iters: int, config: str = "c4", timeout_s: int = 240):
     """run the CPU leg in its own process (fresh OpenMP pool, hard timeout) and parse its JSON line."""
     import subprocess
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-iters", str(iters)],
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-iters", str(iters),
+                              "--config", config],
                              capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for ln in reversed(out.stdout.strip().splitlines()):
             if ln.startswith("{"):
@@ -161,9 +187,90 @@ def cpu_baseline(iters=12):
         one()
     dt = time.perf_counter() - t0
     return {"value": round(N_ENVS * HORIZON * iters / dt, 1), "unit": "env-steps/s", "cores": th.get_num_threads(),
-            "kind": "port", "sample": f"{iters} PPO iterations (+1 warm-up) of the same config-4 workload "
-                                      f"(4096 envs x 32 steps, 40 minibatches of 16384) via oracle/torch_port.py",
+            "kind": "port", "sample": f"{iters} PPO iterations (+1 warm-up) of the same workload "
+                                      f"({N_ENVS} envs x {HORIZON} steps, {UPDATE_TIMES} minibatches of {BATCH}) via "
+                                      f"oracle/torch_port.py",
             "seconds": round(dt, 2)}
+
+
+def bench_sac(opt):
+    """--config c3: BASELINE configs[2], AgentSAC on a Hopper-v3-shaped synthetic env (obs 11, act 3) with a FULL 1e6-transition
+    replay ring.  One step = one off-policy iteration as elegantrl/train/run.py drives it: explore_env (64 steps x 64 envs) ->
+    buffer.update -> update_net = 64 x [ReplayBuffer.sample(256) + the SAC update].  value = SAC updates/s; `roofline` is the
+    sample kernel K9 (HBM bound, (2S + A + 3) * 4 B read + the same written + 8 B id per sample)."""
+    from elegantrl_amd import ops
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config, ReplayBuffer
+    assert opt.gpus == 1, "config 3 is a single-GPU configuration"
+    dev = th.device("cuda:0")
+    N, S, A, H, B, UPD, NET = 64, 11, 3, 64, 256, 64, [256, 256]
+    max_size = 1_000_000 // N                                           # ring capacity in time rows: 1e6 transitions
+    args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 1000, "state_dim": S, "action_dim": A,
+                                        "if_discrete": False})
+    args.net_dims, args.horizon_len, args.batch_size = NET, H, B
+    args.repeat_times = UPD * B / max_size                              # AgentBase.update_net: int(cur_size * repeat_times / B) = 64
+    args.gpu_id, args.random_seed = 0, 0
+    th.manual_seed(0)
+    agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    env = SynVecEnv(N, S, A, max_step=1000, gpu_id=0, seed=0)
+    agent.last_state = env.reset()[0]
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N)
+    g = th.Generator(device=dev).manual_seed(1)
+    for _ in range(2):                                                   # fill the ring completely (and wrap once)
+        buf.update((th.randn((max_size // 2 + 7, N, S), device=dev, generator=g), th.randn((max_size // 2 + 7, N, A), device=dev, generator=g).tanh(),
+                    th.randn((max_size // 2 + 7, N), device=dev, generator=g), th.rand((max_size // 2 + 7, N), device=dev, generator=g) < 0.99,
+                    th.rand((max_size // 2 + 7, N), device=dev, generator=g) < 0.995))
+    assert buf.if_full and buf.cur_size == max_size
+    t_k9 = EventTimer()
+    ops.replay_sample = t_k9.wrap(ops.replay_sample)
+
+    def step():
+        buf.update(agent.explore_env(env, H))
+        return agent.update_net(buf)
+
+    for _ in range(opt.warmup):
+        step()
+    t_k9.enabled = True
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        objs = step()
+    th.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t_k9.enabled = False
+    k9_s = t_k9.mean_seconds()
+    bytes_per = (2 * (2 * S + A + 3) * 4 + 8) * B
+    # the kernel's capability away from the launch floor: one sample call of 2^20 transitions on the same ring
+    big = th.randint((max_size - 1) * N, (1 << 20,), device=dev, generator=g)
+    for _ in range(3):
+        ops.replay_sample(buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks, big, max_size - 1)
+    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.replay_sample(buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks, big, max_size - 1)
+    e1.record()
+    th.cuda.synchronize()
+    big_s = e0.elapsed_time(e1) * 1e-4
+    big_bytes = (2 * (2 * S + A + 3) * 4 + 8) * (1 << 20)
+    line = {
+        "metric": "sac_updates_per_sec_replay1M_batch256", "value": round(UPD * opt.steps / elapsed, 1), "unit": "updates/s",
+        "n_gpus": 1, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: AgentSAC, Hopper-v3-shaped synthetic VecEnv obs_dim=11 act_dim=3, 64 envs, full "
+                               "ReplayBuffer of 1e6 transitions, per step 64x64 env steps + 64 x [sample(256) + SAC update], "
+                               "net [256,256], 4 critics, fp32", "name": "c3", "envs_per_gpu": N, "horizon": H, "batch": B,
+                   "update_times": UPD, "parallelism": "single"},
+        "env_steps_per_sec": round(N * H * opt.steps / elapsed, 1),
+        "us_per_update": round(elapsed / opt.steps / UPD * 1e6, 1),
+        "roofline": {"kernel": "replay_sample_kernel", "bound": "hbm", "achieved": round(bytes_per / k9_s / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(bytes_per / k9_s / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "bytes_per_launch": bytes_per, "avg_launch_us": round(k9_s * 1e6, 2), "launches_timed": len(t_k9.pairs),
+                     "at_batch_2^20": {"bytes_per_launch": big_bytes, "us": round(big_s * 1e6, 1),
+                                       "achieved": round(big_bytes / big_s / 1e9, 1), "frac": round(big_bytes / big_s / 1e9 / HBM_PEAK_GBPS, 4)}},
+        "objectives_last": [round(float(x), 6) for x in objs],
+    }
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -177,14 +284,20 @@ def main():
     ap.add_argument("--k6-sample", type=int, default=16,
                     help="bracket every n-th K6 launch with HIP events (0 = none): each bracket costs ~3 us of stream time")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5"], default="c4",
+                    help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
+                         "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs")
     opt = ap.parse_args()
+    if opt.config == "c3":
+        return bench_sac(opt)
+    cfg = select_config(opt.config)
     if opt.cpu_baseline_only:
         print(json.dumps(cpu_baseline(opt.cpu_iters)), flush=True)
         return
 
     from elegantrl_amd import ops, parallel
     from elegantrl_amd.agents import AgentPPO
-    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.envs import PendulumVecEnv, SynVecEnv
     from elegantrl_amd.train import Config
 
     rank, world, local_rank = parallel.init_from_env()
@@ -193,8 +306,13 @@ def main():
     th.cuda.set_device(local_rank)
     dev = th.device(f"cuda:{local_rank}")
 
-    args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N_ENVS, "max_step": 1000,
-                                        "state_dim": STATE_DIM, "action_dim": ACTION_DIM, "if_discrete": False})
+    pendulum = cfg["env"] == "pendulum"
+    max_step = 200 if pendulum else 1000
+    args = Config(AgentPPO, PendulumVecEnv if pendulum else SynVecEnv,
+                  {"env_name": "Pendulum-v1" if pendulum else "SynVecEnv", "num_envs": N_ENVS, "max_step": max_step,
+                   "state_dim": STATE_DIM, "action_dim": ACTION_DIM, "if_discrete": False})
+    for k, v in cfg["hyper"].items():
+        setattr(args, k, v)
     args.net_dims = list(NET_DIMS)
     args.horizon_len, args.batch_size = HORIZON, BATCH
     args.repeat_times = UPDATE_TIMES * BATCH / HORIZON        # reference formula int(H * repeat_times / B) = 40
@@ -203,7 +321,8 @@ def main():
     th.manual_seed(0)
     agent = AgentPPO(args.net_dims, STATE_DIM, ACTION_DIM, gpu_id=local_rank, args=args)
     parallel.broadcast_(agent._flat)
-    env = SynVecEnv(N_ENVS, STATE_DIM, ACTION_DIM, max_step=1000, gpu_id=local_rank, seed=7919 * rank)
+    env = (PendulumVecEnv(N_ENVS, max_step=max_step, gpu_id=local_rank, seed=7919 * rank) if pendulum else
+           SynVecEnv(N_ENVS, STATE_DIM, ACTION_DIM, max_step=max_step, gpu_id=local_rank, seed=7919 * rank))
     agent.last_state = env.reset()[0]
 
     from elegantrl_amd import _hip
@@ -238,26 +357,29 @@ def main():
     env_steps = world * N_ENVS * HORIZON * opt.steps
     flops = ppo_flops_per_sample(STATE_DIM, *NET_DIMS, ACTION_DIM) * BATCH
     ppo_s, n_k6 = (k6_seconds / k6_launches if k6_launches else float("nan")), k6_launches
+    # which K6 kernel erl_ppo_step_f32 dispatches to: the one-wave-per-SIMD form for 16-byte-aligned [128,128] shapes
+    k6_kernel = "ppo_step_w4_kernel" if (NET_DIMS == [128, 128] and STATE_DIM <= 64 and STATE_DIM % 4 == 0 and ACTION_DIM <= 8) \
+        else "ppo_step2_kernel"
     gae_s = t_gae.mean_seconds()
     line = {
-        "metric": "env_steps_per_sec_ppo_4096envs_obs64", "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
+        "metric": cfg["metric"], "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: AgentPPO, synthetic VecEnv obs_dim=64 act_dim=8, 4096 envs/GPU, "
-                               "horizon 32, 40 minibatches x 16384, net [128,128], fp32",
+        "config": {"workload": cfg["workload"], "name": opt.config,
                    "envs_per_gpu": N_ENVS, "horizon": HORIZON, "batch": BATCH, "update_times": UPDATE_TIMES,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
-        "roofline": {"kernel": "ppo_step_w4_kernel", "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
+        "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     "traffic": pmc_traffic("ppo_step_w4_kernel"), "flops_per_launch": flops,
+                     "traffic": pmc_traffic(k6_kernel) if opt.config == "c4" else None, "flops_per_launch": flops,
                      "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6},
-        "roofline_gae": {"kernel": "gae_exact_kernel (in-loop 32x4096)", "bound": "hbm",
+        "roofline_gae": {"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
+                         "bound": "hbm",
                          "achieved": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                          "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": round(gae_s * 1e6, 2)},
         "objectives_last": [round(float(x), 6) for x in objs],
     }
-    if not opt.no_gae_sweep:
+    if not opt.no_gae_sweep and opt.config == "c4":
         log("GAE size sweep")
         sweep = gae_sweep(ops, dev)
         line["roofline_gae"]["sweep"] = sweep
@@ -265,9 +387,9 @@ def main():
         line["roofline_gae"]["at_2048x4096"] = {"kernel": "gae_lookback_kernel (+ slot memset)", "achieved": big["GBps"],
                                                 "frac": big["frac"], "us": big["us"], "bytes_per_launch": big["bytes"],
                                                 "traffic": pmc_traffic("gae_lookback_kernel")}
-    if world == 1 and not opt.no_cpu_baseline:
+    if world == 1 and not opt.no_cpu_baseline and not pendulum:      # the torch port has the synthetic env only
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
-        line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters)
+        line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else max(2, opt.cpu_iters // 4), opt.config)
     log("done")
     print(json.dumps(line), flush=True)
 

@@ -291,7 +291,10 @@ void erl_gae_lookback_pick(int64_t H, int64_t N, int *L, int *W)
     int l, w;
     // measured on MI355X (tools/gae_sweep.py, profiles/gae_sweep_r01.json): slabs of 128 steps once H is large,
     // short slabs (more workgroups) for short horizons
-    if (H >= 4096) { l = 16; w = 8; }
+    // (L = 16, W = 8: 512 threads, 256 VGPRs, no scratch; the L = 8 instantiation is built for 1024 threads = 64 VGPRs and
+    // spills 24-32 bytes per lane -- equally fast at 2048 x 4096 (32.5 vs 33.1 us, profiles/r02_gae_tiling_ab.txt), so the large
+    // sizes avoid it; nontemporal output stores were measured there too: no change)
+    if (H >= 2048) { l = 16; w = 8; }
     else if (H >= 512) { l = 8; w = 16; }
     else if (H >= 64) { l = 4; w = 8; }
     else { l = 4; w = 2; }
