@@ -11,7 +11,7 @@ fwd/bwd, gradient reduce, [RCCL all-reduce when N > 1], clip + Adam).  Inputs ar
 one per GPU (weak scaling).  Rank 0 prints ONE JSON line.
 
 Besides the throughput the line carries
-  roofline      dominant kernel of the timed region (ppo_step2_kernel, fp32 MFMA bound), timed with HIP events
+  roofline      dominant kernel of the timed region (ppo_step_w4_kernel, fp32 MFMA bound), timed with HIP events
                 around every launch inside the timed region
   roofline_gae  the GAE scan (HBM bound; the metric's second half): in-loop launches + a size sweep run after
                 the timed region (the in-loop 32 x 4096 problem is 2.4 MB, i.e. launch-latency sized)
