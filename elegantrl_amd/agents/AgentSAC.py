@@ -131,6 +131,7 @@ class AgentSAC(AgentBase):
         self.target_entropy = math.log(action_dim)               # np.log(action_dim), as the reference (:31)
         self._step = 0
         self._objs = th.zeros(2, dtype=f32, device=dev)
+        self._td_error = None                      # per-sample td errors of a prioritised step (csrc/sac.hip critic_loss_kernel)
         self.save_attr_names = self.save_attr_names | {"alpha_log", "alpha_optim"}
 
     def _on_act_replaced(self):
@@ -174,7 +175,7 @@ class AgentSAC(AgentBase):
         self.rng_counter += 1
         return action
 
-    def _update_on_batch(self, batch, objs_out: TEN, noises=None):
+    def _update_on_batch(self, batch, objs_out: TEN, noises=None, is_weight=None, td_error_out=None):
         from .. import ops
         self._step += 1
         ops.sac_update(self._spec, self._actor_flat, self._critic_flat, self._target_flat, self.alpha_log,
@@ -182,7 +183,8 @@ class AgentSAC(AgentBase):
                         self.cri_optimizer.exp_avg_sq, self.alpha_optim.exp_avg, self.alpha_optim.exp_avg_sq),
                        batch, self._step, gamma=float(self.gamma), target_entropy=float(self.target_entropy),
                        tau=float(self.soft_update_tau), lr=float(self.learning_rate), max_norm=float(self.clip_grad_norm),
-                       objs_out=objs_out, noises=noises, seed=self.rng_seed + 1, counter=self._step)
+                       objs_out=objs_out, noises=noises, seed=self.rng_seed + 1, counter=self._step, is_weight=is_weight,
+                       td_error_out=td_error_out)
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self.alpha_optim.step_count = self._step
 
     @_hip.on_device
@@ -190,20 +192,29 @@ class AgentSAC(AgentBase):
                           noises: Optional[Tuple[TEN, TEN]] = None) -> Tuple[float, float]:
         """one SAC step (AgentSAC.py:42-86).  `ids` / `noises` = (eps for next_state, eps for state) inject the random draws."""
         assert isinstance(update_t, int)
-        if self.if_use_per:
-            raise NotImplementedError("prioritised replay is SURVEY.md 8f row f2")
         if self.lambda_fit_cum_r:
             raise NotImplementedError("lambda_fit_cum_r != 0 is not part of the HIP SAC step yet")
         self._sync_modules()
-        batch = buffer.sample(self.batch_size, ids=ids)                                   # HIP K9
-        self._update_on_batch(batch, self._objs, noises)
+        if self.if_use_per:                                                               # AgentSAC.py:45-47, :60-62
+            self._per_step(buffer, self._objs, noises)
+        else:
+            batch = buffer.sample(self.batch_size, ids=ids)                               # HIP K9
+            self._update_on_batch(batch, self._objs, noises)
         oc, oa = self._objs.cpu().tolist()
         return oc, oa
+
+    def _per_step(self, buffer, objs_out: TEN, noises=None):
+        """one step on a prioritised sample: importance weights into the critic objective, td errors back into the trees"""
+        *batch, is_weight, is_index = buffer.sample_for_per(self.batch_size)
+        if self._td_error is None or self._td_error.numel() != is_weight.numel():
+            self._td_error = th.empty_like(is_weight)
+        self._update_on_batch(batch, objs_out, noises, is_weight=is_weight, td_error_out=self._td_error)
+        buffer.td_error_update_for_per(is_index, self._td_error)
 
     @_hip.on_device
     def update_net(self, buffer) -> Tuple[float, float]:
         """AgentBase.update_net (:172-189) with ONE host sync: the per-step objectives stay on the device until the end."""
-        if self.if_use_per or self.lambda_fit_cum_r:
+        if self.lambda_fit_cum_r:
             return super().update_net(buffer)
         self._sync_modules()
         update_times = int(buffer.cur_size * self.repeat_times / self.batch_size)
@@ -211,6 +222,9 @@ class AgentSAC(AgentBase):
             return 0.0, 0.0
         objs = th.zeros((update_times, 2), dtype=th.float32, device=self.device)
         for t in range(update_times):
-            self._update_on_batch(buffer.sample(self.batch_size, reuse=True), objs[t])   # the batch is consumed before the next draw
+            if self.if_use_per:
+                self._per_step(buffer, objs[t])
+            else:
+                self._update_on_batch(buffer.sample(self.batch_size, reuse=True), objs[t])   # the batch is consumed before the next draw
         o = objs.cpu().numpy()
         return float(np.nanmean(o[:, 0])), float(np.nanmean(o[:, 1]))

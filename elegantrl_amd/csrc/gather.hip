@@ -218,7 +218,9 @@ int replay_sample_impl(const char *what, bool act_u8, const float *buf_states, c
 {
     ERL_REQUIRE(buf_states && buf_actions && buf_rewards && buf_undones && buf_unmasks && ids, "%s: NULL tensor", what);
     ERL_REQUIRE(out_state && out_action && out_reward && out_undone && out_unmask && out_next_state, "%s: NULL output", what);
-    ERL_REQUIRE(num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0 && sample_len >= 1 && sample_len < max_size,
+    // sample_len = cur_size - 1 for the uniform sampler; the prioritised sampler passes cur_size (<= max_size) and guarantees
+    // ids0 <= cur_size - 2 itself, so that row ids0 + 1 exists either way
+    ERL_REQUIRE(num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0 && sample_len >= 1 && sample_len <= max_size,
                 "%s: bad shape (sample_len=%lld max_size=%lld)", what, (long long)sample_len, (long long)max_size);
     if (B == 0) return ERL_OK;
     const int g = grid_for(erl_cdiv(B, RS_SAMPLES) * 256);

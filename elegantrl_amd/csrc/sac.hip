@@ -95,23 +95,27 @@ __global__ __launch_bounds__(256) void q_label_kernel(const float *__restrict__ 
     label[b] = reward[b] + (undone[b] * gamma) * (m - next_lp[b] * alpha);
 }
 
-// critic objective: td = mean_e (q - label)^2 * unmask; obj = mean_b td; dq[e][b] = 2 (q - label) unmask / (E B)
+// critic objective: td = mean_e (q - label)^2 * unmask; obj = mean_b (td w); dq[e][b] = 2 (q - label) unmask w / (E B), with the
+// importance-sampling weights w of prioritised replay (AgentSAC.py:60-62; w = 1 without) and td written out for the priorities
 __global__ __launch_bounds__(256) void critic_loss_kernel(const float *__restrict__ q, const float *__restrict__ label,
-                                                          const float *__restrict__ unmask, int E, int64_t B, float *__restrict__ dq,
+                                                          const float *__restrict__ unmask, const float *__restrict__ is_weight,
+                                                          int E, int64_t B, float *__restrict__ dq, float *__restrict__ td_out,
                                                           float *__restrict__ part)
 {
     __shared__ float red[4];
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float td = 0.f;
     if (b < B) {
-        const float l = label[b], um = unmask[b];
+        const float l = label[b], um = unmask[b], w = is_weight ? is_weight[b] : 1.f;
         float s = 0.f;
         for (int e = 0; e < E; ++e) {
             const float diff = q[(size_t)e * B + b] - l;
             s += diff * diff;
-            dq[(size_t)e * B + b] = 2.f * diff * um / ((float)E * (float)B);
+            dq[(size_t)e * B + b] = 2.f * diff * um * w / ((float)E * (float)B);
         }
         td = (s / (float)E) * um;
+        if (td_out) td_out[b] = td;
+        td *= w;
     }
     const float t = block_sum(td, red);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
@@ -252,7 +256,8 @@ extern "C" int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int 
 extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
                                   float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
                                   const int *hidden, int n_hidden, int E, const float *state, const float *action,
-                                  const float *reward, const float *undone, const float *unmask, const float *next_state, int64_t B,
+                                  const float *reward, const float *undone, const float *unmask, const float *next_state,
+                                  const float *is_weight, float *td_error_out, int64_t B,
                                   const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
                                   float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
                                   int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, void *stream)
@@ -302,7 +307,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     // ---- (2) critic objective, backward, clip + Adam, soft target update                          (:57-70)
     hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, state, action, S, A, B, xa);
     if ((rc = critic_forward(s, d, critic_params, B, xa, cw, true))) return rc;
-    hipLaunchKernelGGL(critic_loss_kernel, rows_grid, blk, 0, s, cw.q, label, unmask, E, B, dq, part);
+    hipLaunchKernelGGL(critic_loss_kernel, rows_grid, blk, 0, s, cw.q, label, unmask, is_weight, E, B, dq, td_error_out, part);
     hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, part, (int64_t)nparts, 1.0f / (float)B, 0.f, objs_out);
     for (int e = 0; e < E; ++e) {
         float *Gdec = g_critic + d.enc.count + (int64_t)e * d.dec.count;

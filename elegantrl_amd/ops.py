@@ -191,6 +191,42 @@ def replay_sample(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undon
 
 
 # ------------------------------------------------------------------------------------------------
+# prioritised replay (row f2): device-resident sum / min trees, csrc/per.hip
+# ------------------------------------------------------------------------------------------------
+class PerTrees:
+    """one sum tree + one min tree per sequence as implicit heaps (num_seqs, 2 L) on the device."""
+
+    def __init__(self, max_size: int, num_seqs: int, device):
+        n = lib().erl_per_tree_floats(max_size, num_seqs)
+        if n <= 0:
+            raise HipExtensionError(f"erl_per_tree_floats({max_size}, {num_seqs}) failed")
+        self.max_size, self.num_seqs = int(max_size), int(num_seqs)
+        self.sum = th.empty(n, dtype=th.float32, device=device)
+        self.min = th.empty(n, dtype=th.float32, device=device)
+        check(lib().erl_per_init_f32(ptr(self.sum), ptr(self.min), self.max_size, self.num_seqs, stream_ptr()), "erl_per_init_f32")
+        self.leaves = n // (2 * self.num_seqs)
+
+    def add_rows(self, start: int, add: int, prob: float = 10.0) -> None:
+        check(lib().erl_per_add_rows_f32(ptr(self.sum), ptr(self.min), self.max_size, self.num_seqs, int(start), int(add), float(prob),
+                                         stream_ptr()), "erl_per_add_rows_f32")
+
+    def update(self, ids0: TEN, ids1: TEN, td_error: TEN, per_alpha: float) -> None:
+        check(lib().erl_per_update_f32(ptr(self.sum), ptr(self.min), self.max_size, self.num_seqs, ptr(ids0, th.int64),
+                                       ptr(ids1, th.int64), ptr(td_error, th.float32), ids0.numel(), float(per_alpha), stream_ptr()),
+              "erl_per_update_f32")
+
+    def sample(self, uniform: TEN, cur_size: int, per_beta: float):
+        """uniform (num_seqs, n) in [0, 1) -> (is_indices (num_seqs * n,) int64 = ids1 * cur_size + ids0, is_weights float32)"""
+        assert uniform.shape[0] == self.num_seqs and uniform.dtype == th.float32
+        n = uniform.shape[1]
+        idx = th.empty(self.num_seqs * n, dtype=th.int64, device=uniform.device)
+        w = th.empty(self.num_seqs * n, dtype=th.float32, device=uniform.device)
+        check(lib().erl_per_sample_f32(ptr(self.sum), ptr(self.min), self.max_size, self.num_seqs, ptr(uniform.contiguous(), th.float32),
+                                       n, int(cur_size), float(per_beta), ptr(idx), ptr(w), stream_ptr()), "erl_per_sample_f32")
+        return idx, w
+
+
+# ------------------------------------------------------------------------------------------------
 # MLP kernels (K1, K2, K6, K7)
 # ------------------------------------------------------------------------------------------------
 @dataclass
@@ -478,7 +514,8 @@ class SacSpec:
 
 def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: TEN, moments: Sequence[TEN], batch: Sequence[TEN],
                step: int, *, gamma: float, target_entropy: float, tau: float, lr: float, max_norm: float, objs_out: TEN,
-               noises: Optional[Tuple[TEN, TEN]] = None, seed: int = 0, counter: int = 0, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+               noises: Optional[Tuple[TEN, TEN]] = None, seed: int = 0, counter: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
+               is_weight: Optional[TEN] = None, td_error_out: Optional[TEN] = None) -> None:
     """one AgentSAC.update_objectives step after the sample; `moments` = (actor_m, actor_v, critic_m, critic_v, alpha_m,
     alpha_v); `batch` = (state, action, reward, undone, unmask, next_state); objs_out: float32[2] on the device."""
     state, action, reward, undone, unmask, next_state = batch
@@ -488,7 +525,8 @@ def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: T
     f32 = th.float32
     check(lib().erl_sac_update_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
                                    spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ptr(state, f32), ptr(action, f32),
-                                   ptr(reward, f32), ptr(undone, f32), ptr(unmask, f32), ptr(next_state, f32), B, ptr(n_next),
+                                   ptr(reward, f32), ptr(undone, f32), ptr(unmask, f32), ptr(next_state, f32), ptr(is_weight), ptr(td_error_out),
+                                   B, ptr(n_next),
                                    ptr(n_cur), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), gamma, target_entropy, tau, lr, betas[0],
                                    betas[1], eps, max_norm, step, ptr(objs_out, f32), ptr(ws), ws.numel(), stream_ptr()),
           "erl_sac_update_f32")

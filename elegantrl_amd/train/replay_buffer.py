@@ -4,8 +4,8 @@ Same constructor, attributes and cursor behaviour as elegantrl/train/replay_buff
 cursor arithmetic (p, cur_size, if_full, add_size) is host-side integer code and reproduces the
 reference bit for bit (including landing exactly on max_size, Appendix A12 of SURVEY.md).  The tensor
 traffic goes through erl_replay_write_f32 / erl_replay_sample_f32 (uint8 action rings of discrete agents:
-erl_replay_*_discrete_f32).  Prioritised replay (SumTree) is a "next" row of SURVEY.md section 8f and raises
-NotImplementedError.
+erl_replay_*_discrete_f32).  Prioritised replay (`if_use_per=True`) keeps its per-sequence
+sum / min trees on the device (csrc/per.hip, erl_per_*).
 """
 from __future__ import annotations
 
@@ -23,8 +23,6 @@ TEN = th.Tensor
 class ReplayBuffer:
     def __init__(self, max_size: int, state_dim: int, action_dim: int, gpu_id: int = 0, num_seqs: int = 1,
                  if_use_per: bool = False, if_discrete: bool = False, args: Optional[Config] = None):
-        if if_use_per:
-            raise NotImplementedError("prioritised replay (per-sequence SumTree) is not part of the HIP hot path yet")
         assert (action_dim < 256) or (not if_discrete)       # replay_buffer.py:50: a discrete action must fit a byte
         self.p = 0                 # write cursor (time row)
         self.if_full = False
@@ -45,10 +43,15 @@ class ReplayBuffer:
         self.cum_rewards = th.empty_like(self.rewards)
         self.ids0 = th.tensor((), dtype=th.long, device=self.device)
         self.ids1 = th.tensor((), dtype=th.long, device=self.device)
-        self.if_use_per = False
+        # prioritised replay (replay_buffer.py:64-76): the reference keeps one CPU SumTree per sequence; here the trees of all
+        # sequences live on the device (csrc/per.hip) behind `self.sum_trees` (an ops.PerTrees, not a list)
+        self.if_use_per = bool(if_use_per)
         self.sum_trees = None
-        self.per_alpha = None
-        self.per_beta = None
+        self.per_alpha = getattr(args, "per_alpha", 0.6) if if_use_per else None     # alpha = (Uniform:0, Greedy:1)
+        self.per_beta = getattr(args, "per_beta", 0.4) if if_use_per else None
+        if if_use_per:
+            from .. import ops
+            self.sum_trees = ops.PerTrees(self.max_size, self.num_seqs, self.device)
 
     # ---- cursor arithmetic: replay_buffer.py:84-118 -------------------------------------------
     def _advance(self, add_size: int) -> int:
@@ -72,6 +75,8 @@ class ReplayBuffer:
         ops.replay_write(self.states, self.actions, self.rewards, self.undones, self.unmasks,
                          (states.contiguous(), actions.contiguous(), rewards.contiguous(), undones.contiguous(),
                           unmasks.contiguous()), start)
+        if self.if_use_per:                          # new rows enter with the maximum priority (replay_buffer.py:107-115)
+            self.sum_trees.add_rows(start, self.add_size, 10.0)
 
     @_hip.on_device
     def sample(self, batch_size: int, ids: Optional[TEN] = None, reuse: bool = False) -> Tuple[TEN, TEN, TEN, TEN, TEN, TEN]:
@@ -95,11 +100,32 @@ class ReplayBuffer:
                                                         ids, sample_len, stage=stage)
         return out
 
-    def sample_for_per(self, batch_size: int):
-        raise NotImplementedError("prioritised replay is not part of the HIP hot path yet")
+    @_hip.on_device
+    def sample_for_per(self, batch_size: int, uniform: Optional[TEN] = None):
+        """Prioritised sample (replay_buffer.py:136-165): (state, action, reward, undone, unmask, next_state, is_weights,
+        is_indices); `batch_size // num_seqs` stratified proportional draws per sequence.  The reference's SumTree does not run
+        (DESIGN.md section 8); this follows the corrected restatement oracle/per_numpy.py (its header lists the deviations:
+        full-depth trees, per-sequence batch share, is_indices = ids1 * cur_size + ids0, no draw on the last filled row).
+        `uniform` (num_seqs, batch_size // num_seqs) in [0, 1) injects the random numbers (tests)."""
+        from .. import ops
+        assert self.if_use_per, "ReplayBuffer was built with if_use_per=False"
+        assert batch_size % self.num_seqs == 0                                        # replay_buffer.py:144
+        assert self.cur_size >= 2
+        sub = batch_size // self.num_seqs
+        if uniform is None:
+            uniform = th.rand((self.num_seqs, sub), dtype=th.float32, device=self.device)
+        is_indices, is_weights = self.sum_trees.sample(uniform, self.cur_size, self.per_beta)
+        out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
+                                                        is_indices, self.cur_size)     # ids0 = fmod, ids1 = div (:155-156)
+        return (*out, is_weights, is_indices)
 
+    @_hip.on_device
     def td_error_update_for_per(self, is_indices: TEN, td_error: TEN):
-        raise NotImplementedError("prioritised replay is not part of the HIP hot path yet")
+        """priorities <- clamp(td_error, 1e-8, 10)^per_alpha for the sampled transitions (replay_buffer.py:167-179)."""
+        assert self.if_use_per, "ReplayBuffer was built with if_use_per=False"
+        ids0 = th.fmod(is_indices, self.cur_size)
+        ids1 = th.div(is_indices, self.cur_size, rounding_mode="floor")
+        self.sum_trees.update(ids0, ids1, td_error.detach().to(th.float32).reshape(-1).contiguous(), self.per_alpha)
 
     # ---- persistence: replay_buffer.py:181-211 (same file names and unrolled order) --------------
     def save_or_load_history(self, cwd: str, if_save: bool):

@@ -154,6 +154,29 @@ ERL_API int erl_replay_sample_discrete_f32(const float *buf_states, const uint8_
                                    void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Prioritised experience replay: the per-sequence SumTree of replay_buffer.py:226-299 as device-resident
+ * implicit heaps, one sum tree and one min tree per sequence: (num_seqs, 2 L) fp32, L = next power of two >= max_size, node 1 =
+ * root, leaf of time row r at L + r (erl_per_tree_floats floats each).  Parents are recomputed as left + right level by level
+ * (deterministic).  The reference's SumTree does not run (its loops stop two levels short and its own assert fires); these entry
+ * points implement the corrected restatement oracle/per_numpy.py, whose header lists the deviations.
+ *   erl_per_add_rows_f32   ReplayBuffer.update's PER part (:107-115): rows [start, start + add) mod max_size of every sequence <- prob
+ *   erl_per_update_f32     td_error_update_for_per (:167-179): leaf (ids1, ids0) <- clamp(td_error, 1e-8, 10)^per_alpha
+ *   erl_per_sample_f32     sample_for_per / important_sampling (:136-151, :285-298): n_per_seq stratified draws per sequence from
+ *                          uniform (num_seqs, n_per_seq) in [0,1); out_index = ids1 * cur_size + ids0 (decodes by the reference's
+ *                          fmod / div), out_weight = (priority / min priority)^(-per_beta); a draw on row cur_size - 1 moves to
+ *                          cur_size - 2 (it has no successor row)
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int64_t erl_per_tree_floats(int64_t max_size, int64_t num_seqs);
+ERL_API int erl_per_init_f32(float *sum_tree, float *min_tree, int64_t max_size, int64_t num_seqs, void *stream);
+ERL_API int erl_per_add_rows_f32(float *sum_tree, float *min_tree, int64_t max_size, int64_t num_seqs, int64_t start, int64_t add,
+                         float prob, void *stream);
+ERL_API int erl_per_update_f32(float *sum_tree, float *min_tree, int64_t max_size, int64_t num_seqs, const int64_t *ids0,
+                       const int64_t *ids1, const float *td_error, int64_t n, float per_alpha, void *stream);
+ERL_API int erl_per_sample_f32(const float *sum_tree, const float *min_tree, int64_t max_size, int64_t num_seqs,
+                       const float *uniform, int64_t n_per_seq, int64_t cur_size, float per_beta, int64_t *out_index,
+                       float *out_weight, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * MLP parameter block used by K1/K2/K6/K7: one flat fp32 buffer per network, laid out as
  *   W1[h1][S] b1[h1] W2[h2][h1] b2[h2] W3[out][h2] b3[out] (+ action_std_log[A] for the actor)
  * i.e. nn.Linear.weight/.bias of build_mlp([S, h1, h2, out]) (elegantrl/agents/AgentBase.py:345-360)
@@ -336,7 +359,8 @@ ERL_API int erl_mlpn_ppo_step_discrete_f32(const float *actor_params, const floa
  * three clip + Adam steps (AgentBase.py:239-248).  hidden = net_dims (n_hidden <= ERL_MAX_LAYERS), E = num_ensembles.
  * Parameter blocks: actor = build_mlp([S, *hidden]) (GELU after every layer) + Linear(hidden[-1], 2A);
  * critic/target = Linear(S + A, hidden[0]) | E x build_mlp([*hidden, 1]).  The batch tensors are what
- * erl_replay_sample_f32 returned (B rows).  eps_next / eps_cur (B, A) inject the two rsample() draws (tests); NULL ->
+ * erl_replay_sample_f32 returned (B rows); is_weight (B) / td_error_out (B), both optional, are prioritised replay's importance
+ * weights in and per-sample td errors out (AgentSAC.py:58-62).  eps_next / eps_cur (B, A) inject the two rsample() draws (tests); NULL ->
  * Philox keyed by (seed, counter).  objs_out: device float[2] = (obj_critic, obj_actor).  step = 1-based Adam step.
  * erl_sac_explore_action_f32 = ActorSAC.get_action (:179-185) for the off-policy rollout.
  * ------------------------------------------------------------------------------------------- */
@@ -347,7 +371,7 @@ ERL_API int erl_sac_update_f32(float *actor_params, float *critic_params, float 
                        float *actor_m, float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v,
                        int S, int A, const int *hidden, int n_hidden, int E, const float *state, const float *action,
                        const float *reward, const float *undone, const float *unmask, const float *next_state,
-                       int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
+                       const float *is_weight, float *td_error_out, int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
                        float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam,
                        float max_norm, int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes,
                        void *stream);

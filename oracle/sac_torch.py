@@ -110,7 +110,9 @@ class SacStepper:
         th.nn.utils.clip_grad_norm_(parameters=opt.param_groups[0]["params"], max_norm=self.max_norm)
         opt.step()
 
-    def step(self, batch, eps_next: TEN, eps_cur: TEN) -> Tuple[float, float]:
+    def step(self, batch, eps_next: TEN, eps_cur: TEN, is_weight: Optional[TEN] = None) -> Tuple[float, float]:
+        """`is_weight`: prioritised replay's importance weights (AgentSAC.py:60-62); the per-sample td errors of the step are
+        left in `self.td_error`."""
         state, action, reward, undone, unmask, next_state = batch
         with th.no_grad():
             next_action, next_logprob = self.act.get_action_logprob(next_state, eps_next)
@@ -118,7 +120,8 @@ class SacStepper:
             q_label = reward + undone * self.gamma * (next_q - next_logprob * self.alpha_log.exp())
         q_values = self.cri.get_q_values(state, action)
         td = ((q_values - q_label.view(-1, 1)) ** 2).mean(dim=1) * unmask
-        obj_critic = td.mean()
+        self.td_error = td.detach().clone()
+        obj_critic = td.mean() if is_weight is None else (td * is_weight).mean()
         self._opt(self.cri_opt, obj_critic)
         with th.no_grad():
             for tar, cur in zip(self.cri_target.parameters(), self.cri.parameters()):

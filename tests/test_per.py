@@ -1,0 +1,120 @@
+"""Row f2: prioritised replay.  The reference's SumTree does not run (its own assert fires), so the target is the corrected
+restatement oracle/per_numpy.py: its properties are checked on the CPU, the device trees (csrc/per.hip) against it bit for bit."""
+import numpy as np
+import pytest
+import torch as th
+
+from oracle.per_numpy import PerTrees
+
+
+def test_reference_sumtree_asserts_which_is_why_parity_is_unpinned():
+    """documents the claim in oracle/per_numpy.py: run the reference's SumTree when it is mounted (authoring container only)."""
+    import os
+    import sys
+    ref = os.environ.get("ERL_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        pytest.skip("reference not mounted")
+    sys.path.insert(0, ref)
+    try:
+        from elegantrl.train.replay_buffer import SumTree
+    finally:
+        sys.path.remove(ref)
+    for buf_len in (8, 1000, 1024):
+        tree = SumTree(buf_len=buf_len)
+        tree.update_ids(th.arange(buf_len), prob=th.rand(buf_len) + 0.1)
+        with pytest.raises(AssertionError):
+            tree.important_sampling(batch_size=16, beg=-buf_len, end=-1, per_beta=0.4)
+
+
+def test_oracle_trees_are_consistent_and_sampling_is_proportional():
+    rng = np.random.default_rng(0)
+    max_size, Q = 37, 3
+    t = PerTrees(max_size, Q)
+    t.add_rows(0, 30)
+    t.td_error_update(rng.integers(0, 30, 40), rng.integers(0, Q, 40), rng.random(40).astype(np.float32) * 12)
+    L = t.L
+    for q in range(Q):                          # every parent is the sum / min of its children; unwritten leaves 0 / inf
+        for node in range(1, L):
+            assert t.sum[q, node] == np.float32(t.sum[q, 2 * node] + t.sum[q, 2 * node + 1])
+            assert t.min[q, node] == min(t.min[q, 2 * node], t.min[q, 2 * node + 1])
+        assert (t.sum[q, L + 30:] == 0).all() and np.isinf(t.min[q, L + 30:]).all()
+    # proportional draws: row frequencies follow the priorities (the last filled row's share moves to its neighbour, D4)
+    n = 20000
+    ids0, ids1, w = t.sample(rng.random((Q, n)).astype(np.float32), cur_size=30)
+    assert ids0.min() >= 0 and ids0.max() <= 28 and (ids1 == np.repeat(np.arange(Q), n)).all()
+    for q in range(Q):
+        pri = t.sum[q, L:L + 30].astype(np.float64)
+        expect = pri.copy()
+        expect[28] += expect[29]
+        expect = expect[:29] / pri.sum()
+        freq = np.bincount(ids0[q * n:(q + 1) * n], minlength=29) / n
+        assert np.abs(freq - expect).max() < 0.01
+    np.testing.assert_allclose(w, (t.sum[ids1, L + ids0] / t.min[ids1, 1]) ** -0.4, rtol=1e-6)
+    assert w.max() <= 1.0 + 1e-6                # the least likely transition has weight 1, all others less
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_size,Q", [(37, 3), (1000, 1), (4096, 8)])
+def test_device_trees_match_the_oracle_bitwise(max_size, Q):
+    from elegantrl_amd import ops
+    dev = th.device("cuda:0")
+    rng = np.random.default_rng(max_size)
+    ref, t = PerTrees(max_size, Q), ops.PerTrees(max_size, Q, dev)
+    cur, p = 0, 0
+    for add in (max_size // 3, max_size // 2, max_size // 4 + 1, 5):       # wraps; the second one takes the bulk (per-level) path
+        ref.add_rows(p, add)
+        t.add_rows(p, add)
+        p = (p + add) % max_size
+        cur = min(max_size, cur + add)
+        n = min(64, cur * Q)
+        flat = rng.choice(cur * Q, size=n, replace=False)                  # distinct transitions (duplicates race, as in torch)
+        ids0, ids1 = flat % cur, flat // cur
+        td = (rng.random(n) * 12).astype(np.float32)
+        ref.td_error_update(ids0, ids1, td)
+        t.update(th.from_numpy(ids0).to(dev), th.from_numpy(ids1).to(dev), th.from_numpy(td).to(dev), 0.6)
+        got_sum, got_min = t.sum.view(Q, -1).cpu().numpy(), t.min.view(Q, -1).cpu().numpy()
+        np.testing.assert_allclose(got_sum[:, ref.L:], ref.sum[:, ref.L:], rtol=2e-7)        # powf: one ulp
+        leaves_equal = np.array_equal(got_sum[:, ref.L:], ref.sum[:, ref.L:])
+        if not leaves_equal:                     # continue from the device's leaves so that the tree arithmetic is compared exactly
+            ref.sum[:, ref.L:], ref.min[:, ref.L:] = got_sum[:, ref.L:], got_min[:, ref.L:]
+            for node in range(ref.L - 1, 0, -1):
+                ref.sum[:, node] = ref.sum[:, 2 * node] + ref.sum[:, 2 * node + 1]
+                ref.min[:, node] = np.minimum(ref.min[:, 2 * node], ref.min[:, 2 * node + 1])
+        np.testing.assert_array_equal(got_sum[:, 1:], ref.sum[:, 1:])
+        np.testing.assert_array_equal(got_min[:, 1:], ref.min[:, 1:])
+        u = rng.random((Q, 48)).astype(np.float32)
+        idx, w = t.sample(th.from_numpy(u).to(dev), cur, 0.4)
+        r0, r1, rw = ref.sample(u, cur)
+        np.testing.assert_array_equal(idx.cpu().numpy(), r1 * cur + r0)
+        np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=2e-6)
+
+
+@pytest.mark.gpu
+def test_replay_buffer_per_end_to_end():
+    from elegantrl_amd.train import Config, ReplayBuffer
+    dev = th.device("cuda:0")
+    args = Config()
+    args.per_alpha, args.per_beta = 0.6, 0.4
+    max_size, S, A, Q = 50, 5, 2, 4
+    buf = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=Q, if_use_per=True, args=args)
+    g = th.Generator(device=dev).manual_seed(0)
+    for add in (20, 20, 20):                                                              # wraps once
+        buf.update((th.randn((add, Q, S), device=dev, generator=g), th.randn((add, Q, A), device=dev, generator=g),
+                    th.randn((add, Q), device=dev, generator=g), th.rand((add, Q), device=dev, generator=g) < 0.9,
+                    th.rand((add, Q), device=dev, generator=g) < 0.9))
+    assert buf.if_full and buf.cur_size == max_size
+    out = buf.sample_for_per(32)
+    assert len(out) == 8
+    state, action, reward, undone, unmask, next_state, w, idx = out
+    ids0, ids1 = th.fmod(idx, buf.cur_size), th.div(idx, buf.cur_size, rounding_mode="floor")
+    assert th.equal(ids0, buf.ids0) and th.equal(ids1, buf.ids1) and int(ids0.max()) <= max_size - 2
+    assert th.equal(ids1, th.arange(Q, device=dev).repeat_interleave(8))                   # sequence-major, batch_size // num_seqs each
+    assert th.equal(state, buf.states[ids0, ids1]) and th.equal(next_state, buf.states[ids0 + 1, ids1])
+    assert th.equal(action, buf.actions[ids0, ids1]) and th.equal(reward, buf.rewards[ids0, ids1])
+    assert th.allclose(w, th.ones_like(w))                                                 # all priorities equal (10) so far
+    buf.td_error_update_for_per(idx, th.full((32,), 1e-3, device=dev))                     # sampled transitions become unlikely
+    again = th.fmod(buf.sample_for_per(32)[7], buf.cur_size)
+    leaf = buf.sum_trees.sum.view(Q, -1)[ids1, buf.sum_trees.leaves + ids0]
+    np.testing.assert_allclose(leaf.cpu().numpy(), np.float32(1e-3) ** np.float32(0.6), rtol=1e-6)
+    w2 = buf.sample_for_per(32)[6]
+    assert float(w2.min()) < 1.0 and again.shape == (32,)

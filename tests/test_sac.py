@@ -222,3 +222,67 @@ def test_sac_update_matches_torch_restatement_on_other_shapes(S, A, hidden, E, B
             assert (diff <= 5e-5).mean() >= 0.995, f"{(diff > 5e-5).mean():.4%} of the block is off"
             assert diff.max() <= 2.2 * step * 1e-3
         np.testing.assert_allclose(alpha.cpu().numpy(), st.alpha_log.detach().numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_sac_update_with_importance_weights_and_td_errors():
+    """prioritised replay through the SAC step (AgentSAC.py:58-62): obj_critic = mean(td_error * is_weight), td_error comes back
+    per sample; against oracle/sac_torch.py with the same weights."""
+    from elegantrl_amd import ops
+    from oracle.sac_torch import SacStepper
+    dev = th.device("cuda:0")
+    th.set_grad_enabled(True)
+    th.manual_seed(77)
+    S, A, hidden, E, B = 11, 3, (64, 32), 4, 96
+    st = SacStepper(list(hidden), S, A, E, lr=1e-3, gamma=0.97, tau=5e-3, max_norm=3.0)
+    spec = ops.SacSpec(S, A, hidden, E)
+
+    def flat(module, slices):
+        sd = dict(module.named_parameters())
+        return th.cat([sd[name].detach().reshape(-1) for name, _, _ in slices]).to(dev).contiguous()
+
+    pa, pc, pt = flat(st.act, spec.actor_slices()), flat(st.cri, spec.critic_slices()), flat(st.cri_target, spec.critic_slices())
+    alpha = st.alpha_log.detach().clone().to(dev)
+    mom = [th.zeros_like(pa), th.zeros_like(pa), th.zeros_like(pc), th.zeros_like(pc), th.zeros(1, device=dev), th.zeros(1, device=dev)]
+    objs, td = th.zeros(2, device=dev), th.zeros(B, device=dev)
+    for step in range(1, 3):
+        batch = (th.randn(B, S), th.randn(B, A).tanh(), th.randn(B), (th.rand(B) > 0.1).float(), (th.rand(B) > 0.1).float(),
+                 th.randn(B, S))
+        w = th.rand(B) * 0.9 + 0.1
+        e_next, e_cur = th.randn(B, A), th.randn(B, A)
+        ref = st.step(batch, e_next, e_cur, is_weight=w)
+        ops.sac_update(spec, pa, pc, pt, alpha, mom, [x.to(dev).contiguous() for x in batch], step, gamma=0.97,
+                       target_entropy=st.target_entropy, tau=5e-3, lr=1e-3, max_norm=3.0, objs_out=objs,
+                       noises=(e_next.to(dev), e_cur.to(dev)), is_weight=w.to(dev), td_error_out=td)
+        np.testing.assert_allclose(objs.cpu().numpy(), ref, rtol=3e-4, atol=3e-6)
+        np.testing.assert_allclose(td.cpu().numpy(), st.td_error.numpy(), rtol=3e-4, atol=1e-6)
+        diff = np.abs(pc.cpu().numpy() - flat(st.cri, spec.critic_slices()).cpu().numpy())
+        assert (diff <= 5e-5).mean() >= 0.995 and diff.max() <= 2.2 * step * 1e-3
+
+
+@pytest.mark.gpu
+def test_agent_sac_with_prioritised_replay_runs_and_updates_priorities():
+    """AgentSAC(if_use_per=True) + ReplayBuffer(if_use_per=True): update_net draws prioritised batches and writes the td errors
+    back -- the sampled leaves leave the initial priority 10."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config, ReplayBuffer
+    dev = th.device("cuda:0")
+    N, S, A, H = 8, 11, 3, 16
+    args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
+                                        "if_discrete": False})
+    args.net_dims, args.horizon_len, args.batch_size, args.if_use_per = [64, 32], H, 64, True
+    args.repeat_times = 4 * 64 / 64.0
+    agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=1)
+    agent.last_state = env.reset()[0]
+    buf = ReplayBuffer(max_size=64, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N, if_use_per=True, args=args)
+    buf.update(agent.explore_env(env, H))
+    buf.update(agent.explore_env(env, H))
+    leaves0 = buf.sum_trees.sum.view(N, -1)[:, buf.sum_trees.leaves:buf.sum_trees.leaves + buf.cur_size].clone()
+    assert th.all(leaves0 == 10.0)
+    objs = agent.update_net(buf)
+    assert all(np.isfinite(o) for o in objs)
+    leaves1 = buf.sum_trees.sum.view(N, -1)[:, buf.sum_trees.leaves:buf.sum_trees.leaves + buf.cur_size]
+    changed = (leaves1 != 10.0)
+    assert int(changed.sum()) > 20 and float(leaves1.max()) <= 10.0 and float(leaves1.min()) > 0.0
