@@ -70,6 +70,8 @@ _SIGNATURES = {
     "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),
     "erl_clip_adam_f32": (c_int, [_P, _P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, _P, c_int32, c_float,
                                   c_float, c_float, c_float, c_float, c_float, _P]),
+    "erl_reduce_clip_adam_f32": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
+                                         c_float, c_float, c_float, c_float, c_float, _P]),
     "erl_ppo_update_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
                                    _P, c_int64, c_int, c_float, c_float, c_int, _P, _P, c_int32, c_float, c_float, c_float, c_float,
                                    c_float, _P]),

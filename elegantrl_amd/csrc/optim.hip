@@ -80,7 +80,175 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ par
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Slab reduction + clip + Adam in ONE launch (single-process path: nothing sits between the reduction and the optimiser).
+// grid = ceil(stride / 256) workgroups of 1024 threads: element e of the flat gradient is summed by 4 threads in exactly
+// grad_reduce_kernel's association (bit-identical gradient), written out, and its square goes into the workgroup's
+// per-group partial sum (fp64).  Workgroups then ARRIVE on a monotonic device counter; the one that arrives last -- no
+// workgroup ever waits, so no co-residency is assumed and nothing can deadlock -- reads every partial in a fixed order,
+// derives the clip coefficients and applies Adam to all parameters (50k elements: 25 per thread and trip, two trips).
+// Visibility across CUs / XCDs (cdna_hip_programming.md Guideline 16, form R1): gradient and partials are stored
+// write-through (agent-scope relaxed atomic stores = sc1), every storing wave drains its stores before the workgroup's one
+// arrival, and the last workgroup makes ONE agent-scope acquire before it reads them back with plain loads.
+// MEASURED SLOWER than the two launches it replaces (34.9 vs 18.2 us at config 4, tools/tail_bench.py): the last workgroup's
+// Adam phase is one CU moving 1.4 MB (~75 GB/s per CU = ~19 us), which outweighs the saved launch; spreading that phase needs
+// every workgroup to WAIT for the norm (a grid barrier, i.e. co-residency assumptions).  Kept as an opt-in entry point
+// (ERL_FUSED_TAIL=1 in the update loop) and as the record of why the tail stays two launches.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RA_T = 1024, RA_E = 256;      // threads, elements per workgroup
+
+__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__restrict__ slabs, int n_slabs, int64_t stride,
+                                                                float *flat, float *__restrict__ params, float *__restrict__ m1,
+                                                                float *__restrict__ m2, AdamGroups gr, int n_groups, float lr,
+                                                                float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                                                                float step_size, float bc2_sqrt, double *partials,
+                                                                unsigned *counter, unsigned target)
+{
+    __shared__ float part[4][RA_E];
+    __shared__ double scratch[16];
+    __shared__ int s_last;
+    const int el = threadIdx.x & (RA_E - 1), p = threadIdx.x / RA_E;
+    const int64_t i = (int64_t)blockIdx.x * RA_E + el;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < stride) {                                  // (the loop nest of grad_reduce_kernel, mlp.hip: same association)
+        const float *src = slabs + i;
+        int k = p;
+        for (; k + 124 < n_slabs; k += 128) {
+            float x[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) x[u] = src[(size_t)(k + 4 * u) * stride];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += x[8 * v + u];
+        }
+        for (; k + 28 < n_slabs; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += src[(size_t)(k + 4 * u) * stride];
+        }
+        for (; k < n_slabs; k += 4) s[0] += src[(size_t)k * stride];
+    }
+    part[p][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    float gsum = 0.f;
+    if (p == 0 && i < stride) {
+        gsum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+        st_agent(flat + i, gsum);
+    }
+    for (int gi = 0; gi < n_groups; ++gi) {            // this workgroup's share of each group's squared norm
+        const bool in = p == 0 && i >= gr.off[gi] && i < gr.off[gi] + gr.len[gi];
+        const double xs = (double)(gsum * grad_scale);
+        const double t = block_sum(in ? xs * xs : 0.0, scratch);
+        if (threadIdx.x == 0) __hip_atomic_store(partials + (size_t)blockIdx.x * 4 + gi, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
+    __syncthreads();
+    if (threadIdx.x == 0) {                            // ... before the workgroup's one arrival
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old + 1u == target);
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    // ---- the last workgroup: ONE agent-scope acquire (drops this CU's stale L1 lines), then plain loads -- the compiler
+    // serialises agent-scope atomic loads (52 dependent L2 trips per thread: 34 us for the launch, measured), plain ones it batches
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    // norms in a fixed order, then clip + Adam for every group
+    const int nblk = gridDim.x;
+    float gmul[4];
+    for (int gi = 0; gi < n_groups; ++gi) {
+        double ss = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += RA_T)
+            ss += partials[(size_t)b * 4 + gi];
+        ss = block_sum(ss, scratch);
+        const float total_norm = (float)sqrt(ss);
+        float coef = max_norm / (total_norm + 1e-6f);  // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+        coef = coef > 1.f ? 1.f : coef;
+        gmul[gi] = grad_scale * coef;
+    }
+    for (int gi = 0; gi < n_groups; ++gi) {
+        const int64_t off = gr.off[gi], len = gr.len[gi];
+        constexpr int U = 13;                          // elements per thread and trip: 4 U loads in flight
+        for (int64_t i0 = threadIdx.x; i0 < len; i0 += (int64_t)U * RA_T) {
+            float xg[U], xm1[U], xm2[U], xp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t e = i0 + (int64_t)u * RA_T, ec = e < len ? e : len - 1;
+                xg[u] = flat[off + ec];
+                xm1[u] = m1[off + ec];
+                xm2[u] = m2[off + ec];
+                xp[u] = params[off + ec];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t e = i0 + (int64_t)u * RA_T;
+                if (e < len) {
+                    const float gx = xg[u] * gmul[gi];
+                    const float a = xm1[u] * beta1 + (1.f - beta1) * gx;
+                    const float b = xm2[u] * beta2 + (1.f - beta2) * (gx * gx);
+                    m1[off + e] = a;
+                    m2[off + e] = b;
+                    const float denom = sqrtf(b) / bc2_sqrt + eps;
+                    params[off + e] = xp[u] - step_size * (a / denom);
+                }
+            }
+        }
+    }
+}
+
+struct RaScratch {
+    char *ptr = nullptr;        // [counter (256 B)][partials: kRaMaxBlocks x 4 doubles]
+    unsigned base = 0;
+};
+constexpr int kRaMaxBlocks = 8192;
+static RaScratch g_ra[32];
+
 }  // namespace
+
+extern "C" int erl_reduce_clip_adam_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
+                                        float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
+                                        int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                                        float grad_scale, void *stream)
+{
+    ERL_REQUIRE(slabs && flat_grad && params && exp_avg && exp_avg_sq && group_off && group_len, "erl_reduce_clip_adam_f32: NULL argument");
+    ERL_REQUIRE(n_slabs >= 1 && stride >= 1 && n_groups >= 1 && n_groups <= 4 && step >= 1, "erl_reduce_clip_adam_f32: bad argument");
+    AdamGroups gr;
+    for (int i = 0; i < 4; ++i) {
+        gr.off[i] = i < n_groups ? group_off[i] : 0;
+        gr.len[i] = i < n_groups ? group_len[i] : 0;
+        ERL_REQUIRE(gr.off[i] >= 0 && gr.len[i] >= 0 && gr.off[i] + gr.len[i] <= stride, "erl_reduce_clip_adam_f32: group outside the gradient row");
+    }
+    const int64_t nblk = erl_cdiv(stride, RA_E);
+    ERL_REQUIRE(nblk <= kRaMaxBlocks, "erl_reduce_clip_adam_f32: gradient row too long (%lld floats)", (long long)stride);
+    int dev = -1;
+    ERL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32, "erl_reduce_clip_adam_f32: no device");
+    RaScratch &sc = g_ra[dev];
+    hipStream_t st = (hipStream_t)stream;
+    if (!sc.ptr) {
+        void *ptr = nullptr;
+        const size_t bytes = 256 + (size_t)kRaMaxBlocks * 4 * sizeof(double);
+        int rc = erl_hip_status(hipMalloc(&ptr, bytes), "hipMalloc(reduce_clip_adam scratch)");
+        if (rc) return rc;
+        if ((rc = erl_hip_status(hipMemset(ptr, 0, bytes), "hipMemset(reduce_clip_adam scratch)"))) return rc;
+        sc.ptr = (char *)ptr;
+        sc.base = 0;
+    }
+    if ((uint64_t)sc.base + (uint64_t)nblk >= 0xffffff00ull) {      // the arrival counter is about to wrap: restart it behind earlier work
+        int rc = erl_hip_status(hipMemsetAsync(sc.ptr, 0, 256, st), "hipMemsetAsync(arrival counter)");
+        if (rc) return rc;
+        sc.base = 0;
+    }
+    const unsigned target = sc.base + (unsigned)nblk;
+    sc.base = target;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(reduce_clip_adam_kernel, dim3((unsigned)nblk), dim3(RA_T), 0, st, slabs, n_slabs, stride, flat_grad, params, exp_avg,
+                       exp_avg_sq, gr, n_groups, lr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1), (float)sqrt(bc2),
+                       reinterpret_cast<double *>(sc.ptr + 256), reinterpret_cast<unsigned *>(sc.ptr), target);
+    ERL_LAUNCH_CHECK("erl_reduce_clip_adam_f32");
+}
 
 extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
                                  const int64_t *group_len, int n_groups, const int32_t *step_base, int32_t step_offset, float lr,

@@ -326,6 +326,19 @@ def clip_adam(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, groups: Se
           "erl_clip_adam_f32")
 
 
+def reduce_clip_adam(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN, params: TEN, exp_avg: TEN, exp_avg_sq: TEN,
+                     groups: Sequence[Tuple[int, int]], step: int, lr: float, max_norm: float, grad_scale: float = 1.0,
+                     betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """grad_reduce + clip_adam in one launch (the single-process minibatch loop's tail)."""
+    n = len(groups)
+    off = (ctypes.c_int64 * n)(*[g[0] for g in groups])
+    ln = (ctypes.c_int64 * n)(*[g[1] for g in groups])
+    check(lib().erl_reduce_clip_adam_f32(ptr(slabs, th.float32), n_slabs, stride, ptr(flat_grad, th.float32), ptr(params, th.float32),
+                                         ptr(exp_avg, th.float32), ptr(exp_avg_sq, th.float32), off, ln, n, step, lr, betas[0], betas[1],
+                                         eps, max_norm, grad_scale, stream_ptr()),
+          "erl_reduce_clip_adam_f32")
+
+
 def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int,
                h1: int, h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
                ids: TEN, ratio_clip: float, lambda_entropy: float, slabs: TEN, grads: TEN, first_step: int, lr: float,

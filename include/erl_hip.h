@@ -264,6 +264,14 @@ ERL_API int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg,
                       int32_t step_offset, float lr, float beta1, float beta2, float eps, float max_norm,
                       float grad_scale, void *stream);
 
+/* erl_grad_reduce_f32 + erl_clip_adam_f32 in ONE launch (host step only), for loops with nothing between the two: the same
+ * gradient bit for bit (same summation order), written to flat_grad; the workgroup that finishes last derives the clip
+ * coefficients from per-workgroup fp64 partial norms (fixed order) and applies Adam.  No workgroup waits on another. */
+ERL_API int erl_reduce_clip_adam_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
+                             float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
+                             int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                             float grad_scale, void *stream);
+
 /* Whole PPO update in one call (single-process path): for k in [0, update_times):
  *   erl_ppo_step_f32(ids + k*B) -> erl_grad_reduce_f32 -> grads[k] -> erl_clip_adam_f32(step = first_step + k).
  * Replaces the minibatch loop of AgentPPO.update_net (AgentPPO.py:158-167).  flat_params / exp_avg / exp_avg_sq hold
