@@ -352,6 +352,25 @@ def main():
     k6_seconds, k6_launches = _hip.k6_timing_read()
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
+    allreduce = None
+    if world > 1:       # the exchange step on its own: the flat gradient row through the route update_net uses (every rank takes part)
+        comm = parallel.gradient_comm()
+        buf = th.zeros(agent._stride, dtype=th.float32, device=dev)
+        red = (lambda: comm.all_reduce_sum(buf)) if comm is not None else (lambda: parallel.all_reduce_sum(buf))
+        for _ in range(20):
+            red()
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        th.cuda.synchronize()
+        parallel.barrier()
+        e0.record()
+        for _ in range(200):
+            red()
+        e1.record()
+        th.cuda.synchronize()
+        us = parallel.all_reduce_max_float(e0.elapsed_time(e1) * 5.0, device=dev)      # ms / 200 calls -> us per call
+        allreduce = {"route": "library RCCL communicator on the kernels' stream" if comm is not None else "torch.distributed",
+                     "ranks_seen_by_rccl": comm.world if comm is not None else world, "bytes": int(buf.numel() * 4),
+                     "us_per_call": round(us, 2), "calls_per_step": UPDATE_TIMES}
     if rank != 0:
         return
     env_steps = world * N_ENVS * HORIZON * opt.steps
@@ -379,6 +398,8 @@ def main():
                          "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": round(gae_s * 1e6, 2)},
         "objectives_last": [round(float(x), 6) for x in objs],
     }
+    if allreduce is not None:
+        line["allreduce"] = allreduce
     if not opt.no_gae_sweep and opt.config == "c4":
         log("GAE size sweep")
         sweep = gae_sweep(ops, dev)

@@ -1,0 +1,42 @@
+"""bench.py itself: the contract line at N = 1 (every configuration) and the N > 1 code path (two ranks sharing the GPU over
+gloo: the barrier / max-over-ranks timing, the gradient exchange in the loop and the all-reduce micro-benchmark run for real)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def run(cmd, env=None):
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config", ["c4", "c5", "c2", "c3"])
+def test_bench_line_contract(config):
+    line = run([sys.executable, "bench.py", "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-gae-sweep"])
+    assert KEYS <= set(line) and line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+    assert line["config"]["name"] == config and "workload" in line["config"] and line["vs_baseline"] is None
+    r = line["roofline"]
+    assert {"kernel", "bound", "achieved", "peak", "unit", "frac"} <= set(r) and 0 < r["frac"] < 1
+    if config == "c4":
+        assert line["metric"] == "env_steps_per_sec_ppo_4096envs_obs64" and r["kernel"] == "ppo_step_w4_kernel" and r["traffic"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29561", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-gae-sweep"],
+               env={"ERL_DIST_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    a = line["allreduce"]
+    assert a["bytes"] == 4 * (25872 + 24961 + 4) and a["us_per_call"] > 0 and a["calls_per_step"] == 40
+    assert "cpu_baseline" not in line
