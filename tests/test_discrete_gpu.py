@@ -182,6 +182,7 @@ def test_train_agent_discrete_ppo_cartpole_learns(tmp_path):
     args.gamma, args.learning_rate, args.lambda_entropy = 0.98, 2e-3, 0.01
     args.break_step, args.eval_per_step, args.eval_times = 64 * 40, 64 * 8, 8
     args.cwd, args.gpu_id, args.random_seed = str(tmp_path / "run"), 0, 0
+    args.gae_algo = "exact"    # fixed association: the run is reproducible bit for bit (the look-back scan is not)
     train_agent(args, if_single_process=True)
     rec = np.load(os.path.join(args.cwd, "recorder.npy"))
     assert np.isfinite(rec[:, :4]).all()
