@@ -7,9 +7,9 @@
 //
 // C[i][j] = sum_k A(i, k) B(j, k).  An operand is "RC" when its reduction index is the contiguous one in memory
 // (elem(i, k) = P[i ld + k]) and "OC" when its output index is (elem(i, k) = P[k ld + i]).  A workgroup of 4 waves
-// owns a 64 x 64 tile of C (each wave one 32 x 32 accumulator); the reduction advances in chunks of 16 through LDS
-// tiles stored reduction-major (T[k][i], row stride 68), so an MFMA operand read is 32 consecutive floats per lane
-// half; the next chunk's global loads are in flight under the current chunk's MFMAs.  Shapes are arbitrary: loads are
+// owns a 64 x 64 tile of C (each wave one 32 x 32 accumulator); the reduction advances in chunks of 32 through double-buffered
+// LDS tiles stored reduction-major (T[k][i], row stride 68), so an MFMA operand read is 32 consecutive floats per lane
+// half; the next chunks' global loads are in flight under the current chunk's MFMAs.  Shapes are arbitrary: loads are
 // clamped and masked, stores bounds-checked.  The weight-gradient contraction runs over the batch (tens of thousands
 // of rows) into a small output: it is split over blockIdx.z in chunks of rows, each split writes its own partial
 // (fixed-order sum afterwards: deterministic), and the workgroups of the first column tile also emit the row sums of
@@ -20,9 +20,8 @@
 namespace {
 
 constexpr int GT = 64;    // C tile edge
-constexpr int GK = 16;    // reduction chunk
+constexpr int GK = 32;    // reduction chunk
 constexpr int GLD = 68;   // LDS row stride (floats)
-constexpr int GD = 4;     // chunks of global loads in flight per workgroup
 
 enum { OP_RC = 0, OP_OC = 1 };
 enum { EPI_STORE = 0, EPI_ACC, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL, EPI_PARTIAL };
@@ -41,23 +40,26 @@ struct GemmArgs {
     int64_t rs_split;         // PARTIAL: floats between consecutive partial row-sum vectors
 };
 
-// A thread's four elements of a 64 x 16 operand tile.  VEC (16-byte aligned base, ld % 4 == 0 and the contiguous extent a
-// multiple of 4): one 16-byte load along the contiguous index; otherwise four clamped scalar loads.
+// A thread's eight elements (two groups of four) of a 64 x 32 operand tile.  VEC (16-byte aligned base, ld % 4 == 0 and the
+// contiguous extent a multiple of 4): two 16-byte loads along the contiguous index; otherwise eight clamped scalar loads.
 template <int OP, bool VEC>
-__device__ __forceinline__ void tile_load(float (&r)[4], const float *__restrict__ P, int ld, int i0, int imax, int k0, int kmax, int tid)
+__device__ __forceinline__ void tile_load(float (&r)[8], const float *__restrict__ P, int ld, int i0, int imax, int k0, int kmax, int tid)
 {
     if (VEC) {
-        const int i = OP == OP_RC ? tid >> 2 : (tid & 15) * 4, k = OP == OP_RC ? (tid & 3) * 4 : tid >> 4;
-        const int gi = i0 + i, gk = k0 + k;
-        const bool ok = gi < imax && gk < kmax;      // the extent along the vector is a multiple of 4: all four or none
-        const size_t off = !ok ? 0 : (OP == OP_RC ? (size_t)gi * ld + gk : (size_t)gk * ld + gi);
-        const float4 v = *reinterpret_cast<const float4 *>(P + off);
-        r[0] = ok ? v.x : 0.f; r[1] = ok ? v.y : 0.f; r[2] = ok ? v.z : 0.f; r[3] = ok ? v.w : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = OP == OP_RC ? tid >> 2 : (tid & 15) * 4, k = OP == OP_RC ? ((tid & 3) + 4 * h) * 4 : (tid >> 4) + 16 * h;
+            const int gi = i0 + i, gk = k0 + k;
+            const bool ok = gi < imax && gk < kmax;  // the extent along the vector is a multiple of 4: all four or none
+            const size_t off = !ok ? 0 : (OP == OP_RC ? (size_t)gi * ld + gk : (size_t)gk * ld + gi);
+            const float4 v = *reinterpret_cast<const float4 *>(P + off);
+            r[4 * h + 0] = ok ? v.x : 0.f; r[4 * h + 1] = ok ? v.y : 0.f; r[4 * h + 2] = ok ? v.z : 0.f; r[4 * h + 3] = ok ? v.w : 0.f;
+        }
     } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u;
-            const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
+            const int i = OP == OP_RC ? e >> 5 : e & 63, k = OP == OP_RC ? e & 31 : e >> 6;
             const int gi = i0 + i, gk = k0 + k;
             const bool ok = gi < imax && gk < kmax;
             const size_t off = !ok ? 0 : (OP == OP_RC ? (size_t)gi * ld + gk : (size_t)gk * ld + gi);
@@ -68,28 +70,38 @@ __device__ __forceinline__ void tile_load(float (&r)[4], const float *__restrict
 }
 
 template <int OP, bool VEC>
-__device__ __forceinline__ void tile_store(const float (&r)[4], float *T, int tid)
+__device__ __forceinline__ void tile_store(const float (&r)[8], float *T, int tid)
 {
     if (VEC && OP == OP_OC) {
-        *reinterpret_cast<float4 *>(T + (tid >> 4) * GLD + (tid & 15) * 4) = make_float4(r[0], r[1], r[2], r[3]);
-    } else if (VEC) {
-        const int i = tid >> 2, k = (tid & 3) * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) T[(k + c) * GLD + i] = r[c];
+        for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<float4 *>(T + ((tid >> 4) + 16 * h) * GLD + (tid & 15) * 4) = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
+    } else if (VEC) {
+        const int i = tid >> 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = ((tid & 3) + 4 * h) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T[(k + c) * GLD + i] = r[4 * h + c];
+        }
     } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u;
-            const int i = OP == OP_RC ? e >> 4 : e & 63, k = OP == OP_RC ? e & 15 : e >> 6;
+            const int i = OP == OP_RC ? e >> 5 : e & 63, k = OP == OP_RC ? e & 31 : e >> 6;
             T[k * GLD + i] = r[u];
         }
     }
 }
 
+// Main loop: the reduction advances in chunks of GK = 32 through DOUBLE-BUFFERED LDS tiles -- one workgroup barrier per chunk
+// (16 MFMAs per wave between barriers; the first version had two barriers per 8 MFMAs and ran the forward layers at 20-40
+// TFLOP/s) -- with the global loads of the two following chunks in flight in registers:
+//   iteration c:  regs(c + 1) -> LDS[(c + 1) & 1];  issue loads of chunk c + 3 into that register slot;  MFMAs on LDS[c & 1];  barrier.
 template <int AOP, int BOP, int EPI, bool VA, bool VB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
 {
-    __shared__ float As[GK * GLD], Bs[GK * GLD];
+    __shared__ float As[2][GK * GLD], Bs[2][GK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
     const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
     int kb = 0, ke = g.K;
@@ -98,35 +110,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
         ke = min(g.K, kb + g.kchunk);
     }
     const bool want_rs = EPI == EPI_PARTIAL && g.rowsum != nullptr && blockIdx.x == 0;
-    // GD chunks of global loads stay in flight: a lone workgroup (small batches: 16 workgroups on the whole chip) would
-    // otherwise pay one full memory round trip per 16-deep chunk; with 4 chunks ahead the trip hides under ~2k cycles of MFMAs
-    float ra[GD][4], rb[GD][4], rsum = 0.f;
+    const int nch = (ke - kb + GK - 1) / GK;
+    float ra[2][8], rb[2][8], rsum = 0.f;
     f32x16 acc = {0};
+    // chunk 0 straight to LDS[0]; chunks 1 and 2 into the register slots
+    tile_load<AOP, VA>(ra[0], g.A, g.lda, i0, g.M, kb, ke, tid);
+    tile_load<BOP, VB>(rb[0], g.B, g.ldb, j0, g.N, kb, ke, tid);
+    tile_load<AOP, VA>(ra[1], g.A, g.lda, i0, g.M, kb + GK, ke, tid);
+    tile_load<BOP, VB>(rb[1], g.B, g.ldb, j0, g.N, kb + GK, ke, tid);
+    tile_store<AOP, VA>(ra[0], As[0], tid);
+    tile_store<BOP, VB>(rb[0], Bs[0], tid);
+    tile_load<AOP, VA>(ra[0], g.A, g.lda, i0, g.M, kb + 2 * GK, ke, tid);
+    tile_load<BOP, VB>(rb[0], g.B, g.ldb, j0, g.N, kb + 2 * GK, ke, tid);
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
 #pragma unroll
-    for (int d = 0; d < GD; ++d) {
-        tile_load<AOP, VA>(ra[d], g.A, g.lda, i0, g.M, kb + d * GK, ke, tid);
-        tile_load<BOP, VB>(rb[d], g.B, g.ldb, j0, g.N, kb + d * GK, ke, tid);
-    }
-    for (int base = kb; base < ke; base += GD * GK) {
-#pragma unroll
-        for (int d = 0; d < GD; ++d) {
-            const int k0 = base + d * GK;
-            if (k0 < ke) {                                     // uniform
-                __syncthreads();                               // the previous chunk's operand reads are done
-                tile_store<AOP, VA>(ra[d], As, tid);
-                tile_store<BOP, VB>(rb[d], Bs, tid);
-                __syncthreads();
-                if (k0 + GD * GK < ke) {                       // refill this slot with the chunk GD ahead
-                    tile_load<AOP, VA>(ra[d], g.A, g.lda, i0, g.M, k0 + GD * GK, ke, tid);
-                    tile_load<BOP, VB>(rb[d], g.B, g.ldb, j0, g.N, k0 + GD * GK, ke, tid);
+        for (int d = 0; d < 2; ++d) {                          // chunk c + d lives in LDS[d]; register slot (d + 1) & 1 holds chunk c + d + 1
+            const int cc = c + d;
+            if (cc < nch) {                                    // uniform
+                const int slot = (d + 1) & 1;
+                if (cc + 1 < nch) {
+                    tile_store<AOP, VA>(ra[slot], As[slot], tid);
+                    tile_store<BOP, VB>(rb[slot], Bs[slot], tid);
+                    if (cc + 3 < nch) {
+                        tile_load<AOP, VA>(ra[slot], g.A, g.lda, i0, g.M, kb + (cc + 3) * GK, ke, tid);
+                        tile_load<BOP, VB>(rb[slot], g.B, g.ldb, j0, g.N, kb + (cc + 3) * GK, ke, tid);
+                    }
                 }
-                const float *a = As + hi * GLD + 32 * wm + l31, *b = Bs + hi * GLD + 32 * wn + l31;
+                const float *a = As[d] + hi * GLD + 32 * wm + l31, *b = Bs[d] + hi * GLD + 32 * wn + l31;
 #pragma unroll
-                for (int s = 0; s < GK / 2; ++s) acc = mfma32(a[2 * s * GLD], b[2 * s * GLD], acc);
+                for (int s2 = 0; s2 < GK / 2; ++s2) acc = mfma32(a[2 * s2 * GLD], b[2 * s2 * GLD], acc);
                 if (want_rs && tid < GT) {
 #pragma unroll
-                    for (int k = 0; k < GK; ++k) rsum += As[k * GLD + tid];
+                    for (int k = 0; k < GK; ++k) rsum += As[d][k * GLD + tid];
                 }
+                __syncthreads();                               // LDS[slot] is complete, LDS[d] is free for chunk cc + 2
             }
         }
     }
