@@ -252,39 +252,65 @@ __device__ __forceinline__ void stage32(float *T, const f32x16 (&a)[NT_], int co
 // dW (nA32*32 x nB32*32) = TA . TB^T over the 128 staged samples, output tiles split over the waves.  The sum over
 // samples is order-free: lane half `hi` takes samples 8 j + 4 hi + {0..3} of every group of 8 (one 16-byte read per
 // operand feeds four MFMAs); operands are read one group ahead.
-__device__ __forceinline__ void weight_grad_w4(const float *TA, int nA32, const float *TB, int nB32, float *__restrict__ dW,
-                                               int ldw, int cols_real, int wave, int lane)
+template <int NB>
+__device__ __forceinline__ void weight_grad_w4(const float *TA, const float *TB, float *__restrict__ dW, int ldw, int cols_real,
+                                               float *__restrict__ db, int wave, int lane)
 {
+    // wave w owns row tile it = w (features 32 w .. 32 w + 31 of dZ^T) against all NB column tiles: its A operand is the same
+    // for every tile, so the bias gradient -- the row sums of dZ^T -- falls out of the operand reads of the first tile (two
+    // packed adds per four MFMAs) instead of a second pass over the staged tile.  The (tile, group) loop is flat: operands are
+    // read one group ahead across tile seams, and a finished tile is stored after the first group of the next one (its last
+    // MFMA has drained by then), into the other accumulator.
     const int l31 = lane & 31, hi = lane >> 5;
-    const int ntiles = nA32 * nB32;
-    for (int tile = wave; tile < ntiles; tile += QNW) {
-        const int it = tile / nB32, jt = tile - it * nB32;
-        const float *a4 = TA + (32 * it + l31) * PLD + 4 * hi;
-        const float *b4 = TB + (32 * jt + l31) * PLD + 4 * hi;
-        f32x16 acc = {0};
-        float4 av[2], bv[2];
-        av[0] = *reinterpret_cast<const float4 *>(a4);
-        bv[0] = *reinterpret_cast<const float4 *>(b4);
-#pragma unroll
-        for (int j = 0; j < PB / 8; ++j) {
-            if (j + 1 < PB / 8) {
-                av[(j + 1) & 1] = *reinterpret_cast<const float4 *>(a4 + 8 * (j + 1));
-                bv[(j + 1) & 1] = *reinterpret_cast<const float4 *>(b4 + 8 * (j + 1));
-            }
-            const float4 x = av[j & 1], y = bv[j & 1];
-            acc = mfma32(x.x, y.x, acc);
-            acc = mfma32(x.y, y.y, acc);
-            acc = mfma32(x.z, y.z, acc);
-            acc = mfma32(x.w, y.w, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    const float *a4 = TA + (32 * wave + l31) * PLD + 4 * hi;
+    const float *b4 = TB + l31 * PLD + 4 * hi;
+    constexpr int NG = PB / 8;
+    f32x16 acc[2];
+    f32x2 bs = {0.f, 0.f};
+    float4 av[2], bv[2];
+    av[0] = *reinterpret_cast<const float4 *>(a4);
+    bv[0] = *reinterpret_cast<const float4 *>(b4);
+    auto store = [&](int jt, const f32x16 &c) {
         const int i = 32 * jt + l31;
         if (i < cols_real) {
-            float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
+            float *o = dW + (size_t)(32 * wave + 4 * hi) * ldw + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * ldw] = acc[r];
+            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * ldw] = c[r];
+        }
+    };
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int gi = jt * NG + j;
+            if (gi + 1 < NB * NG) {
+                const int jn = (gi + 1) % NG, tn = (gi + 1) / NG;
+                av[(gi + 1) & 1] = *reinterpret_cast<const float4 *>(a4 + 8 * jn);
+                bv[(gi + 1) & 1] = *reinterpret_cast<const float4 *>(b4 + 32 * tn * PLD + 8 * jn);
+            }
+            const float4 x = av[gi & 1], y = bv[gi & 1];
+            f32x16 &c = acc[jt & 1];
+            if (j == 0) {
+                const f32x16 zero = {0};
+                c = mfma32(x.x, y.x, zero);
+            } else {
+                c = mfma32(x.x, y.x, c);
+            }
+            c = mfma32(x.y, y.y, c);
+            c = mfma32(x.z, y.z, c);
+            c = mfma32(x.w, y.w, c);
+            if (jt == 0) {
+                bs += f32x2{x.x, x.y};
+                bs += f32x2{x.z, x.w};
+            }
+            if (j == 0 && jt > 0) store(jt - 1, acc[(jt - 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    store(NB - 1, acc[(NB - 1) & 1]);
+    float s = bs.x + bs.y;
+    s += __shfl_xor(s, 32, 64);
+    if (hi == 0) db[32 * wave + l31] = s;
 }
 
 // copy_load for a matrix that fills its padded tile exactly (rows x COLS, COLS % 4 == 0, 16-byte aligned): no clamps, no
@@ -314,27 +340,6 @@ __device__ __forceinline__ void dma_copy128(const float *__restrict__ src, int r
             const int row = (u * 1986) >> 16, cu = u - 33 * row;     // u / 33 for u < 4224
             if (u < UNITS && row < rows) __builtin_amdgcn_global_load_lds(src + row * 128 + 4 * min(cu, 31), dst + 256 * k, 16, 0, 0);
         }
-    }
-}
-
-// row sums of the 16-row tile RC: rows a < OUT are db3, rows 8 + a are the std_log gradient (actor)
-__device__ __forceinline__ void bias_grad_head(const float *T, int OUT, float *__restrict__ db3, float *__restrict__ dstd, int lane)
-{
-    const int f = lane & 15, p = lane >> 4;
-    const float *src = T + f * PLD + 32 * p;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; k += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(src + k);
-        s0 += v.x + v.z;
-        s1 += v.y + v.w;
-    }
-    float s = s0 + s1;
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if (p == 0) {
-        if (f < OUT) db3[f] = s;
-        else if (dstd && f >= 8 && f - 8 < OUT) dstd[f - 8] = s;
     }
 }
 
@@ -589,9 +594,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     }
     lds_barrier();                                                   // (2)
     PROF(9);
-    weight_grad_w4(RA, 4, RX, (S + 31) >> 5, slab + d.oW1(), S, S, wave, lane);
-    bias_grad<QNW>(RA, h1, slab + d.ob1(), wave, lane);
-    if (wave == 0) bias_grad_head(RC, OUT, slab + d.ob3(), ACTOR ? slab + d.oStd() : nullptr, lane);
+    weight_grad_w4<KX>(RA, RX, slab + d.oW1(), S, S, slab + d.ob1(), wave, lane);       // dW1 and db1
     PROF(10);
     lds_barrier();                                                   // (3) dZ1^T, X^T consumed
 
@@ -601,8 +604,12 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     lds_barrier();                                                   // (4)
     PROF(11);
     {
+        // row sums of the A operand (rows a < OUT: db3; rows 8 + a: the std_log gradient) ride on wave 0's first tile
         const int l15 = lane & 15, q = lane >> 4;
-        for (int it = wave; it < 8; it += QNW) {
+        f32x2 hs = {0.f, 0.f};
+#pragma unroll
+        for (int rep = 0; rep < 8 / QNW; ++rep) {
+            const int it = wave + QNW * rep;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float *a = RC + l15 * PLD + 4 * q;                    // lane group q: samples 16 j + 4 q + {0..3}
             const float *b = RA + (16 * it + l15) * PLD + 4 * q;
@@ -613,12 +620,23 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
                 acc = mfma16(av.y, bv.y, acc);
                 acc = mfma16(av.z, bv.z, acc);
                 acc = mfma16(av.w, bv.w, acc);
+                if (rep == 0) {
+                    hs += f32x2{av.x, av.y};
+                    hs += f32x2{av.z, av.w};
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a_ = 4 * q + r;
                 if (a_ < OUT) slab[d.oW3() + (size_t)a_ * h2 + 16 * it + l15] = acc[r];
             }
+        }
+        float s = hs.x + hs.y;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (wave == 0 && q == 0) {
+            if (l15 < OUT) slab[d.ob3() + l15] = s;
+            else if (ACTOR && l15 >= 8 && l15 - 8 < OUT) slab[d.oStd() + l15 - 8] = s;
         }
     }
     lds_barrier();                                                   // (5) H2^T consumed
@@ -627,8 +645,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     PROF(12);
 
     // ---- layer 2: dW2 = dZ2^T . H1, db2
-    weight_grad_w4(RA, 4, RB, 4, slab + d.oW2(), h1, h1, wave, lane);
-    bias_grad<QNW>(RA, h2, slab + d.ob2(), wave, lane);
+    weight_grad_w4<4>(RA, RB, slab + d.oW2(), h1, h1, slab + d.ob2(), wave, lane);      // dW2 and db2
     PROF(13);
 
     // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
