@@ -203,7 +203,12 @@ __device__ __forceinline__ void bwd32(const float *W, int ldw, const f32x16 (&dz
     auto issue = [&](int c, float(&dst)[4]) {
         const int To = c / NG, gi = c % NG;
         const float *p = wbase + (8 * gi) * ldw + 32 * To;
-        dst[0] = p[0]; dst[1] = p[ldw]; dst[2] = p[2 * ldw]; dst[3] = p[3 * ldw];
+        // volatile: keeps them four ds_read_b32 with 16-bit immediate offsets off ONE base register (every offset of the
+        // layer, <= 15 * 8 * 528 + 3 * 528 + 384 bytes, fits); merged into ds_read2_b32 (8-bit offsets) each pair needs its
+        // own v_add, and a lone VALU instruction between two MFMAs costs ~14 cycles (tools/mfma_issue_bench.hip, mode 51)
+        typedef const volatile __attribute__((address_space(3))) float *lds_vptr;
+        lds_vptr q = (lds_vptr)(uint32_t)(uintptr_t)p;           // low half of a generic LDS pointer = the LDS byte address
+        dst[0] = q[0]; dst[1] = q[ldw]; dst[2] = q[2 * ldw]; dst[3] = q[3 * ldw];
     };
     issue(0, wq[0]);
     f32x16 acc = {0}, prev = {0};

@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // MODE: see names[] in main
 template <int MODE>
-__global__ __launch_bounds__(256) void k(long long *out, float *sink, int reps)
+__global__ __launch_bounds__(256) void k(long long *out, float *sink, float *gbuf, int reps)
 {
     extern __shared__ __attribute__((aligned(16))) float T[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void k(long long *out, float *sink, int reps)
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 pk0 = {x, y}, pk1 = {y, x}, pk2 = {1.0f, 0.999f};
     const unsigned bc_off = 16u * (lane >> 5);
+    float *g1 = gbuf + (size_t)blockIdx.x * 16384 + 1024 * wave + lane;                 // lane-contiguous dwords
+    float *g4 = gbuf + (size_t)blockIdx.x * 16384 + 1024 * wave + 4 * lane;             // lane-contiguous 16-byte units
+    float *gs = gbuf + (size_t)blockIdx.x * 16384 + 32 * threadIdx.x;            // one 128-byte line per lane
+    unsigned qaddr = 0;
     unsigned long long t0, t1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < reps; ++it) {
@@ -99,10 +103,72 @@ __global__ __launch_bounds__(256) void k(long long *out, float *sink, int reps)
             asm volatile(R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") : [l0] "=&v"(l0) : [p] "v"(bc_off));
         else if (MODE == 33)  // 16 x (ds_read_b128 distinct addresses + wait)
             asm volatile(R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") R8("ds_read_b128 %[l0], %[p]\n\ts_waitcnt lgkmcnt(0)\n\t") : [l0] "=&v"(l0) : [p] "v"(lds_off));
+        else if (MODE == 49 || MODE == 50) {  // the dW loop as hipcc builds it: the 4 MFMAs of a group take their operands from two
+                                // 16-byte LDS reads issued one group earlier (50: operands are loop constants, reads still issued)
+            const float *pa = T + 4 * lane + 64 * (it & 1);
+            float4 av[2], bv[2];
+            av[0] = *reinterpret_cast<const float4 *>(pa);
+            bv[0] = *reinterpret_cast<const float4 *>(pa + 512);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                av[(j + 1) & 1] = *reinterpret_cast<const float4 *>(pa + 1024 * ((j + 1) & 3));
+                bv[(j + 1) & 1] = *reinterpret_cast<const float4 *>(pa + 1024 * ((j + 1) & 3) + 512);
+                const float4 u = av[j & 1], v = bv[j & 1];
+                if (MODE == 49) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, v.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, v.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, v.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, v.w, acc0, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+                    x += u.x + v.y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        else if (MODE == 51)  // two chains, 1 VALU per gap
+            asm volatile(R8(M0 VI M1 VJ) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 52)  // two chains, 1 VALU per two MFMAs
+            asm volatile(R8(M0 VI M1) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 53)  // two chains, 2 VALU per gap
+            asm volatile(R8(M0 VI VJ M1 VI VJ) : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "+v"(x), [y] "+v"(y) : [a] "v"(a), [b] "v"(b), [z] "v"(z));
+        else if (MODE == 54)  // one chain, 1 VALU + 1 ds_read2_b32 per gap (the transposed-operand loop of the backward layer)
+            asm volatile(R8(M0 "v_add_u32 %[q], 0x400, %[p]\n\tds_read2_b32 %[l2], %[q] offset0:8 offset1:140\n\t" M0 "s_waitcnt lgkmcnt(0)\n\t")
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1), [q] "=&v"(qaddr), [l2] "=&v"(pk0) : [a] "v"(a), [b] "v"(b), [p] "v"(lds_off));
+        else if (MODE == 40)  // two chains + one coalesced global_store_dword per gap (data in a VGPR)
+            asm volatile(M0 "global_store_dword %[g1], %[x], off offset:0\n\t" M1 "global_store_dword %[g1], %[y], off offset:256\n\t" M0 "global_store_dword %[g1], %[x], off offset:512\n\t" M1 "global_store_dword %[g1], %[y], off offset:768\n\t" M0 "global_store_dword %[g1], %[x], off offset:1024\n\t" M1 "global_store_dword %[g1], %[y], off offset:1280\n\t" M0 "global_store_dword %[g1], %[x], off offset:1536\n\t" M1 "global_store_dword %[g1], %[y], off offset:1792\n\t" M0 "global_store_dword %[g1], %[x], off offset:2048\n\t" M1 "global_store_dword %[g1], %[y], off offset:2304\n\t" M0 "global_store_dword %[g1], %[x], off offset:2560\n\t" M1 "global_store_dword %[g1], %[y], off offset:2816\n\t" M0 "global_store_dword %[g1], %[x], off offset:3072\n\t" M1 "global_store_dword %[g1], %[y], off offset:3328\n\t" M0 "global_store_dword %[g1], %[x], off offset:3584\n\t" M1 "global_store_dword %[g1], %[y], off offset:3840\n\t"
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b), [x] "v"(x), [y] "v"(y), [g1] "v"(g1) : "memory");
+        else if (MODE == 41)  // two chains + one coalesced global_store_dwordx4 per 4 MFMAs (same bytes as 40)
+            asm volatile(M0 M1 M0 "global_store_dwordx4 %[g4], %[l0], off offset:0\n\t" M1 M0 M1 M0 "global_store_dwordx4 %[g4], %[l0], off offset:1024\n\t" M1 M0 M1 M0 "global_store_dwordx4 %[g4], %[l0], off offset:2048\n\t" M1 M0 M1 M0 "global_store_dwordx4 %[g4], %[l0], off offset:3072\n\t" M1
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b), [l0] "v"(l0), [g4] "v"(g4) : "memory");
+        else if (MODE == 42)  // as 40 with the store data in an AGPR
+            asm volatile(M0 "global_store_dword %[g1], %[w], off offset:0\n\t" M1 "global_store_dword %[g1], %[w2], off offset:256\n\t" M0 "global_store_dword %[g1], %[w], off offset:512\n\t" M1 "global_store_dword %[g1], %[w2], off offset:768\n\t" M0 "global_store_dword %[g1], %[w], off offset:1024\n\t" M1 "global_store_dword %[g1], %[w2], off offset:1280\n\t" M0 "global_store_dword %[g1], %[w], off offset:1536\n\t" M1 "global_store_dword %[g1], %[w2], off offset:1792\n\t" M0 "global_store_dword %[g1], %[w], off offset:2048\n\t" M1 "global_store_dword %[g1], %[w2], off offset:2304\n\t" M0 "global_store_dword %[g1], %[w], off offset:2560\n\t" M1 "global_store_dword %[g1], %[w2], off offset:2816\n\t" M0 "global_store_dword %[g1], %[w], off offset:3072\n\t" M1 "global_store_dword %[g1], %[w2], off offset:3328\n\t" M0 "global_store_dword %[g1], %[w], off offset:3584\n\t" M1 "global_store_dword %[g1], %[w2], off offset:3840\n\t"
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b), [w] "a"(wv), [w2] "a"(wv2), [g1] "v"(g1) : "memory");
+        else if (MODE == 43)  // stores only: 16 coalesced global_store_dword
+            asm volatile("global_store_dword %[g1], %[x], off offset:0\n\t" "global_store_dword %[g1], %[y], off offset:256\n\t" "global_store_dword %[g1], %[x], off offset:512\n\t" "global_store_dword %[g1], %[y], off offset:768\n\t" "global_store_dword %[g1], %[x], off offset:1024\n\t" "global_store_dword %[g1], %[y], off offset:1280\n\t" "global_store_dword %[g1], %[x], off offset:1536\n\t" "global_store_dword %[g1], %[y], off offset:1792\n\t" "global_store_dword %[g1], %[x], off offset:2048\n\t" "global_store_dword %[g1], %[y], off offset:2304\n\t" "global_store_dword %[g1], %[x], off offset:2560\n\t" "global_store_dword %[g1], %[y], off offset:2816\n\t" "global_store_dword %[g1], %[x], off offset:3072\n\t" "global_store_dword %[g1], %[y], off offset:3328\n\t" "global_store_dword %[g1], %[x], off offset:3584\n\t" "global_store_dword %[g1], %[y], off offset:3840\n\t"
+                         : : [x] "v"(x), [y] "v"(y), [g1] "v"(g1) : "memory");
+        else if (MODE == 44)  // 16 MFMAs, then the 16 stores in one burst
+            asm volatile(R8(M0 M1) "global_store_dword %[g1], %[x], off offset:0\n\t" "global_store_dword %[g1], %[y], off offset:256\n\t" "global_store_dword %[g1], %[x], off offset:512\n\t" "global_store_dword %[g1], %[y], off offset:768\n\t" "global_store_dword %[g1], %[x], off offset:1024\n\t" "global_store_dword %[g1], %[y], off offset:1280\n\t" "global_store_dword %[g1], %[x], off offset:1536\n\t" "global_store_dword %[g1], %[y], off offset:1792\n\t" "global_store_dword %[g1], %[x], off offset:2048\n\t" "global_store_dword %[g1], %[y], off offset:2304\n\t" "global_store_dword %[g1], %[x], off offset:2560\n\t" "global_store_dword %[g1], %[y], off offset:2816\n\t" "global_store_dword %[g1], %[x], off offset:3072\n\t" "global_store_dword %[g1], %[y], off offset:3328\n\t" "global_store_dword %[g1], %[x], off offset:3584\n\t" "global_store_dword %[g1], %[y], off offset:3840\n\t"
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b), [x] "v"(x), [y] "v"(y), [g1] "v"(g1) : "memory");
+        else if (MODE == 45)  // two chains + one ds_write_b32 per gap
+            asm volatile(R8(M0 "ds_write_b32 %[p], %[x]\n\t" M1 "ds_write_b32 %[p], %[y] offset:1024\n\t")
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b), [x] "v"(x), [y] "v"(y), [p] "v"(lds_off) : "memory");
+        else if (MODE == 46)  // two chains + one ds_write_b128 per 4 MFMAs
+            asm volatile(R4(M0 M1 M0 "ds_write_b128 %[p], %[l0]\n\t" M1)
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b), [l0] "v"(l0), [p] "v"(lds_off) : "memory");
+        else if (MODE == 47)  // two chains + one global_store_dword per gap, 64 lanes on 64 different 128-byte lines
+            asm volatile(R8(M0 "global_store_dword %[gs], %[x], off\n\t" M1 "global_store_dword %[gs], %[y], off offset:4\n\t")
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1) : [a] "v"(a), [b] "v"(b), [x] "v"(x), [y] "v"(y), [gs] "v"(gs) : "memory");
+        else if (MODE == 48)  // two chains + one global_load_dword per gap (coalesced), waited at the end of the 16
+            asm volatile(R8(M0 "global_load_dword %[x], %[g1], off\n\t" M1 "global_load_dword %[y], %[g1], off offset:256\n\t") "s_waitcnt vmcnt(0)\n\t"
+                         : [c0] "+a"(acc0), [c1] "+a"(acc1), [x] "=&v"(x), [y] "=&v"(y) : [a] "v"(a), [b] "v"(b), [g1] "v"(g1) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     if (lane == 0 && blockIdx.x == 0) out[wave] = (long long)(t1 - t0);
-    float s = x + y + l0[0] + l1[1] + wv + wv2 + pk0.x + pk1.y;
+    float s = x + y + (float)qaddr + l0[0] + l1[1] + wv + wv2 + pk0.x + pk1.y;
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
     if (s == 12345.678f) sink[threadIdx.x] = s;
 }
@@ -111,6 +177,8 @@ template <int MODE>
 void run(const char *name)
 {
     long long *d; float *s;
+    static float *gbuf = nullptr;
+    if (!gbuf) hipMalloc(&gbuf, (size_t)256 * 16384 * 4);
     hipMalloc(&d, 64); hipMalloc(&s, 4096);
     const int reps = 200;
     const size_t lds = 100 * 1024;   // one workgroup per CU
@@ -119,7 +187,7 @@ void run(const char *name)
     float ms = 0;
     for (int i = 0; i < 3; ++i) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(256), lds, 0, d, s, reps);
+        hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(256), lds, 0, d, s, gbuf, reps);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -149,6 +217,20 @@ int main()
     run<12>("12 two chains + ds_read_b32 per 2 MFMAs");
     run<13>("13 two chains + 1 s_nop per gap");
     run<14>("14 two chains + accvgpr read+write per gap");
+    run<49>("49 dW-loop shape: operands from ds_read_b128 a group ahead (hipcc)");
+    run<50>("50 as 49 with constant MFMA operands (+2 VALU per group)");
+    run<51>("51 two chains + 1 VALU per gap");
+    run<52>("52 two chains + 1 VALU per two MFMAs");
+    run<53>("53 two chains + 2 VALU per gap");
+    run<54>("54 one chain + (v_add + ds_read2_b32) per two MFMAs");
+    run<40>("40 two chains + coalesced global_store_dword per gap");
+    run<41>("41 two chains + coalesced global_store_dwordx4 per 4 MFMAs");
+    run<42>("42 as 40, store data in AGPRs");
+    run<44>("44 16 MFMAs then 16 global_store_dword in a burst");
+    run<45>("45 two chains + ds_write_b32 per gap");
+    run<46>("46 two chains + ds_write_b128 per 4 MFMAs");
+    run<47>("47 two chains + global_store_dword per gap, one line per lane");
+    run<48>("48 two chains + coalesced global_load_dword per gap");
     printf("--- VALU only: ticks per 16 instructions are (ticks / 'MFMA') x 1, i.e. per instruction = value / 16 ...\n");
     run<20>("20 16 v_fma_f32, two independent accumulators      [per 16]");
     run<21>("21 16 v_fma_f32, one dependent chain               [per 16]");
@@ -162,6 +244,7 @@ int main()
     run<29>("29 16 v_bfi_b32 (dependent pair)                   [per 16]");
     run<30>("30 16 v_fma_f32 + 16 s_nop 0                       [per 16]");
     run<31>("31 16 v_mov_b32                                    [per 16]");
+    run<43>("43 16 global_store_dword, coalesced                [per 16]");
     run<32>("32 16 x (ds_read_b128 half-broadcast + wait)       [per 16]");
     run<33>("33 16 x (ds_read_b128 distinct + wait)             [per 16]");
     return 0;
