@@ -16,6 +16,8 @@
 
 namespace {
 
+constexpr int kDefaultTail = 0;      // ERL_FUSED_TAIL default (see erl_ppo_update_dp_f32)
+
 struct Rccl {
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -127,20 +129,23 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
     const int64_t off[2] = {0, Pa}, len[2] = {Pa, Pc};
     const int world = erl_comm_world_size(comm);
     const float grad_scale = 1.0f / (float)world;          // SUM over ranks -> mean, folded into the optimiser
-    // ERL_FUSED_TAIL=1: erl_reduce_clip_adam_f32 instead of the two tail launches.  OFF by default: measured 34.9 us against
-    // 18.2 us (tools/tail_bench.py, profiles/r02_tail_bench.txt) -- the workgroup that arrives last applies Adam to all 50k
-    // parameters alone, and one CU moves the 1.4 MB of that phase at ~75 GB/s
-    static const bool fused_tail = [] { const char *e = getenv("ERL_FUSED_TAIL"); return e && atoi(e) != 0; }();
+    // The optimiser tail of a single process (nothing sits between the reduction and the optimiser): ERL_FUSED_TAIL selects
+    // 0 = grad_reduce + clip_adam (two launches), 1 = one launch whose last-arriving workgroup applies Adam alone (measured
+    // slower: profiles/r02_tail_bench.txt), 2 = one launch in which every workgroup waits for the norm and updates its own
+    // elements (needs the whole grid resident: erl_reduce_clip_adam_grid_ok).  Default: see kDefaultTail.
+    static const int tail_env = [] { const char *e = getenv("ERL_FUSED_TAIL"); return e ? atoi(e) : kDefaultTail; }();
+    const int tail = comm ? 0 : (tail_env == 2 && !erl_reduce_clip_adam_grid_ok(stride) ? 0 : tail_env);
     for (int k = 0; k < update_times; ++k) {
         float *g = grads + (size_t)k * stride;
         int rc = erl_ppo_step_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
                                   unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
                                   lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, stream);
         if (rc) return rc;
-        if (!comm && fused_tail) {     // nothing between the reduction and the optimiser: one launch for both
-            if ((rc = erl_reduce_clip_adam_f32(slabs, n_slabs, stride, g, flat_params, exp_avg, exp_avg_sq, off, len, 2, first_step + k, lr,
-                                               beta1, beta2, eps, max_norm, grad_scale, stream)))
-                return rc;
+        if (tail) {
+            rc = (tail == 2 ? erl_reduce_clip_adam_grid_f32 : erl_reduce_clip_adam_f32)(slabs, n_slabs, stride, g, flat_params, exp_avg, exp_avg_sq,
+                                                                                        off, len, 2, first_step + k, lr, beta1, beta2, eps,
+                                                                                        max_norm, grad_scale, stream);
+            if (rc) return rc;
             continue;
         }
         if ((rc = erl_grad_reduce_f32(slabs, n_slabs, stride, g, stream))) return rc;

@@ -10,6 +10,9 @@
 // error plumbing (host)
 // ---------------------------------------------------------------------------------------------
 void erl_set_error(const char *fmt, ...);
+// pinned host-mapped word that device code bumps for faults an asynchronous launch cannot return (gae_lookback.hip);
+// read through erl_async_fault_count.  NULL when pinned memory is unavailable.
+uint32_t *erl_fault_word();
 
 #define ERL_REQUIRE(cond, ...)                 \
     do {                                       \

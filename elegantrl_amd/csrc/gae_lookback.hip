@@ -332,7 +332,7 @@ static LbTable g_lb_table[32];
 // word: the kernel bumps it with a system-scope atomic, the host reads it without touching the GPU once the stream has
 // been synchronised (erl_async_fault_count).  Allocated on first use; NULL when pinned memory is unavailable.
 static uint32_t *g_fault_host = nullptr, *g_fault_dev = nullptr;
-static uint32_t *fault_word()
+uint32_t *erl_fault_word()
 {
     static bool tried = false;
     if (!tried) {
@@ -382,7 +382,7 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     g.H = (int)H; g.N = (int)N; g.G = (int)G; g.K = (int)K;
     g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
     g.partials = (double *)(ws + 256 + slot_bytes);
-    g.fault = fault_word();
+    g.fault = erl_fault_word();
     {
         const int lim = env_int("ERL_GAE_LB_SPIN", 1 << 22);
         g.spin_limit = lim > 0 ? (uint32_t)lim : 1u;

@@ -99,18 +99,27 @@ constexpr int RA_T = 1024, RA_E = 256;      // threads, elements per workgroup
 
 __device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+template <bool GRID_WAIT>
 __global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__restrict__ slabs, int n_slabs, int64_t stride,
                                                                 float *flat, float *__restrict__ params, float *__restrict__ m1,
                                                                 float *__restrict__ m2, AdamGroups gr, int n_groups, float lr,
                                                                 float beta1, float beta2, float eps, float max_norm, float grad_scale,
                                                                 float step_size, float bc2_sqrt, double *partials,
-                                                                unsigned *counter, unsigned target)
+                                                                unsigned *counter, unsigned target, uint32_t *fault)
 {
     __shared__ float part[4][RA_E];
     __shared__ double scratch[16];
     __shared__ int s_last;
     const int el = threadIdx.x & (RA_E - 1), p = threadIdx.x / RA_E;
     const int64_t i = (int64_t)blockIdx.x * RA_E + el;
+    // (grid-wait form) the element's optimiser state rides the reduction's first round trip
+    int my_group = -1;
+    float e_m1 = 0.f, e_m2 = 0.f, e_p = 0.f;
+    if (GRID_WAIT && p == 0) {
+        for (int gi = 0; gi < n_groups; ++gi)
+            if (i >= gr.off[gi] && i < gr.off[gi] + gr.len[gi]) my_group = gi;
+        if (my_group >= 0) { e_m1 = m1[i]; e_m2 = m2[i]; e_p = params[i]; }
+    }
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < stride) {                                  // (the loop nest of grad_reduce_kernel, mlp.hip: same association)
         const float *src = slabs + i;
@@ -150,6 +159,45 @@ __global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__r
         s_last = (old + 1u == target);
     }
     __syncthreads();
+    if (GRID_WAIT) {
+        // ---- every workgroup WAITS for the last arrival, then applies Adam to its own 256 elements from registers: the whole
+        // grid is resident (the host checked grid <= the device's capacity for this kernel and the stream is in order, so the
+        // workgroups not yet dispatched can only be waiting for unrelated kernels, which finish without us); the spin is
+        // bounded all the same and reports through the fault word instead of hanging
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) {
+                    if (fault) __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const int nblk = gridDim.x;
+        float mul = 0.f;
+        for (int gi = 0; gi < n_groups; ++gi) {
+            double ss = 0.0;
+            for (int b = threadIdx.x; b < nblk; b += RA_T) ss += partials[(size_t)b * 4 + gi];
+            ss = block_sum(ss, scratch);
+            const float total_norm = (float)sqrt(ss);
+            float coef = max_norm / (total_norm + 1e-6f);  // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+            coef = coef > 1.f ? 1.f : coef;
+            if (gi == my_group) mul = grad_scale * coef;
+        }
+        if (my_group >= 0) {
+            const float gx = gsum * mul;
+            const float a = e_m1 * beta1 + (1.f - beta1) * gx;
+            const float b = e_m2 * beta2 + (1.f - beta2) * (gx * gx);
+            m1[i] = a;
+            m2[i] = b;
+            const float denom = sqrtf(b) / bc2_sqrt + eps;
+            params[i] = e_p - step_size * (a / denom);
+        }
+        return;
+    }
     if (!s_last) return;
 
     // ---- the last workgroup: ONE agent-scope acquire (drops this CU's stale L1 lines), then plain loads -- the compiler
@@ -208,10 +256,10 @@ static RaScratch g_ra[32];
 
 }  // namespace
 
-extern "C" int erl_reduce_clip_adam_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
-                                        float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
-                                        int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
-                                        float grad_scale, void *stream)
+static int reduce_clip_adam_launch(bool grid_wait, const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
+                                   float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
+                                   int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                                   float grad_scale, void *stream)
 {
     ERL_REQUIRE(slabs && flat_grad && params && exp_avg && exp_avg_sq && group_off && group_len, "erl_reduce_clip_adam_f32: NULL argument");
     ERL_REQUIRE(n_slabs >= 1 && stride >= 1 && n_groups >= 1 && n_groups <= 4 && step >= 1, "erl_reduce_clip_adam_f32: bad argument");
@@ -244,10 +292,37 @@ extern "C" int erl_reduce_clip_adam_f32(const float *slabs, int n_slabs, int64_t
     const unsigned target = sc.base + (unsigned)nblk;
     sc.base = target;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(reduce_clip_adam_kernel, dim3((unsigned)nblk), dim3(RA_T), 0, st, slabs, n_slabs, stride, flat_grad, params, exp_avg,
-                       exp_avg_sq, gr, n_groups, lr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1), (float)sqrt(bc2),
-                       reinterpret_cast<double *>(sc.ptr + 256), reinterpret_cast<unsigned *>(sc.ptr), target);
+    if (grid_wait)
+        hipLaunchKernelGGL(reduce_clip_adam_kernel<true>, dim3((unsigned)nblk), dim3(RA_T), 0, st, slabs, n_slabs, stride, flat_grad, params,
+                           exp_avg, exp_avg_sq, gr, n_groups, lr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
+                           (float)sqrt(bc2), reinterpret_cast<double *>(sc.ptr + 256), reinterpret_cast<unsigned *>(sc.ptr), target,
+                           erl_fault_word());
+    else
+        hipLaunchKernelGGL(reduce_clip_adam_kernel<false>, dim3((unsigned)nblk), dim3(RA_T), 0, st, slabs, n_slabs, stride, flat_grad, params,
+                           exp_avg, exp_avg_sq, gr, n_groups, lr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
+                           (float)sqrt(bc2), reinterpret_cast<double *>(sc.ptr + 256), reinterpret_cast<unsigned *>(sc.ptr), target,
+                           (uint32_t *)nullptr);
     ERL_LAUNCH_CHECK("erl_reduce_clip_adam_f32");
+}
+
+// 1 when the grid-wait form of erl_reduce_clip_adam_f32 may be used for a gradient row of `stride` floats on the current
+// device: every workgroup of the launch fits on the device at once (occupancy of the kernel x compute units)
+extern "C" int erl_reduce_clip_adam_grid_ok(int64_t stride)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+    static int capacity[32] = {0};
+    if (!capacity[dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_clip_adam_kernel<true>, RA_T, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            capacity[dev] = -1;
+        } else {
+            capacity[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+        }
+    }
+    return capacity[dev] > 0 && erl_cdiv(stride, RA_E) <= capacity[dev];
 }
 
 extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
@@ -279,3 +354,25 @@ extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_a
     ERL_LAUNCH_CHECK("erl_clip_adam_f32");
 }
 
+
+extern "C" int erl_reduce_clip_adam_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
+                                        float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
+                                        int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                                        float grad_scale, void *stream)
+{
+    return reduce_clip_adam_launch(false, slabs, n_slabs, stride, flat_grad, params, exp_avg, exp_avg_sq, group_off, group_len, n_groups, step,
+                                   lr, beta1, beta2, eps, max_norm, grad_scale, stream);
+}
+
+// The same in the grid-wait form (every workgroup waits for the norm and updates its own elements); EINVAL when the launch
+// would not fit on the device at once (erl_reduce_clip_adam_grid_ok).
+extern "C" int erl_reduce_clip_adam_grid_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
+                                             float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
+                                             int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                                             float grad_scale, void *stream)
+{
+    ERL_REQUIRE(erl_reduce_clip_adam_grid_ok(stride), "erl_reduce_clip_adam_grid_f32: %lld-float row does not fit the device in one wave of workgroups",
+                (long long)stride);
+    return reduce_clip_adam_launch(true, slabs, n_slabs, stride, flat_grad, params, exp_avg, exp_avg_sq, group_off, group_len, n_groups, step,
+                                   lr, beta1, beta2, eps, max_norm, grad_scale, stream);
+}

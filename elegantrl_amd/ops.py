@@ -328,15 +328,21 @@ def clip_adam(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, groups: Se
 
 def reduce_clip_adam(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN, params: TEN, exp_avg: TEN, exp_avg_sq: TEN,
                      groups: Sequence[Tuple[int, int]], step: int, lr: float, max_norm: float, grad_scale: float = 1.0,
-                     betas=(0.9, 0.999), eps: float = 1e-8) -> None:
-    """grad_reduce + clip_adam in one launch (the single-process minibatch loop's tail)."""
+                     betas=(0.9, 0.999), eps: float = 1e-8, grid_wait: bool = False) -> None:
+    """grad_reduce + clip_adam in one launch (the single-process minibatch loop's tail).  grid_wait: every workgroup waits for
+    the norm and updates its own elements (erl_reduce_clip_adam_grid_f32; needs `reduce_clip_adam_grid_ok(stride)`), instead
+    of the last-arriving workgroup applying Adam alone."""
     n = len(groups)
     off = (ctypes.c_int64 * n)(*[g[0] for g in groups])
     ln = (ctypes.c_int64 * n)(*[g[1] for g in groups])
-    check(lib().erl_reduce_clip_adam_f32(ptr(slabs, th.float32), n_slabs, stride, ptr(flat_grad, th.float32), ptr(params, th.float32),
-                                         ptr(exp_avg, th.float32), ptr(exp_avg_sq, th.float32), off, ln, n, step, lr, betas[0], betas[1],
-                                         eps, max_norm, grad_scale, stream_ptr()),
-          "erl_reduce_clip_adam_f32")
+    fn = lib().erl_reduce_clip_adam_grid_f32 if grid_wait else lib().erl_reduce_clip_adam_f32
+    check(fn(ptr(slabs, th.float32), n_slabs, stride, ptr(flat_grad, th.float32), ptr(params, th.float32), ptr(exp_avg, th.float32),
+             ptr(exp_avg_sq, th.float32), off, ln, n, step, lr, betas[0], betas[1], eps, max_norm, grad_scale, stream_ptr()),
+          "erl_reduce_clip_adam_grid_f32" if grid_wait else "erl_reduce_clip_adam_f32")
+
+
+def reduce_clip_adam_grid_ok(stride: int) -> bool:
+    return bool(lib().erl_reduce_clip_adam_grid_ok(stride))
 
 
 def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int,

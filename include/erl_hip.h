@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 9
+#define ERL_ABI_VERSION 10
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -268,6 +268,17 @@ ERL_API int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg,
  * gradient bit for bit (same summation order), written to flat_grad; the workgroup that finishes last derives the clip
  * coefficients from per-workgroup fp64 partial norms (fixed order) and applies Adam.  No workgroup waits on another. */
 ERL_API int erl_reduce_clip_adam_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
+                             float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
+                             int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                             float grad_scale, void *stream);
+
+/* The same in the grid-wait form: every workgroup waits for the last partial norm (device counter) and updates its own
+ * 256 elements from registers -- one launch, no single-workgroup Adam phase.  Valid only when the whole launch is resident
+ * at once: erl_reduce_clip_adam_grid_ok(stride) (occupancy x compute units >= ceil(stride / 256)); EINVAL otherwise.  The
+ * wait is bounded and reports through erl_async_fault_count.  Default optimiser tail of erl_ppo_update_f32 when it applies
+ * (ERL_FUSED_TAIL=0 restores the two launches). */
+ERL_API int erl_reduce_clip_adam_grid_ok(int64_t stride);
+ERL_API int erl_reduce_clip_adam_grid_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
                              float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
                              int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
                              float grad_scale, void *stream);

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch as th
 
+from elegantrl_amd import _hip
 from oracle import c_oracle
 from oracle import ppo_numpy as O
 from tests.helpers import PPO_GOLDENS, dims, hyper, load, mlp_from
@@ -561,9 +562,11 @@ def test_clip_adam_matches_oracle(ops, dev):
         np.testing.assert_allclose(P.cpu().numpy(), np.concatenate([pa[0], pc[0]]), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("grid_wait", [False, True])
 @pytest.mark.parametrize("n_slabs,Pa,Pc,max_norm", [(128, 25872, 24961, 3.0), (128, 25872, 24961, 1e9), (7, 1000, 37, 0.5), (1, 300, 200, 3.0)])
-def test_reduce_clip_adam_equals_the_two_kernel_tail(ops, dev, n_slabs, Pa, Pc, max_norm):
-    """erl_reduce_clip_adam_f32 (one launch, last-arriver) against erl_grad_reduce_f32 + erl_clip_adam_f32: the reduced gradient
+def test_reduce_clip_adam_equals_the_two_kernel_tail(ops, dev, n_slabs, Pa, Pc, max_norm, grid_wait):
+    """erl_reduce_clip_adam_f32 (one launch, last-arriver) and erl_reduce_clip_adam_grid_f32 (one launch, every workgroup waits
+    for the norm) against erl_grad_reduce_f32 + erl_clip_adam_f32: the reduced gradient
     bit for bit (same association), parameters and moments to fp32 round-off of the norm (fp64 partial sums in another order),
     over several back-to-back steps (the arrival counter is monotonic across launches)."""
     g = th.Generator(device=dev).manual_seed(n_slabs + Pa)
@@ -573,15 +576,19 @@ def test_reduce_clip_adam_equals_the_two_kernel_tail(ops, dev, n_slabs, Pa, Pc, 
     pa, ma, va = p0.clone(), th.zeros_like(p0), th.zeros_like(p0)
     pb, mb, vb = p0.clone(), th.zeros_like(p0), th.zeros_like(p0)
     fa, fb = th.empty(stride, device=dev), th.empty(stride, device=dev)
+    if grid_wait:
+        assert ops.reduce_clip_adam_grid_ok(stride)
     for step in range(1, 6):
         slabs = th.randn((n_slabs, stride), device=dev, generator=g) * (0.1 if step % 2 else 10.0)
         ops.grad_reduce(slabs, n_slabs, stride, fa)
         ops.clip_adam(pa, fa, ma, va, groups, step, 1e-3, max_norm)
-        ops.reduce_clip_adam(slabs, n_slabs, stride, fb, pb, mb, vb, groups, step, 1e-3, max_norm)
+        ops.reduce_clip_adam(slabs, n_slabs, stride, fb, pb, mb, vb, groups, step, 1e-3, max_norm, grid_wait=grid_wait)
         assert th.equal(fa, fb)
         for x, y in ((pa, pb), (ma, mb), (va, vb)):
             np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-6, atol=1e-9)
     assert float((pa - p0).abs().max()) > 1e-4
+    th.cuda.synchronize()
+    _hip.check_async_faults()
 
 
 def test_clip_adam_grad_scale_equals_prescaled(ops, dev):

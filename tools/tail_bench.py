@@ -44,3 +44,4 @@ print(f"grad_reduce            {timeit(lambda: ops.grad_reduce(slabs, n_slabs, s
 print(f"clip_adam              {timeit(lambda: ops.clip_adam(p, f, m, v, groups, 5, 1e-4, 3.0)):7.2f} us")
 print(f"grad_reduce+clip_adam  {timeit(two):7.2f} us")
 print(f"reduce_clip_adam       {timeit(lambda: ops.reduce_clip_adam(slabs, n_slabs, stride, f, p, m, v, groups, 5, 1e-4, 3.0)):7.2f} us")
+print(f"reduce_clip_adam(grid) {timeit(lambda: ops.reduce_clip_adam(slabs, n_slabs, stride, f, p, m, v, groups, 5, 1e-4, 3.0, grid_wait=True)):7.2f} us")
