@@ -110,12 +110,12 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restr
                                                             void *__restrict__ o_action, float *__restrict__ o_reward,
                                                             float *__restrict__ o_undone, float *__restrict__ o_unmask,
                                                             float *__restrict__ o_next, int64_t *__restrict__ o_ids0,
-                                                            int64_t *__restrict__ o_ids1)
+                                                            int64_t *__restrict__ o_ids1, int spw)
 {
     __shared__ int64_t s_row[RS_SAMPLES];
     const int W = 2 * S + A + 3;
-    for (int64_t b0 = (int64_t)blockIdx.x * RS_SAMPLES; b0 < B; b0 += (int64_t)gridDim.x * RS_SAMPLES) {
-        const int nb = (int)min((int64_t)RS_SAMPLES, B - b0);
+    for (int64_t b0 = (int64_t)blockIdx.x * spw; b0 < B; b0 += (int64_t)gridDim.x * spw) {
+        const int nb = (int)min((int64_t)spw, B - b0);
         __syncthreads();   // s_row reuse
         if ((int)threadIdx.x < nb) {
             const int64_t id = ids[b0 + threadIdx.x];
@@ -223,16 +223,23 @@ int replay_sample_impl(const char *what, bool act_u8, const float *buf_states, c
     ERL_REQUIRE(num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0 && sample_len >= 1 && sample_len <= max_size,
                 "%s: bad shape (sample_len=%lld max_size=%lld)", what, (long long)sample_len, (long long)max_size);
     if (B == 0) return ERL_OK;
-    const int g = grid_for(erl_cdiv(B, RS_SAMPLES) * 256);
+    // samples per workgroup: 128 for large batches; a small batch (the SAC step's 256 rows) is spread so that every thread
+    // moves about one element in ONE round trip -- two workgroups looping 14 dependent trips took 28-35 us for 256 rows
+    const int W = 2 * S + A + 3;
+    int64_t spw = B / 1024;
+    if (spw < 256 / W) spw = 256 / W;
+    if (spw < 1) spw = 1;
+    if (spw > RS_SAMPLES) spw = RS_SAMPLES;
+    const int g = grid_for(erl_cdiv(B, spw) * 256);
     hipStream_t st = (hipStream_t)stream;
     if (act_u8)
         hipLaunchKernelGGL((replay_sample_kernel<true>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones,
                            buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone, out_unmask,
-                           out_next_state, out_ids0, out_ids1);
+                           out_next_state, out_ids0, out_ids1, (int)spw);
     else
         hipLaunchKernelGGL((replay_sample_kernel<false>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones,
                            buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone, out_unmask,
-                           out_next_state, out_ids0, out_ids1);
+                           out_next_state, out_ids0, out_ids1, (int)spw);
     return erl_hip_status(hipGetLastError(), what);
 }
 

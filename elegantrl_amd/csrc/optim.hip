@@ -247,6 +247,60 @@ __global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// clip + Adam for LONG groups (more than 64 Ki elements: SAC's critic ensemble, 280k): clip_adam_kernel makes every
+// workgroup read the whole group for the norm, which at 274 workgroups x 1.1 MB is what the launch then costs (17-36 us
+// measured in the SAC step).  Here a workgroup squares only its own 1024 elements, publishes the fp64 partial, arrives on
+// the device counter and WAITS for the others (whole grid resident -- checked by the host, see reduce_clip_adam_kernel),
+// sums the group's partials in a fixed order and updates its elements from registers.  grid = (blocks, n_groups).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void clip_adam_grid_kernel(float *__restrict__ params, const float *__restrict__ grads,
+                                                              float *__restrict__ m1, float *__restrict__ m2, AdamGroups gr, float beta1,
+                                                              float beta2, float eps, float max_norm, float grad_scale, float step_size,
+                                                              float bc2_sqrt, double *partials, unsigned *counter, unsigned target,
+                                                              uint32_t *fault)
+{
+    __shared__ double scratch[16];
+    const int gi = blockIdx.y;
+    const int64_t off = gr.off[gi], len = gr.len[gi];
+    const int64_t ie = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const bool own = ie < len;
+    float e_g = 0.f, e_m1 = 0.f, e_m2 = 0.f, e_p = 0.f;
+    if (own) { e_g = grads[off + ie]; e_m1 = m1[off + ie]; e_m2 = m2[off + ie]; e_p = params[off + ie]; }
+    const double xs = (double)(e_g * grad_scale);
+    const double part = block_sum(own ? xs * xs : 0.0, scratch);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partials + (size_t)gi * gridDim.x + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) {
+                if (fault) __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    double ss = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 1024) ss += partials[(size_t)gi * gridDim.x + b];
+    ss = block_sum(ss, scratch);
+    const float total_norm = (float)sqrt(ss);
+    float coef = max_norm / (total_norm + 1e-6f);   // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+    coef = coef > 1.f ? 1.f : coef;
+    if (own) {
+        const float gx = e_g * (grad_scale * coef);
+        const float a = e_m1 * beta1 + (1.f - beta1) * gx;
+        const float b = e_m2 * beta2 + (1.f - beta2) * (gx * gx);
+        m1[off + ie] = a;
+        m2[off + ie] = b;
+        const float denom = sqrtf(b) / bc2_sqrt + eps;
+        params[off + ie] = e_p - step_size * (a / denom);
+    }
+}
+
 struct RaScratch {
     char *ptr = nullptr;        // [counter (256 B)][partials: kRaMaxBlocks x 4 doubles]
     unsigned base = 0;
@@ -255,6 +309,46 @@ constexpr int kRaMaxBlocks = 8192;
 static RaScratch g_ra[32];
 
 }  // namespace
+
+// the per-device arrival counter and partial-norm table of the single-launch tails, and the counter value the launch that
+// is about to be enqueued completes at (`nblk` arrivals after everything enqueued before it).  One table per device: these
+// launches are meant for ONE stream per device (the update loop's); launches from concurrent streams would share the counter.
+static int ra_arrivals(const char *what, int64_t nblk, hipStream_t st, RaScratch **out, unsigned *target)
+{
+    int dev = -1;
+    ERL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32, "%s: no device", what);
+    RaScratch &sc = g_ra[dev];
+    if (!sc.ptr) {
+        void *ptr = nullptr;
+        const size_t bytes = 256 + (size_t)kRaMaxBlocks * 4 * sizeof(double);
+        int rc = erl_hip_status(hipMalloc(&ptr, bytes), "hipMalloc(arrival scratch)");
+        if (rc) return rc;
+        if ((rc = erl_hip_status(hipMemset(ptr, 0, bytes), "hipMemset(arrival scratch)"))) return rc;
+        sc.ptr = (char *)ptr;
+        sc.base = 0;
+    }
+    if ((uint64_t)sc.base + (uint64_t)nblk >= 0x7fffff00ull) {      // the arrival counter is about to wrap: restart it behind earlier work
+        int rc = erl_hip_status(hipMemsetAsync(sc.ptr, 0, 256, st), "hipMemsetAsync(arrival counter)");
+        if (rc) return rc;
+        sc.base = 0;
+    }
+    *target = sc.base + (unsigned)nblk;
+    sc.base = *target;
+    *out = &sc;
+    return ERL_OK;
+}
+
+static int device_capacity(const void *kernel, int threads)
+{
+    int dev = -1, per_cu = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return per_cu * cus > 0 ? per_cu * cus : -1;
+}
 
 static int reduce_clip_adam_launch(bool grid_wait, const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
                                    float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
@@ -271,26 +365,14 @@ static int reduce_clip_adam_launch(bool grid_wait, const float *slabs, int n_sla
     }
     const int64_t nblk = erl_cdiv(stride, RA_E);
     ERL_REQUIRE(nblk <= kRaMaxBlocks, "erl_reduce_clip_adam_f32: gradient row too long (%lld floats)", (long long)stride);
-    int dev = -1;
-    ERL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32, "erl_reduce_clip_adam_f32: no device");
-    RaScratch &sc = g_ra[dev];
+    RaScratch *scp = nullptr;
+    unsigned target = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (!sc.ptr) {
-        void *ptr = nullptr;
-        const size_t bytes = 256 + (size_t)kRaMaxBlocks * 4 * sizeof(double);
-        int rc = erl_hip_status(hipMalloc(&ptr, bytes), "hipMalloc(reduce_clip_adam scratch)");
+    {
+        int rc = ra_arrivals("erl_reduce_clip_adam_f32", nblk, st, &scp, &target);
         if (rc) return rc;
-        if ((rc = erl_hip_status(hipMemset(ptr, 0, bytes), "hipMemset(reduce_clip_adam scratch)"))) return rc;
-        sc.ptr = (char *)ptr;
-        sc.base = 0;
     }
-    if ((uint64_t)sc.base + (uint64_t)nblk >= 0xffffff00ull) {      // the arrival counter is about to wrap: restart it behind earlier work
-        int rc = erl_hip_status(hipMemsetAsync(sc.ptr, 0, 256, st), "hipMemsetAsync(arrival counter)");
-        if (rc) return rc;
-        sc.base = 0;
-    }
-    const unsigned target = sc.base + (unsigned)nblk;
-    sc.base = target;
+    RaScratch &sc = *scp;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     if (grid_wait)
         hipLaunchKernelGGL(reduce_clip_adam_kernel<true>, dim3((unsigned)nblk), dim3(RA_T), 0, st, slabs, n_slabs, stride, flat_grad, params,
@@ -312,16 +394,7 @@ extern "C" int erl_reduce_clip_adam_grid_ok(int64_t stride)
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
     static int capacity[32] = {0};
-    if (!capacity[dev]) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_clip_adam_kernel<true>, RA_T, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            capacity[dev] = -1;
-        } else {
-            capacity[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
-        }
-    }
+    if (!capacity[dev]) capacity[dev] = device_capacity((const void *)reduce_clip_adam_kernel<true>, RA_T);
     return capacity[dev] > 0 && erl_cdiv(stride, RA_E) <= capacity[dev];
 }
 
@@ -342,6 +415,24 @@ extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_a
     }
     int bx = (int)erl_cdiv(longest, 1024);   // one element per thread in the Adam phase (latency bound: no serial loop)
     if (bx < 1) bx = 1;
+    if (bx > 64 && !step_base) {             // long groups: partial norms + a grid-wide wait, if the whole launch is resident at once
+        int dev = -1;
+        static int capacity[32] = {0};
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32) {
+            if (!capacity[dev]) capacity[dev] = device_capacity((const void *)clip_adam_grid_kernel, 1024);
+            if ((int64_t)bx * n_groups <= capacity[dev] && (int64_t)bx * n_groups <= kRaMaxBlocks * 4) {
+                RaScratch *sc = nullptr;
+                unsigned target = 0;
+                int rc = ra_arrivals("erl_clip_adam_f32", (int64_t)bx * n_groups, (hipStream_t)stream, &sc, &target);
+                if (rc) return rc;
+                const double bc1 = 1.0 - pow((double)beta1, (double)step_offset), bc2 = 1.0 - pow((double)beta2, (double)step_offset);
+                hipLaunchKernelGGL(clip_adam_grid_kernel, dim3(bx, n_groups), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg,
+                                   exp_avg_sq, gr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1), (float)sqrt(bc2),
+                                   reinterpret_cast<double *>(sc->ptr + 256), reinterpret_cast<unsigned *>(sc->ptr), target, erl_fault_word());
+                ERL_LAUNCH_CHECK("erl_clip_adam_f32");
+            }
+        }
+    }
     if (bx > 64) bx = 64;
     float step_size = 0.f, bc2_sqrt = 1.f;
     if (!step_base) {

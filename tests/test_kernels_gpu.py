@@ -546,9 +546,11 @@ def test_ppo_step_objective_forms(ops, dev, S, h1, h2, A, objective):
     np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
 
 
-def test_clip_adam_matches_oracle(ops, dev):
+@pytest.mark.parametrize("n_a,n_c", [(25872, 24961), (279556, 70662), (70000, 5)])
+def test_clip_adam_matches_oracle(ops, dev, n_a, n_c):
+    """(25872, 24961): one element per thread; groups beyond 64 Ki elements take the partial-norm + grid-wait kernel (SAC's
+    critic ensemble and actor sizes), also next to a short group in the same launch."""
     rng = np.random.default_rng(9)
-    n_a, n_c = 25872, 24961
     p = rng.standard_normal(n_a + n_c).astype(np.float32)
     P, M1, M2 = cu(p, dev), th.zeros(n_a + n_c, device=dev), th.zeros(n_a + n_c, device=dev)
     pa, pc = [p[:n_a].copy()], [p[n_a:].copy()]
@@ -560,6 +562,8 @@ def test_clip_adam_matches_oracle(ops, dev):
         O.optimizer_backward(pa, [g[:n_a]], sa, 1e-3, 3.0)
         O.optimizer_backward(pc, [g[n_a:]], sc, 1e-3, 3.0)
         np.testing.assert_allclose(P.cpu().numpy(), np.concatenate([pa[0], pc[0]]), rtol=0, atol=2e-6)
+    th.cuda.synchronize()
+    _hip.check_async_faults()
 
 
 @pytest.mark.parametrize("grid_wait", [False, True])
