@@ -38,6 +38,10 @@ struct GemmArgs {
     int64_t c_split;          // PARTIAL: floats between consecutive partial C's
     float *rowsum;            // PARTIAL: sum_k A(i, k) of the split (may be NULL)
     int64_t rs_split;         // PARTIAL: floats between consecutive partial row-sum vectors
+    // batched launch (gemm_small_kernel only: the SAC critic ensemble's E same-shaped layers in one grid): problem b uses
+    // A + b sA, B + b sB, C + b sC, bias + b sBias, G + b sG, rowsum + b sRS; blockIdx.z = b * nsplit + split
+    int nbatch, nsplit;
+    int64_t sA, sB, sC, sBias, sG, sRS;
 };
 
 // A thread's eight elements (two groups of four) of a 64 x 32 operand tile.  VEC (16-byte aligned base, ld % 4 == 0 and the
@@ -214,24 +218,26 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g)
     __shared__ float red[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int i0 = blockIdx.y * ST, j0 = blockIdx.x * ST;
+    const int batch = (int)blockIdx.z / g.nsplit, split = (int)blockIdx.z - batch * g.nsplit;
+    const float *gA = g.A + (size_t)batch * g.sA, *gB = g.B + (size_t)batch * g.sB;
     int kb = 0, ke = g.K;
     if (EPI == EPI_PARTIAL) {
-        kb = blockIdx.z * g.kchunk;
+        kb = split * g.kchunk;
         ke = min(g.K, kb + g.kchunk);
     }
     const bool want_rs = EPI == EPI_PARTIAL && g.rowsum != nullptr && blockIdx.x == 0;
     float ra[8], rb[8], rsum = 0.f;
     f32x16 acc = {0};
-    small_load<AOP>(ra, g.A, g.lda, i0, g.M, kb, ke, tid);
-    small_load<BOP>(rb, g.B, g.ldb, j0, g.N, kb, ke, tid);
+    small_load<AOP>(ra, gA, g.lda, i0, g.M, kb, ke, tid);
+    small_load<BOP>(rb, gB, g.ldb, j0, g.N, kb, ke, tid);
     for (int k0 = kb; k0 < ke; k0 += SK) {
         __syncthreads();
         small_store<AOP>(ra, As, tid);
         small_store<BOP>(rb, Bs, tid);
         __syncthreads();
         if (k0 + SK < ke) {
-            small_load<AOP>(ra, g.A, g.lda, i0, g.M, k0 + SK, ke, tid);
-            small_load<BOP>(rb, g.B, g.ldb, j0, g.N, k0 + SK, ke, tid);
+            small_load<AOP>(ra, gA, g.lda, i0, g.M, k0 + SK, ke, tid);
+            small_load<BOP>(rb, gB, g.ldb, j0, g.N, k0 + SK, ke, tid);
         }
         const float *a = As + (16 * wave + hi) * SLD + l31, *b = Bs + (16 * wave + hi) * SLD + l31;
 #pragma unroll
@@ -246,9 +252,10 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g)
     __syncthreads();
 
     const int j = j0 + l31;
-    float *C = g.C + (EPI == EPI_PARTIAL ? (size_t)blockIdx.z * g.c_split : 0);
+    float *C = g.C + (size_t)batch * g.sC + (EPI == EPI_PARTIAL ? (size_t)split * g.c_split : 0);
+    float *Gm = g.G ? g.G + (size_t)batch * g.sG : nullptr;
     if (j < g.N) {
-        const float bj = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? g.bias[j] : 0.f;
+        const float bj = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? g.bias[(size_t)batch * g.sBias + j] : 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 4 * wave + q;
@@ -259,25 +266,29 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g)
                 if (EPI == EPI_STORE || EPI == EPI_PARTIAL) C[o] = v;
                 else if (EPI == EPI_ACC) C[o] += v;
                 else if (EPI == EPI_BIAS) C[o] = v + bj;
-                else if (EPI == EPI_MUL) C[o] = v * g.G[o];
+                else if (EPI == EPI_MUL) C[o] = v * Gm[o];
                 else {
                     float y, gd;
                     gelu_and_grad_fast(v + bj, y, gd);
                     C[o] = y;
-                    if (g.G) g.G[o] = gd;
+                    if (Gm) Gm[o] = gd;
                 }
             }
         }
     }
-    if (want_rs && tid < ST && i0 + tid < g.M) g.rowsum[(size_t)blockIdx.z * g.rs_split + i0 + tid] = rsum;
+    if (want_rs && tid < ST && i0 + tid < g.M) g.rowsum[(size_t)batch * g.sRS + (size_t)split * g.rs_split + i0 + tid] = rsum;
 }
 
 template <int AOP, int BOP, int EPI>
-int gemm_launch(hipStream_t s, const GemmArgs &g, int splits, const char *what)
+int gemm_launch(hipStream_t s, const GemmArgs &g_in, int splits, const char *what)
 {
+    GemmArgs g = g_in;
+    if (g.nbatch < 1) g.nbatch = 1;
+    g.nsplit = splits;
     const int64_t tiles64 = erl_cdiv(g.N, GT) * erl_cdiv(g.M, GT) * splits;
-    if (tiles64 < 128) {       // fewer 64 x 64 tiles than half the CUs: 32 x 32 tiles with the reduction split over the waves
-        const dim3 grid((unsigned)erl_cdiv(g.N, ST), (unsigned)erl_cdiv(g.M, ST), (unsigned)splits);
+    if (tiles64 < 128 || g.nbatch > 1) {   // fewer 64 x 64 tiles than half the CUs (or a batch of small problems): 32 x 32 tiles with the
+                                           // reduction split over the waves
+        const dim3 grid((unsigned)erl_cdiv(g.N, ST), (unsigned)erl_cdiv(g.M, ST), (unsigned)(splits * g.nbatch));
         hipLaunchKernelGGL((gemm_small_kernel<AOP, BOP, EPI>), grid, dim3(256), 0, s, g);
     } else {
         const dim3 grid((unsigned)erl_cdiv(g.N, GT), (unsigned)erl_cdiv(g.M, GT), (unsigned)splits);

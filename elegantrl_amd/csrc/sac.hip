@@ -188,6 +188,7 @@ struct CriticWs {
     float *act[MAXE][MAXL + 2];       // decoder activations; act[e][0] = enc
     float *gd[MAXE][MAXL + 2];
     float *q;                         // [E][B]
+    int64_t st[MAXL + 2];             // floats between decoder e and e + 1 of act[.][l] / gd[.][l] (0: the shared encoder output)
 };
 
 int64_t critic_ws_floats(const SacDims &d, int64_t B)
@@ -201,17 +202,102 @@ bool carve_critic(Ws &ws, const SacDims &d, int64_t B, CriticWs *c)
 {
     c->enc = ws.take(B * d.enc.d[1]);
     c->q = ws.take((int64_t)d.E * B);
+    c->st[0] = 0;
+    c->st[d.dec.n] = B;
+    bool ok = c->enc && c->q;
+    for (int l = 1; l < d.dec.n; ++l) {               // layer l of every decoder in one block (the batched GEMMs step by st[l])
+        c->st[l] = ((B * d.dec.d[l] + 63) / 64) * 64;
+        float *a = ws.take((int64_t)d.E * c->st[l]), *g = ws.take((int64_t)d.E * c->st[l]);
+        ok = ok && a && g;
+        for (int e = 0; e < d.E; ++e) {
+            c->act[e][l] = a + (size_t)e * c->st[l];
+            c->gd[e][l] = g + (size_t)e * c->st[l];
+        }
+    }
     for (int e = 0; e < d.E; ++e) {
         c->act[e][0] = c->enc;
         c->gd[e][0] = nullptr;
-        for (int l = 1; l < d.dec.n; ++l) {
-            c->act[e][l] = ws.take(B * d.dec.d[l]);
-            c->gd[e][l] = ws.take(B * d.dec.d[l]);
-        }
         c->act[e][d.dec.n] = c->q + (size_t)e * B;   // (B, 1) output column of decoder e
         c->gd[e][d.dec.n] = nullptr;
     }
-    return c->act[d.E - 1][d.dec.n - 1] != nullptr && c->q != nullptr;
+    return ok;
+}
+
+// The E decoders are E same-shaped MLPs on their own parameter blocks (dec.count apart): at the off-policy batch sizes each of
+// their layers is a 5-8 us launch-bound GEMM, so the ensemble runs as ONE batched launch per layer (blockIdx.z = decoder).
+constexpr int64_t kBatchedRows = 1024;   // above this the per-decoder launches fill the device on their own (64 x 64 tiles)
+
+int decoders_forward(hipStream_t s, const SacDims &d, const float *Pdec, int64_t B, CriticWs &c, bool keep)
+{
+    const NetDims &nd = d.dec;
+    for (int l = 0; l < nd.n; ++l) {
+        const bool hidden = l + 1 < nd.n;
+        GemmArgs g{};
+        g.A = c.act[0][l]; g.sA = c.st[l]; g.lda = nd.d[l];
+        g.B = Pdec + nd.oW[l]; g.sB = nd.count; g.ldb = nd.d[l];
+        g.M = (int)B; g.N = nd.d[l + 1]; g.K = nd.d[l];
+        g.C = c.act[0][l + 1]; g.sC = c.st[l + 1]; g.ldc = nd.d[l + 1];
+        g.bias = Pdec + nd.ob[l]; g.sBias = nd.count;
+        g.G = hidden && keep ? c.gd[0][l + 1] : nullptr; g.sG = c.st[l + 1];
+        g.nbatch = d.E;
+        int rc = hidden ? gemm_launch<OP_RC, OP_RC, EPI_BIAS_GELU>(s, g, 1, "decoders_forward") : gemm_launch<OP_RC, OP_RC, EPI_BIAS>(s, g, 1, "decoders_forward");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// dst = ((src_0 + src_1) + src_2) + ...: the order in which the per-decoder launches accumulated into the encoder gradient
+__global__ __launch_bounds__(256) void sum_batches_kernel(const float *__restrict__ src, int E, int64_t stride, int64_t n, float *__restrict__ dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = src[i];
+        for (int e = 1; e < E; ++e) v += src[(size_t)e * stride + i];
+        dst[i] = v;
+    }
+}
+
+// backward through all E decoders: dq [E][B] -> parameter gradients Gdec (E blocks, dec.count apart; may be NULL) and the
+// encoder-output gradient dEnc (B, h0) = sum_e.  tmpA / tmpB: E x tmp_stride floats each; dEncE: E x enc_stride floats.
+int decoders_backward(hipStream_t s, const SacDims &d, const float *Pdec, int64_t B, CriticWs &c, const float *dq, float *Gdec,
+                      float *dEnc, float *dEncE, int64_t enc_stride, float *tmpA, float *tmpB, int64_t tmp_stride)
+{
+    const NetDims &nd = d.dec;
+    const float *dZ = dq;
+    int64_t sdZ = B;
+    int rc;
+    for (int l = nd.n - 1; l >= 0; --l) {
+        const int K = nd.d[l], Nw = nd.d[l + 1];
+        if (Gdec) {                                   // dW = dZ^T . X, db = column sums of dZ (the GEMM's row sums)
+            GemmArgs g{};
+            g.A = dZ; g.sA = sdZ; g.lda = Nw;
+            g.B = c.act[0][l]; g.sB = c.st[l]; g.ldb = K;
+            g.M = Nw; g.N = K; g.K = (int)B; g.ldc = K;
+            g.kchunk = (int)B;
+            g.C = Gdec + nd.oW[l]; g.sC = nd.count; g.c_split = 0;
+            g.rowsum = Gdec + nd.ob[l]; g.sRS = nd.count; g.rs_split = 0;
+            g.nbatch = d.E;
+            if ((rc = gemm_launch<OP_OC, OP_OC, EPI_PARTIAL>(s, g, 1, "decoders_backward(dW)"))) return rc;
+        }
+        GemmArgs g{};
+        g.A = dZ; g.sA = sdZ; g.lda = Nw;
+        g.B = Pdec + nd.oW[l]; g.sB = nd.count; g.ldb = K;
+        g.M = (int)B; g.N = K; g.K = Nw; g.ldc = K;
+        g.nbatch = d.E;
+        if (l > 0) {
+            float *dH = (dZ == tmpA) ? tmpB : tmpA;
+            g.C = dH; g.sC = tmp_stride;
+            g.G = c.gd[0][l]; g.sG = c.st[l];
+            if ((rc = gemm_launch<OP_RC, OP_OC, EPI_MUL>(s, g, 1, "decoders_backward(dX)"))) return rc;
+            dZ = dH;
+            sdZ = tmp_stride;
+        } else {
+            g.C = dEncE; g.sC = enc_stride;
+            if ((rc = gemm_launch<OP_RC, OP_OC, EPI_STORE>(s, g, 1, "decoders_backward(dEnc)"))) return rc;
+            const int64_t n = B * K;
+            hipLaunchKernelGGL(sum_batches_kernel, dim3(grid1d(n)), dim3(256), 0, s, dEncE, d.E, enc_stride, n, dEnc);
+        }
+    }
+    return erl_hip_status(hipGetLastError(), "decoders_backward");
 }
 
 int critic_forward(hipStream_t s, const SacDims &d, const float *P, int64_t B, float *xa, CriticWs &c, bool keep)
@@ -219,6 +305,7 @@ int critic_forward(hipStream_t s, const SacDims &d, const float *P, int64_t B, f
     float *ea[2] = {xa, c.enc};
     int rc = forward(s, d.enc, P, B, ea, nullptr);      // one raw linear layer
     if (rc) return rc;
+    if (B <= kBatchedRows) return decoders_forward(s, d, P + d.enc.count, B, c, keep);
     for (int e = 0; e < d.E; ++e)
         if ((rc = forward(s, d.dec, P + d.enc.count + (int64_t)e * d.dec.count, B, c.act[e], keep ? c.gd[e] : nullptr))) return rc;
     return 0;
@@ -248,7 +335,7 @@ extern "C" int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int 
     f += critic_ws_floats(d, B);
     f += 4 * (B * A + 64) + 6 * (B + 64) + (int64_t)d.E * B + 64;    // actions, eps, dA, t | logprobs, label, ... | dq
     f += colsum_scratch_floats(B, maxd) + 64;                        // bias-gradient partials
-    f += 3 * (B * maxd + 64) + B * 2 * A + 64;                       // tmpA, tmpB, dEnc, dHead
+    f += (2 * (int64_t)E + 1) * (B * maxd + 64) + (int64_t)E * (B * hidden[0] + 64) + B * 2 * A + 64;   // tmpA, tmpB (per decoder), dEnc, per-decoder dEnc, dHead
     f += d.Pa + d.Pc + 64 + 1024;                                     // gradients, partials
     return f * 4 + 8192;
 }
@@ -287,7 +374,10 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     float *act_t = ws.take(B * A), *eps_used = ws.take(B * A), *dAct = ws.take(B * A);
     float *lp_next = ws.take(B), *lp_cur = ws.take(B), *label = ws.take(B), *cs_scr = ws.take(colsum_scratch_floats(B, maxd));   // bias-gradient partials
     float *dq = ws.take((int64_t)E * B);
-    float *tmpA = ws.take(B * maxd), *tmpB = ws.take(B * maxd), *dEnc = ws.take(B * d.enc.d[1]);
+    const int64_t tmp_stride = ((B * maxd + 63) / 64) * 64, enc_stride = ((B * d.enc.d[1] + 63) / 64) * 64;
+    float *tmpA = ws.take((int64_t)E * tmp_stride), *tmpB = ws.take((int64_t)E * tmp_stride), *dEnc = ws.take(B * d.enc.d[1]);
+    float *dEncE = ws.take((int64_t)E * enc_stride);
+    const bool batched = B <= kBatchedRows;
     float *dHead = ws.take(B * 2 * A);
     float *g_actor = ws.take(d.Pa), *g_critic = ws.take(d.Pc), *g_alpha = ws.take(4);
     const int nparts = (int)erl_cdiv(B, 256);
@@ -309,11 +399,17 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     if ((rc = critic_forward(s, d, critic_params, B, xa, cw, true))) return rc;
     hipLaunchKernelGGL(critic_loss_kernel, rows_grid, blk, 0, s, cw.q, label, unmask, is_weight, E, B, dq, td_error_out, part);
     hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, part, (int64_t)nparts, 1.0f / (float)B, 0.f, objs_out);
-    for (int e = 0; e < E; ++e) {
-        float *Gdec = g_critic + d.enc.count + (int64_t)e * d.dec.count;
-        if ((rc = backward(s, d.dec, critic_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
-                           Gdec, cs_scr, dEnc, e > 0, tmpA, tmpB)))
+    if (batched) {
+        if ((rc = decoders_backward(s, d, critic_params + d.enc.count, B, cw, dq, g_critic + d.enc.count, dEnc, dEncE, enc_stride, tmpA, tmpB,
+                                    tmp_stride)))
             return rc;
+    } else {
+        for (int e = 0; e < E; ++e) {
+            float *Gdec = g_critic + d.enc.count + (int64_t)e * d.dec.count;
+            if ((rc = backward(s, d.dec, critic_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
+                               Gdec, cs_scr, dEnc, e > 0, tmpA, tmpB)))
+                return rc;
+        }
     }
     {   // encoder: one raw linear layer, input xa
         float *ea[2] = {xa, cw.enc};
@@ -346,10 +442,15 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     if ((rc = critic_forward(s, d, target_params, B, xa, cw, true))) return rc;
     hipLaunchKernelGGL(actor_obj_kernel, dim3(1), blk, 0, s, cw.q, E, B, lp_cur, alpha_log, objs_out + 1);
     hipLaunchKernelGGL(fillk_kernel, dim3(grid1d((int64_t)E * B)), blk, 0, s, dq, -1.0f / ((float)E * (float)B), (int64_t)E * B);
-    for (int e = 0; e < E; ++e)
-        if ((rc = backward(s, d.dec, target_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
-                           nullptr, cs_scr, dEnc, e > 0, tmpA, tmpB)))
+    if (batched) {
+        if ((rc = decoders_backward(s, d, target_params + d.enc.count, B, cw, dq, nullptr, dEnc, dEncE, enc_stride, tmpA, tmpB, tmp_stride)))
             return rc;
+    } else {
+        for (int e = 0; e < E; ++e)
+            if ((rc = backward(s, d.dec, target_params + d.enc.count + (int64_t)e * d.dec.count, B, cw.act[e], cw.gd[e], dq + (size_t)e * B,
+                               nullptr, cs_scr, dEnc, e > 0, tmpA, tmpB)))
+                return rc;
+    }
     if ((rc = dense_backward_input(s, dEnc, target_params, dxa, nullptr, false, (int)B, d.enc.d[1], S + A))) return rc;   // dL/d[state | action]
     // action columns of dxa -> contiguous (B, A)
     (void)hipMemcpy2DAsync(dAct, (size_t)A * 4, dxa + S, (size_t)(S + A) * 4, (size_t)A * 4, (size_t)B, hipMemcpyDeviceToDevice, s);
