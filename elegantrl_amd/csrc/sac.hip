@@ -64,10 +64,14 @@ __global__ __launch_bounds__(256) void concat_kernel(const float *__restrict__ s
 // ActorSAC.get_action_logprob head: Y (B, 2A) = [mean | log_std] -> tanh action, log-prob; keeps eps for the backward
 __global__ __launch_bounds__(256) void head_forward_kernel(const float *__restrict__ Y, const float *__restrict__ noise, uint64_t seed,
                                                            uint64_t counter, int A, int64_t B, float *__restrict__ act_t,
-                                                           float *__restrict__ logprob, float *__restrict__ eps_out)
+                                                           float *__restrict__ logprob, float *__restrict__ eps_out,
+                                                           const float *__restrict__ xs, int S, float *__restrict__ xa)
 {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
+    // the critic's input row [state | action] is written here as well (one launch less than a separate concat)
+    if (xa)
+        for (int c = 0; c < S; ++c) xa[b * (S + A) + c] = xs[b * S + c];
     float lp = 0.f;
     for (int a = 0; a < A; ++a) {
         const float mean = Y[b * 2 * A + a], ls = Y[b * 2 * A + A + a];
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256) void head_forward_kernel(const float *__restri
         const float eps = noise ? noise[b * A + a] : philox_normal(seed, counter, (uint32_t)b, (uint32_t)a);
         const float t = tanhf(mean + sd * eps);
         act_t[b * A + a] = t;
+        if (xa) xa[b * (S + A) + S + a] = t;
         if (eps_out) eps_out[b * A + a] = eps;
         lp += (-logf(sd) - kLogSqrt2PiS) - logf(-(t * t) + 1.000001f);
     }
@@ -131,6 +136,31 @@ __global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, i
     if (threadIdx.x == 0) out[0] = t * scale + bias;
 }
 
+// temperature step in one launch: g = target_entropy - mean(logprob) (sum_kernel's reduction), then clip_adam_kernel's
+// arithmetic for a one-element group (AgentSAC.py:76-79 through AgentBase.optimizer_backward :239-248); g is left in g_out
+__global__ __launch_bounds__(256) void alpha_step_kernel(const float *__restrict__ lp, int64_t n, float target_entropy, float *__restrict__ g_out,
+                                                         float *__restrict__ alpha_log, float *__restrict__ m1, float *__restrict__ m2,
+                                                         float beta1, float beta2, float eps, float max_norm, float step_size, float bc2_sqrt)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += lp[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x != 0) return;
+    const float g = t * (-1.0f / (float)n) + target_entropy;
+    g_out[0] = g;
+    const float total_norm = (float)sqrt((double)g * (double)g);
+    float coef = max_norm / (total_norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    const float gx = g * (1.0f * coef);
+    const float a = m1[0] * beta1 + (1.f - beta1) * gx;
+    const float b = m2[0] * beta2 + (1.f - beta2) * (gx * gx);
+    m1[0] = a;
+    m2[0] = b;
+    const float denom = sqrtf(b) / bc2_sqrt + eps;
+    alpha_log[0] = alpha_log[0] - step_size * (a / denom);
+}
+
 __global__ __launch_bounds__(256) void fillk_kernel(float *__restrict__ p, float v, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
@@ -139,7 +169,7 @@ __global__ __launch_bounds__(256) void fillk_kernel(float *__restrict__ p, float
 // actor objective value and dL/d(head output) for L = -(mean q_pg - alpha * mean logprob)   (AgentSAC.py:74-85)
 //   action = tanh(u), u = mean + std eps, std = exp(clamp(ls, -16, 2));  logprob = sum_a [-log std - c - log(1 - t^2 + 1e-6)]
 __global__ __launch_bounds__(256) void head_backward_kernel(const float *__restrict__ Y, const float *__restrict__ act_t,
-                                                            const float *__restrict__ eps, const float *__restrict__ dA,
+                                                            const float *__restrict__ eps, const float *__restrict__ dA, int ldA,
                                                             const float *__restrict__ alpha_log, int A, int64_t B,
                                                             float *__restrict__ dY)
 {
@@ -153,7 +183,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float *__restr
         const float sd = expf(lsc);
         const float t = act_t[b * A + a];
         const float one_m = 1.f - t * t;
-        const float du = dA[b * A + a] * one_m + dlp * (2.f * t * one_m / (one_m + 1e-6f));
+        const float du = dA[b * ldA + a] * one_m + dlp * (2.f * t * one_m / (one_m + 1e-6f));
         const bool inside = ls >= -16.f && ls <= 2.f;   // clamp passes its gradient inside [min, max]
         dY[b * 2 * A + a] = du;
         dY[b * 2 * A + A + a] = inside ? du * sd * eps[b * A + a] - dlp : 0.f;
@@ -371,7 +401,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     }
     CriticWs cw;
     ERL_REQUIRE(carve_critic(ws, d, B, &cw), "erl_sac_update_f32: workspace layout");
-    float *act_t = ws.take(B * A), *eps_used = ws.take(B * A), *dAct = ws.take(B * A);
+    float *act_t = ws.take(B * A), *eps_used = ws.take(B * A);
     float *lp_next = ws.take(B), *lp_cur = ws.take(B), *label = ws.take(B), *cs_scr = ws.take(colsum_scratch_floats(B, maxd));   // bias-gradient partials
     float *dq = ws.take((int64_t)E * B);
     const int64_t tmp_stride = ((B * maxd + 63) / 64) * 64, enc_stride = ((B * d.enc.d[1] + 63) / 64) * 64;
@@ -386,11 +416,10 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     const dim3 rows_grid((unsigned)erl_cdiv(B, 256)), blk(256);
 
     // ---- (1) targets: next action / log-prob from the actor, min over the TARGET ensemble          (:50-55)
-    (void)hipMemcpyAsync(aact[0], next_state, (size_t)B * S * 4, hipMemcpyDeviceToDevice, s);
+    aact[0] = const_cast<float *>(next_state);                      // the input layer reads the sample in place
     if ((rc = forward(s, d.actor, actor_params, B, aact, nullptr))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_next, seed, 2 * counter, A, B, act_t, lp_next,
-                       (float *)nullptr);
-    hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, next_state, act_t, S, A, B, xa);
+                       (float *)nullptr, next_state, S, xa);
     if ((rc = critic_forward(s, d, target_params, B, xa, cw, false))) return rc;
     hipLaunchKernelGGL(q_label_kernel, rows_grid, blk, 0, s, cw.q, E, B, reward, undone, lp_next, alpha_log, gamma, label);
 
@@ -424,21 +453,18 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     hipLaunchKernelGGL(soft_update_kernel, dim3(grid1d(d.Pc)), blk, 0, s, target_params, critic_params, tau, d.Pc);
 
     // ---- (3) policy-gradient sample, temperature step                                              (:72-81)
-    (void)hipMemcpyAsync(aact[0], state, (size_t)B * S * 4, hipMemcpyDeviceToDevice, s);
+    aact[0] = const_cast<float *>(state);
     if ((rc = forward(s, d.actor, actor_params, B, aact, agd))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_cur, seed, 2 * counter + 1, A, B, act_t, lp_cur,
-                       eps_used);
+                       eps_used, state, S, xa);                 // xa = [state | action_pg] for step (4)
     // obj_alpha = mean(alpha_log * (target_entropy - logprob)):  d/dalpha_log = target_entropy - mean(logprob)
-    hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, lp_cur, B, -1.0f / (float)B, target_entropy, g_alpha);
     {
-        const int64_t off = 0, len = 1;
-        if ((rc = erl_clip_adam_f32(alpha_log, g_alpha, alpha_m, alpha_v, &off, &len, 1, nullptr, step, lr, beta1, beta2, eps_adam, max_norm,
-                                    1.0f, stream)))
-            return rc;
+        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        hipLaunchKernelGGL(alpha_step_kernel, dim3(1), blk, 0, s, lp_cur, B, target_entropy, g_alpha, alpha_log, alpha_m, alpha_v, beta1, beta2,
+                           eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
     }
 
     // ---- (4) actor objective against the TARGET ensemble's mean, backward into the action, head, actor   (:82-85)
-    hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, state, act_t, S, A, B, xa);
     if ((rc = critic_forward(s, d, target_params, B, xa, cw, true))) return rc;
     hipLaunchKernelGGL(actor_obj_kernel, dim3(1), blk, 0, s, cw.q, E, B, lp_cur, alpha_log, objs_out + 1);
     hipLaunchKernelGGL(fillk_kernel, dim3(grid1d((int64_t)E * B)), blk, 0, s, dq, -1.0f / ((float)E * (float)B), (int64_t)E * B);
@@ -452,9 +478,8 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
                 return rc;
     }
     if ((rc = dense_backward_input(s, dEnc, target_params, dxa, nullptr, false, (int)B, d.enc.d[1], S + A))) return rc;   // dL/d[state | action]
-    // action columns of dxa -> contiguous (B, A)
-    (void)hipMemcpy2DAsync(dAct, (size_t)A * 4, dxa + S, (size_t)(S + A) * 4, (size_t)A * 4, (size_t)B, hipMemcpyDeviceToDevice, s);
-    hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dAct, alpha_log, A, B, dHead);
+    // dL/daction = the action columns of dxa, read in place (row stride S + A)
+    hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dxa + S, S + A, alpha_log, A, B, dHead);
     hipLaunchKernelGGL(clamp_alpha_kernel, dim3(1), dim3(64), 0, s, alpha_log);                  // after alpha was read (:80-81)
     if ((rc = backward(s, d.actor, actor_params, B, aact, agd, dHead, g_actor, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
     {
@@ -485,6 +510,6 @@ extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int 
     ERL_REQUIRE(lp != nullptr, "erl_sac_explore_action_f32: workspace too small");
     if ((rc = forward(s, d.actor, actor_params, N, aact, nullptr))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, aact[d.actor.n], noise, seed, counter, A, N,
-                       action_out, lp, (float *)nullptr);
+                       action_out, lp, (float *)nullptr, (const float *)nullptr, S, (float *)nullptr);
     ERL_LAUNCH_CHECK("erl_sac_explore_action_f32");
 }
