@@ -649,3 +649,10 @@ class AgentDiscretePPO(AgentPPO):
         self.last_state = state
         rewards *= self.reward_scale
         return states, actions, logprobs, rewards, th.logical_not(terminals), th.logical_not(truncates)
+
+
+class AgentDiscreteA2C(AgentDiscretePPO):
+    """elegantrl/agents/AgentPPO.py:332-342.  The reference's class derives from AgentDiscretePPO and overrides nothing but the
+    constructor (which rebuilds the same ActorDiscretePPO / CriticPPO / optimisers): `update_net` / `update_objectives` resolve to
+    AgentPPO's -- AgentA2C is not in its MRO -- so it trains with the clipped-scale PPO objective and the categorical entropy
+    term, exactly like AgentDiscretePPO.  Kept as its own class so that `Config(agent_class=AgentDiscreteA2C, ...)` scripts run."""

@@ -1,3 +1,3 @@
 from .AgentBase import AgentBase
-from .AgentPPO import AgentPPO, AgentA2C, AgentDiscretePPO, ActorPPO, ActorDiscretePPO, CriticPPO
+from .AgentPPO import AgentPPO, AgentA2C, AgentDiscretePPO, AgentDiscreteA2C, ActorPPO, ActorDiscretePPO, CriticPPO
 from .AgentSAC import AgentSAC, ActorSAC, CriticEnsemble

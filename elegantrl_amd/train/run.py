@@ -29,8 +29,14 @@ def train_agent(args: Config, if_single_process: bool = False):
 
 
 def train_agent_multiprocessing(args: Config):
-    """The reference spawns Learner/Worker/Evaluator processes here; one in-process actor-learner replaces them."""
-    train_agent_single_process(args)
+    """elegantrl/train/run.py:141-190 spawns one Learner, `num_workers` Worker and one Evaluator process per GPU and moves
+    rollouts through pipes.  Here the env shard lives on the learner's device and the rollout is one kernel launch, so one
+    in-process actor-learner per GPU replaces that process tree: this entry point says so and routes to the same paths as
+    `train_agent` (several `learner_gpu_ids` -> one data-parallel rank per GPU)."""
+    n_workers = int(getattr(args, "num_workers", 1))
+    print(f"| train_agent_multiprocessing(): the Learner / {n_workers} Worker / Evaluator processes of the reference are one "
+          f"in-process actor-learner per GPU here (num_workers is not used)", flush=True)
+    train_agent(args)
 
 
 def train_agent_single_process(args: Config):

@@ -118,9 +118,10 @@ def test_ppo_step_discrete_gradients(ops, S, hidden, A, B):
     np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], [oc, os_, oe], rtol=1e-4, atol=1e-6)
 
 
-def make_agent(g):
+def make_agent(g, agent_class=None):
     from elegantrl_amd.agents import AgentDiscretePPO
     from elegantrl_amd.train import Config
+    AgentDiscretePPO = agent_class or AgentDiscretePPO
     hp = hyper(g)
     N, S, A, H, B, n_upd, _, *net = [int(x) for x in g["dims"]]
     args = Config(AgentDiscretePPO, None, {"env_name": "golden", "num_envs": N, "max_step": 100, "state_dim": S, "action_dim": A,
@@ -154,9 +155,13 @@ def test_agent_rollout_rows_match_reference_logprobs():
         np.testing.assert_allclose(lp.cpu().numpy(), g["logprobs"][t], rtol=1e-4, atol=1e-4)
 
 
-def test_agent_update_net_matches_reference_weights_and_objectives():
+@pytest.mark.parametrize("cls", ["AgentDiscretePPO", "AgentDiscreteA2C"])
+def test_agent_update_net_matches_reference_weights_and_objectives(cls):
+    """AgentDiscreteA2C: the reference's class inherits AgentPPO.update_net through AgentDiscretePPO (AgentPPO.py:332-342 overrides
+    only the constructor), so the same recorded run pins it."""
+    import elegantrl_amd.agents as agents
     g = load("ppo_discrete_small.npz")
-    agent, _ = make_agent(g)
+    agent, _ = make_agent(g, getattr(agents, cls))
     agent.last_state = th.from_numpy(g["last_state"]).to(DEV)
     buf = [th.from_numpy(g[k]).to(DEV) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
     objs = agent.update_net(buf, ids=th.from_numpy(g["ids"]).to(DEV))
