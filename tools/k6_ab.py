@@ -28,10 +28,20 @@ def main():
     ret = th.randn((H, N), device=dev, generator=g)
     um = th.rand((H, N), device=dev, generator=g) < 0.995
     ids = th.randint(H * N, (B,), device=dev, generator=g)
+    # K6_ROTATE=1: another minibatch of the permutation on every launch, as in the PPO loop (the gathered rows are then cold in
+    # L2); K6_ROTATE=2 additionally streams a slab-sized buffer through the caches between launches (what the tail does)
+    rotate = int(os.environ.get("K6_ROTATE", 0))
+    idsets = [th.randint(H * N, (B,), device=dev, generator=g) for _ in range(8)] if rotate else [ids]
+    scrub = th.empty(26 << 18, device=dev) if rotate == 2 else None
+    call = [0]
     stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
     slabs = th.empty((n_slabs, stride), device=dev)
-    run = lambda: ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,  # noqa: E731
-                               ids, 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    def run():
+        call[0] += 1
+        if scrub is not None:
+            scrub.add_(1.0)
+        ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,
+                     idsets[call[0] % len(idsets)], 0.25, 0.001, 1.0 / B, slabs, n_slabs)
     for _ in range(10):
         run()
     th.cuda.synchronize()
