@@ -1,3 +1,4 @@
+# every number quoted in DESIGN.md for round 2: run on the GPU box (gpurun -- bash tools/measure_all.sh), results under gpurun_out/final/
 set -x
 cd /root/repo
 mkdir -p gpurun_out/final
