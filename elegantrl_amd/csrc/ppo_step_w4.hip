@@ -480,46 +480,64 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     // 16-byte LDS reads), the two lane halves meet through v_permlane32_swap, which also leaves outputs a = 4 hi + j of
     // sample m in lane (m, hi) -- the layout the objective and the dZ2 MFMAs want.
     float Y[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-        constexpr int NR = ACTOR ? 8 : 1;
-        f32x2 yp[NR];
+    if (ACTOR) {
+        // The 8 action rows on v_mfma_f32_4x4x1 (16 independent 4 x 4 blocks, K = 1, 8 cycles): block = 4 neighbouring lanes
+        // = 4 samples (B operand: the lane's own H2 value of one feature), rows = 4 actions (A operand: lane (block, i) supplies
+        // W3[i (+4)][feature]; the lane halves carry different features, which per-block operands allow).  Two instructions
+        // per feature cover the 8 actions: 128 MFMAs = ~1k cycles per wave and 32 16-byte LDS reads per lane.  The packed-FMA
+        // form this replaces issued the same ~1k cycles of arithmetic but read every W3 row as a broadcast operand -- 128
+        // 16-byte reads per lane, 512 KB of LDS return traffic per workgroup = 4k cycles at 128 B/clk: the layer was
+        // LDS-bandwidth bound (3.3k cycles measured), and the actor workgroups are the kernel's critical path.
+        f32x4 ya[2][2];
 #pragma unroll
-        for (int a = 0; a < NR; ++a) yp[a] = f32x2{0.f, 0.f};
-        // batches of four 16-byte reads (one row a, one tile T), issued one batch ahead of the eight packed FMAs that
-        // consume them: with a single wave per SIMD an un-prefetched LDS read costs its whole latency
-        const float *w3 = RW3 + 4 * hi;
-        float4 wq[2][4];
-        auto issue = [&](int bt, float4(&dst)[4]) {
-            const int T = bt / NR, a = bt % NR;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) dst[gq] = *reinterpret_cast<const float4 *>(w3 + a * ld3 + 32 * T + 8 * gq);
+        for (int q = 0; q < 4; ++q) ya[q >> 1][q & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *w3a = RW3 + (lane & 3) * ld3 + 4 * hi;
+        constexpr int DEPTH = 2;
+        float4 wq[DEPTH + 1][2];
+        auto issue = [&](int c, float4(&dst)[2]) {
+            const int T = c >> 2, gq = c & 3;
+            dst[0] = *reinterpret_cast<const float4 *>(w3a + 32 * T + 8 * gq);
+            dst[1] = *reinterpret_cast<const float4 *>(w3a + 4 * ld3 + 32 * T + 8 * gq);
         };
-        issue(0, wq[0]);
 #pragma unroll
-        for (int bt = 0; bt < 4 * NR; ++bt) {
-            const int T = bt / NR, a = bt % NR;
-            if (bt + 1 < 4 * NR) issue(bt + 1, wq[(bt + 1) & 1]);
+        for (int c = 0; c < DEPTH; ++c) issue(c, wq[c]);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float4 w = wq[bt & 1][gq];
-                yp[a] = f32x2{w.x, w.y} * f32x2{H2[T][4 * gq + 0], H2[T][4 * gq + 1]} + yp[a];
-                yp[a] = f32x2{w.z, w.w} * f32x2{H2[T][4 * gq + 2], H2[T][4 * gq + 3]} + yp[a];
+        for (int c = 0; c < 16; ++c) {
+            const int T = c >> 2, gq = c & 3;
+            if (c + DEPTH < 16) issue(c + DEPTH, wq[(c + DEPTH) % (DEPTH + 1)]);
+            const float4 w0 = wq[c % (DEPTH + 1)][0], w1 = wq[c % (DEPTH + 1)][1];
+            const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ya[0][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], H2[T][4 * gq + j], ya[0][j & 1], 0, 0, 0);
+                ya[1][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], H2[T][4 * gq + j], ya[1][j & 1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         const float4 b4 = *reinterpret_cast<const float4 *>(s_b3 + 4 * hi);
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-        if (ACTOR) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float lo = yp[j].x + yp[j].y, hi_ = yp[NR > 4 ? 4 + j : j].x + yp[NR > 4 ? 4 + j : j].y;
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
-                Y[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) + bb[j];   // lanes < 32: output j; lanes >= 32: output 4 + j
-            }
-        } else {
-            const float s = yp[0].x + yp[0].y;
-            Y[0] = s + __shfl_xor(s, 32, 64) + bb[0];
+        for (int j = 0; j < 4; ++j) {
+            const float lo = ya[0][0][j] + ya[0][1][j], hi_ = ya[1][0][j] + ya[1][1][j];     // this half's features: actions j and 4 + j
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
+            Y[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) + bb[j];   // lanes < 32: output j; lanes >= 32: output 4 + j
         }
+    } else {
+        // value head: one row on the vector ALUs -- each lane reduces its own 64 features of H2 against W3's row (broadcast
+        // 16-byte LDS reads, three batches ahead), the lane halves meet through a cross-half shuffle
+        f32x2 yp = {0.f, 0.f}, yq = {0.f, 0.f};
+        const float *w3 = RW3 + 4 * hi;
+        float4 wv[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wv[c] = *reinterpret_cast<const float4 *>(w3 + 32 * (c >> 2) + 8 * (c & 3));
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int T = c >> 2, gq = c & 3;
+            yp = f32x2{wv[c].x, wv[c].y} * f32x2{H2[T][4 * gq + 0], H2[T][4 * gq + 1]} + yp;
+            yq = f32x2{wv[c].z, wv[c].w} * f32x2{H2[T][4 * gq + 2], H2[T][4 * gq + 3]} + yq;
+        }
+        const float s = (yp.x + yp.y) + (yq.x + yq.y);
+        Y[0] = s + __shfl_xor(s, 32, 64) + s_b3[0];
     }
     PROF(5);
 
