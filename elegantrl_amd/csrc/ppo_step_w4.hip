@@ -418,10 +418,16 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     const float xb = ACTOR ? g.advantages[row] : 0.f;
     float act_pre[4] = {0.f, 0.f, 0.f, 0.f}, sl_pre[4] = {0.f, 0.f, 0.f, 0.f};   // this lane's actions a = 4 hi + j (actor)
     if (ACTOR) {
+        // the lane's four actions: ONE 16-byte load when the rows allow it (a scattered dword load touches as many lines)
+        const bool act4 = (OUT & 3) == 0 && (reinterpret_cast<uintptr_t>(g.actions) & 15) == 0;      // uniform
+        if (act4) {
+            const float4 v = *reinterpret_cast<const float4 *>(g.actions + row * OUT + min(4 * hi, OUT - 4));
+            act_pre[0] = v.x; act_pre[1] = v.y; act_pre[2] = v.z; act_pre[3] = v.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ac = min(4 * hi + j, OUT - 1);
-            act_pre[j] = g.actions[row * OUT + ac];
+            if (!act4) act_pre[j] = g.actions[row * OUT + ac];
             sl_pre[j] = std_log[ac];
         }
     }
