@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const float *__restric
         for (; k + 124 < n_slabs; k += 128) {      // 32 loads in flight: one round trip per 128 slabs (config 4: all of them)
             float x[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) x[u] = src[(size_t)(k + 4 * u) * stride];
+            for (int u = 0; u < 32; ++u) x[u] = __builtin_nontemporal_load(src + (size_t)(k + 4 * u) * stride);
 #pragma unroll
             for (int v = 0; v < 4; ++v)            // same association as the 8-wide loop below: s[u] += slab k + 32 v + 4 u
 #pragma unroll

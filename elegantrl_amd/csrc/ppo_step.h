@@ -81,7 +81,7 @@ __device__ __forceinline__ void weight_grad(const float *TA, int nA32, const flo
         const int i = 32 * jt + l31;
         if (i < cols_real) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dW[(size_t)(32 * it + crow(r, hi)) * ldw + i] = acc[r];
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r], dW + (size_t)(32 * it + crow(r, hi)) * ldw + i);   // see ppo_step_w4.hip: slabs stream past L2
         }
     }
 }

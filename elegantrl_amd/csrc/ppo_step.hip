@@ -345,7 +345,7 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int a_ = 4 * q + r;
-            if (a_ < OUT) slab[d.oW3() + (size_t)a_ * h2 + 16 * it + l15] = acc[r];
+            if (a_ < OUT) __builtin_nontemporal_store(acc[r], slab + d.oW3() + (size_t)a_ * h2 + 16 * it + l15);
         }
     }
     lds_barrier();                                                   // (5) H2^T consumed

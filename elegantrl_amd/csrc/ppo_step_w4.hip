@@ -275,12 +275,16 @@ __device__ __forceinline__ void weight_grad_w4(const float *TA, const float *TB,
     float4 av[2], bv[2];
     av[0] = *reinterpret_cast<const float4 *>(a4);
     bv[0] = *reinterpret_cast<const float4 *>(b4);
+    // The slab is written once and read once, by another kernel: NON-TEMPORAL stores keep its 104 KB per workgroup (26 MB per
+    // launch) from being allocated in L2 -- with plain stores the kernel is 3-4 us slower inside the PPO loop (after the slab
+    // reduction has left its lines spread over the XCDs' L2s: 54.8 -> 51.0 us) and 2 us slower back to back (49.6 -> 47.7 us);
+    // on the pool's slow boxes the difference is 83 -> 57 us.
     auto store = [&](int jt, const f32x16 &c) {
         const int i = 32 * jt + l31;
         if (i < cols_real) {
             float *o = dW + (size_t)(32 * wave + 4 * hi) * ldw + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * ldw] = c[r];
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(c[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
         }
     };
 #pragma unroll
@@ -657,7 +661,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a_ = 4 * q + r;
-                if (a_ < OUT) slab[d.oW3() + (size_t)a_ * h2 + 16 * it + l15] = acc[r];
+                if (a_ < OUT) __builtin_nontemporal_store(acc[r], slab + d.oW3() + (size_t)a_ * h2 + 16 * it + l15);
             }
         }
         float s = hs.x + hs.y;

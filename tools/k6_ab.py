@@ -30,6 +30,8 @@ def main():
     ids = th.randint(H * N, (B,), device=dev, generator=g)
     # K6_ROTATE=1: another minibatch of the permutation on every launch, as in the PPO loop (the gathered rows are then cold in
     # L2); K6_ROTATE=2 additionally streams a slab-sized buffer through the caches between launches (what the tail does)
+    # K6_BETWEEN=adam|reduce|both: run the loop's other kernels between launches and time K6 alone with per-launch events
+    between = os.environ.get("K6_BETWEEN", "")
     rotate = int(os.environ.get("K6_ROTATE", 0))
     idsets = [th.randint(H * N, (B,), device=dev, generator=g) for _ in range(8)] if rotate else [ids]
     scrub = th.empty(26 << 18, device=dev) if rotate == 2 else None
@@ -42,6 +44,28 @@ def main():
             scrub.add_(1.0)
         ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,
                      idsets[call[0] % len(idsets)], 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    if between:
+        fgrad = th.zeros(stride, device=dev)
+        m1, m2 = th.zeros_like(flat), th.zeros_like(flat)
+        groups = [(0, Pa), (Pa, sc.count)]
+        for _ in range(300):
+            run()
+        th.cuda.synchronize()
+        ev = []
+        for it in range(400):
+            if between in ("reduce", "both"):
+                ops.grad_reduce(slabs, n_slabs, stride, fgrad)
+            if between in ("adam", "both"):
+                ops.clip_adam(flat, fgrad, m1, m2, groups, 5 + it, 1e-6, 3.0)
+            e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            ev.append((e0, e1))
+        th.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev[100:])
+        print(json.dumps({"between": between, "k6_event_us_median": round(t[len(t) // 2], 2), "p10": round(t[len(t) // 10], 2)}))
+        return
     for _ in range(10):
         run()
     th.cuda.synchronize()
