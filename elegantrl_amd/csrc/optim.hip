@@ -127,7 +127,7 @@ __global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__r
         for (; k + 124 < n_slabs; k += 128) {
             float x[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) x[u] = src[(size_t)(k + 4 * u) * stride];
+            for (int u = 0; u < 32; ++u) x[u] = __builtin_nontemporal_load(src + (size_t)(k + 4 * u) * stride);   // streamed once (see mlp.hip)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
