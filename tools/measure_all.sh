@@ -2,7 +2,7 @@
 set -x
 cd /root/repo
 mkdir -p gpurun_out/final
-python tools/k6_ab.py > gpurun_out/final/k6_ab.txt 2>&1
+K6_REPS=40 python tools/k6_ab.py > gpurun_out/final/k6_ab.txt 2>&1; K6_BETWEEN=both python tools/k6_ab.py >> gpurun_out/final/k6_ab.txt 2>&1
 python tools/ppo_phase_profile.py > gpurun_out/final/k6_phase.txt 2>&1
 python tools/tail_bench.py > gpurun_out/final/tail_bench.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mib tools/mfma_issue_bench.hip 2>/dev/null && timeout 120 /tmp/mib > gpurun_out/final/mfma_issue_bench.txt 2>&1
