@@ -22,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 10
+ABI_VERSION = 11
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 COMM_ID_BYTES = 128
 

@@ -147,7 +147,8 @@ class AgentPPO(AgentBase):
             self._spec_a = ops.MlpSpecN([state_dim, *net_dims, action_dim], not self._discrete)
             self._spec_c = ops.MlpSpecN([state_dim, *net_dims, 1], False)
         self._Pa, self._Pc = self._spec_a.count, self._spec_c.count    # raises for unsupported shapes
-        self._stride = self._Pa + self._Pc + 4
+        # gradient row: [actor | critic | 4 logged values]; the fused kernels pad it to whole 128-byte lines
+        self._stride = ops.ppo_slab_stride(state_dim, *net_dims, action_dim) if self._fused else self._Pa + self._Pc + 4
         f32 = dict(dtype=th.float32, device=self.device)
         self._flat = th.zeros(self._Pa + self._Pc, **f32)
         self._exp_avg = th.zeros_like(self._flat)

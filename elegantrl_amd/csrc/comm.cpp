@@ -124,7 +124,7 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
     ERL_REQUIRE(update_times >= 1 && first_step >= 1 && B >= 1, "erl_ppo_update_dp_f32: bad argument");
     const int64_t Pa = erl_mlp_param_count(S, h1, h2, A, 1), Pc = erl_mlp_param_count(S, h1, h2, 1, 0);
     ERL_REQUIRE(Pa > 0 && Pc > 0, "erl_ppo_update_dp_f32: unsupported dims S=%d net=[%d,%d] A=%d", S, h1, h2, A);
-    const int64_t stride = Pa + Pc + 4;
+    const int64_t stride = erl_ppo_slab_stride(S, h1, h2, A);       // Pa + Pc + 4 rounded up to whole 128-byte lines
     const int n_slabs = erl_ppo_num_slabs(B);
     const int64_t off[2] = {0, Pa}, len[2] = {Pa, Pc};
     const int world = erl_comm_world_size(comm);

@@ -371,6 +371,7 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
         } else {
             logs[0] = t0 * g.inv_batch;
             logs[3] = 0.f;
+            for (int64_t e = g.Pa + g.Pc + 4; e < g.stride; ++e) logs[e - (g.Pa + g.Pc)] = 0.f;   // the row's pad
         }
     }
 }
@@ -420,7 +421,11 @@ extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile
 extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
 {
     if (!dims_ok2(S, h1, h2, A)) return -1;
-    return Dims{S, h1, h2, A}.count(true) + Dims{S, h1, h2, 1}.count(false) + 4;
+    // Pa + Pc + 4 (actor gradient | critic gradient | 4 logged values), rounded up to 32 floats: every slab then starts on a
+    // 128-byte line and the non-temporal gradient stores write whole lines (an unaligned pitch split each one in two partial
+    // writes: WRITE_SIZE 37.6 MB per launch for 26.6 MB of slabs).  The pad [Pa + Pc + 4, stride) is written as zeros.
+    const int64_t n = Dims{S, h1, h2, A}.count(true) + Dims{S, h1, h2, 1}.count(false) + 4;
+    return (n + 31) / 32 * 32;
 }
 
 extern "C" int erl_ppo_num_slabs(int64_t B) { return B >= 1 && B < (1LL << 37) ? (int)erl_cdiv(B, PB) : -1; }
@@ -452,7 +457,7 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     g.slabs = slabs;
     g.Pa = Dims{S, h1, h2, A}.count(true);
     g.Pc = Dims{S, h1, h2, 1}.count(false);
-    g.stride = g.Pa + g.Pc + 4;
+    g.stride = erl_ppo_slab_stride(S, h1, h2, A);
     g.prof = g_ppo_prof;
     g.prof_block = g_ppo_prof_block;
     // 16-byte vector path: every row / parameter block / normalisation vector must be 16-byte aligned

@@ -694,6 +694,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
         } else {
             logs[0] = t0 * g.inv_batch;
             logs[3] = 0.f;
+            for (int64_t e = g.Pa + g.Pc + 4; e < g.stride; ++e) logs[e - (g.Pa + g.Pc)] = 0.f;   // the row's pad
         }
     }
 }

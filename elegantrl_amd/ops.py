@@ -301,6 +301,9 @@ def ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, 
              objective: int = 0) -> None:
     """`objective`: _hip.PPO_OBJ_REFERENCE (AgentPPO.py:199) / PPO_OBJ_CANONICAL (textbook clip) / PPO_OBJ_A2C (AgentPPO.py:296-303)"""
     H, N = states.shape[0], states.shape[1]
+    need = n_slabs * lib().erl_ppo_slab_stride(S, h1, h2, A)
+    if slabs.numel() < need:
+        raise ValueError(f"slabs holds {slabs.numel()} floats, erl_ppo_step_f32 writes n_slabs x erl_ppo_slab_stride = {need}")
     check(lib().erl_ppo_step_f32(ptr(actor_params, th.float32), ptr(critic_params, th.float32), ptr(act_avg), ptr(act_std),
                                  ptr(cri_avg), ptr(cri_std), S, h1, h2, A, ptr(states, th.float32), ptr(actions, th.float32),
                                  flag_ptr(unmasks), ptr(logprobs, th.float32), ptr(advantages, th.float32),

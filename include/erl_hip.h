@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 10
+#define ERL_ABI_VERSION 11
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -238,7 +238,8 @@ ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *cri
  * (n_slabs x erl_ppo_slab_stride floats, n_slabs == erl_ppo_num_slabs(B) = ceil(B / 128)), to be summed in a
  * fixed order by erl_grad_reduce_f32.  inv_batch = 1/B (1/(B*world) is folded into K7 under data parallelism).
  * Slab / flat-gradient layout: [actor grads (Pa)] [critic grads (Pc)] [obj_critic, obj_surrogate,
- * obj_entropy, 0] where Pa/Pc = erl_mlp_param_count(...). */
+ * obj_entropy, 0] [zeros up to erl_ppo_slab_stride] where Pa/Pc = erl_mlp_param_count(...) and erl_ppo_slab_stride =
+ * Pa + Pc + 4 rounded up to 32 floats: rows start on 128-byte lines (the slab stores are non-temporal, whole lines). */
 /* `objective` of the PPO minibatch entry points: which actor objective is differentiated (csrc/ppo_objective.h) */
 #define ERL_PPO_OBJ_REFERENCE 0   /* AgentPPO.py:199   surrogate = adv*ratio*where(adv > 0, 1-clip, 1+clip) */
 #define ERL_PPO_OBJ_CANONICAL 1   /* helloworld_PPO_single_file.py:337-339   min(adv*ratio, adv*clamp(ratio, 1-clip, 1+clip)) */

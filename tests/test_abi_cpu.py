@@ -40,7 +40,7 @@ def test_host_only_entry_points():
     assert L.erl_mlp_param_count(64, 128, 128, 8, 1) == 64 * 128 + 128 + 128 * 128 + 128 + 128 * 8 + 8 + 8
     assert L.erl_mlp_param_count(64, 128, 128, 1, 0) == 64 * 128 + 128 + 128 * 128 + 128 + 128 + 1
     assert L.erl_mlp_param_count(64, 100, 128, 8, 1) == -1           # fused kernels: widths are multiples of 32
-    assert L.erl_ppo_slab_stride(64, 128, 128, 8) == 25872 + 24961 + 4
+    assert L.erl_ppo_slab_stride(64, 128, 128, 8) == (25872 + 24961 + 4 + 31) // 32 * 32       # whole 128-byte lines
     assert L.erl_ppo_num_slabs(16384) == 128 and L.erl_ppo_num_slabs(1) == 1 and L.erl_ppo_num_slabs(0) == -1
     assert L.erl_gae_workspace_bytes(32, 4096) >= 32 * 4096 * 2
     spec = ops.MlpSpecN([17, 256, 128, 64, 5], True)

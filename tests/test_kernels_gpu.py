@@ -497,7 +497,7 @@ def test_ppo_step_gradients(ops, dev, S, h1, h2, A, B):
     actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
     stride = ops.ppo_slab_stride(S, h1, h2, A)
     Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
-    assert stride == Pa + Pc + 4
+    assert stride == (Pa + Pc + 4 + 31) // 32 * 32
     slabs = th.full((n_slabs, stride), float("nan"), device=dev)
     flat = th.zeros(stride, device=dev)
     ops.ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
@@ -539,6 +539,7 @@ def test_ppo_step_objective_forms(ops, dev, S, h1, h2, A, objective):
                  0.25, 0.001, 1.0 / B, slabs, n_slabs, objective=OBJECTIVES[objective])
     ops.grad_reduce(slabs, n_slabs, stride, flat)
     got = flat.cpu().numpy().astype(np.float64)
+    assert not np.any(got[Pa + Pc + 4:])                      # the row's pad to whole 128-byte lines is written (as zeros)
     ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64, objective)
     for name, g, ref in (("actor", got[:Pa], ga), ("critic", got[Pa:Pa + Pc], gc)):
         scale = np.abs(ref).max()
@@ -617,7 +618,7 @@ def test_update_loop_on_reference_golden(ops, dev, name):
     Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
     P = cu(np.concatenate([flat_params(a0), flat_params(c0)]), dev)
     M1, M2 = th.zeros_like(P), th.zeros_like(P)
-    stride = Pa + Pc + 4
+    stride = ops.ppo_slab_stride(S, h1, h2, A)
     n_slabs = ops.ppo_num_slabs(B)
     slabs, flat = th.zeros((n_slabs, stride), device=dev), th.zeros(stride, device=dev)
     buf = [cu(g[k], dev) for k in ("states", "actions", "unmasks", "logprobs", "advantages_norm", "reward_sums")]
