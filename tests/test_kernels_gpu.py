@@ -485,7 +485,12 @@ def oracle_flat_grads(buf, ids, actor, critic, clip, lam_ent, dt, objective="ref
     return ga, gc, np.array([oc, os_, oe], dtype=np.float64)
 
 
-@pytest.mark.parametrize("S,h1,h2,A", MLP_SHAPES)
+# more shapes of the one-wave-per-SIMD kernel (S % 4 == 0, S <= 64, [128,128], A <= 8): one K tile (S <= 32), action counts that
+# do not fill the 4 x 4 output blocks or the 16-byte action load, a single action
+W4_SHAPES = [(32, 128, 128, 3), (16, 128, 128, 4), (64, 128, 128, 1), (4, 128, 128, 8), (48, 128, 128, 6)]
+
+
+@pytest.mark.parametrize("S,h1,h2,A", MLP_SHAPES + W4_SHAPES)
 @pytest.mark.parametrize("B", [64, 200, 1024, 1000, 1])
 def test_ppo_step_gradients(ops, dev, S, h1, h2, A, B):
     rng = np.random.default_rng(S + B)
