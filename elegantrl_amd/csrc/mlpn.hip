@@ -36,6 +36,7 @@ extern "C" int64_t erl_mlpn_workspace_bytes(const int *dims, int n_dims, int64_t
         int64_t nk = 1;
         for (int l = 0; l < nd.n; ++l) nk = (int64_t)nd.d[l] * nd.d[l + 1] > nk ? (int64_t)nd.d[l] * nd.d[l + 1] : nk;
         f += dw_scratch_floats(rows, nk) + 64;                        // per-chunk dW partials
+        f = 2 * f + 128;                                              // actor and critic each own a region (they run on two streams)
     }
     return f * 4 + 4096;
 }
@@ -118,6 +119,33 @@ extern "C" int erl_mlpn_rollout_step_discrete_f32(const float *actor_params, con
 // One PPO minibatch for networks of any depth: writes the summed gradient [actor | critic | logs(4)] to flat_grad.
 namespace {
 
+// a library-owned second stream per device (non-blocking) with the two events that fork it from / join it into the caller's
+// stream; NULL when ERL_MLPN_STREAMS=1 or the runtime refuses (then everything stays on the caller's stream)
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool tried = false;
+};
+static SideStream g_side[32];
+
+SideStream *side_stream()
+{
+    static const bool off = [] { const char *e = getenv("ERL_MLPN_STREAMS"); return e && atoi(e) == 1; }();
+    int dev = -1;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    SideStream &q = g_side[dev];
+    if (!q.tried) {
+        q.tried = true;
+        if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            q.stream = nullptr;
+        }
+    }
+    return q.stream ? &q : nullptr;
+}
+
 int ppo_step_impl(const char *what, bool discrete, const float *actor_params, const float *critic_params, const float *act_avg,
                   const float *act_std, const float *cri_avg, const float *cri_std, const int *actor_dims, int n_dims,
                   const float *states, const void *actions_any, const uint8_t *unmasks, const float *logprobs,
@@ -143,49 +171,80 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
     const int A = na.d[na.n];
     float *logs = flat_grad + na.count + nc.count;
 
+    // The two networks are independent until the optimiser, and each one's ~18 launches are a chain of DEPENDENT launches at
+    // ~7 us apiece whatever they compute (profiles/r02_gemm_small_scaling.txt): the critic's chain runs on a library-owned
+    // side stream next to the actor's (forked from / joined back into the caller's stream by events), each network in its own
+    // half of the workspace.  The host enqueues the two chains in two alternating stages so that neither waits long for the
+    // interpreter-free but still finite (~4 us per launch) enqueue of the other.  ERL_MLPN_STREAMS=1 keeps everything on the
+    // caller's stream.
+    hipStream_t s1 = s;
+    SideStream *side = side_stream();
+    if (side) {
+        if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
+        if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
+        s1 = side->stream;
+    }
+    const int64_t half = (workspace_bytes / 2) & ~(int64_t)255;
+    struct NetState {
+        float *act[MAXL + 2], *gd[MAXL + 2];
+        float *dA, *dB, *dsl, *cs_scr, *part, *dw_scr;
+    } st[2];
+    const int nparts = (int)erl_cdiv(B, 256);
     for (int net = 0; net < 2; ++net) {
         const NetDims &nd = net == 0 ? na : nc;
-        const float *P = net == 0 ? actor_params : critic_params;
-        float *G = flat_grad + (net == 0 ? 0 : na.count);
-        Ws ws{(char *)workspace, 0, workspace_bytes};
-        float *act[MAXL + 2], *gd[MAXL + 2];
+        NetState &q = st[net];
+        Ws ws{(char *)workspace + net * half, 0, half};
         int maxd = 1;
         for (int l = 0; l <= nd.n; ++l) {
-            act[l] = ws.take(B * nd.d[l]);
+            q.act[l] = ws.take(B * nd.d[l]);
             maxd = nd.d[l] > maxd ? nd.d[l] : maxd;
         }
-        gd[0] = gd[nd.n] = nullptr;
-        for (int l = 1; l < nd.n; ++l) gd[l] = ws.take(B * nd.d[l]);
-        float *dA = ws.take(B * maxd), *dB = ws.take(B * maxd);
-        float *dsl = ws.take(B * nd.d[nd.n]);
-        float *cs_scr = ws.take(colsum_scratch_floats(B, maxd));
-        const int nparts = (int)erl_cdiv(B, 256);
-        float *part = ws.take(2 * (int64_t)nparts);
+        q.gd[0] = q.gd[nd.n] = nullptr;
+        for (int l = 1; l < nd.n; ++l) q.gd[l] = ws.take(B * nd.d[l]);
+        q.dA = ws.take(B * maxd);
+        q.dB = ws.take(B * maxd);
+        q.dsl = ws.take(B * nd.d[nd.n]);
+        q.cs_scr = ws.take(colsum_scratch_floats(B, maxd));
+        q.part = ws.take(2 * (int64_t)nparts);
         int64_t nk = 1;
         for (int l = 0; l < nd.n; ++l) nk = (int64_t)nd.d[l] * nd.d[l + 1] > nk ? (int64_t)nd.d[l] * nd.d[l + 1] : nk;
-        float *dw_scr = dw_scratch_floats(B, nk) ? ws.take(dw_scratch_floats(B, nk)) : nullptr;
-        ERL_REQUIRE(part != nullptr && (dw_scr != nullptr || !dw_scratch_floats(B, nk)), "%s: workspace too small (need erl_mlpn_workspace_bytes(dims, rows = B, training = 1))", what);
-
-        hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(B * nd.d[0])), dim3(256), 0, s, states, net == 0 ? act_avg : cri_avg,
-                           net == 0 ? act_std : cri_std, ids, H, N, nd.d[0], B, act[0], (float *)nullptr);
-        if ((rc = forward(s, nd, P, B, act, gd))) return rc;
-        float *Y = act[nd.n];
-        if (net == 0 && discrete)
-            hipLaunchKernelGGL(objective_discrete_kernel, dim3(nparts), dim3(256), 0, s, Y, ids, H, N, A, B, actions_i, unmasks, logprobs,
-                               advantages, ratio_clip, lambda_entropy, inv_batch, part);
-        else if (net == 0)
-            hipLaunchKernelGGL((objective_kernel<true>), dim3(nparts), dim3(256), 0, s, Y, dsl, ids, H, N, A, B, actions, unmasks, logprobs,
-                               advantages, P + nd.oStd, ratio_clip, lambda_entropy, inv_batch, objective, part);
-        else
-            hipLaunchKernelGGL((objective_kernel<false>), dim3(nparts), dim3(256), 0, s, Y, (float *)nullptr, ids, H, N, 1, B, actions,
-                               unmasks, reward_sums, (const float *)nullptr, (const float *)nullptr, ratio_clip, lambda_entropy,
-                               inv_batch, objective, part);
-        hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, s, part, nparts, P + nd.oStd, A, inv_batch,
-                           net == 0 ? (discrete ? 2 : 1) : 0, logs);
-        if (net == 0 && !discrete && (rc = colsum(s, dsl, cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
-
-        // backward: dZ of the output layer is Y (dL/dY); walk the layers down
-        if ((rc = backward(s, nd, P, B, act, gd, Y, G, cs_scr, nullptr, false, dA, dB, dw_scr))) return rc;
+        q.dw_scr = dw_scratch_floats(B, nk) ? ws.take(dw_scratch_floats(B, nk)) : nullptr;
+        ERL_REQUIRE(q.part != nullptr && (q.dw_scr != nullptr || !dw_scratch_floats(B, nk)),
+                    "%s: workspace too small (need erl_mlpn_workspace_bytes(dims, rows = B, training = 1))", what);
+    }
+    for (int stage = 0; stage < 2; ++stage) {
+        for (int net = 0; net < 2; ++net) {
+            const NetDims &nd = net == 0 ? na : nc;
+            const float *P = net == 0 ? actor_params : critic_params;
+            float *G = flat_grad + (net == 0 ? 0 : na.count);
+            NetState &q = st[net];
+            hipStream_t sn = net == 0 ? s : s1;
+            float *Y = q.act[nd.n];
+            if (stage == 0) {          // gather + normalise, forward, objective and dL/dY
+                hipLaunchKernelGGL(gather_norm_kernel, dim3(grid1d(B * nd.d[0])), dim3(256), 0, sn, states, net == 0 ? act_avg : cri_avg,
+                                   net == 0 ? act_std : cri_std, ids, H, N, nd.d[0], B, q.act[0], (float *)nullptr);
+                if ((rc = forward(sn, nd, P, B, q.act, q.gd))) return rc;
+                if (net == 0 && discrete)
+                    hipLaunchKernelGGL(objective_discrete_kernel, dim3(nparts), dim3(256), 0, sn, Y, ids, H, N, A, B, actions_i, unmasks,
+                                       logprobs, advantages, ratio_clip, lambda_entropy, inv_batch, q.part);
+                else if (net == 0)
+                    hipLaunchKernelGGL((objective_kernel<true>), dim3(nparts), dim3(256), 0, sn, Y, q.dsl, ids, H, N, A, B, actions, unmasks,
+                                       logprobs, advantages, P + nd.oStd, ratio_clip, lambda_entropy, inv_batch, objective, q.part);
+                else
+                    hipLaunchKernelGGL((objective_kernel<false>), dim3(nparts), dim3(256), 0, sn, Y, (float *)nullptr, ids, H, N, 1, B, actions,
+                                       unmasks, reward_sums, (const float *)nullptr, (const float *)nullptr, ratio_clip, lambda_entropy,
+                                       inv_batch, objective, q.part);
+                hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, sn, q.part, nparts, P + nd.oStd, A, inv_batch,
+                                   net == 0 ? (discrete ? 2 : 1) : 0, logs);
+            } else {                   // backward: dZ of the output layer is Y (dL/dY); walk the layers down
+                if (net == 0 && !discrete && (rc = colsum(sn, q.dsl, q.cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
+                if ((rc = backward(sn, nd, P, B, q.act, q.gd, Y, G, q.cs_scr, nullptr, false, q.dA, q.dB, q.dw_scr))) return rc;
+            }
+        }
+    }
+    if (side) {
+        if ((rc = erl_hip_status(hipEventRecord(side->join, s1), "hipEventRecord(join)"))) return rc;
+        if ((rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
     }
     return erl_hip_status(hipGetLastError(), what);
 }

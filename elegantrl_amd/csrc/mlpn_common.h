@@ -42,7 +42,8 @@ extern "C" int erl_grad_reduce_f32(const float *slabs, int n_slabs, int64_t stri
 
 // the weight-gradient contraction is split over chunks of DW_CHUNK batch rows when the batch is at least 4 chunks tall
 constexpr int DW_CHUNK = 256;
-inline int64_t dw_scratch_floats(int64_t M, int64_t NK) { return M >= 4 * DW_CHUNK ? ((M + DW_CHUNK - 1) / DW_CHUNK) * NK : 0; }
+// per-split partials of the widest layer: dW (NK floats) followed by db (at most ERL_MAXN_WIDTH floats)
+inline int64_t dw_scratch_floats(int64_t M, int64_t NK) { return M >= 4 * DW_CHUNK ? ((M + DW_CHUNK - 1) / DW_CHUNK) * (NK + ERL_MAXN_WIDTH) : 0; }
 
 // db[N] = column sums of dZ[M][N] (row-major): each block sums a slice of rows into its own partial (threads along the
 // columns: coalesced), a fixed-order fold finishes.  (used for dL/dstd_log; the layers' bias gradients come out of the weight-gradient GEMM.)
@@ -352,13 +353,17 @@ int dense_weight_grad(hipStream_t s, const float *dZ, const float *X, float *dW,
     g.A = dZ; g.lda = Nw; g.B = X; g.ldb = K; g.M = Nw; g.N = K; g.K = rows; g.ldc = K;
     const bool split = dw_scratch && cs_scratch && rows >= 4 * DW_CHUNK;
     const int nsplit = split ? (int)erl_cdiv(rows, DW_CHUNK) : 1;
+    // the parameter block keeps b right behind W: each split's db partial is then laid out right behind its dW partial and
+    // ONE fixed-order sum produces both (a dependent launch costs ~7 us whatever it computes)
+    const bool joint = split && db == dW + (size_t)Nw * K;
     g.kchunk = split ? DW_CHUNK : rows;
     g.C = split ? dw_scratch : dW;
-    g.c_split = (int64_t)Nw * K;
-    g.rowsum = split ? cs_scratch : db;
-    g.rs_split = Nw;
+    g.c_split = (int64_t)Nw * K + (joint ? Nw : 0);
+    g.rowsum = joint ? dw_scratch + (size_t)Nw * K : (split ? cs_scratch : db);
+    g.rs_split = joint ? g.c_split : Nw;
     int rc = gemm_launch<OP_OC, OP_OC, EPI_PARTIAL>(s, g, nsplit, "dense_weight_grad");
     if (rc || !split) return rc;
+    if (joint) return erl_grad_reduce_f32(dw_scratch, nsplit, g.c_split, dW, (void *)s);
     if ((rc = erl_grad_reduce_f32(dw_scratch, nsplit, (int64_t)Nw * K, dW, (void *)s))) return rc;
     return erl_grad_reduce_f32(cs_scratch, nsplit, Nw, db, (void *)s);
 }
