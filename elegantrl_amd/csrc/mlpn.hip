@@ -32,7 +32,7 @@ extern "C" int64_t erl_mlpn_workspace_bytes(const int *dims, int n_dims, int64_t
         f += 2 * (rows * maxd + 64);                                  // dH ping-pong
         f += rows * nd.d[nd.n] + 64;                                  // DSL
         f += colsum_scratch_floats(rows, maxd) + 64;                  // bias-gradient partials
-        f += 2 * (erl_cdiv(rows, 256) + 64);                          // loss partials
+        f += (2 + nd.d[nd.n]) * (erl_cdiv(rows, 256) + 64);          // per-block partials: logged values, dL/dstd_log
         int64_t nk = 1;
         for (int l = 0; l < nd.n; ++l) nk = (int64_t)nd.d[l] * nd.d[l + 1] > nk ? (int64_t)nd.d[l] * nd.d[l + 1] : nk;
         f += dw_scratch_floats(rows, nk) + 64;                        // per-chunk dW partials
@@ -205,7 +205,7 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
         q.dB = ws.take(B * maxd);
         q.dsl = ws.take(B * nd.d[nd.n]);
         q.cs_scr = ws.take(colsum_scratch_floats(B, maxd));
-        q.part = ws.take(2 * (int64_t)nparts);
+        q.part = ws.take((2 + (int64_t)nd.d[nd.n]) * nparts);
         int64_t nk = 1;
         for (int l = 0; l < nd.n; ++l) nk = (int64_t)nd.d[l] * nd.d[l + 1] > nk ? (int64_t)nd.d[l] * nd.d[l + 1] : nk;
         q.dw_scr = dw_scratch_floats(B, nk) ? ws.take(dw_scratch_floats(B, nk)) : nullptr;
@@ -228,16 +228,16 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
                     hipLaunchKernelGGL(objective_discrete_kernel, dim3(nparts), dim3(256), 0, sn, Y, ids, H, N, A, B, actions_i, unmasks,
                                        logprobs, advantages, ratio_clip, lambda_entropy, inv_batch, q.part);
                 else if (net == 0)
-                    hipLaunchKernelGGL((objective_kernel<true>), dim3(nparts), dim3(256), 0, sn, Y, q.dsl, ids, H, N, A, B, actions, unmasks,
+                    hipLaunchKernelGGL((objective_kernel<true>), dim3(nparts), dim3(256), 0, sn, Y, (float *)nullptr, ids, H, N, A, B, actions, unmasks,
                                        logprobs, advantages, P + nd.oStd, ratio_clip, lambda_entropy, inv_batch, objective, q.part);
                 else
                     hipLaunchKernelGGL((objective_kernel<false>), dim3(nparts), dim3(256), 0, sn, Y, (float *)nullptr, ids, H, N, 1, B, actions,
                                        unmasks, reward_sums, (const float *)nullptr, (const float *)nullptr, ratio_clip, lambda_entropy,
                                        inv_batch, objective, q.part);
-                hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, sn, q.part, nparts, P + nd.oStd, A, inv_batch,
-                                   net == 0 ? (discrete ? 2 : 1) : 0, logs);
+                const bool gauss = net == 0 && !discrete;
+                hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, sn, q.part, nparts, gauss ? 2 + A : 2, P + nd.oStd, A, inv_batch,
+                                   net == 0 ? (discrete ? 2 : 1) : 0, logs, gauss ? G + nd.oStd : (float *)nullptr);   // + dL/dstd_log
             } else {                   // backward: dZ of the output layer is Y (dL/dY); walk the layers down
-                if (net == 0 && !discrete && (rc = colsum(sn, q.dsl, q.cs_scr, G + nd.oStd, (int)B, A))) return rc;   // dL/dstd_log
                 if ((rc = backward(sn, nd, P, B, q.act, q.gd, Y, G, q.cs_scr, nullptr, false, q.dA, q.dB, q.dw_scr))) return rc;
             }
         }

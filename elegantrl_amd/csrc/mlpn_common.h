@@ -149,19 +149,21 @@ __global__ __launch_bounds__(256) void objective_kernel(float *__restrict__ Y, f
                                                         float ratio_clip, float lambda_entropy, float inv_batch, int objective,
                                                         float *__restrict__ part)
 {
+    // part[block][2 (+ A)]: the block's sums of the two logged values and (actor) of dL/dstd_log per action -- folded in a
+    // fixed order by fold_logs_kernel (the std_log gradient used to be a (B, A) tensor and two more launches)
     __shared__ float red[4];
+    const int pstride = ACTOR ? 2 + A : 2;
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float l0 = 0.f, l1 = 0.f;
-    if (b < B) {
-        const int64_t id = ids[b];
-        const int64_t n = id / H, t = id - n * H;
-        const int64_t row = t * N + n;
-        const float um = unmasks[row] ? 1.f : 0.f;
-        if (!ACTOR) {
-            const float diff = Y[b] - xa_src[row];
-            l0 = diff * diff * um;
-            Y[b] = 2.f * diff * um * inv_batch;
-        } else {
+    if (ACTOR) {
+        const bool valid = b < B;
+        int64_t row = 0;
+        float dlp = 0.f, ent_term = 0.f;
+        if (valid) {
+            const int64_t id = ids[b];
+            const int64_t n = id / H, t = id - n * H;
+            row = t * N + n;
+            const float um = unmasks[row] ? 1.f : 0.f;
             float lp = 0.f;
             for (int a = 0; a < A; ++a) {
                 const float sdv = expf(std_log[a]), var = sdv * sdv;
@@ -171,20 +173,34 @@ __global__ __launch_bounds__(256) void objective_kernel(float *__restrict__ Y, f
             const PpoActorTerms o = ppo_actor_terms(objective, xb_src[row], lp, xa_src[row], ratio_clip, lambda_entropy, um, A, false);
             l0 = o.logged;
             l1 = o.ent_mask;
-            const float dlp = o.dlp * inv_batch;
-            const float ent_term = o.ent_w * inv_batch;
-            for (int a = 0; a < A; ++a) {
+            dlp = o.dlp * inv_batch;
+            ent_term = o.ent_w * inv_batch;
+        }
+        for (int a = 0; a < A; ++a) {                     // uniform trip count: every thread takes part in the block sums
+            float dsl = 0.f;
+            if (valid) {
                 const float sdv = expf(std_log[a]), var = sdv * sdv;
                 const float diff = actions[row * A + a] - Y[b * A + a];
                 Y[b * A + a] = dlp * (diff / var);
-                DSL[b * A + a] = dlp * (diff * diff / var - 1.f) + ent_term;
+                dsl = dlp * (diff * diff / var - 1.f) + ent_term;
+                if (DSL) DSL[b * A + a] = dsl;
             }
+            const float ts = block_sum(dsl, red);
+            if (threadIdx.x == 0) part[(size_t)blockIdx.x * pstride + 2 + a] = ts;
         }
+    } else if (b < B) {
+        const int64_t id = ids[b];
+        const int64_t n = id / H, t = id - n * H;
+        const int64_t row = t * N + n;
+        const float um = unmasks[row] ? 1.f : 0.f;
+        const float diff = Y[b] - xa_src[row];
+        l0 = diff * diff * um;
+        Y[b] = 2.f * diff * um * inv_batch;
     }
     const float t0 = block_sum(l0, red), t1 = block_sum(l1, red);
     if (threadIdx.x == 0) {
-        part[(size_t)blockIdx.x * 2 + 0] = t0;
-        part[(size_t)blockIdx.x * 2 + 1] = t1;
+        part[(size_t)blockIdx.x * pstride + 0] = t0;
+        part[(size_t)blockIdx.x * pstride + 1] = t1;
     }
 }
 
@@ -279,16 +295,22 @@ __global__ __launch_bounds__(256) void objective_discrete_kernel(float *__restri
     }
 }
 
-// logs: fold the per-block partials in a fixed order (is_actor: 1 = Gaussian head, 2 = categorical head)
-__global__ void fold_logs_kernel(const float *__restrict__ part, int nparts, const float *__restrict__ std_log, int A, float inv_batch,
-                                 int is_actor, float *__restrict__ logs)
+// logs: fold the per-block partials in a fixed order (is_actor: 1 = Gaussian head, 2 = categorical head).  64 threads: thread c
+// sums column c of part[nparts][pstride] (columns 0, 1: the logged values; 2 + a: dL/dstd_log of action a -> dstd[a])
+__global__ __launch_bounds__(64) void fold_logs_kernel(const float *__restrict__ part, int nparts, int pstride,
+                                                       const float *__restrict__ std_log, int A, float inv_batch, int is_actor,
+                                                       float *__restrict__ logs, float *__restrict__ dstd)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int i = 0; i < nparts; ++i) {
-        s0 += part[2 * i];
-        s1 += part[2 * i + 1];
+    __shared__ float s01[2];
+    for (int c = threadIdx.x; c < pstride; c += 64) {
+        float s = 0.f;
+        for (int i = 0; i < nparts; ++i) s += part[(size_t)i * pstride + c];
+        if (c < 2) s01[c] = s;
+        else if (dstd) dstd[c - 2] = s;
     }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float s0 = s01[0], s1 = s01[1];
     if (is_actor == 2) {
         logs[1] = s0 * inv_batch;
         logs[2] = s1 * inv_batch;
