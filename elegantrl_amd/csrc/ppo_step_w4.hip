@@ -19,14 +19,17 @@
 // What bounds it (tools/mfma_issue_bench.hip, profiles/r02_mfma_issue_bench.txt): the fp32 MFMA runs on the vector
 // ALUs -- a wave's VALU instructions do NOT overlap its fp32 MFMAs, each one adds its 4 cycles (transcendentals 8) to the
 // 64 of an MFMA, while LDS reads, waits and s_nops between MFMAs are free and dependent MFMAs issue back to back.  So the
-// kernel's time is (MFMA count x 64 + VALU count x 4) cycles plus whatever latency is exposed, and the design rules are:
-// no padded MFMA work (the 8-row output layer is 256 packed FMAs, not a 32-row MFMA tile), as few VALU instructions as
-// possible (packed-fp32 GELU, normalisation folded into one packed FMA per two elements, biases loaded straight into the
-// accumulators by ds_read), operands prefetched one group ahead, and fences (sched_barrier) that keep the compiler from
-// hoisting a whole unrolled layer's operand reads into registers.
+// kernel's time is (MFMA count x 64 + VALU count x 4) cycles plus whatever latency is exposed -- a burst of n VALU
+// instructions between two MFMAs costs ~10 + 4 n cycles, a coalesced global store ~10, a global load ~17 -- and the design
+// rules are: no padded MFMA work (the actor's 8-row output layer is 128 v_mfma_f32_4x4x1 on 4-sample x 4-action blocks,
+// not a 32-row tile), as few and as few-but-long VALU bursts as possible (packed-fp32 GELU as one block per tile,
+// normalisation folded into one packed FMA per two elements, biases loaded straight into the accumulators by ds_read,
+// LDS reads off one base register with immediate offsets), operands prefetched one group ahead, and fences
+// (sched_barrier) that keep the compiler from hoisting a whole unrolled layer's operand reads into registers.
 //
-// Weight gradients are the same staged scheme as ppo_step.hip (T[feature][sample] tiles in LDS, 32x32x2 tiles, K = 128
-// samples, output tiles split over the waves).
+// Weight gradients are the staged scheme of ppo_step.hip (T[feature][sample] tiles in LDS, 32x32x2 tiles, K = 128 samples;
+// wave = row tile, so that the bias gradient falls out of the operand reads) and leave the CU by NON-TEMPORAL stores: the
+// slab is written once and read once by the reduction, and keeping its 26 MB per launch out of L2 is worth 3-4 us.
 #include "ppo_step.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
