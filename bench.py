@@ -368,8 +368,10 @@ def main():
         e1.record()
         th.cuda.synchronize()
         us = parallel.all_reduce_max_float(e0.elapsed_time(e1) * 5.0, device=dev)      # ms / 200 calls -> us per call
-        allreduce = {"route": "library RCCL communicator on the kernels' stream" if comm is not None else "torch.distributed",
-                     "ranks_seen_by_rccl": comm.world if comm is not None else world, "bytes": int(buf.numel() * 4),
+        route = "torch.distributed" if comm is None else (
+            "library one-shot peer-to-peer all-reduce (csrc/p2p.hip) on the kernels' stream" if getattr(comm, "kind", "rccl") == "p2p"
+            else "library RCCL communicator on the kernels' stream")
+        allreduce = {"route": route, "ranks_seen_by_rccl": comm.world if comm is not None else world, "bytes": int(buf.numel() * 4),
                      "us_per_call": round(us, 2), "calls_per_step": UPDATE_TIMES}
     if rank != 0:
         return

@@ -62,6 +62,7 @@ int rccl_status(ncclResult_t e, const char *what)
 struct Comm {
     ncclComm_t nccl;
     int rank, world;
+    void *p2p = nullptr;            // one-shot peer-to-peer exchange (p2p.hip) instead of RCCL
 };
 
 } // namespace
@@ -96,6 +97,11 @@ extern "C" int erl_comm_destroy(void *comm)
 {
     if (!comm) return ERL_OK;
     Comm *c = (Comm *)comm;
+    if (c->p2p) {
+        erl_p2p_destroy(c->p2p);
+        delete c;
+        return ERL_OK;
+    }
     int rc = rccl().ok ? rccl_status(rccl().CommDestroy(c->nccl), "ncclCommDestroy") : ERL_OK;
     delete c;
     return rc;
@@ -108,8 +114,28 @@ extern "C" int erl_comm_allreduce_sum_f32(void *comm, float *buf, int64_t count,
     ERL_REQUIRE(comm && buf && count >= 0, "erl_comm_allreduce_sum_f32: bad argument");
     if (count == 0) return ERL_OK;
     Comm *c = (Comm *)comm;
+    if (c->p2p) return erl_p2p_allreduce(c->p2p, buf, count, (hipStream_t)stream);
     return rccl_status(rccl().AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->nccl, (hipStream_t)stream),
                        "ncclAllReduce");
+}
+
+// ---- one-shot peer-to-peer communicator (p2p.hip): same handle type, same erl_comm_allreduce_sum_f32 / erl_ppo_update_dp_f32
+extern "C" int erl_comm_p2p_create(int rank, int world_size, int64_t max_count, void **out_comm, uint8_t *out_handle)
+{
+    ERL_REQUIRE(out_comm && out_handle, "erl_comm_p2p_create: NULL argument");
+    void *p = nullptr;
+    int rc = erl_p2p_create(rank, world_size, max_count, &p, out_handle);
+    if (rc) return rc;
+    Comm *c = new Comm{nullptr, rank, world_size};
+    c->p2p = p;
+    *out_comm = c;
+    return ERL_OK;
+}
+
+extern "C" int erl_comm_p2p_connect(void *comm, const uint8_t *handles)
+{
+    ERL_REQUIRE(comm && ((Comm *)comm)->p2p, "erl_comm_p2p_connect: not a peer-to-peer communicator");
+    return erl_p2p_connect(((Comm *)comm)->p2p, handles);
 }
 
 extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg, const float *act_std,

@@ -13,6 +13,11 @@ void erl_set_error(const char *fmt, ...);
 // pinned host-mapped word that device code bumps for faults an asynchronous launch cannot return (gae_lookback.hip);
 // read through erl_async_fault_count.  NULL when pinned memory is unavailable.
 uint32_t *erl_fault_word();
+// p2p.hip (one-shot peer-to-peer all-reduce), driven by comm.cpp
+int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *out_handle);
+int erl_p2p_connect(void *p2p, const uint8_t *handles);
+int erl_p2p_allreduce(void *p2p, float *buf, int64_t count, hipStream_t stream);
+void erl_p2p_destroy(void *p2p);
 
 #define ERL_REQUIRE(cond, ...)                 \
     do {                                       \

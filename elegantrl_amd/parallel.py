@@ -47,6 +47,8 @@ class RcclComm:
     the kernels either side of it, from inside the C loop.  torch.distributed stays the control plane: it carries the
     128-byte unique id to the ranks and the all-ranks agreement that the communicator came up everywhere."""
 
+    kind = "rccl"
+
     def __init__(self, handle: int, rank: int, world: int):
         self.handle, self.rank, self.world = handle, rank, world
 
@@ -100,6 +102,49 @@ class RcclComm:
             self.handle = None
 
 
+class P2PComm(RcclComm):
+    """One-shot peer-to-peer all-reduce (csrc/p2p.hip; prototype, ERL_DP_COLLECTIVE=p2p): the same library handle type as the
+    RCCL communicator, so `all_reduce_sum` and the C update loop take it unchanged.  torch.distributed carries every rank's
+    64-byte IPC handle to every rank and the all-ranks agreement that the peers' stages are mapped everywhere."""
+
+    kind = "p2p"
+    MAX_COUNT = 1 << 22            # floats per all-reduce the stages are sized for (16 MiB per half)
+
+    @classmethod
+    def create(cls, max_count: Optional[int] = None) -> Optional["P2PComm"]:
+        import ctypes
+        from . import _hip
+        L = _hip.lib()
+        distributed = is_distributed()
+        rank = dist.get_rank() if distributed else 0
+        world = dist.get_world_size() if distributed else 1
+        if world > 8:
+            return None
+        out = ctypes.c_void_p(None)
+        handle = (ctypes.c_uint8 * _hip.P2P_HANDLE_BYTES)()
+        ok = int(L.erl_comm_p2p_create(rank, world, int(max_count or cls.MAX_COUNT), ctypes.byref(out), handle) == 0 and bool(out.value))
+        handles = [bytes(handle) if ok else None]
+        if distributed:
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(handle) if ok else None)
+        if any(h is None for h in handles):
+            if ok:
+                L.erl_comm_destroy(out)
+            return None
+        blob = (ctypes.c_uint8 * (_hip.P2P_HANDLE_BYTES * world)).from_buffer_copy(b"".join(handles))
+        ok = int(L.erl_comm_p2p_connect(out, blob) == 0)
+        if distributed:
+            flag = th.tensor([ok], dtype=th.int32)
+            if dist.get_backend() == "nccl":
+                flag = flag.cuda()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            L.erl_comm_destroy(out)
+            return None
+        return cls(out.value, rank, world)
+
+
 _grad_comm: Optional[RcclComm] = None
 _grad_comm_tried = False
 
@@ -112,7 +157,11 @@ def gradient_comm() -> Optional[RcclComm]:
     if _grad_comm_tried:
         return _grad_comm
     _grad_comm_tried = True
-    if os.environ.get("ERL_DP_COLLECTIVE", "rccl") != "rccl" or not th.cuda.is_available():
+    mode = os.environ.get("ERL_DP_COLLECTIVE", "rccl")
+    if mode == "p2p" and th.cuda.is_available() and (is_distributed() or force_dp()):
+        _grad_comm = P2PComm.create()        # None (on every rank) when IPC / peer mapping is unavailable: torch.distributed then
+        return _grad_comm
+    if mode != "rccl" or not th.cuda.is_available():
         return None
     if is_distributed():
         if dist.get_backend() != "nccl":        # several ranks on one GPU (gloo tests): RCCL cannot span duplicates

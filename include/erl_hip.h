@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 11
+#define ERL_ABI_VERSION 12
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -312,6 +312,19 @@ ERL_API int erl_comm_init(const uint8_t *id_bytes, int rank, int world_size, voi
 ERL_API int erl_comm_destroy(void *comm);
 ERL_API int erl_comm_world_size(void *comm);
 ERL_API int erl_comm_allreduce_sum_f32(void *comm, float *buf, int64_t count, void *stream);
+
+/* One-shot peer-to-peer communicator (SURVEY 8e "better" option; prototype, opt-in): the same handle type as above, so
+ * erl_comm_allreduce_sum_f32 / erl_ppo_update_dp_f32 take it unchanged.  Every rank keeps a stage (2 x max_count floats) and
+ * a flag row in uncached device memory; the all-reduce is ONE launch: copy into the stage, publish a sequence number into
+ * every peer's flag row, wait for all of mine, sum the stages in rank order (peer reads over xGMI) -- bit-identical on
+ * every rank.  world_size <= 8.
+ *   all   : erl_comm_p2p_create(rank, world, max_count, &comm, handle)   (handle: ERL_P2P_HANDLE_BYTES, a hipIpcMemHandle_t)
+ *   ship every rank's handle to every rank out of band (torch.distributed), rank-major
+ *   all   : erl_comm_p2p_connect(comm, handles)                          (maps the peers' stages)
+ * A peer that never publishes is reported through erl_async_fault_count (bounded wait), not a hang. */
+#define ERL_P2P_HANDLE_BYTES 64
+ERL_API int erl_comm_p2p_create(int rank, int world_size, int64_t max_count, void **out_comm, uint8_t *out_handle);
+ERL_API int erl_comm_p2p_connect(void *comm, const uint8_t *handles);
 
 /* erl_ppo_update_f32 with the gradient all-reduce in the loop: ppo_step -> grad_reduce -> all-reduce(grads[k]) ->
  * clip_adam(grad_scale = 1/world).  comm == NULL degenerates to the single-process loop.  Every rank must call it with

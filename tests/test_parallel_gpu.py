@@ -57,6 +57,78 @@ def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False):
     parallel.shutdown()
 
 
+def _p2p_worker(rank, world, port, out_dir):
+    """the one-shot peer-to-peer all-reduce on its own: two ranks, ONE GPU, the peers' stages mapped through HIP IPC"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from elegantrl_amd import _hip, parallel
+    parallel.init_from_env(backend="gloo")
+    th.cuda.set_device(0)
+    comm = parallel.P2PComm.create(max_count=70000)
+    result = {"created": comm is not None}
+    if comm is not None:
+        g = th.Generator(device="cuda").manual_seed(1234 + rank)
+        outs, refs = [], []
+        for it, n in enumerate([50848, 1, 70000, 257, 50848, 50848, 4096, 50848]):     # both stage halves, several sizes, reuse
+            x = th.randn(n, device="cuda", generator=g) * (1 + it)
+            ref = x.cpu().clone()
+            parallel.dist.all_reduce(ref)                       # gloo on the host copy: the expected SUM (order-free for 2 ranks)
+            comm.all_reduce_sum(x)
+            th.cuda.synchronize()
+            outs.append(x.cpu().numpy())
+            refs.append(ref.numpy())
+        _hip.check_async_faults()
+        for k, (o, r) in enumerate(zip(outs, refs)):
+            np.save(os.path.join(out_dir, f"p2p_out{k}_{rank}.npy"), o)
+            np.save(os.path.join(out_dir, f"p2p_ref{k}_{rank}.npy"), r)
+        result["n"] = len(outs)
+        parallel.barrier()
+        comm.close()
+    np.save(os.path.join(out_dir, f"p2p_{rank}.npy"), np.array([int(result["created"]), result.get("n", 0)]))
+    parallel.barrier()
+    parallel.dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_p2p_allreduce_two_ranks_on_one_gpu(tmp_path):
+    """csrc/p2p.hip (prototype of SURVEY 8e's one-shot exchange): handle exchange, flag protocol, stage reuse over 8 back-to-back
+    all-reduces of different sizes; sums equal gloo's and are bit-identical on both ranks.  Skips when the box cannot share
+    device memory between two processes (IPC)."""
+    world = 2
+    mp.spawn(_p2p_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    meta = [np.load(tmp_path / f"p2p_{r}.npy") for r in range(world)]
+    if not all(m[0] for m in meta):
+        pytest.skip("HIP IPC between two processes on this device is unavailable")
+    for k in range(int(meta[0][1])):
+        o = [np.load(tmp_path / f"p2p_out{k}_{r}.npy") for r in range(world)]
+        ref = np.load(tmp_path / f"p2p_ref{k}_0.npy")
+        np.testing.assert_array_equal(o[0], o[1])
+        np.testing.assert_array_equal(o[0], ref)          # two addends: every summation order gives the same fp32 result
+
+
+def _worker_p2p_agent(rank, world, port, out_dir):
+    os.environ["ERL_DP_COLLECTIVE"] = "p2p"
+    _worker(rank, world, port, out_dir)
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_agent_in_lockstep_over_p2p(tmp_path):
+    """the whole data-parallel update loop (erl_ppo_update_dp_f32) with the peer-to-peer communicator in place of RCCL"""
+    world = 2
+    mp.spawn(_worker_p2p_agent, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ld = lambda n: [np.load(tmp_path / f"{n}_{r}.npy") for r in range(world)]   # noqa: E731
+    comm = ld("comm")
+    if not all(c[0] for c in comm):
+        pytest.skip("HIP IPC between two processes on this device is unavailable")
+    assert all(c[1] == 2 for c in comm)
+    w0, w, logs = ld("w0"), ld("w"), ld("logs")
+    np.testing.assert_array_equal(w0[0], w0[1])
+    assert not np.array_equal(w[0], w0[0])
+    np.testing.assert_array_equal(w[0], w[1])
+    np.testing.assert_allclose(logs[0], logs[1], rtol=1e-6)
+    assert np.isfinite(w[0]).all() and np.isfinite(logs[0]).all()
+
+
 @pytest.mark.timeout(600)
 def test_two_rank_agent_stays_in_lockstep(tmp_path):
     world = 2
