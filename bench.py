@@ -407,7 +407,7 @@ def main():
         sweep = gae_sweep(ops, dev)
         line["roofline_gae"]["sweep"] = sweep
         big = next(x for x in sweep if (x["H"], x["N"]) == (2048, 4096))
-        line["roofline_gae"]["at_2048x4096"] = {"kernel": "gae_lookback_kernel (+ slot memset)", "achieved": big["GBps"],
+        line["roofline_gae"]["at_2048x4096"] = {"kernel": "gae_lookback_kernel (library-owned granule table, no memset)", "achieved": big["GBps"],
                                                 "frac": big["frac"], "us": big["us"], "bytes_per_launch": big["bytes"],
                                                 "traffic": pmc_traffic("gae_lookback_kernel")}
     if world == 1 and not opt.no_cpu_baseline and not pendulum:      # the torch port has the synthetic env only
