@@ -250,12 +250,16 @@ class AgentPPO(AgentBase):
         H, N, S, A = horizon_len, self.num_envs, self.state_dim, self.action_dim
         dev = self.device
         # every element of the six buffers is written by the rollout below (row t by step t): no zero-fill launches
+        # (the interpreter's time before the first launch is GPU idle time -- the previous iteration ended in a host sync -- so
+        # the (H, N) planes come out of two allocator calls instead of seven)
         states = th.empty((H, N, S), dtype=th.float32, device=dev)
         actions = th.empty((H, N, A), dtype=th.float32, device=dev)
-        logprobs = th.empty((H, N), dtype=th.float32, device=dev)
-        rewards = th.empty((H, N), dtype=th.float32, device=dev)
-        terminals = th.empty((H, N), dtype=th.bool, device=dev)
-        truncates = th.empty((H, N), dtype=th.bool, device=dev)
+        hn = H * N
+        pitch = (hn + 255) // 256 * 256                    # every plane starts on a 256-byte boundary whatever H * N is
+        planes = th.empty((3, pitch), dtype=th.float32, device=dev)
+        logprobs, rewards = planes[0, :hn].view(H, N), planes[1, :hn].view(H, N)
+        flags = th.empty((2, pitch), dtype=th.bool, device=dev)
+        terminals, truncates = flags[0, :hn].view(H, N), flags[1, :hn].view(H, N)
         if self._env_action is None or self._env_action.shape != (N, A):
             self._env_action = th.empty((N, A), dtype=th.float32, device=dev)
         env_action = self._env_action
@@ -274,9 +278,8 @@ class AgentPPO(AgentBase):
                 and _hip.lib().erl_rollout_fused_supported(S, self.net_dims[0], self.net_dims[1], A)):
             # one persistent launch for all H steps: policy, env, buffer rows, reward scaling, flag inversion AND the critic's
             # values of every visited state + cri(last_state) (update_net's pre-pass, AgentPPO.py:141-143, :219-220)
-            undones = th.empty((H, N), dtype=th.bool, device=dev)
-            unmasks = th.empty((H, N), dtype=th.bool, device=dev)
-            values = th.empty((H, N), dtype=th.float32, device=dev)
+            undones, unmasks = terminals, truncates          # the kernel writes the inverted flags straight into these planes
+            values = planes[2, :hn].view(H, N)
             next_value = th.empty((N,), dtype=th.float32, device=dev)
             noise = None if noise is None else noise.contiguous()
             env.fused_rollout(self, H, noise, (states, actions, logprobs, rewards, undones, unmasks), values, next_value)
