@@ -122,17 +122,38 @@ def gae_sweep(ops, dev):
     return out
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json: separate --pmc
-    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); None when the file does not carry the kernel."""
+# the files a kernel's HBM traffic depends on (what the PMC passes were collected on is stamped with their hash)
+KERNEL_SOURCES = {
+    "ppo_step_w4_kernel": ["ppo_step_w4.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
+    "ppo_step2_kernel": ["ppo_step.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
+    "gae_lookback_kernel": ["gae_lookback.hip"],
+}
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+
+
+def kernel_source_sha16(kernel: str):
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES.get(kernel, []):
+        with open(os.path.join(ROOT, "elegantrl_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """(HBM bytes per launch, provenance) from the committed rocprofv3 PMC passes (PMC_FILE: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 correction applied, tools/pmc_summarise.py).  The file stamps every kernel with the hash of
+    the sources it was collected on; when the kernel's sources have changed since, the number is STALE and None is
+    reported (bench.py itself cannot collect counters: that needs rocprofv3 around the process)."""
+    src = {"file": PMC_FILE, "kernel_source_sha16": kernel_source_sha16(kernel), "collected_on_sha16": None, "stale": True}
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        for name, v in prof["kernels"].items():
-            if name.startswith(kernel_prefix):
-                return v["hbm_bytes_per_launch"]
+        prof = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        v = prof["kernels"][kernel]
+        src["collected_on_sha16"] = v.get("source_sha16")
+        src["stale"] = v.get("source_sha16") != src["kernel_source_sha16"]
+        return (None if src["stale"] else v["hbm_bytes_per_launch"]), src
     except Exception:
-        pass
-    return None
+        return None, src
 
 
 def log(msg):
@@ -283,6 +304,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=12)   # ~10-15 s of host work on 16 cores
     ap.add_argument("--k6-sample", type=int, default=16,
                     help="bracket every n-th K6 launch with HIP events (0 = none): each bracket costs ~3 us of stream time")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="after the primary timed region, repeat it this many times and report min / median / max ms per step "
+                         "(`extra`; box variance next to the one primary sample; 0 = off)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--config", choices=["c4", "c2", "c3", "c5"], default="c4",
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
@@ -352,9 +376,20 @@ def main():
     k6_seconds, k6_launches = _hip.k6_timing_read()
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
+    # box variance made visible next to the driver's single sample: the same region repeated (not part of `value`)
+    repeats = []
+    for _ in range(opt.repeats):
+        parallel.barrier()
+        th.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(opt.steps):
+            step()
+        th.cuda.synchronize()
+        parallel.barrier()
+        repeats.append(parallel.all_reduce_max_float(time.perf_counter() - t1, device=dev) / opt.steps * 1e3)
     allreduce = None
-    if world > 1:       # the exchange step on its own: the flat gradient row through the route update_net uses (every rank takes part)
-        comm = parallel.gradient_comm()
+    if world > 1 or parallel.force_dp():   # the exchange step on its own, through the route update_net uses (every rank takes part)
+        comm = parallel.gradient_comm(agent._stride)
         buf = th.zeros(agent._stride, dtype=th.float32, device=dev)
         red = (lambda: comm.all_reduce_sum(buf)) if comm is not None else (lambda: parallel.all_reduce_sum(buf))
         for _ in range(20):
@@ -368,11 +403,12 @@ def main():
         e1.record()
         th.cuda.synchronize()
         us = parallel.all_reduce_max_float(e0.elapsed_time(e1) * 5.0, device=dev)      # ms / 200 calls -> us per call
-        route = "torch.distributed" if comm is None else (
-            "library one-shot peer-to-peer all-reduce (csrc/p2p.hip) on the kernels' stream" if getattr(comm, "kind", "rccl") == "p2p"
-            else "library RCCL communicator on the kernels' stream")
-        allreduce = {"route": route, "ranks_seen_by_rccl": comm.world if comm is not None else world, "bytes": int(buf.numel() * 4),
-                     "us_per_call": round(us, 2), "calls_per_step": UPDATE_TIMES}
+        rep = parallel.route_report()      # what the start-up self-test measured and chose (both library routes)
+        allreduce = {"selected": rep.get("selected"), "mode": rep.get("mode"), "rccl_us": rep.get("rccl_us"), "p2p_us": rep.get("p2p_us"),
+                     "rccl_selftest": rep.get("rccl_selftest"), "p2p_selftest": rep.get("p2p_selftest"),
+                     "ranks_seen_by_rccl": rep.get("ranks_seen_by_rccl"), "bytes": int(buf.numel() * 4),
+                     "selected_us_per_call_after_run": round(us, 2), "calls_per_step": UPDATE_TIMES,
+                     "stats_exchange": "same route (fp64, 8 sums per iteration)" if comm is not None else "torch.distributed"}
     if rank != 0:
         return
     env_steps = world * N_ENVS * HORIZON * opt.steps
@@ -382,6 +418,7 @@ def main():
     k6_kernel = "ppo_step_w4_kernel" if (NET_DIMS == [128, 128] and STATE_DIM <= 64 and STATE_DIM % 4 == 0 and ACTION_DIM <= 8) \
         else "ppo_step2_kernel"
     gae_s = t_gae.mean_seconds()
+    k6_traffic, k6_traffic_src = pmc_traffic(k6_kernel) if opt.config == "c4" else (None, None)
     line = {
         "metric": cfg["metric"], "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
@@ -391,7 +428,7 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     "traffic": pmc_traffic(k6_kernel) if opt.config == "c4" else None, "flops_per_launch": flops,
+                     "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops,
                      "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6},
         "roofline_gae": {"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
                          "bound": "hbm",
@@ -402,14 +439,20 @@ def main():
     }
     if allreduce is not None:
         line["allreduce"] = allreduce
+    if repeats:
+        srt = sorted(repeats)
+        line["extra"] = {"repeated_regions_ms_per_step": [round(x, 3) for x in repeats], "min": round(srt[0], 3),
+                         "median": round(srt[len(srt) // 2], 3), "max": round(srt[-1], 3), "primary": round(elapsed / opt.steps * 1e3, 3),
+                         "note": f"{len(repeats)} more timed regions of {opt.steps} steps each after the primary one (not part of `value`)"}
     if not opt.no_gae_sweep and opt.config == "c4":
         log("GAE size sweep")
         sweep = gae_sweep(ops, dev)
         line["roofline_gae"]["sweep"] = sweep
         big = next(x for x in sweep if (x["H"], x["N"]) == (2048, 4096))
+        gae_tr, gae_tr_src = pmc_traffic("gae_lookback_kernel")
         line["roofline_gae"]["at_2048x4096"] = {"kernel": "gae_lookback_kernel (library-owned granule table, no memset)", "achieved": big["GBps"],
                                                 "frac": big["frac"], "us": big["us"], "bytes_per_launch": big["bytes"],
-                                                "traffic": pmc_traffic("gae_lookback_kernel")}
+                                                "traffic": gae_tr, "traffic_source": gae_tr_src}
     if world == 1 and not opt.no_cpu_baseline and not pendulum:      # the torch port has the synthetic env only
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
         line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else max(2, opt.cpu_iters // 4), opt.config)

@@ -22,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 12
+ABI_VERSION = 13
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -84,8 +84,16 @@ _SIGNATURES = {
     "erl_comm_destroy": (c_int, [_P]),
     "erl_comm_world_size": (c_int, [_P]),
     "erl_comm_allreduce_sum_f32": (c_int, [_P, _P, c_int64, _P]),
+    "erl_comm_allreduce_sum_f64": (c_int, [_P, _P, c_int64, _P]),
+    "erl_comm_kind": (c_int, [_P]),
+    "erl_comm_reduce_exchange_f32": (c_int, [_P, _P, c_int, c_int64, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
+    "erl_grad_reduce_partials_f32": (c_int, [_P, c_int, c_int64, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
+    "erl_grad_sq_partials_f32": (c_int, [_P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
+    "erl_clip_adam_partials_f32": (c_int, [_P, _P, _P, _P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
+                                           c_float, c_float, c_float, c_float, c_float, _P]),
     "erl_comm_p2p_create": (c_int, [c_int, c_int, c_int64, POINTER(c_void_p), _P]),
     "erl_comm_p2p_connect": (c_int, [_P, _P]),
+    "erl_comm_p2p_set_spin": (c_int, [_P, ctypes.c_uint32]),
     "erl_ppo_update_dp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
                                       _P, c_int64, c_int, c_float, c_float, c_int, _P, _P, c_int32, c_float, c_float, c_float,
                                       c_float, c_float, _P, _P]),
@@ -191,7 +199,8 @@ def flag_ptr(t: th.Tensor) -> int:
 
 def check_async_faults() -> None:
     """raise if a kernel recorded a device-side fault since the last check (call after a stream synchronisation; reads a
-    pinned host word, no GPU work): today the look-back GAE scan's bounded wait (csrc/gae_lookback.hip)."""
+    pinned host block, no GPU work): the look-back GAE scan's bounded wait (csrc/gae_lookback.hip), the peer-to-peer gradient
+    exchange's wait for a peer (csrc/grad_tail.hip), the clip + Adam grid wait (csrc/optim.hip) -- the message says which."""
     n = lib().erl_async_fault_count(1)
     if n:
         msg = lib().erl_last_error_string()

@@ -430,8 +430,14 @@ class AgentPPO(AgentBase):
         else:
             values, next_value = self.get_values(states), None                        # (H, N)
         advantages, reward_sums = self._gae(rewards, undones, unmasks, values, stats=self._stats, next_value=next_value)
-        if self.world_size > 1:                                                       # one normalisation for the whole job
-            parallel.all_reduce_sum(self._stats)
+        dp = self.world_size > 1 or parallel.force_dp()
+        # the job's exchange route (selected once, by a self-test: parallel.gradient_comm); None: torch.distributed
+        comm = parallel.gradient_comm(self._stride) if dp else None
+        if self.world_size > 1:                                                       # one normalisation for the whole job:
+            if comm is not None:                                                      # the 5 sums ride the gradient's route
+                comm.all_reduce_sum(self._stats)
+            else:
+                parallel.all_reduce_sum(self._stats)
         advantages = ops.adv_normalize(advantages, self._stats, out=advantages)
         assert logprobs.shape == advantages.shape == reward_sums.shape == (H, N)
 
@@ -450,8 +456,6 @@ class AgentPPO(AgentBase):
         groups = [(0, self._Pa), (self._Pa, self._Pc)]
         inv_batch = 1.0 / B
         grad_scale = 1.0 / self.world_size
-        dp = self.world_size > 1 or parallel.force_dp()
-        comm = parallel.gradient_comm() if dp else None       # library-owned RCCL communicator (None: torch.distributed)
         if not self._fused:             # generic-shape networks: layered path, summed gradient written directly
             for k in range(update_times):
                 g = self._grads[k]
@@ -474,7 +478,8 @@ class AgentPPO(AgentBase):
             return obj_critic, obj_actor, obj_entropy
         h1, h2 = self.net_dims
         if not dp or comm is not None:  # the whole minibatch loop is enqueued by one C call (no interpreter on the launch
-            # path); data-parallel ranks pass the library's RCCL communicator and the all-reduce rides the same stream
+            # path); data-parallel ranks pass the library's communicator: the exchange is part of the slab-reduction launch
+            # (peer-to-peer route) or an RCCL all-reduce on the same stream
             ops.ppo_update(self._flat, self._exp_avg, self._exp_avg_sq, a.state_avg.data, a.state_std.data, c.state_avg.data,
                            c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
                            advantages, reward_sums, ids, float(self.ratio_clip), self.lambda_entropy_value, self._slabs,
@@ -505,10 +510,12 @@ class AgentPPO(AgentBase):
                     _hip.check(rc, "erl_ppo_step_f32 / erl_grad_reduce_f32")
                 parallel.all_reduce_sum(self._grads[k])
                 self._adam_step += 1
-                rc = L.erl_clip_adam_f32(pf, p_g + 4 * k * stride, p_m1, p_m2, off, ln, 2, None, self._adam_step, lr, 0.9, 0.999,
-                                         1e-8, max_norm, grad_scale, sp)
+                # the same two-launch tail as the C loop (partial norms, then clip + Adam): bit-identical weights on every route
+                rc = L.erl_grad_sq_partials_f32(p_g + 4 * k * stride, stride, off, ln, 2, grad_scale, sp)
+                rc = rc or L.erl_clip_adam_partials_f32(pf, p_g + 4 * k * stride, p_m1, p_m2, stride, off, ln, 2, self._adam_step, lr,
+                                                        0.9, 0.999, 1e-8, max_norm, grad_scale, sp)
                 if rc:
-                    _hip.check(rc, "erl_clip_adam_f32")
+                    _hip.check(rc, "erl_grad_sq_partials_f32 / erl_clip_adam_partials_f32")
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
         logs = self._grads[:update_times, self._Pa + self._Pc:self._Pa + self._Pc + 3].mean(dim=0) * grad_scale
         obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())           # the only host sync of update_net

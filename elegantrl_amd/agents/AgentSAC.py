@@ -201,6 +201,7 @@ class AgentSAC(AgentBase):
             batch = buffer.sample(self.batch_size, ids=ids)                               # HIP K9
             self._update_on_batch(batch, self._objs, noises)
         oc, oa = self._objs.cpu().tolist()
+        _hip.check_async_faults()          # the stream is drained: a skipped optimiser step (grid-wait timeout) raises here
         return oc, oa
 
     def _per_step(self, buffer, objs_out: TEN, noises=None):
@@ -227,4 +228,5 @@ class AgentSAC(AgentBase):
             else:
                 self._update_on_batch(buffer.sample(self.batch_size, reuse=True), objs[t])   # the batch is consumed before the next draw
         o = objs.cpu().numpy()
+        _hip.check_async_faults()          # the stream is drained: a skipped optimiser step (grid-wait timeout) raises here
         return float(np.nanmean(o[:, 0])), float(np.nanmean(o[:, 1]))

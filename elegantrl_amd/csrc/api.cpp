@@ -32,6 +32,54 @@ extern "C" int erl_device_info(int *num_cu, int *lds_bytes_per_block)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Device-side faults that cannot be returned by the (asynchronous) launch call are counted in a pinned, host-mapped block,
+// ONE WORD PER SOURCE: the kernel bumps its word with a system-scope atomic, the host reads them without touching the GPU
+// once the stream has been synchronised (erl_async_fault_count).  Allocated on first use; NULL when pinned memory is
+// unavailable.
+// ---------------------------------------------------------------------------------------------------------
+static uint32_t *g_fault_host = nullptr, *g_fault_dev = nullptr;
+uint32_t *erl_fault_word(int source)
+{
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            g_fault_host = (uint32_t *)h;
+            g_fault_dev = (uint32_t *)d;
+            memset(h, 0, 64);
+        } else {
+            if (h) (void)hipHostFree(h);
+            (void)hipGetLastError();
+        }
+    }
+    return g_fault_dev && source >= 0 && source < ERL_FAULT_SOURCES ? g_fault_dev + source : nullptr;
+}
+
+extern "C" int erl_async_fault_count(int reset)
+{
+    if (!g_fault_host) return 0;
+    static const char *const what[ERL_FAULT_SOURCES] = {
+        "gae_lookback_kernel: %u look-back wait(s) timed out (a predecessor slab never published); the affected advantages are NaN. ",
+        "peer-to-peer gradient exchange: %u wait(s) for a peer's slice timed out (a rank is missing or stalled); the summed gradients "
+        "of those minibatches are invalid. ",
+        "clip + Adam grid wait: %u workgroup(s) gave up waiting for the rest of the launch (device shared with another process?); "
+        "those parameter updates were SKIPPED. "};
+    char msg[512] = "";
+    uint64_t total = 0;
+    for (int s = 0; s < ERL_FAULT_SOURCES; ++s) {
+        const uint32_t n = __atomic_load_n(g_fault_host + s, __ATOMIC_ACQUIRE);
+        if (!n) continue;
+        if (reset) __atomic_store_n(g_fault_host + s, 0u, __ATOMIC_RELEASE);
+        total += n;
+        const size_t used = strlen(msg);
+        snprintf(msg + used, sizeof(msg) - used, what[s], n);
+    }
+    if (total) erl_set_error("%s", msg);
+    return (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Host-side batching: one C call enqueues a whole PPO update (update_times x [K6, slab reduce, clip + Adam]) so
 // that the Python interpreter is off the launch path (about 3 us per launch from here instead of about 10 from
 // ctypes).  The loop itself lives in comm.cpp (erl_ppo_update_dp_f32): under data parallelism the gradient all-reduce

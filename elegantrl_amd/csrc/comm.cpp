@@ -114,9 +114,51 @@ extern "C" int erl_comm_allreduce_sum_f32(void *comm, float *buf, int64_t count,
     ERL_REQUIRE(comm && buf && count >= 0, "erl_comm_allreduce_sum_f32: bad argument");
     if (count == 0) return ERL_OK;
     Comm *c = (Comm *)comm;
-    if (c->p2p) return erl_p2p_allreduce(c->p2p, buf, count, (hipStream_t)stream);
+    if (c->p2p) {                            // the fused tail's kernel with ONE "slab": push, flag, wait, rank-ordered sum
+        ErlExchange ex;
+        int rc = erl_p2p_next(c->p2p, &ex);
+        if (rc) return rc;
+        return erl_launch_reduce_exchange_f32(buf, 1, count, buf, nullptr, nullptr, 0, 1.f, false, &ex, (hipStream_t)stream);
+    }
     return rccl_status(rccl().AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->nccl, (hipStream_t)stream),
                        "ncclAllReduce");
+}
+
+extern "C" int erl_comm_allreduce_sum_f64(void *comm, double *buf, int64_t count, void *stream)
+{
+    ERL_REQUIRE(comm && buf && count >= 0, "erl_comm_allreduce_sum_f64: bad argument");
+    if (count == 0) return ERL_OK;
+    Comm *c = (Comm *)comm;
+    if (c->p2p) {
+        ErlExchange ex;
+        int rc = erl_p2p_next(c->p2p, &ex);
+        if (rc) return rc;
+        return erl_launch_exchange_f64(buf, count, &ex, (hipStream_t)stream);
+    }
+    return rccl_status(rccl().AllReduce(buf, buf, (size_t)count, ncclFloat64, ncclSum, c->nccl, (hipStream_t)stream),
+                       "ncclAllReduce(f64)");
+}
+
+extern "C" int erl_comm_kind(void *comm) { return comm ? (((Comm *)comm)->p2p ? ERL_COMM_KIND_P2P : ERL_COMM_KIND_RCCL) : -1; }
+
+// launch 1 of the data-parallel optimiser tail on its own (the update loop below calls the same code): slab reduction +
+// exchange + partial norms for erl_clip_adam_partials_f32.  RCCL communicators take three launches for it.
+extern "C" int erl_comm_reduce_exchange_f32(void *comm, const float *slabs, int n_slabs, int64_t stride, float *flat_grad,
+                                            const int64_t *group_off, const int64_t *group_len, int n_groups, float grad_scale, void *stream)
+{
+    Comm *c = (Comm *)comm;
+    hipStream_t st = (hipStream_t)stream;
+    if (!c) return erl_launch_reduce_exchange_f32(slabs, n_slabs, stride, flat_grad, group_off, group_len, n_groups, grad_scale, true, nullptr, st);
+    if (c->p2p) {
+        ErlExchange ex;
+        int rc = erl_p2p_next(c->p2p, &ex);
+        if (rc) return rc;
+        return erl_launch_reduce_exchange_f32(slabs, n_slabs, stride, flat_grad, group_off, group_len, n_groups, grad_scale, true, &ex, st);
+    }
+    int rc = erl_launch_reduce_exchange_f32(slabs, n_slabs, stride, flat_grad, nullptr, nullptr, 0, 1.f, false, nullptr, st);
+    if (!rc) rc = erl_comm_allreduce_sum_f32(comm, flat_grad, stride, stream);
+    if (!rc) rc = erl_grad_sq_partials_f32(flat_grad, stride, group_off, group_len, n_groups, grad_scale, stream);
+    return rc;
 }
 
 // ---- one-shot peer-to-peer communicator (p2p.hip): same handle type, same erl_comm_allreduce_sum_f32 / erl_ppo_update_dp_f32
@@ -136,6 +178,13 @@ extern "C" int erl_comm_p2p_connect(void *comm, const uint8_t *handles)
 {
     ERL_REQUIRE(comm && ((Comm *)comm)->p2p, "erl_comm_p2p_connect: not a peer-to-peer communicator");
     return erl_p2p_connect(((Comm *)comm)->p2p, handles);
+}
+
+extern "C" int erl_comm_p2p_set_spin(void *comm, uint32_t spins)
+{
+    ERL_REQUIRE(comm && ((Comm *)comm)->p2p, "erl_comm_p2p_set_spin: not a peer-to-peer communicator");
+    erl_p2p_set_spin(((Comm *)comm)->p2p, spins);
+    return ERL_OK;
 }
 
 extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg, const float *act_std,
@@ -174,10 +223,11 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
             if (rc) return rc;
             continue;
         }
-        if ((rc = erl_grad_reduce_f32(slabs, n_slabs, stride, g, stream))) return rc;
-        if (comm && (rc = erl_comm_allreduce_sum_f32(comm, g, stride, stream))) return rc;   // gradient + the 3 logged objectives
-        if ((rc = erl_clip_adam_f32(flat_params, g, exp_avg, exp_avg_sq, off, len, 2, nullptr, first_step + k, lr, beta1, beta2, eps,
-                                    max_norm, grad_scale, stream)))
+        // launch 1: slab reduction [+ the exchange, inside the same kernel on a peer-to-peer communicator] + partial norms;
+        // launch 2: clip + Adam from the partial norms.  Gradient + the 3 logged objectives travel in one row.
+        if ((rc = erl_comm_reduce_exchange_f32(comm, slabs, n_slabs, stride, g, off, len, 2, grad_scale, stream))) return rc;
+        if ((rc = erl_clip_adam_partials_f32(flat_params, g, exp_avg, exp_avg_sq, stride, off, len, 2, first_step + k, lr, beta1, beta2, eps,
+                                             max_norm, grad_scale, stream)))
             return rc;
     }
     return ERL_OK;

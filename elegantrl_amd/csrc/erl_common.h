@@ -10,14 +10,32 @@
 // error plumbing (host)
 // ---------------------------------------------------------------------------------------------
 void erl_set_error(const char *fmt, ...);
-// pinned host-mapped word that device code bumps for faults an asynchronous launch cannot return (gae_lookback.hip);
-// read through erl_async_fault_count.  NULL when pinned memory is unavailable.
-uint32_t *erl_fault_word();
-// p2p.hip (one-shot peer-to-peer all-reduce), driven by comm.cpp
+// pinned host-mapped counters that device code bumps for faults an asynchronous launch cannot return; one word per source
+// (api.cpp), read through erl_async_fault_count.  NULL when pinned memory is unavailable.
+enum ErlFaultSource { ERL_FAULT_GAE_LOOKBACK = 0, ERL_FAULT_P2P_EXCHANGE = 1, ERL_FAULT_ADAM_GRID_WAIT = 2, ERL_FAULT_SOURCES = 3 };
+uint32_t *erl_fault_word(int source);
+
+// ---- one-shot peer-to-peer exchange (p2p.hip owns the IPC-mapped stages, grad_tail.hip the kernels) ----------------------
+#define ERL_P2P_MAX_WORLD 8
+struct ErlExchange {
+    char *stage[ERL_P2P_MAX_WORLD];       // rank r's stage: [half 0: world rows][half 1: world rows] (own rank: local pointer)
+    uint32_t *flags[ERL_P2P_MAX_WORLD];   // rank r's flag table: [sender rank][workgroup] sequence numbers
+    int64_t half_bytes, row_bytes;
+    int nblk_max;                         // workgroups (256-element slices) a row is sized for
+    uint32_t seq, spin_limit;
+    int rank, world;
+    uint32_t *fault;
+};
 int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *out_handle);
 int erl_p2p_connect(void *p2p, const uint8_t *handles);
-int erl_p2p_allreduce(void *p2p, float *buf, int64_t count, hipStream_t stream);
+// the exchange descriptor of the NEXT launch on this communicator (advances the sequence number)
+int erl_p2p_next(void *p2p, ErlExchange *out);
+void erl_p2p_set_spin(void *p2p, uint32_t spins);      // 0 restores the default bound
 void erl_p2p_destroy(void *p2p);
+// grad_tail.hip
+int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len,
+                                   int n_groups, float grad_scale, bool want_partials, const ErlExchange *ex, hipStream_t stream);
+int erl_launch_exchange_f64(double *buf, int64_t count, const ErlExchange *ex, hipStream_t stream);
 
 #define ERL_REQUIRE(cond, ...)                 \
     do {                                       \

@@ -328,38 +328,6 @@ struct LbTable {
 };
 static LbTable g_lb_table[32];
 
-// Device-side faults that cannot be returned by the (asynchronous) launch call are counted in ONE pinned, host-mapped
-// word: the kernel bumps it with a system-scope atomic, the host reads it without touching the GPU once the stream has
-// been synchronised (erl_async_fault_count).  Allocated on first use; NULL when pinned memory is unavailable.
-static uint32_t *g_fault_host = nullptr, *g_fault_dev = nullptr;
-uint32_t *erl_fault_word()
-{
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        void *h = nullptr, *d = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
-            g_fault_host = (uint32_t *)h;
-            g_fault_dev = (uint32_t *)d;
-            *g_fault_host = 0u;
-        } else {
-            if (h) (void)hipHostFree(h);
-            (void)hipGetLastError();
-        }
-    }
-    return g_fault_dev;
-}
-
-extern "C" int erl_async_fault_count(int reset)
-{
-    if (!g_fault_host) return 0;
-    const uint32_t n = __atomic_load_n(g_fault_host, __ATOMIC_ACQUIRE);
-    if (reset && n) __atomic_store_n(g_fault_host, 0u, __ATOMIC_RELEASE);
-    if (n) erl_set_error("gae_lookback_kernel: %u look-back wait(s) timed out (a predecessor slab never published); the affected "
-                         "advantages are NaN", n);
-    return (int)(n > 0x7fffffffu ? 0x7fffffffu : n);
-}
-
 // Enqueues [memset +] kernel.  workspace layout (fallback path): [ticket: 256 B][slots: K*N*8 B][partials: nblk*24 B].
 // Returns the number of statistics partials (blocks) through *nparts and their location through *partials.
 int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
@@ -382,7 +350,7 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     g.H = (int)H; g.N = (int)N; g.G = (int)G; g.K = (int)K;
     g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
     g.partials = (double *)(ws + 256 + slot_bytes);
-    g.fault = erl_fault_word();
+    g.fault = erl_fault_word(ERL_FAULT_GAE_LOOKBACK);
     {
         const int lim = env_int("ERL_GAE_LB_SPIN", 1 << 22);
         g.spin_limit = lim > 0 ? (uint32_t)lim : 1u;

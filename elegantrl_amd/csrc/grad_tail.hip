@@ -1,0 +1,265 @@
+// The optimiser tail of a PPO minibatch (elegantrl/agents/AgentBase.py:239-248 after backward()) in TWO launches, with the
+// data-parallel exchange inside the first one:
+//
+//   1  reduce_exchange_kernel   sums the per-workgroup gradient slabs of K6 (grad_reduce_kernel's association, bit for bit);
+//                               under data parallelism every workgroup then PUSHES its 256 reduced elements into its row of
+//                               every peer's stage (remote stores over xGMI, own rank: a local store), publishes a per-workgroup
+//                               sequence flag to every peer, waits for the `world` flags of its own slice (it polls LOCAL
+//                               memory only) and forms the rank-ordered sum of the rows from its own memory; writes the flat
+//                               gradient and the workgroup's fp64 share of every parameter group's squared norm
+//   2  clip_adam_partials_kernel sums <= ceil(stride / 256) partial norms in a fixed order (not 25k gradients per workgroup as
+//                               clip_adam_kernel does), clips, applies Adam to its own elements.
+//
+// No workgroup waits on another workgroup of its OWN launch (it publishes before it waits, and what it waits for is the same
+// slice of the peers' launches), so no co-residency is assumed; the wait is bounded and reports through
+// erl_async_fault_count.  Stage reuse: rows are double buffered by the parity of the sequence number; a rank overwrites half
+// (s & 1) in launch s + 2, which it enters only after launch s + 1 finished, whose workgroups waited for every peer's s + 1
+// flags, which a peer publishes only after ITS launch s has finished reading -- no second handshake.
+// Every rank adds the same rows in the same (rank) order: the replicas' gradients, hence weights, stay bit-identical.
+// The same kernel with one "slab" is the standalone all-reduce (erl_comm_allreduce_sum_f32 / _f64 on a p2p communicator)
+// and the squared-norm pass after a foreign all-reduce (RCCL / torch.distributed routes: erl_grad_sq_partials_f32).
+#include "erl_common.h"
+
+namespace {
+
+constexpr int kMaxPartialChunks = 32768;     // 64-element chunks the partial-norm table holds (rows up to 2 Mi floats)
+
+struct TailGroups {
+    int64_t off[4], len[4];
+};
+
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+
+// System-coherent accesses spelled out (sc0 sc1 = write through to / read from memory, past L1 and L2, local or over xGMI)
+// instead of C++ system-scope fences: a release / acquire fence at system scope is a whole-L2 write-back / invalidate PER
+// WAVE (buffer_wbl2 / buffer_inv sc1), 3184 of them per launch here -- measured 73 us for the 203 KB exchange against 9 us
+// for the slab reduction alone.  The stage is uncached memory and these accesses bypass the caches by themselves, so the
+// ordering that is needed is only: my stores are ACKNOWLEDGED (s_waitcnt vmcnt(0) in every storing wave) before the
+// workgroup barrier that precedes the flag store; the rows are read after the barrier that follows the flag poll.
+__device__ __forceinline__ void st_sys(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_sys(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ld_sys_issue(float &d, const float *p) { asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ld_sys_issue(double &d, const double *p) { asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(d) : "v"(p) : "memory"); }
+template <typename T>
+__device__ __forceinline__ void ld_sys_wait(T (&x)[ERL_P2P_MAX_WORLD])     // the loads above have landed; ties their registers to the wait
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])::"memory");
+}
+
+// NT threads reduce NT / 4 elements (4 threads per element, grad_reduce_kernel's association whatever NT is).  The partial
+// norms are per 64-element CHUNK (= the wave of threads that holds the chunk's sums: one butterfly, no cross-wave step), so
+// every block shape writes the same table bit for bit.
+template <typename T, bool DP, int NT>
+__global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int n_slabs, int64_t stride, T *out, TailGroups gr,
+                                                             int n_groups, float grad_scale, double *partials, ErlExchange ex)
+{
+    constexpr int NE = NT / 4;
+    __shared__ T part[4][NE];
+    const int el = threadIdx.x & (NE - 1), p = threadIdx.x / NE;
+    const int64_t i = (int64_t)blockIdx.x * NE + el;
+    T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < stride) {                                  // (the loop nest of grad_reduce_kernel, mlp.hip: same association)
+        const T *src = slabs + i;
+        int k = p;
+        for (; k + 124 < n_slabs; k += 128) {          // 32 loads in flight: one round trip per 128 slabs
+            T x[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) x[u] = ld_stream(src + (size_t)(k + 4 * u) * stride);   // slabs are streamed once
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += x[8 * v + u];
+        }
+        for (; k + 28 < n_slabs; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += src[(size_t)(k + 4 * u) * stride];
+        }
+        for (; k < n_slabs; k += 4) s[0] += src[(size_t)k * stride];
+    }
+    part[p][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    T gsum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);        // all four threads of an element hold it
+    if (DP) {
+        // ---- push my reduced slice into my row of every rank's stage (thread quarter p serves ranks p, p + 4)
+        const int64_t half_off = (int64_t)(ex.seq & 1u) * ex.half_bytes;
+        if (i < stride)
+            for (int r = p; r < ex.world; r += 4)
+                st_sys(reinterpret_cast<T *>(ex.stage[r] + half_off + (int64_t)ex.rank * ex.row_bytes) + i, gsum);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores are acknowledged by their memories ...
+        __syncthreads();
+        if ((int)threadIdx.x < ex.world) {             // ... before the slice's flag is raised on every rank (myself included)
+            __hip_atomic_store(ex.flags[threadIdx.x] + (int64_t)ex.rank * ex.nblk_max + blockIdx.x, ex.seq, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t *f = ex.flags[ex.rank] + (int64_t)threadIdx.x * ex.nblk_max + blockIdx.x;     // my own memory
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - ex.seq) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > ex.spin_limit) {         // a peer never arrived: reported, never a hang (the sum below is then garbage)
+                    if (ex.fault) __hip_atomic_fetch_add(ex.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (p == 0 && i < stride) {                    // the rank-ordered sum of the rows, all from my own memory
+            const char *rows = ex.stage[ex.rank] + half_off;
+            T x[ERL_P2P_MAX_WORLD];
+#pragma unroll
+            for (int r = 0; r < ERL_P2P_MAX_WORLD; ++r) {
+                x[r] = (T)0;
+                if (r < ex.world) ld_sys_issue(x[r], reinterpret_cast<const T *>(rows + (int64_t)r * ex.row_bytes) + i);
+            }
+            ld_sys_wait(x);
+            gsum = x[0];
+#pragma unroll
+            for (int r = 1; r < ERL_P2P_MAX_WORLD; ++r)
+                if (r < ex.world) gsum += x[r];        // rank order on every rank: bit-identical sums
+        }
+    }
+    if (p == 0 && i < stride) out[i] = gsum;
+    if (partials && threadIdx.x < NE) {                // whole waves (NE is a multiple of 64): chunk c = elements 64 c .. 64 c + 63
+        const int64_t chunk = i >> 6;
+        for (int gi = 0; gi < n_groups; ++gi) {
+            const bool in = i < stride && i >= gr.off[gi] && i < gr.off[gi] + gr.len[gi];
+            const double xs = (double)((float)gsum * grad_scale);
+            const double t = wave_sum(in ? xs * xs : 0.0);
+            if ((threadIdx.x & 63) == 0) partials[(size_t)chunk * 4 + gi] = t;
+        }
+    }
+}
+
+// clip + Adam from the partial norms: grid = (ceil(longest / 1024), n_groups); one element per thread, its four loads
+// and the partials ride one round trip.
+__global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restrict__ params, const float *__restrict__ grads,
+                                                                  float *__restrict__ m1, float *__restrict__ m2, TailGroups gr,
+                                                                  const double *__restrict__ partials, int nblk, float beta1,
+                                                                  float beta2, float eps, float max_norm, float grad_scale,
+                                                                  float step_size, float bc2_sqrt)
+{
+    __shared__ double scratch[16];
+    const int gi = blockIdx.y;
+    const int64_t off = gr.off[gi], len = gr.len[gi];
+    const int64_t ie = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const bool own = ie < len;
+    float e_g = 0.f, e_m1 = 0.f, e_m2 = 0.f, e_p = 0.f;
+    if (own) { e_g = grads[off + ie]; e_m1 = m1[off + ie]; e_m2 = m2[off + ie]; e_p = params[off + ie]; }
+    double ss = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 1024) ss += partials[(size_t)b * 4 + gi];
+    ss = block_sum(ss, scratch);
+    const float total_norm = (float)sqrt(ss);
+    float coef = max_norm / (total_norm + 1e-6f);      // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+    coef = coef > 1.f ? 1.f : coef;
+    if (own) {
+        const float gx = e_g * (grad_scale * coef);
+        const float a = e_m1 * beta1 + (1.f - beta1) * gx;          // exp_avg.lerp_(grad, 1 - beta1)
+        const float b = e_m2 * beta2 + (1.f - beta2) * (gx * gx);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        m1[off + ie] = a;
+        m2[off + ie] = b;
+        const float denom = sqrtf(b) / bc2_sqrt + eps;
+        params[off + ie] = e_p - step_size * (a / denom);
+    }
+}
+
+// the partial-norm table of the update loop: library-owned, one per device, written by launch 1 and read by launch 2 of the
+// SAME stream (the update loop's)
+double *g_partials[32] = {};
+
+int fill_groups(const char *what, const int64_t *off, const int64_t *len, int n_groups, int64_t stride, TailGroups *gr)
+{
+    ERL_REQUIRE(n_groups >= 0 && n_groups <= 4 && (n_groups == 0 || (off && len)), "%s: n_groups must be 0..4", what);
+    for (int i = 0; i < 4; ++i) {
+        gr->off[i] = i < n_groups ? off[i] : 0;
+        gr->len[i] = i < n_groups ? len[i] : 0;
+        ERL_REQUIRE(gr->off[i] >= 0 && gr->len[i] >= 0 && gr->off[i] + gr->len[i] <= stride, "%s: group outside the gradient row", what);
+    }
+    return ERL_OK;
+}
+
+}  // namespace
+
+int erl_tail_partials(double **out)
+{
+    int dev = -1;
+    ERL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32, "gradient tail: no device");
+    if (!g_partials[dev]) {
+        void *p = nullptr;
+        int rc = erl_hip_status(hipMalloc(&p, (size_t)kMaxPartialChunks * 4 * sizeof(double)), "hipMalloc(partial norms)");
+        if (rc) return rc;
+        g_partials[dev] = (double *)p;
+    }
+    *out = g_partials[dev];
+    return ERL_OK;
+}
+
+// slabs (n_slabs, stride) -> out (stride) [+ exchange over `ex`] [+ partial norms of `n_groups` groups]
+int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len,
+                                   int n_groups, float grad_scale, bool want_partials, const ErlExchange *ex, hipStream_t stream)
+{
+    ERL_REQUIRE(slabs && out && n_slabs >= 1 && stride >= 1, "gradient reduce / exchange: bad argument");
+    TailGroups gr;
+    int rc = fill_groups("gradient reduce / exchange", off, len, n_groups, stride, &gr);
+    if (rc) return rc;
+    double *partials = nullptr;
+    if (want_partials) {
+        ERL_REQUIRE(erl_cdiv(stride, 64) <= kMaxPartialChunks, "gradient reduce / exchange: row too long for the partial-norm table (%lld floats)",
+                    (long long)stride);
+        if ((rc = erl_tail_partials(&partials))) return rc;
+    }
+    if (ex) {       // 1024 threads x 256 elements: one flag per workgroup and peer -- 199 x world small remote stores per exchange at config 4
+        const int64_t nblk = erl_cdiv(stride, 256);
+        ERL_REQUIRE(nblk <= ex->nblk_max && stride * (int64_t)sizeof(float) <= ex->row_bytes,
+                    "gradient exchange: %lld floats > the %lld the peer stages were sized for", (long long)stride, (long long)(ex->row_bytes / 4));
+        hipLaunchKernelGGL((reduce_exchange_kernel<float, true, 1024>), dim3((unsigned)nblk), dim3(1024), 0, stream, slabs, n_slabs, stride, out, gr,
+                           n_groups, grad_scale, partials, *ex);
+    } else {        // 256 threads x 64 elements (grad_reduce_kernel's shape: 795 workgroups keep every CU's memory pipes busy)
+        hipLaunchKernelGGL((reduce_exchange_kernel<float, false, 256>), dim3((unsigned)erl_cdiv(stride, 64)), dim3(256), 0, stream, slabs, n_slabs,
+                           stride, out, gr, n_groups, grad_scale, partials, ErlExchange{});
+    }
+    ERL_LAUNCH_CHECK("gradient reduce / exchange");
+}
+
+int erl_launch_exchange_f64(double *buf, int64_t count, const ErlExchange *ex, hipStream_t stream)
+{
+    ERL_REQUIRE(buf && ex && count >= 1, "erl_comm_allreduce_sum_f64: bad argument");
+    const int64_t nblk = erl_cdiv(count, 256);
+    ERL_REQUIRE(nblk <= ex->nblk_max && count * (int64_t)sizeof(double) <= ex->row_bytes,
+                "erl_comm_allreduce_sum_f64: %lld doubles > the %lld the peer stages were sized for", (long long)count, (long long)(ex->row_bytes / 8));
+    hipLaunchKernelGGL((reduce_exchange_kernel<double, true, 1024>), dim3((unsigned)nblk), dim3(1024), 0, stream, (const double *)buf, 1, count, buf,
+                       TailGroups{}, 0, 1.f, (double *)nullptr, *ex);
+    ERL_LAUNCH_CHECK("erl_comm_allreduce_sum_f64");
+}
+
+extern "C" int erl_grad_reduce_partials_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, const int64_t *group_off,
+                                            const int64_t *group_len, int n_groups, float grad_scale, void *stream)
+{
+    return erl_launch_reduce_exchange_f32(slabs, n_slabs, stride, flat_grad, group_off, group_len, n_groups, grad_scale, true, nullptr,
+                                          (hipStream_t)stream);
+}
+
+extern "C" int erl_grad_sq_partials_f32(float *grads, int64_t stride, const int64_t *group_off, const int64_t *group_len, int n_groups,
+                                        float grad_scale, void *stream)
+{
+    return erl_launch_reduce_exchange_f32(grads, 1, stride, grads, group_off, group_len, n_groups, grad_scale, true, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int erl_clip_adam_partials_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
+                                          const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
+                                          float beta2, float eps, float max_norm, float grad_scale, void *stream)
+{
+    ERL_REQUIRE(params && grads && exp_avg && exp_avg_sq && n_groups >= 1 && step >= 1, "erl_clip_adam_partials_f32: bad argument");
+    TailGroups gr;
+    int rc = fill_groups("erl_clip_adam_partials_f32", group_off, group_len, n_groups, stride, &gr);
+    if (rc) return rc;
+    const int64_t nblk = erl_cdiv(stride, 64);      // partial norms: one per 64-element chunk and group
+    ERL_REQUIRE(nblk <= kMaxPartialChunks, "erl_clip_adam_partials_f32: row too long (%lld floats)", (long long)stride);
+    double *partials = nullptr;
+    if ((rc = erl_tail_partials(&partials))) return rc;
+    int64_t longest = 1;
+    for (int i = 0; i < n_groups; ++i) longest = gr.len[i] > longest ? gr.len[i] : longest;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(clip_adam_partials_kernel, dim3((unsigned)erl_cdiv(longest, 1024), n_groups), dim3(1024), 0, (hipStream_t)stream, params,
+                       grads, exp_avg, exp_avg_sq, gr, partials, (int)nblk, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
+                       (float)sqrt(bc2));
+    ERL_LAUNCH_CHECK("erl_clip_adam_partials_f32");
+}

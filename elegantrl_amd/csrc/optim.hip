@@ -166,16 +166,19 @@ __global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__r
         // bounded all the same and reports through the fault word instead of hanging
         if (threadIdx.x == 0) {
             unsigned spins = 0;
+            s_last = 0;                                // reused: 1 = the wait timed out
             while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 24)) {
                     if (fault) __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    s_last = 1;
                     break;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        if (s_last) return;                            // incomplete norm: the update is SKIPPED (and reported), never applied
         const int nblk = gridDim.x;
         float mul = 0.f;
         for (int gi = 0; gi < n_groups; ++gi) {
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(1024) void clip_adam_grid_kernel(float *__restrict_
                                                               uint32_t *fault)
 {
     __shared__ double scratch[16];
+    __shared__ int s_timeout;
     const int gi = blockIdx.y;
     const int64_t off = gr.off[gi], len = gr.len[gi];
     const int64_t ie = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -274,16 +278,19 @@ __global__ __launch_bounds__(1024) void clip_adam_grid_kernel(float *__restrict_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
+        s_timeout = 0;
         while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24)) {
                 if (fault) __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_timeout = 1;
                 break;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    if (s_timeout) return;                             // incomplete norm: this workgroup's update is SKIPPED (and reported)
     double ss = 0.0;
     for (int b = threadIdx.x; b < (int)gridDim.x; b += 1024) ss += partials[(size_t)gi * gridDim.x + b];
     ss = block_sum(ss, scratch);
@@ -378,7 +385,7 @@ static int reduce_clip_adam_launch(bool grid_wait, const float *slabs, int n_sla
         hipLaunchKernelGGL(reduce_clip_adam_kernel<true>, dim3((unsigned)nblk), dim3(RA_T), 0, st, slabs, n_slabs, stride, flat_grad, params,
                            exp_avg, exp_avg_sq, gr, n_groups, lr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
                            (float)sqrt(bc2), reinterpret_cast<double *>(sc.ptr + 256), reinterpret_cast<unsigned *>(sc.ptr), target,
-                           erl_fault_word());
+                           erl_fault_word(ERL_FAULT_ADAM_GRID_WAIT));
     else
         hipLaunchKernelGGL(reduce_clip_adam_kernel<false>, dim3((unsigned)nblk), dim3(RA_T), 0, st, slabs, n_slabs, stride, flat_grad, params,
                            exp_avg, exp_avg_sq, gr, n_groups, lr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
@@ -428,7 +435,7 @@ extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_a
                 const double bc1 = 1.0 - pow((double)beta1, (double)step_offset), bc2 = 1.0 - pow((double)beta2, (double)step_offset);
                 hipLaunchKernelGGL(clip_adam_grid_kernel, dim3(bx, n_groups), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg,
                                    exp_avg_sq, gr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1), (float)sqrt(bc2),
-                                   reinterpret_cast<double *>(sc->ptr + 256), reinterpret_cast<unsigned *>(sc->ptr), target, erl_fault_word());
+                                   reinterpret_cast<double *>(sc->ptr + 256), reinterpret_cast<unsigned *>(sc->ptr), target, erl_fault_word(ERL_FAULT_ADAM_GRID_WAIT));
                 ERL_LAUNCH_CHECK("erl_clip_adam_f32");
             }
         }

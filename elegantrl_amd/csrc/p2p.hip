@@ -1,110 +1,59 @@
-// One-shot peer-to-peer SUM all-reduce of the flat gradient row (the "better" option): 203 KB per minibatch is
-// ~1.3 us of xGMI wire time, so the exchange is latency bound and a ring's 2 (P - 1) hops are the wrong shape for it.
-// Every rank keeps a STAGE (two halves, used alternately) and a row of FLAGS in uncached device memory that its peers map
-// through HIP IPC.  One launch per all-reduce, on the caller's stream, a few workgroups (always resident together):
+// One-shot peer-to-peer exchange of the flat gradient row (the "better" option): 203 KB per minibatch is a few
+// microseconds of xGMI wire time, so the exchange is latency bound and a ring's 2 (P - 1) hops are the wrong shape for it.
+// This file owns the memory: every rank keeps a FLAG table [sender][workgroup] and a STAGE of two halves x `world` rows in
+// uncached device memory that its peers map through HIP IPC.  The kernels that use it live in grad_tail.hip
+// (reduce_exchange_kernel): a rank PUSHES its reduced slice into its row of every peer's stage (posted remote stores, one-way
+// latency; no round trips over the fabric), raises a per-workgroup sequence flag on every peer, and each rank then polls and
+// sums its OWN memory in rank order.  The protocol, its reuse argument and its forward-progress argument are in the header
+// of grad_tail.hip.
 //
-//   1  copy the caller's buffer into my stage half (parity of the sequence number)
-//   2  the workgroup that finishes last publishes my sequence number into the flag word "rank" of EVERY peer (remote
-//      4-byte system-scope stores: a waiter polls its own memory, never the fabric)
-//   3  wait until all `world` words of my own flag row carry this sequence number (bounded; a lost peer is reported
-//      through erl_async_fault_count, never a hang)
-//   4  out[i] = stage_0[i] + stage_1[i] + ... in RANK ORDER (own stage locally, the others by peer reads over xGMI, all
-//      links in parallel): every rank forms bit-identical sums, so the replicas' weights cannot drift.
-//
-// Stage reuse is safe without a second handshake: a rank passes the wait of sequence s + 1 only after every peer has
-// published s + 1, which each peer does after its launch s has finished reading -- so when launch s + 2 overwrites the half
-// launch s used, nobody reads it any more.
-//
-// STATUS: prototype.  Protocol, handle exchange and arithmetic are tested with two ranks that share ONE GPU through IPC
-// (tests/test_parallel_gpu.py); it has never run across xGMI (no multi-GPU box was available), so it is opt-in
-// (ERL_DP_COLLECTIVE=p2p) and the RCCL all-reduce stays the default exchange.
+// Whether the route is used at all is decided at communicator creation by a self-test against RCCL (parallel.py): a route
+// that cannot be validated on the machine it runs on is never selected.
 #include "erl_common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace {
 
-constexpr int P2P_MAX_WORLD = 8;
-constexpr int P2P_WGS = 32, P2P_THREADS = 256;
-constexpr size_t P2P_FLAG_BYTES = 4096;              // flag row (one 64-byte line per sender) + the local arrival counter
-
-struct P2PArgs {
-    float *buf;
-    int64_t count;
-    float *stage[P2P_MAX_WORLD];                     // this launch's half of every rank's stage (own one: local pointer)
-    uint32_t *flags[P2P_MAX_WORLD];                  // every rank's flag row
-    unsigned *arrive;                                // local arrival counter (monotonic)
-    unsigned arrive_target;
-    uint32_t seq;
-    int rank, world;
-    uint32_t *fault;
-};
-
-__global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs g)
-{
-    __shared__ int s_last;
-    const int64_t per = (g.count + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < g.count ? lo + per : g.count;
-    float *mine = g.stage[g.rank];
-    for (int64_t i = lo + threadIdx.x; i < hi; i += P2P_THREADS) __builtin_nontemporal_store(g.buf[i], mine + i);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(g.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old + 1u == g.arrive_target;
-    }
-    __syncthreads();
-    if (s_last && (int)threadIdx.x < g.world) {      // my whole stage half is in memory: tell every rank (myself included)
-        __threadfence_system();
-        __hip_atomic_store(g.flags[threadIdx.x] + 16 * g.rank, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if ((int)threadIdx.x < g.world) {
-        const uint32_t *f = g.flags[g.rank] + 16 * threadIdx.x;
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - g.seq) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 24)) {
-                if (g.fault) __hip_atomic_fetch_add(g.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: drop every cached line of the stages
-    for (int64_t i = lo + threadIdx.x; i < hi; i += P2P_THREADS) {
-        float s = __builtin_nontemporal_load(g.stage[0] + i);
-        for (int r = 1; r < g.world; ++r) s += __builtin_nontemporal_load(g.stage[r] + i);
-        g.buf[i] = s;
-    }
-}
+constexpr size_t P2P_ALIGN = 4096;
 
 struct P2PComm {
     int rank = 0, world = 1, dev = -1;
-    int64_t max_count = 0;
-    char *local = nullptr;                           // [flags + counter: P2P_FLAG_BYTES][stage half 0][stage half 1]
-    char *peer[P2P_MAX_WORLD] = {};                  // mapped bases (peer[rank] == local)
-    bool opened[P2P_MAX_WORLD] = {};
+    int64_t max_count = 0;               // floats per exchange the rows are sized for
+    int64_t row_bytes = 0, half_bytes = 0, flag_bytes = 0;
+    int nblk_max = 0;
+    char *local = nullptr;               // [flags: world x nblk_max words][half 0: world rows][half 1: world rows]
+    char *peer[ERL_P2P_MAX_WORLD] = {};  // mapped bases (peer[rank] == local)
+    bool opened[ERL_P2P_MAX_WORLD] = {};
     uint32_t seq = 0;
-    unsigned arrive_base = 0;
+    uint32_t spin = 1u << 24;            // polls before a wait gives up (~1 us each: tens of seconds; ERL_P2P_SPIN / erl_comm_p2p_set_spin)
     bool connected = false;
 };
 
-size_t p2p_bytes(int64_t max_count) { return P2P_FLAG_BYTES + 2 * (size_t)((max_count + 63) / 64 * 64) * sizeof(float); }
+size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
-// opaque to comm.cpp -------------------------------------------------------------------------------------------------
 int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *out_handle)
 {
-    ERL_REQUIRE(out && out_handle && world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world && max_count >= 1,
-                "erl_comm_p2p_create: bad argument (world <= %d)", P2P_MAX_WORLD);
+    ERL_REQUIRE(out && out_handle && world >= 1 && world <= ERL_P2P_MAX_WORLD && rank >= 0 && rank < world && max_count >= 1 &&
+                    max_count <= (1LL << 26),
+                "erl_comm_p2p_create: bad argument (world <= %d)", ERL_P2P_MAX_WORLD);
     static_assert(sizeof(hipIpcMemHandle_t) == ERL_P2P_HANDLE_BYTES, "hipIpcMemHandle_t size changed");
     P2PComm *c = new P2PComm;
     c->rank = rank; c->world = world; c->max_count = max_count;
+    if (const char *e = getenv("ERL_P2P_SPIN"))
+        if (atol(e) > 0) c->spin = (uint32_t)atol(e);
+    c->nblk_max = (int)erl_cdiv(max_count, 256);
+    c->row_bytes = (int64_t)round_up((size_t)c->nblk_max * 256 * sizeof(float), 256);
+    c->half_bytes = (int64_t)world * c->row_bytes;
+    c->flag_bytes = (int64_t)round_up((size_t)world * c->nblk_max * sizeof(uint32_t), P2P_ALIGN);
+    const size_t bytes = (size_t)c->flag_bytes + 2 * (size_t)c->half_bytes;
     int rc = erl_hip_status(hipGetDevice(&c->dev), "hipGetDevice");
     void *p = nullptr;
-    if (!rc) rc = erl_hip_status(hipExtMallocWithFlags(&p, p2p_bytes(max_count), hipDeviceMallocUncached), "hipExtMallocWithFlags(uncached stage)");
-    if (!rc) rc = erl_hip_status(hipMemset(p, 0, p2p_bytes(max_count)), "hipMemset(stage)");
+    if (!rc) rc = erl_hip_status(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached), "hipExtMallocWithFlags(uncached stage)");
+    if (!rc) rc = erl_hip_status(hipMemset(p, 0, bytes), "hipMemset(stage)");
     if (!rc) rc = erl_hip_status(hipDeviceSynchronize(), "hipDeviceSynchronize");     // zeroed before any peer can learn the handle
     hipIpcMemHandle_t h;
     if (!rc) rc = erl_hip_status(hipIpcGetMemHandle(&h, p), "hipIpcGetMemHandle");
@@ -138,28 +87,29 @@ int erl_p2p_connect(void *p2p, const uint8_t *handles)
     return ERL_OK;
 }
 
-int erl_p2p_allreduce(void *p2p, float *buf, int64_t count, hipStream_t stream)
+int erl_p2p_next(void *p2p, ErlExchange *ex)
 {
     P2PComm *c = (P2PComm *)p2p;
-    ERL_REQUIRE(c && c->connected, "erl_comm_allreduce_sum_f32: peer stages are not connected (erl_comm_p2p_connect)");
-    ERL_REQUIRE(count <= c->max_count, "erl_comm_allreduce_sum_f32: %lld floats > the %lld the peer stages were sized for", (long long)count,
-                (long long)c->max_count);
-    P2PArgs g{};
-    g.buf = buf; g.count = count; g.rank = c->rank; g.world = c->world;
-    g.seq = ++c->seq;
-    const size_t half = (size_t)((c->max_count + 63) / 64 * 64) * sizeof(float);
+    ERL_REQUIRE(c && c->connected && ex, "peer-to-peer exchange: the peer stages are not connected (erl_comm_p2p_connect)");
+    *ex = ErlExchange{};
     for (int r = 0; r < c->world; ++r) {
-        g.stage[r] = reinterpret_cast<float *>(c->peer[r] + P2P_FLAG_BYTES + (g.seq & 1u) * half);
-        g.flags[r] = reinterpret_cast<uint32_t *>(c->peer[r]);
+        ex->flags[r] = reinterpret_cast<uint32_t *>(c->peer[r]);
+        ex->stage[r] = c->peer[r] + c->flag_bytes;
     }
-    g.arrive = reinterpret_cast<unsigned *>(c->local + P2P_FLAG_BYTES - 64);
-    int wgs = (int)erl_cdiv(count, 4 * P2P_THREADS);
-    wgs = wgs < 1 ? 1 : (wgs > P2P_WGS ? P2P_WGS : wgs);
-    c->arrive_base += (unsigned)wgs;                 // wraps with the device counter: equality is all the kernel tests
-    g.arrive_target = c->arrive_base;
-    g.fault = erl_fault_word();
-    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(wgs), dim3(P2P_THREADS), 0, stream, g);
-    return erl_hip_status(hipGetLastError(), "erl_comm_allreduce_sum_f32(p2p)");
+    ex->half_bytes = c->half_bytes;
+    ex->row_bytes = c->row_bytes;
+    ex->nblk_max = c->nblk_max;
+    ex->seq = ++c->seq;
+    ex->spin_limit = c->spin;
+    ex->rank = c->rank;
+    ex->world = c->world;
+    ex->fault = erl_fault_word(ERL_FAULT_P2P_EXCHANGE);
+    return ERL_OK;
+}
+
+void erl_p2p_set_spin(void *p2p, uint32_t spins)
+{
+    if (p2p) ((P2PComm *)p2p)->spin = spins ? spins : (1u << 24);
 }
 
 void erl_p2p_destroy(void *p2p)

@@ -329,6 +329,37 @@ def clip_adam(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, groups: Se
           "erl_clip_adam_f32")
 
 
+def _groups_c(groups):
+    n = len(groups)
+    return n, (ctypes.c_int64 * n)(*[g[0] for g in groups]), (ctypes.c_int64 * n)(*[g[1] for g in groups])
+
+
+def grad_reduce_partials(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN, groups: Sequence[Tuple[int, int]],
+                         grad_scale: float = 1.0, comm=None) -> None:
+    """launch 1 of the two-launch optimiser tail: slab reduction [+ the data-parallel exchange through `comm`] + the partial
+    norms that `clip_adam_partials` consumes (library-owned table, same stream)."""
+    n, off, ln = _groups_c(groups)
+    check(lib().erl_comm_reduce_exchange_f32(None if comm is None else comm.handle, ptr(slabs, th.float32), n_slabs, stride,
+                                             ptr(flat_grad, th.float32), off, ln, n, grad_scale, stream_ptr()),
+          "erl_comm_reduce_exchange_f32")
+
+
+def grad_sq_partials(grads: TEN, stride: int, groups: Sequence[Tuple[int, int]], grad_scale: float = 1.0) -> None:
+    """partial norms of an already-summed gradient row (after a torch.distributed / RCCL all-reduce)."""
+    n, off, ln = _groups_c(groups)
+    check(lib().erl_grad_sq_partials_f32(ptr(grads, th.float32), stride, off, ln, n, grad_scale, stream_ptr()), "erl_grad_sq_partials_f32")
+
+
+def clip_adam_partials(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, stride: int, groups: Sequence[Tuple[int, int]],
+                       step: int, lr: float, max_norm: float, grad_scale: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """launch 2: clip_grad_norm_ from the partial norms left by launch 1 + Adam (AgentBase.py:246-248)."""
+    n, off, ln = _groups_c(groups)
+    check(lib().erl_clip_adam_partials_f32(ptr(params, th.float32), ptr(grads, th.float32), ptr(exp_avg, th.float32),
+                                           ptr(exp_avg_sq, th.float32), stride, off, ln, n, step, lr, betas[0], betas[1], eps, max_norm,
+                                           grad_scale, stream_ptr()),
+          "erl_clip_adam_partials_f32")
+
+
 def reduce_clip_adam(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN, params: TEN, exp_avg: TEN, exp_avg_sq: TEN,
                      groups: Sequence[Tuple[int, int]], step: int, lr: float, max_norm: float, grad_scale: float = 1.0,
                      betas=(0.9, 0.999), eps: float = 1e-8, grid_wait: bool = False) -> None:

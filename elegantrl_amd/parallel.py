@@ -89,9 +89,15 @@ class RcclComm:
         return cls(out.value, rank, world)
 
     def all_reduce_sum(self, t: th.Tensor) -> th.Tensor:
+        """in-place SUM over ranks of a contiguous fp32 or fp64 device tensor, on torch's current stream"""
         from . import _hip
-        _hip.check(_hip.lib().erl_comm_allreduce_sum_f32(self.handle, _hip.ptr(t, th.float32), t.numel(), _hip.stream_ptr()),
-                   "erl_comm_allreduce_sum_f32")
+        L = _hip.lib()
+        if t.dtype == th.float64:
+            _hip.check(L.erl_comm_allreduce_sum_f64(self.handle, _hip.ptr(t, th.float64), t.numel(), _hip.stream_ptr()),
+                       "erl_comm_allreduce_sum_f64")
+        else:
+            _hip.check(L.erl_comm_allreduce_sum_f32(self.handle, _hip.ptr(t, th.float32), t.numel(), _hip.stream_ptr()),
+                       "erl_comm_allreduce_sum_f32")
         return t
 
     def close(self):
@@ -103,12 +109,18 @@ class RcclComm:
 
 
 class P2PComm(RcclComm):
-    """One-shot peer-to-peer all-reduce (csrc/p2p.hip; prototype, ERL_DP_COLLECTIVE=p2p): the same library handle type as the
-    RCCL communicator, so `all_reduce_sum` and the C update loop take it unchanged.  torch.distributed carries every rank's
-    64-byte IPC handle to every rank and the all-ranks agreement that the peers' stages are mapped everywhere."""
+    """One-shot peer-to-peer exchange (csrc/p2p.hip + csrc/grad_tail.hip): the same library handle type as the RCCL
+    communicator, so `all_reduce_sum` and the C update loop take it unchanged -- and the update loop's exchange then happens
+    INSIDE its slab-reduction launch.  torch.distributed carries every rank's 64-byte IPC handle to every rank and the
+    all-ranks agreement that the peers' stages are mapped everywhere."""
 
     kind = "p2p"
-    MAX_COUNT = 1 << 22            # floats per all-reduce the stages are sized for (16 MiB per half)
+    MAX_COUNT = 1 << 18            # floats per exchange the stage rows are sized for (1 MiB per row, 2 x world rows per rank)
+
+    def set_spin(self, spins: int) -> None:
+        """polls before a wait for a peer gives up (0 = default); the self-test lowers it so a dead route costs seconds"""
+        from . import _hip
+        _hip.check(_hip.lib().erl_comm_p2p_set_spin(self.handle, int(spins)), "erl_comm_p2p_set_spin")
 
     @classmethod
     def create(cls, max_count: Optional[int] = None) -> Optional["P2PComm"]:
@@ -147,28 +159,157 @@ class P2PComm(RcclComm):
 
 _grad_comm: Optional[RcclComm] = None
 _grad_comm_tried = False
+_route_report: dict = {}
 
 
-def gradient_comm() -> Optional[RcclComm]:
-    """The job's RCCL communicator for the per-minibatch gradient exchange; None means "use torch.distributed"
-    (CPU/gloo runs, ERL_DP_COLLECTIVE=torch, or RCCL did not come up on every rank).  ERL_FORCE_DP=1 builds a 1-rank
-    communicator without a process group (measures the data-parallel loop on one GPU)."""
-    global _grad_comm, _grad_comm_tried
+def route_report() -> dict:
+    """what `gradient_comm` measured and decided (bench.py prints it): per-route self-test verdict and microseconds per
+    all-reduce of the gradient row, the selected route, the ranks RCCL saw."""
+    return dict(_route_report)
+
+
+def _agree(ok: bool) -> bool:
+    """all-ranks AND over the process group (identity without one)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(ok)
+    flag = th.tensor([int(bool(ok))], dtype=th.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def _reference_sum(x: th.Tensor) -> th.Tensor:
+    """SUM over ranks through torch.distributed (the route that needs no validation); gloo groups reduce a host copy"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x.clone()
+    if dist.get_backend() == "nccl":
+        y = x.clone()
+        dist.all_reduce(y)
+        return y
+    y = x.cpu()
+    dist.all_reduce(y)
+    return y.to(x.device)
+
+
+def selftest(comm: RcclComm, count: int, rounds: int = 8, timed_calls: int = 100) -> dict:
+    """Validate a library communicator on THIS machine before the update loop trusts it: `rounds` all-reduces of `count`
+    floats (rank-distinct data, both stage halves of the peer-to-peer route, plus an 8-double one) must agree with
+    torch.distributed's sums on every rank and leave no device-side fault; then `timed_calls` back-to-back calls are timed
+    with HIP events (max over ranks).  Collective: every rank calls it with the same arguments.  Returns
+    {"ok": bool, "us": float | None, "why": str}."""
+    from . import _hip
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    world = comm.world
+    is_p2p = getattr(comm, "kind", "rccl") == "p2p"
+    ok, why = True, "ok"
+    _hip.lib().erl_async_fault_count(1)
+    if is_p2p:
+        comm.set_spin(1 << 20)                # a peer that never shows up costs ~a second here, not the run-time bound
+    g = th.Generator(device="cuda").manual_seed(4242 + rank)
+    for it in range(rounds):
+        n = count if it % 3 != 2 else max(1, count // 3 + it)
+        x = th.randn(n, device="cuda", generator=g) * (1.0 + it)
+        d = th.randn(8, device="cuda", generator=g, dtype=th.float64)
+        ref, dref = _reference_sum(x), _reference_sum(d)          # the process group's collectives first, in lockstep ...
+        good, err = False, ""
+        try:                                                      # ... then the route under test, whose failure stays local
+            y = comm.all_reduce_sum(x.clone())
+            dy = comm.all_reduce_sum(d.clone())
+            th.cuda.synchronize()
+            faults = _hip.lib().erl_async_fault_count(1)
+            good = (faults == 0 and bool(th.allclose(y, ref, rtol=1e-5, atol=1e-5 * (1.0 + it) * world))
+                    and bool(th.allclose(dy, dref, rtol=1e-12, atol=1e-12 * world)))
+            err = "device-side wait timed out" if faults else "sums disagree with torch.distributed"
+        except Exception as e:                                    # noqa: BLE001 -- a route that raises is a route that is not selected
+            err = f"raised {type(e).__name__}: {e}"
+        if not _agree(good):                                      # ... until the all-ranks verdict of the round
+            ok, why = False, f"round {it}: " + (err if not good else "failed on another rank")
+            break
+    us = None
+    if ok:
+        buf = th.zeros(count, dtype=th.float32, device="cuda")
+        for _ in range(10):
+            comm.all_reduce_sum(buf)
+        th.cuda.synchronize()
+        barrier()
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(timed_calls):
+            comm.all_reduce_sum(buf)
+        e1.record()
+        th.cuda.synchronize()
+        us = all_reduce_max_float(e0.elapsed_time(e1) * 1e3 / timed_calls, device="cuda")
+        if not _agree(_hip.lib().erl_async_fault_count(1) == 0):
+            ok, why, us = False, "device-side wait timed out in the timed calls", None
+    if is_p2p:
+        comm.set_spin(0)
+    return {"ok": ok, "us": None if us is None else round(us, 2), "why": why}
+
+
+# the peer-to-peer route folds the exchange into the slab-reduction launch; RCCL needs two more launches per minibatch
+# (the collective + the partial norms): that much slower in the stand-alone timing still wins in the loop
+_P2P_LAUNCH_CREDIT_US = 8.0
+
+
+def gradient_comm(count: Optional[int] = None) -> Optional[RcclComm]:
+    """The job's library communicator for the per-minibatch gradient exchange and the advantage sums; None means "use
+    torch.distributed" (CPU/gloo runs without a usable library route, or ERL_DP_COLLECTIVE=torch).
+
+    ERL_DP_COLLECTIVE = auto (default) | p2p | rccl | torch.  `auto` brings up BOTH library routes -- RCCL (only when the
+    process group is "nccl": one rank per GPU) and the one-shot peer-to-peer exchange -- runs `selftest` on each (agreement
+    with torch.distributed's sums on every rank, no device-side timeouts) and keeps the faster of the ones that passed; a
+    route that fails its self-test anywhere is dropped on every rank, so an unvalidated path can never carry a run.
+    `count` = floats of the gradient row (the agent's slab stride).  ERL_FORCE_DP=1 builds 1-rank communicators without
+    world > 1 (measures the data-parallel loop on one GPU)."""
+    global _grad_comm, _grad_comm_tried, _route_report
     if _grad_comm_tried:
         return _grad_comm
     _grad_comm_tried = True
-    mode = os.environ.get("ERL_DP_COLLECTIVE", "rccl")
-    if mode == "p2p" and th.cuda.is_available() and (is_distributed() or force_dp()):
-        _grad_comm = P2PComm.create()        # None (on every rank) when IPC / peer mapping is unavailable: torch.distributed then
-        return _grad_comm
-    if mode != "rccl" or not th.cuda.is_available():
+    mode = os.environ.get("ERL_DP_COLLECTIVE", "auto")
+    report = {"mode": mode, "selected": "torch.distributed", "rccl_us": None, "p2p_us": None, "rccl_selftest": "not tried",
+              "p2p_selftest": "not tried", "ranks_seen_by_rccl": None}
+    _route_report = report
+    if mode == "torch" or not th.cuda.is_available() or not (is_distributed() or force_dp()):
         return None
-    if is_distributed():
-        if dist.get_backend() != "nccl":        # several ranks on one GPU (gloo tests): RCCL cannot span duplicates
-            return None
-    elif not force_dp():
+    count = int(count or 50848)
+    up = dist.is_available() and dist.is_initialized()
+    want_rccl = mode in ("auto", "rccl") and (not up or dist.get_backend() == "nccl")     # gloo groups share GPUs: RCCL cannot
+    want_p2p = mode in ("auto", "p2p")
+    cands = {}
+    if want_rccl:
+        c = RcclComm.create()
+        if c is None:
+            report["rccl_selftest"] = "communicator did not come up on every rank"
+        else:
+            report["ranks_seen_by_rccl"] = c.world
+            t = selftest(c, count)
+            report["rccl_selftest"], report["rccl_us"] = t["why"], t["us"]
+            if t["ok"]:
+                cands["rccl"] = (c, t["us"])
+            else:
+                c.close()
+    if want_p2p:
+        c = P2PComm.create(max_count=max(count, P2PComm.MAX_COUNT))
+        if c is None:
+            report["p2p_selftest"] = "HIP IPC stages could not be created / mapped on every rank"
+        else:
+            t = selftest(c, count)
+            report["p2p_selftest"], report["p2p_us"] = t["why"], t["us"]
+            if t["ok"]:
+                cands["p2p"] = (c, t["us"])
+            else:
+                c.close()
+    if not cands:
         return None
-    _grad_comm = RcclComm.create()
+    pick = "p2p" if "p2p" in cands and ("rccl" not in cands or cands["p2p"][1] <= cands["rccl"][1] + _P2P_LAUNCH_CREDIT_US) else "rccl"
+    for name, (c, _) in cands.items():
+        if name != pick:
+            barrier()
+            c.close()
+    _grad_comm = cands[pick][0]
+    report["selected"] = ("library one-shot peer-to-peer exchange inside the slab-reduction launch (csrc/grad_tail.hip)" if pick == "p2p"
+                          else "library RCCL communicator on the kernels' stream")
     return _grad_comm
 
 

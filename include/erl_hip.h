@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 12
+#define ERL_ABI_VERSION 13
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -74,10 +74,13 @@ ERL_API int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t *un
                      float lam, int flags, double *stats, void *workspace, int64_t workspace_bytes,
                      void *stream);
 
-/* Device-side faults that an asynchronous launch cannot return (today: a look-back wait of ERL_GAE_ALGO_LOOKBACK that
- * timed out because a predecessor slab never published -- the affected advantages are NaN) are counted in a pinned,
- * host-mapped word.  Call after the stream has been synchronised: returns the number of faults since the last reset
- * (0 = none), describes them in erl_last_error_string(), and clears the counter when `reset` != 0.  Costs no GPU work. */
+/* Device-side faults that an asynchronous launch cannot return are counted in a pinned, host-mapped block, one counter
+ * per source: (0) a look-back wait of ERL_GAE_ALGO_LOOKBACK that timed out because a predecessor slab never published --
+ * the affected advantages are NaN; (1) a wait of the peer-to-peer gradient exchange for a peer's slice (a rank missing or
+ * stalled) -- those summed gradients are invalid; (2) a clip + Adam grid wait that gave up (device shared with another
+ * process) -- those parameter updates were skipped.  Call after the stream has been synchronised: returns the number of
+ * faults since the last reset (0 = none), describes them per source in erl_last_error_string(), and clears the counters
+ * when `reset` != 0.  Costs no GPU work. */
 ERL_API int erl_async_fault_count(int reset);
 
 /* n-step discounted return for the off-policy agents.  Replaces AgentBase.get_cumulative_rewards' scan
@@ -265,6 +268,29 @@ ERL_API int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg,
                       int32_t step_offset, float lr, float beta1, float beta2, float eps, float max_norm,
                       float grad_scale, void *stream);
 
+/* The optimiser tail of a PPO minibatch as TWO launches (csrc/grad_tail.hip; the default of erl_ppo_update_f32 /
+ * erl_ppo_update_dp_f32 since round 3).  optimizer_backward = zero_grad / backward / clip_grad_norm_ / Adam.step
+ * (elegantrl/agents/AgentBase.py:239-248); the backward's per-workgroup slabs come from erl_ppo_step_f32.
+ *   launch 1  erl_grad_reduce_partials_f32: erl_grad_reduce_f32's sum (same association, bit for bit) + every 256-element
+ *             workgroup's fp64 share of each parameter group's squared norm of (grad * grad_scale), kept in a library-owned
+ *             per-device table for the next launch on the same stream;
+ *             erl_grad_sq_partials_f32: the partial norms alone, of a gradient row that is already summed (after a foreign
+ *             all-reduce: RCCL / torch.distributed routes);
+ *             erl_comm_reduce_exchange_f32: the reduction with the data-parallel exchange INSIDE the kernel when `comm` is a
+ *             peer-to-peer communicator (push to the peers' stages, per-workgroup flags, rank-ordered sum: one launch),
+ *             reduce -> ncclAllReduce -> partial norms on an RCCL communicator, erl_grad_reduce_partials_f32 for NULL;
+ *   launch 2  erl_clip_adam_partials_f32: clip_grad_norm_ from the <= ceil(stride / 256) partial norms (fixed order), Adam
+ *             on one element per thread.  `step` is the 1-based Adam step.
+ * Every route through these leaves bit-identical parameters for the same summed gradient. */
+ERL_API int erl_grad_reduce_partials_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad,
+                                 const int64_t *group_off, const int64_t *group_len, int n_groups, float grad_scale,
+                                 void *stream);
+ERL_API int erl_grad_sq_partials_f32(float *grads, int64_t stride, const int64_t *group_off, const int64_t *group_len,
+                             int n_groups, float grad_scale, void *stream);
+ERL_API int erl_clip_adam_partials_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
+                               const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr,
+                               float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream);
+
 /* erl_grad_reduce_f32 + erl_clip_adam_f32 in ONE launch (host step only), for loops with nothing between the two: the same
  * gradient bit for bit (same summation order), written to flat_grad; the workgroup that finishes last derives the clip
  * coefficients from per-workgroup fp64 partial norms (fixed order) and applies Adam.  No workgroup waits on another. */
@@ -313,21 +339,36 @@ ERL_API int erl_comm_destroy(void *comm);
 ERL_API int erl_comm_world_size(void *comm);
 ERL_API int erl_comm_allreduce_sum_f32(void *comm, float *buf, int64_t count, void *stream);
 
-/* One-shot peer-to-peer communicator (SURVEY 8e "better" option; prototype, opt-in): the same handle type as above, so
- * erl_comm_allreduce_sum_f32 / erl_ppo_update_dp_f32 take it unchanged.  Every rank keeps a stage (2 x max_count floats) and
- * a flag row in uncached device memory; the all-reduce is ONE launch: copy into the stage, publish a sequence number into
- * every peer's flag row, wait for all of mine, sum the stages in rank order (peer reads over xGMI) -- bit-identical on
- * every rank.  world_size <= 8.
+/* One-shot peer-to-peer communicator (SURVEY 8e "better" option): the same handle type as above, so every erl_comm_* entry
+ * point and erl_ppo_update_dp_f32 take it unchanged.  Every rank keeps a flag table [sender][workgroup] and a stage of
+ * 2 halves x world rows x max_count floats in uncached device memory that the peers map through HIP IPC.  An exchange is
+ * part of ONE launch (csrc/grad_tail.hip): a rank pushes its reduced slice into its row of every peer's stage (posted
+ * remote stores over xGMI), raises a per-workgroup sequence flag on every peer, polls its own flags and sums the rows of
+ * its own memory in rank order -- bit-identical sums on every rank, no round trip over the fabric.  world_size <= 8.
  *   all   : erl_comm_p2p_create(rank, world, max_count, &comm, handle)   (handle: ERL_P2P_HANDLE_BYTES, a hipIpcMemHandle_t)
  *   ship every rank's handle to every rank out of band (torch.distributed), rank-major
  *   all   : erl_comm_p2p_connect(comm, handles)                          (maps the peers' stages)
- * A peer that never publishes is reported through erl_async_fault_count (bounded wait), not a hang. */
+ * A peer that never publishes is reported through erl_async_fault_count (bounded wait), not a hang.  The Python side
+ * selects this route only after a start-up self-test against RCCL passed on every rank (elegantrl_amd/parallel.py). */
 #define ERL_P2P_HANDLE_BYTES 64
 ERL_API int erl_comm_p2p_create(int rank, int world_size, int64_t max_count, void **out_comm, uint8_t *out_handle);
 ERL_API int erl_comm_p2p_connect(void *comm, const uint8_t *handles);
+/* polls (about a microsecond each) before a wait for a peer gives up and reports a fault; 0 = the default (2^24).  The
+ * start-up self-test lowers it so that a route that does not work costs seconds, not a hang. */
+ERL_API int erl_comm_p2p_set_spin(void *comm, uint32_t spins);
+
+#define ERL_COMM_KIND_RCCL 0
+#define ERL_COMM_KIND_P2P 1
+ERL_API int erl_comm_kind(void *comm);                                                  /* -1 for NULL */
+/* SUM all-reduce of doubles (the 5 advantage sums of AgentPPO.py:149 under data parallelism) on either kind */
+ERL_API int erl_comm_allreduce_sum_f64(void *comm, double *buf, int64_t count, void *stream);
+ERL_API int erl_comm_reduce_exchange_f32(void *comm, const float *slabs, int n_slabs, int64_t stride, float *flat_grad,
+                                 const int64_t *group_off, const int64_t *group_len, int n_groups, float grad_scale,
+                                 void *stream);
 
 /* erl_ppo_update_f32 with the gradient all-reduce in the loop: ppo_step -> grad_reduce -> all-reduce(grads[k]) ->
- * clip_adam(grad_scale = 1/world).  comm == NULL degenerates to the single-process loop.  Every rank must call it with
+ * clip_adam(grad_scale = 1/world), as the two launches erl_comm_reduce_exchange_f32 + erl_clip_adam_partials_f32.
+ * comm == NULL degenerates to the single-process loop.  Every rank must call it with
  * the same update_times; ids are this rank's own minibatch indices into its own rollout shard. */
 ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg,
                           const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,

@@ -601,6 +601,38 @@ def test_reduce_clip_adam_equals_the_two_kernel_tail(ops, dev, n_slabs, Pa, Pc, 
     _hip.check_async_faults()
 
 
+@pytest.mark.parametrize("n_slabs,Pa,Pc,max_norm,scale", [(128, 25872, 24961, 3.0, 1.0), (128, 25872, 24961, 1e9, 0.125), (7, 1000, 37, 0.5, 0.5),
+                                                          (1, 300, 200, 3.0, 1.0), (37, 70000, 5, 3.0, 1.0)])
+def test_partials_tail_equals_the_two_kernel_tail(ops, dev, n_slabs, Pa, Pc, max_norm, scale):
+    """csrc/grad_tail.hip, the default optimiser tail since round 3: erl_grad_reduce_partials_f32 (slab sum + every 256-element
+    workgroup's fp64 share of the group norms) + erl_clip_adam_partials_f32, against erl_grad_reduce_f32 + erl_clip_adam_f32:
+    the reduced gradient bit for bit (same association), parameters and moments to fp32 round-off of the norm (fp64 partial
+    sums in another order); and erl_grad_sq_partials_f32 on the already-summed row (the route behind a foreign all-reduce)
+    gives exactly the fused launch's parameters."""
+    g = th.Generator(device=dev).manual_seed(n_slabs + Pa)
+    stride = (Pa + Pc + 4 + 31) // 32 * 32
+    groups = [(0, Pa), (Pa, Pc)]
+    p0 = th.randn(Pa + Pc, device=dev, generator=g)
+    pa, ma, va = p0.clone(), th.zeros_like(p0), th.zeros_like(p0)
+    pb, mb, vb = p0.clone(), th.zeros_like(p0), th.zeros_like(p0)
+    pc, mc, vc = p0.clone(), th.zeros_like(p0), th.zeros_like(p0)
+    fa, fb, fc = th.empty(stride, device=dev), th.empty(stride, device=dev), th.empty(stride, device=dev)
+    for step in range(1, 6):
+        slabs = th.randn((n_slabs, stride), device=dev, generator=g) * (0.1 if step % 2 else 10.0)
+        ops.grad_reduce(slabs, n_slabs, stride, fa)
+        ops.clip_adam(pa, fa, ma, va, groups, step, 1e-3, max_norm, grad_scale=scale)
+        ops.grad_reduce_partials(slabs, n_slabs, stride, fb, groups, grad_scale=scale)
+        ops.clip_adam_partials(pb, fb, mb, vb, stride, groups, step, 1e-3, max_norm, grad_scale=scale)
+        ops.grad_reduce(slabs, n_slabs, stride, fc)
+        ops.grad_sq_partials(fc, stride, groups, grad_scale=scale)
+        ops.clip_adam_partials(pc, fc, mc, vc, stride, groups, step, 1e-3, max_norm, grad_scale=scale)
+        assert th.equal(fa, fb) and th.equal(fa, fc)
+        for x, y in ((pa, pb), (ma, mb), (va, vb)):
+            np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-6, atol=1e-9)
+        assert th.equal(pb, pc) and th.equal(mb, mc) and th.equal(vb, vc)
+    assert float((pa - p0).abs().max()) > 1e-4
+
+
 def test_clip_adam_grad_scale_equals_prescaled(ops, dev):
     rng = np.random.default_rng(10)
     n = 5000

@@ -20,9 +20,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False):
+def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False, collective="torch"):
     gpu = rank if one_gpu_per_rank else 0
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(gpu), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(gpu), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      ERL_DP_COLLECTIVE=collective)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from elegantrl_amd import parallel
     from elegantrl_amd.agents import AgentPPO
@@ -52,16 +53,20 @@ def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False):
     np.save(os.path.join(out_dir, f"rew_{rank}.npy"), items[3].cpu().numpy())
     np.save(os.path.join(out_dir, f"logs_{rank}.npy"), np.array(logs))
     comm = parallel.gradient_comm()
-    np.save(os.path.join(out_dir, f"comm_{rank}.npy"), np.array([comm is not None, comm.world if comm is not None else 0]))
+    np.save(os.path.join(out_dir, f"comm_{rank}.npy"), np.array([comm is not None, comm.world if comm is not None else 0,
+                                                                 {"rccl": 1, "p2p": 2}[comm.kind] if comm is not None else 0]))
+    import json
+    with open(os.path.join(out_dir, f"route_{rank}.json"), "w") as f:
+        json.dump(parallel.route_report(), f)
     parallel.barrier()
     parallel.shutdown()
 
 
 def _p2p_worker(rank, world, port, out_dir):
-    """the one-shot peer-to-peer all-reduce on its own: two ranks, ONE GPU, the peers' stages mapped through HIP IPC"""
+    """the one-shot peer-to-peer exchange on its own: two ranks, ONE GPU, the peers' stages mapped through HIP IPC"""
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    from elegantrl_amd import _hip, parallel
+    from elegantrl_amd import _hip, ops, parallel
     parallel.init_from_env(backend="gloo")
     th.cuda.set_device(0)
     comm = parallel.P2PComm.create(max_count=70000)
@@ -74,9 +79,38 @@ def _p2p_worker(rank, world, port, out_dir):
             ref = x.cpu().clone()
             parallel.dist.all_reduce(ref)                       # gloo on the host copy: the expected SUM (order-free for 2 ranks)
             comm.all_reduce_sum(x)
+            d = th.randn(5 + it, device="cuda", generator=g, dtype=th.float64)          # the advantage sums' route (fp64)
+            dref = d.cpu().clone()
+            parallel.dist.all_reduce(dref)
+            comm.all_reduce_sum(d)
             th.cuda.synchronize()
+            assert th.equal(d.cpu(), dref), "fp64 peer-to-peer sum differs from gloo's"
             outs.append(x.cpu().numpy())
             refs.append(ref.numpy())
+        # the fused optimiser tail: [slab reduction + exchange + partial norms] -> [clip + Adam], against the same tail with
+        # gloo in the middle (reduce -> gloo all-reduce -> partial norms -> clip + Adam)
+        n_slabs, stride, groups = 37, 50848, [(0, 25872), (25872, 24961)]
+        slabs = th.randn((n_slabs, stride), device="cuda", generator=g)
+        slabs[:, 50833 + 4:] = 0
+        w = []
+        for route in ("p2p", "gloo"):
+            gsum = th.empty(stride, device="cuda")
+            params = th.linspace(-1, 1, 50833, device="cuda")
+            m1, m2 = th.zeros_like(params), th.zeros_like(params)
+            for step in (1, 2):
+                if route == "p2p":
+                    ops.grad_reduce_partials(slabs, n_slabs, stride, gsum, groups, grad_scale=0.5, comm=comm)
+                else:
+                    ops.grad_reduce(slabs, n_slabs, stride, gsum)
+                    h = gsum.cpu()
+                    parallel.dist.all_reduce(h)
+                    gsum.copy_(h)
+                    ops.grad_sq_partials(gsum, stride, groups, grad_scale=0.5)
+                ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, step, 1e-3, 0.5, grad_scale=0.5)
+            th.cuda.synchronize()
+            w.append(params.cpu().numpy())
+            np.save(os.path.join(out_dir, f"tail_{route}_{rank}.npy"), w[-1])
+            np.save(os.path.join(out_dir, f"tailg_{route}_{rank}.npy"), gsum.cpu().numpy())
         _hip.check_async_faults()
         for k, (o, r) in enumerate(zip(outs, refs)):
             np.save(os.path.join(out_dir, f"p2p_out{k}_{rank}.npy"), o)
@@ -91,9 +125,10 @@ def _p2p_worker(rank, world, port, out_dir):
 
 @pytest.mark.timeout(600)
 def test_p2p_allreduce_two_ranks_on_one_gpu(tmp_path):
-    """csrc/p2p.hip (prototype of SURVEY 8e's one-shot exchange): handle exchange, flag protocol, stage reuse over 8 back-to-back
-    all-reduces of different sizes; sums equal gloo's and are bit-identical on both ranks.  Skips when the box cannot share
-    device memory between two processes (IPC)."""
+    """csrc/p2p.hip + csrc/grad_tail.hip (SURVEY 8e's one-shot exchange): handle exchange, per-workgroup flag protocol, stage
+    reuse over 16 back-to-back exchanges of different sizes and dtypes; sums equal gloo's and are bit-identical on both
+    ranks; the FUSED tail (exchange inside the slab reduction) leaves the weights of the same tail with gloo in the middle.
+    Skips when the box cannot share device memory between two processes (IPC)."""
     world = 2
     mp.spawn(_p2p_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     meta = [np.load(tmp_path / f"p2p_{r}.npy") for r in range(world)]
@@ -104,37 +139,32 @@ def test_p2p_allreduce_two_ranks_on_one_gpu(tmp_path):
         ref = np.load(tmp_path / f"p2p_ref{k}_0.npy")
         np.testing.assert_array_equal(o[0], o[1])
         np.testing.assert_array_equal(o[0], ref)          # two addends: every summation order gives the same fp32 result
+    t = {(route, r): np.load(tmp_path / f"tail_{route}_{r}.npy") for route in ("p2p", "gloo") for r in range(world)}
+    tg = {(route, r): np.load(tmp_path / f"tailg_{route}_{r}.npy") for route in ("p2p", "gloo") for r in range(world)}
+    np.testing.assert_array_equal(tg[("p2p", 0)], tg[("p2p", 1)])
+    np.testing.assert_array_equal(tg[("p2p", 0)], tg[("gloo", 0)])
+    np.testing.assert_array_equal(t[("p2p", 0)], t[("p2p", 1)])
+    np.testing.assert_array_equal(t[("p2p", 0)], t[("gloo", 0)])
+    assert np.isfinite(t[("p2p", 0)]).all() and not np.array_equal(t[("p2p", 0)], np.linspace(-1, 1, 50833, dtype=np.float32))
 
 
-def _worker_p2p_agent(rank, world, port, out_dir):
-    os.environ["ERL_DP_COLLECTIVE"] = "p2p"
-    _worker(rank, world, port, out_dir)
+def _load(tmp_path, sub, n, world=2):
+    return [np.load(tmp_path / sub / f"{n}_{r}.npy") for r in range(world)]
 
 
-@pytest.mark.timeout(600)
-def test_two_rank_agent_in_lockstep_over_p2p(tmp_path):
-    """the whole data-parallel update loop (erl_ppo_update_dp_f32) with the peer-to-peer communicator in place of RCCL"""
+@pytest.mark.timeout(900)
+def test_two_rank_agent_in_lockstep_on_every_route(tmp_path):
+    """Two ranks share the one GPU (gloo process group) and run two data-parallel PPO iterations three times: through
+    torch.distributed (`torch`), through the peer-to-peer communicator forced (`p2p`), and with the route chosen by the
+    start-up self-test (`auto`: RCCL cannot span two ranks on one device, so the self-tested peer-to-peer route must win).
+    Every run: identical weights after the broadcast, job-wide advantage sums, ranks bit-identical after training.  Across
+    runs: the fused tail (exchange inside the slab-reduction launch) leaves exactly the weights of the gloo route."""
+    import json
     world = 2
-    mp.spawn(_worker_p2p_agent, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    ld = lambda n: [np.load(tmp_path / f"{n}_{r}.npy") for r in range(world)]   # noqa: E731
-    comm = ld("comm")
-    if not all(c[0] for c in comm):
-        pytest.skip("HIP IPC between two processes on this device is unavailable")
-    assert all(c[1] == 2 for c in comm)
-    w0, w, logs = ld("w0"), ld("w"), ld("logs")
-    np.testing.assert_array_equal(w0[0], w0[1])
-    assert not np.array_equal(w[0], w0[0])
-    np.testing.assert_array_equal(w[0], w[1])
-    np.testing.assert_allclose(logs[0], logs[1], rtol=1e-6)
-    assert np.isfinite(w[0]).all() and np.isfinite(logs[0]).all()
-
-
-@pytest.mark.timeout(600)
-def test_two_rank_agent_stays_in_lockstep(tmp_path):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    ld = lambda n: [np.load(tmp_path / f"{n}_{r}.npy") for r in range(world)]   # noqa: E731
-    w0, w, stats, rew, logs = ld("w0"), ld("w"), ld("stats"), ld("rew"), ld("logs")
+    for mode in ("torch", "p2p", "auto"):
+        (tmp_path / mode).mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / mode), "gloo", False, mode), nprocs=world, join=True)
+    w0, w, stats, rew, logs = (_load(tmp_path, "torch", n) for n in ("w0", "w", "stats", "rew", "logs"))
     np.testing.assert_array_equal(w0[0], w0[1])                       # broadcast
     assert not np.array_equal(rew[0], rew[1])                         # different env shards were rolled out
     np.testing.assert_array_equal(stats[0], stats[1])                 # job-wide advantage sums
@@ -143,29 +173,50 @@ def test_two_rank_agent_stays_in_lockstep(tmp_path):
     np.testing.assert_array_equal(w[0], w[1])                         # ... identically on both ranks
     np.testing.assert_allclose(logs[0], logs[1], rtol=1e-6)           # logged objectives are global means
     assert np.isfinite(w[0]).all() and np.isfinite(logs[0]).all()
+    assert all(c[0] == 0 for c in _load(tmp_path, "torch", "comm"))
+    p2p_comm = _load(tmp_path, "p2p", "comm")
+    if not all(c[0] for c in p2p_comm):
+        pytest.skip("HIP IPC between two processes on this device is unavailable")
+    for mode in ("p2p", "auto"):
+        comm = _load(tmp_path, mode, "comm")
+        assert all(c[0] == 1 and c[1] == 2 and c[2] == 2 for c in comm), f"{mode}: the peer-to-peer route was not selected"
+        wm = _load(tmp_path, mode, "w")
+        np.testing.assert_array_equal(wm[0], wm[1])
+        np.testing.assert_array_equal(wm[0], w[0])                    # == the torch.distributed / gloo route, bit for bit
+        np.testing.assert_array_equal(_load(tmp_path, mode, "stats")[0], stats[0])
+        np.testing.assert_array_equal(_load(tmp_path, mode, "logs")[0], logs[0])
+    rep = json.load(open(tmp_path / "auto" / "route_0.json"))
+    assert rep["p2p_selftest"] == "ok" and rep["p2p_us"] > 0 and "peer-to-peer" in rep["selected"], rep
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1200)
 @pytest.mark.skipif(th.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
-def test_two_rank_rccl_one_gpu_per_rank(tmp_path):
-    """The multi-GPU path as the 8-GPU run takes it: backend "nccl" (= RCCL over xGMI), one GPU per rank, the library's own
-    communicator (erl_comm_init with world > 1) issuing the gradient all-reduce from inside erl_ppo_update_dp_f32.  Ranks
-    end bit-identical to each other AND to the gloo route on the same two GPUs (a two-term sum is order-free, so any
-    all-reduce algorithm yields the same bits)."""
+def test_two_rank_one_gpu_per_rank_every_route(tmp_path):
+    """The multi-GPU path as the 8-GPU run takes it: backend "nccl" (= RCCL over xGMI), one GPU per rank.  `rccl`: the
+    library's own communicator (erl_comm_init with world > 1) issuing the gradient all-reduce from inside
+    erl_ppo_update_dp_f32; `p2p`: the exchange across xGMI inside the slab-reduction launch; `auto`: both self-tested, the
+    faster kept.  Ranks end bit-identical to each other AND to the gloo route on the same two GPUs (a two-term sum is
+    order-free, so any all-reduce algorithm yields the same bits)."""
+    import json
     world = 2
-    (tmp_path / "rccl").mkdir()
-    (tmp_path / "gloo").mkdir()
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / "rccl"), "nccl", True), nprocs=world, join=True)
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / "gloo"), "gloo", True), nprocs=world, join=True)
-    ld = lambda d, n: [np.load(tmp_path / d / f"{n}_{r}.npy") for r in range(world)]   # noqa: E731
-    comm = ld("rccl", "comm")
-    assert all(c[0] == 1 and c[1] == world for c in comm), "the library RCCL communicator did not come up with world = 2"
-    assert all(c[0] == 0 for c in ld("gloo", "comm"))
-    w, wg = ld("rccl", "w"), ld("gloo", "w")
-    np.testing.assert_array_equal(w[0], w[1])                         # ranks in lockstep over RCCL
-    np.testing.assert_array_equal(w[0], wg[0])                        # RCCL route == torch.distributed/gloo route
-    np.testing.assert_array_equal(ld("rccl", "stats")[0], ld("gloo", "stats")[0])
-    assert not np.array_equal(w[0], ld("rccl", "w0")[0]) and np.isfinite(w[0]).all()
+    for mode, backend in (("rccl", "nccl"), ("p2p", "nccl"), ("auto", "nccl"), ("torch", "gloo")):
+        (tmp_path / mode).mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / mode), backend, True, mode), nprocs=world, join=True)
+    wg = _load(tmp_path, "torch", "w")
+    comm = _load(tmp_path, "rccl", "comm")
+    assert all(c[0] == 1 and c[1] == world and c[2] == 1 for c in comm), "the library RCCL communicator did not come up with world = 2"
+    assert all(c[0] == 0 for c in _load(tmp_path, "torch", "comm"))
+    rep = json.load(open(tmp_path / "auto" / "route_0.json"))
+    assert rep["rccl_selftest"] == "ok", rep
+    for mode in ("rccl", "p2p", "auto"):
+        if mode == "p2p" and not all(c[0] for c in _load(tmp_path, "p2p", "comm")):
+            continue                                                  # no peer mapping on this box: auto must have fallen back
+        w = _load(tmp_path, mode, "w")
+        np.testing.assert_array_equal(w[0], w[1])                     # ranks in lockstep
+        np.testing.assert_array_equal(w[0], wg[0])                    # == torch.distributed/gloo route
+        np.testing.assert_array_equal(_load(tmp_path, mode, "stats")[0], _load(tmp_path, "torch", "stats")[0])
+        assert not np.array_equal(w[0], _load(tmp_path, mode, "w0")[0]) and np.isfinite(w[0]).all()
+    assert all(c[0] == 1 for c in _load(tmp_path, "auto", "comm")), rep
 
 
 # ---- the library-owned RCCL communicator (erl_comm_*) on one rank --------------------------------------------------
@@ -195,6 +246,8 @@ if comm is not None:                      # the collective on its own: SUM over 
     x = th.randn(50837, device="cuda")
     y = comm.all_reduce_sum(x.clone())
     assert th.equal(x, y)
+    d = th.randn(8, device="cuda", dtype=th.float64)
+    assert th.equal(d, comm.all_reduce_sum(d.clone()))
 np.savez(sys.argv[1], w=agent._flat.cpu().numpy(), logs=np.array(logs), used_comm=comm is not None,
          pg=parallel.dist.is_initialized())
 """
@@ -213,17 +266,17 @@ def _run_dp_script(tmp_path, name, **env):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("net", ["128,128", "96,64,32"], ids=["fused", "generic"])
-def test_rccl_comm_one_rank_matches_single_process(tmp_path, net):
+def test_one_rank_comm_matches_single_process(tmp_path, net):
     """ERL_FORCE_DP=1 drives the data-parallel branch of update_net with one rank: (a) through the library's RCCL
-    communicator inside erl_ppo_update_dp_f32 (unique id carried by the nccl process group), (b) through
-    torch.distributed's all_reduce.  Both must leave exactly the weights of the plain single-process loop."""
+    communicator inside erl_ppo_update_dp_f32 (unique id carried by the nccl process group), (b) through the peer-to-peer
+    communicator (the exchange protocol inside the slab-reduction launch, with itself as the only peer), (c) with the
+    self-tested choice, (d) through torch.distributed's all_reduce.  All must leave exactly the weights of the plain
+    single-process loop."""
     plain = _run_dp_script(tmp_path, "plain", ERL_TEST_NET=net)
-    rccl = _run_dp_script(tmp_path, "rccl", ERL_TEST_NET=net, ERL_FORCE_DP="1")
-    torch_pg = _run_dp_script(tmp_path, "torch", ERL_TEST_NET=net, ERL_FORCE_DP="1", ERL_DP_COLLECTIVE="torch")
     assert not plain["used_comm"] and not plain["pg"]
-    assert rccl["used_comm"] and rccl["pg"], "RCCL communicator did not come up on the GPU box"
-    assert not torch_pg["used_comm"] and torch_pg["pg"]
-    np.testing.assert_array_equal(plain["w"], rccl["w"])
-    np.testing.assert_array_equal(plain["w"], torch_pg["w"])
-    np.testing.assert_array_equal(plain["logs"], rccl["logs"])
-    np.testing.assert_array_equal(plain["logs"], torch_pg["logs"])
+    for mode in ("rccl", "p2p", "auto", "torch"):
+        run = _run_dp_script(tmp_path, mode, ERL_TEST_NET=net, ERL_FORCE_DP="1", ERL_DP_COLLECTIVE=mode)
+        assert run["pg"]
+        assert bool(run["used_comm"]) == (mode != "torch"), f"{mode}: library communicator did not come up on the GPU box"
+        np.testing.assert_array_equal(plain["w"], run["w"])
+        np.testing.assert_array_equal(plain["logs"], run["logs"])

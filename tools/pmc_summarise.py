@@ -6,9 +6,13 @@ the kernel.  FETCH_SIZE / WRITE_SIZE (KB) are turned into HBM bytes with the gfx
 (FETCH_SIZE counts 128-byte read requests as 64 bytes: x2; WRITE_SIZE as reported)."""
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import KERNEL_SOURCES, kernel_source_sha16  # noqa: E402  (stamp = hash of the sources the counters were collected on)
 
 
 def short(name: str) -> str:
@@ -42,6 +46,8 @@ def main():
             # the counter sums busy cycles over all SIMDs (256 CUs x 4); gfx950 engine clock 2.4 GHz
             e["mfma_busy_cycles_per_simd"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024, 1)
             e["mfma_busy_frac_of_kernel_time_at_2.4GHz"] = round(e["mfma_busy_cycles_per_simd"] / (e["avg_duration_us"] * 2400), 3)
+        if k in KERNEL_SOURCES:
+            e["source_sha16"] = kernel_source_sha16(k)
         res[k] = e
     json.dump({"note": "rocprofv3 --kernel-trace --pmc <one counter set per pass>; per-dispatch averages, summed over XCDs "
                        "(tools/pmc_summarise.py)", "kernels": res}, open(out_path, "w"), indent=1)

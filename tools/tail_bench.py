@@ -45,3 +45,13 @@ print(f"clip_adam              {timeit(lambda: ops.clip_adam(p, f, m, v, groups,
 print(f"grad_reduce+clip_adam  {timeit(two):7.2f} us")
 print(f"reduce_clip_adam       {timeit(lambda: ops.reduce_clip_adam(slabs, n_slabs, stride, f, p, m, v, groups, 5, 1e-4, 3.0)):7.2f} us")
 print(f"reduce_clip_adam(grid) {timeit(lambda: ops.reduce_clip_adam(slabs, n_slabs, stride, f, p, m, v, groups, 5, 1e-4, 3.0, grid_wait=True)):7.2f} us")
+
+
+def partials():
+    ops.grad_reduce_partials(slabs, n_slabs, stride, f, groups)
+    ops.clip_adam_partials(p, f, m, v, stride, groups, 5, 1e-4, 3.0)
+
+
+print(f"reduce_partials        {timeit(lambda: ops.grad_reduce_partials(slabs, n_slabs, stride, f, groups)):7.2f} us")
+print(f"clip_adam_partials     {timeit(lambda: ops.clip_adam_partials(p, f, m, v, stride, groups, 5, 1e-4, 3.0)):7.2f} us")
+print(f"reduce_partials+clip_adam_partials {timeit(partials):7.2f} us   (the default tail since round 3)")
