@@ -124,7 +124,7 @@ def gae_sweep(ops, dev):
 
 # the files a kernel's HBM traffic depends on (what the PMC passes were collected on is stamped with their hash)
 KERNEL_SOURCES = {
-    "ppo_step_w4_kernel": ["ppo_step_w4.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
+    "ppo_step_w4_kernel": ["ppo_step_w4_impl.h", "ppo_step_w4.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "ppo_step2_kernel": ["ppo_step.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "gae_lookback_kernel": ["gae_lookback.hip"],
 }
@@ -414,9 +414,9 @@ def main():
     env_steps = world * N_ENVS * HORIZON * opt.steps
     flops = ppo_flops_per_sample(STATE_DIM, *NET_DIMS, ACTION_DIM) * BATCH
     ppo_s, n_k6 = (k6_seconds / k6_launches if k6_launches else float("nan")), k6_launches
-    # which K6 kernel erl_ppo_step_f32 dispatches to: the one-wave-per-SIMD form for 16-byte-aligned [128,128] shapes
-    k6_kernel = "ppo_step_w4_kernel" if (NET_DIMS == [128, 128] and STATE_DIM <= 64 and STATE_DIM % 4 == 0 and ACTION_DIM <= 8) \
-        else "ppo_step2_kernel"
+    # which K6 kernel erl_ppo_step_f32 dispatches to: the one-wave-per-SIMD form for h1, h2 in {64, 128}, S <= 64, A <= 8
+    k6_kernel = "ppo_step_w4_kernel" if (len(NET_DIMS) == 2 and all(d in (64, 128) for d in NET_DIMS) and STATE_DIM <= 64
+                                         and ACTION_DIM <= 8) else "ppo_step2_kernel"
     gae_s = t_gae.mean_seconds()
     k6_traffic, k6_traffic_src = pmc_traffic(k6_kernel) if opt.config == "c4" else (None, None)
     line = {

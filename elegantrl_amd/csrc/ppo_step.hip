@@ -471,7 +471,7 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     // K6 form: 0 = automatic (one-wave-per-SIMD 32x32x2 kernel where its shape class applies), 8 = always the 8-wave
     // 16x16x4 kernel (A/B measurements: ERL_K6_FORM=8)
     static const int form = [] { const char *e = getenv("ERL_K6_FORM"); return e ? atoi(e) : 0; }();
-    if (form != 8 && vec && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 4 / 5
+    if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 2 / 4 / 5
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
     else rc = launch<0, 0, 0, false>(g, n_slabs, st);

@@ -29,7 +29,13 @@ def test_bench_line_contract(config):
     r = line["roofline"]
     assert {"kernel", "bound", "achieved", "peak", "unit", "frac"} <= set(r) and 0 < r["frac"] < 1
     if config == "c4":
-        assert line["metric"] == "env_steps_per_sec_ppo_4096envs_obs64" and r["kernel"] == "ppo_step_w4_kernel" and r["traffic"] > 0
+        assert line["metric"] == "env_steps_per_sec_ppo_4096envs_obs64" and r["kernel"] == "ppo_step_w4_kernel"
+        # HBM bytes per launch from the committed PMC passes, or None when they were collected on other kernel sources
+        src = r["traffic_source"]
+        assert (r["traffic"] is None) == bool(src["stale"]) and (r["traffic"] is None or r["traffic"] > 0)
+        assert len(src["kernel_source_sha16"]) == 16
+        e = line["extra"]
+        assert len(e["repeated_regions_ms_per_step"]) == 5 and e["min"] <= e["median"] <= e["max"]
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():
@@ -38,5 +44,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
                env={"ERL_DIST_BACKEND": "gloo"})
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
     a = line["allreduce"]
-    assert a["bytes"] == 4 * ((25872 + 24961 + 4 + 31) // 32 * 32) and a["us_per_call"] > 0 and a["calls_per_step"] == 40
+    assert a["bytes"] == 4 * ((25872 + 24961 + 4 + 31) // 32 * 32) and a["selected_us_per_call_after_run"] > 0 and a["calls_per_step"] == 40
+    # two ranks on one GPU: RCCL cannot come up (gloo group), the self-tested peer-to-peer exchange must be the route
+    assert a["mode"] == "auto" and a["rccl_selftest"] == "not tried" and a["p2p_selftest"] == "ok" and a["p2p_us"] > 0, a
+    assert "peer-to-peer" in a["selected"], a
     assert "cpu_baseline" not in line

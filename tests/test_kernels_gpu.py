@@ -485,9 +485,12 @@ def oracle_flat_grads(buf, ids, actor, critic, clip, lam_ent, dt, objective="ref
     return ga, gc, np.array([oc, os_, oe], dtype=np.float64)
 
 
-# more shapes of the one-wave-per-SIMD kernel (S % 4 == 0, S <= 64, [128,128], A <= 8): one K tile (S <= 32), action counts that
-# do not fill the 4 x 4 output blocks or the 16-byte action load, a single action
-W4_SHAPES = [(32, 128, 128, 3), (16, 128, 128, 4), (64, 128, 128, 1), (4, 128, 128, 8), (48, 128, 128, 6)]
+# more shapes of the one-wave-per-SIMD kernel (S <= 64, h1, h2 in {64, 128}, A <= 8): one K tile (S <= 32), action counts that
+# do not fill the 4 x 4 output blocks or the 16-byte action load, a single action; round 3: the other three (h1, h2) pairs
+# (two waves per row tile in the weight gradients, W2 / W3 copied through registers instead of LDS-DMA) and unaligned state
+# rows (S % 4 != 0: MLP_SHAPES' Pendulum shape (3, 128, 64, 1) and (17, 128, 128, 5) take this kernel's element-wise loaders)
+W4_SHAPES = [(32, 128, 128, 3), (16, 128, 128, 4), (64, 128, 128, 1), (4, 128, 128, 8), (48, 128, 128, 6),
+             (64, 128, 64, 8), (60, 128, 64, 8), (32, 64, 128, 4), (12, 64, 64, 3), (3, 64, 64, 1), (7, 64, 128, 2), (33, 128, 64, 5)]
 
 
 @pytest.mark.parametrize("S,h1,h2,A", MLP_SHAPES + W4_SHAPES)
@@ -522,8 +525,8 @@ def test_ppo_step_gradients(ops, dev, S, h1, h2, A, B):
 OBJECTIVES = {"canonical": 1, "a2c": 2}
 
 
-@pytest.mark.parametrize("S,h1,h2,A", [(64, 128, 128, 8), (17, 128, 128, 5), (6, 64, 32, 2)],
-                         ids=["one-wave-per-SIMD kernel", "8-wave kernel", "8-wave kernel, small net"])
+@pytest.mark.parametrize("S,h1,h2,A", [(64, 128, 128, 8), (3, 128, 64, 1), (128, 96, 128, 5), (6, 64, 32, 2)],
+                         ids=["one-wave-per-SIMD kernel", "one-wave-per-SIMD kernel, Pendulum shape", "8-wave kernel", "8-wave kernel, small net"])
 @pytest.mark.parametrize("objective", list(OBJECTIVES))
 def test_ppo_step_objective_forms(ops, dev, S, h1, h2, A, objective):
     """the textbook clipped surrogate (SURVEY App. A1 / helloworld_PPO_single_file.py:337-339) and AgentA2C's un-clipped

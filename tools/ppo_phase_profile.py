@@ -15,7 +15,9 @@ _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "liberl_hip_prof.so
 from elegantrl_amd import ops  # noqa: E402
 
 dev = th.device("cuda:0")
-N, S, A, H, B, h1, h2 = 4096, 64, 8, 32, 16384, 128, 128
+# shape: K6_SHAPE="S,h1,h2,A" (default config 4: 64,128,128,8; config 2 / Pendulum: 3,128,64,1)
+S, h1, h2, A = (int(x) for x in os.environ.get("K6_SHAPE", "64,128,128,8").split(","))
+N, H, B = 4096, 32, 16384
 NAMES = ["prologue (2 global trips, copies, norm_x)", "barrier0", "L1 fwd", "L2 fwd", "out layer", "objective + dstd partials",
          "dZ2 + dZ1", "barrier1 (wave skew)", "stage dZ1/dY + barrier2", "dW1 + db1 + db3", "barrier3 + stage H2/H1 + barrier4",
          "dW3 + barrier5 + stage dZ2 + barrier6", "dW2 + db2", "loss reduce + logs"]
@@ -30,6 +32,7 @@ def main():
     Pa, Pc = sa.count, sc.count
     flat = th.randn(Pa + Pc, device=dev, generator=g) * 0.05
     avg, std = th.zeros(S, device=dev), th.ones(S, device=dev)
+    print(f"shape S={S} net=[{h1},{h2}] A={A} B={B}")
     states = th.randn((H, N, S), device=dev, generator=g)
     actions = th.randn((H, N, A), device=dev, generator=g)
     logprobs = th.randn((H, N), device=dev, generator=g) - 8
