@@ -54,7 +54,7 @@ _SIGNATURES = {
     "erl_per_init_f32": (c_int, [_P, _P, c_int64, c_int64, _P]),
     "erl_per_add_rows_f32": (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int64, c_float, _P]),
     "erl_per_update_f32": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_float, _P]),
-    "erl_per_sample_f32": (c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_float, _P, _P, _P]),
+    "erl_per_sample_f32": (c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_float, _P, _P, _P]),
     "erl_mlp_param_count": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "erl_value_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     "erl_rollout_step_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_uint64, c_uint64,
@@ -110,7 +110,7 @@ _SIGNATURES = {
                                                c_int64, _P, c_int64, c_float, c_float, c_float, _P, _P, c_int64, _P]),
     "erl_sac_param_counts": (c_int, [c_int, c_int, POINTER(c_int), c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "erl_sac_workspace_bytes": (c_int64, [c_int, c_int, POINTER(c_int), c_int, c_int, c_int64]),
-    "erl_sac_update_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int] + [_P] * 8 + [c_int64, _P, _P, c_uint64,
+    "erl_sac_update_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int] + [_P] * 9 + [c_float, c_int64, _P, _P, c_uint64,
                                    c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
     "erl_sac_explore_action_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P,
                                            c_int64, _P]),

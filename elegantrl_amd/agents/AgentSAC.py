@@ -175,16 +175,19 @@ class AgentSAC(AgentBase):
         self.rng_counter += 1
         return action
 
-    def _update_on_batch(self, batch, objs_out: TEN, noises=None, is_weight=None, td_error_out=None):
+    def _update_on_batch(self, batch, objs_out: TEN, noises=None, is_weight=None, td_error_out=None, buffer=None):
         from .. import ops
         self._step += 1
+        cum_reward = None
+        if self.lambda_fit_cum_r:          # AgentSAC.py:66-68: the sampled transitions' n-step returns (the sampler left ids0 / ids1)
+            cum_reward = buffer.cum_rewards[buffer.ids0, buffer.ids1].to(th.float32).contiguous()
         ops.sac_update(self._spec, self._actor_flat, self._critic_flat, self._target_flat, self.alpha_log,
                        (self.act_optimizer.exp_avg, self.act_optimizer.exp_avg_sq, self.cri_optimizer.exp_avg,
                         self.cri_optimizer.exp_avg_sq, self.alpha_optim.exp_avg, self.alpha_optim.exp_avg_sq),
                        batch, self._step, gamma=float(self.gamma), target_entropy=float(self.target_entropy),
                        tau=float(self.soft_update_tau), lr=float(self.learning_rate), max_norm=float(self.clip_grad_norm),
                        objs_out=objs_out, noises=noises, seed=self.rng_seed + 1, counter=self._step, is_weight=is_weight,
-                       td_error_out=td_error_out)
+                       td_error_out=td_error_out, cum_reward=cum_reward, lambda_fit_cum_r=float(self.lambda_fit_cum_r or 0.0))
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self.alpha_optim.step_count = self._step
 
     @_hip.on_device
@@ -192,14 +195,12 @@ class AgentSAC(AgentBase):
                           noises: Optional[Tuple[TEN, TEN]] = None) -> Tuple[float, float]:
         """one SAC step (AgentSAC.py:42-86).  `ids` / `noises` = (eps for next_state, eps for state) inject the random draws."""
         assert isinstance(update_t, int)
-        if self.lambda_fit_cum_r:
-            raise NotImplementedError("lambda_fit_cum_r != 0 is not part of the HIP SAC step yet")
         self._sync_modules()
         if self.if_use_per:                                                               # AgentSAC.py:45-47, :60-62
             self._per_step(buffer, self._objs, noises)
         else:
             batch = buffer.sample(self.batch_size, ids=ids)                               # HIP K9
-            self._update_on_batch(batch, self._objs, noises)
+            self._update_on_batch(batch, self._objs, noises, buffer=buffer)
         oc, oa = self._objs.cpu().tolist()
         _hip.check_async_faults()          # the stream is drained: a skipped optimiser step (grid-wait timeout) raises here
         return oc, oa
@@ -209,14 +210,14 @@ class AgentSAC(AgentBase):
         *batch, is_weight, is_index = buffer.sample_for_per(self.batch_size)
         if self._td_error is None or self._td_error.numel() != is_weight.numel():
             self._td_error = th.empty_like(is_weight)
-        self._update_on_batch(batch, objs_out, noises, is_weight=is_weight, td_error_out=self._td_error)
+        self._update_on_batch(batch, objs_out, noises, is_weight=is_weight, td_error_out=self._td_error, buffer=buffer)
         buffer.td_error_update_for_per(is_index, self._td_error)
 
     @_hip.on_device
     def update_net(self, buffer) -> Tuple[float, float]:
         """AgentBase.update_net (:172-189) with ONE host sync: the per-step objectives stay on the device until the end."""
-        if self.lambda_fit_cum_r:
-            return super().update_net(buffer)
+        if self.lambda_fit_cum_r:                     # AgentBase.py:176-177 (bootstraps with the current actor: see get_cumulative_rewards)
+            buffer.update_cum_rewards(get_cumulative_rewards=self.get_cumulative_rewards)
         self._sync_modules()
         update_times = int(buffer.cur_size * self.repeat_times / self.batch_size)
         if update_times < 1:
@@ -226,7 +227,7 @@ class AgentSAC(AgentBase):
             if self.if_use_per:
                 self._per_step(buffer, objs[t])
             else:
-                self._update_on_batch(buffer.sample(self.batch_size, reuse=True), objs[t])   # the batch is consumed before the next draw
+                self._update_on_batch(buffer.sample(self.batch_size, reuse=True), objs[t], buffer=buffer)   # the batch is consumed before the next draw
         o = objs.cpu().numpy()
         _hip.check_async_faults()          # the stream is drained: a skipped optimiser step (grid-wait timeout) raises here
         return float(np.nanmean(o[:, 0])), float(np.nanmean(o[:, 1]))

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void q_label_kernel(const float *__restrict__ 
 // importance-sampling weights w of prioritised replay (AgentSAC.py:60-62; w = 1 without) and td written out for the priorities
 __global__ __launch_bounds__(256) void critic_loss_kernel(const float *__restrict__ q, const float *__restrict__ label,
                                                           const float *__restrict__ unmask, const float *__restrict__ is_weight,
-                                                          int E, int64_t B, float *__restrict__ dq, float *__restrict__ td_out,
-                                                          float *__restrict__ part)
+                                                          const float *__restrict__ fit, int E, int64_t B, float *__restrict__ dq,
+                                                          float *__restrict__ td_out, float *__restrict__ part)
 {
     __shared__ float red[4];
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float *__restric
         for (int e = 0; e < E; ++e) {
             const float diff = q[(size_t)e * B + b] - l;
             s += diff * diff;
-            dq[(size_t)e * B + b] = 2.f * diff * um * w / ((float)E * (float)B);
+            float d = 2.f * diff * um * w / ((float)E * (float)B);
+            if (fit) d += fit[e];                      // the lambda_fit_cum_r term's gradient (fit_cum_r_kernel)
+            dq[(size_t)e * B + b] = d;
         }
         td = (s / (float)E) * um;
         if (td_out) td_out[b] = td;
@@ -126,14 +128,37 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float *__restric
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-// single-block deterministic reductions of small vectors:  out = scale * sum_i x[i] (+ bias)
-__global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, int64_t n, float scale, float bias, float *__restrict__ out)
+// `lambda_fit_cum_r` term of the critic objective (AgentSAC.py:66-68):
+//   obj += lambda * mean_e ( mean_b cum_reward[b] - mean_b q[e][b] )^2
+// One workgroup: the E + 1 batch means, then fit[e] = d term / d q[e][b] = 2 lambda (qbar_e - cbar) / (E B) and fit[E] = the term.
+__global__ __launch_bounds__(256) void fit_cum_r_kernel(const float *__restrict__ q, const float *__restrict__ cum_reward, int E, int64_t B,
+                                                        float lambda_fit, float *__restrict__ fit)
+{
+    __shared__ float red[4];
+    float c = 0.f;
+    for (int64_t i = threadIdx.x; i < B; i += 256) c += cum_reward[i];
+    const float cbar = block_sum(c, red) / (float)B;
+    float term = 0.f;
+    for (int e = 0; e < E; ++e) {
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < B; i += 256) s += q[(size_t)e * B + i];
+        const float qbar = block_sum(s, red) / (float)B;
+        const float diff = cbar - qbar;
+        term += diff * diff;
+        if (threadIdx.x == 0) fit[e] = 2.f * lambda_fit * (qbar - cbar) / ((float)E * (float)B);
+    }
+    if (threadIdx.x == 0) fit[E] = lambda_fit * term / (float)E;
+}
+
+// single-block deterministic reductions of small vectors:  out = scale * sum_i x[i] (+ bias) (+ *add)
+__global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, int64_t n, float scale, float bias, float *__restrict__ out,
+                                                  const float *__restrict__ add = nullptr)
 {
     __shared__ float red[4];
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
     const float t = block_sum(s, red);
-    if (threadIdx.x == 0) out[0] = t * scale + bias;
+    if (threadIdx.x == 0) out[0] = t * scale + bias + (add ? add[0] : 0.f);
 }
 
 // temperature step in one launch: g = target_entropy - mean(logprob) (sum_kernel's reduction), then clip_adam_kernel's
@@ -366,7 +391,7 @@ extern "C" int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int 
     f += 4 * (B * A + 64) + 6 * (B + 64) + (int64_t)d.E * B + 64;    // actions, eps, dA, t | logprobs, label, ... | dq
     f += colsum_scratch_floats(B, maxd) + 64;                        // bias-gradient partials
     f += (2 * (int64_t)E + 1) * (B * maxd + 64) + (int64_t)E * (B * hidden[0] + 64) + B * 2 * A + 64;   // tmpA, tmpB (per decoder), dEnc, per-decoder dEnc, dHead
-    f += d.Pa + d.Pc + 64 + 1024;                                     // gradients, partials
+    f += d.Pa + d.Pc + 64 + 1024 + E + 64;                            // gradients, partials, lambda_fit_cum_r scratch
     return f * 4 + 8192;
 }
 
@@ -374,7 +399,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
                                   float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
                                   const int *hidden, int n_hidden, int E, const float *state, const float *action,
                                   const float *reward, const float *undone, const float *unmask, const float *next_state,
-                                  const float *is_weight, float *td_error_out, int64_t B,
+                                  const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r, int64_t B,
                                   const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
                                   float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
                                   int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, void *stream)
@@ -385,6 +410,7 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     SacDims d;
     ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, E, &d), "erl_sac_update_f32: unsupported dims");
     ERL_REQUIRE(B >= 1 && B < (1LL << 24) && step >= 1, "erl_sac_update_f32: bad argument");
+    ERL_REQUIRE(lambda_fit_cum_r == 0.f || cum_reward, "erl_sac_update_f32: lambda_fit_cum_r != 0 needs the batch's cum_reward");
     ERL_REQUIRE(workspace_bytes >= erl_sac_workspace_bytes(S, A, hidden, n_hidden, E, B), "erl_sac_update_f32: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -412,7 +438,8 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     float *g_actor = ws.take(d.Pa), *g_critic = ws.take(d.Pc), *g_alpha = ws.take(4);
     const int nparts = (int)erl_cdiv(B, 256);
     float *part = ws.take(nparts);
-    ERL_REQUIRE(part != nullptr, "erl_sac_update_f32: workspace layout (tail)");
+    float *fit = ws.take(E + 4);
+    ERL_REQUIRE(part != nullptr && fit != nullptr, "erl_sac_update_f32: workspace layout (tail)");
     const dim3 rows_grid((unsigned)erl_cdiv(B, 256)), blk(256);
 
     // ---- (1) targets: next action / log-prob from the actor, min over the TARGET ensemble          (:50-55)
@@ -426,8 +453,12 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     // ---- (2) critic objective, backward, clip + Adam, soft target update                          (:57-70)
     hipLaunchKernelGGL(concat_kernel, dim3(grid1d(B * (S + A))), blk, 0, s, state, action, S, A, B, xa);
     if ((rc = critic_forward(s, d, critic_params, B, xa, cw, true))) return rc;
-    hipLaunchKernelGGL(critic_loss_kernel, rows_grid, blk, 0, s, cw.q, label, unmask, is_weight, E, B, dq, td_error_out, part);
-    hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, part, (int64_t)nparts, 1.0f / (float)B, 0.f, objs_out);
+    const bool fit_on = lambda_fit_cum_r != 0.f;                     // AgentSAC.py:66-68 (off by default: config.py:52)
+    if (fit_on) hipLaunchKernelGGL(fit_cum_r_kernel, dim3(1), blk, 0, s, cw.q, cum_reward, E, B, lambda_fit_cum_r, fit);
+    hipLaunchKernelGGL(critic_loss_kernel, rows_grid, blk, 0, s, cw.q, label, unmask, is_weight, fit_on ? fit : (const float *)nullptr, E, B, dq,
+                       td_error_out, part);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), blk, 0, s, part, (int64_t)nparts, 1.0f / (float)B, 0.f, objs_out,
+                       fit_on ? fit + E : (const float *)nullptr);
     if (batched) {
         if ((rc = decoders_backward(s, d, critic_params + d.enc.count, B, cw, dq, g_critic + d.enc.count, dEnc, dEncE, enc_stride, tmpA, tmpB,
                                     tmp_stride)))

@@ -215,14 +215,15 @@ class PerTrees:
                                        ptr(ids1, th.int64), ptr(td_error, th.float32), ids0.numel(), float(per_alpha), stream_ptr()),
               "erl_per_update_f32")
 
-    def sample(self, uniform: TEN, cur_size: int, per_beta: float):
-        """uniform (num_seqs, n) in [0, 1) -> (is_indices (num_seqs * n,) int64 = ids1 * cur_size + ids0, is_weights float32)"""
+    def sample(self, uniform: TEN, cur_size: int, per_beta: float, cursor: int = -1):
+        """uniform (num_seqs, n) in [0, 1) -> (is_indices (num_seqs * n,) int64 = ids1 * cur_size + ids0, is_weights float32);
+        `cursor`: the ring's write position when the ring is full (the newest row then has no valid successor), else -1"""
         assert uniform.shape[0] == self.num_seqs and uniform.dtype == th.float32
         n = uniform.shape[1]
         idx = th.empty(self.num_seqs * n, dtype=th.int64, device=uniform.device)
         w = th.empty(self.num_seqs * n, dtype=th.float32, device=uniform.device)
         check(lib().erl_per_sample_f32(ptr(self.sum), ptr(self.min), self.max_size, self.num_seqs, ptr(uniform.contiguous(), th.float32),
-                                       n, int(cur_size), float(per_beta), ptr(idx), ptr(w), stream_ptr()), "erl_per_sample_f32")
+                                       n, int(cur_size), int(cursor), float(per_beta), ptr(idx), ptr(w), stream_ptr()), "erl_per_sample_f32")
         return idx, w
 
 
@@ -568,9 +569,11 @@ class SacSpec:
 def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: TEN, moments: Sequence[TEN], batch: Sequence[TEN],
                step: int, *, gamma: float, target_entropy: float, tau: float, lr: float, max_norm: float, objs_out: TEN,
                noises: Optional[Tuple[TEN, TEN]] = None, seed: int = 0, counter: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
-               is_weight: Optional[TEN] = None, td_error_out: Optional[TEN] = None) -> None:
+               is_weight: Optional[TEN] = None, td_error_out: Optional[TEN] = None, cum_reward: Optional[TEN] = None,
+               lambda_fit_cum_r: float = 0.0) -> None:
     """one AgentSAC.update_objectives step after the sample; `moments` = (actor_m, actor_v, critic_m, critic_v, alpha_m,
-    alpha_v); `batch` = (state, action, reward, undone, unmask, next_state); objs_out: float32[2] on the device."""
+    alpha_v); `batch` = (state, action, reward, undone, unmask, next_state); objs_out: float32[2] on the device.
+    `cum_reward` (B,) + `lambda_fit_cum_r`: the critic's fit-the-batch's-mean-return term (AgentSAC.py:66-68)."""
     state, action, reward, undone, unmask, next_state = batch
     B = state.shape[0]
     ws = _workspace(state.device, spec.workspace_bytes(B))
@@ -579,7 +582,7 @@ def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: T
     check(lib().erl_sac_update_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
                                    spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ptr(state, f32), ptr(action, f32),
                                    ptr(reward, f32), ptr(undone, f32), ptr(unmask, f32), ptr(next_state, f32), ptr(is_weight), ptr(td_error_out),
-                                   B, ptr(n_next),
+                                   ptr(cum_reward), float(lambda_fit_cum_r), B, ptr(n_next),
                                    ptr(n_cur), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), gamma, target_entropy, tau, lr, betas[0],
                                    betas[1], eps, max_norm, step, ptr(objs_out, f32), ptr(ws), ws.numel(), stream_ptr()),
           "erl_sac_update_f32")

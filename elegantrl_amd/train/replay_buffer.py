@@ -114,7 +114,8 @@ class ReplayBuffer:
         sub = batch_size // self.num_seqs
         if uniform is None:
             uniform = th.rand((self.num_seqs, sub), dtype=th.float32, device=self.device)
-        is_indices, is_weights = self.sum_trees.sample(uniform, self.cur_size, self.per_beta)
+        # full ring: the newest row (p - 1) is followed in memory by the oldest one -- never drawn (oracle/per_numpy.py D6)
+        is_indices, is_weights = self.sum_trees.sample(uniform, self.cur_size, self.per_beta, cursor=self.p if self.if_full else -1)
         out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
                                                         is_indices, self.cur_size)     # ids0 = fmod, ids1 = div (:155-156)
         return (*out, is_weights, is_indices)
@@ -150,6 +151,10 @@ class ReplayBuffer:
             assert all(s == sizes[0] for s in sizes)
             self.cur_size = self.p = sizes[0]
             self.if_full = self.cur_size == self.max_size
+            if self.if_use_per:        # the priorities are not part of the reference's file set: a resumed run starts every loaded
+                from .. import ops    # transition at the maximum priority, like freshly written rows (replay_buffer.py:107-115)
+                self.sum_trees = ops.PerTrees(self.max_size, self.num_seqs, self.device)
+                self.sum_trees.add_rows(0, self.cur_size, 10.0)
 
     def update_cum_rewards(self, get_cumulative_rewards):
         if self.p >= self.add_size:

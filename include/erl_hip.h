@@ -167,7 +167,10 @@ ERL_API int erl_replay_sample_discrete_f32(const float *buf_states, const uint8_
  *   erl_per_sample_f32     sample_for_per / important_sampling (:136-151, :285-298): n_per_seq stratified draws per sequence from
  *                          uniform (num_seqs, n_per_seq) in [0,1); out_index = ids1 * cur_size + ids0 (decodes by the reference's
  *                          fmod / div), out_weight = (priority / min priority)^(-per_beta); a draw on row cur_size - 1 moves to
- *                          cur_size - 2 (it has no successor row)
+ *                          cur_size - 2 (it has no successor row); `cursor` = the ring's write position p when the ring is full
+ *                          (< 0 otherwise): a draw on the newest row p - 1, whose successor slot holds the oldest data, moves to
+ *                          p - 2.  Duplicate (ids0, ids1) pairs in one erl_per_update_f32 list: the highest list index wins;
+ *                          pairs outside the trees are skipped.
  * ------------------------------------------------------------------------------------------- */
 ERL_API int64_t erl_per_tree_floats(int64_t max_size, int64_t num_seqs);
 ERL_API int erl_per_init_f32(float *sum_tree, float *min_tree, int64_t max_size, int64_t num_seqs, void *stream);
@@ -176,7 +179,7 @@ ERL_API int erl_per_add_rows_f32(float *sum_tree, float *min_tree, int64_t max_s
 ERL_API int erl_per_update_f32(float *sum_tree, float *min_tree, int64_t max_size, int64_t num_seqs, const int64_t *ids0,
                        const int64_t *ids1, const float *td_error, int64_t n, float per_alpha, void *stream);
 ERL_API int erl_per_sample_f32(const float *sum_tree, const float *min_tree, int64_t max_size, int64_t num_seqs,
-                       const float *uniform, int64_t n_per_seq, int64_t cur_size, float per_beta, int64_t *out_index,
+                       const float *uniform, int64_t n_per_seq, int64_t cur_size, int64_t cursor, float per_beta, int64_t *out_index,
                        float *out_weight, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -445,7 +448,8 @@ ERL_API int erl_sac_update_f32(float *actor_params, float *critic_params, float 
                        float *actor_m, float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v,
                        int S, int A, const int *hidden, int n_hidden, int E, const float *state, const float *action,
                        const float *reward, const float *undone, const float *unmask, const float *next_state,
-                       const float *is_weight, float *td_error_out, int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
+                       const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r,
+                       int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
                        float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam,
                        float max_norm, int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes,
                        void *stream);

@@ -314,7 +314,7 @@ def make_replay_discrete():
     print("wrote", path)
 
 
-def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed):
+def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed, lambda_fit=0.0):
     """Run the reference's AgentSAC.update_objectives on a seeded ring; record every random draw it makes
     (minibatch ids via th.randint, the two rsample() noise tensors per step via th.distributions.Normal.rsample) so the
     same step can be replayed elsewhere with injected draws.  Also records the off-policy rollout contract
@@ -361,6 +361,15 @@ def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed):
 
     buf = ReplayBuffer(max_size=rows + 5, state_dim=S, action_dim=A, gpu_id=-1, num_seqs=N)
     buf.update(items)
+    if lambda_fit:
+        # the critic's `lambda_fit_cum_r` term (AgentSAC.py:66-68) reads buffer.cum_rewards[buffer.ids0, buffer.ids1].  The
+        # reference fills that array through AgentBase.get_cumulative_rewards, which for AgentSAC calls `self.act_target`
+        # = None (AgentBase.py:55, AgentSAC.py:24) and raises; update_objectives itself runs on any contents, so the array is
+        # seeded here and recorded
+        agent.lambda_fit_cum_r = float(lambda_fit)
+        buf.cum_rewards[:] = th.randn(buf.cum_rewards.shape) * 2.0 + 1.0
+        g["cum_rewards"] = np32(buf.cum_rewards)
+        g["lambda_fit_cum_r"] = np.array([lambda_fit], dtype=np.float64)
 
     # --- n_updates SAC steps with recorded ids / noise ---
     ids_log = []
@@ -535,7 +544,9 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     if only:                       # regenerate selected fixtures only: python oracle/make_golden.py cum_rewards ...
         for name in only:
-            if name == "a2c":
+            if name == "sac_fit_cum_r":
+                make_sac("fit_cum_r", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=22, lambda_fit=0.3)
+            elif name == "a2c":
                 make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)
                 make_a2c("mid", S=64, A=8, H=48, net_dims=(128, 128), batch_size=32, repeat_times=2.0, seed=42)
             else:
@@ -550,6 +561,7 @@ if __name__ == "__main__":
     make_replay()
     make_replay_discrete()
     make_sac("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=21)
+    make_sac("fit_cum_r", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=22, lambda_fit=0.3)
     make_ppo_discrete("small", N=8, S=6, A=4, H=12, net_dims=(64, 32), batch_size=16, repeat_times=4.0, seed=31)
     make_cum_rewards()
     make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)

@@ -16,7 +16,13 @@ CORRECTED restatement the HIP kernels (csrc/per.hip) are bit-exact against, with
   D4  the last filled row position (cur_size - 1) has no successor row for `states[ids0 + 1]` (:167): a draw that lands on it is
       moved to cur_size - 2 (the uniform `sample` excludes that position through sample_len = cur_size - 1, :121);
   D5  unwritten leaves carry priority 0 in the sum tree and +inf in the min tree (the reference's `tree[beg:end].min()` slices
-      the written leaves; a min tree gives the same value without an O(n) pass per sample).
+      the written leaves; a min tree gives the same value without an O(n) pass per sample);
+  D6  once the ring is full the newest row (write cursor p - 1) is followed in memory by the OLDEST row, so `states[ids0 + 1]`
+      would pair it with unrelated data -- and new rows enter at the maximum priority, so a prioritised draw would pick that
+      invalid pair far more often than the uniform sampler does (which has the same seam): a draw that lands
+      on it is moved to p - 2 (row 1 when the newest row is row 0);
+  D7  duplicate (row, sequence) pairs in one td-error update (stratified draws and the moves of D4 / D6 can repeat a
+      transition): the LAST one in the list sets the priority (made explicit below; the device resolves it the same way).
 """
 from __future__ import annotations
 
@@ -37,6 +43,10 @@ class PerTrees:
     def set(self, rows: np.ndarray, seqs: np.ndarray, prob: np.ndarray) -> None:
         """leaf (seqs[i], rows[i]) <- prob[i]; parents recomputed level by level as left + right in fp32."""
         prob = np.broadcast_to(np.asarray(prob, F), rows.shape)
+        key = np.asarray(seqs, np.int64) * self.L + np.asarray(rows, np.int64)       # D7: keep the last occurrence of every leaf
+        _, first_rev = np.unique(key[::-1], return_index=True)
+        keep = np.sort(len(key) - 1 - first_rev)
+        rows, seqs, prob = np.asarray(rows)[keep], np.asarray(seqs)[keep], prob[keep]
         node = rows.astype(np.int64) + self.L
         self.sum[seqs, node] = prob
         self.min[seqs, node] = prob
@@ -58,8 +68,10 @@ class PerTrees:
         self.set(ids0, ids1, prob)
 
     # ---- sample: SumTree.important_sampling (:285-298) + get_leaf_id_and_value (:264-283), corrected ---------------------
-    def sample(self, uniform: np.ndarray, cur_size: int):
-        """uniform: (num_seqs, n) in [0, 1).  Returns (ids0, ids1, weights), each (num_seqs * n,), sequence-major (:145-151)."""
+    def sample(self, uniform: np.ndarray, cur_size: int, cursor: int = -1):
+        """uniform: (num_seqs, n) in [0, 1).  Returns (ids0, ids1, weights), each (num_seqs * n,), sequence-major (:145-151).
+        `cursor`: the ring's write position p when the ring is full (D6), else -1."""
+        newest = (cursor + self.max_size - 1) % self.max_size if (cursor >= 0 and cur_size == self.max_size and self.max_size >= 3) else -1
         Q, n = uniform.shape
         ids0 = np.empty((Q, n), np.int64)
         w = np.empty((Q, n), F)
@@ -77,6 +89,8 @@ class PerTrees:
                         node = 2 * node + 1
                 row = node - self.L
                 row = min(row, cur_size - 2)          # D4 (and fp32 round-off at the right edge cannot step into unwritten leaves)
+                if row == newest:
+                    row = newest - 1 if newest >= 1 else 1                                                       # D6
                 ids0[q, j] = row
                 w[q, j] = np.power(self.sum[q, self.L + row] / self.min[q, 1], F(-self.per_beta))             # :296-297
         ids1 = np.repeat(np.arange(Q, dtype=np.int64), n)

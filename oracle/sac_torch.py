@@ -110,9 +110,10 @@ class SacStepper:
         th.nn.utils.clip_grad_norm_(parameters=opt.param_groups[0]["params"], max_norm=self.max_norm)
         opt.step()
 
-    def step(self, batch, eps_next: TEN, eps_cur: TEN, is_weight: Optional[TEN] = None) -> Tuple[float, float]:
+    def step(self, batch, eps_next: TEN, eps_cur: TEN, is_weight: Optional[TEN] = None, cum_reward: Optional[TEN] = None,
+             lambda_fit_cum_r: float = 0.0) -> Tuple[float, float]:
         """`is_weight`: prioritised replay's importance weights (AgentSAC.py:60-62); the per-sample td errors of the step are
-        left in `self.td_error`."""
+        left in `self.td_error`.  `cum_reward` (B,) + `lambda_fit_cum_r`: the fit-the-mean-return term (AgentSAC.py:66-68)."""
         state, action, reward, undone, unmask, next_state = batch
         with th.no_grad():
             next_action, next_logprob = self.act.get_action_logprob(next_state, eps_next)
@@ -122,6 +123,9 @@ class SacStepper:
         td = ((q_values - q_label.view(-1, 1)) ** 2).mean(dim=1) * unmask
         self.td_error = td.detach().clone()
         obj_critic = td.mean() if is_weight is None else (td * is_weight).mean()
+        if lambda_fit_cum_r:
+            cum_reward_mean = cum_reward.mean().repeat(q_values.shape[1])
+            obj_critic = obj_critic + ((cum_reward_mean - q_values.mean(dim=0)) ** 2).mean() * lambda_fit_cum_r
         self._opt(self.cri_opt, obj_critic)
         with th.no_grad():
             for tar, cur in zip(self.cri_target.parameters(), self.cri.parameters()):

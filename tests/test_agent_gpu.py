@@ -194,10 +194,29 @@ def test_c4_iteration_against_oracle(N, S):
 
     actor, critic = to_mlp(agent.act, True), to_mlp(agent.cri, False)
     s_np = states.cpu().numpy().astype(np.float64)
-    for t in (0, H - 1):
-        a_ref, lp_ref = O.actor_sample(s_np[t], actor, noise[t].cpu().numpy().astype(np.float64))
-        np.testing.assert_allclose(actions[t].cpu().numpy(), a_ref, rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose(logprobs[t].cpu().numpy(), lp_ref, rtol=1e-4, atol=1e-4)
+    # EVERY time row of the persistent rollout kernel against the fp64 oracle, directly (not through the per-step kernels):
+    # the policy head on the recorded state, and the env transition + reward + flags that produced the next recorded state
+    a_np, lp_np, r_np = actions.cpu().numpy(), logprobs.cpu().numpy(), rewards.cpu().numpy()
+    ud_np, um_np, n_np = undones.cpu().numpy(), unmasks.cpu().numpy(), noise.cpu().numpy().astype(np.float64)
+    Ws, Wa = env.Ws.cpu().numpy().astype(np.float64), env.Wa.cpu().numpy().astype(np.float64)
+    last_np = agent.last_state.cpu().numpy().astype(np.float64)
+    for t in range(H):
+        a_ref, lp_ref = O.actor_sample(s_np[t], actor, n_np[t])
+        np.testing.assert_allclose(a_np[t], a_ref, rtol=1e-4, atol=2e-5, err_msg=f"actions[{t}]")
+        np.testing.assert_allclose(lp_np[t], lp_ref, rtol=1e-4, atol=1e-4, err_msg=f"logprobs[{t}]")
+        env_a = np.tanh(a_np[t].astype(np.float64))                      # convert_action_for_env (AgentPPO.py:388-390)
+        s2 = s_np[t] @ Ws + env_a @ Wa                                    # SynVecEnv
+        r_ref = (-(s2 ** 2).mean(1) - 0.01 * (env_a ** 2).mean(1)) * agent.reward_scale
+        np.testing.assert_allclose(r_np[t], r_ref, rtol=1e-4, atol=1e-5, err_msg=f"rewards[{t}]")
+        term = np.abs(s2).max(1) > 10
+        margin = np.abs(np.abs(s2).max(1) - 10) > 1e-3                    # fp32 vs fp64 may disagree on a row sitting on the threshold
+        np.testing.assert_array_equal(ud_np[t][margin], ~term[margin], err_msg=f"undones[{t}]")
+        trunc = ((t + 1) % 5 == 0) & ~term                                # max_step = 5, every env was reset at step 0 ...
+        live = ud_np[:t + 1].all(0)                                       # ... valid for envs that have not terminated so far
+        np.testing.assert_array_equal(um_np[t][live & margin], ~(np.full(N, trunc) & ~term)[live & margin], err_msg=f"unmasks[{t}]")
+        nxt = s_np[t + 1] if t + 1 < H else last_np
+        keep = ud_np[t] & um_np[t]                                        # rows that were not auto-reset carry the transition
+        np.testing.assert_allclose(nxt[keep], s2[keep], rtol=1e-4, atol=2e-5, err_msg=f"states[{t + 1}]")
 
     ids = th.randint(H * N, (2, B), device=DEV, generator=g)
     objs = agent.update_net(list(items), ids=ids)

@@ -60,18 +60,25 @@ def test_device_trees_match_the_oracle_bitwise(max_size, Q):
     dev = th.device("cuda:0")
     rng = np.random.default_rng(max_size)
     ref, t = PerTrees(max_size, Q), ops.PerTrees(max_size, Q, dev)
-    cur, p = 0, 0
+    cur, p, full = 0, 0, False
     for add in (max_size // 3, max_size // 2, max_size // 4 + 1, 5):       # wraps; the second one takes the bulk (per-level) path
         ref.add_rows(p, add)
         t.add_rows(p, add)
+        full = full or p + add > max_size
         p = (p + add) % max_size
         cur = min(max_size, cur + add)
         n = min(64, cur * Q)
-        flat = rng.choice(cur * Q, size=n, replace=False)                  # distinct transitions (duplicates race, as in torch)
+        # WITH repeats: a transition drawn twice gets the priority of its LAST td error (oracle D7), deterministically
+        flat = rng.choice(cur * Q, size=n, replace=True)
+        flat[1::7] = flat[0]
         ids0, ids1 = flat % cur, flat // cur
         td = (rng.random(n) * 12).astype(np.float32)
         ref.td_error_update(ids0, ids1, td)
-        t.update(th.from_numpy(ids0).to(dev), th.from_numpy(ids1).to(dev), th.from_numpy(td).to(dev), 0.6)
+        # plus two pairs outside the trees, which the device skips (the host cannot validate device-resident ids)
+        d0 = np.concatenate([ids0, [max_size + 3, 0]]).astype(np.int64)
+        d1 = np.concatenate([ids1, [0, Q]]).astype(np.int64)
+        dtd = np.concatenate([td, [5.0, 5.0]]).astype(np.float32)
+        t.update(th.from_numpy(d0).to(dev), th.from_numpy(d1).to(dev), th.from_numpy(dtd).to(dev), 0.6)
         got_sum, got_min = t.sum.view(Q, -1).cpu().numpy(), t.min.view(Q, -1).cpu().numpy()
         np.testing.assert_allclose(got_sum[:, ref.L:], ref.sum[:, ref.L:], rtol=2e-7)        # powf: one ulp
         leaves_equal = np.array_equal(got_sum[:, ref.L:], ref.sum[:, ref.L:])
@@ -83,10 +90,57 @@ def test_device_trees_match_the_oracle_bitwise(max_size, Q):
         np.testing.assert_array_equal(got_sum[:, 1:], ref.sum[:, 1:])
         np.testing.assert_array_equal(got_min[:, 1:], ref.min[:, 1:])
         u = rng.random((Q, 48)).astype(np.float32)
-        idx, w = t.sample(th.from_numpy(u).to(dev), cur, 0.4)
-        r0, r1, rw = ref.sample(u, cur)
+        cursor = p if full else -1
+        idx, w = t.sample(th.from_numpy(u).to(dev), cur, 0.4, cursor=cursor)
+        r0, r1, rw = ref.sample(u, cur, cursor=cursor)
         np.testing.assert_array_equal(idx.cpu().numpy(), r1 * cur + r0)
         np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=2e-6)
+        if full:                                 # D6: the newest row (its successor slot holds the oldest data) is never drawn
+            assert ((p - 1) % max_size) not in set(r0.tolist())
+    assert full
+
+
+@pytest.mark.gpu
+def test_large_update_list_with_duplicates_takes_the_bulk_path():
+    """more than 8192 td errors in one list (the per-level launches): duplicates resolved like the single-workgroup kernel"""
+    from elegantrl_amd import ops
+    dev = th.device("cuda:0")
+    rng = np.random.default_rng(5)
+    max_size, Q, n = 3000, 4, 9000
+    ref, t = PerTrees(max_size, Q), ops.PerTrees(max_size, Q, dev)
+    ref.add_rows(0, max_size)
+    t.add_rows(0, max_size)
+    ids0, ids1 = rng.integers(0, max_size, n), rng.integers(0, Q, n)
+    td = (rng.random(n) * 12).astype(np.float32)
+    ref.td_error_update(ids0, ids1, td)
+    t.update(th.from_numpy(ids0).to(dev), th.from_numpy(ids1).to(dev), th.from_numpy(td).to(dev), 0.6)
+    got = t.sum.view(Q, -1).cpu().numpy()
+    np.testing.assert_allclose(got[:, ref.L:], ref.sum[:, ref.L:], rtol=2e-7)
+    assert len(set(zip(ids0.tolist(), ids1.tolist()))) < n                    # the list did contain repeats
+
+
+@pytest.mark.gpu
+def test_resumed_per_buffer_does_not_sample_from_empty_trees(tmp_path):
+    """save_or_load_history(if_save=False) on a prioritised buffer: the priorities are not in the reference's file set, so the
+    loaded transitions re-enter at the maximum priority (empty trees gave total = 0, weights = inf)."""
+    from elegantrl_amd.train import Config, ReplayBuffer
+    dev = th.device("cuda:0")
+    args = Config()
+    args.per_alpha, args.per_beta = 0.6, 0.4
+    mk = lambda: ReplayBuffer(max_size=40, state_dim=3, action_dim=2, gpu_id=0, num_seqs=2, if_use_per=True, args=args)   # noqa: E731
+    a = mk()
+    g = th.Generator(device=dev).manual_seed(0)
+    a.update((th.randn((25, 2, 3), device=dev, generator=g), th.randn((25, 2, 2), device=dev, generator=g),
+              th.randn((25, 2), device=dev, generator=g), th.rand((25, 2), device=dev, generator=g) < 0.9,
+              th.rand((25, 2), device=dev, generator=g) < 0.9))
+    a.save_or_load_history(str(tmp_path), if_save=True)
+    b = mk()
+    b.save_or_load_history(str(tmp_path), if_save=False)
+    assert b.cur_size == 25
+    out = b.sample_for_per(16)
+    w, idx = out[6], out[7]
+    assert bool(th.isfinite(w).all()) and th.allclose(w, th.ones_like(w))
+    assert len(set(th.fmod(idx, b.cur_size).tolist())) > 4                   # draws spread over the rows, not all on row 0
 
 
 @pytest.mark.gpu

@@ -13,12 +13,17 @@ def _load_nets(g, tag, act, cri):
     cri.load_state_dict({k[len(f"cri{tag}."):]: th.from_numpy(v) for k, v in g.items() if k.startswith(f"cri{tag}.")})
 
 
-def test_torch_restatement_replays_the_reference():
+SAC_GOLDENS = ["sac_small.npz", "sac_fit_cum_r.npz"]      # the second: lambda_fit_cum_r = 0.3 (AgentSAC.py:66-68), seeded cum_rewards
+
+
+@pytest.mark.parametrize("name", SAC_GOLDENS)
+def test_torch_restatement_replays_the_reference(name):
     """oracle/sac_torch.py (CPU) against the reference-generated golden: objectives, actor, critics, target and alpha after
     each of the 3 recorded update steps."""
     from oracle.sac_torch import SacStepper
     th.set_grad_enabled(True)
-    g = load("sac_small.npz")
+    g = load(name)
+    lam = float(g["lambda_fit_cum_r"][0]) if "lambda_fit_cum_r" in g else 0.0
     N, S, A, rows, B, n_upd, n_ens, h1, h2 = [int(x) for x in g["dims"]]
     gamma, lr, max_norm, reward_scale, tau, target_entropy = [float(x) for x in g["hyper"]]
     st = SacStepper([h1, h2], S, A, n_ens, lr, gamma, tau, max_norm)
@@ -34,7 +39,8 @@ def test_torch_restatement_replays_the_reference():
         i0, i1 = ids % L, ids // L
         batch = (ring["states"][i0, i1], ring["actions"][i0, i1], ring["rewards"][i0, i1], ring["undones"][i0, i1].float(),
                  ring["unmasks"][i0, i1].float(), ring["states"][i0 + 1, i1])
-        oc, oa = st.step(batch, th.from_numpy(g["eps_next"][t]), th.from_numpy(g["eps_cur"][t]))
+        cum = th.from_numpy(g["cum_rewards"])[i0, i1] if lam else None
+        oc, oa = st.step(batch, th.from_numpy(g["eps_next"][t]), th.from_numpy(g["eps_cur"][t]), cum_reward=cum, lambda_fit_cum_r=lam)
         np.testing.assert_allclose([oc, oa], g["objs"][t], rtol=1e-5, atol=1e-7)
         for prefix, net in ((f"act{t + 1}", st.act), (f"cri{t + 1}", st.cri), (f"crit{t + 1}", st.cri_target)):
             for k, v in net.state_dict().items():
@@ -75,10 +81,12 @@ class _ReplayEnv:
 
 
 @pytest.mark.gpu
-def test_sac_rollout_and_updates_replay_the_reference():
+@pytest.mark.parametrize("name", SAC_GOLDENS)
+def test_sac_rollout_and_updates_replay_the_reference(name):
     from elegantrl_amd.agents import AgentSAC
     from elegantrl_amd.train import Config, ReplayBuffer
-    g = load("sac_small.npz")
+    g = load(name)
+    lam = float(g["lambda_fit_cum_r"][0]) if "lambda_fit_cum_r" in g else 0.0
     N, S, A, rows, B, n_upd, n_ens, h1, h2 = [int(x) for x in g["dims"]]
     gamma, lr, max_norm, reward_scale, tau, target_entropy = [float(x) for x in g["hyper"]]
     dev = th.device("cuda:0")
@@ -88,8 +96,9 @@ def test_sac_rollout_and_updates_replay_the_reference():
     args.net_dims = [h1, h2]
     args.batch_size, args.learning_rate, args.gamma, args.reward_scale, args.soft_update_tau = B, lr, gamma, reward_scale, tau
     args.clip_grad_norm = max_norm
+    args.lambda_fit_cum_r = lam
     agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
-    assert abs(agent.target_entropy - target_entropy) < 1e-12
+    assert abs(agent.target_entropy - target_entropy) < 1e-12 and agent.lambda_fit_cum_r == lam
     _load_nets(g, 0, agent.act, agent.cri)
     agent.cri_target.load_state_dict(agent.cri.state_dict())
     with th.no_grad():
@@ -110,6 +119,8 @@ def test_sac_rollout_and_updates_replay_the_reference():
     buf = ReplayBuffer(max_size=rows + 5, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N)
     buf.update(tuple(th.from_numpy(g[n]).to(dev) for n in ("ro_states", "ro_actions", "ro_rewards", "ro_undones", "ro_unmasks")))
     assert (buf.p, buf.cur_size, buf.if_full) == (rows, rows, False)
+    if lam:                       # the recorded contents of buffer.cum_rewards (the reference cannot fill it for AgentSAC: make_golden.py)
+        buf.cum_rewards[:] = th.from_numpy(g["cum_rewards"]).to(dev)
     th.set_grad_enabled(True)
     for t in range(n_upd):
         oc, oa = agent.update_objectives(buf, t, ids=th.from_numpy(g["ids"][t]).to(dev),
@@ -123,8 +134,10 @@ def test_sac_rollout_and_updates_replay_the_reference():
 
 
 @pytest.mark.gpu
-def test_sac_update_net_loop_on_hopper_shaped_ring():
-    """config-3 shapes end to end: GPU-resident synthetic env (S=11, A=3) -> off-policy rollout -> ring -> update_net."""
+@pytest.mark.parametrize("lambda_fit", [0.0, 0.5], ids=["default", "lambda_fit_cum_r"])
+def test_sac_update_net_loop_on_hopper_shaped_ring(lambda_fit):
+    """config-3 shapes end to end: GPU-resident synthetic env (S=11, A=3) -> off-policy rollout -> ring -> update_net; with
+    lambda_fit_cum_r the loop first refreshes the newest rows' n-step returns (AgentBase.py:176-177, erl_cum_rewards_f32)."""
     from elegantrl_amd.agents import AgentSAC
     from elegantrl_amd.envs import SynVecEnv
     from elegantrl_amd.train import Config, ReplayBuffer
@@ -132,6 +145,7 @@ def test_sac_update_net_loop_on_hopper_shaped_ring():
     args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
                                         "if_discrete": False})
     args.net_dims, args.batch_size, args.repeat_times = [64, 64], 256, 16.0   # update_times = int(cur_size * 16 / 256)
+    args.lambda_fit_cum_r = lambda_fit
     th.manual_seed(0)
     agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
     env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=3)
@@ -144,8 +158,12 @@ def test_sac_update_net_loop_on_hopper_shaped_ring():
         assert [tuple(x.shape) for x in items] == [(H, N, S), (H, N, A), (H, N), (H, N), (H, N)]
         assert items[1].abs().max() <= 1.0 and items[3].dtype == th.bool
         buf.update(items)
+        if lambda_fit:
+            buf.cum_rewards[buf.p - H:buf.p] = float("nan")          # the rows update_net must refresh before it samples
         oc, oa = agent.update_net(buf)
         assert np.isfinite([oc, oa]).all()
+        if lambda_fit:             # the newest add_size rows were refreshed: discounted sums of finite rewards
+            assert bool(th.isfinite(buf.cum_rewards[:buf.cur_size]).all())
     assert buf.cur_size == 2 * H and int(buf.cur_size * args.repeat_times / args.batch_size) == 4
     assert any(not th.equal(a, b) for a, b in zip(w0, agent.act.parameters()))
 
