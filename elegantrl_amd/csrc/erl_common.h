@@ -37,6 +37,20 @@ int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stri
                                    int n_groups, float grad_scale, bool want_partials, const ErlExchange *ex, hipStream_t stream);
 int erl_launch_exchange_f64(double *buf, int64_t count, const ErlExchange *ex, hipStream_t stream);
 
+// optim.hip: clip + Adam with the soft target update folded in; sac_fused.hip: the fused SAC step and its shape class
+int erl_clip_adam_soft_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
+                           const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                           float grad_scale, float *soft, float tau, hipStream_t stream);
+bool erl_sac_fused_supported(int S, int A, const int *hidden, int n_hidden, int E, int64_t B);
+int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, int64_t Pa, int64_t Pc);
+int erl_sac_update_fused(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m, float *actor_v,
+                         float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A, int h0, int h1, int E,
+                         const int64_t *aoff, const int64_t *coff, int64_t Pa, int64_t Pc, const float *state, const float *action,
+                         const float *reward, const float *undone, const float *unmask, const float *next_state, const float *is_weight,
+                         float *td_error_out, int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
+                         float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                         int32_t step, float *objs_out, float *workspace, hipStream_t s);
+
 #define ERL_REQUIRE(cond, ...)                 \
     do {                                       \
         if (!(cond)) {                         \

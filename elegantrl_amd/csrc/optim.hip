@@ -18,7 +18,7 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ par
                                                          float *__restrict__ m1, float *__restrict__ m2, AdamGroups gr,
                                                          const int32_t *__restrict__ step_base, int32_t step_offset, float lr,
                                                          float beta1, float beta2, float eps, float max_norm, float grad_scale,
-                                                         float host_step_size, float host_bc2_sqrt)
+                                                         float host_step_size, float host_bc2_sqrt, float *__restrict__ soft, float tau)
 {
     __shared__ double scratch[16];
     const int gi = blockIdx.y;
@@ -71,7 +71,10 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ par
         m1[off + i] = a;
         m2[off + i] = b;
         const float denom = sqrtf(b) / bc2_sqrt + eps;
-        params[off + i] = pv - step_size * (a / denom);
+        const float pn = pv - step_size * (a / denom);
+        params[off + i] = pn;
+        // soft target update in the same launch (AgentBase.soft_update :270-278: tar = cur * tau + tar * (1 - tau))
+        if (soft) soft[off + i] = __fadd_rn(__fmul_rn(pn, tau), __fmul_rn(soft[off + i], 1.0f - tau));
     };
     if (per <= 1024) {
         if (own) adam(ie, e_g, e_m1, e_m2, e_p);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(1024) void clip_adam_grid_kernel(float *__restrict_
                                                               float *__restrict__ m1, float *__restrict__ m2, AdamGroups gr, float beta1,
                                                               float beta2, float eps, float max_norm, float grad_scale, float step_size,
                                                               float bc2_sqrt, double *partials, unsigned *counter, unsigned target,
-                                                              uint32_t *fault)
+                                                              uint32_t *fault, float *__restrict__ soft, float tau)
 {
     __shared__ double scratch[16];
     __shared__ int s_timeout;
@@ -304,7 +307,9 @@ __global__ __launch_bounds__(1024) void clip_adam_grid_kernel(float *__restrict_
         m1[off + ie] = a;
         m2[off + ie] = b;
         const float denom = sqrtf(b) / bc2_sqrt + eps;
-        params[off + ie] = e_p - step_size * (a / denom);
+        const float pn = e_p - step_size * (a / denom);
+        params[off + ie] = pn;
+        if (soft) soft[off + ie] = __fadd_rn(__fmul_rn(pn, tau), __fmul_rn(soft[off + ie], 1.0f - tau));
     }
 }
 
@@ -405,9 +410,9 @@ extern "C" int erl_reduce_clip_adam_grid_ok(int64_t stride)
     return capacity[dev] > 0 && erl_cdiv(stride, RA_E) <= capacity[dev];
 }
 
-extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
-                                 const int64_t *group_len, int n_groups, const int32_t *step_base, int32_t step_offset, float lr,
-                                 float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream)
+static int clip_adam_impl(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
+                          const int64_t *group_len, int n_groups, const int32_t *step_base, int32_t step_offset, float lr, float beta1,
+                          float beta2, float eps, float max_norm, float grad_scale, float *soft, float tau, void *stream)
 {
     ERL_REQUIRE(params && grads && exp_avg && exp_avg_sq && group_off && group_len, "erl_clip_adam_f32: NULL argument");
     ERL_REQUIRE(n_groups >= 1 && n_groups <= 4, "erl_clip_adam_f32: n_groups must be 1..4");
@@ -435,7 +440,8 @@ extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_a
                 const double bc1 = 1.0 - pow((double)beta1, (double)step_offset), bc2 = 1.0 - pow((double)beta2, (double)step_offset);
                 hipLaunchKernelGGL(clip_adam_grid_kernel, dim3(bx, n_groups), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg,
                                    exp_avg_sq, gr, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1), (float)sqrt(bc2),
-                                   reinterpret_cast<double *>(sc->ptr + 256), reinterpret_cast<unsigned *>(sc->ptr), target, erl_fault_word(ERL_FAULT_ADAM_GRID_WAIT));
+                                   reinterpret_cast<double *>(sc->ptr + 256), reinterpret_cast<unsigned *>(sc->ptr), target, erl_fault_word(ERL_FAULT_ADAM_GRID_WAIT),
+                                   soft, tau);
                 ERL_LAUNCH_CHECK("erl_clip_adam_f32");
             }
         }
@@ -448,8 +454,27 @@ extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_a
         bc2_sqrt = (float)sqrt(bc2);
     }
     hipLaunchKernelGGL(clip_adam_kernel, dim3(bx, n_groups), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                       gr, step_base, step_offset, lr, beta1, beta2, eps, max_norm, grad_scale, step_size, bc2_sqrt);
+                       gr, step_base, step_offset, lr, beta1, beta2, eps, max_norm, grad_scale, step_size, bc2_sqrt, soft, tau);
     ERL_LAUNCH_CHECK("erl_clip_adam_f32");
+}
+
+extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
+                                 const int64_t *group_len, int n_groups, const int32_t *step_base, int32_t step_offset, float lr,
+                                 float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream)
+{
+    return clip_adam_impl(params, grads, exp_avg, exp_avg_sq, group_off, group_len, n_groups, step_base, step_offset, lr, beta1, beta2, eps,
+                          max_norm, grad_scale, nullptr, 0.f, stream);
+}
+
+// the same with the soft target update  soft <- params_new * tau + soft * (1 - tau)  of every updated element folded into the
+// launch (AgentBase.soft_update, elegantrl/agents/AgentBase.py:270-278; the arithmetic of soft_update_kernel, sac.hip);
+// `soft` has the layout of `params` and may be NULL.  Internal (sac_fused.hip).
+int erl_clip_adam_soft_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
+                           const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                           float grad_scale, float *soft, float tau, hipStream_t stream)
+{
+    return clip_adam_impl(params, grads, exp_avg, exp_avg_sq, group_off, group_len, n_groups, nullptr, step, lr, beta1, beta2, eps, max_norm,
+                          grad_scale, soft, tau, (void *)stream);
 }
 
 

@@ -12,6 +12,8 @@
 // Parameter blocks (flat fp32):
 //   actor   build_mlp([S, h0..hL-1]) with GELU after every layer, then Linear(hL-1, 2A):  W b ... Whead bhead
 //   critic  encoder Linear(S + A, h0) (no activation), then E decoders build_mlp([h0, h1, .., hL-1, 1]):  We be | dec0 | dec1 ...
+#include <stdlib.h>
+
 #include "mlpn_common.h"
 
 extern "C" int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
@@ -392,6 +394,10 @@ extern "C" int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int 
     f += colsum_scratch_floats(B, maxd) + 64;                        // bias-gradient partials
     f += (2 * (int64_t)E + 1) * (B * maxd + 64) + (int64_t)E * (B * hidden[0] + 64) + B * 2 * A + 64;   // tmpA, tmpB (per decoder), dEnc, per-decoder dEnc, dHead
     f += d.Pa + d.Pc + 64 + 1024 + E + 64;                            // gradients, partials, lambda_fit_cum_r scratch
+    if (erl_sac_fused_supported(S, A, hidden, n_hidden, E, B)) {      // the fused step (sac_fused.hip) carves its own layout
+        const int64_t ff = erl_sac_fused_ws_floats(S, A, hidden[0], hidden[1], E, B, d.Pa, d.Pc);
+        f = ff > f ? ff : f;
+    }
     return f * 4 + 8192;
 }
 
@@ -414,6 +420,18 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     ERL_REQUIRE(workspace_bytes >= erl_sac_workspace_bytes(S, A, hidden, n_hidden, E, B), "erl_sac_update_f32: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     int rc;
+
+    // Off-policy batch sizes with two hidden layers up to 256 wide (config 3): the fused step, 12 launches (sac_fused.hip).
+    // ERL_SAC_FUSED=0 keeps the layered step below (A/B runs); lambda_fit_cum_r != 0 (off by default) is layered only.
+    static const bool fused_on = [] { const char *e = getenv("ERL_SAC_FUSED"); return !(e && atoi(e) == 0); }();
+    if (fused_on && lambda_fit_cum_r == 0.f && erl_sac_fused_supported(S, A, hidden, n_hidden, E, B)) {
+        const int64_t aoff[6] = {d.actor.oW[0], d.actor.ob[0], d.actor.oW[1], d.actor.ob[1], d.actor.oW[2], d.actor.ob[2]};
+        const int64_t coff[8] = {d.enc.oW[0], d.enc.ob[0], d.enc.count, d.dec.oW[0], d.dec.ob[0], d.dec.oW[1], d.dec.ob[1], d.dec.count};
+        return erl_sac_update_fused(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S,
+                                    A, hidden[0], hidden[1], E, aoff, coff, d.Pa, d.Pc, state, action, reward, undone, unmask, next_state,
+                                    is_weight, td_error_out, B, eps_next, eps_cur, seed, counter, gamma, target_entropy, tau, lr, beta1, beta2,
+                                    eps_adam, max_norm, step, objs_out, (float *)workspace, s);
+    }
 
     Ws ws{(char *)workspace, 0, workspace_bytes};
     int maxd = S + A;

@@ -1,0 +1,957 @@
+// Fused SAC update step for off-policy batch sizes (config 3: B = 256..1024, net [256,256], 4 critics): the same arithmetic
+// as the layered step in sac.hip (AgentSAC.update_objectives, elegantrl/agents/AgentSAC.py:42-86) in 12 launches instead of
+// ~52.  At these sizes every dense layer of the layered path is a launch-bound GEMM (~7 us whatever it computes,
+// profiles/r02_gemm_small_scaling.txt), so the step's time IS its launch count.  What needs the whole batch -- the weight
+// gradients (a reduction over the batch) and the global-norm clip -- stays a launch of its own; everything between two such
+// points is ROW-LOCAL and runs as one kernel per 16-sample tile:
+//
+//   actor_fwd      gather-free read of the sampled rows -> L1 -> L2 -> head (mean, log_std) -> tanh action, log-prob
+//   critic_fwd     [state | action] -> shared encoder -> decoder e -> q_e                          grid (tiles, E)
+//   critic_train   the same with the loss: q_label from the target's q (min over e), dq, back through the decoder to the
+//                  encoder output; leaves the operands of the weight gradients in memory            grid (tiles, E)
+//   critic_pg      target ensemble on [state | action_pg]: q_e and dq/d(action)                     grid (tiles, E)
+//   actor_bwd      head backward (tanh / reparameterisation / the log-prob quirk) -> L2 -> L1 pre-activation gradients
+//   dw_table       ALL weight and bias gradients of a network in one launch (a table of small contractions over the batch)
+//   clip + Adam    optim.hip, with the soft target update folded into the critic's (AgentBase.py:270-278)
+//
+// Inside a tile kernel a layer is computed transposed on v_mfma_f32_16x16x4_f32 (exact fp32), outT (features x 16 samples) =
+// W . inT, the 8 waves of the workgroup splitting the OUTPUT feature tiles (a 256 x 256 layer on 16 samples is 2.1 MFLOP = one
+// CU for ~8k cycles; it cannot be spread further without a cross-workgroup exchange, i.e. a launch); a wave's weight rows come
+// straight from L2 into registers as MFMA A operands, all issued before the first MFMA; activations cross waves through a
+// [sample][feature] LDS image.  Layers with <= 16 outputs (policy head, Q value, action gradient) split the REDUCTION over the
+// waves instead and meet in LDS in a fixed order.  Everything is deterministic.
+#include "mlpn_common.h"
+
+namespace {
+
+constexpr int FT = 512, FWV = 8;       // threads / waves per tile workgroup
+constexpr int TS = 16;                 // samples per tile
+constexpr int LDT = 260;               // LDS image row stride (floats): 16-byte aligned rows, consecutive samples 4 banks apart
+constexpr int FMAXW = 256;             // widest hidden layer
+constexpr int FMAXE = 8;
+constexpr float kLogSqrt2PiF2 = 0.91893853320467274178f;
+
+struct FusedDims {
+    int S, A, E, h0, h1;
+    int64_t B;
+    // actor block: Linear(S, h0) GELU Linear(h0, h1) GELU Linear(h1, 2A)
+    int64_t aW1, ab1, aW2, ab2, aWh, abh;
+    // critic block: encoder Linear(S + A, h0) | decoder e: Linear(h0, h1) GELU Linear(h1, 1), `dec` floats apart
+    int64_t cWe, cbe, cdec0, dW1, db1, dWo, dbo, dec;
+};
+
+#ifdef ERL_PROFILE
+// profiling builds (make EXTRA=-DERL_PROFILE): cycle stamps of workgroup (0, 0), wave 0, per kernel slot (tools/sac_fused_profile.py)
+__device__ long long g_fprof[8][32];
+#define FPROF(slot, i)                                                                                       \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                                        \
+            unsigned long long t_;                                                                           \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_fprof[slot][i] = (long long)t_;                                                                \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#else
+#define FPROF(slot, i) do { } while (0)
+#endif
+
+struct LaneId {
+    int tid, wave, lane, l15, q;
+};
+__device__ __forceinline__ LaneId lane_id()
+{
+    LaneId L;
+    L.tid = threadIdx.x; L.lane = L.tid & 63; L.l15 = L.lane & 15; L.q = L.lane >> 4;
+    L.wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);        // in an SGPR: conditions on it are scalar branches, not exec masks
+    return L;
+}
+
+// four consecutive weights W[row][k0 .. k0 + 3] of a [nrows][K] row-major matrix, zeros outside.  VEC: K % 4 == 0, so a group of
+// four is entirely inside or outside the row -- ONE 16-byte load that only needs 4-byte alignment (the decoder blocks of the
+// critic ensemble are an odd number of floats apart; gfx950 global loads take any dword-aligned address)
+template <bool VEC>
+__device__ __forceinline__ float4 ldw4_raw(const float *__restrict__ W, int row, int nrows, int K, int k0)
+{
+    // the load alone, from an address clamped into the matrix: the caller issues a whole layer's loads back to back, fences the
+    // scheduler, and only then applies ldw4_mask (a select or multiply right behind each load makes hipcc wait for every load
+    // before it issues the next: measured 3-10x on these kernels)
+    const float *p = W + (size_t)min(row, nrows - 1) * K;
+    float4 v;
+    if (VEC) {
+        __builtin_memcpy(&v, p + max(min(k0, K - 4), 0), 16);
+    } else {
+        v.x = p[min(k0, K - 1)]; v.y = p[min(k0 + 1, K - 1)]; v.z = p[min(k0 + 2, K - 1)]; v.w = p[min(k0 + 3, K - 1)];
+    }
+    return v;
+}
+template <bool VEC>
+__device__ __forceinline__ float4 ldw4_mask(float4 v, int row, int nrows, int K, int k0)
+{
+    const bool r = row < nrows;
+    if (VEC) {
+        const float ok = (r && k0 < K) ? 1.f : 0.f;             // K % 4 == 0: the four are inside or outside together
+        v.x *= ok; v.y *= ok; v.z *= ok; v.w *= ok;
+    } else {
+        v.x *= (r && k0 < K) ? 1.f : 0.f; v.y *= (r && k0 + 1 < K) ? 1.f : 0.f;
+        v.z *= (r && k0 + 2 < K) ? 1.f : 0.f; v.w *= (r && k0 + 3 < K) ? 1.f : 0.f;
+    }
+    return v;
+}
+
+// width classes a tile kernel is compiled for: hidden width <= 64 / <= 128 / <= 256 -> k-tiles of 16 (as an input), output tiles
+// per wave (as an output)
+template <int C> struct WClass { static constexpr int KT = C == 0 ? 4 : (C == 1 ? 8 : 16), NU = C == 2 ? 2 : 1; };
+
+// ---------------------------------------------------------------------------------------------------------
+// forward layer, output-split: wave w computes the 16-feature output tiles w and w + 8 of  Z^T = W . in^T + b  for the
+// workgroup's 16 samples (in: LDS image Tin[sample][feature], K columns, zero padded to a multiple of 16).  Lane
+// (l15 = sample, q) ends up with features 16 ot + 4 q + r (r = 0..3) of its sample: z[u][r] for tile u.
+// ---------------------------------------------------------------------------------------------------------
+template <int KT_, int NU>
+struct FwdW {
+    float4 v[NU][KT_];
+};
+
+// the weights of a layer, issued as early as the kernel knows which layer comes (they depend on nothing): by the time the
+// layer's input image is ready they have landed
+template <int KT_, int NU, bool VEC>
+__device__ __forceinline__ void layer_fwd_load(const float *__restrict__ W, int K, int N, const LaneId &L, FwdW<KT_, NU> &w)
+{
+    if (VEC) {
+        // hidden-width inputs (K a multiple of 16): ONE per-lane base per tile and wave-uniform k-tile offsets (a clamped address
+        // per load costs two VGPRs each before the loads issue: 128 loads' worth spills)
+        const int KTr = K >> 4;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float *base = W + (size_t)min(16 * (L.wave + FWV * u) + L.l15, N - 1) * K + 4 * L.q;
+#pragma unroll
+            for (int kt = 0; kt < KT_; ++kt) __builtin_memcpy(&w.v[u][kt], base + 16 * min(kt, KTr - 1), 16);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int kt = 0; kt < KT_; ++kt) w.v[u][kt] = ldw4_raw<false>(W, 16 * (L.wave + FWV * u) + L.l15, N, K, 16 * kt + 4 * L.q);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KT_, int NU, bool VEC>
+__device__ __forceinline__ void layer_fwd_mma(FwdW<KT_, NU> &w, const float *__restrict__ bias, int K, int N, const float *Tin, const LaneId &L,
+                                              f32x4 (&z)[2])
+{
+    // Hidden-width inputs (VEC: K a multiple of 16): no per-element masks -- 512 multiplies per lane and layer would cost as much
+    // as the layer's MFMAs (fp32 MFMA and VALU share the pipe); k-tiles beyond K are skipped by a wave-uniform branch, output tiles
+    // beyond N are computed on clamped rows and dropped by the epilogue.  Input layers (K = S or S + A, any value): the partial
+    // k-tile is masked (8 loads).
+    const int KTr = (K + 15) >> 4;
+    if (!VEC) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int kt = 0; kt < KT_; ++kt) w.v[u][kt] = ldw4_mask<false>(w.v[u][kt], 16 * (L.wave + FWV * u) + L.l15, N, K, 16 * kt + 4 * L.q);
+        }
+    }
+    z[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    z[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *xr = Tin + L.l15 * LDT + 4 * L.q;
+#pragma unroll
+    for (int kt = 0; kt < KT_; ++kt) {
+        if (kt < KTr) {                                             // (SGPR condition: a scalar branch)
+            const float4 x = *reinterpret_cast<const float4 *>(xr + 16 * kt);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                z[u] = mfma16(w.v[u][kt].x, x.x, z[u]);
+                z[u] = mfma16(w.v[u][kt].y, x.y, z[u]);
+                z[u] = mfma16(w.v[u][kt].z, x.z, z[u]);
+                z[u] = mfma16(w.v[u][kt].w, x.w, z[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int f = 16 * (L.wave + FWV * u) + 4 * L.q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float b = bias[min(f + r, N - 1)];
+            z[u][r] += (f + r < N) ? b : 0.f;
+        }
+    }
+}
+
+// the epilogue of a hidden layer: optional exact-erf GELU, the LDS image for the next layer, optional copies in memory
+// (H: what the next layer's weight gradient contracts with; G: GELU' for a backward pass in another kernel)
+__device__ __forceinline__ void emit_hidden(const f32x4 (&z)[2], int N, bool gelu, float *Tout, f32x4 (&gk)[2], float *gH, float *gG, int64_t row,
+                                            bool valid, const LaneId &L)
+{
+    const int NT = (N + 15) >> 4;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ot = L.wave + FWV * u;
+        if (ot >= NT) continue;
+        const int f = 16 * ot + 4 * L.q;
+        float h[4], g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (gelu) gelu_and_grad_fast(z[u][r], h[r], g[r]);
+            else { h[r] = z[u][r]; g[r] = 1.f; }
+            if (f + r >= N) { h[r] = 0.f; g[r] = 0.f; }
+            gk[u][r] = g[r];
+        }
+        *reinterpret_cast<float4 *>(Tout + L.l15 * LDT + f) = make_float4(h[0], h[1], h[2], h[3]);
+        if (valid && f < N) {                                     // hidden widths are multiples of 16: whole float4s
+            if (gH) *reinterpret_cast<float4 *>(gH + row * N + f) = make_float4(h[0], h[1], h[2], h[3]);
+            if (gG) *reinterpret_cast<float4 *>(gG + row * N + f) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward through a layer's input, output-split:  dX^T (Kin features x 16 samples) = W^T . dZ^T, W = [Kz][Kin] row-major in
+// memory, dZ: LDS image Tin[sample][feature] (Kz columns, zero padded).  Wave w computes input-feature tiles w and w + 8; lane
+// (l15, q) ends up with dX features 16 it + 4 q + r of its sample.  The A operand is W^T: lane (i = l15, q) reads
+// W[16 kt + 4 q + j][16 it + i] -- 64-byte runs of a row per quarter wave.
+// ---------------------------------------------------------------------------------------------------------
+template <int KT_, int NU>
+struct BwdW {
+    float v[NU][KT_][4];
+};
+
+template <int KT_, int NU>
+__device__ __forceinline__ void layer_bwd_load(const float *__restrict__ W, int Kz, int Kin, const LaneId &L, BwdW<KT_, NU> &w)
+{
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int colc = min(16 * (L.wave + FWV * u) + L.l15, Kin - 1);
+        if (KT_ == 1) {                                             // Kz <= 16, any value (the policy head's 2 A rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w.v[u][0][j] = W[(size_t)min(4 * L.q + j, Kz - 1) * Kin + colc];
+        } else {                                                    // Kz a multiple of 16: one per-lane offset, wave-uniform row offsets
+            const int KTr = Kz >> 4;
+            const uint32_t voff = (uint32_t)(4 * L.q) * (uint32_t)Kin + (uint32_t)colc;
+#pragma unroll
+            for (int kt = 0; kt < KT_; ++kt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w.v[u][kt][j] = (W + (size_t)(16 * min(kt, KTr - 1) + j) * Kin)[voff];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KT_, int NU>
+__device__ __forceinline__ void layer_bwd_mma(BwdW<KT_, NU> &w, int Kz, int Kin, const float *Tin, const LaneId &L, f32x4 (&dx)[2])
+{
+    const int KTr = (Kz + 15) >> 4;
+    if (KT_ == 1) {                                                 // Kz <= 16, any value: rows beyond Kz masked (4 loads per tile)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w.v[u][0][j] *= (4 * L.q + j < Kz) ? 1.f : 0.f;
+        }
+    }
+    dx[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dx[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *zr = Tin + L.l15 * LDT + 4 * L.q;
+#pragma unroll
+    for (int kt = 0; kt < KT_; ++kt) {
+        if (kt < KTr) {                                             // Kz a multiple of 16 otherwise: whole k-tiles, no masks (see layer_fwd_mma)
+            const float4 d = *reinterpret_cast<const float4 *>(zr + 16 * kt);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                dx[u] = mfma16(w.v[u][kt][0], d.x, dx[u]);
+                dx[u] = mfma16(w.v[u][kt][1], d.y, dx[u]);
+                dx[u] = mfma16(w.v[u][kt][2], d.z, dx[u]);
+                dx[u] = mfma16(w.v[u][kt][3], d.w, dx[u]);
+            }
+        }
+    }
+}
+
+struct SmallW {
+    float v[2][4];
+};
+
+template <bool TRANSPOSED, bool VEC>
+__device__ __forceinline__ void layer_small_load(const float *__restrict__ W, int K, int N, int ldw, int col0, const LaneId &L, SmallW &w)
+{
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                   // K <= 256: k-tiles wave and wave + 8 (zero weights beyond K)
+        const int kt = L.wave + FWV * u;
+        if (!TRANSPOSED) {
+            const float4 v = ldw4_raw<VEC>(W, L.l15, N, K, 16 * kt + 4 * L.q);
+            w.v[u][0] = v.x; w.v[u][1] = v.y; w.v[u][2] = v.z; w.v[u][3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w.v[u][j] = W[(size_t)min(16 * kt + 4 * L.q + j, K - 1) * ldw + col0 + min(L.l15, N - 1)];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool TRANSPOSED, bool VEC>
+__device__ __forceinline__ void layer_small_mma(SmallW &w, const float *__restrict__ bias, int K, int N, const float *Tin, float *part, float *Yl,
+                                                const LaneId &L)
+{
+    // K is a hidden width (a multiple of 16): whole k-tiles, skipped by a wave-uniform branch beyond K; outputs f >= N are
+    // computed on clamped rows / columns and dropped below
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int KTr = (K + 15) >> 4;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int kt = L.wave + FWV * u;
+        if (kt < KTr) {
+            const float4 x = *reinterpret_cast<const float4 *>(Tin + L.l15 * LDT + 16 * kt + 4 * L.q);
+            acc = mfma16(w.v[u][0], x.x, acc);
+            acc = mfma16(w.v[u][1], x.y, acc);
+            acc = mfma16(w.v[u][2], x.z, acc);
+            acc = mfma16(w.v[u][3], x.w, acc);
+        }
+    }
+    *reinterpret_cast<float4 *>(part + (L.wave * TS + L.l15) * 16 + 4 * L.q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    lds_barrier();
+    if (L.tid < TS * 16) {
+        const int s = L.tid >> 4, f = L.tid & 15;
+        float y = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < FWV; ++wv) y += part[(wv * TS + s) * 16 + f];
+        Yl[s * 16 + f] = f < N ? y + (bias ? bias[min(f, N - 1)] : 0.f) : 0.f;
+    }
+    lds_barrier();
+}
+
+// rows [row0, row0 + 16) of up to two row-major matrices side by side ([X0 (c0 columns) | X1 (c1 columns)]) into an LDS image,
+// zero padded to a multiple of 16 columns and beyond the batch; optionally the concatenated rows go to memory as well
+__device__ __forceinline__ void load_rows(const float *__restrict__ X0, int c0, const float *__restrict__ X1, int c1, int64_t row0, int64_t B,
+                                          float *T, float *gcat, const LaneId &L)
+{
+    const int C = c0 + c1, CP = ((C + 15) >> 4) << 4;
+    for (int e = L.tid; e < TS * CP; e += FT) {
+        const int s = e / CP, c = e - s * CP;
+        const int64_t row = row0 + s;
+        float v = 0.f;
+        if (row < B && c < C) v = c < c0 ? X0[row * c0 + c] : X1[row * c1 + (c - c0)];
+        T[s * LDT + c] = v;
+        if (gcat && row < B && c < C) gcat[row * C + c] = v;
+    }
+}
+
+// Barriers in the tile kernels order LDS traffic only (lds_barrier: s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also
+// drain the vector-memory counter, i.e. wait for the prefetched weights (a CU streams a cold 256 KB layer at ~30 GB/s: ~9 us) and for
+// every global store of the epilogues at each barrier.
+// the images must hold finite values everywhere a (zero-weighted) padded k-tile may read
+__device__ __forceinline__ void clear_images(float *T0, float *T1, const LaneId &L)
+{
+    for (int e = L.tid; e < TS * LDT; e += FT) { T0[e] = 0.f; T1[e] = 0.f; }
+}
+
+struct TileLds {
+    float T0[TS * LDT], T1[TS * LDT];
+    float part[FWV * TS * 16];
+    float Yl[TS * 16];
+    float red[FWV];
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// actor forward + policy head:  ActorSAC.get_action_logprob (AgentSAC.py:187-199)
+// ---------------------------------------------------------------------------------------------------------
+struct ActorFwdArgs {
+    const float *P;
+    FusedDims d;
+    const float *X;                // (B, S) sampled state rows
+    const float *noise;            // (B, A) or NULL: Philox keyed by (seed, counter, row, a)
+    uint64_t seed, counter;
+    float *act_t, *lp;             // (B, A), (B,)
+    float *eps_out, *Y;            // keep: (B, A) draws used, (B, 2A) raw head output
+    float *H0, *G0, *H1, *G1;      // keep: activations / GELU' for the backward pass and the weight gradients
+    const float *alpha_log;        // first call of a step: the temperature BEFORE its update is parked in alpha0 (q_label uses it)
+    float *alpha0;
+};
+
+template <int C0, int C1>
+__global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
+{
+    __shared__ TileLds lds;
+    const LaneId L = lane_id();
+    const FusedDims &d = g.d;
+    const int64_t row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
+    const bool valid = row < d.B;
+    if (g.alpha0 && blockIdx.x == 0 && L.tid == 0) g.alpha0[0] = g.alpha_log[0];
+    FPROF(0, 0);
+    // every weight this wave will use, requested before anything else
+    FwdW<4, WClass<C0>::NU> w1;
+    FwdW<WClass<C0>::KT, WClass<C1>::NU> w2;
+    SmallW wh;
+    layer_fwd_load<4, WClass<C0>::NU, false>(g.P + d.aW1, d.S, d.h0, L, w1);
+    layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(g.P + d.aW2, d.h0, d.h1, L, w2);
+    layer_small_load<false, true>(g.P + d.aWh, d.h1, 2 * d.A, 0, 0, L, wh);
+    clear_images(lds.T0, lds.T1, L);
+    lds_barrier();
+    FPROF(0, 1);
+    load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, nullptr, L);
+    lds_barrier();
+    FPROF(0, 2);
+    f32x4 z[2], gk[2];
+    layer_fwd_mma<4, WClass<C0>::NU, false>(w1, g.P + d.ab1, d.S, d.h0, lds.T0, L, z);
+    FPROF(0, 3);
+    emit_hidden(z, d.h0, true, lds.T1, gk, g.H0, g.G0, row, valid, L);
+    lds_barrier();
+    FPROF(0, 4);
+    layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w2, g.P + d.ab2, d.h0, d.h1, lds.T1, L, z);
+    FPROF(0, 5);
+    emit_hidden(z, d.h1, true, lds.T0, gk, g.H1, g.G1, row, valid, L);
+    lds_barrier();
+    FPROF(0, 6);
+    layer_small_mma<false, true>(wh, g.P + d.abh, d.h1, 2 * d.A, lds.T0, lds.part, lds.Yl, L);
+    FPROF(0, 7);
+    if (L.tid < TS) {
+        const int64_t b = row0 + L.tid;
+        if (b < d.B) {
+            const int A = d.A;
+            float lp = 0.f;
+            for (int a = 0; a < A; ++a) {
+                const float mean = lds.Yl[L.tid * 16 + a], ls = lds.Yl[L.tid * 16 + A + a];
+                const float lsc = fminf(fmaxf(ls, -16.f), 2.f);
+                const float sd = expf(lsc);
+                const float eps = g.noise ? g.noise[b * A + a] : philox_normal(g.seed, g.counter, (uint32_t)b, (uint32_t)a);
+                const float t = tanhf(mean + sd * eps);
+                g.act_t[b * A + a] = t;
+                if (g.eps_out) g.eps_out[b * A + a] = eps;
+                if (g.Y) { g.Y[b * 2 * A + a] = mean; g.Y[b * 2 * A + A + a] = ls; }
+                lp += (-logf(sd) - kLogSqrt2PiF2) - logf(-(t * t) + 1.000001f);
+            }
+            g.lp[b] = lp;
+        }
+    }
+    FPROF(0, 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// critic passes: grid = (tiles, E).  MODE 0: forward only -> q[e][b] (the TARGET ensemble on the next state);
+// MODE 1: training pass (labels, loss gradient, backward to the encoder output, operands of the weight gradients);
+// MODE 2: policy-gradient pass (TARGET ensemble on [state | action_pg]: q and d(mean q)/d(action)).
+// ---------------------------------------------------------------------------------------------------------
+struct CriticArgs {
+    const float *P;                          // critic or target parameter block
+    FusedDims d;
+    const float *Xs, *Xa;                    // (B, S), (B, A)
+    float *q;                                // [E][B]: this pass's q values
+    // MODE 1
+    const float *qt;                         // [E][B] target q of the next state
+    const float *reward, *undone, *unmask, *lp_next, *is_weight, *alpha0;
+    float gamma;
+    float *label, *dq;                       // (B,), [E][B]
+    float *xa, *enc, *H1e, *dZ1e, *dEncE;    // (B, S+A), (B, h0), [E](B, h1), [E](B, h1), [E](B, h0)
+    // MODE 2
+    float *dAct, *qpart;                     // [E](B, A), [E][tiles]
+    const float *qc, *label_in;              // the training pass's q and labels: the critic objective is finished here
+    float *td_out, *tdpart;                  // (B,) or NULL, [tiles]
+};
+
+template <int MODE, int C0, int C1>
+__global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
+{
+    __shared__ TileLds lds;
+    __shared__ float dql[TS];
+    const LaneId L = lane_id();
+    const FusedDims &d = g.d;
+    const int e = blockIdx.y, E = d.E;
+    const int64_t B = d.B, row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
+    const bool valid = row < B;
+    const float *Pd = g.P + d.cdec0 + (int64_t)e * d.dec;
+    const bool first = e == 0;
+    FwdW<4, WClass<C0>::NU> we;
+    FwdW<WClass<C0>::KT, WClass<C1>::NU> w1;
+    SmallW wo;
+    layer_fwd_load<4, WClass<C0>::NU, false>(g.P + d.cWe, d.S + d.A, d.h0, L, we);
+    layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(Pd + d.dW1, d.h0, d.h1, L, w1);
+    layer_small_load<false, true>(Pd + d.dWo, d.h1, 1, 0, 0, L, wo);
+    clear_images(lds.T0, lds.T1, L);
+    lds_barrier();
+    load_rows(g.Xs, d.S, g.Xa, d.A, row0, B, lds.T0, (MODE == 1 && first) ? g.xa : nullptr, L);
+    lds_barrier();
+    f32x4 z[2], gk[2], gk1[2];
+    layer_fwd_mma<4, WClass<C0>::NU, false>(we, g.P + d.cbe, d.S + d.A, d.h0, lds.T0, L, z);            // shared encoder: raw linear
+    emit_hidden(z, d.h0, false, lds.T1, gk, (MODE == 1 && first) ? g.enc : nullptr, nullptr, row, valid, L);
+    lds_barrier();
+    layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w1, Pd + d.db1, d.h0, d.h1, lds.T1, L, z);
+    // the backward pass's weights are requested now (the forward layer's registers are free): they land under the output layer,
+    // the loss and the gate
+    BwdW<WClass<C1>::KT, WClass<C0>::NU> wb;
+    SmallW wa;
+    emit_hidden(z, d.h1, true, lds.T0, gk1, MODE == 1 ? g.H1e + (size_t)e * B * d.h1 : nullptr, nullptr, row, valid, L);
+    if (MODE != 0) layer_bwd_load<WClass<C1>::KT, WClass<C0>::NU>(Pd + d.dW1, d.h1, d.h0, L, wb);
+    if (MODE == 2) layer_small_load<true, false>(g.P + d.cWe, d.h0, d.A, d.S + d.A, d.S, L, wa);
+    lds_barrier();
+    layer_small_mma<false, true>(wo, Pd + d.dbo, d.h1, 1, lds.T0, lds.part, lds.Yl, L);
+    if (MODE == 0) {
+        if (L.tid < TS && row0 + L.tid < B) g.q[(size_t)e * B + row0 + L.tid] = lds.Yl[L.tid * 16];
+        return;
+    }
+    // ---- dL/dq of this decoder for the tile's samples
+    if (L.tid < TS) {
+        const int64_t b = row0 + L.tid;
+        float dqv = 0.f;
+        if (b < B) {
+            const float qv = lds.Yl[L.tid * 16];
+            g.q[(size_t)e * B + b] = qv;
+            if (MODE == 1) {
+                // q_label = reward + undone * gamma * (min_e q_target - next_logprob * alpha)      (AgentSAC.py:52-55)
+                float m = g.qt[b];
+                for (int k = 1; k < E; ++k) m = fminf(m, g.qt[(size_t)k * B + b]);
+                const float alpha = expf(g.alpha0[0]);
+                const float lab = g.reward[b] + (g.undone[b] * g.gamma) * (m - g.lp_next[b] * alpha);
+                if (first) g.label[b] = lab;
+                // td = mean_e (q - label)^2 * unmask; obj = mean_b (td w): dq = 2 (q - label) unmask w / (E B)   (:57-62)
+                const float w = g.is_weight ? g.is_weight[b] : 1.f;
+                dqv = 2.f * (qv - lab) * g.unmask[b] * w / ((float)E * (float)B);
+                g.dq[(size_t)e * B + b] = dqv;
+            } else {
+                dqv = -1.0f / ((float)E * (float)B);               // L = -(mean_b mean_e q - alpha mean_b logprob)   (:82-84)
+            }
+        }
+        dql[L.tid] = dqv;
+    }
+    if (MODE == 2) {                                               // partial sums of q for the logged actor objective
+        float s = (L.tid < TS && row0 + L.tid < B) ? lds.Yl[L.tid * 16] : 0.f;
+        s = wave_sum(s);
+        if (L.tid == 0) g.qpart[(size_t)e * gridDim.x + blockIdx.x] = s;
+        if (first && L.wave == 1) {                                // (wave 1, whole wave) the critic objective's per-sample td errors, now
+            const int64_t b = row0 + L.lane;                       // that every decoder's q of the training pass is in memory
+            float td = 0.f;
+            if (L.lane < TS && b < B) {
+                const float lab = g.label_in[b];
+                float s2 = 0.f;
+                for (int k = 0; k < E; ++k) {
+                    const float diff = g.qc[(size_t)k * B + b] - lab;
+                    s2 += diff * diff;
+                }
+                td = (s2 / (float)E) * g.unmask[b];
+                if (g.td_out) g.td_out[b] = td;
+                td *= g.is_weight ? g.is_weight[b] : 1.f;
+            }
+            td = wave_sum(td);
+            if (L.lane == 0) g.tdpart[blockIdx.x] = td;
+        }
+    }
+    lds_barrier();
+    // ---- dZ1 = (Wo^T dq) * GELU'(z1): the wave's own tiles (it still holds their GELU')
+    {
+        const int NT = (d.h1 + 15) >> 4;
+        const float dqs = dql[L.l15];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ot = L.wave + FWV * u;
+            if (ot >= NT) continue;
+            const int f = 16 * ot + 4 * L.q;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (f + r < d.h1) ? Pd[d.dWo + f + r] * dqs * gk1[u][r] : 0.f;
+            *reinterpret_cast<float4 *>(lds.T1 + L.l15 * LDT + f) = make_float4(v[0], v[1], v[2], v[3]);
+            if (MODE == 1 && valid && f < d.h1)
+                *reinterpret_cast<float4 *>(g.dZ1e + ((size_t)e * B + row) * d.h1 + f) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    lds_barrier();
+    // ---- dEnc = W1^T dZ1 (the encoder is a raw linear layer: no gate)
+    f32x4 dx[2];
+    layer_bwd_mma<WClass<C1>::KT, WClass<C0>::NU>(wb, d.h1, d.h0, lds.T1, L, dx);
+    {
+        const int NT = (d.h0 + 15) >> 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = L.wave + FWV * u;
+            if (it >= NT) continue;
+            const int f = 16 * it + 4 * L.q;
+            if (MODE == 1) {
+                if (valid && f < d.h0)
+                    *reinterpret_cast<float4 *>(g.dEncE + ((size_t)e * B + row) * d.h0 + f) = make_float4(dx[u][0], dx[u][1], dx[u][2], dx[u][3]);
+            } else {
+                *reinterpret_cast<float4 *>(lds.T0 + L.l15 * LDT + f) = make_float4(dx[u][0], dx[u][1], dx[u][2], dx[u][3]);
+            }
+        }
+    }
+    if (MODE == 1) return;
+    lds_barrier();
+    // ---- d(mean q)/d(action) = the action columns of We^T dEnc
+    layer_small_mma<true, false>(wa, nullptr, d.h0, d.A, lds.T0, lds.part, lds.Yl, L);
+    if (L.tid < TS * 16) {
+        const int s = L.tid >> 4, a = L.tid & 15;
+        if (a < d.A && row0 + s < B) g.dAct[((size_t)e * B + row0 + s) * d.A + a] = lds.Yl[s * 16 + a];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// actor backward: head (tanh, reparameterisation, the log-prob-at-the-mean quirk) -> dZ2 -> dZ1; also finishes the two logged
+// objectives from the partial sums of the passes before it (workgroup 0, fixed order)
+// ---------------------------------------------------------------------------------------------------------
+struct ActorBwdArgs {
+    const float *P;
+    FusedDims d;
+    const float *Y, *act_t, *eps, *dAct, *alpha_log, *G0, *G1, *lp_cur;
+    float *dY, *dZ2, *dZ1;                   // (B, 2A), (B, h1), (B, h0)
+    const float *tdpart, *qpart;
+    int ntiles;
+    float *objs_out;
+};
+
+template <int C0, int C1>
+__global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
+{
+    __shared__ TileLds lds;
+    const LaneId L = lane_id();
+    const FusedDims &d = g.d;
+    const int A = d.A, E = d.E;
+    const int64_t B = d.B, row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
+    const bool valid = row < B;
+    if (blockIdx.x == 0) {                                         // the logged objectives (AgentSAC.py:86)
+        float sl = 0.f;
+        for (int64_t i = L.tid; i < B; i += FT) sl += g.lp_cur[i];
+        const float tl = block_sum(sl, lds.red);
+        if (L.tid == 0) {
+            float std_ = 0.f, sq = 0.f;
+            for (int t = 0; t < g.ntiles; ++t) std_ += g.tdpart[t];
+            for (int k = 0; k < E * g.ntiles; ++k) sq += g.qpart[k];
+            g.objs_out[0] = std_ / (float)B;
+            g.objs_out[1] = sq / ((float)E * (float)B) - expf(g.alpha_log[0]) * (tl / (float)B);
+        }
+    }
+    BwdW<1, WClass<C1>::NU> wbh;
+    BwdW<WClass<C1>::KT, WClass<C0>::NU> wb2;
+    layer_bwd_load<1, WClass<C1>::NU>(g.P + d.aWh, 2 * A, d.h1, L, wbh);
+    clear_images(lds.T0, lds.T1, L);
+    lds_barrier();
+    if (L.tid < TS) {                                              // dL/d(head output) of sample row0 + tid (head_backward_kernel, sac.hip)
+        const int64_t b = row0 + L.tid;
+        if (b < B) {
+            const float alpha = expf(g.alpha_log[0]);
+            const float dlp = alpha / (float)B;
+            for (int a = 0; a < A; ++a) {
+                const float ls = g.Y[b * 2 * A + A + a];
+                const float lsc = fminf(fmaxf(ls, -16.f), 2.f);
+                const float sd = expf(lsc);
+                const float t = g.act_t[b * A + a];
+                const float one_m = 1.f - t * t;
+                float dA = g.dAct[b * A + a];
+                for (int k = 1; k < E; ++k) dA += g.dAct[((size_t)k * B + b) * A + a];
+                const float du = dA * one_m + dlp * (2.f * t * one_m / (one_m + 1e-6f));
+                const bool inside = ls >= -16.f && ls <= 2.f;
+                const float dls = inside ? du * sd * g.eps[b * A + a] - dlp : 0.f;
+                lds.T0[L.tid * LDT + a] = du;
+                lds.T0[L.tid * LDT + A + a] = dls;
+                g.dY[b * 2 * A + a] = du;
+                g.dY[b * 2 * A + A + a] = dls;
+            }
+        }
+    }
+    lds_barrier();
+    layer_bwd_load<WClass<C1>::KT, WClass<C0>::NU>(g.P + d.aW2, d.h1, d.h0, L, wb2);   // (lands under the head layer and its gate)
+    f32x4 dx[2];
+    layer_bwd_mma<1, WClass<C1>::NU>(wbh, 2 * A, d.h1, lds.T0, L, dx);        // dH1 = Wh^T dY
+    {
+        const int NT = (d.h1 + 15) >> 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = L.wave + FWV * u;
+            if (it >= NT) continue;
+            const int f = 16 * it + 4 * L.q;
+            float4 gate = zero4();
+            if (valid && f < d.h1) gate = *reinterpret_cast<const float4 *>(g.G1 + row * d.h1 + f);
+            const float4 v = make_float4(dx[u][0] * gate.x, dx[u][1] * gate.y, dx[u][2] * gate.z, dx[u][3] * gate.w);
+            *reinterpret_cast<float4 *>(lds.T1 + L.l15 * LDT + f) = v;
+            if (valid && f < d.h1) *reinterpret_cast<float4 *>(g.dZ2 + row * d.h1 + f) = v;
+        }
+    }
+    lds_barrier();
+    layer_bwd_mma<WClass<C1>::KT, WClass<C0>::NU>(wb2, d.h1, d.h0, lds.T1, L, dx);   // dH0 = W2^T dZ2
+    {
+        const int NT = (d.h0 + 15) >> 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = L.wave + FWV * u;
+            if (it >= NT) continue;
+            const int f = 16 * it + 4 * L.q;
+            if (valid && f < d.h0) {
+                const float4 gate = *reinterpret_cast<const float4 *>(g.G0 + row * d.h0 + f);
+                *reinterpret_cast<float4 *>(g.dZ1 + row * d.h0 + f) =
+                    make_float4(dx[u][0] * gate.x, dx[u][1] * gate.y, dx[u][2] * gate.z, dx[u][3] * gate.w);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// all weight / bias gradients of a network in one launch: a table of contractions over the batch
+//     dW[m][n] = sum_b (sum_k dZ_k[b][m]) X[b][n],   db[m] = sum_b (sum_k dZ_k[b][m])
+// One workgroup (4 waves) per 32 x 32 tile of one dW: the waves split the batch rows, each contracts its quarter on
+// v_mfma_f32_32x32x2_f32 with both operands straight from memory (16 row pairs in flight), the four partial tiles meet in LDS and
+// are added in wave order.  The bias gradient rides the A operand of the tile column 0.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DW_MAXP = 12;
+struct DwProb {
+    const float *dZ; int64_t sZ; int nZ; int M;     // (B, M) row-major, nZ matrices sZ floats apart summed in order
+    const float *X; int N;                          // (B, N) row-major
+    float *dW, *db;                                 // [M][N], [M]
+    int tiles_n, tile0, ntiles;
+};
+struct DwArgs {
+    DwProb p[DW_MAXP];
+    int np;
+    int64_t B;
+};
+
+__global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
+{
+    __shared__ float red[4][32 * 33];
+    __shared__ float bsum[4][32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    int pi = 0;
+    for (int k = 1; k < g.np; ++k)
+        if ((int)blockIdx.x >= g.p[k].tile0) pi = k;
+    const DwProb &p = g.p[pi];
+    const int t = blockIdx.x - p.tile0, tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m = 32 * tm + l31, n = 32 * tn + l31;
+    const bool mok = m < p.M, nok = n < p.N;
+    const int64_t B = g.B;
+    const int64_t per = ((B + 7) / 8) * 2;                          // rows per wave (even)
+    const int64_t b0 = per * wave, b1 = min(B, b0 + per);
+    f32x16 acc = {0};
+    float bs = 0.f;
+    constexpr int U = 16;
+    const int mc = min(m, p.M - 1), nc = min(n, p.N - 1);
+    const int64_t rmax = B - 1;
+    for (int64_t b = b0; b < b1; b += 2 * U) {       // (uniform trip count; loads clamped + selected: 32 in flight per lane)
+        float a[U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t rc = min(b + 2 * u + hi, rmax);
+            a[u] = p.dZ[rc * p.M + mc];
+            x[u] = p.X[rc * p.N + nc];
+        }
+        for (int k = 1; k < p.nZ; ++k) {             // A = the sum of nZ matrices, added in order (the encoder gradient: sum over decoders)
+            float t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = p.dZ[(size_t)k * p.sZ + min(b + 2 * u + hi, rmax) * p.M + mc];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] += t[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);           // (all loads issued; masks afterwards: see ldw4_raw)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool rok = b + 2 * u + hi < b1;
+            a[u] *= (rok && mok) ? 1.f : 0.f;
+            x[u] *= (rok && nok) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = mfma32(a[u], x[u], acc);
+            bs += a[u];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][crow(r, hi) * 33 + l31] = acc[r];
+    bs += __shfl_xor(bs, 32, 64);
+    if (hi == 0) bsum[wave][l31] = bs;
+    lds_barrier();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        const float s = ((red[0][i * 33 + j] + red[1][i * 33 + j]) + red[2][i * 33 + j]) + red[3][i * 33 + j];
+        if (32 * tm + i < p.M && 32 * tn + j < p.N) p.dW[(size_t)(32 * tm + i) * p.N + 32 * tn + j] = s;
+    }
+    if (tn == 0 && tid < 32 && 32 * tm + tid < p.M && p.db)
+        p.db[32 * tm + tid] = ((bsum[0][tid] + bsum[1][tid]) + bsum[2][tid]) + bsum[3][tid];
+}
+
+int dw_add(DwArgs &a, const float *dZ, int64_t sZ, int nZ, int M, const float *X, int N, float *dW, float *db)
+{
+    DwProb &p = a.p[a.np];
+    p.dZ = dZ; p.sZ = sZ; p.nZ = nZ; p.M = M; p.X = X; p.N = N; p.dW = dW; p.db = db;
+    p.tiles_n = (N + 31) / 32;
+    p.ntiles = ((M + 31) / 32) * p.tiles_n;
+    p.tile0 = a.np ? a.p[a.np - 1].tile0 + a.p[a.np - 1].ntiles : 0;
+    return ++a.np;
+}
+
+int dw_launch(const DwArgs &a, hipStream_t s)
+{
+    const DwProb &last = a.p[a.np - 1];
+    hipLaunchKernelGGL(dw_table_kernel, dim3(last.tile0 + last.ntiles), dim3(256), 0, s, a);
+    return erl_hip_status(hipGetLastError(), "erl_sac_update_f32(fused: dw_table)");
+}
+
+__global__ __launch_bounds__(256) void alpha_step_fused_kernel(const float *__restrict__ lp, int64_t n, float target_entropy, float *__restrict__ alpha_log,
+                                                               float *__restrict__ m1, float *__restrict__ m2, float beta1, float beta2, float eps,
+                                                               float max_norm, float step_size, float bc2_sqrt)
+{
+    // obj_alpha = mean(alpha_log * (target_entropy - logprob)): g = target_entropy - mean(logprob); clip + Adam on one element
+    // (the arithmetic of alpha_step_kernel, sac.hip)
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += lp[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x != 0) return;
+    const float gr = t * (-1.0f / (float)n) + target_entropy;
+    const float total_norm = (float)sqrt((double)gr * (double)gr);
+    float coef = max_norm / (total_norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    const float gx = gr * (1.0f * coef);
+    const float a = m1[0] * beta1 + (1.f - beta1) * gx;
+    const float b = m2[0] * beta2 + (1.f - beta2) * (gx * gx);
+    m1[0] = a;
+    m2[0] = b;
+    const float denom = sqrtf(b) / bc2_sqrt + eps;
+    alpha_log[0] = alpha_log[0] - step_size * (a / denom);
+}
+
+__global__ void clamp_alpha_fused_kernel(float *alpha_log)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) alpha_log[0] = fminf(fmaxf(alpha_log[0], -16.f), 2.f);   // after alpha was read (:80-81)
+}
+
+int wclass(int width) { return width <= 64 ? 0 : (width <= 128 ? 1 : 2); }
+
+}  // namespace
+
+// ---- shape class of the fused step ---------------------------------------------------------------------------
+#ifdef ERL_PROFILE
+extern "C" __attribute__((visibility("default"))) int erl_debug_sac_fused_profile(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fprof), sizeof(long long) * (n < 256 ? n : 256));
+}
+#endif
+
+bool erl_sac_fused_supported(int S, int A, const int *hidden, int n_hidden, int E, int64_t B)
+{
+    if (n_hidden != 2 || !hidden) return false;
+    const int h0 = hidden[0], h1 = hidden[1];
+    return S >= 1 && S <= 64 && A >= 1 && A <= 8 && S + A <= 64 && h0 >= 16 && h0 <= FMAXW && h0 % 16 == 0 && h1 >= 16 && h1 <= FMAXW &&
+           h1 % 16 == 0 && E >= 1 && E <= FMAXE && B >= 1 && B <= 4096;
+}
+
+int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, int64_t Pa, int64_t Pc)
+{
+    const int64_t tiles = (B + TS - 1) / TS;
+    auto r = [](int64_t n) { return (n + 63) / 64 * 64; };
+    int64_t f = 0;
+    f += 2 * r(B * A) + 2 * r(B);                                       // a_next / act_t, eps | lp_next, lp_cur
+    f += 3 * r((int64_t)E * B) + r(B);                                  // qt, qc (also q_pg), dq | label
+    f += r(B * (S + A)) + r(B * h0);                                    // xa, enc
+    f += 2 * r((int64_t)E * B * h1) + r((int64_t)E * B * h0);           // H1e, dZ1e | dEncE
+    f += r(B * 2 * A) * 2 + 2 * r(B * h0) + 2 * r(B * h1);              // Y, dY | H0, G0 | H1, G1
+    f += r((int64_t)E * B * A) + r(B * h1) + r(B * h0);                 // dAct | dZ2, dZ1 (actor)
+    f += r(Pa) + r(Pc) + r((int64_t)E * tiles) + r(tiles) + 64;        // gradients, partial sums, alpha0
+    return f;
+}
+
+#define FUSED_KT_DISPATCH(KERNEL_MACRO)                                                                          \
+    switch (wclass(d.h0) * 3 + wclass(d.h1)) {                                                                  \
+        case 0: KERNEL_MACRO(0, 0); break; case 1: KERNEL_MACRO(0, 1); break; case 2: KERNEL_MACRO(0, 2); break; \
+        case 3: KERNEL_MACRO(1, 0); break; case 4: KERNEL_MACRO(1, 1); break; case 5: KERNEL_MACRO(1, 2); break; \
+        case 6: KERNEL_MACRO(2, 0); break; case 7: KERNEL_MACRO(2, 1); break; default: KERNEL_MACRO(2, 2); break; \
+    }
+
+// The whole step.  Pointers / scalars as erl_sac_update_f32 (sac.hip), which validates them and dispatches here.
+int erl_sac_update_fused(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m, float *actor_v,
+                         float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A, int h0, int h1, int E,
+                         const int64_t *aoff, const int64_t *coff, int64_t Pa, int64_t Pc, const float *state, const float *action,
+                         const float *reward, const float *undone, const float *unmask, const float *next_state, const float *is_weight,
+                         float *td_error_out, int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
+                         float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                         int32_t step, float *objs_out, float *workspace, hipStream_t s)
+{
+    FusedDims d{};
+    d.S = S; d.A = A; d.E = E; d.h0 = h0; d.h1 = h1; d.B = B;
+    d.aW1 = aoff[0]; d.ab1 = aoff[1]; d.aW2 = aoff[2]; d.ab2 = aoff[3]; d.aWh = aoff[4]; d.abh = aoff[5];
+    d.cWe = coff[0]; d.cbe = coff[1]; d.cdec0 = coff[2]; d.dW1 = coff[3]; d.db1 = coff[4]; d.dWo = coff[5]; d.dbo = coff[6]; d.dec = coff[7];
+    const int tiles = (int)((B + TS - 1) / TS);
+    auto r = [](int64_t n) { return (n + 63) / 64 * 64; };
+    float *w = workspace;
+    auto take = [&](int64_t n) { float *p = w; w += r(n); return p; };
+    float *a_next = take(B * A), *eps_used = take(B * A), *lp_next = take(B), *lp_cur = take(B);
+    float *qt = take((int64_t)E * B), *qc = take((int64_t)E * B), *dq = take((int64_t)E * B), *label = take(B);
+    float *xa = take(B * (S + A)), *enc = take(B * h0);
+    float *H1e = take((int64_t)E * B * h1), *dZ1e = take((int64_t)E * B * h1), *dEncE = take((int64_t)E * B * h0);
+    float *Y = take(B * 2 * A), *dY = take(B * 2 * A), *H0 = take(B * h0), *G0 = take(B * h0), *H1 = take(B * h1), *G1 = take(B * h1);
+    float *dAct = take((int64_t)E * B * A), *dZ2 = take(B * h1), *dZ1 = take(B * h0);
+    float *g_actor = take(Pa), *g_critic = take(Pc), *qpart = take((int64_t)E * tiles), *tdpart = take(tiles), *alpha0 = take(64);
+    float *act_pg = a_next, *q_pg = qt;                 // reused once their first contents are consumed
+    const dim3 tgrid(tiles), cgrid(tiles, E), blk(FT);
+    int rc;
+
+    // ---- (1) next action / log-prob (actor on next_state)                                                      (:50-51)
+    ActorFwdArgs af{};
+    af.P = actor_params; af.d = d; af.X = next_state; af.noise = eps_next; af.seed = seed; af.counter = 2 * counter;
+    af.act_t = a_next; af.lp = lp_next; af.alpha_log = alpha_log; af.alpha0 = alpha0;
+#define LAUNCH_ACTOR_FWD(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, s, af)
+    FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
+    // ---- (2) target ensemble on (next_state, next_action)                                                     (:52)
+    CriticArgs ca{};
+    ca.P = target_params; ca.d = d; ca.Xs = next_state; ca.Xa = a_next; ca.q = qt;
+#define LAUNCH_CRITIC(MODE, K0, K1) hipLaunchKernelGGL((critic_tile_kernel<MODE, K0, K1>), cgrid, blk, 0, s, ca)
+#define LAUNCH_CRITIC0(K0, K1) LAUNCH_CRITIC(0, K0, K1)
+#define LAUNCH_CRITIC1(K0, K1) LAUNCH_CRITIC(1, K0, K1)
+#define LAUNCH_CRITIC2(K0, K1) LAUNCH_CRITIC(2, K0, K1)
+    FUSED_KT_DISPATCH(LAUNCH_CRITIC0)
+    // ---- (3) critic training pass: labels, loss gradient, backward to the encoder output                      (:53-62)
+    ca.P = critic_params; ca.Xs = state; ca.Xa = action; ca.q = qc;
+    ca.qt = qt; ca.reward = reward; ca.undone = undone; ca.unmask = unmask; ca.lp_next = lp_next; ca.is_weight = is_weight; ca.alpha0 = alpha0;
+    ca.gamma = gamma; ca.label = label; ca.dq = dq; ca.xa = xa; ca.enc = enc; ca.H1e = H1e; ca.dZ1e = dZ1e; ca.dEncE = dEncE;
+    FUSED_KT_DISPATCH(LAUNCH_CRITIC1)
+    // ---- (4) every critic weight / bias gradient in one launch
+    {
+        DwArgs dw{};
+        dw.B = B;
+        dw_add(dw, dEncE, B * h0, E, h0, xa, S + A, g_critic + d.cWe, g_critic + d.cbe);                 // encoder: dEnc = sum_e
+        for (int e = 0; e < E; ++e) {
+            float *G = g_critic + d.cdec0 + (int64_t)e * d.dec;
+            dw_add(dw, dZ1e + (size_t)e * B * h1, 0, 1, h1, enc, h0, G + d.dW1, G + d.db1);
+            dw_add(dw, dq + (size_t)e * B, 0, 1, 1, H1e + (size_t)e * B * h1, h1, G + d.dWo, G + d.dbo);
+        }
+        if ((rc = dw_launch(dw, s))) return rc;
+    }
+    // ---- (5) clip + Adam on the critic, soft target update in the same launch                                  (:69-70)
+    {
+        const int64_t off = 0, len = Pc;
+        if ((rc = erl_clip_adam_soft_f32(critic_params, g_critic, critic_m, critic_v, &off, &len, 1, step, lr, beta1, beta2, eps_adam, max_norm,
+                                         1.0f, target_params, tau, s)))
+            return rc;
+    }
+    // ---- (6) policy-gradient sample (actor on state, kept for the backward pass), temperature step             (:72-79)
+    af.X = state; af.noise = eps_cur; af.counter = 2 * counter + 1; af.act_t = act_pg; af.lp = lp_cur; af.eps_out = eps_used; af.Y = Y;
+    af.H0 = H0; af.G0 = G0; af.H1 = H1; af.G1 = G1; af.alpha0 = nullptr;
+    FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
+    {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        hipLaunchKernelGGL(alpha_step_fused_kernel, dim3(1), dim3(256), 0, s, lp_cur, B, target_entropy, alpha_log, alpha_m, alpha_v, beta1, beta2,
+                           eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
+    }
+    // ---- (7) TARGET ensemble on (state, action_pg): q and d(mean q)/d(action); finishes the critic objective    (:82-83)
+    ca.P = target_params; ca.Xs = state; ca.Xa = act_pg; ca.q = q_pg;
+    ca.dAct = dAct; ca.qpart = qpart; ca.qc = qc; ca.label_in = label; ca.td_out = td_error_out; ca.tdpart = tdpart;
+    FUSED_KT_DISPATCH(LAUNCH_CRITIC2)
+    // ---- (8) actor backward, (9) its weight gradients, (10) clip + Adam, alpha clamp                            (:80-85)
+    {
+        ActorBwdArgs ab{};
+        ab.P = actor_params; ab.d = d; ab.Y = Y; ab.act_t = act_pg; ab.eps = eps_used; ab.dAct = dAct; ab.alpha_log = alpha_log; ab.G0 = G0;
+        ab.G1 = G1; ab.lp_cur = lp_cur; ab.dY = dY; ab.dZ2 = dZ2; ab.dZ1 = dZ1; ab.tdpart = tdpart; ab.qpart = qpart; ab.ntiles = tiles;
+        ab.objs_out = objs_out;
+#define LAUNCH_ACTOR_BWD(K0, K1) hipLaunchKernelGGL((actor_bwd_kernel<K0, K1>), tgrid, blk, 0, s, ab)
+        FUSED_KT_DISPATCH(LAUNCH_ACTOR_BWD)
+        DwArgs dw{};
+        dw.B = B;
+        dw_add(dw, dZ1, 0, 1, h0, state, S, g_actor + d.aW1, g_actor + d.ab1);
+        dw_add(dw, dZ2, 0, 1, h1, H0, h0, g_actor + d.aW2, g_actor + d.ab2);
+        dw_add(dw, dY, 0, 1, 2 * A, H1, h1, g_actor + d.aWh, g_actor + d.abh);
+        if ((rc = dw_launch(dw, s))) return rc;
+        hipLaunchKernelGGL(clamp_alpha_fused_kernel, dim3(1), dim3(64), 0, s, alpha_log);
+        const int64_t off = 0, len = Pa;
+        if ((rc = erl_clip_adam_soft_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, step, lr, beta1, beta2, eps_adam, max_norm, 1.0f,
+                                         nullptr, 0.f, s)))
+            return rc;
+    }
+    return erl_hip_status(hipGetLastError(), "erl_sac_update_f32(fused)");
+}
