@@ -153,11 +153,11 @@ __device__ __forceinline__ void gelu_tile(const f32x16 &acc, f32x16 &H, f32x16 &
 // MFMAs; the accumulator starts from the bias (read a tile ahead); the GELU epilogue of tile To sits after the first
 // group of tile To + 1, when its accumulator has long been written back.
 // ---------------------------------------------------------------------------------------------------------
-template <int KT, int NO>
+template <int KT, int NO, int NG = 4 * KT>      // NG: reduction groups of 8 (default: the whole KT tiles; 1 for S <= 8)
 __device__ __forceinline__ void fwd32(const float *W, int ldw, const float *bias, const f32x16 (&in)[KT], f32x16 (&outH)[NO],
                                       f32x16 (&outG)[NO], int m, int hi)
 {
-    constexpr int NG = 4 * KT, NC = NO * NG;
+    constexpr int NC = NO * NG;
     const float *wbase = W + m * ldw + 4 * hi;
     float4 wq[2];
     auto issue = [&](int c, float4 &dst) {
@@ -334,6 +334,59 @@ __device__ __forceinline__ void weight_grad_w4(const float *TA, const float *TB,
     if (hi == 0 && jc == 0) db[32 * it + l31] = s;
 }
 
+// dW1 and db1 for S <= 8 inputs (the Pendulum demo's S = 3) on the vector ALUs: a 32-column MFMA tile would be at least 3/4
+// padding (64 MFMAs = 4.1k cycles per wave for 24 real columns' worth at S = 3).  Lane (l31 = feature of the wave's row tile, hi =
+// sample half) reduces its 64 samples of dZ1^T[f][:] against X^T[k][:] (broadcast 16-byte reads), the halves meet by one shuffle.
+template <int NR, int KM>      // KM = 4 (S <= 4) or 8: columns reduced unconditionally -- rows k >= S of X^T are zero; no branch in the loop
+__device__ __forceinline__ void weight_grad_tiny_k(const float *TA, const float *TX, float *__restrict__ dW, int S, float *__restrict__ db,
+                                                   int wave, int lane)
+{
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int it = wave % NR;
+    const float *a = TA + (32 * it + l31) * PLD + 64 * hi;
+    const float *x = TX + 64 * hi;
+    f32x2 acc[KM][2];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) acc[k][0] = acc[k][1] = f32x2{0.f, 0.f};
+    f32x2 bs = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 dz = *reinterpret_cast<const float4 *>(a + 4 * j);
+        bs += f32x2{dz.x, dz.y};
+        bs += f32x2{dz.z, dz.w};
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + k * PLD + 4 * j);      // same address in every lane of a half: broadcast
+            acc[k][0] += f32x2{dz.x, dz.y} * f32x2{xv.x, xv.y};
+            acc[k][1] += f32x2{dz.z, dz.w} * f32x2{xv.z, xv.w};
+        }
+    }
+    float s = bs.x + bs.y;
+    s += __shfl_xor(s, 32, 64);
+    float r[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        r[k] = (acc[k][0].x + acc[k][0].y) + (acc[k][1].x + acc[k][1].y);
+        r[k] += __shfl_xor(r[k], 32, 64);
+    }
+    if (hi == 0) {
+        const int f = 32 * it + l31;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < S) __builtin_nontemporal_store(r[k], dW + (size_t)f * S + k);
+        db[f] = s;
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void weight_grad_tiny(const float *TA, const float *TX, float *__restrict__ dW, int S, float *__restrict__ db,
+                                                 int wave, int lane)
+{
+    if (wave / NR > 0) return;                                // (wave-uniform) NR < 4: one wave per row tile is enough here
+    if (S <= 4) weight_grad_tiny_k<NR, 4>(TA, TX, dW, S, db, wave, lane);
+    else weight_grad_tiny_k<NR, 8>(TA, TX, dW, S, db, wave, lane);
+}
+
 // copy_load for a matrix that fills its padded tile exactly (rows x COLS, COLS % 4 == 0, 16-byte aligned): no clamps, no
 // selects -- one address and immediate offsets (the generic copy_load spends ~14 VALU instructions per 16-byte load)
 template <int MAXV, int COLS>
@@ -364,9 +417,11 @@ __device__ __forceinline__ void dma_copy128(const float *__restrict__ src, int r
     }
 }
 
-template <bool ACTOR, int KX, int N1, int N2, bool VEC>
+template <bool ACTOR, int KXP, int N1, int N2, bool VEC>     // KXP: input tiles of 32 (1: S <= 32, 2: S <= 64); 0: S <= 8
 __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
 {
+    constexpr bool TINY = KXP == 0;
+    constexpr int KX = TINY ? 1 : KXP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hi = lane >> 5;
     constexpr int net = ACTOR ? 0 : 1;
@@ -496,7 +551,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     if constexpr (DMA3) dma_copy128<16>(P + d.oW3(), OUT, RW3, wave, lane);
     else copy_load<VEC, 2, QNT>(c3, P + d.oW3(), OUT, h2, 16, h2, tid);
     f32x16 H1[N1], G1[N1], H2[N2], G2[N2];
-    fwd32<KX, N1>(RB, ld1, s_b1, X, H1, G1, m, hi);
+    fwd32<KX, N1, TINY ? 1 : 4 * KX>(RB, ld1, s_b1, X, H1, G1, m, hi);       // S <= 8: one reduction group (k = 0..7)
     PROF_NV(3);
     if constexpr (!DMA2) copy_store<N1 * N2, QNT>(c2, RA, ld2, h2, h1, tid);
     if constexpr (!DMA3) copy_store<2, QNT>(c3, RW3, ld3, 16, h2, tid);
@@ -646,7 +701,8 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     }
     lds_barrier();                                                   // (2)
     PROF(9);
-    weight_grad_w4<N1, KX>(RA, RX, slab + d.oW1(), S, S, slab + d.ob1(), wave, lane);   // dW1 and db1
+    if constexpr (TINY) weight_grad_tiny<N1>(RA, RX, slab + d.oW1(), S, slab + d.ob1(), wave, lane);
+    else weight_grad_w4<N1, KX>(RA, RX, slab + d.oW1(), S, S, slab + d.ob1(), wave, lane);   // dW1 and db1
     PROF(10);
     lds_barrier();                                                   // (3) dZ1^T, X^T consumed
 
@@ -742,10 +798,11 @@ int launch_w4(const Ppo2Args &g, int n_slabs, hipStream_t stream)
     return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");
 }
 
-// the four instantiations of one (h1, h2) pair: S <= 32 / S <= 64, 16-byte-aligned inputs with S % 4 == 0 (vec) or not
+// the five instantiations of one (h1, h2) pair: S <= 8 | S <= 32 / S <= 64, 16-byte-aligned inputs with S % 4 == 0 (vec) or not
 template <int N1, int N2>
 int launch_w4_shape(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream)
 {
+    if (g.S <= 8) return launch_w4<0, N1, N2, false>(g, n_slabs, stream);        // (element-wise loaders: at most 8 floats per row)
     if (vec) return g.S > 32 ? launch_w4<2, N1, N2, true>(g, n_slabs, stream) : launch_w4<1, N1, N2, true>(g, n_slabs, stream);
     return g.S > 32 ? launch_w4<2, N1, N2, false>(g, n_slabs, stream) : launch_w4<1, N1, N2, false>(g, n_slabs, stream);
 }
