@@ -98,6 +98,40 @@ __device__ __forceinline__ T block_sum(T v, T *scratch)
 }
 
 // ---------------------------------------------------------------------------------------------
+// device: ONE Adam update for every optimiser kernel of the library (clip_adam_kernel, the fused tails, the long-group and the
+// partial-norm kernels): every product and sum rounded separately and spelled out, so that no kernel's code generation (fma
+// contraction differs with the surrounding code) can make two routes through the library disagree -- m1 * beta1 and
+// (1 - beta1) * g cancel almost completely when the gradient changes sign and scale, which turns a contraction difference
+// into a visible one.  torch.optim.Adam defaults: exp_avg.lerp_(g, 1 - b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2);
+// denom = sqrt(v) / sqrt(bc2) + eps; p -= (lr / bc1) * m / denom.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void erl_adam_update(float gx, float &m1, float &m2, float &p, float beta1, float beta2, float eps, float step_size,
+                                                float bc2_sqrt)
+{
+#pragma clang fp contract(off)      // (HIP's __fmul_rn / __fadd_rn are plain operators: they do NOT stop the contraction)
+    const float a = m1 * beta1 + (1.f - beta1) * gx;
+    const float b = m2 * beta2 + (1.f - beta2) * (gx * gx);
+    const float denom = sqrtf(b) / bc2_sqrt + eps;
+    m1 = a;
+    m2 = b;
+    p = p - step_size * (a / denom);
+}
+
+// AgentBase.soft_update (elegantrl/agents/AgentBase.py:270-278): tar = cur * tau + tar * (1 - tau), products rounded separately
+__device__ __forceinline__ float erl_soft_update(float cur, float tar, float tau)
+{
+#pragma clang fp contract(off)
+    return cur * tau + tar * (1.0f - tau);
+}
+
+// x * y rounded on its own (never folded into a following add)
+__device__ __forceinline__ float erl_mul_rn(float x, float y)
+{
+#pragma clang fp contract(off)
+    return x * y;
+}
+
+// ---------------------------------------------------------------------------------------------
 // device: Philox4x32-10 counter RNG + Box-Muller (production noise for K1 and env resets)
 // ---------------------------------------------------------------------------------------------
 struct Philox4 {

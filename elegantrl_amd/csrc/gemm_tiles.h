@@ -107,13 +107,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
 {
     __shared__ float As[2][GK * GLD], Bs[2][GK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2: the nx column
+    // tiles of one row tile all read the same 64 rows of A (the activations: the big operand), so they should share an L2 and run
+    // at the same time.  Linear id L -> xcd = L % 8, slot = L / 8; row tile = (slot / nx) * 8 + xcd, column tile = slot % nx: the nx
+    // tiles of a row tile are nx consecutive slots of ONE XCD.  (Rows beyond the last full group of 8 keep the plain order.)
+    int ty = blockIdx.y, tx = blockIdx.x;
+    {
+        const int nx = gridDim.x, ny = gridDim.y, lin = blockIdx.y * nx + blockIdx.x, full = (ny / 8) * 8 * nx;
+        if (lin < full) {
+            const int xcd = lin & 7, slot = lin >> 3;
+            ty = (slot / nx) * 8 + xcd;
+            tx = slot - (slot / nx) * nx;
+        }
+    }
+    const int i0 = ty * GT, j0 = tx * GT;
     int kb = 0, ke = g.K;
     if (EPI == EPI_PARTIAL) {
         kb = blockIdx.z * g.kchunk;
         ke = min(g.K, kb + g.kchunk);
     }
-    const bool want_rs = EPI == EPI_PARTIAL && g.rowsum != nullptr && blockIdx.x == 0;
+    const bool want_rs = EPI == EPI_PARTIAL && g.rowsum != nullptr && tx == 0;
     const int nch = (ke - kb + GK - 1) / GK;
     float ra[2][8], rb[2][8], rsum = 0.f;
     f32x16 acc = {0};

@@ -151,13 +151,10 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
     float coef = max_norm / (total_norm + 1e-6f);      // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
     coef = coef > 1.f ? 1.f : coef;
     if (own) {
-        const float gx = e_g * (grad_scale * coef);
-        const float a = e_m1 * beta1 + (1.f - beta1) * gx;          // exp_avg.lerp_(grad, 1 - beta1)
-        const float b = e_m2 * beta2 + (1.f - beta2) * (gx * gx);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-        m1[off + ie] = a;
-        m2[off + ie] = b;
-        const float denom = sqrtf(b) / bc2_sqrt + eps;
-        params[off + ie] = e_p - step_size * (a / denom);
+        erl_adam_update(erl_mul_rn(e_g, erl_mul_rn(grad_scale, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);
+        m1[off + ie] = e_m1;
+        m2[off + ie] = e_m2;
+        params[off + ie] = e_p;
     }
 }
 

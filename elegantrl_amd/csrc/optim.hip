@@ -65,16 +65,12 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float *__restrict__ par
     }
 
     auto adam = [&](int64_t i, float graw, float m1v, float m2v, float pv) {
-        const float gx = graw * gmul;
-        const float a = m1v * beta1 + (1.f - beta1) * gx;          // exp_avg.lerp_(grad, 1 - beta1)
-        const float b = m2v * beta2 + (1.f - beta2) * (gx * gx);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-        m1[off + i] = a;
-        m2[off + i] = b;
-        const float denom = sqrtf(b) / bc2_sqrt + eps;
-        const float pn = pv - step_size * (a / denom);
-        params[off + i] = pn;
+        erl_adam_update(erl_mul_rn(graw, gmul), m1v, m2v, pv, beta1, beta2, eps, step_size, bc2_sqrt);
+        m1[off + i] = m1v;
+        m2[off + i] = m2v;
+        params[off + i] = pv;
         // soft target update in the same launch (AgentBase.soft_update :270-278: tar = cur * tau + tar * (1 - tau))
-        if (soft) soft[off + i] = __fadd_rn(__fmul_rn(pn, tau), __fmul_rn(soft[off + i], 1.0f - tau));
+        if (soft) soft[off + i] = erl_soft_update(pv, soft[off + i], tau);
     };
     if (per <= 1024) {
         if (own) adam(ie, e_g, e_m1, e_m2, e_p);
@@ -194,13 +190,10 @@ __global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__r
             if (gi == my_group) mul = grad_scale * coef;
         }
         if (my_group >= 0) {
-            const float gx = gsum * mul;
-            const float a = e_m1 * beta1 + (1.f - beta1) * gx;
-            const float b = e_m2 * beta2 + (1.f - beta2) * (gx * gx);
-            m1[i] = a;
-            m2[i] = b;
-            const float denom = sqrtf(b) / bc2_sqrt + eps;
-            params[i] = e_p - step_size * (a / denom);
+            erl_adam_update(erl_mul_rn(gsum, mul), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);
+            m1[i] = e_m1;
+            m2[i] = e_m2;
+            params[i] = e_p;
         }
         return;
     }
@@ -240,13 +233,11 @@ __global__ __launch_bounds__(RA_T) void reduce_clip_adam_kernel(const float *__r
             for (int u = 0; u < U; ++u) {
                 const int64_t e = i0 + (int64_t)u * RA_T;
                 if (e < len) {
-                    const float gx = xg[u] * gmul[gi];
-                    const float a = xm1[u] * beta1 + (1.f - beta1) * gx;
-                    const float b = xm2[u] * beta2 + (1.f - beta2) * (gx * gx);
+                    float a = xm1[u], b = xm2[u], pv = xp[u];
+                    erl_adam_update(erl_mul_rn(xg[u], gmul[gi]), a, b, pv, beta1, beta2, eps, step_size, bc2_sqrt);
                     m1[off + e] = a;
                     m2[off + e] = b;
-                    const float denom = sqrtf(b) / bc2_sqrt + eps;
-                    params[off + e] = xp[u] - step_size * (a / denom);
+                    params[off + e] = pv;
                 }
             }
         }
@@ -301,15 +292,11 @@ __global__ __launch_bounds__(1024) void clip_adam_grid_kernel(float *__restrict_
     float coef = max_norm / (total_norm + 1e-6f);   // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
     coef = coef > 1.f ? 1.f : coef;
     if (own) {
-        const float gx = e_g * (grad_scale * coef);
-        const float a = e_m1 * beta1 + (1.f - beta1) * gx;
-        const float b = e_m2 * beta2 + (1.f - beta2) * (gx * gx);
-        m1[off + ie] = a;
-        m2[off + ie] = b;
-        const float denom = sqrtf(b) / bc2_sqrt + eps;
-        const float pn = e_p - step_size * (a / denom);
-        params[off + ie] = pn;
-        if (soft) soft[off + ie] = __fadd_rn(__fmul_rn(pn, tau), __fmul_rn(soft[off + ie], 1.0f - tau));
+        erl_adam_update(erl_mul_rn(e_g, erl_mul_rn(grad_scale, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);
+        m1[off + ie] = e_m1;
+        m2[off + ie] = e_m2;
+        params[off + ie] = e_p;
+        if (soft) soft[off + ie] = erl_soft_update(e_p, soft[off + ie], tau);
     }
 }
 

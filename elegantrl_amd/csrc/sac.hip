@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void actor_obj_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void soft_update_kernel(float *__restrict__ tar, const float *__restrict__ cur, float tau, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        tar[i] = __fadd_rn(__fmul_rn(cur[i], tau), __fmul_rn(tar[i], 1.0f - tau));   // cur * tau + tar * (1 - tau)
+        tar[i] = erl_soft_update(cur[i], tar[i], tau);
 }
 
 __global__ void clamp_alpha_kernel(float *alpha_log)
