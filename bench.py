@@ -405,7 +405,7 @@ def main():
         us = parallel.all_reduce_max_float(e0.elapsed_time(e1) * 5.0, device=dev)      # ms / 200 calls -> us per call
         rep = parallel.route_report()      # what the start-up self-test measured and chose (both library routes)
         allreduce = {"selected": rep.get("selected"), "mode": rep.get("mode"), "rccl_us": rep.get("rccl_us"), "p2p_us": rep.get("p2p_us"),
-                     "rccl_selftest": rep.get("rccl_selftest"), "p2p_selftest": rep.get("p2p_selftest"),
+                     "rccl_selftest": rep.get("rccl_selftest"), "p2p_selftest": rep.get("p2p_selftest"), "p2p_probe": rep.get("p2p_probe"),
                      "ranks_seen_by_rccl": rep.get("ranks_seen_by_rccl"), "bytes": int(buf.numel() * 4),
                      "selected_us_per_call_after_run": round(us, 2), "calls_per_step": UPDATE_TIMES,
                      "stats_exchange": "same route (fp64, 8 sums per iteration)" if comm is not None else "torch.distributed"}

@@ -247,6 +247,41 @@ def selftest(comm: RcclComm, count: int, rounds: int = 8, timed_calls: int = 100
     return {"ok": ok, "us": None if us is None else round(us, 2), "why": why}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def probe_p2p_out_of_process(count: int, timeout_s: float = 180.0) -> str:
+    """First contact with the peer-to-peer route in a throw-away child process per rank (elegantrl_amd/p2p_probe.py): a route
+    whose peer mapping faults on this machine kills the CHILD, never the run.  Collective over the default process group.
+    Returns "ok" or the reason the route is not to be used (agreed by all ranks)."""
+    import subprocess
+    import sys
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [_free_port() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(box[0]), LOCAL_RANK=str(th.cuda.current_device()), ERL_P2P_PROBE_COUNT=str(int(count)))
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("ERL_FORCE_DP", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME")]:
+        env.pop(k)                        # (under torchrun the child must host its own store on the new port, not look for the agent's)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    why = "ok"
+    try:
+        out = subprocess.run([sys.executable, "-m", "elegantrl_amd.p2p_probe"], env=env, cwd=root, capture_output=True, text=True,
+                             timeout=timeout_s)
+        if out.returncode != 0:
+            why = f"probe process exited with {out.returncode}: {(out.stderr or out.stdout)[-200:].strip()}"
+    except subprocess.TimeoutExpired:
+        why = f"probe process timed out after {timeout_s:.0f} s"
+    if not _agree(why == "ok"):
+        return why if why != "ok" else "probe failed on another rank"
+    return "ok"
+
+
 # the peer-to-peer route folds the exchange into the slab-reduction launch; RCCL needs two more launches per minibatch
 # (the collective + the partial norms): that much slower in the stand-alone timing still wins in the loop
 _P2P_LAUNCH_CREDIT_US = 8.0
@@ -268,7 +303,7 @@ def gradient_comm(count: Optional[int] = None) -> Optional[RcclComm]:
     _grad_comm_tried = True
     mode = os.environ.get("ERL_DP_COLLECTIVE", "auto")
     report = {"mode": mode, "selected": "torch.distributed", "rccl_us": None, "p2p_us": None, "rccl_selftest": "not tried",
-              "p2p_selftest": "not tried", "ranks_seen_by_rccl": None}
+              "p2p_selftest": "not tried", "p2p_probe": "not run", "ranks_seen_by_rccl": None}
     _route_report = report
     if mode == "torch" or not th.cuda.is_available() or not (is_distributed() or force_dp()):
         return None
@@ -289,6 +324,12 @@ def gradient_comm(count: Optional[int] = None) -> Optional[RcclComm]:
                 cands["rccl"] = (c, t["us"])
             else:
                 c.close()
+    if want_p2p and up and dist.get_world_size() > 1 and os.environ.get("ERL_P2P_PROBE", "1") != "0":
+        # first contact out of process: a faulting peer mapping must not take the run down with it
+        report["p2p_probe"] = probe_p2p_out_of_process(count)
+        if report["p2p_probe"] != "ok":
+            report["p2p_selftest"] = "not run: " + report["p2p_probe"]
+            want_p2p = False
     if want_p2p:
         c = P2PComm.create(max_count=max(count, P2PComm.MAX_COUNT))
         if c is None:

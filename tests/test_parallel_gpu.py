@@ -186,6 +186,7 @@ def test_two_rank_agent_in_lockstep_on_every_route(tmp_path):
         np.testing.assert_array_equal(_load(tmp_path, mode, "stats")[0], stats[0])
         np.testing.assert_array_equal(_load(tmp_path, mode, "logs")[0], logs[0])
     rep = json.load(open(tmp_path / "auto" / "route_0.json"))
+    assert rep["p2p_probe"] == "ok", rep                               # first contact happened in a throw-away child process per rank
     assert rep["p2p_selftest"] == "ok" and rep["p2p_us"] > 0 and "peer-to-peer" in rep["selected"], rep
 
 
