@@ -15,6 +15,8 @@
 // (fixed-order sum afterwards: deterministic), and the workgroups of the first column tile also emit the row sums of
 // A -- the bias gradient -- from the LDS tiles they already hold.
 #pragma once
+#include <stdlib.h>
+
 #include "mlp_chain.h"
 
 namespace {
@@ -73,42 +75,49 @@ __device__ __forceinline__ void tile_load(float (&r)[8], const float *__restrict
     }
 }
 
-template <int OP, bool VEC>
+template <int OP, bool VEC, int LD = GLD>      // LD: row stride of the reduction-major LDS tile T[k][i]
 __device__ __forceinline__ void tile_store(const float (&r)[8], float *T, int tid)
 {
     if (VEC && OP == OP_OC) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            *reinterpret_cast<float4 *>(T + ((tid >> 4) + 16 * h) * GLD + (tid & 15) * 4) = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
+            *reinterpret_cast<float4 *>(T + ((tid >> 4) + 16 * h) * LD + (tid & 15) * 4) = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
     } else if (VEC) {
         const int i = tid >> 2;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = ((tid & 3) + 4 * h) * 4;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) T[(k + c) * GLD + i] = r[4 * h + c];
+            for (int c = 0; c < 4; ++c) T[(k + c) * LD + i] = r[4 * h + c];
         }
     } else {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u;
             const int i = OP == OP_RC ? e >> 5 : e & 63, k = OP == OP_RC ? e & 31 : e >> 6;
-            T[k * GLD + i] = r[u];
+            T[k * LD + i] = r[u];
         }
     }
 }
 
 // Main loop: the reduction advances in chunks of GK = 32 through DOUBLE-BUFFERED LDS tiles -- one workgroup barrier per chunk
-// (16 MFMAs per wave between barriers; the first version had two barriers per 8 MFMAs and ran the forward layers at 20-40
-// TFLOP/s) -- with the global loads of the two following chunks in flight in registers:
+// (16 MFMAs per wave and accumulator between barriers; the first version had two barriers per 8 MFMAs and ran the forward layers at
+// 20-40 TFLOP/s) -- with the global loads of the two following chunks in flight in registers:
 //   iteration c:  regs(c + 1) -> LDS[(c + 1) & 1];  issue loads of chunk c + 3 into that register slot;  MFMAs on LDS[c & 1];  barrier.
-template <int AOP, int BOP, int EPI, bool VA, bool VB>
+// Tile shape (round 3): (64 RM) x (64 RN), RM, RN in {1, 2}; a wave owns RM x RN accumulators of 32 x 32.  With 64 x 64 tiles a
+// workgroup needs 16 KB of operands per 1024 MFMA cycles = 16 B/clk, and a CU streams ~12 B/clk from beyond its (cold) L2 (measured
+// in the fused SAC kernels): the GEMMs ran at 20-33 % of the fp32 MFMA peak whatever their FLOP count.
+// 128 x 128 tiles need 8 B/clk (and read the LDS operands once per two MFMAs instead of once per MFMA) -- built to test that
+// explanation, and it is wrong for these GEMMs: every larger shape measured slower (see gemm_launch); 64 x 64 stays the default.
+template <int AOP, int BOP, int EPI, bool VA, bool VB, int RM, int RN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
 {
-    __shared__ float As[2][GK * GLD], Bs[2][GK * GLD];
+    constexpr int TM = GT * RM, TN = GT * RN, LDA = TM + 4, LDB = TN + 4;
+    extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
+    float *As0 = gemm_lds, *As1 = As0 + GK * LDA, *Bs0 = As1 + GK * LDA, *Bs1 = Bs0 + GK * LDB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2: the nx column
-    // tiles of one row tile all read the same 64 rows of A (the activations: the big operand), so they should share an L2 and run
+    // tiles of one row tile all read the same rows of A (the activations: the big operand), so they should share an L2 and run
     // at the same time.  Linear id L -> xcd = L % 8, slot = L / 8; row tile = (slot / nx) * 8 + xcd, column tile = slot % nx: the nx
     // tiles of a row tile are nx consecutive slots of ONE XCD.  (Rows beyond the last full group of 8 keep the plain order.)
     int ty = blockIdx.y, tx = blockIdx.x;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
             tx = slot - (slot / nx) * nx;
         }
     }
-    const int i0 = ty * GT, j0 = tx * GT;
+    const int i0 = ty * TM, j0 = tx * TN;
     int kb = 0, ke = g.K;
     if (EPI == EPI_PARTIAL) {
         kb = blockIdx.z * g.kchunk;
@@ -128,17 +137,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
     }
     const bool want_rs = EPI == EPI_PARTIAL && g.rowsum != nullptr && tx == 0;
     const int nch = (ke - kb + GK - 1) / GK;
-    float ra[2][8], rb[2][8], rsum = 0.f;
-    f32x16 acc = {0};
+    float ra[2][RM][8], rb[2][RN][8], rsum = 0.f;
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int a = 0; a < RM; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b) acc[a][b] = f32x16{0};
+    auto load = [&](int slot, int k0) {
+#pragma unroll
+        for (int a = 0; a < RM; ++a) tile_load<AOP, VA>(ra[slot][a], g.A, g.lda, i0 + GT * a, g.M, k0, ke, tid);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) tile_load<BOP, VB>(rb[slot][b], g.B, g.ldb, j0 + GT * b, g.N, k0, ke, tid);
+    };
+    auto store = [&](int slot, float *As, float *Bs) {
+#pragma unroll
+        for (int a = 0; a < RM; ++a) tile_store<AOP, VA, LDA>(ra[slot][a], As + GT * a, tid);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) tile_store<BOP, VB, LDB>(rb[slot][b], Bs + GT * b, tid);
+    };
     // chunk 0 straight to LDS[0]; chunks 1 and 2 into the register slots
-    tile_load<AOP, VA>(ra[0], g.A, g.lda, i0, g.M, kb, ke, tid);
-    tile_load<BOP, VB>(rb[0], g.B, g.ldb, j0, g.N, kb, ke, tid);
-    tile_load<AOP, VA>(ra[1], g.A, g.lda, i0, g.M, kb + GK, ke, tid);
-    tile_load<BOP, VB>(rb[1], g.B, g.ldb, j0, g.N, kb + GK, ke, tid);
-    tile_store<AOP, VA>(ra[0], As[0], tid);
-    tile_store<BOP, VB>(rb[0], Bs[0], tid);
-    tile_load<AOP, VA>(ra[0], g.A, g.lda, i0, g.M, kb + 2 * GK, ke, tid);
-    tile_load<BOP, VB>(rb[0], g.B, g.ldb, j0, g.N, kb + 2 * GK, ke, tid);
+    load(0, kb);
+    load(1, kb + GK);
+    store(0, As0, Bs0);
+    load(0, kb + 2 * GK);
     __syncthreads();
     for (int c = 0; c < nch; c += 2) {
 #pragma unroll
@@ -146,50 +167,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
             const int cc = c + d;
             if (cc < nch) {                                    // uniform
                 const int slot = (d + 1) & 1;
+                float *Asd = d ? As1 : As0, *Bsd = d ? Bs1 : Bs0;
                 if (cc + 1 < nch) {
-                    tile_store<AOP, VA>(ra[slot], As[slot], tid);
-                    tile_store<BOP, VB>(rb[slot], Bs[slot], tid);
-                    if (cc + 3 < nch) {
-                        tile_load<AOP, VA>(ra[slot], g.A, g.lda, i0, g.M, kb + (cc + 3) * GK, ke, tid);
-                        tile_load<BOP, VB>(rb[slot], g.B, g.ldb, j0, g.N, kb + (cc + 3) * GK, ke, tid);
-                    }
+                    store(slot, slot ? As1 : As0, slot ? Bs1 : Bs0);
+                    if (cc + 3 < nch) load(slot, kb + (cc + 3) * GK);
                 }
-                const float *a = As[d] + hi * GLD + 32 * wm + l31, *b = Bs[d] + hi * GLD + 32 * wn + l31;
+                const float *a = Asd + hi * LDA + 32 * RM * wm + l31, *b = Bsd + hi * LDB + 32 * RN * wn + l31;
 #pragma unroll
-                for (int s2 = 0; s2 < GK / 2; ++s2) acc = mfma32(a[2 * s2 * GLD], b[2 * s2 * GLD], acc);
-                if (want_rs && tid < GT) {
+                for (int s2 = 0; s2 < GK / 2; ++s2) {
+                    float av[RM], bv[RN];
 #pragma unroll
-                    for (int k = 0; k < GK; ++k) rsum += As[d][k * GLD + tid];
+                    for (int x = 0; x < RM; ++x) av[x] = a[2 * s2 * LDA + 32 * x];
+#pragma unroll
+                    for (int y = 0; y < RN; ++y) bv[y] = b[2 * s2 * LDB + 32 * y];
+#pragma unroll
+                    for (int x = 0; x < RM; ++x)
+#pragma unroll
+                        for (int y = 0; y < RN; ++y) acc[x][y] = mfma32(av[x], bv[y], acc[x][y]);
+                }
+                if (want_rs && tid < TM) {
+#pragma unroll
+                    for (int k = 0; k < GK; ++k) rsum += Asd[k * LDA + tid];
                 }
                 __syncthreads();                               // LDS[slot] is complete, LDS[d] is free for chunk cc + 2
             }
         }
     }
 
-    const int j = j0 + 32 * wn + l31;
     float *C = g.C + (EPI == EPI_PARTIAL ? (size_t)blockIdx.z * g.c_split : 0);
-    if (j < g.N) {
+#pragma unroll
+    for (int y = 0; y < RN; ++y) {
+        const int j = j0 + 32 * (RN * wn + y) + l31;
+        if (j >= g.N) continue;
         const float bj = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? g.bias[j] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = i0 + 32 * wm + crow(r, hi);
-            if (i < g.M) {
-                const size_t o = (size_t)i * g.ldc + j;
-                const float v = acc[r];
-                if (EPI == EPI_STORE || EPI == EPI_PARTIAL) C[o] = v;
-                else if (EPI == EPI_ACC) C[o] += v;
-                else if (EPI == EPI_BIAS) C[o] = v + bj;
-                else if (EPI == EPI_MUL) C[o] = v * g.G[o];
-                else {
-                    float y, gd;
-                    gelu_and_grad_fast(v + bj, y, gd);
-                    C[o] = y;
-                    if (g.G) g.G[o] = gd;
+        for (int x = 0; x < RM; ++x) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 32 * (RM * wm + x) + crow(r, hi);
+                if (i < g.M) {
+                    const size_t o = (size_t)i * g.ldc + j;
+                    const float v = acc[x][y][r];
+                    if (EPI == EPI_STORE || EPI == EPI_PARTIAL) C[o] = v;
+                    else if (EPI == EPI_ACC) C[o] += v;
+                    else if (EPI == EPI_BIAS) C[o] = v + bj;
+                    else if (EPI == EPI_MUL) C[o] = v * g.G[o];
+                    else {
+                        float yv, gd;
+                        gelu_and_grad_fast(v + bj, yv, gd);
+                        C[o] = yv;
+                        if (g.G) g.G[o] = gd;
+                    }
                 }
             }
         }
     }
-    if (want_rs && tid < GT && i0 + tid < g.M) g.rowsum[(size_t)blockIdx.z * g.rs_split + i0 + tid] = rsum;
+    if (want_rs && tid < TM && i0 + tid < g.M) g.rowsum[(size_t)blockIdx.z * g.rs_split + i0 + tid] = rsum;
 }
 
 // Small outputs (the off-policy agents' batches of a few hundred rows: 16 tiles of 64 x 64 would leave 240 CUs idle and
@@ -292,6 +325,17 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g)
     if (want_rs && tid < ST && i0 + tid < g.M) g.rowsum[(size_t)batch * g.sRS + (size_t)split * g.rs_split + i0 + tid] = rsum;
 }
 
+template <int AOP, int BOP, int EPI, bool VA, bool VB, int RM, int RN>
+void gemm_go(dim3 grid, size_t lds, hipStream_t s, const GemmArgs &g)
+{
+    static bool attr_set = false;                 // the 128 x 128 shape stages 67.6 KB: beyond the default dynamic-LDS limit
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)gemm_kernel<AOP, BOP, EPI, VA, VB, RM, RN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, VA, VB, RM, RN>), grid, dim3(256), lds, s, g);
+}
+
 template <int AOP, int BOP, int EPI>
 int gemm_launch(hipStream_t s, const GemmArgs &g_in, int splits, const char *what)
 {
@@ -304,15 +348,32 @@ int gemm_launch(hipStream_t s, const GemmArgs &g_in, int splits, const char *wha
         const dim3 grid((unsigned)erl_cdiv(g.N, ST), (unsigned)erl_cdiv(g.M, ST), (unsigned)(splits * g.nbatch));
         hipLaunchKernelGGL((gemm_small_kernel<AOP, BOP, EPI>), grid, dim3(256), 0, s, g);
     } else {
-        const dim3 grid((unsigned)erl_cdiv(g.N, GT), (unsigned)erl_cdiv(g.M, GT), (unsigned)splits);
         auto vec_ok = [](int op, const float *P, int ld, int outs, int red) {
             return (reinterpret_cast<uintptr_t>(P) & 15) == 0 && ld % 4 == 0 && (op == OP_RC ? red : outs) % 4 == 0;
         };
         const bool va = vec_ok(AOP, g.A, g.lda, g.M, g.K), vb = vec_ok(BOP, g.B, g.ldb, g.N, g.K);
-        if (va && vb) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, true, true>), grid, dim3(256), 0, s, g);
-        else if (va) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, true, false>), grid, dim3(256), 0, s, g);
-        else if (vb) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, false, true>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, EPI, false, false>), grid, dim3(256), 0, s, g);
+        // tile shape: 64 x 64.  The 128-wide shapes exist (ERL_GEMM_TILE=12|21|22 forces one) and were MEASURED SLOWER at the PPO
+        // minibatch (B = 16384; profiles/r03_gemm_tile_ab.txt: whole layered step 180 / 227 / 266 us with 64 x 64 tiles against
+        // 222 / 266 / 307 with 64 x 128, 227 / 264 / 308 with 128 x 64 and 329 / 361 / 418 with 128 x 128 at [128,128] / (256,128) /
+        // (256,128,64)): the hypothesis that these GEMMs are bound by the ~12 B/clk a CU streams from beyond its L2 does not hold
+        // for them -- four 64 x 64 workgroups per CU hide each other's latency better than one big one.
+        static const int forced = [] { const char *e = getenv("ERL_GEMM_TILE"); return e ? atoi(e) : 0; }();
+        int rm = 1, rn = 1;
+        if (forced == 12 || forced == 21 || forced == 22) { rm = forced / 10; rn = forced % 10; }
+        const dim3 grid((unsigned)erl_cdiv(g.N, GT * rn), (unsigned)erl_cdiv(g.M, GT * rm), (unsigned)splits);
+        const size_t lds = (size_t)2 * GK * ((GT * rm + 4) + (GT * rn + 4)) * sizeof(float);
+#define ERL_GEMM_GO(RM, RN)                                                                 \
+    do {                                                                                    \
+        if (va && vb) gemm_go<AOP, BOP, EPI, true, true, RM, RN>(grid, lds, s, g);           \
+        else if (va) gemm_go<AOP, BOP, EPI, true, false, RM, RN>(grid, lds, s, g);           \
+        else if (vb) gemm_go<AOP, BOP, EPI, false, true, RM, RN>(grid, lds, s, g);           \
+        else gemm_go<AOP, BOP, EPI, false, false, RM, RN>(grid, lds, s, g);                  \
+    } while (0)
+        if (rm == 2 && rn == 2) ERL_GEMM_GO(2, 2);
+        else if (rn == 2) ERL_GEMM_GO(1, 2);
+        else if (rm == 2) ERL_GEMM_GO(2, 1);
+        else ERL_GEMM_GO(1, 1);
+#undef ERL_GEMM_GO
     }
     return erl_hip_status(hipGetLastError(), what);
 }
