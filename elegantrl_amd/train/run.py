@@ -30,12 +30,26 @@ def train_agent(args: Config, if_single_process: bool = False):
 
 def train_agent_multiprocessing(args: Config):
     """elegantrl/train/run.py:141-190 spawns one Learner, `num_workers` Worker and one Evaluator process per GPU and moves
-    rollouts through pipes.  Here the env shard lives on the learner's device and the rollout is one kernel launch, so one
-    in-process actor-learner per GPU replaces that process tree: this entry point says so and routes to the same paths as
-    `train_agent` (several `learner_gpu_ids` -> one data-parallel rank per GPU)."""
-    n_workers = int(getattr(args, "num_workers", 1))
-    print(f"| train_agent_multiprocessing(): the Learner / {n_workers} Worker / Evaluator processes of the reference are one "
-          f"in-process actor-learner per GPU here (num_workers is not used)", flush=True)
+    rollouts through pipes; the Learner trains on the `num_workers` x `num_envs` env columns it gathers per horizon
+    (`num_seqs = num_envs * num_workers * num_learners`, run.py:245).  Here the env shard lives on the learner's device and the
+    rollout is one kernel launch, so one in-process actor-learner per GPU replaces that process tree -- and `num_workers` keeps its
+    MEANING: the shard is widened to `num_workers * num_envs` envs (same data per iteration as the reference's topology), for
+    vectorised env classes that take `num_envs` from `env_args`.  A single non-vectorised env cannot be widened: that is said,
+    not ignored.  Several `learner_gpu_ids` -> one data-parallel rank per GPU, as `train_agent`."""
+    n_workers = max(1, int(getattr(args, "num_workers", 1)))
+    if n_workers > 1 and int(args.num_envs) > 1 and isinstance(getattr(args, "env_args", None), dict) and "num_envs" in args.env_args:
+        wide = int(args.num_envs) * n_workers
+        print(f"| train_agent_multiprocessing(): {n_workers} workers x {args.num_envs} envs -> one in-process actor-learner per GPU "
+              f"with a shard of {wide} envs (no Worker processes, no pipes)", flush=True)
+        args.env_args = dict(args.env_args, num_envs=wide)
+        args.num_envs = wide
+        args.num_workers = 1
+    elif n_workers > 1:
+        print(f"| train_agent_multiprocessing(): num_workers = {n_workers} asks for {n_workers} copies of a non-vectorised env; this "
+              f"package runs ONE in-process actor-learner per GPU -- use a vectorised env (env_args['num_envs']) to widen the shard",
+              flush=True)
+    else:
+        print("| train_agent_multiprocessing(): one in-process actor-learner per GPU (no Learner / Worker / Evaluator processes)", flush=True)
     train_agent(args)
 
 

@@ -364,6 +364,26 @@ def test_train_agent_pendulum_smoke(tmp_path):
     assert actor(th.zeros((2, 3), device=DEV)).shape == (2, 1)
 
 
+def test_train_agent_multiprocessing_widens_the_shard_by_num_workers(tmp_path, capsys):
+    """elegantrl/train/run.py:141-190: `num_workers` Worker processes x `num_envs` envs feed one Learner.  Here: ONE in-process
+    actor-learner whose shard is num_workers * num_envs envs wide -- the flag keeps its meaning (data per iteration) instead of
+    being ignored."""
+    from elegantrl_amd import train_agent_multiprocessing
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.envs import PendulumVecEnv
+    from elegantrl_amd.train import Config
+    args = Config(AgentPPO, PendulumVecEnv, {"env_name": "Pendulum-v1", "num_envs": 64, "max_step": 200, "state_dim": 3,
+                                             "action_dim": 1, "if_discrete": False})
+    args.net_dims, args.num_workers = [128, 64], 4
+    args.horizon_len, args.batch_size, args.repeat_times = 32, 1024, 64.0
+    args.break_step, args.eval_per_step, args.eval_times = 32 * 3, 32 * 2, 2
+    args.cwd, args.gpu_id, args.random_seed = str(tmp_path / "run"), 0, 0
+    train_agent_multiprocessing(args)
+    assert args.num_envs == 256 and args.env_args["num_envs"] == 256
+    assert "4 workers x 64 envs" in capsys.readouterr().out
+    assert "act.pth" in os.listdir(args.cwd)
+
+
 def test_train_agent_ppo_pendulum_learns(tmp_path):
     """the whole loop on the HIP kernels learns: PPO on 1024 GPU-resident Pendulum envs (config-2 hyper-parameters) lifts the
     evaluated return from about -1200..-600 (random policy) to better than -400 at some evaluation within 100 iterations
