@@ -88,6 +88,7 @@ _SIGNATURES = {
     "erl_comm_kind": (c_int, [_P]),
     "erl_comm_reduce_exchange_f32": (c_int, [_P, _P, c_int, c_int64, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
     "erl_grad_reduce_partials_f32": (c_int, [_P, c_int, c_int64, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
+    "erl_ppo_logs_mean_f32": (c_int, [_P, c_int64, c_int64, c_int, c_float, _P, _P]),
     "erl_grad_sq_partials_f32": (c_int, [_P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
     "erl_clip_adam_partials_f32": (c_int, [_P, _P, _P, _P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
                                            c_float, c_float, c_float, c_float, c_float, _P]),

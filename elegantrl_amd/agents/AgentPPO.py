@@ -167,6 +167,7 @@ class AgentPPO(AgentBase):
         self._slabs = None
         self._grads = None
         self._stats = None
+        self._logs = None
         self._env_action = None
         # GPU-resident envs that expose `fused_rollout` get the whole horizon in ONE launch (csrc/rollout_fused.hip), which
         # also leaves the critic's values of the visited states for update_net; ERL_FUSED_ROLLOUT=0 / args.fused_rollout=False
@@ -517,8 +518,11 @@ class AgentPPO(AgentBase):
                 if rc:
                     _hip.check(rc, "erl_grad_sq_partials_f32 / erl_clip_adam_partials_f32")
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
-        logs = self._grads[:update_times, self._Pa + self._Pc:self._Pa + self._Pc + 3].mean(dim=0) * grad_scale
-        obj_critic, obj_actor, obj_entropy = (float(x) for x in logs.cpu())           # the only host sync of update_net
+        if self._logs is None:
+            self._logs = th.empty(4, dtype=th.float32, device=dev)
+        _hip.check(_hip.lib().erl_ppo_logs_mean_f32(_hip.ptr(self._grads, th.float32), self._stride, self._Pa + self._Pc, update_times,
+                                                    grad_scale, _hip.ptr(self._logs, th.float32), _hip.stream_ptr()), "erl_ppo_logs_mean_f32")
+        obj_critic, obj_actor, obj_entropy = self._logs[:3].tolist()                  # the only host sync of update_net
         _hip.check_async_faults()              # the stream is drained: a lost look-back predecessor (NaN advantages) raises here
         return obj_critic, obj_actor, obj_entropy
 

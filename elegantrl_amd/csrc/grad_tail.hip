@@ -119,12 +119,27 @@ __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int
     }
     if (p == 0 && i < stride) out[i] = gsum;
     if (partials && threadIdx.x < NE) {                // whole waves (NE is a multiple of 64): chunk c = elements 64 c .. 64 c + 63
-        const int64_t chunk = i >> 6;
+        const int64_t chunk = i >> 6, c_lo = chunk << 6, c_hi = c_lo + 63;
+        const double xs = (double)((float)gsum * grad_scale), sq = xs * xs;
+        // a chunk almost always lies inside ONE group (the only straddler at config 4 is the chunk holding the actor | critic
+        // seam): one butterfly then, the other groups' partials are exactly 0 -- the same bits the general path produces
+        int own = -1, touched = 0;
         for (int gi = 0; gi < n_groups; ++gi) {
-            const bool in = i < stride && i >= gr.off[gi] && i < gr.off[gi] + gr.len[gi];
-            const double xs = (double)((float)gsum * grad_scale);
-            const double t = wave_sum(in ? xs * xs : 0.0);
-            if ((threadIdx.x & 63) == 0) partials[(size_t)chunk * 4 + gi] = t;
+            const bool overlap = c_lo < gr.off[gi] + gr.len[gi] && c_hi >= gr.off[gi];
+            const bool inside = c_lo >= gr.off[gi] && c_hi < gr.off[gi] + gr.len[gi];
+            touched += overlap;
+            if (inside) own = gi;
+        }
+        if (touched == 0 || (touched == 1 && own >= 0)) {          // (wave-uniform: depends on the chunk only)
+            const double t = own >= 0 ? wave_sum(i < stride ? sq : 0.0) : 0.0;
+            if ((threadIdx.x & 63) == 0)
+                for (int gi = 0; gi < n_groups; ++gi) partials[(size_t)chunk * 4 + gi] = gi == own ? t : 0.0;
+        } else {
+            for (int gi = 0; gi < n_groups; ++gi) {
+                const bool in = i < stride && i >= gr.off[gi] && i < gr.off[gi] + gr.len[gi];
+                const double t = wave_sum(in ? sq : 0.0);
+                if ((threadIdx.x & 63) == 0) partials[(size_t)chunk * 4 + gi] = t;
+            }
         }
     }
 }
@@ -156,6 +171,17 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
         m2[off + ie] = e_m2;
         params[off + ie] = e_p;
     }
+}
+
+// the three logged objectives of update_net (AgentPPO.py:168-171: means over the minibatches) from the gradient rows' tails:
+// out[j] = scale * mean_k rows[k][offset + j], j < 3, summed in row order by one thread each -- replaces a torch mean + mul pair
+__global__ void logs_mean_kernel(const float *__restrict__ rows, int64_t stride, int64_t offset, int n_rows, float scale, float *__restrict__ out)
+{
+    const int j = threadIdx.x;
+    if (j >= 3) return;
+    float s = 0.f;
+    for (int k = 0; k < n_rows; ++k) s += rows[(size_t)k * stride + offset + j];
+    out[j] = s / (float)n_rows * scale;
 }
 
 // the partial-norm table of the update loop: library-owned, one per device, written by launch 1 and read by launch 2 of the
@@ -225,6 +251,13 @@ int erl_launch_exchange_f64(double *buf, int64_t count, const ErlExchange *ex, h
     hipLaunchKernelGGL((reduce_exchange_kernel<double, true, 1024>), dim3((unsigned)nblk), dim3(1024), 0, stream, (const double *)buf, 1, count, buf,
                        TailGroups{}, 0, 1.f, (double *)nullptr, *ex);
     ERL_LAUNCH_CHECK("erl_comm_allreduce_sum_f64");
+}
+
+extern "C" int erl_ppo_logs_mean_f32(const float *grad_rows, int64_t stride, int64_t offset, int n_rows, float scale, float *out3, void *stream)
+{
+    ERL_REQUIRE(grad_rows && out3 && n_rows >= 1 && offset >= 0 && offset + 3 <= stride, "erl_ppo_logs_mean_f32: bad argument");
+    hipLaunchKernelGGL(logs_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grad_rows, stride, offset, n_rows, scale, out3);
+    ERL_LAUNCH_CHECK("erl_ppo_logs_mean_f32");
 }
 
 extern "C" int erl_grad_reduce_partials_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, const int64_t *group_off,

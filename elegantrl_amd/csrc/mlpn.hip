@@ -235,7 +235,7 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
                                        unmasks, reward_sums, (const float *)nullptr, (const float *)nullptr, ratio_clip, lambda_entropy,
                                        inv_batch, objective, q.part);
                 const bool gauss = net == 0 && !discrete;
-                hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(64), 0, sn, q.part, nparts, gauss ? 2 + A : 2, P + nd.oStd, A, inv_batch,
+                hipLaunchKernelGGL(fold_logs_kernel, dim3(1), dim3(256), 0, sn, q.part, nparts, gauss ? 2 + A : 2, P + nd.oStd, A, inv_batch,
                                    net == 0 ? (discrete ? 2 : 1) : 0, logs, gauss ? G + nd.oStd : (float *)nullptr);   // + dL/dstd_log
             } else {                   // backward: dZ of the output layer is Y (dL/dY); walk the layers down
                 if ((rc = backward(sn, nd, P, B, q.act, q.gd, Y, G, q.cs_scr, nullptr, false, q.dA, q.dB, q.dw_scr))) return rc;

@@ -295,18 +295,32 @@ __global__ __launch_bounds__(256) void objective_discrete_kernel(float *__restri
     }
 }
 
-// logs: fold the per-block partials in a fixed order (is_actor: 1 = Gaussian head, 2 = categorical head).  64 threads: thread c
-// sums column c of part[nparts][pstride] (columns 0, 1: the logged values; 2 + a: dL/dstd_log of action a -> dstd[a])
-__global__ __launch_bounds__(64) void fold_logs_kernel(const float *__restrict__ part, int nparts, int pstride,
-                                                       const float *__restrict__ std_log, int A, float inv_batch, int is_actor,
-                                                       float *__restrict__ logs, float *__restrict__ dstd)
+// logs: fold the per-block partials part[nparts][pstride] in a fixed order (is_actor: 1 = Gaussian head, 2 = categorical head;
+// columns 0, 1: the logged values; 2 + a: dL/dstd_log of action a -> dstd[a]).
+// 256 threads = 32 column slots x 8 row groups: a thread adds every 8th partial of its column (8x fewer dependent loads than one
+// thread per column: the fold was 7.8 us of a ~4.5 us launch floor), the 8 group sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void fold_logs_kernel(const float *__restrict__ part, int nparts, int pstride,
+                                                        const float *__restrict__ std_log, int A, float inv_batch, int is_actor,
+                                                        float *__restrict__ logs, float *__restrict__ dstd)
 {
     __shared__ float s01[2];
-    for (int c = threadIdx.x; c < pstride; c += 64) {
+    __shared__ float grp[8][32];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    for (int c0 = 0; c0 < pstride; c0 += 32) {
+        const int c = c0 + col;
         float s = 0.f;
-        for (int i = 0; i < nparts; ++i) s += part[(size_t)i * pstride + c];
-        if (c < 2) s01[c] = s;
-        else if (dstd) dstd[c - 2] = s;
+        if (c < pstride)
+            for (int i = rg; i < nparts; i += 8) s += part[(size_t)i * pstride + c];
+        grp[rg][col] = s;
+        __syncthreads();
+        if (rg == 0 && c < pstride) {
+            float t = grp[0][col];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) t += grp[r][col];
+            if (c < 2) s01[c] = t;
+            else if (dstd) dstd[c - 2] = t;
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x != 0) return;

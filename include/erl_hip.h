@@ -294,6 +294,11 @@ ERL_API int erl_clip_adam_partials_f32(float *params, const float *grads, float 
                                const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr,
                                float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream);
 
+/* update_net's three returned objectives (AgentPPO.py:168-171): out3[j] = scale * mean over the n_rows minibatch rows of
+ * grad_rows[k][offset + j] (the logged values K6 leaves behind the gradient; offset = Pa + Pc), one launch. */
+ERL_API int erl_ppo_logs_mean_f32(const float *grad_rows, int64_t stride, int64_t offset, int n_rows, float scale, float *out3,
+                          void *stream);
+
 /* erl_grad_reduce_f32 + erl_clip_adam_f32 in ONE launch (host step only), for loops with nothing between the two: the same
  * gradient bit for bit (same summation order), written to flat_grad; the workgroup that finishes last derives the clip
  * coefficients from per-workgroup fp64 partial norms (fixed order) and applies Adam.  No workgroup waits on another. */
