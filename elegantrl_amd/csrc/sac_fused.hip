@@ -814,6 +814,34 @@ __global__ void clamp_alpha_fused_kernel(float *alpha_log)
 
 int wclass(int width) { return width <= 64 ? 0 : (width <= 128 ? 1 : 2); }
 
+// a library-owned second stream per device (non-blocking) + the events that fork it from / join it into the caller's stream: the
+// policy-gradient sample (actor forward on `state`) and the temperature step depend on nothing the critic update produces, so they
+// run NEXT TO it (ERL_SAC_STREAMS=1 keeps everything on the caller's stream)
+struct SacSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool tried = false;
+};
+SacSide g_sac_side[32];
+
+SacSide *sac_side_stream()
+{
+    static const bool off = [] { const char *e = getenv("ERL_SAC_STREAMS"); return e && atoi(e) == 1; }();
+    int dev = -1;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    SacSide &q = g_sac_side[dev];
+    if (!q.tried) {
+        q.tried = true;
+        if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            q.stream = nullptr;
+        }
+    }
+    return q.stream ? &q : nullptr;
+}
+
 }  // namespace
 
 // ---- shape class of the fused step ---------------------------------------------------------------------------
@@ -837,7 +865,7 @@ int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, 
     const int64_t tiles = (B + TS - 1) / TS;
     auto r = [](int64_t n) { return (n + 63) / 64 * 64; };
     int64_t f = 0;
-    f += 2 * r(B * A) + 2 * r(B);                                       // a_next / act_t, eps | lp_next, lp_cur
+    f += 3 * r(B * A) + 2 * r(B);                                       // a_next, act_pg, eps | lp_next, lp_cur
     f += 3 * r((int64_t)E * B) + r(B);                                  // qt, qc (also q_pg), dq | label
     f += r(B * (S + A)) + r(B * h0);                                    // xa, enc
     f += 2 * r((int64_t)E * B * h1) + r((int64_t)E * B * h0);           // H1e, dZ1e | dEncE
@@ -878,7 +906,8 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     float *Y = take(B * 2 * A), *dY = take(B * 2 * A), *H0 = take(B * h0), *G0 = take(B * h0), *H1 = take(B * h1), *G1 = take(B * h1);
     float *dAct = take((int64_t)E * B * A), *dZ2 = take(B * h1), *dZ1 = take(B * h0);
     float *g_actor = take(Pa), *g_critic = take(Pc), *qpart = take((int64_t)E * tiles), *tdpart = take(tiles), *alpha0 = take(64);
-    float *act_pg = a_next, *q_pg = qt;                 // reused once their first contents are consumed
+    float *act_pg = take(B * A);                        // (its own buffer: the policy-gradient sample runs next to the critic update)
+    float *q_pg = qt;                                   // reused once its first contents are consumed
     const dim3 tgrid(tiles), cgrid(tiles, E), blk(FT);
     int rc;
 
@@ -886,8 +915,32 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     ActorFwdArgs af{};
     af.P = actor_params; af.d = d; af.X = next_state; af.noise = eps_next; af.seed = seed; af.counter = 2 * counter;
     af.act_t = a_next; af.lp = lp_next; af.alpha_log = alpha_log; af.alpha0 = alpha0;
-#define LAUNCH_ACTOR_FWD(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, s, af)
+    hipStream_t sa = s;                                 // the stream the actor-forward launches go to
+#define LAUNCH_ACTOR_FWD(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, sa, af)
     FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
+    // ---- (6) policy-gradient sample (actor on state, kept for the backward pass) and temperature step              (:72-79)
+    // FORKED here onto the side stream: they read the actor, `state` and alpha_log only -- the temperature BEFORE its update
+    // is already parked in alpha0 by launch (1) -- and run next to the critic update (2)-(5); joined before (7).
+    SacSide *side = sac_side_stream();
+    if (side) {
+        if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
+        if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
+        sa = side->stream;
+    }
+    {
+        ActorFwdArgs af2 = af;
+        af2.X = state; af2.noise = eps_cur; af2.counter = 2 * counter + 1; af2.act_t = act_pg; af2.lp = lp_cur; af2.eps_out = eps_used; af2.Y = Y;
+        af2.H0 = H0; af2.G0 = G0; af2.H1 = H1; af2.G1 = G1; af2.alpha0 = nullptr;
+        ActorFwdArgs keep = af;
+        af = af2;
+        FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
+        af = keep;
+        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        hipLaunchKernelGGL(alpha_step_fused_kernel, dim3(1), dim3(256), 0, sa, lp_cur, B, target_entropy, alpha_log, alpha_m, alpha_v, beta1, beta2,
+                           eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
+        if (side && (rc = erl_hip_status(hipEventRecord(side->join, sa), "hipEventRecord(join)"))) return rc;
+        sa = s;
+    }
     // ---- (2) target ensemble on (next_state, next_action)                                                     (:52)
     CriticArgs ca{};
     ca.P = target_params; ca.d = d; ca.Xs = next_state; ca.Xa = a_next; ca.q = qt;
@@ -920,16 +973,8 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
                                          1.0f, target_params, tau, s)))
             return rc;
     }
-    // ---- (6) policy-gradient sample (actor on state, kept for the backward pass), temperature step             (:72-79)
-    af.X = state; af.noise = eps_cur; af.counter = 2 * counter + 1; af.act_t = act_pg; af.lp = lp_cur; af.eps_out = eps_used; af.Y = Y;
-    af.H0 = H0; af.G0 = G0; af.H1 = H1; af.G1 = G1; af.alpha0 = nullptr;
-    FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
-    {
-        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-        hipLaunchKernelGGL(alpha_step_fused_kernel, dim3(1), dim3(256), 0, s, lp_cur, B, target_entropy, alpha_log, alpha_m, alpha_v, beta1, beta2,
-                           eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
-    }
     // ---- (7) TARGET ensemble on (state, action_pg): q and d(mean q)/d(action); finishes the critic objective    (:82-83)
+    if (side && (rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
     ca.P = target_params; ca.Xs = state; ca.Xa = act_pg; ca.q = q_pg;
     ca.dAct = dAct; ca.qpart = qpart; ca.qc = qc; ca.label_in = label; ca.td_out = td_error_out; ca.tdpart = tdpart;
     FUSED_KT_DISPATCH(LAUNCH_CRITIC2)
