@@ -22,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 13
+ABI_VERSION = 14
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -66,6 +66,8 @@ _SIGNATURES = {
                                          c_uint64, c_float] + [_P] * 9),
     "erl_ppo_slab_stride": (c_int64, [c_int, c_int, c_int, c_int]),
     "erl_ppo_num_slabs": (c_int, [c_int64]),
+    "erl_ppo_set_arith": (c_int, [c_int]),
+    "erl_ppo_arith_in_use": (c_int, [c_int, c_int, c_int, c_int]),
     "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, c_int, _P, c_int, _P]),
     "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),

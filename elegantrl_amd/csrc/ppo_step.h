@@ -112,3 +112,6 @@ __device__ __forceinline__ void bias_grad(const float *T, int nfeat, float *__re
 // ppo_step_w4.hip
 bool erl_ppo_w4_supported(int S, int h1, int h2, int A);
 int erl_ppo_w4_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);
+// ppo_step_s3.hip
+bool erl_ppo_s3_supported(int S, int h1, int h2, int A);
+int erl_ppo_s3_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);

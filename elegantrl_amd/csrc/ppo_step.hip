@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "ppo_step.h"
+#include <cstring>
 
 namespace {
 
@@ -418,6 +419,40 @@ extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile
 extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile_block(int b) { g_ppo_prof_block = b; }
 #endif
 
+namespace {
+constexpr int kDefaultArith = ERL_PPO_ARITH_F32;
+int g_k6_arith = ERL_PPO_ARITH_AUTO;
+int k6_arith_resolved()
+{
+    if (g_k6_arith != ERL_PPO_ARITH_AUTO) return g_k6_arith;
+    static const int env = [] {
+        const char *e = getenv("ERL_K6_ARITH");
+        if (e && !strcmp(e, "f32")) return (int)ERL_PPO_ARITH_F32;
+        if (e && !strcmp(e, "split")) return (int)ERL_PPO_ARITH_SPLIT;
+        return kDefaultArith;
+    }();
+    return env;
+}
+int k6_form()     // 0 = automatic, 8 = always the 8-wave 16x16x4 kernel (A/B measurements: ERL_K6_FORM=8)
+{
+    static const int form = [] { const char *e = getenv("ERL_K6_FORM"); return e ? atoi(e) : 0; }();
+    return form;
+}
+}  // namespace
+
+extern "C" int erl_ppo_set_arith(int arith)
+{
+    const int prev = g_k6_arith;
+    if (arith >= ERL_PPO_ARITH_AUTO && arith <= ERL_PPO_ARITH_SPLIT) g_k6_arith = arith;
+    return prev;
+}
+
+extern "C" int erl_ppo_arith_in_use(int S, int h1, int h2, int A)
+{
+    return (k6_form() != 8 && k6_arith_resolved() == ERL_PPO_ARITH_SPLIT && erl_ppo_s3_supported(S, h1, h2, A)) ? ERL_PPO_ARITH_SPLIT
+                                                                                                               : ERL_PPO_ARITH_F32;
+}
+
 extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
 {
     if (!dims_ok2(S, h1, h2, A)) return -1;
@@ -468,10 +503,11 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     const int ns = (S + 15) / 16;
     erl_k6_timing_mark(st, 0);
     int rc;
-    // K6 form: 0 = automatic (one-wave-per-SIMD 32x32x2 kernel where its shape class applies), 8 = always the 8-wave
-    // 16x16x4 kernel (A/B measurements: ERL_K6_FORM=8)
-    static const int form = [] { const char *e = getenv("ERL_K6_FORM"); return e ? atoi(e) : 0; }();
-    if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 2 / 4 / 5
+    // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else
+    // the fp32 32x32x2 one), 8 = always the 8-wave 16x16x4 kernel
+    const int form = k6_form();
+    if (erl_ppo_arith_in_use(S, h1, h2, A) == ERL_PPO_ARITH_SPLIT) rc = erl_ppo_s3_launch(g, n_slabs, vec, st);
+    else if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 2 / 4 / 5
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
     else rc = launch<0, 0, 0, false>(g, n_slabs, st);

@@ -1,0 +1,783 @@
+// K6 on the bf16 matrix pipe with fp32-equivalent arithmetic: every fp32 operand x of the five big products of a PPO minibatch
+// (two forward layers, the backward through W2, dW1, dW2) is split into three bf16 parts x = h + m + l (round-to-nearest each,
+// h + m + l == x exactly), and a product a . b is accumulated in fp32 from the six partial products whose weight is >= 2^-16
+//     ah bh + (ah bm + am bh) + (ah bl + al bh + am bm)
+// on v_mfma_f32_32x32x16_bf16 (every bf16 x bf16 product is exact in fp32; the three dropped terms are <= 2^-23 |a b|, one or
+// two fp32 roundings' worth -- measured against fp64 the result is as close as v_mfma_f32_32x32x2_f32's:
+// tools/split_mfma_probe.hip, profiles/r03_split_mfma_probe.txt).  Six bf16 MFMAs of K = 16 (192 cycles) replace eight fp32 MFMAs
+// of K = 2 (512 cycles), and the bf16 matrix pipe runs beside the vector ALUs instead of on them.
+//
+// Same contract as ppo_step_w4_impl.h (AgentPPO.update_objectives up to the optimizer steps, elegantrl/agents/AgentPPO.py:173-204;
+// ActorPPO.get_logprob_entropy :378-386; same slabs, same logged sums), same mapping (grid (ceil(B / 128), 2), four waves, one
+// per SIMD, 32 samples each, every activation of a sample in its lane's registers).  What differs:
+//   * result-row permutation: A-row i of every forward / backward tile carries feature phi(i) = i with bits 2 and 3 swapped, so
+//     that lane (sample, hi) ends up with features 16 a + 8 hi + 0..7 (a = 0, 1) of a 32-feature tile in acc[8 a .. 8 a + 7]: the
+//     B operand of the next layer's k-step (tile, a) is those eight values in natural order (four v_cvt_pk_bf16_f32 per part), its
+//     A operand one 16-byte LDS read per part, and a staging store 16 bytes per part;
+//   * weights live in LDS as images [row][3 parts][K bf16], rows 6 K bytes, no padding: 16-byte chunks are XOR-swizzled with a
+//     function of the row index (swz<>) chosen so that the three access patterns are bank-conflict free at once -- 16-byte reads
+//     by the lane groups of ds_read_b128, the [4 rows][64 bytes] blocks of ds_read_b64_tr_b16 (the backward's W2^T operand and
+//     both operands of the weight gradients are transposing reads), and 16-byte stores by 8 consecutive rows;
+//   * the weight gradients contract over samples, which sit in lanes: both operands go through LDS as sample-major images
+//     S[sample][part][feature] (16-byte stores straight from the split registers) and come back transposed.  A wave's A operand
+//     (its 32 features of dZ^T, all 128 samples) is read once into 96 registers; the bias gradient is three more MFMAs per k-step
+//     against a constant ones operand.
+//   * the 8-row output layer, dZ2 = W3^T dY and dW3 stay on the fp32 instructions of ppo_step_w4_impl.h (K <= 8 or 16 rows).
+#pragma once
+#include "ppo_step_w4_impl.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b)      // v_cvt_pk_bf16_f32 (round to nearest even): a in the low half
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// (x0, x1) -> three packed bf16 pairs with h + m + l == x exactly (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|, the last residual has
+// <= 8 significant bits left)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = pk_bf16(x0, x1);
+    const float r0 = x0 - bf_lo(h), r1 = x1 - bf_hi(h);
+    m = pk_bf16(r0, r1);
+    const float q0 = r0 - bf_lo(m), q1 = r1 - bf_hi(m);
+    l = pk_bf16(q0, q1);
+}
+
+struct Parts {          // one MFMA operand (8 k-values of one row / column) in its three parts
+    u32x4 h, m, l;
+};
+
+// acc[8 a .. 8 a + 7] of a tile -> the operand of k-step (tile, a)
+__device__ __forceinline__ Parts split8(const f32x16 &t, int a)
+{
+    Parts p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        uint32_t h, m, l;
+        split2(t[8 * a + 2 * e], t[8 * a + 2 * e + 1], h, m, l);
+        p.h[e] = h; p.m[e] = m; p.l[e] = l;
+    }
+    return p;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// the six partial products, smallest first
+__device__ __forceinline__ void mma6(const Parts &a, const Parts &b, f32x16 &acc)
+{
+    acc = mfma_bf(a.m, b.m, acc);
+    acc = mfma_bf(a.l, b.h, acc);
+    acc = mfma_bf(a.h, b.l, acc);
+    acc = mfma_bf(a.m, b.h, acc);
+    acc = mfma_bf(a.h, b.m, acc);
+    acc = mfma_bf(a.h, b.h, acc);
+}
+
+__device__ __forceinline__ int phi(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }   // bits 2 and 3 swapped
+
+// ---- LDS images: [row][3 parts][CP chunks of 16 bytes], CP = K / 8 in {4, 8, 16}; chunk c of a row sits at c ^ swz(row).
+// Conditions (banks: 64 dwords for reads, 32 for writes; lane groups per /opt/skills/guides/MI355X_MICROARCH.md): for a fixed
+// chunk, (a) the 16 rows of a ds_read_b128 lane group -- four aligned quads with distinct (row >> 2) & 3 -- and (c) 8 consecutive
+// rows of a ds_write_b128 group must land in distinct 16-byte bank groups; (b) a transposing read's 32 lanes cover 4 aligned
+// rows x 4 aligned chunks.  With r0..r3 the row's low bits:
+template <int CP>
+__device__ __forceinline__ int swz(int r)
+{
+    const int r0 = r & 1, r1 = (r >> 1) & 1, r2 = (r >> 2) & 1, r3 = (r >> 3) & 1;
+    if (CP == 16) return ((r1 ^ r3) << 3) | (r0 << 2) | ((r1 ^ r2) << 1) | r2;
+    if (CP == 8) return (r1 << 2) | (r2 << 1) | (r0 ^ r3);
+    return (r2 << 1) | (r1 ^ r3);
+}
+
+typedef unsigned char u8;
+
+template <int CP>
+__device__ __forceinline__ u8 *img_at(u8 *img, int row, int part, int chunk)
+{
+    return img + row * (48 * CP) + part * (16 * CP) + 16 * (chunk ^ swz<CP>(row));
+}
+
+// a float4 (columns 4 j4 .. 4 j4 + 3 of `row`) into an image: three 8-byte stores
+template <int CP>
+__device__ __forceinline__ void img_store4(u8 *img, int row, int j4, float4 v)
+{
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split2(v.x, v.y, h0, m0, l0);
+    split2(v.z, v.w, h1, m1, l1);
+    u8 *p = img_at<CP>(img, row, 0, j4 >> 1) + 8 * (j4 & 1);
+    *reinterpret_cast<u32x2 *>(p) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2 *>(p + 16 * CP) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2 *>(p + 32 * CP) = u32x2{l0, l1};
+}
+
+// the registers of copy_load (row-major [rows_pad][4 * CP * 2 ... ] see mlp_chain.h) into an image with K = 8 CP columns
+template <int MAXV, int CP>
+__device__ __forceinline__ void img_store(const float4 (&v)[MAXV], u8 *img, int rows_pad, int tid)
+{
+    constexpr int vpr = 2 * CP;                       // float4 per row
+    const int total = rows_pad * vpr;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int e = tid + u * QNT;
+        if (e < total) img_store4<CP>(img, e / vpr, e % vpr, v[u]);
+    }
+}
+
+__device__ __forceinline__ u32x2 lds_tr(const u8 *p)
+{
+    typedef __attribute__((address_space(3))) s16x4_t *lptr;
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uint32_t)(uintptr_t)p));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward layer: tile To of the result (A-row i <-> feature 32 To + phi(i)) = GELU(bias + W . in), W an image with CP chunks
+// per part; `in`: the NK k-steps of the input.  Leaves H (fp32, for the fp32 consumers), GELU' and the split H.
+// ---------------------------------------------------------------------------------------------------------
+template <int NK, int NO, int CP, bool KEEP_H>
+__device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, const Parts (&in)[NK], f32x16 (&outH)[KEEP_H ? NO : 1],
+                                       f32x16 (&outG)[NO], Parts (&outP)[2 * NO], int m, int hi)
+{
+    constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
+    const int row = phi(m);
+    const u8 *base = img + row * ROWB;
+    const int x16 = 16 * (swz<CP>(row) ^ hi);            // chunk 2 ks + hi, swizzled: (32 ks) ^ x16
+    Parts aq[2];
+    auto issue = [&](int c, Parts &dst) {
+        const int To = c / NK, ks = c % NK;
+        const u8 *p = base + 32 * To * ROWB + ((32 * ks) ^ x16);
+        dst.h = *reinterpret_cast<const u32x4 *>(p);
+        dst.m = *reinterpret_cast<const u32x4 *>(p + PBY);
+        dst.l = *reinterpret_cast<const u32x4 *>(p + 2 * PBY);
+    };
+    issue(0, aq[0]);
+#pragma unroll
+    for (int To = 0; To < NO; ++To) {
+        f32x16 acc;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi);
+            const float4 b1 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi + 4);
+            acc[8 * a + 0] = b0.x; acc[8 * a + 1] = b0.y; acc[8 * a + 2] = b0.z; acc[8 * a + 3] = b0.w;
+            acc[8 * a + 4] = b1.x; acc[8 * a + 5] = b1.y; acc[8 * a + 6] = b1.z; acc[8 * a + 7] = b1.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = To * NK + ks;
+            if (c + 1 < NC) issue(c + 1, aq[(c + 1) & 1]);
+            mma6(aq[c & 1], in[ks], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16 H;
+        gelu_tile(acc, H, outG[To]);
+        outP[2 * To] = split8(H, 0);
+        outP[2 * To + 1] = split8(H, 1);
+        if (KEEP_H) outH[To] = H;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward through a layer's input: gate[To] *= W^T . dz, W the [32 NK / 2 ... ] image of the layer (rows = its outputs, CP chunks
+// = its inputs / 8).  The A operand W^T comes through transposing reads: lane (q = lane >> 4: kb = q >> 1, half = q & 1;
+// t = lane & 15: rr = t >> 2, u = t & 3) addresses row 16 ks + 8 kb + 4 ridx + rr, columns 32 To + 16 half + 4 sigma(u) .. + 3
+// (sigma swaps 1 and 2), and receives rows .. + 0..3 of column 32 To + phi(lane & 31): the result rows are in the gate's order.
+// ---------------------------------------------------------------------------------------------------------
+template <int NK, int NO, int CP>
+__device__ __forceinline__ void bwd_s3(const u8 *img, const Parts (&dz)[NK], f32x16 (&gate)[NO], int lane)
+{
+    constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
+    const int q = lane >> 4, kb = q >> 1, half = q & 1, t = lane & 15, rr = t >> 2, u = t & 3;
+    const int su = ((u & 1) << 1) | (u >> 1);                 // sigma(u)
+    const int ccl = 2 * half + (su >> 1), sub = 8 * (su & 1);
+    const int rl0 = 8 * kb + rr, rl1 = rl0 + 4;               // row within the 16 of a k-step, ridx = 0 / 1
+    const u8 *b0 = img + rl0 * ROWB + sub, *b1 = img + rl1 * ROWB + sub;
+    const int x0 = 16 * (ccl ^ swz<CP>(rl0)), x1 = 16 * (ccl ^ swz<CP>(rl1));
+    u32x2 rq[2][6];
+    auto issue = [&](int c, u32x2(&dst)[6]) {
+        const int To = c / NK, ks = c % NK;
+        const u8 *p0 = b0 + 16 * ks * ROWB + ((64 * To) ^ x0), *p1 = b1 + 16 * ks * ROWB + ((64 * To) ^ x1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            dst[2 * pl] = lds_tr(p0 + pl * PBY);
+            dst[2 * pl + 1] = lds_tr(p1 + pl * PBY);
+        }
+    };
+    issue(0, rq[0]);
+#pragma unroll
+    for (int To = 0; To < NO; ++To) {
+        f32x16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = To * NK + ks;
+            if (c + 1 < NC) issue(c + 1, rq[(c + 1) & 1]);
+            const u32x2(&r)[6] = rq[c & 1];
+            Parts a;
+            a.h = u32x4{r[0].x, r[0].y, r[1].x, r[1].y};
+            a.m = u32x4{r[2].x, r[2].y, r[3].x, r[3].y};
+            a.l = u32x4{r[4].x, r[4].y, r[5].x, r[5].y};
+            mma6(a, dz[ks], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gate[To][e] *= acc[e];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// split registers of an activation (NKS k-steps = 16 NKS features) of this lane's sample -> the sample-major image
+template <int NKS, int CP, int KS0, int N>      // k-steps KS0 .. KS0 + NKS - 1 of p become features 0 .. 16 NKS - 1 of the image
+__device__ __forceinline__ void stage_s3(u8 *S, const Parts (&p)[N], int srow, int hi)
+{
+    static_assert(KS0 + NKS <= N && 2 * NKS <= CP, "image too narrow");
+    constexpr int PBY = 16 * CP;
+    u8 *base = S + srow * (48 * CP);
+    const int sw = swz<CP>(srow);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        u8 *d = base + 16 * ((2 * ks + hi) ^ sw);
+        *reinterpret_cast<u32x4 *>(d) = p[KS0 + ks].h;
+        *reinterpret_cast<u32x4 *>(d + PBY) = p[KS0 + ks].m;
+        *reinterpret_cast<u32x4 *>(d + 2 * PBY) = p[KS0 + ks].l;
+    }
+}
+
+// the two k-steps of feature tile T
+template <int CP>
+__device__ __forceinline__ void stage_tile_s3(u8 *S, const Parts (&p)[2], int T, int srow, int hi)
+{
+    constexpr int PBY = 16 * CP;
+    u8 *base = S + srow * (48 * CP);
+    const int sw = swz<CP>(srow);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        u8 *d = base + 16 * ((4 * T + 2 * a + hi) ^ sw);
+        *reinterpret_cast<u32x4 *>(d) = p[a].h;
+        *reinterpret_cast<u32x4 *>(d + PBY) = p[a].m;
+        *reinterpret_cast<u32x4 *>(d + 2 * PBY) = p[a].l;
+    }
+}
+
+// one operand (feature tile `tile`, 16 samples of k-step ks) of a weight gradient from a sample-major image
+template <int CP>
+struct TrOperand {
+    const u8 *b0, *b1;
+    int x0, x1;
+    __device__ __forceinline__ TrOperand(const u8 *S, int lane)
+    {
+        const int q = lane >> 4, kb = q >> 1, half = q & 1, t = lane & 15, rr = t >> 2, u = t & 3;
+        const int ccl = 2 * half + (u >> 1), sub = 8 * (u & 1);
+        const int rl0 = 8 * kb + rr, rl1 = rl0 + 4;
+        b0 = S + rl0 * (48 * CP) + sub;
+        b1 = S + rl1 * (48 * CP) + sub;
+        x0 = 16 * (ccl ^ swz<CP>(rl0));
+        x1 = 16 * (ccl ^ swz<CP>(rl1));
+    }
+    __device__ __forceinline__ void issue(int tile, int ks, u32x2 (&dst)[6]) const
+    {
+        const u8 *p0 = b0 + 16 * ks * (48 * CP) + ((64 * tile) ^ x0), *p1 = b1 + 16 * ks * (48 * CP) + ((64 * tile) ^ x1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            dst[2 * pl] = lds_tr(p0 + pl * 16 * CP);
+            dst[2 * pl + 1] = lds_tr(p1 + pl * 16 * CP);
+        }
+    }
+};
+
+__device__ __forceinline__ Parts parts_of(const u32x2 (&r)[6])
+{
+    Parts a;
+    a.h = u32x4{r[0].x, r[0].y, r[1].x, r[1].y};
+    a.m = u32x4{r[2].x, r[2].y, r[3].x, r[3].y};
+    a.l = u32x4{r[4].x, r[4].y, r[5].x, r[5].y};
+    return a;
+}
+
+// The A operand of a weight gradient: row tile `it` of dZ^T over the 128 staged samples, 8 k-steps x 3 parts (96 registers).
+// row_sums: the bias gradient (sum over samples of every part, exact products with 1.0 accumulated in fp32) by three MFMAs per
+// k-step against a ones operand; every column of the result tile is the same vector.
+template <int CP>
+__device__ __forceinline__ void grad_a_load(const u8 *SA, int it, Parts (&A)[8], int lane)
+{
+    const TrOperand<CP> ta(SA, lane);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        u32x2 r[6];
+        ta.issue(it, ks, r);
+        A[ks] = parts_of(r);
+    }
+}
+
+__device__ __forceinline__ void grad_bias(const Parts (&A)[8], float *__restrict__ db, int it, int lane)
+{
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    f32x16 acc = {0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        acc = mfma_bf(A[ks].l, ones, acc);
+        acc = mfma_bf(A[ks].m, ones, acc);
+        acc = mfma_bf(A[ks].h, ones, acc);
+    }
+    const int hi = lane >> 5;
+    if ((lane & 31) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) db[32 * it + crow(r, hi)] = acc[r];
+    }
+}
+
+// dW tiles (it, jt0 + CS k) = A . B^T, B read from the sample-major image SB (CPB chunks per part) one k-step ahead
+template <int CPB, int NBW, int CS>
+__device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, int it, int jc, int jt_store0, float *__restrict__ dW, int ldw,
+                                           int cols_real, int lane)
+{
+    const TrOperand<CPB> tb(SB, lane);
+    const int l31 = lane & 31, hi = lane >> 5;
+    u32x2 rq[2][6];
+    tb.issue(jc, 0, rq[0]);
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+        f32x16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int c = 8 * k + ks;
+            if (c + 1 < 8 * NBW) tb.issue(jc + CS * ((c + 1) / 8), (c + 1) % 8, rq[(c + 1) & 1]);
+            mma6(A[ks], parts_of(rq[c & 1]), acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int i = 32 * (jt_store0 + jc + CS * k) + l31;
+        if (i < cols_real) {
+            float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
+        }
+    }
+}
+
+// LDS pool (bytes): [IMG2: W2 image, later SA][IMG1: W1 image, later SB][RW3: W3 copy fp32, later RC dY^T][biases][norm][s_part][s_red]
+constexpr int kS3Img2 = 128 * 768;
+constexpr int kS3Img1 = 128 * 384;
+constexpr int kS3W3 = 16 * 132 * 4;
+static_assert(kS3W3 >= 16 * PLD * 4, "dY^T overlays the W3 copy");
+static_assert(kS3Img2 >= 128 * PLD * 4, "H2^T (fp32, feature-major) overlays the W2 image");
+constexpr int kS3Small = (128 + 128 + 16 + 64 + 64 + QNW * 16 + 16) * 4;
+constexpr size_t kS3LdsBytes = (size_t)kS3Img2 + kS3Img1 + kS3W3 + kS3Small;
+static_assert(kS3LdsBytes <= 160 * 1024, "LDS budget");
+
+template <bool ACTOR, int KXP, int N1, int N2, bool VEC>     // KXP: input tiles of 32 (1: S <= 32, 2: S <= 64); 0: S <= 8
+__device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
+{
+    constexpr bool TINY = KXP == 0;
+    constexpr int KX = TINY ? 1 : KXP;
+    constexpr int NK1 = TINY ? 1 : 2 * KX;                  // k-steps of 16 of the input actually multiplied
+    constexpr int CP1 = 4 * KX, CP2 = 4 * N1, CPH2 = 4 * N2; // chunks per part: W1 / X images, W2 / H1 / dZ1 images, dZ2 image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, hi = lane >> 5;
+    constexpr int net = ACTOR ? 0 : 1;
+    constexpr int h1 = 32 * N1, h2 = 32 * N2;
+    const int S = g.S, OUT = ACTOR ? g.A : 1;
+    const Dims d{S, h1, h2, OUT};
+    const float *P = g.P[net];
+    const float *std_log = P + d.oStd();
+
+    u8 *IMG2 = smem;                        // W2 image [h2][3][h1 bf16]; later SA (the dZ^T operand) / H2^T fp32
+    u8 *IMG1 = IMG2 + kS3Img2;              // W1 image [h1][3][32 KX bf16]; later SB (the other operand)
+    float *RW3 = reinterpret_cast<float *>(IMG1 + kS3Img1);     // W3 copy [16][ld3] fp32 (rows >= OUT zero); later RC = dY^T [16][PLD]
+    float *s_b1 = RW3 + kS3W3 / 4, *s_b2 = s_b1 + 128, *s_b3 = s_b2 + 128;
+    float *s_nr = s_b3 + 16, *s_nn = s_nr + 64;                 // input normalisation: x * nr + nn
+    float *s_part = s_nn + 64;
+    float *s_red = s_part + QNW * 16;
+    constexpr int ld3 = lds_ld(128);
+
+    PROF(0);
+    // ---- prologue, trip 1: the sample id, the weights, the biases, the normalisation constants
+    const int col = 32 * wave + m;                         // sample slot inside the workgroup
+    const int64_t bidx = (int64_t)blockIdx.x * PB + col;
+    const bool valid = bidx < g.B;
+    const int64_t id = g.ids[valid ? bidx : 0];
+    float4 c1[N1 * KX], c2[N1 * N2], c3[2];
+    copy_load<VEC, N1 * KX, QNT>(c1, P + d.oW1(), h1, S, h1, 32 * KX, tid);
+    copy_load<VEC, N1 * N2, QNT>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
+    copy_load<VEC, 2, QNT>(c3, P + d.oW3(), OUT, h2, 16, h2, tid);
+    const float bias_pre = (tid < 128) ? (tid < h1 ? P[d.ob1() + tid] : 0.f) : (tid - 128 < h2 ? P[d.ob2() + tid - 128] : 0.f);
+    float b3_pre = 0.f;
+    if (tid < 16) b3_pre = (tid < OUT) ? P[d.ob3() + tid] : 0.f;
+    float nr_pre = 0.f, nn_pre = 0.f;
+    if (tid < 64 && tid < S) {
+        nr_pre = __builtin_amdgcn_rcpf(g.sd[net][tid] + 1e-4f);        // (x - avg) / (std + 1e-4)  (AgentPPO.py:360-361)
+        nn_pre = -(g.avg[net][tid] * nr_pre);
+    }
+
+    // ---- trip 2: id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
+    int64_t n_, t_;
+    if (g.H * g.N <= 0x7fffffffLL) {
+        const uint32_t i32 = (uint32_t)id, h32 = (uint32_t)g.H, n32 = i32 / h32;
+        n_ = n32;
+        t_ = i32 - n32 * h32;
+    } else {
+        n_ = id / g.H;
+        t_ = id - n_ * g.H;
+    }
+    const int64_t row = valid ? t_ * g.N + n_ : 0;          // padding slots read row 0 (finite data) and carry zero weight
+    // this lane's own state row, in the operand order: features 16 ks + 8 hi + 0..7 of k-step ks
+    float4 XR[NK1][2];
+    {
+        const float *xrow = g.states + row * S;
+#pragma unroll
+        for (int ks = 0; ks < NK1; ++ks) {
+            XR[ks][0] = load4<VEC>(xrow, 16 * ks + 8 * hi, S);
+            XR[ks][1] = load4<VEC>(xrow, 16 * ks + 8 * hi + 4, S);
+        }
+    }
+    const float um = (valid && g.unmasks[row]) ? 1.f : 0.f;
+    const float xa = ACTOR ? g.logprobs[row] : g.reward_sums[row];
+    const float xb = ACTOR ? g.advantages[row] : 0.f;
+    float act_pre[4] = {0.f, 0.f, 0.f, 0.f}, sl_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ACTOR) {
+        const bool act4 = (OUT & 3) == 0 && (reinterpret_cast<uintptr_t>(g.actions) & 15) == 0;      // uniform
+        if (act4) {
+            const float4 v = *reinterpret_cast<const float4 *>(g.actions + row * OUT + min(4 * hi, OUT - 4));
+            act_pre[0] = v.x; act_pre[1] = v.y; act_pre[2] = v.z; act_pre[3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ac = min(4 * hi + j, OUT - 1);
+            if (!act4) act_pre[j] = g.actions[row * OUT + ac];
+            sl_pre[j] = std_log[ac];
+        }
+    }
+    // ---- the weight images (split here; every workgroup converts the same 24k weights -- see DESIGN.md for the pre-split plan)
+    img_store<N1 * KX, CP1>(c1, IMG1, h1, tid);
+    img_store<N1 * N2, CP2>(c2, IMG2, h2, tid);
+#pragma unroll
+    for (int e = tid; e < kS3W3 / 16; e += QNT) reinterpret_cast<float4 *>(RW3)[e] = zero4();
+    s_b1[tid] = bias_pre;                                   // s_b1 | s_b2 contiguous
+    if (tid < 16) s_b3[tid] = b3_pre;
+    if (tid < 64) { s_nr[tid] = nr_pre; s_nn[tid] = nn_pre; }
+    PROF_NV(1);
+    lds_barrier();                                                   // (0a) images, biases, constants visible; RW3 zeroed
+    PROF_NV(2);
+    copy_store<2, QNT>(c3, RW3, ld3, 16, h2, tid);                  // visible after (0b)
+    // ---- normalise and split the own row
+    Parts Xp[NK1];
+#pragma unroll
+    for (int ks = 0; ks < NK1; ++ks) {
+        const float *nr = s_nr + 16 * ks + 8 * hi, *nn = s_nn + 16 * ks + 8 * hi;
+        const float4 r0 = *reinterpret_cast<const float4 *>(nr), r1 = *reinterpret_cast<const float4 *>(nr + 4);
+        const float4 n0 = *reinterpret_cast<const float4 *>(nn), n1 = *reinterpret_cast<const float4 *>(nn + 4);
+        f32x16 t;
+        t[0] = fmaf(XR[ks][0].x, r0.x, n0.x); t[1] = fmaf(XR[ks][0].y, r0.y, n0.y);
+        t[2] = fmaf(XR[ks][0].z, r0.z, n0.z); t[3] = fmaf(XR[ks][0].w, r0.w, n0.w);
+        t[4] = fmaf(XR[ks][1].x, r1.x, n1.x); t[5] = fmaf(XR[ks][1].y, r1.y, n1.y);
+        t[6] = fmaf(XR[ks][1].z, r1.z, n1.z); t[7] = fmaf(XR[ks][1].w, r1.w, n1.w);
+        Xp[ks] = split8(t, 0);
+    }
+    f32x16 G1[N1], H2[N2], G2[N2], Hdummy[1];
+    Parts H1p[2 * N1], H2p_unused[2 * N2];
+    fwd_s3<NK1, N1, CP1, false>(IMG1, s_b1, Xp, Hdummy, G1, H1p, m, hi);
+    PROF_NV(3);
+    lds_barrier();                                                   // (0b) W3 copy visible; every wave is done with the W1 image
+    u8 *SA = IMG2, *SB = IMG1;
+    {
+        // the input goes to its place for dW1 right away (SB = the W1 image's bytes): 12 registers per k-step less from here on.
+        // The X image always has CP1 chunks per part; k-steps the forward skipped (TINY) are zero
+        Parts Xs[2 * KX];
+#pragma unroll
+        for (int ks = 0; ks < 2 * KX; ++ks) {
+            if (ks < NK1) Xs[ks] = Xp[ks];
+            else { Xs[ks].h = Xs[ks].m = Xs[ks].l = u32x4{0u, 0u, 0u, 0u}; }
+        }
+        stage_s3<2 * KX, CP1, 0>(SB, Xs, col, hi);
+    }
+    fwd_s3<2 * N1, N2, CP2, true>(IMG2, s_b2, H1p, H2, G2, H2p_unused, m, hi);
+    PROF(4);
+
+    // ---- output layer (fp32, as in ppo_step_w4_impl.h; H2[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j here)
+    float Y[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ACTOR) {
+        f32x4 ya[2][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ya[q >> 1][q & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *w3a = RW3 + (lane & 3) * ld3 + 8 * hi;
+        constexpr int DEPTH = 2;
+        float4 wq[DEPTH + 1][2];
+        auto issue = [&](int c, float4(&dst)[2]) {
+            const int T = c >> 2, gq = c & 3;
+            dst[0] = *reinterpret_cast<const float4 *>(w3a + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
+            dst[1] = *reinterpret_cast<const float4 *>(w3a + 4 * ld3 + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
+        };
+#pragma unroll
+        for (int c = 0; c < DEPTH; ++c) issue(c, wq[c]);
+#pragma unroll
+        for (int c = 0; c < 4 * N2; ++c) {
+            const int T = c >> 2, gq = c & 3;
+            if (c + DEPTH < 4 * N2) issue(c + DEPTH, wq[(c + DEPTH) % (DEPTH + 1)]);
+            const float4 w0 = wq[c % (DEPTH + 1)][0], w1 = wq[c % (DEPTH + 1)][1];
+            const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ya[0][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], H2[T][4 * gq + j], ya[0][j & 1], 0, 0, 0);
+                ya[1][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], H2[T][4 * gq + j], ya[1][j & 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 b4 = *reinterpret_cast<const float4 *>(s_b3 + 4 * hi);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = ya[0][0][j] + ya[0][1][j], hi_ = ya[1][0][j] + ya[1][1][j];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
+            Y[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) + bb[j];   // lanes < 32: output j; lanes >= 32: output 4 + j
+        }
+    } else {
+        f32x2 yp = {0.f, 0.f}, yq = {0.f, 0.f};
+        const float *w3 = RW3 + 8 * hi;
+        float4 wv[4 * N2];
+#pragma unroll
+        for (int c = 0; c < 4 * N2; ++c) wv[c] = *reinterpret_cast<const float4 *>(w3 + 32 * (c >> 2) + 16 * ((c & 3) >> 1) + 4 * (c & 1));
+#pragma unroll
+        for (int c = 0; c < 4 * N2; ++c) {
+            const int T = c >> 2, gq = c & 3;
+            yp = f32x2{wv[c].x, wv[c].y} * f32x2{H2[T][4 * gq + 0], H2[T][4 * gq + 1]} + yp;
+            yq = f32x2{wv[c].z, wv[c].w} * f32x2{H2[T][4 * gq + 2], H2[T][4 * gq + 3]} + yq;
+        }
+        const float s = (yp.x + yp.y) + (yq.x + yq.y);
+        Y[0] = s + __shfl_xor(s, 32, 64) + s_b3[0];
+    }
+    PROF(5);
+
+    // ---- objective and dL/dY for this lane's outputs a = 4 hi + j   (AgentPPO.py:189-204)
+    float dY[4] = {0.f, 0.f, 0.f, 0.f};
+    float loss0 = 0.f, loss1 = 0.f;
+    float dsl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!ACTOR) {
+        const float diff = Y[0] - xa;
+        const bool head = hi == 0;
+        loss0 = head ? diff * diff * um : 0.f;
+        dY[0] = head ? 2.f * diff * um * g.inv_batch : 0.f;
+    } else {
+        float diffv[4], ivar[4];
+        float lp = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = 4 * hi + j;
+            const float sl = sl_pre[j];
+            const float diff = act_pre[j] - Y[j];
+            const bool on = a < OUT;
+            ivar[j] = __expf(-2.f * sl);
+            diffv[j] = on ? diff : 0.f;
+            const float term = -(diff * diff) * (0.5f * ivar[j]) - sl - kLogSqrt2PiF;
+            lp += on ? term : 0.f;
+        }
+        lp += __shfl_xor(lp, 32, 64);
+        const PpoActorTerms o = ppo_actor_terms(g.objective, xb, lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, true);
+        if (hi == 0) {
+            loss0 = valid ? o.logged : 0.f;
+            loss1 = valid ? o.ent_mask : 0.f;
+        }
+        const float dlp = (valid ? o.dlp : 0.f) * g.inv_batch;
+        const float ent_term = (valid ? o.ent_w : 0.f) * g.inv_batch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = 4 * hi + j < OUT;
+            dY[j] = on ? dlp * (diffv[j] * ivar[j]) : 0.f;
+            dsl[j] = on ? dlp * (diffv[j] * diffv[j] * ivar[j] - 1.f) + ent_term : 0.f;
+        }
+    }
+
+    // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 8 outputs: four fp32 k-pairs; A-row m carries feature 32 To + phi(m));
+    //      dZ1 = (W2^T dZ2) * GELU'(z1)
+    PROF(6);
+    Parts dZ2p[2 * N2];
+    {
+        const int pm = phi(m);
+        float w3[N2][4];
+#pragma unroll
+        for (int To = 0; To < N2; ++To) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w3[To][j] = RW3[(4 * hi + j) * ld3 + 32 * To + pm];
+        }
+#pragma unroll
+        for (int To = 0; To < N2; ++To) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma32(w3[To][j], dY[j], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G2[To][r] *= acc[r];
+            dZ2p[2 * To] = split8(G2[To], 0);
+            dZ2p[2 * To + 1] = split8(G2[To], 1);
+        }
+    }
+    bwd_s3<2 * N2, N1, CP2>(IMG2, dZ2p, G1, lane);                   // G1 (the gate) <- dZ1
+    PROF(7);
+    lds_barrier();                                                   // (1) every wave is done with the weight images and W3
+    PROF(8);
+
+    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
+    float *RC = RW3;
+    // ---- layer 1: dW1 = dZ1^T . X, db1   (dZ1 is split and stored tile by tile: 24 registers in flight, not 96)
+#pragma unroll
+    for (int T = 0; T < N1; ++T) {
+        Parts pz[2];
+        pz[0] = split8(G1[T], 0);
+        pz[1] = split8(G1[T], 1);
+        stage_tile_s3<CP2>(SA, pz, T, col, hi);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        RC[(4 * hi + j) * PLD + col] = dY[j];
+        RC[(8 + 4 * hi + j) * PLD + col] = dsl[j];       // rows 8..15: per-sample dL/dstd_log (zero for the critic)
+    }
+    lds_barrier();                                                   // (2)
+    PROF(9);
+    {
+        // wave w owns row tile it = w % N1; the CS = 4 / N1 waves of a row tile split the KX column tiles
+        constexpr int CS = 4 / N1, NBW = (KX + CS - 1) / CS;
+        const int it = wave % N1, jc = wave / N1;
+        if (jc < KX) {
+            Parts A[8];
+            grad_a_load<CP2>(SA, it, A, lane);
+            grad_tiles<CP1, NBW, CS>(A, SB, it, jc, 0, slab + d.oW1(), S, S, lane);
+            if (jc == 0) grad_bias(A, slab + d.ob1(), it, lane);
+        }
+    }
+    PROF(10);
+    lds_barrier();                                                   // (3) dZ1, X images consumed
+
+    // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2^T staged feature-major in fp32); the first half of
+    //      H1 goes to SB meanwhile
+    {
+        float *T2 = reinterpret_cast<float *>(SA);
+#pragma unroll
+        for (int t = 0; t < N2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T2[(32 * t + 16 * (r >> 3) + 8 * hi + (r & 7)) * PLD + col] = H2[t][r];
+        }
+    }
+    constexpr int NH1 = (N1 > 2) ? 2 : 1;                            // passes over H1's features: SB holds 64 of them
+    constexpr int KSH = 2 * N1 / NH1;                                // k-steps (16 features) per pass
+    constexpr int CPB2 = KSH / 2 * 4;                                // chunks per part of the SB image in dW2
+    stage_s3<KSH, CPB2, 0>(SB, H1p, col, hi);
+    lds_barrier();                                                   // (4)
+    PROF(11);
+    {
+        const float *T2 = reinterpret_cast<const float *>(SA);
+        const int l15 = lane & 15, q = lane >> 4;
+        f32x2 hs = {0.f, 0.f};
+#pragma unroll
+        for (int rep = 0; rep < (2 * N2 + QNW - 1) / QNW; ++rep) {
+            const int it = wave + QNW * rep;                            // 16-column tile of dW3 (wave-uniform)
+            if (it >= 2 * N2) break;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float *a = RC + l15 * PLD + 4 * q;
+            const float *b = T2 + (16 * it + l15) * PLD + 4 * q;
+#pragma unroll
+            for (int j = 0; j < PB / 16; ++j) {
+                const float4 av = *reinterpret_cast<const float4 *>(a + 16 * j), bv = *reinterpret_cast<const float4 *>(b + 16 * j);
+                acc = mfma16(av.x, bv.x, acc);
+                acc = mfma16(av.y, bv.y, acc);
+                acc = mfma16(av.z, bv.z, acc);
+                acc = mfma16(av.w, bv.w, acc);
+                if (rep == 0) {
+                    hs += f32x2{av.x, av.y};
+                    hs += f32x2{av.z, av.w};
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a_ = 4 * q + r;
+                if (a_ < OUT) __builtin_nontemporal_store(acc[r], slab + d.oW3() + (size_t)a_ * h2 + 16 * it + l15);
+            }
+        }
+        float s = hs.x + hs.y;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (wave == 0 && q == 0) {
+            if (l15 < OUT) slab[d.ob3() + l15] = s;
+            else if (ACTOR && l15 >= 8 && l15 - 8 < OUT) slab[d.oStd() + l15 - 8] = s;
+        }
+    }
+    lds_barrier();                                                   // (5) H2^T consumed
+    stage_s3<2 * N2, CPH2, 0>(SA, dZ2p, col, hi);
+    lds_barrier();                                                   // (6)
+    PROF(12);
+
+    // ---- layer 2: dW2 = dZ2^T . H1, db2  (wave w: row tile w % N2; its column tiles pass by pass)
+    {
+        constexpr int CS = 4 / N2;
+        constexpr int TPP = N1 / NH1;                                // column tiles per pass
+        constexpr int NBW = (TPP + CS - 1) / CS;
+        const int it = wave % N2, jc = wave / N2;
+        Parts A[8];
+        grad_a_load<CPH2>(SA, it, A, lane);
+        if (jc < TPP) grad_tiles<CPB2, NBW, CS>(A, SB, it, jc, 0, slab + d.oW2(), h1, h1, lane);
+        if (NH1 == 2) {
+            lds_barrier();                                           // (7) first half of H1 consumed
+            stage_s3<KSH, CPB2, (NH1 == 2 ? KSH : 0)>(SB, H1p, col, hi);
+            lds_barrier();                                           // (8)
+            if (jc < TPP) grad_tiles<CPB2, NBW, CS>(A, SB, it, jc, TPP, slab + d.oW2(), h1, h1, lane);
+        }
+        if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
+    }
+    PROF(13);
+
+    // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
+    const float t0 = block_sum(loss0, s_red);
+    const float t1 = block_sum(loss1, s_red);
+    if (tid == 0) {
+        float *logs = g.slabs + (size_t)blockIdx.x * g.stride + g.Pa + g.Pc;
+        if (ACTOR) {
+            float ent = 0.f;
+            for (int a = 0; a < OUT; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));
+            logs[1] = t0 * g.inv_batch;
+            logs[2] = ent * t1 * g.inv_batch;
+        } else {
+            logs[0] = t0 * g.inv_batch;
+            logs[3] = 0.f;
+            for (int64_t e = g.Pa + g.Pc + 4; e < g.stride; ++e) logs[e - (g.Pa + g.Pc)] = 0.f;
+        }
+    }
+}
+
+template <int KX, int N1, int N2, bool VEC>
+__global__ __launch_bounds__(QNT) void ppo_step_s3_kernel(Ppo2Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem_s3[];
+    if (blockIdx.y == 0) ppo_block_s3<true, KX, N1, N2, VEC>(g, smem_s3);
+    else ppo_block_s3<false, KX, N1, N2, VEC>(g, smem_s3);
+}
+
+template <int KX, int N1, int N2, bool VEC>
+int launch_s3(const Ppo2Args &g, int n_slabs, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = erl_hip_status(hipFuncSetAttribute((const void *)ppo_step_s3_kernel<KX, N1, N2, VEC>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS3LdsBytes),
+                                "hipFuncSetAttribute(ppo_step_s3_kernel)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC>), dim3(n_slabs, 2), dim3(QNT), kS3LdsBytes, stream, g);
+    return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");
+}
+
+template <int N1, int N2>
+int launch_s3_shape(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream)
+{
+    if (g.S <= 8) return launch_s3<0, N1, N2, false>(g, n_slabs, stream);
+    if (vec) return g.S > 32 ? launch_s3<2, N1, N2, true>(g, n_slabs, stream) : launch_s3<1, N1, N2, true>(g, n_slabs, stream);
+    return g.S > 32 ? launch_s3<2, N1, N2, false>(g, n_slabs, stream) : launch_s3<1, N1, N2, false>(g, n_slabs, stream);
+}
+
+}  // namespace

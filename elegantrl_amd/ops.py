@@ -296,6 +296,21 @@ def ppo_num_slabs(batch_size: int) -> int:
     return lib().erl_ppo_num_slabs(batch_size)
 
 
+PPO_ARITH = {"auto": 0, "f32": 1, "split": 2}
+
+
+def ppo_set_arith(arith: str) -> str:
+    """arithmetic of K6's large products: "f32" (fp32 MFMA), "split" (three-way bf16 operand split on the bf16 matrix pipe,
+    fp32-equivalent) or "auto" (library default / ERL_K6_ARITH).  Returns the previous setting."""
+    prev = lib().erl_ppo_set_arith(PPO_ARITH[arith])
+    return {v: k for k, v in PPO_ARITH.items()}[prev]
+
+
+def ppo_arith_in_use(S: int, h1: int, h2: int, A: int) -> str:
+    """which arithmetic erl_ppo_step_f32 uses for this shape under the current setting ("f32" or "split")."""
+    return {1: "f32", 2: "split"}[lib().erl_ppo_arith_in_use(S, h1, h2, A)]
+
+
 def ppo_step(actor_params: TEN, critic_params: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int, h1: int,
              h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
              ids: TEN, ratio_clip: float, lambda_entropy: float, inv_batch: float, slabs: TEN, n_slabs: int,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 13
+#define ERL_ABI_VERSION 14
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -250,6 +250,18 @@ ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *cri
 #define ERL_PPO_OBJ_REFERENCE 0   /* AgentPPO.py:199   surrogate = adv*ratio*where(adv > 0, 1-clip, 1+clip) */
 #define ERL_PPO_OBJ_CANONICAL 1   /* helloworld_PPO_single_file.py:337-339   min(adv*ratio, adv*clamp(ratio, 1-clip, 1+clip)) */
 #define ERL_PPO_OBJ_A2C 2         /* AgentA2C.update_objectives (AgentPPO.py:296-303)   mean(adv * logp_a), no clip / mask / entropy */
+/* Arithmetic of K6's five large products (both forward layers, the backward through W2, dW1, dW2), process-wide:
+ *   ERL_PPO_ARITH_F32    v_mfma_f32_32x32x2_f32 on fp32 operands;
+ *   ERL_PPO_ARITH_SPLIT  every fp32 operand split into three bf16 parts (exactly: h + m + l == x), six partial products per
+ *                        product on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- fp32-equivalent (csrc/ppo_step_s3_impl.h);
+ *                        shapes it does not cover take the fp32 kernel;
+ *   ERL_PPO_ARITH_AUTO   the library default (environment ERL_K6_ARITH=f32|split overrides it).
+ * Returns the previous setting. */
+#define ERL_PPO_ARITH_AUTO 0
+#define ERL_PPO_ARITH_F32 1
+#define ERL_PPO_ARITH_SPLIT 2
+ERL_API int erl_ppo_set_arith(int arith);
+ERL_API int erl_ppo_arith_in_use(int S, int h1, int h2, int A);   /* ERL_PPO_ARITH_F32 or _SPLIT for this shape under the current setting */
 ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
 ERL_API int erl_ppo_num_slabs(int64_t B);
 ERL_API int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg,

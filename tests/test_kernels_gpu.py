@@ -522,6 +522,48 @@ def test_ppo_step_gradients(ops, dev, S, h1, h2, A, B):
     np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
 
 
+S3_SHAPES = [(64, 128, 128, 8), (32, 128, 128, 3), (4, 128, 128, 8), (48, 128, 128, 6), (17, 128, 128, 5), (3, 128, 128, 1), (33, 128, 128, 2)]
+
+
+@pytest.mark.parametrize("S,h1,h2,A", S3_SHAPES)
+@pytest.mark.parametrize("B", [200, 1024, 1])
+def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
+    """K6 on the bf16 matrix pipe (every operand split into three bf16 parts, six partial products, fp32 accumulation:
+    csrc/ppo_step_s3_impl.h) against the fp64 restatement, next to the fp32-MFMA kernel on the same inputs: the split kernel
+    must be as close to fp64 as the fp32 one (its error may not exceed twice the fp32 kernel's, floor 3e-7 of the gradient's
+    scale) -- "fp32-equivalent" is asserted, not assumed."""
+    rng = np.random.default_rng(7 * S + B)
+    n_slabs, stride = ops.ppo_num_slabs(B), ops.ppo_slab_stride(S, h1, h2, A)
+    H, N = 9, 50
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = buf_ids[:6], buf_ids[6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64)
+    errs = {}
+    prev = ops.ppo_set_arith("f32")
+    try:
+        for arith in ("f32", "split"):
+            ops.ppo_set_arith(arith)
+            assert ops.ppo_arith_in_use(S, h1, h2, A) == arith
+            slabs = th.full((n_slabs, stride), float("nan"), device=dev)
+            flat = th.zeros(stride, device=dev)
+            ops.ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                         cu(critic.state_avg, dev), cu(critic.state_std, dev), S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev),
+                         0.25, 0.001, 1.0 / B, slabs, n_slabs)
+            ops.grad_reduce(slabs, n_slabs, stride, flat)
+            got = flat.cpu().numpy().astype(np.float64)
+            assert np.isfinite(got).all(), f"{arith}: a slab slot was left unwritten"
+            assert not np.any(got[Pa + Pc + 4:])
+            errs[arith] = [np.abs(got[:Pa] - ga).max() / max(1e-30, np.abs(ga).max()), np.abs(got[Pa:Pa + Pc] - gc).max() / max(1e-30, np.abs(gc).max()),
+                           np.abs(got[Pa + Pc:Pa + Pc + 3] - objs).max() / max(1e-30, np.abs(objs).max())]
+    finally:
+        ops.ppo_set_arith(prev)
+    print(f"S={S} A={A} B={B}: max error / scale vs fp64 (actor grad, critic grad, objectives): f32 MFMA {errs['f32']}, split bf16 {errs['split']}")
+    for name, e32, es in zip(("actor grad", "critic grad", "objectives"), errs["f32"], errs["split"]):
+        assert es <= max(2.0 * e32, 3e-7), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
+
+
 OBJECTIVES = {"canonical": 1, "a2c": 2}
 
 
