@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include "erl_common.h"
+#include "s3_image.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -210,11 +211,18 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
     // elements (needs the whole grid resident: erl_reduce_clip_adam_grid_ok).  Default: see kDefaultTail.
     static const int tail_env = [] { const char *e = getenv("ERL_FUSED_TAIL"); return e ? atoi(e) : kDefaultTail; }();
     const int tail = comm ? 0 : (tail_env == 2 && !erl_reduce_clip_adam_grid_ok(stride) ? 0 : tail_env);
+    // split-arithmetic minibatch kernel: its W2 images are built here once and kept current by clip + Adam (two-launch tail only)
+    S3Images images{}, *im = nullptr;
+    if (!tail && erl_ppo_arith_in_use(S, h1, h2, A) == ERL_PPO_ARITH_SPLIT) {
+        int rc = erl_s3_images_build(flat_params, S, h1, h2, A, &images, (hipStream_t)stream);
+        if (rc) return rc;
+        im = &images;
+    }
     for (int k = 0; k < update_times; ++k) {
         float *g = grads + (size_t)k * stride;
-        int rc = erl_ppo_step_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
-                                  unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
-                                  lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, stream);
+        int rc = erl_ppo_step_images_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
+                                         unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
+                                         lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, im, stream);
         if (rc) return rc;
         if (tail) {
             rc = (tail == 2 ? erl_reduce_clip_adam_grid_f32 : erl_reduce_clip_adam_f32)(slabs, n_slabs, stride, g, flat_params, exp_avg, exp_avg_sq,
@@ -226,8 +234,8 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
         // launch 1: slab reduction [+ the exchange, inside the same kernel on a peer-to-peer communicator] + partial norms;
         // launch 2: clip + Adam from the partial norms.  Gradient + the 3 logged objectives travel in one row.
         if ((rc = erl_comm_reduce_exchange_f32(comm, slabs, n_slabs, stride, g, off, len, 2, grad_scale, stream))) return rc;
-        if ((rc = erl_clip_adam_partials_f32(flat_params, g, exp_avg, exp_avg_sq, stride, off, len, 2, first_step + k, lr, beta1, beta2, eps,
-                                             max_norm, grad_scale, stream)))
+        if ((rc = erl_clip_adam_partials_images_f32(flat_params, g, exp_avg, exp_avg_sq, stride, off, len, 2, first_step + k, lr, beta1, beta2,
+                                                    eps, max_norm, grad_scale, im, stream)))
             return rc;
     }
     return ERL_OK;

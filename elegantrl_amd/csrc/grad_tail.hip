@@ -19,6 +19,7 @@
 // The same kernel with one "slab" is the standalone all-reduce (erl_comm_allreduce_sum_f32 / _f64 on a p2p communicator)
 // and the squared-norm pass after a foreign all-reduce (RCCL / torch.distributed routes: erl_grad_sq_partials_f32).
 #include "erl_common.h"
+#include "s3_image.h"
 
 namespace {
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
                                                                   float *__restrict__ m1, float *__restrict__ m2, TailGroups gr,
                                                                   const double *__restrict__ partials, int nblk, float beta1,
                                                                   float beta2, float eps, float max_norm, float grad_scale,
-                                                                  float step_size, float bc2_sqrt)
+                                                                  float step_size, float bc2_sqrt, S3Images im)
 {
     __shared__ double scratch[16];
     const int gi = blockIdx.y;
@@ -170,7 +171,23 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
         m1[off + ie] = e_m1;
         m2[off + ie] = e_m2;
         params[off + ie] = e_p;
+        // the split-arithmetic minibatch kernel's W2 image of this network follows its fp32 weights (s3_image.h)
+        if (gi < 2 && im.net[gi].img) {
+            const int64_t e = ie - im.net[gi].w2_off;
+            const int h1 = im.net[gi].h1;
+            if (e >= 0 && e < (int64_t)h1 * im.net[gi].h2) s3_image_put(im.net[gi].img, h1, (int)(e / h1), (int)(e % h1), e_p);
+        }
     }
+}
+
+// W2 images of both networks from the flat parameters [actor | critic]: one thread per weight
+__global__ __launch_bounds__(256) void s3_image_build_kernel(const float *__restrict__ params, int64_t Pa, S3Images im)
+{
+    const int gi = blockIdx.y;
+    const int h1 = im.net[gi].h1;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < (int64_t)h1 * im.net[gi].h2)
+        s3_image_put(im.net[gi].img, h1, (int)(e / h1), (int)(e % h1), params[(gi ? Pa : 0) + im.net[gi].w2_off + e]);
 }
 
 // the three logged objectives of update_net (AgentPPO.py:168-171: means over the minibatches) from the gradient rows' tails:
@@ -282,9 +299,9 @@ extern "C" int erl_grad_sq_partials_f32(float *grads, int64_t stride, const int6
     return erl_launch_reduce_exchange_f32(grads, 1, stride, grads, group_off, group_len, n_groups, grad_scale, true, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int erl_clip_adam_partials_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
-                                          const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
-                                          float beta2, float eps, float max_norm, float grad_scale, void *stream)
+int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
+                                      const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
+                                      float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, void *stream)
 {
     ERL_REQUIRE(params && grads && exp_avg && exp_avg_sq && n_groups >= 1 && step >= 1, "erl_clip_adam_partials_f32: bad argument");
     TailGroups gr;
@@ -299,6 +316,61 @@ extern "C" int erl_clip_adam_partials_f32(float *params, const float *grads, flo
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(clip_adam_partials_kernel, dim3((unsigned)erl_cdiv(longest, 1024), n_groups), dim3(1024), 0, (hipStream_t)stream, params,
                        grads, exp_avg, exp_avg_sq, gr, partials, (int)nblk, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
-                       (float)sqrt(bc2));
+                       (float)sqrt(bc2), images ? *images : S3Images{});
     ERL_LAUNCH_CHECK("erl_clip_adam_partials_f32");
+}
+
+extern "C" int erl_clip_adam_partials_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
+                                          const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
+                                          float beta2, float eps, float max_norm, float grad_scale, void *stream)
+{
+    return erl_clip_adam_partials_images_f32(params, grads, exp_avg, exp_avg_sq, stride, group_off, group_len, n_groups, step, lr, beta1, beta2,
+                                             eps, max_norm, grad_scale, nullptr, stream);
+}
+
+// Image buffers: library-owned, one pair per (device, stream) that ran an update loop (a handful in any process); rebuilt from
+// the fp32 parameters at the start of every loop, so nothing has to be kept coherent across calls.
+namespace {
+struct S3Slot {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    unsigned char *buf = nullptr;
+    size_t bytes = 0;
+};
+S3Slot g_s3_slots[16];
+}  // namespace
+
+int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, hipStream_t stream)
+{
+    int dev = 0;
+    int rc = erl_hip_status(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    const size_t one = (s3_image_bytes(h1, h2) + 1023) / 1024 * 1024, need = 2 * one;
+    S3Slot *slot = nullptr;
+    for (auto &s : g_s3_slots)
+        if (s.buf && s.device == dev && s.stream == stream) slot = &s;
+    if (!slot)
+        for (auto &s : g_s3_slots)
+            if (!s.buf) { slot = &s; break; }
+    ERL_REQUIRE(slot, "erl_s3_images_build: more than 16 (device, stream) pairs ran a split-arithmetic update loop");
+    if (slot->bytes < need) {
+        if (slot->buf) {
+            if ((rc = erl_hip_status(hipStreamSynchronize(slot->stream), "hipStreamSynchronize"))) return rc;
+            if ((rc = erl_hip_status(hipFree(slot->buf), "hipFree"))) return rc;
+            slot->buf = nullptr;
+        }
+        if ((rc = erl_hip_status(hipMalloc((void **)&slot->buf, need), "hipMalloc(W2 images)"))) return rc;
+        slot->bytes = need;
+    }
+    slot->device = dev;
+    slot->stream = stream;
+    const int64_t Pa = (int64_t)h1 * S + h1 + (int64_t)h2 * h1 + h2 + (int64_t)A * h2 + A + A;     // actor block incl. action_std_log
+    for (int gi = 0; gi < 2; ++gi) {
+        out->net[gi].img = slot->buf + gi * one;
+        out->net[gi].w2_off = (int64_t)h1 * S + h1;
+        out->net[gi].h1 = h1;
+        out->net[gi].h2 = h2;
+    }
+    hipLaunchKernelGGL(s3_image_build_kernel, dim3((unsigned)erl_cdiv((int64_t)h1 * h2, 256), 2), dim3(256), 0, stream, flat_params, Pa, *out);
+    ERL_LAUNCH_CHECK("erl_s3_images_build");
 }

@@ -20,6 +20,7 @@ struct Ppo2Args {
     int objective;        // ERL_PPO_OBJ_* (ppo_objective.h)
     float *slabs;
     int64_t stride, Pa, Pc;
+    const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -115,3 +116,4 @@ int erl_ppo_w4_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stre
 // ppo_step_s3.hip
 bool erl_ppo_s3_supported(int S, int h1, int h2, int A);
 int erl_ppo_s3_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);
+int erl_ppo_s3_launch_pre(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);      // ppo_step_s3_pre.hip: W2 images given

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "ppo_step.h"
+#include "s3_image.h"
 #include <cstring>
 
 namespace {
@@ -420,7 +421,7 @@ extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile
 #endif
 
 namespace {
-constexpr int kDefaultArith = ERL_PPO_ARITH_F32;
+constexpr int kDefaultArith = ERL_PPO_ARITH_SPLIT;     // fp32-equivalent by test (tests/test_kernels_gpu.py::test_ppo_step_split_arith) and ~1.2x faster
 int g_k6_arith = ERL_PPO_ARITH_AUTO;
 int k6_arith_resolved()
 {
@@ -465,11 +466,13 @@ extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
 
 extern "C" int erl_ppo_num_slabs(int64_t B) { return B >= 1 && B < (1LL << 37) ? (int)erl_cdiv(B, PB) : -1; }
 
-extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
-                                const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
-                                const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
-                                const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
-                                float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, void *stream)
+// erl_ppo_step_f32 with the pre-split W2 images of the split-arithmetic kernel (s3_image.h; nullptr: none)
+int erl_ppo_step_images_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
+                            const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
+                            const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
+                            const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
+                            float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
+                            void *stream)
 {
     ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions && unmasks &&
                     logprobs && advantages && reward_sums && ids && slabs,
@@ -493,6 +496,8 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     g.Pa = Dims{S, h1, h2, A}.count(true);
     g.Pc = Dims{S, h1, h2, 1}.count(false);
     g.stride = erl_ppo_slab_stride(S, h1, h2, A);
+    g.w2img[0] = images ? images->net[0].img : nullptr;
+    g.w2img[1] = images ? images->net[1].img : nullptr;
     g.prof = g_ppo_prof;
     g.prof_block = g_ppo_prof_block;
     // 16-byte vector path: every row / parameter block / normalisation vector must be 16-byte aligned
@@ -506,11 +511,23 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else
     // the fp32 32x32x2 one), 8 = always the 8-wave 16x16x4 kernel
     const int form = k6_form();
-    if (erl_ppo_arith_in_use(S, h1, h2, A) == ERL_PPO_ARITH_SPLIT) rc = erl_ppo_s3_launch(g, n_slabs, vec, st);
+    if (erl_ppo_arith_in_use(S, h1, h2, A) == ERL_PPO_ARITH_SPLIT)
+        rc = (g.w2img[0] && g.w2img[1]) ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st);
     else if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 2 / 4 / 5
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
     else rc = launch<0, 0, 0, false>(g, n_slabs, st);
     erl_k6_timing_mark(st, 1);
     return rc;
+}
+
+extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
+                                const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
+                                const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
+                                const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
+                                float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, void *stream)
+{
+    return erl_ppo_step_images_f32(actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions, unmasks,
+                                   logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy, inv_batch, objective, slabs,
+                                   n_slabs, nullptr, stream);
 }

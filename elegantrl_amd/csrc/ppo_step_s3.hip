@@ -9,7 +9,7 @@ bool erl_ppo_s3_supported(int S, int h1, int h2, int A)
 
 int erl_ppo_s3_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream)
 {
-    if (g.h1 == 128 && g.h2 == 128) return launch_s3_shape<4, 4>(g, n_slabs, vec, stream);
+    if (g.h1 == 128 && g.h2 == 128) return launch_s3_shape<4, 4, false>(g, n_slabs, vec, stream);
     erl_set_error("erl_ppo_s3_launch: unsupported net [%d,%d]", g.h1, g.h2);
     return ERL_EINVAL;
 }

@@ -25,6 +25,9 @@
 //   * the 8-row output layer, dZ2 = W3^T dY and dW3 stay on the fp32 instructions of ppo_step_w4_impl.h (K <= 8 or 16 rows).
 #pragma once
 #include "ppo_step_w4_impl.h"
+#ifndef S3_EXP
+#define S3_EXP 0
+#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -85,6 +88,18 @@ __device__ __forceinline__ void mma6(const Parts &a, const Parts &b, f32x16 &acc
     acc = mfma_bf(a.h, b.h, acc);
 }
 
+// the same into two accumulators in turn: beside interleaved vector work, consecutive MFMAs must not chain on one accumulator
+// (an instruction between two MFMAs on the SAME accumulator costs ~43 cycles: the back-to-back forwarding path is lost)
+__device__ __forceinline__ void mma6_2(const Parts &a, const Parts &b, f32x16 &acc0, f32x16 &acc1)
+{
+    acc0 = mfma_bf(a.m, b.m, acc0);
+    acc1 = mfma_bf(a.l, b.h, acc1);
+    acc0 = mfma_bf(a.h, b.l, acc0);
+    acc1 = mfma_bf(a.m, b.h, acc1);
+    acc0 = mfma_bf(a.h, b.m, acc0);
+    acc1 = mfma_bf(a.h, b.h, acc1);
+}
+
 __device__ __forceinline__ int phi(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }   // bits 2 and 3 swapped
 
 // ---- LDS images: [row][3 parts][CP chunks of 16 bytes], CP = K / 8 in {4, 8, 16}; chunk c of a row sits at c ^ swz(row).
@@ -141,15 +156,33 @@ __device__ __forceinline__ u32x2 lds_tr(const u8 *p)
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uint32_t)(uintptr_t)p));
 }
 
+__device__ __forceinline__ Parts parts_of(const u32x2 (&r)[6])
+{
+    Parts a;
+    a.h = u32x4{r[0].x, r[0].y, r[1].x, r[1].y};
+    a.m = u32x4{r[2].x, r[2].y, r[3].x, r[3].y};
+    a.l = u32x4{r[4].x, r[4].y, r[5].x, r[5].y};
+    return a;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward layer: tile To of the result (A-row i <-> feature 32 To + phi(i)) = GELU(bias + W . in), W an image with CP chunks
-// per part; `in`: the NK k-steps of the input.  Leaves H (fp32, for the fp32 consumers), GELU' and the split H.
+// per part.  Leaves H (fp32) and GELU'.  The input is either split already (JIT = false: inP) or comes as fp32 tiles (inH) and
+// is split on the way -- k-step ks + 1's operand behind the MFMAs of k-step ks of tile 0 -- into inP, which the caller keeps.
+//
+// The bf16 matrix pipe runs beside the vector ALUs (32 cycles per MFMA, room for ~6 other instructions each), and a wave issues
+// in order: the vector work is cut into six stages per k-step, one behind each MFMA, pinned there by scheduling fences (left to
+// itself hipcc bunches it): the operand split under tile 0, the GELU of tile To - 1 under tile To.  Consecutive MFMAs alternate
+// between two accumulators: an instruction between two MFMAs on the SAME accumulator costs ~43 cycles (the back-to-back
+// forwarding path is lost).
 // ---------------------------------------------------------------------------------------------------------
-template <int NK, int NO, int CP, bool KEEP_H>
-__device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, const Parts (&in)[NK], f32x16 (&outH)[KEEP_H ? NO : 1],
-                                       f32x16 (&outG)[NO], Parts (&outP)[2 * NO], int m, int hi)
+template <int NK, int NO, int CP, bool JIT>
+__device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (&inP)[NK], const f32x16 (&inH)[JIT ? NK / 2 : 1],
+                                       f32x16 (&outH)[NO], f32x16 (&outG)[NO], int m, int hi)
 {
     constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
+    constexpr int EP = 16 / NK;                          // elements of the previous tile finished per k-step (NK in {1, 2, 4, 8})
+    static_assert(EP * NK == 16 && EP >= 2, "k-steps per tile");
     const int row = phi(m);
     const u8 *base = img + row * ROWB;
     const int x16 = 16 * (swz<CP>(row) ^ hi);            // chunk 2 ks + hi, swizzled: (32 ks) ^ x16
@@ -161,10 +194,63 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, const P
         dst.m = *reinterpret_cast<const u32x4 *>(p + PBY);
         dst.l = *reinterpret_cast<const u32x4 *>(p + 2 * PBY);
     };
+    f32x16 prev, prev1;
+    // exact-erf GELU (Abramowitz-Stegun 7.1.26 as in gelu2: exp(-z^2 / 2) as one v_exp_f32, half-scaled coefficients) and its
+    // derivative for elements EP ks .. EP ks + EP - 1 of tile Tp, stage s of 6 (3 instructions per element and stage).  Scalar
+    // fp32 instructions: beside bf16 MFMAs a packed-fp32 instruction costs more than the two it replaces.
+    constexpr float kC = 0.84932180028801904272f;              // sqrt(log2(e) / 2)
+    constexpr float kP = 0.3275911f * 0.70710678118654752440f / kC;
+    float z[EP], xa[EP], tt[EP], uu[EP], pp[EP];
+    auto stage = [&](int Tp, int ks, int s) {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) {
+            const int e = EP * ks + i;
+            if (s == 0) {
+                z[i] = prev[e] + prev1[e];
+                xa[i] = fabsf(z[i]) * kC;
+                tt[i] = fmaf(xa[i], kP, 1.0f);
+            } else if (s == 1) {
+                tt[i] = __builtin_amdgcn_rcpf(tt[i]);
+                uu[i] = __builtin_amdgcn_exp2f(-(xa[i] * xa[i]));
+            } else if (s == 2) {
+                pp[i] = fmaf(tt[i], 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * 1.421413741f);
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * -0.284496736f);
+            } else if (s == 3) {
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * 0.254829592f);
+                pp[i] = pp[i] * tt[i];
+                pp[i] = fmaf(-pp[i], uu[i], 0.5f);                  // 0.5 erf(|z| / sqrt 2)
+            } else if (s == 4) {
+                pp[i] = copysignf(pp[i], z[i]) + 0.5f;              // the normal cdf
+                uu[i] = z[i] * uu[i];
+            } else {
+                float y = z[i] * pp[i];
+                float gd = fmaf(uu[i], 0.39894228040143267794f, pp[i]);
+                asm volatile("" : "+v"(y), "+v"(gd));      // (LLVM sinks pure arithmetic towards its first use: see ERL_PIN4)
+                outG[Tp][e] = gd;
+                outH[Tp][e] = y;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // pair s (of 4) of the operand of k-step ks from the fp32 input
+    auto jit = [&](int ks, int s) {
+        if (JIT && ks < NK && s < 4) {
+            uint32_t h, mm, l;
+            split2(inH[ks >> 1][8 * (ks & 1) + 2 * s], inH[ks >> 1][8 * (ks & 1) + 2 * s + 1], h, mm, l);
+            asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+            inP[ks].h[s] = h; inP[ks].m[s] = mm; inP[ks].l[s] = l;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (JIT) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) jit(0, s);
+    }
     issue(0, aq[0]);
 #pragma unroll
     for (int To = 0; To < NO; ++To) {
-        f32x16 acc;
+        f32x16 acc, acc1 = {0};
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float4 b0 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi);
@@ -172,32 +258,61 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, const P
             acc[8 * a + 0] = b0.x; acc[8 * a + 1] = b0.y; acc[8 * a + 2] = b0.z; acc[8 * a + 3] = b0.w;
             acc[8 * a + 4] = b1.x; acc[8 * a + 5] = b1.y; acc[8 * a + 6] = b1.z; acc[8 * a + 7] = b1.w;
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             const int c = To * NK + ks;
             if (c + 1 < NC) issue(c + 1, aq[(c + 1) & 1]);
-            mma6(aq[c & 1], in[ks], acc);
+            const Parts &a = aq[c & 1], &b = inP[ks];
+            auto fill = [&](int s) {
+                if (To > 0) stage(To - 1, ks, s);
+                else jit(ks + 1, s);
+            };
+            acc = mfma_bf(a.m, b.m, acc);
             __builtin_amdgcn_sched_barrier(0);
+            fill(0);
+            acc1 = mfma_bf(a.l, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(1);
+            acc = mfma_bf(a.h, b.l, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(2);
+            acc1 = mfma_bf(a.m, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(3);
+            acc = mfma_bf(a.h, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(4);
+            acc1 = mfma_bf(a.h, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(5);
         }
-        f32x16 H;
-        gelu_tile(acc, H, outG[To]);
-        outP[2 * To] = split8(H, 0);
-        outP[2 * To + 1] = split8(H, 1);
-        if (KEEP_H) outH[To] = H;
-        __builtin_amdgcn_sched_barrier(0);
+        prev = acc;
+        prev1 = acc1;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) stage(NO - 1, ks, s);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// backward through a layer's input: gate[To] *= W^T . dz, W the [32 NK / 2 ... ] image of the layer (rows = its outputs, CP chunks
-// = its inputs / 8).  The A operand W^T comes through transposing reads: lane (q = lane >> 4: kb = q >> 1, half = q & 1;
-// t = lane & 15: rr = t >> 2, u = t & 3) addresses row 16 ks + 8 kb + 4 ridx + rr, columns 32 To + 16 half + 4 sigma(u) .. + 3
-// (sigma swaps 1 and 2), and receives rows .. + 0..3 of column 32 To + phi(lane & 31): the result rows are in the gate's order.
+// backward through a layer's input: dzin[To] = gate[To] * (W^T . dz), W the image of the layer (rows = its outputs, CP chunks
+// per part = its inputs / 8).  dz comes as fp32 tiles (dzH) and is split on the way into dzP (kept by the caller) behind tile
+// 0's MFMAs; behind tile To's MFMAs the gate product of tile To - 1 is formed and split (outP), so that the weight-gradient
+// staging finds registers to store.  The A operand W^T comes through transposing reads: lane (q = lane >> 4: kb = q >> 1,
+// half = q & 1; t = lane & 15: rr = t >> 2, u = t & 3) addresses row 16 ks + 8 kb + 4 ridx + rr, columns 32 To + 16 half +
+// 4 sigma(u) .. + 3 (sigma swaps 1 and 2), and receives rows .. + 0..3 of column 32 To + phi(lane & 31): the result rows are in
+// the gate's order.
 // ---------------------------------------------------------------------------------------------------------
 template <int NK, int NO, int CP>
-__device__ __forceinline__ void bwd_s3(const u8 *img, const Parts (&dz)[NK], f32x16 (&gate)[NO], int lane)
+__device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f32x16 (&dzH)[NK / 2], const f32x16 (&gate)[NO],
+                                       Parts (&outP)[2 * NO], int lane)
 {
     constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
+    constexpr int EP = 16 / NK;
+    static_assert(EP * NK == 16 && EP == 2, "the gate stage handles one pair per k-step (layers of 128 outputs)");
     const int q = lane >> 4, kb = q >> 1, half = q & 1, t = lane & 15, rr = t >> 2, u = t & 3;
     const int su = ((u & 1) << 1) | (u >> 1);                 // sigma(u)
     const int ccl = 2 * half + (su >> 1), sub = 8 * (su & 1);
@@ -214,25 +329,72 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, const Parts (&dz)[NK], f32
             dst[2 * pl + 1] = lds_tr(p1 + pl * PBY);
         }
     };
+    auto jit = [&](int ks, int s) {
+        if (ks < NK && s < 4) {
+            uint32_t h, mm, l;
+            split2(dzH[ks >> 1][8 * (ks & 1) + 2 * s], dzH[ks >> 1][8 * (ks & 1) + 2 * s + 1], h, mm, l);
+            asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+            dzP[ks].h[s] = h; dzP[ks].m[s] = mm; dzP[ks].l[s] = l;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x16 prev, prev1;
+    float v0, v1;
+    // elements 2 ks, 2 ks + 1 of tile Tp: the gate product (stage 0) and its split (stage 1)
+    auto gstage = [&](int Tp, int ks, int s) {
+        const int e = 2 * ks;
+        if (s == 0) {
+            v0 = gate[Tp][e] * (prev[e] + prev1[e]);
+            v1 = gate[Tp][e + 1] * (prev[e + 1] + prev1[e + 1]);
+        } else if (s == 1) {
+            uint32_t h, mm, l;
+            split2(v0, v1, h, mm, l);
+            asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+            Parts &o = outP[2 * Tp + (e >> 3)];
+            o.h[(e & 7) >> 1] = h; o.m[(e & 7) >> 1] = mm; o.l[(e & 7) >> 1] = l;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) jit(0, s);
     issue(0, rq[0]);
 #pragma unroll
     for (int To = 0; To < NO; ++To) {
-        f32x16 acc = {0};
+        f32x16 acc = {0}, acc1 = {0};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             const int c = To * NK + ks;
             if (c + 1 < NC) issue(c + 1, rq[(c + 1) & 1]);
-            const u32x2(&r)[6] = rq[c & 1];
-            Parts a;
-            a.h = u32x4{r[0].x, r[0].y, r[1].x, r[1].y};
-            a.m = u32x4{r[2].x, r[2].y, r[3].x, r[3].y};
-            a.l = u32x4{r[4].x, r[4].y, r[5].x, r[5].y};
-            mma6(a, dz[ks], acc);
+            const Parts a = parts_of(rq[c & 1]);
+            const Parts &b = dzP[ks];
+            auto fill = [&](int s) {
+                if (To > 0) gstage(To - 1, ks, s);
+                else jit(ks + 1, s);
+            };
+            acc = mfma_bf(a.m, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(0);
+            acc1 = mfma_bf(a.l, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(1);
+            acc = mfma_bf(a.h, b.l, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(2);
+            acc1 = mfma_bf(a.m, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(3);
+            acc = mfma_bf(a.h, b.m, acc);
+            acc1 = mfma_bf(a.h, b.h, acc1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        prev = acc;
+        prev1 = acc1;
+    }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) gate[To][e] *= acc[e];
-        __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < NK; ++ks) {
+        gstage(NO - 1, ks, 0);
+        gstage(NO - 1, ks, 1);
     }
 }
 
@@ -294,15 +456,6 @@ struct TrOperand {
         }
     }
 };
-
-__device__ __forceinline__ Parts parts_of(const u32x2 (&r)[6])
-{
-    Parts a;
-    a.h = u32x4{r[0].x, r[0].y, r[1].x, r[1].y};
-    a.m = u32x4{r[2].x, r[2].y, r[3].x, r[3].y};
-    a.l = u32x4{r[4].x, r[4].y, r[5].x, r[5].y};
-    return a;
-}
 
 // The A operand of a weight gradient: row tile `it` of dZ^T over the 128 staged samples, 8 k-steps x 3 parts (96 registers).
 // row_sums: the bias gradient (sum over samples of every part, exact products with 1.0 accumulated in fp32) by three MFMAs per
@@ -374,7 +527,9 @@ constexpr int kS3Small = (128 + 128 + 16 + 64 + 64 + QNW * 16 + 16) * 4;
 constexpr size_t kS3LdsBytes = (size_t)kS3Img2 + kS3Img1 + kS3W3 + kS3Small;
 static_assert(kS3LdsBytes <= 160 * 1024, "LDS budget");
 
-template <bool ACTOR, int KXP, int N1, int N2, bool VEC>     // KXP: input tiles of 32 (1: S <= 32, 2: S <= 64); 0: S <= 8
+// PRE: the W2 image comes ready from memory (g.w2img: built by the update loop, refreshed by clip + Adam) by LDS-DMA under the
+// first layer; otherwise every workgroup splits W2 itself (stand-alone calls of erl_ppo_step_f32)
+template <bool ACTOR, int KXP, int N1, int N2, bool VEC, bool PRE>     // KXP: input tiles of 32 (1: S <= 32, 2: S <= 64); 0: S <= 8
 __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
 {
     constexpr bool TINY = KXP == 0;
@@ -405,9 +560,8 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     const int64_t bidx = (int64_t)blockIdx.x * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
-    float4 c1[N1 * KX], c2[N1 * N2], c3[2];
+    float4 c1[N1 * KX], c2[PRE ? 1 : N1 * N2], c3[2];
     copy_load<VEC, N1 * KX, QNT>(c1, P + d.oW1(), h1, S, h1, 32 * KX, tid);
-    copy_load<VEC, N1 * N2, QNT>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
     copy_load<VEC, 2, QNT>(c3, P + d.oW3(), OUT, h2, 16, h2, tid);
     const float bias_pre = (tid < 128) ? (tid < h1 ? P[d.ob1() + tid] : 0.f) : (tid - 128 < h2 ? P[d.ob2() + tid - 128] : 0.f);
     float b3_pre = 0.f;
@@ -456,9 +610,21 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
             sl_pre[j] = std_log[ac];
         }
     }
+    // ---- the W2 image: requested LAST (the memory pipe returns W1 and the rows first), issued while those are in flight (an LDS-DMA
+    // piece costs its wave 60-180 cycles of issue: here they fall into the wait for the gathered rows), landing under the first layer
+    if constexpr (PRE) {
+        constexpr int KB = h2 * 48 * CP2 / 1024;            // the image in 1 KB pieces: one wave instruction each, straight into LDS
+        static_assert(h2 * 48 * CP2 % 1024 == 0, "image size");
+        const u8 *src = g.w2img[net] + 16 * lane;
+#pragma unroll
+        for (int i = 0; i < (KB + QNW - 1) / QNW; ++i) {
+            const int k = wave + QNW * i;                   // wave-uniform
+            if (k < KB)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(src + 1024 * k), reinterpret_cast<float *>(IMG2 + 1024 * k), 16, 0, 0);
+        }
+    }
     // ---- the weight images (split here; every workgroup converts the same 24k weights -- see DESIGN.md for the pre-split plan)
     img_store<N1 * KX, CP1>(c1, IMG1, h1, tid);
-    img_store<N1 * N2, CP2>(c2, IMG2, h2, tid);
 #pragma unroll
     for (int e = tid; e < kS3W3 / 16; e += QNT) reinterpret_cast<float4 *>(RW3)[e] = zero4();
     s_b1[tid] = bias_pre;                                   // s_b1 | s_b2 contiguous
@@ -468,6 +634,9 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     lds_barrier();                                                   // (0a) images, biases, constants visible; RW3 zeroed
     PROF_NV(2);
     copy_store<2, QNT>(c3, RW3, ld3, 16, h2, tid);                  // visible after (0b)
+    // (without images) W2 is not needed before the second layer: requested only now, so that the prologue's burst (every CU pulls
+    // its W1 and its 32 KB of gathered rows at once, ~11 B/clk per CU) is not stretched by another 64 KB
+    if constexpr (!PRE) copy_load<VEC, N1 * N2, QNT>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
     // ---- normalise and split the own row
     Parts Xp[NK1];
 #pragma unroll
@@ -482,11 +651,13 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         t[6] = fmaf(XR[ks][1].z, r1.z, n1.z); t[7] = fmaf(XR[ks][1].w, r1.w, n1.w);
         Xp[ks] = split8(t, 0);
     }
-    f32x16 G1[N1], H2[N2], G2[N2], Hdummy[1];
-    Parts H1p[2 * N1], H2p_unused[2 * N2];
-    fwd_s3<NK1, N1, CP1, false>(IMG1, s_b1, Xp, Hdummy, G1, H1p, m, hi);
+    f32x16 H1[N1], G1[N1], H2[N2], G2[N2], Hnone[1];
+    Parts H1p[2 * N1];
+    fwd_s3<NK1, N1, CP1, false>(IMG1, s_b1, Xp, Hnone, H1, G1, m, hi);
     PROF_NV(3);
-    lds_barrier();                                                   // (0b) W3 copy visible; every wave is done with the W1 image
+    if constexpr (PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the W2 image have landed
+    else img_store<N1 * N2, CP2>(c2, IMG2, h2, tid);
+    lds_barrier();                                                   // (0b) W2 image, W3 copy visible; every wave is done with the W1 image
     u8 *SA = IMG2, *SB = IMG1;
     {
         // the input goes to its place for dW1 right away (SB = the W1 image's bytes): 12 registers per k-step less from here on.
@@ -499,7 +670,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         }
         stage_s3<2 * KX, CP1, 0>(SB, Xs, col, hi);
     }
-    fwd_s3<2 * N1, N2, CP2, true>(IMG2, s_b2, H1p, H2, G2, H2p_unused, m, hi);
+    fwd_s3<2 * N1, N2, CP2, true>(IMG2, s_b2, H1p, H1, H2, G2, m, hi);       // splits H1 into H1p on the way
     PROF(4);
 
     // ---- output layer (fp32, as in ppo_step_w4_impl.h; H2[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j here)
@@ -614,25 +785,18 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
             for (int j = 0; j < 4; ++j) acc = mfma32(w3[To][j], dY[j], acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) G2[To][r] *= acc[r];
-            dZ2p[2 * To] = split8(G2[To], 0);
-            dZ2p[2 * To + 1] = split8(G2[To], 1);
         }
     }
-    bwd_s3<2 * N2, N1, CP2>(IMG2, dZ2p, G1, lane);                   // G1 (the gate) <- dZ1
+    Parts dZ1p[2 * N1];
+    bwd_s3<2 * N2, N1, CP2>(IMG2, dZ2p, G2, G1, dZ1p, lane);         // splits dZ2 into dZ2p on the way; dZ1 leaves split
     PROF(7);
     lds_barrier();                                                   // (1) every wave is done with the weight images and W3
     PROF(8);
 
     float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
     float *RC = RW3;
-    // ---- layer 1: dW1 = dZ1^T . X, db1   (dZ1 is split and stored tile by tile: 24 registers in flight, not 96)
-#pragma unroll
-    for (int T = 0; T < N1; ++T) {
-        Parts pz[2];
-        pz[0] = split8(G1[T], 0);
-        pz[1] = split8(G1[T], 1);
-        stage_tile_s3<CP2>(SA, pz, T, col, hi);
-    }
+    // ---- layer 1: dW1 = dZ1^T . X, db1
+    stage_s3<2 * N1, CP2, 0>(SA, dZ1p, col, hi);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         RC[(4 * hi + j) * PLD + col] = dY[j];
@@ -749,35 +913,35 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     }
 }
 
-template <int KX, int N1, int N2, bool VEC>
+template <int KX, int N1, int N2, bool VEC, bool PRE>
 __global__ __launch_bounds__(QNT) void ppo_step_s3_kernel(Ppo2Args g)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_s3[];
-    if (blockIdx.y == 0) ppo_block_s3<true, KX, N1, N2, VEC>(g, smem_s3);
-    else ppo_block_s3<false, KX, N1, N2, VEC>(g, smem_s3);
+    if (blockIdx.y == 0) ppo_block_s3<true, KX, N1, N2, VEC, PRE>(g, smem_s3);
+    else ppo_block_s3<false, KX, N1, N2, VEC, PRE>(g, smem_s3);
 }
 
-template <int KX, int N1, int N2, bool VEC>
+template <int KX, int N1, int N2, bool VEC, bool PRE>
 int launch_s3(const Ppo2Args &g, int n_slabs, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        int rc = erl_hip_status(hipFuncSetAttribute((const void *)ppo_step_s3_kernel<KX, N1, N2, VEC>,
+        int rc = erl_hip_status(hipFuncSetAttribute((const void *)ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS3LdsBytes),
                                 "hipFuncSetAttribute(ppo_step_s3_kernel)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC>), dim3(n_slabs, 2), dim3(QNT), kS3LdsBytes, stream, g);
+    hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(n_slabs, 2), dim3(QNT), kS3LdsBytes, stream, g);
     return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");
 }
 
-template <int N1, int N2>
+template <int N1, int N2, bool PRE>
 int launch_s3_shape(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream)
 {
-    if (g.S <= 8) return launch_s3<0, N1, N2, false>(g, n_slabs, stream);
-    if (vec) return g.S > 32 ? launch_s3<2, N1, N2, true>(g, n_slabs, stream) : launch_s3<1, N1, N2, true>(g, n_slabs, stream);
-    return g.S > 32 ? launch_s3<2, N1, N2, false>(g, n_slabs, stream) : launch_s3<1, N1, N2, false>(g, n_slabs, stream);
+    if (g.S <= 8) return launch_s3<0, N1, N2, false, PRE>(g, n_slabs, stream);
+    if (vec) return g.S > 32 ? launch_s3<2, N1, N2, true, PRE>(g, n_slabs, stream) : launch_s3<1, N1, N2, true, PRE>(g, n_slabs, stream);
+    return g.S > 32 ? launch_s3<2, N1, N2, false, PRE>(g, n_slabs, stream) : launch_s3<1, N1, N2, false, PRE>(g, n_slabs, stream);
 }
 
 }  // namespace

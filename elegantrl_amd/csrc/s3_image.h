@@ -1,0 +1,62 @@
+// The W2 images of ppo_step_s3 (K6 on the bf16 matrix pipe) as the optimiser sees them: a global-memory copy of the kernel's LDS
+// image [row][3 parts][h1 bf16] (16-byte chunks XOR-swizzled by the row, see ppo_step_s3_impl.h), built once per update loop from
+// the fp32 parameters and refreshed by clip + Adam element by element, so that the minibatch kernel copies it straight into LDS
+// (LDS-DMA under the first layer's MFMAs) instead of every workgroup splitting the same 16k weights.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+struct S3Image {
+    unsigned char *img;     // nullptr: none
+    int64_t w2_off;         // offset of W2 inside the network's flat parameter block
+    int h1, h2;
+};
+struct S3Images {
+    S3Image net[2];         // actor, critic (= parameter groups 0, 1 of the update loop)
+};
+
+// chunk swizzle of an image with CP = K / 8 chunks per part (the formulas of swz<> in ppo_step_s3_impl.h)
+__host__ __device__ inline int s3_swz(int CP, int r)
+{
+    const int r0 = r & 1, r1 = (r >> 1) & 1, r2 = (r >> 2) & 1, r3 = (r >> 3) & 1;
+    if (CP == 16) return ((r1 ^ r3) << 3) | (r0 << 2) | ((r1 ^ r2) << 1) | r2;
+    if (CP == 8) return (r1 << 2) | (r2 << 1) | (r0 ^ r3);
+    return (r2 << 1) | (r1 ^ r3);
+}
+
+__device__ inline unsigned short s3_bf16_rne(float x)
+{
+    typedef __bf16 bf16x2_s3 __attribute__((ext_vector_type(2)));
+    typedef float f32x2_s3 __attribute__((ext_vector_type(2)));
+    return (unsigned short)(__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_s3{x, 0.f}, bf16x2_s3)) & 0xffffu);
+}
+
+// element (row, col) of a K-column matrix into its image: x = h + m + l exactly, each a bf16 (round to nearest even)
+__device__ inline void s3_image_put(unsigned char *img, int K, int row, int col, float x)
+{
+    const int CP = K >> 3;
+    const unsigned short h = s3_bf16_rne(x);
+    const float r = x - __uint_as_float((uint32_t)h << 16);
+    const unsigned short m = s3_bf16_rne(r);
+    const float q = r - __uint_as_float((uint32_t)m << 16);
+    const unsigned short l = s3_bf16_rne(q);
+    unsigned char *p = img + (size_t)row * (48 * CP) + 16 * ((col >> 3) ^ s3_swz(CP, row)) + 2 * (col & 7);
+    *reinterpret_cast<unsigned short *>(p) = h;
+    *reinterpret_cast<unsigned short *>(p + 16 * CP) = m;
+    *reinterpret_cast<unsigned short *>(p + 32 * CP) = l;
+}
+
+inline size_t s3_image_bytes(int h1, int h2) { return (size_t)h2 * 6 * h1; }
+
+// ppo_step.hip / grad_tail.hip: the entry points of the update loop (comm.cpp) that carry the images along
+int erl_ppo_step_images_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
+                            const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
+                            const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
+                            const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
+                            float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
+                            void *stream);
+int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
+                                      const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
+                                      float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, void *stream);
+// grad_tail.hip: library-owned image buffers of (device, stream), built from the flat parameters [actor | critic]
+int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, hipStream_t stream);

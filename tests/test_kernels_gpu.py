@@ -564,6 +564,54 @@ def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
         assert es <= max(2.0 * e32, 3e-7), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
 
 
+@pytest.mark.parametrize("S,A,B", [(64, 8, 512), (32, 3, 200), (17, 5, 300), (3, 1, 128)])
+def test_update_loop_split_arith_images(ops, dev, S, A, B):
+    """the C update loop under split arithmetic hands the minibatch kernel pre-split W2 images (built once per loop, refreshed by
+    clip + Adam element by element, copied into LDS by DMA) where the stand-alone erl_ppo_step_f32 splits W2 itself: both must
+    leave the same bits -- weights, moments, gradient rows.  Next to it the fp32-MFMA loop: after six Adam steps the weights agree
+    to a few 1e-6 except where a gradient sits at rounding level (Adam's update is ~lr sign(g) there)."""
+    h1 = h2 = 128
+    rng = np.random.default_rng(S + B)
+    H, N, T = 9, 400, 6
+    buf = ppo_case(rng, H, N, S, A, B)[:6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
+    stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
+    ids = cu(rng.integers(0, H * N, (T, B)), dev)
+    P0 = cu(np.concatenate([flat_params(actor), flat_params(critic)]), dev)
+    norm = [cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(critic.state_avg, dev), cu(critic.state_std, dev)]
+    tb = [cu(x, dev) for x in buf]
+    groups = [(0, Pa), (Pa, Pc)]
+    out = {}
+    prev = ops.ppo_set_arith("split")
+    try:
+        # (a) python loop, stand-alone minibatch kernel
+        P, M1, M2 = P0.clone(), th.zeros_like(P0), th.zeros_like(P0)
+        slabs, rows = th.zeros((n_slabs, stride), device=dev), th.zeros((T, stride), device=dev)
+        for k in range(T):
+            ops.ppo_step(P[:Pa], P[Pa:], *norm, S, h1, h2, A, *tb, ids[k], 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+            ops.grad_reduce_partials(slabs, n_slabs, stride, rows[k], groups)
+            ops.clip_adam_partials(P, rows[k], M1, M2, stride, groups, k + 1, 1e-3, 3.0)
+        out["python"] = (P, M1, M2, rows)
+        # (b) the C loop with images, (c) the C loop on the fp32 MFMA
+        for name, arith in (("c", "split"), ("f32", "f32")):
+            ops.ppo_set_arith(arith)
+            P, M1, M2 = P0.clone(), th.zeros_like(P0), th.zeros_like(P0)
+            slabs, rows = th.zeros((n_slabs, stride), device=dev), th.zeros((T, stride), device=dev)
+            ops.ppo_update(P, M1, M2, *norm, S, h1, h2, A, *tb, ids, 0.25, 0.001, slabs, rows, 1, 1e-3, 3.0)
+            out[name] = (P, M1, M2, rows)
+    finally:
+        ops.ppo_set_arith(prev)
+    for x, y, what in zip(out["python"], out["c"], ("weights", "exp_avg", "exp_avg_sq", "gradient rows")):
+        assert th.equal(x, y), f"{what}: the loop with W2 images differs from the stand-alone kernel (max {float((x - y).abs().max()):.3e})"
+    dp = (out["c"][0] - out["f32"][0]).abs().cpu().numpy()
+    moved = float((out["c"][0] - P0).abs().max())
+    assert moved > 1e-3
+    assert np.mean(dp > 2e-5) < 0.01 and dp.max() <= 2.1 * T * 1e-3, f"split vs fp32 weights: {np.mean(dp > 2e-5):.4f} of the elements differ by > 2e-5, max {dp.max():.3e}"
+    gr = (out["c"][3] - out["f32"][3]).abs().max().item() / out["f32"][3].abs().max().item()
+    assert gr < 1e-4, f"gradient rows: split vs fp32 {gr:.3e} of the scale"
+
+
 OBJECTIVES = {"canonical": 1, "a2c": 2}
 
 

@@ -46,6 +46,12 @@ def main():
     lib.erl_debug_set_ppo_profile(prof.data_ptr())
     run = lambda: ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,  # noqa: E731
                                ids, 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    if os.environ.get("K6_LOOP"):
+        # through the C update loop (one minibatch, lr = 0): the split-arithmetic kernel then gets its W2 images from the loop
+        m1, m2, rows = th.zeros_like(flat), th.zeros_like(flat), th.zeros((1, stride), device=dev)
+        run = lambda: ops.ppo_update(flat, m1, m2, avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret,  # noqa: E731
+                                     ids.view(1, B), 0.25, 0.001, slabs, rows, 1, 0.0, 3.0)
+        print("minibatch kernel launched through erl_ppo_update_dp_f32 (wall time below includes the optimiser tail)")
     lib.erl_debug_set_ppo_profile_block.argtypes = [ctypes.c_int]
     lib.erl_debug_set_ppo_profile_block.restype = None
     for blk in (1, 37, 64, 127):                      # are the workgroups alike?  (total cycles, wave 0 of each net)

@@ -158,6 +158,101 @@ __global__ __launch_bounds__(256) void mfma_time(long long *out, float *sink, in
     if (s == 12345.f) sink[0] = s;
 }
 
+// ---- E: the same stream with the vector work DISTRIBUTED: PER instructions behind each of the 6 MFMAs of a group (two
+//      accumulators in turn), of kind KIND: 0 independent v_fma_f32 chains, 1 the operand split (cvt_pk / shift / and / sub),
+//      2 v_accvgpr_read of a finished accumulator + fma, 3 transcendentals (v_exp_f32 / v_rcp_f32) mixed 1:3 with fma
+template <int PER, int KIND>
+__global__ __launch_bounds__(256) void mfma_fill(long long *out, float *sink, int groups)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, hi = lane >> 5;
+    constexpr int ROWB = 768;
+    for (int e = threadIdx.x; e < 128 * ROWB / 4; e += 256) reinterpret_cast<uint32_t *>(smem)[e] = 0x3f803f80u;
+    __syncthreads();
+    u32x4 bh = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, bm = bh, bl = bh;
+    f32x16 acc0 = {0}, acc1 = {0}, old = {0};
+    for (int r = 0; r < 16; ++r) old[r] = (float)(r + lane);
+    float v[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+    uint32_t pk[4] = {0, 0, 0, 0};
+    // rows 768 bytes apart would put a 16-lane read group on ONE bank group: chunks are XOR-swizzled by the row as in
+    // csrc/ppo_step_s3_impl.h (swz<16>)
+    const int r0 = i & 1, r1 = (i >> 1) & 1, r2 = (i >> 2) & 1, r3 = (i >> 3) & 1;
+    const int sw = ((r1 ^ r3) << 3) | (r0 << 2) | ((r1 ^ r2) << 1) | r2;
+    const uint32_t base = (uint32_t)(uintptr_t)(smem + i * ROWB);
+    const uint32_t x16 = 16 * (sw ^ hi);
+    typedef __attribute__((address_space(3))) u32x4 *l4;
+    auto issue = [&](int g, u32x4(&r)[3]) {
+        const uint32_t off = (g & 3) * 32 * ROWB + ((((g >> 2) & 7) * 32) ^ x16);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) r[pl] = *(l4)(base + off + 256 * pl);
+    };
+    auto filler = [&](int slot) {
+#pragma unroll
+        for (int n = 0; n < PER; ++n) {
+            const int j = (slot * PER + n) & 7;
+            if (KIND == 0) {
+                v[j] = __builtin_fmaf(v[j], 1.0001f, 0.5f);
+            } else if (KIND == 1) {
+                switch (n % 6) {
+                case 0: pk[j & 3] = pk_bf16(v[j], v[(j + 1) & 7]); break;
+                case 1: v[(j + 2) & 7] = v[j] - lo_f32(pk[j & 3]); break;
+                case 2: v[(j + 3) & 7] = v[(j + 1) & 7] - hi_f32(pk[j & 3]); break;
+                case 3: pk[(j + 1) & 3] = pk_bf16(v[(j + 2) & 7], v[(j + 3) & 7]); break;
+                case 4: v[(j + 4) & 7] = v[(j + 2) & 7] - lo_f32(pk[(j + 1) & 3]); break;
+                default: v[(j + 5) & 7] = v[(j + 3) & 7] - hi_f32(pk[(j + 1) & 3]); break;
+                }
+            } else if (KIND == 2) {
+                v[j] = __builtin_fmaf(old[(slot * PER + n) & 15], 1.0001f, v[j]);
+            } else {
+                if ((n & 3) == 0) v[j] = __builtin_amdgcn_exp2f(v[j]);
+                else v[j] = __builtin_fmaf(v[j], 1.0001f, 0.5f);
+            }
+            asm volatile("" : "+v"(v[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    u32x4 r[2][3];
+    issue(0, r[0]);
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int g = 0; g < groups; g += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            issue(g + u + 1, r[(u + 1) & 1]);
+            const u32x4 ah = r[u][0], am = r[u][1], al = r[u][2];
+            acc0 = mfma_bf16(am, bm, acc0); __builtin_amdgcn_sched_barrier(0); filler(0);
+            acc1 = mfma_bf16(al, bh, acc1); __builtin_amdgcn_sched_barrier(0); filler(1);
+            acc0 = mfma_bf16(ah, bl, acc0); __builtin_amdgcn_sched_barrier(0); filler(2);
+            acc1 = mfma_bf16(am, bh, acc1); __builtin_amdgcn_sched_barrier(0); filler(3);
+            acc0 = mfma_bf16(ah, bm, acc0); __builtin_amdgcn_sched_barrier(0); filler(4);
+            acc1 = mfma_bf16(ah, bh, acc1); __builtin_amdgcn_sched_barrier(0); filler(5);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (lane == 0) out[wave] = (long long)(t1 - t0);
+    float s = 0.f;
+    for (int r_ = 0; r_ < 16; ++r_) s += acc0[r_] + acc1[r_];
+    for (int n = 0; n < 8; ++n) s += v[n];
+    for (int n = 0; n < 4; ++n) s += (float)pk[n];
+    if (s == 12345.f) sink[0] = s;
+}
+
+template <int PER, int KIND>
+void time_fill(const char *name)
+{
+    long long *d; float *s;
+    CK(hipMalloc(&d, 64)); CK(hipMalloc(&s, 64));
+    const int groups = 1024;
+    const size_t lds = 128 * 768;
+    CK(hipFuncSetAttribute((const void *)mfma_fill<PER, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((mfma_fill<PER, KIND>), dim3(1), dim3(256), lds, 0, d, s, groups);
+    long long h[4];
+    CK(hipMemcpy(h, d, 32, hipMemcpyDeviceToHost));
+    printf("E  %-34s %d per MFMA: %6.1f cycles per group of 6 MFMAs  (%+.1f per filler instruction over 206)\n", name, PER, (double)h[0] / groups,
+           PER ? ((double)h[0] / groups - 206.0) / (6 * PER) : 0.0);
+    CK(hipFree(d)); CK(hipFree(s));
+}
+
 template <int NV, bool TR, int NACC>
 void time_it(const char *name)
 {
@@ -227,5 +322,18 @@ int main()
     time_it<0, true, 1>("tr reads, no VALU, 1 acc");
     time_it<0, true, 2>("tr reads, no VALU, 2 acc");
     time_it<24, true, 2>("tr reads, 24 VALU, 2 acc");
+    time_fill<0, 0>("no filler");
+    time_fill<2, 0>("independent fma");
+    time_fill<4, 0>("independent fma");
+    time_fill<6, 0>("independent fma");
+    time_fill<8, 0>("independent fma");
+    time_fill<12, 0>("independent fma");
+    time_fill<4, 1>("operand split");
+    time_fill<6, 1>("operand split");
+    time_fill<8, 1>("operand split");
+    time_fill<4, 2>("accumulator read + fma");
+    time_fill<6, 2>("accumulator read + fma");
+    time_fill<4, 3>("exp2 : fma 1 : 3");
+    time_fill<8, 3>("exp2 : fma 1 : 3");
     return 0;
 }
