@@ -11,7 +11,8 @@ fwd/bwd, gradient reduce, [RCCL all-reduce when N > 1], clip + Adam).  Inputs ar
 one per GPU (weak scaling).  Rank 0 prints ONE JSON line.
 
 Besides the throughput the line carries
-  roofline      dominant kernel of the timed region (ppo_step_w4_kernel, fp32 MFMA bound), timed with HIP events
+  roofline      dominant kernel of the timed region (the PPO minibatch kernel: ppo_step_s3_kernel, bf16 matrix pipe with
+                fp32-equivalent split arithmetic, or ppo_step_w4_kernel on the fp32 MFMA), timed with HIP events
                 around every launch inside the timed region
   roofline_gae  the GAE scan (HBM bound; the metric's second half): in-loop launches + a size sweep run after
                 the timed region (the in-loop 32 x 4096 problem is 2.4 MB, i.e. launch-latency sized)
@@ -33,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SPLIT_TERMS = 6  # bf16 partial products per fp32-equivalent product in the split-arithmetic K6 (csrc/ppo_step_s3_impl.h)
 
 # BASELINE configs (SURVEY.md section 8 header / 8d).  c4 = configs[3] is the metric's configuration and the default; the
 # others are run with --config and recorded under profiles/ (same JSON schema, the workload named in config.workload).
@@ -125,6 +128,8 @@ def gae_sweep(ops, dev):
 # the files a kernel's HBM traffic depends on (what the PMC passes were collected on is stamped with their hash)
 KERNEL_SOURCES = {
     "ppo_step_w4_kernel": ["ppo_step_w4_impl.h", "ppo_step_w4.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
+    "ppo_step_s3_kernel": ["ppo_step_s3_impl.h", "ppo_step_s3.hip", "ppo_step_s3_pre.hip", "s3_image.h", "ppo_step_w4_impl.h", "ppo_step.h",
+                           "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "ppo_step2_kernel": ["ppo_step.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "gae_lookback_kernel": ["gae_lookback.hip"],
 }
@@ -387,6 +392,25 @@ def main():
         th.cuda.synchronize()
         parallel.barrier()
         repeats.append(parallel.all_reduce_max_float(time.perf_counter() - t1, device=dev) / opt.steps * 1e3)
+    # the same region on the fp32-MFMA minibatch kernel (when the default is the split-arithmetic one), for the record
+    f32_region = None
+    k6_arith = ops.ppo_arith_in_use(STATE_DIM, NET_DIMS[0], NET_DIMS[1], ACTION_DIM) if len(NET_DIMS) == 2 else "f32"
+    if k6_arith == "split" and opt.repeats:
+        prev_arith = ops.ppo_set_arith("f32")
+        for _ in range(2):
+            step()
+        parallel.barrier()
+        th.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(opt.steps):
+            objs_f32 = step()
+        th.cuda.synchronize()
+        parallel.barrier()
+        el = parallel.all_reduce_max_float(time.perf_counter() - t1, device=dev)
+        ops.ppo_set_arith(prev_arith)
+        f32_region = {"ms_per_step": round(el / opt.steps * 1e3, 3), "value": round(world * N_ENVS * HORIZON * opt.steps / el, 1),
+                      "objectives_last": [round(float(x), 6) for x in objs_f32],
+                      "note": "one more region of the same steps with erl_ppo_set_arith(f32): the fp32-MFMA minibatch kernel (not part of `value`)"}
     allreduce = None
     if world > 1 or parallel.force_dp():   # the exchange step on its own, through the route update_net uses (every rank takes part)
         comm = parallel.gradient_comm(agent._stride)
@@ -417,6 +441,11 @@ def main():
     # which K6 kernel erl_ppo_step_f32 dispatches to: the one-wave-per-SIMD form for h1, h2 in {64, 128}, S <= 64, A <= 8
     k6_kernel = "ppo_step_w4_kernel" if (len(NET_DIMS) == 2 and all(d in (64, 128) for d in NET_DIMS) and STATE_DIM <= 64
                                          and ACTION_DIM <= 8) else "ppo_step2_kernel"
+    if k6_arith == "split":
+        k6_kernel = "ppo_step_s3_kernel"
+    # the fp32-equivalent ceiling of the pipe the kernel runs on: the split-arithmetic kernel issues SPLIT_TERMS bf16 MFMA flops per
+    # algorithmic flop on the bf16 matrix pipe; the fp32 kernel runs on the fp32 MFMA
+    k6_peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS if k6_arith == "split" else MFMA_F32_PEAK_TFLOPS
     gae_s = t_gae.mean_seconds()
     k6_traffic, k6_traffic_src = pmc_traffic(k6_kernel) if opt.config == "c4" else (None, None)
     line = {
@@ -425,9 +454,15 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["workload"], "name": opt.config,
                    "envs_per_gpu": N_ENVS, "horizon": HORIZON, "batch": BATCH, "update_times": UPDATE_TIMES,
-                   "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "k6_arith": ("split: fp32 operands as three bf16 parts on the bf16 matrix pipe, fp32 accumulate (as close to fp64 as the "
+                                "fp32 MFMA: tests/test_kernels_gpu.py::test_ppo_step_split_arith)" if k6_arith == "split" else "f32 MFMA")},
         "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
-                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                     "peak": round(k6_peak, 1), "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / k6_peak, 4),
+                     "arith": ("fp32-equivalent: operands split into three bf16 parts, six partial products per product on v_mfma_f32_32x32x16_bf16, "
+                               "fp32 accumulation; `achieved` counts ALGORITHMIC flops, `peak` = bf16 dense MFMA peak / 6"
+                               if k6_arith == "split" else "fp32 operands on v_mfma_f32_32x32x2_f32"),
+                     "frac_of_fp32_mfma_peak": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops,
                      "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6},
         "roofline_gae": {"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
@@ -444,6 +479,8 @@ def main():
         line["extra"] = {"repeated_regions_ms_per_step": [round(x, 3) for x in repeats], "min": round(srt[0], 3),
                          "median": round(srt[len(srt) // 2], 3), "max": round(srt[-1], 3), "primary": round(elapsed / opt.steps * 1e3, 3),
                          "note": f"{len(repeats)} more timed regions of {opt.steps} steps each after the primary one (not part of `value`)"}
+    if f32_region is not None:
+        line.setdefault("extra", {})["k6_arith_f32"] = f32_region
     if not opt.no_gae_sweep and opt.config == "c4":
         log("GAE size sweep")
         sweep = gae_sweep(ops, dev)

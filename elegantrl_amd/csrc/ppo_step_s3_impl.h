@@ -248,16 +248,22 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
         for (int s = 0; s < 4; ++s) jit(0, s);
     }
     issue(0, aq[0]);
-#pragma unroll
-    for (int To = 0; To < NO; ++To) {
-        f32x16 acc, acc1 = {0};
+    // the accumulator starts from the bias, read a tile ahead (acc[8 a + e] <-> feature 32 To + 16 a + 8 hi + e)
+    f32x16 nb;
+    auto load_bias = [&](int To) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float4 b0 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi);
             const float4 b1 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi + 4);
-            acc[8 * a + 0] = b0.x; acc[8 * a + 1] = b0.y; acc[8 * a + 2] = b0.z; acc[8 * a + 3] = b0.w;
-            acc[8 * a + 4] = b1.x; acc[8 * a + 5] = b1.y; acc[8 * a + 6] = b1.z; acc[8 * a + 7] = b1.w;
+            nb[8 * a + 0] = b0.x; nb[8 * a + 1] = b0.y; nb[8 * a + 2] = b0.z; nb[8 * a + 3] = b0.w;
+            nb[8 * a + 4] = b1.x; nb[8 * a + 5] = b1.y; nb[8 * a + 6] = b1.z; nb[8 * a + 7] = b1.w;
         }
+    };
+    load_bias(0);
+#pragma unroll
+    for (int To = 0; To < NO; ++To) {
+        f32x16 acc = nb, acc1 = {0};
+        if (To + 1 < NO) load_bias(To + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {

@@ -29,7 +29,12 @@ def test_bench_line_contract(config):
     r = line["roofline"]
     assert {"kernel", "bound", "achieved", "peak", "unit", "frac"} <= set(r) and 0 < r["frac"] < 1
     if config == "c4":
-        assert line["metric"] == "env_steps_per_sec_ppo_4096envs_obs64" and r["kernel"] == "ppo_step_w4_kernel"
+        # the default minibatch kernel of [128,128] nets: split arithmetic on the bf16 matrix pipe, priced against that pipe's
+        # fp32-equivalent ceiling (bf16 dense peak / 6 partial products); the fp32-MFMA region rides along in `extra`
+        assert line["metric"] == "env_steps_per_sec_ppo_4096envs_obs64" and r["kernel"] == "ppo_step_s3_kernel"
+        assert abs(r["peak"] - 2500.0 / 6) < 0.1 and "split" in line["config"]["k6_arith"] and r["frac_of_fp32_mfma_peak"] > r["frac"]
+        f32 = line["extra"]["k6_arith_f32"]
+        assert f32["value"] > 0 and len(f32["objectives_last"]) == 3
         # HBM bytes per launch from the committed PMC passes, or None when they were collected on other kernel sources
         src = r["traffic_source"]
         assert (r["traffic"] is None) == bool(src["stale"]) and (r["traffic"] is None or r["traffic"] > 0)

@@ -35,7 +35,11 @@ um = th.rand((H, N), device=dev, generator=g) < 0.995
 ids = th.randint(H * N, (B,), device=dev, generator=g)
 stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
 slabs = th.empty((n_slabs, stride), device=dev)
-for _ in range(5):
-    ops.ppo_step(flat[:Pa], flat[Pa:], avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv2, ret2, ids, 0.25, 0.001,
-                 1.0 / B, slabs, n_slabs)
+# through the C update loop (5 minibatches, lr = 0): that is how the agent launches the minibatch kernel -- the split-arithmetic
+# kernel gets its W2 images from the loop; K6_ARITH=f32 measures the fp32-MFMA kernel instead
+if os.environ.get("K6_ARITH"):
+    ops.ppo_set_arith(os.environ["K6_ARITH"])
+m1, m2, rows = th.zeros_like(flat), th.zeros_like(flat), th.zeros((5, stride), device=dev)
+ops.ppo_update(flat, m1, m2, avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv2, ret2, ids.repeat(5, 1), 0.25, 0.001,
+               slabs, rows, 1, 0.0, 3.0)
 th.cuda.synchronize()
