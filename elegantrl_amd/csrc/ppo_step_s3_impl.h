@@ -318,7 +318,8 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
 {
     constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
     constexpr int EP = 16 / NK;
-    static_assert(EP * NK == 16 && EP == 2, "the gate stage handles one pair per k-step (layers of 128 outputs)");
+    static_assert(EP * NK == 16 && EP % 2 == 0, "k-steps per tile");
+    constexpr int NPR = EP / 2;                               // element pairs of the previous tile finished per k-step
     const int q = lane >> 4, kb = q >> 1, half = q & 1, t = lane & 15, rr = t >> 2, u = t & 3;
     const int su = ((u & 1) << 1) | (u >> 1);                 // sigma(u)
     const int ccl = 2 * half + (su >> 1), sub = 8 * (su & 1);
@@ -345,19 +346,22 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
         __builtin_amdgcn_sched_barrier(0);
     };
     f32x16 prev, prev1;
-    float v0, v1;
-    // elements 2 ks, 2 ks + 1 of tile Tp: the gate product (stage 0) and its split (stage 1)
+    float v0[NPR], v1[NPR];
+    // elements EP ks .. EP ks + EP - 1 of tile Tp: the gate products (stage 0) and their splits (stage 1)
     auto gstage = [&](int Tp, int ks, int s) {
-        const int e = 2 * ks;
-        if (s == 0) {
-            v0 = gate[Tp][e] * (prev[e] + prev1[e]);
-            v1 = gate[Tp][e + 1] * (prev[e + 1] + prev1[e + 1]);
-        } else if (s == 1) {
-            uint32_t h, mm, l;
-            split2(v0, v1, h, mm, l);
-            asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
-            Parts &o = outP[2 * Tp + (e >> 3)];
-            o.h[(e & 7) >> 1] = h; o.m[(e & 7) >> 1] = mm; o.l[(e & 7) >> 1] = l;
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+            const int e = EP * ks + 2 * i;
+            if (s == 0) {
+                v0[i] = gate[Tp][e] * (prev[e] + prev1[e]);
+                v1[i] = gate[Tp][e + 1] * (prev[e + 1] + prev1[e + 1]);
+            } else if (s == 1) {
+                uint32_t h, mm, l;
+                split2(v0[i], v1[i], h, mm, l);
+                asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+                Parts &o = outP[2 * Tp + (e >> 3)];
+                o.h[(e & 7) >> 1] = h; o.m[(e & 7) >> 1] = mm; o.l[(e & 7) >> 1] = l;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };

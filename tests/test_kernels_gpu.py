@@ -522,7 +522,8 @@ def test_ppo_step_gradients(ops, dev, S, h1, h2, A, B):
     np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-4, atol=1e-6)
 
 
-S3_SHAPES = [(64, 128, 128, 8), (32, 128, 128, 3), (4, 128, 128, 8), (48, 128, 128, 6), (17, 128, 128, 5), (3, 128, 128, 1), (33, 128, 128, 2)]
+S3_SHAPES = [(64, 128, 128, 8), (32, 128, 128, 3), (4, 128, 128, 8), (48, 128, 128, 6), (17, 128, 128, 5), (3, 128, 128, 1), (33, 128, 128, 2),
+             (3, 128, 64, 1), (64, 128, 64, 8), (60, 128, 64, 8), (32, 64, 128, 4), (7, 64, 128, 2), (12, 64, 64, 3), (3, 64, 64, 1), (33, 128, 64, 5)]
 
 
 @pytest.mark.parametrize("S,h1,h2,A", S3_SHAPES)
@@ -564,13 +565,13 @@ def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
         assert es <= max(2.0 * e32, 3e-7), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
 
 
-@pytest.mark.parametrize("S,A,B", [(64, 8, 512), (32, 3, 200), (17, 5, 300), (3, 1, 128)])
-def test_update_loop_split_arith_images(ops, dev, S, A, B):
+@pytest.mark.parametrize("S,A,B,h1,h2", [(64, 8, 512, 128, 128), (32, 3, 200, 128, 128), (17, 5, 300, 128, 128), (3, 1, 128, 128, 128),
+                                          (3, 1, 256, 128, 64), (64, 8, 300, 64, 128), (20, 4, 200, 64, 64)])
+def test_update_loop_split_arith_images(ops, dev, S, A, B, h1, h2):
     """the C update loop under split arithmetic hands the minibatch kernel pre-split W2 images (built once per loop, refreshed by
     clip + Adam element by element, copied into LDS by DMA) where the stand-alone erl_ppo_step_f32 splits W2 itself: both must
     leave the same bits -- weights, moments, gradient rows.  Next to it the fp32-MFMA loop: after six Adam steps the weights agree
     to a few 1e-6 except where a gradient sits at rounding level (Adam's update is ~lr sign(g) there)."""
-    h1 = h2 = 128
     rng = np.random.default_rng(S + B)
     H, N, T = 9, 400, 6
     buf = ppo_case(rng, H, N, S, A, B)[:6]
