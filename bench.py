@@ -410,7 +410,8 @@ def main():
         ops.ppo_set_arith(prev_arith)
         f32_region = {"ms_per_step": round(el / opt.steps * 1e3, 3), "value": round(world * N_ENVS * HORIZON * opt.steps / el, 1),
                       "objectives_last": [round(float(x), 6) for x in objs_f32],
-                      "note": "one more region of the same steps with erl_ppo_set_arith(f32): the fp32-MFMA minibatch kernel (not part of `value`)"}
+                      "note": "one more region of the same steps with erl_ppo_set_arith(f32): the fp32-MFMA minibatch kernel (not part of `value`; "
+                              "its objectives belong to later iterations of the same training run than `objectives_last`)"}
     allreduce = None
     if world > 1 or parallel.force_dp():   # the exchange step on its own, through the route update_net uses (every rank takes part)
         comm = parallel.gradient_comm(agent._stride)

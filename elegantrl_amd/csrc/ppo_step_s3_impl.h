@@ -25,9 +25,6 @@
 //   * the 8-row output layer, dZ2 = W3^T dY and dW3 stay on the fp32 instructions of ppo_step_w4_impl.h (K <= 8 or 16 rows).
 #pragma once
 #include "ppo_step_w4_impl.h"
-#ifndef S3_EXP
-#define S3_EXP 0
-#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -86,18 +83,6 @@ __device__ __forceinline__ void mma6(const Parts &a, const Parts &b, f32x16 &acc
     acc = mfma_bf(a.m, b.h, acc);
     acc = mfma_bf(a.h, b.m, acc);
     acc = mfma_bf(a.h, b.h, acc);
-}
-
-// the same into two accumulators in turn: beside interleaved vector work, consecutive MFMAs must not chain on one accumulator
-// (an instruction between two MFMAs on the SAME accumulator costs ~43 cycles: the back-to-back forwarding path is lost)
-__device__ __forceinline__ void mma6_2(const Parts &a, const Parts &b, f32x16 &acc0, f32x16 &acc1)
-{
-    acc0 = mfma_bf(a.m, b.m, acc0);
-    acc1 = mfma_bf(a.l, b.h, acc1);
-    acc0 = mfma_bf(a.h, b.l, acc0);
-    acc1 = mfma_bf(a.m, b.h, acc1);
-    acc0 = mfma_bf(a.h, b.m, acc0);
-    acc1 = mfma_bf(a.h, b.h, acc1);
 }
 
 __device__ __forceinline__ int phi(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }   // bits 2 and 3 swapped
@@ -422,22 +407,6 @@ __device__ __forceinline__ void stage_s3(u8 *S, const Parts (&p)[N], int srow, i
         *reinterpret_cast<u32x4 *>(d) = p[KS0 + ks].h;
         *reinterpret_cast<u32x4 *>(d + PBY) = p[KS0 + ks].m;
         *reinterpret_cast<u32x4 *>(d + 2 * PBY) = p[KS0 + ks].l;
-    }
-}
-
-// the two k-steps of feature tile T
-template <int CP>
-__device__ __forceinline__ void stage_tile_s3(u8 *S, const Parts (&p)[2], int T, int srow, int hi)
-{
-    constexpr int PBY = 16 * CP;
-    u8 *base = S + srow * (48 * CP);
-    const int sw = swz<CP>(srow);
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        u8 *d = base + 16 * ((4 * T + 2 * a + hi) ^ sw);
-        *reinterpret_cast<u32x4 *>(d) = p[a].h;
-        *reinterpret_cast<u32x4 *>(d + PBY) = p[a].m;
-        *reinterpret_cast<u32x4 *>(d + 2 * PBY) = p[a].l;
     }
 }
 
