@@ -152,8 +152,8 @@ __device__ __forceinline__ Parts parts_of(const u32x2 (&r)[6])
 
 // ---------------------------------------------------------------------------------------------------------
 // forward layer: tile To of the result (A-row i <-> feature 32 To + phi(i)) = GELU(bias + W . in), W an image with CP chunks
-// per part.  Leaves H (fp32) and GELU'.  The input is either split already (JIT = false: inP) or comes as fp32 tiles (inH) and
-// is split on the way -- k-step ks + 1's operand behind the MFMAs of k-step ks of tile 0 -- into inP, which the caller keeps.
+// per part.  Leaves H (fp32) and GELU'.  The input comes as fp32 tiles (inH) and is split on the way -- k-step ks + 1's operand
+// behind the MFMAs of k-step ks of tile 0 -- into inP, which the caller keeps.
 //
 // The bf16 matrix pipe runs beside the vector ALUs (32 cycles per MFMA, room for ~6 other instructions each), and a wave issues
 // in order: the vector work is cut into six stages per k-step, one behind each MFMA, pinned there by scheduling fences (left to
@@ -161,8 +161,8 @@ __device__ __forceinline__ Parts parts_of(const u32x2 (&r)[6])
 // between two accumulators: an instruction between two MFMAs on the SAME accumulator costs ~43 cycles (the back-to-back
 // forwarding path is lost).
 // ---------------------------------------------------------------------------------------------------------
-template <int NK, int NO, int CP, bool JIT>
-__device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (&inP)[NK], const f32x16 (&inH)[JIT ? NK / 2 : 1],
+template <int NK, int NO, int CP>
+__device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (&inP)[NK], const f32x16 (&inH)[(NK + 1) / 2],
                                        f32x16 (&outH)[NO], f32x16 (&outG)[NO], int m, int hi)
 {
     constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
     };
     // pair s (of 4) of the operand of k-step ks from the fp32 input
     auto jit = [&](int ks, int s) {
-        if (JIT && ks < NK && s < 4) {
+        if (ks < NK && s < 4) {
             uint32_t h, mm, l;
             split2(inH[ks >> 1][8 * (ks & 1) + 2 * s], inH[ks >> 1][8 * (ks & 1) + 2 * s + 1], h, mm, l);
             asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
@@ -228,10 +228,8 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    if (JIT) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) jit(0, s);
-    }
+    for (int s = 0; s < 4; ++s) jit(0, s);
     issue(0, aq[0]);
     // the accumulator starts from the bias, read a tile ahead (acc[8 a + e] <-> feature 32 To + 16 a + 8 hi + e)
     f32x16 nb;
@@ -616,23 +614,24 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     // (without images) W2 is not needed before the second layer: requested only now, so that the prologue's burst (every CU pulls
     // its W1 and its 32 KB of gathered rows at once, ~11 B/clk per CU) is not stretched by another 64 KB
     if constexpr (!PRE) copy_load<VEC, N1 * N2, QNT>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
-    // ---- normalise and split the own row
+    // ---- normalise the own row; its split rides behind the first output tile's MFMAs of the first layer
     Parts Xp[NK1];
+    f32x16 XH[(NK1 + 1) / 2];
 #pragma unroll
     for (int ks = 0; ks < NK1; ++ks) {
         const float *nr = s_nr + 16 * ks + 8 * hi, *nn = s_nn + 16 * ks + 8 * hi;
         const float4 r0 = *reinterpret_cast<const float4 *>(nr), r1 = *reinterpret_cast<const float4 *>(nr + 4);
         const float4 n0 = *reinterpret_cast<const float4 *>(nn), n1 = *reinterpret_cast<const float4 *>(nn + 4);
-        f32x16 t;
-        t[0] = fmaf(XR[ks][0].x, r0.x, n0.x); t[1] = fmaf(XR[ks][0].y, r0.y, n0.y);
-        t[2] = fmaf(XR[ks][0].z, r0.z, n0.z); t[3] = fmaf(XR[ks][0].w, r0.w, n0.w);
-        t[4] = fmaf(XR[ks][1].x, r1.x, n1.x); t[5] = fmaf(XR[ks][1].y, r1.y, n1.y);
-        t[6] = fmaf(XR[ks][1].z, r1.z, n1.z); t[7] = fmaf(XR[ks][1].w, r1.w, n1.w);
-        Xp[ks] = split8(t, 0);
+        f32x16 &t = XH[ks >> 1];
+        const int o = 8 * (ks & 1);
+        t[o + 0] = fmaf(XR[ks][0].x, r0.x, n0.x); t[o + 1] = fmaf(XR[ks][0].y, r0.y, n0.y);
+        t[o + 2] = fmaf(XR[ks][0].z, r0.z, n0.z); t[o + 3] = fmaf(XR[ks][0].w, r0.w, n0.w);
+        t[o + 4] = fmaf(XR[ks][1].x, r1.x, n1.x); t[o + 5] = fmaf(XR[ks][1].y, r1.y, n1.y);
+        t[o + 6] = fmaf(XR[ks][1].z, r1.z, n1.z); t[o + 7] = fmaf(XR[ks][1].w, r1.w, n1.w);
     }
-    f32x16 H1[N1], G1[N1], H2[N2], G2[N2], Hnone[1];
+    f32x16 H1[N1], G1[N1], H2[N2], G2[N2];
     Parts H1p[2 * N1];
-    fwd_s3<NK1, N1, CP1, false>(IMG1, s_b1, Xp, Hnone, H1, G1, m, hi);
+    fwd_s3<NK1, N1, CP1>(IMG1, s_b1, Xp, XH, H1, G1, m, hi);
     PROF_NV(3);
     if constexpr (PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the W2 image have landed
     else img_store<N1 * N2, CP2>(c2, IMG2, h2, tid);
@@ -649,7 +648,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         }
         stage_s3<2 * KX, CP1, 0>(SB, Xs, col, hi);
     }
-    fwd_s3<2 * N1, N2, CP2, true>(IMG2, s_b2, H1p, H1, H2, G2, m, hi);       // splits H1 into H1p on the way
+    fwd_s3<2 * N1, N2, CP2>(IMG2, s_b2, H1p, H1, H2, G2, m, hi);       // splits H1 into H1p on the way
     PROF(4);
 
     // ---- output layer (fp32, as in ppo_step_w4_impl.h; H2[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j here)
