@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void mfma_time(long long *out, float *sink, in
 
 // ---- E: the same stream with the vector work DISTRIBUTED: PER instructions behind each of the 6 MFMAs of a group (two
 //      accumulators in turn), of kind KIND: 0 independent v_fma_f32 chains, 1 the operand split (cvt_pk / shift / and / sub),
-//      2 v_accvgpr_read of a finished accumulator + fma, 3 transcendentals (v_exp_f32 / v_rcp_f32) mixed 1:3 with fma
+//      2 v_accvgpr_read of a finished accumulator + fma, 3 transcendentals (v_exp_f32 / v_rcp_f32) mixed 1:3 with fma,
+//      4 / 5 / 6 one / two / four DEPENDENT fma chains (how much of the price is dependent-issue latency)
 template <int PER, int KIND>
 __global__ __launch_bounds__(256) void mfma_fill(long long *out, float *sink, int groups)
 {
@@ -203,9 +204,13 @@ __global__ __launch_bounds__(256) void mfma_fill(long long *out, float *sink, in
                 }
             } else if (KIND == 2) {
                 v[j] = __builtin_fmaf(old[(slot * PER + n) & 15], 1.0001f, v[j]);
-            } else {
+            } else if (KIND == 3) {
                 if ((n & 3) == 0) v[j] = __builtin_amdgcn_exp2f(v[j]);
                 else v[j] = __builtin_fmaf(v[j], 1.0001f, 0.5f);
+            } else {      // KIND 4 / 5 / 6: 1 / 2 / 4 dependent chains
+                const int c = (slot * PER + n) % (KIND == 4 ? 1 : KIND == 5 ? 2 : 4);
+                v[c] = __builtin_fmaf(v[c], 1.0001f, 0.5f);
+                asm volatile("" : "+v"(v[c]));
             }
             asm volatile("" : "+v"(v[j]));
         }
@@ -333,6 +338,13 @@ int main()
     time_fill<8, 1>("operand split");
     time_fill<4, 2>("accumulator read + fma");
     time_fill<6, 2>("accumulator read + fma");
+    time_fill<4, 4>("one dependent fma chain");
+    time_fill<6, 4>("one dependent fma chain");
+    time_fill<4, 5>("two dependent fma chains");
+    time_fill<6, 5>("two dependent fma chains");
+    time_fill<8, 5>("two dependent fma chains");
+    time_fill<6, 6>("four dependent fma chains");
+    time_fill<8, 6>("four dependent fma chains");
     time_fill<4, 3>("exp2 : fma 1 : 3");
     time_fill<8, 3>("exp2 : fma 1 : 3");
     return 0;
