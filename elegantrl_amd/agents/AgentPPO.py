@@ -133,6 +133,11 @@ class AgentPPO(AgentBase):
         # the reference reads `if_use_v_trace`; its Config sets `if_use_vtrace` (never consumed): accept both
         self.if_use_v_trace = getattr(args, "if_use_v_trace", getattr(args, "if_use_vtrace", True))
         self.gae_algo = getattr(args, "gae_algo", "auto")
+        # arithmetic of the minibatch kernel's large products (include/erl_hip.h, erl_ppo_set_arith): "auto" = the library default
+        # (split bf16 operands on the bf16 matrix pipe, fp32-equivalent, where the net shape allows), "f32" = the fp32 MFMA.
+        # Process-wide in the library: applied at every update_net of an agent that asks for something else than "auto".
+        self.ppo_arith = str(getattr(args, "ppo_arith", "auto"))
+        assert self.ppo_arith in ("auto", "f32", "split"), f"args.ppo_arith = {self.ppo_arith!r}"
         # which actor objective the kernels differentiate: the reference's sign-dependent scale (AgentPPO.py:199, default) or,
         # with args.canonical_ppo = True, the textbook min(r A, clamp(r, 1 - clip, 1 + clip) A) of
         # helloworld/helloworld_PPO_single_file.py:337-339
@@ -418,6 +423,8 @@ class AgentPPO(AgentBase):
         from .. import ops, parallel
         self._require_gpu("update_net")
         self._sync_modules()
+        if self.ppo_arith != "auto":
+            ops.ppo_set_arith(self.ppo_arith)
         states, actions, logprobs, rewards, undones, unmasks = buffer
         H, N = rewards.shape
         dev = self.device

@@ -186,7 +186,7 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
     constexpr float kC = 0.84932180028801904272f;              // sqrt(log2(e) / 2)
     constexpr float kP = 0.3275911f * 0.70710678118654752440f / kC;
     float z[EP], xa[EP], tt[EP], uu[EP], pp[EP];
-    auto stage = [&](int Tp, int ks, int s) {
+    auto stage = [&](int Tp, int ks, int s, bool fence = true) {
 #pragma unroll
         for (int i = 0; i < EP; ++i) {
             const int e = EP * ks + i;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
                 outH[Tp][e] = y;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (fence) __builtin_amdgcn_sched_barrier(0);
     };
     // pair s (of 4) of the operand of k-step ks from the fp32 input
     auto jit = [&](int ks, int s) {
@@ -279,11 +279,14 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
         prev = acc;
         prev1 = acc1;
     }
+    // the last tile has no MFMAs to ride behind: unfenced, so that all 16 elements' chains interleave (two dependent chains
+    // alone stall on each other: tools/split_mfma_probe.hip, part E)
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
 #pragma unroll
-        for (int s = 0; s < 6; ++s) stage(NO - 1, ks, s);
+        for (int s = 0; s < 6; ++s) stage(NO - 1, ks, s, false);
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -331,7 +334,7 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
     f32x16 prev, prev1;
     float v0[NPR], v1[NPR];
     // elements EP ks .. EP ks + EP - 1 of tile Tp: the gate products (stage 0) and their splits (stage 1)
-    auto gstage = [&](int Tp, int ks, int s) {
+    auto gstage = [&](int Tp, int ks, int s, bool fence = true) {
 #pragma unroll
         for (int i = 0; i < NPR; ++i) {
             const int e = EP * ks + 2 * i;
@@ -346,7 +349,7 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
                 o.h[(e & 7) >> 1] = h; o.m[(e & 7) >> 1] = mm; o.l[(e & 7) >> 1] = l;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (fence) __builtin_amdgcn_sched_barrier(0);
     };
 #pragma unroll
     for (int s = 0; s < 4; ++s) jit(0, s);
@@ -386,9 +389,10 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
     }
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        gstage(NO - 1, ks, 0);
-        gstage(NO - 1, ks, 1);
+        gstage(NO - 1, ks, 0, false);
+        gstage(NO - 1, ks, 1, false);
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // split registers of an activation (NKS k-steps = 16 NKS features) of this lane's sample -> the sample-major image

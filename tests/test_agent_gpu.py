@@ -33,7 +33,7 @@ class PlaybackVecEnv:
                 th.from_numpy(~g["undones"][t]).to(DEV), th.from_numpy(~g["unmasks"][t]).to(DEV), {})
 
 
-def make_agent(g):
+def make_agent(g, ppo_arith=None):
     from elegantrl_amd.agents import AgentPPO
     from elegantrl_amd.train import Config
     hp, d = hyper(g), dims(g)
@@ -46,6 +46,8 @@ def make_agent(g):
     args.clip_grad_norm = hp["max_norm"]
     args.if_use_v_trace = d["vtrace"]
     args.lambda_gae_adv, args.ratio_clip, args.lambda_entropy = hp["lam"], hp["ratio_clip"], hp["lambda_entropy"]
+    if ppo_arith is not None:
+        args.ppo_arith = ppo_arith
     agent = AgentPPO(args.net_dims, d["S"], d["A"], gpu_id=0, args=args)
     with th.no_grad():
         for net, prefix in ((agent.act, "act0"), (agent.cri, "cri0")):
@@ -95,10 +97,15 @@ def test_get_advantages_matches_reference_and_mutates_like_it(name):
     assert agent.get_reward_sum_gae.__func__ is agent.get_advantages.__func__
 
 
+@pytest.mark.parametrize("ppo_arith", ["auto", "f32", "split"])
 @pytest.mark.parametrize("name", PPO_GOLDENS)
-def test_update_net_matches_reference_weights_and_objectives(name):
+def test_update_net_matches_reference_weights_and_objectives(name, ppo_arith):
+    """the reference's own update_net run (weights and objectives after every recorded minibatch) under the library default, the
+    fp32-MFMA minibatch kernel and the split-bf16 one (args.ppo_arith)"""
+    from elegantrl_amd import ops
     g = load(name)
-    agent, _ = make_agent(g)
+    agent, _ = make_agent(g, ppo_arith)
+    prev = ops.ppo_set_arith("auto")
     agent.last_state = th.from_numpy(g["last_state"]).to(DEV)
     buf = [th.from_numpy(g[k]).to(DEV) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
     objs = agent.update_net(buf, ids=th.from_numpy(g["ids"]).to(DEV))
@@ -108,6 +115,7 @@ def test_update_net_matches_reference_weights_and_objectives(name):
             np.testing.assert_allclose(v.cpu().numpy(), g[f"{prefix}.{k}"], rtol=0, atol=3e-5, err_msg=f"{prefix}.{k}")
     moved = np.abs(agent.act.net[0].weight.detach().cpu().numpy() - g["act0.net.0.weight"]).max()
     assert moved > 1e-4
+    ops.ppo_set_arith(prev)
 
 
 @pytest.mark.parametrize("name", ["a2c_small.npz", "a2c_mid.npz"])
