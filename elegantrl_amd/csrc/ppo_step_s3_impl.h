@@ -231,6 +231,27 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
 #pragma unroll
     for (int s = 0; s < 4; ++s) jit(0, s);
     issue(0, aq[0]);
+    if constexpr (NK == 1) {
+        // one k-step per tile (S <= 8): six MFMAs cannot carry sixteen GELUs -- the epilogue runs on its own, on packed fp32
+        // (gelu_tile of ppo_step_w4_impl.h: 12.5 instructions per element instead of 17)
+#pragma unroll
+        for (int To = 0; To < NO; ++To) {
+            f32x16 acc;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi);
+                const float4 b1 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi + 4);
+                acc[8 * a + 0] = b0.x; acc[8 * a + 1] = b0.y; acc[8 * a + 2] = b0.z; acc[8 * a + 3] = b0.w;
+                acc[8 * a + 4] = b1.x; acc[8 * a + 5] = b1.y; acc[8 * a + 6] = b1.z; acc[8 * a + 7] = b1.w;
+            }
+            if (To + 1 < NO) issue(To + 1, aq[(To + 1) & 1]);
+            mma6(aq[To & 1], inP[0], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            gelu_tile(acc, outH[To], outG[To]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     // the accumulator starts from the bias, read a tile ahead (acc[8 a + e] <-> feature 32 To + 16 a + 8 hi + e)
     f32x16 nb;
     auto load_bias = [&](int To) {

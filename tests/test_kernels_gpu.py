@@ -531,8 +531,9 @@ S3_SHAPES = [(64, 128, 128, 8), (32, 128, 128, 3), (4, 128, 128, 8), (48, 128, 1
 def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
     """K6 on the bf16 matrix pipe (every operand split into three bf16 parts, six partial products, fp32 accumulation:
     csrc/ppo_step_s3_impl.h) against the fp64 restatement, next to the fp32-MFMA kernel on the same inputs: the split kernel
-    must be as close to fp64 as the fp32 one (its error may not exceed twice the fp32 kernel's, floor 3e-7 of the gradient's
-    scale) -- "fp32-equivalent" is asserted, not assumed."""
+    must be as close to fp64 as the fp32 one (its error may not exceed twice the fp32 kernel's, floor 1e-6 of the gradient's
+    scale: the fp32 kernel's own errors on this set reach 8.5e-7; one bf16 rounding would be 4e-3) -- "fp32-equivalent" is
+    asserted, not assumed."""
     rng = np.random.default_rng(7 * S + B)
     n_slabs, stride = ops.ppo_num_slabs(B), ops.ppo_slab_stride(S, h1, h2, A)
     H, N = 9, 50
@@ -562,7 +563,7 @@ def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
         ops.ppo_set_arith(prev)
     print(f"S={S} A={A} B={B}: max error / scale vs fp64 (actor grad, critic grad, objectives): f32 MFMA {errs['f32']}, split bf16 {errs['split']}")
     for name, e32, es in zip(("actor grad", "critic grad", "objectives"), errs["f32"], errs["split"]):
-        assert es <= max(2.0 * e32, 3e-7), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
+        assert es <= max(2.0 * e32, 1e-6), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
 
 
 @pytest.mark.parametrize("S,A,B,h1,h2", [(64, 8, 512, 128, 128), (32, 3, 200, 128, 128), (17, 5, 300, 128, 128), (3, 1, 128, 128, 128),
