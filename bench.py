@@ -128,7 +128,7 @@ def gae_sweep(ops, dev):
 # the files a kernel's HBM traffic depends on (what the PMC passes were collected on is stamped with their hash)
 KERNEL_SOURCES = {
     "ppo_step_w4_kernel": ["ppo_step_w4_impl.h", "ppo_step_w4.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
-    "ppo_step_s3_kernel": ["ppo_step_s3_impl.h", "ppo_step_s3.hip", "ppo_step_s3_pre.hip", "s3_image.h", "ppo_step_w4_impl.h", "ppo_step.h",
+    "ppo_step_s3_kernel": ["ppo_step_s3_impl.h", "split_bf16.h", "ppo_step_s3.hip", "ppo_step_s3_pre.hip", "s3_image.h", "ppo_step_w4_impl.h", "ppo_step.h",
                            "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "ppo_step2_kernel": ["ppo_step.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "gae_lookback_kernel": ["gae_lookback.hip"],

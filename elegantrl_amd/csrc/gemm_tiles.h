@@ -356,7 +356,9 @@ int gemm_launch(hipStream_t s, const GemmArgs &g_in, int splits, const char *wha
         // minibatch (B = 16384; profiles/r03_gemm_tile_ab.txt: whole layered step 180 / 227 / 266 us with 64 x 64 tiles against
         // 222 / 266 / 307 with 64 x 128, 227 / 264 / 308 with 128 x 64 and 329 / 361 / 418 with 128 x 128 at [128,128] / (256,128) /
         // (256,128,64)): the hypothesis that these GEMMs are bound by the ~12 B/clk a CU streams from beyond its L2 does not hold
-        // for them -- four 64 x 64 workgroups per CU hide each other's latency better than one big one.
+        // for them -- four 64 x 64 workgroups per CU hide each other's latency better than one big one.  Nor are they bound by the MFMA
+        // rate: the same GEMMs on the bf16 matrix pipe with split operands (as the PPO minibatch kernel, 2.7x the MFMA rate) measured
+        // 206 / 254 / 290 us (profiles/r03_gemm_split_ab.txt): K is 64 .. 256, the pipeline fill and the staging dominate.
         static const int forced = [] { const char *e = getenv("ERL_GEMM_TILE"); return e ? atoi(e) : 0; }();
         int rm = 1, rn = 1;
         if (forced == 12 || forced == 21 || forced == 22) { rm = forced / 10; rn = forced % 10; }

@@ -1,4 +1,4 @@
-"""The LDS image layout of the split-arithmetic minibatch kernel (elegantrl_amd/csrc/ppo_step_s3_impl.h: swz<>, phi; s3_image.h:
+"""The LDS image layout of the split-arithmetic minibatch kernel (elegantrl_amd/csrc/split_bf16.h: swz<>; ppo_step_s3_impl.h: phi; s3_image.h:
 s3_swz) restated in Python and checked against the three access patterns it was solved for, with the LDS lane groups and bank
 moduli of /opt/skills/guides/MI355X_MICROARCH.md (reads: 64 dword banks; writes: 32; ds_read_b128 in four 16-lane groups
 {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32; transposing reads in two 32-lane passes; ds_write_b128 in groups of 8 consecutive lanes).
@@ -32,7 +32,7 @@ def addr(CP, row, part, chunk, byte=0):
 
 def test_formulas_match_the_sources():
     """the C sources carry exactly these expressions (both copies: the kernel's template and the optimiser's runtime form)"""
-    for f in ("ppo_step_s3_impl.h", "s3_image.h"):
+    for f in ("split_bf16.h", "s3_image.h"):
         src = (CSRC / f).read_text()
         flat = re.sub(r"\s+", " ", src)
         assert "((r1 ^ r3) << 3) | (r0 << 2) | ((r1 ^ r2) << 1) | r2" in flat, f
