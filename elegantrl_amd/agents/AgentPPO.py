@@ -136,6 +136,7 @@ class AgentPPO(AgentBase):
         # arithmetic of the minibatch kernel's large products (include/erl_hip.h, erl_ppo_set_arith): "auto" = the library default
         # (split bf16 operands on the bf16 matrix pipe, fp32-equivalent, where the net shape allows), "f32" = the fp32 MFMA.
         # Process-wide in the library: applied at every update_net of an agent that asks for something else than "auto".
+        self.snapshot_last_state = bool(getattr(args, "snapshot_last_state", False))
         self.ppo_arith = str(getattr(args, "ppo_arith", "auto"))
         assert self.ppo_arith in ("auto", "f32", "split"), f"args.ppo_arith = {self.ppo_arith!r}"
         # which actor objective the kernels differentiate: the reference's sign-dependent scale (AgentPPO.py:199, default) or,
@@ -290,7 +291,10 @@ class AgentPPO(AgentBase):
             noise = None if noise is None else noise.contiguous()
             env.fused_rollout(self, H, noise, (states, actions, logprobs, rewards, undones, unmasks), values, next_value)
             self.rng_counter += H
-            self.last_state = env.state.clone()
+            # the env's live state buffer IS the last state (no copy out now, no copy back at the next call: two launches and
+            # ~50 us of interpreter time between them, with the GPU idle -- the previous iteration ended in a host sync);
+            # args.snapshot_last_state = True restores the private copy for callers that keep last_state across rollouts
+            self.last_state = env.state.clone() if self.snapshot_last_state else env.state
             self._rollout_cache = dict(states=states, values=values, next_value=next_value, last_state=self.last_state,
                                        key=self._value_cache_key(states, self.last_state))
             return states, actions, logprobs, rewards, undones, unmasks
