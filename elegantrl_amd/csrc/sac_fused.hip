@@ -701,6 +701,7 @@ struct DwArgs {
     DwProb p[DW_MAXP];
     int np;
     int64_t B;
+    float *clamp_alpha_log;     // not NULL: workgroup 0 also clamps the temperature's logarithm to [-16, 2] (see erl_sac_update_fused)
 };
 
 __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
@@ -708,6 +709,8 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
     __shared__ float red[4][32 * 33];
     __shared__ float bsum[4][32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    if (g.clamp_alpha_log && blockIdx.x == 0 && tid == 0)        // after alpha was read (AgentSAC.py:80-81): the actor's backward has run
+        g.clamp_alpha_log[0] = fminf(fmaxf(g.clamp_alpha_log[0], -16.f), 2.f);
     int pi = 0;
     for (int k = 1; k < g.np; ++k)
         if ((int)blockIdx.x >= g.p[k].tile0) pi = k;
@@ -805,11 +808,6 @@ __global__ __launch_bounds__(256) void alpha_step_fused_kernel(const float *__re
     m2[0] = b;
     const float denom = sqrtf(b) / bc2_sqrt + eps;
     alpha_log[0] = alpha_log[0] - step_size * (a / denom);
-}
-
-__global__ void clamp_alpha_fused_kernel(float *alpha_log)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) alpha_log[0] = fminf(fmaxf(alpha_log[0], -16.f), 2.f);   // after alpha was read (:80-81)
 }
 
 int wclass(int width) { return width <= 64 ? 0 : (width <= 128 ? 1 : 2); }
@@ -991,8 +989,8 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
         dw_add(dw, dZ1, 0, 1, h0, state, S, g_actor + d.aW1, g_actor + d.ab1);
         dw_add(dw, dZ2, 0, 1, h1, H0, h0, g_actor + d.aW2, g_actor + d.ab2);
         dw_add(dw, dY, 0, 1, 2 * A, H1, h1, g_actor + d.aWh, g_actor + d.abh);
+        dw.clamp_alpha_log = alpha_log;        // (one launch less than a kernel of its own: ~5 us of a 230 us step)
         if ((rc = dw_launch(dw, s))) return rc;
-        hipLaunchKernelGGL(clamp_alpha_fused_kernel, dim3(1), dim3(64), 0, s, alpha_log);
         const int64_t off = 0, len = Pa;
         if ((rc = erl_clip_adam_soft_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, step, lr, beta1, beta2, eps_adam, max_norm, 1.0f,
                                          nullptr, 0.f, s)))
