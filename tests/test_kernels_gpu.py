@@ -566,6 +566,45 @@ def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
         assert es <= max(2.0 * e32, 1e-6), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
 
 
+def test_ppo_step_split_arith_at_benchmark_size(ops, dev):
+    """BASELINE configs[3] at full size (4096 envs x 32 steps, minibatch 16384, obs 64, act 8, net [128,128]): the split-arithmetic
+    kernel and the fp32-MFMA kernel on the same minibatch, both against the fp64 restatement -- 128 gradient slabs per network
+    summed in a fixed order; the two kernels may differ from fp64 (and from each other) by fp32 rounding only."""
+    S, h1, h2, A, H, N, B = 64, 128, 128, 8, 32, 4096, 16384
+    rng = np.random.default_rng(2024)
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = buf_ids[:6], buf_ids[6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
+    n_slabs, stride = ops.ppo_num_slabs(B), ops.ppo_slab_stride(S, h1, h2, A)
+    assert n_slabs == 128
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64)
+    ref = np.concatenate([ga, gc])
+    got = {}
+    prev = ops.ppo_set_arith("f32")
+    try:
+        for arith in ("f32", "split"):
+            ops.ppo_set_arith(arith)
+            slabs = th.full((n_slabs, stride), float("nan"), device=dev)
+            flat = th.zeros(stride, device=dev)
+            ops.ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                         cu(critic.state_avg, dev), cu(critic.state_std, dev), S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev),
+                         0.25, 0.001, 1.0 / B, slabs, n_slabs)
+            ops.grad_reduce(slabs, n_slabs, stride, flat)
+            got[arith] = flat.cpu().numpy().astype(np.float64)
+            assert np.isfinite(got[arith]).all()
+    finally:
+        ops.ppo_set_arith(prev)
+    scale_a, scale_c = np.abs(ga).max(), np.abs(gc).max()
+    for arith, g in got.items():
+        ea, ec = np.abs(g[:Pa] - ga).max() / scale_a, np.abs(g[Pa:Pa + Pc] - gc).max() / scale_c
+        eo = np.abs(g[Pa + Pc:Pa + Pc + 3] - objs).max() / np.abs(objs).max()
+        print(f"{arith}: actor grad {ea:.2e}, critic grad {ec:.2e}, objectives {eo:.2e} of the scale against fp64")
+        assert ea < 1e-6 and ec < 1e-6 and eo < 1e-6, (arith, ea, ec, eo)
+    d = np.abs(got["split"][:Pa + Pc] - got["f32"][:Pa + Pc])
+    assert d[:Pa].max() / scale_a < 1e-6 and d[Pa:].max() / scale_c < 1e-6
+
+
 @pytest.mark.parametrize("S,A,B,h1,h2", [(64, 8, 512, 128, 128), (32, 3, 200, 128, 128), (17, 5, 300, 128, 128), (3, 1, 128, 128, 128),
                                           (3, 1, 256, 128, 64), (64, 8, 300, 64, 128), (20, 4, 200, 64, 64)])
 def test_update_loop_split_arith_images(ops, dev, S, A, B, h1, h2):
