@@ -11,7 +11,7 @@ import torch as th
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elegantrl_amd import _hip  # noqa: E402
 
-_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "liberl_hip_prof.so")
+_hip.LIB_PATH = os.environ.get("ERL_HIP_PROF_LIB") or os.path.join(os.path.dirname(_hip.LIB_PATH), "liberl_hip_prof.so")
 from elegantrl_amd import ops  # noqa: E402
 
 dev = th.device("cuda:0")
@@ -40,6 +40,9 @@ def main():
     ret = th.randn((H, N), device=dev, generator=g)
     um = th.rand((H, N), device=dev, generator=g) < 0.995
     ids = th.randint(H * N, (B,), device=dev, generator=g)
+    if os.environ.get("K6_IDS") == "contiguous":      # buffer rows t * N + n consecutive: id = n * H + t  (how much of the prologue is the gather?)
+        ar = th.arange(B, device=dev)
+        ids = (ar % N) * H + ar // N
     stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
     slabs = th.empty((n_slabs, stride), device=dev)
     prof = th.zeros(2 * 8 * 32, dtype=th.int64, device=dev)
