@@ -100,7 +100,7 @@ class EventTimer:
 
 def gae_sweep(ops, dev):
     out = []
-    for H, N in [(32, 4096), (200, 4096), (1024, 4096), (2048, 4096), (4096, 4096), (32, 32768)]:
+    for H, N in [(32, 4096), (128, 4096), (200, 4096), (1024, 4096), (2048, 4096), (4096, 4096), (32, 32768)]:   # SURVEY 8d sizes (+ 4096 x 4096)
         g = th.Generator(device=dev).manual_seed(0)
         r, v = th.randn((H, N), device=dev, generator=g), th.randn((H, N), device=dev, generator=g)
         u = th.rand((H, N), device=dev, generator=g) < 0.99
@@ -133,7 +133,8 @@ KERNEL_SOURCES = {
     "ppo_step2_kernel": ["ppo_step.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "gae_lookback_kernel": ["gae_lookback.hip"],
 }
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+KTIME_FILE = os.path.join("profiles", "r04_kernel_times.json")     # tools/kstats_summarise.py over rocprofv3 --kernel-trace --stats of this command
 
 
 def kernel_source_sha16(kernel: str):
@@ -161,6 +162,21 @@ def pmc_traffic(kernel):
         return None, src
 
 
+def rocprof_kernel_us(kernel):
+    """(average kernel duration under rocprofv3 --kernel-trace of this bench command on the authoring round's box, provenance) from the
+    committed summary KTIME_FILE; None when the kernel's sources have changed since it was collected.  A cross-check for
+    `avg_launch_us`, which is measured live: the two must agree."""
+    src = {"file": KTIME_FILE, "kernel_source_sha16": kernel_source_sha16(kernel), "collected_on_sha16": None, "stale": True}
+    try:
+        v = json.load(open(os.path.join(ROOT, KTIME_FILE)))["kernels"][kernel]
+        src["collected_on_sha16"] = v.get("source_sha16")
+        src["stale"] = v.get("source_sha16") != src["kernel_source_sha16"]
+        src["calls"] = v.get("calls")
+        return (None if src["stale"] else v["avg_us"]), src
+    except Exception:
+        return None, src
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -178,8 +194,9 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline_subprocess(iters: int, config: str = "c4", timeout_s: int = 240):
-    """run the CPU leg in its own process (fresh OpenMP pool, hard timeout) and parse its JSON line."""
+def cpu_baseline_subprocess(iters: int, config: str = "c4", timeout_s: int = 300):
+    """run the CPU leg in its own process (fresh OpenMP pool, hard timeout, and -- where /root/reference is mounted -- the
+    reference's own `elegantrl` package instead of this repository's import alias) and parse its JSON line."""
     import subprocess
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-iters", str(iters),
@@ -193,30 +210,30 @@ def cpu_baseline_subprocess(iters: int, config: str = "c4", timeout_s: int = 240
         return {"value": None, "unit": "env-steps/s", "kind": "port", "error": f"timed out after {timeout_s}s"}
 
 
-def cpu_baseline(iters=12):
-    """oracle/torch_port.py on the host cores, same workload shape (bounded sample: 1 warm-up + `iters` iterations)."""
-    from oracle.torch_port import TorchPortPPO, TorchSynEnv
-    th.manual_seed(0)
+def cpu_baseline(iters=12, config="c4"):
+    """the reference's CPU path on this box's host cores, same workload, bounded sample (oracle/cpu_baseline.py): the
+    reference's own classes where /root/reference is mounted (kind "reference", with the torch port timed right after it on the
+    same cores as `port_same_cores`, so that the port's number on a box without the reference is a validated stand-in), else the
+    port (kind "port").  Per-stage seconds: explore_env / get_advantages / update_net (+ buffer_update / sample for c3)."""
+    from oracle import cpu_baseline as cb
     cores = usable_cores()
     th.set_num_threads(cores)
-    env = TorchSynEnv(N_ENVS, STATE_DIM, ACTION_DIM, 1000, seed=0)
-    port = TorchPortPPO(STATE_DIM, ACTION_DIM, tuple(NET_DIMS))
-    port.last_state = env.reset()
-
-    def one():
-        buf = port.explore(env, HORIZON)
-        port.update(list(buf), BATCH, UPDATE_TIMES)
-
-    one()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        one()
-    dt = time.perf_counter() - t0
-    return {"value": round(N_ENVS * HORIZON * iters / dt, 1), "unit": "env-steps/s", "cores": th.get_num_threads(),
-            "kind": "port", "sample": f"{iters} PPO iterations (+1 warm-up) of the same workload "
-                                      f"({N_ENVS} envs x {HORIZON} steps, {UPDATE_TIMES} minibatches of {BATCH}) via "
-                                      f"oracle/torch_port.py",
-            "seconds": round(dt, 2)}
+    if config == "c3":
+        kw = dict(N=64, S=11, A=3, H=64, B=256, updates=64, net_dims=[256, 256], max_size=1_000_000 // 64, iters=iters)
+        run = cb.sac
+    else:
+        c = PPO_CONFIGS[config]
+        kw = dict(N=c["N"], S=c["S"], A=c["A"], H=c["H"], B=c["B"], update_times=c["update_times"], net_dims=c["net_dims"], iters=iters,
+                  hyper=c["hyper"], max_step=200 if c["env"] == "pendulum" else 1000, env_kind=c["env"])
+        run = cb.ppo
+    if cb.reference_available():
+        line = run("reference", **kw)
+        port = run("port", **kw)
+        line["port_same_cores"] = {k: port[k] for k in ("value", "unit", "seconds", "stage_seconds")}
+        line["port_over_reference"] = round(port["value"] / line["value"], 3)
+    else:
+        line = run("port", **kw)
+    return line
 
 
 def bench_sac(opt):
@@ -296,6 +313,9 @@ def bench_sac(opt):
                                        "achieved": round(big_bytes / big_s / 1e9, 1), "frac": round(big_bytes / big_s / 1e9 / HBM_PEAK_GBPS, 4)}},
         "objectives_last": [round(float(x), 6) for x in objs],
     }
+    if not opt.no_cpu_baseline:
+        log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
+        line["cpu_baseline"] = cpu_baseline_subprocess(max(2, opt.cpu_iters // 2), "c3")
     print(json.dumps(line), flush=True)
 
 
@@ -317,12 +337,12 @@ def main():
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
                          "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs")
     opt = ap.parse_args()
+    if opt.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(opt.cpu_iters, opt.config)), flush=True)
+        return
     if opt.config == "c3":
         return bench_sac(opt)
     cfg = select_config(opt.config)
-    if opt.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(opt.cpu_iters)), flush=True)
-        return
 
     from elegantrl_amd import ops, parallel
     from elegantrl_amd.agents import AgentPPO
@@ -358,16 +378,23 @@ def main():
     t_gae = EventTimer()
     ops.gae_scan = t_gae.wrap(ops.gae_scan)
 
+    # one event bracket per call around the two drop-in entry points (2 per iteration: ~6 us of a 2.4 ms step): the parts of a step
+    t_explore, t_update = EventTimer(), EventTimer()
+    explore_env, update_net = t_explore.wrap(agent.explore_env), t_update.wrap(agent.update_net)
+
     def step():
-        items = agent.explore_env(env, HORIZON)
-        return agent.update_net(list(items))
+        items = explore_env(env, HORIZON)
+        return update_net(list(items))
 
     log(f"rank {rank}/{world}: agent + env ready, warm-up x{opt.warmup}")
     for _ in range(opt.warmup):
         step()
+    th.cuda.synchronize()
+    null_bracket_us = _hip.k6_null_bracket_us(200)       # what an event bracket adds to its content on this box (empty launch)
     log("timed region")
-    t_gae.enabled = True
-    _hip.k6_timing_enable(opt.k6_sample)         # erl_ppo_step_f32 brackets every n-th K6 launch with HIP events on its stream
+    t_gae.enabled = t_explore.enabled = t_update.enabled = True
+    # every n-th K6 launch is timed twice: a HIP-event bracket on its stream and the kernel's own span on the device clock
+    _hip.k6_timing_enable(opt.k6_sample)
     parallel.barrier()
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -376,9 +403,9 @@ def main():
     th.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.all_reduce_max_float(time.perf_counter() - t0, device=dev)
-    t_gae.enabled = False
+    t_gae.enabled = t_explore.enabled = t_update.enabled = False
     _hip.k6_timing_enable(False)
-    k6_seconds, k6_launches = _hip.k6_timing_read()
+    k6_event_seconds, k6_span_seconds, k6_launches = _hip.k6_timing_read2()
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
     # box variance made visible next to the driver's single sample: the same region repeated (not part of `value`)
@@ -396,7 +423,7 @@ def main():
     f32_region = None
     k6_arith = ops.ppo_arith_in_use(STATE_DIM, NET_DIMS[0], NET_DIMS[1], ACTION_DIM) if len(NET_DIMS) == 2 else "f32"
     if k6_arith == "split" and opt.repeats:
-        prev_arith = ops.ppo_set_arith("f32")
+        prev_arith, agent.ppo_arith = agent.ppo_arith, "f32"      # (the agent applies its ppo_arith at every update_net)
         for _ in range(2):
             step()
         parallel.barrier()
@@ -407,6 +434,7 @@ def main():
         th.cuda.synchronize()
         parallel.barrier()
         el = parallel.all_reduce_max_float(time.perf_counter() - t1, device=dev)
+        agent.ppo_arith = prev_arith
         ops.ppo_set_arith(prev_arith)
         f32_region = {"ms_per_step": round(el / opt.steps * 1e3, 3), "value": round(world * N_ENVS * HORIZON * opt.steps / el, 1),
                       "objectives_last": [round(float(x), 6) for x in objs_f32],
@@ -438,7 +466,13 @@ def main():
         return
     env_steps = world * N_ENVS * HORIZON * opt.steps
     flops = ppo_flops_per_sample(STATE_DIM, *NET_DIMS, ACTION_DIM) * BATCH
-    ppo_s, n_k6 = (k6_seconds / k6_launches if k6_launches else float("nan")), k6_launches
+    n_k6 = k6_launches
+    k6_event_s = k6_event_seconds / n_k6 if n_k6 else float("nan")
+    k6_span_s = k6_span_seconds / n_k6 if n_k6 and k6_span_seconds > 0 else float("nan")
+    # the kernel's duration: its own first-workgroup-in to last-workgroup-out span on the device's constant-rate clock (no dispatch or
+    # completion overhead of a bracket in it; agrees with rocprofv3's kernel duration -- `kernel_us_rocprof`); fallback: the event
+    # bracket minus the bracket of an empty launch
+    ppo_s = k6_span_s if k6_span_s == k6_span_s else max(k6_event_s - null_bracket_us * 1e-6, 1e-9)
     # which K6 kernel erl_ppo_step_f32 dispatches to: the one-wave-per-SIMD form for h1, h2 in {64, 128}, S <= 64, A <= 8
     k6_kernel = "ppo_step_w4_kernel" if (len(NET_DIMS) == 2 and all(d in (64, 128) for d in NET_DIMS) and STATE_DIM <= 64
                                          and ACTION_DIM <= 8) else "ppo_step2_kernel"
@@ -449,6 +483,22 @@ def main():
     k6_peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS if k6_arith == "split" else MFMA_F32_PEAK_TFLOPS
     gae_s = t_gae.mean_seconds()
     k6_traffic, k6_traffic_src = pmc_traffic(k6_kernel) if opt.config == "c4" else (None, None)
+    k6_rocprof_us, k6_rocprof_src = rocprof_kernel_us(k6_kernel) if opt.config == "c4" else (None, None)
+    # the parts of a step against the step: explore_env + update_net brackets (each carries one bracket overhead) must fit into
+    # ms_per_step, and the K6 launches must fit into update_net
+    explore_ms, update_ms = t_explore.mean_seconds() * 1e3, t_update.mean_seconds() * 1e3
+    k6_ms = UPDATE_TIMES * ppo_s * 1e3
+    step_ms = elapsed / opt.steps * 1e3
+    breakdown = {"explore_env_ms": round(explore_ms, 4), "update_net_ms": round(update_ms, 4),
+                 "k6_ms": round(k6_ms, 4), "update_net_minus_k6_ms": round(update_ms - k6_ms, 4),
+                 "per_minibatch_rest_us": round((update_ms - k6_ms) / UPDATE_TIMES * 1e3, 2),
+                 "host_and_gaps_ms": round(step_ms - explore_ms - update_ms, 4),
+                 "consistent": bool(k6_ms <= update_ms and explore_ms + update_ms <= step_ms * 1.01),
+                 "note": "HIP-event brackets around agent.explore_env / agent.update_net (means over the timed region); k6_ms = update_times x "
+                         "roofline.avg_launch_us; per_minibatch_rest_us = slab reduction + clip/Adam + launch boundaries (+ GAE, statistics, "
+                         "index draw, log fold, amortised over the minibatches); consistent = the parts fit into the step"}
+    if not breakdown["consistent"]:
+        log(f"WARNING: timing parts do not fit into the step: {breakdown}")
     line = {
         "metric": cfg["metric"], "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
@@ -456,6 +506,7 @@ def main():
         "config": {"workload": cfg["workload"], "name": opt.config,
                    "envs_per_gpu": N_ENVS, "horizon": HORIZON, "batch": BATCH, "update_times": UPDATE_TIMES,
                    "parallelism": f"dp{world}" if world > 1 else "single",
+                   "last_state": "private copy (reference behaviour)" if agent.snapshot_last_state else "aliases the env's live state buffer",
                    "k6_arith": ("split: fp32 operands as three bf16 parts on the bf16 matrix pipe, fp32 accumulate (as close to fp64 as the "
                                 "fp32 MFMA: tests/test_kernels_gpu.py::test_ppo_step_split_arith)" if k6_arith == "split" else "f32 MFMA")},
         "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
@@ -465,7 +516,12 @@ def main():
                                if k6_arith == "split" else "fp32 operands on v_mfma_f32_32x32x2_f32"),
                      "frac_of_fp32_mfma_peak": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops,
-                     "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6},
+                     "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6,
+                     "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel, every "
+                               f"{opt.k6_sample}th launch of the timed region)" if k6_span_s == k6_span_s else "HIP-event bracket minus empty-launch bracket"),
+                     "event_bracket_us": round(k6_event_s * 1e6, 2), "event_bracket_null_us": round(null_bracket_us, 2),
+                     "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src},
+        "breakdown": breakdown,
         "roofline_gae": {"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
                          "bound": "hbm",
                          "achieved": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -491,7 +547,7 @@ def main():
         line["roofline_gae"]["at_2048x4096"] = {"kernel": "gae_lookback_kernel (library-owned granule table, no memset)", "achieved": big["GBps"],
                                                 "frac": big["frac"], "us": big["us"], "bytes_per_launch": big["bytes"],
                                                 "traffic": gae_tr, "traffic_source": gae_tr_src}
-    if world == 1 and not opt.no_cpu_baseline and not pendulum:      # the torch port has the synthetic env only
+    if world == 1 and not opt.no_cpu_baseline:
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
         line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else max(2, opt.cpu_iters // 4), opt.config)
     log("done")

@@ -22,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 14
+ABI_VERSION = 15
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -94,6 +94,8 @@ _SIGNATURES = {
     "erl_grad_sq_partials_f32": (c_int, [_P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
     "erl_clip_adam_partials_f32": (c_int, [_P, _P, _P, _P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
                                            c_float, c_float, c_float, c_float, c_float, _P]),
+    "erl_comm_clip_adam_partials_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
+                                                c_float, c_float, c_float, c_float, c_float, _P]),
     "erl_comm_p2p_create": (c_int, [c_int, c_int, c_int64, POINTER(c_void_p), _P]),
     "erl_comm_p2p_connect": (c_int, [_P, _P]),
     "erl_comm_p2p_set_spin": (c_int, [_P, ctypes.c_uint32]),
@@ -119,6 +121,8 @@ _SIGNATURES = {
                                            c_int64, _P]),
     "erl_k6_timing_enable": (None, [c_int]),
     "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
+    "erl_k6_timing_read2": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
+    "erl_k6_timing_null_bracket_us": (c_int, [_P, c_int, POINTER(ctypes.c_double)]),
     "erl_synenv_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_uint64, _P]),
     "erl_pendulum_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_uint64, _P]),
     "erl_selftest_mfma": (c_int, [POINTER(c_float)]),
@@ -226,6 +230,22 @@ def k6_timing_read():
     ms, n = ctypes.c_double(0), c_int(0)
     check(lib().erl_k6_timing_read(ctypes.byref(ms), ctypes.byref(n)), "erl_k6_timing_read")
     return ms.value * 1e-3, n.value
+
+
+def k6_timing_read2():
+    """(event-bracket seconds, in-kernel span seconds, number of launches) summed over the K6 launches sampled since the last read:
+    the HIP-event bracket contains the bracket's own dispatch / completion overhead, the span is first workgroup in to last
+    workgroup out on the device's constant-rate clock."""
+    ev, sp, n = ctypes.c_double(0), ctypes.c_double(0), c_int(0)
+    check(lib().erl_k6_timing_read2(ctypes.byref(ev), ctypes.byref(sp), ctypes.byref(n)), "erl_k6_timing_read2")
+    return ev.value * 1e-3, sp.value * 1e-3, n.value
+
+
+def k6_null_bracket_us(reps: int = 200) -> float:
+    """median HIP-event bracket around an EMPTY launch on the current stream (microseconds): what a bracket adds to its content."""
+    us = ctypes.c_double(0)
+    check(lib().erl_k6_timing_null_bracket_us(stream_ptr(), int(reps), ctypes.byref(us)), "erl_k6_timing_null_bracket_us")
+    return us.value
 
 
 def selftest_mfma() -> float:

@@ -135,7 +135,7 @@ class AgentPPO(AgentBase):
         self.gae_algo = getattr(args, "gae_algo", "auto")
         # arithmetic of the minibatch kernel's large products (include/erl_hip.h, erl_ppo_set_arith): "auto" = the library default
         # (split bf16 operands on the bf16 matrix pipe, fp32-equivalent, where the net shape allows), "f32" = the fp32 MFMA.
-        # Process-wide in the library: applied at every update_net of an agent that asks for something else than "auto".
+        # Process-wide in the library: applied at every update_net (an "auto" agent resets what an "f32" agent set before it).
         self.snapshot_last_state = bool(getattr(args, "snapshot_last_state", False))
         self.ppo_arith = str(getattr(args, "ppo_arith", "auto"))
         assert self.ppo_arith in ("auto", "f32", "split"), f"args.ppo_arith = {self.ppo_arith!r}"
@@ -427,8 +427,7 @@ class AgentPPO(AgentBase):
         from .. import ops, parallel
         self._require_gpu("update_net")
         self._sync_modules()
-        if self.ppo_arith != "auto":
-            ops.ppo_set_arith(self.ppo_arith)
+        ops.ppo_set_arith(self.ppo_arith)       # process-wide in the library: set at EVERY update, so that "auto" is the library default
         states, actions, logprobs, rewards, undones, unmasks = buffer
         H, N = rewards.shape
         dev = self.device

@@ -61,8 +61,8 @@ extern "C" int erl_async_fault_count(int reset)
     if (!g_fault_host) return 0;
     static const char *const what[ERL_FAULT_SOURCES] = {
         "gae_lookback_kernel: %u look-back wait(s) timed out (a predecessor slab never published); the affected advantages are NaN. ",
-        "peer-to-peer gradient exchange: %u wait(s) for a peer's slice timed out (a rank is missing or stalled); the summed gradients "
-        "of those minibatches are invalid. ",
+        "peer-to-peer gradient exchange: %u wait(s) for a peer's slice timed out (a rank is missing or stalled); the optimiser steps "
+        "from that exchange on were SKIPPED (parameters and moments untouched). ",
         "clip + Adam grid wait: %u workgroup(s) gave up waiting for the rest of the launch (device shared with another process?); "
         "those parameter updates were SKIPPED. "};
     char msg[512] = "";
@@ -71,6 +71,7 @@ extern "C" int erl_async_fault_count(int reset)
         const uint32_t n = __atomic_load_n(g_fault_host + s, __ATOMIC_ACQUIRE);
         if (!n) continue;
         if (reset) __atomic_store_n(g_fault_host + s, 0u, __ATOMIC_RELEASE);
+        if (reset && s == ERL_FAULT_P2P_EXCHANGE) erl_p2p_clear_poison_all();     // the fault is being reported: un-poison the communicators
         total += n;
         const size_t used = strlen(msg);
         snprintf(msg + used, sizeof(msg) - used, what[s], n);
@@ -85,40 +86,77 @@ extern "C" int erl_async_fault_count(int reset)
 // ctypes).  The loop itself lives in comm.cpp (erl_ppo_update_dp_f32): under data parallelism the gradient all-reduce
 // sits between the slab reduction and the optimiser step, issued by RCCL on the same stream.
 // ---------------------------------------------------------------------------------------------------------
-// optional per-launch timing of K6 (measurement hook for bench.py: erl_ppo_step_f32 brackets its launch with HIP events
-// on the launch stream; off by default).  The event pairs are kept until erl_k6_timing_read() drains them.
+// optional per-launch timing of K6 (measurement hook for bench.py; off by default).  Two clocks on every sampled launch:
+//   * a HIP-event bracket on the launch stream.  It contains the dispatch of the kernel behind the first event and the completion
+//     signal in front of the second one -- 3 to 15 us on top of the kernel depending on the box (round 3's driver line could not be
+//     reconciled with its own step time because of it); erl_k6_timing_null_bracket_us() brackets an EMPTY launch the same way,
+//     so that the overhead is a measured number, not a guess;
+//   * the kernel's own span on the device's constant-rate clock: thread 0 of every workgroup folds its entry and exit time
+//     (wall_clock64) into a {min, max} slot of a library-owned table (Ppo2Args::span) -- first workgroup in to last workgroup out,
+//     no host, no command processor in it.  This is what rocprofv3's kernel duration measures to within the dispatch ramp.
+// The pairs are kept until erl_k6_timing_read2() drains them.
+#include <algorithm>
 #include <vector>
-static int g_k6_timing = 0;              // 0 = off, n = bracket every n-th launch
+static int g_k6_timing = 0;              // 0 = off, n = sample every n-th launch
 static long g_k6_launch = 0;
 static bool g_k6_skip = false;
 static std::vector<hipEvent_t> g_k6_events;
 static hipEvent_t g_k6_open = nullptr;
+static unsigned long long *g_k6_span = nullptr;      // device: kK6SpanSlots x {min entry, max exit}
+static int g_k6_span_used = 0;
+constexpr int kK6SpanSlots = 8192;
 
-// called by erl_ppo_step_f32 right before (which = 0) and right after (which = 1) it enqueues K6
-void erl_k6_timing_mark(hipStream_t stream, int which)
+static void k6_span_reset()
 {
-    if (!g_k6_timing) return;
-    if (which == 0) g_k6_skip = (g_k6_launch++ % g_k6_timing) != 0;
-    if (g_k6_skip) return;
+    if (!g_k6_span && hipMalloc((void **)&g_k6_span, sizeof(unsigned long long) * 2 * kK6SpanSlots) != hipSuccess) {
+        g_k6_span = nullptr;
+        (void)hipGetLastError();
+        return;
+    }
+    std::vector<unsigned long long> init(2 * kK6SpanSlots);
+    for (int i = 0; i < kK6SpanSlots; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+    (void)hipMemcpy(g_k6_span, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+    g_k6_span_used = 0;
+}
+
+// called by erl_ppo_step_f32 right before it enqueues K6: first event of the bracket; returns the span slot of this launch
+// (nullptr: launch not sampled)
+unsigned long long *erl_k6_timing_begin(hipStream_t stream)
+{
+    if (!g_k6_timing) return nullptr;
+    g_k6_skip = (g_k6_launch++ % g_k6_timing) != 0;
+    if (g_k6_skip) return nullptr;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { g_k6_skip = true; return nullptr; }
+    (void)hipEventRecord(e, stream);
+    if (g_k6_open) (void)hipEventDestroy(g_k6_open);
+    g_k6_open = e;
+    if (!g_k6_span || g_k6_span_used >= kK6SpanSlots) return nullptr;
+    return g_k6_span + 2 * g_k6_span_used++;
+}
+
+// ... and right after
+void erl_k6_timing_end(hipStream_t stream)
+{
+    if (!g_k6_timing || g_k6_skip || !g_k6_open) return;
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, stream);
-    if (which == 0) {
-        if (g_k6_open) (void)hipEventDestroy(g_k6_open);
-        g_k6_open = e;
-    } else if (g_k6_open) {
-        g_k6_events.push_back(g_k6_open);
-        g_k6_events.push_back(e);
-        g_k6_open = nullptr;
-    } else {
-        (void)hipEventDestroy(e);
-    }
+    g_k6_events.push_back(g_k6_open);
+    g_k6_events.push_back(e);
+    g_k6_open = nullptr;
 }
 
-extern "C" void erl_k6_timing_enable(int every_nth) { g_k6_timing = every_nth > 0 ? every_nth : 0; g_k6_launch = 0; }
+extern "C" void erl_k6_timing_enable(int every_nth)
+{
+    g_k6_timing = every_nth > 0 ? every_nth : 0;
+    g_k6_launch = 0;
+    if (g_k6_timing) k6_span_reset();
+}
 
-// waits for the recorded events, returns the summed K6 time in milliseconds and the number of launches, and clears.
-extern "C" int erl_k6_timing_read(double *total_ms, int *launches)
+// waits for the recorded events; returns the summed event-bracket time and the summed in-kernel spans (milliseconds; the
+// latter 0 when the span table could not be allocated) over `launches` sampled launches, and clears both lists.
+extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launches)
 {
     double tot = 0.0;
     int n = 0;
@@ -133,8 +171,57 @@ extern "C" int erl_k6_timing_read(double *total_ms, int *launches)
         (void)hipEventDestroy(g_k6_events[i + 1]);
     }
     g_k6_events.clear();
-    if (total_ms) *total_ms = tot;
+    double span = 0.0;
+    if (g_k6_span && g_k6_span_used > 0) {
+        int dev = 0, khz = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
+        std::vector<unsigned long long> h(2 * (size_t)g_k6_span_used);
+        if (hipMemcpy(h.data(), g_k6_span, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            int m = 0;
+            for (int i = 0; i < g_k6_span_used; ++i)
+                if (h[2 * i + 1] > h[2 * i]) { span += (double)(h[2 * i + 1] - h[2 * i]) / khz; ++m; }
+            if (m && m != n) span *= (double)n / m;         // (slots that never ran: scale to the bracketed count)
+        }
+        k6_span_reset();
+    }
+    if (event_ms) *event_ms = tot;
+    if (span_ms) *span_ms = span;
     if (launches) *launches = n;
+    return ERL_OK;
+}
+
+extern "C" int erl_k6_timing_read(double *total_ms, int *launches) { return erl_k6_timing_read2(total_ms, nullptr, launches); }
+
+void erl_launch_null_kernel(hipStream_t stream);     // ppo_step.hip
+
+// the event bracket around an EMPTY launch (one workgroup, no work) behind a finished kernel, the way K6 is bracketed in the
+// loop: median over `reps` in microseconds -- what a bracket adds to whatever it contains on this box, at this moment.
+extern "C" int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median_us)
+{
+    hipStream_t st = (hipStream_t)stream;
+    reps = std::max(1, std::min(reps, 1000));
+    std::vector<hipEvent_t> ev(2 * (size_t)reps, nullptr);
+    for (auto &e : ev) {
+        int rc = erl_hip_status(hipEventCreate(&e), "hipEventCreate");
+        if (rc) return rc;
+    }
+    for (int i = 0; i < reps; ++i) {
+        erl_launch_null_kernel(st);                    // "the previous kernel of the loop"
+        (void)hipEventRecord(ev[2 * i], st);
+        erl_launch_null_kernel(st);
+        (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    std::vector<double> us;
+    for (int i = 0; i < reps; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess)
+            us.push_back(ms * 1e3);
+    }
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (us.empty()) { erl_set_error("erl_k6_timing_null_bracket_us: no event pair completed"); return ERL_EINVAL; }
+    std::sort(us.begin(), us.end());
+    if (median_us) *median_us = us[us.size() / 2];
     return ERL_OK;
 }
 

@@ -140,6 +140,8 @@ extern "C" int erl_comm_allreduce_sum_f64(void *comm, double *buf, int64_t count
                        "ncclAllReduce(f64)");
 }
 
+uint32_t *erl_comm_poison_word(void *comm) { return comm && ((Comm *)comm)->p2p ? erl_p2p_poison_word(((Comm *)comm)->p2p) : nullptr; }
+
 extern "C" int erl_comm_kind(void *comm) { return comm ? (((Comm *)comm)->p2p ? ERL_COMM_KIND_P2P : ERL_COMM_KIND_RCCL) : -1; }
 
 // launch 1 of the data-parallel optimiser tail on its own (the update loop below calls the same code): slab reduction +
@@ -235,7 +237,7 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
         // launch 2: clip + Adam from the partial norms.  Gradient + the 3 logged objectives travel in one row.
         if ((rc = erl_comm_reduce_exchange_f32(comm, slabs, n_slabs, stride, g, off, len, 2, grad_scale, stream))) return rc;
         if ((rc = erl_clip_adam_partials_images_f32(flat_params, g, exp_avg, exp_avg_sq, stride, off, len, 2, first_step + k, lr, beta1, beta2,
-                                                    eps, max_norm, grad_scale, im, stream)))
+                                                    eps, max_norm, grad_scale, im, erl_comm_poison_word(comm), stream)))
             return rc;
     }
     return ERL_OK;

@@ -25,6 +25,7 @@ struct ErlExchange {
     uint32_t seq, spin_limit;
     int rank, world;
     uint32_t *fault;
+    uint32_t *poison;                     // the communicator's sticky word: set when a wait of this update loop timed out
 };
 int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *out_handle);
 int erl_p2p_connect(void *p2p, const uint8_t *handles);
@@ -32,6 +33,9 @@ int erl_p2p_connect(void *p2p, const uint8_t *handles);
 int erl_p2p_next(void *p2p, ErlExchange *out);
 void erl_p2p_set_spin(void *p2p, uint32_t spins);      // 0 restores the default bound
 void erl_p2p_destroy(void *p2p);
+uint32_t *erl_p2p_poison_word(void *p2p);                  // device word; non-zero: skip the optimiser steps
+void erl_p2p_clear_poison_all();                           // host, synchronous: after the fault has been reported
+uint32_t *erl_comm_poison_word(void *comm);                // comm.cpp: nullptr unless a peer-to-peer communicator
 // grad_tail.hip
 int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len,
                                    int n_groups, float grad_scale, bool want_partials, const ErlExchange *ex, hipStream_t stream);

@@ -96,8 +96,13 @@ __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - ex.seq) < 0) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > ex.spin_limit) {         // a peer never arrived: reported, never a hang (the sum below is then garbage)
+                if (++spins > ex.spin_limit) {
+                    // a peer never arrived: reported, never a hang.  The sum below is then garbage, so the communicator is POISONED
+                    // (sticky device word): clip_adam_partials_kernel leaves parameters, moments and W2 images untouched for the
+                    // rest of the update loop -- the same policy as a timed-out grid wait in optim.hip -- and the error is raised
+                    // when the host reads the fault counter at the end of update_net (which also clears the word)
                     if (ex.fault) __hip_atomic_fetch_add(ex.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (ex.poison) __hip_atomic_fetch_or(ex.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }
@@ -151,9 +156,12 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
                                                                   float *__restrict__ m1, float *__restrict__ m2, TailGroups gr,
                                                                   const double *__restrict__ partials, int nblk, float beta1,
                                                                   float beta2, float eps, float max_norm, float grad_scale,
-                                                                  float step_size, float bc2_sqrt, S3Images im)
+                                                                  float step_size, float bc2_sqrt, S3Images im,
+                                                                  const uint32_t *__restrict__ poison)
 {
     __shared__ double scratch[16];
+    // a gradient exchange of this update loop timed out (reduce_exchange_kernel): its sums are garbage -- touch nothing
+    if (poison && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int gi = blockIdx.y;
     const int64_t off = gr.off[gi], len = gr.len[gi];
     const int64_t ie = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -210,9 +218,14 @@ __global__ __launch_bounds__(192) void logs_mean_kernel(const float *__restrict_
     }
 }
 
-// the partial-norm table of the update loop: library-owned, one per device, written by launch 1 and read by launch 2 of the
-// SAME stream (the update loop's)
-double *g_partials[32] = {};
+// the partial-norm table of an optimiser tail: library-owned, one per (device, stream) that ran one -- written by launch 1 and
+// read by launch 2 of the SAME stream, so two update loops on different streams of a device never share a table
+struct PartialsSlot {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    double *buf = nullptr;
+};
+PartialsSlot g_partials[32];
 
 int fill_groups(const char *what, const int64_t *off, const int64_t *len, int n_groups, int64_t stride, TailGroups *gr)
 {
@@ -227,17 +240,25 @@ int fill_groups(const char *what, const int64_t *off, const int64_t *len, int n_
 
 }  // namespace
 
-int erl_tail_partials(double **out)
+int erl_tail_partials(double **out, hipStream_t stream)
 {
     int dev = -1;
-    ERL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32, "gradient tail: no device");
-    if (!g_partials[dev]) {
+    ERL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, "gradient tail: no device");
+    PartialsSlot *slot = nullptr;
+    for (auto &s : g_partials)
+        if (s.buf && s.device == dev && s.stream == stream) { slot = &s; break; }
+    if (!slot) {
+        for (auto &s : g_partials)
+            if (!s.buf) { slot = &s; break; }
+        ERL_REQUIRE(slot, "gradient tail: more than 32 (device, stream) pairs ran an optimiser tail");
         void *p = nullptr;
         int rc = erl_hip_status(hipMalloc(&p, (size_t)kMaxPartialChunks * 4 * sizeof(double)), "hipMalloc(partial norms)");
         if (rc) return rc;
-        g_partials[dev] = (double *)p;
+        slot->buf = (double *)p;
+        slot->device = dev;
+        slot->stream = stream;
     }
-    *out = g_partials[dev];
+    *out = slot->buf;
     return ERL_OK;
 }
 
@@ -251,9 +272,10 @@ int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stri
     if (rc) return rc;
     double *partials = nullptr;
     if (want_partials) {
-        ERL_REQUIRE(erl_cdiv(stride, 64) <= kMaxPartialChunks, "gradient reduce / exchange: row too long for the partial-norm table (%lld floats)",
+        // (the exchanging form writes whole 256-element workgroups: up to 4 * ceil(stride / 256) chunks)
+        ERL_REQUIRE(4 * erl_cdiv(stride, 256) <= kMaxPartialChunks, "gradient reduce / exchange: row too long for the partial-norm table (%lld floats)",
                     (long long)stride);
-        if ((rc = erl_tail_partials(&partials))) return rc;
+        if ((rc = erl_tail_partials(&partials, stream))) return rc;
     }
     if (ex) {       // 1024 threads x 256 elements: one flag per workgroup and peer -- 199 x world small remote stores per exchange at config 4
         const int64_t nblk = erl_cdiv(stride, 256);
@@ -301,7 +323,8 @@ extern "C" int erl_grad_sq_partials_f32(float *grads, int64_t stride, const int6
 
 int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
                                       const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
-                                      float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, void *stream)
+                                      float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, const uint32_t *poison,
+                                      void *stream)
 {
     ERL_REQUIRE(params && grads && exp_avg && exp_avg_sq && n_groups >= 1 && step >= 1, "erl_clip_adam_partials_f32: bad argument");
     TailGroups gr;
@@ -310,13 +333,13 @@ int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *
     const int64_t nblk = erl_cdiv(stride, 64);      // partial norms: one per 64-element chunk and group
     ERL_REQUIRE(nblk <= kMaxPartialChunks, "erl_clip_adam_partials_f32: row too long (%lld floats)", (long long)stride);
     double *partials = nullptr;
-    if ((rc = erl_tail_partials(&partials))) return rc;
+    if ((rc = erl_tail_partials(&partials, (hipStream_t)stream))) return rc;
     int64_t longest = 1;
     for (int i = 0; i < n_groups; ++i) longest = gr.len[i] > longest ? gr.len[i] : longest;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(clip_adam_partials_kernel, dim3((unsigned)erl_cdiv(longest, 1024), n_groups), dim3(1024), 0, (hipStream_t)stream, params,
                        grads, exp_avg, exp_avg_sq, gr, partials, (int)nblk, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
-                       (float)sqrt(bc2), images ? *images : S3Images{});
+                       (float)sqrt(bc2), images ? *images : S3Images{}, poison);
     ERL_LAUNCH_CHECK("erl_clip_adam_partials_f32");
 }
 
@@ -325,7 +348,17 @@ extern "C" int erl_clip_adam_partials_f32(float *params, const float *grads, flo
                                           float beta2, float eps, float max_norm, float grad_scale, void *stream)
 {
     return erl_clip_adam_partials_images_f32(params, grads, exp_avg, exp_avg_sq, stride, group_off, group_len, n_groups, step, lr, beta1, beta2,
-                                             eps, max_norm, grad_scale, nullptr, stream);
+                                             eps, max_norm, grad_scale, nullptr, nullptr, stream);
+}
+
+// the same with a communicator: a peer-to-peer communicator whose exchange timed out in this update loop is poisoned, and the
+// update is then SKIPPED (parameters, moments untouched) -- erl_comm_reduce_exchange_f32 + this = the data-parallel tail
+extern "C" int erl_comm_clip_adam_partials_f32(void *comm, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
+                                               const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr,
+                                               float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream)
+{
+    return erl_clip_adam_partials_images_f32(params, grads, exp_avg, exp_avg_sq, stride, group_off, group_len, n_groups, step, lr, beta1, beta2,
+                                             eps, max_norm, grad_scale, nullptr, erl_comm_poison_word(comm), stream);
 }
 
 // Image buffers: library-owned, one pair per (device, stream) that ran an update loop (a handful in any process); rebuilt from

@@ -27,11 +27,14 @@ struct P2PComm {
     char *peer[ERL_P2P_MAX_WORLD] = {};  // mapped bases (peer[rank] == local)
     bool opened[ERL_P2P_MAX_WORLD] = {};
     uint32_t seq = 0;
+    uint32_t *poison = nullptr;          // device word (ordinary memory): a wait of the current update loop timed out
     uint32_t spin = 1u << 24;            // polls before a wait gives up (~1 us each: tens of seconds; ERL_P2P_SPIN / erl_comm_p2p_set_spin)
     bool connected = false;
 };
 
 size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+P2PComm *g_live[64] = {};            // live communicators of this process (poison words are cleared through it)
 
 }  // namespace
 
@@ -57,11 +60,18 @@ int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *
     if (!rc) rc = erl_hip_status(hipDeviceSynchronize(), "hipDeviceSynchronize");     // zeroed before any peer can learn the handle
     hipIpcMemHandle_t h;
     if (!rc) rc = erl_hip_status(hipIpcGetMemHandle(&h, p), "hipIpcGetMemHandle");
+    void *pw = nullptr;
+    if (!rc) rc = erl_hip_status(hipMalloc(&pw, 256), "hipMalloc(poison word)");
+    if (!rc) rc = erl_hip_status(hipMemset(pw, 0, 256), "hipMemset(poison word)");
     if (rc) {
         if (p) (void)hipFree(p);
+        if (pw) (void)hipFree(pw);
         delete c;
         return rc;
     }
+    c->poison = (uint32_t *)pw;
+    for (auto &g : g_live)
+        if (!g) { g = c; break; }
     c->local = (char *)p;
     c->peer[rank] = c->local;
     memcpy(out_handle, &h, sizeof(h));
@@ -104,6 +114,7 @@ int erl_p2p_next(void *p2p, ErlExchange *ex)
     ex->rank = c->rank;
     ex->world = c->world;
     ex->fault = erl_fault_word(ERL_FAULT_P2P_EXCHANGE);
+    ex->poison = c->poison;
     return ERL_OK;
 }
 
@@ -112,11 +123,29 @@ void erl_p2p_set_spin(void *p2p, uint32_t spins)
     if (p2p) ((P2PComm *)p2p)->spin = spins ? spins : (1u << 24);
 }
 
+uint32_t *erl_p2p_poison_word(void *p2p) { return p2p ? ((P2PComm *)p2p)->poison : nullptr; }
+
+void erl_p2p_clear_poison_all()
+{
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (auto c : g_live)
+        if (c && c->poison) {
+            (void)hipSetDevice(c->dev);
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(c->poison, 0, 4);
+        }
+    if (cur >= 0) (void)hipSetDevice(cur);
+}
+
 void erl_p2p_destroy(void *p2p)
 {
     P2PComm *c = (P2PComm *)p2p;
     if (!c) return;
+    for (auto &g : g_live)
+        if (g == c) g = nullptr;
     (void)hipDeviceSynchronize();
+    if (c->poison) (void)hipFree(c->poison);
     for (int r = 0; r < c->world; ++r)
         if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
     if (c->local) (void)hipFree(c->local);

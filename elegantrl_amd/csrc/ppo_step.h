@@ -21,6 +21,7 @@ struct Ppo2Args {
     float *slabs;
     int64_t stride, Pa, Pc;
     const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
+    unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): {min entry, max exit} on the constant-rate clock; nullptr = off
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -32,6 +33,20 @@ constexpr int PB = 128;        // samples per workgroup
 // bytes apart modulo the 128-byte bank span => 8 consecutive rows form one conflict-free ds_read_b128 wavefront slice,
 // and a transposing ds_write_b32 of a D-layout tile lands 2 lanes per bank (the minimum for 64 lanes).
 constexpr int PLD = PB + 4;
+
+// entry / exit of a workgroup on the device's constant-rate clock, folded into the launch's {min, max} slot (sampled launches only)
+__device__ __forceinline__ unsigned long long span_enter(const Ppo2Args &g)
+{
+    return g.span ? wall_clock64() : 0ull;        // wave-uniform: lives in a scalar register pair, no vector registers
+}
+__device__ __forceinline__ void span_exit(const Ppo2Args &g, unsigned long long t0)
+{
+    if (g.span && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+        atomicMin(g.span, t0);
+        atomicMax(g.span + 1, (unsigned long long)wall_clock64());
+    }
+}
 
 #ifdef ERL_PROFILE
 #define PROF(i)                                                                                   \
@@ -51,9 +66,17 @@ constexpr int PLD = PB + 4;
         if (g.prof && (int)blockIdx.x == g.prof_block && lane == 0) g.prof[(net * 8 + wave) * 32 + (i)] = (long long)t_; \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
+// a stamp taken when the value `v` exists (the wait for its producer -- a load -- falls in front of the stamp; nothing else drained)
+#define PROF_X(i, v)                                                                              \
+    do {                                                                                          \
+        auto pv_ = (v);                                                                           \
+        asm volatile("" : "+v"(pv_));                                                             \
+        PROF_NV(i);                                                                               \
+    } while (0)
 #else
 #define PROF(i) do { } while (0)
 #define PROF_NV(i) do { } while (0)
+#define PROF_X(i, v) do { } while (0)
 #endif
 
 // dW (nA32*32 x nB32*32) = TA . TB^T over the 128 staged samples; output tiles split over the NW waves.

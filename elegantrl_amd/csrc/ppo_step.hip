@@ -382,8 +382,10 @@ template <int NS_, int N1_, int N2_, bool VEC>
 __global__ __launch_bounds__(PNW * 64) void ppo_step2_kernel(Ppo2Args g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned long long t_span = span_enter(g);
     if (blockIdx.y == 0) ppo_block<true, NS_, N1_, N2_, VEC>(g, smem);
     else ppo_block<false, NS_, N1_, N2_, VEC>(g, smem);
+    span_exit(g, t_span);
 }
 
 bool dims_ok2(int S, int h1, int h2, int out)
@@ -412,7 +414,13 @@ int g_ppo_prof_block = 0;
 
 }  // namespace
 
-void erl_k6_timing_mark(hipStream_t stream, int which);   // api.cpp (measurement hook, no-op unless enabled)
+unsigned long long *erl_k6_timing_begin(hipStream_t stream);   // api.cpp (measurement hook, no-op unless enabled)
+void erl_k6_timing_end(hipStream_t stream);
+
+namespace {
+__global__ void null_kernel() {}
+}  // namespace
+void erl_launch_null_kernel(hipStream_t stream) { hipLaunchKernelGGL(null_kernel, dim3(1), dim3(64), 0, stream); }
 
 #ifdef ERL_PROFILE
 // profiling builds only (make EXTRA=-DERL_PROFILE): device buffer of 2 * 8 * 32 int64 cycle stamps
@@ -506,7 +514,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                      al(cri_avg) && al(cri_std);
     hipStream_t st = (hipStream_t)stream;
     const int ns = (S + 15) / 16;
-    erl_k6_timing_mark(st, 0);
+    g.span = erl_k6_timing_begin(st);
     int rc;
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else
     // the fp32 32x32x2 one), 8 = always the 8-wave 16x16x4 kernel
@@ -517,7 +525,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
     else rc = launch<0, 0, 0, false>(g, n_slabs, st);
-    erl_k6_timing_mark(st, 1);
+    erl_k6_timing_end(st);
     return rc;
 }
 

@@ -27,6 +27,12 @@
 #include "ppo_step_w4_impl.h"
 #include "split_bf16.h"
 
+// experiments on the prologue's memory fill (tools/r04_k6_exp.sh; never set in the product build): 1 no W2-image copy (wrong
+// results, timing only), 2 the image's 1 KB pieces requested in an order rotated by the workgroup index
+#ifndef ERL_K6_EXP
+#define ERL_K6_EXP 0
+#endif
+
 namespace {
 
 __device__ __forceinline__ int phi(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }   // bits 2 and 3 swapped
@@ -267,7 +273,9 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
     };
     f32x16 prev, prev1;
     float v0[NPR], v1[NPR];
-    // elements EP ks .. EP ks + EP - 1 of tile Tp: the gate products (stage 0) and their splits (stage 1)
+    uint32_t sh[NPR], sm[NPR];
+    // elements EP ks .. EP ks + EP - 1 of tile Tp: the gate products (stage 0) and their three-way split, one part per stage
+    // (stages 1..3: five, five and one instruction per pair -- one clump of eleven behind a single MFMA left the pipe idle)
     auto gstage = [&](int Tp, int ks, int s, bool fence = true) {
 #pragma unroll
         for (int i = 0; i < NPR; ++i) {
@@ -275,12 +283,22 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
             if (s == 0) {
                 v0[i] = gate[Tp][e] * (prev[e] + prev1[e]);
                 v1[i] = gate[Tp][e + 1] * (prev[e + 1] + prev1[e + 1]);
+                asm volatile("" : "+v"(v0[i]), "+v"(v1[i]));
             } else if (s == 1) {
-                uint32_t h, mm, l;
-                split2(v0[i], v1[i], h, mm, l);
-                asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+                sh[i] = pk_bf16(v0[i], v1[i]);
+                v0[i] -= bf_lo(sh[i]);
+                v1[i] -= bf_hi(sh[i]);
+                asm volatile("" : "+v"(sh[i]), "+v"(v0[i]), "+v"(v1[i]));
+            } else if (s == 2) {
+                sm[i] = pk_bf16(v0[i], v1[i]);
+                v0[i] -= bf_lo(sm[i]);
+                v1[i] -= bf_hi(sm[i]);
+                asm volatile("" : "+v"(sm[i]), "+v"(v0[i]), "+v"(v1[i]));
+            } else if (s == 3) {
+                uint32_t l = pk_bf16(v0[i], v1[i]);
+                asm volatile("" : "+v"(l));
                 Parts &o = outP[2 * Tp + (e >> 3)];
-                o.h[(e & 7) >> 1] = h; o.m[(e & 7) >> 1] = mm; o.l[(e & 7) >> 1] = l;
+                o.h[(e & 7) >> 1] = sh[i]; o.m[(e & 7) >> 1] = sm[i]; o.l[(e & 7) >> 1] = l;
             }
         }
         if (fence) __builtin_amdgcn_sched_barrier(0);
@@ -323,8 +341,8 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
     }
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        gstage(NO - 1, ks, 0, false);
-        gstage(NO - 1, ks, 1, false);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) gstage(NO - 1, ks, s, false);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -387,6 +405,15 @@ __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, in
     const int l31 = lane & 31, hi = lane >> 5;
     u32x2 rq[2][6];
     tb.issue(jc, 0, rq[0]);
+    auto store = [&](const f32x16 &t, int k) {
+        const int i = 32 * (jt_store0 + jc + CS * k) + l31;
+        if (i < cols_real) {
+            float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(t[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
+        }
+    };
+    f32x16 done;
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
         f32x16 acc = {0};
@@ -394,16 +421,21 @@ __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, in
         for (int ks = 0; ks < 8; ++ks) {
             const int c = 8 * k + ks;
             if (c + 1 < 8 * NBW) tb.issue(jc + CS * ((c + 1) / 8), (c + 1) % 8, rq[(c + 1) & 1]);
+            // the next k-step's reads go out BEFORE this k-step's MFMAs (192 cycles of cover): left in one scheduling region hipcc
+            // lets the two operand buffers share registers and sinks the reads behind the fifth MFMA, one MFMA (32 cycles) before
+            // their use -- every k-step then waited for the LDS (round 3: 50-52 cycles per MFMA in dW1 / dW2, floor 32)
+            __builtin_amdgcn_sched_barrier(0);
             mma6(A[ks], parts_of(rq[c & 1]), acc);
             __builtin_amdgcn_sched_barrier(0);
+            // a finished tile is stored behind the NEXT tile's first k-step: its last MFMA has long retired, no wait at the seam
+            if (ks == 0 && k > 0) {
+                store(done, k - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        const int i = 32 * (jt_store0 + jc + CS * k) + l31;
-        if (i < cols_real) {
-            float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
-        }
+        done = acc;
     }
+    store(done, NBW - 1);
 }
 
 // LDS pool (bytes): [IMG2: W2 image, later SA][IMG1: W1 image, later SB][RW3: W3 copy fp32, later RC dY^T][biases][norm][s_part][s_red]
@@ -472,6 +504,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         t_ = id - n_ * g.H;
     }
     const int64_t row = valid ? t_ * g.N + n_ : 0;          // padding slots read row 0 (finite data) and carry zero weight
+    PROF_X(16, row);                                        // (profile builds: the id has arrived)
     // this lane's own state row, in the operand order: features 16 ks + 8 hi + 0..7 of k-step ks
     float4 XR[NK1][2];
     {
@@ -499,21 +532,26 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
             sl_pre[j] = std_log[ac];
         }
     }
+    PROF_NV(17);                                            // (row loads issued)
     // ---- the W2 image: requested LAST (the memory pipe returns W1 and the rows first), issued while those are in flight (an LDS-DMA
     // piece costs its wave 60-180 cycles of issue: here they fall into the wait for the gathered rows), landing under the first layer
     if constexpr (PRE) {
         constexpr int KB = h2 * 48 * CP2 / 1024;            // the image in 1 KB pieces: one wave instruction each, straight into LDS
         static_assert(h2 * 48 * CP2 % 1024 == 0, "image size");
         const u8 *src = g.w2img[net] + 16 * lane;
+        const int rot = (ERL_K6_EXP & 2) ? (int)((blockIdx.x * 29u + blockIdx.y * 47u) % KB) : 0;
 #pragma unroll
         for (int i = 0; i < (KB + QNW - 1) / QNW; ++i) {
-            const int k = wave + QNW * i;                   // wave-uniform
-            if (k < KB)
+            const int k0 = wave + QNW * i;                  // wave-uniform
+            const int k = (ERL_K6_EXP & 2) ? (k0 + rot) % KB : k0;
+            if (k0 < KB && !(ERL_K6_EXP & 1))
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(src + 1024 * k), reinterpret_cast<float *>(IMG2 + 1024 * k), 16, 0, 0);
         }
     }
+    PROF_NV(18);                                            // (W2 image pieces issued)
     // ---- the weight images (split here; every workgroup converts the same 24k weights -- see DESIGN.md for the pre-split plan)
     img_store<N1 * KX, CP1>(c1, IMG1, h1, tid);
+    PROF_NV(19);                                            // (W1 has arrived and is split into its image)
 #pragma unroll
     for (int e = tid; e < kS3W3 / 16; e += QNT) reinterpret_cast<float4 *>(RW3)[e] = zero4();
     s_b1[tid] = bias_pre;                                   // s_b1 | s_b2 contiguous
@@ -541,6 +579,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         t[o + 4] = fmaf(XR[ks][1].x, r1.x, n1.x); t[o + 5] = fmaf(XR[ks][1].y, r1.y, n1.y);
         t[o + 6] = fmaf(XR[ks][1].z, r1.z, n1.z); t[o + 7] = fmaf(XR[ks][1].w, r1.w, n1.w);
     }
+    PROF_X(20, XH[0][0]);                                   // (the own row has arrived and is normalised)
     f32x16 H1[N1], G1[N1], H2[N2], G2[N2];
     Parts H1p[2 * N1];
     fwd_s3<NK1, N1, CP1>(IMG1, s_b1, Xp, XH, H1, G1, m, hi);
@@ -807,8 +846,10 @@ template <int KX, int N1, int N2, bool VEC, bool PRE>
 __global__ __launch_bounds__(QNT) void ppo_step_s3_kernel(Ppo2Args g)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_s3[];
+    const unsigned long long t_span = span_enter(g);
     if (blockIdx.y == 0) ppo_block_s3<true, KX, N1, N2, VEC, PRE>(g, smem_s3);
     else ppo_block_s3<false, KX, N1, N2, VEC, PRE>(g, smem_s3);
+    span_exit(g, t_span);
 }
 
 template <int KX, int N1, int N2, bool VEC, bool PRE>

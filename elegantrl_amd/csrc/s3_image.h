@@ -57,6 +57,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             void *stream);
 int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
                                       const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
-                                      float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, void *stream);
+                                      float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, const uint32_t *poison,
+                                      void *stream);
 // grad_tail.hip: library-owned image buffers of (device, stream), built from the flat parameters [actor | critic]
 int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, hipStream_t stream);

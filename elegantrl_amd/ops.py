@@ -367,13 +367,15 @@ def grad_sq_partials(grads: TEN, stride: int, groups: Sequence[Tuple[int, int]],
 
 
 def clip_adam_partials(params: TEN, grads: TEN, exp_avg: TEN, exp_avg_sq: TEN, stride: int, groups: Sequence[Tuple[int, int]],
-                       step: int, lr: float, max_norm: float, grad_scale: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
-    """launch 2: clip_grad_norm_ from the partial norms left by launch 1 + Adam (AgentBase.py:246-248)."""
+                       step: int, lr: float, max_norm: float, grad_scale: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                       comm=None) -> None:
+    """launch 2: clip_grad_norm_ from the partial norms left by launch 1 + Adam (AgentBase.py:246-248).  With the peer-to-peer
+    `comm` of launch 1: skipped (nothing touched) when an exchange of this update loop timed out (include/erl_hip.h)."""
     n, off, ln = _groups_c(groups)
-    check(lib().erl_clip_adam_partials_f32(ptr(params, th.float32), ptr(grads, th.float32), ptr(exp_avg, th.float32),
-                                           ptr(exp_avg_sq, th.float32), stride, off, ln, n, step, lr, betas[0], betas[1], eps, max_norm,
-                                           grad_scale, stream_ptr()),
-          "erl_clip_adam_partials_f32")
+    check(lib().erl_comm_clip_adam_partials_f32(None if comm is None else comm.handle, ptr(params, th.float32), ptr(grads, th.float32),
+                                                ptr(exp_avg, th.float32), ptr(exp_avg_sq, th.float32), stride, off, ln, n, step, lr,
+                                                betas[0], betas[1], eps, max_norm, grad_scale, stream_ptr()),
+          "erl_comm_clip_adam_partials_f32")
 
 
 def reduce_clip_adam(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN, params: TEN, exp_avg: TEN, exp_avg_sq: TEN,

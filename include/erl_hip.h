@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 14
+#define ERL_ABI_VERSION 15
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -288,7 +288,7 @@ ERL_API int erl_clip_adam_f32(float *params, const float *grads, float *exp_avg,
  * (elegantrl/agents/AgentBase.py:239-248); the backward's per-workgroup slabs come from erl_ppo_step_f32.
  *   launch 1  erl_grad_reduce_partials_f32: erl_grad_reduce_f32's sum (same association, bit for bit) + every 256-element
  *             workgroup's fp64 share of each parameter group's squared norm of (grad * grad_scale), kept in a library-owned
- *             per-device table for the next launch on the same stream;
+ *             per-(device, stream) table for the next launch on the same stream;
  *             erl_grad_sq_partials_f32: the partial norms alone, of a gradient row that is already summed (after a foreign
  *             all-reduce: RCCL / torch.distributed routes);
  *             erl_comm_reduce_exchange_f32: the reduction with the data-parallel exchange INSIDE the kernel when `comm` is a
@@ -305,6 +305,15 @@ ERL_API int erl_grad_sq_partials_f32(float *grads, int64_t stride, const int64_t
 ERL_API int erl_clip_adam_partials_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
                                const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr,
                                float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream);
+/* ... with a communicator: when an exchange on a peer-to-peer `comm` timed out earlier in this update loop (a peer missing:
+ * the bounded wait of erl_comm_reduce_exchange_f32 / erl_comm_allreduce_sum_* gave up and its sums are garbage), the
+ * communicator is poisoned and this launch SKIPS the update -- parameters and moments untouched -- until the host has read
+ * the fault (erl_async_fault_count(1) reports "peer-to-peer gradient exchange" and clears the poison).  NULL / RCCL `comm`:
+ * identical to erl_clip_adam_partials_f32. */
+ERL_API int erl_comm_clip_adam_partials_f32(void *comm, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                                    int64_t stride, const int64_t *group_off, const int64_t *group_len, int n_groups,
+                                    int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                                    float grad_scale, void *stream);
 
 /* update_net's three returned objectives (AgentPPO.py:168-171): out3[j] = scale * mean over the n_rows minibatch rows of
  * grad_rows[k][offset + j] (the logged values K6 leaves behind the gradient; offset = Pa + Pc), one launch. */
@@ -474,11 +483,17 @@ ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, 
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
                                float *action_out, void *workspace, int64_t workspace_bytes, void *stream);
 
-/* measurement hook: every_nth > 0 makes erl_ppo_step_f32 bracket every n-th K6 launch with HIP events on the launch
- * stream (1 = every launch, 0 = off); erl_k6_timing_read waits for them, returns the summed time (ms) and the number of
- * bracketed launches, and clears the list. */
+/* measurement hook (bench.py's `roofline`; no reference counterpart): every_nth > 0 makes erl_ppo_step_f32 time every n-th K6
+ * launch (1 = every launch, 0 = off) two ways -- a HIP-event bracket on the launch stream (contains the dispatch and completion
+ * overhead of the bracket itself, 3-15 us depending on the box) and the kernel's own span, first workgroup in to last workgroup
+ * out, on the device's constant-rate clock (what rocprofv3's kernel duration measures).  erl_k6_timing_read2 waits for the
+ * sampled launches, returns both sums (ms) and the number of launches, and clears the lists; erl_k6_timing_read is the
+ * event sum alone.  erl_k6_timing_null_bracket_us brackets an EMPTY launch the same way (median of `reps`, microseconds): the
+ * part of an event bracket that is not the kernel. */
 ERL_API void erl_k6_timing_enable(int every_nth);
 ERL_API int erl_k6_timing_read(double *total_ms, int *launches);
+ERL_API int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launches);
+ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median_us);
 
 /* ---------------------------------------------------------------------------------------------
  * GPU-resident synthetic environments for measurement; they implement the

@@ -162,3 +162,39 @@ class TorchSynEnv:
             self.count[done] = 0
         self.state = s
         return s, reward, terminal, truncate
+
+
+class TorchPendulumEnv:
+    """CPU twin of elegantrl_amd.envs.PendulumVecEnv (csrc/envs.hip pendulum_step_kernel): Pendulum-v1 (g = 10, m = l = 1,
+    dt = 0.05, |u| <= 2, |theta_dot| <= 8) behind the reference wrapper's scaling (elegantrl/envs/CustomGymEnv.py:42-44: torque =
+    2 * action, reward = 0.5 * gym reward), truncation after max_step steps, reset theta ~ U(-pi, pi), theta_dot ~ U(-1, 1)."""
+
+    def __init__(self, num_envs=4096, max_step=200, seed=0):
+        import math
+        self.pi = math.pi
+        self.g = th.Generator().manual_seed(seed)
+        self.n, self.max_step = num_envs, max_step
+        self.theta = (th.rand(num_envs, generator=self.g) * 2 - 1) * self.pi
+        self.theta_dot = th.rand(num_envs, generator=self.g) * 2 - 1
+        self.count = th.zeros(num_envs, dtype=th.int32)
+
+    def _obs(self):
+        return th.stack((self.theta.cos(), self.theta.sin(), self.theta_dot), dim=1)
+
+    def reset(self):
+        return self._obs()
+
+    def step(self, action: TEN):
+        u = (2.0 * action.reshape(-1)).clamp(-2.0, 2.0)
+        ang = th.remainder(self.theta + self.pi, 2 * self.pi) - self.pi
+        cost = ang * ang + 0.1 * self.theta_dot * self.theta_dot + 0.001 * u * u
+        nthdot = (self.theta_dot + (15.0 * self.theta.sin() + 3.0 * u) * 0.05).clamp(-8.0, 8.0)
+        nth = self.theta + nthdot * 0.05
+        self.count += 1
+        truncate = self.count >= self.max_step
+        if bool(truncate.any()):
+            nth = th.where(truncate, (th.rand(self.n, generator=self.g) * 2 - 1) * self.pi, nth)
+            nthdot = th.where(truncate, th.rand(self.n, generator=self.g) * 2 - 1, nthdot)
+            self.count[truncate] = 0
+        self.theta, self.theta_dot = nth, nthdot
+        return self._obs(), -0.5 * cost, th.zeros(self.n, dtype=th.bool), truncate

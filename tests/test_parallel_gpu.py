@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False, collective="torch"):
+def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False, collective="torch", shape=None):
     gpu = rank if one_gpu_per_rank else 0
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(gpu), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       ERL_DP_COLLECTIVE=collective)
@@ -32,8 +32,13 @@ def _worker(rank, world, port, out_dir, backend="gloo", one_gpu_per_rank=False, 
     parallel.init_from_env(backend=backend)
     th.cuda.set_device(gpu)
     N, S, A, H, B = 256, 64, 8, 16, 1024
+    net_dims = None
+    if shape is not None:                                       # (N, S, A, H, B, net_dims): small rows for many ranks on ONE GPU
+        N, S, A, H, B, net_dims = shape
     args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
                                         "if_discrete": False})
+    if net_dims is not None:
+        args.net_dims = list(net_dims)
     args.horizon_len, args.batch_size, args.repeat_times = H, B, 3 * B / H
     args.learning_rate, args.random_seed = 1e-3, 5
     args.world_size, args.rank, args.gpu_id = world, rank, gpu
@@ -218,6 +223,163 @@ def test_two_rank_one_gpu_per_rank_every_route(tmp_path):
         np.testing.assert_array_equal(_load(tmp_path, mode, "stats")[0], _load(tmp_path, "torch", "stats")[0])
         assert not np.array_equal(w[0], _load(tmp_path, mode, "w0")[0]) and np.isfinite(w[0]).all()
     assert all(c[0] == 1 for c in _load(tmp_path, "auto", "comm")), rep
+
+
+# ---- the exchange at the node's real world sizes (4, 8 ranks), on the one GPU of the test box -----------------------
+# Ranks share the device, so their launches share its 256 CUs: rows are kept short (<= 8192 floats = 32 workgroups per rank)
+# so that every rank's exchange workgroups are resident together -- a workgroup spins for its peers' SAME slice, which only
+# arrives if those launches get CUs (on a node every rank has its own GPU).
+def _rank_ordered_sum(t_host):
+    """what the exchange kernel computes: x[0] + x[1] + ... in RANK order, sequential adds in the tensor's dtype (gloo's
+    all-reduce associates differently for world > 2, so it is not the bit-exact reference any more)"""
+    from elegantrl_amd import parallel
+    world = parallel.dist.get_world_size()
+    parts = [th.empty_like(t_host) for _ in range(world)]
+    parallel.dist.all_gather(parts, t_host)
+    ref = parts[0].clone()
+    for r in range(1, world):
+        ref += parts[r]
+    return ref
+
+
+def _pn_worker(rank, world, port, out_dir, withhold):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from elegantrl_amd import _hip, ops, parallel
+    parallel.init_from_env(backend="gloo")
+    th.cuda.set_device(0)
+    comm = parallel.P2PComm.create(max_count=8192)
+    res = {"created": comm is not None, "exact": True, "tail": True, "fault": None}
+    if comm is not None:
+        g = th.Generator(device="cuda").manual_seed(99 + rank)
+        for it, n in enumerate([4096, 1, 8192, 257, 5000, 5000, 8192, 300]):          # both stage halves, reuse, odd sizes
+            x = th.randn(n, device="cuda", generator=g) * (1 + it)
+            d = th.randn(3 + it, device="cuda", generator=g, dtype=th.float64)
+            ref, dref = _rank_ordered_sum(x.cpu()), _rank_ordered_sum(d.cpu())
+            comm.all_reduce_sum(x)
+            comm.all_reduce_sum(d)
+            th.cuda.synchronize()
+            res["exact"] = res["exact"] and bool(th.equal(x.cpu(), ref)) and bool(th.equal(d.cpu(), dref))
+        # the fused tail (exchange inside the slab reduction) against reduce -> rank-ordered host sum -> partial norms -> Adam
+        n_slabs, stride, groups = 19, 8192, [(0, 4100), (4100, 4060)]
+        slabs = th.randn((n_slabs, stride), device="cuda", generator=g)
+        slabs[:, 8160 + 4:] = 0
+        w = {}
+        for route in ("p2p", "host"):
+            gsum = th.empty(stride, device="cuda")
+            params = th.linspace(-1, 1, 8160, device="cuda")
+            m1, m2 = th.zeros_like(params), th.zeros_like(params)
+            for step in (1, 2):
+                if route == "p2p":
+                    ops.grad_reduce_partials(slabs, n_slabs, stride, gsum, groups, grad_scale=1.0 / world, comm=comm)
+                else:
+                    ops.grad_reduce(slabs, n_slabs, stride, gsum)
+                    gsum.copy_(_rank_ordered_sum(gsum.cpu()))
+                    ops.grad_sq_partials(gsum, stride, groups, grad_scale=1.0 / world)
+                ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, step, 1e-3, 0.5, grad_scale=1.0 / world,
+                                       comm=comm if route == "p2p" else None)
+            th.cuda.synchronize()
+            w[route] = params.cpu()
+        res["tail"] = bool(th.equal(w["p2p"], w["host"])) and bool(th.isfinite(w["p2p"]).all())
+        np.save(os.path.join(out_dir, f"tailw_{rank}.npy"), w["p2p"].numpy())
+        _hip.check_async_faults()
+        if withhold:
+            # ---- fault path: the LAST rank never launches this exchange.  Every other rank's wait is bounded, reports through
+            # erl_async_fault_count (source "peer-to-peer ... exchange") and POISONS the communicator: clip + Adam of this update
+            # loop touch nothing.  Reading the fault clears the poison.
+            parallel.barrier()
+            params = th.linspace(-1, 1, 8160, device="cuda")
+            m1, m2 = th.zeros_like(params), th.zeros_like(params)
+            before = params.clone()
+            if rank != world - 1:
+                comm.set_spin(1 << 13)
+                gsum = th.empty(stride, device="cuda")
+                ops.grad_reduce_partials(slabs, n_slabs, stride, gsum, groups, grad_scale=1.0 / world, comm=comm)
+                ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, 1, 1e-3, 0.5, grad_scale=1.0 / world, comm=comm)
+                ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, 2, 1e-3, 0.5, grad_scale=1.0 / world, comm=comm)   # sticky
+                th.cuda.synchronize()
+                untouched = bool(th.equal(params, before)) and not bool(m1.any()) and not bool(m2.any())
+                n_faults = _hip.lib().erl_async_fault_count(1)                     # report + reset: clears the poison
+                msg = _hip.lib().erl_last_error_string().decode()
+                # un-poisoned: the same launch (partial norms from a local reduction) now updates
+                ops.grad_reduce_partials(slabs, n_slabs, stride, gsum, groups, grad_scale=1.0 / world)
+                ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, 1, 1e-3, 0.5, grad_scale=1.0 / world, comm=comm)
+                th.cuda.synchronize()
+                res["fault"] = [untouched, int(n_faults), "peer-to-peer" in msg and "SKIPPED" in msg, not bool(th.equal(params, before))]
+            else:
+                res["fault"] = "withheld"
+        parallel.barrier()
+        comm.close()
+    import json
+    with open(os.path.join(out_dir, f"pn_{rank}.json"), "w") as f:
+        json.dump(res, f)
+    parallel.barrier()
+    parallel.dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world", [4, 8])
+def test_p2p_exchange_at_node_world_sizes_on_one_gpu(tmp_path, world):
+    """`world` ranks share the GPU through HIP IPC (ERL_P2P_MAX_WORLD = 8: the 8-stage rank-ordered sum and the
+    [sender][workgroup] flag table of csrc/grad_tail.hip at their real sizes): stand-alone fp32 / fp64 all-reduces equal the
+    rank-ordered sum BIT FOR BIT on every rank, the fused tail leaves the weights of the tail with a host-side sum in the
+    middle on every rank (identical across ranks), and -- world 4 -- a rank that withholds its launch makes every other
+    rank's bounded wait give up, skip its optimiser steps and name the exchange in erl_async_fault_count."""
+    import json
+    mp.spawn(_pn_worker, args=(world, _free_port(), str(tmp_path), world == 4), nprocs=world, join=True)
+    res = [json.load(open(tmp_path / f"pn_{r}.json")) for r in range(world)]
+    if not all(r["created"] for r in res):
+        pytest.skip("HIP IPC between processes on this device is unavailable")
+    assert all(r["exact"] for r in res), "an all-reduce differs from the rank-ordered sum"
+    assert all(r["tail"] for r in res), "fused tail != tail with the host-side rank-ordered sum"
+    w = [np.load(tmp_path / f"tailw_{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(w[0], w[r])
+    if world == 4:
+        assert res[world - 1]["fault"] == "withheld"
+        for r in range(world - 1):
+            untouched, n_faults, named, recovered = res[r]["fault"]
+            assert untouched, f"rank {r}: a timed-out exchange was applied to the parameters"
+            assert n_faults > 0 and named, f"rank {r}: the timeout was not reported as a peer-to-peer exchange fault"
+            assert recovered, f"rank {r}: the communicator stayed poisoned after the fault was read"
+
+
+_SMALL = (64, 8, 2, 8, 256, (64, 64))      # N, S, A, H, B, net: gradient row of 9.7k floats = 38 exchange workgroups per rank
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("world", [4, 8])
+def test_agent_in_lockstep_at_node_world_sizes_on_one_gpu(tmp_path, world):
+    """One data-parallel PPO job of 4 / 8 ranks on the one GPU (gloo group; small nets so that all ranks' exchange workgroups
+    are co-resident), two iterations per route: `torch` (torch.distributed), `p2p` (forced), `auto` (probe + self-test).
+    Ranks end BIT-IDENTICAL on every route; `p2p` == `auto` bit for bit; against `torch` only to rounding (gloo's all-reduce
+    associates the `world` addends differently from the kernel's rank order)."""
+    import json
+    for mode in ("torch", "p2p", "auto"):
+        (tmp_path / mode).mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / mode), "gloo", False, mode, _SMALL), nprocs=world, join=True)
+    N, S, A, H, B, _ = _SMALL
+    wt, w0 = _load(tmp_path, "torch", "w", world), _load(tmp_path, "torch", "w0", world)
+    stats = _load(tmp_path, "torch", "stats", world)
+    for r in range(1, world):
+        np.testing.assert_array_equal(w0[0], w0[r])
+        np.testing.assert_array_equal(wt[0], wt[r])
+        np.testing.assert_array_equal(stats[0], stats[r])
+    assert stats[0][1] == world * H * N and not np.array_equal(wt[0], w0[0]) and np.isfinite(wt[0]).all()
+    if not all(c[0] for c in _load(tmp_path, "p2p", "comm", world)):
+        pytest.skip("HIP IPC between processes on this device is unavailable")
+    wp = _load(tmp_path, "p2p", "w", world)
+    for mode in ("p2p", "auto"):
+        comm = _load(tmp_path, mode, "comm", world)
+        assert all(c[0] == 1 and c[1] == world and c[2] == 2 for c in comm), f"{mode}: the peer-to-peer route was not selected"
+        wm = _load(tmp_path, mode, "w", world)
+        for r in range(1, world):
+            np.testing.assert_array_equal(wm[0], wm[r])
+        np.testing.assert_array_equal(wm[0], wp[0])
+        np.testing.assert_allclose(wm[0], wt[0], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(_load(tmp_path, mode, "stats", world)[0], stats[0], rtol=1e-6)    # second rollout: weights differ by rounding
+    rep = json.load(open(tmp_path / "auto" / "route_0.json"))
+    assert rep["p2p_probe"] == "ok" and rep["p2p_selftest"] == "ok", rep
 
 
 # ---- the library-owned RCCL communicator (erl_comm_*) on one rank --------------------------------------------------

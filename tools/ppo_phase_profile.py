@@ -77,7 +77,14 @@ def main():
     e1.record()
     th.cuda.synchronize()
     print(f"wall time per launch of this (instrumented) build: {e0.elapsed_time(e1) * 50:.1f} us")
-    p = prof.cpu().view(2, 8, 32)[:, :, :NP]
+    full = prof.cpu().view(2, 8, 32)
+    if int(full[0, 0, 16]) != 0:                      # extra prologue stamps of the split-arithmetic kernel (cycles since kernel entry, wave 0..3 mean)
+        names = {16: "sample id arrived", 17: "row loads issued", 18: "W2 image pieces issued", 19: "W1 arrived + split into its image",
+                 1: "(end of prologue)", 2: "(barrier0 passed)", 20: "own row arrived + normalised", 3: "(end of L1 fwd)"}
+        for net, nm in enumerate(("actor", "critic")):
+            w = full[net, :4].double()
+            print(f"--- {nm}: prologue detail (cycles since entry): " + ", ".join(f"{names[k]} {float((w[:, k] - w[:, 0]).mean()):.0f}" for k in (16, 17, 18, 19, 1, 2, 20, 3)))
+    p = full[:, :, :NP]
     p = p[:, (p[0, :, 0] != 0)]                        # the 4-wave form stamps waves 0..3 only
     print(f"{p.shape[1]} waves per workgroup")
     for net, name in enumerate(("actor", "critic")):
