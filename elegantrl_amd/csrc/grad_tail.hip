@@ -182,20 +182,27 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
         // the split-arithmetic minibatch kernel's W2 image of this network follows its fp32 weights (s3_image.h)
         if (gi < 2 && im.net[gi].img) {
             const int64_t e = ie - im.net[gi].w2_off;
-            const int h1 = im.net[gi].h1;
+            const int h1 = im.net[gi].h1, S = im.net[gi].S;
             if (e >= 0 && e < (int64_t)h1 * im.net[gi].h2) s3_image_put(im.net[gi].img, h1, (int)(e / h1), (int)(e % h1), e_p);
+            else if (im.net[gi].img1 && ie < (int64_t)h1 * S) s3_image_put(im.net[gi].img1, im.net[gi].K1, (int)(ie / S), (int)(ie % S), e_p);
         }
     }
 }
 
-// W2 images of both networks from the flat parameters [actor | critic]: one thread per weight
+// W2 and W1 images of both networks from the flat parameters [actor | critic]: one thread per image element (W1's pad columns: 0)
 __global__ __launch_bounds__(256) void s3_image_build_kernel(const float *__restrict__ params, int64_t Pa, S3Images im)
 {
     const int gi = blockIdx.y;
-    const int h1 = im.net[gi].h1;
+    const int h1 = im.net[gi].h1, S = im.net[gi].S, K1 = im.net[gi].K1;
+    const float *P = params + (gi ? Pa : 0);
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < (int64_t)h1 * im.net[gi].h2)
-        s3_image_put(im.net[gi].img, h1, (int)(e / h1), (int)(e % h1), params[(gi ? Pa : 0) + im.net[gi].w2_off + e]);
+    const int64_t n2 = (int64_t)h1 * im.net[gi].h2;
+    if (e < n2) {
+        s3_image_put(im.net[gi].img, h1, (int)(e / h1), (int)(e % h1), P[im.net[gi].w2_off + e]);
+    } else if (im.net[gi].img1 && e - n2 < (int64_t)h1 * K1) {
+        const int row = (int)((e - n2) / K1), col = (int)((e - n2) % K1);
+        s3_image_put(im.net[gi].img1, K1, row, col, col < S ? P[(int64_t)row * S + col] : 0.f);
+    }
 }
 
 // the three logged objectives of update_net (AgentPPO.py:168-171: means over the minibatches) from the gradient rows' tails:
@@ -378,7 +385,8 @@ int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, 
     int dev = 0;
     int rc = erl_hip_status(hipGetDevice(&dev), "hipGetDevice");
     if (rc) return rc;
-    const size_t one = (s3_image_bytes(h1, h2) + 1023) / 1024 * 1024, need = 2 * one;
+    const size_t two = (s3_image_bytes(h1, h2) + 1023) / 1024 * 1024, first = (s3_image1_bytes(h1, S) + 1023) / 1024 * 1024;
+    const size_t one = two + first, need = 2 * one;
     S3Slot *slot = nullptr;
     for (auto &s : g_s3_slots)
         if (s.buf && s.device == dev && s.stream == stream) slot = &s;
@@ -392,7 +400,7 @@ int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, 
             if ((rc = erl_hip_status(hipFree(slot->buf), "hipFree"))) return rc;
             slot->buf = nullptr;
         }
-        if ((rc = erl_hip_status(hipMalloc((void **)&slot->buf, need), "hipMalloc(W2 images)"))) return rc;
+        if ((rc = erl_hip_status(hipMalloc((void **)&slot->buf, need), "hipMalloc(weight images)"))) return rc;
         slot->bytes = need;
     }
     slot->device = dev;
@@ -403,7 +411,11 @@ int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, 
         out->net[gi].w2_off = (int64_t)h1 * S + h1;
         out->net[gi].h1 = h1;
         out->net[gi].h2 = h2;
+        out->net[gi].img1 = slot->buf + gi * one + two;
+        out->net[gi].S = S;
+        out->net[gi].K1 = s3_image_k1(S);
     }
-    hipLaunchKernelGGL(s3_image_build_kernel, dim3((unsigned)erl_cdiv((int64_t)h1 * h2, 256), 2), dim3(256), 0, stream, flat_params, Pa, *out);
+    const int64_t elems = (int64_t)h1 * h2 + (int64_t)h1 * s3_image_k1(S);
+    hipLaunchKernelGGL(s3_image_build_kernel, dim3((unsigned)erl_cdiv(elems, 256), 2), dim3(256), 0, stream, flat_params, Pa, *out);
     ERL_LAUNCH_CHECK("erl_s3_images_build");
 }

@@ -21,6 +21,7 @@ struct Ppo2Args {
     float *slabs;
     int64_t stride, Pa, Pc;
     const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
+    const unsigned char *w1img[2];   // ... and W1 images (columns padded to 32 / 64); both or neither
     unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): {min entry, max exit} on the constant-rate clock; nullptr = off
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;

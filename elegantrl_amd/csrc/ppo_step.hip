@@ -506,6 +506,8 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     g.stride = erl_ppo_slab_stride(S, h1, h2, A);
     g.w2img[0] = images ? images->net[0].img : nullptr;
     g.w2img[1] = images ? images->net[1].img : nullptr;
+    g.w1img[0] = images ? images->net[0].img1 : nullptr;
+    g.w1img[1] = images ? images->net[1].img1 : nullptr;
     g.prof = g_ppo_prof;
     g.prof_block = g_ppo_prof_block;
     // 16-byte vector path: every row / parameter block / normalisation vector must be 16-byte aligned
@@ -520,7 +522,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     // the fp32 32x32x2 one), 8 = always the 8-wave 16x16x4 kernel
     const int form = k6_form();
     if (erl_ppo_arith_in_use(S, h1, h2, A) == ERL_PPO_ARITH_SPLIT)
-        rc = (g.w2img[0] && g.w2img[1]) ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st);
+        rc = (g.w2img[0] && g.w2img[1] && g.w1img[0] && g.w1img[1]) ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st);
     else if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 2 / 4 / 5
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);

@@ -27,12 +27,6 @@
 #include "ppo_step_w4_impl.h"
 #include "split_bf16.h"
 
-// experiments on the prologue's memory fill (tools/r04_k6_exp.sh; never set in the product build): 1 no W2-image copy (wrong
-// results, timing only), 2 the image's 1 KB pieces requested in an order rotated by the workgroup index
-#ifndef ERL_K6_EXP
-#define ERL_K6_EXP 0
-#endif
-
 namespace {
 
 __device__ __forceinline__ int phi(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }   // bits 2 and 3 swapped
@@ -80,9 +74,15 @@ __device__ __forceinline__ void img_store(const float4 (&v)[MAXV], u8 *img, int 
 // between two accumulators: an instruction between two MFMAs on the SAME accumulator costs ~43 cycles (the back-to-back
 // forwarding path is lost).
 // ---------------------------------------------------------------------------------------------------------
-template <int NK, int NO, int CP>
+struct NoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// `side(c)` is called once per k-step c = To NK + ks, between its first MFMA and its first vector stage (the caller's LDS-DMA
+// pieces ride there: a vector-memory instruction among MFMAs costs its issue slot, a burst of them 60-180 cycles apiece)
+template <int NK, int NO, int CP, typename Side = NoSide>
 __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (&inP)[NK], const f32x16 (&inH)[(NK + 1) / 2],
-                                       f32x16 (&outH)[NO], f32x16 (&outG)[NO], int m, int hi)
+                                       f32x16 (&outH)[NO], f32x16 (&outG)[NO], int m, int hi, const Side &side = Side())
 {
     constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
     constexpr int EP = 16 / NK;                          // elements of the previous tile finished per k-step (NK in {1, 2, 4, 8})
@@ -198,6 +198,8 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
                 else jit(ks + 1, s);
             };
             acc = mfma_bf(a.m, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            side(c);
             __builtin_amdgcn_sched_barrier(0);
             fill(0);
             acc1 = mfma_bf(a.l, b.h, acc1);
@@ -481,17 +483,36 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     const int64_t bidx = (int64_t)blockIdx.x * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
-    float4 c1[N1 * KX], c2[PRE ? 1 : N1 * N2], c3[2];
-    copy_load<VEC, N1 * KX, QNT>(c1, P + d.oW1(), h1, S, h1, 32 * KX, tid);
-    copy_load<VEC, 2, QNT>(c3, P + d.oW3(), OUT, h2, 16, h2, tid);
-    const float bias_pre = (tid < 128) ? (tid < h1 ? P[d.ob1() + tid] : 0.f) : (tid - 128 < h2 ? P[d.ob2() + tid - 128] : 0.f);
-    float b3_pre = 0.f;
-    if (tid < 16) b3_pre = (tid < OUT) ? P[d.ob3() + tid] : 0.f;
-    float nr_pre = 0.f, nn_pre = 0.f;
-    if (tid < 64 && tid < S) {
-        nr_pre = __builtin_amdgcn_rcpf(g.sd[net][tid] + 1e-4f);        // (x - avg) / (std + 1e-4)  (AgentPPO.py:360-361)
-        nn_pre = -(g.avg[net][tid] * nr_pre);
+    // FAST (round 4; images from the update loop, 16-byte-aligned rows, S > 8): W1 comes as a ready image by LDS-DMA, issued while
+    // the sample ids are in flight (the old prologue spent 2.4k cycles splitting it in every workgroup), and the state rows are
+    // gathered with whole-row coalesced loads (below)
+    constexpr bool FAST = PRE && VEC && !TINY;
+    float4 c1[FAST ? 1 : N1 * KX], c2[PRE ? 1 : N1 * N2], c3[2];
+    if constexpr (FAST) {
+        constexpr int KB1 = h1 * 48 * CP1 / 1024;           // the W1 image in 1 KB pieces
+        static_assert(h1 * 48 * CP1 % 1024 == 0, "W1 image size");
+        static_assert(KB1 % QNW == 0, "W1 image pieces per wave");
+        const u8 *src1 = g.w1img[net] + 16 * lane;
+#pragma unroll
+        for (int i = 0; i < KB1 / QNW; ++i) {
+            const int k = wave + QNW * i;                   // wave-uniform
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(src1 + 1024 * k), reinterpret_cast<float *>(IMG1 + 1024 * k), 16, 0, 0);
+        }
+    } else {
+        copy_load<VEC, N1 * KX, QNT>(c1, P + d.oW1(), h1, S, h1, 32 * KX, tid);
     }
+    // Every load of the prologue is UNCONDITIONAL (clamped addresses, values selected where they are stored): a load behind a
+    // condition -- `tid < 16 ? P[..] : 0`, `valid && unmasks[row]`, a zero written over a load's own destination -- made hipcc drain
+    // the whole vector-memory counter (s_waitcnt vmcnt(0)) inside the branch, five times between kernel entry and the first MFMA:
+    // five exposed round trips with the weight images and the gathered rows behind them (round 4's prologue profile)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                           // W3 rows [16][h2] (rows >= OUT zeroed when stored)
+        const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
+        c3[u] = load4<VEC>(P + d.oW3() + (size_t)min(i, OUT - 1) * h2, 4 * j4, h2);
+    }
+    const float bias_raw = P[tid < 128 ? d.ob1() + min(tid, h1 - 1) : d.ob2() + min(tid - 128, h2 - 1)];
+    const float b3_raw = P[d.ob3() + min(tid, OUT - 1)];
+    const float sd_raw = g.sd[net][min(tid, S - 1)], avg_raw = g.avg[net][min(tid, S - 1)];
 
     // ---- trip 2: id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
     int64_t n_, t_;
@@ -507,7 +528,20 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     PROF_X(16, row);                                        // (profile builds: the id has arrived)
     // this lane's own state row, in the operand order: features 16 ks + 8 hi + 0..7 of k-step ks
     float4 XR[NK1][2];
-    {
+    // FAST: the rows are fetched COALESCED -- load i of a wave takes the whole rows of its samples 4 i .. 4 i + 3 (lane = (row in
+    // the group, 16-byte chunk); the row numbers cross lanes by ds_bpermute) -- and pass through a wave-private LDS tile (chunks
+    // XOR-swizzled by the sample) to the lanes that own them.  A lane fetching its own 32-byte pieces put 32 .. 64 different
+    // lines into every load instruction: 3.3k cycles of address processing for 16 loads (round 4's prologue stamps).
+    float4 GR[FAST ? 8 : 1];
+    if constexpr (FAST) {
+        const int r4 = lane >> 4, c16 = lane & 15;
+        const uint32_t row_lo = (uint32_t)row, row_hi = (uint32_t)((uint64_t)row >> 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rw = (int64_t)(((uint64_t)(uint32_t)__shfl((int)row_hi, 4 * i + r4, 64) << 32) | (uint32_t)__shfl((int)row_lo, 4 * i + r4, 64));
+            GR[i] = load4<true>(g.states + rw * S, 4 * c16, S);
+        }
+    } else {
         const float *xrow = g.states + row * S;
 #pragma unroll
         for (int ks = 0; ks < NK1; ++ks) {
@@ -515,9 +549,11 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
             XR[ks][1] = load4<VEC>(xrow, 16 * ks + 8 * hi + 4, S);
         }
     }
-    const float um = (valid && g.unmasks[row]) ? 1.f : 0.f;
-    const float xa = ACTOR ? g.logprobs[row] : g.reward_sums[row];
-    const float xb = ACTOR ? g.advantages[row] : 0.f;
+    const uint8_t um_raw = g.unmasks[row];
+    float um_k = (valid && um_raw) ? 1.f : 0.f;
+    float xa_k = ACTOR ? g.logprobs[row] : g.reward_sums[row];
+    float xb_k = ACTOR ? g.advantages[row] : 0.f;
+    const float &um = um_k, &xa = xa_k, &xb = xb_k;
     float act_pre[4] = {0.f, 0.f, 0.f, 0.f}, sl_pre[4] = {0.f, 0.f, 0.f, 0.f};
     if (ACTOR) {
         const bool act4 = (OUT & 3) == 0 && (reinterpret_cast<uintptr_t>(g.actions) & 15) == 0;      // uniform
@@ -533,36 +569,80 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         }
     }
     PROF_NV(17);                                            // (row loads issued)
-    // ---- the W2 image: requested LAST (the memory pipe returns W1 and the rows first), issued while those are in flight (an LDS-DMA
-    // piece costs its wave 60-180 cycles of issue: here they fall into the wait for the gathered rows), landing under the first layer
-    if constexpr (PRE) {
-        constexpr int KB = h2 * 48 * CP2 / 1024;            // the image in 1 KB pieces: one wave instruction each, straight into LDS
-        static_assert(h2 * 48 * CP2 % 1024 == 0, "image size");
+    // ---- the W2 image.  Without FAST: requested here, last (the memory pipe returns W1 and the rows first), by the compiler's own
+    // LDS-DMA intrinsic.  hipcc orders EVERY later LDS access behind an intrinsic LDS-DMA (it cannot tell the bytes apart): the
+    // s_waitcnt vmcnt(0) it put in front of the W1 split below waited for the whole 96 KB image -- nothing "landed under the first
+    // layer" (round 4's prologue stamps: 1.9k cycles, gone when the copy was taken out).  FAST requests it after barrier (0a) through
+    // inline assembly the compiler does not see, and waits for it by hand before barrier (0b).
+    constexpr int KB = h2 * 48 * CP2 / 1024;                // the image in 1 KB pieces: one wave instruction each, straight into LDS
+    static_assert(h2 * 48 * CP2 % 1024 == 0 && KB % (2 * QNW) == 0, "image size");
+    if constexpr (PRE && !FAST) {
         const u8 *src = g.w2img[net] + 16 * lane;
-        const int rot = (ERL_K6_EXP & 2) ? (int)((blockIdx.x * 29u + blockIdx.y * 47u) % KB) : 0;
 #pragma unroll
-        for (int i = 0; i < (KB + QNW - 1) / QNW; ++i) {
-            const int k0 = wave + QNW * i;                  // wave-uniform
-            const int k = (ERL_K6_EXP & 2) ? (k0 + rot) % KB : k0;
-            if (k0 < KB && !(ERL_K6_EXP & 1))
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(src + 1024 * k), reinterpret_cast<float *>(IMG2 + 1024 * k), 16, 0, 0);
+        for (int i = 0; i < KB / QNW; ++i) {
+            const int k = wave + QNW * i;                   // wave-uniform
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(src + 1024 * k), reinterpret_cast<float *>(IMG2 + 1024 * k), 16, 0, 0);
         }
     }
-    PROF_NV(18);                                            // (W2 image pieces issued)
-    // ---- the weight images (split here; every workgroup converts the same 24k weights -- see DESIGN.md for the pre-split plan)
-    img_store<N1 * KX, CP1>(c1, IMG1, h1, tid);
-    PROF_NV(19);                                            // (W1 has arrived and is split into its image)
+    PROF_NV(18);                                            // (W2 image pieces issued / FAST: row loads issued)
+    if constexpr (FAST) {
+        // the rows through the wave-private tile (8 KB per wave at the start of the W2 image's region, which is still free):
+        // [32 samples][16 chunks of 16 bytes], chunk c of sample s at c ^ (s & 15) -- conflict-free for the 16-byte stores by
+        // (4 rows x 16 chunks) and for the reads by (sample, half)
+        u8 *stg = IMG2 + 8192 * wave;
+        const int r4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sm = 4 * i + r4;
+            *reinterpret_cast<float4 *>(stg + 256 * sm + 16 * (c16 ^ (sm & 15))) = GR[i];
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK1; ++ks) {
+            XR[ks][0] = *reinterpret_cast<const float4 *>(stg + 256 * m + 16 * ((4 * ks + 2 * hi) ^ (m & 15)));
+            XR[ks][1] = *reinterpret_cast<const float4 *>(stg + 256 * m + 16 * ((4 * ks + 2 * hi + 1) ^ (m & 15)));
+        }
+    } else {
+        // ---- the weight images (split here; every workgroup converts the same 24k weights)
+        img_store<N1 * KX, CP1>(c1, IMG1, h1, tid);
+    }
+    PROF_NV(19);                                            // (W1 has arrived and is split into its image / the rows are in their lanes)
 #pragma unroll
     for (int e = tid; e < kS3W3 / 16; e += QNT) reinterpret_cast<float4 *>(RW3)[e] = zero4();
-    s_b1[tid] = bias_pre;                                   // s_b1 | s_b2 contiguous
-    if (tid < 16) s_b3[tid] = b3_pre;
-    if (tid < 64) { s_nr[tid] = nr_pre; s_nn[tid] = nn_pre; }
+    s_b1[tid] = (tid < 128 ? tid < h1 : tid - 128 < h2) ? bias_raw : 0.f;          // s_b1 | s_b2 contiguous
+    if (tid < 16) s_b3[tid] = tid < OUT ? b3_raw : 0.f;
+    if (tid < 64) {
+        const float nr = __builtin_amdgcn_rcpf(sd_raw + 1e-4f);                  // (x - avg) / (std + 1e-4)  (AgentPPO.py:360-361)
+        s_nr[tid] = tid < S ? nr : 0.f;
+        s_nn[tid] = tid < S ? -(avg_raw * nr) : 0.f;
+    }
     PROF_NV(1);
-    lds_barrier();                                                   // (0a) images, biases, constants visible; RW3 zeroed
+    if constexpr (FAST) {
+        // every value loaded so far is in its register (the tile's reads too) before the hidden copy below goes out: from here on
+        // the compiler knows of no load in flight and inserts no vector-memory wait that the image pieces would stretch
+        float act_l[4] = {act_pre[0], act_pre[1], act_pre[2], act_pre[3]}, sl_l[4] = {sl_pre[0], sl_pre[1], sl_pre[2], sl_pre[3]};
+        float um_l = um, xa_l = xa, xb_l = xb;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(act_l[0]), "+v"(act_l[1]), "+v"(act_l[2]), "+v"(act_l[3]), "+v"(sl_l[0]), "+v"(sl_l[1]), "+v"(sl_l[2]), "+v"(sl_l[3]),
+                       "+v"(um_l), "+v"(xa_l), "+v"(xb_l)::"memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { act_pre[j] = act_l[j]; sl_pre[j] = sl_l[j]; }
+        um_k = um_l; xa_k = xa_l; xb_k = xb_l;
+#pragma unroll
+        for (int ks = 0; ks < NK1; ++ks)
+            asm volatile("" : "+v"(XR[ks][0].x), "+v"(XR[ks][0].y), "+v"(XR[ks][0].z), "+v"(XR[ks][0].w), "+v"(XR[ks][1].x), "+v"(XR[ks][1].y),
+                              "+v"(XR[ks][1].z), "+v"(XR[ks][1].w));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(c3[u].x), "+v"(c3[u].y), "+v"(c3[u].z), "+v"(c3[u].w));
+    }
+    lds_barrier();                                                   // (0a) images, biases, constants visible; RW3 zeroed; row tiles read
     PROF_NV(2);
-    copy_store<2, QNT>(c3, RW3, ld3, 16, h2, tid);                  // visible after (0b)
-    // (without images) W2 is not needed before the second layer: requested only now, so that the prologue's burst (every CU pulls
-    // its W1 and its 32 KB of gathered rows at once, ~11 B/clk per CU) is not stretched by another 64 KB
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                    // W3 copy [16][ld3], rows >= OUT zero; visible after (0b)
+        const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
+        if (i < 16) *reinterpret_cast<float4 *>(RW3 + i * ld3 + 4 * j4) = i < OUT ? c3[u] : zero4();
+    }
+    // (without images) W2 is not needed before the second layer: requested only now, so that the prologue's burst is not stretched
+    // by another 64 KB
     if constexpr (!PRE) copy_load<VEC, N1 * N2, QNT>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
     // ---- normalise the own row; its split rides behind the first output tile's MFMAs of the first layer
     Parts Xp[NK1];
@@ -582,7 +662,35 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     PROF_X(20, XH[0][0]);                                   // (the own row has arrived and is normalised)
     f32x16 H1[N1], G1[N1], H2[N2], G2[N2];
     Parts H1p[2 * N1];
-    fwd_s3<NK1, N1, CP1>(IMG1, s_b1, Xp, XH, H1, G1, m, hi);
+    if constexpr (FAST) {
+        // the W2 image rides the first layer's k-steps: wave w copies the quarter [w KB / 4, (w + 1) KB / 4) KB of it, PPK pieces of
+        // 1 KB behind the first MFMA of a k-step (one LDS base per k-step: the instruction offset advances the memory and the
+        // LDS address alike); hidden from the compiler (see above), waited for by hand before barrier (0b)
+        constexpr int KBW = KB / QNW, KS1 = N1 * NK1;                     // pieces per wave, k-steps of the first layer
+        constexpr int PPK = (KBW + KS1 - 1) / KS1 <= 2 ? 2 : 4;           // pieces per k-step (2: 16 k-steps x 2 >= 24)
+        static_assert(PPK * KS1 >= KBW && KBW % 2 == 0, "the first layer has too few k-steps for the W2 image");
+        const u8 *src = g.w2img[net] + 16 * lane + KBW * 1024 * wave;
+        const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(IMG2 + KBW * 1024 * wave));
+        auto w2_pieces = [&](int c) {
+            const int q = PPK * c;
+            if (q < KBW) {
+                const u8 *pq = src + 1024 * q;
+                if (PPK == 4 && q + 4 <= KBW)
+                    asm volatile("s_mov_b32 m0, %1\n\t"
+                                 "global_load_lds_dwordx4 %0, off\n\t"
+                                 "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+                                 "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+                                 "global_load_lds_dwordx4 %0, off offset:3072" ::"v"(pq), "s"(l0 + 1024u * q) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %1\n\t"
+                                 "global_load_lds_dwordx4 %0, off\n\t"
+                                 "global_load_lds_dwordx4 %0, off offset:1024" ::"v"(pq), "s"(l0 + 1024u * q) : "memory");
+            }
+        };
+        fwd_s3<NK1, N1, CP1>(IMG1, s_b1, Xp, XH, H1, G1, m, hi, w2_pieces);
+    } else {
+        fwd_s3<NK1, N1, CP1>(IMG1, s_b1, Xp, XH, H1, G1, m, hi);
+    }
     PROF_NV(3);
     if constexpr (PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the W2 image have landed
     else img_store<N1 * N2, CP2>(c2, IMG2, h2, tid);

@@ -1,15 +1,19 @@
-// The W2 images of ppo_step_s3 (K6 on the bf16 matrix pipe) as the optimiser sees them: a global-memory copy of the kernel's LDS
-// image [row][3 parts][h1 bf16] (16-byte chunks XOR-swizzled by the row, see ppo_step_s3_impl.h), built once per update loop from
-// the fp32 parameters and refreshed by clip + Adam element by element, so that the minibatch kernel copies it straight into LDS
-// (LDS-DMA under the first layer's MFMAs) instead of every workgroup splitting the same 16k weights.
+// The weight images of ppo_step_s3 (K6 on the bf16 matrix pipe) as the optimiser sees them: global-memory copies of the kernel's LDS
+// images [row][3 parts][K bf16] (16-byte chunks XOR-swizzled by the row, see ppo_step_s3_impl.h) -- W2 ([h2][3][h1]) and, since
+// round 4, W1 ([h1][3][K1], K1 = the state dimension padded to 32 or 64 columns, pad = 0) -- built once per update loop from the
+// fp32 parameters and refreshed by clip + Adam element by element, so that the minibatch kernel copies them straight into LDS
+// (LDS-DMA: W1 while the sample ids are in flight, W2 under the first layer's MFMAs) instead of every workgroup splitting the same
+// 24k weights (round 4's prologue profile: 2.4k of the kernel's first 11.7k cycles were that split).
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
 struct S3Image {
-    unsigned char *img;     // nullptr: none
+    unsigned char *img;     // W2 image; nullptr: none
     int64_t w2_off;         // offset of W2 inside the network's flat parameter block
     int h1, h2;
+    unsigned char *img1;    // W1 image [h1][3][K1 bf16] (W1 sits at offset 0 of the block, row-major [h1][S]); nullptr: none
+    int S, K1;              // real / padded columns of W1 (K1 = 32 for S <= 32, else 64)
 };
 struct S3Images {
     S3Image net[2];         // actor, critic (= parameter groups 0, 1 of the update loop)
@@ -47,6 +51,8 @@ __device__ inline void s3_image_put(unsigned char *img, int K, int row, int col,
 }
 
 inline size_t s3_image_bytes(int h1, int h2) { return (size_t)h2 * 6 * h1; }
+inline int s3_image_k1(int S) { return S <= 32 ? 32 : 64; }
+inline size_t s3_image1_bytes(int h1, int S) { return (size_t)h1 * 6 * s3_image_k1(S); }
 
 // ppo_step.hip / grad_tail.hip: the entry points of the update loop (comm.cpp) that carry the images along
 int erl_ppo_step_images_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
