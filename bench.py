@@ -522,11 +522,15 @@ def main():
                      "event_bracket_us": round(k6_event_s * 1e6, 2), "event_bracket_null_us": round(null_bracket_us, 2),
                      "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src},
         "breakdown": breakdown,
-        "roofline_gae": {"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
-                         "bound": "hbm",
-                         "achieved": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": round(gae_s * 1e6, 2)},
+        "roofline_gae": ({"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
+                          "bound": "hbm",
+                          "achieved": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                          "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": round(gae_s * 1e6, 2)} if t_gae.pairs else
+                         {"kernel": f"none in the loop: at {HORIZON}x{N_ENVS} get_advantages and its statistics run in the persistent rollout's "
+                                    "epilogue (csrc/rollout_fused.hip; ERL_FUSED_GAE=0 restores the scan launches); the scan kernel's HBM figures: `sweep`",
+                          "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+                          "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": None}),
         "objectives_last": [round(float(x), 6) for x in objs],
     }
     if allreduce is not None:

@@ -60,10 +60,11 @@ _SIGNATURES = {
     "erl_rollout_step_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_uint64, c_uint64,
                                      _P, _P, _P, _P, _P]),
     "erl_rollout_fused_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "erl_rollout_gae_workspace_bytes": (c_int64, [c_int64]),
     "erl_rollout_synenv_f32": (c_int, [_P] * 6 + [c_int] * 4 + [_P] * 5 + [c_int, c_uint64, c_int64, c_int64, _P, c_uint64, c_uint64,
-                                       c_float] + [_P] * 9),
+                                       c_float] + [_P] * 8 + [_P] * 5 + [c_int64, c_float, c_float, c_int, _P]),
     "erl_rollout_pendulum_f32": (c_int, [_P] * 6 + [c_int] * 2 + [_P] * 4 + [c_int, c_uint64, c_int64, c_int64, _P, c_uint64,
-                                         c_uint64, c_float] + [_P] * 9),
+                                         c_uint64, c_float] + [_P] * 8 + [_P] * 5 + [c_int64, c_float, c_float, c_int, _P]),
     "erl_ppo_slab_stride": (c_int64, [c_int, c_int, c_int, c_int]),
     "erl_ppo_num_slabs": (c_int, [c_int64]),
     "erl_ppo_set_arith": (c_int, [c_int]),
@@ -91,6 +92,7 @@ _SIGNATURES = {
     "erl_comm_reduce_exchange_f32": (c_int, [_P, _P, c_int, c_int64, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
     "erl_grad_reduce_partials_f32": (c_int, [_P, c_int, c_int64, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
     "erl_ppo_logs_mean_f32": (c_int, [_P, c_int64, c_int64, c_int, c_float, _P, _P]),
+    "erl_ppo_finish_f32": (c_int, [_P, c_int64, c_int64, c_int, c_float, _P, _P, _P, _P, _P, c_int64, _P]),
     "erl_grad_sq_partials_f32": (c_int, [_P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_float, _P]),
     "erl_clip_adam_partials_f32": (c_int, [_P, _P, _P, _P, c_int64, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
                                            c_float, c_float, c_float, c_float, c_float, _P]),
@@ -101,7 +103,7 @@ _SIGNATURES = {
     "erl_comm_p2p_set_spin": (c_int, [_P, ctypes.c_uint32]),
     "erl_ppo_update_dp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
                                       _P, c_int64, c_int, c_float, c_float, c_int, _P, _P, c_int32, c_float, c_float, c_float,
-                                      c_float, c_float, _P, _P]),
+                                      c_float, c_float, _P, _P, _P]),
     "erl_mlpn_param_count": (c_int64, [POINTER(c_int), c_int, c_int]),
     "erl_mlpn_workspace_bytes": (c_int64, [POINTER(c_int), c_int, c_int64, c_int]),
     "erl_mlpn_value_forward_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, _P, c_int64, _P]),

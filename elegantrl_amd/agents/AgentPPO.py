@@ -136,7 +136,15 @@ class AgentPPO(AgentBase):
         # arithmetic of the minibatch kernel's large products (include/erl_hip.h, erl_ppo_set_arith): "auto" = the library default
         # (split bf16 operands on the bf16 matrix pipe, fp32-equivalent, where the net shape allows), "f32" = the fp32 MFMA.
         # Process-wide in the library: applied at every update_net (an "auto" agent resets what an "f32" agent set before it).
-        self.snapshot_last_state = bool(getattr(args, "snapshot_last_state", False))
+        # `agent.last_state` after a fused rollout: a tensor of the agent's own, written by the rollout kernel itself (the reference's
+        # behaviour, AgentPPO.py:125; no extra launch).  args.snapshot_last_state = False aliases the env's live state buffer instead.
+        self.snapshot_last_state = bool(getattr(args, "snapshot_last_state", True))
+        # the persistent rollout's epilogue also runs get_advantages + its statistics (three launches less per iteration);
+        # args.fused_gae = False / ERL_FUSED_GAE=0 keeps them in update_net (A/B runs, parity tests)
+        import os as _os
+        self.fused_gae = bool(getattr(args, "fused_gae", _os.environ.get("ERL_FUSED_GAE", "1") != "0"))
+        self._gae_ws = None
+        self._last_state_token = None
         self.ppo_arith = str(getattr(args, "ppo_arith", "auto"))
         assert self.ppo_arith in ("auto", "f32", "split"), f"args.ppo_arith = {self.ppo_arith!r}"
         # which actor objective the kernels differentiate: the reference's sign-dependent scale (AgentPPO.py:199, default) or,
@@ -278,7 +286,16 @@ class AgentPPO(AgentBase):
         assert state.shape == (N, S), f"last_state {tuple(state.shape)} != {(N, S)}"
         state = state.to(dev, th.float32).contiguous()
         if hasattr(env, "raw_stepper") and state.data_ptr() != env.state.data_ptr():
-            env.state.copy_(state)                 # the env owns the live state buffer; keep it authoritative
+            tok = self._last_state_token
+            # `state` is the very tensor the last fused rollout of THIS env wrote as its copy of the final state, nobody has written
+            # to it, and the env has not moved since: the live buffer already holds it (no copy-back launch)
+            same = (tok is not None and tok[0] is self.last_state and tok[1] == self.last_state._version and tok[2] is env
+                    and tok[3] == getattr(env, "state_epoch", None))
+            if not same:
+                env.state.copy_(state)             # the env owns the live state buffer; keep it authoritative
+                if hasattr(env, "state_epoch"):
+                    env.state_epoch += 1
+        self._last_state_token = None
         self._rollout_cache = None
         if (self.fused_rollout and self._fused and hasattr(env, "fused_rollout") and getattr(env, "num_envs", None) == N
                 and getattr(env, "device", None) == dev
@@ -289,14 +306,32 @@ class AgentPPO(AgentBase):
             values = planes[2, :hn].view(H, N)
             next_value = th.empty((N,), dtype=th.float32, device=dev)
             noise = None if noise is None else noise.contiguous()
-            env.fused_rollout(self, H, noise, (states, actions, logprobs, rewards, undones, unmasks), values, next_value)
+            epilogue, adv_raw, ret, stats = None, None, None, None
+            last_out = th.empty((N, S), dtype=th.float32, device=dev) if self.snapshot_last_state else None
+            if self.fused_gae:
+                more = th.empty((2, pitch), dtype=th.float32, device=dev)
+                adv_raw, ret = more[0, :hn].view(H, N), more[1, :hn].view(H, N)
+                stats = th.empty(8, dtype=th.float64, device=dev)
+                need = int(_hip.lib().erl_rollout_gae_workspace_bytes(N)) // 8
+                if self._gae_ws is None or self._gae_ws.numel() < need:
+                    self._gae_ws = th.zeros(need, dtype=th.float64, device=dev)
+            if last_out is not None or self.fused_gae:
+                epilogue = (last_out, adv_raw, ret, stats, self._gae_ws if self.fused_gae else None, float(self.gamma),
+                            float(self.lambda_gae_adv), bool(self.if_use_v_trace))
+            env.fused_rollout(self, H, noise, (states, actions, logprobs, rewards, undones, unmasks), values, next_value,
+                              **({} if epilogue is None else {"epilogue": epilogue}))
             self.rng_counter += H
-            # the env's live state buffer IS the last state (no copy out now, no copy back at the next call: two launches and
-            # ~50 us of interpreter time between them, with the GPU idle -- the previous iteration ended in a host sync);
-            # args.snapshot_last_state = True restores the private copy for callers that keep last_state across rollouts
-            self.last_state = env.state.clone() if self.snapshot_last_state else env.state
+            # the agent's copy of the final state is written by the rollout kernel itself (no clone, and no copy back at the next
+            # call while nobody touches either side: _last_state_token); args.snapshot_last_state = False hands out the env's
+            # live buffer instead
+            self.last_state = last_out if last_out is not None else env.state
+            if last_out is not None:
+                self._last_state_token = (last_out, last_out._version, env, getattr(env, "state_epoch", None))
             self._rollout_cache = dict(states=states, values=values, next_value=next_value, last_state=self.last_state,
                                        key=self._value_cache_key(states, self.last_state))
+            if self.fused_gae:
+                self._rollout_cache.update(adv=adv_raw, ret=ret, stats=stats, rewards=rewards, undones=undones, unmasks=unmasks,
+                                           adv_key=self._adv_cache_key(rewards, undones, unmasks))
             return states, actions, logprobs, rewards, undones, unmasks
         rollout_step = ops.rollout_step if self._fused else ops.mlpn_rollout_step
         if hasattr(env, "raw_stepper") and self._fused:
@@ -400,6 +435,22 @@ class AgentPPO(AgentBase):
                 self._adam_step, self._flat._version, id(self.cri), self._norm_version,
                 sum(p._version for p in self.cri.parameters()))      # in-place edits / load_state_dict of the critic
 
+    def _adv_cache_key(self, rewards: TEN, undones: TEN, unmasks: TEN):
+        """what the advantages left by the rollout's epilogue depend on besides the values: the flag / reward tensors as they
+        were written (an in-place edit by the caller bumps _version) and the scan's hyper-parameters"""
+        return (rewards.data_ptr(), rewards._version, undones.data_ptr(), undones._version, unmasks.data_ptr(), unmasks._version,
+                float(self.gamma), float(self.lambda_gae_adv), bool(self.if_use_v_trace))
+
+    def _cached_advantages(self, rewards: TEN, undones: TEN, unmasks: TEN):
+        """(raw advantages, reward_sums, stats) computed by the fused rollout's epilogue for exactly these tensors, else None
+        (call after _cached_values said yes)."""
+        c = self._rollout_cache
+        if c is None or "adv" not in c or rewards is not c["rewards"] or undones is not c["undones"] or unmasks is not c["unmasks"]:
+            return None
+        if c["adv_key"] != self._adv_cache_key(rewards, undones, unmasks):
+            return None
+        return c["adv"], c["ret"], c["stats"]
+
     def _cached_values(self, states: TEN):
         """(values, next_value) computed by the fused rollout for exactly this buffer and this critic, else None."""
         c = self._rollout_cache
@@ -434,22 +485,34 @@ class AgentPPO(AgentBase):
         if self._stats is None:
             self._stats = th.zeros(8, dtype=th.float64, device=dev)
 
-        cached = self._cached_values(states)
-        if cached is not None:                                                        # left by the fused rollout (same critic)
-            values, next_value = cached
-            self._rollout_cache = None                                                # the GAE below mutates rewards / undones
-        else:
-            values, next_value = self.get_values(states), None                        # (H, N)
-        advantages, reward_sums = self._gae(rewards, undones, unmasks, values, stats=self._stats, next_value=next_value)
         dp = self.world_size > 1 or parallel.force_dp()
         # the job's exchange route (selected once, by a self-test: parallel.gradient_comm); None: torch.distributed
         comm = parallel.gradient_comm(self._stride) if dp else None
+        c_loop = self._fused and (not dp or comm is not None)       # the whole minibatch loop in one C call (below)
+        cached = self._cached_values(states)
+        from_rollout = None
+        if cached is not None:                                                        # left by the fused rollout (same critic)
+            values, next_value = cached
+            if c_loop:
+                from_rollout = self._cached_advantages(rewards, undones, unmasks)     # ... and get_advantages + its sums
+            self._rollout_cache = None                                                # the GAE below mutates rewards / undones
+        else:
+            values, next_value = self.get_values(states), None                        # (H, N)
+        if from_rollout is not None:
+            # raw advantages, reward sums and the five sums come from the rollout's epilogue; rewards / undones still are what
+            # explore_env returned: get_advantages' in-place fix-up of truncated steps rides the last launch (erl_ppo_finish_f32)
+            advantages, reward_sums, stats = from_rollout
+            self._stats = stats                # (the sums this update normalised with stay inspectable, as on the other path)
+        else:
+            stats = self._stats
+            advantages, reward_sums = self._gae(rewards, undones, unmasks, values, stats=stats, next_value=next_value)
         if self.world_size > 1:                                                       # one normalisation for the whole job:
             if comm is not None:                                                      # the 5 sums ride the gradient's route
-                comm.all_reduce_sum(self._stats)
+                comm.all_reduce_sum(stats)
             else:
-                parallel.all_reduce_sum(self._stats)
-        advantages = ops.adv_normalize(advantages, self._stats, out=advantages)
+                parallel.all_reduce_sum(stats)
+        if not c_loop:     # (the C loop's minibatch kernels normalise at their row loads from `stats`: no launch for it)
+            advantages = ops.adv_normalize(advantages, stats, out=advantages)
         assert logprobs.shape == advantages.shape == reward_sums.shape == (H, N)
 
         B = int(self.batch_size)
@@ -495,7 +558,7 @@ class AgentPPO(AgentBase):
                            c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
                            advantages, reward_sums, ids, float(self.ratio_clip), self.lambda_entropy_value, self._slabs,
                            self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm), comm=comm,
-                           objective=self._objective)
+                           objective=self._objective, adv_stats=stats)
             self._adam_step += update_times
         else:                           # data parallel through torch.distributed (gloo tests, ERL_DP_COLLECTIVE=torch)
             # raw pointers + direct C-ABI calls: the interpreter spends ~3 us per launch instead of ~10 (ptr checks, views)
@@ -530,8 +593,14 @@ class AgentPPO(AgentBase):
         self.act_optimizer.step_count = self.cri_optimizer.step_count = self._adam_step
         if self._logs is None:
             self._logs = th.empty(4, dtype=th.float32, device=dev)
-        _hip.check(_hip.lib().erl_ppo_logs_mean_f32(_hip.ptr(self._grads, th.float32), self._stride, self._Pa + self._Pc, update_times,
-                                                    grad_scale, _hip.ptr(self._logs, th.float32), _hip.stream_ptr()), "erl_ppo_logs_mean_f32")
+        if from_rollout is not None:           # the logged means + get_advantages' side effect on rewards / undones (AgentPPO.py:211-214)
+            _hip.check(_hip.lib().erl_ppo_finish_f32(_hip.ptr(self._grads, th.float32), self._stride, self._Pa + self._Pc, update_times,
+                                                     grad_scale, _hip.ptr(self._logs, th.float32), _hip.ptr(rewards, th.float32),
+                                                     _hip.flag_ptr(undones), _hip.flag_ptr(unmasks), _hip.ptr(values, th.float32), H * N,
+                                                     _hip.stream_ptr()), "erl_ppo_finish_f32")
+        else:
+            _hip.check(_hip.lib().erl_ppo_logs_mean_f32(_hip.ptr(self._grads, th.float32), self._stride, self._Pa + self._Pc, update_times,
+                                                        grad_scale, _hip.ptr(self._logs, th.float32), _hip.stream_ptr()), "erl_ppo_logs_mean_f32")
         obj_critic, obj_actor, obj_entropy = self._logs[:3].tolist()                  # the only host sync of update_net
         _hip.check_async_faults()              # the stream is drained: a lost look-back predecessor (NaN advantages) raises here
         return obj_critic, obj_actor, obj_entropy

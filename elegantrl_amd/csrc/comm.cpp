@@ -195,8 +195,8 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
                                      const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                                      const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
                                      int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs, float *grads,
-                                     int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, void *comm,
-                                     void *stream)
+                                     int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, const double *adv_stats,
+                                     void *comm, void *stream)
 {
     ERL_REQUIRE(flat_params && exp_avg && exp_avg_sq && ids && slabs && grads, "erl_ppo_update_dp_f32: NULL tensor");
     ERL_REQUIRE(update_times >= 1 && first_step >= 1 && B >= 1, "erl_ppo_update_dp_f32: bad argument");
@@ -224,7 +224,7 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
         float *g = grads + (size_t)k * stride;
         int rc = erl_ppo_step_images_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
                                          unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
-                                         lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, im, stream);
+                                         lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, im, adv_stats, stream);
         if (rc) return rc;
         if (tail) {
             rc = (tail == 2 ? erl_reduce_clip_adam_grid_f32 : erl_reduce_clip_adam_f32)(slabs, n_slabs, stride, g, flat_params, exp_avg, exp_avg_sq,

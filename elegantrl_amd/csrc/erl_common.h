@@ -128,6 +128,13 @@ __device__ __forceinline__ float erl_soft_update(float cur, float tar, float tau
     return cur * tau + tar * (1.0f - tau);
 }
 
+// x + y as one rounded add whatever surrounds it
+__device__ __forceinline__ float erl_add_rn(float x, float y)
+{
+#pragma clang fp contract(off)
+    return x + y;
+}
+
 // x * y rounded on its own (never folded into a following add)
 __device__ __forceinline__ float erl_mul_rn(float x, float y)
 {

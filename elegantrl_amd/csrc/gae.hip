@@ -17,6 +17,7 @@
 //              are walked (decoupled look-back; slabs are handed out by an atomic ticket, latest time first,
 //              so a slab only waits for workgroups that are already running).  AUTO picks it for H >= 64.
 #include "erl_common.h"
+#include "gae_step.h"
 
 #pragma clang fp contract(off)
 
@@ -69,27 +70,13 @@ __global__ __launch_bounds__(64) void gae_exact_kernel(float *__restrict__ rewar
                 const int t = tb - j;
                 if (t < 0) break;
                 const size_t i = (size_t)t * N + n;
-                float r = st[j].r;
                 const float v = st[j].v;
-                uint8_t ud = st[j].ud;
-                if (!st[j].um) {  // truncated: bootstrap with V(s_t), then cut the chain (:211-214)
-                    r = add_rn(r, v);
-                    ud = 0;
-                    if (mutate) {
-                        rewards[i] = r;
-                        undones[i] = 0;
-                    }
-                }
-                const float m = ud ? gamma : 0.f;
-                float out;
-                if (VTRACE) {  // :225-227
-                    nv = add_rn(r, mul_rn(m, nv));
-                    a = add_rn(sub_rn(nv, v), mul_rn(mul_rn(m, lam), a));
-                    out = a;
-                    nv = v;
-                } else {       // :229-231
-                    out = add_rn(sub_rn(r, v), mul_rn(m, a));
-                    a = add_rn(v, mul_rn(lam, out));
+                float r_eff;
+                uint8_t ud_eff;
+                const float out = erl_gae_step<VTRACE>(st[j].r, v, st[j].ud, st[j].um, gamma, lam, nv, a, r_eff, ud_eff);
+                if (!st[j].um && mutate) {  // truncated: the bootstrapped reward and the cut flag go back to the caller (:211-214)
+                    rewards[i] = r_eff;
+                    undones[i] = 0;
                 }
                 adv[i] = out;
                 if (ret) ret[i] = add_rn(out, v);

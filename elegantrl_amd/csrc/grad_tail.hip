@@ -315,6 +315,52 @@ extern "C" int erl_ppo_logs_mean_f32(const float *grad_rows, int64_t stride, int
     ERL_LAUNCH_CHECK("erl_ppo_logs_mean_f32");
 }
 
+// the last launch of update_net when the advantages came from the rollout's epilogue: the logged means as above (workgroup 0) AND
+// the side effect of get_advantages on the caller's buffers (elegantrl/agents/AgentPPO.py:211-214): rewards[trunc] += values[trunc],
+// undones[trunc] = False -- one fp32 add per truncated element, as gae_exact_kernel's `mutate` does
+namespace {
+__global__ __launch_bounds__(256) void ppo_finish_kernel(const float *__restrict__ rows, int64_t stride, int64_t offset, int n_rows, float scale,
+                                                         float *__restrict__ out, float *__restrict__ rewards, uint8_t *__restrict__ undones,
+                                                         const uint8_t *__restrict__ unmasks, const float *__restrict__ values, int64_t total)
+{
+    if (blockIdx.x == 0) {
+        __shared__ float part[64][3];
+        if (threadIdx.x < 192) {
+            const int slot = threadIdx.x / 3, j = threadIdx.x - 3 * slot;
+            float s = 0.f;
+            for (int k = slot; k < n_rows; k += 64) s += rows[(size_t)k * stride + offset + j];
+            part[slot][j] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float t = 0.f;
+            for (int q = 0; q < 64; ++q) t += part[q][threadIdx.x];
+            out[threadIdx.x] = t / (float)n_rows * scale;
+        }
+        return;
+    }
+    const int64_t stride_e = (int64_t)(gridDim.x - 1) * 256;
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; i < total; i += stride_e) {
+        if (!unmasks[i]) {
+            rewards[i] = erl_add_rn(rewards[i], values[i]);
+            undones[i] = 0;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int erl_ppo_finish_f32(const float *grad_rows, int64_t stride, int64_t offset, int n_rows, float scale, float *out3, float *rewards,
+                                  uint8_t *undones, const uint8_t *unmasks, const float *values, int64_t total, void *stream)
+{
+    ERL_REQUIRE(grad_rows && out3 && n_rows >= 1 && offset >= 0 && offset + 3 <= stride, "erl_ppo_finish_f32: bad argument");
+    ERL_REQUIRE(rewards && undones && unmasks && values && total >= 1, "erl_ppo_finish_f32: NULL rollout tensor");
+    int nblk = (int)erl_cdiv(total, 256 * 4);
+    if (nblk > 512) nblk = 512;
+    hipLaunchKernelGGL(ppo_finish_kernel, dim3(1 + (unsigned)nblk), dim3(256), 0, (hipStream_t)stream, grad_rows, stride, offset, n_rows, scale, out3,
+                       rewards, undones, unmasks, values, total);
+    ERL_LAUNCH_CHECK("erl_ppo_finish_f32");
+}
+
 extern "C" int erl_grad_reduce_partials_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, const int64_t *group_off,
                                             const int64_t *group_len, int n_groups, float grad_scale, void *stream)
 {

@@ -20,6 +20,7 @@ struct Ppo2Args {
     int objective;        // ERL_PPO_OBJ_* (ppo_objective.h)
     float *slabs;
     int64_t stride, Pa, Pc;
+    const double *adv_stats;         // nullptr: `advantages` are normalised already; else the raw sums of erl_gae_scan_f32 / the rollout epilogue
     const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
     const unsigned char *w1img[2];   // ... and W1 images (columns padded to 32 / 64); both or neither
     unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): {min entry, max exit} on the constant-rate clock; nullptr = off
@@ -34,6 +35,34 @@ constexpr int PB = 128;        // samples per workgroup
 // bytes apart modulo the 128-byte bank span => 8 consecutive rows form one conflict-free ds_read_b128 wavefront slice,
 // and a transposing ds_write_b32 of a D-layout tile lands 2 lanes per bank (the minimum for 64 lanes).
 constexpr int PLD = PB + 4;
+
+// (adv - mean(adv)) / (std(adv[::4, ::4]) + 1e-5)  (elegantrl/agents/AgentPPO.py:149) from the five raw sums: the arithmetic of
+// adv_normalize_kernel (gae.hip), operation for operation, so that a minibatch kernel that normalises at its row load sees the bits
+// the separate launch would have written
+struct AdvNorm {
+    float mean, denom;
+    bool on;
+};
+// computed once at kernel entry (wave-uniform: kept in scalar registers), while the sample ids are in flight
+__device__ __forceinline__ AdvNorm adv_norm_consts(const double *__restrict__ stats)
+{
+#pragma clang fp contract(off)
+    AdvNorm n{0.f, 1.f, stats != nullptr};
+    if (stats) {
+        const double mean_d = stats[0] / stats[1];
+        const double cnt = stats[4];
+        double var = (stats[3] - stats[2] * stats[2] / cnt) / (cnt - 1.0);  // unbiased (torch.std default)
+        var = var > 0 ? var : 0;
+        n.mean = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)mean_d)));
+        n.denom = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)sqrt(var) + 1e-5f)));
+    }
+    return n;
+}
+__device__ __forceinline__ float adv_normalized(float adv, const AdvNorm &n)
+{
+#pragma clang fp contract(off)
+    return n.on ? (adv - n.mean) / n.denom : adv;
+}
 
 // entry / exit of a workgroup on the device's constant-rate clock, folded into the launch's {min, max} slot (sampled launches only)
 __device__ __forceinline__ unsigned long long span_enter(const Ppo2Args &g)

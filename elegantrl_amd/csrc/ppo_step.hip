@@ -136,6 +136,7 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
     const int64_t bidx = (int64_t)blockIdx.x * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
+    const AdvNorm advn = adv_norm_consts(ACTOR ? g.adv_stats : nullptr);   // (under the id's round trip; scalar registers)
     float4 c2[8], c1[8], c3[1];
     copy_load<VEC, 8, PNW * 64>(c2, P + d.oW2(), h2, h1, h2, h1, tid);
     copy_load<VEC, 8, PNW * 64>(c1, P + d.oW1(), h1, S, h1, 16 * ns, tid);
@@ -265,7 +266,8 @@ __device__ __forceinline__ void ppo_block(const Ppo2Args &g, float *smem)
         }
         lp += __shfl_xor(lp, 16, 64);
         lp += __shfl_xor(lp, 32, 64);
-        const PpoActorTerms o = ppo_actor_terms(g.objective, xb, lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, false);
+        const PpoActorTerms o = ppo_actor_terms(g.objective, adv_normalized(xb, advn),   /* raw advantages are normalised here (AgentPPO.py:149) */
+                                                    lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, false);
         if (q == 0) {
             loss0 = valid ? o.logged : 0.f;                    // padding rows contribute 0
             loss1 = valid ? o.ent_mask : 0.f;
@@ -480,7 +482,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                             const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
-                            void *stream)
+                            const double *adv_stats, void *stream)
 {
     ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions && unmasks &&
                     logprobs && advantages && reward_sums && ids && slabs,
@@ -504,6 +506,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     g.Pa = Dims{S, h1, h2, A}.count(true);
     g.Pc = Dims{S, h1, h2, 1}.count(false);
     g.stride = erl_ppo_slab_stride(S, h1, h2, A);
+    g.adv_stats = adv_stats;
     g.w2img[0] = images ? images->net[0].img : nullptr;
     g.w2img[1] = images ? images->net[1].img : nullptr;
     g.w1img[0] = images ? images->net[0].img1 : nullptr;
@@ -539,5 +542,5 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
 {
     return erl_ppo_step_images_f32(actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions, unmasks,
                                    logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy, inv_batch, objective, slabs,
-                                   n_slabs, nullptr, stream);
+                                   n_slabs, nullptr, nullptr, stream);
 }

@@ -483,6 +483,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     const int64_t bidx = (int64_t)blockIdx.x * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
+    const AdvNorm advn = adv_norm_consts(ACTOR ? g.adv_stats : nullptr);   // (under the id's round trip; scalar registers)
     // FAST (round 4; images from the update loop, 16-byte-aligned rows, S > 8): W1 comes as a ready image by LDS-DMA, issued while
     // the sample ids are in flight (the old prologue spent 2.4k cycles splitting it in every workgroup), and the state rows are
     // gathered with whole-row coalesced loads (below)
@@ -788,7 +789,8 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
             lp += on ? term : 0.f;
         }
         lp += __shfl_xor(lp, 32, 64);
-        const PpoActorTerms o = ppo_actor_terms(g.objective, xb, lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, true);
+        const PpoActorTerms o = ppo_actor_terms(g.objective, adv_normalized(xb, advn),   /* raw advantages are normalised here (AgentPPO.py:149) */
+                                                    lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, true);
         if (hi == 0) {
             loss0 = valid ? o.logged : 0.f;
             loss1 = valid ? o.ent_mask : 0.f;

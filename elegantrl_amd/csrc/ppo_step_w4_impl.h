@@ -450,6 +450,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
     const int64_t bidx = (int64_t)blockIdx.x * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
+    const AdvNorm advn = adv_norm_consts(ACTOR ? g.adv_stats : nullptr);   // (under the id's round trip; scalar registers)
     float4 c1[N1 * KX];
     if (VEC && S == 32 * KX) copy_load_full<N1 * KX, 32 * KX>(c1, P + d.oW1(), tid);     // uniform branch
     else copy_load<VEC, N1 * KX, QNT>(c1, P + d.oW1(), h1, S, h1, 32 * KX, tid);
@@ -652,7 +653,8 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
             lp += on ? term : 0.f;
         }
         lp += __shfl_xor(lp, 32, 64);
-        const PpoActorTerms o = ppo_actor_terms(g.objective, xb, lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, true);
+        const PpoActorTerms o = ppo_actor_terms(g.objective, adv_normalized(xb, advn),   /* raw advantages are normalised here (AgentPPO.py:149) */
+                                                    lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, true);
         if (hi == 0) {
             loss0 = valid ? o.logged : 0.f;                     // padding rows contribute 0
             loss1 = valid ? o.ent_mask : 0.f;

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "erl_common.h"
+#include "gae_step.h"
 #include "mlp_chain.h"
 
 namespace {
@@ -45,6 +46,13 @@ struct RfArgs {
     float *o_states, *o_actions, *o_logprobs, *o_rewards;
     uint8_t *o_undones, *o_unmasks;
     float *o_values, *o_next_value;                // may be NULL
+    // epilogue (round 4; all may be NULL): a private copy of the final state, and get_advantages over the rollout just written --
+    // raw advantages, reward sums, the raw sums of the advantage normalisation (erl_gae_scan_f32's `stats` block)
+    float *o_last_state;
+    float *o_adv, *o_ret;
+    double *gae_stats, *gae_ws;                    // ws: [3 x workgroups] fp64 partial sums, then one 64-bit arrival counter (zero between launches)
+    float gamma, lam;
+    int vtrace;
     // environment
     float *env_state;                              // (N, S) live state (SynVecEnv.state / PendulumVecEnv.state = obs)
     float *phys;                                   // Pendulum: (N, 2) theta, theta_dot
@@ -494,15 +502,100 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     for (int t = 0; t < H; ++t) step(t, std::false_type{});
     step(H, std::true_type{});
 
-    // ---- hand the environment back: live state, counters (the per-step kernels keep them in global memory)
+    // ---- hand the environment back: live state, counters (the per-step kernels keep them in global memory); the agent's own
+    // copy of the final state (AgentPPO.py:125 `self.last_state = state`: a tensor of its own, not the env's live buffer)
     for (int e = tid; e < 16 * 64; e += 512) {
         const int i = e >> 6, k = e & 63;
-        if (env0 + i < g.N && k < S) g.env_state[(env0 + i) * S + k] = XS[i * RF_XLD + k];
+        if (env0 + i < g.N && k < S) {
+            const float x = XS[i * RF_XLD + k];
+            g.env_state[(env0 + i) * S + k] = x;
+            if (g.o_last_state) g.o_last_state[(env0 + i) * S + k] = x;
+        }
     }
     if (wave == 0 && q == 0 && valid) {
         g.step_count[row] = sc;
         g.episode[row] = ep;
         if (ENV == ENV_PENDULUM) { g.phys[2 * row] = th; g.phys[2 * row + 1] = thdot; }
+    }
+
+    // ---- epilogue: AgentPPO.get_advantages (elegantrl/agents/AgentPPO.py:207-232) + reward_sums (:146) + the sums of the advantage
+    // normalisation (:149) for the 16 envs of this workgroup, straight from the rows it has just written (its own stores: visible
+    // to the workgroup after the barrier) -- three launches less per iteration than scan + statistics fold + normalisation, which
+    // at the benchmark's 32 x 4096 are launch-sized (9.3 + 4.6 + 4.8 us).  The exact scan's arithmetic (gae_step.h): bit-identical to
+    // erl_gae_scan_f32(EXACT).  The caller's rewards / undones are NOT touched here (explore_env returns them as the reference
+    // does; the truncation fix-up of get_advantages is applied by erl_ppo_finish_f32 at the end of update_net).
+    if (g.o_adv) {
+        __syncthreads();                                   // (drains this workgroup's stores: vmcnt(0), then the barrier)
+        double s_all = 0, s_sub = 0, q_sub = 0;
+        if (wave == 0 && q == 0 && valid) {
+            float nv = g.o_next_value[row], a = 0.f;
+            const bool sub_col = (row & 3) == 0;
+            constexpr int U = 8;
+            for (int tb = H - 1; tb >= 0; tb -= U) {
+                float r_[U], v_[U];
+                uint8_t ud_[U], um_[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int t = max(tb - j, 0);
+                    const size_t i = (size_t)t * N + row;
+                    r_[j] = g.o_rewards[i]; v_[j] = g.o_values[i]; ud_[j] = g.o_undones[i]; um_[j] = g.o_unmasks[i];
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int t = tb - j;
+                    if (t < 0) break;
+                    const size_t i = (size_t)t * N + row;
+                    float r_eff;
+                    uint8_t ud_eff;
+                    const float out = g.vtrace ? erl_gae_step<true>(r_[j], v_[j], ud_[j], um_[j], g.gamma, g.lam, nv, a, r_eff, ud_eff)
+                                               : erl_gae_step<false>(r_[j], v_[j], ud_[j], um_[j], g.gamma, g.lam, nv, a, r_eff, ud_eff);
+                    g.o_adv[i] = out;
+                    g.o_ret[i] = erl_add_rn(out, v_[j]);
+                    s_all += out;
+                    if (sub_col && (t & 3) == 0) {
+                        s_sub += out;
+                        q_sub += (double)out * out;
+                    }
+                }
+            }
+        }
+        if (wave == 0) {
+            // workgroup partials -> the LAST workgroup to arrive folds all of them in index order (deterministic) into the 5 raw
+            // sums.  Partials and counter are 8-byte agent-scope atomics on both sides (no cache maintenance, MI355X_MICROARCH.md);
+            // the counter returns to 0 for the next launch.
+            const double w0 = wave_sum(s_all), w1 = wave_sum(s_sub), w2 = wave_sum(q_sub);
+            const unsigned nwg = gridDim.x;
+            unsigned long long *counter = reinterpret_cast<unsigned long long *>(g.gae_ws + 3 * (size_t)nwg);
+            int last = 0;
+            if (lane == 0) {
+                unsigned long long *pw = reinterpret_cast<unsigned long long *>(g.gae_ws) + 3 * (size_t)blockIdx.x;
+                __hip_atomic_store(pw + 0, (unsigned long long)__double_as_longlong(w0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pw + 1, (unsigned long long)__double_as_longlong(w1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pw + 2, (unsigned long long)__double_as_longlong(w2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partials are acknowledged before the arrival counts
+                last = __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(nwg - 1);
+            }
+            last = __shfl(last, 0, 64);
+            if (last) {
+                double f0 = 0, f1 = 0, f2 = 0;
+                for (unsigned b = lane; b < nwg; b += 64) {
+                    const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(g.gae_ws) + 3 * (size_t)b;
+                    f0 += __longlong_as_double((long long)__hip_atomic_load(pr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    f1 += __longlong_as_double((long long)__hip_atomic_load(pr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    f2 += __longlong_as_double((long long)__hip_atomic_load(pr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                f0 = wave_sum(f0); f1 = wave_sum(f1); f2 = wave_sum(f2);
+                if (lane == 0) {
+                    g.gae_stats[0] = f0;
+                    g.gae_stats[1] = (double)H * (double)g.N;
+                    g.gae_stats[2] = f1;
+                    g.gae_stats[3] = f2;
+                    g.gae_stats[4] = (double)((H + 3) / 4) * (double)((g.N + 3) / 4);
+                    g.gae_stats[5] = g.gae_stats[6] = g.gae_stats[7] = 0.0;      // (the block is all-reduced whole under data parallelism)
+                    __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 }
 
@@ -545,7 +638,8 @@ int rf_fill(RfArgs &g, const char *what, const float *actor_params, const float 
             const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, int64_t N, int64_t H,
             const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states, float *out_actions,
             float *out_logprobs, float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks, float *out_values,
-            float *out_next_value)
+            float *out_next_value, float *out_last_state, float *out_adv, float *out_ret, double *gae_stats, double *gae_ws,
+            int64_t gae_ws_bytes, float gamma, float lam, int use_v_trace)
 {
     ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std, "%s: NULL network tensor", what);
     ERL_REQUIRE(out_states && out_actions && out_logprobs && out_rewards && out_undones && out_unmasks, "%s: NULL rollout buffer", what);
@@ -558,6 +652,15 @@ int rf_fill(RfArgs &g, const char *what, const float *actor_params, const float 
     g.noise = noise; g.seed = seed; g.counter0 = counter0; g.reward_scale = reward_scale;
     g.o_states = out_states; g.o_actions = out_actions; g.o_logprobs = out_logprobs; g.o_rewards = out_rewards;
     g.o_undones = out_undones; g.o_unmasks = out_unmasks; g.o_values = out_values; g.o_next_value = out_next_value;
+    g.o_last_state = out_last_state;
+    if (out_adv || out_ret) {
+        ERL_REQUIRE(out_adv && out_ret && gae_stats && gae_ws && out_values && out_next_value,
+                    "%s: the advantage epilogue needs out_advantages, out_reward_sums, gae_stats, gae_workspace, out_values and out_next_value", what);
+        ERL_REQUIRE(gae_ws_bytes >= erl_rollout_gae_workspace_bytes(N), "%s: gae_workspace of %lld bytes, erl_rollout_gae_workspace_bytes(N) = %lld",
+                    what, (long long)gae_ws_bytes, (long long)erl_rollout_gae_workspace_bytes(N));
+    }
+    g.o_adv = out_adv; g.o_ret = out_ret; g.gae_stats = gae_stats; g.gae_ws = gae_ws;
+    g.gamma = gamma; g.lam = lam; g.vtrace = use_v_trace ? 1 : 0;
 #ifdef ERL_PROFILE
     g.prof = g_rf_prof;
 #endif
@@ -573,18 +676,24 @@ extern "C" __attribute__((visibility("default"))) void erl_debug_set_rollout_fus
 
 extern "C" int erl_rollout_fused_supported(int S, int h1, int h2, int A) { return rf_dims_ok(S, h1, h2, A) ? 1 : 0; }
 
+// bytes of `gae_workspace` of the persistent rollouts for N envs: 3 fp64 partial sums per 16-env workgroup + the arrival counter
+extern "C" int64_t erl_rollout_gae_workspace_bytes(int64_t N) { return N >= 1 ? (3 * erl_cdiv(N, 16) + 1) * 8 : -1; }
+
 extern "C" int erl_rollout_synenv_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
                                       const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, float *env_state,
                                       const float *Ws, const float *Wa, int32_t *step_count, int32_t *episode, int max_step,
                                       uint64_t env_seed, int64_t N, int64_t H, const float *noise, uint64_t seed, uint64_t counter0,
                                       float reward_scale, float *out_states, float *out_actions, float *out_logprobs,
                                       float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks, float *out_values,
-                                      float *out_next_value, void *stream)
+                                      float *out_next_value, float *out_last_state, float *out_advantages, float *out_reward_sums,
+                                      double *gae_stats, double *gae_workspace, int64_t gae_workspace_bytes, float gamma,
+                                      float lambda_gae, int use_v_trace, void *stream)
 {
     RfArgs g{};
     int rc = rf_fill(g, "erl_rollout_synenv_f32", actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, N, H,
                      noise, seed, counter0, reward_scale, out_states, out_actions, out_logprobs, out_rewards, out_undones, out_unmasks,
-                     out_values, out_next_value);
+                     out_values, out_next_value, out_last_state, out_advantages, out_reward_sums, gae_stats, gae_workspace,
+                     gae_workspace_bytes, gamma, lambda_gae, use_v_trace);
     if (rc) return rc;
     ERL_REQUIRE(env_state && Ws && Wa && step_count && episode && max_step >= 1, "erl_rollout_synenv_f32: bad environment argument");
     g.env_state = env_state; g.Ws = Ws; g.Wa = Wa; g.step_count = step_count; g.episode = episode;
@@ -598,12 +707,15 @@ extern "C" int erl_rollout_pendulum_f32(const float *actor_params, const float *
                                         int64_t H, const float *noise, uint64_t seed, uint64_t counter0, float reward_scale,
                                         float *out_states, float *out_actions, float *out_logprobs, float *out_rewards,
                                         uint8_t *out_undones, uint8_t *out_unmasks, float *out_values, float *out_next_value,
-                                        void *stream)
+                                        float *out_last_state, float *out_advantages, float *out_reward_sums, double *gae_stats,
+                                        double *gae_workspace, int64_t gae_workspace_bytes, float gamma, float lambda_gae,
+                                        int use_v_trace, void *stream)
 {
     RfArgs g{};
     int rc = rf_fill(g, "erl_rollout_pendulum_f32", actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, 3, h1, h2, 1, N, H,
                      noise, seed, counter0, reward_scale, out_states, out_actions, out_logprobs, out_rewards, out_undones, out_unmasks,
-                     out_values, out_next_value);
+                     out_values, out_next_value, out_last_state, out_advantages, out_reward_sums, gae_stats, gae_workspace,
+                     gae_workspace_bytes, gamma, lambda_gae, use_v_trace);
     if (rc) return rc;
     ERL_REQUIRE(phys && obs && step_count && episode && max_step >= 1, "erl_rollout_pendulum_f32: bad environment argument");
     g.env_state = obs; g.phys = phys; g.step_count = step_count; g.episode = episode;

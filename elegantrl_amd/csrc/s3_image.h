@@ -60,7 +60,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                             const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
-                            void *stream);
+                            const double *adv_stats, void *stream);
 int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
                                       const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
                                       float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, const uint32_t *poison,

@@ -19,6 +19,18 @@ from .. import _hip
 TEN = th.Tensor
 
 
+def _epilogue_args(epilogue):
+    """the nine epilogue arguments of erl_rollout_*_f32 from (last_state_out, advantages, reward_sums, stats, workspace, gamma,
+    lambda_gae, use_v_trace); all-NULL when there is none"""
+    if epilogue is None:
+        return None, None, None, None, None, 0, 0.0, 0.0, 0
+    last, adv, ret, stats, ws, gamma, lam, vtrace = epilogue
+    p = _hip.ptr
+    return (None if last is None else p(last, th.float32), None if adv is None else p(adv, th.float32),
+            None if ret is None else p(ret, th.float32), None if stats is None else p(stats, th.float64),
+            None if ws is None else p(ws, th.float64), 0 if ws is None else ws.numel() * 8, float(gamma), float(lam), int(bool(vtrace)))
+
+
 class _GpuVecEnv:
     env_name = "GpuVecEnv"
     if_discrete = False
@@ -35,6 +47,9 @@ class _GpuVecEnv:
         self._reward = th.zeros(num_envs, dtype=th.float32, device=dev)
         self._terminal = th.zeros(num_envs, dtype=th.bool, device=dev)
         self._truncate = th.zeros(num_envs, dtype=th.bool, device=dev)
+        # bumped whenever the live state changes (reset, any step): lets an agent that rolled this env out know whether its own
+        # copy of the last state still IS the env's live state (AgentPPO._explore_vec_env skips the copy-back then)
+        self.state_epoch = 0
 
     @_hip.on_device
     def step(self, action: TEN) -> Tuple[TEN, TEN, TEN, TEN, dict]:
@@ -60,6 +75,7 @@ class SynVecEnv(_GpuVecEnv):
         self.state = th.zeros((num_envs, state_dim), dtype=th.float32, device=self.device)
 
     def reset(self) -> Tuple[TEN, dict]:
+        self.state_epoch += 1
         g = th.Generator(device=self.device).manual_seed(self.seed)
         self.state = th.randn((self.num_envs, self.state_dim), device=self.device, generator=g)
         self.step_count.zero_()
@@ -68,6 +84,7 @@ class SynVecEnv(_GpuVecEnv):
 
     def step_into(self, action: TEN, reward_row: TEN, terminal_row: TEN, truncate_row: TEN) -> TEN:
         from .. import ops
+        self.state_epoch += 1
         ops.synenv_step(self.state, action, self.Ws, self.Wa, self.step_count, self.episode, reward_row, terminal_row,
                         truncate_row, self.max_step, self.seed)
         return self.state
@@ -81,16 +98,20 @@ class SynVecEnv(_GpuVecEnv):
         n, s, a, ms, seed = self.num_envs, self.state_dim, self.action_dim, self.max_step, self.seed & (2 ** 64 - 1)
 
         def step(action_ptr, reward_ptr, terminal_ptr, truncate_ptr, stream):
+            self.state_epoch += 1
             rc = fn(st, action_ptr, ws, wa, sc, ep, reward_ptr, terminal_ptr, truncate_ptr, n, s, a, ms, seed, stream)
             if rc:
                 _hip.check(rc, "erl_synenv_step_f32")
         return step
 
 
-    def fused_rollout(self, agent, horizon_len: int, noise, bufs, values, next_value) -> None:
+    def fused_rollout(self, agent, horizon_len: int, noise, bufs, values, next_value, epilogue=None) -> None:
         """all `horizon_len` steps of AgentPPO._explore_vec_env in ONE launch (erl_rollout_synenv_f32); `bufs` = (states,
-        actions, logprobs, rewards, undones, unmasks) time-major, written in place; the env's state / counters advance."""
+        actions, logprobs, rewards, undones, unmasks) time-major, written in place; the env's state / counters advance.
+        `epilogue` = (last_state_out, advantages, reward_sums, stats, workspace, gamma, lambda_gae, use_v_trace) or None: the
+        kernel's optional tail (include/erl_hip.h): the agent's own copy of the final state, get_advantages + its statistics."""
         from .. import _hip
+        self.state_epoch += 1
         p, f32 = _hip.ptr, th.float32
         a, c = agent._act, agent.cri
         states, actions, logprobs, rewards, undones, unmasks = bufs
@@ -102,7 +123,7 @@ class SynVecEnv(_GpuVecEnv):
             self.seed & (2 ** 64 - 1), self.num_envs, horizon_len, p(noise, f32), agent.rng_seed & (2 ** 64 - 1),
             agent.rng_counter & (2 ** 64 - 1), float(agent.reward_scale), p(states, f32), p(actions, f32), p(logprobs, f32),
             p(rewards, f32), _hip.flag_ptr(undones), _hip.flag_ptr(unmasks), p(values, f32), p(next_value, f32),
-            _hip.stream_ptr()), "erl_rollout_synenv_f32")
+            *_epilogue_args(epilogue), _hip.stream_ptr()), "erl_rollout_synenv_f32")
 
 
 class PendulumVecEnv(_GpuVecEnv):
@@ -116,6 +137,7 @@ class PendulumVecEnv(_GpuVecEnv):
         self.state = th.zeros((num_envs, 3), dtype=th.float32, device=self.device)
 
     def reset(self) -> Tuple[TEN, dict]:
+        self.state_epoch += 1
         g = th.Generator(device=self.device).manual_seed(self.seed)
         u = th.rand((self.num_envs, 2), device=self.device, generator=g) * 2 - 1
         self.phys = th.stack((u[:, 0] * math.pi, u[:, 1]), dim=1).contiguous()
@@ -126,6 +148,7 @@ class PendulumVecEnv(_GpuVecEnv):
 
     def step_into(self, action: TEN, reward_row: TEN, terminal_row: TEN, truncate_row: TEN) -> TEN:
         from .. import ops
+        self.state_epoch += 1
         ops.pendulum_step(self.phys, self.state, action, self.step_count, self.episode, reward_row, terminal_row,
                           truncate_row, self.max_step, self.seed)
         return self.state
@@ -137,15 +160,18 @@ class PendulumVecEnv(_GpuVecEnv):
         n, ms, seed = self.num_envs, self.max_step, self.seed & (2 ** 64 - 1)
 
         def step(action_ptr, reward_ptr, terminal_ptr, truncate_ptr, stream):
+            self.state_epoch += 1
             rc = fn(ph, ob, action_ptr, sc, ep, reward_ptr, terminal_ptr, truncate_ptr, n, ms, seed, stream)
             if rc:
                 _hip.check(rc, "erl_pendulum_step_f32")
         return step
 
 
-    def fused_rollout(self, agent, horizon_len: int, noise, bufs, values, next_value) -> None:
-        """all `horizon_len` steps of AgentPPO._explore_vec_env in ONE launch (erl_rollout_pendulum_f32)."""
+    def fused_rollout(self, agent, horizon_len: int, noise, bufs, values, next_value, epilogue=None) -> None:
+        """all `horizon_len` steps of AgentPPO._explore_vec_env in ONE launch (erl_rollout_pendulum_f32); `epilogue` as
+        SynVecEnv.fused_rollout."""
         from .. import _hip
+        self.state_epoch += 1
         p, f32 = _hip.ptr, th.float32
         a, c = agent._act, agent.cri
         states, actions, logprobs, rewards, undones, unmasks = bufs
@@ -156,8 +182,8 @@ class PendulumVecEnv(_GpuVecEnv):
             p(self.step_count, th.int32), p(self.episode, th.int32), self.max_step, self.seed & (2 ** 64 - 1), self.num_envs,
             horizon_len, p(noise, f32), agent.rng_seed & (2 ** 64 - 1), agent.rng_counter & (2 ** 64 - 1),
             float(agent.reward_scale), p(states, f32), p(actions, f32), p(logprobs, f32), p(rewards, f32),
-            _hip.flag_ptr(undones), _hip.flag_ptr(unmasks), p(values, f32), p(next_value, f32), _hip.stream_ptr()),
-            "erl_rollout_pendulum_f32")
+            _hip.flag_ptr(undones), _hip.flag_ptr(unmasks), p(values, f32), p(next_value, f32), *_epilogue_args(epilogue),
+            _hip.stream_ptr()), "erl_rollout_pendulum_f32")
 
 
 class CartPoleVecEnv:

@@ -400,9 +400,11 @@ def reduce_clip_adam_grid_ok(stride: int) -> bool:
 def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int,
                h1: int, h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
                ids: TEN, ratio_clip: float, lambda_entropy: float, slabs: TEN, grads: TEN, first_step: int, lr: float,
-               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8, comm=None, objective: int = 0) -> None:
+               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8, comm=None, objective: int = 0, adv_stats: Optional[TEN] = None) -> None:
     """the whole minibatch loop of AgentPPO.update_net in one C call; ids: (update_times, B).  `comm` (a
-    parallel.RcclComm) puts the gradient all-reduce inside the loop, on the same stream (data-parallel ranks)."""
+    parallel.RcclComm) puts the gradient all-reduce inside the loop, on the same stream (data-parallel ranks).
+    `adv_stats` (8 float64: the raw sums left by gae_scan(stats=...) or the rollout's epilogue): `advantages` are then RAW
+    and every minibatch kernel normalises them at its row load (AgentPPO.py:149) instead of a separate launch."""
     H, N = states.shape[0], states.shape[1]
     update_times, B = ids.shape
     assert grads.shape[0] >= update_times and slabs.shape[0] == ppo_num_slabs(B)
@@ -412,7 +414,8 @@ def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, ac
                                       ptr(advantages, th.float32), ptr(reward_sums, th.float32), H, N, ptr(ids, th.int64), B,
                                       update_times, ratio_clip, lambda_entropy, int(objective), ptr(slabs, th.float32),
                                       ptr(grads, th.float32),
-                                      first_step, lr, betas[0], betas[1], eps, max_norm, None if comm is None else comm.handle,
+                                      first_step, lr, betas[0], betas[1], eps, max_norm,
+                                      None if adv_stats is None else ptr(adv_stats, th.float64), None if comm is None else comm.handle,
                                       stream_ptr()),
           "erl_ppo_update_dp_f32")
 

@@ -217,22 +217,35 @@ ERL_API int erl_rollout_step_f32(const float *actor_params, const float *state_a
  * erl_rollout_step_f32 calls would use -- and every step's arithmetic is that of erl_rollout_step_f32 (N <= 16384 form) +
  * erl_synenv_step_f32 / erl_pendulum_step_f32, so the six rollout buffers come out bit-identical to the per-step path.
  * The env's live state / counters are read at entry and written back at exit.  Needs erl_rollout_fused_supported(...):
- * state_dim <= 64 on top of the K1 constraints. */
+ * state_dim <= 64 on top of the K1 constraints.
+ * Epilogue (round 4; each output may be NULL): out_last_state (N, S) = a copy of the final state for `agent.last_state`
+ * (AgentPPO.py:125: a tensor of the agent's own, not the env's live buffer); out_advantages / out_reward_sums (H, N) +
+ * gae_stats (8 doubles) = AgentPPO.get_advantages (:207-232), reward_sums (:146) and the raw sums of the advantage
+ * normalisation (:149) over the rollout just written -- exactly erl_gae_scan_f32(EXACT, STATS)'s outputs except that the
+ * caller's rewards / undones are left as explore_env returns them (the truncation fix-up of get_advantages is applied by
+ * erl_ppo_finish_f32).  The advantages are RAW: erl_ppo_update_dp_f32(adv_stats = gae_stats) normalises them at its row
+ * loads.  They need out_values, out_next_value and gae_workspace (erl_rollout_gae_workspace_bytes(N) bytes, zero before the
+ * first launch; the kernel leaves it zero-countered).  gamma / lambda_gae / use_v_trace as erl_gae_scan_f32. */
 ERL_API int erl_rollout_fused_supported(int S, int h1, int h2, int A);
+ERL_API int64_t erl_rollout_gae_workspace_bytes(int64_t N);
 ERL_API int erl_rollout_synenv_f32(const float *actor_params, const float *critic_params, const float *act_avg,
                            const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
                            float *env_state, const float *Ws, const float *Wa, int32_t *step_count, int32_t *episode,
                            int max_step, uint64_t env_seed, int64_t N, int64_t H, const float *noise, uint64_t seed,
                            uint64_t counter0, float reward_scale, float *out_states, float *out_actions,
                            float *out_logprobs, float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks,
-                           float *out_values, float *out_next_value, void *stream);
+                           float *out_values, float *out_next_value, float *out_last_state, float *out_advantages,
+                           float *out_reward_sums, double *gae_stats, double *gae_workspace, int64_t gae_workspace_bytes,
+                           float gamma, float lambda_gae, int use_v_trace, void *stream);
 ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *critic_params, const float *act_avg,
                              const float *act_std, const float *cri_avg, const float *cri_std, int h1, int h2, float *phys,
                              float *obs, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N,
                              int64_t H, const float *noise, uint64_t seed, uint64_t counter0, float reward_scale,
                              float *out_states, float *out_actions, float *out_logprobs, float *out_rewards,
                              uint8_t *out_undones, uint8_t *out_unmasks, float *out_values, float *out_next_value,
-                             void *stream);
+                             float *out_last_state, float *out_advantages, float *out_reward_sums, double *gae_stats,
+                             double *gae_workspace, int64_t gae_workspace_bytes, float gamma, float lambda_gae,
+                             int use_v_trace, void *stream);
 
 /* K6  one PPO minibatch: gather (K5 indices) + critic fwd/bwd + actor fwd/bwd, both networks in one
  * launch.  Replaces AgentPPO.update_objectives up to (not including) the two optimizer steps
@@ -319,6 +332,12 @@ ERL_API int erl_comm_clip_adam_partials_f32(void *comm, float *params, const flo
  * grad_rows[k][offset + j] (the logged values K6 leaves behind the gradient; offset = Pa + Pc), one launch. */
 ERL_API int erl_ppo_logs_mean_f32(const float *grad_rows, int64_t stride, int64_t offset, int n_rows, float scale, float *out3,
                           void *stream);
+/* ... and, in the same launch, the side effect AgentPPO.get_advantages has on the caller's buffers (AgentPPO.py:211-214):
+ * rewards[~unmasks] += values[~unmasks]; undones[~unmasks] = False over `total` = H * N elements.  The last launch of
+ * update_net when the advantages came from the rollout's epilogue (which leaves rewards / undones untouched). */
+ERL_API int erl_ppo_finish_f32(const float *grad_rows, int64_t stride, int64_t offset, int n_rows, float scale, float *out3,
+                       float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values, int64_t total,
+                       void *stream);
 
 /* erl_grad_reduce_f32 + erl_clip_adam_f32 in ONE launch (host step only), for loops with nothing between the two: the same
  * gradient bit for bit (same summation order), written to flat_grad; the workgroup that finishes last derives the clip
@@ -398,14 +417,18 @@ ERL_API int erl_comm_reduce_exchange_f32(void *comm, const float *slabs, int n_s
 /* erl_ppo_update_f32 with the gradient all-reduce in the loop: ppo_step -> grad_reduce -> all-reduce(grads[k]) ->
  * clip_adam(grad_scale = 1/world), as the two launches erl_comm_reduce_exchange_f32 + erl_clip_adam_partials_f32.
  * comm == NULL degenerates to the single-process loop.  Every rank must call it with
- * the same update_times; ids are this rank's own minibatch indices into its own rollout shard. */
+ * the same update_times; ids are this rank's own minibatch indices into its own rollout shard.
+ * adv_stats: NULL when `advantages` are normalised already (erl_adv_normalize_f32); else the 8-double block of raw sums
+ * (erl_gae_scan_f32 / the rollout epilogue, all-reduced under data parallelism) and `advantages` are RAW: every minibatch
+ * kernel applies (adv - mean) / (std(adv[::4, ::4]) + 1e-5) (AgentPPO.py:149) at its row load, in erl_adv_normalize_f32's
+ * arithmetic -- one launch less per update. */
 ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg,
                           const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
                           const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
                           const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
                           int64_t B, int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs,
                           float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
-                          float max_norm, void *comm, void *stream);
+                          float max_norm, const double *adv_stats, void *comm, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic-shape path: build_mlp([S, d1, ..., dL, out]) with ANY number (<= ERL_MAX_LAYERS) and width of hidden layers

@@ -546,6 +546,8 @@ if __name__ == "__main__":
         for name in only:
             if name == "sac_fit_cum_r":
                 make_sac("fit_cum_r", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=22, lambda_fit=0.3)
+            elif name == "ppo_c4shape":
+                make_ppo("c4shape", N=64, S=64, A=8, H=16, net_dims=(128, 128), batch_size=256, repeat_times=32.0, use_v_trace=True, seed=14)
             elif name == "a2c":
                 make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)
                 make_a2c("mid", S=64, A=8, H=48, net_dims=(128, 128), batch_size=32, repeat_times=2.0, seed=42)
@@ -558,6 +560,8 @@ if __name__ == "__main__":
              use_v_trace=False, seed=12)
     make_ppo("mid_vtrace", N=40, S=17, A=5, H=20, net_dims=(128, 128), batch_size=64, repeat_times=6.4,
              use_v_trace=True, seed=13)
+    # the benchmark's own kernel instance (S = 64, A = 8, net [128,128], 16-byte-aligned rows): two minibatches of 256 out of 16 x 64
+    make_ppo("c4shape", N=64, S=64, A=8, H=16, net_dims=(128, 128), batch_size=256, repeat_times=32.0, use_v_trace=True, seed=14)
     make_replay()
     make_replay_discrete()
     make_sac("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=21)

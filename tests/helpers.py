@@ -35,7 +35,7 @@ def dims(g):
     return dict(N=N, S=S, A=A, H=H, B=B, n_upd=n_upd, vtrace=bool(vtrace), h1=h1, h2=h2)
 
 
-PPO_GOLDENS = ["ppo_small_vtrace.npz", "ppo_small_alt.npz", "ppo_mid_vtrace.npz"]
+PPO_GOLDENS = ["ppo_small_vtrace.npz", "ppo_small_alt.npz", "ppo_mid_vtrace.npz", "ppo_c4shape.npz"]
 
 
 # ---- toy envs + actor for the evaluator format fixture (oracle/make_golden.py:make_evaluator and tests/test_evaluator_cpu.py)

@@ -137,3 +137,81 @@ def test_fused_rollout_rejects_what_it_cannot_run():
     agent, env, _ = _make("syn", 64, 100, 4, (128, 128), 10, True)
     items = agent.explore_env(env, 4)
     assert agent._rollout_cache is None and items[0].shape == (4, 64, 100)
+
+
+# ---- the rollout's epilogue (round 4): the agent's own last_state, get_advantages + its statistics in the same launch ---------
+@pytest.mark.parametrize("kind,N,S,A,net,max_step,H,scale", CASES)
+@pytest.mark.parametrize("vtrace", [True, False], ids=["vtrace", "alt"])
+def test_rollout_epilogue_is_the_exact_gae_scan(kind, N, S, A, net, max_step, H, scale, vtrace):
+    """advantages / reward sums left by the persistent rollout == erl_gae_scan_f32(EXACT) on the same buffers BIT FOR BIT (the
+    scan shares its step with gae.hip: csrc/gae_step.h), the five raw sums agree to fp64 rounding, the caller's rewards / undones
+    come back as explore_env returns them in the reference (untouched), and last_state is a tensor of the agent's own."""
+    from elegantrl_amd import ops
+    agent, env, _ = _make(kind, N, S, A, net, max_step, True, scale)
+    agent.if_use_v_trace = vtrace
+    for it in range(2):
+        items = agent._explore_vec_env(env, H)
+        states, actions, logprobs, rewards, undones, unmasks = items
+        c = agent._rollout_cache
+        assert c is not None and "adv" in c
+        assert agent.last_state.data_ptr() != env.state.data_ptr() and th.equal(agent.last_state, env.state)
+        r0, u0 = rewards.clone(), undones.clone()
+        stats = th.zeros(8, dtype=th.float64, device=DEV)
+        adv, ret = ops.gae_scan(rewards.clone(), undones.clone(), unmasks, c["values"], c["next_value"], float(agent.gamma),
+                                float(agent.lambda_gae_adv), use_v_trace=vtrace, mutate=True, algo="exact", stats=stats)
+        assert th.equal(c["adv"], adv), f"advantages differ in {(c['adv'] != adv).sum().item()} elements"
+        assert th.equal(c["ret"], ret)
+        assert th.equal(rewards, r0) and th.equal(undones, u0)            # explore_env's outputs are not mutated by the epilogue
+        np.testing.assert_allclose(c["stats"].cpu().numpy()[:5], stats.cpu().numpy()[:5], rtol=1e-12, atol=1e-9)
+        if max_step < H:
+            assert (~unmasks).any()
+    # a second launch finds the arrival counter back at zero (the statistics were folded exactly once per launch)
+    assert float(agent._gae_ws[-1].view(th.int64)) == 0
+
+
+def test_update_net_with_the_rollout_epilogue_matches_the_separate_launches():
+    """one iteration with args.fused_gae on and off (same weights, noise, minibatch ids): the buffers leave update_net with
+    get_advantages' side effect applied either way (rewards[trunc] += values[trunc], undones[trunc] = False: bitwise), objectives
+    and weights agree to the last bits the statistics' summation order can move."""
+    N, S, A, H, B = 1024, 64, 8, 16, 4096
+    out = {}
+    for fused_gae in (True, False):
+        agent, env, _ = _make("syn", N, S, A, (128, 128), 6, True)
+        agent.fused_gae = fused_gae
+        agent.batch_size, agent.repeat_times = B, 3 * B / H
+        g = th.Generator(device=DEV).manual_seed(2)
+        noise = th.randn((H, N, A), device=DEV, generator=g)
+        ids = th.randint(H * N, (3, B), device=DEV, generator=g)
+        items = agent._explore_vec_env(env, H, noise=noise)
+        assert ("adv" in agent._rollout_cache) == fused_gae
+        raw = [x.clone() for x in items]
+        objs = agent.update_net(list(items), ids=ids)
+        out[fused_gae] = (raw, [x.clone() for x in items], objs, agent._flat.clone())
+    (raw_f, after_f, objs_f, w_f), (raw_s, after_s, objs_s, w_s) = out[True], out[False]
+    for a, b in zip(raw_f, raw_s):
+        assert th.equal(a, b)
+    assert (~raw_f[5]).any()                                                # truncations present
+    assert not th.equal(after_f[3], raw_f[3]) and not th.equal(after_f[4], raw_f[4])     # the side effect happened ...
+    for a, b in zip(after_f, after_s):
+        assert th.equal(a, b)                                               # ... identically on both paths
+    np.testing.assert_allclose(objs_f, objs_s, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(w_f.cpu().numpy(), w_s.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_last_state_copy_back_is_skipped_only_while_both_sides_are_untouched():
+    """agent.last_state is the rollout kernel's own copy; the next explore_env copies it into the env's live buffer only if
+    somebody changed either side in between (AgentPPO._last_state_token)."""
+    agent, env, _ = _make("syn", 256, 64, 8, (128, 128), 50, True)
+    agent.explore_env(env, 4)
+    assert agent._last_state_token is not None
+    ls = agent.last_state
+    with th.no_grad():
+        ls.add_(1.0)                                       # the caller edits its last_state in place: must reach the env
+    items = agent.explore_env(env, 2)
+    assert th.equal(items[0][0], ls)                        # the rollout started from the edited state
+    agent.last_state = th.zeros_like(agent.last_state)     # run.py-style assignment of another tensor
+    items = agent.explore_env(env, 2)
+    assert float(items[0][0].abs().max()) == 0.0
+    e0 = env.state_epoch
+    agent.explore_env(env, 2)
+    assert env.state_epoch == e0 + 1                       # only the rollout itself moved the env: no copy-back in between
