@@ -119,32 +119,52 @@ extern "C" int erl_mlpn_rollout_step_discrete_f32(const float *actor_params, con
 // One PPO minibatch for networks of any depth: writes the summed gradient [actor | critic | logs(4)] to flat_grad.
 namespace {
 
-// a library-owned second stream per device (non-blocking) with the two events that fork it from / join it into the caller's
-// stream; NULL when ERL_MLPN_STREAMS=1 or the runtime refuses (then everything stays on the caller's stream)
+// a library-owned second stream per (device, caller stream) (non-blocking) with the two events that fork it from / join it into
+// the caller's stream; NULL when ERL_MLPN_STREAMS=1 or the runtime refuses (then everything stays on the caller's stream)
 struct SideStream {
+    int device = -1;
+    hipStream_t owner = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false;
 };
-static SideStream g_side[32];
+static SideStream g_side[16];
 
-SideStream *side_stream()
+SideStream *side_stream(hipStream_t owner)
 {
     static const bool off = [] { const char *e = getenv("ERL_MLPN_STREAMS"); return e && atoi(e) == 1; }();
     int dev = -1;
-    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    SideStream &q = g_side[dev];
-    if (!q.tried) {
-        q.tried = true;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    for (auto &q : g_side)
+        if (q.stream && q.device == dev && q.owner == owner) return &q;
+    for (auto &q : g_side) {
+        if (q.stream) continue;
         if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             q.stream = nullptr;
+            return nullptr;
+        }
+        q.device = dev;
+        q.owner = owner;
+        return &q;
+    }
+    return nullptr;
+}
+
+// every exit path after the fork joins the side stream back into the caller's
+struct SideJoin {
+    SideStream *side;
+    hipStream_t s;
+    bool armed = false;
+    ~SideJoin()
+    {
+        if (armed && side) {
+            (void)hipEventRecord(side->join, side->stream);
+            (void)hipStreamWaitEvent(s, side->join, 0);
         }
     }
-    return q.stream ? &q : nullptr;
-}
+};
 
 int ppo_step_impl(const char *what, bool discrete, const float *actor_params, const float *critic_params, const float *act_avg,
                   const float *act_std, const float *cri_avg, const float *cri_std, const int *actor_dims, int n_dims,
@@ -178,11 +198,13 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
     // interpreter-free but still finite (~4 us per launch) enqueue of the other.  ERL_MLPN_STREAMS=1 keeps everything on the
     // caller's stream.
     hipStream_t s1 = s;
-    SideStream *side = side_stream();
+    SideStream *side = side_stream(s);
+    SideJoin joiner{side, s};
     if (side) {
         if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
         if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
         s1 = side->stream;
+        joiner.armed = true;
     }
     const int64_t half = (workspace_bytes / 2) & ~(int64_t)255;
     struct NetState {
@@ -245,6 +267,7 @@ int ppo_step_impl(const char *what, bool discrete, const float *actor_params, co
     if (side) {
         if ((rc = erl_hip_status(hipEventRecord(side->join, s1), "hipEventRecord(join)"))) return rc;
         if ((rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
+        joiner.armed = false;
     }
     return erl_hip_status(hipGetLastError(), what);
 }

@@ -179,13 +179,11 @@ __global__ __launch_bounds__(256) void alpha_step_kernel(const float *__restrict
     const float total_norm = (float)sqrt((double)g * (double)g);
     float coef = max_norm / (total_norm + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
-    const float gx = g * (1.0f * coef);
-    const float a = m1[0] * beta1 + (1.f - beta1) * gx;
-    const float b = m2[0] * beta2 + (1.f - beta2) * (gx * gx);
-    m1[0] = a;
-    m2[0] = b;
-    const float denom = sqrtf(b) / bc2_sqrt + eps;
-    alpha_log[0] = alpha_log[0] - step_size * (a / denom);
+    float e_m1 = m1[0], e_m2 = m2[0], e_p = alpha_log[0];
+    erl_adam_update(erl_mul_rn(g, erl_mul_rn(1.0f, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);   // the library's one Adam
+    m1[0] = e_m1;
+    m2[0] = e_m2;
+    alpha_log[0] = e_p;
 }
 
 __global__ __launch_bounds__(256) void fillk_kernel(float *__restrict__ p, float v, int64_t n)

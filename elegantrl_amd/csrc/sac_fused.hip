@@ -801,13 +801,11 @@ __global__ __launch_bounds__(256) void alpha_step_fused_kernel(const float *__re
     const float total_norm = (float)sqrt((double)gr * (double)gr);
     float coef = max_norm / (total_norm + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
-    const float gx = gr * (1.0f * coef);
-    const float a = m1[0] * beta1 + (1.f - beta1) * gx;
-    const float b = m2[0] * beta2 + (1.f - beta2) * (gx * gx);
-    m1[0] = a;
-    m2[0] = b;
-    const float denom = sqrtf(b) / bc2_sqrt + eps;
-    alpha_log[0] = alpha_log[0] - step_size * (a / denom);
+    float e_m1 = m1[0], e_m2 = m2[0], e_p = alpha_log[0];
+    erl_adam_update(erl_mul_rn(gr, erl_mul_rn(1.0f, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);   // the library's one Adam
+    m1[0] = e_m1;
+    m2[0] = e_m2;
+    alpha_log[0] = e_p;
 }
 
 int wclass(int width) { return width <= 64 ? 0 : (width <= 128 ? 1 : 2); }
@@ -816,29 +814,52 @@ int wclass(int width) { return width <= 64 ? 0 : (width <= 128 ? 1 : 2); }
 // policy-gradient sample (actor forward on `state`) and the temperature step depend on nothing the critic update produces, so they
 // run NEXT TO it (ERL_SAC_STREAMS=1 keeps everything on the caller's stream)
 struct SacSide {
+    int device = -1;
+    hipStream_t owner = nullptr;          // the caller's stream this side stream serves
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false;
 };
-SacSide g_sac_side[32];
+SacSide g_sac_side[16];
 
-SacSide *sac_side_stream()
+// one side stream + event pair per (device, caller stream): two agents on different streams of one device never record each
+// other's events
+SacSide *sac_side_stream(hipStream_t owner)
 {
     static const bool off = [] { const char *e = getenv("ERL_SAC_STREAMS"); return e && atoi(e) == 1; }();
     int dev = -1;
-    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    SacSide &q = g_sac_side[dev];
-    if (!q.tried) {
-        q.tried = true;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    for (auto &q : g_sac_side)
+        if (q.stream && q.device == dev && q.owner == owner) return &q;
+    for (auto &q : g_sac_side) {
+        if (q.stream) continue;
         if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             q.stream = nullptr;
+            return nullptr;
+        }
+        q.device = dev;
+        q.owner = owner;
+        return &q;
+    }
+    return nullptr;                          // every slot taken: run on the caller's stream
+}
+
+// after the fork every exit path must bring the side stream's work back under the caller's stream (an early error return would
+// otherwise leave kernels running on the shared workspace while the caller moves on)
+struct SacJoin {
+    SacSide *side;
+    hipStream_t s;
+    bool armed = false;
+    ~SacJoin()
+    {
+        if (armed && side) {
+            (void)hipEventRecord(side->join, side->stream);
+            (void)hipStreamWaitEvent(s, side->join, 0);
         }
     }
-    return q.stream ? &q : nullptr;
-}
+};
 
 }  // namespace
 
@@ -919,11 +940,13 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     // ---- (6) policy-gradient sample (actor on state, kept for the backward pass) and temperature step              (:72-79)
     // FORKED here onto the side stream: they read the actor, `state` and alpha_log only -- the temperature BEFORE its update
     // is already parked in alpha0 by launch (1) -- and run next to the critic update (2)-(5); joined before (7).
-    SacSide *side = sac_side_stream();
+    SacSide *side = sac_side_stream(s);
+    SacJoin joiner{side, s};
     if (side) {
         if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
         if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
         sa = side->stream;
+        joiner.armed = true;
     }
     {
         ActorFwdArgs af2 = af;
@@ -973,6 +996,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     }
     // ---- (7) TARGET ensemble on (state, action_pg): q and d(mean q)/d(action); finishes the critic objective    (:82-83)
     if (side && (rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
+    joiner.armed = false;
     ca.P = target_params; ca.Xs = state; ca.Xa = act_pg; ca.q = q_pg;
     ca.dAct = dAct; ca.qpart = qpart; ca.qc = qc; ca.label_in = label; ca.td_out = td_error_out; ca.tdpart = tdpart;
     FUSED_KT_DISPATCH(LAUNCH_CRITIC2)
