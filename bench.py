@@ -177,6 +177,29 @@ def rocprof_kernel_us(kernel):
         return None, src
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """ONE JSON line on stdout is the contract: libraries that print to the C-level stdout (RCCL's version banner at communicator
+    creation, flushed at exit, i.e. AFTER the line) must not end up there.  File descriptor 1 is pointed at stderr for the whole run;
+    the result line is written to the saved descriptor by emit()."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: dict):
+    data = (json.dumps(line) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -316,7 +339,7 @@ def bench_sac(opt):
     if not opt.no_cpu_baseline:
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
         line["cpu_baseline"] = cpu_baseline_subprocess(max(2, opt.cpu_iters // 2), "c3")
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 def main():
@@ -337,8 +360,9 @@ def main():
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
                          "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs")
     opt = ap.parse_args()
+    claim_stdout()
     if opt.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(opt.cpu_iters, opt.config)), flush=True)
+        emit(cpu_baseline(opt.cpu_iters, opt.config))
         return
     if opt.config == "c3":
         return bench_sac(opt)
@@ -555,7 +579,7 @@ def main():
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
         line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else max(2, opt.cpu_iters // 4), opt.config)
     log("done")
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 if __name__ == "__main__":

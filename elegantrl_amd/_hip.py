@@ -39,6 +39,8 @@ _SIGNATURES = {
     "erl_cum_rewards_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, _P]),
     "erl_adv_stats_f32": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P]),
     "erl_adv_normalize_f32": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
+    "erl_adv_stats_fold_f32": (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
+    "erl_rollout_gae_partials": (c_int, [c_int64]),
     "erl_split_ids_i64": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
     "erl_ppo_gather_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P, c_int64,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -103,7 +105,7 @@ _SIGNATURES = {
     "erl_comm_p2p_set_spin": (c_int, [_P, ctypes.c_uint32]),
     "erl_ppo_update_dp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
                                       _P, c_int64, c_int, c_float, c_float, c_int, _P, _P, c_int32, c_float, c_float, c_float,
-                                      c_float, c_float, _P, _P, _P]),
+                                      c_float, c_float, _P, _P, c_int, _P, _P]),
     "erl_mlpn_param_count": (c_int64, [POINTER(c_int), c_int, c_int]),
     "erl_mlpn_workspace_bytes": (c_int64, [POINTER(c_int), c_int, c_int64, c_int]),
     "erl_mlpn_value_forward_f32": (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, c_int64, _P, _P, c_int64, _P]),

@@ -143,7 +143,6 @@ class AgentPPO(AgentBase):
         # args.fused_gae = False / ERL_FUSED_GAE=0 keeps them in update_net (A/B runs, parity tests)
         import os as _os
         self.fused_gae = bool(getattr(args, "fused_gae", _os.environ.get("ERL_FUSED_GAE", "1") != "0"))
-        self._gae_ws = None
         self._last_state_token = None
         self.ppo_arith = str(getattr(args, "ppo_arith", "auto"))
         assert self.ppo_arith in ("auto", "f32", "split"), f"args.ppo_arith = {self.ppo_arith!r}"
@@ -271,7 +270,8 @@ class AgentPPO(AgentBase):
         actions = th.empty((H, N, A), dtype=th.float32, device=dev)
         hn = H * N
         pitch = (hn + 255) // 256 * 256                    # every plane starts on a 256-byte boundary whatever H * N is
-        planes = th.empty((3, pitch), dtype=th.float32, device=dev)
+        # planes: logprobs | rewards | values [| raw advantages | reward sums: the fused rollout's epilogue]
+        planes = th.empty((5 if getattr(self, "fused_gae", False) else 3, pitch), dtype=th.float32, device=dev)
         logprobs, rewards = planes[0, :hn].view(H, N), planes[1, :hn].view(H, N)
         flags = th.empty((2, pitch), dtype=th.bool, device=dev)
         terminals, truncates = flags[0, :hn].view(H, N), flags[1, :hn].view(H, N)
@@ -309,14 +309,13 @@ class AgentPPO(AgentBase):
             epilogue, adv_raw, ret, stats = None, None, None, None
             last_out = th.empty((N, S), dtype=th.float32, device=dev) if self.snapshot_last_state else None
             if self.fused_gae:
-                more = th.empty((2, pitch), dtype=th.float32, device=dev)
-                adv_raw, ret = more[0, :hn].view(H, N), more[1, :hn].view(H, N)
-                stats = th.empty(8, dtype=th.float64, device=dev)
-                need = int(_hip.lib().erl_rollout_gae_workspace_bytes(N)) // 8
-                if self._gae_ws is None or self._gae_ws.numel() < need:
-                    self._gae_ws = th.zeros(need, dtype=th.float64, device=dev)
+                adv_raw, ret = planes[3, :hn].view(H, N), planes[4, :hn].view(H, N)
+                # [8 doubles: the folded sums | 3 per 16-env workgroup: the epilogue's partial sums]
+                n_parts = int(_hip.lib().erl_rollout_gae_partials(N))
+                sums = th.empty(8 + 3 * n_parts, dtype=th.float64, device=dev)
+                stats, gae_parts = sums[:8], sums[8:]
             if last_out is not None or self.fused_gae:
-                epilogue = (last_out, adv_raw, ret, stats, self._gae_ws if self.fused_gae else None, float(self.gamma),
+                epilogue = (last_out, adv_raw, ret, None, gae_parts if self.fused_gae else None, float(self.gamma),
                             float(self.lambda_gae_adv), bool(self.if_use_v_trace))
             env.fused_rollout(self, H, noise, (states, actions, logprobs, rewards, undones, unmasks), values, next_value,
                               **({} if epilogue is None else {"epilogue": epilogue}))
@@ -330,8 +329,8 @@ class AgentPPO(AgentBase):
             self._rollout_cache = dict(states=states, values=values, next_value=next_value, last_state=self.last_state,
                                        key=self._value_cache_key(states, self.last_state))
             if self.fused_gae:
-                self._rollout_cache.update(adv=adv_raw, ret=ret, stats=stats, rewards=rewards, undones=undones, unmasks=unmasks,
-                                           adv_key=self._adv_cache_key(rewards, undones, unmasks))
+                self._rollout_cache.update(adv=adv_raw, ret=ret, stats=stats, parts=gae_parts, n_parts=n_parts, rewards=rewards,
+                                           undones=undones, unmasks=unmasks, adv_key=self._adv_cache_key(rewards, undones, unmasks))
             return states, actions, logprobs, rewards, undones, unmasks
         rollout_step = ops.rollout_step if self._fused else ops.mlpn_rollout_step
         if hasattr(env, "raw_stepper") and self._fused:
@@ -442,14 +441,14 @@ class AgentPPO(AgentBase):
                 float(self.gamma), float(self.lambda_gae_adv), bool(self.if_use_v_trace))
 
     def _cached_advantages(self, rewards: TEN, undones: TEN, unmasks: TEN):
-        """(raw advantages, reward_sums, stats) computed by the fused rollout's epilogue for exactly these tensors, else None
+        """(raw advantages, reward_sums, stats block, partial sums, their count) computed by the fused rollout's epilogue for exactly these tensors, else None
         (call after _cached_values said yes)."""
         c = self._rollout_cache
         if c is None or "adv" not in c or rewards is not c["rewards"] or undones is not c["undones"] or unmasks is not c["unmasks"]:
             return None
         if c["adv_key"] != self._adv_cache_key(rewards, undones, unmasks):
             return None
-        return c["adv"], c["ret"], c["stats"]
+        return c["adv"], c["ret"], c["stats"], c["parts"], c["n_parts"]
 
     def _cached_values(self, states: TEN):
         """(values, next_value) computed by the fused rollout for exactly this buffer and this critic, else None."""
@@ -501,10 +500,13 @@ class AgentPPO(AgentBase):
         if from_rollout is not None:
             # raw advantages, reward sums and the five sums come from the rollout's epilogue; rewards / undones still are what
             # explore_env returned: get_advantages' in-place fix-up of truncated steps rides the last launch (erl_ppo_finish_f32)
-            advantages, reward_sums, stats = from_rollout
+            advantages, reward_sums, stats, adv_parts, n_parts = from_rollout
             self._stats = stats                # (the sums this update normalised with stay inspectable, as on the other path)
+            if self.world_size > 1:            # the sums are all-reduced below: fold them now (one small launch)
+                ops.adv_stats_fold(adv_parts, n_parts, H, N, stats)
+                adv_parts = None
         else:
-            stats = self._stats
+            stats, adv_parts, n_parts = self._stats, None, 0
             advantages, reward_sums = self._gae(rewards, undones, unmasks, values, stats=stats, next_value=next_value)
         if self.world_size > 1:                                                       # one normalisation for the whole job:
             if comm is not None:                                                      # the 5 sums ride the gradient's route
@@ -558,7 +560,7 @@ class AgentPPO(AgentBase):
                            c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
                            advantages, reward_sums, ids, float(self.ratio_clip), self.lambda_entropy_value, self._slabs,
                            self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm), comm=comm,
-                           objective=self._objective, adv_stats=stats)
+                           objective=self._objective, adv_stats=stats, adv_partials=adv_parts, n_partials=n_parts)
             self._adam_step += update_times
         else:                           # data parallel through torch.distributed (gloo tests, ERL_DP_COLLECTIVE=torch)
             # raw pointers + direct C-ABI calls: the interpreter spends ~3 us per launch instead of ~10 (ptr checks, views)

@@ -235,5 +235,5 @@ extern "C" int erl_ppo_update_f32(float *flat_params, float *exp_avg, float *exp
     return erl_ppo_update_dp_f32(flat_params, exp_avg, exp_avg_sq, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
                                  unmasks, logprobs, advantages, reward_sums, H, N, ids, B, update_times, ratio_clip, lambda_entropy,
                                  objective, slabs, grads, first_step, lr, beta1, beta2, eps, max_norm, /*adv_stats=*/nullptr,
-                                 /*comm=*/nullptr, stream);
+                                 /*adv_partials=*/nullptr, 0, /*comm=*/nullptr, stream);
 }

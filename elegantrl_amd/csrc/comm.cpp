@@ -195,8 +195,8 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
                                      const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                                      const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
                                      int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs, float *grads,
-                                     int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, const double *adv_stats,
-                                     void *comm, void *stream)
+                                     int32_t first_step, float lr, float beta1, float beta2, float eps, float max_norm, double *adv_stats,
+                                     const double *adv_partials, int n_partials, void *comm, void *stream)
 {
     ERL_REQUIRE(flat_params && exp_avg && exp_avg_sq && ids && slabs && grads, "erl_ppo_update_dp_f32: NULL tensor");
     ERL_REQUIRE(update_times >= 1 && first_step >= 1 && B >= 1, "erl_ppo_update_dp_f32: bad argument");
@@ -215,10 +215,17 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
     const int tail = comm ? 0 : (tail_env == 2 && !erl_reduce_clip_adam_grid_ok(stride) ? 0 : tail_env);
     // split-arithmetic minibatch kernel: its W2 images are built here once and kept current by clip + Adam (two-launch tail only)
     S3Images images{}, *im = nullptr;
+    ERL_REQUIRE(!adv_partials || (adv_stats && n_partials >= 1), "erl_ppo_update_dp_f32: adv_partials needs adv_stats and n_partials");
+    bool folded = adv_partials == nullptr;
     if (!tail && erl_ppo_arith_in_use(S, h1, h2, A) == ERL_PPO_ARITH_SPLIT) {
-        int rc = erl_s3_images_build(flat_params, S, h1, h2, A, &images, (hipStream_t)stream);
+        int rc = erl_s3_images_build(flat_params, S, h1, h2, A, &images, adv_partials, n_partials, H, N, adv_stats, (hipStream_t)stream);
         if (rc) return rc;
         im = &images;
+        folded = true;
+    }
+    if (!folded) {           // no image launch to ride: the fold is a launch of its own
+        int rc = erl_adv_stats_fold_f32(adv_partials, n_partials, H, N, adv_stats, stream);
+        if (rc) return rc;
     }
     for (int k = 0; k < update_times; ++k) {
         float *g = grads + (size_t)k * stride;

@@ -101,6 +101,31 @@ __device__ __forceinline__ T block_sum(T v, T *scratch)
     return t;
 }
 
+// the five raw sums of the advantage normalisation (elegantrl/agents/AgentPPO.py:149) from per-workgroup fp64 partials
+// [n][3] = (sum adv, sum over the [::4, ::4] subsample, sum of squares over it), folded in a fixed order by one 256-thread block:
+// adv_stats_fold_kernel (gae.hip) and the extra block of the update loop's weight-image kernel (grad_tail.hip)
+__device__ __forceinline__ void erl_adv_stats_fold_block(const double *__restrict__ partials, int nparts, int H, int N, double *__restrict__ stats,
+                                                         double *scratch)
+{
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        s0 += partials[(size_t)i * 3 + 0];
+        s1 += partials[(size_t)i * 3 + 1];
+        s2 += partials[(size_t)i * 3 + 2];
+    }
+    s0 = block_sum(s0, scratch);
+    s1 = block_sum(s1, scratch);
+    s2 = block_sum(s2, scratch);
+    if (threadIdx.x == 0) {
+        stats[0] = s0;
+        stats[1] = (double)H * (double)N;
+        stats[2] = s1;
+        stats[3] = s2;
+        stats[4] = (double)((H + 3) / 4) * (double)((N + 3) / 4);
+        stats[5] = stats[6] = stats[7] = 0.0;      // (the 8-double block is all-reduced whole under data parallelism)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // device: ONE Adam update for every optimiser kernel of the library (clip_adam_kernel, the fused tails, the long-group and the
 // partial-norm kernels): every product and sum rounded separately and spelled out, so that no kernel's code generation (fma

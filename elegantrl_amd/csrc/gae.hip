@@ -307,22 +307,7 @@ __global__ __launch_bounds__(256) void adv_stats_fold_kernel(const double *__res
                                                              int N, double *__restrict__ stats)
 {
     __shared__ double scratch[4];
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int i = threadIdx.x; i < nparts; i += 256) {
-        s0 += partials[(size_t)i * 3 + 0];
-        s1 += partials[(size_t)i * 3 + 1];
-        s2 += partials[(size_t)i * 3 + 2];
-    }
-    s0 = block_sum(s0, scratch);
-    s1 = block_sum(s1, scratch);
-    s2 = block_sum(s2, scratch);
-    if (threadIdx.x == 0) {
-        stats[0] = s0;
-        stats[1] = (double)H * (double)N;
-        stats[2] = s1;
-        stats[3] = s2;
-        stats[4] = (double)((H + 3) / 4) * (double)((N + 3) / 4);
-    }
+    erl_adv_stats_fold_block(partials, nparts, H, N, stats, scratch);
 }
 
 __global__ __launch_bounds__(256) void adv_normalize_kernel(const float *__restrict__ adv, float *__restrict__ out,
@@ -508,6 +493,13 @@ extern "C" int erl_adv_stats_f32(const float *adv, int64_t H, int64_t N, double 
     hipLaunchKernelGGL(adv_stats_fold_kernel, dim3(1), dim3(256), 0, stream, (const double *)workspace, nblk, (int)H, (int)N,
                        stats);
     ERL_LAUNCH_CHECK("erl_adv_stats_f32");
+}
+
+extern "C" int erl_adv_stats_fold_f32(const double *partials, int n_partials, int64_t H, int64_t N, double *stats, void *stream)
+{
+    ERL_REQUIRE(partials && stats && n_partials >= 1 && H >= 1 && N >= 1 && N < (1LL << 31) && H < (1LL << 31), "erl_adv_stats_fold_f32: bad argument");
+    hipLaunchKernelGGL(adv_stats_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_partials, (int)H, (int)N, stats);
+    ERL_LAUNCH_CHECK("erl_adv_stats_fold_f32");
 }
 
 extern "C" int erl_adv_normalize_f32(const float *adv, float *out, int64_t H, int64_t N, const double *stats, void *stream_)

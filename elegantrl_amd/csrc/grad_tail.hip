@@ -190,8 +190,15 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
 }
 
 // W2 and W1 images of both networks from the flat parameters [actor | critic]: one thread per image element (W1's pad columns: 0)
-__global__ __launch_bounds__(256) void s3_image_build_kernel(const float *__restrict__ params, int64_t Pa, S3Images im)
+__global__ __launch_bounds__(256) void s3_image_build_kernel(const float *__restrict__ params, int64_t Pa, S3Images im,
+                                                             const double *__restrict__ adv_partials, int n_partials, int H, int N,
+                                                             double *__restrict__ adv_stats)
 {
+    if (blockIdx.y == 2) {          // the advantage statistics' fold rides this launch (one block)
+        __shared__ double scratch[4];
+        if (blockIdx.x == 0) erl_adv_stats_fold_block(adv_partials, n_partials, H, N, adv_stats, scratch);
+        return;
+    }
     const int gi = blockIdx.y;
     const int h1 = im.net[gi].h1, S = im.net[gi].S, K1 = im.net[gi].K1;
     const float *P = params + (gi ? Pa : 0);
@@ -426,7 +433,8 @@ struct S3Slot {
 S3Slot g_s3_slots[16];
 }  // namespace
 
-int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, hipStream_t stream)
+int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, const double *adv_partials, int n_partials,
+                        int64_t H, int64_t N, double *adv_stats, hipStream_t stream)
 {
     int dev = 0;
     int rc = erl_hip_status(hipGetDevice(&dev), "hipGetDevice");
@@ -462,6 +470,7 @@ int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, 
         out->net[gi].K1 = s3_image_k1(S);
     }
     const int64_t elems = (int64_t)h1 * h2 + (int64_t)h1 * s3_image_k1(S);
-    hipLaunchKernelGGL(s3_image_build_kernel, dim3((unsigned)erl_cdiv(elems, 256), 2), dim3(256), 0, stream, flat_params, Pa, *out);
+    hipLaunchKernelGGL(s3_image_build_kernel, dim3((unsigned)erl_cdiv(elems, 256), adv_partials ? 3 : 2), dim3(256), 0, stream, flat_params, Pa, *out,
+                       adv_partials, n_partials, (int)H, (int)N, adv_stats);
     ERL_LAUNCH_CHECK("erl_s3_images_build");
 }

@@ -50,9 +50,10 @@ struct RfArgs {
     // raw advantages, reward sums, the raw sums of the advantage normalisation (erl_gae_scan_f32's `stats` block)
     float *o_last_state;
     float *o_adv, *o_ret;
-    double *gae_stats, *gae_ws;                    // ws: [3 x workgroups] fp64 partial sums, then one 64-bit arrival counter (zero between launches)
+    double *gae_stats, *gae_ws;                    // ws: [3 x workgroups] fp64 partial sums (erl_adv_stats_fold_f32 folds them into the 5 sums)
     float gamma, lam;
     int vtrace;
+    int gae_lds;                                   // 1: the epilogue's inputs are kept in LDS during the rollout (H <= kRfGaeLdsSteps)
     // environment
     float *env_state;                              // (N, S) live state (SynVecEnv.state / PendulumVecEnv.state = obs)
     float *phys;                                   // Pendulum: (N, 2) theta, theta_dot
@@ -97,6 +98,11 @@ constexpr int RF_O_WST = RF_O_W1C + 128 * RF_WLD;       // [64][RF_WLD]   Ws^T: 
 constexpr int RF_O_WAT = RF_O_WST + 64 * RF_WLD;        // [64][16]       Wa^T
 constexpr int RF_FLOATS = RF_O_WAT + 64 * 16;
 constexpr size_t kRfLdsBytes = (size_t)RF_FLOATS * sizeof(float);
+// the advantage epilogue keeps its inputs -- [t][reward | value | flags][16 envs] + the bootstrap values -- behind the layout above while
+// they fit (192 bytes per step); longer horizons read them back from the rollout buffers
+constexpr int kRfGaeLdsSteps = 128;
+constexpr size_t rf_gae_lds_bytes(int H) { return ((size_t)H * 3 + 1) * 16 * sizeof(float); }
+static_assert(kRfLdsBytes + rf_gae_lds_bytes(kRfGaeLdsSteps) <= 160 * 1024, "LDS budget of the rollout kernel with the epilogue's tile");
 
 // NS_ / N1_ / N2_: k-tiles of the state / hidden layers as compile-time constants for the tuned shapes (0 = read them from
 // the arguments): with them the step body is straight-line code between barriers, which lets the scheduler interleave the
@@ -108,6 +114,7 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     float *XS = smem + RF_O_XS, *XA = smem + RF_O_XA, *XC = smem + RF_O_XC, *NRM = smem + RF_O_NRM, *T1A = smem + RF_O_T1A, *T1C = smem + RF_O_T1C, *PSA = smem + RF_O_PSA;
     float *PSC = smem + RF_O_PSC, *EPS = smem + RF_O_EPS, *RED = smem + RF_O_RED;
     float *W1A = smem + RF_O_W1A, *W1C = smem + RF_O_W1C, *WST = smem + RF_O_WST, *WAT = smem + RF_O_WAT;
+    float *GAE = smem + RF_FLOATS;            // [H][3][16] + [16] (only with g.gae_lds)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const Dims da{g.S, g.h1, g.h2, g.A}, dc{g.S, g.h1, g.h2, 1};
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                 if (last) { if (g.o_next_value) g.o_next_value[row] = v; }
                 else if (g.o_values) g.o_values[(size_t)t * N + row] = v;
             }
+            if (g.gae_lds && q == 0) GAE[last ? H * 48 + l15 : (t * 3 + 1) * 16 + l15] = v;
         }
         if (last) return;
         draw(t + 1);
@@ -455,11 +463,18 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                     *reinterpret_cast<float4 *>(XC + l15 * RF_XLD + j0) =
                         make_float4((out[0] - ca.x) / cd.x, (out[1] - ca.y) / cd.y, (out[2] - ca.z) / cd.z, (out[3] - ca.w) / cd.w);
                 }
-                if (valid && wave == 0 && q == 0) {
+                if (wave == 0 && q == 0) {
                     const float rew = -(sq / (float)S) - 0.01f * (a2 / (float)A);
-                    g.o_rewards[(size_t)t * N + row] = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;   // rewards *= reward_scale (:126)
-                    g.o_undones[(size_t)t * N + row] = term ? 0 : 1;                                          // logical_not (:127-128)
-                    g.o_unmasks[(size_t)t * N + row] = trunc ? 0 : 1;
+                    const float rws = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;                   // rewards *= reward_scale (:126)
+                    if (valid) {
+                        g.o_rewards[(size_t)t * N + row] = rws;
+                        g.o_undones[(size_t)t * N + row] = term ? 0 : 1;                                      // logical_not (:127-128)
+                        g.o_unmasks[(size_t)t * N + row] = trunc ? 0 : 1;
+                    }
+                    if (g.gae_lds) {
+                        GAE[(t * 3 + 0) * 16 + l15] = rws;
+                        GAE[(t * 3 + 2) * 16 + l15] = __int_as_float((term ? 0 : 1) | (trunc ? 0 : 2));
+                    }
                 }
                 sc = done ? 0 : sc1;
                 if (done) ep = ep + 1;
@@ -486,11 +501,16 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                         XA[l15 * RF_XLD + k] = (ob[k] - NRM[k]) / NRM[64 + k];
                         XC[l15 * RF_XLD + k] = (ob[k] - NRM[128 + k]) / NRM[192 + k];
                     }
+                    const float rew = -0.5f * pend_cost;
+                    const float rws = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;
                     if (valid) {
-                        const float rew = -0.5f * pend_cost;
-                        g.o_rewards[(size_t)t * N + row] = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;
+                        g.o_rewards[(size_t)t * N + row] = rws;
                         g.o_undones[(size_t)t * N + row] = 1;
                         g.o_unmasks[(size_t)t * N + row] = trunc ? 0 : 1;
+                    }
+                    if (g.gae_lds) {
+                        GAE[(t * 3 + 0) * 16 + l15] = rws;
+                        GAE[(t * 3 + 2) * 16 + l15] = __int_as_float(1 | (trunc ? 0 : 2));
                     }
                 }
             }
@@ -527,7 +547,27 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     if (g.o_adv) {
         __syncthreads();                                   // (drains this workgroup's stores: vmcnt(0), then the barrier)
         double s_all = 0, s_sub = 0, q_sub = 0;
-        if (wave == 0 && q == 0 && valid) {
+        if (wave == 0 && q == 0 && valid && g.gae_lds) {
+            // inputs from the LDS tile the steps filled (no round trip through memory)
+            float nv = GAE[H * 48 + l15], a = 0.f;
+            const bool sub_col = (row & 3) == 0;
+            for (int t = H - 1; t >= 0; --t) {
+                const float r = GAE[(t * 3 + 0) * 16 + l15], v = GAE[(t * 3 + 1) * 16 + l15];
+                const int fl = __float_as_int(GAE[(t * 3 + 2) * 16 + l15]);
+                const size_t i = (size_t)t * N + row;
+                float r_eff;
+                uint8_t ud_eff;
+                const float out = g.vtrace ? erl_gae_step<true>(r, v, (uint8_t)(fl & 1), (uint8_t)((fl >> 1) & 1), g.gamma, g.lam, nv, a, r_eff, ud_eff)
+                                           : erl_gae_step<false>(r, v, (uint8_t)(fl & 1), (uint8_t)((fl >> 1) & 1), g.gamma, g.lam, nv, a, r_eff, ud_eff);
+                g.o_adv[i] = out;
+                g.o_ret[i] = erl_add_rn(out, v);
+                s_all += out;
+                if (sub_col && (t & 3) == 0) {
+                    s_sub += out;
+                    q_sub += (double)out * out;
+                }
+            }
+        } else if (wave == 0 && q == 0 && valid) {
             float nv = g.o_next_value[row], a = 0.f;
             const bool sub_col = (row & 3) == 0;
             constexpr int U = 8;
@@ -559,41 +599,16 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                 }
             }
         }
+        // the workgroup's three fp64 partial sums go to gae_ws[3 b ..]; they are folded in index order by the consumer's first
+        // launch (erl_adv_stats_fold_f32, or inside the update loop's weight-image kernel).  A fold by the last workgroup to arrive
+        // was built first and measured: +22-26 us per rollout -- its arrival counter, its partial loads and its result are three
+        // dependent memory round trips AFTER the slowest workgroup has finished, while 40 MB of rollout buffers drain.
         if (wave == 0) {
-            // workgroup partials -> the LAST workgroup to arrive folds all of them in index order (deterministic) into the 5 raw
-            // sums.  Partials and counter are 8-byte agent-scope atomics on both sides (no cache maintenance, MI355X_MICROARCH.md);
-            // the counter returns to 0 for the next launch.
             const double w0 = wave_sum(s_all), w1 = wave_sum(s_sub), w2 = wave_sum(q_sub);
-            const unsigned nwg = gridDim.x;
-            unsigned long long *counter = reinterpret_cast<unsigned long long *>(g.gae_ws + 3 * (size_t)nwg);
-            int last = 0;
             if (lane == 0) {
-                unsigned long long *pw = reinterpret_cast<unsigned long long *>(g.gae_ws) + 3 * (size_t)blockIdx.x;
-                __hip_atomic_store(pw + 0, (unsigned long long)__double_as_longlong(w0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pw + 1, (unsigned long long)__double_as_longlong(w1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pw + 2, (unsigned long long)__double_as_longlong(w2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partials are acknowledged before the arrival counts
-                last = __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(nwg - 1);
-            }
-            last = __shfl(last, 0, 64);
-            if (last) {
-                double f0 = 0, f1 = 0, f2 = 0;
-                for (unsigned b = lane; b < nwg; b += 64) {
-                    const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(g.gae_ws) + 3 * (size_t)b;
-                    f0 += __longlong_as_double((long long)__hip_atomic_load(pr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    f1 += __longlong_as_double((long long)__hip_atomic_load(pr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    f2 += __longlong_as_double((long long)__hip_atomic_load(pr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                }
-                f0 = wave_sum(f0); f1 = wave_sum(f1); f2 = wave_sum(f2);
-                if (lane == 0) {
-                    g.gae_stats[0] = f0;
-                    g.gae_stats[1] = (double)H * (double)g.N;
-                    g.gae_stats[2] = f1;
-                    g.gae_stats[3] = f2;
-                    g.gae_stats[4] = (double)((H + 3) / 4) * (double)((g.N + 3) / 4);
-                    g.gae_stats[5] = g.gae_stats[6] = g.gae_stats[7] = 0.0;      // (the block is all-reduced whole under data parallelism)
-                    __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                g.gae_ws[3 * (size_t)blockIdx.x + 0] = w0;
+                g.gae_ws[3 * (size_t)blockIdx.x + 1] = w1;
+                g.gae_ws[3 * (size_t)blockIdx.x + 2] = w2;
             }
         }
     }
@@ -609,17 +624,20 @@ int rf_launch(RfArgs &g, int env_kind, hipStream_t stream)
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = (g.S % 4 == 0) && al(g.Pa) && al(g.Pc) && al(g.o_states);
     const dim3 grid((unsigned)erl_cdiv(g.N, 16)), block(512);
+    g.gae_lds = (g.o_adv && g.H <= kRfGaeLdsSteps) ? 1 : 0;
+    const size_t lds_bytes = kRfLdsBytes + (g.gae_lds ? rf_gae_lds_bytes(g.H) : 0);
     static bool attr[6] = {false, false, false, false, false, false};
 #define RF_LAUNCH(E, V, A_, B_, C_, SLOT)                                                                                  \
     do {                                                                                                                   \
         if (!attr[SLOT]) {                                                                                                 \
             int rc = erl_hip_status(hipFuncSetAttribute((const void *)rollout_fused_kernel<E, V, A_, B_, C_>,              \
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRfLdsBytes),     \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,                         \
+                                                        (int)(kRfLdsBytes + rf_gae_lds_bytes(kRfGaeLdsSteps))),             \
                                     "hipFuncSetAttribute(rollout_fused_kernel)");                                          \
             if (rc) return rc;                                                                                             \
             attr[SLOT] = true;                                                                                             \
         }                                                                                                                  \
-        hipLaunchKernelGGL((rollout_fused_kernel<E, V, A_, B_, C_>), grid, block, kRfLdsBytes, stream, g);                 \
+        hipLaunchKernelGGL((rollout_fused_kernel<E, V, A_, B_, C_>), grid, block, lds_bytes, stream, g);                 \
     } while (0)
     const int ns = (g.S + 15) / 16;
     if (env_kind == ENV_SYN) {
@@ -654,8 +672,8 @@ int rf_fill(RfArgs &g, const char *what, const float *actor_params, const float 
     g.o_undones = out_undones; g.o_unmasks = out_unmasks; g.o_values = out_values; g.o_next_value = out_next_value;
     g.o_last_state = out_last_state;
     if (out_adv || out_ret) {
-        ERL_REQUIRE(out_adv && out_ret && gae_stats && gae_ws && out_values && out_next_value,
-                    "%s: the advantage epilogue needs out_advantages, out_reward_sums, gae_stats, gae_workspace, out_values and out_next_value", what);
+        ERL_REQUIRE(out_adv && out_ret && gae_ws && out_values && out_next_value,
+                    "%s: the advantage epilogue needs out_advantages, out_reward_sums, gae_workspace, out_values and out_next_value", what);
         ERL_REQUIRE(gae_ws_bytes >= erl_rollout_gae_workspace_bytes(N), "%s: gae_workspace of %lld bytes, erl_rollout_gae_workspace_bytes(N) = %lld",
                     what, (long long)gae_ws_bytes, (long long)erl_rollout_gae_workspace_bytes(N));
     }
@@ -676,8 +694,9 @@ extern "C" __attribute__((visibility("default"))) void erl_debug_set_rollout_fus
 
 extern "C" int erl_rollout_fused_supported(int S, int h1, int h2, int A) { return rf_dims_ok(S, h1, h2, A) ? 1 : 0; }
 
-// bytes of `gae_workspace` of the persistent rollouts for N envs: 3 fp64 partial sums per 16-env workgroup + the arrival counter
-extern "C" int64_t erl_rollout_gae_workspace_bytes(int64_t N) { return N >= 1 ? (3 * erl_cdiv(N, 16) + 1) * 8 : -1; }
+// bytes of `gae_workspace` of the persistent rollouts for N envs: 3 fp64 partial sums per 16-env workgroup (erl_rollout_gae_partials of them)
+extern "C" int64_t erl_rollout_gae_workspace_bytes(int64_t N) { return N >= 1 ? 3 * erl_cdiv(N, 16) * 8 : -1; }
+extern "C" int erl_rollout_gae_partials(int64_t N) { return N >= 1 ? (int)erl_cdiv(N, 16) : -1; }
 
 extern "C" int erl_rollout_synenv_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
                                       const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, float *env_state,

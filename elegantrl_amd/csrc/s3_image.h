@@ -66,4 +66,7 @@ int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *
                                       float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, const uint32_t *poison,
                                       void *stream);
 // grad_tail.hip: library-owned image buffers of (device, stream), built from the flat parameters [actor | critic]
-int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, hipStream_t stream);
+// (adv_partials != nullptr: one more block of the same launch folds the n_partials x 3 fp64 partial sums of the rollout's advantage
+// epilogue into adv_stats -- erl_adv_stats_fold_f32 without a launch of its own)
+int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, const double *adv_partials, int n_partials,
+                        int64_t H, int64_t N, double *adv_stats, hipStream_t stream);

@@ -56,6 +56,13 @@ def gae_scan(rewards: TEN, undones: TEN, unmasks: TEN, values: TEN, next_value: 
     return adv, (ret if with_ret else None)
 
 
+def adv_stats_fold(partials: TEN, n_partials: int, H: int, N: int, stats: TEN) -> TEN:
+    """n_partials x 3 fp64 partial sums (the persistent rollout's epilogue) -> the 8-double block of raw sums (AgentPPO.py:149)."""
+    check(lib().erl_adv_stats_fold_f32(ptr(partials, th.float64), int(n_partials), H, N, ptr(stats, th.float64), stream_ptr()),
+          "erl_adv_stats_fold_f32")
+    return stats
+
+
 def cum_rewards(rewards: TEN, undones: TEN, next_value: TEN, gamma: float, out: Optional[TEN] = None) -> TEN:
     """AgentBase.get_cumulative_rewards' backward scan (AgentBase.py:226-237): rewards / undones (H, N) f32, next_value (N,)."""
     H, N = rewards.shape
@@ -400,11 +407,13 @@ def reduce_clip_adam_grid_ok(stride: int) -> bool:
 def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, act_std: TEN, cri_avg: TEN, cri_std: TEN, S: int,
                h1: int, h2: int, A: int, states: TEN, actions: TEN, unmasks: TEN, logprobs: TEN, advantages: TEN, reward_sums: TEN,
                ids: TEN, ratio_clip: float, lambda_entropy: float, slabs: TEN, grads: TEN, first_step: int, lr: float,
-               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8, comm=None, objective: int = 0, adv_stats: Optional[TEN] = None) -> None:
+               max_norm: float, betas=(0.9, 0.999), eps: float = 1e-8, comm=None, objective: int = 0, adv_stats: Optional[TEN] = None,
+               adv_partials: Optional[TEN] = None, n_partials: int = 0) -> None:
     """the whole minibatch loop of AgentPPO.update_net in one C call; ids: (update_times, B).  `comm` (a
     parallel.RcclComm) puts the gradient all-reduce inside the loop, on the same stream (data-parallel ranks).
     `adv_stats` (8 float64: the raw sums left by gae_scan(stats=...) or the rollout's epilogue): `advantages` are then RAW
-    and every minibatch kernel normalises them at its row load (AgentPPO.py:149) instead of a separate launch."""
+    and every minibatch kernel normalises them at its row load (AgentPPO.py:149) instead of a separate launch.  `adv_partials`
+    (n_partials x 3 float64, the rollout epilogue's workspace): the sums are folded into `adv_stats` by the loop's first launch."""
     H, N = states.shape[0], states.shape[1]
     update_times, B = ids.shape
     assert grads.shape[0] >= update_times and slabs.shape[0] == ppo_num_slabs(B)
@@ -415,8 +424,9 @@ def ppo_update(flat_params: TEN, exp_avg: TEN, exp_avg_sq: TEN, act_avg: TEN, ac
                                       update_times, ratio_clip, lambda_entropy, int(objective), ptr(slabs, th.float32),
                                       ptr(grads, th.float32),
                                       first_step, lr, betas[0], betas[1], eps, max_norm,
-                                      None if adv_stats is None else ptr(adv_stats, th.float64), None if comm is None else comm.handle,
-                                      stream_ptr()),
+                                      None if adv_stats is None else ptr(adv_stats, th.float64),
+                                      None if adv_partials is None else ptr(adv_partials, th.float64), int(n_partials),
+                                      None if comm is None else comm.handle, stream_ptr()),
           "erl_ppo_update_dp_f32")
 
 

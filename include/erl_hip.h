@@ -103,6 +103,9 @@ ERL_API int erl_adv_stats_f32(const float *adv, int64_t H, int64_t N, double *st
                       int64_t workspace_bytes, void *stream);
 ERL_API int erl_adv_normalize_f32(const float *adv, float *out, int64_t H, int64_t N, const double *stats,
                           void *stream);
+/* the fold on its own: n_partials x 3 fp64 partial sums (sum adv | sum over [::4, ::4] | sum of squares over it) -> stats[0..4]
+ * (stats[5..7] = 0), in index order.  For the per-workgroup partials the persistent rollouts' epilogue leaves. */
+ERL_API int erl_adv_stats_fold_f32(const double *partials, int n_partials, int64_t H, int64_t N, double *stats, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  minibatch index decomposition + gather.  Replaces AgentPPO.update_objectives' sampling
@@ -224,10 +227,14 @@ ERL_API int erl_rollout_step_f32(const float *actor_params, const float *state_a
  * normalisation (:149) over the rollout just written -- exactly erl_gae_scan_f32(EXACT, STATS)'s outputs except that the
  * caller's rewards / undones are left as explore_env returns them (the truncation fix-up of get_advantages is applied by
  * erl_ppo_finish_f32).  The advantages are RAW: erl_ppo_update_dp_f32(adv_stats = gae_stats) normalises them at its row
- * loads.  They need out_values, out_next_value and gae_workspace (erl_rollout_gae_workspace_bytes(N) bytes, zero before the
- * first launch; the kernel leaves it zero-countered).  gamma / lambda_gae / use_v_trace as erl_gae_scan_f32. */
+ * loads.  They need out_values, out_next_value and gae_workspace (erl_rollout_gae_workspace_bytes(N) bytes): the sums are
+ * left there as erl_rollout_gae_partials(N) per-workgroup fp64 partials (a fold inside the rollout launch costs three
+ * dependent memory round trips at its end: measured +22-26 us); erl_adv_stats_fold_f32 -- or erl_ppo_update_dp_f32's
+ * adv_partials argument -- folds them into the 8-double block (`gae_stats` is reserved, may be NULL).  gamma / lambda_gae /
+ * use_v_trace as erl_gae_scan_f32. */
 ERL_API int erl_rollout_fused_supported(int S, int h1, int h2, int A);
 ERL_API int64_t erl_rollout_gae_workspace_bytes(int64_t N);
+ERL_API int erl_rollout_gae_partials(int64_t N);     /* rows of 3 doubles the epilogue leaves in gae_workspace */
 ERL_API int erl_rollout_synenv_f32(const float *actor_params, const float *critic_params, const float *act_avg,
                            const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
                            float *env_state, const float *Ws, const float *Wa, int32_t *step_count, int32_t *episode,
@@ -421,14 +428,16 @@ ERL_API int erl_comm_reduce_exchange_f32(void *comm, const float *slabs, int n_s
  * adv_stats: NULL when `advantages` are normalised already (erl_adv_normalize_f32); else the 8-double block of raw sums
  * (erl_gae_scan_f32 / the rollout epilogue, all-reduced under data parallelism) and `advantages` are RAW: every minibatch
  * kernel applies (adv - mean) / (std(adv[::4, ::4]) + 1e-5) (AgentPPO.py:149) at its row load, in erl_adv_normalize_f32's
- * arithmetic -- one launch less per update. */
+ * arithmetic -- one launch less per update.  adv_partials (n_partials x 3 doubles, the rollout epilogue's gae_workspace):
+ * the sums are not folded yet; the loop folds them into adv_stats first (inside its weight-image launch where it has one). */
 ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg,
                           const float *act_std, const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A,
                           const float *states, const float *actions, const uint8_t *unmasks, const float *logprobs,
                           const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
                           int64_t B, int update_times, float ratio_clip, float lambda_entropy, int objective, float *slabs,
                           float *grads, int32_t first_step, float lr, float beta1, float beta2, float eps,
-                          float max_norm, const double *adv_stats, void *comm, void *stream);
+                          float max_norm, double *adv_stats, const double *adv_partials, int n_partials, void *comm,
+                          void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic-shape path: build_mlp([S, d1, ..., dL, out]) with ANY number (<= ERL_MAX_LAYERS) and width of hidden layers
