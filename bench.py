@@ -97,6 +97,9 @@ class EventTimer:
     def mean_seconds(self):
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs)) * 1e-3
 
+    def each_ms(self):
+        return [round(a.elapsed_time(b), 3) for a, b in self.pairs]
+
 
 def gae_sweep(ops, dev):
     out = []
@@ -200,6 +203,15 @@ def emit(line: dict):
         os.write(_JSON_FD, data)
 
 
+def quiet_gc():
+    """after the warm-up: collect once and move what survives (everything torch built at import) to the permanent generation, as
+    elegantrl_amd.train.run does after its first iterations: a full collection of the interpreter costs 40-65 ms of idle GPU in
+    the middle of a 50 ms timed region (measured: tools/iter_times.py), and which step it lands on depends on allocation counts"""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -297,6 +309,7 @@ def bench_sac(opt):
 
     for _ in range(opt.warmup):
         step()
+    quiet_gc()
     t_k9.enabled = True
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -414,6 +427,7 @@ def main():
     for _ in range(opt.warmup):
         step()
     th.cuda.synchronize()
+    quiet_gc()
     null_bracket_us = _hip.k6_null_bracket_us(200)       # what an event bracket adds to its content on this box (empty launch)
     log("timed region")
     t_gae.enabled = t_explore.enabled = t_update.enabled = True
@@ -517,6 +531,7 @@ def main():
                  "k6_ms": round(k6_ms, 4), "update_net_minus_k6_ms": round(update_ms - k6_ms, 4),
                  "per_minibatch_rest_us": round((update_ms - k6_ms) / UPDATE_TIMES * 1e3, 2),
                  "host_and_gaps_ms": round(step_ms - explore_ms - update_ms, 4),
+                 "explore_env_ms_each": t_explore.each_ms(), "update_net_ms_each": t_update.each_ms(),
                  "consistent": bool(k6_ms <= update_ms and explore_ms + update_ms <= step_ms * 1.01),
                  "note": "HIP-event brackets around agent.explore_env / agent.update_net (means over the timed region); k6_ms = update_times x "
                          "roofline.avg_launch_us; per_minibatch_rest_us = slab reduction + clip/Adam + launch boundaries (+ GAE, statistics, "
@@ -531,6 +546,7 @@ def main():
                    "envs_per_gpu": N_ENVS, "horizon": HORIZON, "batch": BATCH, "update_times": UPDATE_TIMES,
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "last_state": "private copy (reference behaviour)" if agent.snapshot_last_state else "aliases the env's live state buffer",
+                   "interpreter": "gc.collect() + gc.freeze() after the warm-up (as elegantrl_amd.train.run does)",
                    "k6_arith": ("split: fp32 operands as three bf16 parts on the bf16 matrix pipe, fp32 accumulate (as close to fp64 as the "
                                 "fp32 MFMA: tests/test_kernels_gpu.py::test_ppo_step_split_arith)" if k6_arith == "split" else "f32 MFMA")},
         "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),

@@ -29,8 +29,21 @@ struct TailGroups {
     int64_t off[4], len[4];
 };
 
+// the slabs are read once (ERL_SLAB_LD, A/B builds only: 1 plain, 2 `sc1`)
+#ifndef ERL_SLAB_LD
+#define ERL_SLAB_LD 0
+#endif
 template <typename T>
-__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ T ld_stream(const T *p)
+{
+#if ERL_SLAB_LD == 0
+    return __builtin_nontemporal_load(p);
+#elif ERL_SLAB_LD == 1
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 
 // System-coherent accesses spelled out (sc0 sc1 = write through to / read from memory, past L1 and L2, local or over xGMI)
 // instead of C++ system-scope fences: a release / acquire fence at system scope is a whole-L2 write-back / invalidate PER

@@ -19,17 +19,43 @@ th.manual_seed(0)
 agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
 env = SynVecEnv(N, S, A, max_step=1000, gpu_id=0, seed=0)
 agent.last_state = env.reset()[0]
-rows = []
+rows, allocs, hosts = [], [], []
+bench_like = os.environ.get("BENCH_LIKE") == "1"      # no syncs between the two calls, event brackets, K6 sampling: what bench.py does
+from elegantrl_amd import _hip  # noqa: E402
 for it in range(int(os.environ.get("ITERS", 30))):
-    th.cuda.synchronize()
-    t0 = time.perf_counter()
-    items = agent.explore_env(env, H)
-    th.cuda.synchronize()
-    t1 = time.perf_counter()
-    agent.update_net(list(items))
-    th.cuda.synchronize()
-    t2 = time.perf_counter()
-    rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    if it == 3 and os.environ.get("GC_FREEZE") == "1":
+        import gc
+        gc.collect()
+        gc.freeze()
+    if bench_like and it == 3:
+        _hip.k6_null_bracket_us(200)
+        _hip.k6_timing_enable(16)
+    if bench_like:
+        e0, e1, e2 = (th.cuda.Event(enable_timing=True) for _ in range(3))
+        h0 = time.perf_counter()
+        e0.record()
+        items = agent.explore_env(env, H)
+        e1.record()
+        h1 = time.perf_counter()
+        agent.update_net(list(items))
+        e2.record()
+        th.cuda.synchronize()
+        rows.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        hosts.append((h1 - h0) * 1e3)
+    else:
+        th.cuda.synchronize()
+        t0 = time.perf_counter()
+        items = agent.explore_env(env, H)
+        th.cuda.synchronize()
+        t1 = time.perf_counter()
+        agent.update_net(list(items))
+        th.cuda.synchronize()
+        t2 = time.perf_counter()
+        rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    allocs.append(th.cuda.memory_stats()["num_device_alloc"])
+print("device allocs after each iteration:", allocs)
+if hosts:
+    print("host ms inside explore_env:", " ".join(f"{h:.2f}" for h in hosts))
 print("fused_gae", agent.fused_gae, "explore ms:", " ".join(f"{a:.2f}" for a, _ in rows))
 print("update ms:", " ".join(f"{b:.2f}" for _, b in rows))
 print("reserved MB", th.cuda.memory_reserved() >> 20, "allocs", th.cuda.memory_stats()["num_device_alloc"])
