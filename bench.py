@@ -439,8 +439,11 @@ def main():
     for _ in range(opt.steps):
         objs = step()
     th.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0                  # this rank's own time to its last kernel (before the closing barrier)
     parallel.barrier()
     elapsed = parallel.all_reduce_max_float(time.perf_counter() - t0, device=dev)
+    rank_ms_max = parallel.all_reduce_max_float(own_elapsed, device=dev) / opt.steps * 1e3
+    rank_ms_min = -parallel.all_reduce_max_float(-own_elapsed, device=dev) / opt.steps * 1e3
     t_gae.enabled = t_explore.enabled = t_update.enabled = False
     _hip.k6_timing_enable(False)
     k6_event_seconds, k6_span_seconds, k6_launches = _hip.k6_timing_read2()
@@ -582,6 +585,9 @@ def main():
                          "note": f"{len(repeats)} more timed regions of {opt.steps} steps each after the primary one (not part of `value`)"}
     if f32_region is not None:
         line.setdefault("extra", {})["k6_arith_f32"] = f32_region
+    if world > 1:
+        line.setdefault("extra", {})["per_rank_ms_per_step"] = {"min": round(rank_ms_min, 3), "max": round(rank_ms_max, 3),
+                                                                 "note": "every rank's own time to its last kernel, before the closing barrier"}
     if not opt.no_gae_sweep and opt.config == "c4":
         log("GAE size sweep")
         sweep = gae_sweep(ops, dev)

@@ -28,7 +28,31 @@ struct Ppo2Args {
     int prof_block;
 };
 
+// how the gradient slabs leave the kernel (26 MB per launch, read once by the slab reduction).  Default since round 4: write-through
+// `sc1` stores (the line is dropped from the XCD's L2 as it is written): 2.26-2.32 ms per config-4 iteration against 2.34-2.42 with
+// the non-temporal stores of round 2 on four boxes of the pool -- the minibatch kernel itself is as fast, the slab reduction behind it
+// 1.1-1.4 us faster per minibatch (tools/r04_slab_policy.sh, profiles/r04_slab_policy.txt).  ERL_SLAB_ST (A/B builds only):
+// 0 non-temporal, 1 plain (kernel -1.5 us, reduction +2.4), 2 `sc1`, 3 `sc0 sc1` (= 2), 4 `sc1 nt` (between 0 and 2)
+#ifndef ERL_SLAB_ST
+#define ERL_SLAB_ST 2
+#endif
+
 namespace {
+
+__device__ __forceinline__ void slab_store(float v, float *p)
+{
+#if ERL_SLAB_ST == 0
+    __builtin_nontemporal_store(v, p);
+#elif ERL_SLAB_ST == 1
+    *p = v;
+#elif ERL_SLAB_ST == 2
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif ERL_SLAB_ST == 3
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#endif
+}
 
 constexpr int PB = 128;        // samples per workgroup
 // leading dimension of the staged feature-major tiles T[feature][sample]: 16-byte aligned rows, consecutive rows 16
@@ -135,7 +159,7 @@ __device__ __forceinline__ void weight_grad(const float *TA, int nA32, const flo
         const int i = 32 * jt + l31;
         if (i < cols_real) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r], dW + (size_t)(32 * it + crow(r, hi)) * ldw + i);   // see ppo_step_w4.hip: slabs stream past L2
+            for (int r = 0; r < 16; ++r) slab_store(acc[r], dW + (size_t)(32 * it + crow(r, hi)) * ldw + i);
         }
     }
 }

@@ -27,31 +27,7 @@
 #include "ppo_step_w4_impl.h"
 #include "split_bf16.h"
 
-// how the gradient slabs leave the kernel (26 MB per launch, read once by the slab reduction).  Default since round 4: write-through
-// `sc1` stores (the line is dropped from the XCD's L2 as it is written): 2.26-2.32 ms per config-4 iteration against 2.34-2.42 with
-// the non-temporal stores of round 2 on four boxes of the pool -- the minibatch kernel itself is as fast, the slab reduction behind it
-// 1.1-1.4 us faster per minibatch (tools/r04_slab_policy.sh, profiles/r04_slab_policy.txt).  ERL_SLAB_ST (A/B builds only):
-// 0 non-temporal, 1 plain (kernel -1.5 us, reduction +2.4), 2 `sc1`, 3 `sc0 sc1` (= 2), 4 `sc1 nt` (between 0 and 2)
-#ifndef ERL_SLAB_ST
-#define ERL_SLAB_ST 2
-#endif
-
 namespace {
-
-__device__ __forceinline__ void slab_store(float v, float *p)
-{
-#if ERL_SLAB_ST == 0
-    __builtin_nontemporal_store(v, p);
-#elif ERL_SLAB_ST == 1
-    *p = v;
-#elif ERL_SLAB_ST == 2
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#elif ERL_SLAB_ST == 3
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
-#endif
-}
 
 __device__ __forceinline__ int phi(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }   // bits 2 and 3 swapped
 

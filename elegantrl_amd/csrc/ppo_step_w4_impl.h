@@ -296,7 +296,7 @@ __device__ __forceinline__ void weight_grad_w4(const float *TA, const float *TB,
         if (i < cols_real) {
             float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(c[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
+            for (int r = 0; r < 16; ++r) slab_store(c[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
         }
     };
 #pragma unroll
@@ -373,7 +373,7 @@ __device__ __forceinline__ void weight_grad_tiny_k(const float *TA, const float 
         const int f = 32 * it + l31;
 #pragma unroll
         for (int k = 0; k < KM; ++k)
-            if (k < S) __builtin_nontemporal_store(r[k], dW + (size_t)f * S + k);
+            if (k < S) slab_store(r[k], dW + (size_t)f * S + k);
         db[f] = s;
     }
 }
@@ -739,7 +739,7 @@ __device__ __forceinline__ void ppo_block_w4(const Ppo2Args &g, float *smem)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a_ = 4 * q + r;
-                if (a_ < OUT) __builtin_nontemporal_store(acc[r], slab + d.oW3() + (size_t)a_ * h2 + 16 * it + l15);
+                if (a_ < OUT) slab_store(acc[r], slab + d.oW3() + (size_t)a_ * h2 + 16 * it + l15);
             }
         }
         float s = hs.x + hs.y;
