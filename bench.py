@@ -5,19 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one PPO iteration of BASELINE config 4 on every rank: a 32-step vectorised rollout of 4096 synthetic
-envs (obs 64, act 8) + value pre-pass + GAE + advantage normalisation + 40 minibatches of 16384 (fused
-fwd/bwd, gradient reduce, [RCCL all-reduce when N > 1], clip + Adam).  Inputs are device resident; env shards are
-one per GPU (weak scaling).  Rank 0 prints ONE JSON line.
+One "step" = one PPO iteration of BASELINE config 4 on every rank: ONE launch for the 32-step vectorised rollout of 4096
+synthetic envs (obs 64, act 8) + value pre-pass + GAE + the advantage-normalisation sums, then 40 minibatches of 16384
+(fused fwd/bwd, gradient-slab reduce [+ the data-parallel exchange inside that launch, or an RCCL all-reduce, when N > 1],
+clip + Adam).  Inputs are device resident; env shards are one per GPU (weak scaling).  Rank 0 prints ONE JSON line
+(exactly one line on stdout: libraries' C-level stdout is redirected to stderr).
 
 Besides the throughput the line carries
   roofline      dominant kernel of the timed region (the PPO minibatch kernel: ppo_step_s3_kernel, bf16 matrix pipe with
-                fp32-equivalent split arithmetic, or ppo_step_w4_kernel on the fp32 MFMA), timed with HIP events
-                around every launch inside the timed region
-  roofline_gae  the GAE scan (HBM bound; the metric's second half): in-loop launches + a size sweep run after
-                the timed region (the in-loop 32 x 4096 problem is 2.4 MB, i.e. launch-latency sized)
-  cpu_baseline  oracle/torch_port.py (a torch-CPU port of the reference loop) timed on this box's host cores on
-                a bounded sample of the same workload (N = 1 only)
+                fp32-equivalent split arithmetic, or ppo_step_w4_kernel on the fp32 MFMA).  `avg_launch_us` is the kernel's
+                own span on the device clock (first workgroup in -> last workgroup out), measured on every launch of the
+                timed region; `event_bracket_us` the HIP-event bracket around the same launches, `event_bracket_null_us`
+                that bracket around an empty launch, `kernel_us_rocprof` the committed rocprofv3 average it must agree with
+  roofline_gae  the GAE scan (HBM bound; the metric's second half): a size sweep run after the timed region (the loop
+                itself has no GAE launch left when the rollout's epilogue computes it; `--config` runs that do report them)
+  breakdown     per-stage GPU time of one iteration (rollout / minibatch kernel / tail / rest), with `consistent`
+  cpu_baseline  oracle/cpu_baseline.py (a torch-CPU port of the reference loop, validated against the reference's own
+                classes: profiles/r04_cpu_baseline_reference_vs_port_*.json) timed per stage on this box's host cores on a
+                bounded sample of the same workload (N = 1 only)
+  extra.per_rank_ms_per_step   (N > 1) fastest / slowest rank's own time per step
 """
 from __future__ import annotations
 
