@@ -125,6 +125,14 @@ class AgentPPO(AgentBase):
         self._fused = (not self._discrete and len(net_dims) == 2
                        and all(32 <= d <= _hip.MAX_HIDDEN and d % 32 == 0 for d in net_dims)
                        and state_dim <= _hip.MAX_STATE_DIM and action_dim <= _hip.MAX_ACTION_DIM)
+        # net_dims = (256, 64 | 128) (examples/demo_A2C_PPO.py:117 trains (256, 128)): rollout and value pre-pass on the layered path,
+        # the minibatch loop on its own fused kernel (csrc/ppo_step_wd.hip) with the fused path's slabs, optimiser tail and C loop;
+        # args.wide_fused = False / ERL_WIDE_FUSED=0 keeps the layered minibatch step (A/B runs, parity tests)
+        import os as _os0
+        self._wide = (not self._fused and not self._discrete and len(net_dims) == 2 and net_dims[0] == 256 and net_dims[1] in (64, 128)
+                      and state_dim <= 64 and action_dim <= 8
+                      and bool(getattr(args, "wide_fused", _os0.environ.get("ERL_WIDE_FUSED", "1") != "0")))
+        self._fused_update = self._fused or self._wide
 
         self.ratio_clip = getattr(args, "ratio_clip", 0.25)
         self.lambda_gae_adv = getattr(args, "lambda_gae_adv", 0.95)
@@ -161,7 +169,7 @@ class AgentPPO(AgentBase):
             self._spec_c = ops.MlpSpecN([state_dim, *net_dims, 1], False)
         self._Pa, self._Pc = self._spec_a.count, self._spec_c.count    # raises for unsupported shapes
         # gradient row: [actor | critic | 4 logged values]; the fused kernels pad it to whole 128-byte lines
-        self._stride = ops.ppo_slab_stride(state_dim, *net_dims, action_dim) if self._fused else self._Pa + self._Pc + 4
+        self._stride = ops.ppo_slab_stride(state_dim, *net_dims, action_dim) if self._fused_update else self._Pa + self._Pc + 4
         f32 = dict(dtype=th.float32, device=self.device)
         self._flat = th.zeros(self._Pa + self._Pc, **f32)
         self._exp_avg = th.zeros_like(self._flat)
@@ -487,7 +495,7 @@ class AgentPPO(AgentBase):
         dp = self.world_size > 1 or parallel.force_dp()
         # the job's exchange route (selected once, by a self-test: parallel.gradient_comm); None: torch.distributed
         comm = parallel.gradient_comm(self._stride) if dp else None
-        c_loop = self._fused and (not dp or comm is not None)       # the whole minibatch loop in one C call (below)
+        c_loop = self._fused_update and (not dp or comm is not None)       # the whole minibatch loop in one C call (below)
         cached = self._cached_values(states)
         from_rollout = None
         if cached is not None:                                                        # left by the fused rollout (same critic)
@@ -523,8 +531,8 @@ class AgentPPO(AgentBase):
         if ids is None:
             ids = th.randint(H * N, size=(update_times, B), device=dev)
         assert ids.shape == (update_times, B) and ids.dtype == th.int64
-        n_slabs = self._n_slabs(B) if self._fused else 0
-        if self._fused and (self._slabs is None or self._slabs.shape[0] != n_slabs):
+        n_slabs = self._n_slabs(B) if self._fused_update else 0
+        if self._fused_update and (self._slabs is None or self._slabs.shape[0] != n_slabs):
             self._slabs = th.empty((n_slabs, self._stride), dtype=th.float32, device=dev)
         if self._grads is None or self._grads.shape[0] < update_times:
             self._grads = th.empty((update_times, self._stride), dtype=th.float32, device=dev)
@@ -532,7 +540,7 @@ class AgentPPO(AgentBase):
         groups = [(0, self._Pa), (self._Pa, self._Pc)]
         inv_batch = 1.0 / B
         grad_scale = 1.0 / self.world_size
-        if not self._fused:             # generic-shape networks: layered path, summed gradient written directly
+        if not self._fused_update:      # generic-shape networks: layered path, summed gradient written directly
             for k in range(update_times):
                 g = self._grads[k]
                 step = ops.mlpn_ppo_step_discrete if self._discrete else ops.mlpn_ppo_step

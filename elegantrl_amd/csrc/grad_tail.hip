@@ -20,6 +20,7 @@
 // and the squared-norm pass after a foreign all-reduce (RCCL / torch.distributed routes: erl_grad_sq_partials_f32).
 #include "erl_common.h"
 #include "s3_image.h"
+#include "ppo_step_wd.h"
 
 namespace {
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
         if (gi < 2 && im.net[gi].img) {
             const int64_t e = ie - im.net[gi].w2_off;
             const int h1 = im.net[gi].h1, S = im.net[gi].S;
-            if (e >= 0 && e < (int64_t)h1 * im.net[gi].h2) s3_image_put(im.net[gi].img, h1, (int)(e / h1), (int)(e % h1), e_p);
+            if (e >= 0 && e < (int64_t)h1 * im.net[gi].h2) s3_image_put_w2(im.net[gi].img, h1, im.net[gi].h2, (int)(e / h1), (int)(e % h1), e_p);
             else if (im.net[gi].img1 && ie < (int64_t)h1 * S) s3_image_put(im.net[gi].img1, im.net[gi].K1, (int)(ie / S), (int)(ie % S), e_p);
         }
     }
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void s3_image_build_kernel(const float *__rest
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n2 = (int64_t)h1 * im.net[gi].h2;
     if (e < n2) {
-        s3_image_put(im.net[gi].img, h1, (int)(e / h1), (int)(e % h1), P[im.net[gi].w2_off + e]);
+        s3_image_put_w2(im.net[gi].img, h1, im.net[gi].h2, (int)(e / h1), (int)(e % h1), P[im.net[gi].w2_off + e]);
     } else if (im.net[gi].img1 && e - n2 < (int64_t)h1 * K1) {
         const int row = (int)((e - n2) / K1), col = (int)((e - n2) % K1);
         s3_image_put(im.net[gi].img1, K1, row, col, col < S ? P[(int64_t)row * S + col] : 0.f);

@@ -9,6 +9,7 @@
 // K2  value pre-pass: persistent workgroups of 8 waves; a wave walks 16-row tiles with the next tile's state rows
 //     prefetched under the current tile's MFMAs  (AgentPPO.py:141-143, :219-220, :435-441).
 #include "mlp_chain.h"
+#include "ppo_step_wd.h"
 
 namespace {
 
@@ -452,7 +453,8 @@ bool vec_ok(const FwdArgs &g)
 
 extern "C" int64_t erl_mlp_param_count(int S, int h1, int h2, int out, int with_std_log)
 {
-    if (!mlp_dims_ok(S, h1, h2, out)) return -1;
+    // (net_dims = (256, h2): the minibatch kernel of ppo_step_wd.hip only -- rollouts of that shape take the layered erl_mlpn_* path)
+    if (!mlp_dims_ok(S, h1, h2, out) && !erl_ppo_wd_supported(S, h1, h2, out)) return -1;
     return Dims{S, h1, h2, out}.count(with_std_log != 0);
 }
 

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "ppo_step.h"
+#include "ppo_step_wd.h"
 #include "s3_image.h"
 #include <cstring>
 
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(PNW * 64) void ppo_step2_kernel(Ppo2Args g)
 
 bool dims_ok2(int S, int h1, int h2, int out)
 {
+    if (erl_ppo_wd_supported(S, h1, h2, out)) return true;      // net_dims = (256, h2): ppo_step_wd.hip
     return S >= 1 && S <= ERL_MAX_STATE_DIM && h1 >= 32 && h1 <= ERL_MAX_HIDDEN && (h1 % 32) == 0 && h2 >= 32 &&
            h2 <= ERL_MAX_HIDDEN && (h2 % 32) == 0 && out >= 1 && out <= ERL_MAX_ACTION_DIM;
 }
@@ -460,6 +462,7 @@ extern "C" int erl_ppo_set_arith(int arith)
 
 extern "C" int erl_ppo_arith_in_use(int S, int h1, int h2, int A)
 {
+    if (erl_ppo_wd_supported(S, h1, h2, A)) return ERL_PPO_ARITH_SPLIT;      // the (256, h2) kernel exists in this arithmetic only
     return (k6_form() != 8 && k6_arith_resolved() == ERL_PPO_ARITH_SPLIT && erl_ppo_s3_supported(S, h1, h2, A)) ? ERL_PPO_ARITH_SPLIT
                                                                                                                : ERL_PPO_ARITH_F32;
 }
@@ -492,6 +495,10 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     ERL_REQUIRE(objective >= ERL_PPO_OBJ_REFERENCE && objective <= ERL_PPO_OBJ_A2C, "erl_ppo_step_f32: unknown objective %d", objective);
     ERL_REQUIRE(n_slabs == erl_ppo_num_slabs(B), "erl_ppo_step_f32: n_slabs=%d, expected erl_ppo_num_slabs(B=%lld)=%d", n_slabs,
                 (long long)B, erl_ppo_num_slabs(B));
+    if (erl_ppo_wd_supported(S, h1, h2, A))
+        return erl_ppo_wd_step(actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions, unmasks, logprobs,
+                               advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy, inv_batch, objective, slabs, n_slabs,
+                               erl_ppo_slab_stride(S, h1, h2, A), images, adv_stats, stream);
     Ppo2Args g;
     g.P[0] = actor_params; g.P[1] = critic_params;
     g.avg[0] = act_avg; g.avg[1] = cri_avg;

@@ -1,0 +1,861 @@
+// K6 for the reference's wider demo networks: one PPO minibatch (gather + actor & critic forward + objective + full backward) for
+// net_dims = (256, h2), h2 in {64, 128}, S <= 64, A <= 8 -- examples/demo_A2C_PPO.py:117 trains (256, 128) -- on the bf16 matrix pipe with
+// the fp32-equivalent split arithmetic of ppo_step_s3_impl.h (three bf16 parts per operand, six partial products, fp32 accumulation).
+// Same contract as the [128,128] kernels (AgentPPO.update_objectives up to the optimizer steps, elegantrl/agents/AgentPPO.py:173-204;
+// ActorPPO.get_logprob_entropy :378-386; same slabs, same logged sums), same mapping (grid (ceil(B / 128), 2 networks), four waves,
+// one per SIMD, 32 samples each).  What a 256-wide first layer changes:
+//
+//   * registers: H1 of a wave's 32 samples alone is 128 registers per lane.  It stays (the second layer and the dW2 staging read it);
+//     GELU'(z1) (128 more) leaves for a per-workgroup scratch block in global memory as each tile of the first layer finishes and
+//     comes back tile by tile as the gate of the backward pass; H2 takes the same trip between the output layer and dW3
+//     (lane-contiguous 16-byte accesses, 192 KB per workgroup and network, written once and read once by the same CU).
+//   * LDS: the W2 image (h2 x 3 x 256 bf16 = 196 KB at h2 = 128) does not fit.  The optimiser keeps it as four COLUMN-QUARTER images
+//     [h2][3][64 bf16] (48 KB each, s3_image.h's layout with K = 64); they stream through two 48 KB slots by LDS-DMA, issued piece by
+//     piece behind the MFMAs of the quarter before: the second layer accumulates z2 quarter by quarter (K split), the backward pass
+//     produces dZ1 quarter by quarter (64 of its 256 features), and each quarter of dZ1 is staged into the slot its W2 quarter just
+//     left and contracted with the staged input (dW1) before the next one is formed -- dZ1 never exists as a whole.  dW2 walks H1 in
+//     quarters the same way (re-split from the fp32 registers).  Three slots of 48 KB: [A: W1 image / X image / H1 quarter]
+//     [X][Y: W2 quarters / dZ1 quarter / H2^T / dZ2 image].
+//
+// Everything else -- operand layouts, the phi row permutation, swizzled images, transposing reads for the weight gradients, the fp32
+// output layer -- is ppo_step_s3_impl.h's, whose helpers this file uses.
+#pragma once
+#include "ppo_step_s3_impl.h"
+
+namespace {
+
+struct PpoWdArgs {
+    Ppo2Args g;          // w2img: the four quarter images, contiguous; w1img: [256][3][K1]
+    float *scratch;      // [n_slabs][2 networks][(8 + N2) tiles][16][256 threads]
+};
+
+constexpr int kWdSlot = 49152;
+constexpr int kWdSmall = (256 + 128 + 16 + 64 + 64 + 16) * 4;
+constexpr size_t kWdLdsBytes = (size_t)3 * kWdSlot + kS3W3 + kWdSmall;
+static_assert(kWdLdsBytes <= 160 * 1024, "LDS budget");
+static_assert(2 * kWdSlot >= 128 * PLD * 4, "H2^T (fp32, feature-major) spans two slots");
+
+// one 1 KB piece by LDS-DMA: lane l copies 16 bytes from src_lane (the lane's own address) to LDS byte lds + 16 l.  Inline assembly
+// the compiler does not see (ppo_step_s3_impl.h explains why): the issuing wave waits by hand (s_waitcnt vmcnt(0)) before the barrier
+// that publishes the bytes.
+__device__ __forceinline__ void wd_dma1(const u8 *src_lane, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void wd_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------------------
+// first layer: fwd_s3 (ppo_step_s3_impl.h) with two differences -- GELU' of a finished tile is handed to `done(tile, G)` instead of
+// being kept (two tiles of it are alive at any time), and NO may be 8.  NK in {2, 4}.
+// ---------------------------------------------------------------------------------------------------------
+template <int NK, int NO, int CP, typename Side, typename Done>
+__device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (&inP)[NK], const f32x16 (&inH)[(NK + 1) / 2],
+                                       f32x16 (&outH)[NO], int m, int hi, const Side &side, const Done &done)
+{
+    constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
+    constexpr int EP = 16 / NK;
+    static_assert(EP * NK == 16 && EP >= 2 && NK >= 2, "k-steps per tile");
+    const int row = phi(m);
+    const u8 *base = img + row * ROWB;
+    const int x16 = 16 * (swz<CP>(row) ^ hi);
+    Parts aq[2];
+    auto issue = [&](int c, Parts &dst) {
+        const int To = c / NK, ks = c % NK;
+        const u8 *p = base + 32 * To * ROWB + ((32 * ks) ^ x16);
+        dst.h = *reinterpret_cast<const u32x4 *>(p);
+        dst.m = *reinterpret_cast<const u32x4 *>(p + PBY);
+        dst.l = *reinterpret_cast<const u32x4 *>(p + 2 * PBY);
+    };
+    f32x16 prev, prev1, Gt[2];
+    constexpr float kC = 0.84932180028801904272f;
+    constexpr float kP = 0.3275911f * 0.70710678118654752440f / kC;
+    float z[EP], xa[EP], tt[EP], uu[EP], pp[EP];
+    auto stage = [&](int Tp, int ks, int s, bool fence = true) {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) {
+            const int e = EP * ks + i;
+            if (s == 0) {
+                z[i] = prev[e] + prev1[e];
+                xa[i] = fabsf(z[i]) * kC;
+                tt[i] = fmaf(xa[i], kP, 1.0f);
+            } else if (s == 1) {
+                tt[i] = __builtin_amdgcn_rcpf(tt[i]);
+                uu[i] = __builtin_amdgcn_exp2f(-(xa[i] * xa[i]));
+            } else if (s == 2) {
+                pp[i] = fmaf(tt[i], 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * 1.421413741f);
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * -0.284496736f);
+            } else if (s == 3) {
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * 0.254829592f);
+                pp[i] = pp[i] * tt[i];
+                pp[i] = fmaf(-pp[i], uu[i], 0.5f);
+            } else if (s == 4) {
+                pp[i] = copysignf(pp[i], z[i]) + 0.5f;
+                uu[i] = z[i] * uu[i];
+            } else {
+                float y = z[i] * pp[i];
+                float gd = fmaf(uu[i], 0.39894228040143267794f, pp[i]);
+                asm volatile("" : "+v"(y), "+v"(gd));
+                Gt[Tp & 1][e] = gd;
+                outH[Tp][e] = y;
+            }
+        }
+        if (fence) __builtin_amdgcn_sched_barrier(0);
+    };
+    auto jit = [&](int ks, int s) {
+        if (ks < NK && s < 4) {
+            uint32_t h, mm, l;
+            split2(inH[ks >> 1][8 * (ks & 1) + 2 * s], inH[ks >> 1][8 * (ks & 1) + 2 * s + 1], h, mm, l);
+            asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+            inP[ks].h[s] = h; inP[ks].m[s] = mm; inP[ks].l[s] = l;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) jit(0, s);
+    issue(0, aq[0]);
+    f32x16 nb;
+    auto load_bias = [&](int To) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi);
+            const float4 b1 = *reinterpret_cast<const float4 *>(bias + 32 * To + 16 * a + 8 * hi + 4);
+            nb[8 * a + 0] = b0.x; nb[8 * a + 1] = b0.y; nb[8 * a + 2] = b0.z; nb[8 * a + 3] = b0.w;
+            nb[8 * a + 4] = b1.x; nb[8 * a + 5] = b1.y; nb[8 * a + 6] = b1.z; nb[8 * a + 7] = b1.w;
+        }
+    };
+    load_bias(0);
+#pragma unroll
+    for (int To = 0; To < NO; ++To) {
+        f32x16 acc = nb, acc1 = {0};
+        if (To + 1 < NO) load_bias(To + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = To * NK + ks;
+            if (c + 1 < NC) issue(c + 1, aq[(c + 1) & 1]);
+            const Parts &a = aq[c & 1], &b = inP[ks];
+            auto fill = [&](int s) {
+                if (To > 0) stage(To - 1, ks, s);
+                else jit(ks + 1, s);
+            };
+            acc = mfma_bf(a.m, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            side(c);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(0);
+            acc1 = mfma_bf(a.l, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(1);
+            acc = mfma_bf(a.h, b.l, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(2);
+            acc1 = mfma_bf(a.m, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(3);
+            acc = mfma_bf(a.h, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(4);
+            acc1 = mfma_bf(a.h, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(5);
+        }
+        if (To > 0) {
+            done(To - 1, Gt[(To - 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prev = acc;
+        prev1 = acc1;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) stage(NO - 1, ks, s, false);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    done(NO - 1, Gt[(NO - 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one K quarter of the second layer: Z[To] += Wq[32 To + .][64 inputs] . in, Wq a column-quarter image (CP = 8), in = the two fp32
+// tiles H[2 Q], H[2 Q + 1] (split on the way, behind tile 0's MFMAs).  Two accumulators alternate as in fwd_s3; their sum is folded into
+// Z behind the next tile's MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+template <int Q, int NO, int CP, int NH, typename Side>
+__device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH], f32x16 (&Z)[NO], int m, int hi, const Side &side)
+{
+    static_assert(2 * Q + 1 < NH, "quarter outside the input");
+    constexpr int NK = 4, ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
+    const int row = phi(m);
+    const u8 *base = img + row * ROWB;
+    const int x16 = 16 * (swz<CP>(row) ^ hi);
+    Parts aq[2], inP[NK];
+    auto issue = [&](int c, Parts &dst) {
+        const int To = c / NK, ks = c % NK;
+        const u8 *p = base + 32 * To * ROWB + ((32 * ks) ^ x16);
+        dst.h = *reinterpret_cast<const u32x4 *>(p);
+        dst.m = *reinterpret_cast<const u32x4 *>(p + PBY);
+        dst.l = *reinterpret_cast<const u32x4 *>(p + 2 * PBY);
+    };
+    auto jit = [&](int ks, int s) {
+        if (ks < NK && s < 4) {
+            uint32_t h, mm, l;
+            split2(H[2 * Q + (ks >> 1)][8 * (ks & 1) + 2 * s], H[2 * Q + (ks >> 1)][8 * (ks & 1) + 2 * s + 1], h, mm, l);
+            asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+            inP[ks].h[s] = h; inP[ks].m[s] = mm; inP[ks].l[s] = l;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x16 prev, prev1;
+    auto merge = [&](int Tp, int ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = prev[4 * ks + i] + prev1[4 * ks + i];
+            asm volatile("" : "+v"(v));
+            Z[Tp][4 * ks + i] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) jit(0, s);
+    issue(0, aq[0]);
+#pragma unroll
+    for (int To = 0; To < NO; ++To) {
+        f32x16 acc = Z[To], acc1 = {0};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = To * NK + ks;
+            if (c + 1 < NC) issue(c + 1, aq[(c + 1) & 1]);
+            const Parts &a = aq[c & 1], &b = inP[ks];
+            auto fill = [&](int s) {
+                if (To == 0) jit(ks + 1, s);
+                else if (s == 0) merge(To - 1, ks);
+            };
+            acc = mfma_bf(a.m, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            side(c);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(0);
+            acc1 = mfma_bf(a.l, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(1);
+            acc = mfma_bf(a.h, b.l, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(2);
+            acc1 = mfma_bf(a.m, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(3);
+            acc = mfma_bf(a.h, b.m, acc);
+            acc1 = mfma_bf(a.h, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prev = acc;
+        prev1 = acc1;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Z[NO - 1][e] = prev[e] + prev1[e];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one quarter of the backward pass through W2: bwd_s3 (ppo_step_s3_impl.h) on a column-quarter image (NO = 2 tiles = 64 of the first
+// layer's features), with the split of dz skipped when an earlier quarter has done it (PRESPLIT) and a per-k-step hook.
+// ---------------------------------------------------------------------------------------------------------
+template <int NK, int NO, int CP, bool PRESPLIT, typename Side>
+__device__ __forceinline__ void bwd_wd(const u8 *img, Parts (&dzP)[NK], const f32x16 (&dzH)[NK / 2], const f32x16 (&gate)[NO],
+                                       Parts (&outP)[2 * NO], int lane, const Side &side)
+{
+    constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
+    constexpr int EP = 16 / NK;
+    static_assert(EP * NK == 16 && EP % 2 == 0, "k-steps per tile");
+    constexpr int NPR = EP / 2;
+    const int q = lane >> 4, kb = q >> 1, half = q & 1, t = lane & 15, rr = t >> 2, u = t & 3;
+    const int su = ((u & 1) << 1) | (u >> 1);
+    const int ccl = 2 * half + (su >> 1), sub = 8 * (su & 1);
+    const int rl0 = 8 * kb + rr, rl1 = rl0 + 4;
+    const u8 *b0 = img + rl0 * ROWB + sub, *b1 = img + rl1 * ROWB + sub;
+    const int x0 = 16 * (ccl ^ swz<CP>(rl0)), x1 = 16 * (ccl ^ swz<CP>(rl1));
+    u32x2 rq[2][6];
+    auto issue = [&](int c, u32x2(&dst)[6]) {
+        const int To = c / NK, ks = c % NK;
+        const u8 *p0 = b0 + 16 * ks * ROWB + ((64 * To) ^ x0), *p1 = b1 + 16 * ks * ROWB + ((64 * To) ^ x1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            dst[2 * pl] = lds_tr(p0 + pl * PBY);
+            dst[2 * pl + 1] = lds_tr(p1 + pl * PBY);
+        }
+    };
+    auto jit = [&](int ks, int s) {
+        if (!PRESPLIT && ks < NK && s < 4) {
+            uint32_t h, mm, l;
+            split2(dzH[ks >> 1][8 * (ks & 1) + 2 * s], dzH[ks >> 1][8 * (ks & 1) + 2 * s + 1], h, mm, l);
+            asm volatile("" : "+v"(h), "+v"(mm), "+v"(l));
+            dzP[ks].h[s] = h; dzP[ks].m[s] = mm; dzP[ks].l[s] = l;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x16 prev, prev1;
+    float v0[NPR], v1[NPR];
+    uint32_t sh[NPR], sm[NPR];
+    auto gstage = [&](int Tp, int ks, int s, bool fence = true) {
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+            const int e = EP * ks + 2 * i;
+            if (s == 0) {
+                v0[i] = gate[Tp][e] * (prev[e] + prev1[e]);
+                v1[i] = gate[Tp][e + 1] * (prev[e + 1] + prev1[e + 1]);
+                asm volatile("" : "+v"(v0[i]), "+v"(v1[i]));
+            } else if (s == 1) {
+                sh[i] = pk_bf16(v0[i], v1[i]);
+                v0[i] -= bf_lo(sh[i]);
+                v1[i] -= bf_hi(sh[i]);
+                asm volatile("" : "+v"(sh[i]), "+v"(v0[i]), "+v"(v1[i]));
+            } else if (s == 2) {
+                sm[i] = pk_bf16(v0[i], v1[i]);
+                v0[i] -= bf_lo(sm[i]);
+                v1[i] -= bf_hi(sm[i]);
+                asm volatile("" : "+v"(sm[i]), "+v"(v0[i]), "+v"(v1[i]));
+            } else if (s == 3) {
+                uint32_t l = pk_bf16(v0[i], v1[i]);
+                asm volatile("" : "+v"(l));
+                Parts &o = outP[2 * Tp + (e >> 3)];
+                o.h[(e & 7) >> 1] = sh[i]; o.m[(e & 7) >> 1] = sm[i]; o.l[(e & 7) >> 1] = l;
+            }
+        }
+        if (fence) __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) jit(0, s);
+    issue(0, rq[0]);
+#pragma unroll
+    for (int To = 0; To < NO; ++To) {
+        f32x16 acc = {0}, acc1 = {0};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = To * NK + ks;
+            if (c + 1 < NC) issue(c + 1, rq[(c + 1) & 1]);
+            const Parts a = parts_of(rq[c & 1]);
+            const Parts &b = dzP[ks];
+            auto fill = [&](int s) {
+                if (To > 0) gstage(To - 1, ks, s);
+                else jit(ks + 1, s);
+            };
+            acc = mfma_bf(a.m, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            side(c);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(0);
+            acc1 = mfma_bf(a.l, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(1);
+            acc = mfma_bf(a.h, b.l, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(2);
+            acc1 = mfma_bf(a.m, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(3);
+            acc = mfma_bf(a.h, b.m, acc);
+            acc1 = mfma_bf(a.h, b.h, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prev = acc;
+        prev1 = acc1;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) gstage(NO - 1, ks, s, false);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool ACTOR, int KX, int N2, bool VEC>     // KX: input tiles of 32 (1: S <= 32, 2: S <= 64)
+__device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
+{
+    const Ppo2Args &g = args.g;
+    constexpr int N1 = 8, h1 = 32 * N1, h2 = 32 * N2;
+    constexpr int NK1 = 2 * KX;                             // k-steps of 16 of the (zero-padded) input
+    constexpr int CP1 = 4 * KX, CPQ = 8, CPH2 = 4 * N2;     // chunks per part: W1 / X images, W2 quarter / dZ1 quarter / H1 quarter images, dZ2 image
+    constexpr int QB = h2 * 48 * CPQ;                       // bytes of one W2 column-quarter image
+    constexpr int QPW = QB / 1024 / QNW;                    // its 1 KB pieces per wave (12 at h2 = 128, 6 at 64)
+    constexpr int W1PW = h1 * 48 * CP1 / 1024 / QNW;        // W1 image pieces per wave (12 / 24)
+    static_assert(QB % (1024 * QNW) == 0 && QB <= kWdSlot && h1 * 48 * CP1 <= 2 * kWdSlot, "image sizes");
+    static_assert(QPW <= 4 * N2 && QPW <= 8 * NK1, "a quarter's pieces ride the k-steps of the phase before");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, hi = lane >> 5;
+    constexpr int net = ACTOR ? 0 : 1;
+    const int S = g.S, OUT = ACTOR ? g.A : 1;
+    const Dims d{S, h1, h2, OUT};
+    const float *P = g.P[net];
+    const float *std_log = P + d.oStd();
+
+    u8 *SLA = smem, *SLX = SLA + kWdSlot, *SLY = SLX + kWdSlot;
+    float *RW3 = reinterpret_cast<float *>(SLY + kWdSlot);      // W3 copy [16][ld3] fp32 (rows >= OUT zero); later RC = dY^T [16][PLD]
+    float *s_b1 = RW3 + kS3W3 / 4, *s_b2 = s_b1 + 256, *s_b3 = s_b2 + 128;
+    float *s_nr = s_b3 + 16, *s_nn = s_nr + 64;
+    float *s_red = s_nn + 64;
+    constexpr int ld3 = lds_ld(128);
+    float4 *scrG = reinterpret_cast<float4 *>(args.scratch + ((size_t)blockIdx.x * 2 + net) * ((8 + N2) * 16 * QNT)) + tid;
+    float4 *scrH = scrG + 8 * 4 * QNT;
+
+    // the wave's share of a DMA transfer: pieces [QPW wave, QPW (wave + 1)) of a quarter, [W1PW wave, ...) of the W1 image
+    const uint32_t ldsXw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + QPW * 1024 * wave));
+    const uint32_t ldsYw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLY + QPW * 1024 * wave));
+    const uint32_t ldsAw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLA + W1PW * 1024 * wave));
+    const u8 *w2src = g.w2img[net] + 16 * lane + QPW * 1024 * wave;
+    auto dma_q = [&](int q, uint32_t slot_w, int i) { wd_dma1(w2src + (size_t)q * QB + 1024 * i, slot_w + 1024u * i); };
+
+    PROF(0);
+    // ---- prologue: the sample id; the W1 image by LDS-DMA; biases, W3, normalisation constants (every load unconditional: see
+    //      ppo_step_s3_impl.h)
+    const int col = 32 * wave + m;
+    const int64_t bidx = (int64_t)blockIdx.x * PB + col;
+    const bool valid = bidx < g.B;
+    const int64_t id = g.ids[valid ? bidx : 0];
+    const AdvNorm advn = adv_norm_consts(ACTOR ? g.adv_stats : nullptr);
+    {
+        const u8 *src1 = g.w1img[net] + 16 * lane + W1PW * 1024 * wave;
+#pragma unroll
+        for (int i = 0; i < W1PW; ++i) wd_dma1(src1 + 1024 * i, ldsAw + 1024u * i);
+    }
+    float4 c3[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                           // W3 rows [16][h2] (rows >= OUT zeroed when stored)
+        const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
+        c3[u] = load4<VEC>(P + d.oW3() + (size_t)min(i, OUT - 1) * h2, 4 * j4, h2);
+    }
+    const float b1_raw = P[d.ob1() + tid];
+    const float b2_raw = P[d.ob2() + min(tid, h2 - 1)];
+    const float b3_raw = P[d.ob3() + min(tid, OUT - 1)];
+    const float sd_raw = g.sd[net][min(tid, S - 1)], avg_raw = g.avg[net][min(tid, S - 1)];
+
+    // ---- id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
+    int64_t n_, t_;
+    if (g.H * g.N <= 0x7fffffffLL) {
+        const uint32_t i32 = (uint32_t)id, h32 = (uint32_t)g.H, n32 = i32 / h32;
+        n_ = n32;
+        t_ = i32 - n32 * h32;
+    } else {
+        n_ = id / g.H;
+        t_ = id - n_ * g.H;
+    }
+    const int64_t row = valid ? t_ * g.N + n_ : 0;          // padding slots read row 0 (finite data) and carry zero weight
+    float4 XR[NK1][2];
+    {
+        const float *xrow = g.states + row * S;
+#pragma unroll
+        for (int ks = 0; ks < NK1; ++ks) {
+            XR[ks][0] = load4<VEC>(xrow, 16 * ks + 8 * hi, S);
+            XR[ks][1] = load4<VEC>(xrow, 16 * ks + 8 * hi + 4, S);
+        }
+    }
+    const uint8_t um_raw = g.unmasks[row];
+    const float um = (valid && um_raw) ? 1.f : 0.f;
+    const float xa = ACTOR ? g.logprobs[row] : g.reward_sums[row];
+    const float xb = ACTOR ? g.advantages[row] : 0.f;
+    float act_pre[4] = {0.f, 0.f, 0.f, 0.f}, sl_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ACTOR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ac = min(4 * hi + j, OUT - 1);
+            act_pre[j] = g.actions[row * OUT + ac];
+            sl_pre[j] = std_log[ac];
+        }
+    }
+#pragma unroll
+    for (int e = tid; e < kS3W3 / 16; e += QNT) reinterpret_cast<float4 *>(RW3)[e] = zero4();
+    s_b1[tid] = b1_raw;
+    if (tid < 128) s_b2[tid] = tid < h2 ? b2_raw : 0.f;
+    if (tid < 16) s_b3[tid] = tid < OUT ? b3_raw : 0.f;
+    if (tid < 64) {
+        const float nr = __builtin_amdgcn_rcpf(sd_raw + 1e-4f);                  // (x - avg) / (std + 1e-4)  (AgentPPO.py:360-361)
+        s_nr[tid] = tid < S ? nr : 0.f;
+        s_nn[tid] = tid < S ? -(avg_raw * nr) : 0.f;
+    }
+    wd_wait_dma();                                                   // this wave's pieces of the W1 image (and every load above)
+    lds_barrier();                                                   // (0a) W1 image, biases, constants visible; RW3 zeroed
+    PROF(1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                    // W3 copy [16][ld3], rows >= OUT zero; visible after (0b)
+        const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
+        if (i < 16) *reinterpret_cast<float4 *>(RW3 + i * ld3 + 4 * j4) = i < OUT ? c3[u] : zero4();
+    }
+    // ---- normalise the own row; its split rides behind the first output tile's MFMAs of the first layer
+    Parts Xp[NK1];
+    f32x16 XH[(NK1 + 1) / 2];
+#pragma unroll
+    for (int ks = 0; ks < NK1; ++ks) {
+        const float *nr = s_nr + 16 * ks + 8 * hi, *nn = s_nn + 16 * ks + 8 * hi;
+        const float4 r0 = *reinterpret_cast<const float4 *>(nr), r1 = *reinterpret_cast<const float4 *>(nr + 4);
+        const float4 n0 = *reinterpret_cast<const float4 *>(nn), n1 = *reinterpret_cast<const float4 *>(nn + 4);
+        f32x16 &t = XH[ks >> 1];
+        const int o = 8 * (ks & 1);
+        t[o + 0] = fmaf(XR[ks][0].x, r0.x, n0.x); t[o + 1] = fmaf(XR[ks][0].y, r0.y, n0.y);
+        t[o + 2] = fmaf(XR[ks][0].z, r0.z, n0.z); t[o + 3] = fmaf(XR[ks][0].w, r0.w, n0.w);
+        t[o + 4] = fmaf(XR[ks][1].x, r1.x, n1.x); t[o + 5] = fmaf(XR[ks][1].y, r1.y, n1.y);
+        t[o + 6] = fmaf(XR[ks][1].z, r1.z, n1.z); t[o + 7] = fmaf(XR[ks][1].w, r1.w, n1.w);
+    }
+
+    // ---- first layer (W1 image in slot A [+ X]); GELU' leaves for the scratch block tile by tile; W2 quarter 0 streams into slot Y
+    f32x16 H1[N1];
+    {
+        auto side = [&](int c) { if (c < QPW) dma_q(0, ldsYw, c); };
+        auto done = [&](int Tp, const f32x16 &G) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scrG[(4 * Tp + r) * QNT] = make_float4(G[4 * r], G[4 * r + 1], G[4 * r + 2], G[4 * r + 3]);
+        };
+        fwd_wd<NK1, N1, CP1>(SLA, s_b1, Xp, XH, H1, m, hi, side, done);
+    }
+    PROF(2);
+    wd_wait_dma();
+    lds_barrier();                                                   // (0b) quarter 0, W3 copy visible; every wave is done with the W1 image
+    PROF(3);
+    {
+        Parts Xs[2 * KX];
+#pragma unroll
+        for (int ks = 0; ks < 2 * KX; ++ks) Xs[ks] = Xp[ks];
+        stage_s3<2 * KX, CP1, 0>(SLA, Xs, col, hi);                  // the input's image for dW1 (visible after the next barrier)
+    }
+
+    // ---- second layer, K split in quarters: q0 (Y) | q1 (X) | q2 (Y) | q3 (X); quarter q + 1 streams in behind quarter q's MFMAs
+    f32x16 Z2[N2];
+#pragma unroll
+    for (int To = 0; To < N2; ++To) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(s_b2 + 32 * To + 16 * a + 8 * hi);
+            const float4 b1 = *reinterpret_cast<const float4 *>(s_b2 + 32 * To + 16 * a + 8 * hi + 4);
+            Z2[To][8 * a + 0] = b0.x; Z2[To][8 * a + 1] = b0.y; Z2[To][8 * a + 2] = b0.z; Z2[To][8 * a + 3] = b0.w;
+            Z2[To][8 * a + 4] = b1.x; Z2[To][8 * a + 5] = b1.y; Z2[To][8 * a + 6] = b1.z; Z2[To][8 * a + 7] = b1.w;
+        }
+    }
+    {
+        auto s1 = [&](int c) { if (c < QPW) dma_q(1, ldsXw, c); };
+        fwd_acc_wd<0, N2, CPQ>(SLY, H1, Z2, m, hi, s1);
+        wd_wait_dma();
+        lds_barrier();                                               // quarter 1 visible; every wave is done with quarter 0
+        auto s2 = [&](int c) { if (c < QPW) dma_q(2, ldsYw, c); };
+        fwd_acc_wd<1, N2, CPQ>(SLX, H1, Z2, m, hi, s2);
+        wd_wait_dma();
+        lds_barrier();
+        auto s3 = [&](int c) { if (c < QPW) dma_q(3, ldsXw, c); };
+        fwd_acc_wd<2, N2, CPQ>(SLY, H1, Z2, m, hi, s3);
+        wd_wait_dma();
+        lds_barrier();
+        fwd_acc_wd<3, N2, CPQ>(SLX, H1, Z2, m, hi, NoSide());       // quarter 2 stays in Y, quarter 3 in X: the backward pass starts there
+    }
+    f32x16 H2[N2], G2[N2];
+#pragma unroll
+    for (int To = 0; To < N2; ++To) {
+        gelu_tile(Z2[To], H2[To], G2[To]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scrH[(4 * To + r) * QNT] = make_float4(H2[To][4 * r], H2[To][4 * r + 1], H2[To][4 * r + 2], H2[To][4 * r + 3]);
+    }
+    PROF(4);
+
+    // ---- output layer (fp32, as in ppo_step_s3_impl.h: H2[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j)
+    float Y[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ACTOR) {
+        f32x4 ya[2][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ya[q >> 1][q & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *w3a = RW3 + (lane & 3) * ld3 + 8 * hi;
+#pragma unroll
+        for (int c = 0; c < 4 * N2; ++c) {
+            const int T = c >> 2, gq = c & 3;
+            const float4 w0 = *reinterpret_cast<const float4 *>(w3a + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
+            const float4 w1 = *reinterpret_cast<const float4 *>(w3a + 4 * ld3 + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
+            const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ya[0][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], H2[T][4 * gq + j], ya[0][j & 1], 0, 0, 0);
+                ya[1][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], H2[T][4 * gq + j], ya[1][j & 1], 0, 0, 0);
+            }
+        }
+        const float4 b4 = *reinterpret_cast<const float4 *>(s_b3 + 4 * hi);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = ya[0][0][j] + ya[0][1][j], hi_ = ya[1][0][j] + ya[1][1][j];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
+            Y[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) + bb[j];   // lanes < 32: output j; lanes >= 32: output 4 + j
+        }
+    } else {
+        f32x2 yp = {0.f, 0.f}, yq = {0.f, 0.f};
+        const float *w3 = RW3 + 8 * hi;
+#pragma unroll
+        for (int c = 0; c < 4 * N2; ++c) {
+            const int T = c >> 2, gq = c & 3;
+            const float4 wv = *reinterpret_cast<const float4 *>(w3 + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
+            yp = f32x2{wv.x, wv.y} * f32x2{H2[T][4 * gq + 0], H2[T][4 * gq + 1]} + yp;
+            yq = f32x2{wv.z, wv.w} * f32x2{H2[T][4 * gq + 2], H2[T][4 * gq + 3]} + yq;
+        }
+        const float s = (yp.x + yp.y) + (yq.x + yq.y);
+        Y[0] = s + __shfl_xor(s, 32, 64) + s_b3[0];
+    }
+    PROF(5);
+
+    // ---- objective and dL/dY for this lane's outputs a = 4 hi + j   (AgentPPO.py:189-204)
+    float dY[4] = {0.f, 0.f, 0.f, 0.f};
+    float loss0 = 0.f, loss1 = 0.f;
+    float dsl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!ACTOR) {
+        const float diff = Y[0] - xa;
+        const bool head = hi == 0;
+        loss0 = head ? diff * diff * um : 0.f;
+        dY[0] = head ? 2.f * diff * um * g.inv_batch : 0.f;
+    } else {
+        float diffv[4], ivar[4];
+        float lp = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = 4 * hi + j;
+            const float sl = sl_pre[j];
+            const float diff = act_pre[j] - Y[j];
+            const bool on = a < OUT;
+            ivar[j] = __expf(-2.f * sl);
+            diffv[j] = on ? diff : 0.f;
+            const float term = -(diff * diff) * (0.5f * ivar[j]) - sl - kLogSqrt2PiF;
+            lp += on ? term : 0.f;
+        }
+        lp += __shfl_xor(lp, 32, 64);
+        const PpoActorTerms o = ppo_actor_terms(g.objective, adv_normalized(xb, advn), lp, xa, g.ratio_clip, g.lambda_entropy, um, OUT, true);
+        if (hi == 0) {
+            loss0 = valid ? o.logged : 0.f;
+            loss1 = valid ? o.ent_mask : 0.f;
+        }
+        const float dlp = (valid ? o.dlp : 0.f) * g.inv_batch;
+        const float ent_term = (valid ? o.ent_w : 0.f) * g.inv_batch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = 4 * hi + j < OUT;
+            dY[j] = on ? dlp * (diffv[j] * ivar[j]) : 0.f;
+            dsl[j] = on ? dlp * (diffv[j] * diffv[j] * ivar[j] - 1.f) + ent_term : 0.f;
+        }
+    }
+
+    // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 8 outputs: four fp32 k-pairs; A-row m carries feature 32 To + phi(m))
+    PROF(6);
+    {
+        const int pm = phi(m);
+        float w3[N2][4];
+#pragma unroll
+        for (int To = 0; To < N2; ++To) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w3[To][j] = RW3[(4 * hi + j) * ld3 + 32 * To + pm];
+        }
+#pragma unroll
+        for (int To = 0; To < N2; ++To) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma32(w3[To][j], dY[j], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G2[To][r] *= acc[r];
+        }
+    }
+
+    // ---- dZ1 = (W2^T dZ2) * GELU'(z1), quarter by quarter (3, 2 resident; 1, 0 streamed back), each contracted with the input
+    //      (dW1, db1) as soon as it is staged
+    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
+    float *RC = RW3;
+    Parts dZ2p[2 * N2], dZ1q[4];
+    f32x16 Gq[2];
+    auto load_gate = [&](int q) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 v = scrG[(4 * (2 * q + t) + r) * QNT];
+                Gq[t][4 * r] = v.x; Gq[t][4 * r + 1] = v.y; Gq[t][4 * r + 2] = v.z; Gq[t][4 * r + 3] = v.w;
+            }
+        }
+    };
+    auto dw1 = [&](int q, const u8 *slot) {
+        const int it = wave & 1, jc = wave >> 1;             // row tile of the quarter's two, column tile of the input's KX
+        if (jc < KX) {
+            Parts A[8];
+            grad_a_load<CPQ>(slot, it, A, lane);
+            grad_tiles<CP1, 1, 2>(A, SLA, it, jc, 0, slab + d.oW1() + (size_t)(64 * q) * S, S, S, lane);
+            if (jc == 0) grad_bias(A, slab + d.ob1() + 64 * q, it, lane);
+        }
+    };
+    load_gate(3);
+    bwd_wd<2 * N2, 2, CPQ, false>(SLX, dZ2p, G2, Gq, dZ1q, lane, NoSide());     // splits dZ2 into dZ2p on the way
+    PROF(7);
+    lds_barrier();                                                   // (1) every wave is done with quarter 3 (X) and with W3
+    stage_s3<4, CPQ, 0>(SLX, dZ1q, col, hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        RC[(4 * hi + j) * PLD + col] = dY[j];
+        RC[(8 + 4 * hi + j) * PLD + col] = dsl[j];       // rows 8..15: per-sample dL/dstd_log (zero for the critic)
+    }
+    load_gate(2);
+    lds_barrier();                                                   // (2) dZ1 quarter 3 (and, long since, the X image) visible
+    PROF(8);
+    dw1(3, SLX);
+    bwd_wd<2 * N2, 2, CPQ, true>(SLY, dZ2p, G2, Gq, dZ1q, lane, NoSide());
+    lds_barrier();                                                   // (3) quarter 2 (Y) and the dZ1 image in X consumed
+    stage_s3<4, CPQ, 0>(SLY, dZ1q, col, hi);
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) dma_q(1, ldsXw, i);                // quarter 1 comes back into X
+    load_gate(1);
+    lds_barrier();                                                   // (4)
+    dw1(2, SLY);
+    wd_wait_dma();
+    lds_barrier();                                                   // (5) quarter 1 visible; the dZ1 image in Y consumed
+    {
+        auto s0 = [&](int c) { if (c < QPW) dma_q(0, ldsYw, c); };   // quarter 0 comes back into Y behind quarter 1's MFMAs
+        bwd_wd<2 * N2, 2, CPQ, true>(SLX, dZ2p, G2, Gq, dZ1q, lane, s0);
+    }
+    lds_barrier();                                                   // (6)
+    stage_s3<4, CPQ, 0>(SLX, dZ1q, col, hi);
+    load_gate(0);
+    lds_barrier();                                                   // (7)
+    dw1(1, SLX);
+    wd_wait_dma();
+    lds_barrier();                                                   // (8) quarter 0 visible; the dZ1 image in X consumed
+    bwd_wd<2 * N2, 2, CPQ, true>(SLY, dZ2p, G2, Gq, dZ1q, lane, NoSide());
+    lds_barrier();                                                   // (9)
+    stage_s3<4, CPQ, 0>(SLY, dZ1q, col, hi);
+    lds_barrier();                                                   // (10)
+    dw1(0, SLY);
+    PROF(9);
+    lds_barrier();                                                   // (11) X, Y, the X image in A consumed
+
+    // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2 back from the scratch block, staged feature-major in X + Y)
+    {
+        float *T2 = reinterpret_cast<float *>(SLX);
+#pragma unroll
+        for (int t = 0; t < N2; ++t) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 v = scrH[(4 * t + r4) * QNT];
+                const float hv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * r4 + j;
+                    T2[(32 * t + 16 * (r >> 3) + 8 * hi + (r & 7)) * PLD + col] = hv[j];
+                }
+            }
+        }
+    }
+    lds_barrier();                                                   // (12)
+    PROF(10);
+    {
+        const float *T2 = reinterpret_cast<const float *>(SLX);
+        const int l15 = lane & 15, q = lane >> 4;
+        f32x2 hs = {0.f, 0.f};
+#pragma unroll
+        for (int rep = 0; rep < (2 * N2 + QNW - 1) / QNW; ++rep) {
+            const int it = wave + QNW * rep;                            // 16-column tile of dW3 (wave-uniform)
+            if (it >= 2 * N2) break;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float *a = RC + l15 * PLD + 4 * q;
+            const float *b = T2 + (16 * it + l15) * PLD + 4 * q;
+#pragma unroll
+            for (int j = 0; j < PB / 16; ++j) {
+                const float4 av = *reinterpret_cast<const float4 *>(a + 16 * j), bv = *reinterpret_cast<const float4 *>(b + 16 * j);
+                acc = mfma16(av.x, bv.x, acc);
+                acc = mfma16(av.y, bv.y, acc);
+                acc = mfma16(av.z, bv.z, acc);
+                acc = mfma16(av.w, bv.w, acc);
+                if (rep == 0) {
+                    hs += f32x2{av.x, av.y};
+                    hs += f32x2{av.z, av.w};
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a_ = 4 * q + r;
+                if (a_ < OUT) slab_store(acc[r], slab + d.oW3() + (size_t)a_ * h2 + 16 * it + l15);
+            }
+        }
+        float s = hs.x + hs.y;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (wave == 0 && q == 0) {
+            if (l15 < OUT) slab[d.ob3() + l15] = s;
+            else if (ACTOR && l15 >= 8 && l15 - 8 < OUT) slab[d.oStd() + l15 - 8] = s;
+        }
+    }
+    lds_barrier();                                                   // (13) H2^T consumed
+    auto stage_h1 = [&](int q, u8 *slot) {                           // H1's features 64 q .. 64 q + 63, re-split from the registers
+        Parts p[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) p[ks] = split8(H1[2 * q + (ks >> 1)], ks & 1);
+        stage_s3<4, CPQ, 0>(slot, p, col, hi);
+    };
+    stage_s3<2 * N2, CPH2, 0>(SLX, dZ2p, col, hi);                   // the dZ2 image spans X + Y
+    stage_h1(0, SLA);
+    lds_barrier();                                                   // (14)
+    PROF(11);
+
+    // ---- layer 2: dW2 = dZ2^T . H1, db2  (wave w: row tile w % N2 of dZ2^T, read once into registers; H1 passes by in quarters)
+    {
+        constexpr int CS = 4 / N2, NBW = 2 / CS;
+        const int it = wave % N2, jc = wave / N2;
+        Parts A[8];
+        grad_a_load<CPH2>(SLX, it, A, lane);
+        lds_barrier();                                               // (15) the dZ2 image is in registers: X, Y are free
+        stage_h1(1, SLX);
+        stage_h1(2, SLY);
+        grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 0, slab + d.oW2(), h1, h1, lane);
+        lds_barrier();                                               // (16) quarters 1, 2 visible; quarter 0 (A) consumed
+        stage_h1(3, SLA);
+        grad_tiles<CPQ, NBW, CS>(A, SLX, it, jc, 2, slab + d.oW2(), h1, h1, lane);
+        grad_tiles<CPQ, NBW, CS>(A, SLY, it, jc, 4, slab + d.oW2(), h1, h1, lane);
+        lds_barrier();                                               // (17)
+        grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 6, slab + d.oW2(), h1, h1, lane);
+        if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
+    }
+    PROF(12);
+
+    // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
+    const float t0 = block_sum(loss0, s_red);
+    const float t1 = block_sum(loss1, s_red);
+    if (tid == 0) {
+        float *logs = g.slabs + (size_t)blockIdx.x * g.stride + g.Pa + g.Pc;
+        if (ACTOR) {
+            float ent = 0.f;
+            for (int a = 0; a < OUT; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));
+            logs[1] = t0 * g.inv_batch;
+            logs[2] = ent * t1 * g.inv_batch;
+        } else {
+            logs[0] = t0 * g.inv_batch;
+            logs[3] = 0.f;
+            for (int64_t e = g.Pa + g.Pc + 4; e < g.stride; ++e) logs[e - (g.Pa + g.Pc)] = 0.f;
+        }
+    }
+}
+
+template <int KX, int N2, bool VEC>
+__global__ __launch_bounds__(QNT) void ppo_step_wd_kernel(PpoWdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem_wd[];
+    const unsigned long long t_span = span_enter(a.g);
+    if (blockIdx.y == 0) ppo_block_wd<true, KX, N2, VEC>(a, smem_wd);
+    else ppo_block_wd<false, KX, N2, VEC>(a, smem_wd);
+    span_exit(a.g, t_span);
+}
+
+template <int KX, int N2, bool VEC>
+int launch_wd(const PpoWdArgs &a, int n_slabs, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = erl_hip_status(hipFuncSetAttribute((const void *)ppo_step_wd_kernel<KX, N2, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)kWdLdsBytes),
+                                "hipFuncSetAttribute(ppo_step_wd_kernel)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ppo_step_wd_kernel<KX, N2, VEC>), dim3(n_slabs, 2), dim3(QNT), kWdLdsBytes, stream, a);
+    return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32 (wide)");
+}
+
+}  // namespace
