@@ -428,8 +428,8 @@ void erl_launch_null_kernel(hipStream_t stream) { hipLaunchKernelGGL(null_kernel
 
 #ifdef ERL_PROFILE
 // profiling builds only (make EXTRA=-DERL_PROFILE): device buffer of 2 * 8 * 32 int64 cycle stamps
-extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile(long long *dev_buf) { g_ppo_prof = dev_buf; }
-extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile_block(int b) { g_ppo_prof_block = b; }
+extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile(long long *dev_buf) { g_ppo_prof = dev_buf; erl_ppo_wd_set_prof(dev_buf, g_ppo_prof_block); }
+extern "C" __attribute__((visibility("default"))) void erl_debug_set_ppo_profile_block(int b) { g_ppo_prof_block = b; erl_ppo_wd_set_prof(g_ppo_prof, b); }
 #endif
 
 namespace {

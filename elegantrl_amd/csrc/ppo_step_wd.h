@@ -20,3 +20,6 @@ int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const
                     const float *logprobs, const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids,
                     int64_t B, float ratio_clip, float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs,
                     int64_t stride, const S3Images *images, const double *adv_stats, void *stream);
+
+// ERL_PROFILE builds: where the kernel's cycle stamps go ([net][8 waves][32] int64), which workgroup stamps
+void erl_ppo_wd_set_prof(long long *dev_buf, int block);

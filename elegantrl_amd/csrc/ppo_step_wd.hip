@@ -12,6 +12,12 @@ bool erl_ppo_wd_supported(int S, int h1, int h2, int A)
 }
 
 namespace {
+long long *g_wd_prof = nullptr;
+int g_wd_prof_block = 0;
+}  // namespace
+void erl_ppo_wd_set_prof(long long *dev_buf, int block) { g_wd_prof = dev_buf; g_wd_prof_block = block; }
+
+namespace {
 
 // GELU'(z1) and H2 of every workgroup between the forward and the backward pass: library-owned, one block per (device, stream)
 struct WdScratch {
@@ -96,10 +102,10 @@ int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const
     g.adv_stats = adv_stats;
     g.w2img[0] = images->net[0].img; g.w2img[1] = images->net[1].img;
     g.w1img[0] = images->net[0].img1; g.w1img[1] = images->net[1].img1;
-    g.prof = nullptr;
-    g.prof_block = 0;
+    g.prof = g_wd_prof;
+    g.prof_block = g_wd_prof_block;
     const int N2 = h2 / 32;
-    int rc = wd_scratch((size_t)n_slabs * 2 * (8 + N2) * 16 * QNT, st, &a.scratch);
+    int rc = wd_scratch((size_t)n_slabs * 2 * wd_scratch_floats(N2), st, &a.scratch);
     if (rc) return rc;
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states);

@@ -26,8 +26,12 @@ namespace {
 
 struct PpoWdArgs {
     Ppo2Args g;          // w2img: the four quarter images, contiguous; w1img: [256][3][K1]
-    float *scratch;      // [n_slabs][2 networks][(8 + N2) tiles][16][256 threads]
+    float *scratch;      // [n_slabs][2 networks] blocks of wd_scratch_floats(N2): GELU'(z1) tiles | H2 tiles | four H1 quarter images
 };
+// per workgroup and network: (8 + N2) register tiles [16][256 threads] fp32, then H1 as four sample-major quarter images
+// [128 samples][3 parts][64 bf16] (the LDS layout of the dW2 operand: they come back by LDS-DMA)
+constexpr int kWdH1ImgBytes = 128 * 384;
+__host__ __device__ constexpr size_t wd_scratch_floats(int N2) { return (size_t)(8 + N2) * 16 * 256 + 4 * kWdH1ImgBytes / 4; }
 
 constexpr int kWdSlot = 49152;
 constexpr int kWdSmall = (256 + 128 + 16 + 64 + 64 + 16) * 4;
@@ -35,19 +39,34 @@ constexpr size_t kWdLdsBytes = (size_t)3 * kWdSlot + kS3W3 + kWdSmall;
 static_assert(kWdLdsBytes <= 160 * 1024, "LDS budget");
 static_assert(2 * kWdSlot >= 128 * PLD * 4, "H2^T (fp32, feature-major) spans two slots");
 
-// one 1 KB piece by LDS-DMA: lane l copies 16 bytes from src_lane (the lane's own address) to LDS byte lds + 16 l.  Inline assembly
-// the compiler does not see (ppo_step_s3_impl.h explains why): the issuing wave waits by hand (s_waitcnt vmcnt(0)) before the barrier
-// that publishes the bytes.
-__device__ __forceinline__ void wd_dma1(const u8 *src_lane, uint32_t lds)
+// one 1 KB piece by LDS-DMA: lane l copies 16 bytes from src + voff (voff = 16 l) to LDS byte lds + 16 l.  Inline assembly the
+// compiler does not see (ppo_step_s3_impl.h explains why): the issuing wave waits by hand (s_waitcnt vmcnt(0)) before the barrier that
+// publishes the bytes.  The address is a wave-uniform base in scalar registers plus ONE 32-bit lane offset shared by every piece: with
+// per-lane 64-bit addresses the compiler computed all of a phase's piece addresses ahead, spilled the register pairs to scratch memory
+// and reloaded one in front of every piece -- and a scratch reload returns behind the pieces already in flight (memory operations
+// return in order): 7k cycles per wave in one quarter of the backward pass (tools/wide_phase_profile.py, first version).
+__device__ __forceinline__ void wd_dma1(const u8 *src, uint32_t voff, uint32_t lds)
 {
-    asm volatile("s_mov_b32 m0, %1\n\t"
-                 "global_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void wd_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// the lane index, computed where it is asked for (the compiler cannot merge two of these): the thread's indices are re-derived at every
+// phase of the kernel instead of living in registers from entry to exit -- long-lived and rarely used, they were what the register
+// allocator spilled to scratch memory first, and a scratch reload returns behind every LDS-DMA piece, gate tile and gradient store in
+// flight (all of the first version's reloads were `tid & 63` and its relatives)
+__device__ __forceinline__ int wd_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// first layer: fwd_s3 (ppo_step_s3_impl.h) with two differences -- GELU' of a finished tile is handed to `done(tile, G)` instead of
-// being kept (two tiles of it are alive at any time), and NO may be 8.  NK in {2, 4}.
+// first layer: fwd_s3 (ppo_step_s3_impl.h) with two differences -- GELU' is handed to `done(tile, k-step, values)` as each k-step's
+// share of a tile is finished instead of being kept, and NO may be 8.  NK in {2, 4}.
 // ---------------------------------------------------------------------------------------------------------
 template <int NK, int NO, int CP, typename Side, typename Done>
 __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (&inP)[NK], const f32x16 (&inH)[(NK + 1) / 2],
@@ -67,7 +86,8 @@ __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (
         dst.m = *reinterpret_cast<const u32x4 *>(p + PBY);
         dst.l = *reinterpret_cast<const u32x4 *>(p + 2 * PBY);
     };
-    f32x16 prev, prev1, Gt[2];
+    f32x16 prev, prev1;
+    float gdt[EP];
     constexpr float kC = 0.84932180028801904272f;
     constexpr float kP = 0.3275911f * 0.70710678118654752440f / kC;
     float z[EP], xa[EP], tt[EP], uu[EP], pp[EP];
@@ -97,10 +117,11 @@ __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (
                 float y = z[i] * pp[i];
                 float gd = fmaf(uu[i], 0.39894228040143267794f, pp[i]);
                 asm volatile("" : "+v"(y), "+v"(gd));
-                Gt[Tp & 1][e] = gd;
+                gdt[i] = gd;
                 outH[Tp][e] = y;
             }
         }
+        if (s == 5) done(Tp, ks, gdt);        // GELU' of elements EP ks .. EP ks + EP - 1 leaves right away
         if (fence) __builtin_amdgcn_sched_barrier(0);
     };
     auto jit = [&](int ks, int s) {
@@ -161,10 +182,6 @@ __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (
             __builtin_amdgcn_sched_barrier(0);
             fill(5);
         }
-        if (To > 0) {
-            done(To - 1, Gt[(To - 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         prev = acc;
         prev1 = acc1;
     }
@@ -174,8 +191,6 @@ __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (
         for (int s = 0; s < 6; ++s) stage(NO - 1, ks, s, false);
     }
     __builtin_amdgcn_sched_barrier(0);
-    done(NO - 1, Gt[(NO - 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -183,8 +198,8 @@ __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (
 // tiles H[2 Q], H[2 Q + 1] (split on the way, behind tile 0's MFMAs).  Two accumulators alternate as in fwd_s3; their sum is folded into
 // Z behind the next tile's MFMAs.
 // ---------------------------------------------------------------------------------------------------------
-template <int Q, int NO, int CP, int NH, typename Side>
-__device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH], f32x16 (&Z)[NO], int m, int hi, const Side &side)
+template <int Q, int NO, int CP, int NH, typename Side, typename Keep>
+__device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH], f32x16 (&Z)[NO], int m, int hi, const Side &side, const Keep &keep)
 {
     static_assert(2 * Q + 1 < NH, "quarter outside the input");
     constexpr int NK = 4, ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
@@ -249,6 +264,11 @@ __device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH],
             __builtin_amdgcn_sched_barrier(0);
             fill(3);
             acc = mfma_bf(a.h, b.m, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (To == 1) {                  // (this k-step's operand is complete since tile 0; its copy for dW2 leaves behind tile 1)
+                keep(ks, inP[ks]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             acc1 = mfma_bf(a.h, b.h, acc1);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -385,8 +405,19 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     constexpr int W1PW = h1 * 48 * CP1 / 1024 / QNW;        // W1 image pieces per wave (12 / 24)
     static_assert(QB % (1024 * QNW) == 0 && QB <= kWdSlot && h1 * 48 * CP1 <= 2 * kWdSlot, "image sizes");
     static_assert(QPW <= 4 * N2 && QPW <= 8 * NK1, "a quarter's pieces ride the k-steps of the phase before");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);      // wave index (scalar)
+    const int wave = wave_u;
+    int lane, m, hi, col, tid;                              // re-derived by refresh() at every phase (see wd_lane)
+    uint32_t lane16;
+    auto refresh = [&]() {
+        lane = wd_lane();
+        m = lane & 31;
+        hi = lane >> 5;
+        col = 32 * wave_u + m;                              // sample slot inside the workgroup
+        tid = 64 * wave_u + lane;
+        lane16 = 16u * (uint32_t)lane;
+    };
+    refresh();
     constexpr int net = ACTOR ? 0 : 1;
     const int S = g.S, OUT = ACTOR ? g.A : 1;
     const Dims d{S, h1, h2, OUT};
@@ -399,28 +430,29 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     float *s_nr = s_b3 + 16, *s_nn = s_nr + 64;
     float *s_red = s_nn + 64;
     constexpr int ld3 = lds_ld(128);
-    float4 *scrG = reinterpret_cast<float4 *>(args.scratch + ((size_t)blockIdx.x * 2 + net) * ((8 + N2) * 16 * QNT)) + tid;
-    float4 *scrH = scrG + 8 * 4 * QNT;
+    float *scr0 = args.scratch + ((size_t)blockIdx.x * 2 + net) * wd_scratch_floats(N2);
+    // register tile T (0..7: GELU'(z1); 8..: H2), quad r of this thread: wave-uniform base + the thread's 16 bytes
+    auto scr_tile = [&](int T, int r) -> float4 & { return reinterpret_cast<float4 *>(scr0 + (size_t)(4 * T + r) * QNT * 4)[tid]; };
+    u8 *scrI = reinterpret_cast<u8 *>(scr0 + (8 + N2) * 16 * QNT);      // H1 quarter images
 
     // the wave's share of a DMA transfer: pieces [QPW wave, QPW (wave + 1)) of a quarter, [W1PW wave, ...) of the W1 image
     const uint32_t ldsXw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + QPW * 1024 * wave));
     const uint32_t ldsYw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLY + QPW * 1024 * wave));
     const uint32_t ldsAw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLA + W1PW * 1024 * wave));
-    const u8 *w2src = g.w2img[net] + 16 * lane + QPW * 1024 * wave;
-    auto dma_q = [&](int q, uint32_t slot_w, int i) { wd_dma1(w2src + (size_t)q * QB + 1024 * i, slot_w + 1024u * i); };
+    const u8 *w2src = g.w2img[net] + QPW * 1024 * wave_u;
+    auto dma_q = [&](int q, uint32_t slot_w, int i) { wd_dma1(w2src + (size_t)q * QB + 1024 * i, lane16, slot_w + 1024u * i); };
 
-    PROF(0);
     // ---- prologue: the sample id; the W1 image by LDS-DMA; biases, W3, normalisation constants (every load unconditional: see
     //      ppo_step_s3_impl.h)
-    const int col = 32 * wave + m;
+    PROF(0);
     const int64_t bidx = (int64_t)blockIdx.x * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
     const AdvNorm advn = adv_norm_consts(ACTOR ? g.adv_stats : nullptr);
     {
-        const u8 *src1 = g.w1img[net] + 16 * lane + W1PW * 1024 * wave;
+        const u8 *src1 = g.w1img[net] + W1PW * 1024 * wave_u;
 #pragma unroll
-        for (int i = 0; i < W1PW; ++i) wd_dma1(src1 + 1024 * i, ldsAw + 1024u * i);
+        for (int i = 0; i < W1PW; ++i) wd_dma1(src1 + 1024 * i, lane16, ldsAw + 1024u * i);
     }
     float4 c3[2];
 #pragma unroll
@@ -477,8 +509,9 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         s_nn[tid] = tid < S ? -(avg_raw * nr) : 0.f;
     }
     wd_wait_dma();                                                   // this wave's pieces of the W1 image (and every load above)
-    lds_barrier();                                                   // (0a) W1 image, biases, constants visible; RW3 zeroed
-    PROF(1);
+    lds_barrier();
+    refresh();                                                   // (0a) W1 image, biases, constants visible; RW3 zeroed
+    PROF_NV(1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                                    // W3 copy [16][ld3], rows >= OUT zero; visible after (0b)
         const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
@@ -504,16 +537,18 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     f32x16 H1[N1];
     {
         auto side = [&](int c) { if (c < QPW) dma_q(0, ldsYw, c); };
-        auto done = [&](int Tp, const f32x16 &G) {
+        constexpr int EP1 = 16 / NK1;                                 // elements of a tile finished per k-step: one or two quads
+        auto done = [&](int Tp, int ks, const float (&gd)[EP1]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scrG[(4 * Tp + r) * QNT] = make_float4(G[4 * r], G[4 * r + 1], G[4 * r + 2], G[4 * r + 3]);
+            for (int r = 0; r < EP1 / 4; ++r) scr_tile(Tp, ks * (EP1 / 4) + r) = make_float4(gd[4 * r], gd[4 * r + 1], gd[4 * r + 2], gd[4 * r + 3]);
         };
         fwd_wd<NK1, N1, CP1>(SLA, s_b1, Xp, XH, H1, m, hi, side, done);
     }
-    PROF(2);
+    PROF_NV(2);
     wd_wait_dma();
-    lds_barrier();                                                   // (0b) quarter 0, W3 copy visible; every wave is done with the W1 image
-    PROF(3);
+    lds_barrier();
+    refresh();                                                   // (0b) quarter 0, W3 copy visible; every wave is done with the W1 image
+    PROF_NV(3);
     {
         Parts Xs[2 * KX];
 #pragma unroll
@@ -534,30 +569,55 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         }
     }
     {
+        // the split H1 operand of every k-step also leaves for the scratch block, in the layout of the dW2 operand image (stage_s3's)
+        const int isw = swz<CPQ>(col);
+        uint32_t ioff[4];                                             // this lane's byte offset of k-step ks inside a quarter image
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ioff[ks] = (uint32_t)(col * (48 * CPQ) + 16 * ((2 * ks + hi) ^ isw));
+        auto keep_q = [&](int q) {
+            return [=](int ks, const Parts &p) {
+                u8 *ub = scrI + q * kWdH1ImgBytes;                      // wave-uniform
+                *reinterpret_cast<u32x4 *>(ub + ioff[ks]) = p.h;
+                *reinterpret_cast<u32x4 *>(ub + 16 * CPQ + ioff[ks]) = p.m;
+                *reinterpret_cast<u32x4 *>(ub + 32 * CPQ + ioff[ks]) = p.l;
+            };
+        };
         auto s1 = [&](int c) { if (c < QPW) dma_q(1, ldsXw, c); };
-        fwd_acc_wd<0, N2, CPQ>(SLY, H1, Z2, m, hi, s1);
+        fwd_acc_wd<0, N2, CPQ>(SLY, H1, Z2, m, hi, s1, keep_q(0));
         wd_wait_dma();
-        lds_barrier();                                               // quarter 1 visible; every wave is done with quarter 0
+        lds_barrier();
+        refresh();
+    refresh();                                               // quarter 1 visible; every wave is done with quarter 0
+        PROF_NV(4);
         auto s2 = [&](int c) { if (c < QPW) dma_q(2, ldsYw, c); };
-        fwd_acc_wd<1, N2, CPQ>(SLX, H1, Z2, m, hi, s2);
+        fwd_acc_wd<1, N2, CPQ>(SLX, H1, Z2, m, hi, s2, keep_q(1));
         wd_wait_dma();
         lds_barrier();
+        refresh();
+    refresh();
+        PROF_NV(5);
         auto s3 = [&](int c) { if (c < QPW) dma_q(3, ldsXw, c); };
-        fwd_acc_wd<2, N2, CPQ>(SLY, H1, Z2, m, hi, s3);
+        fwd_acc_wd<2, N2, CPQ>(SLY, H1, Z2, m, hi, s3, keep_q(2));
         wd_wait_dma();
         lds_barrier();
-        fwd_acc_wd<3, N2, CPQ>(SLX, H1, Z2, m, hi, NoSide());       // quarter 2 stays in Y, quarter 3 in X: the backward pass starts there
+        refresh();
+    refresh();
+        PROF_NV(6);
+        fwd_acc_wd<3, N2, CPQ>(SLX, H1, Z2, m, hi, NoSide(), keep_q(3));       // quarter 2 stays in Y, quarter 3 in X: the backward pass starts there
+        PROF_NV(7);
     }
+    refresh();
     f32x16 H2[N2], G2[N2];
 #pragma unroll
     for (int To = 0; To < N2; ++To) {
         gelu_tile(Z2[To], H2[To], G2[To]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scrH[(4 * To + r) * QNT] = make_float4(H2[To][4 * r], H2[To][4 * r + 1], H2[To][4 * r + 2], H2[To][4 * r + 3]);
+        for (int r = 0; r < 4; ++r) scr_tile(8 + To, r) = make_float4(H2[To][4 * r], H2[To][4 * r + 1], H2[To][4 * r + 2], H2[To][4 * r + 3]);
     }
-    PROF(4);
 
+    PROF_NV(8);
+    refresh();
     // ---- output layer (fp32, as in ppo_step_s3_impl.h: H2[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j)
     float Y[4] = {0.f, 0.f, 0.f, 0.f};
     if (ACTOR) {
@@ -598,8 +658,8 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         const float s = (yp.x + yp.y) + (yq.x + yq.y);
         Y[0] = s + __shfl_xor(s, 32, 64) + s_b3[0];
     }
-    PROF(5);
 
+    refresh();
     // ---- objective and dL/dY for this lane's outputs a = 4 hi + j   (AgentPPO.py:189-204)
     float dY[4] = {0.f, 0.f, 0.f, 0.f};
     float loss0 = 0.f, loss1 = 0.f;
@@ -639,8 +699,8 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         }
     }
 
+    refresh();
     // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 8 outputs: four fp32 k-pairs; A-row m carries feature 32 To + phi(m))
-    PROF(6);
     {
         const int pm = phi(m);
         float w3[N2][4];
@@ -659,6 +719,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         }
     }
 
+    PROF_NV(9);
     // ---- dZ1 = (W2^T dZ2) * GELU'(z1), quarter by quarter (3, 2 resident; 1, 0 streamed back), each contracted with the input
     //      (dW1, db1) as soon as it is staged
     float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
@@ -670,9 +731,19 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float4 v = scrG[(4 * (2 * q + t) + r) * QNT];
+                const float4 v = scr_tile(2 * q + t, r);
                 Gq[t][4 * r] = v.x; Gq[t][4 * r + 1] = v.y; Gq[t][4 * r + 2] = v.z; Gq[t][4 * r + 3] = v.w;
             }
+        }
+    };
+    // the gate tiles requested a phase ago are IN their registers as far as the compiler is concerned (called right after a
+    // s_waitcnt vmcnt(0)): a compiler-placed wait for them inside the next quarter would also wait for every LDS-DMA piece issued
+    // there before it (memory operations return in order) -- 7k cycles per wave in the first version of this kernel
+    auto gate_arrived = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(Gq[t][e]));
         }
     };
     auto dw1 = [&](int q, const u8 *slot) {
@@ -684,10 +755,12 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
             if (jc == 0) grad_bias(A, slab + d.ob1() + 64 * q, it, lane);
         }
     };
+    refresh();
     load_gate(3);
     bwd_wd<2 * N2, 2, CPQ, false>(SLX, dZ2p, G2, Gq, dZ1q, lane, NoSide());     // splits dZ2 into dZ2p on the way
-    PROF(7);
-    lds_barrier();                                                   // (1) every wave is done with quarter 3 (X) and with W3
+    PROF_NV(10);
+    lds_barrier();
+    refresh();                                                   // (1) every wave is done with quarter 3 (X) and with W3
     stage_s3<4, CPQ, 0>(SLX, dZ1q, col, hi);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -695,37 +768,65 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         RC[(8 + 4 * hi + j) * PLD + col] = dsl[j];       // rows 8..15: per-sample dL/dstd_log (zero for the critic)
     }
     load_gate(2);
-    lds_barrier();                                                   // (2) dZ1 quarter 3 (and, long since, the X image) visible
-    PROF(8);
+    lds_barrier();
+    refresh();                                                   // (2) dZ1 quarter 3 (and, long since, the X image) visible
+    PROF_NV(11);
     dw1(3, SLX);
+    refresh();
+    PROF_NV(12);
     bwd_wd<2 * N2, 2, CPQ, true>(SLY, dZ2p, G2, Gq, dZ1q, lane, NoSide());
-    lds_barrier();                                                   // (3) quarter 2 (Y) and the dZ1 image in X consumed
+    PROF_NV(13);
+    lds_barrier();
+    refresh();                                                   // (3) quarter 2 (Y) and the dZ1 image in X consumed
     stage_s3<4, CPQ, 0>(SLY, dZ1q, col, hi);
 #pragma unroll
     for (int i = 0; i < QPW; ++i) dma_q(1, ldsXw, i);                // quarter 1 comes back into X
     load_gate(1);
-    lds_barrier();                                                   // (4)
+    lds_barrier();
+    refresh();                                                   // (4)
+    PROF_NV(14);
     dw1(2, SLY);
     wd_wait_dma();
-    lds_barrier();                                                   // (5) quarter 1 visible; the dZ1 image in Y consumed
+    gate_arrived();
+    lds_barrier();
+    refresh();                                                   // (5) quarter 1 visible; the dZ1 image in Y consumed
+    PROF_NV(15);
     {
         auto s0 = [&](int c) { if (c < QPW) dma_q(0, ldsYw, c); };   // quarter 0 comes back into Y behind quarter 1's MFMAs
         bwd_wd<2 * N2, 2, CPQ, true>(SLX, dZ2p, G2, Gq, dZ1q, lane, s0);
     }
-    lds_barrier();                                                   // (6)
+    PROF_NV(16);
+    lds_barrier();
+    refresh();                                                   // (6)
     stage_s3<4, CPQ, 0>(SLX, dZ1q, col, hi);
     load_gate(0);
-    lds_barrier();                                                   // (7)
+    lds_barrier();
+    refresh();                                                   // (7)
+    PROF_NV(17);
     dw1(1, SLX);
     wd_wait_dma();
-    lds_barrier();                                                   // (8) quarter 0 visible; the dZ1 image in X consumed
+    gate_arrived();
+    lds_barrier();
+    refresh();                                                   // (8) quarter 0 visible; the dZ1 image in X consumed
+    PROF_NV(18);
     bwd_wd<2 * N2, 2, CPQ, true>(SLY, dZ2p, G2, Gq, dZ1q, lane, NoSide());
-    lds_barrier();                                                   // (9)
+    PROF_NV(19);
+    lds_barrier();
+    refresh();                                                   // (9)
     stage_s3<4, CPQ, 0>(SLY, dZ1q, col, hi);
-    lds_barrier();                                                   // (10)
+    lds_barrier();
+    refresh();                                                   // (10)
+    PROF_NV(20);
+    float4 h2v[N2][4];                                               // H2 comes back under dW1's last quarter
+#pragma unroll
+    for (int t = 0; t < N2; ++t) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) h2v[t][r4] = scr_tile(8 + t, r4);
+    }
     dw1(0, SLY);
-    PROF(9);
-    lds_barrier();                                                   // (11) X, Y, the X image in A consumed
+    lds_barrier();
+    refresh();                                                   // (11) X, Y, the X image in A consumed
+    PROF_NV(21);
 
     // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2 back from the scratch block, staged feature-major in X + Y)
     {
@@ -734,7 +835,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         for (int t = 0; t < N2; ++t) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 v = scrH[(4 * t + r4) * QNT];
+                const float4 v = h2v[t][r4];
                 const float hv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -744,8 +845,9 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
             }
         }
     }
-    lds_barrier();                                                   // (12)
-    PROF(10);
+    lds_barrier();
+    refresh();                                                   // (12)
+    PROF_NV(22);
     {
         const float *T2 = reinterpret_cast<const float *>(SLX);
         const int l15 = lane & 15, q = lane >> 4;
@@ -783,17 +885,26 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
             else if (ACTOR && l15 >= 8 && l15 - 8 < OUT) slab[d.oStd() + l15 - 8] = s;
         }
     }
-    lds_barrier();                                                   // (13) H2^T consumed
-    auto stage_h1 = [&](int q, u8 *slot) {                           // H1's features 64 q .. 64 q + 63, re-split from the registers
-        Parts p[4];
+    lds_barrier();
+    refresh();                                                   // (13) H2^T consumed
+    PROF_NV(23);
+    // H1's quarter images come back from the scratch block by LDS-DMA (every wave its share of the 1 KB pieces): quarter 0 into A now
+    // (the X image was consumed before (11)), 1 and 2 into X and Y once the dZ2 image is in registers, 3 into A behind quarter 0
+    constexpr int HPW = kWdH1ImgBytes / 1024 / QNW;                  // pieces per wave (12)
+    const u8 *isrc = scrI + HPW * 1024 * wave_u;
+    const uint32_t ldsAh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLA + HPW * 1024 * wave));
+    const uint32_t ldsXh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + HPW * 1024 * wave));
+    const uint32_t ldsYh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLY + HPW * 1024 * wave));
+    auto dma_h1 = [&](int q, uint32_t slot_w) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) p[ks] = split8(H1[2 * q + (ks >> 1)], ks & 1);
-        stage_s3<4, CPQ, 0>(slot, p, col, hi);
+        for (int i = 0; i < HPW; ++i) wd_dma1(isrc + (size_t)q * kWdH1ImgBytes + 1024 * i, lane16, slot_w + 1024u * i);
     };
+    dma_h1(0, ldsAh);
     stage_s3<2 * N2, CPH2, 0>(SLX, dZ2p, col, hi);                   // the dZ2 image spans X + Y
-    stage_h1(0, SLA);
-    lds_barrier();                                                   // (14)
-    PROF(11);
+    wd_wait_dma();
+    lds_barrier();
+    refresh();                                                   // (14)
+    PROF_NV(24);
 
     // ---- layer 2: dW2 = dZ2^T . H1, db2  (wave w: row tile w % N2 of dZ2^T, read once into registers; H1 passes by in quarters)
     {
@@ -801,19 +912,30 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         const int it = wave % N2, jc = wave / N2;
         Parts A[8];
         grad_a_load<CPH2>(SLX, it, A, lane);
-        lds_barrier();                                               // (15) the dZ2 image is in registers: X, Y are free
-        stage_h1(1, SLX);
-        stage_h1(2, SLY);
+        lds_barrier();
+        refresh();
+    refresh();                                               // (15) the dZ2 image is in registers: X, Y are free
+        PROF_NV(25);
+        dma_h1(1, ldsXh);
+        dma_h1(2, ldsYh);
         grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 0, slab + d.oW2(), h1, h1, lane);
-        lds_barrier();                                               // (16) quarters 1, 2 visible; quarter 0 (A) consumed
-        stage_h1(3, SLA);
+        wd_wait_dma();
+        lds_barrier();
+        refresh();
+    refresh();                                               // (16) quarters 1, 2 visible; quarter 0 (A) consumed
+        PROF_NV(26);
+        dma_h1(3, ldsAh);
         grad_tiles<CPQ, NBW, CS>(A, SLX, it, jc, 2, slab + d.oW2(), h1, h1, lane);
         grad_tiles<CPQ, NBW, CS>(A, SLY, it, jc, 4, slab + d.oW2(), h1, h1, lane);
-        lds_barrier();                                               // (17)
+        wd_wait_dma();
+        lds_barrier();
+        refresh();
+    refresh();                                               // (17)
+        PROF_NV(27);
         grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 6, slab + d.oW2(), h1, h1, lane);
         if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
     }
-    PROF(12);
+    PROF(28);
 
     // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
     const float t0 = block_sum(loss0, s_red);
