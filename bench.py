@@ -59,6 +59,14 @@ PPO_CONFIGS = {
                net_dims=[128, 64], hyper=dict(gamma=0.97, reward_scale=0.25, learning_rate=4e-4),
                workload="BASELINE configs[1]: AgentPPO, GPU-resident vectorised Pendulum-v1, 4096 envs, horizon 200, "
                         "40 minibatches x 16384, net [128,64], fp32"),
+    # not a BASELINE configuration: the network of the reference's LunarLanderContinuous demo (examples/demo_A2C_PPO.py:117,
+    # net_dims (256, 128), with its hyper-parameters :118-125) on a synthetic VecEnv of that env's shape, vectorised like configs[3];
+    # its minibatch loop runs on csrc/ppo_step_wd_impl.h (rollout and value pre-pass on the layered erl_mlpn_* path)
+    "cw": dict(metric="env_steps_per_sec_ppo_net256x128_lunarlander_shaped_4096envs", env="syn", N=4096, S=8, A=2, H=32, B=16384,
+               update_times=40, net_dims=[256, 128],
+               hyper=dict(gamma=0.99, reward_scale=0.5, learning_rate=2e-4, lambda_gae_adv=0.97, lambda_entropy=0.04),
+               workload="reference demo network net_dims (256,128) (examples/demo_A2C_PPO.py:117-125 hyper-parameters) on a "
+                        "LunarLanderContinuous-shaped synthetic VecEnv obs_dim=8 act_dim=2, 4096 envs/GPU, horizon 32, 40 minibatches x 16384, fp32"),
 }
 N_ENVS, STATE_DIM, ACTION_DIM, HORIZON, BATCH, UPDATE_TIMES, NET_DIMS = 4096, 64, 8, 32, 16384, 40, [128, 128]
 
@@ -141,6 +149,8 @@ KERNEL_SOURCES = {
                            "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "ppo_step2_kernel": ["ppo_step.hip", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
     "gae_lookback_kernel": ["gae_lookback.hip"],
+    "ppo_step_wd_kernel": ["ppo_step_wd_impl.h", "ppo_step_wd.hip", "ppo_step_wd.h", "ppo_step_s3_impl.h", "split_bf16.h", "s3_image.h",
+                           "ppo_step_w4_impl.h", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
 }
 PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 KTIME_FILE = os.path.join("profiles", "r04_kernel_times.json")     # tools/kstats_summarise.py over rocprofv3 --kernel-trace --stats of this command
@@ -375,7 +385,7 @@ def main():
                     help="after the primary timed region, repeat it this many times and report min / median / max ms per step "
                          "(`extra`; box variance next to the one primary sample; 0 = off)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5"], default="c4",
+    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5", "cw"], default="c4",
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
                          "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs")
     opt = ap.parse_args()
@@ -469,7 +479,8 @@ def main():
     # the same region on the fp32-MFMA minibatch kernel (when the default is the split-arithmetic one), for the record
     f32_region = None
     k6_arith = ops.ppo_arith_in_use(STATE_DIM, NET_DIMS[0], NET_DIMS[1], ACTION_DIM) if len(NET_DIMS) == 2 else "f32"
-    if k6_arith == "split" and opt.repeats:
+    wide = bool(getattr(agent, "_wide", False))             # net_dims (256, h2): one kernel, split arithmetic only
+    if k6_arith == "split" and opt.repeats and not wide:
         prev_arith, agent.ppo_arith = agent.ppo_arith, "f32"      # (the agent applies its ppo_arith at every update_net)
         for _ in range(2):
             step()
@@ -524,7 +535,7 @@ def main():
     k6_kernel = "ppo_step_w4_kernel" if (len(NET_DIMS) == 2 and all(d in (64, 128) for d in NET_DIMS) and STATE_DIM <= 64
                                          and ACTION_DIM <= 8) else "ppo_step2_kernel"
     if k6_arith == "split":
-        k6_kernel = "ppo_step_s3_kernel"
+        k6_kernel = "ppo_step_wd_kernel" if wide else "ppo_step_s3_kernel"
     # the fp32-equivalent ceiling of the pipe the kernel runs on: the split-arithmetic kernel issues SPLIT_TERMS bf16 MFMA flops per
     # algorithmic flop on the bf16 matrix pipe; the fp32 kernel runs on the fp32 MFMA
     k6_peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS if k6_arith == "split" else MFMA_F32_PEAK_TFLOPS

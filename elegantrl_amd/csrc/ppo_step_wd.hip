@@ -1,7 +1,8 @@
 // K6 for net_dims = (256, h2) (templates: ppo_step_wd_impl.h): instantiations, the scratch blocks and the entry point behind
 // erl_ppo_step_f32 / erl_ppo_update_dp_f32 for this shape class.
-#include "ppo_step_wd_impl.h"
+#include "ppo_step_wd_args.h"
 #include "ppo_step_wd.h"
+#include "erl_common.h"
 
 unsigned long long *erl_k6_timing_begin(hipStream_t stream);   // api.cpp (measurement hook, no-op unless enabled)
 void erl_k6_timing_end(hipStream_t stream);
@@ -56,13 +57,6 @@ int wd_scratch(size_t floats, hipStream_t stream, float **out)
     return ERL_OK;
 }
 
-template <int N2>
-int launch_wd_shape(const PpoWdArgs &a, int n_slabs, bool vec, hipStream_t stream)
-{
-    if (vec) return a.g.S > 32 ? launch_wd<2, N2, true>(a, n_slabs, stream) : launch_wd<1, N2, true>(a, n_slabs, stream);
-    return a.g.S > 32 ? launch_wd<2, N2, false>(a, n_slabs, stream) : launch_wd<1, N2, false>(a, n_slabs, stream);
-}
-
 }  // namespace
 
 int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std, const float *cri_avg,
@@ -110,7 +104,8 @@ int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states);
     g.span = erl_k6_timing_begin(st);
-    rc = h2 == 128 ? launch_wd_shape<4>(a, n_slabs, vec, st) : launch_wd_shape<2>(a, n_slabs, vec, st);
+    if (h2 == 128) rc = S > 32 ? erl_ppo_wd_launch_24(a, n_slabs, vec, st) : erl_ppo_wd_launch_14(a, n_slabs, vec, st);
+    else rc = S > 32 ? erl_ppo_wd_launch_22(a, n_slabs, vec, st) : erl_ppo_wd_launch_12(a, n_slabs, vec, st);
     erl_k6_timing_end(st);
     return rc;
 }

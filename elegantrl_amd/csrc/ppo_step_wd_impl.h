@@ -21,18 +21,23 @@
 // output layer -- is ppo_step_s3_impl.h's, whose helpers this file uses.
 #pragma once
 #include "ppo_step_s3_impl.h"
+#include "ppo_step_wd_args.h"
 
 namespace {
 
-struct PpoWdArgs {
-    Ppo2Args g;          // w2img: the four quarter images, contiguous; w1img: [256][3][K1]
-    float *scratch;      // [n_slabs][2 networks] blocks of wd_scratch_floats(N2): GELU'(z1) tiles | H2 tiles | four H1 quarter images
-};
-// per workgroup and network: (8 + N2) register tiles [16][256 threads] fp32, then H1 as four sample-major quarter images
-// [128 samples][3 parts][64 bf16] (the LDS layout of the dW2 operand: they come back by LDS-DMA)
-constexpr int kWdH1ImgBytes = 128 * 384;
-__host__ __device__ constexpr size_t wd_scratch_floats(int N2) { return (size_t)(8 + N2) * 16 * 256 + 4 * kWdH1ImgBytes / 4; }
-
+// ERL_WD_LAST = 1: the second layer's GELU rides the last quarter's MFMAs (fwd_acc_wd<LAST>) instead of running on its own on packed
+// fp32 -- measured slower (quarter 3: 4.6k -> 10.5k cycles for 3.3k of GELU saved; 17 scalar-fp32 instructions per element against
+// 12.5 packed, and six MFMAs hide four or five of them): off.  ERL_WD_GATE_EARLY = 1: the first gate tiles of the backward pass are
+// requested before the output layer (dZ1's first quarter: 8.1k -> 5.3k cycles).
+#ifndef ERL_WD_LAST
+#define ERL_WD_LAST 0
+#endif
+#ifndef ERL_WD_GATE_EARLY
+#define ERL_WD_GATE_EARLY 1
+#endif
+#ifndef ERL_WD_DBG
+#define ERL_WD_DBG 0
+#endif
 constexpr int kWdSlot = 49152;
 constexpr int kWdSmall = (256 + 128 + 16 + 64 + 64 + 16) * 4;
 constexpr size_t kWdLdsBytes = (size_t)3 * kWdSlot + kS3W3 + kWdSmall;
@@ -198,8 +203,11 @@ __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (
 // tiles H[2 Q], H[2 Q + 1] (split on the way, behind tile 0's MFMAs).  Two accumulators alternate as in fwd_s3; their sum is folded into
 // Z behind the next tile's MFMAs.
 // ---------------------------------------------------------------------------------------------------------
-template <int Q, int NO, int CP, int NH, typename Side, typename Keep>
-__device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH], f32x16 (&Z)[NO], int m, int hi, const Side &side, const Keep &keep)
+// LAST: this is the layer's last quarter -- behind tile To's MFMAs the finished sum of tile To - 1 goes through the GELU stages of
+// fwd_wd (outH, outG instead of Z).
+template <int Q, int NO, int CP, bool LAST, int NH, typename Side, typename Keep>
+__device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH], f32x16 (&Z)[NO], int m, int hi, const Side &side, const Keep &keep,
+                                           f32x16 *outH = nullptr, f32x16 *outG = nullptr)
 {
     static_assert(2 * Q + 1 < NH, "quarter outside the input");
     constexpr int NK = 4, ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
@@ -233,6 +241,42 @@ __device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH],
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // LAST: exact-erf GELU and its derivative of elements 4 ks .. 4 ks + 3 of tile Tp, stage s of 6 (fwd_wd's)
+    constexpr float kC = 0.84932180028801904272f;
+    constexpr float kP = 0.3275911f * 0.70710678118654752440f / kC;
+    float z[4], xa[4], tt[4], uu[4], pp[4];
+    auto stage = [&](int Tp, int ks, int s, bool fence = true) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * ks + i;
+            if (s == 0) {
+                z[i] = prev[e] + prev1[e];
+                xa[i] = fabsf(z[i]) * kC;
+                tt[i] = fmaf(xa[i], kP, 1.0f);
+            } else if (s == 1) {
+                tt[i] = __builtin_amdgcn_rcpf(tt[i]);
+                uu[i] = __builtin_amdgcn_exp2f(-(xa[i] * xa[i]));
+            } else if (s == 2) {
+                pp[i] = fmaf(tt[i], 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * 1.421413741f);
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * -0.284496736f);
+            } else if (s == 3) {
+                pp[i] = fmaf(tt[i], pp[i], 0.5f * 0.254829592f);
+                pp[i] = pp[i] * tt[i];
+                pp[i] = fmaf(-pp[i], uu[i], 0.5f);
+            } else if (s == 4) {
+                pp[i] = copysignf(pp[i], z[i]) + 0.5f;
+                uu[i] = z[i] * uu[i];
+            } else {
+                float y = z[i] * pp[i];
+                float gd = fmaf(uu[i], 0.39894228040143267794f, pp[i]);
+                asm volatile("" : "+v"(y), "+v"(gd));
+                outG[Tp][e] = gd;
+                outH[Tp][e] = y;
+            }
+        }
+        if (fence) __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll
     for (int s = 0; s < 4; ++s) jit(0, s);
     issue(0, aq[0]);
@@ -247,6 +291,7 @@ __device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH],
             const Parts &a = aq[c & 1], &b = inP[ks];
             auto fill = [&](int s) {
                 if (To == 0) jit(ks + 1, s);
+                else if (LAST) stage(To - 1, ks, s);
                 else if (s == 0) merge(To - 1, ks);
             };
             acc = mfma_bf(a.m, b.m, acc);
@@ -265,18 +310,29 @@ __device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH],
             fill(3);
             acc = mfma_bf(a.h, b.m, acc);
             __builtin_amdgcn_sched_barrier(0);
+            if (LAST && To > 0) fill(4);
             if (To == 1) {                  // (this k-step's operand is complete since tile 0; its copy for dW2 leaves behind tile 1)
                 keep(ks, inP[ks]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc1 = mfma_bf(a.h, b.h, acc1);
             __builtin_amdgcn_sched_barrier(0);
+            if (LAST && To > 0) fill(5);
         }
         prev = acc;
         prev1 = acc1;
     }
+    if (LAST) {
+        // the last tile has no MFMAs to ride behind: unfenced, so that its elements' chains interleave
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Z[NO - 1][e] = prev[e] + prev1[e];
+        for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) stage(NO - 1, ks, s, false);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Z[NO - 1][e] = prev[e] + prev1[e];
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -454,16 +510,23 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
 #pragma unroll
         for (int i = 0; i < W1PW; ++i) wd_dma1(src1 + 1024 * i, lane16, ldsAw + 1024u * i);
     }
-    float4 c3[2];
+    // The prologue's loads AND stores are unconditional -- no block of it runs under a partial EXEC mask (a wave's whole mask can be
+    // empty there: `tid < 64` in waves 1..3, the second W3 pass at h2 = 64).  hipcc put a live-range split of the thread index (a copy
+    // into an AGPR, read back much later) at the end of such a block: lanes inactive at the copy read garbage back, and the logged sums
+    // of the (8, 256, 64, 2) shape were summed over stale LDS (tests/test_ppo_wide_gpu.py caught it).  Guarded stores become stores of
+    // selected values at wrapped / clamped indices (two threads may write the same value to the same place).
+    constexpr int NU3 = 16 * (h2 / 4) / QNT;                // float4 of the W3 copy per thread: rows [16][h2], 1 (h2 = 64) or 2
+    static_assert(NU3 * QNT == 16 * (h2 / 4), "W3 copy passes");
+    float4 c3[NU3];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {                           // W3 rows [16][h2] (rows >= OUT zeroed when stored)
+    for (int u = 0; u < NU3; ++u) {                         // W3 rows [16][h2] (rows >= OUT zeroed when stored)
         const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
         c3[u] = load4<VEC>(P + d.oW3() + (size_t)min(i, OUT - 1) * h2, 4 * j4, h2);
     }
     const float b1_raw = P[d.ob1() + tid];
-    const float b2_raw = P[d.ob2() + min(tid, h2 - 1)];
-    const float b3_raw = P[d.ob3() + min(tid, OUT - 1)];
-    const float sd_raw = g.sd[net][min(tid, S - 1)], avg_raw = g.avg[net][min(tid, S - 1)];
+    const float b2_raw = P[d.ob2() + min(tid & 127, h2 - 1)];
+    const float b3_raw = P[d.ob3() + min(tid & 15, OUT - 1)];
+    const float sd_raw = g.sd[net][min(tid & 63, S - 1)], avg_raw = g.avg[net][min(tid & 63, S - 1)];
 
     // ---- id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
     int64_t n_, t_;
@@ -499,23 +562,23 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         }
     }
 #pragma unroll
-    for (int e = tid; e < kS3W3 / 16; e += QNT) reinterpret_cast<float4 *>(RW3)[e] = zero4();
+    for (int u = 0; u < (kS3W3 / 16 + QNT - 1) / QNT; ++u) reinterpret_cast<float4 *>(RW3)[min(tid + u * QNT, kS3W3 / 16 - 1)] = zero4();
     s_b1[tid] = b1_raw;
-    if (tid < 128) s_b2[tid] = tid < h2 ? b2_raw : 0.f;
-    if (tid < 16) s_b3[tid] = tid < OUT ? b3_raw : 0.f;
-    if (tid < 64) {
+    s_b2[tid & 127] = (tid & 127) < h2 ? b2_raw : 0.f;
+    s_b3[tid & 15] = (tid & 15) < OUT ? b3_raw : 0.f;
+    {
         const float nr = __builtin_amdgcn_rcpf(sd_raw + 1e-4f);                  // (x - avg) / (std + 1e-4)  (AgentPPO.py:360-361)
-        s_nr[tid] = tid < S ? nr : 0.f;
-        s_nn[tid] = tid < S ? -(avg_raw * nr) : 0.f;
+        s_nr[tid & 63] = (tid & 63) < S ? nr : 0.f;
+        s_nn[tid & 63] = (tid & 63) < S ? -(avg_raw * nr) : 0.f;
     }
     wd_wait_dma();                                                   // this wave's pieces of the W1 image (and every load above)
     lds_barrier();
     refresh();                                                   // (0a) W1 image, biases, constants visible; RW3 zeroed
     PROF_NV(1);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {                                    // W3 copy [16][ld3], rows >= OUT zero; visible after (0b)
+    for (int u = 0; u < NU3; ++u) {                                  // W3 copy [16][ld3], rows >= OUT zero; visible after (0b)
         const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
-        if (i < 16) *reinterpret_cast<float4 *>(RW3 + i * ld3 + 4 * j4) = i < OUT ? c3[u] : zero4();
+        *reinterpret_cast<float4 *>(RW3 + i * ld3 + 4 * j4) = i < OUT ? c3[u] : zero4();
     }
     // ---- normalise the own row; its split rides behind the first output tile's MFMAs of the first layer
     Parts Xp[NK1];
@@ -557,7 +620,17 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     }
 
     // ---- second layer, K split in quarters: q0 (Y) | q1 (X) | q2 (Y) | q3 (X); quarter q + 1 streams in behind quarter q's MFMAs
-    f32x16 Z2[N2];
+    f32x16 Z2[N2], H2[N2], G2[N2], Gq[2];
+    auto load_gate = [&](int q) {                                    // GELU'(z1) tiles 2 q, 2 q + 1 back from the scratch block
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 v = scr_tile(2 * q + t, r);
+                Gq[t][4 * r] = v.x; Gq[t][4 * r + 1] = v.y; Gq[t][4 * r + 2] = v.z; Gq[t][4 * r + 3] = v.w;
+            }
+        }
+    };
 #pragma unroll
     for (int To = 0; To < N2; ++To) {
 #pragma unroll
@@ -570,51 +643,60 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     }
     {
         // the split H1 operand of every k-step also leaves for the scratch block, in the layout of the dW2 operand image (stage_s3's)
-        const int isw = swz<CPQ>(col);
-        uint32_t ioff[4];                                             // this lane's byte offset of k-step ks inside a quarter image
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ioff[ks] = (uint32_t)(col * (48 * CPQ) + 16 * ((2 * ks + hi) ^ isw));
+        // (in the order the lanes hold it: block [wave][k-step][part] of 64 lanes x 16 bytes, one whole 1 KB line group per store --
+        // stored in image order, 32 rows of 384 bytes per instruction, a quarter's twelve stores cost ~2.4k cycles; the DMA that brings
+        // the image back gathers instead: every lane of a piece fetches the 16 bytes that belong at its LDS position, h1_gather below)
         auto keep_q = [&](int q) {
             return [=](int ks, const Parts &p) {
-                u8 *ub = scrI + q * kWdH1ImgBytes;                      // wave-uniform
-                *reinterpret_cast<u32x4 *>(ub + ioff[ks]) = p.h;
-                *reinterpret_cast<u32x4 *>(ub + 16 * CPQ + ioff[ks]) = p.m;
-                *reinterpret_cast<u32x4 *>(ub + 32 * CPQ + ioff[ks]) = p.l;
+                u8 *ub = scrI + q * kWdH1ImgBytes + wave_u * (kWdH1ImgBytes / QNW) + ks * 3072;     // wave-uniform
+                *reinterpret_cast<u32x4 *>(ub + lane16) = p.h;
+                *reinterpret_cast<u32x4 *>(ub + 1024 + lane16) = p.m;
+                *reinterpret_cast<u32x4 *>(ub + 2048 + lane16) = p.l;
             };
         };
         auto s1 = [&](int c) { if (c < QPW) dma_q(1, ldsXw, c); };
-        fwd_acc_wd<0, N2, CPQ>(SLY, H1, Z2, m, hi, s1, keep_q(0));
+        fwd_acc_wd<0, N2, CPQ, false>(SLY, H1, Z2, m, hi, s1, keep_q(0));
         wd_wait_dma();
         lds_barrier();
         refresh();
     refresh();                                               // quarter 1 visible; every wave is done with quarter 0
         PROF_NV(4);
         auto s2 = [&](int c) { if (c < QPW) dma_q(2, ldsYw, c); };
-        fwd_acc_wd<1, N2, CPQ>(SLX, H1, Z2, m, hi, s2, keep_q(1));
+        fwd_acc_wd<1, N2, CPQ, false>(SLX, H1, Z2, m, hi, s2, keep_q(1));
         wd_wait_dma();
         lds_barrier();
         refresh();
-    refresh();
         PROF_NV(5);
         auto s3 = [&](int c) { if (c < QPW) dma_q(3, ldsXw, c); };
-        fwd_acc_wd<2, N2, CPQ>(SLY, H1, Z2, m, hi, s3, keep_q(2));
+        fwd_acc_wd<2, N2, CPQ, false>(SLY, H1, Z2, m, hi, s3, keep_q(2));
         wd_wait_dma();
         lds_barrier();
         refresh();
-    refresh();
         PROF_NV(6);
-        fwd_acc_wd<3, N2, CPQ>(SLX, H1, Z2, m, hi, NoSide(), keep_q(3));       // quarter 2 stays in Y, quarter 3 in X: the backward pass starts there
+        // the last quarter applies the GELU on the way (tile To - 1's behind tile To's MFMAs); quarter 2 stays in Y, quarter 3 in X:
+        // the backward pass starts there
+#if ERL_WD_LAST
+        fwd_acc_wd<3, N2, CPQ, true>(SLX, H1, Z2, m, hi, NoSide(), keep_q(3), H2, G2);
+#else
+        fwd_acc_wd<3, N2, CPQ, false>(SLX, H1, Z2, m, hi, NoSide(), keep_q(3));
+#pragma unroll
+        for (int To = 0; To < N2; ++To) {
+            gelu_tile(Z2[To], H2[To], G2[To]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         PROF_NV(7);
     }
     refresh();
-    f32x16 H2[N2], G2[N2];
 #pragma unroll
     for (int To = 0; To < N2; ++To) {
-        gelu_tile(Z2[To], H2[To], G2[To]);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) scr_tile(8 + To, r) = make_float4(H2[To][4 * r], H2[To][4 * r + 1], H2[To][4 * r + 2], H2[To][4 * r + 3]);
     }
+    // the first gate tiles of the backward pass (GELU'(z1), features 192..255) are requested now: they arrive under the output layer
+#if ERL_WD_GATE_EARLY
+    load_gate(3);
+#endif
 
     PROF_NV(8);
     refresh();
@@ -725,17 +807,6 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
     float *RC = RW3;
     Parts dZ2p[2 * N2], dZ1q[4];
-    f32x16 Gq[2];
-    auto load_gate = [&](int q) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 v = scr_tile(2 * q + t, r);
-                Gq[t][4 * r] = v.x; Gq[t][4 * r + 1] = v.y; Gq[t][4 * r + 2] = v.z; Gq[t][4 * r + 3] = v.w;
-            }
-        }
-    };
     // the gate tiles requested a phase ago are IN their registers as far as the compiler is concerned (called right after a
     // s_waitcnt vmcnt(0)): a compiler-placed wait for them inside the next quarter would also wait for every LDS-DMA piece issued
     // there before it (memory operations return in order) -- 7k cycles per wave in the first version of this kernel
@@ -756,7 +827,9 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         }
     };
     refresh();
+#if !ERL_WD_GATE_EARLY
     load_gate(3);
+#endif
     bwd_wd<2 * N2, 2, CPQ, false>(SLX, dZ2p, G2, Gq, dZ1q, lane, NoSide());     // splits dZ2 into dZ2p on the way
     PROF_NV(10);
     lds_barrier();
@@ -827,6 +900,37 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     lds_barrier();
     refresh();                                                   // (11) X, Y, the X image in A consumed
     PROF_NV(21);
+    // H1's quarter images come back from the scratch block by LDS-DMA (every wave its share of the 1 KB pieces): quarter 0 into A now
+    // (the X image was consumed before (11)), 1 and 2 into X and Y once the dZ2 image is in registers, 3 into A behind quarter 0
+    constexpr int HPW = kWdH1ImgBytes / 1024 / QNW;                  // pieces per wave (12)
+    static_assert(HPW * 1024 == 32 * 48 * CPQ, "a wave's pieces are exactly its own 32 sample rows");
+    const u8 *isrc = scrI + HPW * 1024 * wave_u;
+    const uint32_t ldsAh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLA + HPW * 1024 * wave));
+    const uint32_t ldsXh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + HPW * 1024 * wave));
+    const uint32_t ldsYh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLY + HPW * 1024 * wave));
+    // where the 16 bytes at LDS position 1024 i + 16 lane of this wave's 32 image rows sit in the wave's scratch block (keep_q's order):
+    // row r, part, chunk position cs hold the logical chunk cs ^ swz(r) = (k-step, lane half) of sample r
+    uint32_t h1_gather[kWdH1ImgBytes / 1024 / QNW];
+#pragma unroll
+    for (int i = 0; i < kWdH1ImgBytes / 1024 / QNW; ++i) {
+        const uint32_t o = 1024u * i + lane16, x = o >> 7;          // x = 3 r + part
+        const uint32_t r = (x * 171u) >> 9, part = x - 3u * r;      // (x / 3 for x < 256)
+        const uint32_t c = ((o & 127u) >> 4) ^ (uint32_t)swz<CPQ>((int)r);
+        h1_gather[i] = (((c >> 1) * 3u + part) * 64u + (c & 1u) * 32u + r) * 16u;
+    }
+    auto dma_h1 = [&](int q, uint32_t slot_w) {
+#pragma unroll
+        for (int i = 0; i < HPW; ++i) wd_dma1(isrc + (size_t)q * kWdH1ImgBytes, h1_gather[i], slot_w + 1024u * i);
+    };
+    // (H2, requested before dW1's last quarter, is in its registers as far as the compiler is concerned before the pieces go out:
+    // see gate_arrived)
+    wd_wait_dma();
+#pragma unroll
+    for (int t = 0; t < N2; ++t) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) asm volatile("" : "+v"(h2v[t][r4].x), "+v"(h2v[t][r4].y), "+v"(h2v[t][r4].z), "+v"(h2v[t][r4].w));
+    }
+    dma_h1(0, ldsAh);                                                // (A is free: the X image was consumed before (11))
 
     // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2 back from the scratch block, staged feature-major in X + Y)
     {
@@ -888,18 +992,6 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     lds_barrier();
     refresh();                                                   // (13) H2^T consumed
     PROF_NV(23);
-    // H1's quarter images come back from the scratch block by LDS-DMA (every wave its share of the 1 KB pieces): quarter 0 into A now
-    // (the X image was consumed before (11)), 1 and 2 into X and Y once the dZ2 image is in registers, 3 into A behind quarter 0
-    constexpr int HPW = kWdH1ImgBytes / 1024 / QNW;                  // pieces per wave (12)
-    const u8 *isrc = scrI + HPW * 1024 * wave_u;
-    const uint32_t ldsAh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLA + HPW * 1024 * wave));
-    const uint32_t ldsXh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + HPW * 1024 * wave));
-    const uint32_t ldsYh = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLY + HPW * 1024 * wave));
-    auto dma_h1 = [&](int q, uint32_t slot_w) {
-#pragma unroll
-        for (int i = 0; i < HPW; ++i) wd_dma1(isrc + (size_t)q * kWdH1ImgBytes + 1024 * i, lane16, slot_w + 1024u * i);
-    };
-    dma_h1(0, ldsAh);
     stage_s3<2 * N2, CPH2, 0>(SLX, dZ2p, col, hi);                   // the dZ2 image spans X + Y
     wd_wait_dma();
     lds_barrier();
@@ -938,8 +1030,20 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     PROF(28);
 
     // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
-    const float t0 = block_sum(loss0, s_red);
-    const float t1 = block_sum(loss1, s_red);
+    // (sums over the workgroup with the kernel's own wave / lane indices)
+    auto wg_sum = [&](float v, float *red) {
+        v = wave_sum(v);
+        lds_barrier();
+        if (lane == 0) red[wave_u] = v;
+        lds_barrier();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < QNW; ++w) t += red[w];
+        return t;
+    };
+    refresh();
+    const float t0 = wg_sum(loss0, s_red);
+    const float t1 = wg_sum(loss1, s_red + 8);
     if (tid == 0) {
         float *logs = g.slabs + (size_t)blockIdx.x * g.stride + g.Pa + g.Pc;
         if (ACTOR) {
