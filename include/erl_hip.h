@@ -193,6 +193,11 @@ ERL_API int erl_per_sample_f32(const float *sum_tree, const float *min_tree, int
  * state_std are the (S,) normalisation buffers of ActorPPO/CriticPPO (AgentPPO.py:357-361, :432-441).
  * Activation is exact-erf GELU.  Constraints: h1, h2 multiples of 32 and <= ERL_MAX_HIDDEN,
  * S <= ERL_MAX_STATE_DIM, A <= ERL_MAX_ACTION_DIM.
+ * One wider shape class is accepted by erl_mlp_param_count, erl_ppo_slab_stride, K6 (erl_ppo_step_f32) and erl_ppo_update_dp_f32 only:
+ * h1 == 256, h2 in {64, 128}, S <= 64, A <= 8 -- net_dims (256, 128) of the reference's LunarLander demo (examples/demo_A2C_PPO.py:117).
+ * Its minibatch kernel streams W2 through LDS from images it builds from the parameters: a stand-alone erl_ppo_step_f32 call of this
+ * shape needs critic_params == actor_params + erl_mlp_param_count(S, h1, h2, A, 1) (one flat block [actor | critic]); rollouts and value
+ * pre-passes of the shape go through the erl_mlpn_* entry points.
  * ------------------------------------------------------------------------------------------- */
 ERL_API int64_t erl_mlp_param_count(int S, int h1, int h2, int out, int with_std_log);
 
