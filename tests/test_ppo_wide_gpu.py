@@ -39,7 +39,7 @@ def block_errors(got, ref, S, h1, h2, out, with_std):
     return {n: float(np.abs(got[o:o + ln] - ref[o:o + ln]).max() / scale) for n, o, ln in blocks(S, h1, h2, out, with_std)}
 
 
-def wide_step(ops, dev, S, h1, h2, A, B, buf, ids, actor, critic, H, N):
+def wide_step(ops, dev, S, h1, h2, A, B, buf, ids, actor, critic, H, N, objective=0):
     Pa, Pc = ops.MlpSpec(S, h1, h2, A, True).count, ops.MlpSpec(S, h1, h2, 1, False).count
     n_slabs, stride = ops.ppo_num_slabs(B), ops.ppo_slab_stride(S, h1, h2, A)
     assert stride >= Pa + Pc + 4 and stride % 32 == 0
@@ -47,7 +47,7 @@ def wide_step(ops, dev, S, h1, h2, A, B, buf, ids, actor, critic, H, N):
     slabs = th.full((n_slabs, stride), float("nan"), device=dev)
     flat = th.zeros(stride, device=dev)
     ops.ppo_step(P[:Pa], P[Pa:], cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(critic.state_avg, dev), cu(critic.state_std, dev),
-                 S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev), 0.25, 0.001, 1.0 / B, slabs, n_slabs)
+                 S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev), 0.25, 0.001, 1.0 / B, slabs, n_slabs, objective=objective)
     ops.grad_reduce(slabs, n_slabs, stride, flat)
     got = flat.cpu().numpy().astype(np.float64)
     return got, Pa, Pc
@@ -78,6 +78,25 @@ def test_wide_step_against_fp64(ops, dev, S, h1, h2, A, B):
     assert max(ea.values()) <= 2e-6, f"actor gradient: {ea}"
     assert max(ec.values()) <= 2e-6, f"critic gradient: {ec}"
     assert eo.max() <= 2e-6, f"objectives: {eo}"
+
+
+@pytest.mark.parametrize("S,h2,A", [(24, 128, 4), (8, 64, 2)])
+@pytest.mark.parametrize("objective", ["canonical", "a2c"])
+def test_wide_step_objective_forms(ops, dev, S, h2, A, objective):
+    """the textbook clipped surrogate and AgentA2C's un-clipped objective (AgentPPO.py:296-303; examples/demo_A2C_PPO.py trains A2C on
+    the same (256, 128) network) through the wide kernel, ratios on both sides of the clip"""
+    h1, B, H, N = 256, 300, 9, 50
+    rng = np.random.default_rng(S + len(objective))
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = list(buf_ids[:6]), buf_ids[6]
+    buf[3] = (buf[3] + 0.5 * rng.standard_normal(buf[3].shape)).astype(np.float32)
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64, objective)
+    got, Pa, Pc = wide_step(ops, dev, S, h1, h2, A, B, buf, ids, actor, critic, H, N, objective={"canonical": 1, "a2c": 2}[objective])
+    ea = block_errors(got[:Pa], ga, S, h1, h2, A, True)
+    ec = block_errors(got[Pa:Pa + Pc], gc, S, h1, h2, 1, False)
+    assert max(ea.values()) <= 2e-6 and max(ec.values()) <= 2e-6, (ea, ec)
+    np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-5, atol=1e-6)
 
 
 def test_wide_step_matches_the_layered_path(ops, dev):
@@ -175,5 +194,35 @@ def test_agent_wide_against_the_layered_update():
         out[wide] = (np.array(objs), agent._flat.detach().cpu().numpy().copy())
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-5, atol=2e-6)
     # Adam's first steps move every weight by ~lr whatever the gradient's size: elements whose gradient sits at rounding level may differ by 2 lr
+    d = np.abs(out[True][1] - out[False][1])
+    assert np.quantile(d, 0.999) < 2e-5 and d.max() < 4.1e-3, (np.quantile(d, 0.999), d.max())
+
+
+def test_agent_a2c_wide_against_the_layered_update():
+    """AgentA2C (whole time rows per minibatch, un-clipped objective) at net_dims (256, 128) through the fused kernel and through the
+    layered path: same objectives, same weights up to fp32 rounding through Adam"""
+    from elegantrl_amd.agents import AgentA2C
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config
+    N, S, A, H = 1, 24, 4, 256
+    dev = th.device("cuda:0")
+    out = {}
+    for wide in (True, False):
+        args = Config(AgentA2C, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A, "if_discrete": False})
+        args.net_dims = [256, 128]
+        args.horizon_len, args.batch_size, args.repeat_times, args.learning_rate = H, 128, 1.0, 1e-3
+        args.wide_fused = wide
+        th.manual_seed(3)
+        agent = AgentA2C(args.net_dims, S, A, gpu_id=0, args=args)
+        assert agent._wide == wide
+        env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=5)
+        agent.last_state = env.reset()[0]
+        g = th.Generator(device=dev).manual_seed(6)
+        noise = th.randn((H, N, A), device=dev, generator=g)
+        items = agent._explore_vec_env(env, H, noise=noise)
+        th.manual_seed(7)                                   # (the agent draws its minibatch rows with the global generator)
+        objs = agent.update_net(list(items))
+        out[wide] = (np.array(objs), agent._flat.detach().cpu().numpy().copy())
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-5, atol=5e-6)
     d = np.abs(out[True][1] - out[False][1])
     assert np.quantile(d, 0.999) < 2e-5 and d.max() < 4.1e-3, (np.quantile(d, 0.999), d.max())
