@@ -12,6 +12,7 @@
 // Parameter block (one flat fp32 buffer per network, same convention as the fused kernels):
 //   W1[d1][d0] b1[d1] ... WL[dL][dL-1] bL[dL] Wout[out][dL] bout[out] (+ action_std_log[out] for the actor)
 #include "mlpn_common.h"
+#include "ppo_step_wd.h"
 
 extern "C" int64_t erl_mlpn_param_count(const int *dims, int n_dims, int with_std_log)
 {
@@ -283,6 +284,11 @@ extern "C" int erl_mlpn_ppo_step_f32(const float *actor_params, const float *cri
 {
     ERL_REQUIRE(objective >= ERL_PPO_OBJ_REFERENCE && objective <= ERL_PPO_OBJ_A2C, "erl_mlpn_ppo_step_f32: unknown objective %d",
                 objective);
+    // net_dims (256, 128, 64 | 128), the reference's BipedalWalker / Humanoid demo networks: one fused kernel (ppo_step_wd_impl.h)
+    if (actor_dims && erl_ppo_wd3_supported(actor_dims, n_dims) && actor_params && critic_params && act_avg && act_std && cri_avg && cri_std &&
+        states && actions && unmasks && logprobs && advantages && reward_sums && ids && flat_grad && H >= 1 && N >= 1 && B >= 1)
+        return erl_ppo_wd3_step(actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, actor_dims, states, actions, unmasks, logprobs,
+                                advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy, inv_batch, objective, flat_grad, stream);
     return ppo_step_impl("erl_mlpn_ppo_step_f32", false, actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, actor_dims,
                          n_dims, states, actions, unmasks, logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy,
                          inv_batch, objective, flat_grad, workspace, workspace_bytes, stream);

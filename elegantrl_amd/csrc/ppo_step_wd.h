@@ -23,3 +23,11 @@ int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const
 
 // ERL_PROFILE builds: where the kernel's cycle stamps go ([net][8 waves][32] int64), which workgroup stamps
 void erl_ppo_wd_set_prof(long long *dev_buf, int block);
+
+// net_dims = (256, 128, 64 | 128) (dims = [S, 256, 128, h3, A], S <= 64, A <= 8): the fused minibatch step behind erl_mlpn_ppo_step_f32
+// (ERL_WIDE_FUSED=0 keeps the layered step); flat_grad receives [actor | critic | 3 objectives, 0]
+bool erl_ppo_wd3_supported(const int *dims, int n_dims);
+int erl_ppo_wd3_step(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std, const float *cri_avg,
+                     const float *cri_std, const int *dims, const float *states, const float *actions, const uint8_t *unmasks,
+                     const float *logprobs, const float *advantages, const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B,
+                     float ratio_clip, float lambda_entropy, float inv_batch, int objective, float *flat_grad, void *stream);

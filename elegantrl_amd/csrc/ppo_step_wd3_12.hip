@@ -1,0 +1,7 @@
+// K6 for net_dims = (256, 128, 64), S <= 32 (templates: ppo_step_wd_impl.h)
+#include "ppo_step_wd_impl.h"
+
+int erl_ppo_wd3_launch_12(const PpoWdArgs &a, int n_slabs, bool vec, hipStream_t stream)
+{
+    return vec ? launch_wd<1, 4, 2, true>(a, n_slabs, stream) : launch_wd<1, 4, 2, false>(a, n_slabs, stream);
+}

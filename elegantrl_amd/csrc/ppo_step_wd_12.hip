@@ -3,5 +3,5 @@
 
 int erl_ppo_wd_launch_12(const PpoWdArgs &a, int n_slabs, bool vec, hipStream_t stream)
 {
-    return vec ? launch_wd<1, 2, true>(a, n_slabs, stream) : launch_wd<1, 2, false>(a, n_slabs, stream);
+    return vec ? launch_wd<1, 2, 0, true>(a, n_slabs, stream) : launch_wd<1, 2, 0, false>(a, n_slabs, stream);
 }

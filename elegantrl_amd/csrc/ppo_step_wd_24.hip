@@ -3,5 +3,5 @@
 
 int erl_ppo_wd_launch_24(const PpoWdArgs &a, int n_slabs, bool vec, hipStream_t stream)
 {
-    return vec ? launch_wd<2, 4, true>(a, n_slabs, stream) : launch_wd<2, 4, false>(a, n_slabs, stream);
+    return vec ? launch_wd<2, 4, 0, true>(a, n_slabs, stream) : launch_wd<2, 4, 0, false>(a, n_slabs, stream);
 }

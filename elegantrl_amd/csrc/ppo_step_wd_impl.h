@@ -39,7 +39,7 @@ namespace {
 #define ERL_WD_DBG 0
 #endif
 constexpr int kWdSlot = 49152;
-constexpr int kWdSmall = (256 + 128 + 16 + 64 + 64 + 16) * 4;
+constexpr int kWdSmall = (256 + 128 + 16 + 64 + 64 + 16 + 128) * 4;
 constexpr size_t kWdLdsBytes = (size_t)3 * kWdSlot + kS3W3 + kWdSmall;
 static_assert(kWdLdsBytes <= 160 * 1024, "LDS budget");
 static_assert(2 * kWdSlot >= 128 * PLD * 4, "H2^T (fp32, feature-major) spans two slots");
@@ -73,7 +73,9 @@ __device__ __forceinline__ int wd_lane()
 // first layer: fwd_s3 (ppo_step_s3_impl.h) with two differences -- GELU' is handed to `done(tile, k-step, values)` as each k-step's
 // share of a tile is finished instead of being kept, and NO may be 8.  NK in {2, 4}.
 // ---------------------------------------------------------------------------------------------------------
-template <int NK, int NO, int CP, typename Side, typename Done>
+// TROT: the image's row tiles sit rotated in LDS (tile To at position (To + TROT) % NO: a 96 KB image whose first half was streamed into
+// the upper slot).
+template <int NK, int NO, int CP, int TROT = 0, typename Side, typename Done>
 __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (&inP)[NK], const f32x16 (&inH)[(NK + 1) / 2],
                                        f32x16 (&outH)[NO], int m, int hi, const Side &side, const Done &done)
 {
@@ -86,7 +88,7 @@ __device__ __forceinline__ void fwd_wd(const u8 *img, const float *bias, Parts (
     Parts aq[2];
     auto issue = [&](int c, Parts &dst) {
         const int To = c / NK, ks = c % NK;
-        const u8 *p = base + 32 * To * ROWB + ((32 * ks) ^ x16);
+        const u8 *p = base + 32 * ((To + TROT) % NO) * ROWB + ((32 * ks) ^ x16);
         dst.h = *reinterpret_cast<const u32x4 *>(p);
         dst.m = *reinterpret_cast<const u32x4 *>(p + PBY);
         dst.l = *reinterpret_cast<const u32x4 *>(p + 2 * PBY);
@@ -340,7 +342,8 @@ __device__ __forceinline__ void fwd_acc_wd(const u8 *img, const f32x16 (&H)[NH],
 // one quarter of the backward pass through W2: bwd_s3 (ppo_step_s3_impl.h) on a column-quarter image (NO = 2 tiles = 64 of the first
 // layer's features), with the split of dz skipped when an earlier quarter has done it (PRESPLIT) and a per-k-step hook.
 // ---------------------------------------------------------------------------------------------------------
-template <int NK, int NO, int CP, bool PRESPLIT, typename Side>
+// KROT: the image's rows sit rotated by 16 KROT in LDS (see fwd_wd).
+template <int NK, int NO, int CP, bool PRESPLIT, int KROT = 0, typename Side>
 __device__ __forceinline__ void bwd_wd(const u8 *img, Parts (&dzP)[NK], const f32x16 (&dzH)[NK / 2], const f32x16 (&gate)[NO],
                                        Parts (&outP)[2 * NO], int lane, const Side &side)
 {
@@ -357,7 +360,7 @@ __device__ __forceinline__ void bwd_wd(const u8 *img, Parts (&dzP)[NK], const f3
     u32x2 rq[2][6];
     auto issue = [&](int c, u32x2(&dst)[6]) {
         const int To = c / NK, ks = c % NK;
-        const u8 *p0 = b0 + 16 * ks * ROWB + ((64 * To) ^ x0), *p1 = b1 + 16 * ks * ROWB + ((64 * To) ^ x1);
+        const u8 *p0 = b0 + 16 * ((ks + KROT) % NK) * ROWB + ((64 * To) ^ x0), *p1 = b1 + 16 * ((ks + KROT) % NK) * ROWB + ((64 * To) ^ x1);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             dst[2 * pl] = lds_tr(p0 + pl * PBY);
@@ -449,11 +452,26 @@ __device__ __forceinline__ void bwd_wd(const u8 *img, Parts (&dzP)[NK], const f3
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool ACTOR, int KX, int N2, bool VEC>     // KX: input tiles of 32 (1: S <= 32, 2: S <= 64)
+// N3 > 0: a third hidden layer of 32 N3 features (net_dims (256, 128, 64 | 128): examples/demo_A2C_PPO.py:171, :224); N2 = 4 then
+// where the 16 bytes at LDS position 1024 i + lane16 of a wave's 32 rows of a sample-major image (CP chunks per part) sit in the wave's
+// lane-ordered scratch block [k-step][part][64 lanes]: row r, part, chunk position cs hold the logical chunk cs ^ swz(r) = (k-step, lane half)
+template <int CP>
+__device__ __forceinline__ uint32_t wd_gather_off(int i, uint32_t lane16)
+{
+    const uint32_t o = 1024u * i + lane16, x = o / (16u * CP);      // x = 3 r + part
+    const uint32_t r = (x * 171u) >> 9, part = x - 3u * r;           // (x / 3 for x < 256)
+    const uint32_t c = ((o % (16u * CP)) >> 4) ^ (uint32_t)swz<CP>((int)r);
+    return (((c >> 1) * 3u + part) * 64u + (c & 1u) * 32u + r) * 16u;
+}
+
+template <bool ACTOR, int KX, int N2, int N3, bool VEC>     // KX: input tiles of 32 (1: S <= 32, 2: S <= 64)
 __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
 {
     const Ppo2Args &g = args.g;
-    constexpr int N1 = 8, h1 = 32 * N1, h2 = 32 * N2;
+    constexpr int N1 = 8, h1 = 32 * N1, h2 = 32 * N2, h3 = 32 * N3;
+    constexpr bool L3 = N3 > 0;
+    constexpr int NL = L3 ? N3 : N2, hL = 32 * NL;          // the hidden layer that feeds the output layer
+    static_assert(!L3 || N2 == 4, "three hidden layers: (256, 128, h3)");
     constexpr int NK1 = 2 * KX;                             // k-steps of 16 of the (zero-padded) input
     constexpr int CP1 = 4 * KX, CPQ = 8, CPH2 = 4 * N2;     // chunks per part: W1 / X images, W2 quarter / dZ1 quarter / H1 quarter images, dZ2 image
     constexpr int QB = h2 * 48 * CPQ;                       // bytes of one W2 column-quarter image
@@ -476,20 +494,33 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     refresh();
     constexpr int net = ACTOR ? 0 : 1;
     const int S = g.S, OUT = ACTOR ? g.A : 1;
-    const Dims d{S, h1, h2, OUT};
+    // flat parameter block: W1 b1 W2 b2 [W3 b3] Wout bout [action_std_log]
+    struct Offs {
+        int64_t W1, b1, W2, b2, W3, b3, Wo, bo, sd;
+    };
+    const Offs d = [&]() {
+        Offs o;
+        o.W1 = 0; o.b1 = (int64_t)h1 * S; o.W2 = o.b1 + h1; o.b2 = o.W2 + (int64_t)h2 * h1;
+        o.W3 = o.b2 + h2; o.b3 = o.W3 + (int64_t)h3 * h2;
+        o.Wo = L3 ? o.b3 + h3 : o.W3; o.bo = o.Wo + (int64_t)OUT * hL; o.sd = o.bo + OUT;
+        return o;
+    }();
     const float *P = g.P[net];
-    const float *std_log = P + d.oStd();
+    const float *std_log = P + d.sd;
 
     u8 *SLA = smem, *SLX = SLA + kWdSlot, *SLY = SLX + kWdSlot;
     float *RW3 = reinterpret_cast<float *>(SLY + kWdSlot);      // W3 copy [16][ld3] fp32 (rows >= OUT zero); later RC = dY^T [16][PLD]
     float *s_b1 = RW3 + kS3W3 / 4, *s_b2 = s_b1 + 256, *s_b3 = s_b2 + 128;
     float *s_nr = s_b3 + 16, *s_nn = s_nr + 64;
     float *s_red = s_nn + 64;
+    float *s_b3h = s_red + 16;                                  // the third hidden layer's bias (128)
     constexpr int ld3 = lds_ld(128);
-    float *scr0 = args.scratch + ((size_t)blockIdx.x * 2 + net) * wd_scratch_floats(N2);
+    float *scr0 = args.scratch + ((size_t)blockIdx.x * 2 + net) * wd_scratch_floats(NL, N3);
     // register tile T (0..7: GELU'(z1); 8..: H2), quad r of this thread: wave-uniform base + the thread's 16 bytes
     auto scr_tile = [&](int T, int r) -> float4 & { return reinterpret_cast<float4 *>(scr0 + (size_t)(4 * T + r) * QNT * 4)[tid]; };
-    u8 *scrI = reinterpret_cast<u8 *>(scr0 + (8 + N2) * 16 * QNT);      // H1 quarter images
+    u8 *scrI = reinterpret_cast<u8 *>(scr0 + (8 + NL) * 16 * QNT);      // H1 quarter images
+    u8 *scrI2 = scrI + 4 * kWdH1ImgBytes;                               // (three hidden layers) the H2 image, then the dZ3 image
+    u8 *scrI3 = scrI2 + 128 * 768;
 
     // the wave's share of a DMA transfer: pieces [QPW wave, QPW (wave + 1)) of a quarter, [W1PW wave, ...) of the W1 image
     const uint32_t ldsXw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + QPW * 1024 * wave));
@@ -515,17 +546,18 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     // into an AGPR, read back much later) at the end of such a block: lanes inactive at the copy read garbage back, and the logged sums
     // of the (8, 256, 64, 2) shape were summed over stale LDS (tests/test_ppo_wide_gpu.py caught it).  Guarded stores become stores of
     // selected values at wrapped / clamped indices (two threads may write the same value to the same place).
-    constexpr int NU3 = 16 * (h2 / 4) / QNT;                // float4 of the W3 copy per thread: rows [16][h2], 1 (h2 = 64) or 2
-    static_assert(NU3 * QNT == 16 * (h2 / 4), "W3 copy passes");
+    constexpr int NU3 = 16 * (hL / 4) / QNT;                // float4 of the output layer's copy per thread: rows [16][hL], 1 (hL = 64) or 2
+    static_assert(NU3 * QNT == 16 * (hL / 4), "output-layer copy passes");
     float4 c3[NU3];
 #pragma unroll
-    for (int u = 0; u < NU3; ++u) {                         // W3 rows [16][h2] (rows >= OUT zeroed when stored)
-        const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
-        c3[u] = load4<VEC>(P + d.oW3() + (size_t)min(i, OUT - 1) * h2, 4 * j4, h2);
+    for (int u = 0; u < NU3; ++u) {                         // output-layer rows [16][hL] (rows >= OUT zeroed when stored)
+        const int e = tid + u * QNT, i = e / (hL / 4), j4 = e - i * (hL / 4);
+        c3[u] = load4<VEC>(P + d.Wo + (size_t)min(i, OUT - 1) * hL, 4 * j4, hL);
     }
-    const float b1_raw = P[d.ob1() + tid];
-    const float b2_raw = P[d.ob2() + min(tid & 127, h2 - 1)];
-    const float b3_raw = P[d.ob3() + min(tid & 15, OUT - 1)];
+    const float b3h_raw = L3 ? P[d.b3 + min(tid & 127, (L3 ? h3 : 1) - 1)] : 0.f;
+    const float b1_raw = P[d.b1 + tid];
+    const float b2_raw = P[d.b2 + min(tid & 127, h2 - 1)];
+    const float b3_raw = P[d.bo + min(tid & 15, OUT - 1)];
     const float sd_raw = g.sd[net][min(tid & 63, S - 1)], avg_raw = g.avg[net][min(tid & 63, S - 1)];
 
     // ---- id -> (t = id % H, n = id // H) -> buffer row t*N + n  (AgentPPO.py:179-187) and its data
@@ -566,6 +598,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     s_b1[tid] = b1_raw;
     s_b2[tid & 127] = (tid & 127) < h2 ? b2_raw : 0.f;
     s_b3[tid & 15] = (tid & 15) < OUT ? b3_raw : 0.f;
+    if constexpr (L3) s_b3h[tid & 127] = (tid & 127) < h3 ? b3h_raw : 0.f;
     {
         const float nr = __builtin_amdgcn_rcpf(sd_raw + 1e-4f);                  // (x - avg) / (std + 1e-4)  (AgentPPO.py:360-361)
         s_nr[tid & 63] = (tid & 63) < S ? nr : 0.f;
@@ -577,7 +610,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     PROF_NV(1);
 #pragma unroll
     for (int u = 0; u < NU3; ++u) {                                  // W3 copy [16][ld3], rows >= OUT zero; visible after (0b)
-        const int e = tid + u * QNT, i = e / (h2 / 4), j4 = e - i * (h2 / 4);
+        const int e = tid + u * QNT, i = e / (hL / 4), j4 = e - i * (hL / 4);
         *reinterpret_cast<float4 *>(RW3 + i * ld3 + 4 * j4) = i < OUT ? c3[u] : zero4();
     }
     // ---- normalise the own row; its split rides behind the first output tile's MFMAs of the first layer
@@ -620,7 +653,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     }
 
     // ---- second layer, K split in quarters: q0 (Y) | q1 (X) | q2 (Y) | q3 (X); quarter q + 1 streams in behind quarter q's MFMAs
-    f32x16 Z2[N2], H2[N2], G2[N2], Gq[2];
+    f32x16 Z2[N2], H2[N2], G2[N2], H3[NL], G3[NL], Gq[2];            // (H3 / G3: three hidden layers only)
     auto load_gate = [&](int q) {                                    // GELU'(z1) tiles 2 q, 2 q + 1 back from the scratch block
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -673,25 +706,59 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         lds_barrier();
         refresh();
         PROF_NV(6);
-        // the last quarter applies the GELU on the way (tile To - 1's behind tile To's MFMAs); quarter 2 stays in Y, quarter 3 in X:
-        // the backward pass starts there
-#if ERL_WD_LAST
-        fwd_acc_wd<3, N2, CPQ, true>(SLX, H1, Z2, m, hi, NoSide(), keep_q(3), H2, G2);
-#else
-        fwd_acc_wd<3, N2, CPQ, false>(SLX, H1, Z2, m, hi, NoSide(), keep_q(3));
+        // quarter 2 stays in Y, quarter 3 in X: the backward pass of a two-layer net starts there; with a third hidden layer the first
+        // half of its weight image (rows 0 .. 63) streams into Y behind quarter 3's MFMAs
+        if constexpr (L3) {
+            const u8 *w3src = args.w3img[net] + 12 * 1024 * wave_u;
+            const uint32_t ldsY3 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLY + 12 * 1024 * wave));
+            auto s4 = [&](int c) { if (c < 12) wd_dma1(w3src + 1024 * c, lane16, ldsY3 + 1024u * c); };
+            fwd_acc_wd<3, N2, CPQ, false>(SLX, H1, Z2, m, hi, s4, keep_q(3));
+        } else {
+            fwd_acc_wd<3, N2, CPQ, false>(SLX, H1, Z2, m, hi, NoSide(), keep_q(3));
+        }
 #pragma unroll
         for (int To = 0; To < N2; ++To) {
             gelu_tile(Z2[To], H2[To], G2[To]);
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
         PROF_NV(7);
     }
     refresh();
+    if constexpr (L3) {
+        // ---- third hidden layer: its weight image [h3][3][128 bf16] in Y (h3 = 64) or in X + Y with its halves swapped (rows 64 .. 127
+        //      come into X once every wave is done with quarter 3: TROT / KROT); H2's split operand leaves for the scratch block (the
+        //      dW3 operand image, lane order), GELU'(z3) stays
+        wd_wait_dma();
+        lds_barrier();
+        refresh();
+        if constexpr (N3 == 4) {
+            const u8 *w3src = args.w3img[net] + 49152 + 12 * 1024 * wave_u;
+            const uint32_t ldsX3 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + 12 * 1024 * wave));
 #pragma unroll
-    for (int To = 0; To < N2; ++To) {
+            for (int i = 0; i < 12; ++i) wd_dma1(w3src + 1024 * i, lane16, ldsX3 + 1024u * i);
+            wd_wait_dma();
+            lds_barrier();
+            refresh();
+        }
+        Parts H2p[2 * N2];
+        auto done3 = [&](int Tp, int ks, const float (&gd)[2]) { G3[Tp][2 * ks] = gd[0]; G3[Tp][2 * ks + 1] = gd[1]; };
+        fwd_wd<2 * N2, NL, 4 * N2, (N3 == 4 ? 2 : 0)>(N3 == 4 ? SLX : SLY, s_b3h, H2p, H2, H3, m, hi, NoSide(), done3);
+        u8 *ub2 = scrI2 + wave_u * (2 * N2 * 3072);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scr_tile(8 + To, r) = make_float4(H2[To][4 * r], H2[To][4 * r + 1], H2[To][4 * r + 2], H2[To][4 * r + 3]);
+        for (int ks = 0; ks < 2 * N2; ++ks) {
+            *reinterpret_cast<u32x4 *>(ub2 + ks * 3072 + lane16) = H2p[ks].h;
+            *reinterpret_cast<u32x4 *>(ub2 + ks * 3072 + 1024 + lane16) = H2p[ks].m;
+            *reinterpret_cast<u32x4 *>(ub2 + ks * 3072 + 2048 + lane16) = H2p[ks].l;
+        }
+        refresh();
+    }
+    // HL / GL: the hidden layer that feeds the output layer and its GELU'
+    auto &HL = [&]() -> f32x16(&)[NL] { if constexpr (L3) return H3; else return H2; }();
+    auto &GL = [&]() -> f32x16(&)[NL] { if constexpr (L3) return G3; else return G2; }();
+#pragma unroll
+    for (int To = 0; To < NL; ++To) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scr_tile(8 + To, r) = make_float4(HL[To][4 * r], HL[To][4 * r + 1], HL[To][4 * r + 2], HL[To][4 * r + 3]);
     }
     // the first gate tiles of the backward pass (GELU'(z1), features 192..255) are requested now: they arrive under the output layer
 #if ERL_WD_GATE_EARLY
@@ -700,7 +767,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
 
     PROF_NV(8);
     refresh();
-    // ---- output layer (fp32, as in ppo_step_s3_impl.h: H2[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j)
+    // ---- output layer (fp32, as in ppo_step_s3_impl.h: HL[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j)
     float Y[4] = {0.f, 0.f, 0.f, 0.f};
     if (ACTOR) {
         f32x4 ya[2][2];
@@ -708,15 +775,15 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         for (int q = 0; q < 4; ++q) ya[q >> 1][q & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float *w3a = RW3 + (lane & 3) * ld3 + 8 * hi;
 #pragma unroll
-        for (int c = 0; c < 4 * N2; ++c) {
+        for (int c = 0; c < 4 * NL; ++c) {
             const int T = c >> 2, gq = c & 3;
             const float4 w0 = *reinterpret_cast<const float4 *>(w3a + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
             const float4 w1 = *reinterpret_cast<const float4 *>(w3a + 4 * ld3 + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
             const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ya[0][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], H2[T][4 * gq + j], ya[0][j & 1], 0, 0, 0);
-                ya[1][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], H2[T][4 * gq + j], ya[1][j & 1], 0, 0, 0);
+                ya[0][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], HL[T][4 * gq + j], ya[0][j & 1], 0, 0, 0);
+                ya[1][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], HL[T][4 * gq + j], ya[1][j & 1], 0, 0, 0);
             }
         }
         const float4 b4 = *reinterpret_cast<const float4 *>(s_b3 + 4 * hi);
@@ -731,11 +798,11 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         f32x2 yp = {0.f, 0.f}, yq = {0.f, 0.f};
         const float *w3 = RW3 + 8 * hi;
 #pragma unroll
-        for (int c = 0; c < 4 * N2; ++c) {
+        for (int c = 0; c < 4 * NL; ++c) {
             const int T = c >> 2, gq = c & 3;
             const float4 wv = *reinterpret_cast<const float4 *>(w3 + 32 * T + 16 * (gq >> 1) + 4 * (gq & 1));
-            yp = f32x2{wv.x, wv.y} * f32x2{H2[T][4 * gq + 0], H2[T][4 * gq + 1]} + yp;
-            yq = f32x2{wv.z, wv.w} * f32x2{H2[T][4 * gq + 2], H2[T][4 * gq + 3]} + yq;
+            yp = f32x2{wv.x, wv.y} * f32x2{HL[T][4 * gq + 0], HL[T][4 * gq + 1]} + yp;
+            yq = f32x2{wv.z, wv.w} * f32x2{HL[T][4 * gq + 2], HL[T][4 * gq + 3]} + yq;
         }
         const float s = (yp.x + yp.y) + (yq.x + yq.y);
         Y[0] = s + __shfl_xor(s, 32, 64) + s_b3[0];
@@ -785,19 +852,19 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     // ---- dZ2 = (W3^T dY) * GELU'(z2)  (K = 8 outputs: four fp32 k-pairs; A-row m carries feature 32 To + phi(m))
     {
         const int pm = phi(m);
-        float w3[N2][4];
+        float w3[NL][4];
 #pragma unroll
-        for (int To = 0; To < N2; ++To) {
+        for (int To = 0; To < NL; ++To) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) w3[To][j] = RW3[(4 * hi + j) * ld3 + 32 * To + pm];
         }
 #pragma unroll
-        for (int To = 0; To < N2; ++To) {
+        for (int To = 0; To < NL; ++To) {
             f32x16 acc = {0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = mfma32(w3[To][j], dY[j], acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) G2[To][r] *= acc[r];
+            for (int r = 0; r < 16; ++r) GL[To][r] *= acc[r];
         }
     }
 
@@ -822,15 +889,41 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         if (jc < KX) {
             Parts A[8];
             grad_a_load<CPQ>(slot, it, A, lane);
-            grad_tiles<CP1, 1, 2>(A, SLA, it, jc, 0, slab + d.oW1() + (size_t)(64 * q) * S, S, S, lane);
-            if (jc == 0) grad_bias(A, slab + d.ob1() + 64 * q, it, lane);
+            grad_tiles<CP1, 1, 2>(A, SLA, it, jc, 0, slab + d.W1 + (size_t)(64 * q) * S, S, S, lane);
+            if (jc == 0) grad_bias(A, slab + d.b1 + 64 * q, it, lane);
         }
     };
+    if constexpr (L3) {
+        // ---- back through the third layer: dZ2 = (W3^T dZ3) * GELU'(z2) leaves split (dZ2p); dZ3's split operand goes to the scratch
+        //      block (the dW3 operand image, lane order); then W2's quarters come back: 2 into Y, 3 into X where W3 overwrote it
+        Parts dZ3p[2 * NL];
+        refresh();
+        bwd_wd<2 * NL, N2, 4 * N2, false, (N3 == 4 ? 4 : 0)>(N3 == 4 ? SLX : SLY, dZ3p, G3, G2, dZ2p, lane, NoSide());
+        u8 *ub3 = scrI3 + wave_u * (2 * NL * 3072);
+#pragma unroll
+        for (int ks = 0; ks < 2 * NL; ++ks) {
+            *reinterpret_cast<u32x4 *>(ub3 + ks * 3072 + lane16) = dZ3p[ks].h;
+            *reinterpret_cast<u32x4 *>(ub3 + ks * 3072 + 1024 + lane16) = dZ3p[ks].m;
+            *reinterpret_cast<u32x4 *>(ub3 + ks * 3072 + 2048 + lane16) = dZ3p[ks].l;
+        }
+        lds_barrier();
+        refresh();                                               // every wave is done with the W3 image
+        if constexpr (N3 == 4) {
+#pragma unroll
+            for (int i = 0; i < QPW; ++i) dma_q(3, ldsXw, i);
+        }
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) dma_q(2, ldsYw, i);
+        wd_wait_dma();
+        gate_arrived();
+        lds_barrier();
+        refresh();
+    }
     refresh();
 #if !ERL_WD_GATE_EARLY
     load_gate(3);
 #endif
-    bwd_wd<2 * N2, 2, CPQ, false>(SLX, dZ2p, G2, Gq, dZ1q, lane, NoSide());     // splits dZ2 into dZ2p on the way
+    bwd_wd<2 * N2, 2, CPQ, L3>(SLX, dZ2p, G2, Gq, dZ1q, lane, NoSide());        // (two hidden layers: splits dZ2 into dZ2p on the way)
     PROF_NV(10);
     lds_barrier();
     refresh();                                                   // (1) every wave is done with quarter 3 (X) and with W3
@@ -890,9 +983,9 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     lds_barrier();
     refresh();                                                   // (10)
     PROF_NV(20);
-    float4 h2v[N2][4];                                               // H2 comes back under dW1's last quarter
+    float4 h2v[NL][4];                                               // the last hidden layer comes back under dW1's last quarter
 #pragma unroll
-    for (int t = 0; t < N2; ++t) {
+    for (int t = 0; t < NL; ++t) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) h2v[t][r4] = scr_tile(8 + t, r4);
     }
@@ -912,12 +1005,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     // row r, part, chunk position cs hold the logical chunk cs ^ swz(r) = (k-step, lane half) of sample r
     uint32_t h1_gather[kWdH1ImgBytes / 1024 / QNW];
 #pragma unroll
-    for (int i = 0; i < kWdH1ImgBytes / 1024 / QNW; ++i) {
-        const uint32_t o = 1024u * i + lane16, x = o >> 7;          // x = 3 r + part
-        const uint32_t r = (x * 171u) >> 9, part = x - 3u * r;      // (x / 3 for x < 256)
-        const uint32_t c = ((o & 127u) >> 4) ^ (uint32_t)swz<CPQ>((int)r);
-        h1_gather[i] = (((c >> 1) * 3u + part) * 64u + (c & 1u) * 32u + r) * 16u;
-    }
+    for (int i = 0; i < kWdH1ImgBytes / 1024 / QNW; ++i) h1_gather[i] = wd_gather_off<CPQ>(i, lane16);
     auto dma_h1 = [&](int q, uint32_t slot_w) {
 #pragma unroll
         for (int i = 0; i < HPW; ++i) wd_dma1(isrc + (size_t)q * kWdH1ImgBytes, h1_gather[i], slot_w + 1024u * i);
@@ -926,7 +1014,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     // see gate_arrived)
     wd_wait_dma();
 #pragma unroll
-    for (int t = 0; t < N2; ++t) {
+    for (int t = 0; t < NL; ++t) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) asm volatile("" : "+v"(h2v[t][r4].x), "+v"(h2v[t][r4].y), "+v"(h2v[t][r4].z), "+v"(h2v[t][r4].w));
     }
@@ -936,7 +1024,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     {
         float *T2 = reinterpret_cast<float *>(SLX);
 #pragma unroll
-        for (int t = 0; t < N2; ++t) {
+        for (int t = 0; t < NL; ++t) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const float4 v = h2v[t][r4];
@@ -957,9 +1045,9 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         const int l15 = lane & 15, q = lane >> 4;
         f32x2 hs = {0.f, 0.f};
 #pragma unroll
-        for (int rep = 0; rep < (2 * N2 + QNW - 1) / QNW; ++rep) {
+        for (int rep = 0; rep < (2 * NL + QNW - 1) / QNW; ++rep) {
             const int it = wave + QNW * rep;                            // 16-column tile of dW3 (wave-uniform)
-            if (it >= 2 * N2) break;
+            if (it >= 2 * NL) break;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float *a = RC + l15 * PLD + 4 * q;
             const float *b = T2 + (16 * it + l15) * PLD + 4 * q;
@@ -978,15 +1066,15 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a_ = 4 * q + r;
-                if (a_ < OUT) slab_store(acc[r], slab + d.oW3() + (size_t)a_ * h2 + 16 * it + l15);
+                if (a_ < OUT) slab_store(acc[r], slab + d.Wo + (size_t)a_ * hL + 16 * it + l15);
             }
         }
         float s = hs.x + hs.y;
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         if (wave == 0 && q == 0) {
-            if (l15 < OUT) slab[d.ob3() + l15] = s;
-            else if (ACTOR && l15 >= 8 && l15 - 8 < OUT) slab[d.oStd() + l15 - 8] = s;
+            if (l15 < OUT) slab[d.bo + l15] = s;
+            else if (ACTOR && l15 >= 8 && l15 - 8 < OUT) slab[d.sd + l15 - 8] = s;
         }
     }
     lds_barrier();
@@ -1010,24 +1098,53 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
         PROF_NV(25);
         dma_h1(1, ldsXh);
         dma_h1(2, ldsYh);
-        grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 0, slab + d.oW2(), h1, h1, lane);
+        grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 0, slab + d.W2, h1, h1, lane);
         wd_wait_dma();
         lds_barrier();
         refresh();
     refresh();                                               // (16) quarters 1, 2 visible; quarter 0 (A) consumed
         PROF_NV(26);
         dma_h1(3, ldsAh);
-        grad_tiles<CPQ, NBW, CS>(A, SLX, it, jc, 2, slab + d.oW2(), h1, h1, lane);
-        grad_tiles<CPQ, NBW, CS>(A, SLY, it, jc, 4, slab + d.oW2(), h1, h1, lane);
+        grad_tiles<CPQ, NBW, CS>(A, SLX, it, jc, 2, slab + d.W2, h1, h1, lane);
+        grad_tiles<CPQ, NBW, CS>(A, SLY, it, jc, 4, slab + d.W2, h1, h1, lane);
         wd_wait_dma();
         lds_barrier();
         refresh();
     refresh();                                               // (17)
         PROF_NV(27);
-        grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 6, slab + d.oW2(), h1, h1, lane);
-        if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
+        grad_tiles<CPQ, NBW, CS>(A, SLA, it, jc, 6, slab + d.W2, h1, h1, lane);
+        if (jc == 0) grad_bias(A, slab + d.b2, it, lane);
     }
     PROF(28);
+    if constexpr (L3) {
+        // ---- layer 3: dW3 = dZ3^T . H2, db3 -- both operand images come back from the scratch block by gathering LDS-DMA: H2
+        //      ([128][3][128], 96 KB) into X + Y, dZ3 in halves of 64 features ([128][3][64]) into A
+        lds_barrier();
+        refresh();                                               // every wave is done with dW2's last quarter (A)
+        constexpr int P2W = 32 * 48 * 16 / 1024;                 // H2 image pieces per wave (24); a dZ3 half: HPW (12)
+        const u8 *s2 = scrI2 + wave_u * (P2W * 1024);
+        const uint32_t lX = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(SLX + P2W * 1024 * wave));
+#pragma unroll
+        for (int i = 0; i < P2W; ++i) wd_dma1(s2, wd_gather_off<16>(i, lane16), lX + 1024u * i);
+        const int it = wave & 1, jc = wave >> 1;                 // row tile of the half's two; column tiles jc, jc + 2 of H2's four
+#pragma unroll
+        for (int hf = 0; hf < N3 / 2; ++hf) {
+            const u8 *s3 = scrI3 + wave_u * (2 * N3 * 3072) + hf * (4 * 3072);
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) wd_dma1(s3, h1_gather[i], ldsAh + 1024u * i);     // (the same gather as an H1 quarter: CP = 8)
+            wd_wait_dma();
+            lds_barrier();
+            refresh();
+            Parts A[8];
+            grad_a_load<CPQ>(SLA, it, A, lane);
+            grad_tiles<16, 2, 2>(A, SLX, it, jc, 0, slab + d.W3 + (size_t)(64 * hf) * h2, h2, h2, lane);
+            if (jc == 0) grad_bias(A, slab + d.b3 + 64 * hf, it, lane);
+            if (hf + 1 < N3 / 2) {
+                lds_barrier();
+                refresh();                                       // the first half of the dZ3 image is consumed
+            }
+        }
+    }
 
     // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
     // (sums over the workgroup with the kernel's own wave / lane indices)
@@ -1059,28 +1176,28 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     }
 }
 
-template <int KX, int N2, bool VEC>
+template <int KX, int N2, int N3, bool VEC>
 __global__ __launch_bounds__(QNT) void ppo_step_wd_kernel(PpoWdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_wd[];
     const unsigned long long t_span = span_enter(a.g);
-    if (blockIdx.y == 0) ppo_block_wd<true, KX, N2, VEC>(a, smem_wd);
-    else ppo_block_wd<false, KX, N2, VEC>(a, smem_wd);
+    if (blockIdx.y == 0) ppo_block_wd<true, KX, N2, N3, VEC>(a, smem_wd);
+    else ppo_block_wd<false, KX, N2, N3, VEC>(a, smem_wd);
     span_exit(a.g, t_span);
 }
 
-template <int KX, int N2, bool VEC>
+template <int KX, int N2, int N3, bool VEC>
 int launch_wd(const PpoWdArgs &a, int n_slabs, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        int rc = erl_hip_status(hipFuncSetAttribute((const void *)ppo_step_wd_kernel<KX, N2, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = erl_hip_status(hipFuncSetAttribute((const void *)ppo_step_wd_kernel<KX, N2, N3, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     (int)kWdLdsBytes),
                                 "hipFuncSetAttribute(ppo_step_wd_kernel)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ppo_step_wd_kernel<KX, N2, VEC>), dim3(n_slabs, 2), dim3(QNT), kWdLdsBytes, stream, a);
+    hipLaunchKernelGGL((ppo_step_wd_kernel<KX, N2, N3, VEC>), dim3(n_slabs, 2), dim3(QNT), kWdLdsBytes, stream, a);
     return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32 (wide)");
 }
 

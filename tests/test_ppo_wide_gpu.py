@@ -226,3 +226,78 @@ def test_agent_a2c_wide_against_the_layered_update():
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-5, atol=5e-6)
     d = np.abs(out[True][1] - out[False][1])
     assert np.quantile(d, 0.999) < 2e-5 and d.max() < 4.1e-3, (np.quantile(d, 0.999), d.max())
+
+
+# ---- three hidden layers: net_dims (256, 128, 64 | 128) behind erl_mlpn_ppo_step_f32 ------------------------------------------------
+def blocks3(S, h3, out, with_std):
+    names = [("W1", 256 * S), ("b1", 256), ("W2", 128 * 256), ("b2", 128), ("W3", h3 * 128), ("b3", h3), ("W4", out * h3), ("b4", out)]
+    names += [("std", out)] if with_std else []
+    res, o = [], 0
+    for n, ln in names:
+        res.append((n, o, ln))
+        o += ln
+    return res
+
+
+def block_errors3(got, ref, S, h3, out, with_std):
+    scale = max(1e-30, np.abs(ref).max())
+    return {n: float(np.abs(got[o:o + ln] - ref[o:o + ln]).max() / scale) for n, o, ln in blocks3(S, h3, out, with_std)}
+
+
+def wide3_step(ops, dev, S, h3, A, B, H, N, seed, objective=0, noisy_logprobs=False):
+    from tests.test_mlpn_gpu import random_net_n
+    rng = np.random.default_rng(seed)
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = list(buf_ids[:6]), buf_ids[6]
+    if noisy_logprobs:
+        buf[3] = (buf[3] + 0.5 * rng.standard_normal(buf[3].shape)).astype(np.float32)
+    dims = [S, 256, 128, h3]
+    actor, critic = random_net_n(rng, dims + [A], True), random_net_n(rng, dims + [1], False)
+    spec = ops.MlpSpecN(dims + [A], True)
+    Pa, Pc = spec.count, ops.MlpSpecN(dims + [1], False).count
+    flat = th.full((Pa + Pc + 4,), float("nan"), device=dev)
+    ops.mlpn_ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                      cu(critic.state_avg, dev), cu(critic.state_std, dev), spec, *[cu(x, dev) for x in buf], cu(ids, dev), 0.25, 0.001,
+                      1.0 / B, flat, objective=objective)
+    got = flat.cpu().numpy().astype(np.float64)
+    return got, Pa, Pc, buf, ids, actor, critic
+
+
+WIDE3_SHAPES = [(64, 128, 8), (24, 64, 4), (17, 64, 5), (3, 128, 1), (60, 64, 8), (8, 128, 2)]
+
+
+@pytest.mark.parametrize("S,h3,A", WIDE3_SHAPES)
+@pytest.mark.parametrize("B", [200, 1024, 1])
+def test_wide3_step_against_fp64(ops, dev, S, h3, A, B):
+    """net_dims (256, 128, h3) (examples/demo_A2C_PPO.py:171, :224): erl_mlpn_ppo_step_f32 routes this shape to the fused kernel; both
+    networks' gradients per parameter block and the three objectives against the fp64 restatement"""
+    got, Pa, Pc, buf, ids, actor, critic = wide3_step(ops, dev, S, h3, A, B, 9, 50, 13 * S + B)
+    assert np.isfinite(got).all(), "a slab slot was left unwritten"
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64)
+    ea = block_errors3(got[:Pa], ga, S, h3, A, True)
+    ec = block_errors3(got[Pa:Pa + Pc], gc, S, h3, 1, False)
+    eo = np.abs(got[Pa + Pc:Pa + Pc + 3] - objs) / np.maximum(1e-30, np.abs(objs).max())
+    print(f"S={S} net=(256,128,{h3}) A={A} B={B}: actor {ea}\n  critic {ec}\n  objectives {eo}")
+    assert max(ea.values()) <= 2e-6, f"actor gradient: {ea}"
+    assert max(ec.values()) <= 2e-6, f"critic gradient: {ec}"
+    assert eo.max() <= 2e-6, f"objectives: {eo}"
+    assert got[Pa + Pc + 3] == 0.0
+
+
+@pytest.mark.parametrize("objective", ["canonical", "a2c"])
+def test_wide3_step_objective_forms(ops, dev, objective):
+    got, Pa, Pc, buf, ids, actor, critic = wide3_step(ops, dev, 24, 64, 4, 300, 9, 50, len(objective), {"canonical": 1, "a2c": 2}[objective], True)
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64, objective)
+    ea, ec = block_errors3(got[:Pa], ga, 24, 64, 4, True), block_errors3(got[Pa:Pa + Pc], gc, 24, 64, 1, False)
+    assert max(ea.values()) <= 2e-6 and max(ec.values()) <= 2e-6, (ea, ec)
+    np.testing.assert_allclose(got[Pa + Pc:Pa + Pc + 3], objs, rtol=1e-5, atol=1e-6)
+
+
+def test_wide3_step_at_demo_batch_size(ops, dev):
+    """a full-size minibatch (128 slabs per network) at (256, 128, 128), S = 64, A = 8"""
+    got, Pa, Pc, buf, ids, actor, critic = wide3_step(ops, dev, 64, 128, 8, 16384, 32, 4096, 77)
+    ga, gc, objs = oracle_flat_grads(buf, ids, actor, critic, 0.25, 0.001, np.float64)
+    ea, ec = block_errors3(got[:Pa], ga, 64, 128, 8, True), block_errors3(got[Pa:Pa + Pc], gc, 64, 128, 1, False)
+    eo = np.abs(got[Pa + Pc:Pa + Pc + 3] - objs).max() / np.abs(objs).max()
+    print(f"actor {ea}\ncritic {ec}\nobjectives {eo:.2e}")
+    assert max(ea.values()) < 1e-6 and max(ec.values()) < 1e-6 and eo < 1e-6

@@ -56,3 +56,22 @@ th.cuda.synchronize()
 ev, sp, n = _hip.k6_timing_read2()
 print(f"minibatch kernel alone: {sp / n * 1e6:.1f} us by its own device clock, {ev / n * 1e6:.1f} us inside a HIP-event bracket ({n} launches)")
 _hip.k6_timing_enable(0)
+
+# three hidden layers, (256, 128, h3): the fused kernel sits behind erl_mlpn_ppo_step_f32 (ERL_WIDE_FUSED=0 in the environment = the layered step)
+for h3 in (64, 128):
+    spec3 = ops.MlpSpecN([S, 256, 128, h3, A], True)
+    Pa3, Pc3 = spec3.count, ops.MlpSpecN([S, 256, 128, h3, 1], False).count
+    fl3 = th.randn(Pa3 + Pc3, device=dev, generator=g) * 0.05
+    g3 = th.empty(Pa3 + Pc3 + 4, device=dev)
+    run3 = lambda k: ops.mlpn_ppo_step(fl3[:Pa3], fl3[Pa3:], avg, std, avg, std, spec3, states, actions, um, logprobs, adv, ret, ids[k], 0.25, 0.001,  # noqa: E731
+                                       1.0 / B, g3)
+    for k in range(5):
+        run3(k)
+    th.cuda.synchronize()
+    e0.record()
+    for k in range(T):
+        run3(k)
+    e1.record()
+    th.cuda.synchronize()
+    mode = "layered step (ERL_WIDE_FUSED=0)" if os.environ.get("ERL_WIDE_FUSED") == "0" else "fused kernel + image build + slab reduction"
+    print(f"net (256,128,{h3}) S={S} A={A} B={B}: erl_mlpn_ppo_step_f32, {mode}: {e0.elapsed_time(e1) * 1000 / T:.1f} us per minibatch (no optimiser)")
