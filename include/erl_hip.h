@@ -453,6 +453,10 @@ ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp
  *   erl_mlpn_value_forward_f32  = erl_value_forward_f32,  erl_mlpn_rollout_step_f32 = erl_rollout_step_f32,
  *   erl_mlpn_ppo_step_f32       = erl_ppo_step_f32 + erl_grad_reduce_f32 (writes the summed gradient
  *                                 [actor | critic | obj_critic, obj_surrogate, obj_entropy, 0] straight to flat_grad).
+ * erl_mlpn_ppo_step_f32 with dims = [S <= 64, 256, 128, 64 | 128, A <= 8] (two of the demos' networks) runs as ONE fused kernel on the
+ * bf16 matrix pipe with fp32-equivalent split arithmetic (csrc/ppo_step_wd_impl.h) + an image build + the slab reduction, on
+ * library-owned buffers -- same arguments, same result; `workspace` is not used then; ERL_WIDE_FUSED=0 in the environment keeps the
+ * layered step.
  * ------------------------------------------------------------------------------------------- */
 ERL_API int64_t erl_mlpn_param_count(const int *dims, int n_dims, int with_std_log);
 ERL_API int64_t erl_mlpn_workspace_bytes(const int *dims, int n_dims, int64_t rows, int training);
