@@ -285,6 +285,9 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         RFPROF(2);
 
         // ================= phase 1: layer 2 + the output-layer partials of this wave's k-slice =================
+        // (a wave whose 16 rows of W2 lie beyond h2 -- waves 4..7 of the Pendulum demo's [128, 64] -- holds zero operands: it skips the
+        // chain and leaves its zero partials; the four waves with rows then have the SIMDs' matrix pipes to themselves.  Scalar branch.)
+        if (__builtin_amdgcn_readfirstlane(wave) < n2)
         {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -326,6 +329,10 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             pc = mfma16(w3c.z, h[2], pc);
             pc = mfma16(w3c.w, h[3], pc);
             if (q == 0) PSC[wave * 16 + l15] = on2 ? pc[0] : 0.f;
+        }
+        else {
+            if (!last) *reinterpret_cast<float4 *>(PSA + (wave * 64 + lane) * 4) = zero4();
+            if (q == 0) PSC[wave * 16 + l15] = 0.f;
         }
         RFPROF(3);
         lds_barrier();                                                                               // (2) partials

@@ -12,7 +12,7 @@ from elegantrl_amd import _hip  # noqa: E402
 
 _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "liberl_hip_prof.so")
 from elegantrl_amd.agents import AgentPPO  # noqa: E402
-from elegantrl_amd.envs import SynVecEnv  # noqa: E402
+from elegantrl_amd.envs import PendulumVecEnv, SynVecEnv  # noqa: E402
 from elegantrl_amd.train import Config  # noqa: E402
 
 NAMES = ["state tile -> registers, states[t], L1 of both nets", "barrier 1", "L2 + output partials", "barrier 2",
@@ -23,13 +23,15 @@ def main():
     lib = _hip.lib()
     lib.erl_debug_set_rollout_fused_profile.argtypes = [ctypes.c_void_p]
     lib.erl_debug_set_rollout_fused_profile.restype = None
-    N, S, A, H = 4096, 64, 8, 32
-    args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 1000, "state_dim": S, "action_dim": A,
-                                        "if_discrete": False})
-    args.net_dims, args.horizon_len, args.batch_size = [128, 128], H, 16384
+    pend = os.environ.get("RF_ENV") == "pendulum"             # config 2: Pendulum, net [128, 64], 200 steps
+    N, S, A, H = (4096, 3, 1, 200) if pend else (4096, 64, 8, 32)
+    args = Config(AgentPPO, PendulumVecEnv if pend else SynVecEnv,
+                  {"env_name": "Pendulum-v1" if pend else "SynVecEnv", "num_envs": N, "max_step": 200 if pend else 1000, "state_dim": S,
+                   "action_dim": A, "if_discrete": False})
+    args.net_dims, args.horizon_len, args.batch_size = ([128, 64] if pend else [128, 128]), H, 16384
     args.gpu_id = 0
     agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
-    env = SynVecEnv(N, S, A, max_step=1000, gpu_id=0, seed=0)
+    env = PendulumVecEnv(N, max_step=200, gpu_id=0, seed=0) if pend else SynVecEnv(N, S, A, max_step=1000, gpu_id=0, seed=0)
     agent.last_state = env.reset()[0]
     prof = th.zeros(8 * 16, dtype=th.int64, device="cuda:0")
     lib.erl_debug_set_rollout_fused_profile(prof.data_ptr())
