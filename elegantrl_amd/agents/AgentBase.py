@@ -176,12 +176,19 @@ class AgentBase:
         native = hasattr(env, "step_into")
         state = self.last_state.to(dev, th.float32)
         assert state.shape == (N, self.state_dim)
+        import inspect
+        into_row = "out" in inspect.signature(self.explore_action).parameters     # the agent's kernel writes the action into its buffer row
+        # (the rows as views made once: the loop is bound by the interpreter -- ~45 us per time step for three launches)
+        st_rows, ac_rows, rw_rows, te_rows, tr_rows = states.unbind(0), actions.unbind(0), rewards.unbind(0), terminals.unbind(0), truncates.unbind(0)
         for t in range(H):
-            action = self.explore_action(state) if noise is None else self.explore_action(state, noise[t])
-            states[t] = state
-            actions[t] = action
+            if into_row:
+                action = self.explore_action(state, None if noise is None else noise[t], out=ac_rows[t])
+            else:
+                action = self.explore_action(state) if noise is None else self.explore_action(state, noise[t])
+                ac_rows[t].copy_(action)
+            st_rows[t].copy_(state)
             if native:
-                state = env.step_into(action.contiguous(), rewards[t], terminals[t], truncates[t])
+                state = env.step_into(action if into_row else action.contiguous(), rw_rows[t], te_rows[t], tr_rows[t])
             else:
                 state, reward, terminal, truncate, _ = env.step(action)
                 state = state.to(dev, th.float32)

@@ -167,11 +167,12 @@ class AgentSAC(AgentBase):
             self._sync_modules()
 
     @_hip.on_device
-    def explore_action(self, state: TEN, noise: Optional[TEN] = None) -> TEN:
+    def explore_action(self, state: TEN, noise: Optional[TEN] = None, out: Optional[TEN] = None) -> TEN:
+        """`out` (n, action_dim), contiguous: the kernel writes the action there (the rollout passes its buffer row: no copy)"""
         from .. import ops
         self._sync_modules()
         action = ops.sac_explore_action(self._spec, self._actor_flat, state.contiguous(), noise=noise, seed=self.rng_seed,
-                                        counter=self.rng_counter)
+                                        counter=self.rng_counter, out=out)
         self.rng_counter += 1
         return action
 
