@@ -47,6 +47,8 @@ int erl_clip_adam_soft_f32(float *params, const float *grads, float *exp_avg, fl
                            float grad_scale, float *soft, float tau, hipStream_t stream);
 bool erl_sac_fused_supported(int S, int A, const int *hidden, int n_hidden, int E, int64_t B);
 int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, int64_t Pa, int64_t Pc);
+int erl_sac_explore_fused(const float *actor_params, int S, int A, int h0, int h1, const int64_t *aoff, const float *state, int64_t N,
+                          const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *lp_scratch, hipStream_t sa);
 int erl_sac_update_fused(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m, float *actor_v,
                          float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A, int h0, int h1, int E,
                          const int64_t *aoff, const int64_t *coff, int64_t Pa, int64_t Pc, const float *state, const float *action,

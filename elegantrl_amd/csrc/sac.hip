@@ -550,6 +550,15 @@ extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int 
     hipStream_t s = (hipStream_t)stream;
     int rc;
     Ws ws{(char *)workspace, 0, workspace_bytes};
+    // two hidden layers up to 256 wide, N <= 4096 rows (config 3: 64 envs): one launch, the fused step's actor kernel (sac_fused.hip);
+    // ERL_SAC_FUSED=0 keeps the layered form below
+    static const bool fused_on = [] { const char *e = getenv("ERL_SAC_FUSED"); return !(e && atoi(e) == 0); }();
+    if (fused_on && erl_sac_fused_supported(S, A, hidden, n_hidden, 1, N)) {
+        float *lp_s = ws.take(N);
+        ERL_REQUIRE(lp_s != nullptr, "erl_sac_explore_action_f32: workspace too small");
+        const int64_t aoff[6] = {d.actor.oW[0], d.actor.ob[0], d.actor.oW[1], d.actor.ob[1], d.actor.oW[2], d.actor.ob[2]};
+        return erl_sac_explore_fused(actor_params, S, A, hidden[0], hidden[1], aoff, state, N, noise, seed, counter, action_out, lp_s, s);
+    }
     float *aact[MAXL + 2];
     aact[0] = const_cast<float *>(state);
     for (int l = 1; l <= d.actor.n; ++l) aact[l] = ws.take(N * d.actor.d[l]);

@@ -901,6 +901,25 @@ int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, 
         case 6: KERNEL_MACRO(2, 0); break; case 7: KERNEL_MACRO(2, 1); break; default: KERNEL_MACRO(2, 2); break; \
     }
 
+// ActorSAC.get_action for the off-policy rollout (AgentSAC.py:179-185) as ONE launch: the step's actor_fwd kernel on the rollout's N state
+// rows (16 per workgroup), nothing kept but the action (lp_scratch: N floats the kernel also writes).  Same Philox keys and the same
+// arithmetic per element as the layered form (erl_sac_explore_action_f32's four launches), summed in this kernel's order.
+int erl_sac_explore_fused(const float *actor_params, int S, int A, int h0, int h1, const int64_t *aoff, const float *state, int64_t N,
+                          const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *lp_scratch, hipStream_t sa)
+{
+    FusedDims d{};
+    d.S = S; d.A = A; d.E = 1; d.h0 = h0; d.h1 = h1; d.B = N;
+    d.aW1 = aoff[0]; d.ab1 = aoff[1]; d.aW2 = aoff[2]; d.ab2 = aoff[3]; d.aWh = aoff[4]; d.abh = aoff[5];
+    ActorFwdArgs af{};
+    af.P = actor_params; af.d = d; af.X = state; af.noise = noise; af.seed = seed; af.counter = counter;
+    af.act_t = action_out; af.lp = lp_scratch;
+    const dim3 tgrid((unsigned)((N + TS - 1) / TS)), blk(FT);
+#define LAUNCH_ACTOR_EXPLORE(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, sa, af)
+    FUSED_KT_DISPATCH(LAUNCH_ACTOR_EXPLORE)
+#undef LAUNCH_ACTOR_EXPLORE
+    return erl_hip_status(hipGetLastError(), "erl_sac_explore_action_f32 (fused)");
+}
+
 // The whole step.  Pointers / scalars as erl_sac_update_f32 (sac.hip), which validates them and dispatches here.
 int erl_sac_update_fused(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m, float *actor_v,
                          float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A, int h0, int h1, int E,
