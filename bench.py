@@ -385,6 +385,8 @@ def main():
                     help="after the primary timed region, repeat it this many times and report min / median / max ms per step "
                          "(`extra`; box variance next to the one primary sample; 0 = off)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--eager-logs", action="store_true", help="read update_net's logged objectives at once (one host sync per iteration with the GPU "
+                                                              "idle behind it) instead of one rollout late, as train_agent does by default")
     ap.add_argument("--config", choices=["c4", "c2", "c3", "c5", "cw"], default="c4",
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
                          "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs")
@@ -435,13 +437,28 @@ def main():
     t_explore, t_update = EventTimer(), EventTimer()
     explore_env, update_net = t_explore.wrap(agent.explore_env), t_update.wrap(agent.update_net)
 
+    # the loop of elegantrl_amd.train.run.train_agent_single_process: an update's three logged objectives are read ONE ROLLOUT LATE
+    # (update_net(lazy=True) -> PendingLogs), i.e. after the next rollout has been enqueued -- the GPU runs it while the interpreter
+    # blocks on the finished update instead of idling behind update_net's host sync (--eager-logs: read them at once)
+    lazy = bool(getattr(agent, "supports_lazy_logs", False)) and not opt.eager_logs
+    pend = []
+
     def step():
         items = explore_env(env, HORIZON)
-        return update_net(list(items))
+        out = pend.pop().result() if pend else None
+        r = update_net(list(items), lazy=True) if lazy else update_net(list(items))
+        if hasattr(r, "result"):
+            pend.append(r)
+            return out
+        return r
+
+    def flush():
+        return pend.pop().result() if pend else None
 
     log(f"rank {rank}/{world}: agent + env ready, warm-up x{opt.warmup}")
     for _ in range(opt.warmup):
         step()
+    flush()
     th.cuda.synchronize()
     quiet_gc()
     null_bracket_us = _hip.k6_null_bracket_us(200)       # what an event bracket adds to its content on this box (empty launch)
@@ -454,6 +471,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         objs = step()
+    objs = flush() or objs
     th.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0                  # this rank's own time to its last kernel (before the closing barrier)
     parallel.barrier()
@@ -473,6 +491,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(opt.steps):
             step()
+        flush()
         th.cuda.synchronize()
         parallel.barrier()
         repeats.append(parallel.all_reduce_max_float(time.perf_counter() - t1, device=dev) / opt.steps * 1e3)
@@ -484,11 +503,13 @@ def main():
         prev_arith, agent.ppo_arith = agent.ppo_arith, "f32"      # (the agent applies its ppo_arith at every update_net)
         for _ in range(2):
             step()
+        flush()
         parallel.barrier()
         th.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(opt.steps):
             objs_f32 = step()
+        objs_f32 = flush() or objs_f32
         th.cuda.synchronize()
         parallel.barrier()
         el = parallel.all_reduce_max_float(time.perf_counter() - t1, device=dev)
@@ -567,6 +588,9 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "last_state": "private copy (reference behaviour)" if agent.snapshot_last_state else "aliases the env's live state buffer",
                    "interpreter": "gc.collect() + gc.freeze() after the warm-up (as elegantrl_amd.train.run does)",
+                   "logs": ("update_net's three logged objectives are read one rollout late (update_net(lazy=True), as elegantrl_amd.train.run does): "
+                            "no host sync between an update and the next rollout's launch; every kernel of the K steps and the last read are inside the timed region"
+                            if lazy else "read at once (one host sync per iteration)"),
                    "k6_arith": ("split: fp32 operands as three bf16 parts on the bf16 matrix pipe, fp32 accumulate (as close to fp64 as the "
                                 "fp32 MFMA: tests/test_kernels_gpu.py::test_ppo_step_split_arith)" if k6_arith == "split" else "f32 MFMA")},
         "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),

@@ -108,10 +108,33 @@ class FlatAdam:
         self.param_groups = [{"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8}]
 
 
+class PendingLogs:
+    """update_net(..., lazy=True): the logged objectives of an update whose kernels are still running.  `result()` -> the three floats
+    update_net returns otherwise (and the device-fault check that goes with its host sync)."""
+
+    def __init__(self, agent):
+        ring = agent.__dict__.setdefault("_lazy_ring", [])
+        if len(ring) < 2:                                   # two pinned blocks, used in turn (allocated once: hipHostMalloc is slow)
+            ring.append((th.empty(4, dtype=th.float32, pin_memory=True), th.cuda.Event()))
+        agent._lazy_turn = (getattr(agent, "_lazy_turn", -1) + 1) % 2
+        self._host, self._event = ring[min(agent._lazy_turn, len(ring) - 1)]
+        self._host.copy_(agent._logs, non_blocking=True)
+        self._event.record()
+        self._vals = None
+
+    def result(self) -> Tuple[float, float, float]:
+        if self._vals is None:
+            self._event.synchronize()
+            self._vals = tuple(self._host[:3].tolist())
+            _hip.check_async_faults()
+        return self._vals
+
+
 class AgentPPO(AgentBase):
     """PPO + GAE, reference-form objective, HIP kernels."""
     _discrete = False            # AgentDiscretePPO: categorical head on the layered path
     _actor_class = ActorPPO
+    supports_lazy_logs = True          # update_net(..., lazy=True) -> PendingLogs (train_agent reads it after the next rollout is enqueued)
 
     def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
         args = Config() if args is None else args
@@ -478,7 +501,7 @@ class AgentPPO(AgentBase):
 
     # ---- update: AgentPPO.py:135-205 ------------------------------------------------------------------
     @_hip.on_device
-    def update_net(self, buffer, ids: Optional[TEN] = None) -> Tuple[float, float, float]:
+    def update_net(self, buffer, ids: Optional[TEN] = None, lazy: bool = False) -> Tuple[float, float, float]:
         """One PPO update on the rollout `buffer`; returns (obj_critic, obj_surrogate, obj_entropy) means.
         `ids` (update_times, batch_size) int64 injects the minibatch indices (tests); otherwise they are drawn
         with th.randint(H*N, ...) like the reference."""
@@ -611,6 +634,11 @@ class AgentPPO(AgentBase):
         else:
             _hip.check(_hip.lib().erl_ppo_logs_mean_f32(_hip.ptr(self._grads, th.float32), self._stride, self._Pa + self._Pc, update_times,
                                                         grad_scale, _hip.ptr(self._logs, th.float32), _hip.stream_ptr()), "erl_ppo_logs_mean_f32")
+        if lazy:
+            # the three logged means travel to a pinned host block behind the update's last kernel; PendingLogs.result() waits for that
+            # copy only.  The caller enqueues the next rollout first (train_agent does): the GPU no longer idles behind this host sync
+            # while the interpreter works its way to the next launch (~70 us of a 2.3 ms iteration at config 4).
+            return PendingLogs(self)
         obj_critic, obj_actor, obj_entropy = self._logs[:3].tolist()                  # the only host sync of update_net
         _hip.check_async_faults()              # the stream is drained: a lost look-back predecessor (NaN advantages) raises here
         return obj_critic, obj_actor, obj_entropy
@@ -645,6 +673,7 @@ class AgentA2C(AgentPPO):
     ValueError otherwise).  With one env the reference's `get_logprob_entropy(...).sum(1)` sums over the env axis (size 1)
     instead of the action axis, so `new_logprob` is per action dimension and the mean runs over (batch, action_dim): the
     objective is mean_B(adv * logp) / action_dim -- reproduced (ERL_PPO_OBJ_A2C, csrc/ppo_objective.h)."""
+    supports_lazy_logs = False
 
     def __init__(self, net_dims: List[int], state_dim: int, action_dim: int, gpu_id: int = 0, args: Config = None):
         super().__init__(net_dims, state_dim, action_dim, gpu_id, args)

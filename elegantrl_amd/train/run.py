@@ -92,6 +92,15 @@ def train_agent_single_process(args: Config):
     total_step, start = 0, time.time()
     if_train = True
     n_iter = 0
+    lazy_ok = bool(getattr(args, "lazy_logs", True)) and bool(getattr(agent, "supports_lazy_logs", False)) and not if_off_policy
+    pending = None
+
+    def report(exp_r, logs, steps):
+        logging_tuple = logs.result() if hasattr(logs, "result") else logs
+        logging_tuple = (*logging_tuple, agent.explore_rate, "")
+        if evaluator is not None:
+            evaluator.evaluate_and_save(actor=agent.act, steps=steps, exp_r=float(exp_r), logging_tuple=logging_tuple)
+
     while if_train:
         n_iter += 1
         if n_iter == 3 and getattr(args, "gc_freeze", True):
@@ -105,21 +114,34 @@ def train_agent_single_process(args: Config):
             buffer.update(buffer_items)
         else:
             buffer[:] = buffer_items
-        exp_r = buffer_items[2].mean().item()        # (for on-policy this is mean(logprobs), as in run.py:122)
+        exp_r = buffer_items[2].mean()               # (for on-policy this is mean(logprobs), as in run.py:122); read below
 
+        # Agents whose update_net can hand its logged objectives over later (AgentPPO's fused paths: lazy=True -> PendingLogs) are read
+        # ONE ROLLOUT LATE: iteration k's numbers reach the evaluator after iteration k + 1's rollout has been enqueued, so the GPU runs
+        # that rollout while the interpreter blocks on the (already finished) logs instead of idling behind every update_net
+        # (args.lazy_logs = False: read them at once, as the reference does)
+        if pending is not None:
+            report(*pending)
+            pending = None
         th.set_grad_enabled(True)
-        logging_tuple = agent.update_net(buffer)
-        logging_tuple = (*logging_tuple, agent.explore_rate, "")
+        if lazy_ok:
+            logs = agent.update_net(buffer, lazy=True)
+        else:
+            logs = agent.update_net(buffer)
         th.set_grad_enabled(False)
 
         total_step += horizon_len
-        if evaluator is not None:
-            evaluator.evaluate_and_save(actor=agent.act, steps=horizon_len, exp_r=exp_r, logging_tuple=logging_tuple)
+        if lazy_ok and hasattr(logs, "result"):
+            pending = (exp_r, logs, horizon_len)
+        else:
+            report(exp_r, logs, horizon_len)
         stop = (total_step > break_step) or os.path.exists(f"{cwd}/stop")
         if world > 1:
             stop = parallel.all_reduce_max_float(float(stop), device=agent.device) > 0
         if_train = not stop
 
+    if pending is not None:
+        report(*pending)
     if rank == 0:
         env_steps = total_step * args.num_envs * world
         print(f"| UsedTime: {time.time() - start:>7.0f} | SavedDir: {cwd} | env-steps: {env_steps:.3e}", flush=True)

@@ -413,3 +413,36 @@ def test_train_agent_ppo_pendulum_learns(tmp_path):
     rec = np.load(os.path.join(args.cwd, "recorder.npy"))
     assert np.isfinite(rec[:, :4]).all()
     assert rec[:, 1].max() > -400.0, f"PPO did not learn Pendulum: evaluated returns {np.round(rec[:, 1], 1).tolist()}"
+
+
+def test_update_net_lazy_logs_are_the_eager_ones():
+    """update_net(lazy=True) returns its three logged objectives as a PendingLogs (read after the next rollout is enqueued: what
+    train_agent does); same numbers, same weights as the blocking form, also when two updates are in flight before the first is read"""
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.agents.AgentPPO import PendingLogs
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config
+    N, S, A, H, B = 256, 16, 4, 8, 512
+    out = {}
+    for lazy in (False, True):
+        args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 6, "state_dim": S, "action_dim": A, "if_discrete": False})
+        args.net_dims, args.horizon_len, args.batch_size, args.repeat_times = [128, 128], H, B, 2 * B / H
+        th.manual_seed(11)
+        agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
+        env = SynVecEnv(N, S, A, max_step=6, gpu_id=0, seed=3)
+        agent.last_state = env.reset()[0]
+        logs, pend = [], []
+        for it in range(3):
+            items = agent.explore_env(env, H)
+            if lazy:
+                r = agent.update_net(list(items), lazy=True)
+                assert isinstance(r, PendingLogs)
+                pend.append(r)
+                if len(pend) == 2:                       # read one rollout late
+                    logs.append(pend.pop(0).result())
+            else:
+                logs.append(agent.update_net(list(items)))
+        logs += [p.result() for p in pend]
+        out[lazy] = (np.array(logs), agent._flat.detach().cpu().numpy().copy())
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    np.testing.assert_array_equal(out[True][1], out[False][1])
