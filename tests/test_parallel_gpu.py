@@ -443,3 +443,21 @@ def test_one_rank_comm_matches_single_process(tmp_path, net):
         assert bool(run["used_comm"]) == (mode != "torch"), f"{mode}: library communicator did not come up on the GPU box"
         np.testing.assert_array_equal(plain["w"], run["w"])
         np.testing.assert_array_equal(plain["logs"], run["logs"])
+
+
+_WIDE = (128, 24, 4, 8, 256, (256, 128))      # N, S, A, H, B, net_dims: the reference demo's (256, 128) network (csrc/ppo_step_wd_impl.h)
+
+
+def test_two_rank_agent_with_the_wide_minibatch_kernel(tmp_path):
+    """two data-parallel ranks on one GPU with net_dims (256, 128): the fused wide minibatch kernel under the `torch` route (gradient rows
+    of 80k floats all-reduced by torch.distributed); ranks end bit-identical.  (The in-launch peer-to-peer exchange cannot be exercised
+    with this kernel on ONE shared GPU: a rank's spinning exchange workgroups occupy SIMDs, and the other rank's minibatch kernel needs
+    whole CUs -- 512 registers per wave, 154 KB of LDS -- to start; with one GPU per rank the two never compete.)"""
+    (tmp_path / "torch").mkdir()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path / "torch"), "gloo", False, "torch", _WIDE), nprocs=2, join=True)
+    wt, w0 = _load(tmp_path, "torch", "w", 2), _load(tmp_path, "torch", "w0", 2)
+    np.testing.assert_array_equal(w0[0], w0[1])
+    np.testing.assert_array_equal(wt[0], wt[1])
+    assert not np.array_equal(wt[0], w0[0]) and np.isfinite(wt[0]).all()
+    stats = _load(tmp_path, "torch", "stats", 2)
+    np.testing.assert_array_equal(stats[0], stats[1])
