@@ -165,14 +165,18 @@ def kernel_source_sha16(kernel: str):
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+WIDE_PMC_FILE = os.path.join("profiles", "r04_wide_pmc_traffic_S8_h128.json")     # tools/wide_pmc_workload.py, WD_S=8 WD_A=2 WD_ONLY=128 (cw's shape)
+
+
+def pmc_traffic(kernel, file=None):
     """(HBM bytes per launch, provenance) from the committed rocprofv3 PMC passes (PMC_FILE: separate --pmc FETCH_SIZE /
     WRITE_SIZE passes, gfx950 correction applied, tools/pmc_summarise.py).  The file stamps every kernel with the hash of
     the sources it was collected on; when the kernel's sources have changed since, the number is STALE and None is
     reported (bench.py itself cannot collect counters: that needs rocprofv3 around the process)."""
-    src = {"file": PMC_FILE, "kernel_source_sha16": kernel_source_sha16(kernel), "collected_on_sha16": None, "stale": True}
+    file = file or PMC_FILE
+    src = {"file": file, "kernel_source_sha16": kernel_source_sha16(kernel), "collected_on_sha16": None, "stale": True}
     try:
-        prof = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        prof = json.load(open(os.path.join(ROOT, file)))
         v = prof["kernels"][kernel]
         src["collected_on_sha16"] = v.get("source_sha16")
         src["stale"] = v.get("source_sha16") != src["kernel_source_sha16"]
@@ -561,7 +565,8 @@ def main():
     # algorithmic flop on the bf16 matrix pipe; the fp32 kernel runs on the fp32 MFMA
     k6_peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS if k6_arith == "split" else MFMA_F32_PEAK_TFLOPS
     gae_s = t_gae.mean_seconds()
-    k6_traffic, k6_traffic_src = pmc_traffic(k6_kernel) if opt.config == "c4" else (None, None)
+    k6_traffic, k6_traffic_src = (pmc_traffic(k6_kernel) if opt.config == "c4" else
+                                  pmc_traffic(k6_kernel, WIDE_PMC_FILE) if opt.config == "cw" else (None, None))
     k6_rocprof_us, k6_rocprof_src = rocprof_kernel_us(k6_kernel) if opt.config == "c4" else (None, None)
     # the parts of a step against the step: explore_env + update_net brackets (each carries one bracket overhead) must fit into
     # ms_per_step, and the K6 launches must fit into update_net
