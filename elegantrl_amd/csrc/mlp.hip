@@ -1,5 +1,5 @@
 // K1 rollout step and K2 value pre-pass on the register-chained MLP (mlp_chain.h), slab reduction of K6, MFMA self-test.
-// gfx950 / fp32 MFMA.
+// gfx950 / fp32 MFMA; the latency form of K1 runs its hidden layers on the bf16 matrix pipe (rollout_bf16.h).
 //
 // K1  one vectorised rollout step = ActorPPO.get_action + the three buffer stores + convert_action_for_env
 //     (elegantrl/agents/AgentPPO.py:113-119, :368-376, :388-390).  A wave owns 16 envs; 4 waves per workgroup share
@@ -9,6 +9,7 @@
 // K2  value pre-pass: persistent workgroups of 8 waves; a wave walks 16-row tiles with the next tile's state rows
 //     prefetched under the current tile's MFMAs  (AgentPPO.py:141-143, :219-220, :435-441).
 #include "mlp_chain.h"
+#include "rollout_bf16.h"
 #include "ppo_step_wd.h"
 
 namespace {
@@ -216,22 +217,24 @@ __global__ __launch_bounds__(256) void rollout_step2_kernel(FwdArgs g)
 // dependent chain, so what counts is the length of that chain, not throughput).  The 8 waves of a workgroup split
 // the OUTPUT features of each layer: wave w owns feature tile w (rows 16 w .. 16 w + 15 of W1 and of W2) and reads
 // exactly those weight rows straight from L2 into registers as MFMA A operands -- all of them, together with the
-// state tile, in ONE round trip issued before anything else; no LDS weight image, no staging barrier.
-//   L1: 16 x 16 tile of H1^T per wave (ns x 4 MFMAs on two accumulators)  -> LDS image T1[sample][feature] -> barrier
-//   L2: every wave reads all of H1 back as B operands (8 ds_read_b128), n1 x 4 MFMAs -> its H2^T tile in registers
+// state tile, in ONE round trip issued before anything else; no LDS weight image, no staging barrier.  Both hidden layers
+// run on v_mfma_f32_16x16x32_bf16 from three-way bf16 splits of both operands (rollout_bf16.h: six partial products, fp32
+// accumulation -- as close to fp64 as the fp32 instruction, 2.7x less matrix-pipe time), instruction for instruction what
+// the persistent rollout (rollout_fused.hip) does per step.
+//   L1: 16 x 16 tile of H1^T per wave (6 MFMAs per 32 state columns) -> split -> LDS tile T1[part][sample][feature] -> barrier
+//   L2: every wave reads all of H1 back as B operands (3 ds_read_b128 per 32 features), 6 MFMAs each -> its H2^T tile in registers
 //   out: the wave's H2 tile IS the k-slice 16 w .. 16 w + 15 of the output layer: 4 MFMAs give a partial Y^T;
 //        the 8 partials meet in LDS, wave 0 adds them in a fixed order and does the sampling / log-prob / stores.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kSplitLd = 132;   // T1 row stride (floats): 16-byte aligned rows, consecutive samples 4 banks apart
-
 template <int NS_, int N1_, int N2_, bool VEC>
 __global__ __launch_bounds__(512) void rollout_split_kernel(FwdArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float T1[16 * kSplitLd];
+    __shared__ __attribute__((aligned(16))) u8 T1[RB_TBYTES];
     __shared__ __attribute__((aligned(16))) float PS[8 * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const Dims d{g.S, N1_ ? 16 * N1_ : g.h1, N2_ ? 16 * N2_ : g.h2, g.out};
-    const int S = d.S, A = d.out, ns = NS_ ? NS_ : (S + 15) >> 4, n1 = d.h1 >> 4, n2 = d.h2 >> 4;
+    const int S = d.S, A = d.out, n1 = d.h1 >> 4, n2 = d.h2 >> 4;
+    const int ks_s = NS_ ? (NS_ + 1) >> 1 : (S + 31) >> 5, ks_1 = d.h1 >> 5;      // k-steps of 32 (rollout_bf16.h)
     const bool on1 = wave < n1, on2 = wave < n2;
     const float *std_log = g.P + d.oStd();
 
@@ -240,16 +243,25 @@ __global__ __launch_bounds__(512) void rollout_split_kernel(FwdArgs g)
     const int64_t row = valid ? env : g.rows - 1;
 
     RPROF(0);
-    // ---- every global load of the step, issued back to back ----
-    float4 XR[8], w1[8], w2[8];
-    load_rows_raw<VEC>(XR, g.states + row * S, ns, S, q);
+    // ---- every global load of the step, issued back to back: the lane's 8-column groups k = 32 ks + 8 q .. + 7 ----
+    float4 XR[8], w1r[8], w2r[8];
     {
+        const float *srow = g.states + row * S;
         const float *r1 = g.P + d.oW1() + (size_t)min(16 * wave + l15, d.h1 - 1) * S;
         const float *r2 = g.P + d.oW2() + (size_t)min(16 * wave + l15, d.h2 - 1) * d.h1;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (t < ns) w1[t] = load4<VEC>(r1, 16 * t + 4 * q, S);
-            if (t < n1) w2[t] = load4<VEC>(r2, 16 * t + 4 * q, d.h1);
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k0 = 32 * ks + 8 * q;
+            if (ks < ks_s) {
+                XR[2 * ks] = load4<VEC>(srow, k0, S);
+                XR[2 * ks + 1] = load4<VEC>(srow, k0 + 4, S);
+                w1r[2 * ks] = load4<VEC>(r1, k0, S);
+                w1r[2 * ks + 1] = load4<VEC>(r1, k0 + 4, S);
+            }
+            if (ks < ks_1) {
+                w2r[2 * ks] = load4<VEC>(r2, k0, d.h1);
+                w2r[2 * ks + 1] = load4<VEC>(r2, k0 + 4, d.h1);
+            }
         }
     }
     const int kt = min(wave, n2 - 1);                      // this wave's k-tile of the output layer
@@ -270,8 +282,8 @@ __global__ __launch_bounds__(512) void rollout_split_kernel(FwdArgs g)
     if (wave == 7 && g.o_state && valid) {   // states[t] = state: raw rows, the lane's 4-float groups
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            if (t < ns) {
-                const int k0 = 16 * t + 4 * q;
+            if ((t >> 1) < ks_s) {
+                const int k0 = 32 * (t >> 1) + 8 * q + 4 * (t & 1);
                 float *dst = g.o_state + row * S + k0;
                 if (VEC) { if (k0 < S) *reinterpret_cast<float4 *>(dst) = XR[t]; }
                 else {
@@ -283,51 +295,55 @@ __global__ __launch_bounds__(512) void rollout_split_kernel(FwdArgs g)
         }
     }
     RPROF(1);
-    f32x4 X[8];
-    normalise_rows<VEC>(XR, X, g.avg, g.sd, ns, S, q, valid);
+    // (s - avg) / (std + 1e-4), AgentPPO.py:360-361; columns >= S and rows past the end are zero
+    Parts X[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks < ks_s) {
+            float4 xn[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int k0 = 32 * ks + 8 * q + 4 * hh;
+                const float4 a4 = load4<VEC>(g.avg, k0, S), s4 = load4<VEC>(g.sd, k0, S), x4 = XR[2 * ks + hh];
+                xn[hh].x = (valid && k0 + 0 < S) ? (x4.x - a4.x) / (s4.x + 1e-4f) : 0.f;
+                xn[hh].y = (valid && k0 + 1 < S) ? (x4.y - a4.y) / (s4.y + 1e-4f) : 0.f;
+                xn[hh].z = (valid && k0 + 2 < S) ? (x4.z - a4.z) / (s4.z + 1e-4f) : 0.f;
+                xn[hh].w = (valid && k0 + 3 < S) ? (x4.w - a4.w) / (s4.w + 1e-4f) : 0.f;
+            }
+            X[ks] = rb_split8(xn[0], xn[1]);
+        }
+    }
     RPROF(2);
 
     // ---- L1: this wave's feature tile of H1^T ----
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    {
+        RbAcc acc;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (t < ns) {
-            a0 = mfma16(w1[t].x, X[t][0], a0);
-            a1 = mfma16(w1[t].y, X[t][1], a1);
-            a0 = mfma16(w1[t].z, X[t][2], a0);
-            a1 = mfma16(w1[t].w, X[t][3], a1);
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < ks_s) rb_mma6(rb_split8(w1r[2 * ks], w1r[2 * ks + 1]), X[ks], acc);
+        if (on1) {
+            const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+            float h[4], gd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(acc, r) + bb[r], h[r], gd);
+            rb_tile_put(T1, RB_TLD, l15, 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
         }
-    }
-    if (on1) {
-        const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
-        float h[4], gd;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
-        *reinterpret_cast<float4 *>(T1 + l15 * kSplitLd + 16 * wave + 4 * q) = make_float4(h[0], h[1], h[2], h[3]);
     }
     RPROF(3);
     lds_barrier();
     RPROF(4);
 
     // ---- L2: all of H1 back as B operands, this wave's feature tile of H2^T stays in registers ----
-    a0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (t < n1) {
-            const float4 hv = *reinterpret_cast<const float4 *>(T1 + l15 * kSplitLd + 16 * t + 4 * q);
-            a0 = mfma16(w2[t].x, hv.x, a0);
-            a1 = mfma16(w2[t].y, hv.y, a1);
-            a0 = mfma16(w2[t].z, hv.z, a0);
-            a1 = mfma16(w2[t].w, hv.w, a1);
-        }
-    }
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
     {
+        RbAcc acc;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < ks_1) rb_mma6(rb_split8(w2r[2 * ks], w2r[2 * ks + 1]), rb_tile_get(T1, RB_TLD, l15, ks, q), acc);
         const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
         float h[4], gd;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
+        for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(acc, r) + bb[r], h[r], gd);
         // ---- output layer, k-slice 16 w + 4 q + r: the B operand is the tile just computed ----
         part = mfma16(w3.x, h[0], part);
         part = mfma16(w3.y, h[1], part);

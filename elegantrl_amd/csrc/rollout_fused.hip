@@ -1,4 +1,5 @@
-// Persistent H-step rollout for device-resident environments: ONE launch per AgentPPO.explore_env.  gfx950 / fp32 MFMA.
+// Persistent H-step rollout for device-resident environments: ONE launch per AgentPPO.explore_env.  gfx950; hidden layers on the
+// bf16 matrix pipe (three-way operand split, rollout_bf16.h), output layers and the environment on the fp32 MFMA.
 //
 // Replaces the whole loop of AgentPPO._explore_vec_env (elegantrl/agents/AgentPPO.py:87-129): for t in range(H):
 // ActorPPO.get_action (:368-376), the three buffer stores (:115-117), convert_action_for_env (:388-390), env.step, the
@@ -8,11 +9,12 @@
 //
 // Envs are independent, so a workgroup (8 waves) owns a 16-env tile for all H steps; nothing crosses workgroups and there
 // is no launch, no weight re-read and no HBM round trip between steps:
-//   * wave w holds rows 16 w .. 16 w + 15 of W2 of BOTH networks (the big operand: 2 x 32 VGPRs) and its k-slice of the
-//     output layers in registers as MFMA A operands for the whole rollout (v_mfma_f32_16x16x4_f32; the layout of the
-//     latency-form step kernel, mlp.hip rollout_split_kernel); the W1 images and -- SynVecEnv -- Ws^T / Wa^T sit in LDS
-//     (one conflict-free ds_read_b128 per 4 MFMAs), loaded once per launch;
-//   * the state tile lives in LDS (XS); per step: L1 of both nets -> H1 tiles to LDS -> barrier -> L2 + output-layer
+//   * wave w holds rows 16 w .. 16 w + 15 of W2 of BOTH networks and of the actor's W1 in registers for the whole rollout, split
+//     once into their three bf16 parts (A operands of v_mfma_f32_16x16x32_bf16: 2 x 48 + 24 VGPRs; the layout of the latency-form
+//     step kernel, mlp.hip rollout_split_kernel), and its k-slice of the output layers (fp32); the critic's W1 (split), the
+//     biases and -- SynVecEnv -- Ws^T / Wa^T sit in LDS, loaded once per launch: 256 registers per lane are all a wave has at two
+//     waves per SIMD, and with a fourth weight block in them the step loop spilled;
+//   * the state tile lives in LDS (XS, and normalised + split per network: XA / XC); per step: L1 of both nets -> H1 tiles (split) to LDS -> barrier -> L2 + output-layer
 //     partials -> LDS -> barrier -> waves < ceil(S/16) finish the policy head in registers (action, log-prob, tanh) and
 //     step the env on the matrix cores, wave 7 finishes the value, waves 4..7 draw the next step's N(0,1) (injected or
 //     Philox4x32-10) -> barrier -> done flags, auto-reset, new state tile -> barrier.  Four LDS-only barriers per step; the
@@ -27,12 +29,12 @@
 #include "erl_common.h"
 #include "gae_step.h"
 #include "mlp_chain.h"
+#include "rollout_bf16.h"
 
 namespace {
 
 constexpr int RF_NSM = 4;      // state k-tiles of 16 held per lane: state_dim <= 64
 constexpr int RF_XLD = 68;     // row stride of the state tile XS[16][.]
-constexpr int RF_TLD = 132;    // row stride of the H1 tiles (as kSplitLd in mlp.hip)
 
 struct RfArgs {
     const float *Pa, *Pc;                          // actor / critic flat parameter blocks (include/erl_hip.h)
@@ -83,20 +85,22 @@ enum { ENV_SYN = 0, ENV_PENDULUM = 1 };
 constexpr int RF_WLD = 68;     // row stride of the LDS operand images (W1 rows, Ws^T rows): 16-byte rows, 4 banks apart
 // dynamic LDS layout (floats)
 constexpr int RF_O_XS = 0;                              // [16][RF_XLD]   state tile
-constexpr int RF_O_XA = RF_O_XS + 16 * RF_XLD;          // [16][RF_XLD]   state tile normalised for the actor
-constexpr int RF_O_XC = RF_O_XA + 16 * RF_XLD;          // [16][RF_XLD]   ... for the critic
-constexpr int RF_O_NRM = RF_O_XC + 16 * RF_XLD;         // [4][64]        avg_a | den_a | avg_c | den_c  (den = std + 1e-4)
-constexpr int RF_O_T1A = RF_O_NRM + 4 * 64;             // [16][RF_TLD]   actor H1 tile
-constexpr int RF_O_T1C = RF_O_T1A + 16 * RF_TLD;        // [16][RF_TLD]   critic H1 tile
-constexpr int RF_O_PSA = RF_O_T1C + 16 * RF_TLD;        // [8][64][4]     actor output-layer partials
+constexpr int RF_O_XA = RF_O_XS + 16 * RF_XLD;          // [3][16][RB_XLD bytes]  state tile normalised for the actor, split (rollout_bf16.h)
+constexpr int RF_O_XC = RF_O_XA + RB_XBYTES / 4;        //                ... for the critic
+constexpr int RF_O_NRM = RF_O_XC + RB_XBYTES / 4;       // [4][64]        avg_a | den_a | avg_c | den_c  (den = std + 1e-4)
+constexpr int RF_O_T1A = RF_O_NRM + 4 * 64;             // [3][16][RB_TLD bytes]  actor H1 tile, split
+constexpr int RF_O_T1C = RF_O_T1A + RB_TBYTES / 4;      //                critic H1 tile
+constexpr int RF_O_PSA = RF_O_T1C + RB_TBYTES / 4;      // [8][64][4]     actor output-layer partials
 constexpr int RF_O_PSC = RF_O_PSA + 8 * 64 * 4;         // [8][16]        critic output-layer partials
 constexpr int RF_O_EPS = RF_O_PSC + 8 * 16;             // [2][16][16]    N(0,1) draws of step t (t & 1) and t + 1, produced a step ahead
 constexpr int RF_O_RED = RF_O_EPS + 2 * 16 * 16;        // [8][16][2]     env reductions
-constexpr int RF_O_W1A = RF_O_RED + 8 * 16 * 2;         // [128][RF_WLD]  actor W1 (rows >= h1 / cols >= S zero)
-constexpr int RF_O_W1C = RF_O_W1A + 128 * RF_WLD;       // [128][RF_WLD]  critic W1
-constexpr int RF_O_WST = RF_O_W1C + 128 * RF_WLD;       // [64][RF_WLD]   Ws^T: WST[j][k] = Ws[k][j]
+constexpr int RF_O_BIA = RF_O_RED + 8 * 16 * 2;         // [4][128]       b1 | b2 of the actor, b1 | b2 of the critic (zero beyond h)
+constexpr int RF_O_HEAD = RF_O_BIA + 4 * 128;           // [2][16]        action_std_log | b3 of the actor (index clamped to A - 1)
+constexpr int RF_O_WST = RF_O_HEAD + 32;                // [64][RF_WLD]   Ws^T: WST[j][k] = Ws[k][j]
 constexpr int RF_O_WAT = RF_O_WST + 64 * RF_WLD;        // [64][16]       Wa^T
-constexpr int RF_FLOATS = RF_O_WAT + 64 * 16;
+constexpr int RF_O_W1C = RF_O_WAT + 64 * 16;            // [128][RF_W1LD bytes]  critic W1, split: [row][3 parts][64 bf16] + 16 bytes (A operands of layer 1)
+constexpr int RF_W1LD = 3 * 128 + 16;                   //                rows 100 dwords apart: the 16 rows of a ds_read_b128 lane group on 16 distinct 4-bank groups
+constexpr int RF_FLOATS = RF_O_W1C + 128 * RF_W1LD / 4;
 constexpr size_t kRfLdsBytes = (size_t)RF_FLOATS * sizeof(float);
 // the advantage epilogue keeps its inputs -- [t][reward | value | flags][16 envs] + the bootstrap values -- behind the layout above while
 // they fit (192 bytes per step); longer horizons read them back from the rollout buffers
@@ -111,14 +115,18 @@ template <int ENV, bool VEC, int NS_, int N1_, int N2_>
 __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *XS = smem + RF_O_XS, *XA = smem + RF_O_XA, *XC = smem + RF_O_XC, *NRM = smem + RF_O_NRM, *T1A = smem + RF_O_T1A, *T1C = smem + RF_O_T1C, *PSA = smem + RF_O_PSA;
+    float *XS = smem + RF_O_XS, *NRM = smem + RF_O_NRM, *PSA = smem + RF_O_PSA;
+    u8 *XA = reinterpret_cast<u8 *>(smem + RF_O_XA), *XC = reinterpret_cast<u8 *>(smem + RF_O_XC);
+    u8 *T1A = reinterpret_cast<u8 *>(smem + RF_O_T1A), *T1C = reinterpret_cast<u8 *>(smem + RF_O_T1C);
     float *PSC = smem + RF_O_PSC, *EPS = smem + RF_O_EPS, *RED = smem + RF_O_RED;
-    float *W1A = smem + RF_O_W1A, *W1C = smem + RF_O_W1C, *WST = smem + RF_O_WST, *WAT = smem + RF_O_WAT;
+    float *WST = smem + RF_O_WST, *WAT = smem + RF_O_WAT, *BIA = smem + RF_O_BIA;
+    u8 *W1C = reinterpret_cast<u8 *>(smem + RF_O_W1C);
     float *GAE = smem + RF_FLOATS;            // [H][3][16] + [16] (only with g.gae_lds)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const Dims da{g.S, g.h1, g.h2, g.A}, dc{g.S, g.h1, g.h2, 1};
     const int S = g.S, A = g.A, ns = NS_ ? NS_ : (S + 15) >> 4, n1 = N1_ ? N1_ : g.h1 >> 4, n2 = N2_ ? N2_ : g.h2 >> 4;
+    const int ks_s = NS_ ? (NS_ + 1) >> 1 : (S + 31) >> 5, ks_1 = N1_ ? N1_ >> 1 : g.h1 >> 5;      // k-steps of 32 (rollout_bf16.h)
     const bool on1 = wave < n1, on2 = wave < n2;
     const int64_t env0 = (int64_t)blockIdx.x * 16;
     const int64_t env = env0 + l15;
@@ -131,13 +139,23 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     // the normalisation constants into LDS; columns >= S stay 0 for the whole rollout.  The normalised tiles are written by
     // whoever produces a state (here, then the env waves): 8 divides per producing lane per step instead of 32 per lane in
     // every one of the 8 waves that consume the tile as an MFMA B operand.
-    for (int e = tid; e < 16 * 64; e += 512) {
-        const int i = e >> 6, k = e & 63, kc = min(k, S - 1);
+    {
+        const int i = tid >> 5, k = 2 * (tid & 31);          // 512 threads x 2 columns = the 16 x 64 tile
         const int64_t r_ = min(env0 + i, g.N - 1);
-        const float x = g.env_state[r_ * S + kc];
-        XS[i * RF_XLD + k] = (k < S) ? x : 0.f;
-        XA[i * RF_XLD + k] = (k < S) ? (x - g.avg_a[kc]) / (g.std_a[kc] + 1e-4f) : 0.f;
-        XC[i * RF_XLD + k] = (k < S) ? (x - g.avg_c[kc]) / (g.std_c[kc] + 1e-4f) : 0.f;
+        float xs[2], xa[2], xc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int kc = min(k + c, S - 1);
+            const float x = g.env_state[r_ * S + kc];
+            const bool in = k + c < S;
+            xs[c] = in ? x : 0.f;
+            xa[c] = in ? (x - g.avg_a[kc]) / (g.std_a[kc] + 1e-4f) : 0.f;
+            xc[c] = in ? (x - g.avg_c[kc]) / (g.std_c[kc] + 1e-4f) : 0.f;
+        }
+        XS[i * RF_XLD + k] = xs[0];
+        XS[i * RF_XLD + k + 1] = xs[1];
+        rb_tile_put2(XA, RB_XLD, i, k, xa[0], xa[1]);
+        rb_tile_put2(XC, RB_XLD, i, k, xc[0], xc[1]);
     }
     if (tid < 256) {
         const int which = tid >> 6, k = tid & 63, kc = min(k, S - 1);
@@ -148,13 +166,6 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         else v = g.std_c[kc] + 1e-4f;
         if (k >= S) v = (which & 1) ? 1.f : 0.f;
         NRM[tid] = v;
-    }
-    // W1 images of both networks, rows clamped like the step kernel's register loads, columns >= S zero
-    for (int e = tid; e < 128 * 64; e += 512) {
-        const int i = e >> 6, k = e & 63;
-        const size_t src = (size_t)min(i, g.h1 - 1) * S + min(k, S - 1);
-        W1A[i * RF_WLD + k] = (k < S) ? g.Pa[da.oW1() + src] : 0.f;
-        W1C[i * RF_WLD + k] = (k < S) ? g.Pc[dc.oW1() + src] : 0.f;
     }
     if (ENV == ENV_SYN) {
         for (int e = tid; e < 64 * 64; e += 512) {           // WST[j][k] = Ws[k][j]  (coalesced along j)
@@ -168,33 +179,55 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     }
 
     // ---- the wave's rows of W2 of both networks, held in registers for the whole rollout
-    float4 w2a[8], w2c[8];
+    // (and of W1: rows clamped like the step kernel's loads, columns >= S zero), split into their bf16 parts once
+    // (the critic's W1 waits in LDS in its split form: 256 registers hold the three weight blocks below, not four)
+    Parts w1a[2], w2a[4], w2c[4];
     {
+        const int i = tid >> 2, c = tid & 3;                 // row i, columns 16 c .. 16 c + 15
+        const float *rc1 = g.Pc + dc.oW1() + (size_t)min(i, dc.h1 - 1) * S;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const Parts p = rb_split8(load4<VEC>(rc1, 16 * c + 8 * hh, S), load4<VEC>(rc1, 16 * c + 8 * hh + 4, S));
+            u8 *dst = W1C + i * RF_W1LD + 32 * c + 16 * hh;
+            *reinterpret_cast<u32x4 *>(dst) = p.h;
+            *reinterpret_cast<u32x4 *>(dst + 128) = p.m;
+            *reinterpret_cast<u32x4 *>(dst + 256) = p.l;
+        }
+    }
+    const u8 *w1c_at = W1C + (16 * wave + l15) * RF_W1LD + 16 * q;
+    {
+        const float *ra1 = g.Pa + da.oW1() + (size_t)min(16 * wave + l15, da.h1 - 1) * S;
         const float *ra2 = g.Pa + da.oW2() + (size_t)min(16 * wave + l15, da.h2 - 1) * da.h1;
         const float *rc2 = g.Pc + dc.oW2() + (size_t)min(16 * wave + l15, dc.h2 - 1) * dc.h1;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            w2a[t] = (t < n1) ? load4<VEC>(ra2, 16 * t + 4 * q, da.h1) : zero4();
-            w2c[t] = (t < n1) ? load4<VEC>(rc2, 16 * t + 4 * q, dc.h1) : zero4();
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < ks_s) {
+                w1a[ks] = rb_load_w<VEC>(ra1, ks, q, S);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < ks_1) {
+                w2a[ks] = rb_load_w<VEC>(ra2, ks, q, da.h1);
+                w2c[ks] = rb_load_w<VEC>(rc2, ks, q, dc.h1);
+            }
         }
     }
-    const float *w1a_row = W1A + (16 * wave + l15) * RF_WLD + 4 * q, *w1c_row = W1C + (16 * wave + l15) * RF_WLD + 4 * q;
     const int kt = min(wave, n2 - 1);                      // this wave's k-tile of the output layers
     float4 w3a = load4<VEC>(g.Pa + da.oW3() + (size_t)min(l15, A - 1) * da.h2, 16 * kt + 4 * q, da.h2);
     if (l15 >= A || !on2) w3a = zero4();
     float4 w3c = load4<VEC>(g.Pc + dc.oW3(), 16 * kt + 4 * q, dc.h2);
     if (l15 >= 1 || !on2) w3c = zero4();
-    const float4 b1a = load4<VEC>(g.Pa + da.ob1(), 16 * min(wave, n1 - 1) + 4 * q, da.h1);
-    const float4 b2a = load4<VEC>(g.Pa + da.ob2(), 16 * kt + 4 * q, da.h2);
-    const float4 b1c = load4<VEC>(g.Pc + dc.ob1(), 16 * min(wave, n1 - 1) + 4 * q, dc.h1);
-    const float4 b2c = load4<VEC>(g.Pc + dc.ob2(), 16 * kt + 4 * q, dc.h2);
-    float sl[4], b3a[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ac = min(4 * q + r, A - 1);
-        sl[r] = g.Pa[da.oStd() + ac];
-        b3a[r] = g.Pa[da.ob3() + ac];
+    {   // the biases wait in LDS (a ds_read_b128 per layer and network per step; 16 registers less across the MFMA chains)
+        const int which = tid >> 7, k = tid & 127;
+        const float *src = (which & 2 ? g.Pc : g.Pa) + (which & 2 ? (which & 1 ? dc.ob2() : dc.ob1()) : (which & 1 ? da.ob2() : da.ob1()));
+        const int hk = (which & 1) ? g.h2 : g.h1;
+        const float v = src[min(k, hk - 1)];
+        BIA[tid] = k < hk ? v : 0.f;
     }
+    const float *b1_at = BIA + 16 * min(wave, n1 - 1) + 4 * q, *b2_at = BIA + 128 + 16 * kt + 4 * q;
+    float *HEAD = smem + RF_O_HEAD;
+    if (tid < 32) HEAD[tid] = g.Pa[(tid < 16 ? da.oStd() : da.ob3()) + min(tid & 15, A - 1)];
     const float b3c = g.Pc[dc.ob3()];
 
     // ---- the environment's per-lane constants
@@ -224,13 +257,11 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         constexpr bool last = decltype(last_c)::value;
         // ================= phase 0: state tile -> registers; states[t]; layer 1 of both networks =================
         RFPROF(0);
-        float4 R[RF_NSM];                    // raw state: B operand of the env step (waves < nt), states[t] (wave 7)
-        if (!last && (wave < nt || wave == 7)) {
+        if (wave == 7 && !last && valid) {   // states[t] = state (AgentPPO.py:115)
+            float4 R[RF_NSM];
 #pragma unroll
             for (int tt = 0; tt < RF_NSM; ++tt)
                 R[tt] = (tt < ns) ? *reinterpret_cast<const float4 *>(XS + l15 * RF_XLD + 16 * tt + 4 * q) : zero4();
-        }
-        if (wave == 7 && !last && valid) {   // states[t] = state (AgentPPO.py:115)
             float *dst0 = g.o_states + ((size_t)t * N + row) * S;
 #pragma unroll
             for (int tt = 0; tt < RF_NSM; ++tt) {
@@ -246,38 +277,32 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             }
         }
         {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            RbAcc ca, cc;
 #pragma unroll
-            for (int tt = 0; tt < RF_NSM; ++tt) {
-                if (tt < ns) {
-                    if (!last) {
-                        const float4 xa = *reinterpret_cast<const float4 *>(XA + l15 * RF_XLD + 16 * tt + 4 * q);
-                        const float4 w1 = *reinterpret_cast<const float4 *>(w1a_row + 16 * tt);
-                        a0 = mfma16(w1.x, xa.x, a0);
-                        a1 = mfma16(w1.y, xa.y, a1);
-                        a0 = mfma16(w1.z, xa.z, a0);
-                        a1 = mfma16(w1.w, xa.w, a1);
-                    }
-                    const float4 xc = *reinterpret_cast<const float4 *>(XC + l15 * RF_XLD + 16 * tt + 4 * q);
-                    const float4 w1 = *reinterpret_cast<const float4 *>(w1c_row + 16 * tt);
-                    c0 = mfma16(w1.x, xc.x, c0);
-                    c1 = mfma16(w1.y, xc.y, c1);
-                    c0 = mfma16(w1.z, xc.z, c0);
-                    c1 = mfma16(w1.w, xc.w, c1);
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks < ks_s) {
+                    if (!last) rb_mma6(w1a[ks], rb_tile_get(XA, RB_XLD, l15, ks, q), ca);
+                    Parts w1c;
+                    w1c.h = *reinterpret_cast<const u32x4 *>(w1c_at + 64 * ks);
+                    w1c.m = *reinterpret_cast<const u32x4 *>(w1c_at + 64 * ks + 128);
+                    w1c.l = *reinterpret_cast<const u32x4 *>(w1c_at + 64 * ks + 256);
+                    rb_mma6(w1c, rb_tile_get(XC, RB_XLD, l15, ks, q), cc);
                 }
             }
             if (on1) {
                 float h[4], gd;
                 if (!last) {
+                    const float4 b1a = *reinterpret_cast<const float4 *>(b1_at);
                     const float bb[4] = {b1a.x, b1a.y, b1a.z, b1a.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
-                    *reinterpret_cast<float4 *>(T1A + l15 * RF_TLD + 16 * wave + 4 * q) = make_float4(h[0], h[1], h[2], h[3]);
+                    for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(ca, r) + bb[r], h[r], gd);
+                    rb_tile_put(T1A, RB_TLD, l15, 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
                 }
+                const float4 b1c = *reinterpret_cast<const float4 *>(b1_at + 256);
                 const float bc[4] = {b1c.x, b1c.y, b1c.z, b1c.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gelu_and_grad_fast((c0[r] + c1[r]) + bc[r], h[r], gd);
-                *reinterpret_cast<float4 *>(T1C + l15 * RF_TLD + 16 * wave + 4 * q) = make_float4(h[0], h[1], h[2], h[3]);
+                for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(cc, r) + bc[r], h[r], gd);
+                rb_tile_put(T1C, RB_TLD, l15, 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
             }
         }
         RFPROF(1);
@@ -289,29 +314,20 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         // chain and leaves its zero partials; the four waves with rows then have the SIMDs' matrix pipes to themselves.  Scalar branch.)
         if (__builtin_amdgcn_readfirstlane(wave) < n2)
         {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            RbAcc ca, cc;
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                if (tt < n1) {
-                    if (!last) {
-                        const float4 hv = *reinterpret_cast<const float4 *>(T1A + l15 * RF_TLD + 16 * tt + 4 * q);
-                        a0 = mfma16(w2a[tt].x, hv.x, a0);
-                        a1 = mfma16(w2a[tt].y, hv.y, a1);
-                        a0 = mfma16(w2a[tt].z, hv.z, a0);
-                        a1 = mfma16(w2a[tt].w, hv.w, a1);
-                    }
-                    const float4 hc = *reinterpret_cast<const float4 *>(T1C + l15 * RF_TLD + 16 * tt + 4 * q);
-                    c0 = mfma16(w2c[tt].x, hc.x, c0);
-                    c1 = mfma16(w2c[tt].y, hc.y, c1);
-                    c0 = mfma16(w2c[tt].z, hc.z, c0);
-                    c1 = mfma16(w2c[tt].w, hc.w, c1);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < ks_1) {
+                    if (!last) rb_mma6(w2a[ks], rb_tile_get(T1A, RB_TLD, l15, ks, q), ca);
+                    rb_mma6(w2c[ks], rb_tile_get(T1C, RB_TLD, l15, ks, q), cc);
                 }
             }
             float h[4], gd;
             if (!last) {
+                const float4 b2a = *reinterpret_cast<const float4 *>(b2_at);
                 const float bb[4] = {b2a.x, b2a.y, b2a.z, b2a.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gelu_and_grad_fast((a0[r] + a1[r]) + bb[r], h[r], gd);
+                for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(ca, r) + bb[r], h[r], gd);
                 f32x4 part = {0.f, 0.f, 0.f, 0.f};
                 part = mfma16(w3a.x, h[0], part);
                 part = mfma16(w3a.y, h[1], part);
@@ -320,9 +336,10 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                 *reinterpret_cast<float4 *>(PSA + (wave * 64 + lane) * 4) =
                     on2 ? make_float4(part[0], part[1], part[2], part[3]) : zero4();
             }
+            const float4 b2c = *reinterpret_cast<const float4 *>(b2_at + 256);
             const float bc[4] = {b2c.x, b2c.y, b2c.z, b2c.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gelu_and_grad_fast((c0[r] + c1[r]) + bc[r], h[r], gd);
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(cc, r) + bc[r], h[r], gd);
             f32x4 pc = {0.f, 0.f, 0.f, 0.f};
             pc = mfma16(w3c.x, h[0], pc);
             pc = mfma16(w3c.y, h[1], pc);
@@ -355,9 +372,22 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         float out[4] = {0.f, 0.f, 0.f, 0.f}, a2 = 0.f, pend_cost = 0.f;
         const int j0 = 16 * wave + 4 * q;
         if (wave < nt) {
+            // the raw state tile: B operand of the env step (read here, not before the layers: 16 registers less across their MFMA chains;
+            // XS is not written before barrier (3))
+            float4 R[RF_NSM];
+            if (ENV == ENV_SYN) {
+#pragma unroll
+                for (int tt = 0; tt < RF_NSM; ++tt)
+                    R[tt] = (tt < ns) ? *reinterpret_cast<const float4 *>(XS + l15 * RF_XLD + 16 * tt + 4 * q) : zero4();
+            }
             // every env wave finishes the policy head for its own lanes (same fixed-order sum, same draws: bit-identical in
             // all of them), so tanh(action) reaches the env's MFMA B operand -- k = 4 q + r -- without an LDS round trip
-            float Y[4];
+            float Y[4], sl[4], b3a[4];
+            {
+                const float4 s4 = *reinterpret_cast<const float4 *>(HEAD + 4 * q), b4 = *reinterpret_cast<const float4 *>(HEAD + 16 + 4 * q);
+                sl[0] = s4.x; sl[1] = s4.y; sl[2] = s4.z; sl[3] = s4.w;
+                b3a[0] = b4.x; b3a[1] = b4.y; b3a[2] = b4.z; b3a[3] = b4.w;
+            }
             {
                 float4 p[8];
 #pragma unroll
@@ -465,10 +495,8 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                     *reinterpret_cast<float4 *>(XS + l15 * RF_XLD + j0) = make_float4(out[0], out[1], out[2], out[3]);
                     const float4 aa = *reinterpret_cast<const float4 *>(NRM + j0), ad = *reinterpret_cast<const float4 *>(NRM + 64 + j0);
                     const float4 ca = *reinterpret_cast<const float4 *>(NRM + 128 + j0), cd = *reinterpret_cast<const float4 *>(NRM + 192 + j0);
-                    *reinterpret_cast<float4 *>(XA + l15 * RF_XLD + j0) =
-                        make_float4((out[0] - aa.x) / ad.x, (out[1] - aa.y) / ad.y, (out[2] - aa.z) / ad.z, (out[3] - aa.w) / ad.w);
-                    *reinterpret_cast<float4 *>(XC + l15 * RF_XLD + j0) =
-                        make_float4((out[0] - ca.x) / cd.x, (out[1] - ca.y) / cd.y, (out[2] - ca.z) / cd.z, (out[3] - ca.w) / cd.w);
+                    rb_tile_put(XA, RB_XLD, l15, j0, (out[0] - aa.x) / ad.x, (out[1] - aa.y) / ad.y, (out[2] - aa.z) / ad.z, (out[3] - aa.w) / ad.w);
+                    rb_tile_put(XC, RB_XLD, l15, j0, (out[0] - ca.x) / cd.x, (out[1] - ca.y) / cd.y, (out[2] - ca.z) / cd.z, (out[3] - ca.w) / cd.w);
                 }
                 if (wave == 0 && q == 0) {
                     const float rew = -(sq / (float)S) - 0.01f * (a2 / (float)A);
@@ -503,11 +531,10 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                 if (q == 0) {
                     const float ob[3] = {cosf(nth), sinf(nth), nthdot};
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        XS[l15 * RF_XLD + k] = ob[k];
-                        XA[l15 * RF_XLD + k] = (ob[k] - NRM[k]) / NRM[64 + k];
-                        XC[l15 * RF_XLD + k] = (ob[k] - NRM[128 + k]) / NRM[192 + k];
-                    }
+                    for (int k = 0; k < 3; ++k) XS[l15 * RF_XLD + k] = ob[k];
+                    rb_tile_put(XA, RB_XLD, l15, 0, (ob[0] - NRM[0]) / NRM[64], (ob[1] - NRM[1]) / NRM[65], (ob[2] - NRM[2]) / NRM[66], 0.f);
+                    rb_tile_put(XC, RB_XLD, l15, 0, (ob[0] - NRM[128]) / NRM[192], (ob[1] - NRM[129]) / NRM[193],
+                                (ob[2] - NRM[130]) / NRM[194], 0.f);
                     const float rew = -0.5f * pend_cost;
                     const float rws = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;
                     if (valid) {
