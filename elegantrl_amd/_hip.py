@@ -22,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 15
+ABI_VERSION = 16
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -121,7 +121,7 @@ _SIGNATURES = {
     "erl_sac_workspace_bytes": (c_int64, [c_int, c_int, POINTER(c_int), c_int, c_int, c_int64]),
     "erl_sac_update_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int] + [_P] * 9 + [c_float, c_int64, _P, _P, c_uint64,
                                    c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
-    "erl_sac_explore_action_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P,
+    "erl_sac_explore_action_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P,
                                            c_int64, _P]),
     "erl_k6_timing_enable": (None, [c_int]),
     "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),

@@ -177,16 +177,21 @@ class AgentBase:
         state = self.last_state.to(dev, th.float32)
         assert state.shape == (N, self.state_dim)
         import inspect
-        into_row = "out" in inspect.signature(self.explore_action).parameters     # the agent's kernel writes the action into its buffer row
+        sig = inspect.signature(self.explore_action).parameters
+        into_row = "out" in sig                     # the agent's kernel writes the action into its buffer row
+        state_row = into_row and "out_state" in sig     # ... and `states[t] = state` too
         # (the rows as views made once: the loop is bound by the interpreter -- ~45 us per time step for three launches)
         st_rows, ac_rows, rw_rows, te_rows, tr_rows = states.unbind(0), actions.unbind(0), rewards.unbind(0), terminals.unbind(0), truncates.unbind(0)
         for t in range(H):
-            if into_row:
+            if state_row:
+                action = self.explore_action(state, None if noise is None else noise[t], out=ac_rows[t], out_state=st_rows[t])
+            elif into_row:
                 action = self.explore_action(state, None if noise is None else noise[t], out=ac_rows[t])
             else:
                 action = self.explore_action(state) if noise is None else self.explore_action(state, noise[t])
                 ac_rows[t].copy_(action)
-            st_rows[t].copy_(state)
+            if not state_row:
+                st_rows[t].copy_(state)
             if native:
                 state = env.step_into(action if into_row else action.contiguous(), rw_rows[t], te_rows[t], tr_rows[t])
             else:

@@ -112,6 +112,8 @@ class AgentSAC(AgentBase):
             raise _hip.HipExtensionError("AgentSAC runs on the HIP kernels only; no GPU is visible and there is no CPU fallback")
         from .. import ops
         self.num_ensembles = getattr(args, "num_ensembles", 4)
+        # update_net draws the sample ids of all its steps with one th.randint (False: one draw per step, the reference's call pattern)
+        self.sample_ids_ahead = bool(getattr(args, "sample_ids_ahead", True))
         self._spec = ops.SacSpec(state_dim, action_dim, net_dims, self.num_ensembles)
         dev, f32 = self.device, th.float32
         self._actor_flat = th.zeros(self._spec.actor_count, dtype=f32, device=dev)
@@ -167,12 +169,13 @@ class AgentSAC(AgentBase):
             self._sync_modules()
 
     @_hip.on_device
-    def explore_action(self, state: TEN, noise: Optional[TEN] = None, out: Optional[TEN] = None) -> TEN:
-        """`out` (n, action_dim), contiguous: the kernel writes the action there (the rollout passes its buffer row: no copy)"""
+    def explore_action(self, state: TEN, noise: Optional[TEN] = None, out: Optional[TEN] = None, out_state: Optional[TEN] = None) -> TEN:
+        """`out` (n, action_dim), contiguous: the kernel writes the action there (the rollout passes its buffer row: no copy);
+        `out_state` (n, state_dim), contiguous: the kernel also copies `state` there (the rollout's `states[t] = state`)"""
         from .. import ops
         self._sync_modules()
         action = ops.sac_explore_action(self._spec, self._actor_flat, state.contiguous(), noise=noise, seed=self.rng_seed,
-                                        counter=self.rng_counter, out=out)
+                                        counter=self.rng_counter, out=out, out_state=out_state)
         self.rng_counter += 1
         return action
 
@@ -224,11 +227,17 @@ class AgentSAC(AgentBase):
         if update_times < 1:
             return 0.0, 0.0
         objs = th.zeros((update_times, 2), dtype=th.float32, device=self.device)
+        id_rows = None
+        if not self.if_use_per and self.sample_ids_ahead:
+            # the sample ids of ALL the steps in one th.randint (the reference draws batch_size of them per step, replay_buffer.py:121-122:
+            # same distribution, same generator, one launch instead of `update_times`; nothing is written to the buffer inside this loop)
+            id_rows = th.randint((buffer.cur_size - 1) * buffer.num_seqs, size=(update_times, self.batch_size), requires_grad=False,
+                                 device=self.device).unbind(0)
         for t in range(update_times):
             if self.if_use_per:
                 self._per_step(buffer, objs[t])
-            else:
-                self._update_on_batch(buffer.sample(self.batch_size, reuse=True), objs[t], buffer=buffer)   # the batch is consumed before the next draw
+            else:       # (the batch is consumed before the next draw)
+                self._update_on_batch(buffer.sample(self.batch_size, ids=None if id_rows is None else id_rows[t], reuse=True), objs[t], buffer=buffer)
         o = objs.cpu().numpy()
         _hip.check_async_faults()          # the stream is drained: a skipped optimiser step (grid-wait timeout) raises here
         return float(np.nanmean(o[:, 0])), float(np.nanmean(o[:, 1]))

@@ -45,10 +45,14 @@ int erl_launch_exchange_f64(double *buf, int64_t count, const ErlExchange *ex, h
 int erl_clip_adam_soft_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const int64_t *group_off,
                            const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
                            float grad_scale, float *soft, float tau, hipStream_t stream);
+int erl_clip_adam_parts_soft_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t len, const double *parts,
+                                 int nparts, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm, float *soft, float tau,
+                                 hipStream_t stream);
 bool erl_sac_fused_supported(int S, int A, const int *hidden, int n_hidden, int E, int64_t B);
 int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, int64_t Pa, int64_t Pc);
 int erl_sac_explore_fused(const float *actor_params, int S, int A, int h0, int h1, const int64_t *aoff, const float *state, int64_t N,
-                          const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *lp_scratch, hipStream_t sa);
+                          const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *state_out, float *lp_scratch,
+                          hipStream_t sa);
 int erl_sac_update_fused(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m, float *actor_v,
                          float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A, int h0, int h1, int E,
                          const int64_t *aoff, const int64_t *coff, int64_t Pa, int64_t Pc, const float *state, const float *action,

@@ -300,6 +300,36 @@ __global__ __launch_bounds__(1024) void clip_adam_grid_kernel(float *__restrict_
     }
 }
 
+// clip + Adam from squared-norm PIECES the gradient's producer left (sac_fused.hip dw_table_kernel: one fp64 sum per weight-gradient
+// workgroup): every workgroup adds the `nparts` pieces in one fixed order -- no pass over the gradient, no arrival counter, no wait --
+// and updates its 1024 elements; the soft target update rides along as in clip_adam_grid_kernel.  One group (the whole optimiser).
+__global__ __launch_bounds__(1024) void clip_adam_parts_kernel(float *__restrict__ params, const float *__restrict__ grads,
+                                                               float *__restrict__ m1, float *__restrict__ m2, int64_t len,
+                                                               const double *__restrict__ parts, int nparts, float beta1, float beta2,
+                                                               float eps, float max_norm, float step_size, float bc2_sqrt,
+                                                               float *__restrict__ soft, float tau)
+{
+    __shared__ double scratch[16];
+    const int64_t ie = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const bool own = ie < len;
+    const int64_t ic = own ? ie : len - 1;
+    float e_g = grads[ic], e_m1 = m1[ic], e_m2 = m2[ic], e_p = params[ic];       // (one round trip with the pieces)
+    const float e_s = soft ? soft[ic] : 0.f;
+    double ss = 0.0;
+    for (int b = threadIdx.x; b < nparts; b += 1024) ss += parts[b];
+    ss = block_sum(ss, scratch);
+    const float total_norm = (float)sqrt(ss);
+    float coef = max_norm / (total_norm + 1e-6f);   // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+    coef = coef > 1.f ? 1.f : coef;
+    if (own) {
+        erl_adam_update(erl_mul_rn(e_g, erl_mul_rn(1.0f, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);
+        m1[ie] = e_m1;
+        m2[ie] = e_m2;
+        params[ie] = e_p;
+        if (soft) soft[ie] = erl_soft_update(e_p, e_s, tau);
+    }
+}
+
 struct RaScratch {
     char *ptr = nullptr;        // [counter (256 B)][partials: kRaMaxBlocks x 4 doubles]
     unsigned base = 0;
@@ -464,6 +494,20 @@ int erl_clip_adam_soft_f32(float *params, const float *grads, float *exp_avg, fl
                           grad_scale, soft, tau, (void *)stream);
 }
 
+
+// clip_grad_norm_ + Adam (+ soft target update) of ONE group whose squared gradient norm arrives as `nparts` fp64 pieces (see
+// clip_adam_parts_kernel).  Internal (sac_fused.hip).
+int erl_clip_adam_parts_soft_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t len, const double *parts,
+                                 int nparts, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm, float *soft, float tau,
+                                 hipStream_t stream)
+{
+    ERL_REQUIRE(params && grads && exp_avg && exp_avg_sq && parts, "erl_clip_adam_parts_soft_f32: NULL tensor");
+    ERL_REQUIRE(len >= 1 && nparts >= 1 && step >= 1, "erl_clip_adam_parts_soft_f32: bad shape len=%lld nparts=%d step=%d", (long long)len, nparts, (int)step);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(clip_adam_parts_kernel, dim3((unsigned)erl_cdiv(len, 1024)), dim3(1024), 0, stream, params, grads, exp_avg, exp_avg_sq, len,
+                       parts, nparts, beta1, beta2, eps, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2), soft, tau);
+    ERL_LAUNCH_CHECK("erl_clip_adam_parts_soft_f32");
+}
 
 extern "C" int erl_reduce_clip_adam_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
                                         float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,

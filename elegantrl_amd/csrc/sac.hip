@@ -538,10 +538,11 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     ERL_LAUNCH_CHECK("erl_sac_update_f32");
 }
 
-// ActorSAC.get_action for the off-policy rollout (AgentSAC.py:179-185): action = tanh(mean + std * eps)
+// ActorSAC.get_action for the off-policy rollout (AgentSAC.py:179-185): action = tanh(mean + std * eps); state_out (may be NULL):
+// the rollout's `states[t] = state` (AgentBase.py:145) written by the same launch
 extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden, const float *state,
                                           int64_t N, const float *noise, uint64_t seed, uint64_t counter, float *action_out,
-                                          void *workspace, int64_t workspace_bytes, void *stream)
+                                          float *state_out, void *workspace, int64_t workspace_bytes, void *stream)
 {
     ERL_REQUIRE(actor_params && state && action_out && workspace, "erl_sac_explore_action_f32: NULL tensor");
     SacDims d;
@@ -557,13 +558,16 @@ extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int 
         float *lp_s = ws.take(N);
         ERL_REQUIRE(lp_s != nullptr, "erl_sac_explore_action_f32: workspace too small");
         const int64_t aoff[6] = {d.actor.oW[0], d.actor.ob[0], d.actor.oW[1], d.actor.ob[1], d.actor.oW[2], d.actor.ob[2]};
-        return erl_sac_explore_fused(actor_params, S, A, hidden[0], hidden[1], aoff, state, N, noise, seed, counter, action_out, lp_s, s);
+        return erl_sac_explore_fused(actor_params, S, A, hidden[0], hidden[1], aoff, state, N, noise, seed, counter, action_out, state_out, lp_s, s);
     }
     float *aact[MAXL + 2];
     aact[0] = const_cast<float *>(state);
     for (int l = 1; l <= d.actor.n; ++l) aact[l] = ws.take(N * d.actor.d[l]);
     float *lp = ws.take(N);
     ERL_REQUIRE(lp != nullptr, "erl_sac_explore_action_f32: workspace too small");
+    if (state_out && (rc = erl_hip_status(hipMemcpyAsync(state_out, state, (size_t)N * S * sizeof(float), hipMemcpyDeviceToDevice, s),
+                                          "erl_sac_explore_action_f32: hipMemcpyAsync(state row)")))
+        return rc;
     if ((rc = forward(s, d.actor, actor_params, N, aact, nullptr))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, aact[d.actor.n], noise, seed, counter, A, N,
                        action_out, lp, (float *)nullptr, (const float *)nullptr, S, (float *)nullptr);

@@ -362,6 +362,7 @@ struct ActorFwdArgs {
     const float *P;
     FusedDims d;
     const float *X;                // (B, S) sampled state rows
+    float *Xcopy;                  // not NULL: the rows are also written here (the off-policy rollout's states[t] = state)
     const float *noise;            // (B, A) or NULL: Philox keyed by (seed, counter, row, a)
     uint64_t seed, counter;
     float *act_t, *lp;             // (B, A), (B,)
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
     clear_images(lds.T0, lds.T1, L);
     lds_barrier();
     FPROF(0, 1);
-    load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, nullptr, L);
+    load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, g.Xcopy, L);
     lds_barrier();
     FPROF(0, 2);
     f32x4 z[2], gk[2];
@@ -702,12 +703,16 @@ struct DwArgs {
     int np;
     int64_t B;
     float *clamp_alpha_log;     // not NULL: workgroup 0 also clamps the temperature's logarithm to [-16, 2] (see erl_sac_update_fused)
+    double *norm_parts;         // not NULL: [workgroups] the fp64 sum of squares of what each workgroup stores (its dW tile, its db rows): the
+                                // squared gradient norm in pieces, so that clip + Adam needs no pass over the gradient and no grid-wide wait
 };
+constexpr int kDwMaxParts = 1024;      // workgroups of one dw_table launch at the widest supported network (8 decoders of 256 x 256: 592)
 
 __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
 {
     __shared__ float red[4][32 * 33];
     __shared__ float bsum[4][32];
+    __shared__ double nscratch[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     if (g.clamp_alpha_log && blockIdx.x == 0 && tid == 0)        // after alpha was read (AgentSAC.py:80-81): the actor's backward has run
         g.clamp_alpha_log[0] = fminf(fmaxf(g.clamp_alpha_log[0], -16.f), 2.f);
@@ -760,13 +765,24 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
     bs += __shfl_xor(bs, 32, 64);
     if (hi == 0) bsum[wave][l31] = bs;
     lds_barrier();
+    double sq = 0.0;
     for (int e = tid; e < 32 * 32; e += 256) {
         const int i = e >> 5, j = e & 31;
         const float s = ((red[0][i * 33 + j] + red[1][i * 33 + j]) + red[2][i * 33 + j]) + red[3][i * 33 + j];
-        if (32 * tm + i < p.M && 32 * tn + j < p.N) p.dW[(size_t)(32 * tm + i) * p.N + 32 * tn + j] = s;
+        if (32 * tm + i < p.M && 32 * tn + j < p.N) {
+            p.dW[(size_t)(32 * tm + i) * p.N + 32 * tn + j] = s;
+            sq += (double)s * (double)s;
+        }
     }
-    if (tn == 0 && tid < 32 && 32 * tm + tid < p.M && p.db)
-        p.db[32 * tm + tid] = ((bsum[0][tid] + bsum[1][tid]) + bsum[2][tid]) + bsum[3][tid];
+    if (tn == 0 && tid < 32 && 32 * tm + tid < p.M && p.db) {
+        const float s = ((bsum[0][tid] + bsum[1][tid]) + bsum[2][tid]) + bsum[3][tid];
+        p.db[32 * tm + tid] = s;
+        sq += (double)s * (double)s;
+    }
+    if (g.norm_parts) {                 // (fixed association: thread-strided, wave butterfly, waves in order)
+        sq = block_sum(sq, nscratch);
+        if (tid == 0) g.norm_parts[blockIdx.x] = sq;
+    }
 }
 
 int dw_add(DwArgs &a, const float *dZ, int64_t sZ, int nZ, int M, const float *X, int N, float *dW, float *db)
@@ -782,6 +798,8 @@ int dw_add(DwArgs &a, const float *dZ, int64_t sZ, int nZ, int M, const float *X
 int dw_launch(const DwArgs &a, hipStream_t s)
 {
     const DwProb &last = a.p[a.np - 1];
+    ERL_REQUIRE(!a.norm_parts || last.tile0 + last.ntiles <= kDwMaxParts, "erl_sac_update_f32(fused): %d weight-gradient tiles, table of %d",
+                last.tile0 + last.ntiles, kDwMaxParts);
     hipLaunchKernelGGL(dw_table_kernel, dim3(last.tile0 + last.ntiles), dim3(256), 0, s, a);
     return erl_hip_status(hipGetLastError(), "erl_sac_update_f32(fused: dw_table)");
 }
@@ -891,6 +909,7 @@ int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, 
     f += r(B * 2 * A) * 2 + 2 * r(B * h0) + 2 * r(B * h1);              // Y, dY | H0, G0 | H1, G1
     f += r((int64_t)E * B * A) + r(B * h1) + r(B * h0);                 // dAct | dZ2, dZ1 (actor)
     f += r(Pa) + r(Pc) + r((int64_t)E * tiles) + r(tiles) + 64;        // gradients, partial sums, alpha0
+    f += 2 * 2 * kDwMaxParts;                                           // the squared-norm pieces of the two dw_table launches (doubles)
     return f;
 }
 
@@ -905,14 +924,15 @@ int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, 
 // rows (16 per workgroup), nothing kept but the action (lp_scratch: N floats the kernel also writes).  Same Philox keys and the same
 // arithmetic per element as the layered form (erl_sac_explore_action_f32's four launches), summed in this kernel's order.
 int erl_sac_explore_fused(const float *actor_params, int S, int A, int h0, int h1, const int64_t *aoff, const float *state, int64_t N,
-                          const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *lp_scratch, hipStream_t sa)
+                          const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *state_out, float *lp_scratch,
+                          hipStream_t sa)
 {
     FusedDims d{};
     d.S = S; d.A = A; d.E = 1; d.h0 = h0; d.h1 = h1; d.B = N;
     d.aW1 = aoff[0]; d.ab1 = aoff[1]; d.aW2 = aoff[2]; d.ab2 = aoff[3]; d.aWh = aoff[4]; d.abh = aoff[5];
     ActorFwdArgs af{};
     af.P = actor_params; af.d = d; af.X = state; af.noise = noise; af.seed = seed; af.counter = counter;
-    af.act_t = action_out; af.lp = lp_scratch;
+    af.act_t = action_out; af.lp = lp_scratch; af.Xcopy = state_out;
     const dim3 tgrid((unsigned)((N + TS - 1) / TS)), blk(FT);
 #define LAUNCH_ACTOR_EXPLORE(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, sa, af)
     FUSED_KT_DISPATCH(LAUNCH_ACTOR_EXPLORE)
@@ -945,6 +965,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     float *dAct = take((int64_t)E * B * A), *dZ2 = take(B * h1), *dZ1 = take(B * h0);
     float *g_actor = take(Pa), *g_critic = take(Pc), *qpart = take((int64_t)E * tiles), *tdpart = take(tiles), *alpha0 = take(64);
     float *act_pg = take(B * A);                        // (its own buffer: the policy-gradient sample runs next to the critic update)
+    double *nparts_c = reinterpret_cast<double *>(take(2 * kDwMaxParts)), *nparts_a = reinterpret_cast<double *>(take(2 * kDwMaxParts));
     float *q_pg = qt;                                   // reused once its first contents are consumed
     const dim3 tgrid(tiles), cgrid(tiles, E), blk(FT);
     int rc;
@@ -1004,13 +1025,11 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
             dw_add(dw, dZ1e + (size_t)e * B * h1, 0, 1, h1, enc, h0, G + d.dW1, G + d.db1);
             dw_add(dw, dq + (size_t)e * B, 0, 1, 1, H1e + (size_t)e * B * h1, h1, G + d.dWo, G + d.dbo);
         }
+        dw.norm_parts = nparts_c;
         if ((rc = dw_launch(dw, s))) return rc;
-    }
-    // ---- (5) clip + Adam on the critic, soft target update in the same launch                                  (:69-70)
-    {
-        const int64_t off = 0, len = Pc;
-        if ((rc = erl_clip_adam_soft_f32(critic_params, g_critic, critic_m, critic_v, &off, &len, 1, step, lr, beta1, beta2, eps_adam, max_norm,
-                                         1.0f, target_params, tau, s)))
+        // ---- (5) clip + Adam on the critic from the launch's squared-norm pieces, soft target update in the same launch  (:69-70)
+        if ((rc = erl_clip_adam_parts_soft_f32(critic_params, g_critic, critic_m, critic_v, Pc, nparts_c, dw.p[dw.np - 1].tile0 + dw.p[dw.np - 1].ntiles,
+                                               step, lr, beta1, beta2, eps_adam, max_norm, target_params, tau, s)))
             return rc;
     }
     // ---- (7) TARGET ensemble on (state, action_pg): q and d(mean q)/d(action); finishes the critic objective    (:82-83)
@@ -1033,10 +1052,10 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
         dw_add(dw, dZ2, 0, 1, h1, H0, h0, g_actor + d.aW2, g_actor + d.ab2);
         dw_add(dw, dY, 0, 1, 2 * A, H1, h1, g_actor + d.aWh, g_actor + d.abh);
         dw.clamp_alpha_log = alpha_log;        // (one launch less than a kernel of its own: ~5 us of a 230 us step)
+        dw.norm_parts = nparts_a;
         if ((rc = dw_launch(dw, s))) return rc;
-        const int64_t off = 0, len = Pa;
-        if ((rc = erl_clip_adam_soft_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, step, lr, beta1, beta2, eps_adam, max_norm, 1.0f,
-                                         nullptr, 0.f, s)))
+        if ((rc = erl_clip_adam_parts_soft_f32(actor_params, g_actor, actor_m, actor_v, Pa, nparts_a, dw.p[dw.np - 1].tile0 + dw.p[dw.np - 1].ntiles, step,
+                                               lr, beta1, beta2, eps_adam, max_norm, nullptr, 0.f, s)))
             return rc;
     }
     return erl_hip_status(hipGetLastError(), "erl_sac_update_f32(fused)");

@@ -619,13 +619,14 @@ def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: T
 
 
 def sac_explore_action(spec: SacSpec, actor: TEN, state: TEN, *, noise: Optional[TEN] = None, seed: int = 0, counter: int = 0,
-                       out: Optional[TEN] = None) -> TEN:
+                       out: Optional[TEN] = None, out_state: Optional[TEN] = None) -> TEN:
+    """`out` (N, A): the action's destination (e.g. the rollout's row); `out_state` (N, S): a copy of `state` from the same launch."""
     N = state.shape[0]
     out = th.empty((N, spec.A), dtype=th.float32, device=state.device) if out is None else out
     ws = _workspace(state.device, spec.workspace_bytes(N))
     check(lib().erl_sac_explore_action_f32(ptr(actor, th.float32), spec.S, spec.A, spec._c, len(spec.hidden), ptr(state, th.float32), N,
-                                           ptr(noise), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), ptr(out, th.float32), ptr(ws),
-                                           ws.numel(), stream_ptr()),
+                                           ptr(noise), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), ptr(out, th.float32),
+                                           ptr(out_state, th.float32) if out_state is not None else None, ptr(ws), ws.numel(), stream_ptr()),
           "erl_sac_explore_action_f32")
     return out
 

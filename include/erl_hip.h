@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 15
+#define ERL_ABI_VERSION 16
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -506,7 +506,8 @@ ERL_API int erl_mlpn_ppo_step_discrete_f32(const float *actor_params, const floa
  * erl_replay_sample_f32 returned (B rows); is_weight (B) / td_error_out (B), both optional, are prioritised replay's importance
  * weights in and per-sample td errors out (AgentSAC.py:58-62).  eps_next / eps_cur (B, A) inject the two rsample() draws (tests); NULL ->
  * Philox keyed by (seed, counter).  objs_out: device float[2] = (obj_critic, obj_actor).  step = 1-based Adam step.
- * erl_sac_explore_action_f32 = ActorSAC.get_action (:179-185) for the off-policy rollout.
+ * erl_sac_explore_action_f32 = ActorSAC.get_action (:179-185) for the off-policy rollout; state_out (N, S), may be NULL: the
+ * rollout's `states[t] = state` (AgentBase.py:145) from the same launch (ABI 16).
  * ------------------------------------------------------------------------------------------- */
 ERL_API int erl_sac_param_counts(int S, int A, const int *hidden, int n_hidden, int E, int64_t *actor_count,
                          int64_t *critic_count);
@@ -522,7 +523,7 @@ ERL_API int erl_sac_update_f32(float *actor_params, float *critic_params, float 
                        void *stream);
 ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
-                               float *action_out, void *workspace, int64_t workspace_bytes, void *stream);
+                               float *action_out, float *state_out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* measurement hook (bench.py's `roofline`; no reference counterpart): every_nth > 0 makes erl_ppo_step_f32 time every n-th K6
  * launch (1 = every launch, 0 = off) two ways -- a HIP-event bracket on the launch stream (contains the dispatch and completion

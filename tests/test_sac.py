@@ -304,3 +304,66 @@ def test_agent_sac_with_prioritised_replay_runs_and_updates_priorities():
     leaves1 = buf.sum_trees.sum.view(N, -1)[:, buf.sum_trees.leaves:buf.sum_trees.leaves + buf.cur_size]
     changed = (leaves1 != 10.0)
     assert int(changed.sum()) > 20 and float(leaves1.max()) <= 10.0 and float(leaves1.min()) > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net,N", [((256, 256), 64), ((64, 48, 32), 50)], ids=["one-launch-form", "layered-form"])
+def test_sac_rollout_rows_written_by_the_explore_launch(net, N):
+    """the off-policy rollout (AgentBase.py:130-170) lets the explore kernel write `actions[t]` AND `states[t]` into the buffer rows:
+    the same five tensors, bit for bit, as the loop that copies them (explore_action without `out` / `out_state`)."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config
+    S, A, H = 11, 3, 9
+
+    def run(rows: bool):
+        args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 5, "state_dim": S, "action_dim": A, "if_discrete": False})
+        args.net_dims, args.random_seed = list(net), 3
+        th.manual_seed(5)
+        agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+        if not rows:                                            # the signature without the row arguments: the loop copies
+            inner = agent.explore_action
+            agent.explore_action = lambda state, noise=None: inner(state, noise)
+        env = SynVecEnv(N, S, A, max_step=5, gpu_id=0, seed=1)
+        agent.last_state = env.reset()[0]
+        noise = th.randn((H, N, A), device="cuda:0", generator=th.Generator(device="cuda:0").manual_seed(2))
+        return agent._explore_vec_env(env, H, noise=noise), agent.last_state.clone()
+    (a, la), (b, lb) = run(True), run(False)
+    for name, x, y in zip(("states", "actions", "rewards", "undones", "unmasks"), a, b):
+        assert x.shape == y.shape and th.equal(x, y), name
+    assert th.equal(la, lb)
+    assert a[0].abs().sum().item() > 0 and not th.equal(a[0][0], a[0][-1])
+
+
+@pytest.mark.gpu
+def test_sac_update_net_draws_its_sample_ids_ahead_from_the_same_distribution():
+    """AgentSAC.update_net draws the ids of all its steps with one th.randint (sample_ids_ahead, default on) instead of one per step:
+    both loops run, stay finite and visit the whole ring (a statistical statement: the streams differ by construction)."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config, ReplayBuffer
+    N, S, A, H = 8, 11, 3, 32
+    for ahead in (True, False):
+        args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A, "if_discrete": False})
+        args.net_dims, args.horizon_len, args.batch_size, args.sample_ids_ahead = [64, 32], H, 64, ahead
+        args.repeat_times = 8.0
+        agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+        assert agent.sample_ids_ahead is ahead
+        env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=1)
+        agent.last_state = env.reset()[0]
+        buf = ReplayBuffer(max_size=H, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N, args=args)
+        buf.update(agent.explore_env(env, H))
+        seen = []
+        inner = buf.sample
+
+        def spy(batch_size, ids=None, reuse=False):
+            out = inner(batch_size, ids=ids, reuse=reuse)
+            seen.append((ids is not None, buf.ids0.clone(), buf.ids1.clone()))
+            return out
+        buf.sample = spy
+        oc, oa = agent.update_net(buf)
+        assert np.isfinite(oc) and np.isfinite(oa)
+        assert len(seen) == int(buf.cur_size * 8.0 / 64) == 4 and all(flag is ahead for flag, _, _ in seen)
+        ids0 = th.cat([s[1] for s in seen]).cpu().numpy()
+        ids1 = th.cat([s[2] for s in seen]).cpu().numpy()
+        assert ids0.min() >= 0 and ids0.max() <= buf.cur_size - 2 and ids1.min() >= 0 and ids1.max() <= N - 1
