@@ -191,3 +191,36 @@ def test_agent_ppo_on_reference_demo_shapes(hidden):
     np.testing.assert_allclose(np.array(objs), ref, rtol=5e-4, atol=5e-6)
     np.testing.assert_allclose(agent.act.net[0].weight.detach().cpu().numpy(), actor.weights[0], rtol=0, atol=2e-5)
     np.testing.assert_allclose(agent.cri.net[2 * len(hidden)].weight.detach().cpu().numpy(), critic.weights[-1], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("S,h2,A,N", [(8, 128, 2, 4096), (24, 64, 6, 777), (33, 32, 1, 50), (64, 128, 16, 1000), (3, 96, 3, 16), (61, 128, 8, 16384)])
+def test_wide_rollout_step_is_one_launch_and_matches_fp64(ops, dev, S, h2, A, N):
+    """net_dims = (256, h2) (examples/demo_A2C_PPO.py:117): erl_mlpn_rollout_step_f32 takes the one-launch latency form (csrc/rollout_wide.hip) --
+    actions, log-probs and tanh(actions) against the fp64 restatement (split-bf16 hidden layers: fp32-class), the state row bit for bit,
+    aligned and unaligned state_dim, N not a multiple of the 16-env tile, every second-layer width."""
+    rng = np.random.default_rng(S + h2)
+    actor = random_net_n(rng, [S, 256, h2, A], True)
+    x = rng.standard_normal((N, S), dtype=np.float32)
+    eps = rng.standard_normal((N, A), dtype=np.float32)
+    spec = ops.MlpSpecN([S, 256, h2, A], True)
+    o_s, o_a, o_l, o_e = (th.zeros((N, S), device=dev), th.zeros((N, A), device=dev), th.zeros(N, device=dev), th.zeros((N, A), device=dev))
+    ops.mlpn_rollout_step(cu(flat_params(actor), dev), spec, cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(x, dev),
+                          noise=cu(eps, dev), out_state=o_s, out_action=o_a, out_logprob=o_l, out_env_action=o_e)
+    a_ref, lp_ref = O.actor_sample(x.astype(np.float64), actor.astype(np.float64), eps.astype(np.float64))
+    np.testing.assert_array_equal(o_s.cpu().numpy(), x)
+    scale = max(1.0, float(np.abs(a_ref).max()))
+    err = float(np.abs(o_a.cpu().numpy() - a_ref).max())
+    assert err <= 1e-5 * scale, err
+    np.testing.assert_allclose(o_l.cpu().numpy(), lp_ref, rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(o_e.cpu().numpy(), np.tanh(a_ref), rtol=0, atol=2e-5)
+    # optional outputs may be absent; the Philox draws are those of every other rollout kernel: (seed, counter, env, action-dim)
+    o_a2 = th.zeros((N, A), device=dev)
+    ops.mlpn_rollout_step(cu(flat_params(actor), dev), spec, cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(x, dev), seed=5, counter=9,
+                          out_action=o_a2)
+    z = (o_a2.cpu().numpy() - O.actor_mean(x.astype(np.float64), actor.astype(np.float64))) / np.exp(actor.action_std_log)
+    if N >= 777:
+        assert abs(z.mean()) < 0.1 and abs(z.std() - 1.0) < 0.1
+    z2 = th.zeros((N, A), device=dev)
+    ops.mlpn_rollout_step(cu(flat_params(actor), dev), spec, cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(x, dev), seed=5, counter=9,
+                          out_action=z2)
+    assert th.equal(o_a2, z2)                   # deterministic in (seed, counter)
