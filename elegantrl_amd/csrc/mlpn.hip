@@ -79,9 +79,9 @@ int rollout_impl(const char *what, bool discrete, const float *actor_params, con
     ERL_REQUIRE(N >= 1 && N < (1LL << 31), "%s: bad N", what);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    // net_dims = (256, h2), a few thousand envs: ONE launch (rollout_wide.hip; ERL_WIDE_FUSED=0 keeps the layered launches below)
+    // net_dims = (256, h2) / (256, h2, h3), a few thousand envs: ONE launch (rollout_wide.hip; ERL_WIDE_FUSED=0 keeps the layered launches below)
     if (!discrete && erl_rollout_wide_supported(dims, n_dims, N) && (reinterpret_cast<uintptr_t>(actor_params) & 15) == 0)
-        return erl_rollout_wide_step(actor_params, state_avg, state_std, dims, state, N, noise, seed, counter, out_state_row,
+        return erl_rollout_wide_step(actor_params, state_avg, state_std, dims, n_dims, state, N, noise, seed, counter, out_state_row,
                                      (float *)out_action_row, out_logprob_row, (float *)out_action_env, s);
     Ws ws{(char *)workspace, 0, workspace_bytes};
     float *act[MAXL + 2];

@@ -1,6 +1,6 @@
-// One vectorised rollout step for the reference's wider demo network, net_dims = (256, 32..128): ActorPPO.get_action + the three buffer
-// stores + convert_action_for_env (elegantrl/agents/AgentPPO.py:113-119, :368-376, :388-390; examples/demo_A2C_PPO.py:117 trains
-// net_dims = (256, 128)) as ONE launch instead of the layered path's five (normalise, three GEMMs, sample: ~45 us per 4096-env step).
+// One vectorised rollout step for the reference's wider demo networks, net_dims = (256, 32..128) and (256, 32..128, 32..128): ActorPPO.get_action + the three buffer
+// stores + convert_action_for_env (elegantrl/agents/AgentPPO.py:113-119, :368-376, :388-390; examples/demo_A2C_PPO.py:117, :171, :224 train
+// net_dims = (256, 128), (256, 128, 64), (256, 128, 128)) as ONE launch instead of the layered path's five (normalise, three GEMMs, sample: ~45 us per 4096-env step).
 //
 // The latency form of K1 (mlp.hip rollout_split_kernel) with a first layer twice as wide: one 16-env tile per workgroup, the 8 waves split
 // the OUTPUT features of each layer -- wave w owns first-layer feature tiles w and w + 8 (rows 16 w .. and 128 + 16 w .. of W1) and
@@ -23,7 +23,7 @@ constexpr int RW_TBYTES = 3 * 16 * RW_TLD;      // 25344
 
 struct RwArgs {
     const float *P, *avg, *sd;
-    int S, h2, A;
+    int S, h2, h3, A;              // h3 = 0: two hidden layers
     const float *states;
     int64_t rows;
     const float *noise;
@@ -31,16 +31,32 @@ struct RwArgs {
     float *o_state, *o_action, *o_logprob, *o_env;
 };
 
-template <bool VEC>
+// parameter block of build_mlp([S, 256, h2, (h3,) A]) + action_std_log (include/erl_hip.h): W1 b1 W2 b2 (W3 b3) Wout bout std_log
+struct RwOff {
+    int S, h2, h3, A, hl;          // hl = width of the last hidden layer
+    __host__ __device__ RwOff(int S_, int h2_, int h3_, int A_) : S(S_), h2(h2_), h3(h3_), A(A_), hl(h3_ ? h3_ : h2_) {}
+    __host__ __device__ size_t oW1() const { return 0; }
+    __host__ __device__ size_t ob1() const { return (size_t)RW_H1 * S; }
+    __host__ __device__ size_t oW2() const { return ob1() + RW_H1; }
+    __host__ __device__ size_t ob2() const { return oW2() + (size_t)h2 * RW_H1; }
+    __host__ __device__ size_t oW3() const { return ob2() + h2; }
+    __host__ __device__ size_t ob3() const { return oW3() + (size_t)h3 * h2; }
+    __host__ __device__ size_t oWo() const { return h3 ? ob3() + h3 : ob2() + h2; }
+    __host__ __device__ size_t obo() const { return oWo() + (size_t)A * hl; }
+    __host__ __device__ size_t oStd() const { return obo() + A; }
+};
+
+template <bool VEC, bool L3>
 __global__ __launch_bounds__(512) void rollout_wide_kernel(RwArgs g)
 {
     __shared__ __attribute__((aligned(16))) u8 T1[RW_TBYTES];
+    __shared__ __attribute__((aligned(16))) u8 T2[L3 ? RB_TBYTES : 16];
     __shared__ __attribute__((aligned(16))) float PS[8 * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const Dims d{g.S, RW_H1, g.h2, g.A};
-    const int S = d.S, A = d.out, n2 = d.h2 >> 4;
+    const RwOff d(g.S, g.h2, L3 ? g.h3 : 0, g.A);
+    const int S = d.S, A = d.A, n2 = d.h2 >> 4, nl = d.hl >> 4;
     const int ks_s = (S + 31) >> 5;                        // k-steps of 32 state columns (S <= 64: 1 or 2)
-    const bool on2 = wave < n2;
+    const bool onl = wave < nl;
     const float *std_log = g.P + d.oStd();
 
     const int64_t env = (int64_t)blockIdx.x * 16 + l15;
@@ -71,18 +87,28 @@ __global__ __launch_bounds__(512) void rollout_wide_kernel(RwArgs g)
             w2r[2 * ks + 1] = load4<true>(r2, 32 * ks + 8 * q + 4, RW_H1);
         }
     }
-    const int kt = min(wave, n2 - 1);                      // this wave's k-tile of the output layer
-    float4 w3 = load4<VEC>(g.P + d.oW3() + (size_t)min(l15, A - 1) * d.h2, 16 * kt + 4 * q, d.h2);
-    if (l15 >= A || !on2) w3 = zero4();
+    const int kt = min(wave, nl - 1);                      // this wave's k-tile of the output layer
+    float4 wo = load4<VEC>(g.P + d.oWo() + (size_t)min(l15, A - 1) * d.hl, 16 * kt + 4 * q, d.hl);
+    if (l15 >= A || !onl) wo = zero4();
     const float4 b1a = load4<true>(g.P + d.ob1(), 16 * wave + 4 * q, RW_H1), b1b = load4<true>(g.P + d.ob1(), 128 + 16 * wave + 4 * q, RW_H1);
-    const float4 b2 = load4<VEC>(g.P + d.ob2(), 16 * kt + 4 * q, d.h2);
+    const float4 b2 = load4<VEC>(g.P + d.ob2(), 16 * min(wave, n2 - 1) + 4 * q, d.h2);
+    float4 w3r[8], b3h = zero4();                          // third hidden layer: rows 16 w .. of W3 (h3 x h2), K = h2 <= 128
+    if (L3) {
+        const float *r3 = g.P + d.oW3() + (size_t)min(16 * wave + l15, d.h3 - 1) * d.h2;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            w3r[2 * ks] = load4<VEC>(r3, 32 * ks + 8 * q, d.h2);
+            w3r[2 * ks + 1] = load4<VEC>(r3, 32 * ks + 8 * q + 4, d.h2);
+        }
+        b3h = load4<VEC>(g.P + d.ob3(), 16 * kt + 4 * q, d.h3);
+    }
     float eps[4], sl[4], b3[4];
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int a = 4 * q + r, ac = min(a, A - 1);
             sl[r] = std_log[ac];
-            b3[r] = g.P[d.ob3() + ac];
+            b3[r] = g.P[d.obo() + ac];
             eps[r] = g.noise ? g.noise[row * A + ac] : philox_normal(g.seed, g.counter, (uint32_t)row, (uint32_t)ac);
         }
     }
@@ -138,19 +164,36 @@ __global__ __launch_bounds__(512) void rollout_wide_kernel(RwArgs g)
 
     // ---- L2: all of H1 back as B operands, this wave's feature tile of H2^T stays in registers ----
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
-    if (__builtin_amdgcn_readfirstlane(wave) < n2) {      // (waves beyond h2 / 16 hold no rows: they leave zero partials)
+    float h[4] = {0.f, 0.f, 0.f, 0.f}, gd;
+    if (__builtin_amdgcn_readfirstlane(wave) < n2) {      // (waves beyond h2 / 16 hold no rows)
         RbAcc acc;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) rb_mma6(rb_split8(w2r[2 * ks], w2r[2 * ks + 1]), rb_tile_get(T1, RW_TLD, l15, ks, q), acc);
         const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
-        float h[4], gd;
 #pragma unroll
         for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(acc, r) + bb[r], h[r], gd);
+        if (L3) rb_tile_put(T2, RB_TLD, l15, 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
+    }
+    if (L3) {
+        // ---- L3: H2 crosses the waves like H1 did; this wave's feature tile of H3^T ----
+        lds_barrier();
+        if (__builtin_amdgcn_readfirstlane(wave) < nl) {
+            RbAcc acc;
+            const int ks_2 = d.h2 >> 5;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                if (ks < ks_2) rb_mma6(rb_split8(w3r[2 * ks], w3r[2 * ks + 1]), rb_tile_get(T2, RB_TLD, l15, ks, q), acc);
+            const float bb[4] = {b3h.x, b3h.y, b3h.z, b3h.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(acc, r) + bb[r], h[r], gd);
+        }
+    }
+    if (__builtin_amdgcn_readfirstlane(wave) < nl) {
         // ---- output layer, k-slice 16 w + 4 q + r: the B operand is the tile just computed ----
-        part = mfma16(w3.x, h[0], part);
-        part = mfma16(w3.y, h[1], part);
-        part = mfma16(w3.z, h[2], part);
-        part = mfma16(w3.w, h[3], part);
+        part = mfma16(wo.x, h[0], part);
+        part = mfma16(wo.y, h[1], part);
+        part = mfma16(wo.z, h[2], part);
+        part = mfma16(wo.w, h[3], part);
     }
     *reinterpret_cast<float4 *>(PS + (wave * 64 + lane) * 4) = make_float4(part[0], part[1], part[2], part[3]);
     lds_barrier();
@@ -191,27 +234,35 @@ constexpr int64_t kRwMaxEnvs = 16384;      // beyond: the weight re-reads (196 K
 
 }  // namespace
 
-// dims = [S, 256, h2, A]: S <= 64, h2 in 32..128 (steps of 32), A <= 16, N <= 16 384 envs; ERL_WIDE_FUSED=0 turns the kernel off
+// dims = [S, 256, h2, A] or [S, 256, h2, h3, A]: S <= 64, h2 / h3 in 32..128 (steps of 32), A <= 16, N <= 16 384 envs; ERL_WIDE_FUSED=0 turns
+// the kernel off
 int erl_rollout_wide_supported(const int *dims, int n_dims, int64_t N)
 {
     static const bool on = [] { const char *e = getenv("ERL_WIDE_FUSED"); return !(e && atoi(e) == 0); }();
-    return on && dims && n_dims == 4 && dims[0] >= 1 && dims[0] <= 64 && dims[1] == RW_H1 && dims[2] >= 32 && dims[2] <= 128 && dims[2] % 32 == 0 &&
-           dims[3] >= 1 && dims[3] <= 16 && N >= 1 && N <= kRwMaxEnvs;
+    if (!on || !dims || (n_dims != 4 && n_dims != 5) || N < 1 || N > kRwMaxEnvs) return 0;
+    auto mid = [](int h) { return h >= 32 && h <= 128 && h % 32 == 0; };
+    const int A = dims[n_dims - 1];
+    return dims[0] >= 1 && dims[0] <= 64 && dims[1] == RW_H1 && mid(dims[2]) && (n_dims == 4 || mid(dims[3])) && A >= 1 && A <= 16;
 }
 
-int erl_rollout_wide_step(const float *actor_params, const float *state_avg, const float *state_std, const int *dims, const float *state, int64_t N,
+int erl_rollout_wide_step(const float *actor_params, const float *state_avg, const float *state_std, const int *dims, int n_dims, const float *state, int64_t N,
                           const float *noise, uint64_t seed, uint64_t counter, float *out_state_row, float *out_action_row, float *out_logprob_row,
                           float *out_action_env, hipStream_t stream)
 {
     RwArgs g{};
     g.P = actor_params; g.avg = state_avg; g.sd = state_std;
-    g.S = dims[0]; g.h2 = dims[2]; g.A = dims[3];
+    g.S = dims[0]; g.h2 = dims[2]; g.h3 = n_dims == 5 ? dims[3] : 0; g.A = dims[n_dims - 1];
     g.states = state; g.rows = N; g.noise = noise; g.seed = seed; g.counter = counter;
     g.o_state = out_state_row; g.o_action = out_action_row; g.o_logprob = out_logprob_row; g.o_env = out_action_env;
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = (g.S % 4 == 0) && al(g.P) && al(g.states) && al(g.avg) && al(g.sd) && (!g.o_state || al(g.o_state));
     const dim3 grid((unsigned)erl_cdiv(N, 16)), block(512);
-    if (vec) hipLaunchKernelGGL(rollout_wide_kernel<true>, grid, block, 0, stream, g);
-    else hipLaunchKernelGGL(rollout_wide_kernel<false>, grid, block, 0, stream, g);
+    if (g.h3) {
+        if (vec) hipLaunchKernelGGL((rollout_wide_kernel<true, true>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((rollout_wide_kernel<false, true>), grid, block, 0, stream, g);
+    } else {
+        if (vec) hipLaunchKernelGGL((rollout_wide_kernel<true, false>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((rollout_wide_kernel<false, false>), grid, block, 0, stream, g);
+    }
     return erl_hip_status(hipGetLastError(), "erl_mlpn_rollout_step_f32 (wide latency form)");
 }

@@ -456,7 +456,7 @@ ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp
  * erl_mlpn_ppo_step_f32 with dims = [S <= 64, 256, 128, 64 | 128, A <= 8] (two of the demos' networks) runs as ONE fused kernel on the
  * bf16 matrix pipe with fp32-equivalent split arithmetic (csrc/ppo_step_wd_impl.h) + an image build + the slab reduction, on
  * library-owned buffers -- same arguments, same result; `workspace` is not used then; ERL_WIDE_FUSED=0 in the environment keeps the
- * layered step.  erl_mlpn_rollout_step_f32 with dims = [S <= 64, 256, 32..128, A <= 16] and N <= 16384 runs as ONE launch too
+ * layered step.  erl_mlpn_rollout_step_f32 with dims = [S <= 64, 256, 32..128, (32..128,) A <= 16] and N <= 16384 runs as ONE launch too
  * (csrc/rollout_wide.hip: the latency form of K1 for a 256-wide first layer); same arguments, `workspace` not used then.
  * ------------------------------------------------------------------------------------------- */
 ERL_API int64_t erl_mlpn_param_count(const int *dims, int n_dims, int with_std_log);

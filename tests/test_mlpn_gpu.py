@@ -193,16 +193,18 @@ def test_agent_ppo_on_reference_demo_shapes(hidden):
     np.testing.assert_allclose(agent.cri.net[2 * len(hidden)].weight.detach().cpu().numpy(), critic.weights[-1], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("S,h2,A,N", [(8, 128, 2, 4096), (24, 64, 6, 777), (33, 32, 1, 50), (64, 128, 16, 1000), (3, 96, 3, 16), (61, 128, 8, 16384)])
+@pytest.mark.parametrize("S,h2,A,N", [(8, 128, 2, 4096), (24, 64, 6, 777), (33, 32, 1, 50), (64, 128, 16, 1000), (3, 96, 3, 16), (61, 128, 8, 16384),
+                                      (17, (128, 64), 5, 777), (64, (128, 128), 8, 4096), (6, (32, 96), 1, 33)])
 def test_wide_rollout_step_is_one_launch_and_matches_fp64(ops, dev, S, h2, A, N):
     """net_dims = (256, h2) (examples/demo_A2C_PPO.py:117): erl_mlpn_rollout_step_f32 takes the one-launch latency form (csrc/rollout_wide.hip) --
     actions, log-probs and tanh(actions) against the fp64 restatement (split-bf16 hidden layers: fp32-class), the state row bit for bit,
     aligned and unaligned state_dim, N not a multiple of the 16-env tile, every second-layer width."""
-    rng = np.random.default_rng(S + h2)
-    actor = random_net_n(rng, [S, 256, h2, A], True)
+    mid = list(h2) if isinstance(h2, tuple) else [h2]                      # (h2,) or (h2, h3): examples/demo_A2C_PPO.py:171, :224
+    rng = np.random.default_rng(S + sum(mid))
+    actor = random_net_n(rng, [S, 256, *mid, A], True)
     x = rng.standard_normal((N, S), dtype=np.float32)
     eps = rng.standard_normal((N, A), dtype=np.float32)
-    spec = ops.MlpSpecN([S, 256, h2, A], True)
+    spec = ops.MlpSpecN([S, 256, *mid, A], True)
     o_s, o_a, o_l, o_e = (th.zeros((N, S), device=dev), th.zeros((N, A), device=dev), th.zeros(N, device=dev), th.zeros((N, A), device=dev))
     ops.mlpn_rollout_step(cu(flat_params(actor), dev), spec, cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(x, dev),
                           noise=cu(eps, dev), out_state=o_s, out_action=o_a, out_logprob=o_l, out_env_action=o_e)
