@@ -17,7 +17,7 @@
 //   * the state tile lives in LDS (XS, and normalised + split per network: XA / XC); per step: L1 of both nets -> H1 tiles (split) to LDS -> barrier -> L2 + output-layer
 //     partials -> LDS -> barrier -> waves < ceil(S/16) finish the policy head in registers (action, log-prob, tanh) and
 //     step the env on the matrix cores, wave 7 finishes the value, waves 4..7 draw the next step's N(0,1) (injected or
-//     Philox4x32-10) -> barrier -> done flags, auto-reset, new state tile -> barrier.  Four LDS-only barriers per step; the
+//     Philox4x32-10) -> barrier (SynVecEnv only) -> done flags, auto-reset, new state tile -> barrier.  Four (Pendulum: three) LDS-only barriers per step; the
 //     per-step chain is MFMA-bound (~100 kFLOP per env-step);
 //   * every buffer row is written straight from the kernel: states / actions (pre-tanh) / logprobs / rewards (already
 //     multiplied by reward_scale) / undones = !terminal / unmasks = !truncate / values, time-major (H, N, .).
@@ -474,7 +474,9 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             }
         }
         RFPROF(5);
-        lds_barrier();                                                                               // (3) env reductions
+        // (3) the env's cross-wave reductions (SynVecEnv: S features over nt waves).  Pendulum is stepped by wave 0 alone, which goes straight
+        // on: nothing it reads below was written by another wave since barrier (2), and what it writes is read after barrier (4)
+        if (ENV == ENV_SYN) lds_barrier();
         RFPROF(6);
         if (wave < nt) {
             if (ENV == ENV_SYN) {
