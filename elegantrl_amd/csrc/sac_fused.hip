@@ -447,9 +447,15 @@ struct CriticArgs {
     float *label, *dq;                       // (B,), [E][B]
     float *xa, *enc, *H1e, *dZ1e, *dEncE;    // (B, S+A), (B, h0), [E](B, h1), [E](B, h1), [E](B, h0)
     // MODE 2
-    float *dAct, *qpart;                     // [E](B, A), [E][tiles]
+    float *dAct, *qpart;                     // [E * split](B, A), [E * split][tiles]
     const float *qc, *label_in;              // the training pass's q and labels: the critic objective is finished here
     float *td_out, *tdpart;                  // (B,) or NULL, [tiles]
+    // Feature split of the decoders (MODE 0 and 2: passes whose backward does not need q): grid.y = E * split, workgroup (e, s) owns
+    // hidden features [s d.h1, (s + 1) d.h1) of decoder e -- d.h1 is the SLICE's width here -- i.e. rows of W1, entries of b1 and of the
+    // output row, and streams a split-th of the decoder's weights.  What leaves is linear in the slice: q (bias from slice 0), the
+    // logged sums and d(mean q)/d(action) come out as `split` partial results per decoder, added in slice order by their consumers.
+    int split;
+    int qt_split;                            // MODE 1: qt holds [E][qt_split][B] partial target values
 };
 
 template <int MODE, int C0, int C1>
@@ -459,17 +465,18 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
     __shared__ float dql[TS];
     const LaneId L = lane_id();
     const FusedDims &d = g.d;
-    const int e = blockIdx.y, E = d.E;
+    const int ey = blockIdx.y, e = ey / g.split, E = d.E;
+    const int64_t fo = (int64_t)(ey - e * g.split) * d.h1;          // first hidden feature of this workgroup's slice
     const int64_t B = d.B, row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
     const bool valid = row < B;
     const float *Pd = g.P + d.cdec0 + (int64_t)e * d.dec;
-    const bool first = e == 0;
+    const bool first = ey == 0;
     FwdW<4, WClass<C0>::NU> we;
     FwdW<WClass<C0>::KT, WClass<C1>::NU> w1;
     SmallW wo;
     layer_fwd_load<4, WClass<C0>::NU, false>(g.P + d.cWe, d.S + d.A, d.h0, L, we);
-    layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(Pd + d.dW1, d.h0, d.h1, L, w1);
-    layer_small_load<false, true>(Pd + d.dWo, d.h1, 1, 0, 0, L, wo);
+    layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(Pd + d.dW1 + fo * d.h0, d.h0, d.h1, L, w1);
+    layer_small_load<false, true>(Pd + d.dWo + fo, d.h1, 1, 0, 0, L, wo);
     clear_images(lds.T0, lds.T1, L);
     lds_barrier();
     load_rows(g.Xs, d.S, g.Xa, d.A, row0, B, lds.T0, (MODE == 1 && first) ? g.xa : nullptr, L);
@@ -478,19 +485,34 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
     layer_fwd_mma<4, WClass<C0>::NU, false>(we, g.P + d.cbe, d.S + d.A, d.h0, lds.T0, L, z);            // shared encoder: raw linear
     emit_hidden(z, d.h0, false, lds.T1, gk, (MODE == 1 && first) ? g.enc : nullptr, nullptr, row, valid, L);
     lds_barrier();
-    layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w1, Pd + d.db1, d.h0, d.h1, lds.T1, L, z);
+    layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w1, Pd + d.db1 + fo, d.h0, d.h1, lds.T1, L, z);
     // the backward pass's weights are requested now (the forward layer's registers are free): they land under the output layer,
     // the loss and the gate
     BwdW<WClass<C1>::KT, WClass<C0>::NU> wb;
     SmallW wa;
     emit_hidden(z, d.h1, true, lds.T0, gk1, MODE == 1 ? g.H1e + (size_t)e * B * d.h1 : nullptr, nullptr, row, valid, L);
-    if (MODE != 0) layer_bwd_load<WClass<C1>::KT, WClass<C0>::NU>(Pd + d.dW1, d.h1, d.h0, L, wb);
+    if (MODE != 0) layer_bwd_load<WClass<C1>::KT, WClass<C0>::NU>(Pd + d.dW1 + fo * d.h0, d.h1, d.h0, L, wb);
     if (MODE == 2) layer_small_load<true, false>(g.P + d.cWe, d.h0, d.A, d.S + d.A, d.S, L, wa);
     lds_barrier();
-    layer_small_mma<false, true>(wo, Pd + d.dbo, d.h1, 1, lds.T0, lds.part, lds.Yl, L);
+    layer_small_mma<false, true>(wo, fo == 0 ? Pd + d.dbo : nullptr, d.h1, 1, lds.T0, lds.part, lds.Yl, L);
     if (MODE == 0) {
-        if (L.tid < TS && row0 + L.tid < B) g.q[(size_t)e * B + row0 + L.tid] = lds.Yl[L.tid * 16];
+        if (L.tid < TS && row0 + L.tid < B) g.q[(size_t)ey * B + row0 + L.tid] = lds.Yl[L.tid * 16];
         return;
+    }
+    // ---- the target's q of the next state, E values per sample: thread (sample, k) adds the qt_split partial values the target pass left
+    __shared__ float qtl[TS * FMAXE];
+    if (MODE == 1) {
+        if (L.tid < TS * FMAXE) {
+            const int s_ = L.tid / FMAXE, k = L.tid - s_ * FMAXE;
+            const int64_t b = row0 + s_;
+            float qk = 0.f;
+            if (k < E && b < B) {
+                qk = g.qt[(size_t)k * g.qt_split * B + b];
+                for (int j = 1; j < g.qt_split; ++j) qk += g.qt[((size_t)k * g.qt_split + j) * B + b];
+            }
+            qtl[L.tid] = qk;
+        }
+        lds_barrier();
     }
     // ---- dL/dq of this decoder for the tile's samples
     if (L.tid < TS) {
@@ -498,11 +520,11 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
         float dqv = 0.f;
         if (b < B) {
             const float qv = lds.Yl[L.tid * 16];
-            g.q[(size_t)e * B + b] = qv;
+            g.q[(size_t)ey * B + b] = qv;
             if (MODE == 1) {
                 // q_label = reward + undone * gamma * (min_e q_target - next_logprob * alpha)      (AgentSAC.py:52-55)
-                float m = g.qt[b];
-                for (int k = 1; k < E; ++k) m = fminf(m, g.qt[(size_t)k * B + b]);
+                float m = qtl[L.tid * FMAXE];
+                for (int k = 1; k < E; ++k) m = fminf(m, qtl[L.tid * FMAXE + k]);
                 const float alpha = expf(g.alpha0[0]);
                 const float lab = g.reward[b] + (g.undone[b] * g.gamma) * (m - g.lp_next[b] * alpha);
                 if (first) g.label[b] = lab;
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
     if (MODE == 2) {                                               // partial sums of q for the logged actor objective
         float s = (L.tid < TS && row0 + L.tid < B) ? lds.Yl[L.tid * 16] : 0.f;
         s = wave_sum(s);
-        if (L.tid == 0) g.qpart[(size_t)e * gridDim.x + blockIdx.x] = s;
+        if (L.tid == 0) g.qpart[(size_t)ey * gridDim.x + blockIdx.x] = s;
         if (first && L.wave == 1) {                                // (wave 1, whole wave) the critic objective's per-sample td errors, now
             const int64_t b = row0 + L.lane;                       // that every decoder's q of the training pass is in memory
             float td = 0.f;
@@ -550,7 +572,7 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
             const int f = 16 * ot + 4 * L.q;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (f + r < d.h1) ? Pd[d.dWo + f + r] * dqs * gk1[u][r] : 0.f;
+            for (int r = 0; r < 4; ++r) v[r] = (f + r < d.h1) ? Pd[d.dWo + fo + f + r] * dqs * gk1[u][r] : 0.f;
             *reinterpret_cast<float4 *>(lds.T1 + L.l15 * LDT + f) = make_float4(v[0], v[1], v[2], v[3]);
             if (MODE == 1 && valid && f < d.h1)
                 *reinterpret_cast<float4 *>(g.dZ1e + ((size_t)e * B + row) * d.h1 + f) = make_float4(v[0], v[1], v[2], v[3]);
@@ -581,7 +603,7 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
     layer_small_mma<true, false>(wa, nullptr, d.h0, d.A, lds.T0, lds.part, lds.Yl, L);
     if (L.tid < TS * 16) {
         const int s = L.tid >> 4, a = L.tid & 15;
-        if (a < d.A && row0 + s < B) g.dAct[((size_t)e * B + row0 + s) * d.A + a] = lds.Yl[s * 16 + a];
+        if (a < d.A && row0 + s < B) g.dAct[((size_t)ey * B + row0 + s) * d.A + a] = lds.Yl[s * 16 + a];
     }
 }
 
@@ -596,6 +618,7 @@ struct ActorBwdArgs {
     float *dY, *dZ2, *dZ1;                   // (B, 2A), (B, h1), (B, h0)
     const float *tdpart, *qpart;
     int ntiles;
+    int nsplit;                              // dAct / qpart hold E * nsplit partial results (critic_tile_kernel's feature split)
     float *objs_out;
 };
 
@@ -609,13 +632,14 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
     const int64_t B = d.B, row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
     const bool valid = row < B;
     if (blockIdx.x == 0) {                                         // the logged objectives (AgentSAC.py:86)
-        float sl = 0.f;
+        float sl = 0.f, sqp = 0.f;
         for (int64_t i = L.tid; i < B; i += FT) sl += g.lp_cur[i];
+        for (int k = L.tid; k < E * g.nsplit * g.ntiles; k += FT) sqp += g.qpart[k];      // (one thread walking the table: a load latency per entry)
         const float tl = block_sum(sl, lds.red);
+        const float sq = block_sum(sqp, lds.red);
         if (L.tid == 0) {
-            float std_ = 0.f, sq = 0.f;
+            float std_ = 0.f;
             for (int t = 0; t < g.ntiles; ++t) std_ += g.tdpart[t];
-            for (int k = 0; k < E * g.ntiles; ++k) sq += g.qpart[k];
             g.objs_out[0] = std_ / (float)B;
             g.objs_out[1] = sq / ((float)E * (float)B) - expf(g.alpha_log[0]) * (tl / (float)B);
         }
@@ -624,6 +648,17 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
     BwdW<WClass<C1>::KT, WClass<C0>::NU> wb2;
     layer_bwd_load<1, WClass<C1>::NU>(g.P + d.aWh, 2 * A, d.h1, L, wbh);
     clear_images(lds.T0, lds.T1, L);
+    // d(mean q)/d(action) arrives as E * nsplit partial results per (sample, action): thread (sample, action, j) adds every fourth of them,
+    // the head thread below adds the four sums in order (E = 4 unsplit: the former left-to-right sum)
+    __shared__ float dal[TS * 8 * 4];
+    {
+        const int s_ = L.tid >> 5, a = (L.tid >> 2) & 7, j = L.tid & 3, nk = E * g.nsplit;
+        const int64_t b = row0 + s_;
+        float acc = 0.f;
+        if (a < A && b < B)
+            for (int k = j; k < nk; k += 4) acc += g.dAct[((size_t)k * B + b) * A + a];
+        dal[L.tid] = acc;
+    }
     lds_barrier();
     if (L.tid < TS) {                                              // dL/d(head output) of sample row0 + tid (head_backward_kernel, sac.hip)
         const int64_t b = row0 + L.tid;
@@ -636,8 +671,8 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
                 const float sd = expf(lsc);
                 const float t = g.act_t[b * A + a];
                 const float one_m = 1.f - t * t;
-                float dA = g.dAct[b * A + a];
-                for (int k = 1; k < E; ++k) dA += g.dAct[((size_t)k * B + b) * A + a];
+                const float *dp = dal + (L.tid * 8 + a) * 4;
+                const float dA = ((dp[0] + dp[1]) + dp[2]) + dp[3];
                 const float du = dA * one_m + dlp * (2.f * t * one_m / (one_m + 1e-6f));
                 const bool inside = ls >= -16.f && ls <= 2.f;
                 const float dls = inside ? du * sd * g.eps[b * A + a] - dlp : 0.f;
@@ -897,24 +932,27 @@ bool erl_sac_fused_supported(int S, int A, const int *hidden, int n_hidden, int 
            h1 % 16 == 0 && E >= 1 && E <= FMAXE && B >= 1 && B <= 4096;
 }
 
+constexpr int kCritSplit = 4;          // feature slices per decoder in the critic passes that split (see CriticArgs::split)
+
 int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, int64_t Pa, int64_t Pc)
 {
     const int64_t tiles = (B + TS - 1) / TS;
     auto r = [](int64_t n) { return (n + 63) / 64 * 64; };
     int64_t f = 0;
     f += 3 * r(B * A) + 2 * r(B);                                       // a_next, act_pg, eps | lp_next, lp_cur
-    f += 3 * r((int64_t)E * B) + r(B);                                  // qt, qc (also q_pg), dq | label
+    f += r((int64_t)kCritSplit * E * B) + 2 * r((int64_t)E * B) + r(B);  // qt (also q_pg; up to kCritSplit partial values each), qc, dq | label
     f += r(B * (S + A)) + r(B * h0);                                    // xa, enc
     f += 2 * r((int64_t)E * B * h1) + r((int64_t)E * B * h0);           // H1e, dZ1e | dEncE
     f += r(B * 2 * A) * 2 + 2 * r(B * h0) + 2 * r(B * h1);              // Y, dY | H0, G0 | H1, G1
-    f += r((int64_t)E * B * A) + r(B * h1) + r(B * h0);                 // dAct | dZ2, dZ1 (actor)
-    f += r(Pa) + r(Pc) + r((int64_t)E * tiles) + r(tiles) + 64;        // gradients, partial sums, alpha0
+    f += r((int64_t)kCritSplit * E * B * A) + r(B * h1) + r(B * h0);     // dAct | dZ2, dZ1 (actor)
+    f += r(Pa) + r(Pc) + r((int64_t)kCritSplit * E * tiles) + r(tiles) + 64;   // gradients, partial sums, alpha0
     f += 2 * 2 * kDwMaxParts;                                           // the squared-norm pieces of the two dw_table launches (doubles)
     return f;
 }
 
-#define FUSED_KT_DISPATCH(KERNEL_MACRO)                                                                          \
-    switch (wclass(d.h0) * 3 + wclass(d.h1)) {                                                                  \
+#define FUSED_KT_DISPATCH(KERNEL_MACRO) FUSED_KT_DISPATCH_D(d, KERNEL_MACRO)
+#define FUSED_KT_DISPATCH_D(DD, KERNEL_MACRO)                                                                    \
+    switch (wclass((DD).h0) * 3 + wclass((DD).h1)) {                                                            \
         case 0: KERNEL_MACRO(0, 0); break; case 1: KERNEL_MACRO(0, 1); break; case 2: KERNEL_MACRO(0, 2); break; \
         case 3: KERNEL_MACRO(1, 0); break; case 4: KERNEL_MACRO(1, 1); break; case 5: KERNEL_MACRO(1, 2); break; \
         case 6: KERNEL_MACRO(2, 0); break; case 7: KERNEL_MACRO(2, 1); break; default: KERNEL_MACRO(2, 2); break; \
@@ -958,12 +996,12 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     float *w = workspace;
     auto take = [&](int64_t n) { float *p = w; w += r(n); return p; };
     float *a_next = take(B * A), *eps_used = take(B * A), *lp_next = take(B), *lp_cur = take(B);
-    float *qt = take((int64_t)E * B), *qc = take((int64_t)E * B), *dq = take((int64_t)E * B), *label = take(B);
+    float *qt = take((int64_t)kCritSplit * E * B), *qc = take((int64_t)E * B), *dq = take((int64_t)E * B), *label = take(B);
     float *xa = take(B * (S + A)), *enc = take(B * h0);
     float *H1e = take((int64_t)E * B * h1), *dZ1e = take((int64_t)E * B * h1), *dEncE = take((int64_t)E * B * h0);
     float *Y = take(B * 2 * A), *dY = take(B * 2 * A), *H0 = take(B * h0), *G0 = take(B * h0), *H1 = take(B * h1), *G1 = take(B * h1);
-    float *dAct = take((int64_t)E * B * A), *dZ2 = take(B * h1), *dZ1 = take(B * h0);
-    float *g_actor = take(Pa), *g_critic = take(Pc), *qpart = take((int64_t)E * tiles), *tdpart = take(tiles), *alpha0 = take(64);
+    float *dAct = take((int64_t)kCritSplit * E * B * A), *dZ2 = take(B * h1), *dZ1 = take(B * h0);
+    float *g_actor = take(Pa), *g_critic = take(Pc), *qpart = take((int64_t)kCritSplit * E * tiles), *tdpart = take(tiles), *alpha0 = take(64);
     float *act_pg = take(B * A);                        // (its own buffer: the policy-gradient sample runs next to the critic update)
     double *nparts_c = reinterpret_cast<double *>(take(2 * kDwMaxParts)), *nparts_a = reinterpret_cast<double *>(take(2 * kDwMaxParts));
     float *q_pg = qt;                                   // reused once its first contents are consumed
@@ -1003,14 +1041,24 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
         sa = s;
     }
     // ---- (2) target ensemble on (next_state, next_action)                                                     (:52)
+    // (the passes whose backward does not need q -- (2) and (7) -- split every 256-wide decoder over kCritSplit workgroups while the
+    // launch stays within the chip: 16 tiles x 4 decoders x 4 slices = 256 workgroups at B = 256, each streaming 64 KB of W1 instead of
+    // 256 KB through one CU's ~30 GB/s; ERL_SAC_SPLIT=0 turns it off)
+    static const bool split_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 0); }();
+    const int split = (split_on && h1 == 64 * kCritSplit && (int64_t)tiles * E * kCritSplit <= 256) ? kCritSplit : 1;
+    FusedDims dsl = d;
+    dsl.h1 = h1 / split;
+    dim3 cg(tiles, E * split);
     CriticArgs ca{};
-    ca.P = target_params; ca.d = d; ca.Xs = next_state; ca.Xa = a_next; ca.q = qt;
-#define LAUNCH_CRITIC(MODE, K0, K1) hipLaunchKernelGGL((critic_tile_kernel<MODE, K0, K1>), cgrid, blk, 0, s, ca)
+    ca.P = target_params; ca.d = dsl; ca.split = split; ca.qt_split = 1; ca.Xs = next_state; ca.Xa = a_next; ca.q = qt;
+#define LAUNCH_CRITIC(MODE, K0, K1) hipLaunchKernelGGL((critic_tile_kernel<MODE, K0, K1>), cg, blk, 0, s, ca)
 #define LAUNCH_CRITIC0(K0, K1) LAUNCH_CRITIC(0, K0, K1)
 #define LAUNCH_CRITIC1(K0, K1) LAUNCH_CRITIC(1, K0, K1)
 #define LAUNCH_CRITIC2(K0, K1) LAUNCH_CRITIC(2, K0, K1)
-    FUSED_KT_DISPATCH(LAUNCH_CRITIC0)
+    FUSED_KT_DISPATCH_D(dsl, LAUNCH_CRITIC0)
     // ---- (3) critic training pass: labels, loss gradient, backward to the encoder output                      (:53-62)
+    cg = cgrid;
+    ca.d = d; ca.split = 1; ca.qt_split = split;
     ca.P = critic_params; ca.Xs = state; ca.Xa = action; ca.q = qc;
     ca.qt = qt; ca.reward = reward; ca.undone = undone; ca.unmask = unmask; ca.lp_next = lp_next; ca.is_weight = is_weight; ca.alpha0 = alpha0;
     ca.gamma = gamma; ca.label = label; ca.dq = dq; ca.xa = xa; ca.enc = enc; ca.H1e = H1e; ca.dZ1e = dZ1e; ca.dEncE = dEncE;
@@ -1035,14 +1083,16 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     // ---- (7) TARGET ensemble on (state, action_pg): q and d(mean q)/d(action); finishes the critic objective    (:82-83)
     if (side && (rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
     joiner.armed = false;
+    cg = dim3(tiles, E * split);
+    ca.d = dsl; ca.split = split; ca.qt_split = 1;
     ca.P = target_params; ca.Xs = state; ca.Xa = act_pg; ca.q = q_pg;
     ca.dAct = dAct; ca.qpart = qpart; ca.qc = qc; ca.label_in = label; ca.td_out = td_error_out; ca.tdpart = tdpart;
-    FUSED_KT_DISPATCH(LAUNCH_CRITIC2)
+    FUSED_KT_DISPATCH_D(dsl, LAUNCH_CRITIC2)
     // ---- (8) actor backward, (9) its weight gradients, (10) clip + Adam, alpha clamp                            (:80-85)
     {
         ActorBwdArgs ab{};
         ab.P = actor_params; ab.d = d; ab.Y = Y; ab.act_t = act_pg; ab.eps = eps_used; ab.dAct = dAct; ab.alpha_log = alpha_log; ab.G0 = G0;
-        ab.G1 = G1; ab.lp_cur = lp_cur; ab.dY = dY; ab.dZ2 = dZ2; ab.dZ1 = dZ1; ab.tdpart = tdpart; ab.qpart = qpart; ab.ntiles = tiles;
+        ab.G1 = G1; ab.lp_cur = lp_cur; ab.dY = dY; ab.dZ2 = dZ2; ab.dZ1 = dZ1; ab.tdpart = tdpart; ab.qpart = qpart; ab.ntiles = tiles; ab.nsplit = split;
         ab.objs_out = objs_out;
 #define LAUNCH_ACTOR_BWD(K0, K1) hipLaunchKernelGGL((actor_bwd_kernel<K0, K1>), tgrid, blk, 0, s, ab)
         FUSED_KT_DISPATCH(LAUNCH_ACTOR_BWD)
