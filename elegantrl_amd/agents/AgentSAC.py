@@ -114,6 +114,9 @@ class AgentSAC(AgentBase):
         self.num_ensembles = getattr(args, "num_ensembles", 4)
         # update_net draws the sample ids of all its steps with one th.randint (False: one draw per step, the reference's call pattern)
         self.sample_ids_ahead = bool(getattr(args, "sample_ids_ahead", True))
+        # device-resident envs that offer it: the whole off-policy rollout as one launch (False: the per-step loop)
+        self.fused_rollout = bool(getattr(args, "fused_rollout", True))
+        self._last_state_token = None
         self._spec = ops.SacSpec(state_dim, action_dim, net_dims, self.num_ensembles)
         dev, f32 = self.device, th.float32
         self._actor_flat = th.zeros(self._spec.actor_count, dtype=f32, device=dev)
@@ -169,6 +172,41 @@ class AgentSAC(AgentBase):
             self._sync_modules()
 
     @_hip.on_device
+    @_hip.on_device
+    def _explore_vec_env(self, env, horizon_len: int, noise: Optional[TEN] = None) -> Tuple[TEN, ...]:
+        """AgentBase._explore_vec_env (AgentBase.py:130-170); on a device-resident env that offers `fused_rollout_offpolicy` (SynVecEnv) the
+        whole loop is ONE launch (erl_sac_rollout_synenv_f32: same five tensors, final state and env counters, bit for bit, as the
+        per-step loop; `args.fused_rollout = False` keeps the loop)."""
+        H, N, S, A, dev = horizon_len, self.num_envs, self.state_dim, self.action_dim, self.device
+        if not (self.fused_rollout and hasattr(env, "fused_rollout_offpolicy") and getattr(env, "num_envs", None) == N
+                and getattr(env, "device", None) == dev and getattr(env, "state_dim", None) == S
+                and _hip.lib().erl_sac_rollout_synenv_supported(self._spec.S, self._spec.A, self._spec._c, len(self._spec.hidden), N)):
+            self._last_state_token = None
+            return super()._explore_vec_env(env, horizon_len, noise)
+        self._sync_modules()
+        state = self.last_state.to(dev, th.float32)
+        assert state.shape == (N, S)
+        if state.data_ptr() != env.state.data_ptr():
+            tok = self._last_state_token
+            # `state` is the copy of the final state the last fused rollout of THIS env wrote, untouched, and the env has not moved since:
+            # the env's live buffer already holds it; otherwise the env takes the agent's state (it owns the live buffer)
+            same = (tok is not None and tok[0] is self.last_state and tok[1] == self.last_state._version and tok[2] is env
+                    and tok[3] == getattr(env, "state_epoch", None))
+            if not same:
+                env.state.copy_(state)
+                env.state_epoch += 1
+        states = th.empty((H, N, S), dtype=th.float32, device=dev)
+        actions = th.empty((H, N, A), dtype=th.float32, device=dev)
+        rewards = th.empty((H, N), dtype=th.float32, device=dev)
+        undones = th.empty((H, N), dtype=th.bool, device=dev)
+        unmasks = th.empty((H, N), dtype=th.bool, device=dev)
+        last_out = th.empty((N, S), dtype=th.float32, device=dev)
+        env.fused_rollout_offpolicy(self, H, None if noise is None else noise.contiguous(), (states, actions, rewards, undones, unmasks), last_out)
+        self.rng_counter += H
+        self.last_state = last_out
+        self._last_state_token = (last_out, last_out._version, env, getattr(env, "state_epoch", None))
+        return states, actions, rewards, undones, unmasks
+
     def explore_action(self, state: TEN, noise: Optional[TEN] = None, out: Optional[TEN] = None, out_state: Optional[TEN] = None) -> TEN:
         """`out` (n, action_dim), contiguous: the kernel writes the action there (the rollout passes its buffer row: no copy);
         `out_state` (n, state_dim), contiguous: the kernel also copies `state` there (the rollout's `states[t] = state`)"""

@@ -914,6 +914,206 @@ struct SacJoin {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent off-policy rollout for the device-resident SynVecEnv: ONE launch per AgentSAC.explore_env.
+//
+// Replaces the loop of AgentBase._explore_vec_env (elegantrl/agents/AgentBase.py:130-170): for t in range(H): ActorSAC.get_action
+// (AgentSAC.py:179-185), `states[t] = state`, `actions[t] = action`, env.step, the reward / flag stores; then `rewards *= reward_scale`
+// and the two logical_not.  Per step the loop cost an explore launch (actor_fwd_kernel: 21 us at 64 envs, almost all of it four
+// workgroups streaming the actor's cold weights) and an env launch; here a workgroup owns a 16-env tile for all H steps and the
+// actor's weights stay in REGISTERS (the A operands actor_fwd_kernel loads once per launch anyway: 32 + 128 + 8 per lane at
+// [256,256]), Ws^T / Wa^T of the environment and the state tile in LDS.  A step is instruction for instruction actor_fwd_kernel
+// followed by erl_synenv_step_f32's tile form (envs.hip; the code of rollout_fused.hip's SynVecEnv branch), so the five rollout
+// tensors, the final state and the env's counters are bit-identical to the per-step loop under the same Philox keys / injected
+// noise (tests/test_sac.py).
+// ---------------------------------------------------------------------------------------------------------
+struct SacRolloutArgs {
+    const float *P;
+    FusedDims d;                                   // B = number of envs
+    int H;
+    const float *noise;                            // (H, N, A) or NULL: Philox keyed by (seed, counter0 + t, env, a)
+    uint64_t seed, counter0;
+    float reward_scale;
+    float *o_states, *o_actions, *o_rewards;       // (H, N, S), (H, N, A), (H, N)
+    uint8_t *o_undones, *o_unmasks;                // (H, N): !terminal, !truncate
+    float *o_last_state;                           // (N, S) or NULL
+    float *env_state;                              // (N, S) live state
+    const float *Ws, *Wa;
+    int32_t *step_count, *episode;
+    int max_step;
+    uint64_t env_seed;
+};
+
+constexpr int SR_XLD = 68, SR_WLD = 68;
+// dynamic LDS (floats): [XS 16 x 68][WST 64 x 68][WAT 64 x 16][ACT 16 x 16][RED 8 x 16 x 2][W1L 256 x 68: the actor's first layer][BIA 3 x 256: b1 | b2 | head bias]
+constexpr int SR_O_XS = 0, SR_O_WST = SR_O_XS + 16 * SR_XLD, SR_O_WAT = SR_O_WST + 64 * SR_WLD, SR_O_ACT = SR_O_WAT + 64 * 16;
+constexpr int SR_O_RED = SR_O_ACT + 16 * 16, SR_O_W1L = SR_O_RED + 8 * 16 * 2, SR_O_BIA = SR_O_W1L + FMAXW * SR_WLD, SR_FLOATS = SR_O_BIA + 3 * FMAXW;
+
+template <int C0, int C1>
+__global__ __launch_bounds__(FT) void sac_rollout_synenv_kernel(SacRolloutArgs g)
+{
+    __shared__ TileLds lds;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *XS = smem + SR_O_XS, *WST = smem + SR_O_WST, *WAT = smem + SR_O_WAT, *ACT = smem + SR_O_ACT, *RED = smem + SR_O_RED, *W1L = smem + SR_O_W1L, *BIA = smem + SR_O_BIA;
+    const LaneId L = lane_id();
+    const FusedDims &d = g.d;
+    const int S = d.S, A = d.A, H = g.H, ns = (S + 15) >> 4;
+    const int64_t N = d.B, row0 = (int64_t)blockIdx.x * TS, env = row0 + L.l15;
+    const bool valid = env < N;
+    const int64_t row = valid ? env : N - 1;              // rows past N replay env N - 1 (never stored)
+    // the weights of the second layer and of the head, once; the first layer's (<= 64 columns) wait in LDS, zero padded -- 32 registers
+    // less across the loop, which at [256,256] is what fits
+    FwdW<WClass<C0>::KT, WClass<C1>::NU> w2;
+    SmallW wh;
+    layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(g.P + d.aW2, d.h0, d.h1, L, w2);
+    layer_small_load<false, true>(g.P + d.aWh, d.h1, 2 * d.A, 0, 0, L, wh);
+    clear_images(lds.T0, lds.T1, L);
+    for (int e = L.tid; e < 16 * 64; e += FT) {            // state tile (rows past N: env N - 1), zero beyond S
+        const int i = e >> 6, k = e & 63;
+        const int64_t r_ = min(row0 + i, N - 1);
+        XS[i * SR_XLD + k] = (k < S) ? g.env_state[r_ * S + min(k, S - 1)] : 0.f;
+    }
+    for (int e = L.tid; e < 64 * 64; e += FT) {            // WST[j][k] = Ws[k][j]
+        const int k = e >> 6, jj = e & 63;
+        WST[jj * SR_WLD + k] = (k < S && jj < S) ? g.Ws[(size_t)min(k, S - 1) * S + min(jj, S - 1)] : 0.f;
+    }
+    for (int e = L.tid; e < 16 * 64; e += FT) {
+        const int k = e >> 6, jj = e & 63;
+        WAT[jj * 16 + k] = (k < A && jj < S) ? g.Wa[(size_t)min(k, A - 1) * S + min(jj, S - 1)] : 0.f;
+    }
+    if (L.tid < 16 * 16) ACT[L.tid] = 0.f;
+    for (int e = L.tid; e < FMAXW * 64; e += FT) {         // W1L[row][k] = W1[row][k], zero beyond (h0, S)
+        const int i = e >> 6, k = e & 63;
+        W1L[i * SR_WLD + k] = (i < d.h0 && k < S) ? g.P[d.aW1 + (size_t)min(i, d.h0 - 1) * S + min(k, S - 1)] : 0.f;
+    }
+    for (int e = L.tid; e < 3 * FMAXW; e += FT) {          // the biases too (read per step: hoisted out of the loop they would be 24 more registers)
+        const int which = e / FMAXW, k = e - which * FMAXW;
+        const int n = which == 0 ? d.h0 : (which == 1 ? d.h1 : 2 * A);
+        BIA[e] = k < n ? g.P[(which == 0 ? d.ab1 : (which == 1 ? d.ab2 : d.abh)) + min(k, n - 1)] : 0.f;
+    }
+    const float *wst_row = WST + ((16 * L.wave + L.l15) & 63) * SR_WLD + 4 * L.q, *wat_row = WAT + ((16 * L.wave + L.l15) & 63) * 16 + 4 * L.q;
+    int sc = g.step_count[row], ep = g.episode[row];
+    lds_barrier();
+
+    for (int t = 0; t < H; ++t) {
+        FwdW<4, WClass<C0>::NU> w1;
+#pragma unroll
+        for (int u = 0; u < WClass<C0>::NU; ++u) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                w1.v[u][kt] = *reinterpret_cast<const float4 *>(W1L + (16 * (L.wave + FWV * u) + L.l15) * SR_WLD + 16 * kt + 4 * L.q);
+        }
+        // ---- the state rows into the first layer's input image; states[t] = state
+        for (int e = L.tid; e < TS * 16 * ns; e += FT) {
+            const int s_ = e / (16 * ns), c = e - s_ * (16 * ns);
+            const float v = XS[s_ * SR_XLD + c];
+            lds.T0[s_ * LDT + c] = v;
+            if (c < S && row0 + s_ < N) g.o_states[((size_t)t * N + row0 + s_) * S + c] = v;
+        }
+        lds_barrier();
+        f32x4 z[2], gk[2];
+        layer_fwd_mma<4, WClass<C0>::NU, true>(w1, BIA, 16 * ns, d.h0, lds.T0, L, z);     // (the LDS image is zero padded: no masks; the same ns k-tiles)
+        emit_hidden(z, d.h0, true, lds.T1, gk, nullptr, nullptr, row, valid, L);
+        lds_barrier();
+        layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w2, BIA + FMAXW, d.h0, d.h1, lds.T1, L, z);
+        emit_hidden(z, d.h1, true, lds.T0, gk, nullptr, nullptr, row, valid, L);
+        lds_barrier();
+        layer_small_mma<false, true>(wh, BIA + 2 * FMAXW, d.h1, 2 * d.A, lds.T0, lds.part, lds.Yl, L);
+        if (L.tid < TS) {                                  // actor_fwd_kernel's tail: action = tanh(mean + std * eps)
+            const int64_t b = row0 + L.tid, bc = min(b, N - 1);
+            for (int a = 0; a < A; ++a) {
+                const float mean = lds.Yl[L.tid * 16 + a], ls = lds.Yl[L.tid * 16 + A + a];
+                const float lsc = fminf(fmaxf(ls, -16.f), 2.f);
+                const float sd = expf(lsc);
+                const float eps = g.noise ? g.noise[((size_t)t * N + bc) * A + a]
+                                          : philox_normal(g.seed, g.counter0 + (uint64_t)t, (uint32_t)bc, (uint32_t)a);
+                const float tv = tanhf(mean + sd * eps);
+                ACT[L.tid * 16 + a] = tv;
+                if (b < N) g.o_actions[((size_t)t * N + b) * A + a] = tv;
+            }
+        }
+        lds_barrier();
+        // ---- env.step on the matrix cores: s' = s Ws + a Wa, wave w < ns owns features 16 w .. 16 w + 15 (envs.hip synenv_tile_kernel)
+        float out[4] = {0.f, 0.f, 0.f, 0.f}, a2 = 0.f;
+        const int j0 = 16 * L.wave + 4 * L.q;
+        if (L.wave < ns) {
+            const float4 av = *reinterpret_cast<const float4 *>(ACT + L.l15 * 16 + 4 * L.q);
+            a2 = (av.x * av.x + av.y * av.y) + (av.z * av.z + av.w * av.w);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            const float4 wb = *reinterpret_cast<const float4 *>(wat_row);
+            c0 = mfma16(wb.x, av.x, c0);
+            c1 = mfma16(wb.y, av.y, c1);
+            c0 = mfma16(wb.z, av.z, c0);
+            c1 = mfma16(wb.w, av.w, c1);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                if (tt < ns) {
+                    const float4 wa = *reinterpret_cast<const float4 *>(wst_row + 16 * tt);
+                    const float4 xr = *reinterpret_cast<const float4 *>(XS + L.l15 * SR_XLD + 16 * tt + 4 * L.q);
+                    c0 = mfma16(wa.x, xr.x, c0);
+                    c1 = mfma16(wa.y, xr.y, c1);
+                    c0 = mfma16(wa.z, xr.z, c0);
+                    c1 = mfma16(wa.w, xr.w, c1);
+                }
+            }
+            float sq = 0.f, mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[r] = c0[r] + c1[r];
+                if (j0 + r < S) {
+                    sq += out[r] * out[r];
+                    mx = fmaxf(mx, fabsf(out[r]));
+                }
+            }
+            const float a2x = __shfl_xor(a2, 16, 64), sqx = __shfl_xor(sq, 16, 64), mxx = __shfl_xor(mx, 16, 64);
+            a2 += a2x; sq += sqx; mx = fmaxf(mx, mxx);
+            const float a2y = __shfl_xor(a2, 32, 64), sqy = __shfl_xor(sq, 32, 64), mxy = __shfl_xor(mx, 32, 64);
+            a2 += a2y; sq += sqy; mx = fmaxf(mx, mxy);
+            if (L.q == 0) { RED[(L.wave * 16 + L.l15) * 2] = sq; RED[(L.wave * 16 + L.l15) * 2 + 1] = mx; }
+        }
+        lds_barrier();
+        if (L.wave < ns) {
+            float sq = 0.f, mx = 0.f;
+            for (int w = 0; w < ns; ++w) { sq += RED[(w * 16 + L.l15) * 2]; mx = fmaxf(mx, RED[(w * 16 + L.l15) * 2 + 1]); }
+            const int sc1 = sc + 1;
+            const bool term = mx > 10.f;
+            const bool trunc = (sc1 >= g.max_step) && !term;
+            const bool done = term || trunc;
+            if (j0 < S) {
+                if (done) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[r] = philox_normal(g.env_seed, (uint64_t)(ep + 1), (uint32_t)row, (uint32_t)(j0 + r));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (j0 + r >= S) out[r] = 0.f;
+                *reinterpret_cast<float4 *>(XS + L.l15 * SR_XLD + j0) = make_float4(out[0], out[1], out[2], out[3]);
+            }
+            if (L.wave == 0 && L.q == 0 && valid) {
+                const float rew = -(sq / (float)S) - 0.01f * (a2 / (float)A);
+                g.o_rewards[(size_t)t * N + row] = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;      // rewards *= reward_scale
+                g.o_undones[(size_t)t * N + row] = term ? 0 : 1;                                               // logical_not
+                g.o_unmasks[(size_t)t * N + row] = trunc ? 0 : 1;
+            }
+            sc = done ? 0 : sc1;
+            if (done) ep = ep + 1;
+        }
+        lds_barrier();
+    }
+    // ---- hand the environment back; the agent's own copy of the final state
+    for (int e = L.tid; e < 16 * 64; e += FT) {
+        const int i = e >> 6, k = e & 63;
+        if (row0 + i < N && k < S) {
+            const float x = XS[i * SR_XLD + k];
+            g.env_state[(row0 + i) * S + k] = x;
+            if (g.o_last_state) g.o_last_state[(row0 + i) * S + k] = x;
+        }
+    }
+    if (L.wave == 0 && L.q == 0 && valid) {
+        g.step_count[row] = sc;
+        g.episode[row] = ep;
+    }
+}
+
 }  // namespace
 
 // ---- shape class of the fused step ---------------------------------------------------------------------------
@@ -1109,4 +1309,43 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
             return rc;
     }
     return erl_hip_status(hipGetLastError(), "erl_sac_update_f32(fused)");
+}
+
+// ---- the persistent off-policy rollout (sac_rollout_synenv_kernel) ----
+extern "C" int erl_sac_rollout_synenv_supported(int S, int A, const int *hidden, int n_hidden, int64_t N)
+{
+    static const bool on = [] { const char *e = getenv("ERL_SAC_FUSED"); return !(e && atoi(e) == 0); }();
+    return (on && erl_sac_fused_supported(S, A, hidden, n_hidden, 1, N < 1 ? 1 : (N > 4096 ? 4096 : N)) && N >= 1 && N <= 4096) ? 1 : 0;
+}
+
+int erl_sac_rollout_fused(const float *actor_params, int S, int A, int h0, int h1, const int64_t *aoff, float *env_state, const float *Ws,
+                          const float *Wa, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N, int64_t H,
+                          const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states, float *out_actions,
+                          float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks, float *out_last_state, hipStream_t stream)
+{
+    FusedDims d{};
+    d.S = S; d.A = A; d.E = 1; d.h0 = h0; d.h1 = h1; d.B = N;
+    d.aW1 = aoff[0]; d.ab1 = aoff[1]; d.aW2 = aoff[2]; d.ab2 = aoff[3]; d.aWh = aoff[4]; d.abh = aoff[5];
+    SacRolloutArgs g{};
+    g.P = actor_params; g.d = d; g.H = (int)H; g.noise = noise; g.seed = seed; g.counter0 = counter0; g.reward_scale = reward_scale;
+    g.o_states = out_states; g.o_actions = out_actions; g.o_rewards = out_rewards; g.o_undones = out_undones; g.o_unmasks = out_unmasks;
+    g.o_last_state = out_last_state; g.env_state = env_state; g.Ws = Ws; g.Wa = Wa; g.step_count = step_count; g.episode = episode;
+    g.max_step = max_step; g.env_seed = env_seed;
+    const dim3 grid((unsigned)((N + TS - 1) / TS)), blk(FT);
+    const size_t lds_bytes = (size_t)SR_FLOATS * sizeof(float);
+    static bool attr[9] = {false, false, false, false, false, false, false, false, false};      // (the dynamic part alone is beyond 64 KB)
+#define LAUNCH_SAC_ROLLOUT(K0, K1)                                                                                              \
+    do {                                                                                                                        \
+        if (!attr[K0 * 3 + K1]) {                                                                                               \
+            int rc = erl_hip_status(hipFuncSetAttribute((const void *)sac_rollout_synenv_kernel<K0, K1>,                        \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),            \
+                                    "hipFuncSetAttribute(sac_rollout_synenv_kernel)");                                          \
+            if (rc) return rc;                                                                                                  \
+            attr[K0 * 3 + K1] = true;                                                                                           \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((sac_rollout_synenv_kernel<K0, K1>), grid, blk, lds_bytes, stream, g);                               \
+    } while (0)
+    FUSED_KT_DISPATCH(LAUNCH_SAC_ROLLOUT)
+#undef LAUNCH_SAC_ROLLOUT
+    return erl_hip_status(hipGetLastError(), "erl_sac_rollout_synenv_f32");
 }

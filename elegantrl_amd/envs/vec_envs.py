@@ -126,6 +126,23 @@ class SynVecEnv(_GpuVecEnv):
             *_epilogue_args(epilogue), _hip.stream_ptr()), "erl_rollout_synenv_f32")
 
 
+    def fused_rollout_offpolicy(self, agent, horizon_len: int, noise, bufs, last_state_out) -> None:
+        """all `horizon_len` steps of the off-policy AgentBase._explore_vec_env in ONE launch (erl_sac_rollout_synenv_f32): `bufs` = (states,
+        actions, rewards, undones, unmasks) time-major, written in place (rewards scaled, flags inverted); `last_state_out` (N, S) or None:
+        the agent's own copy of the final state; the env's state / counters advance."""
+        from .. import _hip
+        self.state_epoch += 1
+        p, f32 = _hip.ptr, th.float32
+        states, actions, rewards, undones, unmasks = bufs
+        spec = agent._spec
+        _hip.check(_hip.lib().erl_sac_rollout_synenv_f32(
+            p(agent._actor_flat, f32), spec.S, spec.A, spec._c, len(spec.hidden), p(self.state, f32), p(self.Ws, f32), p(self.Wa, f32),
+            p(self.step_count, th.int32), p(self.episode, th.int32), self.max_step, self.seed & (2 ** 64 - 1), self.num_envs, horizon_len,
+            p(noise, f32), agent.rng_seed & (2 ** 64 - 1), agent.rng_counter & (2 ** 64 - 1), float(agent.reward_scale), p(states, f32),
+            p(actions, f32), p(rewards, f32), _hip.flag_ptr(undones), _hip.flag_ptr(unmasks),
+            p(last_state_out, f32) if last_state_out is not None else None, _hip.stream_ptr()), "erl_sac_rollout_synenv_f32")
+
+
 class PendulumVecEnv(_GpuVecEnv):
     """Pendulum-v1 (g=10, m=l=1, dt=0.05, 200-step truncation) behind the reference wrapper's scaling
     (elegantrl/envs/CustomGymEnv.py:42-44: torque = 2*action, reward = 0.5*gym reward)."""

@@ -522,6 +522,19 @@ ERL_API int erl_sac_update_f32(float *actor_params, float *critic_params, float 
                        float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam,
                        float max_norm, int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes,
                        void *stream);
+/* The off-policy rollout of AgentBase._explore_vec_env (elegantrl/agents/AgentBase.py:130-170) on the device-resident SynVecEnv as ONE
+ * launch: H x [ActorSAC.get_action (AgentSAC.py:179-185), states[t] = state, actions[t] = action, env.step, reward / flag stores], then
+ * `rewards *= reward_scale` and the two logical_not -- out_undones / out_unmasks are !terminal / !truncate.  A 16-env tile per workgroup
+ * for all H steps, the actor's weights in registers / LDS for the whole rollout; per step the arithmetic of erl_sac_explore_action_f32
+ * followed by erl_synenv_step_f32, so the five tensors, the final state and the env's counters are bit-identical to the per-step loop
+ * under the same Philox keys (seed, counter0 + t, env, action-dim) / injected noise (H, N, A).  out_last_state (N, S) may be NULL.
+ * Needs erl_sac_rollout_synenv_supported(...) (the fused SAC step's dims, N <= 4096).  ABI 16. */
+ERL_API int erl_sac_rollout_synenv_supported(int S, int A, const int *hidden, int n_hidden, int64_t N);
+ERL_API int erl_sac_rollout_synenv_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden, float *env_state,
+                               const float *Ws, const float *Wa, int32_t *step_count, int32_t *episode, int max_step,
+                               uint64_t env_seed, int64_t N, int64_t H, const float *noise, uint64_t seed, uint64_t counter0,
+                               float reward_scale, float *out_states, float *out_actions, float *out_rewards,
+                               uint8_t *out_undones, uint8_t *out_unmasks, float *out_last_state, void *stream);
 ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
                                float *action_out, float *state_out, void *workspace, int64_t workspace_bytes, void *stream);

@@ -318,7 +318,7 @@ def test_sac_rollout_rows_written_by_the_explore_launch(net, N):
 
     def run(rows: bool):
         args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 5, "state_dim": S, "action_dim": A, "if_discrete": False})
-        args.net_dims, args.random_seed = list(net), 3
+        args.net_dims, args.random_seed, args.fused_rollout = list(net), 3, False        # (the per-step loop is what is under test)
         th.manual_seed(5)
         agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
         if not rows:                                            # the signature without the row arguments: the loop copies
@@ -367,3 +367,52 @@ def test_sac_update_net_draws_its_sample_ids_ahead_from_the_same_distribution():
         ids0 = th.cat([s[1] for s in seen]).cpu().numpy()
         ids1 = th.cat([s[2] for s in seen]).cpu().numpy()
         assert ids0.min() >= 0 and ids0.max() <= buf.cur_size - 2 and ids1.min() >= 0 and ids1.max() <= N - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,S,A,net,max_step,H,scale", [(64, 11, 3, (256, 256), 5, 9, 1.0), (50, 17, 6, (64, 48), 4, 7, 0.25),
+                                                        (100, 56, 8, (128, 256), 1000, 6, 2.0), (16, 3, 1, (256, 64), 3, 12, 1.0)])
+@pytest.mark.parametrize("inject", [True, False], ids=["injected-noise", "philox"])
+def test_sac_persistent_rollout_is_bit_identical_to_the_per_step_loop(N, S, A, net, max_step, H, scale, inject):
+    """erl_sac_rollout_synenv_f32 (one launch per explore_env) against the loop it replaces (explore launch + env launch per step,
+    AgentBase.py:130-170): states, actions, rewards, undones, unmasks, the final state and the env's counters, over two consecutive
+    rollouts (state / counters / rng counter carry over), with resets (max_step < H), N not a multiple of the 16-env tile, reward scaling."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config
+
+    def make(fused):
+        args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": max_step, "state_dim": S, "action_dim": A,
+                                            "if_discrete": False})
+        args.net_dims, args.random_seed, args.reward_scale, args.fused_rollout = list(net), 3, scale, fused
+        th.manual_seed(5)
+        agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+        env = SynVecEnv(N, S, A, max_step=max_step, gpu_id=0, seed=1)
+        agent.last_state = env.reset()[0]
+        return agent, env
+    (fa, fe), (pa, pe) = make(True), make(False)
+    assert th.equal(fa._actor_flat, pa._actor_flat) and th.equal(fe.state, pe.state)
+    launches = []
+    inner = fe.fused_rollout_offpolicy
+    fe.fused_rollout_offpolicy = lambda *a, **k: (launches.append(1), inner(*a, **k))[1]
+    g = th.Generator(device="cuda:0").manual_seed(2)
+    for it in range(2):
+        noise = th.randn((H, N, A), device="cuda:0", generator=g) if inject else None
+        f_items = fa._explore_vec_env(fe, H, noise=noise)
+        p_items = pa._explore_vec_env(pe, H, noise=noise)
+        assert len(launches) == it + 1                                        # the one-launch path really ran on one side only
+        for name, x, y in zip(("states", "actions", "rewards", "undones", "unmasks"), f_items, p_items):
+            assert x.dtype == y.dtype and x.shape == y.shape, name
+            assert th.equal(x, y), f"{name} differs at rollout {it}: {(x != y).sum().item()} elements"
+        assert th.equal(fa.last_state, pa.last_state) and th.equal(fe.state, pe.state)
+        assert th.equal(fe.step_count, pe.step_count) and th.equal(fe.episode, pe.episode)
+        assert fa.rng_counter == pa.rng_counter
+        if max_step < H:
+            assert (~f_items[4]).any(), "the case is meant to contain truncations"
+    # somebody moves the env between two rollouts: the agent's last_state wins (it is copied into the env's live buffer), as in the loop
+    fe.state.add_(1.0)
+    fe.state_epoch += 1
+    pe.state.add_(1.0)
+    pe.state_epoch += 1
+    f_items, p_items = fa._explore_vec_env(fe, 3), pa._explore_vec_env(pe, 3)
+    assert th.equal(f_items[1][0], p_items[1][0])                             # the first actions come from the agent's last_state either way
