@@ -281,8 +281,8 @@ __device__ __forceinline__ void layer_small_load(const float *__restrict__ W, in
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                                   // K <= 256: k-tiles wave and wave + 8 (zero weights beyond K)
         const int kt = L.wave + FWV * u;
-        if (!TRANSPOSED) {
-            const float4 v = ldw4_raw<VEC>(W, L.l15, N, K, 16 * kt + 4 * L.q);
+        if (!TRANSPOSED) {         // rows `ldw` floats apart (0: K), K columns of each used
+            const float4 v = ldw4_raw<VEC>(W + (size_t)min(L.l15, N - 1) * (size_t)(ldw ? ldw : K), 0, 1, K, 16 * kt + 4 * L.q);
             w.v[u][0] = v.x; w.v[u][1] = v.y; w.v[u][2] = v.z; w.v[u][3] = v.w;
         } else {
 #pragma unroll
@@ -363,6 +363,13 @@ struct ActorFwdArgs {
     FusedDims d;
     const float *X;                // (B, S) sampled state rows
     float *Xcopy;                  // not NULL: the rows are also written here (the off-policy rollout's states[t] = state)
+    // Feature split of the second layer (a call that keeps nothing for a backward pass): grid.y = split, workgroup (tile, s) owns hidden
+    // features [s d.h1, (s + 1) d.h1) -- d.h1 is the slice's width, h1_full the layer's: 64 KB of W2 instead of 256 KB through one CU -- and
+    // leaves its share of the head's output (a sum over the slice: bias from slice 0) in Ypart[s][b][2 A].  The workgroups of a tile count
+    // their arrivals in arrive[tile]; the LAST one adds the shares in slice order, samples, and re-arms the counter: nobody waits.
+    int split, h1_full;
+    float *Ypart;
+    unsigned *arrive;
     const float *noise;            // (B, A) or NULL: Philox keyed by (seed, counter, row, a)
     uint64_t seed, counter;
     float *act_t, *lp;             // (B, A), (B,)
@@ -380,19 +387,21 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
     const FusedDims &d = g.d;
     const int64_t row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
     const bool valid = row < d.B;
-    if (g.alpha0 && blockIdx.x == 0 && L.tid == 0) g.alpha0[0] = g.alpha_log[0];
+    const int64_t fo = (int64_t)blockIdx.y * d.h1;                   // first second-layer feature of this workgroup's slice (0 unsplit)
+    const int h1f = g.split > 1 ? g.h1_full : d.h1;
+    if (g.alpha0 && blockIdx.x == 0 && blockIdx.y == 0 && L.tid == 0) g.alpha0[0] = g.alpha_log[0];
     FPROF(0, 0);
     // every weight this wave will use, requested before anything else
     FwdW<4, WClass<C0>::NU> w1;
     FwdW<WClass<C0>::KT, WClass<C1>::NU> w2;
     SmallW wh;
     layer_fwd_load<4, WClass<C0>::NU, false>(g.P + d.aW1, d.S, d.h0, L, w1);
-    layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(g.P + d.aW2, d.h0, d.h1, L, w2);
-    layer_small_load<false, true>(g.P + d.aWh, d.h1, 2 * d.A, 0, 0, L, wh);
+    layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(g.P + d.aW2 + fo * d.h0, d.h0, d.h1, L, w2);
+    layer_small_load<false, true>(g.P + d.aWh + fo, d.h1, 2 * d.A, h1f, 0, L, wh);
     clear_images(lds.T0, lds.T1, L);
     lds_barrier();
     FPROF(0, 1);
-    load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, g.Xcopy, L);
+    load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, blockIdx.y == 0 ? g.Xcopy : nullptr, L);
     lds_barrier();
     FPROF(0, 2);
     f32x4 z[2], gk[2];
@@ -401,13 +410,45 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
     emit_hidden(z, d.h0, true, lds.T1, gk, g.H0, g.G0, row, valid, L);
     lds_barrier();
     FPROF(0, 4);
-    layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w2, g.P + d.ab2, d.h0, d.h1, lds.T1, L, z);
+    layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w2, g.P + d.ab2 + fo, d.h0, d.h1, lds.T1, L, z);
     FPROF(0, 5);
     emit_hidden(z, d.h1, true, lds.T0, gk, g.H1, g.G1, row, valid, L);
     lds_barrier();
     FPROF(0, 6);
-    layer_small_mma<false, true>(wh, g.P + d.abh, d.h1, 2 * d.A, lds.T0, lds.part, lds.Yl, L);
+    layer_small_mma<false, true>(wh, fo == 0 ? g.P + d.abh : nullptr, d.h1, 2 * d.A, lds.T0, lds.part, lds.Yl, L);
     FPROF(0, 7);
+    if (g.split > 1) {
+        // this slice's share of the head output goes to memory past the (per-XCD) L2; the last of the tile's workgroups to arrive adds the
+        // shares in slice order -- the sum every order of arrival gives -- into Yl and carries on as the unsplit kernel does
+        __shared__ int s_last;
+        const int A2 = 2 * d.A;
+        if (L.tid < TS * 16) {
+            const int s_ = L.tid >> 4, f = L.tid & 15;
+            if (f < A2 && row0 + s_ < d.B)
+                __hip_atomic_store(g.Ypart + ((size_t)blockIdx.y * d.B + row0 + s_) * A2 + f, lds.Yl[s_ * 16 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (L.tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(g.arrive + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)g.split - 1u;
+            if (s_last) __hip_atomic_store(g.arrive + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (L.tid < TS * 16) {
+            const int s_ = L.tid >> 4, f = L.tid & 15;
+            float y = 0.f;
+            if (f < A2 && row0 + s_ < d.B) {
+                y = __hip_atomic_load(g.Ypart + ((size_t)0 * d.B + row0 + s_) * A2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 1; k < g.split; ++k)
+                    y += __hip_atomic_load(g.Ypart + ((size_t)k * d.B + row0 + s_) * A2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lds.Yl[s_ * 16 + f] = y;
+        }
+        lds_barrier();
+    }
     if (L.tid < TS) {
         const int64_t b = row0 + L.tid;
         if (b < d.B) {
@@ -871,6 +912,7 @@ struct SacSide {
     hipStream_t owner = nullptr;          // the caller's stream this side stream serves
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    unsigned *arrive = nullptr;           // [256] arrival counters of the split actor forward (zero between launches), owned by this slot
 };
 SacSide g_sac_side[16];
 
@@ -892,6 +934,9 @@ SacSide *sac_side_stream(hipStream_t owner)
             q.stream = nullptr;
             return nullptr;
         }
+        void *cnt = nullptr;
+        if (hipMalloc(&cnt, 256 * sizeof(unsigned)) == hipSuccess && hipMemset(cnt, 0, 256 * sizeof(unsigned)) == hipSuccess) q.arrive = (unsigned *)cnt;
+        else (void)hipGetLastError();          // (no counters: the actor's forward stays unsplit)
         q.device = dev;
         q.owner = owner;
         return &q;
@@ -1147,6 +1192,7 @@ int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, 
     f += r((int64_t)kCritSplit * E * B * A) + r(B * h1) + r(B * h0);     // dAct | dZ2, dZ1 (actor)
     f += r(Pa) + r(Pc) + r((int64_t)kCritSplit * E * tiles) + r(tiles) + 64;   // gradients, partial sums, alpha0
     f += 2 * 2 * kDwMaxParts;                                           // the squared-norm pieces of the two dw_table launches (doubles)
+    f += r((int64_t)kCritSplit * B * 2 * A);                            // the slices' shares of the actor's head output
     return f;
 }
 
@@ -1204,6 +1250,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     float *g_actor = take(Pa), *g_critic = take(Pc), *qpart = take((int64_t)kCritSplit * E * tiles), *tdpart = take(tiles), *alpha0 = take(64);
     float *act_pg = take(B * A);                        // (its own buffer: the policy-gradient sample runs next to the critic update)
     double *nparts_c = reinterpret_cast<double *>(take(2 * kDwMaxParts)), *nparts_a = reinterpret_cast<double *>(take(2 * kDwMaxParts));
+    float *ypart = take((int64_t)kCritSplit * B * 2 * A);      // the slices' shares of the actor's head output (launch (1))
     float *q_pg = qt;                                   // reused once its first contents are consumed
     const dim3 tgrid(tiles), cgrid(tiles, E), blk(FT);
     int rc;
@@ -1214,11 +1261,24 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     af.act_t = a_next; af.lp = lp_next; af.alpha_log = alpha_log; af.alpha0 = alpha0;
     hipStream_t sa = s;                                 // the stream the actor-forward launches go to
 #define LAUNCH_ACTOR_FWD(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, sa, af)
-    FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
+    SacSide *side = sac_side_stream(s);
+    static const bool split_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 0); }();
+    static const bool asplit_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 2); }();      // (2: the critic passes only)
+    if (split_on && asplit_on && side && side->arrive && h1 == 64 * kCritSplit && tiles * kCritSplit <= 256) {
+        // (nothing of this pass is kept for a backward pass: a 256-wide second layer is split over kCritSplit workgroups per tile, the last
+        // of them to arrive finishes the head -- ActorFwdArgs::split)
+        ActorFwdArgs sp = af;
+        sp.split = kCritSplit; sp.h1_full = h1; sp.d.h1 = h1 / kCritSplit; sp.Ypart = ypart; sp.arrive = side->arrive;
+        const dim3 sgrid(tiles, kCritSplit);
+#define LAUNCH_ACTOR_SPLIT(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), sgrid, blk, 0, sa, sp)
+        FUSED_KT_DISPATCH_D(sp.d, LAUNCH_ACTOR_SPLIT)
+#undef LAUNCH_ACTOR_SPLIT
+    } else {
+        FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
+    }
     // ---- (6) policy-gradient sample (actor on state, kept for the backward pass) and temperature step              (:72-79)
     // FORKED here onto the side stream: they read the actor, `state` and alpha_log only -- the temperature BEFORE its update
     // is already parked in alpha0 by launch (1) -- and run next to the critic update (2)-(5); joined before (7).
-    SacSide *side = sac_side_stream(s);
     SacJoin joiner{side, s};
     if (side) {
         if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
@@ -1244,7 +1304,6 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     // (the passes whose backward does not need q -- (2) and (7) -- split every 256-wide decoder over kCritSplit workgroups while the
     // launch stays within the chip: 16 tiles x 4 decoders x 4 slices = 256 workgroups at B = 256, each streaming 64 KB of W1 instead of
     // 256 KB through one CU's ~30 GB/s; ERL_SAC_SPLIT=0 turns it off)
-    static const bool split_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 0); }();
     const int split = (split_on && h1 == 64 * kCritSplit && (int64_t)tiles * E * kCritSplit <= 256) ? kCritSplit : 1;
     FusedDims dsl = d;
     dsl.h1 = h1 / split;
