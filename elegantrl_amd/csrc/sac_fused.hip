@@ -220,22 +220,24 @@ struct BwdW {
     float v[NU][KT_][4];
 };
 
+// (`ld`: the rows of W are ld floats apart and Kin of their columns, from W on, are used -- a slice of the input features; 0: ld = Kin)
 template <int KT_, int NU>
-__device__ __forceinline__ void layer_bwd_load(const float *__restrict__ W, int Kz, int Kin, const LaneId &L, BwdW<KT_, NU> &w)
+__device__ __forceinline__ void layer_bwd_load(const float *__restrict__ W, int Kz, int Kin, const LaneId &L, BwdW<KT_, NU> &w, int ld = 0)
 {
+    if (ld == 0) ld = Kin;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int colc = min(16 * (L.wave + FWV * u) + L.l15, Kin - 1);
         if (KT_ == 1) {                                             // Kz <= 16, any value (the policy head's 2 A rows)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w.v[u][0][j] = W[(size_t)min(4 * L.q + j, Kz - 1) * Kin + colc];
+            for (int j = 0; j < 4; ++j) w.v[u][0][j] = W[(size_t)min(4 * L.q + j, Kz - 1) * ld + colc];
         } else {                                                    // Kz a multiple of 16: one per-lane offset, wave-uniform row offsets
             const int KTr = Kz >> 4;
-            const uint32_t voff = (uint32_t)(4 * L.q) * (uint32_t)Kin + (uint32_t)colc;
+            const uint32_t voff = (uint32_t)(4 * L.q) * (uint32_t)ld + (uint32_t)colc;
 #pragma unroll
             for (int kt = 0; kt < KT_; ++kt) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w.v[u][kt][j] = (W + (size_t)(16 * min(kt, KTr - 1) + j) * Kin)[voff];
+                for (int j = 0; j < 4; ++j) w.v[u][kt][j] = (W + (size_t)(16 * min(kt, KTr - 1) + j) * ld)[voff];
             }
         }
     }
@@ -660,6 +662,10 @@ struct ActorBwdArgs {
     const float *tdpart, *qpart;
     int ntiles;
     int nsplit;                              // dAct / qpart hold E * nsplit partial results (critic_tile_kernel's feature split)
+    // Feature split of the last step, dH0 = W2^T dZ2 (output-split: no exchange): grid.y = split, workgroup (tile, s) owns first-layer
+    // features [s d.h0, (s + 1) d.h0) -- d.h0 is the slice's width, h0_full the layer's -- i.e. 64 of W2's 256 columns; everything before it
+    // (head backward, dZ2) is small and done by every slice, stored by slice 0.
+    int split, h0_full;
     float *objs_out;
 };
 
@@ -672,7 +678,10 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
     const int A = d.A, E = d.E;
     const int64_t B = d.B, row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
     const bool valid = row < B;
-    if (blockIdx.x == 0) {                                         // the logged objectives (AgentSAC.py:86)
+    const int64_t fo = (int64_t)blockIdx.y * d.h0;                 // first first-layer feature of this workgroup's slice (0 unsplit)
+    const int h0f = g.split > 1 ? g.h0_full : d.h0;
+    const bool s0 = blockIdx.y == 0;
+    if (blockIdx.x == 0 && s0) {                                   // the logged objectives (AgentSAC.py:86)
         float sl = 0.f, sqp = 0.f;
         for (int64_t i = L.tid; i < B; i += FT) sl += g.lp_cur[i];
         for (int k = L.tid; k < E * g.nsplit * g.ntiles; k += FT) sqp += g.qpart[k];      // (one thread walking the table: a load latency per entry)
@@ -719,13 +728,15 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
                 const float dls = inside ? du * sd * g.eps[b * A + a] - dlp : 0.f;
                 lds.T0[L.tid * LDT + a] = du;
                 lds.T0[L.tid * LDT + A + a] = dls;
-                g.dY[b * 2 * A + a] = du;
-                g.dY[b * 2 * A + A + a] = dls;
+                if (s0) {
+                    g.dY[b * 2 * A + a] = du;
+                    g.dY[b * 2 * A + A + a] = dls;
+                }
             }
         }
     }
     lds_barrier();
-    layer_bwd_load<WClass<C1>::KT, WClass<C0>::NU>(g.P + d.aW2, d.h1, d.h0, L, wb2);   // (lands under the head layer and its gate)
+    layer_bwd_load<WClass<C1>::KT, WClass<C0>::NU>(g.P + d.aW2 + fo, d.h1, d.h0, L, wb2, h0f);   // (lands under the head layer and its gate)
     f32x4 dx[2];
     layer_bwd_mma<1, WClass<C1>::NU>(wbh, 2 * A, d.h1, lds.T0, L, dx);        // dH1 = Wh^T dY
     {
@@ -739,7 +750,7 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
             if (valid && f < d.h1) gate = *reinterpret_cast<const float4 *>(g.G1 + row * d.h1 + f);
             const float4 v = make_float4(dx[u][0] * gate.x, dx[u][1] * gate.y, dx[u][2] * gate.z, dx[u][3] * gate.w);
             *reinterpret_cast<float4 *>(lds.T1 + L.l15 * LDT + f) = v;
-            if (valid && f < d.h1) *reinterpret_cast<float4 *>(g.dZ2 + row * d.h1 + f) = v;
+            if (s0 && valid && f < d.h1) *reinterpret_cast<float4 *>(g.dZ2 + row * d.h1 + f) = v;
         }
     }
     lds_barrier();
@@ -752,8 +763,8 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
             if (it >= NT) continue;
             const int f = 16 * it + 4 * L.q;
             if (valid && f < d.h0) {
-                const float4 gate = *reinterpret_cast<const float4 *>(g.G0 + row * d.h0 + f);
-                *reinterpret_cast<float4 *>(g.dZ1 + row * d.h0 + f) =
+                const float4 gate = *reinterpret_cast<const float4 *>(g.G0 + row * h0f + fo + f);
+                *reinterpret_cast<float4 *>(g.dZ1 + row * h0f + fo + f) =
                     make_float4(dx[u][0] * gate.x, dx[u][1] * gate.y, dx[u][2] * gate.z, dx[u][3] * gate.w);
             }
         }
@@ -1353,8 +1364,13 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
         ab.P = actor_params; ab.d = d; ab.Y = Y; ab.act_t = act_pg; ab.eps = eps_used; ab.dAct = dAct; ab.alpha_log = alpha_log; ab.G0 = G0;
         ab.G1 = G1; ab.lp_cur = lp_cur; ab.dY = dY; ab.dZ2 = dZ2; ab.dZ1 = dZ1; ab.tdpart = tdpart; ab.qpart = qpart; ab.ntiles = tiles; ab.nsplit = split;
         ab.objs_out = objs_out;
-#define LAUNCH_ACTOR_BWD(K0, K1) hipLaunchKernelGGL((actor_bwd_kernel<K0, K1>), tgrid, blk, 0, s, ab)
-        FUSED_KT_DISPATCH(LAUNCH_ACTOR_BWD)
+        // (the one heavy layer of this pass, dH0 = W2^T dZ2, is output-split over kCritSplit workgroups per tile like the critic passes above)
+        static const bool bsplit_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && (atoi(e) == 2 || atoi(e) == 3)); }();   // (3: all but this one)
+        const int bsplit = (split_on && bsplit_on && h0 == 64 * kCritSplit && tiles * kCritSplit <= 256) ? kCritSplit : 1;
+        ab.split = bsplit; ab.h0_full = h0; ab.d.h0 = h0 / bsplit;
+        const dim3 bgrid(tiles, bsplit);
+#define LAUNCH_ACTOR_BWD(K0, K1) hipLaunchKernelGGL((actor_bwd_kernel<K0, K1>), bgrid, blk, 0, s, ab)
+        FUSED_KT_DISPATCH_D(ab.d, LAUNCH_ACTOR_BWD)
         DwArgs dw{};
         dw.B = B;
         dw_add(dw, dZ1, 0, 1, h0, state, S, g_actor + d.aW1, g_actor + d.ab1);
