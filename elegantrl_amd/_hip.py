@@ -126,6 +126,8 @@ _SIGNATURES = {
     "erl_sac_rollout_synenv_supported": (c_int, [c_int, c_int, POINTER(c_int), c_int, c_int64]),
     "erl_sac_rollout_synenv_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, _P, _P, _P, _P, c_int, c_uint64, c_int64, c_int64, _P,
                                            c_uint64, c_uint64, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "erl_sac_rollout_pendulum_f32": (c_int, [_P, POINTER(c_int), c_int, _P, _P, _P, _P, c_int, c_uint64, c_int64, c_int64, _P, c_uint64, c_uint64,
+                                             c_float, _P, _P, _P, _P, _P, _P, _P]),
     "erl_k6_timing_enable": (None, [c_int]),
     "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_read2": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),

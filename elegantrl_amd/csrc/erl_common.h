@@ -55,7 +55,7 @@ int erl_clip_adam_parts_soft_f32(float *params, const float *grads, float *exp_a
                                  hipStream_t stream);
 bool erl_sac_fused_supported(int S, int A, const int *hidden, int n_hidden, int E, int64_t B);
 int erl_sac_rollout_fused(const float *actor_params, int S, int A, int h0, int h1, const int64_t *aoff, float *env_state, const float *Ws,
-                          const float *Wa, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N, int64_t H,
+                          const float *Wa, float *phys, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N, int64_t H,
                           const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states, float *out_actions,
                           float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks, float *out_last_state, hipStream_t stream);
 int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, int64_t Pa, int64_t Pc);

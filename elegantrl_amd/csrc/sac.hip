@@ -554,8 +554,28 @@ extern "C" int erl_sac_rollout_synenv_f32(const float *actor_params, int S, int 
     SacDims d;
     ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, 1, &d), "erl_sac_rollout_synenv_f32: unsupported dims");
     const int64_t aoff[6] = {d.actor.oW[0], d.actor.ob[0], d.actor.oW[1], d.actor.ob[1], d.actor.oW[2], d.actor.ob[2]};
-    return erl_sac_rollout_fused(actor_params, S, A, hidden[0], hidden[1], aoff, env_state, Ws, Wa, step_count, episode, max_step, env_seed, N, H,
-                                 noise, seed, counter0, reward_scale, out_states, out_actions, out_rewards, out_undones, out_unmasks,
+    return erl_sac_rollout_fused(actor_params, S, A, hidden[0], hidden[1], aoff, env_state, Ws, Wa, nullptr, step_count, episode, max_step, env_seed,
+                                 N, H, noise, seed, counter0, reward_scale, out_states, out_actions, out_rewards, out_undones, out_unmasks,
+                                 out_last_state, (hipStream_t)stream);
+}
+
+// the same loop on the device-resident PendulumVecEnv (S = 3, A = 1; phys: (N, 2) theta, theta_dot; obs: (N, 3) the live observation)
+extern "C" int erl_sac_rollout_pendulum_f32(const float *actor_params, const int *hidden, int n_hidden, float *phys, float *obs,
+                                            int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N, int64_t H,
+                                            const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states,
+                                            float *out_actions, float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks,
+                                            float *out_last_state, void *stream)
+{
+    ERL_REQUIRE(actor_params && phys && obs && step_count && episode && out_states && out_actions && out_rewards && out_undones && out_unmasks,
+                "erl_sac_rollout_pendulum_f32: NULL tensor");
+    ERL_REQUIRE(erl_sac_rollout_synenv_supported(3, 1, hidden, n_hidden, N), "erl_sac_rollout_pendulum_f32: unsupported dims N=%lld (two hidden "
+                "layers <= 256 wide in steps of 16, N <= 4096; ERL_SAC_FUSED=0 turns it off)", (long long)N);
+    ERL_REQUIRE(H >= 1 && H < (1LL << 30) && max_step >= 1, "erl_sac_rollout_pendulum_f32: bad H=%lld max_step=%d", (long long)H, max_step);
+    SacDims d;
+    ERL_REQUIRE(make_sac_dims(3, 1, hidden, n_hidden, 1, &d), "erl_sac_rollout_pendulum_f32: unsupported dims");
+    const int64_t aoff[6] = {d.actor.oW[0], d.actor.ob[0], d.actor.oW[1], d.actor.ob[1], d.actor.oW[2], d.actor.ob[2]};
+    return erl_sac_rollout_fused(actor_params, 3, 1, hidden[0], hidden[1], aoff, obs, nullptr, nullptr, phys, step_count, episode, max_step, env_seed,
+                                 N, H, noise, seed, counter0, reward_scale, out_states, out_actions, out_rewards, out_undones, out_unmasks,
                                  out_last_state, (hipStream_t)stream);
 }
 

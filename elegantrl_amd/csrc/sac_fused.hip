@@ -993,8 +993,9 @@ struct SacRolloutArgs {
     float *o_states, *o_actions, *o_rewards;       // (H, N, S), (H, N, A), (H, N)
     uint8_t *o_undones, *o_unmasks;                // (H, N): !terminal, !truncate
     float *o_last_state;                           // (N, S) or NULL
-    float *env_state;                              // (N, S) live state
-    const float *Ws, *Wa;
+    float *env_state;                              // (N, S) live state (PendulumVecEnv: the observation cos, sin, theta_dot)
+    const float *Ws, *Wa;                          // SynVecEnv
+    float *phys;                                   // PendulumVecEnv: (N, 2) theta, theta_dot
     int32_t *step_count, *episode;
     int max_step;
     uint64_t env_seed;
@@ -1005,7 +1006,9 @@ constexpr int SR_XLD = 68, SR_WLD = 68;
 constexpr int SR_O_XS = 0, SR_O_WST = SR_O_XS + 16 * SR_XLD, SR_O_WAT = SR_O_WST + 64 * SR_WLD, SR_O_ACT = SR_O_WAT + 64 * 16;
 constexpr int SR_O_RED = SR_O_ACT + 16 * 16, SR_O_W1L = SR_O_RED + 8 * 16 * 2, SR_O_BIA = SR_O_W1L + FMAXW * SR_WLD, SR_FLOATS = SR_O_BIA + 3 * FMAXW;
 
-template <int C0, int C1>
+enum { SR_ENV_SYN = 0, SR_ENV_PENDULUM = 1 };
+
+template <int C0, int C1, int ENV>
 __global__ __launch_bounds__(FT) void sac_rollout_synenv_kernel(SacRolloutArgs g)
 {
     __shared__ TileLds lds;
@@ -1029,13 +1032,15 @@ __global__ __launch_bounds__(FT) void sac_rollout_synenv_kernel(SacRolloutArgs g
         const int64_t r_ = min(row0 + i, N - 1);
         XS[i * SR_XLD + k] = (k < S) ? g.env_state[r_ * S + min(k, S - 1)] : 0.f;
     }
-    for (int e = L.tid; e < 64 * 64; e += FT) {            // WST[j][k] = Ws[k][j]
-        const int k = e >> 6, jj = e & 63;
-        WST[jj * SR_WLD + k] = (k < S && jj < S) ? g.Ws[(size_t)min(k, S - 1) * S + min(jj, S - 1)] : 0.f;
-    }
-    for (int e = L.tid; e < 16 * 64; e += FT) {
-        const int k = e >> 6, jj = e & 63;
-        WAT[jj * 16 + k] = (k < A && jj < S) ? g.Wa[(size_t)min(k, A - 1) * S + min(jj, S - 1)] : 0.f;
+    if (ENV == SR_ENV_SYN) {
+        for (int e = L.tid; e < 64 * 64; e += FT) {        // WST[j][k] = Ws[k][j]
+            const int k = e >> 6, jj = e & 63;
+            WST[jj * SR_WLD + k] = (k < S && jj < S) ? g.Ws[(size_t)min(k, S - 1) * S + min(jj, S - 1)] : 0.f;
+        }
+        for (int e = L.tid; e < 16 * 64; e += FT) {
+            const int k = e >> 6, jj = e & 63;
+            WAT[jj * 16 + k] = (k < A && jj < S) ? g.Wa[(size_t)min(k, A - 1) * S + min(jj, S - 1)] : 0.f;
+        }
     }
     if (L.tid < 16 * 16) ACT[L.tid] = 0.f;
     for (int e = L.tid; e < FMAXW * 64; e += FT) {         // W1L[row][k] = W1[row][k], zero beyond (h0, S)
@@ -1049,6 +1054,11 @@ __global__ __launch_bounds__(FT) void sac_rollout_synenv_kernel(SacRolloutArgs g
     }
     const float *wst_row = WST + ((16 * L.wave + L.l15) & 63) * SR_WLD + 4 * L.q, *wat_row = WAT + ((16 * L.wave + L.l15) & 63) * 16 + 4 * L.q;
     int sc = g.step_count[row], ep = g.episode[row];
+    // Pendulum: thread s < 16 steps env row0 + s by itself (no matrix product, no cross-wave reduction)
+    const int64_t prow = min(row0 + (int64_t)min(L.tid, TS - 1), N - 1);
+    float th = 0.f, thdot = 0.f;
+    int psc = 0, pep = 0;
+    if (ENV == SR_ENV_PENDULUM) { th = g.phys[2 * prow]; thdot = g.phys[2 * prow + 1]; psc = g.step_count[prow]; pep = g.episode[prow]; }
     lds_barrier();
 
     for (int t = 0; t < H; ++t) {
@@ -1087,8 +1097,43 @@ __global__ __launch_bounds__(FT) void sac_rollout_synenv_kernel(SacRolloutArgs g
                 ACT[L.tid * 16 + a] = tv;
                 if (b < N) g.o_actions[((size_t)t * N + b) * A + a] = tv;
             }
+            if (ENV == SR_ENV_PENDULUM) {
+                // Pendulum-v1 behind the reference wrapper's scaling (envs.hip pendulum_step_kernel, operation for operation)
+                const float PI = 3.14159265358979323846f;
+                float u = 2.f * ACT[L.tid * 16];
+                u = fminf(fmaxf(u, -2.f), 2.f);
+                const float two_pi = 2.f * PI;
+                float ang = fmodf(th + PI, two_pi);
+                if (ang < 0.f) ang += two_pi;
+                ang -= PI;
+                const float cost = ang * ang + 0.1f * thdot * thdot + 0.001f * u * u;
+                float nthdot = thdot + (3.f * 10.f / 2.f * sinf(th) + 3.f * u) * 0.05f;
+                nthdot = fminf(fmaxf(nthdot, -8.f), 8.f);
+                float nth = th + nthdot * 0.05f;
+                const int sc1 = psc + 1;
+                const bool trunc = sc1 >= g.max_step;
+                if (trunc) {       // reset: theta ~ U(-pi, pi), theta_dot ~ U(-1, 1)
+                    pep = pep + 1;
+                    const Philox4 p = philox4x32_10((uint32_t)bc, 0u, (uint32_t)pep, 0x50454e44u, (uint32_t)g.env_seed, (uint32_t)(g.env_seed >> 32));
+                    nth = ((float)(p.x >> 8) * (1.f / 16777216.f) * 2.f - 1.f) * PI;
+                    nthdot = (float)(p.y >> 8) * (1.f / 16777216.f) * 2.f - 1.f;
+                }
+                th = nth;
+                thdot = nthdot;
+                psc = trunc ? 0 : sc1;
+                XS[L.tid * SR_XLD + 0] = cosf(nth);
+                XS[L.tid * SR_XLD + 1] = sinf(nth);
+                XS[L.tid * SR_XLD + 2] = nthdot;
+                if (b < N) {
+                    const float rew = -0.5f * cost;
+                    g.o_rewards[(size_t)t * N + b] = g.reward_scale == 1.0f ? rew : rew * g.reward_scale;
+                    g.o_undones[(size_t)t * N + b] = 1;
+                    g.o_unmasks[(size_t)t * N + b] = trunc ? 0 : 1;
+                }
+            }
         }
         lds_barrier();
+        if (ENV == SR_ENV_PENDULUM) continue;              // (the new state tile is in place: the barrier above publishes it)
         // ---- env.step on the matrix cores: s' = s Ws + a Wa, wave w < ns owns features 16 w .. 16 w + 15 (envs.hip synenv_tile_kernel)
         float out[4] = {0.f, 0.f, 0.f, 0.f}, a2 = 0.f;
         const int j0 = 16 * L.wave + 4 * L.q;
@@ -1164,9 +1209,16 @@ __global__ __launch_bounds__(FT) void sac_rollout_synenv_kernel(SacRolloutArgs g
             if (g.o_last_state) g.o_last_state[(row0 + i) * S + k] = x;
         }
     }
-    if (L.wave == 0 && L.q == 0 && valid) {
-        g.step_count[row] = sc;
-        g.episode[row] = ep;
+    if (ENV == SR_ENV_SYN) {
+        if (L.wave == 0 && L.q == 0 && valid) {
+            g.step_count[row] = sc;
+            g.episode[row] = ep;
+        }
+    } else if (L.tid < TS && row0 + L.tid < N) {
+        g.step_count[prow] = psc;
+        g.episode[prow] = pep;
+        g.phys[2 * prow] = th;
+        g.phys[2 * prow + 1] = thdot;
     }
 }
 
@@ -1394,7 +1446,7 @@ extern "C" int erl_sac_rollout_synenv_supported(int S, int A, const int *hidden,
 }
 
 int erl_sac_rollout_fused(const float *actor_params, int S, int A, int h0, int h1, const int64_t *aoff, float *env_state, const float *Ws,
-                          const float *Wa, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N, int64_t H,
+                          const float *Wa, float *phys, int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N, int64_t H,
                           const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states, float *out_actions,
                           float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks, float *out_last_state, hipStream_t stream)
 {
@@ -1404,23 +1456,28 @@ int erl_sac_rollout_fused(const float *actor_params, int S, int A, int h0, int h
     SacRolloutArgs g{};
     g.P = actor_params; g.d = d; g.H = (int)H; g.noise = noise; g.seed = seed; g.counter0 = counter0; g.reward_scale = reward_scale;
     g.o_states = out_states; g.o_actions = out_actions; g.o_rewards = out_rewards; g.o_undones = out_undones; g.o_unmasks = out_unmasks;
-    g.o_last_state = out_last_state; g.env_state = env_state; g.Ws = Ws; g.Wa = Wa; g.step_count = step_count; g.episode = episode;
+    g.o_last_state = out_last_state; g.env_state = env_state; g.Ws = Ws; g.Wa = Wa; g.phys = phys; g.step_count = step_count; g.episode = episode;
     g.max_step = max_step; g.env_seed = env_seed;
     const dim3 grid((unsigned)((N + TS - 1) / TS)), blk(FT);
     const size_t lds_bytes = (size_t)SR_FLOATS * sizeof(float);
-    static bool attr[9] = {false, false, false, false, false, false, false, false, false};      // (the dynamic part alone is beyond 64 KB)
-#define LAUNCH_SAC_ROLLOUT(K0, K1)                                                                                              \
+    static bool attr[2][9] = {};                         // (the dynamic part alone is beyond 64 KB)
+#define LAUNCH_SAC_ROLLOUT_E(K0, K1, EV)                                                                                        \
     do {                                                                                                                        \
-        if (!attr[K0 * 3 + K1]) {                                                                                               \
-            int rc = erl_hip_status(hipFuncSetAttribute((const void *)sac_rollout_synenv_kernel<K0, K1>,                        \
+        if (!attr[EV][K0 * 3 + K1]) {                                                                                           \
+            int rc = erl_hip_status(hipFuncSetAttribute((const void *)sac_rollout_synenv_kernel<K0, K1, EV>,                    \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),            \
                                     "hipFuncSetAttribute(sac_rollout_synenv_kernel)");                                          \
             if (rc) return rc;                                                                                                  \
-            attr[K0 * 3 + K1] = true;                                                                                           \
+            attr[EV][K0 * 3 + K1] = true;                                                                                       \
         }                                                                                                                       \
-        hipLaunchKernelGGL((sac_rollout_synenv_kernel<K0, K1>), grid, blk, lds_bytes, stream, g);                               \
+        hipLaunchKernelGGL((sac_rollout_synenv_kernel<K0, K1, EV>), grid, blk, lds_bytes, stream, g);                           \
     } while (0)
-    FUSED_KT_DISPATCH(LAUNCH_SAC_ROLLOUT)
-#undef LAUNCH_SAC_ROLLOUT
+#define LAUNCH_SAC_ROLLOUT_SYN(K0, K1) LAUNCH_SAC_ROLLOUT_E(K0, K1, SR_ENV_SYN)
+#define LAUNCH_SAC_ROLLOUT_PEN(K0, K1) LAUNCH_SAC_ROLLOUT_E(K0, K1, SR_ENV_PENDULUM)
+    if (phys) { FUSED_KT_DISPATCH(LAUNCH_SAC_ROLLOUT_PEN) }
+    else { FUSED_KT_DISPATCH(LAUNCH_SAC_ROLLOUT_SYN) }
+#undef LAUNCH_SAC_ROLLOUT_SYN
+#undef LAUNCH_SAC_ROLLOUT_PEN
+#undef LAUNCH_SAC_ROLLOUT_E
     return erl_hip_status(hipGetLastError(), "erl_sac_rollout_synenv_f32");
 }

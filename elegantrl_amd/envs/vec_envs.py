@@ -184,6 +184,21 @@ class PendulumVecEnv(_GpuVecEnv):
         return step
 
 
+    def fused_rollout_offpolicy(self, agent, horizon_len: int, noise, bufs, last_state_out) -> None:
+        """all `horizon_len` steps of the off-policy AgentBase._explore_vec_env in ONE launch (erl_sac_rollout_pendulum_f32); arguments as
+        SynVecEnv.fused_rollout_offpolicy."""
+        from .. import _hip
+        self.state_epoch += 1
+        p, f32 = _hip.ptr, th.float32
+        states, actions, rewards, undones, unmasks = bufs
+        spec = agent._spec
+        _hip.check(_hip.lib().erl_sac_rollout_pendulum_f32(
+            p(agent._actor_flat, f32), spec._c, len(spec.hidden), p(self.phys, f32), p(self.state, f32), p(self.step_count, th.int32),
+            p(self.episode, th.int32), self.max_step, self.seed & (2 ** 64 - 1), self.num_envs, horizon_len, p(noise, f32),
+            agent.rng_seed & (2 ** 64 - 1), agent.rng_counter & (2 ** 64 - 1), float(agent.reward_scale), p(states, f32), p(actions, f32),
+            p(rewards, f32), _hip.flag_ptr(undones), _hip.flag_ptr(unmasks), p(last_state_out, f32) if last_state_out is not None else None,
+            _hip.stream_ptr()), "erl_sac_rollout_pendulum_f32")
+
     def fused_rollout(self, agent, horizon_len: int, noise, bufs, values, next_value, epilogue=None) -> None:
         """all `horizon_len` steps of AgentPPO._explore_vec_env in ONE launch (erl_rollout_pendulum_f32); `epilogue` as
         SynVecEnv.fused_rollout."""

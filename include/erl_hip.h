@@ -535,6 +535,12 @@ ERL_API int erl_sac_rollout_synenv_f32(const float *actor_params, int S, int A, 
                                uint64_t env_seed, int64_t N, int64_t H, const float *noise, uint64_t seed, uint64_t counter0,
                                float reward_scale, float *out_states, float *out_actions, float *out_rewards,
                                uint8_t *out_undones, uint8_t *out_unmasks, float *out_last_state, void *stream);
+/* ... on the device-resident PendulumVecEnv (S = 3, A = 1; erl_pendulum_step_f32's dynamics, operation for operation) */
+ERL_API int erl_sac_rollout_pendulum_f32(const float *actor_params, const int *hidden, int n_hidden, float *phys, float *obs,
+                                 int32_t *step_count, int32_t *episode, int max_step, uint64_t env_seed, int64_t N, int64_t H,
+                                 const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states,
+                                 float *out_actions, float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks,
+                                 float *out_last_state, void *stream);
 ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
                                float *action_out, float *state_out, void *workspace, int64_t workspace_bytes, void *stream);

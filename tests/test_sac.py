@@ -416,3 +416,41 @@ def test_sac_persistent_rollout_is_bit_identical_to_the_per_step_loop(N, S, A, n
     pe.state_epoch += 1
     f_items, p_items = fa._explore_vec_env(fe, 3), pa._explore_vec_env(pe, 3)
     assert th.equal(f_items[1][0], p_items[1][0])                             # the first actions come from the agent's last_state either way
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,net,max_step,H,scale", [(64, (256, 256), 7, 20, 1.0), (50, (64, 48), 200, 9, 0.5), (4096, (128, 64), 5, 6, 1.0)])
+@pytest.mark.parametrize("inject", [True, False], ids=["injected-noise", "philox"])
+def test_sac_persistent_rollout_on_pendulum_is_bit_identical_to_the_per_step_loop(N, net, max_step, H, scale, inject):
+    """erl_sac_rollout_pendulum_f32 against explore launch + erl_pendulum_step_f32 per step: the five tensors, the final observation, theta /
+    theta_dot and the counters, two consecutive rollouts, truncation resets inside the horizon."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import PendulumVecEnv
+    from elegantrl_amd.train import Config
+
+    def make(fused):
+        args = Config(AgentSAC, PendulumVecEnv, {"env_name": "Pendulum-v1", "num_envs": N, "max_step": max_step, "state_dim": 3, "action_dim": 1,
+                                                 "if_discrete": False})
+        args.net_dims, args.random_seed, args.reward_scale, args.fused_rollout = list(net), 3, scale, fused
+        th.manual_seed(5)
+        agent = AgentSAC(args.net_dims, 3, 1, gpu_id=0, args=args)
+        env = PendulumVecEnv(N, max_step=max_step, gpu_id=0, seed=1)
+        agent.last_state = env.reset()[0]
+        return agent, env
+    (fa, fe), (pa, pe) = make(True), make(False)
+    launches = []
+    inner = fe.fused_rollout_offpolicy
+    fe.fused_rollout_offpolicy = lambda *a, **k: (launches.append(1), inner(*a, **k))[1]
+    g = th.Generator(device="cuda:0").manual_seed(2)
+    for it in range(2):
+        noise = th.randn((H, N, 1), device="cuda:0", generator=g) if inject else None
+        f_items = fa._explore_vec_env(fe, H, noise=noise)
+        p_items = pa._explore_vec_env(pe, H, noise=noise)
+        assert len(launches) == it + 1
+        for name, x, y in zip(("states", "actions", "rewards", "undones", "unmasks"), f_items, p_items):
+            assert x.dtype == y.dtype and x.shape == y.shape, name
+            assert th.equal(x, y), f"{name} differs at rollout {it}: {(x != y).sum().item()} elements"
+        assert th.equal(fa.last_state, pa.last_state) and th.equal(fe.state, pe.state) and th.equal(fe.phys, pe.phys)
+        assert th.equal(fe.step_count, pe.step_count) and th.equal(fe.episode, pe.episode)
+        if max_step < H:
+            assert (~f_items[4]).any()
