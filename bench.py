@@ -338,6 +338,13 @@ def bench_sac(opt):
     th.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t_k9.enabled = False
+    sample_in_step = len(t_k9.pairs) == 0      # (update_net handed ring + ids to the step: the gather rides in the step's first launch)
+    if sample_in_step:                         # the sample kernel at the loop's batch size, on its own, for the roofline object
+        t_k9.enabled = True
+        for _ in range(200):
+            buf.sample(B, reuse=True)
+        th.cuda.synchronize()
+        t_k9.enabled = False
     k9_s = t_k9.mean_seconds()
     bytes_per = (2 * (2 * S + A + 3) * 4 + 8) * B
     # the kernel's capability away from the launch floor: one sample call of 2^20 transitions on the same ring
@@ -365,6 +372,9 @@ def bench_sac(opt):
         "roofline": {"kernel": "replay_sample_kernel", "bound": "hbm", "achieved": round(bytes_per / k9_s / 1e9, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(bytes_per / k9_s / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                      "bytes_per_launch": bytes_per, "avg_launch_us": round(k9_s * 1e6, 2), "launches_timed": len(t_k9.pairs),
+                     "in_loop": not sample_in_step,
+                     "note": ("the loop's sample rides inside the SAC step's first launch (erl_sac_update_ring_f32): the kernel was timed on its own, "
+                              "200 calls at the loop's batch size" if sample_in_step else "timed in the loop"),
                      "at_batch_2^20": {"bytes_per_launch": big_bytes, "us": round(big_s * 1e6, 1),
                                        "achieved": round(big_bytes / big_s / 1e9, 1), "frac": round(big_bytes / big_s / 1e9 / HBM_PEAK_GBPS, 4)}},
         "objectives_last": [round(float(x), 6) for x in objs],

@@ -121,6 +121,8 @@ _SIGNATURES = {
     "erl_sac_workspace_bytes": (c_int64, [c_int, c_int, POINTER(c_int), c_int, c_int, c_int64]),
     "erl_sac_update_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int] + [_P] * 9 + [c_float, c_int64, _P, _P, c_uint64,
                                    c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
+    "erl_sac_update_ring_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int, _P] + [_P] * 6 + [c_int64, _P, _P, c_uint64,
+                                        c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
     "erl_sac_explore_action_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P,
                                            c_int64, _P]),
     "erl_sac_rollout_synenv_supported": (c_int, [c_int, c_int, POINTER(c_int), c_int, c_int64]),

@@ -116,6 +116,9 @@ class AgentSAC(AgentBase):
         self.sample_ids_ahead = bool(getattr(args, "sample_ids_ahead", True))
         # device-resident envs that offer it: the whole off-policy rollout as one launch (False: the per-step loop)
         self.fused_rollout = bool(getattr(args, "fused_rollout", True))
+        # update_net hands the replay ring + the drawn ids to the step instead of sampling first (False: sample, then step)
+        import os as _os
+        self.sample_in_step = bool(getattr(args, "sample_in_step", _os.environ.get("ERL_SAC_SAMPLE_IN_STEP", "1") != "0"))
         self._last_state_token = None
         self._spec = ops.SacSpec(state_dim, action_dim, net_dims, self.num_ensembles)
         dev, f32 = self.device, th.float32
@@ -217,6 +220,20 @@ class AgentSAC(AgentBase):
         self.rng_counter += 1
         return action
 
+    def _update_from_ring(self, buffer, ring, ids: TEN, objs_out: TEN, noises=None):
+        """ReplayBuffer.sample(ids) and the step from one C call; the buffer's stage / ids0 / ids1 end up as after `buffer.sample`"""
+        from .. import ops
+        self._step += 1
+        arrays, sample_len, stage = ring
+        ops.sac_update_from_ring(self._spec, self._actor_flat, self._critic_flat, self._target_flat, self.alpha_log,
+                                 (self.act_optimizer.exp_avg, self.act_optimizer.exp_avg_sq, self.cri_optimizer.exp_avg,
+                                  self.cri_optimizer.exp_avg_sq, self.alpha_optim.exp_avg, self.alpha_optim.exp_avg_sq),
+                                 arrays, ids, sample_len, stage, self._step, gamma=float(self.gamma), target_entropy=float(self.target_entropy),
+                                 tau=float(self.soft_update_tau), lr=float(self.learning_rate), max_norm=float(self.clip_grad_norm),
+                                 objs_out=objs_out, noises=noises, seed=self.rng_seed + 1, counter=self._step)
+        buffer.ids0, buffer.ids1 = stage.ids
+        self.act_optimizer.step_count = self.cri_optimizer.step_count = self.alpha_optim.step_count = self._step
+
     def _update_on_batch(self, batch, objs_out: TEN, noises=None, is_weight=None, td_error_out=None, buffer=None):
         from .. import ops
         self._step += 1
@@ -271,9 +288,15 @@ class AgentSAC(AgentBase):
             # same distribution, same generator, one launch instead of `update_times`; nothing is written to the buffer inside this loop)
             id_rows = th.randint((buffer.cur_size - 1) * buffer.num_seqs, size=(update_times, self.batch_size), requires_grad=False,
                                  device=self.device).unbind(0)
+        # the sample rides in the step's first launch (erl_sac_update_ring_f32) where the buffer is the library's continuous-action ring and
+        # nothing needs ids0 / ids1 before the step
+        ring = (id_rows is not None and self.sample_in_step and not self.lambda_fit_cum_r and getattr(buffer, "ring_for_fused_sample", None)
+                and buffer.ring_for_fused_sample(self.batch_size))
         for t in range(update_times):
             if self.if_use_per:
                 self._per_step(buffer, objs[t])
+            elif ring:
+                self._update_from_ring(buffer, ring, id_rows[t], objs[t])
             else:       # (the batch is consumed before the next draw)
                 self._update_on_batch(buffer.sample(self.batch_size, ids=None if id_rows is None else id_rows[t], reuse=True), objs[t], buffer=buffer)
         o = objs.cpu().numpy()

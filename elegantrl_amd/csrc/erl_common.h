@@ -68,7 +68,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
                          const float *reward, const float *undone, const float *unmask, const float *next_state, const float *is_weight,
                          float *td_error_out, int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
                          float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
-                         int32_t step, float *objs_out, float *workspace, hipStream_t s);
+                         int32_t step, float *objs_out, float *workspace, const ErlRingSample *ring, hipStream_t s);
 
 #define ERL_REQUIRE(cond, ...)                 \
     do {                                       \

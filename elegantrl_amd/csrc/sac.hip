@@ -399,6 +399,15 @@ extern "C" int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int 
     return f * 4 + 8192;
 }
 
+static int sac_update_impl(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
+                           float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
+                           const int *hidden, int n_hidden, int E, const float *state, const float *action,
+                           const float *reward, const float *undone, const float *unmask, const float *next_state,
+                           const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r, int64_t B,
+                           const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
+                           float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                           int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, const ErlRingSample *ring, void *stream);
+
 extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
                                   float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
                                   const int *hidden, int n_hidden, int E, const float *state, const float *action,
@@ -407,6 +416,41 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
                                   const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
                                   float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
                                   int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return sac_update_impl(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S, A, hidden,
+                           n_hidden, E, state, action, reward, undone, unmask, next_state, is_weight, td_error_out, cum_reward, lambda_fit_cum_r, B,
+                           eps_next, eps_cur, seed, counter, gamma, target_entropy, tau, lr, beta1, beta2, eps_adam, max_norm, step, objs_out,
+                           workspace, workspace_bytes, nullptr, stream);
+}
+
+// ReplayBuffer.sample + the step from one call (include/erl_hip.h): in the fused step the gather rides in the first launch
+extern "C" int erl_sac_update_ring_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
+                                       float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
+                                       const int *hidden, int n_hidden, int E, const ErlRingSample *ring, float *state, float *action,
+                                       float *reward, float *undone, float *unmask, float *next_state, int64_t B, const float *eps_next,
+                                       const float *eps_cur, uint64_t seed, uint64_t counter, float gamma, float target_entropy, float tau,
+                                       float lr, float beta1, float beta2, float eps_adam, float max_norm, int32_t step, float *objs_out,
+                                       void *workspace, int64_t workspace_bytes, void *stream)
+{
+    ERL_REQUIRE(ring && ring->buf_states && ring->buf_actions && ring->buf_rewards && ring->buf_undones && ring->buf_unmasks && ring->ids,
+                "erl_sac_update_ring_f32: NULL ring tensor");
+    ERL_REQUIRE(ring->num_seqs >= 1 && ring->sample_len >= 1 && ring->sample_len <= ring->max_size,
+                "erl_sac_update_ring_f32: bad ring shape max_size=%lld num_seqs=%lld sample_len=%lld", (long long)ring->max_size,
+                (long long)ring->num_seqs, (long long)ring->sample_len);
+    return sac_update_impl(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S, A, hidden,
+                           n_hidden, E, state, action, reward, undone, unmask, next_state, nullptr, nullptr, nullptr, 0.f, B, eps_next, eps_cur, seed,
+                           counter, gamma, target_entropy, tau, lr, beta1, beta2, eps_adam, max_norm, step, objs_out, workspace, workspace_bytes, ring,
+                           stream);
+}
+
+static int sac_update_impl(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
+                           float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
+                           const int *hidden, int n_hidden, int E, const float *state, const float *action,
+                           const float *reward, const float *undone, const float *unmask, const float *next_state,
+                           const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r, int64_t B,
+                           const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
+                           float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                           int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, const ErlRingSample *ring, void *stream)
 {
     ERL_REQUIRE(actor_params && critic_params && target_params && alpha_log && actor_m && actor_v && critic_m && critic_v && alpha_m &&
                     alpha_v && state && action && reward && undone && unmask && next_state && objs_out && workspace,
@@ -428,7 +472,14 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
         return erl_sac_update_fused(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S,
                                     A, hidden[0], hidden[1], E, aoff, coff, d.Pa, d.Pc, state, action, reward, undone, unmask, next_state,
                                     is_weight, td_error_out, B, eps_next, eps_cur, seed, counter, gamma, target_entropy, tau, lr, beta1, beta2,
-                                    eps_adam, max_norm, step, objs_out, (float *)workspace, s);
+                                    eps_adam, max_norm, step, objs_out, (float *)workspace, ring, s);
+    }
+    if (ring) {        // the layered step reads a finished batch: the sample as a launch of its own
+        rc = erl_replay_sample_f32(ring->buf_states, ring->buf_actions, ring->buf_rewards, ring->buf_undones, ring->buf_unmasks, ring->max_size, ring->num_seqs, S,
+                                   A, ring->ids, B, ring->sample_len, const_cast<float *>(state), const_cast<float *>(action),
+                                   const_cast<float *>(reward), const_cast<float *>(undone), const_cast<float *>(unmask),
+                                   const_cast<float *>(next_state), ring->out_ids0, ring->out_ids1, stream);
+        if (rc) return rc;
     }
 
     Ws ws{(char *)workspace, 0, workspace_bytes};

@@ -372,6 +372,12 @@ struct ActorFwdArgs {
     int split, h1_full;
     float *Ypart;
     unsigned *arrive;
+    // ReplayBuffer.sample inside this launch (elegantrl/train/replay_buffer.py:120-134; the gather of csrc/gather.hip replay_sample_kernel):
+    // rg.ids != NULL makes X the ring's NEXT-state rows of the drawn transitions, read in place, and the tile's slice-0 workgroup also copies
+    // the batch out for the launches behind it (state, action, reward, undone, unmask, next_state, ids0, ids1) -- under the weight loads
+    // this kernel waits for anyway
+    ErlRingSample rg;
+    float *o_state, *o_action, *o_reward, *o_undone, *o_unmask, *o_next;
     const float *noise;            // (B, A) or NULL: Philox keyed by (seed, counter, row, a)
     uint64_t seed, counter;
     float *act_t, *lp;             // (B, A), (B,)
@@ -401,9 +407,46 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
     layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(g.P + d.aW2 + fo * d.h0, d.h0, d.h1, L, w2);
     layer_small_load<false, true>(g.P + d.aWh + fo, d.h1, 2 * d.A, h1f, 0, L, wh);
     clear_images(lds.T0, lds.T1, L);
+    __shared__ int64_t s_row[TS];
+    if (g.rg.ids && L.tid < TS) {                          // ids0 = ids % L, ids1 = ids // L  (replay_buffer.py:124-125)
+        const int64_t b = row0 + L.tid, id = g.rg.ids[min(b, d.B - 1)];
+        const int64_t n = id / g.rg.sample_len, t = id - n * g.rg.sample_len;
+        s_row[L.tid] = t * g.rg.num_seqs + n;
+        if (blockIdx.y == 0 && b < d.B) {
+            if (g.rg.out_ids0) g.rg.out_ids0[b] = t;
+            if (g.rg.out_ids1) g.rg.out_ids1[b] = n;
+        }
+    }
     lds_barrier();
     FPROF(0, 1);
-    load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, blockIdx.y == 0 ? g.Xcopy : nullptr, L);
+    if (g.rg.ids) {
+        const int S = d.S, A = d.A, CP = ((S + 15) >> 4) << 4;
+        for (int e = L.tid; e < TS * CP; e += FT) {        // the next-state rows: the first layer's input image (+ the batch's copy)
+            const int s_ = e / CP, c = e - s_ * CP;
+            const int64_t b = row0 + s_;
+            float v = 0.f;
+            if (b < d.B && c < S) {
+                v = g.rg.buf_states[(s_row[s_] + g.rg.num_seqs) * S + c];
+                if (blockIdx.y == 0) g.o_next[b * S + c] = v;
+            }
+            lds.T0[s_ * LDT + c] = v;
+        }
+        if (blockIdx.y == 0) {
+            const int W = S + A + 3;
+            for (int e = L.tid; e < TS * W; e += FT) {
+                const int s_ = e / W, c = e - s_ * W;
+                const int64_t b = row0 + s_, rr = s_row[s_];
+                if (b >= d.B) continue;
+                if (c < S) g.o_state[b * S + c] = g.rg.buf_states[rr * S + c];
+                else if (c < S + A) g.o_action[b * A + (c - S)] = g.rg.buf_actions[rr * A + (c - S)];
+                else if (c == S + A) g.o_reward[b] = g.rg.buf_rewards[rr];
+                else if (c == S + A + 1) g.o_undone[b] = g.rg.buf_undones[rr];
+                else g.o_unmask[b] = g.rg.buf_unmasks[rr];
+            }
+        }
+    } else {
+        load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, blockIdx.y == 0 ? g.Xcopy : nullptr, L);
+    }
     lds_barrier();
     FPROF(0, 2);
     f32x4 z[2], gk[2];
@@ -1294,7 +1337,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
                          const float *reward, const float *undone, const float *unmask, const float *next_state, const float *is_weight,
                          float *td_error_out, int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
                          float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
-                         int32_t step, float *objs_out, float *workspace, hipStream_t s)
+                         int32_t step, float *objs_out, float *workspace, const ErlRingSample *ring, hipStream_t s)
 {
     FusedDims d{};
     d.S = S; d.A = A; d.E = E; d.h0 = h0; d.h1 = h1; d.B = B;
@@ -1322,6 +1365,12 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     ActorFwdArgs af{};
     af.P = actor_params; af.d = d; af.X = next_state; af.noise = eps_next; af.seed = seed; af.counter = 2 * counter;
     af.act_t = a_next; af.lp = lp_next; af.alpha_log = alpha_log; af.alpha0 = alpha0;
+    if (ring) {
+        // the replay sample rides in this launch: the batch pointers are the staging block it fills (sac.hip erl_sac_update_ring_f32)
+        af.rg = *ring;
+        af.o_state = const_cast<float *>(state); af.o_action = const_cast<float *>(action); af.o_reward = const_cast<float *>(reward);
+        af.o_undone = const_cast<float *>(undone); af.o_unmask = const_cast<float *>(unmask); af.o_next = const_cast<float *>(next_state);
+    }
     hipStream_t sa = s;                                 // the stream the actor-forward launches go to
 #define LAUNCH_ACTOR_FWD(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, sa, af)
     SacSide *side = sac_side_stream(s);
@@ -1353,6 +1402,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
         ActorFwdArgs af2 = af;
         af2.X = state; af2.noise = eps_cur; af2.counter = 2 * counter + 1; af2.act_t = act_pg; af2.lp = lp_cur; af2.eps_out = eps_used; af2.Y = Y;
         af2.H0 = H0; af2.G0 = G0; af2.H1 = H1; af2.G1 = G1; af2.alpha0 = nullptr;
+        af2.rg = ErlRingSample{};                        // (`state` was staged by launch (1), which the fork waits for)
         ActorFwdArgs keep = af;
         af = af2;
         FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)

@@ -618,6 +618,35 @@ def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: T
           "erl_sac_update_f32")
 
 
+class _RingSample(ctypes.Structure):        # include/erl_hip.h ErlRingSample
+    _fields_ = [("buf_states", ctypes.c_void_p), ("buf_actions", ctypes.c_void_p), ("buf_rewards", ctypes.c_void_p),
+                ("buf_undones", ctypes.c_void_p), ("buf_unmasks", ctypes.c_void_p), ("max_size", ctypes.c_int64), ("num_seqs", ctypes.c_int64),
+                ("ids", ctypes.c_void_p), ("sample_len", ctypes.c_int64), ("out_ids0", ctypes.c_void_p), ("out_ids1", ctypes.c_void_p)]
+
+
+def sac_update_from_ring(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: TEN, moments: Sequence[TEN], ring: Sequence[TEN],
+                         ids: TEN, sample_len: int, stage: ReplayStage, step: int, *, gamma: float, target_entropy: float, tau: float, lr: float,
+                         max_norm: float, objs_out: TEN, noises: Optional[Tuple[TEN, TEN]] = None, seed: int = 0, counter: int = 0,
+                         betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """ReplayBuffer.sample(ids) + one AgentSAC.update_objectives step from ONE call (erl_sac_update_ring_f32): `ring` = the buffer's
+    (states, actions, rewards, undones, unmasks), `stage` receives the batch (stage.out / stage.ids: what replay_sample would have left)."""
+    b_states, b_actions, b_rewards, b_undones, b_unmasks = ring
+    max_size, num_seqs, S = b_states.shape
+    B = ids.numel()
+    assert stage.B == B and not stage.discrete and b_actions.dtype == th.float32
+    ws = _workspace(b_states.device, spec.workspace_bytes(B))
+    n_next, n_cur = (None, None) if noises is None else noises
+    f32 = th.float32
+    rs = _RingSample(ptr(b_states, f32), ptr(b_actions, f32), ptr(b_rewards, f32), ptr(b_undones, f32), ptr(b_unmasks, f32), max_size, num_seqs,
+                     ptr(ids, th.int64), int(sample_len), stage.p_ids0, stage.p_ids1)
+    check(lib().erl_sac_update_ring_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
+                                        spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ctypes.addressof(rs), stage.p_state, stage.p_action,
+                                        stage.p_reward, stage.p_undone, stage.p_unmask, stage.p_next, B, ptr(n_next), ptr(n_cur),
+                                        seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), gamma, target_entropy, tau, lr, betas[0], betas[1], eps,
+                                        max_norm, step, ptr(objs_out, f32), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_sac_update_ring_f32")
+
+
 def sac_explore_action(spec: SacSpec, actor: TEN, state: TEN, *, noise: Optional[TEN] = None, seed: int = 0, counter: int = 0,
                        out: Optional[TEN] = None, out_state: Optional[TEN] = None) -> TEN:
     """`out` (N, A): the action's destination (e.g. the rollout's row); `out_state` (N, S): a copy of `state` from the same launch."""

@@ -100,6 +100,17 @@ class ReplayBuffer:
                                                         ids, sample_len, stage=stage)
         return out
 
+    def ring_for_fused_sample(self, batch_size: int):
+        """((states, actions, rewards, undones, unmasks), sample_len, stage) for a consumer that does `sample` itself on given ids
+        (ops.sac_update_from_ring: the gather inside the SAC step's first launch), or None where that does not apply (discrete ring, PER);
+        `stage` is the block `sample(..., reuse=True)` writes to."""
+        from .. import ops
+        if self.if_discrete or self.if_use_per or self.cur_size < 2:
+            return None
+        if self._stage is None or self._stage.B != batch_size:
+            self._stage = ops.ReplayStage(batch_size, self.states.shape[2], self.actions.shape[2], False, self.device)
+        return (self.states, self.actions, self.rewards, self.undones, self.unmasks), self.cur_size - 1, self._stage
+
     @_hip.on_device
     def sample_for_per(self, batch_size: int, uniform: Optional[TEN] = None):
         """Prioritised sample (replay_buffer.py:136-165): (state, action, reward, undone, unmask, next_state, is_weights,

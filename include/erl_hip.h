@@ -510,6 +510,17 @@ ERL_API int erl_mlpn_ppo_step_discrete_f32(const float *actor_params, const floa
  * erl_sac_explore_action_f32 = ActorSAC.get_action (:179-185) for the off-policy rollout; state_out (N, S), may be NULL: the
  * rollout's `states[t] = state` (AgentBase.py:145) from the same launch (ABI 16).
  * ------------------------------------------------------------------------------------------- */
+/* ReplayBuffer.sample (elegantrl/train/replay_buffer.py:120-134) handed to erl_sac_update_ring_f32 instead of its result: the ring's five
+ * arrays (max_size, num_seqs, .), the drawn ids (B,) int64, sample_len = cur_size - 1; out_ids0 / out_ids1 (B,) int64 receive
+ * ids % sample_len / ids // sample_len (:124-125; may be NULL). */
+typedef struct ErlRingSample {
+    const float *buf_states, *buf_actions, *buf_rewards, *buf_undones, *buf_unmasks;
+    int64_t max_size, num_seqs;
+    const int64_t *ids;
+    int64_t sample_len;
+    int64_t *out_ids0, *out_ids1;
+} ErlRingSample;
+
 ERL_API int erl_sac_param_counts(int S, int A, const int *hidden, int n_hidden, int E, int64_t *actor_count,
                          int64_t *critic_count);
 ERL_API int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int n_hidden, int E, int64_t B);
@@ -541,6 +552,18 @@ ERL_API int erl_sac_rollout_pendulum_f32(const float *actor_params, const int *h
                                  const float *noise, uint64_t seed, uint64_t counter0, float reward_scale, float *out_states,
                                  float *out_actions, float *out_rewards, uint8_t *out_undones, uint8_t *out_unmasks,
                                  float *out_last_state, void *stream);
+/* erl_sac_update_f32 with ReplayBuffer.sample in front of it, from ONE call: state / action / reward / undone / unmask / next_state are
+ * the (B, .) staging block the sample is written to (what erl_replay_sample_f32 would have produced: bit-identical), everything else
+ * as erl_sac_update_f32.  In the fused step the gather rides in the step's first launch (under its weight loads: one launch and one
+ * kernel boundary less per update); elsewhere it is erl_replay_sample_f32 followed by erl_sac_update_f32.  cum_reward must be NULL
+ * (lambda_fit_cum_r needs ids0 / ids1 before the step: sample first, then erl_sac_update_f32). */
+ERL_API int erl_sac_update_ring_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log,
+                            float *actor_m, float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v,
+                            int S, int A, const int *hidden, int n_hidden, int E, const ErlRingSample *ring, float *state,
+                            float *action, float *reward, float *undone, float *unmask, float *next_state, int64_t B,
+                            const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
+                            float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                            int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, void *stream);
 ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
                                float *action_out, float *state_out, void *workspace, int64_t workspace_bytes, void *stream);

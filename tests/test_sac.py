@@ -346,6 +346,7 @@ def test_sac_update_net_draws_its_sample_ids_ahead_from_the_same_distribution():
     for ahead in (True, False):
         args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A, "if_discrete": False})
         args.net_dims, args.horizon_len, args.batch_size, args.sample_ids_ahead = [64, 32], H, 64, ahead
+        args.sample_in_step = False                         # (the spy below watches buffer.sample)
         args.repeat_times = 8.0
         agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
         assert agent.sample_ids_ahead is ahead
@@ -454,3 +455,42 @@ def test_sac_persistent_rollout_on_pendulum_is_bit_identical_to_the_per_step_loo
         assert th.equal(fe.step_count, pe.step_count) and th.equal(fe.episode, pe.episode)
         if max_step < H:
             assert (~f_items[4]).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", [(256, 256), (64, 48), (64, 48, 32)], ids=["fused-split", "fused", "layered"])
+def test_sac_update_net_with_the_sample_inside_the_step_is_bit_identical(net):
+    """AgentSAC.update_net hands ring + ids to the step (erl_sac_update_ring_f32: the gather of ReplayBuffer.sample rides in the fused step's
+    first launch, or runs as erl_replay_sample_f32 in front of the layered step) instead of sampling first: same weights, moments, targets,
+    temperature, objectives and the same staged batch / ids0 / ids1, bit for bit."""
+    from elegantrl_amd.agents import AgentSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config, ReplayBuffer
+    N, S, A, H = 16, 11, 3, 40
+
+    def run(in_step):
+        args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A, "if_discrete": False})
+        args.net_dims, args.horizon_len, args.batch_size, args.sample_in_step, args.random_seed = list(net), H, 256, in_step, 3
+        args.repeat_times = 32.0                            # update_times = int(cur_size * repeat_times / batch_size): 5, then 10
+        th.manual_seed(5)
+        agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
+        assert agent.sample_in_step is in_step
+        env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=1)
+        agent.last_state = env.reset()[0]
+        buf = ReplayBuffer(max_size=2 * H, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N, args=args)
+        buf.update(agent.explore_env(env, H))
+        th.manual_seed(9)                                   # the same id draws on both sides
+        out = [agent.update_net(buf)]
+        buf.update(agent.explore_env(env, H))               # the ring wraps; a second update on the full ring
+        out.append(agent.update_net(buf))
+        return agent, buf, out
+    (a, ba, oa), (b, bb, ob) = run(True), run(False)
+    assert oa == ob and all(np.isfinite(x) for pair in oa for x in pair)
+    for name in ("_actor_flat", "_critic_flat", "_target_flat", "alpha_log"):
+        assert th.equal(getattr(a, name), getattr(b, name)), name
+    for x, y in zip((a.act_optimizer.exp_avg, a.cri_optimizer.exp_avg_sq), (b.act_optimizer.exp_avg, b.cri_optimizer.exp_avg_sq)):
+        assert th.equal(x, y)
+    assert th.equal(ba.ids0, bb.ids0) and th.equal(ba.ids1, bb.ids1)
+    for x, y in zip(ba._stage.out, bb._stage.out):          # the last staged batch
+        assert th.equal(x, y)
+    assert a._step == b._step == 15
