@@ -20,6 +20,20 @@
 // straight from L2 into registers as MFMA A operands, all issued before the first MFMA; activations cross waves through a
 // [sample][feature] LDS image.  Layers with <= 16 outputs (policy head, Q value, action gradient) split the REDUCTION over the
 // waves instead and meet in LDS in a fixed order.  Everything is deterministic.
+//
+// Round 4 -- a tile workgroup streams a whole cold 256 x 256 layer through ONE CU (~9 us a layer: the weights were just written by Adam,
+// every kernel starts with cold L2s), and wherever the math allows it four workgroups share a tile, each owning 64 of a layer's 256 features
+// (`split`, ERL_SAC_SPLIT=0 turns it off):
+//   critic_fwd / critic_pg   linear in a slice of the decoder's hidden features (q is a sum over them; the policy-gradient pass's loss gradient is
+//                            a constant): `split` partial q / d q/d(action) per decoder, added in slice order by their consumers; no exchange
+//   actor_bwd                its heavy layer dH0 = W2^T dZ2 is output-split; no exchange
+//   actor_fwd (next state)   the head needs the full second layer: the LAST of a tile's four workgroups to arrive adds the four shares of the
+//                            head output in slice order and samples (an arrival counter per tile; nobody waits)
+//   critic_train             not split: its backward needs the full q of its own forward, i.e. a wait inside the launch
+// The clip + Adam launches sum fp64 squared-norm pieces that dw_table leaves (clip_adam_parts_kernel, optim.hip: no grid-wide wait), and
+// ReplayBuffer.sample rides in actor_fwd's prologue when the caller hands over the ring (erl_sac_update_ring_f32): 9 launches on the critical
+// path, 142 us per update at config 3 (235 in round 3).  The same tile code, looped over H steps with the actor's weights kept in registers /
+// LDS, is the persistent off-policy rollout (sac_rollout_synenv_kernel).
 #include "mlpn_common.h"
 
 namespace {
