@@ -50,6 +50,9 @@ int erl_rollout_wide_supported(const int *dims, int n_dims, int64_t N);
 int erl_rollout_wide_step(const float *actor_params, const float *state_avg, const float *state_std, const int *dims, int n_dims, const float *state, int64_t N,
                           const float *noise, uint64_t seed, uint64_t counter, float *out_state_row, float *out_action_row, float *out_logprob_row,
                           float *out_action_env, hipStream_t stream);
+int erl_value_wide_supported(const int *dims, int n_dims);
+int erl_value_wide_forward(const float *params, const float *state_avg, const float *state_std, const int *dims, int n_dims, const float *states,
+                           int64_t rows, float *values, hipStream_t stream);
 int erl_clip_adam_parts_soft_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t len, const double *parts,
                                  int nparts, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm, float *soft, float tau,
                                  hipStream_t stream);

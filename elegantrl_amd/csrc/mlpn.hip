@@ -53,6 +53,9 @@ extern "C" int erl_mlpn_value_forward_f32(const float *params, const float *stat
     ERL_REQUIRE(rows > 0 && rows < (1LL << 31), "erl_mlpn_value_forward_f32: bad rows");
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    // net_dims = (256, h2) / (256, h2, h3): ONE launch (rollout_wide.hip value_wide_kernel; ERL_WIDE_FUSED=0 keeps the layered launches below)
+    if (erl_value_wide_supported(dims, n_dims) && (reinterpret_cast<uintptr_t>(params) & 15) == 0)
+        return erl_value_wide_forward(params, state_avg, state_std, dims, n_dims, states, rows, values, s);
     Ws ws{(char *)workspace, 0, workspace_bytes};
     float *act[MAXL + 2];
     for (int l = 0; l < nd.n; ++l) act[l] = ws.take(rows * nd.d[l]);

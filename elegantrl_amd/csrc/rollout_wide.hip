@@ -230,6 +230,147 @@ __global__ __launch_bounds__(512) void rollout_wide_kernel(RwArgs g)
     if (valid && q == 0 && g.o_logprob) g.o_logprob[row] = lp;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The value pre-pass of the same shapes: CriticPPO.forward over the rollout's H x N rows (elegantrl/agents/AgentPPO.py:141-143, :219-220,
+// :435-441) as ONE launch instead of the layered path's four (normalise + three GEMMs through memory: ~150 us at 131 072 rows).  Persistent
+// workgroups walk 16-row tiles; the wave's weight rows (first-layer tiles w and w + 8, second-layer tile w) are split into their bf16 parts
+// ONCE and stay in registers (48 + 96 per lane; a third layer's rows are re-read and re-split per tile), a tile costs three LDS barriers.
+// ---------------------------------------------------------------------------------------------------------
+struct VwArgs {
+    const float *P, *avg, *sd;
+    int S, h2, h3;
+    const float *states;
+    int64_t rows;
+    float *values;
+};
+
+template <bool VEC, bool L3>
+__global__ __launch_bounds__(512) void value_wide_kernel(VwArgs g)
+{
+    __shared__ __attribute__((aligned(16))) u8 T1[RW_TBYTES];
+    __shared__ __attribute__((aligned(16))) u8 T2[L3 ? RB_TBYTES : 16];
+    __shared__ __attribute__((aligned(16))) float PS[8 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const RwOff d(g.S, g.h2, L3 ? g.h3 : 0, 1);
+    const int S = d.S, n2 = d.h2 >> 4, nl = d.hl >> 4;
+    const int ks_s = (S + 31) >> 5;
+
+    Parts w1[2][2], w2[8];          // (three hidden layers: the first layer's rows are re-read and re-split per tile too -- 256 registers)
+    float4 b3h = zero4();
+    const float *r1a = g.P + d.oW1() + (size_t)(16 * wave + l15) * S, *r1b = r1a + (size_t)128 * S;
+    {
+        const float *r2 = g.P + d.oW2() + (size_t)min(16 * wave + l15, d.h2 - 1) * RW_H1;
+        if (!L3) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks < ks_s) {
+                    w1[0][ks] = rb_load_w<VEC>(r1a, ks, q, S);
+                    w1[1][ks] = rb_load_w<VEC>(r1b, ks, q, S);
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w2[ks] = rb_load_w<true>(r2, ks, q, RW_H1);
+    }
+    const int kt = min(wave, nl - 1);
+    float4 wo = load4<VEC>(g.P + d.oWo(), 16 * kt + 4 * q, d.hl);            // the value head: ONE output row
+    if (l15 >= 1 || wave >= nl) wo = zero4();
+    const float4 b1a = load4<true>(g.P + d.ob1(), 16 * wave + 4 * q, RW_H1), b1b = load4<true>(g.P + d.ob1(), 128 + 16 * wave + 4 * q, RW_H1);
+    const float4 b2 = load4<VEC>(g.P + d.ob2(), 16 * min(wave, n2 - 1) + 4 * q, d.h2);
+    const float *r3 = g.P + d.oW3() + (size_t)min(16 * wave + l15, (L3 ? d.h3 : 1) - 1) * d.h2;      // (third layer: re-read and re-split per tile)
+    if (L3) b3h = load4<VEC>(g.P + d.ob3(), 16 * kt + 4 * q, d.h3);
+    const float bo = g.P[d.obo()];
+
+    const int64_t ntiles = (g.rows + 15) / 16;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r_ = tile * 16 + l15;
+        const bool valid = r_ < g.rows;
+        const float *srow = g.states + (valid ? r_ : g.rows - 1) * S;
+        // (loop-invariant loads that are meant to be re-issued per tile -- hoisted out of the loop they are 40-70 registers held across it,
+        // which spill: the offset below is opaque to the compiler)
+        int zoff = 0;
+        asm volatile("" : "+s"(zoff));
+        float4 w3r[8];
+        if (L3) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                w3r[2 * ks] = load4<VEC>(r3 + zoff, 32 * ks + 8 * q, d.h2);
+                w3r[2 * ks + 1] = load4<VEC>(r3 + zoff, 32 * ks + 8 * q + 4, d.h2);
+            }
+        }
+        Parts X[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < ks_s) {
+                float4 xn[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int k0 = 32 * ks + 8 * q + 4 * hh;
+                    const float4 x4 = load4<VEC>(srow, k0, S), a4 = load4<VEC>(g.avg + zoff, k0, S), s4 = load4<VEC>(g.sd + zoff, k0, S);
+                    xn[hh].x = (valid && k0 + 0 < S) ? (x4.x - a4.x) / (s4.x + 1e-4f) : 0.f;      // (s - avg) / (std + 1e-4), AgentPPO.py:440-441
+                    xn[hh].y = (valid && k0 + 1 < S) ? (x4.y - a4.y) / (s4.y + 1e-4f) : 0.f;
+                    xn[hh].z = (valid && k0 + 2 < S) ? (x4.z - a4.z) / (s4.z + 1e-4f) : 0.f;
+                    xn[hh].w = (valid && k0 + 3 < S) ? (x4.w - a4.w) / (s4.w + 1e-4f) : 0.f;
+                }
+                X[ks] = rb_split8(xn[0], xn[1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            RbAcc acc;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                if (ks < ks_s) rb_mma6(L3 ? rb_load_w<VEC>((j ? r1b : r1a) + zoff, ks, q, S) : w1[j][ks], X[ks], acc);
+            const float4 b1 = j ? b1b : b1a;
+            const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+            float h[4], gd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(acc, r) + bb[r], h[r], gd);
+            rb_tile_put(T1, RW_TLD, l15, 128 * j + 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
+        }
+        lds_barrier();
+        f32x4 part = {0.f, 0.f, 0.f, 0.f};
+        float h[4] = {0.f, 0.f, 0.f, 0.f}, gd;
+        if (__builtin_amdgcn_readfirstlane(wave) < n2) {
+            RbAcc acc;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) rb_mma6(w2[ks], rb_tile_get(T1, RW_TLD, l15, ks, q), acc);
+            const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(acc, r) + bb[r], h[r], gd);
+            if (L3) rb_tile_put(T2, RB_TLD, l15, 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
+        }
+        if (L3) {
+            lds_barrier();
+            if (__builtin_amdgcn_readfirstlane(wave) < nl) {
+                RbAcc acc;
+                const int ks_2 = d.h2 >> 5;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    if (ks < ks_2) rb_mma6(rb_split8(w3r[2 * ks], w3r[2 * ks + 1]), rb_tile_get(T2, RB_TLD, l15, ks, q), acc);
+                const float bb[4] = {b3h.x, b3h.y, b3h.z, b3h.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(acc, r) + bb[r], h[r], gd);
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane(wave) < nl) {
+            part = mfma16(wo.x, h[0], part);
+            part = mfma16(wo.y, h[1], part);
+            part = mfma16(wo.z, h[2], part);
+            part = mfma16(wo.w, h[3], part);
+        }
+        if (q == 0) PS[wave * 16 + l15] = part[0];           // output row 0 of sample l15 (lanes q = 0 hold rows 0..3)
+        lds_barrier();
+        if (wave == 0 && q == 0 && valid) {
+            float p[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) p[w] = PS[w * 16 + l15];
+            g.values[r_] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + bo;
+        }
+        lds_barrier();                                         // (PS and T1 are rewritten by the next tile)
+    }
+}
+
 constexpr int64_t kRwMaxEnvs = 16384;      // beyond: the weight re-reads (196 KB per 16-env tile) outweigh the launches saved
 
 }  // namespace
@@ -265,4 +406,31 @@ int erl_rollout_wide_step(const float *actor_params, const float *state_avg, con
         else hipLaunchKernelGGL((rollout_wide_kernel<false, false>), grid, block, 0, stream, g);
     }
     return erl_hip_status(hipGetLastError(), "erl_mlpn_rollout_step_f32 (wide latency form)");
+}
+
+// dims = [S, 256, h2, 1] or [S, 256, h2, h3, 1]; any number of rows (persistent workgroups); ERL_WIDE_FUSED=0 turns the kernel off
+int erl_value_wide_supported(const int *dims, int n_dims)
+{
+    return dims && (n_dims == 4 || n_dims == 5) && dims[n_dims - 1] == 1 && erl_rollout_wide_supported(dims, n_dims, 1);
+}
+
+int erl_value_wide_forward(const float *params, const float *state_avg, const float *state_std, const int *dims, int n_dims, const float *states,
+                           int64_t rows, float *values, hipStream_t stream)
+{
+    VwArgs g{};
+    g.P = params; g.avg = state_avg; g.sd = state_std;
+    g.S = dims[0]; g.h2 = dims[2]; g.h3 = n_dims == 5 ? dims[3] : 0;
+    g.states = states; g.rows = rows; g.values = values;
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = (g.S % 4 == 0) && al(g.P) && al(g.states) && al(g.avg) && al(g.sd);
+    const int64_t tiles = erl_cdiv(rows, 16);
+    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(512);
+    if (g.h3) {
+        if (vec) hipLaunchKernelGGL((value_wide_kernel<true, true>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((value_wide_kernel<false, true>), grid, block, 0, stream, g);
+    } else {
+        if (vec) hipLaunchKernelGGL((value_wide_kernel<true, false>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((value_wide_kernel<false, false>), grid, block, 0, stream, g);
+    }
+    return erl_hip_status(hipGetLastError(), "erl_mlpn_value_forward_f32 (wide form)");
 }

@@ -226,3 +226,19 @@ def test_wide_rollout_step_is_one_launch_and_matches_fp64(ops, dev, S, h2, A, N)
     ops.mlpn_rollout_step(cu(flat_params(actor), dev), spec, cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(x, dev), seed=5, counter=9,
                           out_action=z2)
     assert th.equal(o_a2, z2)                   # deterministic in (seed, counter)
+
+
+@pytest.mark.parametrize("S,mid,rows", [(8, (128,), 131072), (24, (64,), 20001), (33, (32,), 50), (64, (128,), 4097), (17, (128, 64), 9000),
+                                        (64, (128, 128), 70000), (6, (32, 96), 17)])
+def test_wide_value_forward_is_one_launch_and_matches_fp64(ops, dev, S, mid, rows):
+    """net_dims = (256, h2[, h3]): erl_mlpn_value_forward_f32 takes the persistent-tile form (csrc/rollout_wide.hip value_wide_kernel: weights
+    split once, kept in registers, workgroups walk 16-row tiles) -- against the fp64 restatement over more rows than one pass of the grid,
+    row counts that are not multiples of the tile, aligned and unaligned state_dim, two and three hidden layers."""
+    rng = np.random.default_rng(S + rows)
+    critic = random_net_n(rng, [S, 256, *mid, 1], False)
+    x = rng.standard_normal((rows, S), dtype=np.float32)
+    spec = ops.MlpSpecN([S, 256, *mid, 1], False)
+    v = ops.mlpn_value_forward(cu(flat_params(critic), dev), spec, cu(critic.state_avg, dev), cu(critic.state_std, dev), cu(x, dev))
+    ref = O.critic_value(x.astype(np.float64), critic.astype(np.float64))
+    err = float(np.abs(v.cpu().numpy() - ref).max())
+    assert v.shape == (rows,) and err <= 4e-6 * max(1.0, float(np.abs(ref).max())), err
