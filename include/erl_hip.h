@@ -458,6 +458,8 @@ ERL_API int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp
  * library-owned buffers -- same arguments, same result; `workspace` is not used then; ERL_WIDE_FUSED=0 in the environment keeps the
  * layered step.  erl_mlpn_rollout_step_f32 with dims = [S <= 64, 256, 32..128, (32..128,) A <= 16] and N <= 16384 runs as ONE launch too
  * (csrc/rollout_wide.hip: the latency form of K1 for a 256-wide first layer); same arguments, `workspace` not used then.
+ * erl_mlpn_value_forward_f32 with dims = [S <= 64, 256, 32..128, (32..128,) 1], any number of rows: ONE launch as well (persistent 16-row
+ * tiles, the weights split once and kept in registers); same arguments, `workspace` not used then.
  * ------------------------------------------------------------------------------------------- */
 ERL_API int64_t erl_mlpn_param_count(const int *dims, int n_dims, int with_std_log);
 ERL_API int64_t erl_mlpn_workspace_bytes(const int *dims, int n_dims, int64_t rows, int training);
