@@ -59,6 +59,14 @@ PPO_CONFIGS = {
                net_dims=[128, 64], hyper=dict(gamma=0.97, reward_scale=0.25, learning_rate=4e-4),
                workload="BASELINE configs[1]: AgentPPO, GPU-resident vectorised Pendulum-v1, 4096 envs, horizon 200, "
                         "40 minibatches x 16384, net [128,64], fp32"),
+    # SURVEY.md 8(d) "also report the reference-default shape": the reference's own on-policy defaults (elegantrl/train/config.py:55-58:
+    # batch_size 128, horizon_len 2048, repeat_times 8.0 => int(2048 * 8 / 128) = 128 minibatches of 128) at config 4's env shape.  The
+    # only BASELINE-adjacent shape at which the GAE scan runs IN THE LOOP at 2048 x 4096 (fused_gae off: the look-back kernel as a launch
+    # of its own, `roofline_gae` = its in-loop figure); the rollout (2048 steps in one launch) is the dominant kernel here.
+    "cd": dict(metric="env_steps_per_sec_ppo_4096envs_obs64_reference_default_shape", env="syn", N=4096, S=64, A=8, H=2048, B=128,
+               update_times=128, net_dims=[128, 128], hyper=dict(fused_gae=False),
+               workload="reference-default on-policy shape (elegantrl/train/config.py:55-58: horizon_len 2048, batch_size 128, repeat_times 8 => "
+                        "128 minibatches x 128) on BASELINE configs[3]'s synthetic VecEnv obs_dim=64 act_dim=8, 4096 envs/GPU, net [128,128], fp32"),
     # not a BASELINE configuration: the network of the reference's LunarLanderContinuous demo (examples/demo_A2C_PPO.py:117,
     # net_dims (256, 128), with its hyper-parameters :118-125) on a synthetic VecEnv of that env's shape, vectorised like configs[3];
     # its minibatch loop runs on csrc/ppo_step_wd_impl.h (rollout and value pre-pass on the layered erl_mlpn_* path)
@@ -87,6 +95,12 @@ def ppo_flops_per_sample(S, h1, h2, A):
         fwd = 2 * (S * h1 + h1 * h2 + h2 * out)
         return fwd + fwd + 2 * (h1 * h2 + h2 * out)
     return net(A) + net(1)
+
+
+def rollout_flops_per_env_step(S, h1, h2, A):
+    """algorithmic flops of one env-step inside the persistent rollout kernel: actor forward + critic forward (the value pre-pass
+    rides in the same launch) + the synthetic env's s Ws + a Wa"""
+    return 2 * (S * h1 + h1 * h2 + h2 * A) + 2 * (S * h1 + h1 * h2 + h2) + 2 * (S * S + A * S)
 
 
 class EventTimer:
@@ -198,6 +212,45 @@ def rocprof_kernel_us(kernel):
         return (None if src["stale"] else v["avg_us"]), src
     except Exception:
         return None, src
+
+
+SHADER_PEAK_MHZ = 2400.0      # the clock the dense-MFMA peaks are quoted at (MI355X_MICROARCH.md: max clock)
+
+
+def smi_snapshot(timeout_s: int = 20):
+    """what the box says about itself right after the timed region (clocks, power cap / draw, temperature, partition modes): the pool's
+    boxes do not all run this workload at the same speed (BENCH_r02..r04: the driver's box ran the minibatch kernel 15-40 % slower than
+    the boxes the kernel was tuned on), and the bench line should carry the evidence.  Best effort: whichever of rocm-smi / amd-smi
+    answers within the timeout; only keys about clocks / power / temperature / partitioning are kept."""
+    import re
+    import subprocess
+    keep = re.compile(r"clk|clock|power|cap|temp|perf|partition|voltage|throttl|sku|vbios|series|model", re.I)
+    out = {}
+    for cmd in (["rocm-smi", "-a", "--json"], ["amd-smi", "static", "--json"], ["amd-smi", "metric", "--json"]):
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            txt = r.stdout.strip()
+            if not txt:
+                continue
+            starts = [i for i in (txt.find("{"), txt.find("[")) if i >= 0]
+            data = json.loads(txt[min(starts):])
+        except Exception as e:      # tool missing / no JSON / timeout: say so, go on
+            out[" ".join(cmd)] = {"error": repr(e)[:120]}
+            continue
+        flat = {}
+
+        def walk(prefix, v):
+            if isinstance(v, dict):
+                for k, x in v.items():
+                    walk(f"{prefix}.{k}" if prefix else str(k), x)
+            elif isinstance(v, list):
+                for i, x in enumerate(v[:2]):          # (one GPU is visible; keep the first entries only)
+                    walk(f"{prefix}[{i}]", x)
+            elif keep.search(prefix) and len(flat) < 80:
+                flat[prefix] = v
+        walk("", data)
+        out[" ".join(cmd)] = flat
+    return out
 
 
 _JSON_FD = None
@@ -392,6 +445,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gae-sweep", action="store_true")
+    ap.add_argument("--no-smi", action="store_true", help="skip the rocm-smi / amd-smi snapshot after the timed region (`clocks.smi`)")
     ap.add_argument("--cpu-iters", type=int, default=12)   # ~10-15 s of host work on 16 cores
     ap.add_argument("--k6-sample", type=int, default=16,
                     help="bracket every n-th K6 launch with HIP events (0 = none): each bracket costs ~3 us of stream time")
@@ -401,9 +455,10 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--eager-logs", action="store_true", help="read update_net's logged objectives at once (one host sync per iteration with the GPU "
                                                               "idle behind it) instead of one rollout late, as train_agent does by default")
-    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5", "cw"], default="c4",
+    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5", "cw", "cd"], default="c4",
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
-                         "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs")
+                         "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs, cw = the reference demo's (256,128) network, "
+                         "cd = the reference's default horizon / batch shape (2048 x 4096 rollout, 128 minibatches of 128)")
     opt = ap.parse_args()
     claim_stdout()
     if opt.cpu_baseline_only:
@@ -495,6 +550,8 @@ def main():
     t_gae.enabled = t_explore.enabled = t_update.enabled = False
     _hip.k6_timing_enable(False)
     k6_event_seconds, k6_span_seconds, k6_launches = _hip.k6_timing_read2()
+    k6_clocks = _hip.k6_timing_clocks()                     # shader clock inside the sampled launches, per-phase cycles (s3 kernel)
+    smi = smi_snapshot() if rank == 0 and not opt.no_smi else None
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
     # box variance made visible next to the driver's single sample: the same region repeated (not part of `value`)
@@ -578,6 +635,19 @@ def main():
     k6_traffic, k6_traffic_src = (pmc_traffic(k6_kernel) if opt.config == "c4" else
                                   pmc_traffic(k6_kernel, WIDE_PMC_FILE) if opt.config == "cw" else (None, None))
     k6_rocprof_us, k6_rocprof_src = rocprof_kernel_us(k6_kernel) if opt.config == "c4" else (None, None)
+    k6_mhz = float(k6_clocks.get("shader_mhz") or 0.0)
+    # live kernel time against the committed rocprofv3 average of the same command on the same sources ("the two must agree"): a
+    # ratio beyond 10 % means THIS box runs the kernel at another speed than the box the profile came from -- said out loud, with
+    # the clock and the per-phase cycles next to it, instead of two disagreeing numbers in one line
+    box_ratio = round(ppo_s * 1e6 / k6_rocprof_us, 3) if k6_rocprof_us else None
+    phase_ref = None
+    try:
+        phase_ref = json.load(open(os.path.join(ROOT, KTIME_FILE))).get("phase_cycles_reference")
+    except Exception:
+        pass
+    if box_ratio is not None and abs(box_ratio - 1.0) > 0.10:
+        log(f"WARNING: the minibatch kernel runs {ppo_s * 1e6:.1f} us here against {k6_rocprof_us:.1f} us in {KTIME_FILE} (x{box_ratio}); shader clock "
+            f"in the kernel {k6_mhz:.0f} MHz, phase cycles {k6_clocks['phase_cycles']} (reference: {phase_ref})")
     # the parts of a step against the step: explore_env + update_net brackets (each carries one bracket overhead) must fit into
     # ms_per_step, and the K6 launches must fit into update_net
     explore_ms, update_ms = t_explore.mean_seconds() * 1e3, t_update.mean_seconds() * 1e3
@@ -619,7 +689,20 @@ def main():
                      "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel, every "
                                f"{opt.k6_sample}th launch of the timed region)" if k6_span_s == k6_span_s else "HIP-event bracket minus empty-launch bracket"),
                      "event_bracket_us": round(k6_event_s * 1e6, 2), "event_bracket_null_us": round(null_bracket_us, 2),
-                     "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src},
+                     "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src,
+                     # this box against the box the committed rocprofv3 summary was collected on (same sources): avg_launch_us / kernel_us_rocprof
+                     "box_ratio": box_ratio,
+                     # the clock the sampled launches actually ran at (shader cycles per constant-rate tick inside the kernel) and the
+                     # fraction against the peak scaled to THAT clock: what the kernel does with the cycles this box gave it
+                     "shader_mhz": round(k6_mhz, 1) if k6_mhz else None,
+                     "frac_at_measured_clock": round(flops / ppo_s / 1e12 / (k6_peak * k6_mhz / SHADER_PEAK_MHZ), 4) if k6_mhz else None,
+                     "phase_cycles": {k: round(v) for k, v in k6_clocks["phase_cycles"].items()} or None,
+                     "phase_cycles_reference": phase_ref},
+        "clocks": {"shader_mhz_in_k6": round(k6_mhz, 1) if k6_mhz else None, "peak_quoted_at_mhz": SHADER_PEAK_MHZ,
+                   "k6_workgroup_us": round(k6_clocks["workgroup_us"], 2), "phase_workgroups": k6_clocks["phase_workgroups"],
+                   "smi": smi,
+                   "note": "shader_mhz_in_k6 = sum over workgroups of (s_memtime exit - entry) / (constant-rate clock exit - entry) x its rate, on the "
+                           "sampled minibatch-kernel launches of the timed region; smi = rocm-smi / amd-smi right after the region"},
         "breakdown": breakdown,
         "roofline_gae": ({"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
                           "bound": "hbm",
@@ -632,6 +715,22 @@ def main():
                           "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": None}),
         "objectives_last": [round(float(x), 6) for x in objs],
     }
+    if opt.config == "cd":
+        # at this shape the rollout (2048 steps x 4096 envs in ONE launch) is the dominant kernel: it becomes `roofline`, the minibatch
+        # kernel (2 workgroups per launch at B = 128: latency, not throughput) moves to `roofline_k6`
+        line["roofline_k6"] = line["roofline"]
+        rflops = rollout_flops_per_env_step(STATE_DIM, *NET_DIMS, ACTION_DIM) * N_ENVS * HORIZON
+        rs = explore_ms * 1e-3
+        peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS
+        line["roofline"] = {"kernel": "rollout_fused_kernel", "bound": "mfma", "achieved": round(rflops / rs / 1e12, 2), "peak": round(peak, 1),
+                            "unit": "TFLOP/s", "frac": round(rflops / rs / 1e12 / peak, 4), "traffic": None, "flops_per_launch": rflops,
+                            "avg_launch_us": round(rs * 1e6, 1), "launches_timed": len(t_explore.pairs),
+                            "us_per_env_step_row": round(rs * 1e6 / HORIZON, 3),
+                            "arith": "hidden layers: fp32 operands as three bf16 parts, six partial products on v_mfma_f32_16x16x32_bf16 (csrc/rollout_bf16.h); "
+                                     "output layers and the env's matrices on the fp32 MFMA; `peak` = bf16 dense MFMA peak / 6",
+                            "timer": "HIP-event bracket around agent.explore_env (one launch + its allocations)",
+                            "note": "a 16-env tile per workgroup walks all H steps: 256 workgroups x 8 waves, a step is a chain of dependent small "
+                                    "layers (latency-bound by construction: DESIGN.md, Persistent rollout)"}
     if allreduce is not None:
         line["allreduce"] = allreduce
     if repeats:
@@ -655,7 +754,9 @@ def main():
                                                 "traffic": gae_tr, "traffic_source": gae_tr_src}
     if world == 1 and not opt.no_cpu_baseline:
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
-        line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else max(2, opt.cpu_iters // 4), opt.config)
+        # (cd: one CPU iteration is 2048 x 4096 env steps + a value pre-pass over 8.4 M rows, ~20 s on 16 cores: warm-up + 1)
+        line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else 1 if opt.config == "cd" else max(2, opt.cpu_iters // 4),
+                                                       opt.config, timeout_s=600 if opt.config == "cd" else 300)
     log("done")
     emit(line)
 

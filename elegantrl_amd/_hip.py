@@ -22,8 +22,9 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 16
+ABI_VERSION = 17
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
+SAC_ACTOR_SAC, SAC_ACTOR_FIX = 0, 1                               # include/erl_hip.h ERL_SAC_ACTOR_*
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
 
@@ -121,10 +122,14 @@ _SIGNATURES = {
     "erl_sac_workspace_bytes": (c_int64, [c_int, c_int, POINTER(c_int), c_int, c_int, c_int64]),
     "erl_sac_update_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int] + [_P] * 9 + [c_float, c_int64, _P, _P, c_uint64,
                                    c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
+    "erl_sac_update_opt_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int] + [_P] * 9 + [c_float, c_int64, _P, _P, c_uint64,
+                                       c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P, _P]),
     "erl_sac_update_ring_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int, _P] + [_P] * 6 + [c_int64, _P, _P, c_uint64,
                                         c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
     "erl_sac_explore_action_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P,
                                            c_int64, _P]),
+    "erl_sac_explore_action_opt_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P,
+                                               c_int64, c_int, _P]),
     "erl_sac_rollout_synenv_supported": (c_int, [c_int, c_int, POINTER(c_int), c_int, c_int64]),
     "erl_sac_rollout_synenv_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, _P, _P, _P, _P, c_int, c_uint64, c_int64, c_int64, _P,
                                            c_uint64, c_uint64, c_float, _P, _P, _P, _P, _P, _P, _P]),
@@ -134,6 +139,8 @@ _SIGNATURES = {
     "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_read2": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_null_bracket_us": (c_int, [_P, c_int, POINTER(ctypes.c_double)]),
+    "erl_k6_timing_clocks": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int, POINTER(c_int),
+                                     POINTER(c_int)]),
     "erl_synenv_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_uint64, _P]),
     "erl_pendulum_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_uint64, _P]),
     "erl_selftest_mfma": (c_int, [POINTER(c_float)]),
@@ -259,6 +266,21 @@ def k6_timing_read2():
     ev, sp, n = ctypes.c_double(0), ctypes.c_double(0), c_int(0)
     check(lib().erl_k6_timing_read2(ctypes.byref(ev), ctypes.byref(sp), ctypes.byref(n)), "erl_k6_timing_read2")
     return ev.value * 1e-3, sp.value * 1e-3, n.value
+
+
+K6_PHASES = ("prologue", "layer1_forward", "layer2_forward", "output_objective_backward", "stage_dW1", "stage_dW3_stage", "dW2_logs_drain")
+
+
+def k6_timing_clocks():
+    """what the launches drained by the last k6_timing_read2() say about the box: {"shader_mhz": the clock they ran at, "workgroup_us": a
+    workgroup's mean duration, "phase_cycles": {phase: mean shader cycles of an actor workgroup's first wave} (empty for kernels that stamp
+    no phases), "phase_workgroups": n}"""
+    mhz, wg = ctypes.c_double(0), ctypes.c_double(0)
+    ph = (ctypes.c_double * 8)()
+    n, nw = c_int(0), c_int(0)
+    check(lib().erl_k6_timing_clocks(ctypes.byref(mhz), ctypes.byref(wg), ph, 8, ctypes.byref(n), ctypes.byref(nw)), "erl_k6_timing_clocks")
+    return {"shader_mhz": mhz.value, "workgroup_us": wg.value, "phase_cycles": {K6_PHASES[k]: ph[k] for k in range(min(n.value, len(K6_PHASES)))},
+            "phase_workgroups": nw.value}
 
 
 def k6_null_bracket_us(reps: int = 200) -> float:

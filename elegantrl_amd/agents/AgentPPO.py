@@ -10,6 +10,8 @@ without a HIP device / the extension they raise.
 """
 from __future__ import annotations
 
+import os
+import weakref
 from typing import List, Optional, Tuple
 
 import torch as th
@@ -110,23 +112,34 @@ class FlatAdam:
 
 class PendingLogs:
     """update_net(..., lazy=True): the logged objectives of an update whose kernels are still running.  `result()` -> the three floats
-    update_net returns otherwise (and the device-fault check that goes with its host sync)."""
+    update_net returns otherwise (and the device-fault check that goes with its host sync).  Two pinned host blocks are used in turn;
+    a block whose previous owner has not been read yet is resolved first (its numbers are cached on that owner), so a third
+    `update_net(lazy=True)` before the first `result()` cannot overwrite what the first one will return."""
 
     def __init__(self, agent):
         ring = agent.__dict__.setdefault("_lazy_ring", [])
         if len(ring) < 2:                                   # two pinned blocks, used in turn (allocated once: hipHostMalloc is slow)
-            ring.append((th.empty(4, dtype=th.float32, pin_memory=True), th.cuda.Event()))
+            ring.append([th.empty(4, dtype=th.float32, pin_memory=True), th.cuda.Event(), None])
         agent._lazy_turn = (getattr(agent, "_lazy_turn", -1) + 1) % 2
-        self._host, self._event = ring[min(agent._lazy_turn, len(ring) - 1)]
+        slot = ring[min(agent._lazy_turn, len(ring) - 1)]
+        owner = slot[2]() if slot[2] is not None else None
+        if owner is not None and owner._vals is None:       # the block's last owner is still unread: read it before the block is reused
+            owner._resolve(check=False)
+        self._host, self._event = slot[0], slot[1]
+        slot[2] = weakref.ref(self)
         self._host.copy_(agent._logs, non_blocking=True)
         self._event.record()
         self._vals = None
 
+    def _resolve(self, check: bool = True):
+        self._event.synchronize()
+        self._vals = tuple(self._host[:3].tolist())
+        if check:
+            _hip.check_async_faults()
+
     def result(self) -> Tuple[float, float, float]:
         if self._vals is None:
-            self._event.synchronize()
-            self._vals = tuple(self._host[:3].tolist())
-            _hip.check_async_faults()
+            self._resolve()
         return self._vals
 
 
@@ -166,7 +179,7 @@ class AgentPPO(AgentBase):
         self.gae_algo = getattr(args, "gae_algo", "auto")
         # arithmetic of the minibatch kernel's large products (include/erl_hip.h, erl_ppo_set_arith): "auto" = the library default
         # (split bf16 operands on the bf16 matrix pipe, fp32-equivalent, where the net shape allows), "f32" = the fp32 MFMA.
-        # Process-wide in the library: applied at every update_net (an "auto" agent resets what an "f32" agent set before it).
+        # Passed with every call of the minibatch entry points (ERL_PPO_MODE, ABI 17), so agents of one process do not share it.
         # `agent.last_state` after a fused rollout: a tensor of the agent's own, written by the rollout kernel itself (the reference's
         # behaviour, AgentPPO.py:125; no extra launch).  args.snapshot_last_state = False aliases the env's live state buffer instead.
         self.snapshot_last_state = bool(getattr(args, "snapshot_last_state", True))
@@ -177,6 +190,11 @@ class AgentPPO(AgentBase):
         self._last_state_token = None
         self.ppo_arith = str(getattr(args, "ppo_arith", "auto"))
         assert self.ppo_arith in ("auto", "f32", "split"), f"args.ppo_arith = {self.ppo_arith!r}"
+        if self._wide and self.ppo_arith == "f32":
+            # the (256, h2) minibatch kernel exists in split arithmetic only: an agent that asks for the fp32 MFMA (the validation
+            # mode) gets the layered path's fp32 GEMMs instead of silently running the split kernel
+            self._wide = False
+            self._fused_update = self._fused
         # which actor objective the kernels differentiate: the reference's sign-dependent scale (AgentPPO.py:199, default) or,
         # with args.canonical_ppo = True, the textbook min(r A, clamp(r, 1 - clip, 1 + clip) A) of
         # helloworld/helloworld_PPO_single_file.py:337-339
@@ -220,6 +238,38 @@ class AgentPPO(AgentBase):
         self.fused_rollout = bool(getattr(args, "fused_rollout", os.environ.get("ERL_FUSED_ROLLOUT", "1") != "0"))
         self._rollout_cache = None
         self._norm_version = 0
+        self.kernel_path = self._describe_kernel_path()
+        if not getattr(args, "quiet", False) and os.environ.get("ERL_QUIET", "0") == "0":
+            print(f"| {type(self).__name__}: {self.kernel_path}", flush=True)
+
+    def _describe_kernel_path(self) -> str:
+        """which kernels this agent's shapes get, and why (the limits are compile-time: include/erl_hip.h ERL_MAX_*; the layered
+        path costs 2.2-2.4x per minibatch, DESIGN.md section 4 "Generic-shape path")"""
+        S, A, dims = self.state_dim, self.action_dim, list(self.net_dims)
+        if self._fused:
+            from .. import ops
+            arith = ops.ppo_arith_in_use(S, dims[0], dims[1], A) if self.ppo_arith != "f32" else "f32"
+            one_wave = all(d in (64, 128) for d in dims) and S <= 64 and A <= 8
+            form = ("one wave per SIMD, " + ("bf16 matrix pipe with fp32-equivalent split arithmetic" if arith == "split" else "fp32 MFMA")
+                    if one_wave else "8-wave fp32-MFMA form (one-wave form needs h1, h2 in {64, 128}, S <= 64, A <= 8)")
+            return f"fused path (net_dims {dims}: two hidden layers of 32..{_hip.MAX_HIDDEN} in steps of 32): minibatch kernel {form}; persistent rollout on device-resident envs"
+        if self._wide:
+            return (f"wide fused path (net_dims {dims} = (256, 64 | 128), S <= 64, A <= 8): fused minibatch kernel with W2 streamed through LDS, "
+                    "one-launch rollout step and value pre-pass")
+        why = []
+        if self._discrete:
+            why.append("categorical policy")
+        if len(dims) != 2:
+            why.append(f"{len(dims)} hidden layers (fused kernels: 2" + ("; (256, 128, 64 | 128) has a fused minibatch kernel of its own" if
+                       len(dims) == 3 and dims[0] == 256 and dims[1] == 128 and dims[2] in (64, 128) and S <= 64 and A <= 8 else "") + ")")
+        elif not all(32 <= d <= _hip.MAX_HIDDEN and d % 32 == 0 for d in dims):
+            why.append(f"hidden widths {dims} outside 32..{_hip.MAX_HIDDEN} in steps of 32" +
+                       (" (wide_fused off or ppo_arith = 'f32')" if dims[0] == 256 and dims[1] in (64, 128) else ""))
+        if S > _hip.MAX_STATE_DIM:
+            why.append(f"state_dim {S} > {_hip.MAX_STATE_DIM}")
+        if A > _hip.MAX_ACTION_DIM:
+            why.append(f"action_dim {A} > {_hip.MAX_ACTION_DIM}")
+        return "layered path (one MFMA GEMM launch per dense layer, ~2.3x the fused minibatch cost): " + "; ".join(why or ["shape outside the fused kernels"])
 
     # ---- checkpoints: AgentBase.save_or_load_agent (AgentBase.py:280-297) + the flat Adam state ------
     def save_or_load_agent(self, cwd: str, if_save: bool):
@@ -321,7 +371,7 @@ class AgentPPO(AgentBase):
             # `state` is the very tensor the last fused rollout of THIS env wrote as its copy of the final state, nobody has written
             # to it, and the env has not moved since: the live buffer already holds it (no copy-back launch)
             same = (tok is not None and tok[0] is self.last_state and tok[1] == self.last_state._version and tok[2] is env
-                    and tok[3] == getattr(env, "state_epoch", None))
+                    and tok[3] == getattr(env, "state_epoch", None) and tok[4] == (id(env.state), env.state._version))
             if not same:
                 env.state.copy_(state)             # the env owns the live state buffer; keep it authoritative
                 if hasattr(env, "state_epoch"):
@@ -356,7 +406,7 @@ class AgentPPO(AgentBase):
             # live buffer instead
             self.last_state = last_out if last_out is not None else env.state
             if last_out is not None:
-                self._last_state_token = (last_out, last_out._version, env, getattr(env, "state_epoch", None))
+                self._last_state_token = (last_out, last_out._version, env, getattr(env, "state_epoch", None), (id(env.state), env.state._version))
             self._rollout_cache = dict(states=states, values=values, next_value=next_value, last_state=self.last_state,
                                        key=self._value_cache_key(states, self.last_state))
             if self.fused_gae:
@@ -508,7 +558,9 @@ class AgentPPO(AgentBase):
         from .. import ops, parallel
         self._require_gpu("update_net")
         self._sync_modules()
-        ops.ppo_set_arith(self.ppo_arith)       # process-wide in the library: set at EVERY update, so that "auto" is the library default
+        # the minibatch kernels' arithmetic travels with every call (ERL_PPO_MODE: objective | arith << 8, ABI 17), not through the
+        # library's process-wide setting: two agents of one process keep their own `ppo_arith`
+        mode = self._objective | ({"auto": 0, "f32": 1, "split": 2}[self.ppo_arith] << 8)
         states, actions, logprobs, rewards, undones, unmasks = buffer
         H, N = rewards.shape
         dev = self.device
@@ -591,7 +643,7 @@ class AgentPPO(AgentBase):
                            c.state_std.data, self.state_dim, h1, h2, self.action_dim, states, actions, unmasks, logprobs,
                            advantages, reward_sums, ids, float(self.ratio_clip), self.lambda_entropy_value, self._slabs,
                            self._grads, self._adam_step + 1, float(self.learning_rate), float(self.clip_grad_norm), comm=comm,
-                           objective=self._objective, adv_stats=stats, adv_partials=adv_parts, n_partials=n_parts)
+                           objective=mode, adv_stats=stats, adv_partials=adv_parts, n_partials=n_parts)
             self._adam_step += update_times
         else:                           # data parallel through torch.distributed (gloo tests, ERL_DP_COLLECTIVE=torch)
             # raw pointers + direct C-ABI calls: the interpreter spends ~3 us per launch instead of ~10 (ptr checks, views)
@@ -610,7 +662,7 @@ class AgentPPO(AgentBase):
             lr, max_norm, stride = float(self.learning_rate), float(self.clip_grad_norm), self._stride
             for k in range(update_times):
                 rc = L.erl_ppo_step_f32(pf, pf + 4 * self._Pa, p_avg_a, p_std_a, p_avg_c, p_std_c, S_, h1, h2, A_, p_s, p_ac, p_um,
-                                        p_lp, p_adv, p_rs, H, N, p_ids + 8 * k * B, B, clip, lam_e, inv_batch, self._objective, p_slabs,
+                                        p_lp, p_adv, p_rs, H, N, p_ids + 8 * k * B, B, clip, lam_e, inv_batch, mode, p_slabs,
                                         n_slabs, sp)
                 rc = rc or L.erl_grad_reduce_f32(p_slabs, n_slabs, stride, p_g + 4 * k * stride, sp)
                 if rc:

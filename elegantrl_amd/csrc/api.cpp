@@ -102,19 +102,23 @@ static long g_k6_launch = 0;
 static bool g_k6_skip = false;
 static std::vector<hipEvent_t> g_k6_events;
 static hipEvent_t g_k6_open = nullptr;
-static unsigned long long *g_k6_span = nullptr;      // device: kK6SpanSlots x {min entry, max exit}
+static unsigned long long *g_k6_span = nullptr;      // device: kK6SpanSlots slots of kK6SpanWords u64 (layout: ppo_step.h, span_enter)
 static int g_k6_span_used = 0;
 constexpr int kK6SpanSlots = 8192;
+constexpr int kK6SpanWords = 16, kK6SpanPhases = 7;  // = kSpanWords, kSpanPhases of ppo_step.h
+static double g_k6_clock_mhz = 0.0, g_k6_wg_us = 0.0;            // of the last erl_k6_timing_read2: shader clock inside the sampled launches, a workgroup's own duration
+static double g_k6_phase_cycles[kK6SpanPhases] = {};             // ... mean shader cycles per phase of an actor workgroup's wave 0 (0: the kernel stamps none)
+static int g_k6_phase_wgs = 0;
 
 static void k6_span_reset()
 {
-    if (!g_k6_span && hipMalloc((void **)&g_k6_span, sizeof(unsigned long long) * 2 * kK6SpanSlots) != hipSuccess) {
+    if (!g_k6_span && hipMalloc((void **)&g_k6_span, sizeof(unsigned long long) * kK6SpanWords * kK6SpanSlots) != hipSuccess) {
         g_k6_span = nullptr;
         (void)hipGetLastError();
         return;
     }
-    std::vector<unsigned long long> init(2 * kK6SpanSlots);
-    for (int i = 0; i < kK6SpanSlots; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+    std::vector<unsigned long long> init((size_t)kK6SpanWords * kK6SpanSlots, 0ull);
+    for (int i = 0; i < kK6SpanSlots; ++i) init[(size_t)kK6SpanWords * i] = ~0ull;
     (void)hipMemcpy(g_k6_span, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
     g_k6_span_used = 0;
 }
@@ -132,7 +136,7 @@ unsigned long long *erl_k6_timing_begin(hipStream_t stream)
     if (g_k6_open) (void)hipEventDestroy(g_k6_open);
     g_k6_open = e;
     if (!g_k6_span || g_k6_span_used >= kK6SpanSlots) return nullptr;
-    return g_k6_span + 2 * g_k6_span_used++;
+    return g_k6_span + (size_t)kK6SpanWords * g_k6_span_used++;
 }
 
 // ... and right after
@@ -176,12 +180,23 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
         int dev = 0, khz = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
-        std::vector<unsigned long long> h(2 * (size_t)g_k6_span_used);
+        std::vector<unsigned long long> h((size_t)kK6SpanWords * g_k6_span_used);
         if (hipMemcpy(h.data(), g_k6_span, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
             int m = 0;
-            for (int i = 0; i < g_k6_span_used; ++i)
-                if (h[2 * i + 1] > h[2 * i]) { span += (double)(h[2 * i + 1] - h[2 * i]) / khz; ++m; }
+            double wall = 0.0, mem = 0.0, wgs = 0.0, pwgs = 0.0, ph[kK6SpanPhases] = {};
+            for (int i = 0; i < g_k6_span_used; ++i) {
+                const unsigned long long *q = h.data() + (size_t)kK6SpanWords * i;
+                if (q[1] > q[0]) { span += (double)(q[1] - q[0]) / khz; ++m; }
+                wall += (double)q[2]; mem += (double)q[3]; wgs += (double)q[4];
+                for (int k = 0; k < kK6SpanPhases; ++k) ph[k] += (double)q[5 + k];
+                pwgs += (double)q[5 + kK6SpanPhases];
+            }
             if (m && m != n) span *= (double)n / m;         // (slots that never ran: scale to the bracketed count)
+            // shader cycles per constant-rate tick x the tick rate = the clock the sampled launches ran at
+            g_k6_clock_mhz = wall > 0 ? mem / wall * (double)khz * 1e-3 : 0.0;
+            g_k6_wg_us = wgs > 0 ? wall / wgs / (double)khz * 1e3 : 0.0;
+            g_k6_phase_wgs = (int)pwgs;
+            for (int k = 0; k < kK6SpanPhases; ++k) g_k6_phase_cycles[k] = pwgs > 0 ? ph[k] / pwgs : 0.0;
         }
         k6_span_reset();
     }
@@ -192,6 +207,24 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
 }
 
 extern "C" int erl_k6_timing_read(double *total_ms, int *launches) { return erl_k6_timing_read2(total_ms, nullptr, launches); }
+
+// what the launches drained by the LAST erl_k6_timing_read2 say about the box: the shader clock they ran at (MHz: shader cycles per tick
+// of the constant-rate clock, summed over every workgroup's own entry-to-exit interval), a workgroup's mean duration (us), and -- for
+// kernels that stamp phases (ppo_step_s3_kernel) -- the mean shader cycles per phase of an actor workgroup's first wave
+// (phase_cycles[0 .. n_phases), n_phases <= 7: prologue | layer-1 forward | layer-2 forward | output layer + objective + backward |
+// staging + dW1 | staging + dW3 + staging | dW2 + logs + store drain); phase_workgroups = how many workgroups the means are over
+extern "C" int erl_k6_timing_clocks(double *shader_mhz, double *workgroup_us, double *phase_cycles, int max_phases, int *n_phases,
+                                    int *phase_workgroups)
+{
+    if (shader_mhz) *shader_mhz = g_k6_clock_mhz;
+    if (workgroup_us) *workgroup_us = g_k6_wg_us;
+    const int np = g_k6_phase_wgs > 0 ? kK6SpanPhases : 0;
+    if (phase_cycles)
+        for (int k = 0; k < np && k < max_phases; ++k) phase_cycles[k] = g_k6_phase_cycles[k];
+    if (n_phases) *n_phases = np;
+    if (phase_workgroups) *phase_workgroups = g_k6_phase_wgs;
+    return ERL_OK;
+}
 
 void erl_launch_null_kernel(hipStream_t stream);     // ppo_step.hip
 

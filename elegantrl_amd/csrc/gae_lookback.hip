@@ -317,16 +317,20 @@ bool erl_gae_lookback_usable(const float *rewards, const uint8_t *undones, const
     return (N % 4 == 0) && (f % 16 == 0) && (b % 4 == 0);
 }
 
-// Library-owned look-back table (one per device): [ticket counter: 256 B][granules].  Only gae_lookback_kernel writes
-// it; stale granules carry older nonces.  Allocated (and zeroed) on first use.
+// Library-owned look-back tables, one per (device, stream) that has launched the scan: [ticket counter: 256 B][granules].  Only
+// gae_lookback_kernel writes them; stale granules carry older nonces, and launches that share a table are ordered by its stream
+// (two agents on two streams of one device each get their own: round 4 kept ONE table per device and sent the second stream to
+// the memset path).  Allocated (and zeroed) on first use; beyond kLbMaxTables the caller's workspace + a memset serve.
 constexpr size_t kLbTableBytes = 256 + ((size_t)8 << 20);   // 8 MiB of granules: K * N <= 1M (e.g. 2048 x 65536 at T = 128)
+constexpr int kLbMaxTables = 16;
 struct LbTable {
     char *ptr = nullptr;
     uint32_t nonce = 1, ticket_base = 0;
+    int dev = -1;
     hipStream_t stream = nullptr;
-    bool used = false;
 };
-static LbTable g_lb_table[32];
+static LbTable g_lb_table[kLbMaxTables];
+static int g_lb_tables = 0;
 
 // Enqueues [memset +] kernel.  workspace layout (fallback path): [ticket: 256 B][slots: K*N*8 B][partials: nblk*24 B].
 // Returns the number of statistics partials (blocks) through *nparts and their location through *partials.
@@ -361,20 +365,21 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     // fast path: the library-owned table (no clearing); fallback: the caller's workspace, cleared by a memset
     LbTable *tab = nullptr;
     int dev = -1;
-    if (!getenv("ERL_GAE_LB_NO_TABLE") && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32 && 256 + slot_bytes <= kLbTableBytes) {
-        LbTable &t = g_lb_table[dev];
-        if (!t.ptr) {
+    if (!getenv("ERL_GAE_LB_NO_TABLE") && hipGetDevice(&dev) == hipSuccess && dev >= 0 && 256 + slot_bytes <= kLbTableBytes) {
+        for (int i = 0; i < g_lb_tables && !tab; ++i)
+            if (g_lb_table[i].dev == dev && g_lb_table[i].stream == stream) tab = &g_lb_table[i];
+        if (!tab && g_lb_tables < kLbMaxTables) {
             void *p = nullptr;
             if (hipMalloc(&p, kLbTableBytes) == hipSuccess) {
-                if (hipMemset(p, 0, kLbTableBytes) == hipSuccess) t.ptr = (char *)p;
-                else (void)hipFree(p);
+                if (hipMemset(p, 0, kLbTableBytes) == hipSuccess) {
+                    LbTable &t = g_lb_table[g_lb_tables++];
+                    t.ptr = (char *)p; t.dev = dev; t.stream = stream;
+                    tab = &t;
+                } else {
+                    (void)hipFree(p);
+                }
             }
             (void)hipGetLastError();
-        }
-        if (t.ptr && (!t.used || t.stream == stream)) {   // launches on the table must be ordered by ONE stream
-            t.used = true;
-            t.stream = stream;
-            tab = &t;
         }
     }
     if (tab) {

@@ -12,6 +12,8 @@ constexpr float kLogSqrt2PiN = 0.91893853320467274178f;
 
 struct NetDims {
     int n;                 // number of dense layers = hidden + 1
+    int n_act;             // layers 0 .. n_act - 1 are followed by GELU (default n - 1: every layer but the last; ActorFixSAC's encoder
+                           // -- build_mlp([S, *net_dims]) with a RAW last layer, elegantrl/agents/AgentSAC.py:204 -- has n - 2)
     int d[MAXL + 2];       // d[0] = S, d[1..n-1] hidden, d[n] = out
     int64_t oW[MAXL + 1], ob[MAXL + 1], oStd, count;
 };
@@ -20,6 +22,7 @@ bool make_dims(const int *dims, int n_dims, bool with_std, NetDims *nd)
 {
     if (!dims || n_dims < 2 || n_dims > MAXL + 2) return false;
     nd->n = n_dims - 1;
+    nd->n_act = nd->n - 1;
     int64_t o = 0;
     for (int i = 0; i < n_dims; ++i) {
         if (dims[i] < 1 || dims[i] > ERL_MAXN_WIDTH) return false;
@@ -370,7 +373,7 @@ int64_t ws_floats_forward(const NetDims &nd, int64_t rows)
 int forward(hipStream_t s, const NetDims &nd, const float *P, int64_t rows, float **act, float **gd)
 {
     for (int l = 0; l < nd.n; ++l) {
-        const bool hidden = l + 1 < nd.n;
+        const bool hidden = l < nd.n_act;
         int rc = dense_forward(s, act[l], P + nd.oW[l], P + nd.ob[l], act[l + 1], hidden && gd ? gd[l + 1] : nullptr, (int)rows,
                                nd.d[l + 1], nd.d[l], hidden);
         if (rc) return rc;
@@ -419,7 +422,7 @@ int backward(hipStream_t s, const NetDims &nd, const float *P, int64_t rows, flo
         if (G && (rc = dense_weight_grad(s, dZ, act[l], G + nd.oW[l], G + nd.ob[l], (int)rows, Nw, K, dw_scratch, cs_scratch))) return rc;
         if (l > 0) {
             float *dH = (dZ == tmpA) ? tmpB : tmpA;
-            if ((rc = dense_backward_input(s, dZ, P + nd.oW[l], dH, gd[l], false, (int)rows, Nw, K))) return rc;
+            if ((rc = dense_backward_input(s, dZ, P + nd.oW[l], dH, l - 1 < nd.n_act ? gd[l] : nullptr, false, (int)rows, Nw, K))) return rc;
             dZ = dH;
         } else if (dX0) {
             if ((rc = dense_backward_input(s, dZ, P + nd.oW[0], dX0, nullptr, acc_dx0, (int)rows, Nw, K))) return rc;

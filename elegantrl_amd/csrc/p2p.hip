@@ -70,8 +70,15 @@ int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *
         return rc;
     }
     c->poison = (uint32_t *)pw;
+    bool listed = false;
     for (auto &g : g_live)
-        if (!g) { g = c; break; }
+        if (!g) { g = c; listed = true; break; }
+    if (!listed) {      // a communicator that is not listed would keep its poison word after a reported fault: refuse it
+        (void)hipFree(p);
+        (void)hipFree(pw);
+        delete c;
+        ERL_REQUIRE(false, "erl_comm_p2p_create: more than %d live peer-to-peer communicators in one process", (int)(sizeof(g_live) / sizeof(g_live[0])));
+    }
     c->local = (char *)p;
     c->peer[rank] = c->local;
     memcpy(out_handle, &h, sizeof(h));

@@ -23,7 +23,7 @@ struct Ppo2Args {
     const double *adv_stats;         // nullptr: `advantages` are normalised already; else the raw sums of erl_gae_scan_f32 / the rollout epilogue
     const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
     const unsigned char *w1img[2];   // ... and W1 images (columns padded to 32 / 64); both or neither
-    unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): {min entry, max exit} on the constant-rate clock; nullptr = off
+    unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): this launch's slot of kSpanWords u64 (see span_enter); nullptr = off
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -88,17 +88,62 @@ __device__ __forceinline__ float adv_normalized(float adv, const AdvNorm &n)
     return n.on ? (adv - n.mean) / n.denom : adv;
 }
 
-// entry / exit of a workgroup on the device's constant-rate clock, folded into the launch's {min, max} slot (sampled launches only)
-__device__ __forceinline__ unsigned long long span_enter(const Ppo2Args &g)
+// entry / exit of a workgroup on the device's constant-rate clock, folded into the launch's slot (sampled launches only).  Slot layout
+// (kSpanWords u64 per sampled launch, api.cpp): [0] min entry, [1] max exit (constant-rate clock: first workgroup in to last workgroup
+// out), [2] sum over workgroups of exit - entry on the constant-rate clock, [3] the same on the SHADER clock (s_memtime: the ratio of
+// the two is the clock the kernel actually ran at -- the chip clocks to its power budget, MI355X_MICROARCH.md "DVFS give-back"),
+// [4] workgroups counted, [5 .. 5 + kSpanPhases) sums of per-phase shader cycles of the ACTOR workgroups' wave 0 (kernels that
+// stamp phases: ppo_step_s3_kernel), [5 + kSpanPhases] actor workgroups counted.
+constexpr int kSpanPhases = 7;
+constexpr int kSpanWords = 16;
+static_assert(6 + kSpanPhases <= kSpanWords, "span slot too small");
+struct SpanT {
+    unsigned long long wall, mem;
+};
+// phase stamps: wave 0's lane 0 parks the shader clock's low word in LDS (t[k], k >= 1: the end of phase k - 1; a phase is far shorter
+// than 2^32 cycles, so differences of low words are exact) -- held in scalar registers from stamp to kernel exit they cost the
+// minibatch kernel 20-50 more scalar-register spills (it runs at 104 of them)
+struct SpanStamps {
+    uint32_t *t;                  // LDS, kSpanPhases words
+};
+__device__ __forceinline__ unsigned long long erl_memtime()
 {
-    return g.span ? wall_clock64() : 0ull;        // wave-uniform: lives in a scalar register pair, no vector registers
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    return t;
 }
-__device__ __forceinline__ void span_exit(const Ppo2Args &g, unsigned long long t0)
+__device__ __forceinline__ SpanT span_enter(const Ppo2Args &g)
+{
+    SpanT t{0ull, 0ull};                          // wave-uniform: scalar register pairs, no vector registers
+    if (g.span) { t.wall = wall_clock64(); t.mem = erl_memtime(); }
+    return t;
+}
+// a phase boundary (sampled launches only: a scalar branch otherwise)
+#ifndef ERL_NO_SPAN_STAMPS
+#define SPAN_STAMP(st, k) do { if (g.span) { const uint32_t t_ = (uint32_t)erl_memtime(); if (threadIdx.x == 0) (st).t[k] = t_; } } while (0)
+#else      // A/B builds: the kernel without its phase stamps (what they cost the unsampled launches)
+#define SPAN_STAMP(st, k) do { } while (0)
+#endif
+__device__ __forceinline__ void span_exit(const Ppo2Args &g, SpanT t0, const SpanStamps *st = nullptr)
 {
     if (g.span && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
-        atomicMin(g.span, t0);
-        atomicMax(g.span + 1, (unsigned long long)wall_clock64());
+        const unsigned long long w1 = wall_clock64(), m1 = erl_memtime();
+        atomicMin(g.span, t0.wall);
+        atomicMax(g.span + 1, w1);
+        atomicAdd(g.span + 2, w1 - t0.wall);
+        atomicAdd(g.span + 3, m1 - t0.mem);
+        atomicAdd(g.span + 4, 1ull);
+        if (st) {
+            uint32_t prev = (uint32_t)t0.mem;
+#pragma unroll
+            for (int k = 1; k <= kSpanPhases; ++k) {
+                const uint32_t tk = k == kSpanPhases ? (uint32_t)m1 : st->t[k];
+                atomicAdd(g.span + 4 + k, (unsigned long long)(uint32_t)(tk - prev));
+                prev = tk;
+            }
+            atomicAdd(g.span + 5 + kSpanPhases, 1ull);
+        }
     }
 }
 

@@ -385,7 +385,7 @@ template <int NS_, int N1_, int N2_, bool VEC>
 __global__ __launch_bounds__(PNW * 64) void ppo_step2_kernel(Ppo2Args g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const unsigned long long t_span = span_enter(g);
+    const SpanT t_span = span_enter(g);
     if (blockIdx.y == 0) ppo_block<true, NS_, N1_, N2_, VEC>(g, smem);
     else ppo_block<false, NS_, N1_, N2_, VEC>(g, smem);
     span_exit(g, t_span);
@@ -460,12 +460,15 @@ extern "C" int erl_ppo_set_arith(int arith)
     return prev;
 }
 
-extern "C" int erl_ppo_arith_in_use(int S, int h1, int h2, int A)
+// the arithmetic a call gets: its own request (the mode word's arith bits), else the process-wide default
+int erl_ppo_arith_for_call(int S, int h1, int h2, int A, int arith_call)
 {
     if (erl_ppo_wd_supported(S, h1, h2, A)) return ERL_PPO_ARITH_SPLIT;      // the (256, h2) kernel exists in this arithmetic only
-    return (k6_form() != 8 && k6_arith_resolved() == ERL_PPO_ARITH_SPLIT && erl_ppo_s3_supported(S, h1, h2, A)) ? ERL_PPO_ARITH_SPLIT
-                                                                                                               : ERL_PPO_ARITH_F32;
+    const int want = (arith_call == ERL_PPO_ARITH_F32 || arith_call == ERL_PPO_ARITH_SPLIT) ? arith_call : k6_arith_resolved();
+    return (k6_form() != 8 && want == ERL_PPO_ARITH_SPLIT && erl_ppo_s3_supported(S, h1, h2, A)) ? ERL_PPO_ARITH_SPLIT : ERL_PPO_ARITH_F32;
 }
+
+extern "C" int erl_ppo_arith_in_use(int S, int h1, int h2, int A) { return erl_ppo_arith_for_call(S, h1, h2, A, ERL_PPO_ARITH_AUTO); }
 
 extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
 {
@@ -487,6 +490,8 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
                             const double *adv_stats, void *stream)
 {
+    const int arith_call = (objective >> 8) & 3;       // ERL_PPO_MODE(objective, arith): the call's own arithmetic (0: process default)
+    objective &= 0xff;
     ERL_REQUIRE(actor_params && critic_params && act_avg && act_std && cri_avg && cri_std && states && actions && unmasks &&
                     logprobs && advantages && reward_sums && ids && slabs,
                 "erl_ppo_step_f32: NULL tensor");
@@ -531,7 +536,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else
     // the fp32 32x32x2 one), 8 = always the 8-wave 16x16x4 kernel
     const int form = k6_form();
-    if (erl_ppo_arith_in_use(S, h1, h2, A) == ERL_PPO_ARITH_SPLIT)
+    if (erl_ppo_arith_for_call(S, h1, h2, A, arith_call) == ERL_PPO_ARITH_SPLIT)
         rc = (g.w2img[0] && g.w2img[1] && g.w1img[0] && g.w1img[1]) ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st);
     else if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 2 / 4 / 5
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);

@@ -446,14 +446,14 @@ constexpr int kS3Img1 = 128 * 384;
 constexpr int kS3W3 = 16 * 132 * 4;
 static_assert(kS3W3 >= 16 * PLD * 4, "dY^T overlays the W3 copy");
 static_assert(kS3Img2 >= 128 * PLD * 4, "H2^T (fp32, feature-major) overlays the W2 image");
-constexpr int kS3Small = (128 + 128 + 16 + 64 + 64 + QNW * 16 + 16) * 4;
+constexpr int kS3Small = (128 + 128 + 16 + 64 + 64 + QNW * 16 + 16 + 8) * 4;       // (the last 8 words: phase stamps of sampled launches)
 constexpr size_t kS3LdsBytes = (size_t)kS3Img2 + kS3Img1 + kS3W3 + kS3Small;
 static_assert(kS3LdsBytes <= 160 * 1024, "LDS budget");
 
 // PRE: the W2 image comes ready from memory (g.w2img: built by the update loop, refreshed by clip + Adam) by LDS-DMA under the
 // first layer; otherwise every workgroup splits W2 itself (stand-alone calls of erl_ppo_step_f32)
 template <bool ACTOR, int KXP, int N1, int N2, bool VEC, bool PRE>     // KXP: input tiles of 32 (1: S <= 32, 2: S <= 64); 0: S <= 8
-__device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
+__device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanStamps &sps)
 {
     constexpr bool TINY = KXP == 0;
     constexpr int KX = TINY ? 1 : KXP;
@@ -636,6 +636,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(c3[u].x), "+v"(c3[u].y), "+v"(c3[u].z), "+v"(c3[u].w));
     }
     lds_barrier();                                                   // (0a) images, biases, constants visible; RW3 zeroed; row tiles read
+    SPAN_STAMP(sps, 1);                                              // phase 0: prologue
     PROF_NV(2);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                                    // W3 copy [16][ld3], rows >= OUT zero; visible after (0b)
@@ -696,6 +697,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     if constexpr (PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the W2 image have landed
     else img_store<N1 * N2, CP2>(c2, IMG2, h2, tid);
     lds_barrier();                                                   // (0b) W2 image, W3 copy visible; every wave is done with the W1 image
+    SPAN_STAMP(sps, 2);                                              // phase 1: first layer forward (+ the W2 image's arrival)
     u8 *SA = IMG2, *SB = IMG1;
     {
         // the input goes to its place for dW1 right away (SB = the W1 image's bytes): 12 registers per k-step less from here on.
@@ -709,6 +711,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
         stage_s3<2 * KX, CP1, 0>(SB, Xs, col, hi);
     }
     fwd_s3<2 * N1, N2, CP2>(IMG2, s_b2, H1p, H1, H2, G2, m, hi);       // splits H1 into H1p on the way
+    SPAN_STAMP(sps, 3);                                              // phase 2: second layer forward
     PROF(4);
 
     // ---- output layer (fp32, as in ppo_step_w4_impl.h; H2[T][4 gq + j] is feature 32 T + 16 (gq >> 1) + 8 hi + 4 (gq & 1) + j here)
@@ -830,6 +833,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     bwd_s3<2 * N2, N1, CP2>(IMG2, dZ2p, G2, G1, dZ1p, lane);         // splits dZ2 into dZ2p on the way; dZ1 leaves split
     PROF(7);
     lds_barrier();                                                   // (1) every wave is done with the weight images and W3
+    SPAN_STAMP(sps, 4);                                              // phase 3: output layer, objective, backward (dZ2, dZ1)
     PROF(8);
 
     float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
@@ -856,6 +860,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     }
     PROF(10);
     lds_barrier();                                                   // (3) dZ1, X images consumed
+    SPAN_STAMP(sps, 5);                                              // phase 4: staging + dW1, db1
 
     // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2^T staged feature-major in fp32); the first half of
     //      H1 goes to SB meanwhile
@@ -913,6 +918,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem)
     lds_barrier();                                                   // (5) H2^T consumed
     stage_s3<2 * N2, CPH2, 0>(SA, dZ2p, col, hi);
     lds_barrier();                                                   // (6)
+    SPAN_STAMP(sps, 6);                                              // phase 5: staging + dW3, db3 + staging; phase 6 = dW2, db2, logs, store drain
     PROF(12);
 
     // ---- layer 2: dW2 = dZ2^T . H1, db2  (wave w: row tile w % N2; its column tiles pass by pass)
@@ -956,10 +962,11 @@ template <int KX, int N1, int N2, bool VEC, bool PRE>
 __global__ __launch_bounds__(QNT) void ppo_step_s3_kernel(Ppo2Args g)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_s3[];
-    const unsigned long long t_span = span_enter(g);
-    if (blockIdx.y == 0) ppo_block_s3<true, KX, N1, N2, VEC, PRE>(g, smem_s3);
-    else ppo_block_s3<false, KX, N1, N2, VEC, PRE>(g, smem_s3);
-    span_exit(g, t_span);
+    const SpanT t_span = span_enter(g);
+    SpanStamps sps{reinterpret_cast<uint32_t *>(smem_s3 + kS3LdsBytes - 32)};
+    if (blockIdx.y == 0) ppo_block_s3<true, KX, N1, N2, VEC, PRE>(g, smem_s3, sps);
+    else ppo_block_s3<false, KX, N1, N2, VEC, PRE>(g, smem_s3, sps);
+    span_exit(g, t_span, blockIdx.y == 0 ? &sps : nullptr);
 }
 
 template <int KX, int N1, int N2, bool VEC, bool PRE>

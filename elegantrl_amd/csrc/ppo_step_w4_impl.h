@@ -781,7 +781,7 @@ template <int KX, int N1, int N2, bool VEC>
 __global__ __launch_bounds__(QNT) void ppo_step_w4_kernel(Ppo2Args g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const unsigned long long t_span = span_enter(g);
+    const SpanT t_span = span_enter(g);
     if (blockIdx.y == 0) ppo_block_w4<true, KX, N1, N2, VEC>(g, smem);
     else ppo_block_w4<false, KX, N1, N2, VEC>(g, smem);
     span_exit(g, t_span);

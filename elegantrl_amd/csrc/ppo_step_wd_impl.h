@@ -1180,7 +1180,7 @@ template <int KX, int N2, int N3, bool VEC>
 __global__ __launch_bounds__(QNT) void ppo_step_wd_kernel(PpoWdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_wd[];
-    const unsigned long long t_span = span_enter(a.g);
+    const SpanT t_span = span_enter(a.g);
     if (blockIdx.y == 0) ppo_block_wd<true, KX, N2, N3, VEC>(a, smem_wd);
     else ppo_block_wd<false, KX, N2, N3, VEC>(a, smem_wd);
     span_exit(a.g, t_span);

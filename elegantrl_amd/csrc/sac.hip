@@ -31,7 +31,7 @@ struct SacDims {
     int64_t Pa, Pc;
 };
 
-bool make_sac_dims(int S, int A, const int *hidden, int n_hidden, int E, SacDims *d)
+bool make_sac_dims(int S, int A, const int *hidden, int n_hidden, int E, SacDims *d, int variant = ERL_SAC_ACTOR_SAC)
 {
     if (S < 1 || A < 1 || !hidden || n_hidden < 1 || n_hidden > MAXL || E < 1 || E > MAXE) return false;
     int dims[MAXL + 2];
@@ -39,6 +39,9 @@ bool make_sac_dims(int S, int A, const int *hidden, int n_hidden, int E, SacDims
     for (int i = 0; i < n_hidden; ++i) dims[i + 1] = hidden[i];
     dims[n_hidden + 1] = 2 * A;
     if (!make_dims(dims, n_hidden + 2, false, &d->actor)) return false;
+    // ActorFixSAC (AgentSAC.py:201-243): encoder_s = build_mlp([S, *net_dims]) keeps its last layer RAW; the two one-layer decoders
+    // (mean | log_std) are the rows [0, A) | [A, 2A) of one Linear(h, 2A) -- the same parameter count and layout as ActorSAC's net_a
+    if (variant == ERL_SAC_ACTOR_FIX) d->actor.n_act = n_hidden - 1;
     int e[2] = {S + A, hidden[0]};
     if (!make_dims(e, 2, false, &d->enc)) return false;
     int dd[MAXL + 2];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void concat_kernel(const float *__restrict__ s
 __global__ __launch_bounds__(256) void head_forward_kernel(const float *__restrict__ Y, const float *__restrict__ noise, uint64_t seed,
                                                            uint64_t counter, int A, int64_t B, float *__restrict__ act_t,
                                                            float *__restrict__ logprob, float *__restrict__ eps_out,
-                                                           const float *__restrict__ xs, int S, float *__restrict__ xa)
+                                                           const float *__restrict__ xs, int S, float *__restrict__ xa, int variant)
 {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
@@ -77,14 +80,23 @@ __global__ __launch_bounds__(256) void head_forward_kernel(const float *__restri
     float lp = 0.f;
     for (int a = 0; a < A; ++a) {
         const float mean = Y[b * 2 * A + a], ls = Y[b * 2 * A + A + a];
-        const float lsc = fminf(fmaxf(ls, -16.f), 2.f);
+        const float lsc = fminf(fmaxf(ls, variant == ERL_SAC_ACTOR_FIX ? -20.f : -16.f), 2.f);
         const float sd = expf(lsc);
         const float eps = noise ? noise[b * A + a] : philox_normal(seed, counter, (uint32_t)b, (uint32_t)a);
-        const float t = tanhf(mean + sd * eps);
+        const float u = mean + sd * eps;
+        const float t = tanhf(u);
         act_t[b * A + a] = t;
         if (xa) xa[b * (S + A) + S + a] = t;
         if (eps_out) eps_out[b * A + a] = eps;
-        lp += (-logf(sd) - kLogSqrt2PiS) - logf(-(t * t) + 1.000001f);
+        if (variant == ERL_SAC_ACTOR_FIX) {
+            // ActorFixSAC.get_action_logprob (AgentSAC.py:226-243): the log-prob AT the sample, -log_std - eps^2 / 2 - log sqrt(2 pi), and
+            // the tanh correction in its softplus form, -(log 2 - u - softplus(-2 u)) * 2 (nn.Softplus: beta 1, threshold 20)
+            const float x = -2.f * u;
+            const float sp = x > 20.f ? x : log1pf(expf(x));
+            lp += (-lsc - (eps * eps) * 0.5f - kLogSqrt2PiS) - (0.69314718055994530942f - u - sp) * 2.f;
+        } else {
+            lp += (-logf(sd) - kLogSqrt2PiS) - logf(-(t * t) + 1.000001f);
+        }
     }
     logprob[b] = lp;
 }
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void fillk_kernel(float *__restrict__ p, float
 __global__ __launch_bounds__(256) void head_backward_kernel(const float *__restrict__ Y, const float *__restrict__ act_t,
                                                             const float *__restrict__ eps, const float *__restrict__ dA, int ldA,
                                                             const float *__restrict__ alpha_log, int A, int64_t B,
-                                                            float *__restrict__ dY)
+                                                            float *__restrict__ dY, int variant)
 {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
@@ -204,12 +216,15 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float *__restr
     const float dlp = alpha / (float)B;                 // dL/dlogprob_b
     for (int a = 0; a < A; ++a) {
         const float ls = Y[b * 2 * A + A + a];
-        const float lsc = fminf(fmaxf(ls, -16.f), 2.f);
+        const float lo = variant == ERL_SAC_ACTOR_FIX ? -20.f : -16.f;
+        const float lsc = fminf(fmaxf(ls, lo), 2.f);
         const float sd = expf(lsc);
         const float t = act_t[b * A + a];
         const float one_m = 1.f - t * t;
-        const float du = dA[b * ldA + a] * one_m + dlp * (2.f * t * one_m / (one_m + 1e-6f));
-        const bool inside = ls >= -16.f && ls <= 2.f;   // clamp passes its gradient inside [min, max]
+        // d logprob / du: -d/du log(1 - t^2 + 1e-6) for ActorSAC; ActorFixSAC: -2 d/du (log 2 - u - softplus(-2 u)) = 2 tanh(u)
+        const float dlp_du = variant == ERL_SAC_ACTOR_FIX ? 2.f * t : 2.f * t * one_m / (one_m + 1e-6f);
+        const float du = dA[b * ldA + a] * one_m + dlp * dlp_du;
+        const bool inside = ls >= lo && ls <= 2.f;      // clamp passes its gradient inside [min, max]
         dY[b * 2 * A + a] = du;
         dY[b * 2 * A + A + a] = inside ? du * sd * eps[b * A + a] - dlp : 0.f;
     }
@@ -406,7 +421,8 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
                            const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r, int64_t B,
                            const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
                            float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
-                           int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, const ErlRingSample *ring, void *stream);
+                           int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, const ErlRingSample *ring,
+                           const ErlSacOptions *opt, void *stream);
 
 extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
                                   float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
@@ -420,7 +436,25 @@ extern "C" int erl_sac_update_f32(float *actor_params, float *critic_params, flo
     return sac_update_impl(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S, A, hidden,
                            n_hidden, E, state, action, reward, undone, unmask, next_state, is_weight, td_error_out, cum_reward, lambda_fit_cum_r, B,
                            eps_next, eps_cur, seed, counter, gamma, target_entropy, tau, lr, beta1, beta2, eps_adam, max_norm, step, objs_out,
-                           workspace, workspace_bytes, nullptr, stream);
+                           workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+// erl_sac_update_f32 with the options of AgentModSAC (include/erl_hip.h, ErlSacOptions): ActorFixSAC's head, the actor step skipped by
+// the two-time-scale rule, the actor's own Adam step count, the actor target's soft update
+extern "C" int erl_sac_update_opt_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
+                                      float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
+                                      const int *hidden, int n_hidden, int E, const float *state, const float *action,
+                                      const float *reward, const float *undone, const float *unmask, const float *next_state,
+                                      const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r, int64_t B,
+                                      const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
+                                      float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                                      int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, const ErlSacOptions *opt,
+                                      void *stream)
+{
+    return sac_update_impl(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S, A, hidden,
+                           n_hidden, E, state, action, reward, undone, unmask, next_state, is_weight, td_error_out, cum_reward, lambda_fit_cum_r, B,
+                           eps_next, eps_cur, seed, counter, gamma, target_entropy, tau, lr, beta1, beta2, eps_adam, max_norm, step, objs_out,
+                           workspace, workspace_bytes, nullptr, opt, stream);
 }
 
 // ReplayBuffer.sample + the step from one call (include/erl_hip.h): in the fused step the gather rides in the first launch
@@ -440,7 +474,7 @@ extern "C" int erl_sac_update_ring_f32(float *actor_params, float *critic_params
     return sac_update_impl(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S, A, hidden,
                            n_hidden, E, state, action, reward, undone, unmask, next_state, nullptr, nullptr, nullptr, 0.f, B, eps_next, eps_cur, seed,
                            counter, gamma, target_entropy, tau, lr, beta1, beta2, eps_adam, max_norm, step, objs_out, workspace, workspace_bytes, ring,
-                           stream);
+                           nullptr, stream);
 }
 
 static int sac_update_impl(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
@@ -450,13 +484,19 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
                            const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r, int64_t B,
                            const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
                            float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
-                           int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, const ErlRingSample *ring, void *stream)
+                           int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, const ErlRingSample *ring,
+                           const ErlSacOptions *opt, void *stream)
 {
     ERL_REQUIRE(actor_params && critic_params && target_params && alpha_log && actor_m && actor_v && critic_m && critic_v && alpha_m &&
                     alpha_v && state && action && reward && undone && unmask && next_state && objs_out && workspace,
                 "erl_sac_update_f32: NULL tensor");
+    const int variant = opt ? opt->actor_variant : ERL_SAC_ACTOR_SAC;
+    const bool update_actor = opt ? opt->update_actor != 0 : true;
+    const int32_t actor_step = opt && opt->actor_step > 0 ? opt->actor_step : step;
+    float *actor_target = opt ? opt->actor_target_params : nullptr;
+    ERL_REQUIRE(variant == ERL_SAC_ACTOR_SAC || variant == ERL_SAC_ACTOR_FIX, "erl_sac_update_opt_f32: unknown actor_variant %d", variant);
     SacDims d;
-    ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, E, &d), "erl_sac_update_f32: unsupported dims");
+    ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, E, &d, variant), "erl_sac_update_f32: unsupported dims");
     ERL_REQUIRE(B >= 1 && B < (1LL << 24) && step >= 1, "erl_sac_update_f32: bad argument");
     ERL_REQUIRE(lambda_fit_cum_r == 0.f || cum_reward, "erl_sac_update_f32: lambda_fit_cum_r != 0 needs the batch's cum_reward");
     ERL_REQUIRE(workspace_bytes >= erl_sac_workspace_bytes(S, A, hidden, n_hidden, E, B), "erl_sac_update_f32: workspace too small");
@@ -466,7 +506,9 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
     // Off-policy batch sizes with two hidden layers up to 256 wide (config 3): the fused step, 12 launches (sac_fused.hip).
     // ERL_SAC_FUSED=0 keeps the layered step below (A/B runs); lambda_fit_cum_r != 0 (off by default) is layered only.
     static const bool fused_on = [] { const char *e = getenv("ERL_SAC_FUSED"); return !(e && atoi(e) == 0); }();
-    if (fused_on && lambda_fit_cum_r == 0.f && erl_sac_fused_supported(S, A, hidden, n_hidden, E, B)) {
+    // (the fused step implements ActorSAC's head with every optimiser on one step count: AgentModSAC's options take the layered step)
+    const bool plain = variant == ERL_SAC_ACTOR_SAC && update_actor && actor_step == step && !actor_target;
+    if (fused_on && plain && lambda_fit_cum_r == 0.f && erl_sac_fused_supported(S, A, hidden, n_hidden, E, B)) {
         const int64_t aoff[6] = {d.actor.oW[0], d.actor.ob[0], d.actor.oW[1], d.actor.ob[1], d.actor.oW[2], d.actor.ob[2]};
         const int64_t coff[8] = {d.enc.oW[0], d.enc.ob[0], d.enc.count, d.dec.oW[0], d.dec.ob[0], d.dec.oW[1], d.dec.ob[1], d.dec.count};
         return erl_sac_update_fused(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m, alpha_v, S,
@@ -490,7 +532,7 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
     float *aact[MAXL + 2], *agd[MAXL + 2];
     for (int l = 0; l <= d.actor.n; ++l) {
         aact[l] = ws.take(B * d.actor.d[l]);
-        agd[l] = (l >= 1 && l < d.actor.n) ? ws.take(B * d.actor.d[l]) : nullptr;
+        agd[l] = (l >= 1 && l <= d.actor.n_act) ? ws.take(B * d.actor.d[l]) : nullptr;      // GELU' of the layers that have one
     }
     CriticWs cw;
     ERL_REQUIRE(carve_critic(ws, d, B, &cw), "erl_sac_update_f32: workspace layout");
@@ -513,7 +555,7 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
     aact[0] = const_cast<float *>(next_state);                      // the input layer reads the sample in place
     if ((rc = forward(s, d.actor, actor_params, B, aact, nullptr))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_next, seed, 2 * counter, A, B, act_t, lp_next,
-                       (float *)nullptr, next_state, S, xa);
+                       (float *)nullptr, next_state, S, xa, variant);
     if ((rc = critic_forward(s, d, target_params, B, xa, cw, false))) return rc;
     hipLaunchKernelGGL(q_label_kernel, rows_grid, blk, 0, s, cw.q, E, B, reward, undone, lp_next, alpha_log, gamma, label);
 
@@ -554,7 +596,7 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
     aact[0] = const_cast<float *>(state);
     if ((rc = forward(s, d.actor, actor_params, B, aact, agd))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], eps_cur, seed, 2 * counter + 1, A, B, act_t, lp_cur,
-                       eps_used, state, S, xa);                 // xa = [state | action_pg] for step (4)
+                       eps_used, state, S, xa, variant);        // xa = [state | action_pg] for step (4)
     // obj_alpha = mean(alpha_log * (target_entropy - logprob)):  d/dalpha_log = target_entropy - mean(logprob)
     {
         const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -562,6 +604,13 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
                            eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
     }
 
+    if (!update_actor) {
+        // AgentModSAC's two-time-scale rule skipped the actor this step (AgentSAC.py:152-158): alpha is clamped as always (:146-147),
+        // obj_actor is nan (:158), actor / actor target / their Adam state stay as they are
+        hipLaunchKernelGGL(clamp_alpha_kernel, dim3(1), dim3(64), 0, s, alpha_log);
+        hipLaunchKernelGGL(fillk_kernel, dim3(1), blk, 0, s, objs_out + 1, __builtin_nanf(""), (int64_t)1);
+        ERL_LAUNCH_CHECK("erl_sac_update_opt_f32");
+    }
     // ---- (4) actor objective against the TARGET ensemble's mean, backward into the action, head, actor   (:82-85)
     if ((rc = critic_forward(s, d, target_params, B, xa, cw, true))) return rc;
     hipLaunchKernelGGL(actor_obj_kernel, dim3(1), blk, 0, s, cw.q, E, B, lp_cur, alpha_log, objs_out + 1);
@@ -577,15 +626,17 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
     }
     if ((rc = dense_backward_input(s, dEnc, target_params, dxa, nullptr, false, (int)B, d.enc.d[1], S + A))) return rc;   // dL/d[state | action]
     // dL/daction = the action columns of dxa, read in place (row stride S + A)
-    hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dxa + S, S + A, alpha_log, A, B, dHead);
+    hipLaunchKernelGGL(head_backward_kernel, rows_grid, blk, 0, s, aact[d.actor.n], act_t, eps_used, dxa + S, S + A, alpha_log, A, B, dHead, variant);
     hipLaunchKernelGGL(clamp_alpha_kernel, dim3(1), dim3(64), 0, s, alpha_log);                  // after alpha was read (:80-81)
     if ((rc = backward(s, d.actor, actor_params, B, aact, agd, dHead, g_actor, cs_scr, nullptr, false, tmpA, tmpB))) return rc;
     {
         const int64_t off = 0, len = d.Pa;
-        if ((rc = erl_clip_adam_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, nullptr, step, lr, beta1, beta2, eps_adam,
+        if ((rc = erl_clip_adam_f32(actor_params, g_actor, actor_m, actor_v, &off, &len, 1, nullptr, actor_step, lr, beta1, beta2, eps_adam,
                                     max_norm, 1.0f, stream)))
             return rc;
     }
+    if (actor_target)      // AgentModSAC: soft_update(act_target, act, tau) after the actor's step (AgentSAC.py:156)
+        hipLaunchKernelGGL(soft_update_kernel, dim3(grid1d(d.Pa)), blk, 0, s, actor_target, actor_params, tau, d.Pa);
     ERL_LAUNCH_CHECK("erl_sac_update_f32");
 }
 
@@ -632,13 +683,37 @@ extern "C" int erl_sac_rollout_pendulum_f32(const float *actor_params, const int
 
 // ActorSAC.get_action for the off-policy rollout (AgentSAC.py:179-185): action = tanh(mean + std * eps); state_out (may be NULL):
 // the rollout's `states[t] = state` (AgentBase.py:145) written by the same launch
+static int sac_explore_impl(const float *actor_params, int S, int A, const int *hidden, int n_hidden, const float *state, int64_t N,
+                            const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *state_out, void *workspace,
+                            int64_t workspace_bytes, int variant, void *stream);
+
 extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden, const float *state,
                                           int64_t N, const float *noise, uint64_t seed, uint64_t counter, float *action_out,
                                           float *state_out, void *workspace, int64_t workspace_bytes, void *stream)
 {
+    return sac_explore_impl(actor_params, S, A, hidden, n_hidden, state, N, noise, seed, counter, action_out, state_out, workspace, workspace_bytes,
+                            ERL_SAC_ACTOR_SAC, stream);
+}
+
+// ... with the actor variant named: ERL_SAC_ACTOR_FIX = ActorFixSAC.get_action (AgentSAC.py:217-224: raw last encoder layer, log_std
+// clamped to [-20, 2]) for AgentModSAC's rollout
+extern "C" int erl_sac_explore_action_opt_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden, const float *state,
+                                              int64_t N, const float *noise, uint64_t seed, uint64_t counter, float *action_out,
+                                              float *state_out, void *workspace, int64_t workspace_bytes, int actor_variant, void *stream)
+{
+    ERL_REQUIRE(actor_variant == ERL_SAC_ACTOR_SAC || actor_variant == ERL_SAC_ACTOR_FIX, "erl_sac_explore_action_opt_f32: unknown actor_variant %d",
+                actor_variant);
+    return sac_explore_impl(actor_params, S, A, hidden, n_hidden, state, N, noise, seed, counter, action_out, state_out, workspace, workspace_bytes,
+                            actor_variant, stream);
+}
+
+static int sac_explore_impl(const float *actor_params, int S, int A, const int *hidden, int n_hidden, const float *state, int64_t N,
+                            const float *noise, uint64_t seed, uint64_t counter, float *action_out, float *state_out, void *workspace,
+                            int64_t workspace_bytes, int variant, void *stream)
+{
     ERL_REQUIRE(actor_params && state && action_out && workspace, "erl_sac_explore_action_f32: NULL tensor");
     SacDims d;
-    ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, 1, &d), "erl_sac_explore_action_f32: unsupported dims");
+    ERL_REQUIRE(make_sac_dims(S, A, hidden, n_hidden, 1, &d, variant), "erl_sac_explore_action_f32: unsupported dims");
     ERL_REQUIRE(N >= 1 && N < (1LL << 31), "erl_sac_explore_action_f32: bad N");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -646,7 +721,7 @@ extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int 
     // two hidden layers up to 256 wide, N <= 4096 rows (config 3: 64 envs): one launch, the fused step's actor kernel (sac_fused.hip);
     // ERL_SAC_FUSED=0 keeps the layered form below
     static const bool fused_on = [] { const char *e = getenv("ERL_SAC_FUSED"); return !(e && atoi(e) == 0); }();
-    if (fused_on && erl_sac_fused_supported(S, A, hidden, n_hidden, 1, N)) {
+    if (fused_on && variant == ERL_SAC_ACTOR_SAC && erl_sac_fused_supported(S, A, hidden, n_hidden, 1, N)) {
         float *lp_s = ws.take(N);
         ERL_REQUIRE(lp_s != nullptr, "erl_sac_explore_action_f32: workspace too small");
         const int64_t aoff[6] = {d.actor.oW[0], d.actor.ob[0], d.actor.oW[1], d.actor.ob[1], d.actor.oW[2], d.actor.ob[2]};
@@ -662,6 +737,6 @@ extern "C" int erl_sac_explore_action_f32(const float *actor_params, int S, int 
         return rc;
     if ((rc = forward(s, d.actor, actor_params, N, aact, nullptr))) return rc;
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)erl_cdiv(N, 256)), dim3(256), 0, s, aact[d.actor.n], noise, seed, counter, A, N,
-                       action_out, lp, (float *)nullptr, (const float *)nullptr, S, (float *)nullptr);
+                       action_out, lp, (float *)nullptr, (const float *)nullptr, S, (float *)nullptr, variant);
     ERL_LAUNCH_CHECK("erl_sac_explore_action_f32");
 }

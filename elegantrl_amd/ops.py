@@ -22,7 +22,9 @@ _workspaces = {}
 
 
 def _workspace(device: th.device, nbytes: int) -> TEN:
-    key = (device.type, device.index)
+    """scratch block for a launch on the CURRENT stream of `device`: keyed by (device, stream), so that two agents driving two
+    streams of one device never share scratch (launches that share a block are ordered by their stream)"""
+    key = (device.type, device.index, stream_ptr())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = th.empty(max(nbytes, 1 << 22), dtype=th.uint8, device=device)
@@ -562,8 +564,11 @@ def mlpn_ppo_step_discrete(actor_params: TEN, critic_params: TEN, act_avg: TEN, 
 class SacSpec:
     """shapes of ActorSAC / CriticEnsemble as flat fp32 blocks (include/erl_hip.h)."""
 
-    def __init__(self, S: int, A: int, hidden: Sequence[int], num_ensembles: int):
+    def __init__(self, S: int, A: int, hidden: Sequence[int], num_ensembles: int, actor_variant: int = 0):
+        """actor_variant: _hip.SAC_ACTOR_SAC (ActorSAC) or _hip.SAC_ACTOR_FIX (AgentModSAC's ActorFixSAC: same block sizes, a raw last
+        encoder layer and the two one-layer decoders as the two row halves of the head)"""
         self.S, self.A, self.hidden, self.E = int(S), int(A), [int(h) for h in hidden], int(num_ensembles)
+        self.actor_variant = int(actor_variant)
         self._c = (ctypes.c_int * len(self.hidden))(*self.hidden)
         pa, pc = ctypes.c_int64(0), ctypes.c_int64(0)
         check(lib().erl_sac_param_counts(self.S, self.A, self._c, len(self.hidden), self.E, ctypes.byref(pa), ctypes.byref(pc)),
@@ -577,6 +582,12 @@ class SacSpec:
             out += [(f"net_s.{2 * i}.weight", o, (d_out, d_in)), (f"net_s.{2 * i}.bias", o + d_out * d_in, (d_out,))]
             o += d_out * d_in + d_out
         d_in, d_out = self.hidden[-1], 2 * self.A
+        if self.actor_variant:        # ActorFixSAC: encoder_s.* | decoder_a_avg = rows [0, A), decoder_a_std = rows [A, 2A) of the head block
+            A = self.A
+            out = [(n.replace("net_s.", "encoder_s."), off, shp) for n, off, shp in out]
+            out += [("decoder_a_avg.0.weight", o, (A, d_in)), ("decoder_a_std.0.weight", o + A * d_in, (A, d_in)),
+                    ("decoder_a_avg.0.bias", o + d_out * d_in, (A,)), ("decoder_a_std.0.bias", o + d_out * d_in + A, (A,))]
+            return out
         out += [("net_a.0.weight", o, (d_out, d_in)), ("net_a.0.bias", o + d_out * d_in, (d_out,))]
         return out
 
@@ -600,7 +611,7 @@ def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: T
                step: int, *, gamma: float, target_entropy: float, tau: float, lr: float, max_norm: float, objs_out: TEN,
                noises: Optional[Tuple[TEN, TEN]] = None, seed: int = 0, counter: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
                is_weight: Optional[TEN] = None, td_error_out: Optional[TEN] = None, cum_reward: Optional[TEN] = None,
-               lambda_fit_cum_r: float = 0.0) -> None:
+               lambda_fit_cum_r: float = 0.0, update_actor: bool = True, actor_step: int = 0, actor_target: Optional[TEN] = None) -> None:
     """one AgentSAC.update_objectives step after the sample; `moments` = (actor_m, actor_v, critic_m, critic_v, alpha_m,
     alpha_v); `batch` = (state, action, reward, undone, unmask, next_state); objs_out: float32[2] on the device.
     `cum_reward` (B,) + `lambda_fit_cum_r`: the critic's fit-the-batch's-mean-return term (AgentSAC.py:66-68)."""
@@ -609,6 +620,18 @@ def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: T
     ws = _workspace(state.device, spec.workspace_bytes(B))
     n_next, n_cur = (None, None) if noises is None else noises
     f32 = th.float32
+    if spec.actor_variant or not update_actor or actor_step or actor_target is not None:
+        # AgentModSAC's step (include/erl_hip.h, ErlSacOptions): ActorFixSAC's head, the actor skipped by the two-time-scale rule, the
+        # actor optimiser's own step count, the actor target's soft update
+        opt = _SacOptions(spec.actor_variant, int(bool(update_actor)), int(actor_step), 0, ptr(actor_target, f32))
+        check(lib().erl_sac_update_opt_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
+                                           spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ptr(state, f32), ptr(action, f32),
+                                           ptr(reward, f32), ptr(undone, f32), ptr(unmask, f32), ptr(next_state, f32), ptr(is_weight),
+                                           ptr(td_error_out), ptr(cum_reward), float(lambda_fit_cum_r), B, ptr(n_next), ptr(n_cur),
+                                           seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), gamma, target_entropy, tau, lr, betas[0], betas[1], eps,
+                                           max_norm, step, ptr(objs_out, f32), ptr(ws), ws.numel(), ctypes.byref(opt), stream_ptr()),
+              "erl_sac_update_opt_f32")
+        return
     check(lib().erl_sac_update_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
                                    spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ptr(state, f32), ptr(action, f32),
                                    ptr(reward, f32), ptr(undone, f32), ptr(unmask, f32), ptr(next_state, f32), ptr(is_weight), ptr(td_error_out),
@@ -616,6 +639,11 @@ def sac_update(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: T
                                    ptr(n_cur), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), gamma, target_entropy, tau, lr, betas[0],
                                    betas[1], eps, max_norm, step, ptr(objs_out, f32), ptr(ws), ws.numel(), stream_ptr()),
           "erl_sac_update_f32")
+
+
+class _SacOptions(ctypes.Structure):        # include/erl_hip.h ErlSacOptions
+    _fields_ = [("actor_variant", ctypes.c_int32), ("update_actor", ctypes.c_int32), ("actor_step", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("actor_target_params", ctypes.c_void_p)]
 
 
 class _RingSample(ctypes.Structure):        # include/erl_hip.h ErlRingSample
@@ -653,6 +681,13 @@ def sac_explore_action(spec: SacSpec, actor: TEN, state: TEN, *, noise: Optional
     N = state.shape[0]
     out = th.empty((N, spec.A), dtype=th.float32, device=state.device) if out is None else out
     ws = _workspace(state.device, spec.workspace_bytes(N))
+    if spec.actor_variant:
+        check(lib().erl_sac_explore_action_opt_f32(ptr(actor, th.float32), spec.S, spec.A, spec._c, len(spec.hidden), ptr(state, th.float32), N,
+                                                   ptr(noise), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), ptr(out, th.float32),
+                                                   ptr(out_state, th.float32) if out_state is not None else None, ptr(ws), ws.numel(),
+                                                   spec.actor_variant, stream_ptr()),
+              "erl_sac_explore_action_opt_f32")
+        return out
     check(lib().erl_sac_explore_action_f32(ptr(actor, th.float32), spec.S, spec.A, spec._c, len(spec.hidden), ptr(state, th.float32), N,
                                            ptr(noise), seed & (2 ** 64 - 1), counter & (2 ** 64 - 1), ptr(out, th.float32),
                                            ptr(out_state, th.float32) if out_state is not None else None, ptr(ws), ws.numel(), stream_ptr()),

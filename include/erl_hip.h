@@ -10,8 +10,8 @@
  * Conventions
  *  - plain C types only: raw device pointers, sizes, scalars, an opaque hipStream_t passed as void*.
  *  - every tensor is caller-allocated, caller-owned device memory (torch tensors in practice).  The library
- *    itself owns only: a last-error string, an RCCL communicator behind erl_comm_* handles, and one 8 MiB per-device
- *    look-back table for the single-pass GAE scan (allocated on first use; see ERL_GAE_ALGO_LOOKBACK).
+ *    itself owns only: a last-error string, an RCCL communicator behind erl_comm_* handles, and one 8 MiB look-back table
+ *    per (device, stream) that launches the single-pass GAE scan (allocated on first use, at most 16; see ERL_GAE_ALGO_LOOKBACK).
  *  - all work is enqueued on `stream`; nothing synchronises the host.
  *  - layout at the seam is the reference's: time-major (H, N, .) row-major contiguous, fp32 values,
  *    1-byte flags (torch.bool), int64 indices.
@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 16
+#define ERL_ABI_VERSION 17
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -275,7 +275,10 @@ ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *cri
 #define ERL_PPO_OBJ_REFERENCE 0   /* AgentPPO.py:199   surrogate = adv*ratio*where(adv > 0, 1-clip, 1+clip) */
 #define ERL_PPO_OBJ_CANONICAL 1   /* helloworld_PPO_single_file.py:337-339   min(adv*ratio, adv*clamp(ratio, 1-clip, 1+clip)) */
 #define ERL_PPO_OBJ_A2C 2         /* AgentA2C.update_objectives (AgentPPO.py:296-303)   mean(adv * logp_a), no clip / mask / entropy */
-/* Arithmetic of K6's five large products (both forward layers, the backward through W2, dW1, dW2), process-wide:
+/* Arithmetic of K6's five large products (both forward layers, the backward through W2, dW1, dW2).  PER CALL since ABI 17: the
+ * `objective` argument of erl_ppo_step_f32 / erl_ppo_update_f32 / erl_ppo_update_dp_f32 is a mode word, ERL_PPO_MODE(objective, arith) =
+ * objective | arith << 8; arith = ERL_PPO_ARITH_AUTO (a bare objective) takes the process-wide default that erl_ppo_set_arith sets, so
+ * two agents of one process no longer share a setting:
  *   ERL_PPO_ARITH_F32    v_mfma_f32_32x32x2_f32 on fp32 operands;
  *   ERL_PPO_ARITH_SPLIT  every fp32 operand split into three bf16 parts (exactly: h + m + l == x), six partial products per
  *                        product on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- fp32-equivalent (csrc/ppo_step_s3_impl.h);
@@ -285,6 +288,7 @@ ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *cri
 #define ERL_PPO_ARITH_AUTO 0
 #define ERL_PPO_ARITH_F32 1
 #define ERL_PPO_ARITH_SPLIT 2
+#define ERL_PPO_MODE(objective, arith) ((objective) | ((arith) << 8))
 ERL_API int erl_ppo_set_arith(int arith);
 ERL_API int erl_ppo_arith_in_use(int S, int h1, int h2, int A);   /* ERL_PPO_ARITH_F32 or _SPLIT for this shape under the current setting */
 ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
@@ -523,6 +527,24 @@ typedef struct ErlRingSample {
     int64_t *out_ids0, *out_ids1;
 } ErlRingSample;
 
+/* AgentModSAC (elegantrl/agents/AgentSAC.py:89-165) on the same step: ErlSacOptions names what differs from AgentSAC (ABI 17).
+ *   actor_variant        ERL_SAC_ACTOR_SAC = ActorSAC (:167-199); ERL_SAC_ACTOR_FIX = ActorFixSAC (:201-243): encoder build_mlp([S, *hidden])
+ *                        with a RAW last layer, two one-layer decoders = rows [0, A) (mean) | [A, 2A) (log_std) of the same Linear(h, 2A)
+ *                        block, log_std clamped to [-20, 2], log-prob AT the sample with the softplus form of the tanh correction
+ *   update_actor         0: the two-time-scale rule (:148-158) skips the actor this step -- objs_out[1] = nan, alpha still clamped
+ *   actor_step           the actor optimiser's own 1-based Adam step (it steps only when the actor is updated); <= 0: `step`
+ *   actor_target_params  soft_update(act_target, act, tau) after the actor's step (:156); NULL: none
+ * These take the layered step (dense layers on the library's MFMA GEMMs); erl_sac_update_f32 == a NULL options pointer. */
+#define ERL_SAC_ACTOR_SAC 0
+#define ERL_SAC_ACTOR_FIX 1
+typedef struct ErlSacOptions {
+    int32_t actor_variant;
+    int32_t update_actor;
+    int32_t actor_step;
+    int32_t reserved;
+    float *actor_target_params;
+} ErlSacOptions;
+
 ERL_API int erl_sac_param_counts(int S, int A, const int *hidden, int n_hidden, int E, int64_t *actor_count,
                          int64_t *critic_count);
 ERL_API int64_t erl_sac_workspace_bytes(int S, int A, const int *hidden, int n_hidden, int E, int64_t B);
@@ -535,6 +557,15 @@ ERL_API int erl_sac_update_f32(float *actor_params, float *critic_params, float 
                        float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam,
                        float max_norm, int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes,
                        void *stream);
+ERL_API int erl_sac_update_opt_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log,
+                           float *actor_m, float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v,
+                           int S, int A, const int *hidden, int n_hidden, int E, const float *state, const float *action,
+                           const float *reward, const float *undone, const float *unmask, const float *next_state,
+                           const float *is_weight, float *td_error_out, const float *cum_reward, float lambda_fit_cum_r,
+                           int64_t B, const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter,
+                           float gamma, float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam,
+                           float max_norm, int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes,
+                           const ErlSacOptions *opt, void *stream);
 /* The off-policy rollout of AgentBase._explore_vec_env (elegantrl/agents/AgentBase.py:130-170) on the device-resident SynVecEnv as ONE
  * launch: H x [ActorSAC.get_action (AgentSAC.py:179-185), states[t] = state, actions[t] = action, env.step, reward / flag stores], then
  * `rewards *= reward_scale` and the two logical_not -- out_undones / out_unmasks are !terminal / !truncate.  A 16-env tile per workgroup
@@ -569,6 +600,11 @@ ERL_API int erl_sac_update_ring_f32(float *actor_params, float *critic_params, f
 ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
                                float *action_out, float *state_out, void *workspace, int64_t workspace_bytes, void *stream);
+/* ... with the actor variant named (ERL_SAC_ACTOR_FIX: ActorFixSAC.get_action, AgentSAC.py:217-224).  ABI 17. */
+ERL_API int erl_sac_explore_action_opt_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
+                                   const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
+                                   float *action_out, float *state_out, void *workspace, int64_t workspace_bytes,
+                                   int actor_variant, void *stream);
 
 /* measurement hook (bench.py's `roofline`; no reference counterpart): every_nth > 0 makes erl_ppo_step_f32 time every n-th K6
  * launch (1 = every launch, 0 = off) two ways -- a HIP-event bracket on the launch stream (contains the dispatch and completion
@@ -581,6 +617,15 @@ ERL_API void erl_k6_timing_enable(int every_nth);
 ERL_API int erl_k6_timing_read(double *total_ms, int *launches);
 ERL_API int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launches);
 ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median_us);
+/* What the launches drained by the LAST erl_k6_timing_read2 say about the box (ABI 17): shader_mhz = the clock the sampled launches
+ * actually ran at (shader cycles per tick of the constant-rate clock, summed over every workgroup's own entry-to-exit interval: the
+ * chip clocks to its power budget, so two boxes -- or two kernels on one box -- do not run the same clock); workgroup_us = a
+ * workgroup's mean duration; phase_cycles[0 .. *n_phases) (at most max_phases written; *n_phases = 0 for kernels that stamp no
+ * phases) = mean shader cycles per phase of an actor workgroup's first wave in ppo_step_s3_kernel: prologue | first layer forward |
+ * second layer forward | output layer + objective + backward | staging + dW1 | staging + dW3 + staging | dW2 + logs + store drain;
+ * phase_workgroups = the number of workgroups the means are over.  Any pointer may be NULL. */
+ERL_API int erl_k6_timing_clocks(double *shader_mhz, double *workgroup_us, double *phase_cycles, int max_phases, int *n_phases,
+                         int *phase_workgroups);
 
 /* ---------------------------------------------------------------------------------------------
  * GPU-resident synthetic environments for measurement; they implement the

@@ -403,6 +403,122 @@ def make_sac(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed, lambd
     print("wrote", path, "objs", objs)
 
 
+def make_sac_mod(tag, *, N, S, A, rows, net_dims, batch_size, n_updates, seed):
+    """The reference's AgentModSAC (elegantrl/agents/AgentSAC.py:89-165) with its ActorFixSAC (:201-243): run update_objectives on a
+    seeded ring and record every random draw (minibatch ids via th.randint; the rollout's and the two per-step noise tensors via
+    th.randn_like, which is what ActorFixSAC draws from) so that the steps can be replayed with injected draws.  The two-time-scale
+    rule (:148-158) skips the actor on some steps (obj_actor = nan there): the fixture covers updated and skipped steps."""
+    sys.path.insert(0, REF)
+    from elegantrl.agents.AgentSAC import AgentModSAC
+    from elegantrl.train.config import Config
+    from elegantrl.train.replay_buffer import ReplayBuffer
+
+    th.manual_seed(seed)
+    args = Config(AgentModSAC, None, {"env_name": "scripted", "num_envs": N, "max_step": 100,
+                                      "state_dim": S, "action_dim": A, "if_discrete": False})
+    assert args.if_off_policy
+    args.net_dims = list(net_dims)
+    args.batch_size, args.learning_rate, args.gamma, args.reward_scale = batch_size, 1e-3, 0.98, 0.5
+    args.soft_update_tau = 5e-3
+    agent = AgentModSAC(args.net_dims, S, A, gpu_id=-1, args=args)
+    g = {}
+    g.update(net_arrays("act0", agent.act))
+    g.update(net_arrays("cri0", agent.cri))
+    g["alpha_log0"] = np32(agent.alpha_log)
+
+    orig_randn_like = th.randn_like
+    eps_log = []
+
+    def rec_randn_like(t, **k):
+        eps = orig_randn_like(t, **k)
+        eps_log.append(eps.detach().clone())
+        return eps
+
+    th.randn_like = rec_randn_like
+    env = ScriptedVecEnv(N, S, A, seed + 1)
+    agent.last_state = env.reset()[0]
+    g["first_state"] = np32(agent.last_state)
+    th.set_grad_enabled(False)
+    items = agent.explore_env(env, rows)
+    states, actions, rewards, undones, unmasks = items
+    assert len(eps_log) == rows
+    g.update(ro_states=np32(states), ro_actions=np32(actions), ro_rewards=np32(rewards), ro_undones=np32(undones),
+             ro_unmasks=np32(unmasks), ro_eps=np.stack([np32(e) for e in eps_log]), ro_last_state=np32(agent.last_state))
+    eps_log.clear()
+    buf = ReplayBuffer(max_size=rows + 5, state_dim=S, action_dim=A, gpu_id=-1, num_seqs=N)
+    buf.update(items)
+
+    ids_log = []
+    orig_randint = th.randint
+
+    def rec_randint(*a, **k):
+        out = orig_randint(*a, **k)
+        ids_log.append(out.clone())
+        return out
+
+    th.randint = rec_randint
+    th.set_grad_enabled(True)
+    objs, upd = [], []
+    for t in range(n_updates):
+        a_before = agent.update_a if t else 0
+        objs.append(agent.update_objectives(buf, t))
+        upd.append(int(agent.update_a != a_before))
+        g.update(net_arrays(f"act{t + 1}", agent.act))
+        g.update(net_arrays(f"actt{t + 1}", agent.act_target))
+        g.update(net_arrays(f"cri{t + 1}", agent.cri))
+        g.update(net_arrays(f"crit{t + 1}", agent.cri_target))
+        g[f"alpha_log{t + 1}"] = np32(agent.alpha_log)
+    th.set_grad_enabled(False)
+    th.randint = orig_randint
+    th.randn_like = orig_randn_like
+    assert len(eps_log) == 2 * n_updates and len(ids_log) == n_updates
+    assert 0 < sum(upd) < n_updates, upd                 # both kinds of step are in the fixture
+    assert all(np.isnan(o[1]) != bool(u) for o, u in zip(objs, upd))
+    g.update(ids=np.stack([np32(i) for i in ids_log]).astype(np.int64), eps_next=np.stack([np32(e) for e in eps_log[0::2]]),
+             eps_cur=np.stack([np32(e) for e in eps_log[1::2]]), objs=np.array(objs, dtype=np.float64),
+             actor_updated=np.array(upd, dtype=np.int64),
+             hyper=np.array([args.gamma, args.learning_rate, args.clip_grad_norm, args.reward_scale, args.soft_update_tau,
+                             agent.target_entropy, agent.critic_tau, agent.critic_value], dtype=np.float64),
+             dims=np.array([N, S, A, rows, batch_size, n_updates, agent.num_ensembles, *net_dims], dtype=np.int64))
+    path = os.path.join(OUT, f"sac_mod_{tag}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, "objs", objs, "actor updated", upd)
+
+
+def make_state_norm():
+    """AgentPPO.update_avg_std_for_normalization (elegantrl/agents/AgentPPO.py:234-249) on seeded states, twice.  The reference's method
+    goes on to `self.act_target.state_avg[:] = ...` (:246), and AgentPPO has no act_target (AgentBase.py:55: None): it raises AFTER the
+    actor's and the critic's vectors are written.  What it leaves in them is recorded (and that it raised)."""
+    sys.path.insert(0, REF)
+    from elegantrl.agents import AgentPPO
+    from elegantrl.train.config import Config
+    th.manual_seed(51)
+    S, A = 6, 2
+    args = Config(AgentPPO, None, {"env_name": "scripted", "num_envs": 8, "max_step": 100, "state_dim": S, "action_dim": A,
+                                   "if_discrete": False})
+    args.net_dims = [64, 32]
+    args.state_value_tau = 0.1
+    agent = AgentPPO(args.net_dims, S, A, gpu_id=-1, args=args)
+    g = {"tau": np.array([args.state_value_tau]), "dims": np.array([S, A], dtype=np.int64)}
+    th.set_grad_enabled(False)
+    raised = []
+    for k in range(2):
+        states = th.randn(50, S) * (1.0 + k) + 0.5 * k
+        states[:, 3] = 2.0                                    # a constant feature: std 0 -> the clamp_min(1e-4) branch after enough calls
+        g[f"states{k}"] = np32(states)
+        try:
+            agent.update_avg_std_for_normalization(states)
+            raised.append(0)
+        except AttributeError:
+            raised.append(1)
+        g[f"act_avg{k}"], g[f"act_std{k}"] = np32(agent.act.state_avg), np32(agent.act.state_std)
+        g[f"cri_avg{k}"], g[f"cri_std{k}"] = np32(agent.cri.state_avg), np32(agent.cri.state_std)
+    g["raised"] = np.array(raised, dtype=np.int64)
+    path = os.path.join(OUT, "state_norm.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, "reference raised AttributeError:", raised)
+
+
 def make_a2c(tag, *, S, A, H, net_dims, batch_size, repeat_times, seed):
     """reference AgentA2C (elegantrl/agents/AgentPPO.py:252-303) on a one-env buffer (the only shape its time-row minibatches
     are well formed for): update_net with recorded time indices; weights before / after and the returned objectives."""
@@ -548,6 +664,8 @@ if __name__ == "__main__":
                 make_sac("fit_cum_r", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=3, seed=22, lambda_fit=0.3)
             elif name == "ppo_c4shape":
                 make_ppo("c4shape", N=64, S=64, A=8, H=16, net_dims=(128, 128), batch_size=256, repeat_times=32.0, use_v_trace=True, seed=14)
+            elif name == "sac_mod":
+                make_sac_mod("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=4, seed=23)
             elif name == "a2c":
                 make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)
                 make_a2c("mid", S=64, A=8, H=48, net_dims=(128, 128), batch_size=32, repeat_times=2.0, seed=42)
@@ -571,3 +689,5 @@ if __name__ == "__main__":
     make_a2c("small", S=6, A=3, H=24, net_dims=(64, 32), batch_size=16, repeat_times=2.0, seed=41)
     make_a2c("mid", S=64, A=8, H=48, net_dims=(128, 128), batch_size=32, repeat_times=2.0, seed=42)
     make_evaluator()
+    make_sac_mod("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=4, seed=23)
+    make_state_norm()

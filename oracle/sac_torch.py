@@ -4,7 +4,8 @@ Restates elegantrl/agents/AgentSAC.py:42-86 (update_objectives), :167-199 (Actor
 elegantrl/agents/AgentBase.py:239-248 (optimizer_backward), :270-278 (soft_update) with every random draw injectable.
 Pinned by tests/test_sac.py::test_torch_restatement_replays_the_reference against tests/golden/sac_small.npz (outputs of
 the reference's own AgentSAC, oracle/make_golden.py:make_sac); the HIP implementation (csrc/sac.hip) is then checked
-against the same fixture.
+against the same fixture.  `ActorFixSAC` / `ModSacStepper` restate AgentModSAC (:89-165, :201-243) the same way, pinned by
+tests/golden/sac_mod_small.npz (oracle/make_golden.py:make_sac_mod).
 """
 from __future__ import annotations
 
@@ -138,3 +139,72 @@ class SacStepper:
         obj_actor = (self.cri_target(state, action_pg).mean() - logprob * alpha).mean()
         self._opt(self.act_opt, -obj_actor)
         return obj_critic.item(), obj_actor.item()
+
+
+class ActorFixSAC(nn.Module):
+    """elegantrl/agents/AgentSAC.py:201-243: raw last encoder layer, two one-layer decoders, log_std in [-20, 2], the log-prob at the
+    sample with the softplus form of the tanh correction"""
+
+    def __init__(self, net_dims: List[int], state_dim: int, action_dim: int):
+        super().__init__()
+        self.state_dim, self.action_dim = state_dim, action_dim
+        self.encoder_s = build_mlp(dims=[state_dim, *net_dims])
+        self.decoder_a_avg = build_mlp(dims=[net_dims[-1], action_dim])
+        self.decoder_a_std = build_mlp(dims=[net_dims[-1], action_dim])
+        self.soft_plus = nn.Softplus()
+        layer_init_with_orthogonal(self.decoder_a_avg[-1], std=0.1)
+        layer_init_with_orthogonal(self.decoder_a_std[-1], std=0.1)
+
+    def get_action(self, state: TEN, noise: TEN) -> TEN:
+        tmp = self.encoder_s(state)
+        return (self.decoder_a_avg(tmp) + self.decoder_a_std(tmp).clamp(-20, 2).exp() * noise).tanh()
+
+    def get_action_logprob(self, state: TEN, noise: TEN) -> Tuple[TEN, TEN]:
+        tmp = self.encoder_s(state)
+        log_std = self.decoder_a_std(tmp).clamp(-20, 2)
+        action = self.decoder_a_avg(tmp) + log_std.exp() * noise
+        logprob = -log_std - noise.pow(2) * 0.5 - math.log(math.sqrt(2 * math.pi))
+        logprob = logprob - (math.log(2.) - action - self.soft_plus(-2. * action)) * 2.
+        return action.tanh(), logprob.sum(1)
+
+
+class ModSacStepper(SacStepper):
+    """AgentModSAC.update_objectives (elegantrl/agents/AgentSAC.py:113-159): SacStepper's step with ActorFixSAC, target_entropy =
+    -log(action_dim), the two-time-scale rule on the actor and an actor target that follows by soft updates"""
+
+    def __init__(self, net_dims, state_dim, action_dim, num_ensembles, lr, gamma, tau, max_norm):
+        super().__init__(net_dims, state_dim, action_dim, num_ensembles, lr, gamma, tau, max_norm)
+        self.act = ActorFixSAC(list(net_dims), state_dim, action_dim)
+        self.act_target = deepcopy(self.act)
+        self.target_entropy = -math.log(action_dim)
+        self.critic_value, self.update_a = 1.0, 0
+        self.reset_optimizers()
+
+    def step(self, batch, eps_next: TEN, eps_cur: TEN, update_t: int = 0) -> Tuple[float, float]:
+        state, action, reward, undone, unmask, next_state = batch
+        with th.no_grad():
+            next_action, next_logprob = self.act.get_action_logprob(next_state, eps_next)
+            next_q = th.min(self.cri_target.get_q_values(next_state, next_action), dim=1)[0]
+            q_label = reward + undone * self.gamma * (next_q - next_logprob * self.alpha_log.exp())
+        q_values = self.cri.get_q_values(state, action)
+        obj_critic = (((q_values - q_label.view(-1, 1)) ** 2).mean(dim=1) * unmask).mean()
+        self._opt(self.cri_opt, obj_critic)
+        with th.no_grad():
+            for tar, cur in zip(self.cri_target.parameters(), self.cri.parameters()):
+                tar.data.copy_(cur.data * self.tau + tar.data * (1.0 - self.tau))
+        action_pg, logprob = self.act.get_action_logprob(state, eps_cur)
+        self._opt(self.alpha_opt, (self.alpha_log * (self.target_entropy - logprob).detach()).mean())
+        alpha = self.alpha_log.exp().detach()
+        with th.no_grad():
+            self.alpha_log[:] = self.alpha_log.clamp(-16, 2)
+        reliable_lambda = math.exp(-self.critic_value ** 2)
+        self.update_a = 0 if update_t == 0 else self.update_a
+        if (self.update_a / (update_t + 1)) < (1 / (2 - reliable_lambda)):
+            self.update_a += 1
+            obj_actor = (self.cri_target(state, action_pg).mean() - logprob * alpha).mean()
+            self._opt(self.act_opt, -obj_actor)
+            with th.no_grad():
+                for tar, cur in zip(self.act_target.parameters(), self.act.parameters()):
+                    tar.data.copy_(cur.data * self.tau + tar.data * (1.0 - self.tau))
+            return obj_critic.item(), obj_actor.item()
+        return obj_critic.item(), float("nan")

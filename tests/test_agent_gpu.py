@@ -118,6 +118,34 @@ def test_update_net_matches_reference_weights_and_objectives(name, ppo_arith):
     ops.ppo_set_arith(prev)
 
 
+def test_two_agents_of_one_process_keep_their_own_arithmetic():
+    """the minibatch kernels' arithmetic is a per-call argument (ERL_PPO_MODE, ABI 17), not the library's process-wide setting:
+    an "f32" and a "split" agent updating in turn each leave EXACTLY the weights they leave alone, whatever the process default says
+    (round 4: `erl_ppo_set_arith` was global and every update_net re-set it)."""
+    from elegantrl_amd import ops
+    g = load("ppo_c4shape.npz")                       # S = 64, A = 8, [128, 128]: both kernels exist for it
+
+    def run(arith, default):
+        prev = ops.ppo_set_arith(default)
+        agent, _ = make_agent(g, arith)
+        agent.last_state = th.from_numpy(g["last_state"]).to(DEV)
+        buf = [th.from_numpy(g[k]).to(DEV) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
+        agent.update_net(buf, ids=th.from_numpy(g["ids"]).to(DEV))
+        ops.ppo_set_arith(prev)
+        return agent._flat.clone()
+
+    solo = {a: run(a, "auto") for a in ("f32", "split")}
+    assert not th.equal(solo["f32"], solo["split"])                       # two different kernels (same result to ~1e-7, not bitwise)
+    for default in ("f32", "split"):                                      # a contrary process default changes nothing
+        for a in ("f32", "split"):
+            assert th.equal(run(a, default), solo[a]), (a, default)
+    prev = ops.ppo_set_arith("f32")                                       # ... and "auto" agents still follow it
+    try:
+        assert th.equal(run("auto", "f32"), solo["f32"]) and th.equal(run("auto", "split"), solo["split"])
+    finally:
+        ops.ppo_set_arith(prev)
+
+
 @pytest.mark.parametrize("name", ["a2c_small.npz", "a2c_mid.npz"])
 def test_a2c_update_net_matches_reference(name):
     """AgentA2C.update_net against the reference's own AgentA2C run (tests/golden/a2c_*.npz, oracle/make_golden.py:make_a2c):
@@ -174,14 +202,28 @@ def test_canonical_ppo_flag_changes_the_objective_only():
 def test_c4_iteration_against_oracle(N, S):
     """BASELINE config 4 (4096 envs, obs 64) and config 5 (Ant-shaped: 8192 envs, obs 60) shapes, act 8, H=32, B=16384:
     one rollout + 2 minibatches, checked end to end against the fp64 oracle driven with the same noise and ids."""
+    _iteration_against_oracle(N, S, H=32, B=16384, n_mb=2)
+
+
+def test_reference_default_shape_iteration_against_oracle():
+    """The reference's own on-policy defaults (elegantrl/train/config.py:55-58: batch_size 128, horizon_len 2048, repeat_times 8) at
+    config 4's env shape = `bench.py --config cd`: minibatches of 128 samples (ONE gradient slab per network), the GAE scan as a launch
+    of its own in the loop (look-back kernel: H >= 64, the rollout's epilogue switched off as in the bench config).  The horizon is cut
+    from 2048 to 128 rows so that the fp64 oracle finishes in seconds; 8 minibatches; every 4th time row of the rollout is checked."""
+    _iteration_against_oracle(4096, 64, H=128, B=128, n_mb=8, row_stride=4, fused_gae=False, lr=2e-4)
+
+
+def _iteration_against_oracle(N, S, H, B, n_mb, row_stride=1, fused_gae=None, lr=1e-3):
     from elegantrl_amd.agents import AgentPPO
     from elegantrl_amd.envs import SynVecEnv
     from elegantrl_amd.train import Config
-    A, H, B = 8, 32, 16384
+    A = 8
     args = Config(AgentPPO, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 1000, "state_dim": S,
                                         "action_dim": A, "if_discrete": False})
-    args.horizon_len, args.batch_size, args.repeat_times = H, B, 2 * B / H
-    args.learning_rate = 1e-3
+    args.horizon_len, args.batch_size, args.repeat_times = H, B, n_mb * B / H
+    args.learning_rate = lr
+    if fused_gae is not None:
+        args.fused_gae = fused_gae
     th.manual_seed(0)
     agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
     env = SynVecEnv(N, S, A, max_step=5, gpu_id=0, seed=3)            # short episodes: truncations occur in H=32
@@ -208,7 +250,7 @@ def test_c4_iteration_against_oracle(N, S):
     ud_np, um_np, n_np = undones.cpu().numpy(), unmasks.cpu().numpy(), noise.cpu().numpy().astype(np.float64)
     Ws, Wa = env.Ws.cpu().numpy().astype(np.float64), env.Wa.cpu().numpy().astype(np.float64)
     last_np = agent.last_state.cpu().numpy().astype(np.float64)
-    for t in range(H):
+    for t in range(0, H, row_stride):
         a_ref, lp_ref = O.actor_sample(s_np[t], actor, n_np[t])
         np.testing.assert_allclose(a_np[t], a_ref, rtol=1e-4, atol=2e-5, err_msg=f"actions[{t}]")
         np.testing.assert_allclose(lp_np[t], lp_ref, rtol=1e-4, atol=1e-4, err_msg=f"logprobs[{t}]")
@@ -226,7 +268,7 @@ def test_c4_iteration_against_oracle(N, S):
         keep = ud_np[t] & um_np[t]                                        # rows that were not auto-reset carry the transition
         np.testing.assert_allclose(nxt[keep], s2[keep], rtol=1e-4, atol=2e-5, err_msg=f"states[{t + 1}]")
 
-    ids = th.randint(H * N, (2, B), device=DEV, generator=g)
+    ids = th.randint(H * N, (n_mb, B), device=DEV, generator=g)
     objs = agent.update_net(list(items), ids=ids)
     # oracle: same pipeline in fp64
     v = O.critic_value(s_np, critic)
@@ -349,6 +391,40 @@ def test_replay_buffer_class_matches_reference_golden():
             np.testing.assert_array_equal(t.cpu().numpy(), g[f"out{k}_{n}"])
     out = buf.sample(8)                                  # production path draws its own ids
     assert out[0].shape == (8, S) and int(buf.ids0.max()) < buf.cur_size - 1
+
+
+def test_update_avg_std_for_normalization_matches_the_reference():
+    """AgentPPO.update_avg_std_for_normalization (elegantrl/agents/AgentPPO.py:234-249) against what the reference's own
+    method leaves in act / cri state_avg / state_std on the same states (tests/golden/state_norm.npz, oracle/make_golden.py:make_state_norm;
+    two calls, tau = 0.1, one constant feature).  The reference's method then dereferences `self.act_target` (None for AgentPPO) and
+    raises -- recorded in the fixture; this implementation stops after the four vectors the reference managed to write.  The kernels
+    read the vectors: the value cache of the fused rollout is invalidated (`_norm_version`) and the next rollout normalises with them."""
+    from elegantrl_amd.agents import AgentPPO
+    from elegantrl_amd.train import Config
+    g = load("state_norm.npz")
+    S, A = [int(x) for x in g["dims"]]
+    assert list(g["raised"]) == [1, 1]
+    args = Config(AgentPPO, None, {"env_name": "x", "num_envs": 8, "max_step": 100, "state_dim": S, "action_dim": A, "if_discrete": False})
+    args.net_dims, args.state_value_tau = [64, 32], float(g["tau"][0])
+    agent = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
+    v0 = agent._norm_version
+    for k in range(2):
+        agent.update_avg_std_for_normalization(th.from_numpy(g[f"states{k}"]).to(DEV))
+        for mod, name in ((agent.act, "act"), (agent.cri, "cri")):
+            np.testing.assert_allclose(mod.state_avg.detach().cpu().numpy(), g[f"{name}_avg{k}"].reshape(-1), rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(mod.state_std.detach().cpu().numpy(), g[f"{name}_std{k}"].reshape(-1), rtol=1e-6, atol=1e-7)
+    assert agent._norm_version == v0 + 2
+    # the kernels see the new vectors: K1's action equals the module's own forward on the normalised state
+    st = th.from_numpy(g["states1"][:8]).to(DEV)
+    noise = th.zeros((8, A), device=DEV)
+    action, _ = agent.explore_action(st, noise=noise)
+    with th.no_grad():
+        ref = agent.act.net(agent.act.state_norm(st))
+    np.testing.assert_allclose(action.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    args.state_value_tau = 0
+    frozen = AgentPPO(args.net_dims, S, A, gpu_id=0, args=args)
+    frozen.update_avg_std_for_normalization(st)                           # tau == 0: a no-op (:236-237)
+    assert float(frozen.act.state_avg.abs().max()) == 0.0 and float((frozen.act.state_std - 1).abs().max()) == 0.0
 
 
 def test_train_agent_pendulum_smoke(tmp_path):

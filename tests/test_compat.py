@@ -95,3 +95,83 @@ assert h._lib is not None                                                # the H
 print("ok", objs)
 """)
     assert "ok" in out
+
+
+def test_every_kernel_launching_agent_method_pins_its_device():
+    """`AgentSAC.explore_action` had lost its `@_hip.on_device` (and `_explore_vec_env` carried it twice): with
+    `gpu_id != current device` the binding then refuses the agent's tensors.  Every public method that enqueues kernels is wrapped
+    exactly once (the wrapper makes the agent's device current for the call)."""
+    from elegantrl_amd.agents import AgentModSAC, AgentPPO, AgentSAC
+    from elegantrl_amd.agents.AgentPPO import AgentDiscretePPO
+
+    def depth(f):
+        n = 0
+        while hasattr(f, "__wrapped__"):
+            f, n = f.__wrapped__, n + 1
+        return n
+
+    for cls, names in ((AgentPPO, ("explore_action", "_explore_vec_env", "_explore_one_env", "get_values", "get_advantages", "update_net")),
+                       (AgentDiscretePPO, ("explore_action", "_explore_vec_env", "_explore_one_env")),
+                       (AgentSAC, ("explore_action", "_explore_vec_env", "update_objectives", "update_net")),
+                       (AgentModSAC, ("explore_action", "_explore_vec_env", "update_objectives", "update_net"))):
+        for n in names:
+            assert depth(getattr(cls, n)) == 1, f"{cls.__name__}.{n}: wrapped {depth(getattr(cls, n))} times by _hip.on_device"
+
+
+@pytest.mark.gpu
+def test_config0_helloworld_shaped_pendulum_run_with_four_envs(tmp_path):
+    """BASELINE configs[0] (helloworld/helloworld_PPO_single_file.py on Pendulum-v1, num_envs = 4: plumbing).  A script written the way
+    the helloworld's `train_ppo_for_pendulum` + `train_agent` are (:490-517, :535-553) -- Config(agent_class, env_class, env_args), its
+    net_dims / gamma / repeat_times, the explicit explore_env -> buffer[:] -> update_net loop, then `train_agent(args)` -- against the
+    REFERENCE's import paths (`elegantrl.*`), on the GPU-resident Pendulum with num_envs = 4 (gymnasium is not in the image; the env
+    class follows CustomGymEnv.py:42-44's action / reward scaling)."""
+    out = _run(f"""
+import os
+import numpy as np
+import torch as th
+from elegantrl.train.config import Config, build_env
+from elegantrl.train.run import train_agent
+from elegantrl.train.evaluator import Evaluator
+from elegantrl.agents import AgentPPO
+from elegantrl.envs import PendulumVecEnv
+
+env_args = {{'env_name': 'Pendulum', 'num_envs': 4, 'max_step': 200, 'state_dim': 3, 'action_dim': 1, 'if_discrete': False}}
+args = Config(AgentPPO, PendulumVecEnv, env_args)
+args.break_step = int(3 * 512)
+args.net_dims = [64, 32]
+args.gamma = 0.97
+args.repeat_times = 16
+args.horizon_len = 512
+args.gpu_id = 0
+args.cwd = {str(tmp_path / 'hello')!r}
+args.eval_times, args.eval_per_step = 4, 512
+assert args.num_envs == 4 and not args.if_off_policy and args.batch_size == 128
+
+# the helloworld's own loop (:500-517)
+args.init_before_training()
+th.set_grad_enabled(False)
+env = build_env(args.env_class, args.env_args, args.gpu_id)
+agent = args.agent_class(args.net_dims, args.state_dim, args.action_dim, gpu_id=args.gpu_id, args=args)
+agent.last_state, info_dict = env.reset()
+assert agent.last_state.shape == (4, 3)
+buffer = []
+for it in range(3):
+    buffer_items = agent.explore_env(env, args.horizon_len)
+    buffer[:] = buffer_items
+    assert [tuple(x.shape) for x in buffer] == [(512, 4, 3), (512, 4, 1), (512, 4), (512, 4), (512, 4), (512, 4)]
+    assert buffer[4].dtype == th.bool and buffer[5].dtype == th.bool
+    th.set_grad_enabled(True)
+    logging_tuple = agent.update_net(buffer)
+    th.set_grad_enabled(False)
+    assert len(logging_tuple) == 3 and all(np.isfinite(x) for x in logging_tuple), logging_tuple
+print('loop ok', logging_tuple)
+
+# ... and through train_agent (run.py:39-138)
+train_agent(args, if_single_process=True)
+files = os.listdir(args.cwd)
+assert 'act.pth' in files and 'recorder.npy' in files, files
+rec = np.load(os.path.join(args.cwd, 'recorder.npy'))
+assert np.isfinite(rec).all() and rec.shape[0] >= 2
+print('ok')
+""")
+    assert out.strip().endswith("ok")

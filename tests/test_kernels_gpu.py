@@ -132,6 +132,33 @@ def test_gae_lookback_at_baseline_sizes_against_c_oracle(ops, dev, H, N, vtrace)
     _hip.check_async_faults()                                  # no look-back wait timed out
 
 
+def test_gae_lookback_tables_are_per_stream(ops, dev):
+    """the look-back scan's library-owned granule table is keyed by (device, stream) (ABI 17; round 4: one per device, a second
+    stream took the memset path): scans interleaved on three streams -- two side streams and the default one, different sizes,
+    several rounds so that nonces advance independently -- all match oracle/gae_scan.c"""
+    from elegantrl_amd import _hip
+    shapes = [(256, 1024), (1024, 512), (128, 4096)]
+    cases = []
+    for k, (H, N) in enumerate(shapes):
+        r, u, m, v, nv = gae_inputs(H, N, seed=77 + k)
+        adv_o, ret_o, _, _ = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95)
+        cases.append(((r, u, m, v, nv), adv_o, ret_o))
+    streams = [th.cuda.Stream(device=dev), th.cuda.Stream(device=dev), th.cuda.current_stream(dev)]
+    outs = []
+    th.cuda.synchronize()
+    for rnd in range(3):
+        for (inp, _, _), st in zip(cases, streams):
+            with th.cuda.stream(st):
+                t = [cu(x, dev) for x in inp]
+                outs.append((rnd, ops.gae_scan(*t, 0.99, 0.95, mutate=False, algo="lookback")))
+    th.cuda.synchronize()
+    for i, (rnd, (adv, ret)) in enumerate(outs):
+        _, adv_o, ret_o = cases[i % 3]
+        rel_close(adv.cpu().numpy(), adv_o, 1e-5)
+        rel_close(ret.cpu().numpy(), ret_o, 1e-5)
+    _hip.check_async_faults()
+
+
 def test_gae_lookback_timeout_is_reported_not_silent(ops, dev, monkeypatch):
     """a predecessor slab that never publishes (fault injection: granules written under a foreign nonce) makes the bounded
     look-back wait expire: the affected advantages are NaN AND the fault reaches the host through the ABI

@@ -73,7 +73,7 @@ def test_update_net_weights_and_objectives(name):
         for p, q in zip(mine.trainable(), ref.trainable()):
             # measured <= 1.3e-6 on the small fixtures, 9e-6 on ONE of the 50k weights of ppo_c4shape (a gradient of ~1e-9: Adam's first steps
             # are lr * g / (|g| + eps), where fp32 autograd and the fp64 restatement disagree)
-            np.testing.assert_allclose(p, q, rtol=0, atol=2e-5)
+            np.testing.assert_allclose(p, q, rtol=0, atol=2e-5 if name == "ppo_c4shape.npz" else 5e-6)
     moved = sum(float(np.abs(p - q).sum()) for p, q in zip(mlp_from(g, "act0").trainable(), ref_a.trainable()))
     assert moved > 0
 

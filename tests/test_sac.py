@@ -48,6 +48,146 @@ def test_torch_restatement_replays_the_reference(name):
         np.testing.assert_allclose(st.alpha_log.detach().numpy(), g[f"alpha_log{t + 1}"], rtol=0, atol=1e-6)
 
 
+def _mod_setup(g):
+    N, S, A, rows, B, n_upd, n_ens, h1, h2 = [int(x) for x in g["dims"]]
+    gamma, lr, max_norm, reward_scale, tau, target_entropy, critic_tau, critic_value = [float(x) for x in g["hyper"]]
+    return (N, S, A, rows, B, n_upd, n_ens, h1, h2), (gamma, lr, max_norm, reward_scale, tau, target_entropy, critic_tau, critic_value)
+
+
+def test_torch_restatement_replays_the_reference_modsac():
+    """oracle/sac_torch.py's ModSacStepper / ActorFixSAC (CPU) against tests/golden/sac_mod_small.npz -- outputs of the reference's own
+    AgentModSAC (elegantrl/agents/AgentSAC.py:89-165, :201-243; oracle/make_golden.py:make_sac_mod): objectives (nan where the
+    two-time-scale rule skipped the actor), actor, actor target, critics, critic target and alpha after each of the 4 recorded steps."""
+    from oracle.sac_torch import ModSacStepper
+    th.set_grad_enabled(True)
+    g = load("sac_mod_small.npz")
+    (N, S, A, rows, B, n_upd, n_ens, h1, h2), (gamma, lr, max_norm, reward_scale, tau, target_entropy, _, _) = _mod_setup(g)
+    assert n_ens == 8 and abs(target_entropy + np.log(A)) < 1e-12                 # AgentModSAC's defaults (:93, :107)
+    st = ModSacStepper([h1, h2], S, A, n_ens, lr, gamma, tau, max_norm)
+    _load_nets(g, 0, st.act, st.cri)
+    st.act_target.load_state_dict(st.act.state_dict())
+    st.cri_target.load_state_dict(st.cri.state_dict())
+    with th.no_grad():
+        st.alpha_log[:] = th.from_numpy(g["alpha_log0"])
+    st.reset_optimizers()
+    with th.no_grad():                                                            # the rollout: ActorFixSAC.get_action (:217-224)
+        a = st.act.get_action(th.from_numpy(g["ro_states"][0]), th.from_numpy(g["ro_eps"][0]))
+        np.testing.assert_allclose(a.numpy(), g["ro_actions"][0], rtol=1e-5, atol=1e-6)
+    ring = {k: th.from_numpy(g[f"ro_{k}"]) for k in ("states", "actions", "rewards", "undones", "unmasks")}
+    L = rows - 1
+    for t in range(n_upd):
+        ids = th.from_numpy(g["ids"][t])
+        i0, i1 = ids % L, ids // L
+        batch = (ring["states"][i0, i1], ring["actions"][i0, i1], ring["rewards"][i0, i1], ring["undones"][i0, i1].float(),
+                 ring["unmasks"][i0, i1].float(), ring["states"][i0 + 1, i1])
+        oc, oa = st.step(batch, th.from_numpy(g["eps_next"][t]), th.from_numpy(g["eps_cur"][t]), update_t=t)
+        assert np.isnan(oa) == (g["actor_updated"][t] == 0) == bool(np.isnan(g["objs"][t][1]))
+        np.testing.assert_allclose([oc, oa], g["objs"][t], rtol=1e-5, atol=1e-7, equal_nan=True)
+        for prefix, net in ((f"act{t + 1}", st.act), (f"actt{t + 1}", st.act_target), (f"cri{t + 1}", st.cri), (f"crit{t + 1}", st.cri_target)):
+            for k, v in net.state_dict().items():
+                np.testing.assert_allclose(v.numpy(), g[f"{prefix}.{k}"], rtol=0, atol=2e-6, err_msg=f"{prefix}.{k}")
+        np.testing.assert_allclose(st.alpha_log.detach().numpy(), g[f"alpha_log{t + 1}"], rtol=0, atol=1e-6)
+    assert list(g["actor_updated"]) == [1, 1, 0, 1]
+
+
+def test_actor_fix_sac_module_matches_the_reference_on_cpu():
+    """the product's ActorFixSAC module (what the Evaluator calls, what checkpoints hold): same parameter names as the reference's
+    (its state_dict loads), same rollout action for the recorded noise"""
+    from elegantrl_amd.agents.AgentSAC import ActorFixSAC
+    g = load("sac_mod_small.npz")
+    (N, S, A, rows, B, n_upd, n_ens, h1, h2), _ = _mod_setup(g)
+    act = ActorFixSAC([h1, h2], S, A)
+    act.load_state_dict({k[len("act0."):]: th.from_numpy(v) for k, v in g.items() if k.startswith("act0.")})
+    with th.no_grad():
+        a = act.get_action(th.from_numpy(g["ro_states"][5]), th.from_numpy(g["ro_eps"][5]))
+        np.testing.assert_allclose(a.numpy(), g["ro_actions"][5], rtol=1e-5, atol=1e-6)
+        assert act(th.from_numpy(g["ro_states"][5])).shape == (N, A)
+
+
+@pytest.mark.gpu
+def test_modsac_rollout_and_updates_replay_the_reference():
+    """AgentModSAC on the HIP step (erl_sac_update_opt_f32, erl_sac_explore_action_opt_f32) replays the reference's own AgentModSAC run:
+    the off-policy rollout, then 4 update steps with the recorded ids / noise -- objectives (nan on the step the two-time-scale rule
+    skips), actor, ACTOR TARGET, critics, critic target, alpha after every step."""
+    from elegantrl_amd.agents import AgentModSAC
+    from elegantrl_amd.train import Config, ReplayBuffer
+    g = load("sac_mod_small.npz")
+    (N, S, A, rows, B, n_upd, n_ens, h1, h2), (gamma, lr, max_norm, reward_scale, tau, target_entropy, critic_tau, critic_value) = _mod_setup(g)
+    dev = th.device("cuda:0")
+    args = Config(AgentModSAC, None, {"env_name": "scripted", "num_envs": N, "max_step": 100, "state_dim": S, "action_dim": A,
+                                      "if_discrete": False})
+    assert args.if_off_policy
+    args.net_dims = [h1, h2]
+    args.batch_size, args.learning_rate, args.gamma, args.reward_scale, args.soft_update_tau = B, lr, gamma, reward_scale, tau
+    args.clip_grad_norm = max_norm
+    agent = AgentModSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    assert agent.num_ensembles == n_ens == 8 and abs(agent.target_entropy - target_entropy) < 1e-12
+    assert agent.critic_tau == critic_tau and agent.critic_value == critic_value
+    _load_nets(g, 0, agent.act, agent.cri)
+    agent.act_target.load_state_dict(agent.act.state_dict())
+    agent.cri_target.load_state_dict(agent.cri.state_dict())
+    with th.no_grad():
+        agent.alpha_log[:] = th.from_numpy(g["alpha_log0"]).to(dev)
+
+    agent.last_state = th.from_numpy(g["first_state"]).to(dev)
+    th.set_grad_enabled(False)
+    items = agent._explore_vec_env(_ReplayEnv(g, dev), rows, noise=th.from_numpy(g["ro_eps"]).to(dev))
+    for got, name in zip(items, ("ro_states", "ro_actions", "ro_rewards", "ro_undones", "ro_unmasks")):
+        if got.dtype == th.bool:
+            np.testing.assert_array_equal(got.cpu().numpy(), g[name])
+        else:
+            np.testing.assert_allclose(got.cpu().numpy(), g[name], rtol=2e-5, atol=2e-6)
+
+    buf = ReplayBuffer(max_size=rows + 5, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N)
+    buf.update(tuple(th.from_numpy(g[n]).to(dev) for n in ("ro_states", "ro_actions", "ro_rewards", "ro_undones", "ro_unmasks")))
+    th.set_grad_enabled(True)
+    for t in range(n_upd):
+        oc, oa = agent.update_objectives(buf, t, ids=th.from_numpy(g["ids"][t]).to(dev),
+                                         noises=(th.from_numpy(g["eps_next"][t]).to(dev), th.from_numpy(g["eps_cur"][t]).to(dev)))
+        assert np.isnan(oa) == (g["actor_updated"][t] == 0) and agent._last_actor_updated == bool(g["actor_updated"][t])
+        np.testing.assert_allclose([oc, oa], g["objs"][t], rtol=2e-4, atol=2e-6, equal_nan=True)
+        for prefix, net in ((f"act{t + 1}", agent.act), (f"actt{t + 1}", agent.act_target), (f"cri{t + 1}", agent.cri),
+                            (f"crit{t + 1}", agent.cri_target)):
+            for k, v in net.state_dict().items():
+                np.testing.assert_allclose(v.cpu().numpy(), g[f"{prefix}.{k}"], rtol=0, atol=3e-5, err_msg=f"{prefix}.{k} after step {t}")
+        np.testing.assert_allclose(agent.alpha_log.detach().cpu().numpy(), g[f"alpha_log{t + 1}"], rtol=0, atol=1e-5)
+    th.set_grad_enabled(False)
+    assert agent._actor_step == 3 and agent.act_optimizer.step_count == 3 and agent.cri_optimizer.step_count == 4
+
+
+@pytest.mark.gpu
+def test_modsac_update_net_loop_and_checkpoint(tmp_path):
+    """AgentModSAC end to end on a GPU-resident env: rollout -> ring -> update_net (the two-time-scale rule inside the loop: about a
+    third of the steps skip the actor, their nan objectives stay out of the mean as AgentBase.py:186-188) -> save / load"""
+    from elegantrl_amd.agents import AgentModSAC
+    from elegantrl_amd.envs import SynVecEnv
+    from elegantrl_amd.train import Config, ReplayBuffer
+    N, S, A = 64, 11, 3
+    args = Config(AgentModSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
+                                           "if_discrete": False})
+    args.net_dims, args.batch_size, args.horizon_len, args.repeat_times = [64, 32], 128, 16, 1.0
+    th.manual_seed(0)
+    agent = AgentModSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=1)
+    agent.last_state = env.reset()[0]
+    buf = ReplayBuffer(max_size=4096, state_dim=S, action_dim=A, gpu_id=0, num_seqs=N)
+    for _ in range(2):
+        buf.update(agent.explore_env(env, 16))
+    w0 = agent.act.encoder_s[0].weight.detach().clone()
+    t0 = agent.act_target.encoder_s[0].weight.detach().clone()
+    oc, oa = agent.update_net(buf)
+    times = int(buf.cur_size * 1.0 / 128)
+    assert times >= 6 and np.isfinite([oc, oa]).all()
+    assert 0 < agent.update_a < times and agent._actor_step == agent.update_a          # some steps skipped the actor
+    assert not th.equal(agent.act.encoder_s[0].weight, w0) and not th.equal(agent.act_target.encoder_s[0].weight, t0)
+    agent.save_or_load_agent(str(tmp_path), if_save=True)
+    fresh = AgentModSAC(args.net_dims, S, A, gpu_id=0, args=args)
+    fresh.save_or_load_agent(str(tmp_path), if_save=False)
+    assert fresh._actor_step == agent._actor_step and fresh._step == agent._step
+    assert th.equal(fresh.act_target.encoder_s[0].weight, agent.act_target.encoder_s[0].weight)
+    assert th.equal(fresh._actor_target_flat, agent._actor_target_flat)
+
+
 def test_actor_critic_modules_match_reference_rollout_on_cpu():
     """module-level math on CPU: stored action == tanh(mean + std * eps) for the recorded eps (AgentSAC.py:179-185)."""
     from elegantrl_amd.agents.AgentSAC import ActorSAC, CriticEnsemble
