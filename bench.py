@@ -130,6 +130,11 @@ class EventTimer:
 
 
 def gae_sweep(ops, dev):
+    """the GAE scan over the SURVEY 8d sizes, two clocks per size: `kernel_us` = the kernel's own first-workgroup-in to last-workgroup-out
+    span on the device clock (erl_kernel_span_*: what rocprofv3's kernel duration measures) and `call_us` = HIP events around 20
+    back-to-back ops.gae_scan calls (interpreter + launch + kernel: at the small sizes mostly not the kernel).  GB/s and frac are the
+    KERNEL's (18 algorithmic bytes per element / kernel_us)."""
+    from elegantrl_amd import _hip
     out = []
     for H, N in [(32, 4096), (128, 4096), (200, 4096), (1024, 4096), (2048, 4096), (4096, 4096), (32, 32768)]:   # SURVEY 8d sizes (+ 4096 x 4096)
         g = th.Generator(device=dev).manual_seed(0)
@@ -143,16 +148,21 @@ def gae_sweep(ops, dev):
             run()
         th.cuda.synchronize()
         iters = 20
+        _hip.kernel_span_enable(True)
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
             run()
         e1.record()
         th.cuda.synchronize()
-        sec = e0.elapsed_time(e1) * 1e-3 / iters
+        kernel_us, n_k = _hip.kernel_span_read(_hip.SPAN_GAE)
+        _hip.kernel_span_enable(False)
+        call_s = e0.elapsed_time(e1) * 1e-3 / iters
+        sec = kernel_us * 1e-6 if kernel_us else call_s
         gbps = 18.0 * H * N / sec / 1e9
-        out.append({"H": H, "N": N, "bytes": 18 * H * N, "us": round(sec * 1e6, 2), "GBps": round(gbps, 1),
-                    "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+        out.append({"H": H, "N": N, "bytes": 18 * H * N, "kernel_us": round(kernel_us, 2) if kernel_us else None, "call_us": round(call_s * 1e6, 2),
+                    "us": round(sec * 1e6, 2), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                    "call_GBps": round(18.0 * H * N / call_s / 1e9, 1)})
     return out
 
 
@@ -179,6 +189,8 @@ def kernel_source_sha16(kernel: str):
     return h.hexdigest()[:16]
 
 
+C3_PMC_FILE = os.path.join("profiles", "r05_c3_pmc.json")            # tools/c3_pmc_workload.py under rocprofv3 --pmc (critic_tile_kernel, replay_sample_kernel)
+K9_PMC_FILE = os.path.join("profiles", "r05_k9_pmc_by_size.json")    # ... replay_sample_kernel per (num_seqs, B) case: FETCH_SIZE / WRITE_SIZE bytes
 WIDE_PMC_FILE = os.path.join("profiles", "r04_wide_pmc_traffic_S8_h128.json")     # tools/wide_pmc_workload.py, WD_S=8 WD_A=2 WD_ONLY=128 (cw's shape)
 
 
@@ -224,7 +236,9 @@ def smi_snapshot(timeout_s: int = 20):
     answers within the timeout; only keys about clocks / power / temperature / partitioning are kept."""
     import re
     import subprocess
-    keep = re.compile(r"clk|clock|power|cap|temp|perf|partition|voltage|throttl|sku|vbios|series|model", re.I)
+    keep = re.compile(r"sclk|mclk|fclk|gfxclk|uclk|gfx_0\.clk\.value|mem_0\.clk\.value|power|temperature_hotspot|temperature_mem|junction|perf|partition|throttl|"
+                      r"vbios|model|sys\.current_frequency|frequency_levels", re.I)
+    drop = re.compile(r"N/A|vclk|dclk|socclk|deep_sleep|clk_locked|min_clk|max_clk|shutdown|slowdown|ppt1|\.unit$", re.I)
     out = {}
     for cmd in (["rocm-smi", "-a", "--json"], ["amd-smi", "static", "--json"], ["amd-smi", "metric", "--json"]):
         try:
@@ -246,7 +260,7 @@ def smi_snapshot(timeout_s: int = 20):
             elif isinstance(v, list):
                 for i, x in enumerate(v[:2]):          # (one GPU is visible; keep the first entries only)
                     walk(f"{prefix}[{i}]", x)
-            elif keep.search(prefix) and len(flat) < 80:
+            elif keep.search(prefix) and not drop.search(prefix) and not drop.search(str(v)) and len(flat) < 40:
                 flat[prefix] = v
         walk("", data)
         out[" ".join(cmd)] = flat
@@ -380,10 +394,12 @@ def bench_sac(opt):
         buf.update(agent.explore_env(env, H))
         return agent.update_net(buf)
 
+    from elegantrl_amd import _hip
     for _ in range(opt.warmup):
         step()
     quiet_gc()
     t_k9.enabled = True
+    _hip.kernel_span_enable(True)      # the critic's training pass and the sample kernel leave their own device-clock spans (no brackets)
     th.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(opt.steps):
@@ -391,6 +407,9 @@ def bench_sac(opt):
     th.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t_k9.enabled = False
+    crit_us, crit_n = _hip.kernel_span_read(_hip.SPAN_SAC_CRITIC_TRAIN)
+    k9_loop_us, k9_loop_n = _hip.kernel_span_read(_hip.SPAN_REPLAY_SAMPLE)
+    _hip.kernel_span_enable(False)
     sample_in_step = len(t_k9.pairs) == 0      # (update_net handed ring + ids to the step: the gather rides in the step's first launch)
     if sample_in_step:                         # the sample kernel at the loop's batch size, on its own, for the roofline object
         t_k9.enabled = True
@@ -400,6 +419,41 @@ def bench_sac(opt):
         t_k9.enabled = False
     k9_s = t_k9.mean_seconds()
     bytes_per = (2 * (2 * S + A + 3) * 4 + 8) * B
+    # the sample kernel's own span at B in {256, 4096, 2^20} on this ring (num_seqs = 64) and on a one-env ring of the same capacity
+    # (num_seqs = 1: BASELINE.md section 3), 18 algorithmic... (2S + A + 3) * 4 B read + the same written + 8 B id per sample
+    k9_sizes = []
+    one = ReplayBuffer(max_size=1_000_000, state_dim=S, action_dim=A, gpu_id=0, num_seqs=1)
+    one.update((th.randn((999_999, 1, S), device=dev, generator=g), th.randn((999_999, 1, A), device=dev, generator=g).tanh(),
+                th.randn((999_999, 1), device=dev, generator=g), th.rand((999_999, 1), device=dev, generator=g) < 0.99,
+                th.rand((999_999, 1), device=dev, generator=g) < 0.995))
+    for ring, seqs in ((buf, N), (one, 1)):
+        for bsz in (256, 4096, 1 << 20):
+            idx = th.randint((ring.cur_size - 1) * seqs, (bsz,), device=dev, generator=g)
+            for _ in range(3):
+                ops.replay_sample(ring.states, ring.actions, ring.rewards, ring.undones, ring.unmasks, idx, ring.cur_size - 1)
+            th.cuda.synchronize()
+            _hip.kernel_span_enable(True)
+            for _ in range(20):
+                ops.replay_sample(ring.states, ring.actions, ring.rewards, ring.undones, ring.unmasks, idx, ring.cur_size - 1)
+            us, _n = _hip.kernel_span_read(_hip.SPAN_REPLAY_SAMPLE)
+            _hip.kernel_span_enable(False)
+            by = (2 * (2 * S + A + 3) * 4 + 8) * bsz
+            k9_sizes.append({"num_seqs": seqs, "B": bsz, "bytes": by, "kernel_us": round(us, 2) if us else None,
+                             "GBps": round(by / (us * 1e-6) / 1e9, 1) if us else None,
+                             "frac": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us else None})
+    del one
+    # the dominant in-loop kernel of the step: the critic ensemble's training pass (forward of the shared encoder + E decoders, loss
+    # gradient, backward to the encoder output; weight gradients are dw_table's): algorithmic flops per launch
+    E_, h0, h1 = agent.num_ensembles, NET[0], NET[1]
+    crit_flops = 2 * B * ((S + A) * h0 + E_ * (h0 * h1 + h1) + E_ * (h1 + h1 * h0))
+    crit_tr, crit_src = None, None
+    try:
+        prof = json.load(open(os.path.join(ROOT, C3_PMC_FILE)))["kernels"]["critic_tile_kernel"]
+        crit_tr = prof.get("hbm_bytes_per_launch")
+        crit_src = {"file": C3_PMC_FILE, "mfma_busy_frac": prof.get("mfma_busy_frac_of_kernel_time_at_2.4GHz"), "avg_duration_us": prof.get("avg_duration_us"),
+                    "note": "all three passes of critic_tile_kernel averaged (target on next_state / training / target on the policy-gradient sample)"}
+    except Exception:
+        pass
     # the kernel's capability away from the launch floor: one sample call of 2^20 transitions on the same ring
     big = th.randint((max_size - 1) * N, (1 << 20,), device=dev, generator=g)
     for _ in range(3):
@@ -422,14 +476,23 @@ def bench_sac(opt):
                    "update_times": UPD, "parallelism": "single"},
         "env_steps_per_sec": round(N * H * opt.steps / elapsed, 1),
         "us_per_update": round(elapsed / opt.steps / UPD * 1e6, 1),
-        "roofline": {"kernel": "replay_sample_kernel", "bound": "hbm", "achieved": round(bytes_per / k9_s / 1e9, 2), "peak": HBM_PEAK_GBPS,
+        "roofline": ({"kernel": "critic_tile_kernel<1> (the critic ensemble's training pass: dominant in-loop kernel of the fused SAC step)",
+                      "bound": "mfma", "achieved": round(crit_flops / (crit_us * 1e-6) / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(crit_flops / (crit_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": crit_tr, "traffic_source": crit_src,
+                      "flops_per_launch": crit_flops, "avg_launch_us": round(crit_us, 2), "launches_timed": crit_n, "in_loop": True,
+                      "timer": "the kernel's own span on the device clock (first workgroup in to last workgroup out), every launch of the timed region",
+                      "note": "fp32 MFMA 16x16x4; a 16-sample tile x decoder per workgroup streams the decoder's whole 256 x 256 layer (forward and "
+                              "transposed) through ONE CU: bound by that CU's ~12 B/clk from L2, not by the matrix pipe or HBM (DESIGN.md section 4, SAC)"}
+                     if crit_us else None),
+        "roofline_sample": {"kernel": "replay_sample_kernel", "bound": "hbm", "achieved": round(bytes_per / k9_s / 1e9, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(bytes_per / k9_s / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                      "bytes_per_launch": bytes_per, "avg_launch_us": round(k9_s * 1e6, 2), "launches_timed": len(t_k9.pairs),
                      "in_loop": not sample_in_step,
                      "note": ("the loop's sample rides inside the SAC step's first launch (erl_sac_update_ring_f32): the kernel was timed on its own, "
                               "200 calls at the loop's batch size" if sample_in_step else "timed in the loop"),
                      "at_batch_2^20": {"bytes_per_launch": big_bytes, "us": round(big_s * 1e6, 1),
-                                       "achieved": round(big_bytes / big_s / 1e9, 1), "frac": round(big_bytes / big_s / 1e9 / HBM_PEAK_GBPS, 4)}},
+                                       "achieved": round(big_bytes / big_s / 1e9, 1), "frac": round(big_bytes / big_s / 1e9 / HBM_PEAK_GBPS, 4)},
+                     "kernel_span_by_size": k9_sizes, "traffic_by_size_file": K9_PMC_FILE},
         "objectives_last": [round(float(x), 6) for x in objs],
     }
     if not opt.no_cpu_baseline:
@@ -535,6 +598,7 @@ def main():
     t_gae.enabled = t_explore.enabled = t_update.enabled = True
     # every n-th K6 launch is timed twice: a HIP-event bracket on its stream and the kernel's own span on the device clock
     _hip.k6_timing_enable(opt.k6_sample)
+    _hip.kernel_span_enable(True)          # the loop's other kernels leave their own device-clock spans (no brackets): GAE scan, slab reduction, clip + Adam
     parallel.barrier()
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -550,7 +614,13 @@ def main():
     t_gae.enabled = t_explore.enabled = t_update.enabled = False
     _hip.k6_timing_enable(False)
     k6_event_seconds, k6_span_seconds, k6_launches = _hip.k6_timing_read2()
-    k6_clocks = _hip.k6_timing_clocks()                     # shader clock inside the sampled launches, per-phase cycles (s3 kernel)
+    span_gae_us, span_gae_n = _hip.kernel_span_read(_hip.SPAN_GAE)
+    span_red_us, span_red_n = _hip.kernel_span_read(_hip.SPAN_SLAB_REDUCE)
+    span_adam_us, span_adam_n = _hip.kernel_span_read(_hip.SPAN_CLIP_ADAM)
+    _hip.kernel_span_enable(False)
+    # every K6 launch of the region left its own span / clock / phase stamps; the launches WITHOUT an event bracket are the kernel as
+    # the loop runs it (a bracket perturbs what it brackets: the bracketed group is reported next to it)
+    k6_clocks, k6_clocks_br = _hip.k6_timing_clocks(False), _hip.k6_timing_clocks(True)
     smi = smi_snapshot() if rank == 0 and not opt.no_smi else None
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
@@ -618,7 +688,8 @@ def main():
     flops = ppo_flops_per_sample(STATE_DIM, *NET_DIMS, ACTION_DIM) * BATCH
     n_k6 = k6_launches
     k6_event_s = k6_event_seconds / n_k6 if n_k6 else float("nan")
-    k6_span_s = k6_span_seconds / n_k6 if n_k6 and k6_span_seconds > 0 else float("nan")
+    k6_span_br_s = k6_span_seconds / n_k6 if n_k6 and k6_span_seconds > 0 else float("nan")      # spans of the BRACKETED launches
+    k6_span_s = k6_clocks["span_us"] * 1e-6 if k6_clocks["launches"] else k6_span_br_s           # ... of the launches without a bracket
     # the kernel's duration: its own first-workgroup-in to last-workgroup-out span on the device's constant-rate clock (no dispatch or
     # completion overhead of a bracket in it; agrees with rocprofv3's kernel duration -- `kernel_us_rocprof`); fallback: the event
     # bracket minus the bracket of an empty launch
@@ -631,7 +702,8 @@ def main():
     # the fp32-equivalent ceiling of the pipe the kernel runs on: the split-arithmetic kernel issues SPLIT_TERMS bf16 MFMA flops per
     # algorithmic flop on the bf16 matrix pipe; the fp32 kernel runs on the fp32 MFMA
     k6_peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS if k6_arith == "split" else MFMA_F32_PEAK_TFLOPS
-    gae_s = t_gae.mean_seconds()
+    gae_s = t_gae.mean_seconds()                      # HIP-event bracket around the ops.gae_scan call (launch + bracket + kernel)
+    gae_k_s = span_gae_us * 1e-6 if span_gae_us else gae_s     # ... the kernel's own span
     k6_traffic, k6_traffic_src = (pmc_traffic(k6_kernel) if opt.config == "c4" else
                                   pmc_traffic(k6_kernel, WIDE_PMC_FILE) if opt.config == "cw" else (None, None))
     k6_rocprof_us, k6_rocprof_src = rocprof_kernel_us(k6_kernel) if opt.config == "c4" else (None, None)
@@ -657,6 +729,10 @@ def main():
                  "k6_ms": round(k6_ms, 4), "update_net_minus_k6_ms": round(update_ms - k6_ms, 4),
                  "per_minibatch_rest_us": round((update_ms - k6_ms) / UPDATE_TIMES * 1e3, 2),
                  "host_and_gaps_ms": round(step_ms - explore_ms - update_ms, 4),
+                 # the tail's kernels by their own device-clock spans (first workgroup in to last workgroup out, every launch of the region)
+                 "slab_reduce_us": round(span_red_us, 2) if span_red_us else None, "clip_adam_us": round(span_adam_us, 2) if span_adam_us else None,
+                 "boundaries_and_rest_per_minibatch_us": (round((update_ms - k6_ms) / UPDATE_TIMES * 1e3 - span_red_us - span_adam_us, 2)
+                                                          if span_red_us and span_adam_us else None),
                  "explore_env_ms_each": t_explore.each_ms(), "update_net_ms_each": t_update.each_ms(),
                  "consistent": bool(k6_ms <= update_ms and explore_ms + update_ms <= step_ms * 1.01),
                  "note": "HIP-event brackets around agent.explore_env / agent.update_net (means over the timed region); k6_ms = update_times x "
@@ -685,9 +761,19 @@ def main():
                                if k6_arith == "split" else "fp32 operands on v_mfma_f32_32x32x2_f32"),
                      "frac_of_fp32_mfma_peak": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops,
-                     "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": n_k6,
-                     "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel, every "
-                               f"{opt.k6_sample}th launch of the timed region)" if k6_span_s == k6_span_s else "HIP-event bracket minus empty-launch bracket"),
+                     "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": k6_clocks["launches"] or n_k6,
+                     "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel), mean over "
+                               "the launches of the timed region that carry NO event bracket" if k6_clocks["launches"] else
+                               "kernel span on the device clock, bracketed launches" if k6_span_s == k6_span_s else
+                               "HIP-event bracket minus empty-launch bracket"),
+                     # every opt.k6_sample-th launch also sits inside a HIP-event bracket: the bracket's own time, the SAME launches' in-kernel
+                     # span, and how much longer a bracketed launch runs than its unbracketed neighbours on this box (round 5's finding: the
+                     # bracket perturbs the kernel inside it by a box-dependent amount -- BENCH_r04's 53.4 us was this group)
+                     "bracketed": {"launches": n_k6, "event_bracket_us": round(k6_event_s * 1e6, 2),
+                                   "span_us": round(k6_span_br_s * 1e6, 2) if k6_span_br_s == k6_span_br_s else None,
+                                   "span_minus_unbracketed_us": round((k6_span_br_s - k6_span_s) * 1e6, 2) if k6_span_br_s == k6_span_br_s else None,
+                                   "shader_mhz": round(k6_clocks_br["shader_mhz"], 1) if k6_clocks_br["shader_mhz"] else None,
+                                   "phase_cycles": {k: round(v) for k, v in k6_clocks_br["phase_cycles"].items()} or None},
                      "event_bracket_us": round(k6_event_s * 1e6, 2), "event_bracket_null_us": round(null_bracket_us, 2),
                      "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src,
                      # this box against the box the committed rocprofv3 summary was collected on (same sources): avg_launch_us / kernel_us_rocprof
@@ -706,9 +792,11 @@ def main():
         "breakdown": breakdown,
         "roofline_gae": ({"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
                           "bound": "hbm",
-                          "achieved": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                          "frac": round(18.0 * HORIZON * N_ENVS / gae_s / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                          "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": round(gae_s * 1e6, 2)} if t_gae.pairs else
+                          "achieved": round(18.0 * HORIZON * N_ENVS / gae_k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": round(18.0 * HORIZON * N_ENVS / gae_k_s / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                          "bytes_per_launch": 18 * HORIZON * N_ENVS, "avg_launch_us": round(gae_k_s * 1e6, 2), "launches_timed": span_gae_n,
+                          "timer": "the kernel's own span on the device clock, every in-loop launch" if span_gae_us else "HIP-event bracket around the call",
+                          "call_bracket_us": round(gae_s * 1e6, 2)} if t_gae.pairs else
                          {"kernel": f"none in the loop: at {HORIZON}x{N_ENVS} get_advantages and its statistics run in the persistent rollout's "
                                     "epilogue (csrc/rollout_fused.hip; ERL_FUSED_GAE=0 restores the scan launches); the scan kernel's HBM figures: `sweep`",
                           "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,

@@ -139,8 +139,10 @@ _SIGNATURES = {
     "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_read2": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_null_bracket_us": (c_int, [_P, c_int, POINTER(ctypes.c_double)]),
-    "erl_k6_timing_clocks": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int, POINTER(c_int),
-                                     POINTER(c_int)]),
+    "erl_kernel_span_enable": (None, [c_int]),
+    "erl_kernel_span_read": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
+    "erl_k6_timing_clocks": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                     POINTER(ctypes.c_double), c_int, POINTER(c_int), POINTER(c_int)]),
     "erl_synenv_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_uint64, _P]),
     "erl_pendulum_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_uint64, _P]),
     "erl_selftest_mfma": (c_int, [POINTER(c_float)]),
@@ -268,19 +270,36 @@ def k6_timing_read2():
     return ev.value * 1e-3, sp.value * 1e-3, n.value
 
 
+SPAN_GAE, SPAN_REPLAY_SAMPLE, SPAN_SAC_CRITIC_TRAIN, SPAN_SLAB_REDUCE, SPAN_CLIP_ADAM, SPAN_ROLLOUT = range(6)      # include/erl_hip.h ERL_SPAN_*
+
+
+def kernel_span_enable(on: bool) -> None:
+    """tagged kernels leave their own first-workgroup-in to last-workgroup-out span on the device clock while this is on"""
+    lib().erl_kernel_span_enable(int(bool(on)))
+
+
+def kernel_span_read(tag: int):
+    """(mean span in microseconds or None, number of launches) of the tagged kernel since the hook was enabled / last read"""
+    us, n = ctypes.c_double(0), c_int(0)
+    check(lib().erl_kernel_span_read(int(tag), ctypes.byref(us), ctypes.byref(n)), "erl_kernel_span_read")
+    return (us.value / n.value if n.value else None), n.value
+
+
 K6_PHASES = ("prologue", "layer1_forward", "layer2_forward", "output_objective_backward", "stage_dW1", "stage_dW3_stage", "dW2_logs_drain")
 
 
-def k6_timing_clocks():
-    """what the launches drained by the last k6_timing_read2() say about the box: {"shader_mhz": the clock they ran at, "workgroup_us": a
-    workgroup's mean duration, "phase_cycles": {phase: mean shader cycles of an actor workgroup's first wave} (empty for kernels that stamp
-    no phases), "phase_workgroups": n}"""
-    mhz, wg = ctypes.c_double(0), ctypes.c_double(0)
+def k6_timing_clocks(bracketed: bool = False):
+    """what the launches drained by the last k6_timing_read2() say about the box, for the launches WITHOUT an event bracket around them
+    (default: the kernel as the loop runs it) or the bracketed ones: {"launches": n, "span_us": mean first-workgroup-in to
+    last-workgroup-out span, "shader_mhz": the clock they ran at, "workgroup_us": a workgroup's mean duration, "phase_cycles": {phase:
+    mean shader cycles of an actor workgroup's first wave} (empty for kernels that stamp no phases), "phase_workgroups": n}"""
+    mhz, wg, sp = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
     ph = (ctypes.c_double * 8)()
-    n, nw = c_int(0), c_int(0)
-    check(lib().erl_k6_timing_clocks(ctypes.byref(mhz), ctypes.byref(wg), ph, 8, ctypes.byref(n), ctypes.byref(nw)), "erl_k6_timing_clocks")
-    return {"shader_mhz": mhz.value, "workgroup_us": wg.value, "phase_cycles": {K6_PHASES[k]: ph[k] for k in range(min(n.value, len(K6_PHASES)))},
-            "phase_workgroups": nw.value}
+    n, nw, nl = c_int(0), c_int(0), c_int(0)
+    check(lib().erl_k6_timing_clocks(int(bool(bracketed)), ctypes.byref(sp), ctypes.byref(nl), ctypes.byref(mhz), ctypes.byref(wg), ph, 8,
+                                     ctypes.byref(n), ctypes.byref(nw)), "erl_k6_timing_clocks")
+    return {"launches": nl.value, "span_us": sp.value * 1e3 / nl.value if nl.value else None, "shader_mhz": mhz.value, "workgroup_us": wg.value,
+            "phase_cycles": {K6_PHASES[k]: ph[k] for k in range(min(n.value, len(K6_PHASES)))}, "phase_workgroups": nw.value}
 
 
 def k6_null_bracket_us(reps: int = 200) -> float:

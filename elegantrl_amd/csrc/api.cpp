@@ -106,9 +106,15 @@ static unsigned long long *g_k6_span = nullptr;      // device: kK6SpanSlots slo
 static int g_k6_span_used = 0;
 constexpr int kK6SpanSlots = 8192;
 constexpr int kK6SpanWords = 16, kK6SpanPhases = 7;  // = kSpanWords, kSpanPhases of ppo_step.h
-static double g_k6_clock_mhz = 0.0, g_k6_wg_us = 0.0;            // of the last erl_k6_timing_read2: shader clock inside the sampled launches, a workgroup's own duration
-static double g_k6_phase_cycles[kK6SpanPhases] = {};             // ... mean shader cycles per phase of an actor workgroup's wave 0 (0: the kernel stamps none)
-static int g_k6_phase_wgs = 0;
+// of the last erl_k6_timing_read2, [0] over the launches WITHOUT an event bracket around them, [1] over the bracketed ones: shader clock
+// inside the launches, a workgroup's own duration, mean shader cycles per phase of an actor workgroup's wave 0 (0: the kernel stamps
+// none), summed first-in-to-last-out spans (ms) and their count
+struct K6Stats {
+    double clock_mhz = 0.0, wg_us = 0.0, phase_cycles[kK6SpanPhases] = {}, span_ms = 0.0;
+    int phase_wgs = 0, launches = 0;
+};
+static K6Stats g_k6_stats[2];
+static std::vector<unsigned char> g_k6_slot_bracketed;          // per span slot: 1 = the launch sat inside an event bracket
 
 static void k6_span_reset()
 {
@@ -119,23 +125,32 @@ static void k6_span_reset()
     }
     std::vector<unsigned long long> init((size_t)kK6SpanWords * kK6SpanSlots, 0ull);
     for (int i = 0; i < kK6SpanSlots; ++i) init[(size_t)kK6SpanWords * i] = ~0ull;
+    g_k6_slot_bracketed.clear();
     (void)hipMemcpy(g_k6_span, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
     g_k6_span_used = 0;
 }
 
-// called by erl_ppo_step_f32 right before it enqueues K6: first event of the bracket; returns the span slot of this launch
-// (nullptr: launch not sampled)
+// called by erl_ppo_step_f32 right before it enqueues K6: first event of the bracket on every n-th launch; returns the span slot of
+// this launch (nullptr: timing off / table full).  EVERY launch gets a span slot while timing is on (round 5): an event bracket turned
+// out to perturb the kernel inside it -- the sampled launches ran 6-8 us longer than their unbracketed neighbours on some boxes, which
+// is what made the driver's bench line disagree with its own step time -- so the kernel's duration is taken from the launches that
+// carry NO bracket, and the bracketed ones are reported next to them.
 unsigned long long *erl_k6_timing_begin(hipStream_t stream)
 {
     if (!g_k6_timing) return nullptr;
     g_k6_skip = (g_k6_launch++ % g_k6_timing) != 0;
-    if (g_k6_skip) return nullptr;
-    hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) { g_k6_skip = true; return nullptr; }
-    (void)hipEventRecord(e, stream);
-    if (g_k6_open) (void)hipEventDestroy(g_k6_open);
-    g_k6_open = e;
+    if (!g_k6_skip) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) {
+            g_k6_skip = true;
+        } else {
+            (void)hipEventRecord(e, stream);
+            if (g_k6_open) (void)hipEventDestroy(g_k6_open);
+            g_k6_open = e;
+        }
+    }
     if (!g_k6_span || g_k6_span_used >= kK6SpanSlots) return nullptr;
+    g_k6_slot_bracketed.push_back(g_k6_skip ? 0 : 1);
     return g_k6_span + (size_t)kK6SpanWords * g_k6_span_used++;
 }
 
@@ -182,21 +197,31 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
         std::vector<unsigned long long> h((size_t)kK6SpanWords * g_k6_span_used);
         if (hipMemcpy(h.data(), g_k6_span, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            int m = 0;
-            double wall = 0.0, mem = 0.0, wgs = 0.0, pwgs = 0.0, ph[kK6SpanPhases] = {};
-            for (int i = 0; i < g_k6_span_used; ++i) {
-                const unsigned long long *q = h.data() + (size_t)kK6SpanWords * i;
-                if (q[1] > q[0]) { span += (double)(q[1] - q[0]) / khz; ++m; }
-                wall += (double)q[2]; mem += (double)q[3]; wgs += (double)q[4];
-                for (int k = 0; k < kK6SpanPhases; ++k) ph[k] += (double)q[5 + k];
-                pwgs += (double)q[5 + kK6SpanPhases];
+            for (int b = 0; b < 2; ++b) {
+                double wall = 0.0, mem = 0.0, wgs = 0.0, pwgs = 0.0, ph[kK6SpanPhases] = {}, sp = 0.0;
+                int m = 0;
+                for (int i = 0; i < g_k6_span_used; ++i) {
+                    if ((i < (int)g_k6_slot_bracketed.size() ? g_k6_slot_bracketed[i] : 1) != b) continue;
+                    const unsigned long long *q = h.data() + (size_t)kK6SpanWords * i;
+                    if (q[1] <= q[0]) continue;            // (a slot whose launch never ran)
+                    sp += (double)(q[1] - q[0]) / khz;
+                    ++m;
+                    wall += (double)q[2]; mem += (double)q[3]; wgs += (double)q[4];
+                    for (int k = 0; k < kK6SpanPhases; ++k) ph[k] += (double)q[5 + k];
+                    pwgs += (double)q[5 + kK6SpanPhases];
+                }
+                K6Stats &st = g_k6_stats[b];
+                st = K6Stats{};
+                st.span_ms = sp;
+                st.launches = m;
+                // shader cycles per constant-rate tick x the tick rate = the clock the launches ran at
+                st.clock_mhz = wall > 0 ? mem / wall * (double)khz * 1e-3 : 0.0;
+                st.wg_us = wgs > 0 ? wall / wgs / (double)khz * 1e3 : 0.0;
+                st.phase_wgs = (int)pwgs;
+                for (int k = 0; k < kK6SpanPhases; ++k) st.phase_cycles[k] = pwgs > 0 ? ph[k] / pwgs : 0.0;
             }
-            if (m && m != n) span *= (double)n / m;         // (slots that never ran: scale to the bracketed count)
-            // shader cycles per constant-rate tick x the tick rate = the clock the sampled launches ran at
-            g_k6_clock_mhz = wall > 0 ? mem / wall * (double)khz * 1e-3 : 0.0;
-            g_k6_wg_us = wgs > 0 ? wall / wgs / (double)khz * 1e3 : 0.0;
-            g_k6_phase_wgs = (int)pwgs;
-            for (int k = 0; k < kK6SpanPhases; ++k) g_k6_phase_cycles[k] = pwgs > 0 ? ph[k] / pwgs : 0.0;
+            span = g_k6_stats[1].span_ms;                   // read2's pair: events and spans of the SAME (bracketed) launches
+            if (g_k6_stats[1].launches && g_k6_stats[1].launches != n) span *= (double)n / g_k6_stats[1].launches;
         }
         k6_span_reset();
     }
@@ -208,21 +233,81 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
 
 extern "C" int erl_k6_timing_read(double *total_ms, int *launches) { return erl_k6_timing_read2(total_ms, nullptr, launches); }
 
-// what the launches drained by the LAST erl_k6_timing_read2 say about the box: the shader clock they ran at (MHz: shader cycles per tick
-// of the constant-rate clock, summed over every workgroup's own entry-to-exit interval), a workgroup's mean duration (us), and -- for
-// kernels that stamp phases (ppo_step_s3_kernel) -- the mean shader cycles per phase of an actor workgroup's first wave
-// (phase_cycles[0 .. n_phases), n_phases <= 7: prologue | layer-1 forward | layer-2 forward | output layer + objective + backward |
-// staging + dW1 | staging + dW3 + staging | dW2 + logs + store drain); phase_workgroups = how many workgroups the means are over
-extern "C" int erl_k6_timing_clocks(double *shader_mhz, double *workgroup_us, double *phase_cycles, int max_phases, int *n_phases,
-                                    int *phase_workgroups)
+// what the launches drained by the LAST erl_k6_timing_read2 say (include/erl_hip.h): bracketed = 0: the launches without an event
+// bracket (the kernel as the loop runs it), 1: the bracketed ones
+extern "C" int erl_k6_timing_clocks(int bracketed, double *span_ms, int *launches, double *shader_mhz, double *workgroup_us,
+                                    double *phase_cycles, int max_phases, int *n_phases, int *phase_workgroups)
 {
-    if (shader_mhz) *shader_mhz = g_k6_clock_mhz;
-    if (workgroup_us) *workgroup_us = g_k6_wg_us;
-    const int np = g_k6_phase_wgs > 0 ? kK6SpanPhases : 0;
+    const K6Stats &st = g_k6_stats[bracketed ? 1 : 0];
+    if (span_ms) *span_ms = st.span_ms;
+    if (launches) *launches = st.launches;
+    if (shader_mhz) *shader_mhz = st.clock_mhz;
+    if (workgroup_us) *workgroup_us = st.wg_us;
+    const int np = st.phase_wgs > 0 ? kK6SpanPhases : 0;
     if (phase_cycles)
-        for (int k = 0; k < np && k < max_phases; ++k) phase_cycles[k] = g_k6_phase_cycles[k];
+        for (int k = 0; k < np && k < max_phases; ++k) phase_cycles[k] = st.phase_cycles[k];
     if (n_phases) *n_phases = np;
-    if (phase_workgroups) *phase_workgroups = g_k6_phase_wgs;
+    if (phase_workgroups) *phase_workgroups = st.phase_wgs;
+    return ERL_OK;
+}
+
+// ---- generic per-kernel spans (erl_common.h: erl_span_slot / erl_span_in / erl_span_out) ----------------------------------------
+constexpr int kSpanTags = ERL_SPAN_TAGS, kSpanSlotsPerTag = 4096;
+static unsigned long long *g_span_tab = nullptr;                // device: [tag][slot]{min entry, max exit}
+static int g_span_used[kSpanTags] = {};
+static bool g_span_on = false;
+
+static void span_tab_reset()
+{
+    const size_t words = (size_t)kSpanTags * kSpanSlotsPerTag * 2;
+    if (!g_span_tab && hipMalloc((void **)&g_span_tab, words * sizeof(unsigned long long)) != hipSuccess) {
+        g_span_tab = nullptr;
+        (void)hipGetLastError();
+        return;
+    }
+    std::vector<unsigned long long> init(words, 0ull);
+    for (size_t i = 0; i < words; i += 2) init[i] = ~0ull;
+    (void)hipMemcpy(g_span_tab, init.data(), words * sizeof(unsigned long long), hipMemcpyHostToDevice);
+    for (int &u : g_span_used) u = 0;
+}
+
+unsigned long long *erl_span_slot(int tag)
+{
+    if (!g_span_on || !g_span_tab || tag < 0 || tag >= kSpanTags || g_span_used[tag] >= kSpanSlotsPerTag) return nullptr;
+    return g_span_tab + ((size_t)tag * kSpanSlotsPerTag + g_span_used[tag]++) * 2;
+}
+
+extern "C" void erl_kernel_span_enable(int on)
+{
+    g_span_on = on != 0;
+    if (g_span_on) span_tab_reset();
+}
+
+// drains tag's slots: the summed spans (microseconds) of the launches since the hook was enabled / last read, and their number;
+// waits for the device (the launches must have finished)
+extern "C" int erl_kernel_span_read(int tag, double *total_us, int *launches)
+{
+    ERL_REQUIRE(tag >= 0 && tag < kSpanTags, "erl_kernel_span_read: unknown tag %d", tag);
+    double tot = 0.0;
+    int n = 0;
+    if (g_span_tab && g_span_used[tag] > 0) {
+        int rc = erl_hip_status(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        if (rc) return rc;
+        int dev = 0, khz = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+        std::vector<unsigned long long> h(2 * (size_t)g_span_used[tag]);
+        unsigned long long *base = g_span_tab + (size_t)tag * kSpanSlotsPerTag * 2;
+        rc = erl_hip_status(hipMemcpy(h.data(), base, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "hipMemcpy(span table)");
+        if (rc) return rc;
+        for (int i = 0; i < g_span_used[tag]; ++i)
+            if (h[2 * i + 1] > h[2 * i]) { tot += (double)(h[2 * i + 1] - h[2 * i]) / khz * 1e3; ++n; }
+        for (size_t i = 0; i < h.size(); i += 2) { h[i] = ~0ull; h[i + 1] = 0ull; }
+        (void)hipMemcpy(base, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+        g_span_used[tag] = 0;
+    }
+    if (total_us) *total_us = tot;
+    if (launches) *launches = n;
     return ERL_OK;
 }
 

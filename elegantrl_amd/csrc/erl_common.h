@@ -90,6 +90,26 @@ static inline int erl_hip_status(hipError_t e, const char *what)
 
 #define ERL_LAUNCH_CHECK(what) return erl_hip_status(hipGetLastError(), what)
 
+// ---------------------------------------------------------------------------------------------
+// measurement hook (api.cpp; include/erl_hip.h erl_kernel_span_*): a kernel's own duration on the device's constant-rate clock, first
+// workgroup in to last workgroup out -- what rocprofv3's kernel duration measures, available to bench.py in the loop without a
+// profiler and without an event bracket (a bracket perturbs the kernel inside it and adds its own dispatch / completion time).
+// Host: `unsigned long long *sp = erl_span_slot(ERL_SPAN_x)` right before the launch (nullptr while the hook is off), passed to the
+// kernel; device: `const auto t0 = erl_span_in(sp); ... erl_span_out(sp, t0);` (thread 0 of every workgroup; no early return between).
+// ---------------------------------------------------------------------------------------------
+unsigned long long *erl_span_slot(int tag);
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long erl_span_in(const unsigned long long *span) { return span ? wall_clock64() : 0ull; }
+__device__ __forceinline__ void erl_span_out(unsigned long long *span, unsigned long long t0)
+{
+    if (span && threadIdx.x == 0 && threadIdx.y == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+        atomicMin(span, t0);
+        atomicMax(span + 1, (unsigned long long)wall_clock64());
+    }
+}
+#endif
+
 static inline int64_t erl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------

@@ -42,8 +42,9 @@ __global__ __launch_bounds__(64) void gae_exact_kernel(float *__restrict__ rewar
                                                        const float *__restrict__ values,
                                                        const float *__restrict__ next_value, float *__restrict__ adv,
                                                        float *__restrict__ ret, int H, int N, float gamma, float lam,
-                                                       int mutate, double *__restrict__ partials)
+                                                       int mutate, double *__restrict__ partials, unsigned long long *span)
 {
+    const unsigned long long t_span = erl_span_in(span);
     const int n = blockIdx.x * 64 + threadIdx.x;
     const bool live = n < N;
     float nv = live ? next_value[n] : 0.f;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(64) void gae_exact_kernel(float *__restrict__ rewar
             partials[(size_t)blockIdx.x * 3 + 2] = w2;
         }
     }
+    erl_span_out(span, t_span);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -430,7 +432,7 @@ extern "C" int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t 
         nparts = nblk;
 #define LAUNCH_EXACT(VT, ST)                                                                                       \
     hipLaunchKernelGGL((gae_exact_kernel<VT, ST>), dim3(nblk), dim3(64), 0, stream, rewards, undones, unmasks, values, \
-                       next_value, adv, ret, (int)H, (int)N, gamma, lam, (int)mutate, partials)
+                       next_value, adv, ret, (int)H, (int)N, gamma, lam, (int)mutate, partials, erl_span_slot(ERL_SPAN_GAE))
         if (vtrace) { if (want_stats) LAUNCH_EXACT(true, true); else LAUNCH_EXACT(true, false); }
         else        { if (want_stats) LAUNCH_EXACT(false, true); else LAUNCH_EXACT(false, false); }
 #undef LAUNCH_EXACT

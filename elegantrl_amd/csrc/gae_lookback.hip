@@ -46,6 +46,7 @@ struct LbArgs {
     uint32_t *fault;           // host-mapped counter of look-back spin timeouts (erl_async_fault_count); may be NULL
     uint32_t spin_limit;       // polls per granule before a predecessor is declared lost
     uint32_t publish_nonce;    // == nonce; ERL_GAE_LB_FAULT=1 (tests) publishes under a foreign nonce so readers time out
+    unsigned long long *span;  // measurement hook (erl_common.h: erl_span_*); nullptr = off
 };
 
 __device__ __forceinline__ unsigned long long pack_granule(float a, uint32_t tag)
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
     __shared__ double s_red[3][LB_MAX_WAVES];
     __shared__ uint32_t s_ticket;
 
+    const unsigned long long t_span = erl_span_in(g.span);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
     if (threadIdx.x == 0) s_ticket = atomicAdd(g.ticket, 1u) - g.ticket_base;   // wrap-safe: tickets of this launch are 0 .. grid-1
     __syncthreads();
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
             g.partials[(size_t)blockIdx.x * 3 + threadIdx.x] = s;
         }
     }
+    erl_span_out(g.span, t_span);
 }
 
 int env_int(const char *name, int dflt)
@@ -355,6 +358,7 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
     g.partials = (double *)(ws + 256 + slot_bytes);
     g.fault = erl_fault_word(ERL_FAULT_GAE_LOOKBACK);
+    g.span = erl_span_slot(ERL_SPAN_GAE);
     {
         const int lim = env_int("ERL_GAE_LB_SPIN", 1 << 22);
         g.spin_limit = lim > 0 ? (uint32_t)lim : 1u;

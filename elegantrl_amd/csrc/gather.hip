@@ -110,9 +110,10 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restr
                                                             void *__restrict__ o_action, float *__restrict__ o_reward,
                                                             float *__restrict__ o_undone, float *__restrict__ o_unmask,
                                                             float *__restrict__ o_next, int64_t *__restrict__ o_ids0,
-                                                            int64_t *__restrict__ o_ids1, int spw)
+                                                            int64_t *__restrict__ o_ids1, int spw, unsigned long long *span)
 {
     __shared__ int64_t s_row[RS_SAMPLES];
+    const unsigned long long t_span = erl_span_in(span);
     const int W = 2 * S + A + 3;
     for (int64_t b0 = (int64_t)blockIdx.x * spw; b0 < B; b0 += (int64_t)gridDim.x * spw) {
         const int nb = (int)min((int64_t)spw, B - b0);
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restr
             }
         }
     }
+    erl_span_out(span, t_span);
 }
 
 inline int grid_for(int64_t total)
@@ -232,14 +234,15 @@ int replay_sample_impl(const char *what, bool act_u8, const float *buf_states, c
     if (spw > RS_SAMPLES) spw = RS_SAMPLES;
     const int g = grid_for(erl_cdiv(B, spw) * 256);
     hipStream_t st = (hipStream_t)stream;
+    unsigned long long *sp = erl_span_slot(ERL_SPAN_REPLAY_SAMPLE);
     if (act_u8)
         hipLaunchKernelGGL((replay_sample_kernel<true>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones,
                            buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone, out_unmask,
-                           out_next_state, out_ids0, out_ids1, (int)spw);
+                           out_next_state, out_ids0, out_ids1, (int)spw, sp);
     else
         hipLaunchKernelGGL((replay_sample_kernel<false>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones,
                            buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone, out_unmask,
-                           out_next_state, out_ids0, out_ids1, (int)spw);
+                           out_next_state, out_ids0, out_ids1, (int)spw, sp);
     return erl_hip_status(hipGetLastError(), what);
 }
 

@@ -67,8 +67,10 @@ __device__ __forceinline__ void ld_sys_wait(T (&x)[ERL_P2P_MAX_WORLD])     // th
 // every block shape writes the same table bit for bit.
 template <typename T, bool DP, int NT>
 __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int n_slabs, int64_t stride, T *out, TailGroups gr,
-                                                             int n_groups, float grad_scale, double *partials, ErlExchange ex)
+                                                             int n_groups, float grad_scale, double *partials, ErlExchange ex,
+                                                             unsigned long long *span = nullptr)
 {
+    const unsigned long long t_span = erl_span_in(span);
     constexpr int NE = NT / 4;
     __shared__ T part[4][NE];
     const int el = threadIdx.x & (NE - 1), p = threadIdx.x / NE;
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int
             }
         }
     }
+    erl_span_out(span, t_span);
 }
 
 // clip + Adam from the partial norms: grid = (ceil(longest / 1024), n_groups); one element per thread, its four loads
@@ -171,9 +174,10 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
                                                                   const double *__restrict__ partials, int nblk, float beta1,
                                                                   float beta2, float eps, float max_norm, float grad_scale,
                                                                   float step_size, float bc2_sqrt, S3Images im,
-                                                                  const uint32_t *__restrict__ poison)
+                                                                  const uint32_t *__restrict__ poison, unsigned long long *span)
 {
     __shared__ double scratch[16];
+    const unsigned long long t_span = erl_span_in(span);
     // a gradient exchange of this update loop timed out (reduce_exchange_kernel): its sums are garbage -- touch nothing
     if (poison && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int gi = blockIdx.y;
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
             else if (im.net[gi].img1 && ie < (int64_t)h1 * S) s3_image_put(im.net[gi].img1, im.net[gi].K1, (int)(ie / S), (int)(ie % S), e_p);
         }
     }
+    erl_span_out(span, t_span);
 }
 
 // W2 and W1 images of both networks from the flat parameters [actor | critic]: one thread per image element (W1's pad columns: 0)
@@ -310,10 +315,10 @@ int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stri
         ERL_REQUIRE(nblk <= ex->nblk_max && stride * (int64_t)sizeof(float) <= ex->row_bytes,
                     "gradient exchange: %lld floats > the %lld the peer stages were sized for", (long long)stride, (long long)(ex->row_bytes / 4));
         hipLaunchKernelGGL((reduce_exchange_kernel<float, true, 1024>), dim3((unsigned)nblk), dim3(1024), 0, stream, slabs, n_slabs, stride, out, gr,
-                           n_groups, grad_scale, partials, *ex);
+                           n_groups, grad_scale, partials, *ex, erl_span_slot(ERL_SPAN_SLAB_REDUCE));
     } else {        // 256 threads x 64 elements (grad_reduce_kernel's shape: 795 workgroups keep every CU's memory pipes busy)
         hipLaunchKernelGGL((reduce_exchange_kernel<float, false, 256>), dim3((unsigned)erl_cdiv(stride, 64)), dim3(256), 0, stream, slabs, n_slabs,
-                           stride, out, gr, n_groups, grad_scale, partials, ErlExchange{});
+                           stride, out, gr, n_groups, grad_scale, partials, ErlExchange{}, erl_span_slot(ERL_SPAN_SLAB_REDUCE));
     }
     ERL_LAUNCH_CHECK("gradient reduce / exchange");
 }
@@ -413,7 +418,7 @@ int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(clip_adam_partials_kernel, dim3((unsigned)erl_cdiv(longest, 1024), n_groups), dim3(1024), 0, (hipStream_t)stream, params,
                        grads, exp_avg, exp_avg_sq, gr, partials, (int)nblk, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
-                       (float)sqrt(bc2), images ? *images : S3Images{}, poison);
+                       (float)sqrt(bc2), images ? *images : S3Images{}, poison, erl_span_slot(ERL_SPAN_CLIP_ADAM));
     ERL_LAUNCH_CHECK("erl_clip_adam_partials_f32");
 }
 

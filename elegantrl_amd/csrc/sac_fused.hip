@@ -556,6 +556,7 @@ struct CriticArgs {
     // logged sums and d(mean q)/d(action) come out as `split` partial results per decoder, added in slice order by their consumers.
     int split;
     int qt_split;                            // MODE 1: qt holds [E][qt_split][B] partial target values
+    unsigned long long *span;                // measurement hook (erl_common.h: erl_span_*; set for the training pass); nullptr = off
 };
 
 template <int MODE, int C0, int C1>
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
 {
     __shared__ TileLds lds;
     __shared__ float dql[TS];
+    const unsigned long long t_span = MODE == 1 ? erl_span_in(g.span) : 0ull;
     const LaneId L = lane_id();
     const FusedDims &d = g.d;
     const int ey = blockIdx.y, e = ey / g.split, E = d.E;
@@ -697,7 +699,10 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
             }
         }
     }
-    if (MODE == 1) return;
+    if (MODE == 1) {
+        erl_span_out(g.span, t_span);
+        return;
+    }
     lds_barrier();
     // ---- d(mean q)/d(action) = the action columns of We^T dEnc
     layer_small_mma<true, false>(wa, nullptr, d.h0, d.A, lds.T0, lds.part, lds.Yl, L);
@@ -1448,7 +1453,9 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     ca.P = critic_params; ca.Xs = state; ca.Xa = action; ca.q = qc;
     ca.qt = qt; ca.reward = reward; ca.undone = undone; ca.unmask = unmask; ca.lp_next = lp_next; ca.is_weight = is_weight; ca.alpha0 = alpha0;
     ca.gamma = gamma; ca.label = label; ca.dq = dq; ca.xa = xa; ca.enc = enc; ca.H1e = H1e; ca.dZ1e = dZ1e; ca.dEncE = dEncE;
+    ca.span = erl_span_slot(ERL_SPAN_SAC_CRITIC_TRAIN);
     FUSED_KT_DISPATCH(LAUNCH_CRITIC1)
+    ca.span = nullptr;
     // ---- (4) every critic weight / bias gradient in one launch
     {
         DwArgs dw{};

@@ -617,15 +617,32 @@ ERL_API void erl_k6_timing_enable(int every_nth);
 ERL_API int erl_k6_timing_read(double *total_ms, int *launches);
 ERL_API int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launches);
 ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median_us);
-/* What the launches drained by the LAST erl_k6_timing_read2 say about the box (ABI 17): shader_mhz = the clock the sampled launches
- * actually ran at (shader cycles per tick of the constant-rate clock, summed over every workgroup's own entry-to-exit interval: the
- * chip clocks to its power budget, so two boxes -- or two kernels on one box -- do not run the same clock); workgroup_us = a
- * workgroup's mean duration; phase_cycles[0 .. *n_phases) (at most max_phases written; *n_phases = 0 for kernels that stamp no
- * phases) = mean shader cycles per phase of an actor workgroup's first wave in ppo_step_s3_kernel: prologue | first layer forward |
- * second layer forward | output layer + objective + backward | staging + dW1 | staging + dW3 + staging | dW2 + logs + store drain;
- * phase_workgroups = the number of workgroups the means are over.  Any pointer may be NULL. */
-ERL_API int erl_k6_timing_clocks(double *shader_mhz, double *workgroup_us, double *phase_cycles, int max_phases, int *n_phases,
-                         int *phase_workgroups);
+/* What the launches drained by the LAST erl_k6_timing_read2 say about the box (ABI 17).  While timing is on EVERY K6 launch leaves its
+ * span and clocks; every_nth only selects which launches also sit inside an event bracket -- and a bracket perturbs the kernel inside it
+ * (the bracketed launches ran 6-8 us longer than their neighbours on some boxes of the pool: round 5), so `bracketed` selects the group:
+ * 0 = the launches WITHOUT a bracket (the kernel as the loop runs it), 1 = the bracketed ones.  span_ms / launches = summed
+ * first-workgroup-in to last-workgroup-out spans and their count; shader_mhz = the clock the launches actually ran at (shader cycles
+ * per tick of the constant-rate clock, summed over every workgroup's own entry-to-exit interval: the chip clocks to its power budget,
+ * so two boxes -- or two kernels on one box -- do not run the same clock); workgroup_us = a workgroup's mean duration;
+ * phase_cycles[0 .. *n_phases) (at most max_phases written; *n_phases = 0 for kernels that stamp no phases) = mean shader cycles per
+ * phase of an actor workgroup's first wave in ppo_step_s3_kernel: prologue | first layer forward | second layer forward | output layer
+ * + objective + backward | staging + dW1 | staging + dW3 + staging | dW2 + logs + store drain; phase_workgroups = the number of
+ * workgroups the means are over.  Any pointer may be NULL. */
+/* The same hook for the other kernels of the hot path (ABI 17): while erl_kernel_span_enable(1), every launch of a tagged kernel
+ * leaves its own first-workgroup-in to last-workgroup-out span on the device's constant-rate clock (up to 4096 launches per tag between
+ * reads); erl_kernel_span_read(tag) waits for the device, returns the summed spans (microseconds) and their number, and clears the
+ * tag.  What rocprofv3's kernel duration measures, without a profiler and without an event bracket around the launch. */
+#define ERL_SPAN_GAE 0             /* gae_exact_kernel / gae_lookback_kernel (erl_gae_scan_f32) */
+#define ERL_SPAN_REPLAY_SAMPLE 1   /* replay_sample_kernel (erl_replay_sample_f32) */
+#define ERL_SPAN_SAC_CRITIC_TRAIN 2 /* critic_tile_kernel<1>: the fused SAC step's critic training pass */
+#define ERL_SPAN_SLAB_REDUCE 3     /* reduce_exchange_kernel: the PPO minibatch's slab reduction (+ exchange) */
+#define ERL_SPAN_CLIP_ADAM 4       /* clip_adam_partials_kernel */
+#define ERL_SPAN_ROLLOUT 5         /* rollout_fused_kernel: the persistent PPO rollout */
+#define ERL_SPAN_TAGS 8
+ERL_API void erl_kernel_span_enable(int on);
+ERL_API int erl_kernel_span_read(int tag, double *total_us, int *launches);
+ERL_API int erl_k6_timing_clocks(int bracketed, double *span_ms, int *launches, double *shader_mhz, double *workgroup_us,
+                         double *phase_cycles, int max_phases, int *n_phases, int *phase_workgroups);
 
 /* ---------------------------------------------------------------------------------------------
  * GPU-resident synthetic environments for measurement; they implement the

@@ -165,7 +165,7 @@ def test_modsac_update_net_loop_and_checkpoint(tmp_path):
     N, S, A = 64, 11, 3
     args = Config(AgentModSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A,
                                            "if_discrete": False})
-    args.net_dims, args.batch_size, args.horizon_len, args.repeat_times = [64, 32], 128, 16, 1.0
+    args.net_dims, args.batch_size, args.horizon_len, args.repeat_times = [64, 32], 128, 16, 32.0      # cur_size counts time rows (AgentBase.py:180)
     th.manual_seed(0)
     agent = AgentModSAC(args.net_dims, S, A, gpu_id=0, args=args)
     env = SynVecEnv(N, S, A, max_step=50, gpu_id=0, seed=1)
@@ -176,7 +176,7 @@ def test_modsac_update_net_loop_and_checkpoint(tmp_path):
     w0 = agent.act.encoder_s[0].weight.detach().clone()
     t0 = agent.act_target.encoder_s[0].weight.detach().clone()
     oc, oa = agent.update_net(buf)
-    times = int(buf.cur_size * 1.0 / 128)
+    times = int(buf.cur_size * 32.0 / 128)
     assert times >= 6 and np.isfinite([oc, oa]).all()
     assert 0 < agent.update_a < times and agent._actor_step == agent.update_a          # some steps skipped the actor
     assert not th.equal(agent.act.encoder_s[0].weight, w0) and not th.equal(agent.act_target.encoder_s[0].weight, t0)

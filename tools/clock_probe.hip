@@ -1,0 +1,159 @@
+// What clock does THIS box give a kernel?  (round 5: the pool's boxes run the PPO minibatch kernel at different speeds; the chip
+// clocks to its power budget -- MI355X_MICROARCH.md, "DVFS give-back" -- so the question is asked of the hardware, per kind of work.)
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/clock_probe tools/clock_probe.hip && tools/bin/clock_probe
+//
+// Every workgroup (one per CU, 4 waves = one per SIMD, like the minibatch kernel) runs a fixed instruction count of ONE kind of work
+// and stamps s_memtime (shader clock) and s_memrealtime (constant 100 MHz) around it; the ratio is the clock the body ran at, the
+// cycles per instruction say whether the pipe itself is as fast as on another box.  Bodies: bf16 MFMA 32x32x16 back to back on two
+// accumulators (the minibatch kernel's matrix instruction), fp32 MFMA 32x32x2, plain fp32 FMA, an MFMA + 5 VALU mix (the minibatch
+// kernel's forward layers), and LDS reads.  Output: one JSON line.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CHECK(x)                                                                  \
+    do {                                                                          \
+        hipError_t e_ = (x);                                                      \
+        if (e_ != hipSuccess) {                                                   \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));               \
+            exit(1);                                                              \
+        }                                                                         \
+    } while (0)
+
+__device__ __forceinline__ unsigned long long memtime()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    return t;
+}
+
+struct Rec {
+    unsigned long long cyc, wall;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void body(int iters, Rec *out, float *sink)
+{
+    __shared__ float lds[4096];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = (float)i * 1e-6f;
+    __syncthreads();
+    f32x16 a0 = {0}, a1 = {0};
+    bf16x8 p = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    bf16x8 q = {0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00};
+    float v0 = lane * 1e-3f, v1 = 1.0f, v2 = 0.5f, v3 = 0.25f, v4 = 0.125f;
+    const unsigned long long w0 = wall_clock64(), c0 = memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (KIND == 0) {                 // bf16 MFMA 32x32x16, two accumulators, 16 per iteration
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p, q, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q, p, a1, 0, 0, 0);
+            }
+        } else if (KIND == 1) {          // fp32 MFMA 32x32x2, 16 per iteration
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, v2, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, v1, a1, 0, 0, 0);
+            }
+        } else if (KIND == 2) {          // fp32 FMA, 5 independent chains, 80 per iteration
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                v0 = __builtin_fmaf(v0, 0.999f, 1e-3f);
+                v1 = __builtin_fmaf(v1, 0.998f, 2e-3f);
+                v2 = __builtin_fmaf(v2, 0.997f, 3e-3f);
+                v3 = __builtin_fmaf(v3, 0.996f, 4e-3f);
+                v4 = __builtin_fmaf(v4, 0.995f, 5e-3f);
+            }
+        } else if (KIND == 3) {          // the forward layers' mix: one bf16 MFMA + 5 VALU, 16 groups per iteration
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p, q, a0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                v0 = __builtin_fmaf(v0, 0.999f, 1e-3f);
+                v1 = __builtin_fmaf(v1, 0.998f, 2e-3f);
+                v2 = __builtin_fmaf(v2, 0.997f, 3e-3f);
+                v3 = __builtin_fmaf(v3, 0.996f, 4e-3f);
+                v4 = __builtin_fmaf(v4, 0.995f, 5e-3f);
+                __builtin_amdgcn_sched_barrier(0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q, p, a1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                v0 = __builtin_fmaf(v0, 0.999f, 1e-3f);
+                v1 = __builtin_fmaf(v1, 0.998f, 2e-3f);
+                v2 = __builtin_fmaf(v2, 0.997f, 3e-3f);
+                v3 = __builtin_fmaf(v3, 0.996f, 4e-3f);
+                v4 = __builtin_fmaf(v4, 0.995f, 5e-3f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {                         // LDS: 16 ds_read_b128 per iteration (dependent on the loop counter only)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float4 x = *reinterpret_cast<const float4 *>(&lds[((lane * 4 + 64 * u + 4 * it) & 4092)]);
+                v0 += x.x; v1 += x.y; v2 += x.z; v3 += x.w;
+            }
+        }
+    }
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4));
+    const unsigned long long c1 = memtime(), w1 = wall_clock64();
+    if (threadIdx.x == 0) out[blockIdx.x] = Rec{c1 - c0, w1 - w0};
+    float s = v0 + v1 + v2 + v3 + v4;
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int KIND>
+void run(const char *name, int per_iter, int iters, int reps, int khz, bool last)
+{
+    Rec *d;
+    float *sink;
+    const int grid = 256;
+    CHECK(hipMalloc(&d, grid * sizeof(Rec)));
+    CHECK(hipMalloc(&sink, 4));
+    std::vector<Rec> h(grid);
+    double best_mhz = 0, sum_mhz = 0, sum_cpi = 0, first_mhz = 0;
+    for (int r = 0; r < reps; ++r) {
+        hipLaunchKernelGGL(body<KIND>, dim3(grid), dim3(256), 0, 0, iters, d, sink);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h.data(), d, grid * sizeof(Rec), hipMemcpyDeviceToHost));
+        double cyc = 0, wall = 0;
+        for (auto &x : h) { cyc += (double)x.cyc; wall += (double)x.wall; }
+        const double mhz = cyc / wall * khz * 1e-3, cpi = cyc / grid / ((double)iters * per_iter);
+        if (r == 0) first_mhz = mhz;
+        if (r >= reps / 2) { sum_mhz += mhz; sum_cpi += cpi; }
+        best_mhz = mhz > best_mhz ? mhz : best_mhz;
+    }
+    const int n = reps - reps / 2;
+    printf("\"%s\": {\"shader_mhz\": %.1f, \"shader_mhz_first_launch\": %.1f, \"shader_mhz_max\": %.1f, \"cycles_per_instruction\": %.2f, "
+           "\"us_per_launch\": %.1f}%s",
+           name, sum_mhz / n, first_mhz, best_mhz, sum_cpi / n, sum_cpi / n * iters * per_iter / (sum_mhz / n), last ? "" : ", ");
+    CHECK(hipFree(d));
+    CHECK(hipFree(sink));
+}
+
+int main()
+{
+    int dev = 0, khz = 0, cus = 0, sclk = 0, mclk = 0;
+    CHECK(hipGetDevice(&dev));
+    CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    CHECK(hipDeviceGetAttribute(&sclk, hipDeviceAttributeClockRate, dev));
+    CHECK(hipDeviceGetAttribute(&mclk, hipDeviceAttributeMemoryClockRate, dev));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, dev));
+    printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"wall_clock_khz\": %d, \"attr_clock_khz\": %d, \"attr_memory_clock_khz\": %d, ",
+           prop.name, prop.gcnArchName, cus, khz, sclk, mclk);
+    // ~100-200 us per launch, 24 launches each: long enough for the power manager to settle on the body's clock
+    run<0>("mfma_bf16_32x32x16", 16, 400, 24, khz, false);
+    run<1>("mfma_f32_32x32x2", 16, 200, 24, khz, false);
+    run<2>("valu_fma_f32", 80, 600, 24, khz, false);
+    run<3>("mfma_bf16_plus_5_valu", 16, 300, 24, khz, false);
+    run<4>("lds_read_b128", 16, 1000, 24, khz, true);
+    printf("}\n");
+    return 0;
+}

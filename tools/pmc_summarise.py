@@ -16,18 +16,42 @@ from bench import KERNEL_SOURCES, kernel_source_sha16  # noqa: E402  (stamp = ha
 
 
 def short(name: str) -> str:
+    # PMC_KEEP_TEMPLATE=1 keeps a kernel's template arguments (critic_tile_kernel<1, 2, 2>: the three passes of the SAC critic apart)
+    if os.environ.get("PMC_KEEP_TEMPLATE"):
+        m = re.search(r"(\w+_kernel(?:<[^(]*>)?)", name)
+        return m.group(1).replace(" ", "") if m else name[:60]
     m = re.search(r"(\w+_kernel)", name)
     return m.group(1) if m else name[:60]
+
+
+def case_names():
+    """PMC_CASES=<kernel>:<launches per case>:<name0>,<name1>,...: the kernel's dispatches, in order, belong to consecutive cases of
+    that many launches each (a workload that runs one kernel at several sizes: tools/c3_pmc_workload.py C3_PART=k9)"""
+    spec = os.environ.get("PMC_CASES")
+    if not spec:
+        return None
+    k, per, names = spec.split(":")
+    return k, int(per), names.split(",")
 
 
 def main():
     out_path, files = sys.argv[1], sys.argv[2:]
     per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # kernel -> counter -> dispatch -> value
     dur = defaultdict(dict)
+    cases = case_names()
     for f in files:
         with open(f, newline="") as fh:
-            for row in csv.DictReader(fh):
+            rows = list(csv.DictReader(fh))
+        order = {}
+        if cases:       # dispatch ids of the case kernel in this file, in launch order -> case index
+            ids = sorted({int(r["Dispatch_Id"]) for r in rows if short(r["Kernel_Name"]) == cases[0]})
+            order = {d: i // cases[1] for i, d in enumerate(ids)}
+        if True:
+            for row in rows:
                 k = short(row["Kernel_Name"])
+                if cases and k == cases[0]:
+                    ci = order[int(row["Dispatch_Id"])]
+                    k = f"{k}[{cases[2][ci] if ci < len(cases[2]) else ci}]"
                 did = (f, row["Dispatch_Id"])
                 per[k][row["Counter_Name"]][did] += float(row["Counter_Value"])
                 if row.get("Start_Timestamp") and row.get("End_Timestamp"):
