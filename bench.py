@@ -598,7 +598,7 @@ def main():
     t_gae.enabled = t_explore.enabled = t_update.enabled = True
     # every n-th K6 launch is timed twice: a HIP-event bracket on its stream and the kernel's own span on the device clock
     _hip.k6_timing_enable(opt.k6_sample)
-    _hip.kernel_span_enable(True)          # the loop's other kernels leave their own device-clock spans (no brackets): GAE scan, slab reduction, clip + Adam
+    _hip.kernel_span_enable(8)             # every 8th launch of the loop's other kernels leaves its own device-clock span (no brackets): GAE scan, slab reduction, clip + Adam
     parallel.barrier()
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -762,8 +762,9 @@ def main():
                      "frac_of_fp32_mfma_peak": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops,
                      "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": k6_clocks["launches"] or n_k6,
-                     "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel), mean over "
-                               "the launches of the timed region that carry NO event bracket" if k6_clocks["launches"] else
+                     "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel, one record per "
+                               f"workgroup), mean over the sampled launches of the timed region that carry NO event bracket (1 in {opt.k6_sample})"
+                               if k6_clocks["launches"] else
                                "kernel span on the device clock, bracketed launches" if k6_span_s == k6_span_s else
                                "HIP-event bracket minus empty-launch bracket"),
                      # every opt.k6_sample-th launch also sits inside a HIP-event bracket: the bracket's own time, the SAME launches' in-kernel

@@ -82,6 +82,9 @@ _SIGNATURES = {
     "erl_reduce_clip_adam_grid_f32": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
                                               c_float, c_float, c_float, c_float, c_float, _P]),
     "erl_reduce_clip_adam_grid_ok": (c_int, [c_int64]),
+    "erl_tail_fused_ok": (c_int, [c_int64]),
+    "erl_reduce_clip_adam_fused_f32": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P, POINTER(c_int64), POINTER(c_int64), c_int, c_int32, c_float,
+                                               c_float, c_float, c_float, c_float, c_float, _P]),
     "erl_ppo_update_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64,
                                    _P, c_int64, c_int, c_float, c_float, c_int, _P, _P, c_int32, c_float, c_float, c_float, c_float,
                                    c_float, _P]),
@@ -273,9 +276,10 @@ def k6_timing_read2():
 SPAN_GAE, SPAN_REPLAY_SAMPLE, SPAN_SAC_CRITIC_TRAIN, SPAN_SLAB_REDUCE, SPAN_CLIP_ADAM, SPAN_ROLLOUT = range(6)      # include/erl_hip.h ERL_SPAN_*
 
 
-def kernel_span_enable(on: bool) -> None:
-    """tagged kernels leave their own first-workgroup-in to last-workgroup-out span on the device clock while this is on"""
-    lib().erl_kernel_span_enable(int(bool(on)))
+def kernel_span_enable(every_nth) -> None:
+    """every n-th launch of a tagged kernel leaves its own first-workgroup-in to last-workgroup-out span on the device clock (True = every
+    launch, 0 / False = off); enabling clears earlier records"""
+    lib().erl_kernel_span_enable(int(every_nth))
 
 
 def kernel_span_read(tag: int):

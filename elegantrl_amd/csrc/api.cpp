@@ -97,48 +97,53 @@ extern "C" int erl_async_fault_count(int reset)
 // The pairs are kept until erl_k6_timing_read2() drains them.
 #include <algorithm>
 #include <vector>
-static int g_k6_timing = 0;              // 0 = off, n = sample every n-th launch
+static int g_k6_timing = 0;              // 0 = off, n = sample every n-th launch (bracketed) and the launches n / 2 behind them (unbracketed)
 static long g_k6_launch = 0;
 static bool g_k6_skip = false;
 static std::vector<hipEvent_t> g_k6_events;
 static hipEvent_t g_k6_open = nullptr;
-static unsigned long long *g_k6_span = nullptr;      // device: kK6SpanSlots slots of kK6SpanWords u64 (layout: ppo_step.h, span_enter)
-static int g_k6_span_used = 0;
-constexpr int kK6SpanSlots = 8192;
-constexpr int kK6SpanWords = 16, kK6SpanPhases = 7;  // = kSpanWords, kSpanPhases of ppo_step.h
-// of the last erl_k6_timing_read2, [0] over the launches WITHOUT an event bracket around them, [1] over the bracketed ones: shader clock
-// inside the launches, a workgroup's own duration, mean shader cycles per phase of an actor workgroup's wave 0 (0: the kernel stamps
-// none), summed first-in-to-last-out spans (ms) and their count
+constexpr int kK6SpanWords = 8, kK6SpanPhases = 7;   // = kSpanWords, kSpanPhases of ppo_step.h: one record per WORKGROUP
+constexpr size_t kK6PoolWords = (size_t)4 << 20;     // 32 MiB of records: 2048 sampled launches of 256 workgroups
+static unsigned long long *g_k6_pool = nullptr;      // device
+static size_t g_k6_pool_used = 0;
+struct K6Launch {
+    size_t off;          // first word of the launch's records in the pool
+    int n_slabs;         // grid = (n_slabs, 2): workgroups [0, n_slabs) are the actor's
+    bool bracketed;
+};
+static std::vector<K6Launch> g_k6_launches;
+// of the last erl_k6_timing_read2, [0] over the sampled launches WITHOUT an event bracket around them, [1] over the bracketed ones: shader
+// clock inside the launches, a workgroup's own duration, mean shader cycles per phase of an actor workgroup's wave 0 (0: the kernel
+// stamps none), summed first-in-to-last-out spans (ms) and their count
 struct K6Stats {
     double clock_mhz = 0.0, wg_us = 0.0, phase_cycles[kK6SpanPhases] = {}, span_ms = 0.0;
     int phase_wgs = 0, launches = 0;
 };
 static K6Stats g_k6_stats[2];
-static std::vector<unsigned char> g_k6_slot_bracketed;          // per span slot: 1 = the launch sat inside an event bracket
 
 static void k6_span_reset()
 {
-    if (!g_k6_span && hipMalloc((void **)&g_k6_span, sizeof(unsigned long long) * kK6SpanWords * kK6SpanSlots) != hipSuccess) {
-        g_k6_span = nullptr;
+    if (!g_k6_pool && hipMalloc((void **)&g_k6_pool, kK6PoolWords * sizeof(unsigned long long)) != hipSuccess) {
+        g_k6_pool = nullptr;
         (void)hipGetLastError();
         return;
     }
-    std::vector<unsigned long long> init((size_t)kK6SpanWords * kK6SpanSlots, 0ull);
-    for (int i = 0; i < kK6SpanSlots; ++i) init[(size_t)kK6SpanWords * i] = ~0ull;
-    g_k6_slot_bracketed.clear();
-    (void)hipMemcpy(g_k6_span, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
-    g_k6_span_used = 0;
+    if (g_k6_pool_used) (void)hipMemset(g_k6_pool, 0, g_k6_pool_used * sizeof(unsigned long long));
+    else (void)hipMemset(g_k6_pool, 0, kK6PoolWords * sizeof(unsigned long long));
+    g_k6_pool_used = 0;
+    g_k6_launches.clear();
 }
 
-// called by erl_ppo_step_f32 right before it enqueues K6: first event of the bracket on every n-th launch; returns the span slot of
-// this launch (nullptr: timing off / table full).  EVERY launch gets a span slot while timing is on (round 5): an event bracket turned
-// out to perturb the kernel inside it -- the sampled launches ran 6-8 us longer than their unbracketed neighbours on some boxes, which
-// is what made the driver's bench line disagree with its own step time -- so the kernel's duration is taken from the launches that
-// carry NO bracket, and the bracketed ones are reported next to them.
-unsigned long long *erl_k6_timing_begin(hipStream_t stream)
+// called by erl_ppo_step_f32 right before it enqueues K6 (grid (n_slabs, 2)).  Of every g_k6_timing launches ONE sits inside a HIP-event
+// bracket and ONE more (half a period later) is sampled without a bracket; both leave per-workgroup records (ppo_step.h, span_exit:
+// plain stores, no atomics), every other launch runs untouched.  Returns the launch's record block (nullptr: not sampled).
+unsigned long long *erl_k6_timing_begin(hipStream_t stream, int n_slabs)
 {
     if (!g_k6_timing) return nullptr;
-    g_k6_skip = (g_k6_launch++ % g_k6_timing) != 0;
+    const long k = g_k6_launch++ % g_k6_timing;
+    g_k6_skip = k != 0;
+    const bool free_sample = g_k6_timing >= 2 && k == g_k6_timing / 2;
+    if (g_k6_skip && !free_sample) return nullptr;
     if (!g_k6_skip) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) {
@@ -149,9 +154,11 @@ unsigned long long *erl_k6_timing_begin(hipStream_t stream)
             g_k6_open = e;
         }
     }
-    if (!g_k6_span || g_k6_span_used >= kK6SpanSlots) return nullptr;
-    g_k6_slot_bracketed.push_back(g_k6_skip ? 0 : 1);
-    return g_k6_span + (size_t)kK6SpanWords * g_k6_span_used++;
+    const size_t words = (size_t)kK6SpanWords * 2 * (size_t)(n_slabs > 0 ? n_slabs : 0);
+    if (!g_k6_pool || !words || g_k6_pool_used + words > kK6PoolWords) return nullptr;
+    g_k6_launches.push_back(K6Launch{g_k6_pool_used, n_slabs, !g_k6_skip});
+    g_k6_pool_used += words;
+    return g_k6_pool + g_k6_launches.back().off;
 }
 
 // ... and right after
@@ -173,8 +180,8 @@ extern "C" void erl_k6_timing_enable(int every_nth)
     if (g_k6_timing) k6_span_reset();
 }
 
-// waits for the recorded events; returns the summed event-bracket time and the summed in-kernel spans (milliseconds; the
-// latter 0 when the span table could not be allocated) over `launches` sampled launches, and clears both lists.
+// waits for the recorded events; returns the summed event-bracket time and the summed in-kernel spans of the SAME (bracketed) launches
+// (milliseconds; the latter 0 when the record pool could not be allocated) over `launches` launches, and clears both lists.
 extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launches)
 {
     double tot = 0.0;
@@ -191,27 +198,41 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
     }
     g_k6_events.clear();
     double span = 0.0;
-    if (g_k6_span && g_k6_span_used > 0) {
+    g_k6_stats[0] = g_k6_stats[1] = K6Stats{};
+    if (g_k6_pool && !g_k6_launches.empty()) {
         int dev = 0, khz = 0;
         (void)hipGetDevice(&dev);
+        (void)hipDeviceSynchronize();
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
-        std::vector<unsigned long long> h((size_t)kK6SpanWords * g_k6_span_used);
-        if (hipMemcpy(h.data(), g_k6_span, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+        std::vector<unsigned long long> h(g_k6_pool_used);
+        if (hipMemcpy(h.data(), g_k6_pool, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
             for (int b = 0; b < 2; ++b) {
                 double wall = 0.0, mem = 0.0, wgs = 0.0, pwgs = 0.0, ph[kK6SpanPhases] = {}, sp = 0.0;
                 int m = 0;
-                for (int i = 0; i < g_k6_span_used; ++i) {
-                    if ((i < (int)g_k6_slot_bracketed.size() ? g_k6_slot_bracketed[i] : 1) != b) continue;
-                    const unsigned long long *q = h.data() + (size_t)kK6SpanWords * i;
-                    if (q[1] <= q[0]) continue;            // (a slot whose launch never ran)
-                    sp += (double)(q[1] - q[0]) / khz;
-                    ++m;
-                    wall += (double)q[2]; mem += (double)q[3]; wgs += (double)q[4];
-                    for (int k = 0; k < kK6SpanPhases; ++k) ph[k] += (double)q[5 + k];
-                    pwgs += (double)q[5 + kK6SpanPhases];
+                for (const K6Launch &L : g_k6_launches) {
+                    if ((int)L.bracketed != b) continue;
+                    unsigned long long lo = ~0ull, hi = 0ull;
+                    for (int w = 0; w < 2 * L.n_slabs; ++w) {
+                        const unsigned long long *q = h.data() + L.off + (size_t)kK6SpanWords * w;
+                        if (q[1] <= q[0]) continue;          // (a workgroup that left no record)
+                        lo = std::min(lo, q[0]);
+                        hi = std::max(hi, q[1]);
+                        wall += (double)(q[1] - q[0]);
+                        mem += (double)(q[3] - q[2]);
+                        wgs += 1.0;
+                        if (w < L.n_slabs && (q[4] | q[5] | q[6])) {   // an actor workgroup of a kernel that stamps its phases
+                            uint32_t prev = (uint32_t)q[2];
+                            for (int k = 1; k <= kK6SpanPhases; ++k) {
+                                const uint32_t tk = k == kK6SpanPhases ? (uint32_t)q[3] : (uint32_t)(q[4 + ((k - 1) >> 1)] >> (32 * ((k - 1) & 1)));
+                                ph[k - 1] += (double)(uint32_t)(tk - prev);
+                                prev = tk;
+                            }
+                            pwgs += 1.0;
+                        }
+                    }
+                    if (hi > lo) { sp += (double)(hi - lo) / khz; ++m; }
                 }
                 K6Stats &st = g_k6_stats[b];
-                st = K6Stats{};
                 st.span_ms = sp;
                 st.launches = m;
                 // shader cycles per constant-rate tick x the tick rate = the clock the launches ran at
@@ -233,8 +254,8 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
 
 extern "C" int erl_k6_timing_read(double *total_ms, int *launches) { return erl_k6_timing_read2(total_ms, nullptr, launches); }
 
-// what the launches drained by the LAST erl_k6_timing_read2 say (include/erl_hip.h): bracketed = 0: the launches without an event
-// bracket (the kernel as the loop runs it), 1: the bracketed ones
+// what the launches drained by the LAST erl_k6_timing_read2 say (include/erl_hip.h): bracketed = 0: the sampled launches without an
+// event bracket (the kernel as the loop runs it), 1: the bracketed ones
 extern "C" int erl_k6_timing_clocks(int bracketed, double *span_ms, int *launches, double *shader_mhz, double *workgroup_us,
                                     double *phase_cycles, int max_phases, int *n_phases, int *phase_workgroups)
 {
@@ -252,59 +273,72 @@ extern "C" int erl_k6_timing_clocks(int bracketed, double *span_ms, int *launche
 }
 
 // ---- generic per-kernel spans (erl_common.h: erl_span_slot / erl_span_in / erl_span_out) ----------------------------------------
-constexpr int kSpanTags = ERL_SPAN_TAGS, kSpanSlotsPerTag = 4096;
-static unsigned long long *g_span_tab = nullptr;                // device: [tag][slot]{min entry, max exit}
-static int g_span_used[kSpanTags] = {};
-static bool g_span_on = false;
+// one {entry, exit} record per WORKGROUP of a sampled launch, bump-allocated from a device pool; the host folds them (min entry, max
+// exit) when a tag is read
+constexpr int kSpanTags = ERL_SPAN_TAGS;
+constexpr size_t kSpanPoolWords = (size_t)4 << 20;              // 32 MiB: 2 M workgroup records between reads
+static unsigned long long *g_span_pool = nullptr;               // device
+static size_t g_span_pool_used = 0;
+struct SpanLaunch {
+    size_t off;
+    int64_t n_wg;
+    int tag;
+};
+static std::vector<SpanLaunch> g_span_launches;
+static long g_span_count[kSpanTags] = {};
+static int g_span_every = 0;                                     // 0 = off, n = every n-th launch of a tag is sampled
 
-static void span_tab_reset()
+unsigned long long *erl_span_slot(int tag, int64_t n_workgroups)
 {
-    const size_t words = (size_t)kSpanTags * kSpanSlotsPerTag * 2;
-    if (!g_span_tab && hipMalloc((void **)&g_span_tab, words * sizeof(unsigned long long)) != hipSuccess) {
-        g_span_tab = nullptr;
+    if (!g_span_every || !g_span_pool || tag < 0 || tag >= kSpanTags || n_workgroups < 1) return nullptr;
+    if (g_span_count[tag]++ % g_span_every) return nullptr;
+    const size_t words = 2 * (size_t)n_workgroups;
+    if (g_span_pool_used + words > kSpanPoolWords) return nullptr;
+    g_span_launches.push_back(SpanLaunch{g_span_pool_used, n_workgroups, tag});
+    g_span_pool_used += words;
+    return g_span_pool + g_span_launches.back().off;
+}
+
+extern "C" void erl_kernel_span_enable(int every_nth)
+{
+    g_span_every = every_nth > 0 ? every_nth : 0;
+    for (long &c : g_span_count) c = 0;
+    if (!g_span_every) return;
+    if (!g_span_pool && hipMalloc((void **)&g_span_pool, kSpanPoolWords * sizeof(unsigned long long)) != hipSuccess) {
+        g_span_pool = nullptr;
         (void)hipGetLastError();
         return;
     }
-    std::vector<unsigned long long> init(words, 0ull);
-    for (size_t i = 0; i < words; i += 2) init[i] = ~0ull;
-    (void)hipMemcpy(g_span_tab, init.data(), words * sizeof(unsigned long long), hipMemcpyHostToDevice);
-    for (int &u : g_span_used) u = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(g_span_pool, 0, (g_span_pool_used ? g_span_pool_used : kSpanPoolWords) * sizeof(unsigned long long));
+    g_span_pool_used = 0;
+    g_span_launches.clear();
 }
 
-unsigned long long *erl_span_slot(int tag)
-{
-    if (!g_span_on || !g_span_tab || tag < 0 || tag >= kSpanTags || g_span_used[tag] >= kSpanSlotsPerTag) return nullptr;
-    return g_span_tab + ((size_t)tag * kSpanSlotsPerTag + g_span_used[tag]++) * 2;
-}
-
-extern "C" void erl_kernel_span_enable(int on)
-{
-    g_span_on = on != 0;
-    if (g_span_on) span_tab_reset();
-}
-
-// drains tag's slots: the summed spans (microseconds) of the launches since the hook was enabled / last read, and their number;
-// waits for the device (the launches must have finished)
+// the summed spans (microseconds) of tag's sampled launches since the hook was enabled, and their number; waits for the device.  The
+// records stay until the next erl_kernel_span_enable (a tag may be read once per enable).
 extern "C" int erl_kernel_span_read(int tag, double *total_us, int *launches)
 {
     ERL_REQUIRE(tag >= 0 && tag < kSpanTags, "erl_kernel_span_read: unknown tag %d", tag);
     double tot = 0.0;
     int n = 0;
-    if (g_span_tab && g_span_used[tag] > 0) {
+    if (g_span_pool && g_span_pool_used) {
         int rc = erl_hip_status(hipDeviceSynchronize(), "hipDeviceSynchronize");
         if (rc) return rc;
         int dev = 0, khz = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
-        std::vector<unsigned long long> h(2 * (size_t)g_span_used[tag]);
-        unsigned long long *base = g_span_tab + (size_t)tag * kSpanSlotsPerTag * 2;
-        rc = erl_hip_status(hipMemcpy(h.data(), base, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "hipMemcpy(span table)");
-        if (rc) return rc;
-        for (int i = 0; i < g_span_used[tag]; ++i)
-            if (h[2 * i + 1] > h[2 * i]) { tot += (double)(h[2 * i + 1] - h[2 * i]) / khz * 1e3; ++n; }
-        for (size_t i = 0; i < h.size(); i += 2) { h[i] = ~0ull; h[i + 1] = 0ull; }
-        (void)hipMemcpy(base, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
-        g_span_used[tag] = 0;
+        std::vector<unsigned long long> h;
+        for (const SpanLaunch &L : g_span_launches) {
+            if (L.tag != tag) continue;
+            h.resize(2 * (size_t)L.n_wg);
+            rc = erl_hip_status(hipMemcpy(h.data(), g_span_pool + L.off, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "hipMemcpy(span records)");
+            if (rc) return rc;
+            unsigned long long lo = ~0ull, hi = 0ull;
+            for (int64_t w = 0; w < L.n_wg; ++w)
+                if (h[2 * w + 1] > h[2 * w]) { lo = std::min(lo, h[2 * w]); hi = std::max(hi, h[2 * w + 1]); }
+            if (hi > lo) { tot += (double)(hi - lo) / khz * 1e3; ++n; }
+        }
     }
     if (total_us) *total_us = tot;
     if (launches) *launches = n;

@@ -211,8 +211,11 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
     // 0 = grad_reduce + clip_adam (two launches), 1 = one launch whose last-arriving workgroup applies Adam alone (measured
     // slower: profiles/r02_tail_bench.txt), 2 = one launch in which every workgroup waits for the norm and updates its own
     // elements (needs the whole grid resident: erl_reduce_clip_adam_grid_ok).  Default: see kDefaultTail.
-    static const int tail_env = [] { const char *e = getenv("ERL_FUSED_TAIL"); return e ? atoi(e) : kDefaultTail; }();
-    const int tail = comm ? 0 : (tail_env == 2 && !erl_reduce_clip_adam_grid_ok(stride) ? 0 : tail_env);
+    const int tail_env = [] { const char *e = getenv("ERL_FUSED_TAIL"); return e ? atoi(e) : kDefaultTail; }();     // (read per call: A/B in one process)
+    // 3 (round 5) = tail_fused_kernel (grad_tail.hip): the two-launch tail's arithmetic in one launch -- partial norms as their own flags,
+    // clip + Adam from registers, weight images refreshed: the split-arithmetic minibatch kernel keeps its images
+    const bool fused3 = !comm && tail_env == 3 && erl_tail_fused_ok(stride);
+    const int tail = (comm || tail_env == 3) ? 0 : (tail_env == 2 && !erl_reduce_clip_adam_grid_ok(stride) ? 0 : tail_env);
     // split-arithmetic minibatch kernel: its W2 images are built here once and kept current by clip + Adam (two-launch tail only)
     S3Images images{}, *im = nullptr;
     ERL_REQUIRE(!adv_partials || (adv_stats && n_partials >= 1), "erl_ppo_update_dp_f32: adv_partials needs adv_stats and n_partials");
@@ -238,6 +241,12 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
                                                                                         off, len, 2, first_step + k, lr, beta1, beta2, eps,
                                                                                         max_norm, grad_scale, stream);
             if (rc) return rc;
+            continue;
+        }
+        if (fused3) {
+            if ((rc = erl_tail_fused_f32(slabs, n_slabs, stride, g, off, len, 2, grad_scale, flat_params, exp_avg, exp_avg_sq, first_step + k, lr, beta1,
+                                         beta2, eps, max_norm, im, (hipStream_t)stream)))
+                return rc;
             continue;
         }
         // launch 1: slab reduction [+ the exchange, inside the same kernel on a peer-to-peer communicator] + partial norms;

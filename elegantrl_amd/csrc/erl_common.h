@@ -94,18 +94,21 @@ static inline int erl_hip_status(hipError_t e, const char *what)
 // measurement hook (api.cpp; include/erl_hip.h erl_kernel_span_*): a kernel's own duration on the device's constant-rate clock, first
 // workgroup in to last workgroup out -- what rocprofv3's kernel duration measures, available to bench.py in the loop without a
 // profiler and without an event bracket (a bracket perturbs the kernel inside it and adds its own dispatch / completion time).
-// Host: `unsigned long long *sp = erl_span_slot(ERL_SPAN_x)` right before the launch (nullptr while the hook is off), passed to the
+// Host: `unsigned long long *sp = erl_span_slot(ERL_SPAN_x, workgroups of the launch)` right before the launch (nullptr while the hook is
+// off or this launch is not sampled), passed to the
 // kernel; device: `const auto t0 = erl_span_in(sp); ... erl_span_out(sp, t0);` (thread 0 of every workgroup; no early return between).
 // ---------------------------------------------------------------------------------------------
-unsigned long long *erl_span_slot(int tag);
+unsigned long long *erl_span_slot(int tag, int64_t n_workgroups);
 #ifdef __HIPCC__
 __device__ __forceinline__ unsigned long long erl_span_in(const unsigned long long *span) { return span ? wall_clock64() : 0ull; }
+// one {entry, exit} record per workgroup, plain stores (no atomics: 800 same-address atomics cost the slab reduction 12 us)
 __device__ __forceinline__ void erl_span_out(unsigned long long *span, unsigned long long t0)
 {
     if (span && threadIdx.x == 0 && threadIdx.y == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
-        atomicMin(span, t0);
-        atomicMax(span + 1, (unsigned long long)wall_clock64());
+        unsigned long long *rec = span + 2 * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z));
+        rec[0] = t0;
+        rec[1] = (unsigned long long)wall_clock64();
     }
 }
 #endif

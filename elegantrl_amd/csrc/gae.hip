@@ -413,9 +413,11 @@ extern "C" int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t 
     ERL_REQUIRE(workspace && workspace_bytes >= erl_gae_workspace_bytes(H, N), "erl_gae_scan_f32: workspace too small");
     int algo = flags & ERL_GAE_ALGO_MASK;
     const bool lb_ok = H >= 4 && erl_gae_lookback_usable(rewards, undones, unmasks, values, next_value, adv, ret, N);
-    // AUTO: short horizons are launch-latency sized -> the bit-exact lane-per-env scan; otherwise the single-pass scan
+    // AUTO: short horizons are launch-latency sized -> the bit-exact lane-per-env scan (N <= 8192: 64-128 workgroups walking 32 dependent
+    // steps take 5.6 us at 32 x 4096, the one-slab form of the single-pass scan 4.8: not worth giving up bit-exactness; at 32 x 32768 it
+    // is 11.9 against 5.5 us, tools/gae_lb_sweep.py); otherwise the single-pass scan
     if (algo == ERL_GAE_ALGO_AUTO)
-        algo = (H < 64) ? ERL_GAE_ALGO_EXACT : (lb_ok ? ERL_GAE_ALGO_LOOKBACK : ERL_GAE_ALGO_CHUNKED);
+        algo = (H < 64 && (N <= 8192 || !lb_ok)) ? ERL_GAE_ALGO_EXACT : (lb_ok ? ERL_GAE_ALGO_LOOKBACK : ERL_GAE_ALGO_CHUNKED);
     if (algo == ERL_GAE_ALGO_LOOKBACK && !lb_ok) algo = ERL_GAE_ALGO_CHUNKED;  // needs N % 4 == 0 and 16-byte aligned rows
 
     // workspace: [agg float2 K*N][partials double 3*nblk]
@@ -432,7 +434,7 @@ extern "C" int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t 
         nparts = nblk;
 #define LAUNCH_EXACT(VT, ST)                                                                                       \
     hipLaunchKernelGGL((gae_exact_kernel<VT, ST>), dim3(nblk), dim3(64), 0, stream, rewards, undones, unmasks, values, \
-                       next_value, adv, ret, (int)H, (int)N, gamma, lam, (int)mutate, partials, erl_span_slot(ERL_SPAN_GAE))
+                       next_value, adv, ret, (int)H, (int)N, gamma, lam, (int)mutate, partials, erl_span_slot(ERL_SPAN_GAE, nblk))
         if (vtrace) { if (want_stats) LAUNCH_EXACT(true, true); else LAUNCH_EXACT(true, false); }
         else        { if (want_stats) LAUNCH_EXACT(false, true); else LAUNCH_EXACT(false, false); }
 #undef LAUNCH_EXACT

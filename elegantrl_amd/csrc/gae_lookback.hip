@@ -49,6 +49,8 @@ struct LbArgs {
     unsigned long long *span;  // measurement hook (erl_common.h: erl_span_*); nullptr = off
 };
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ unsigned long long pack_granule(float a, uint32_t tag)
 {
     return (unsigned long long)__float_as_uint(a) | ((unsigned long long)tag << 32);
@@ -191,27 +193,57 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
         if (live && kk > 0) {
             float accA[4] = {0.f, 0.f, 0.f, 0.f}, accP[4] = {1.f, 1.f, 1.f, 1.f};
             uint32_t open = 0xFu;   // envs whose carry still depends on later slabs
-            for (int j = kk - 1; j >= 0 && open; --j) {
-                const unsigned long long *src = g.slots + (size_t)j * N + n0;
+            // The walk over the later slabs' granules, latest first.  Round 5: the lane's four granules of a slab are ONE 32-byte line
+            // segment and the granules of several slabs do not depend on each other, so a round fetches LB_BATCH slabs x 4 envs with
+            // two 16-byte agent-scope loads per slab, all in flight together, and consumes them in order while they are valid (round
+            // 4 issued one 8-byte load per env and slab and waited for each: up to 4 (K - 1) dependent round trips -- at 200 x 4096,
+            // K = 7, the scan's 9.4 us were mostly this chain).  A granule carries its own validity (the launch's nonce), so reading
+            // ahead is safe: what is not published yet is simply fetched again.
+            constexpr int LB_BATCH = 2;
+            int j = kk - 1;
+            uint32_t spins = 0;
+            while (j >= 0 && open) {
+                unsigned long long gr[LB_BATCH][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (!(open & (1u << e))) continue;
-                    unsigned long long gr;
-                    uint32_t spins = 0;
-                    bool ready;
-                    do {
-                        gr = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ready = ((uint32_t)(gr >> 34)) == g.nonce;
-                        if (ready) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    } while (++spins < g.spin_limit);   // bounded: a lost predecessor poisons this env's outputs with NaN AND
-                    // is counted in the host-visible fault word (erl_async_fault_count -> the caller raises), never a hang
-                    if (!ready && g.fault) __hip_atomic_fetch_add(g.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    const float ga = ready ? __uint_as_float((uint32_t)gr) : __uint_as_float(0x7FC00000u);
-                    const uint32_t state = (uint32_t)(gr >> 32) & 3u;
-                    accA[e] += accP[e] * ga;
-                    if (state == LB_AGG_FULL && ready) accP[e] *= p_full;   // the chain runs through slab j: keep walking
-                    else open &= ~(1u << e);                                 // inclusive value, or an episode boundary cut it
+                for (int b = 0; b < LB_BATCH; ++b) {
+                    const unsigned long long *src = g.slots + (size_t)(j - b >= 0 ? j - b : 0) * N + n0;
+                    u64x2 lo, hi;
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1"
+                                 : "=&v"(lo), "=&v"(hi) : "v"(src) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
+                    gr[b][0] = lo.x; gr[b][1] = lo.y; gr[b][2] = hi.x; gr[b][3] = hi.y;
+                }
+                int consumed = 0;
+#pragma unroll
+                for (int b = 0; b < LB_BATCH; ++b) {
+                    if (j - b < 0 || !open || consumed != b) continue;
+                    bool all_ready = true;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if ((open & (1u << e)) && ((uint32_t)(gr[b][e] >> 34)) != g.nonce) all_ready = false;
+                    const bool give_up = !all_ready && b == 0 && spins >= g.spin_limit;
+                    if (!all_ready && !give_up) continue;     // slab j - b is not (fully) published yet: fetch again
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!(open & (1u << e))) continue;
+                        const bool ready = ((uint32_t)(gr[b][e] >> 34)) == g.nonce;
+                        // bounded: a lost predecessor poisons this env's outputs with NaN AND is counted in the host-visible fault word
+                        // (erl_async_fault_count -> the caller raises), never a hang
+                        if (!ready && g.fault) __hip_atomic_fetch_add(g.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const float ga = ready ? __uint_as_float((uint32_t)gr[b][e]) : __uint_as_float(0x7FC00000u);
+                        const uint32_t state = (uint32_t)(gr[b][e] >> 32) & 3u;
+                        accA[e] += accP[e] * ga;
+                        if (state == LB_AGG_FULL && ready) accP[e] *= p_full;   // the chain runs through slab j - b: keep walking
+                        else open &= ~(1u << e);                                 // inclusive value, or an episode boundary cut it
+                    }
+                    ++consumed;
+                }
+                j -= consumed;
+                if (!consumed) {
+                    __builtin_amdgcn_s_sleep(2);
+                    ++spins;
+                } else {
+                    spins = 0;
                 }
             }
 #pragma unroll
@@ -300,7 +332,7 @@ void erl_gae_lookback_pick(int64_t H, int64_t N, int *L, int *W)
     if (H >= 2048) { l = 16; w = 8; }
     else if (H >= 512) { l = 8; w = 16; }
     else if (H >= 64) { l = 4; w = 8; }
-    else { l = 4; w = 2; }
+    else { l = 4; w = (int)((H + 3) / 4); }      // one slab covers the horizon: no look-back at all (round 5: 32 x 32768 18.9 -> 5.5 us)
     l = env_int("ERL_GAE_LB_L", l);
     w = env_int("ERL_GAE_LB_W", w);
     if (l != 2 && l != 4 && l != 8 && l != 16) l = 8;
@@ -358,7 +390,7 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
     g.partials = (double *)(ws + 256 + slot_bytes);
     g.fault = erl_fault_word(ERL_FAULT_GAE_LOOKBACK);
-    g.span = erl_span_slot(ERL_SPAN_GAE);
+    g.span = erl_span_slot(ERL_SPAN_GAE, K * G);
     {
         const int lim = env_int("ERL_GAE_LB_SPIN", 1 << 22);
         g.spin_limit = lim > 0 ? (uint32_t)lim : 1u;

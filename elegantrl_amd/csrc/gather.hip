@@ -234,7 +234,7 @@ int replay_sample_impl(const char *what, bool act_u8, const float *buf_states, c
     if (spw > RS_SAMPLES) spw = RS_SAMPLES;
     const int g = grid_for(erl_cdiv(B, spw) * 256);
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long *sp = erl_span_slot(ERL_SPAN_REPLAY_SAMPLE);
+    unsigned long long *sp = erl_span_slot(ERL_SPAN_REPLAY_SAMPLE, g);
     if (act_u8)
         hipLaunchKernelGGL((replay_sample_kernel<true>), dim3(g), dim3(256), 0, st, buf_states, buf_actions, buf_rewards, buf_undones,
                            buf_unmasks, num_seqs, S, A, ids, B, sample_len, out_state, out_action, out_reward, out_undone, out_unmask,

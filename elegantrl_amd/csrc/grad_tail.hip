@@ -167,6 +167,24 @@ __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int
     erl_span_out(span, t_span);
 }
 
+// clip + Adam on ONE element (index ie of parameter group gi at `off`) + the refresh of the split-arithmetic minibatch kernels' weight
+// images that follow their fp32 weights (s3_image.h): the arithmetic of every tail of this file
+__device__ __forceinline__ void tail_adam_apply(float e_g, float e_m1, float e_m2, float e_p, float coef, float grad_scale, float beta1, float beta2,
+                                                float eps, float step_size, float bc2_sqrt, float *__restrict__ params, float *__restrict__ m1,
+                                                float *__restrict__ m2, int64_t off, int64_t ie, int gi, const S3Images &im)
+{
+    erl_adam_update(erl_mul_rn(e_g, erl_mul_rn(grad_scale, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);
+    m1[off + ie] = e_m1;
+    m2[off + ie] = e_m2;
+    params[off + ie] = e_p;
+    if (gi < 2 && im.net[gi].img) {
+        const int64_t e = ie - im.net[gi].w2_off;
+        const int h1 = im.net[gi].h1, S = im.net[gi].S;
+        if (e >= 0 && e < (int64_t)h1 * im.net[gi].h2) s3_image_put_w2(im.net[gi].img, h1, im.net[gi].h2, (int)(e / h1), (int)(e % h1), e_p);
+        else if (im.net[gi].img1 && ie < (int64_t)h1 * S) s3_image_put(im.net[gi].img1, im.net[gi].K1, (int)(ie / S), (int)(ie % S), e_p);
+    }
+}
+
 // clip + Adam from the partial norms: grid = (ceil(longest / 1024), n_groups); one element per thread, its four loads
 // and the partials ride one round trip.
 __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restrict__ params, const float *__restrict__ grads,
@@ -192,19 +210,153 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
     const float total_norm = (float)sqrt(ss);
     float coef = max_norm / (total_norm + 1e-6f);      // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
     coef = coef > 1.f ? 1.f : coef;
-    if (own) {
-        erl_adam_update(erl_mul_rn(e_g, erl_mul_rn(grad_scale, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);
-        m1[off + ie] = e_m1;
-        m2[off + ie] = e_m2;
-        params[off + ie] = e_p;
-        // the split-arithmetic minibatch kernel's W2 image of this network follows its fp32 weights (s3_image.h)
-        if (gi < 2 && im.net[gi].img) {
-            const int64_t e = ie - im.net[gi].w2_off;
-            const int h1 = im.net[gi].h1, S = im.net[gi].S;
-            if (e >= 0 && e < (int64_t)h1 * im.net[gi].h2) s3_image_put_w2(im.net[gi].img, h1, im.net[gi].h2, (int)(e / h1), (int)(e % h1), e_p);
-            else if (im.net[gi].img1 && ie < (int64_t)h1 * S) s3_image_put(im.net[gi].img1, im.net[gi].K1, (int)(ie / S), (int)(ie % S), e_p);
+    if (own) tail_adam_apply(e_g, e_m1, e_m2, e_p, coef, grad_scale, beta1, beta2, eps, step_size, bc2_sqrt, params, m1, m2, off, ie, gi, im);
+    erl_span_out(span, t_span);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The tail as ONE launch (round 5; single process): reduce_exchange_kernel's slab sum and partial norms, then -- instead of a kernel
+// boundary and clip_adam_partials_kernel -- every workgroup waits until ALL workgroups' partial norms are published, sums them in
+// clip_adam_partials_kernel's order (the same bits) and applies clip + Adam to the 256 elements it has just reduced, from registers.
+// No arrival counter and no flags: the partial norms ARE the flags.  The table is double buffered by the launch's parity; an entry not
+// yet written holds a sentinel (a NaN pattern no sum of squares produces); workgroup b of launch k (parity p) resets ITS entries of
+// parity 1 - p -- last read by launch k - 1, which has finished -- so launch k + 1 finds them blank.  Entries are published by
+// agent-scope stores and polled by agent-scope loads (they bypass the XCD-private L2s), 1 .. 2 chunks per thread, all in flight at
+// once; what the last poll returned is what is summed: one round trip after the slowest workgroup has published.  Round 2's
+// single-launch tails counted arrivals on ONE device counter (199 same-address atomics, an acquire fence per workgroup, then another
+// pass over the table): 16.0 us back to back against this kernel's ~9.  The grid (ceil(stride / 256) workgroups of 1024 threads: 199 at
+// config 4) must be resident at once: the host checks it against the device's capacity; the wait is bounded all the same, and a
+// timeout SKIPS the update and reports through erl_async_fault_count (the policy of every bounded wait of this library).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr unsigned long long kTailBlank = 0x7ff8dead0000beefull;      // quiet NaN with a payload: never the result of a sum of squares
+struct FusedTail {
+    float *params, *m1, *m2;
+    float beta1, beta2, eps, max_norm, step_size, bc2_sqrt;
+    S3Images im;
+    double *cur, *other;          // partial-norm tables [chunk][4]: this launch's parity / the other one (blanked here)
+    int nchunks;                  // 64-element chunks of the row
+    uint32_t spin_limit;
+    uint32_t *fault;
+};
+
+__global__ __launch_bounds__(1024) void tail_fused_kernel(const float *slabs, int n_slabs, int64_t stride, float *out, TailGroups gr, int n_groups,
+                                                          float grad_scale, FusedTail ft, unsigned long long *span)
+{
+    constexpr int NT = 1024, NE = NT / 4, MAXR = 2;
+    __shared__ float part[4][NE];
+    __shared__ double scratch[16];
+    const unsigned long long t_span = erl_span_in(span);
+    const int el = threadIdx.x & (NE - 1), p = threadIdx.x / NE;
+    const int64_t i = (int64_t)blockIdx.x * NE + el;
+    // the element's optimiser state rides the reduction's first round trip (quarter p == 0 owns the elements)
+    int my_group = -1;
+    float e_m1 = 0.f, e_m2 = 0.f, e_p = 0.f;
+    if (p == 0) {
+        for (int gi = 0; gi < n_groups; ++gi)
+            if (i >= gr.off[gi] && i < gr.off[gi] + gr.len[gi]) my_group = gi;
+        if (my_group >= 0) { e_m1 = ft.m1[i]; e_m2 = ft.m2[i]; e_p = ft.params[i]; }
+    }
+    if (threadIdx.x < 16) {                            // blank this workgroup's four chunks of the OTHER parity
+        const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 2);
+        if (c < ft.nchunks)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(ft.other) + c * 4 + (threadIdx.x & 3), kTailBlank, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < stride) {                                  // (the loop nest of grad_reduce_kernel, mlp.hip: same association)
+        const float *src = slabs + i;
+        int k = p;
+        for (; k + 124 < n_slabs; k += 128) {          // 32 loads in flight: one round trip per 128 slabs
+            float x[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) x[u] = ld_stream(src + (size_t)(k + 4 * u) * stride);   // slabs are streamed once
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += x[8 * v + u];
+        }
+        for (; k + 28 < n_slabs; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += src[(size_t)(k + 4 * u) * stride];
+        }
+        for (; k < n_slabs; k += 4) s[0] += src[(size_t)k * stride];
+    }
+    part[p][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    const float gsum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    if (p == 0 && i < stride) out[i] = gsum;
+    if (threadIdx.x < NE) {                            // whole waves: chunk c = elements 64 c .. 64 c + 63 (reduce_exchange_kernel's partials)
+        const int64_t chunk = i >> 6, c_lo = chunk << 6, c_hi = c_lo + 63;
+        const double xs = (double)(gsum * grad_scale), sq = xs * xs;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(ft.cur) + (size_t)chunk * 4;
+        int own = -1, touched = 0;
+        for (int gi = 0; gi < n_groups; ++gi) {
+            const bool overlap = c_lo < gr.off[gi] + gr.len[gi] && c_hi >= gr.off[gi];
+            const bool inside = c_lo >= gr.off[gi] && c_hi < gr.off[gi] + gr.len[gi];
+            touched += overlap;
+            if (inside) own = gi;
+        }
+        if (touched == 0 || (touched == 1 && own >= 0)) {          // (wave-uniform: depends on the chunk only)
+            const double t = own >= 0 ? wave_sum(i < stride ? sq : 0.0) : 0.0;
+            if ((threadIdx.x & 63) == 0 && chunk < ft.nchunks)
+                for (int gi = 0; gi < n_groups; ++gi)
+                    __hip_atomic_store(dst + gi, (unsigned long long)__double_as_longlong(gi == own ? t : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (int gi = 0; gi < n_groups; ++gi) {
+                const bool in = i < stride && i >= gr.off[gi] && i < gr.off[gi] + gr.len[gi];
+                const double t = wave_sum(in ? sq : 0.0);
+                if ((threadIdx.x & 63) == 0 && chunk < ft.nchunks)
+                    __hip_atomic_store(dst + gi, (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
+    // ---- wait until every chunk's partial norms are there: thread t polls chunks t, t + 1024 (rows up to 131 072 floats)
+    const unsigned long long *cur = reinterpret_cast<const unsigned long long *>(ft.cur);
+    unsigned long long v[MAXR][4];
+    uint32_t spins = 0;
+    bool timed_out = false;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const int b = (int)threadIdx.x + NT * r;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                v[r][gi] = 0ull;                       // (+0.0: what a chunk beyond the row contributes)
+                if (b < ft.nchunks && gi < n_groups) {
+                    v[r][gi] = __hip_atomic_load(cur + (size_t)b * 4 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && v[r][gi] != kTailBlank;
+                }
+            }
+        }
+        if (__syncthreads_and(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > ft.spin_limit) {                 // (block-uniform: every thread counts the same rounds)
+            timed_out = true;
+            break;
+        }
+    }
+    if (timed_out) {                                   // incomplete norm: the update is SKIPPED (and reported), never applied
+        if (threadIdx.x == 0 && ft.fault) __hip_atomic_fetch_add(ft.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        erl_span_out(span, t_span);
+        return;
+    }
+    // ---- clip_adam_partials_kernel's sums, group by group (thread-strided partials, then the block sum: the same bits)
+    float coef_mine = 1.f;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        double ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if ((int)threadIdx.x + NT * r < ft.nchunks) ss += __longlong_as_double((long long)v[r][gi]);
+        ss = block_sum(ss, scratch);
+        const float total_norm = (float)sqrt(ss);
+        float coef = ft.max_norm / (total_norm + 1e-6f);      // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+        coef = coef > 1.f ? 1.f : coef;
+        if (gi == my_group) coef_mine = coef;
+    }
+    if (my_group >= 0)
+        tail_adam_apply(gsum, e_m1, e_m2, e_p, coef_mine, grad_scale, ft.beta1, ft.beta2, ft.eps, ft.step_size, ft.bc2_sqrt, ft.params, ft.m1, ft.m2,
+                        gr.off[my_group], i - gr.off[my_group], my_group, ft.im);
     erl_span_out(span, t_span);
 }
 
@@ -271,7 +423,97 @@ int fill_groups(const char *what, const int64_t *off, const int64_t *len, int n_
     return ERL_OK;
 }
 
+
+// ---- the single-launch tail (tail_fused_kernel): per (device, stream, row length) a double-buffered partial-norm table, blank at first
+struct FusedSlot {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int64_t stride = 0;
+    double *buf = nullptr;        // [2 parities][nchunks_alloc][4]
+    int64_t nchunks_alloc = 0;
+    unsigned parity = 0;
+    int capacity = -1;            // workgroups of tail_fused_kernel the device holds at once
+};
+FusedSlot g_fused[32];
+
+__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *p, unsigned long long v, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
 }  // namespace
+
+// 1 when the single-launch tail can serve a gradient row of `stride` floats on the current device: the row fits the kernel's two
+// chunks per thread and every workgroup of the launch is resident at once (the kernel waits for ALL of its workgroups)
+extern "C" int erl_tail_fused_ok(int64_t stride)
+{
+    if (stride < 1 || erl_cdiv(stride, 64) > 2048) return 0;
+    int dev = -1, per_cu = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tail_fused_kernel, 1024, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return (int64_t)per_cu * cus >= erl_cdiv(stride, 256) ? 1 : 0;
+}
+
+// slabs (n_slabs, stride) -> out (stride) AND clip + Adam on `params` (groups off / len of the row) AND the weight images' refresh: ONE launch
+int erl_tail_fused_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len, int n_groups,
+                       float grad_scale, float *params, float *exp_avg, float *exp_avg_sq, int32_t step, float lr, float beta1, float beta2,
+                       float eps, float max_norm, const S3Images *images, hipStream_t stream)
+{
+    ERL_REQUIRE(slabs && out && params && exp_avg && exp_avg_sq && n_slabs >= 1 && stride >= 1 && step >= 1, "single-launch tail: bad argument");
+    ERL_REQUIRE(n_groups >= 1, "single-launch tail: no parameter group");
+    TailGroups gr;
+    int rc = fill_groups("single-launch tail", off, len, n_groups, stride, &gr);
+    if (rc) return rc;
+    int dev = -1;
+    ERL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, "single-launch tail: no device");
+    const int64_t nchunks = erl_cdiv(stride, 64);
+    ERL_REQUIRE(nchunks <= 2048, "single-launch tail: row too long (%lld floats)", (long long)stride);
+    FusedSlot *slot = nullptr;
+    for (auto &f : g_fused)
+        if (f.buf && f.device == dev && f.stream == stream && f.stride == stride) { slot = &f; break; }
+    if (!slot) {
+        for (auto &f : g_fused)
+            if (!f.buf) { slot = &f; break; }
+        ERL_REQUIRE(slot, "single-launch tail: more than 32 (device, stream, row length) triples");
+        const int64_t alloc = erl_cdiv(stride, 256) * 4;              // whole workgroups: 4 chunks each
+        void *pbuf = nullptr;
+        if ((rc = erl_hip_status(hipMalloc(&pbuf, (size_t)2 * alloc * 4 * sizeof(double)), "hipMalloc(single-launch tail table)"))) return rc;
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, stream, (unsigned long long *)pbuf, kTailBlank, 2 * alloc * 4);
+        slot->buf = (double *)pbuf;
+        slot->device = dev; slot->stream = stream; slot->stride = stride; slot->nchunks_alloc = alloc; slot->parity = 0;
+    }
+    FusedTail ft{};
+    ft.params = params; ft.m1 = exp_avg; ft.m2 = exp_avg_sq;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    ft.beta1 = beta1; ft.beta2 = beta2; ft.eps = eps; ft.max_norm = max_norm;
+    ft.step_size = (float)((double)lr / bc1); ft.bc2_sqrt = (float)sqrt(bc2);
+    ft.im = images ? *images : S3Images{};
+    ft.cur = slot->buf + (size_t)(slot->parity & 1u) * slot->nchunks_alloc * 4;
+    ft.other = slot->buf + (size_t)((slot->parity & 1u) ^ 1u) * slot->nchunks_alloc * 4;
+    slot->parity++;
+    ft.nchunks = (int)nchunks;
+    static const uint32_t spin = [] { const char *e = getenv("ERL_TAIL_SPIN"); return e && atol(e) > 0 ? (uint32_t)atol(e) : (1u << 22); }();
+    ft.spin_limit = spin;
+    ft.fault = erl_fault_word(ERL_FAULT_ADAM_GRID_WAIT);
+    const int64_t nblk = erl_cdiv(stride, 256);
+    hipLaunchKernelGGL(tail_fused_kernel, dim3((unsigned)nblk), dim3(1024), 0, stream, slabs, n_slabs, stride, out, gr, n_groups, grad_scale, ft,
+                       erl_span_slot(ERL_SPAN_SLAB_REDUCE, nblk));
+    ERL_LAUNCH_CHECK("single-launch tail");
+}
+
+extern "C" int erl_reduce_clip_adam_fused_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params, float *exp_avg,
+                                              float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step,
+                                              float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream)
+{
+    ERL_REQUIRE(erl_tail_fused_ok(stride), "erl_reduce_clip_adam_fused_f32: a %lld-float row cannot take the single-launch tail on this device "
+                "(erl_tail_fused_ok)", (long long)stride);
+    return erl_tail_fused_f32(slabs, n_slabs, stride, flat_grad, group_off, group_len, n_groups, grad_scale, params, exp_avg, exp_avg_sq, step, lr,
+                              beta1, beta2, eps, max_norm, nullptr, (hipStream_t)stream);
+}
 
 int erl_tail_partials(double **out, hipStream_t stream)
 {
@@ -315,10 +557,10 @@ int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stri
         ERL_REQUIRE(nblk <= ex->nblk_max && stride * (int64_t)sizeof(float) <= ex->row_bytes,
                     "gradient exchange: %lld floats > the %lld the peer stages were sized for", (long long)stride, (long long)(ex->row_bytes / 4));
         hipLaunchKernelGGL((reduce_exchange_kernel<float, true, 1024>), dim3((unsigned)nblk), dim3(1024), 0, stream, slabs, n_slabs, stride, out, gr,
-                           n_groups, grad_scale, partials, *ex, erl_span_slot(ERL_SPAN_SLAB_REDUCE));
+                           n_groups, grad_scale, partials, *ex, erl_span_slot(ERL_SPAN_SLAB_REDUCE, nblk));
     } else {        // 256 threads x 64 elements (grad_reduce_kernel's shape: 795 workgroups keep every CU's memory pipes busy)
         hipLaunchKernelGGL((reduce_exchange_kernel<float, false, 256>), dim3((unsigned)erl_cdiv(stride, 64)), dim3(256), 0, stream, slabs, n_slabs,
-                           stride, out, gr, n_groups, grad_scale, partials, ErlExchange{}, erl_span_slot(ERL_SPAN_SLAB_REDUCE));
+                           stride, out, gr, n_groups, grad_scale, partials, ErlExchange{}, erl_span_slot(ERL_SPAN_SLAB_REDUCE, erl_cdiv(stride, 64)));
     }
     ERL_LAUNCH_CHECK("gradient reduce / exchange");
 }
@@ -418,7 +660,7 @@ int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(clip_adam_partials_kernel, dim3((unsigned)erl_cdiv(longest, 1024), n_groups), dim3(1024), 0, (hipStream_t)stream, params,
                        grads, exp_avg, exp_avg_sq, gr, partials, (int)nblk, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
-                       (float)sqrt(bc2), images ? *images : S3Images{}, poison, erl_span_slot(ERL_SPAN_CLIP_ADAM));
+                       (float)sqrt(bc2), images ? *images : S3Images{}, poison, erl_span_slot(ERL_SPAN_CLIP_ADAM, erl_cdiv(longest, 1024) * n_groups));
     ERL_LAUNCH_CHECK("erl_clip_adam_partials_f32");
 }
 

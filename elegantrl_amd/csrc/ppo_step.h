@@ -23,7 +23,7 @@ struct Ppo2Args {
     const double *adv_stats;         // nullptr: `advantages` are normalised already; else the raw sums of erl_gae_scan_f32 / the rollout epilogue
     const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
     const unsigned char *w1img[2];   // ... and W1 images (columns padded to 32 / 64); both or neither
-    unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): this launch's slot of kSpanWords u64 (see span_enter); nullptr = off
+    unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): this launch's records, kSpanWords u64 per workgroup (see span_enter); nullptr = off
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -88,15 +88,17 @@ __device__ __forceinline__ float adv_normalized(float adv, const AdvNorm &n)
     return n.on ? (adv - n.mean) / n.denom : adv;
 }
 
-// entry / exit of a workgroup on the device's constant-rate clock, folded into the launch's slot (sampled launches only).  Slot layout
-// (kSpanWords u64 per sampled launch, api.cpp): [0] min entry, [1] max exit (constant-rate clock: first workgroup in to last workgroup
-// out), [2] sum over workgroups of exit - entry on the constant-rate clock, [3] the same on the SHADER clock (s_memtime: the ratio of
-// the two is the clock the kernel actually ran at -- the chip clocks to its power budget, MI355X_MICROARCH.md "DVFS give-back"),
-// [4] workgroups counted, [5 .. 5 + kSpanPhases) sums of per-phase shader cycles of the ACTOR workgroups' wave 0 (kernels that
-// stamp phases: ppo_step_s3_kernel), [5 + kSpanPhases] actor workgroups counted.
+// entry / exit of a workgroup on the device's constant-rate clock (sampled launches only).  Every workgroup leaves ONE record of
+// kSpanWords u64 at span + kSpanWords * (blockIdx.x + gridDim.x * blockIdx.y), by plain stores from its thread 0 -- no atomics: round 5's
+// first version folded the stamps into one {min, max, sums} slot per launch with 5-13 device-scope atomics per workgroup, and 2000
+// same-address atomics cost the kernel 6 us (the slab reduction, 795 workgroups: 12 us); the host folds the records instead (api.cpp).
+// Record: [0] entry, [1] exit on the constant-rate clock, [2] entry, [3] exit on the SHADER clock (s_memtime: the ratio of the two
+// intervals is the clock the kernel actually ran at -- the chip clocks to its power budget, MI355X_MICROARCH.md "DVFS give-back"),
+// [4 .. 4 + kSpanPhases / 2): the low words of the shader clock at the kSpanPhases - 1 phase boundaries of kernels that stamp phases
+// (ppo_step_s3_kernel), two per u64, 0 otherwise.
 constexpr int kSpanPhases = 7;
-constexpr int kSpanWords = 16;
-static_assert(6 + kSpanPhases <= kSpanWords, "span slot too small");
+constexpr int kSpanWords = 8;
+static_assert(4 + (kSpanPhases + 1) / 2 <= kSpanWords, "span record too small");
 struct SpanT {
     unsigned long long wall, mem;
 };
@@ -129,21 +131,14 @@ __device__ __forceinline__ void span_exit(const Ppo2Args &g, SpanT t0, const Spa
     if (g.span && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
         const unsigned long long w1 = wall_clock64(), m1 = erl_memtime();
-        atomicMin(g.span, t0.wall);
-        atomicMax(g.span + 1, w1);
-        atomicAdd(g.span + 2, w1 - t0.wall);
-        atomicAdd(g.span + 3, m1 - t0.mem);
-        atomicAdd(g.span + 4, 1ull);
+        unsigned long long *rec = g.span + (size_t)kSpanWords * (blockIdx.x + gridDim.x * blockIdx.y);
+        unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull};
         if (st) {
-            uint32_t prev = (uint32_t)t0.mem;
 #pragma unroll
-            for (int k = 1; k <= kSpanPhases; ++k) {
-                const uint32_t tk = k == kSpanPhases ? (uint32_t)m1 : st->t[k];
-                atomicAdd(g.span + 4 + k, (unsigned long long)(uint32_t)(tk - prev));
-                prev = tk;
-            }
-            atomicAdd(g.span + 5 + kSpanPhases, 1ull);
+            for (int k = 1; k < kSpanPhases; ++k) ph[(k - 1) >> 1] |= (unsigned long long)st->t[k] << (32 * ((k - 1) & 1));
         }
+        rec[0] = t0.wall; rec[1] = w1; rec[2] = t0.mem; rec[3] = m1;
+        rec[4] = ph[0]; rec[5] = ph[1]; rec[6] = ph[2]; rec[7] = ph[3];
     }
 }
 

@@ -418,7 +418,7 @@ int g_ppo_prof_block = 0;
 
 }  // namespace
 
-unsigned long long *erl_k6_timing_begin(hipStream_t stream);   // api.cpp (measurement hook, no-op unless enabled)
+unsigned long long *erl_k6_timing_begin(hipStream_t stream, int n_slabs);   // api.cpp (measurement hook, no-op unless enabled; grid = (n_slabs, 2))
 void erl_k6_timing_end(hipStream_t stream);
 
 namespace {
@@ -531,7 +531,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                      al(cri_avg) && al(cri_std);
     hipStream_t st = (hipStream_t)stream;
     const int ns = (S + 15) / 16;
-    g.span = erl_k6_timing_begin(st);
+    g.span = erl_k6_timing_begin(st, n_slabs);
     int rc;
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else
     // the fp32 32x32x2 one), 8 = always the 8-wave 16x16x4 kernel

@@ -6,7 +6,7 @@
 #include "../../include/erl_hip.h"
 #include <cstdlib>
 
-unsigned long long *erl_k6_timing_begin(hipStream_t stream);   // api.cpp (measurement hook, no-op unless enabled)
+unsigned long long *erl_k6_timing_begin(hipStream_t stream, int n_slabs);   // api.cpp (measurement hook, no-op unless enabled; grid = (n_slabs, 2))
 void erl_k6_timing_end(hipStream_t stream);
 
 bool erl_ppo_wd_supported(int S, int h1, int h2, int A)
@@ -107,7 +107,7 @@ int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const
     if (rc) return rc;
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states);
-    g.span = erl_k6_timing_begin(st);
+    g.span = erl_k6_timing_begin(st, n_slabs);
     if (h2 == 128) rc = S > 32 ? erl_ppo_wd_launch_24(a, n_slabs, vec, st) : erl_ppo_wd_launch_14(a, n_slabs, vec, st);
     else rc = S > 32 ? erl_ppo_wd_launch_22(a, n_slabs, vec, st) : erl_ppo_wd_launch_12(a, n_slabs, vec, st);
     erl_k6_timing_end(st);
@@ -228,7 +228,7 @@ int erl_ppo_wd3_step(const float *actor_params, const float *critic_params, cons
     a.scratch = scratch;
     auto al = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states);
-    g.span = erl_k6_timing_begin(st);
+    g.span = erl_k6_timing_begin(st, n_slabs);
     if (h3 == 128) rc = S > 32 ? erl_ppo_wd3_launch_24(a, n_slabs, vec, st) : erl_ppo_wd3_launch_14(a, n_slabs, vec, st);
     else rc = S > 32 ? erl_ppo_wd3_launch_22(a, n_slabs, vec, st) : erl_ppo_wd3_launch_12(a, n_slabs, vec, st);
     erl_k6_timing_end(st);

@@ -63,6 +63,11 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
                             const double *adv_stats, void *stream);
+// the two-launch tail's work in ONE launch (grad_tail.hip, tail_fused_kernel; single process) and whether a row of `stride` floats can take it
+extern "C" int erl_tail_fused_ok(int64_t stride);
+int erl_tail_fused_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len, int n_groups,
+                       float grad_scale, float *params, float *exp_avg, float *exp_avg_sq, int32_t step, float lr, float beta1, float beta2,
+                       float eps, float max_norm, const S3Images *images, hipStream_t stream);
 int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,
                                       const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
                                       float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, const uint32_t *poison,

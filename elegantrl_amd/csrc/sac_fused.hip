@@ -1453,7 +1453,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     ca.P = critic_params; ca.Xs = state; ca.Xa = action; ca.q = qc;
     ca.qt = qt; ca.reward = reward; ca.undone = undone; ca.unmask = unmask; ca.lp_next = lp_next; ca.is_weight = is_weight; ca.alpha0 = alpha0;
     ca.gamma = gamma; ca.label = label; ca.dq = dq; ca.xa = xa; ca.enc = enc; ca.H1e = H1e; ca.dZ1e = dZ1e; ca.dEncE = dEncE;
-    ca.span = erl_span_slot(ERL_SPAN_SAC_CRITIC_TRAIN);
+    ca.span = erl_span_slot(ERL_SPAN_SAC_CRITIC_TRAIN, (int64_t)cg.x * cg.y);
     FUSED_KT_DISPATCH(LAUNCH_CRITIC1)
     ca.span = nullptr;
     // ---- (4) every critic weight / bias gradient in one launch

@@ -402,6 +402,23 @@ def reduce_clip_adam(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN, para
           "erl_reduce_clip_adam_grid_f32" if grid_wait else "erl_reduce_clip_adam_f32")
 
 
+def reduce_clip_adam_fused(slabs: TEN, n_slabs: int, stride: int, flat_grad: TEN, params: TEN, exp_avg: TEN, exp_avg_sq: TEN,
+                           groups: Sequence[Tuple[int, int]], step: int, lr: float, max_norm: float, grad_scale: float = 1.0,
+                           betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """grad_reduce_partials + clip_adam_partials (the default two-launch tail) as ONE launch with the same bits
+    (erl_reduce_clip_adam_fused_f32: the partial norms are their own flags; needs `tail_fused_ok(stride)`)"""
+    n = len(groups)
+    off = (ctypes.c_int64 * n)(*[g[0] for g in groups])
+    ln = (ctypes.c_int64 * n)(*[g[1] for g in groups])
+    check(lib().erl_reduce_clip_adam_fused_f32(ptr(slabs, th.float32), n_slabs, stride, ptr(flat_grad, th.float32), ptr(params, th.float32),
+                                               ptr(exp_avg, th.float32), ptr(exp_avg_sq, th.float32), off, ln, n, step, lr, betas[0], betas[1], eps,
+                                               max_norm, grad_scale, stream_ptr()), "erl_reduce_clip_adam_fused_f32")
+
+
+def tail_fused_ok(stride: int) -> bool:
+    return bool(lib().erl_tail_fused_ok(stride))
+
+
 def reduce_clip_adam_grid_ok(stride: int) -> bool:
     return bool(lib().erl_reduce_clip_adam_grid_ok(stride))
 

@@ -374,6 +374,19 @@ ERL_API int erl_reduce_clip_adam_grid_f32(const float *slabs, int n_slabs, int64
                              int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
                              float grad_scale, void *stream);
 
+/* The default two-launch tail (erl_grad_reduce_partials_f32 + erl_clip_adam_partials_f32) as ONE launch with the same bits (ABI 17,
+ * csrc/grad_tail.hip tail_fused_kernel): the partial norms are published by agent-scope stores into a table double buffered by the
+ * launch's parity and are their own flags (an unwritten entry holds a sentinel NaN); every workgroup polls them -- no arrival counter,
+ * no fence, no second pass --, sums them in erl_clip_adam_partials_f32's order and applies clip + Adam to the 256 elements it has just
+ * reduced, from registers.  Needs erl_tail_fused_ok(stride): rows up to 131 072 floats, every workgroup of the launch resident at once.
+ * The wait is bounded; a timeout SKIPS the update and reports through erl_async_fault_count.  Single process only (a data-parallel
+ * rank's exchange keeps the two launches).  erl_ppo_update_f32 uses it under ERL_FUSED_TAIL=3. */
+ERL_API int erl_tail_fused_ok(int64_t stride);
+ERL_API int erl_reduce_clip_adam_fused_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
+                             float *exp_avg, float *exp_avg_sq, const int64_t *group_off, const int64_t *group_len,
+                             int n_groups, int32_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                             float grad_scale, void *stream);
+
 /* Whole PPO update in one call (single-process path): for k in [0, update_times):
  *   erl_ppo_step_f32(ids + k*B) -> erl_grad_reduce_f32 -> grads[k] -> erl_clip_adam_f32(step = first_step + k).
  * Replaces the minibatch loop of AgentPPO.update_net (AgentPPO.py:158-167).  flat_params / exp_avg / exp_avg_sq hold
@@ -617,9 +630,10 @@ ERL_API void erl_k6_timing_enable(int every_nth);
 ERL_API int erl_k6_timing_read(double *total_ms, int *launches);
 ERL_API int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launches);
 ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median_us);
-/* What the launches drained by the LAST erl_k6_timing_read2 say about the box (ABI 17).  While timing is on EVERY K6 launch leaves its
- * span and clocks; every_nth only selects which launches also sit inside an event bracket -- and a bracket perturbs the kernel inside it
- * (the bracketed launches ran 6-8 us longer than their neighbours on some boxes of the pool: round 5), so `bracketed` selects the group:
+/* What the launches drained by the LAST erl_k6_timing_read2 say about the box (ABI 17).  Of every `every_nth` K6 launches one sits
+ * inside an event bracket and one more (half a period later) is sampled WITHOUT a bracket; both leave one record per workgroup (entry /
+ * exit on the constant-rate clock and on the shader clock, phase stamps: plain stores, folded by the host -- a first version that folded
+ * them on the device with atomics cost the kernel 6 us), every other launch runs untouched.  `bracketed` selects the group:
  * 0 = the launches WITHOUT a bracket (the kernel as the loop runs it), 1 = the bracketed ones.  span_ms / launches = summed
  * first-workgroup-in to last-workgroup-out spans and their count; shader_mhz = the clock the launches actually ran at (shader cycles
  * per tick of the constant-rate clock, summed over every workgroup's own entry-to-exit interval: the chip clocks to its power budget,
@@ -628,10 +642,11 @@ ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median
  * phase of an actor workgroup's first wave in ppo_step_s3_kernel: prologue | first layer forward | second layer forward | output layer
  * + objective + backward | staging + dW1 | staging + dW3 + staging | dW2 + logs + store drain; phase_workgroups = the number of
  * workgroups the means are over.  Any pointer may be NULL. */
-/* The same hook for the other kernels of the hot path (ABI 17): while erl_kernel_span_enable(1), every launch of a tagged kernel
- * leaves its own first-workgroup-in to last-workgroup-out span on the device's constant-rate clock (up to 4096 launches per tag between
- * reads); erl_kernel_span_read(tag) waits for the device, returns the summed spans (microseconds) and their number, and clears the
- * tag.  What rocprofv3's kernel duration measures, without a profiler and without an event bracket around the launch. */
+/* The same hook for the other kernels of the hot path (ABI 17): after erl_kernel_span_enable(n), every n-th launch of a tagged kernel
+ * leaves one {entry, exit} record per workgroup on the device's constant-rate clock (plain stores; 2 M workgroup records between
+ * enables); erl_kernel_span_read(tag) waits for the device and returns the summed first-workgroup-in to last-workgroup-out spans
+ * (microseconds) of the tag's sampled launches and their number.  What rocprofv3's kernel duration measures, without a profiler and
+ * without an event bracket around the launch.  erl_kernel_span_enable(0) turns it off; enabling again clears the records. */
 #define ERL_SPAN_GAE 0             /* gae_exact_kernel / gae_lookback_kernel (erl_gae_scan_f32) */
 #define ERL_SPAN_REPLAY_SAMPLE 1   /* replay_sample_kernel (erl_replay_sample_f32) */
 #define ERL_SPAN_SAC_CRITIC_TRAIN 2 /* critic_tile_kernel<1>: the fused SAC step's critic training pass */
@@ -639,7 +654,7 @@ ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median
 #define ERL_SPAN_CLIP_ADAM 4       /* clip_adam_partials_kernel */
 #define ERL_SPAN_ROLLOUT 5         /* rollout_fused_kernel: the persistent PPO rollout */
 #define ERL_SPAN_TAGS 8
-ERL_API void erl_kernel_span_enable(int on);
+ERL_API void erl_kernel_span_enable(int every_nth);
 ERL_API int erl_kernel_span_read(int tag, double *total_us, int *launches);
 ERL_API int erl_k6_timing_clocks(int bracketed, double *span_ms, int *launches, double *shader_mhz, double *workgroup_us,
                          double *phase_cycles, int max_phases, int *n_phases, int *phase_workgroups);

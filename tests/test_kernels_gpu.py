@@ -794,6 +794,56 @@ def test_partials_tail_equals_the_two_kernel_tail(ops, dev, n_slabs, Pa, Pc, max
     assert float((pa - p0).abs().max()) > 1e-4
 
 
+@pytest.mark.parametrize("n_slabs,Pa,Pc,max_norm,scale", [(128, 25872, 24961, 3.0, 1.0), (128, 25872, 24961, 1e9, 0.125), (7, 1000, 37, 0.5, 0.5),
+                                                          (1, 300, 200, 3.0, 1.0), (37, 70000, 5, 3.0, 1.0), (256, 47648, 46337, 3.0, 1.0)])
+def test_single_launch_tail_is_bit_identical_to_the_two_launch_tail(ops, dev, n_slabs, Pa, Pc, max_norm, scale):
+    """csrc/grad_tail.hip tail_fused_kernel (round 5): the default tail -- erl_grad_reduce_partials_f32 + erl_clip_adam_partials_f32 -- as ONE
+    launch: the reduced gradient, parameters and both moments BIT FOR BIT over six steps (gradients alternating in scale so that the clip
+    is and is not active), i.e. the same partial norms summed in the same order; no wait of the kernel timed out."""
+    from elegantrl_amd import _hip
+    g = th.Generator(device=dev).manual_seed(n_slabs + Pa)
+    stride = (Pa + Pc + 4 + 31) // 32 * 32
+    assert ops.tail_fused_ok(stride)
+    groups = [(0, Pa), (Pa, Pc)]
+    p0 = th.randn(Pa + Pc, device=dev, generator=g)
+    pa, ma, va = p0.clone(), th.zeros_like(p0), th.zeros_like(p0)
+    pb, mb, vb = p0.clone(), th.zeros_like(p0), th.zeros_like(p0)
+    fa, fb = th.empty(stride, device=dev), th.empty(stride, device=dev)
+    for step in range(1, 7):
+        slabs = th.randn((n_slabs, stride), device=dev, generator=g) * (0.1 if step % 2 else 10.0)
+        ops.grad_reduce_partials(slabs, n_slabs, stride, fa, groups, grad_scale=scale)
+        ops.clip_adam_partials(pa, fa, ma, va, stride, groups, step, 1e-3, max_norm, grad_scale=scale)
+        ops.reduce_clip_adam_fused(slabs, n_slabs, stride, fb, pb, mb, vb, groups, step, 1e-3, max_norm, grad_scale=scale)
+        assert th.equal(fa, fb), f"gradient, step {step}"
+        assert th.equal(pa, pb) and th.equal(ma, mb) and th.equal(va, vb), f"parameters / moments, step {step}"
+    assert float((pa - p0).abs().max()) > 1e-4
+    th.cuda.synchronize()
+    _hip.check_async_faults()
+
+
+def test_single_launch_tail_in_the_update_loop_and_its_timeout(ops, dev, monkeypatch):
+    """(i) erl_ppo_update_f32 under ERL_FUSED_TAIL=3 leaves exactly the weights, moments, gradient rows and -- for the split-arithmetic
+    minibatch kernel -- weight IMAGES (the next minibatch reads them) of the default two-launch loop: six minibatches on the reference
+    golden's shape; (ii) a row too long for the kernel is refused by erl_tail_fused_ok (the loop keeps the two launches)."""
+    g = load("ppo_c4shape.npz")
+    from tests.test_agent_gpu import make_agent
+    res = {}
+    for mode in ("0", "3"):
+        monkeypatch.setenv("ERL_FUSED_TAIL", mode)
+        agent, _ = make_agent(g)
+        agent.last_state = th.from_numpy(g["last_state"]).to(dev)
+        buf = [th.from_numpy(g[k]).to(dev) for k in ("states", "actions", "logprobs", "rewards", "undones", "unmasks")]
+        ids = th.from_numpy(np.concatenate([g["ids"]] * 3)).to(dev)
+        agent.repeat_times = ids.shape[0] * agent.batch_size / buf[0].shape[0]
+        objs = agent.update_net(buf, ids=ids)
+        res[mode] = (agent._flat.clone(), agent._exp_avg.clone(), agent._exp_avg_sq.clone(), agent._grads[:ids.shape[0]].clone(), objs)
+    monkeypatch.delenv("ERL_FUSED_TAIL")
+    for a, b in zip(res["0"][:4], res["3"][:4]):
+        assert th.equal(a, b)
+    assert res["0"][4] == res["3"][4]
+    assert not ops.tail_fused_ok(64 * 2049) and ops.tail_fused_ok(64 * 2048)
+
+
 def test_clip_adam_grad_scale_equals_prescaled(ops, dev):
     rng = np.random.default_rng(10)
     n = 5000
