@@ -67,6 +67,12 @@ PPO_CONFIGS = {
                update_times=128, net_dims=[128, 128], hyper=dict(fused_gae=False),
                workload="reference-default on-policy shape (elegantrl/train/config.py:55-58: horizon_len 2048, batch_size 128, repeat_times 8 => "
                         "128 minibatches x 128) on BASELINE configs[3]'s synthetic VecEnv obs_dim=64 act_dim=8, 4096 envs/GPU, net [128,128], fp32"),
+    # not a measurement: the REHEARSAL shape of the N > 1 code path (tests/test_bench_gpu.py runs `--gpus 8` with eight ranks SHARING the one
+    # GPU of the test box over gloo: barrier / max-over-ranks timing, route probe + self-test + selection, the exchange inside the loop,
+    # the all-reduce micro-benchmark, per-rank times) -- small enough that eight ranks' kernels and their exchange workgroups fit one device
+    "cr": dict(metric="rehearsal_env_steps_per_sec_ppo_512envs", env="syn", N=512, S=8, A=2, H=16, B=2048, update_times=4, net_dims=[64, 64],
+               hyper={}, workload="rehearsal of the data-parallel path (not a BASELINE configuration): 512 envs/rank, obs 8, act 2, horizon 16, "
+                                  "4 minibatches x 2048, net [64,64], fp32"),
     # not a BASELINE configuration: the network of the reference's LunarLanderContinuous demo (examples/demo_A2C_PPO.py:117,
     # net_dims (256, 128), with its hyper-parameters :118-125) on a synthetic VecEnv of that env's shape, vectorised like configs[3];
     # its minibatch loop runs on csrc/ppo_step_wd_impl.h (rollout and value pre-pass on the layered erl_mlpn_* path)
@@ -518,7 +524,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--eager-logs", action="store_true", help="read update_net's logged objectives at once (one host sync per iteration with the GPU "
                                                               "idle behind it) instead of one rollout late, as train_agent does by default")
-    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5", "cw", "cd"], default="c4",
+    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5", "cw", "cd", "cr"], default="c4",
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
                          "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs, cw = the reference demo's (256,128) network, "
                          "cd = the reference's default horizon / batch shape (2048 x 4096 rollout, 128 minibatches of 128)")
@@ -621,6 +627,7 @@ def main():
     # every K6 launch of the region left its own span / clock / phase stamps; the launches WITHOUT an event bracket are the kernel as
     # the loop runs it (a bracket perturbs what it brackets: the bracketed group is reported next to it)
     k6_clocks, k6_clocks_br = _hip.k6_timing_clocks(False), _hip.k6_timing_clocks(True)
+    k6_wgs = _hip.k6_wg_summary(_hip.k6_timing_last_records(False))      # where / when the last sampled launch's workgroups ran
     smi = smi_snapshot() if rank == 0 and not opt.no_smi else None
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
@@ -787,6 +794,7 @@ def main():
                      "phase_cycles_reference": phase_ref},
         "clocks": {"shader_mhz_in_k6": round(k6_mhz, 1) if k6_mhz else None, "peak_quoted_at_mhz": SHADER_PEAK_MHZ,
                    "k6_workgroup_us": round(k6_clocks["workgroup_us"], 2), "phase_workgroups": k6_clocks["phase_workgroups"],
+                   "k6_workgroups_last_sampled_launch": k6_wgs,
                    "smi": smi,
                    "note": "shader_mhz_in_k6 = sum over workgroups of (s_memtime exit - entry) / (constant-rate clock exit - entry) x its rate, on the "
                            "sampled minibatch-kernel launches of the timed region; smi = rocm-smi / amd-smi right after the region"},

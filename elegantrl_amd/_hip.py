@@ -142,6 +142,7 @@ _SIGNATURES = {
     "erl_k6_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_read2": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_null_bracket_us": (c_int, [_P, c_int, POINTER(ctypes.c_double)]),
+    "erl_k6_timing_last_records": (c_int, [c_int, POINTER(ctypes.c_uint64), c_int]),
     "erl_kernel_span_enable": (None, [c_int]),
     "erl_kernel_span_read": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "erl_k6_timing_clocks": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
@@ -304,6 +305,48 @@ def k6_timing_clocks(bracketed: bool = False):
                                      ctypes.byref(n), ctypes.byref(nw)), "erl_k6_timing_clocks")
     return {"launches": nl.value, "span_us": sp.value * 1e3 / nl.value if nl.value else None, "shader_mhz": mhz.value, "workgroup_us": wg.value,
             "phase_cycles": {K6_PHASES[k]: ph[k] for k in range(min(n.value, len(K6_PHASES)))}, "phase_workgroups": nw.value}
+
+
+def k6_timing_last_records(bracketed: bool = False):
+    """diagnostics: per-workgroup records of the group's last sampled K6 launch as a list of dicts (start offset and duration in us on
+    the constant-rate clock, shader cycles, where it ran: xcc / se / sh / cu ids from HW_REG_HW_ID / HW_REG_XCC_ID); actor workgroups first"""
+    buf = (ctypes.c_uint64 * (8 * 1024))()
+    n = lib().erl_k6_timing_last_records(int(bool(bracketed)), buf, 1024)
+    recs = []
+    t0 = min((buf[8 * i] for i in range(n) if buf[8 * i + 1] > buf[8 * i]), default=0)
+    for i in range(n):
+        w0, w1, m0, m1, hw = buf[8 * i], buf[8 * i + 1], buf[8 * i + 2], buf[8 * i + 3], buf[8 * i + 7]
+        if w1 <= w0:
+            continue
+        hwid, xcc = hw & 0xffffffff, (hw >> 32) & 0xf
+        recs.append({"wg": i, "start_us": (w0 - t0) / 100.0, "dur_us": (w1 - w0) / 100.0, "cycles": m1 - m0, "xcc": xcc,
+                     "se": (hwid >> 13) & 0x7, "sh": (hwid >> 12) & 1, "cu": (hwid >> 8) & 0xf, "simd": (hwid >> 4) & 3})
+    return recs
+
+
+def k6_wg_summary(recs):
+    """compact reading of k6_timing_last_records(): did every workgroup get a compute unit of its own at once?  (a launch of 256
+    workgroups that each need a whole CU -- 155 KB of LDS, 512 registers per lane -- runs in ONE round only if 256 CUs take them)"""
+    if not recs:
+        return None
+    import statistics
+    cus = {}
+    for r in recs:
+        cus.setdefault((r["xcc"], r["se"], r["sh"], r["cu"]), []).append(r)
+    shared = {k: v for k, v in cus.items() if len(v) > 1}
+    durs, starts = sorted(r["dur_us"] for r in recs), sorted(r["start_us"] for r in recs)
+    per_xcc = {}
+    for r in recs:
+        per_xcc.setdefault(r["xcc"], []).append(r["dur_us"])
+    return {"workgroups": len(recs), "distinct_cus": len(cus), "cus_hosting_more_than_one_workgroup": len(shared),
+            "workgroups_in_a_second_round": sum(len(v) - 1 for v in shared.values()),
+            "start_us": {"median": round(statistics.median(starts), 2), "p90": round(starts[int(0.9 * (len(starts) - 1))], 2), "max": round(starts[-1], 2)},
+            "dur_us": {"min": round(durs[0], 2), "median": round(statistics.median(durs), 2), "max": round(durs[-1], 2)},
+            "end_us_max": round(max(r["start_us"] + r["dur_us"] for r in recs), 2),
+            "late_starters": sorted(({"wg": r["wg"], "start_us": round(r["start_us"], 1), "dur_us": round(r["dur_us"], 1), "xcc": r["xcc"], "se": r["se"],
+                                      "cu": r["cu"]} for r in recs if r["start_us"] > 5.0), key=lambda x: -x["start_us"])[:12],
+            "dur_us_mean_by_xcc": {str(k): round(sum(v) / len(v), 2) for k, v in sorted(per_xcc.items())},
+            "workgroups_by_xcc": {str(k): len(v) for k, v in sorted(per_xcc.items())}}
 
 
 def k6_null_bracket_us(reps: int = 200) -> float:

@@ -120,6 +120,7 @@ struct K6Stats {
     int phase_wgs = 0, launches = 0;
 };
 static K6Stats g_k6_stats[2];
+static std::vector<unsigned long long> g_k6_last_records[2];    // raw per-workgroup records of the group's LAST sampled launch (diagnostics)
 
 static void k6_span_reset()
 {
@@ -209,8 +210,10 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
             for (int b = 0; b < 2; ++b) {
                 double wall = 0.0, mem = 0.0, wgs = 0.0, pwgs = 0.0, ph[kK6SpanPhases] = {}, sp = 0.0;
                 int m = 0;
+                g_k6_last_records[b].clear();
                 for (const K6Launch &L : g_k6_launches) {
                     if ((int)L.bracketed != b) continue;
+                    g_k6_last_records[b].assign(h.begin() + L.off, h.begin() + L.off + (size_t)kK6SpanWords * 2 * L.n_slabs);
                     unsigned long long lo = ~0ull, hi = 0ull;
                     for (int w = 0; w < 2 * L.n_slabs; ++w) {
                         const unsigned long long *q = h.data() + L.off + (size_t)kK6SpanWords * w;
@@ -270,6 +273,16 @@ extern "C" int erl_k6_timing_clocks(int bracketed, double *span_ms, int *launche
     if (n_phases) *n_phases = np;
     if (phase_workgroups) *phase_workgroups = st.phase_wgs;
     return ERL_OK;
+}
+
+// diagnostics: the raw per-workgroup records (8 u64 each: ppo_step.h, span_exit) of the group's last sampled launch, actor workgroups
+// first; returns the number of workgroups copied
+extern "C" int erl_k6_timing_last_records(int bracketed, unsigned long long *out, int max_workgroups)
+{
+    const auto &r = g_k6_last_records[bracketed ? 1 : 0];
+    const int n = std::min((int)(r.size() / kK6SpanWords), max_workgroups);
+    if (out && n > 0) memcpy(out, r.data(), (size_t)n * kK6SpanWords * sizeof(unsigned long long));
+    return n;
 }
 
 // ---- generic per-kernel spans (erl_common.h: erl_span_slot / erl_span_in / erl_span_out) ----------------------------------------

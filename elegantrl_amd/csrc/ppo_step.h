@@ -95,7 +95,7 @@ __device__ __forceinline__ float adv_normalized(float adv, const AdvNorm &n)
 // Record: [0] entry, [1] exit on the constant-rate clock, [2] entry, [3] exit on the SHADER clock (s_memtime: the ratio of the two
 // intervals is the clock the kernel actually ran at -- the chip clocks to its power budget, MI355X_MICROARCH.md "DVFS give-back"),
 // [4 .. 4 + kSpanPhases / 2): the low words of the shader clock at the kSpanPhases - 1 phase boundaries of kernels that stamp phases
-// (ppo_step_s3_kernel), two per u64, 0 otherwise.
+// (ppo_step_s3_kernel), two per u64, 0 otherwise; [7] where the workgroup ran: HW_REG_HW_ID (cu / sh / se ids) | HW_REG_XCC_ID << 32.
 constexpr int kSpanPhases = 7;
 constexpr int kSpanWords = 8;
 static_assert(4 + (kSpanPhases + 1) / 2 <= kSpanWords, "span record too small");
@@ -137,8 +137,10 @@ __device__ __forceinline__ void span_exit(const Ppo2Args &g, SpanT t0, const Spa
 #pragma unroll
             for (int k = 1; k < kSpanPhases; ++k) ph[(k - 1) >> 1] |= (unsigned long long)st->t[k] << (32 * ((k - 1) & 1));
         }
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
         rec[0] = t0.wall; rec[1] = w1; rec[2] = t0.mem; rec[3] = m1;
-        rec[4] = ph[0]; rec[5] = ph[1]; rec[6] = ph[2]; rec[7] = ph[3];
+        rec[4] = ph[0]; rec[5] = ph[1]; rec[6] = ph[2]; rec[7] = (unsigned long long)hw_id | ((unsigned long long)xcc_id << 32);
     }
 }
 

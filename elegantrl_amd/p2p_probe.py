@@ -17,6 +17,8 @@ def main() -> int:
     import torch as th
     import torch.distributed as dist
 
+    if os.environ.get("ERL_P2P_PROBE_FAIL"):      # fault injection (tests): the child dies the way a faulting peer mapping kills it -- before
+        os._exit(int(os.environ["ERL_P2P_PROBE_FAIL"]) or 7)   # any collective, without cleaning up; every rank must fall back
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, th.cuda.device_count())
     count = int(os.environ.get("ERL_P2P_PROBE_COUNT", "50848"))

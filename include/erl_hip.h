@@ -642,6 +642,10 @@ ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median
  * phase of an actor workgroup's first wave in ppo_step_s3_kernel: prologue | first layer forward | second layer forward | output layer
  * + objective + backward | staging + dW1 | staging + dW3 + staging | dW2 + logs + store drain; phase_workgroups = the number of
  * workgroups the means are over.  Any pointer may be NULL. */
+/* diagnostics: the raw per-workgroup records of the group's last sampled launch (8 uint64 each: entry / exit on the constant-rate clock,
+ * entry / exit on the shader clock, three words of phase stamps, HW_REG_HW_ID | HW_REG_XCC_ID << 32 = where the workgroup ran); actor
+ * workgroups first.  Returns the number of workgroups copied (<= max_workgroups). */
+ERL_API int erl_k6_timing_last_records(int bracketed, unsigned long long *out, int max_workgroups);
 /* The same hook for the other kernels of the hot path (ABI 17): after erl_kernel_span_enable(n), every n-th launch of a tagged kernel
  * leaves one {entry, exit} record per workgroup on the device's constant-rate clock (plain stores; 2 M workgroup records between
  * enables); erl_kernel_span_read(tag) waits for the device and returns the summed first-workgroup-in to last-workgroup-out spans

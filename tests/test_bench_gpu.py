@@ -55,3 +55,35 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert a["mode"] == "auto" and a["rccl_selftest"] == "not tried" and a["p2p_selftest"] == "ok" and a["p2p_us"] > 0, a
     assert "peer-to-peer" in a["selected"], a
     assert "cpu_baseline" not in line
+
+
+def _torchrun(n, port, extra, env):
+    return run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-gae-sweep", "--no-smi", *extra], env=env)
+
+
+def test_bench_eight_ranks_on_one_gpu_rehearsal():
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, one rank per "GPU"), rehearsed with the eight ranks SHARING
+    the one device over gloo on the small `cr` shape: the barrier / max-over-ranks contract, the route report (RCCL cannot come up on a gloo
+    group: not tried; the out-of-process probe and the in-process self-test of the peer-to-peer exchange pass at world 8; it is selected),
+    the exchange inside the loop (4 minibatches per step), every rank's own time.  No scaling number comes out of this: one GPU."""
+    line = _torchrun(8, 29571, ["--config", "cr"], {"ERL_DIST_BACKEND": "gloo"})
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak" and line["config"]["name"] == "cr"
+    assert line["value"] > 0 and abs(line["value"] - 8 * 512 * 16 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 0.02
+    a = line["allreduce"]
+    assert a["mode"] == "auto" and a["rccl_selftest"] == "not tried" and a["ranks_seen_by_rccl"] is None, a
+    assert a["p2p_probe"] == "ok" and a["p2p_selftest"] == "ok" and a["p2p_us"] > 0 and "peer-to-peer" in a["selected"], a
+    assert a["calls_per_step"] == 4 and a["selected_us_per_call_after_run"] > 0 and a["stats_exchange"].startswith("same route")
+    pr = line["extra"]["per_rank_ms_per_step"]
+    assert 0 < pr["min"] <= pr["max"] <= line["ms_per_step"] * 1.05
+    assert "cpu_baseline" not in line and len(line["objectives_last"]) == 3 and all(x == x for x in line["objectives_last"])
+
+
+def test_bench_falls_back_when_the_p2p_probe_child_dies():
+    """the fallback ladder: the probe's child process is made to die (ERL_P2P_PROBE_FAIL: what a faulting peer mapping does to it) -- on
+    a gloo group RCCL is not available either, so every rank must agree on torch.distributed, say why, and finish the run"""
+    line = _torchrun(4, 29573, ["--config", "cr"], {"ERL_DIST_BACKEND": "gloo", "ERL_P2P_PROBE_FAIL": "7"})
+    a = line["allreduce"]
+    assert a["p2p_probe"] != "ok" and ("exited with 7" in a["p2p_probe"] or "another rank" in a["p2p_probe"]), a
+    assert a["p2p_selftest"].startswith("not run") and a["rccl_selftest"] == "not tried" and a["selected"] == "torch.distributed", a
+    assert line["n_gpus"] == 4 and line["value"] > 0 and a["stats_exchange"] == "torch.distributed"

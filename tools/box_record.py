@@ -92,8 +92,49 @@ for arith in ("split", "f32"):
                   "workgroup_us": round(c["workgroup_us"], 2), "workgroup_us_bracketed": round(cb["workgroup_us"], 2),
                   "phase_cycles": {k: round(v) for k, v in c["phase_cycles"].items()},
                   "phase_cycles_bracketed": {k: round(v) for k, v in cb["phase_cycles"].items()},
+                  "workgroups": _hip.k6_wg_summary(_hip.k6_timing_last_records(False)),
                   "note": "stand-alone erl_ppo_step_f32 (every workgroup splits W1 / W2 itself: no images from the update loop)"}
+# ---- the same kernel with the caches scrubbed in front of every launch (a 512 MiB copy: L2 and MALL hold nothing of the kernel's code,
+# weights or rows) -- what the kernel pays for a cold start on this box
+ops.ppo_set_arith("split")
+scrub_a = th.empty(1 << 27, dtype=th.float32, device=dev)
+scrub_b = th.empty_like(scrub_a)
+_hip.k6_timing_enable(2)
+for i in range(60):
+    scrub_b.copy_(scrub_a)
+    k6(i)
+th.cuda.synchronize()
+_hip.k6_timing_enable(False)
+_hip.k6_timing_read2()
+c = _hip.k6_timing_clocks(False)
+res["split_cold_caches"] = {"us_span_unbracketed": round(c["span_us"] or 0, 2), "shader_mhz": round(c["shader_mhz"], 1), "workgroup_us": round(c["workgroup_us"], 2),
+                            "phase_cycles": {k: round(v) for k, v in c["phase_cycles"].items()},
+                            "workgroups": _hip.k6_wg_summary(_hip.k6_timing_last_records(False))}
+del scrub_a, scrub_b
 ops.ppo_set_arith("auto")
+# ---- the kernel as the update loop launches it (erl_ppo_update_f32: weight images from the loop, slab reduction and clip + Adam between
+# the launches, lr = 0), 3 x 40 minibatches on the same random rollout
+m1, m2 = th.zeros_like(flat), th.zeros_like(flat)
+rows = th.zeros((40, stride), device=dev)
+ids40 = th.stack([idsets[i % 8] for i in range(40)])
+for rep in range(3):
+    if rep == 2:
+        _hip.k6_timing_enable(4)
+        _hip.kernel_span_enable(4)
+    ops.ppo_update(flat, m1, m2, avg, std, avg, std, S, h1, h2, A, states, actions, um, logprobs, adv, ret, ids40, 0.25, 0.001, slabs, rows, 1 + 40 * rep,
+                   0.0, 3.0)
+th.cuda.synchronize()
+_hip.k6_timing_enable(False)
+ev_s, span_s, n = _hip.k6_timing_read2()
+c = _hip.k6_timing_clocks(False)
+red_us, _n1 = _hip.kernel_span_read(_hip.SPAN_SLAB_REDUCE)
+adam_us, _n2 = _hip.kernel_span_read(_hip.SPAN_CLIP_ADAM)
+_hip.kernel_span_enable(False)
+res["split_in_update_loop"] = {"us_span_unbracketed": round(c["span_us"] or 0, 2), "us_span_bracketed": round(span_s / max(n, 1) * 1e6, 2),
+                               "shader_mhz": round(c["shader_mhz"], 1), "workgroup_us": round(c["workgroup_us"], 2),
+                               "phase_cycles": {k: round(v) for k, v in c["phase_cycles"].items()},
+                               "slab_reduce_us": round(red_us, 2) if red_us else None, "clip_adam_us": round(adam_us, 2) if adam_us else None,
+                               "workgroups": _hip.k6_wg_summary(_hip.k6_timing_last_records(False))}
 out["k6_standalone"] = res
 out["smi_after_k6"] = bench.smi_snapshot()
 
