@@ -98,6 +98,15 @@ __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int
     __syncthreads();
     T gsum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);        // all four threads of an element hold it
     if (DP) {
+        // ---- a peer whose wait timed out in an earlier launch of this update loop has raised ITS word in my table: its replica no longer
+        // steps, so neither may mine (round 4 poisoned the timed-out rank only: the others kept stepping and the replicas diverged
+        // silently until that rank raised).  One workgroup looks; the sticky device word stops clip + Adam, the fault word makes the host raise.
+        if (blockIdx.x == 0 && (int)threadIdx.x < ex.world && ex.poison) {
+            const uint32_t *pw = ex.flags[ex.rank] + (int64_t)ex.world * ex.nblk_max + threadIdx.x;
+            if (__hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) &&
+                !__hip_atomic_fetch_or(ex.poison, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && ex.fault)
+                __hip_atomic_fetch_add(ex.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         // ---- push my reduced slice into my row of every rank's stage (thread quarter p serves ranks p, p + 4)
         const int64_t half_off = (int64_t)(ex.seq & 1u) * ex.half_bytes;
         if (i < stride)
@@ -118,7 +127,12 @@ __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int
                     // rest of the update loop -- the same policy as a timed-out grid wait in optim.hip -- and the error is raised
                     // when the host reads the fault counter at the end of update_net (which also clears the word)
                     if (ex.fault) __hip_atomic_fetch_add(ex.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (ex.poison) __hip_atomic_fetch_or(ex.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ex.poison) {
+                        __hip_atomic_fetch_or(ex.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // tell every rank (their next launch reads it): no replica steps once one of them has stopped
+                        for (int r = 0; r < ex.world; ++r)
+                            __hip_atomic_store(ex.flags[r] + (int64_t)ex.world * ex.nblk_max + ex.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     break;
                 }
             }

@@ -51,7 +51,8 @@ int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *
     c->nblk_max = (int)erl_cdiv(max_count, 256);
     c->row_bytes = (int64_t)round_up((size_t)c->nblk_max * 256 * sizeof(float), 256);
     c->half_bytes = (int64_t)world * c->row_bytes;
-    c->flag_bytes = (int64_t)round_up((size_t)world * c->nblk_max * sizeof(uint32_t), P2P_ALIGN);
+    // [flags: world x nblk_max words][poisoned: world words -- rank r's word, raised on EVERY rank when a wait of rank r timed out]
+    c->flag_bytes = (int64_t)round_up(((size_t)world * c->nblk_max + (size_t)world) * sizeof(uint32_t), P2P_ALIGN);
     const size_t bytes = (size_t)c->flag_bytes + 2 * (size_t)c->half_bytes;
     int rc = erl_hip_status(hipGetDevice(&c->dev), "hipGetDevice");
     void *p = nullptr;
@@ -141,6 +142,8 @@ void erl_p2p_clear_poison_all()
             (void)hipSetDevice(c->dev);
             (void)hipDeviceSynchronize();
             (void)hipMemset(c->poison, 0, 4);
+            // ... and the words the peers raised in MY table (theirs are cleared by their own report)
+            if (c->local) (void)hipMemset(c->local + (size_t)c->world * c->nblk_max * sizeof(uint32_t), 0, (size_t)c->world * sizeof(uint32_t));
         }
     if (cur >= 0) (void)hipSetDevice(cur);
 }

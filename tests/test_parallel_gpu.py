@@ -298,6 +298,7 @@ def _pn_worker(rank, world, port, out_dir, withhold):
                 ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, 1, 1e-3, 0.5, grad_scale=1.0 / world, comm=comm)
                 ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, 2, 1e-3, 0.5, grad_scale=1.0 / world, comm=comm)   # sticky
                 th.cuda.synchronize()
+                parallel.barrier()                                                 # (the withholding rank launches now: see below)
                 untouched = bool(th.equal(params, before)) and not bool(m1.any()) and not bool(m2.any())
                 n_faults = _hip.lib().erl_async_fault_count(1)                     # report + reset: clears the poison
                 msg = _hip.lib().erl_last_error_string().decode()
@@ -307,7 +308,16 @@ def _pn_worker(rank, world, port, out_dir, withhold):
                 th.cuda.synchronize()
                 res["fault"] = [untouched, int(n_faults), "peer-to-peer" in msg and "SKIPPED" in msg, not bool(th.equal(params, before))]
             else:
+                # round 5: the ranks that gave up raised their word in EVERY rank's table.  The late rank's launch of the same exchange finds
+                # its peers' slices (they published before they waited) -- and their poison: its own optimiser steps are skipped too and its
+                # host raises as well, instead of one replica stepping on alone
+                parallel.barrier()
+                gsum = th.empty(stride, device="cuda")
+                ops.grad_reduce_partials(slabs, n_slabs, stride, gsum, groups, grad_scale=1.0 / world, comm=comm)
+                ops.clip_adam_partials(params, gsum, m1, m2, stride, groups, 1, 1e-3, 0.5, grad_scale=1.0 / world, comm=comm)
+                th.cuda.synchronize()
                 res["fault"] = "withheld"
+                res["late_rank"] = [bool(th.equal(params, before)), int(_hip.lib().erl_async_fault_count(1))]
         parallel.barrier()
         comm.close()
     import json
@@ -337,6 +347,8 @@ def test_p2p_exchange_at_node_world_sizes_on_one_gpu(tmp_path, world):
         np.testing.assert_array_equal(w[0], w[r])
     if world == 4:
         assert res[world - 1]["fault"] == "withheld"
+        late_untouched, late_faults = res[world - 1]["late_rank"]
+        assert late_untouched and late_faults > 0, "the peers' poison did not reach the rank that launched late"
         for r in range(world - 1):
             untouched, n_faults, named, recovered = res[r]["fault"]
             assert untouched, f"rank {r}: a timed-out exchange was applied to the parameters"

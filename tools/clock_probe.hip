@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -107,6 +108,79 @@ __global__ __launch_bounds__(256) void body(int iters, Rec *out, float *sink)
     if (s == 12345.678f) sink[0] = s;
 }
 
+// KIND 5: the minibatch kernel's forward-layer shape -- per group 3 ds_read_b128 sweeping 152 KB of dynamic LDS (its weight images), 6 bf16
+// MFMAs on two accumulators, 30 vector instructions with transcendentals among them (its GELU stages), one wave per SIMD (the 152 KB
+// keep a second workgroup off the CU).  If a box runs THIS slower than its neighbours while the single-instruction bodies above agree,
+// the difference is in how the pieces share the CU, not in any one pipe.
+__global__ __launch_bounds__(256) void body_k6like(int iters, Rec *out, float *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) float big[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 38912; i += 256) big[i] = (float)i * 1e-6f;
+    __syncthreads();
+    f32x16 a0 = {0}, a1 = {0};
+    float v[6] = {0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f};
+    const unsigned long long w0 = wall_clock64(), c0 = memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int base = ((it * 4 + u) * 3 * 256 + lane * 4) % 38000;
+            const float4 x0 = *reinterpret_cast<const float4 *>(&big[(base) & ~3]);
+            const float4 x1 = *reinterpret_cast<const float4 *>(&big[(base + 256) & ~3]);
+            const float4 x2 = *reinterpret_cast<const float4 *>(&big[(base + 512) & ~3]);
+            bf16x8 p = __builtin_bit_cast(bf16x8, x0), q = __builtin_bit_cast(bf16x8, x1), r = __builtin_bit_cast(bf16x8, x2);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m == 0 ? p : (m == 1 ? q : r), q, a0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], 0.999f, 1e-3f);
+                v[4] = __builtin_amdgcn_rcpf(v[4] + 1.5f);
+                __builtin_amdgcn_sched_barrier(0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p, m == 0 ? r : (m == 1 ? p : q), a1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], 0.998f, 2e-3f);
+                v[5] = __builtin_amdgcn_exp2f(-(v[5] * v[5]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    const unsigned long long c1 = memtime(), w1 = wall_clock64();
+    if (threadIdx.x == 0) out[blockIdx.x] = Rec{c1 - c0, w1 - w0};
+    float s = v[0] + v[1] + v[2] + v[3] + v[4] + v[5];
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+void run_k6like(int khz, int iters, int reps)
+{
+    Rec *d;
+    float *sink;
+    const int grid = 256;
+    const size_t lds = 38912 * sizeof(float);                  // 152 KB
+    CHECK(hipFuncSetAttribute((const void *)body_k6like, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipMalloc(&d, grid * sizeof(Rec)));
+    CHECK(hipMalloc(&sink, 4));
+    std::vector<Rec> h(grid);
+    double sum_mhz = 0, sum_cyc = 0, mn = 1e30, mx = 0;
+    for (int r = 0; r < reps; ++r) {
+        hipLaunchKernelGGL(body_k6like, dim3(grid), dim3(256), lds, 0, iters, d, sink);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h.data(), d, grid * sizeof(Rec), hipMemcpyDeviceToHost));
+        double cyc = 0, wall = 0;
+        for (auto &x : h) { cyc += (double)x.cyc; wall += (double)x.wall; if (r >= reps / 2) { mn = std::min(mn, (double)x.cyc); mx = std::max(mx, (double)x.cyc); } }
+        if (r >= reps / 2) { sum_mhz += cyc / wall * khz * 1e-3; sum_cyc += cyc / grid; }
+    }
+    const int n = reps - reps / 2;
+    printf("\"k6_like_forward_mix\": {\"shader_mhz\": %.1f, \"cycles_per_group\": %.1f, \"workgroup_cycles_min_over_mean\": %.3f, "
+           "\"workgroup_cycles_max_over_mean\": %.3f, \"us_per_launch\": %.1f}, ",
+           sum_mhz / n, sum_cyc / n / (iters * 4.0), mn / (sum_cyc / n), mx / (sum_cyc / n), sum_cyc / n / (sum_mhz / n));
+    CHECK(hipFree(d));
+    CHECK(hipFree(sink));
+}
+
 template <int KIND>
 void run(const char *name, int per_iter, int iters, int reps, int khz, bool last)
 {
@@ -149,6 +223,7 @@ int main()
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"wall_clock_khz\": %d, \"attr_clock_khz\": %d, \"attr_memory_clock_khz\": %d, ",
            prop.name, prop.gcnArchName, cus, khz, sclk, mclk);
     // ~100-200 us per launch, 24 launches each: long enough for the power manager to settle on the body's clock
+    run_k6like(khz, 120, 24);
     run<0>("mfma_bf16_32x32x16", 16, 400, 24, khz, false);
     run<1>("mfma_f32_32x32x2", 16, 200, 24, khz, false);
     run<2>("valu_fma_f32", 80, 600, 24, khz, false);
