@@ -17,8 +17,13 @@ def scan(path):
         t = ln.strip()
         if t.startswith("s_barrier") or t.startswith("s_endpgm"):
             depth = 0
-        elif t.startswith("s_and_saveexec") or t.startswith("s_or_saveexec"):
+        elif t.startswith("s_and_saveexec"):
             depth += 1
+        elif t.startswith("s_or_saveexec"):
+            # the ELSE entry of an if / else lowered as s_and_saveexec ... s_or_saveexec ... s_or_b64 exec: still inside the SAME reduced-mask
+            # region (counting it as a second opener left the depth stuck at 1 behind every if / else: false positives for the rest of
+            # the kernel); an else without a preceding if does open one
+            depth = max(depth, 1)
         elif t.startswith("s_or_b64 exec, exec,"):
             depth = max(0, depth - 1)
         elif depth > 0 and (t.startswith("v_accvgpr_write") or t.startswith("scratch_store")):
@@ -30,7 +35,7 @@ def scan(path):
                 d = depth
                 for j in range(i - 1, max(0, i - 400), -1):
                     tj = lines[j].strip()
-                    if tj.startswith("s_and_saveexec") or tj.startswith("s_or_saveexec"):
+                    if tj.startswith("s_and_saveexec"):
                         d -= 1
                         if d <= 0:
                             break
