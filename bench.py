@@ -182,8 +182,8 @@ KERNEL_SOURCES = {
     "ppo_step_wd_kernel": ["ppo_step_wd_impl.h", "ppo_step_wd.hip", "ppo_step_wd.h", "ppo_step_s3_impl.h", "split_bf16.h", "s3_image.h",
                            "ppo_step_w4_impl.h", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
 }
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
-KTIME_FILE = os.path.join("profiles", "r04_kernel_times.json")     # tools/kstats_summarise.py over rocprofv3 --kernel-trace --stats of this command
+PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+KTIME_FILE = os.path.join("profiles", "r05_kernel_times.json")     # tools/kstats_summarise.py over rocprofv3 --kernel-trace --stats of this command
 
 
 def kernel_source_sha16(kernel: str):
