@@ -67,6 +67,14 @@ PPO_CONFIGS = {
                update_times=128, net_dims=[128, 128], hyper=dict(fused_gae=False),
                workload="reference-default on-policy shape (elegantrl/train/config.py:55-58: horizon_len 2048, batch_size 128, repeat_times 8 => "
                         "128 minibatches x 128) on BASELINE configs[3]'s synthetic VecEnv obs_dim=64 act_dim=8, 4096 envs/GPU, net [128,128], fp32"),
+    # BASELINE configs[0] (helloworld/helloworld_PPO_single_file.py on Pendulum-v1, num_envs = 4: plumbing): the helloworld's hyper-parameters
+    # (:535-553: net_dims [64, 32], gamma 0.97, repeat_times 16; Config defaults horizon_len 2048, batch_size 128 => 256 minibatches) on the
+    # GPU-resident Pendulum with FOUR envs.  Launch-bound by construction (one 16-env rollout workgroup, two minibatch workgroups): the line
+    # documents what the plumbing case costs on a GPU; `tests/test_compat.py::test_config0_helloworld_shaped_pendulum_run_with_four_envs`
+    "c1": dict(metric="env_steps_per_sec_ppo_pendulum_4envs_helloworld_shape", env="pendulum", N=4, S=3, A=1, H=2048, B=128, update_times=256,
+               net_dims=[64, 32], hyper=dict(gamma=0.97),
+               workload="BASELINE configs[0]: helloworld_PPO_single_file.py's Pendulum hyper-parameters (net [64,32], gamma 0.97, repeat_times 16, "
+                        "horizon 2048, batch 128 => 256 minibatches) on the GPU-resident Pendulum-v1 with num_envs = 4 (plumbing; the reference runs it on CPU torch)"),
     # not a measurement: the REHEARSAL shape of the N > 1 code path (tests/test_bench_gpu.py runs `--gpus 8` with eight ranks SHARING the one
     # GPU of the test box over gloo: barrier / max-over-ranks timing, route probe + self-test + selection, the exchange inside the loop,
     # the all-reduce micro-benchmark, per-rank times) -- small enough that eight ranks' kernels and their exchange workgroups fit one device
@@ -524,7 +532,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--eager-logs", action="store_true", help="read update_net's logged objectives at once (one host sync per iteration with the GPU "
                                                               "idle behind it) instead of one rollout late, as train_agent does by default")
-    ap.add_argument("--config", choices=["c4", "c2", "c3", "c5", "cw", "cd", "cr"], default="c4",
+    ap.add_argument("--config", choices=["c4", "c1", "c2", "c3", "c5", "cw", "cd", "cr"], default="c4",
                     help="BASELINE configuration: c4 = configs[3] (the metric; default), c2 = Pendulum 4096 envs, "
                          "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs, cw = the reference demo's (256,128) network, "
                          "cd = the reference's default horizon / batch shape (2048 x 4096 rollout, 128 minibatches of 128)")
@@ -852,7 +860,7 @@ def main():
     if world == 1 and not opt.no_cpu_baseline:
         log(f"cpu baseline ({usable_cores()} usable cores of {os.cpu_count()})")
         # (cd: one CPU iteration is 2048 x 4096 env steps + a value pre-pass over 8.4 M rows, ~20 s on 16 cores: warm-up + 1)
-        line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else 1 if opt.config == "cd" else max(2, opt.cpu_iters // 4),
+        line["cpu_baseline"] = cpu_baseline_subprocess(opt.cpu_iters if opt.config == "c4" else 1 if opt.config in ("cd", "c1") else max(2, opt.cpu_iters // 4),
                                                        opt.config, timeout_s=600 if opt.config == "cd" else 300)
     log("done")
     emit(line)
