@@ -748,6 +748,11 @@ def main():
                  "slab_reduce_us": round(span_red_us, 2) if span_red_us else None, "clip_adam_us": round(span_adam_us, 2) if span_adam_us else None,
                  "boundaries_and_rest_per_minibatch_us": (round((update_ms - k6_ms) / UPDATE_TIMES * 1e3 - span_red_us - span_adam_us, 2)
                                                           if span_red_us and span_adam_us else None),
+                 # what the update loop leaves for a minibatch-kernel launch AND its boundaries: update_net / update_times - the tail's spans.
+                 # avg_launch_us above it (boundaries_and_rest < 0) means the SAMPLED launches ran longer than the loop's mean launch on this
+                 # box (seen on the pool's slow boxes, where a launch that leaves records is ~9 us slower than one that does not)
+                 "k6_us_upper_bound_by_difference": (round(update_ms / UPDATE_TIMES * 1e3 - span_red_us - span_adam_us, 2)
+                                                     if span_red_us and span_adam_us else None),
                  "explore_env_ms_each": t_explore.each_ms(), "update_net_ms_each": t_update.each_ms(),
                  "consistent": bool(k6_ms <= update_ms and explore_ms + update_ms <= step_ms * 1.01),
                  "note": "HIP-event brackets around agent.explore_env / agent.update_net (means over the timed region); k6_ms = update_times x "
@@ -755,6 +760,9 @@ def main():
                          "index draw, log fold, amortised over the minibatches); consistent = the parts fit into the step"}
     if not breakdown["consistent"]:
         log(f"WARNING: timing parts do not fit into the step: {breakdown}")
+    if (breakdown["boundaries_and_rest_per_minibatch_us"] or 0.0) < 0.0:
+        log(f"WARNING: the sampled minibatch-kernel launches ({ppo_s * 1e6:.1f} us) ran longer than the update loop leaves for a launch "
+            f"({breakdown['k6_us_upper_bound_by_difference']} us incl. its boundaries): on this box the sampled launches are not representative")
     line = {
         "metric": cfg["metric"], "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
@@ -791,6 +799,10 @@ def main():
                                    "shader_mhz": round(k6_clocks_br["shader_mhz"], 1) if k6_clocks_br["shader_mhz"] else None,
                                    "phase_cycles": {k: round(v) for k, v in k6_clocks_br["phase_cycles"].items()} or None},
                      "event_bracket_us": round(k6_event_s * 1e6, 2), "event_bracket_null_us": round(null_bracket_us, 2),
+                     # where the kernel's workgroups run (include/erl_hip.h erl_ppo_wg_map_info): the device's first full-chip launch
+                     # measured both maps (us_map0 / us_map1, back to back) and kept one -- map 1 on the boxes where two code paths
+                     # per instruction cache cost 7-9 us per launch (DESIGN.md "K6 in round 5"), map 0 elsewhere
+                     "workgroup_map": _hip.ppo_wg_map_info(),
                      "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src,
                      # this box against the box the committed rocprofv3 summary was collected on (same sources): avg_launch_us / kernel_us_rocprof
                      "box_ratio": box_ratio,

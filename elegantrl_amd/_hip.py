@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import functools
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 from typing import Optional
 
 import torch as th
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "erl_ppo_num_slabs": (c_int, [c_int64]),
     "erl_ppo_set_arith": (c_int, [c_int]),
     "erl_ppo_arith_in_use": (c_int, [c_int, c_int, c_int, c_int]),
+    "erl_ppo_wg_map_info": (c_int, [c_int, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, c_int, _P, c_int, _P]),
     "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),
@@ -346,7 +347,21 @@ def k6_wg_summary(recs):
             "late_starters": sorted(({"wg": r["wg"], "start_us": round(r["start_us"], 1), "dur_us": round(r["dur_us"], 1), "xcc": r["xcc"], "se": r["se"],
                                       "cu": r["cu"]} for r in recs if r["start_us"] > 5.0), key=lambda x: -x["start_us"])[:12],
             "dur_us_mean_by_xcc": {str(k): round(sum(v) / len(v), 2) for k, v in sorted(per_xcc.items())},
-            "workgroups_by_xcc": {str(k): len(v) for k, v in sorted(per_xcc.items())}}
+            "workgroups_by_xcc": {str(k): len(v) for k, v in sorted(per_xcc.items())},
+            # every workgroup: [index (actor's first), xcc, se, sh, cu, duration in 0.1 us] -- CU pairs share an instruction cache
+            "table": [[r["wg"], r["xcc"], r["se"], r["sh"], r["cu"], int(round(r["dur_us"] * 10))] for r in recs]}
+
+
+def ppo_wg_map_info(device: int = None) -> dict:
+    """the minibatch kernel's workgroup map on `device` (default: the current one): {'map': 0 | 1 | None (not decided yet), 'forced': the
+    ERL_K6_WG_MAP override or None, 'us_map0', 'us_map1': the per-launch times the device's one-off measurement saw (None: never measured)}"""
+    import torch as th
+    dev = th.cuda.current_device() if device is None else int(device)
+    m, u0, u1 = c_int(-1), c_double(0), c_double(0)
+    check(lib().erl_ppo_wg_map_info(dev, ctypes.byref(m), ctypes.byref(u0), ctypes.byref(u1)), "erl_ppo_wg_map_info")
+    env = os.environ.get("ERL_K6_WG_MAP", "")
+    return {"map": None if m.value < 0 else m.value, "forced": int(env) if env in ("0", "1") else None,
+            "us_map0": round(u0.value, 2) if u0.value else None, "us_map1": round(u1.value, 2) if u1.value else None}
 
 
 def k6_null_bracket_us(reps: int = 200) -> float:

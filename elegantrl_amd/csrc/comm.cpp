@@ -234,7 +234,8 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
         float *g = grads + (size_t)k * stride;
         int rc = erl_ppo_step_images_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,
                                          unmasks, logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip,
-                                         lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, im, adv_stats, stream);
+                                         lambda_entropy, 1.0f / (float)B, objective, slabs, n_slabs, im, adv_stats,
+                                         k + 1 < update_times ? ids + (size_t)(k + 1) * B : nullptr, stream);
         if (rc) return rc;
         if (tail) {
             rc = (tail == 2 ? erl_reduce_clip_adam_grid_f32 : erl_reduce_clip_adam_f32)(slabs, n_slabs, stride, g, flat_params, exp_avg, exp_avg_sq,

@@ -24,6 +24,10 @@ struct Ppo2Args {
     const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
     const unsigned char *w1img[2];   // ... and W1 images (columns padded to 32 / 64); both or neither
     unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): this launch's records, kSpanWords u64 per workgroup (see span_enter); nullptr = off
+    const int64_t *next_ids;   // the NEXT minibatch's ids (update loops; nullptr: none / unknown): -DERL_K6_EXP & 4 lets the critic's workgroups,
+                               // which finish ~5k cycles before the actor's, pull that minibatch's rows towards their XCD's L2
+    int exp_net;          // -DERL_K6_EXP & 16 builds only (diagnostics): 0 = every workgroup runs the ACTOR's code path, 1 = the critic's, else by blockIdx.y
+    int wg_map;           // ppo_step_s3_kernel's workgroup -> (network, slab) map: 0 = (blockIdx.y, blockIdx.x); 1 = by XCD (k6_wg_map below)
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -53,6 +57,18 @@ __device__ __forceinline__ void slab_store(float v, float *p)
     asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
 #endif
 }
+
+// the same store under a named policy (A/B builds, -DERL_K6_EXP: the LAST weight-gradient pass by plain stores -- the kernel ends in ~5k
+// cycles of write-through drain; what is written last could retire at the L2 and leave with the kernel-end write-back instead)
+template <int POLICY>
+__device__ __forceinline__ void slab_store_as(float v, float *p)
+{
+    if (POLICY == 1) *p = v;
+    else slab_store(v, p);
+}
+#ifndef ERL_K6_EXP
+#define ERL_K6_EXP 0
+#endif
 
 constexpr int PB = 128;        // samples per workgroup
 // leading dimension of the staged feature-major tiles T[feature][sample]: 16-byte aligned rows, consecutive rows 16
@@ -86,6 +102,26 @@ __device__ __forceinline__ float adv_normalized(float adv, const AdvNorm &n)
 {
 #pragma clang fp contract(off)
     return n.on ? (adv - n.mean) / n.denom : adv;
+}
+
+// which (network, slab) a workgroup of the (n_slabs, 2) grid works on.  Workgroups go to the 8 XCDs round-robin by their linear id
+// (MI355X_MICROARCH.md; round 5's per-workgroup records: XCC_ID == linear id % 8 on every box sampled), so map 0 -- network = blockIdx.y
+// -- puts 16 actor and 16 critic workgroups on every XCD, 4 + 4 on every shader array: each instruction cache sees BOTH networks' code
+// paths (2 x 55 KB against 64 KB).  On most boxes that costs nothing; on ~1 box in 4 the same launch takes 55 us instead of 36, and on
+// those boxes a launch whose workgroups all run ONE network's path runs at the fast boxes' speed (DESIGN.md "K6 in round 5").  Map 1:
+// XCDs 0-3 run the actor's workgroups, XCDs 4-7 the critic's -- linear id L: network = (L % 8) / 4, slab = 4 * (L / 8) + L % 4 -- so an
+// instruction cache holds one path; the tail of a grid whose slab count is not a multiple of 4 falls back to halves.
+struct K6Wg {
+    bool actor;
+    int slab;
+};
+__device__ __forceinline__ K6Wg k6_wg_map(const Ppo2Args &g)
+{
+    if (g.wg_map == 0) return K6Wg{blockIdx.y == 0, (int)blockIdx.x};
+    const int n = (int)gridDim.x, L = (int)(blockIdx.x + gridDim.x * blockIdx.y), full = n & ~3;
+    if (L < 2 * full) return K6Wg{(L & 7) < 4, 4 * (L >> 3) + (L & 3)};
+    const int r = n - full, l = L - 2 * full;                 // 2 r workgroups left for slabs full .. n - 1
+    return K6Wg{l < r, full + (l < r ? l : l - r)};
 }
 
 // entry / exit of a workgroup on the device's constant-rate clock (sampled launches only).  Every workgroup leaves ONE record of

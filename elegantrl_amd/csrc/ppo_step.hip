@@ -451,6 +451,20 @@ int k6_form()     // 0 = automatic, 8 = always the 8-wave 16x16x4 kernel (A/B me
     static const int form = [] { const char *e = getenv("ERL_K6_FORM"); return e ? atoi(e) : 0; }();
     return form;
 }
+// the minibatch kernel's workgroup map (ppo_step.h, k6_wg_map).  ERL_K6_WG_MAP=0 / 1 (read per launch: A/B runs flip it inside one process)
+// forces a map; otherwise the FIRST full-chip launch of the split-arithmetic kernel on a device measures both (k6_tune_wg_map below) and the
+// device keeps the faster one: map 1 costs ~1.2 us of 36 on most boxes of the pool and saves 7-9 us of 47-55 on the rest.
+constexpr int kWgMapDevices = 64;
+struct WgMapChoice {
+    int map = -1;                 // -1: not measured yet
+    double us[2] = {0.0, 0.0};    // per launch, back to back, each map (0 when the map was never measured)
+};
+WgMapChoice g_wg_map[kWgMapDevices];
+int k6_wg_map_env()
+{
+    const char *e = getenv("ERL_K6_WG_MAP");
+    return e && (*e == '0' || *e == '1') ? *e - '0' : -1;
+}
 }  // namespace
 
 extern "C" int erl_ppo_set_arith(int arith)
@@ -482,13 +496,64 @@ extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
 
 extern "C" int erl_ppo_num_slabs(int64_t B) { return B >= 1 && B < (1LL << 37) ? (int)erl_cdiv(B, PB) : -1; }
 
+// Which workgroup map this launch runs under.  Not forced and not measured yet on this device: launch the kernel with the CALL'S OWN
+// arguments under both maps, alternating (1 + 4 launches per leg, 2 legs per map, HIP events on the call's stream; the kernel writes
+// nothing but the gradient slabs, which the real launch that follows rewrites) and keep map 1 when it is at least 3 % faster.  Only a
+// launch that fills the chip (>= 256 workgroups) decides; a capturing stream or a failed event leaves the decision to a later call.
+static int k6_wg_map_for_launch(Ppo2Args g, int n_slabs, bool vec, bool pre, hipStream_t st)
+{
+    const int forced = k6_wg_map_env();
+    if (forced >= 0) return forced;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kWgMapDevices) return 0;
+    WgMapChoice &c = g_wg_map[dev];
+    if (c.map >= 0) return c.map;
+    if (2 * n_slabs < 256) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    constexpr int kLegs = 2, kReps = 4;
+    hipEvent_t ev[2 * kLegs][2] = {};
+    bool ok = true;
+    for (auto &e : ev) ok = ok && hipEventCreate(&e[0]) == hipSuccess && hipEventCreate(&e[1]) == hipSuccess;
+    g.span = nullptr;
+    for (int leg = 0; ok && leg < 2 * kLegs; ++leg) {
+        g.wg_map = leg & 1;
+        for (int k = 0; ok && k <= kReps; ++k) {
+            if (k == 1) ok = hipEventRecord(ev[leg][0], st) == hipSuccess;
+            ok = ok && (pre ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st)) == ERL_OK;
+        }
+        ok = ok && hipEventRecord(ev[leg][1], st) == hipSuccess;
+    }
+    double us[2] = {0.0, 0.0};
+    for (int leg = 0; ok && leg < 2 * kLegs; ++leg) {
+        float ms = 0.f;
+        ok = hipEventSynchronize(ev[leg][1]) == hipSuccess && hipEventElapsedTime(&ms, ev[leg][0], ev[leg][1]) == hipSuccess;
+        us[leg & 1] += (double)ms * 1e3 / (kLegs * kReps);
+    }
+    for (auto &e : ev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
+    if (!ok) { (void)hipGetLastError(); return 0; }
+    c.us[0] = us[0]; c.us[1] = us[1];
+    c.map = us[1] < 0.97 * us[0] ? 1 : 0;
+    return c.map;
+}
+
+extern "C" int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map1)
+{
+    ERL_REQUIRE(device >= 0 && device < kWgMapDevices, "erl_ppo_wg_map_info: device %d", device);
+    const int forced = k6_wg_map_env();
+    if (map) *map = forced >= 0 ? forced : g_wg_map[device].map;
+    if (us_map0) *us_map0 = g_wg_map[device].us[0];
+    if (us_map1) *us_map1 = g_wg_map[device].us[1];
+    return ERL_OK;
+}
+
 // erl_ppo_step_f32 with the pre-split W2 images of the split-arithmetic kernel (s3_image.h; nullptr: none)
 int erl_ppo_step_images_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
                             const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
                             const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                             const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
-                            const double *adv_stats, void *stream)
+                            const double *adv_stats, const int64_t *next_ids, void *stream)
 {
     const int arith_call = (objective >> 8) & 3;       // ERL_PPO_MODE(objective, arith): the call's own arithmetic (0: process default)
     objective &= 0xff;
@@ -519,6 +584,9 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     g.Pc = Dims{S, h1, h2, 1}.count(false);
     g.stride = erl_ppo_slab_stride(S, h1, h2, A);
     g.adv_stats = adv_stats;
+    g.next_ids = next_ids;
+    g.wg_map = 0;
+    g.exp_net = [] { const char *e = getenv("ERL_K6_ONLY_NET"); return e ? atoi(e) : -1; }();      // (diagnostic builds read it)
     g.w2img[0] = images ? images->net[0].img : nullptr;
     g.w2img[1] = images ? images->net[1].img : nullptr;
     g.w1img[0] = images ? images->net[0].img1 : nullptr;
@@ -531,13 +599,16 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                      al(cri_avg) && al(cri_std);
     hipStream_t st = (hipStream_t)stream;
     const int ns = (S + 15) / 16;
+    const bool split = erl_ppo_arith_for_call(S, h1, h2, A, arith_call) == ERL_PPO_ARITH_SPLIT;
+    const bool pre = g.w2img[0] && g.w2img[1] && g.w1img[0] && g.w1img[1];
+    g.span = nullptr;
+    if (split) g.wg_map = k6_wg_map_for_launch(g, n_slabs, vec, pre, st);       // (the first full-chip launch on a device measures both maps)
     g.span = erl_k6_timing_begin(st, n_slabs);
     int rc;
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else
     // the fp32 32x32x2 one), 8 = always the 8-wave 16x16x4 kernel
     const int form = k6_form();
-    if (erl_ppo_arith_for_call(S, h1, h2, A, arith_call) == ERL_PPO_ARITH_SPLIT)
-        rc = (g.w2img[0] && g.w2img[1] && g.w1img[0] && g.w1img[1]) ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st);
+    if (split) rc = pre ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st);
     else if (form != 8 && erl_ppo_w4_supported(S, h1, h2, A)) rc = erl_ppo_w4_launch(g, n_slabs, vec, st);   // configs 2 / 4 / 5
     else if (vec && ns == 4 && h1 == 128 && h2 == 128) rc = launch<4, 8, 8, true>(g, n_slabs, st);
     else if (vec) rc = launch<0, 0, 0, true>(g, n_slabs, st);
@@ -554,5 +625,5 @@ extern "C" int erl_ppo_step_f32(const float *actor_params, const float *critic_p
 {
     return erl_ppo_step_images_f32(actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions, unmasks,
                                    logprobs, advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy, inv_batch, objective, slabs,
-                                   n_slabs, nullptr, nullptr, stream);
+                                   n_slabs, nullptr, nullptr, nullptr, stream);
 }

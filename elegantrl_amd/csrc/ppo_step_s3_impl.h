@@ -26,6 +26,7 @@
 #pragma once
 #include "ppo_step_w4_impl.h"
 #include "split_bf16.h"
+#include <type_traits>
 
 namespace {
 
@@ -399,7 +400,7 @@ __device__ __forceinline__ void grad_bias(const Parts (&A)[8], float *__restrict
 }
 
 // dW tiles (it, jt0 + CS k) = A . B^T, B read from the sample-major image SB (CPB chunks per part) one k-step ahead
-template <int CPB, int NBW, int CS>
+template <int CPB, int NBW, int CS, int POLICY = 0, int POLICY_LAST = POLICY>
 __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, int it, int jc, int jt_store0, float *__restrict__ dW, int ldw,
                                            int cols_real, int lane)
 {
@@ -407,12 +408,12 @@ __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, in
     const int l31 = lane & 31, hi = lane >> 5;
     u32x2 rq[2][6];
     tb.issue(jc, 0, rq[0]);
-    auto store = [&](const f32x16 &t, int k) {
+    auto store = [&](const f32x16 &t, int k, auto pol) {
         const int i = 32 * (jt_store0 + jc + CS * k) + l31;
         if (i < cols_real) {
             float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) slab_store(t[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
+            for (int r = 0; r < 16; ++r) slab_store_as<decltype(pol)::value>(t[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
         }
     };
     f32x16 done;
@@ -431,13 +432,13 @@ __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, in
             __builtin_amdgcn_sched_barrier(0);
             // a finished tile is stored behind the NEXT tile's first k-step: its last MFMA has long retired, no wait at the seam
             if (ks == 0 && k > 0) {
-                store(done, k - 1);
+                store(done, k - 1, std::integral_constant<int, POLICY>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         done = acc;
     }
-    store(done, NBW - 1);
+    store(done, NBW - 1, std::integral_constant<int, POLICY_LAST>{});
 }
 
 // LDS pool (bytes): [IMG2: W2 image, later SA][IMG1: W1 image, later SB][RW3: W3 copy fp32, later RC dY^T][biases][norm][s_part][s_red]
@@ -453,7 +454,7 @@ static_assert(kS3LdsBytes <= 160 * 1024, "LDS budget");
 // PRE: the W2 image comes ready from memory (g.w2img: built by the update loop, refreshed by clip + Adam) by LDS-DMA under the
 // first layer; otherwise every workgroup splits W2 itself (stand-alone calls of erl_ppo_step_f32)
 template <bool ACTOR, int KXP, int N1, int N2, bool VEC, bool PRE>     // KXP: input tiles of 32 (1: S <= 32, 2: S <= 64); 0: S <= 8
-__device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanStamps &sps)
+__device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanStamps &sps, const int slab_ix)
 {
     constexpr bool TINY = KXP == 0;
     constexpr int KX = TINY ? 1 : KXP;
@@ -480,7 +481,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     PROF(0);
     // ---- prologue, trip 1: the sample id, the weights, the biases, the normalisation constants
     const int col = 32 * wave + m;                         // sample slot inside the workgroup
-    const int64_t bidx = (int64_t)blockIdx.x * PB + col;
+    const int64_t bidx = (int64_t)slab_ix * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
     const AdvNorm advn = adv_norm_consts(ACTOR ? g.adv_stats : nullptr);   // (under the id's round trip; scalar registers)
@@ -836,7 +837,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     SPAN_STAMP(sps, 4);                                              // phase 3: output layer, objective, backward (dZ2, dZ1)
     PROF(8);
 
-    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
+    float *slab = g.slabs + (size_t)slab_ix * g.stride + (ACTOR ? 0 : g.Pa);
     float *RC = RW3;
     // ---- layer 1: dW1 = dZ1^T . X, db1
     stage_s3<2 * N1, CP2, 0>(SA, dZ1p, col, hi);
@@ -929,12 +930,12 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
         const int it = wave % N2, jc = wave / N2;
         Parts A[8];
         grad_a_load<CPH2>(SA, it, A, lane);
-        if (jc < TPP) grad_tiles<CPB2, NBW, CS>(A, SB, it, jc, 0, slab + d.oW2(), h1, h1, lane);
+        if (jc < TPP) grad_tiles<CPB2, NBW, CS, (ERL_K6_EXP & 2) ? 1 : 0>(A, SB, it, jc, 0, slab + d.oW2(), h1, h1, lane);
         if (NH1 == 2) {
             lds_barrier();                                           // (7) first half of H1 consumed
             stage_s3<KSH, CPB2, (NH1 == 2 ? KSH : 0)>(SB, H1p, col, hi);
             lds_barrier();                                           // (8)
-            if (jc < TPP) grad_tiles<CPB2, NBW, CS>(A, SB, it, jc, TPP, slab + d.oW2(), h1, h1, lane);
+            if (jc < TPP) grad_tiles<CPB2, NBW, CS, (ERL_K6_EXP & 3) ? 1 : 0, (ERL_K6_EXP & 11) ? 1 : 0>(A, SB, it, jc, TPP, slab + d.oW2(), h1, h1, lane);
         }
         if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
     }
@@ -944,7 +945,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     const float t0 = block_sum(loss0, s_red);
     const float t1 = block_sum(loss1, s_red);
     if (tid == 0) {
-        float *logs = g.slabs + (size_t)blockIdx.x * g.stride + g.Pa + g.Pc;
+        float *logs = g.slabs + (size_t)slab_ix * g.stride + g.Pa + g.Pc;
         if (ACTOR) {
             float ent = 0.f;
             for (int a = 0; a < OUT; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));
@@ -956,6 +957,20 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
             for (int64_t e = g.Pa + g.Pc + 4; e < g.stride; ++e) logs[e - (g.Pa + g.Pc)] = 0.f;
         }
     }
+#if ERL_K6_EXP & 4
+    // (experiment) the critic's workgroups finish ~5k cycles before the actor's: pull the NEXT minibatch's rows of this slab towards this
+    // XCD's L2 (the actor's workgroup of the same slab index sits on the same XCD: 128 % 8 == 0), where the next launch's prologue finds them
+    if (!ACTOR && g.next_ids && tid < PB) {
+        const int64_t nb = (int64_t)slab_ix * PB + tid;
+        const int64_t nid = g.next_ids[nb < g.B ? nb : 0];
+        const int64_t nn = nid / g.H, nt = nid - nn * g.H, nrow = nt * g.N + nn;
+        const float *xr = g.states + nrow * S;
+        float sink = 0.f;
+        for (int c = 0; c < S; c += 32) sink += xr[c] * 0.f;                                    // one load per 128-byte line of the row
+        sink += g.actions[nrow * g.A] + g.logprobs[nrow] + g.advantages[nrow] + g.reward_sums[nrow] + (float)g.unmasks[nrow];
+        asm volatile("" ::"v"(sink));
+    }
+#endif
 }
 
 template <int KX, int N1, int N2, bool VEC, bool PRE>
@@ -964,9 +979,16 @@ __global__ __launch_bounds__(QNT) void ppo_step_s3_kernel(Ppo2Args g)
     extern __shared__ __attribute__((aligned(16))) u8 smem_s3[];
     const SpanT t_span = span_enter(g);
     SpanStamps sps{reinterpret_cast<uint32_t *>(smem_s3 + kS3LdsBytes - 32)};
-    if (blockIdx.y == 0) ppo_block_s3<true, KX, N1, N2, VEC, PRE>(g, smem_s3, sps);
-    else ppo_block_s3<false, KX, N1, N2, VEC, PRE>(g, smem_s3, sps);
-    span_exit(g, t_span, blockIdx.y == 0 ? &sps : nullptr);
+    const K6Wg wg = k6_wg_map(g);
+#if ERL_K6_EXP & 16
+    // (diagnostics) every workgroup on ONE network's code path: do two code paths of 55 KB each on a 64 KB instruction cache matter?
+    const bool as_actor = g.exp_net == 0 || (g.exp_net != 1 && wg.actor);
+#else
+    const bool as_actor = wg.actor;
+#endif
+    if (as_actor) ppo_block_s3<true, KX, N1, N2, VEC, PRE>(g, smem_s3, sps, wg.slab);
+    else ppo_block_s3<false, KX, N1, N2, VEC, PRE>(g, smem_s3, sps, wg.slab);
+    span_exit(g, t_span, as_actor ? &sps : nullptr);
 }
 
 template <int KX, int N1, int N2, bool VEC, bool PRE>

@@ -99,6 +99,8 @@ int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const
     g.w2img[0] = images->net[0].img; g.w2img[1] = images->net[1].img;
     g.w1img[0] = images->net[0].img1; g.w1img[1] = images->net[1].img1;
     g.prof = g_wd_prof;
+    g.next_ids = nullptr;
+    g.exp_net = -1; g.wg_map = 0;
     g.prof_block = g_wd_prof_block;
     a.w3img[0] = a.w3img[1] = nullptr;
     a.h3 = 0;
@@ -222,6 +224,8 @@ int erl_ppo_wd3_step(const float *actor_params, const float *critic_params, cons
     g.w2img[0] = im.w2[0]; g.w2img[1] = im.w2[1];
     g.w1img[0] = im.w1[0]; g.w1img[1] = im.w1[1];
     g.prof = g_wd_prof;
+    g.next_ids = nullptr;
+    g.exp_net = -1; g.wg_map = 0;
     g.prof_block = g_wd_prof_block;
     a.w3img[0] = im.w3[0]; a.w3img[1] = im.w3[1];
     a.h3 = h3;

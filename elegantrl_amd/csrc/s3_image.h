@@ -62,7 +62,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                             const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
-                            const double *adv_stats, void *stream);
+                            const double *adv_stats, const int64_t *next_ids, void *stream);
 // the two-launch tail's work in ONE launch (grad_tail.hip, tail_fused_kernel; single process) and whether a row of `stride` floats can take it
 extern "C" int erl_tail_fused_ok(int64_t stride);
 int erl_tail_fused_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len, int n_groups,

@@ -593,6 +593,67 @@ def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
         assert es <= max(2.0 * e32, 1e-6), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
 
 
+@pytest.mark.parametrize("B", [1, 200, 128 * 4, 128 * 5 + 17, 128 * 7, 128 * 11 + 1, 16384])
+def test_ppo_step_workgroup_maps_agree(ops, dev, B, monkeypatch):
+    """the split-arithmetic minibatch kernel under both workgroup maps (csrc/ppo_step.h k6_wg_map: network = blockIdx.y against one
+    network per XCD, with the halves fallback for a slab count that is no multiple of 4): which workgroup computes a slab must not show in
+    the slab -- every slab bit for bit the same, none left unwritten."""
+    S, h1, h2, A, H, N = 64, 128, 128, 8, 9, 2000
+    rng = np.random.default_rng(B)
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = buf_ids[:6], buf_ids[6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    n_slabs, stride = ops.ppo_num_slabs(B), ops.ppo_slab_stride(S, h1, h2, A)
+    got = {}
+    prev = ops.ppo_set_arith("split")
+    try:
+        for wg_map in ("0", "1"):
+            monkeypatch.setenv("ERL_K6_WG_MAP", wg_map)           # read per launch
+            slabs = th.full((n_slabs, stride), float("nan"), device=dev)
+            ops.ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                         cu(critic.state_avg, dev), cu(critic.state_std, dev), S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev),
+                         0.25, 0.001, 1.0 / B, slabs, n_slabs)
+            got[wg_map] = slabs.cpu().numpy()
+            assert np.isfinite(got[wg_map]).all(), f"map {wg_map}: a slab slot was left unwritten"
+            assert _hip.ppo_wg_map_info()["forced"] == int(wg_map) and _hip.ppo_wg_map_info()["map"] == int(wg_map)
+    finally:
+        ops.ppo_set_arith(prev)
+    assert np.array_equal(got["0"].view(np.uint32), got["1"].view(np.uint32))
+
+
+def test_ppo_step_workgroup_map_is_measured_once(ops, dev, monkeypatch):
+    """no override: the first full-chip launch on a device measures both maps and the device keeps one (include/erl_hip.h,
+    erl_ppo_wg_map_info); the launch that did the measuring leaves the same slabs as a forced-map launch"""
+    monkeypatch.delenv("ERL_K6_WG_MAP", raising=False)
+    S, h1, h2, A, H, N, B = 64, 128, 128, 8, 9, 2000, 16384
+    rng = np.random.default_rng(5)
+    buf_ids = ppo_case(rng, H, N, S, A, B)
+    buf, ids = buf_ids[:6], buf_ids[6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    n_slabs, stride = ops.ppo_num_slabs(B), ops.ppo_slab_stride(S, h1, h2, A)
+    args = lambda slabs: (cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
+                          cu(critic.state_avg, dev), cu(critic.state_std, dev), S, h1, h2, A, *[cu(x, dev) for x in buf], cu(ids, dev),
+                          0.25, 0.001, 1.0 / B, slabs, n_slabs)
+    prev = ops.ppo_set_arith("split")
+    try:
+        a = th.full((n_slabs, stride), float("nan"), device=dev)
+        ops.ppo_step(*args(a))
+        th.cuda.synchronize()
+        info = _hip.ppo_wg_map_info()
+        print("workgroup map on this box:", info)
+        assert info["forced"] is None and info["map"] in (0, 1)
+        assert info["us_map0"] and info["us_map1"] and 10.0 < info["us_map0"] < 500.0 and 10.0 < info["us_map1"] < 500.0
+        assert info["map"] == (1 if info["us_map1"] < 0.97 * info["us_map0"] else 0)
+        monkeypatch.setenv("ERL_K6_WG_MAP", "0")
+        b = th.full((n_slabs, stride), float("nan"), device=dev)
+        ops.ppo_step(*args(b))
+        assert th.equal(a.view(th.int32), b.view(th.int32))
+        monkeypatch.delenv("ERL_K6_WG_MAP")
+        assert _hip.ppo_wg_map_info() == info                      # decided once
+    finally:
+        ops.ppo_set_arith(prev)
+
+
 def test_ppo_step_split_arith_at_benchmark_size(ops, dev):
     """BASELINE configs[3] at full size (4096 envs x 32 steps, minibatch 16384, obs 64, act 8, net [128,128]): the split-arithmetic
     kernel and the fp32-MFMA kernel on the same minibatch, both against the fp64 restatement -- 128 gradient slabs per network

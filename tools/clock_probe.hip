@@ -181,6 +181,56 @@ void run_k6like(int khz, int iters, int reps)
     CHECK(hipFree(sink));
 }
 
+// dependent-load latency by working-set size: ONE lane chases a random cycle through a buffer of 128-byte nodes -- 2 MiB sits in an XCD's
+// L2, 64 MiB in the memory-side cache (MALL) if the box has it working, 1 GiB is HBM.  The single-instruction bodies above agree on every
+// box of the pool; the minibatch kernel does not, and it is the one that lives on re-fetched weights, gathered rows and 110 KB of code.
+__global__ void chase(const unsigned *next, int hops, unsigned long long *out)
+{
+    unsigned i = 0;
+    for (int k = 0; k < 1000; ++k) i = next[(size_t)i * 32];          // warm the first lines
+    const unsigned long long w0 = wall_clock64();
+    for (int k = 0; k < hops; ++k) i = next[(size_t)i * 32];
+    const unsigned long long w1 = wall_clock64();
+    out[0] = w1 - w0;
+    out[1] = i;
+}
+
+void run_chase(int khz)
+{
+    const size_t sizes[3] = {(size_t)2 << 20, (size_t)64 << 20, (size_t)1 << 30};
+    const char *names[3] = {"2MiB", "64MiB", "1GiB"};
+    printf("\"dependent_load_ns\": {");
+    for (int s = 0; s < 3; ++s) {
+        const size_t nodes = sizes[s] / 128;
+        std::vector<unsigned> perm(nodes);
+        for (size_t i = 0; i < nodes; ++i) perm[i] = (unsigned)i;
+        unsigned long long x = 88172645463325252ull;
+        for (size_t i = nodes - 1; i > 0; --i) {                       // Sattolo: one cycle through all nodes
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            const size_t j = x % i;
+            std::swap(perm[i], perm[j]);
+        }
+        std::vector<unsigned> buf(nodes * 32, 0u);
+        for (size_t i = 0; i < nodes; ++i) buf[i * 32] = perm[i];
+        unsigned *d;
+        unsigned long long *o, h[2];
+        CHECK(hipMalloc(&d, sizes[s]));
+        CHECK(hipMalloc(&o, 16));
+        CHECK(hipMemcpy(d, buf.data(), sizes[s], hipMemcpyHostToDevice));
+        const int hops = 20000;
+        double best = 1e30;
+        for (int r = 0; r < 3; ++r) {
+            hipLaunchKernelGGL(chase, dim3(1), dim3(1), 0, 0, d, hops, o);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(h, o, 16, hipMemcpyDeviceToHost));
+            best = std::min(best, (double)h[0] / khz * 1e6 / hops);
+        }
+        printf("\"%s\": %.0f%s", names[s], best, s < 2 ? ", " : "}, ");
+        CHECK(hipFree(d));
+        CHECK(hipFree(o));
+    }
+}
+
 template <int KIND>
 void run(const char *name, int per_iter, int iters, int reps, int khz, bool last)
 {
@@ -223,6 +273,7 @@ int main()
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"wall_clock_khz\": %d, \"attr_clock_khz\": %d, \"attr_memory_clock_khz\": %d, ",
            prop.name, prop.gcnArchName, cus, khz, sclk, mclk);
     // ~100-200 us per launch, 24 launches each: long enough for the power manager to settle on the body's clock
+    run_chase(khz);
     run_k6like(khz, 120, 24);
     run<0>("mfma_bf16_32x32x16", 16, 400, 24, khz, false);
     run<1>("mfma_f32_32x32x2", 16, 200, 24, khz, false);

@@ -7,6 +7,13 @@ cd $GRAFT_REPO_ROOT
 export ERL_QUIET=1
 python tools/box_record.py > $O/box.json 2> $O/box.err
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep > $O/bench_c4.json 2> $O/bench_c4.err
+L=$GRAFT_REPO_ROOT/elegantrl_amd/lib
+if [ -f $L/liberl_hip_e16.so ]; then
+  for n in "" 0 1; do
+    if [ -z "$n" ]; then ERL_HIP_LIB=$L/liberl_hip_e16.so python tools/k6_only_net.py >> $O/k6_only_net.jsonl 2>/dev/null
+    else ERL_HIP_LIB=$L/liberl_hip_e16.so ERL_K6_ONLY_NET=$n python tools/k6_only_net.py >> $O/k6_only_net.jsonl 2>/dev/null; fi
+  done
+fi
 [ -n "$2" ] && eval "$2"
 python - <<PY
 import json
@@ -20,5 +27,9 @@ b = json.load(open("$O/box.json"))
 for k, v in b["k6_standalone"].items():
     ww = v.get("workgroups") or {}
     print("box", k, v.get("us_back_to_back_events"), v.get("us_span_unbracketed"), v.get("workgroup_us"), v.get("shader_mhz"), ww.get("dur_us"), ww.get("dur_us_mean_by_xcc"), ww.get("workgroups_in_a_second_round"))
-print(b["clock_probe"].get("k6_like_forward_mix"), b.get("hbm_copy_GBps"))
+print(b["clock_probe"].get("k6_like_forward_mix"), b["clock_probe"].get("dependent_load_ns"), b.get("hbm_copy_GBps"))
+import os
+if os.path.exists("$O/k6_only_net.jsonl"):
+    for ln in open("$O/k6_only_net.jsonl"):
+        r = json.loads(ln); print("only_net", r["only_net"], r["us_span"], r["workgroup_us"], r["shader_mhz"], r["dur_us"])
 PY
