@@ -524,8 +524,10 @@ def main():
     ap.add_argument("--no-gae-sweep", action="store_true")
     ap.add_argument("--no-smi", action="store_true", help="skip the rocm-smi / amd-smi snapshot after the timed region (`clocks.smi`)")
     ap.add_argument("--cpu-iters", type=int, default=12)   # ~10-15 s of host work on 16 cores
-    ap.add_argument("--k6-sample", type=int, default=16,
-                    help="bracket every n-th K6 launch with HIP events (0 = none): each bracket costs ~3 us of stream time")
+    ap.add_argument("--k6-sample", type=int, default=17,
+                    help="of every n K6 launches one sits in a HIP-event bracket and one more leaves its per-workgroup records without a bracket "
+                         "(0 = none); a period coprime with the update loop's length samples every position of the loop equally often -- with 16 "
+                         "and 40 launches per loop every fifth sample was the loop's FIRST launch, which finds the instruction caches cold")
     ap.add_argument("--repeats", type=int, default=5,
                     help="after the primary timed region, repeat it this many times and report min / median / max ms per step "
                          "(`extra`; box variance next to the one primary sample; 0 = off)")
@@ -636,6 +638,7 @@ def main():
     # the loop runs it (a bracket perturbs what it brackets: the bracketed group is reported next to it)
     k6_clocks, k6_clocks_br = _hip.k6_timing_clocks(False), _hip.k6_timing_clocks(True)
     k6_wgs = _hip.k6_wg_summary(_hip.k6_timing_last_records(False))      # where / when the last sampled launch's workgroups ran
+    k6_spans = _hip.k6_timing_spans(False)                                # (launch number since enable, span) of the unbracketed sampled launches
     smi = smi_snapshot() if rank == 0 and not opt.no_smi else None
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
@@ -709,6 +712,21 @@ def main():
     # completion overhead of a bracket in it; agrees with rocprofv3's kernel duration -- `kernel_us_rocprof`); fallback: the event
     # bracket minus the bracket of an empty launch
     ppo_s = k6_span_s if k6_span_s == k6_span_s else max(k6_event_s - null_bracket_us * 1e-6, 1e-9)
+    # where in the update loop a sampled launch sat: the loop's FIRST launch follows the rollout and the GAE scan and finds the instruction
+    # caches (and the XCDs' L2s) without the kernel's code -- +3 us on most boxes of the pool, +50 us on the ones with slow instruction
+    # fetch (DESIGN.md "K6 in round 5").  avg_launch_us weights the two groups as the loop does (1 : update_times - 1), whatever the
+    # sampling period made of them.
+    k6_first = [us for k, us in k6_spans if k % UPDATE_TIMES == 0]
+    k6_rest = [us for k, us in k6_spans if k % UPDATE_TIMES != 0]
+    k6_by_position = None
+    if k6_rest:
+        rest_us = sum(k6_rest) / len(k6_rest)
+        first_us = sum(k6_first) / len(k6_first) if k6_first else rest_us
+        k6_by_position = {"first_launch_of_a_loop_us": round(first_us, 2) if k6_first else None, "first_launches_sampled": len(k6_first),
+                          "other_launches_us": round(rest_us, 2), "other_launches_sampled": len(k6_rest),
+                          "unweighted_mean_us": round(ppo_s * 1e6, 2)}
+        if UPDATE_TIMES > 1:
+            ppo_s = (first_us + (UPDATE_TIMES - 1) * rest_us) / UPDATE_TIMES * 1e-6
     # which K6 kernel erl_ppo_step_f32 dispatches to: the one-wave-per-SIMD form for h1, h2 in {64, 128}, S <= 64, A <= 8
     k6_kernel = "ppo_step_w4_kernel" if (len(NET_DIMS) == 2 and all(d in (64, 128) for d in NET_DIMS) and STATE_DIM <= 64
                                          and ACTION_DIM <= 8) else "ppo_step2_kernel"
@@ -785,14 +803,16 @@ def main():
                      "frac_of_fp32_mfma_peak": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops,
                      "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": k6_clocks["launches"] or n_k6,
+                     "by_position_in_the_update_loop": k6_by_position,
                      "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel, one record per "
-                               f"workgroup), mean over the sampled launches of the timed region that carry NO event bracket (1 in {opt.k6_sample})"
+                               f"workgroup), over the sampled launches of the timed region that carry NO event bracket (1 in {opt.k6_sample}), the loop's "
+                               "first launch weighted 1 : update_times - 1 against the others"
                                if k6_clocks["launches"] else
                                "kernel span on the device clock, bracketed launches" if k6_span_s == k6_span_s else
                                "HIP-event bracket minus empty-launch bracket"),
                      # every opt.k6_sample-th launch also sits inside a HIP-event bracket: the bracket's own time, the SAME launches' in-kernel
-                     # span, and how much longer a bracketed launch runs than its unbracketed neighbours on this box (round 5's finding: the
-                     # bracket perturbs the kernel inside it by a box-dependent amount -- BENCH_r04's 53.4 us was this group)
+                     # span, and how much longer a bracketed launch runs than its unbracketed neighbours on this box (round 5: a bracket
+                     # does not perturb the kernel inside it -- the two groups agree to < 1 us on every box sampled)
                      "bracketed": {"launches": n_k6, "event_bracket_us": round(k6_event_s * 1e6, 2),
                                    "span_us": round(k6_span_br_s * 1e6, 2) if k6_span_br_s == k6_span_br_s else None,
                                    "span_minus_unbracketed_us": round((k6_span_br_s - k6_span_s) * 1e6, 2) if k6_span_br_s == k6_span_br_s else None,

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "erl_ppo_num_slabs": (c_int, [c_int64]),
     "erl_ppo_set_arith": (c_int, [c_int]),
     "erl_ppo_arith_in_use": (c_int, [c_int, c_int, c_int, c_int]),
+    "erl_k6_timing_spans": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), c_int]),
     "erl_ppo_wg_map_info": (c_int, [c_int, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, c_int, _P, c_int, _P]),
@@ -323,6 +324,13 @@ def k6_timing_last_records(bracketed: bool = False):
         recs.append({"wg": i, "start_us": (w0 - t0) / 100.0, "dur_us": (w1 - w0) / 100.0, "cycles": m1 - m0, "xcc": xcc,
                      "se": (hwid >> 13) & 0x7, "sh": (hwid >> 12) & 1, "cu": (hwid >> 8) & 0xf, "simd": (hwid >> 4) & 3})
     return recs
+
+
+def k6_timing_spans(bracketed: bool = False, max_launches: int = 65536):
+    """[(launch number since k6_timing_enable, span in microseconds)] of every sampled launch the last k6_timing_read2 drained"""
+    idx, us = (c_int64 * max_launches)(), (c_double * max_launches)()
+    n = lib().erl_k6_timing_spans(1 if bracketed else 0, idx, us, max_launches)
+    return [(int(idx[i]), float(us[i])) for i in range(n)]
 
 
 def k6_wg_summary(recs):

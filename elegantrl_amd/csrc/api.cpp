@@ -110,6 +110,7 @@ struct K6Launch {
     size_t off;          // first word of the launch's records in the pool
     int n_slabs;         // grid = (n_slabs, 2): workgroups [0, n_slabs) are the actor's
     bool bracketed;
+    long index;          // the launch's number since erl_k6_timing_enable
 };
 static std::vector<K6Launch> g_k6_launches;
 // of the last erl_k6_timing_read2, [0] over the sampled launches WITHOUT an event bracket around them, [1] over the bracketed ones: shader
@@ -120,6 +121,7 @@ struct K6Stats {
     int phase_wgs = 0, launches = 0;
 };
 static K6Stats g_k6_stats[2];
+static std::vector<std::pair<long, double>> g_k6_spans[2];      // of the last read: every sampled launch's (number since enable, span in us)
 static std::vector<unsigned long long> g_k6_last_records[2];    // raw per-workgroup records of the group's LAST sampled launch (diagnostics)
 
 static void k6_span_reset()
@@ -157,7 +159,7 @@ unsigned long long *erl_k6_timing_begin(hipStream_t stream, int n_slabs)
     }
     const size_t words = (size_t)kK6SpanWords * 2 * (size_t)(n_slabs > 0 ? n_slabs : 0);
     if (!g_k6_pool || !words || g_k6_pool_used + words > kK6PoolWords) return nullptr;
-    g_k6_launches.push_back(K6Launch{g_k6_pool_used, n_slabs, !g_k6_skip});
+    g_k6_launches.push_back(K6Launch{g_k6_pool_used, n_slabs, !g_k6_skip, g_k6_launch - 1});
     g_k6_pool_used += words;
     return g_k6_pool + g_k6_launches.back().off;
 }
@@ -211,6 +213,7 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
                 double wall = 0.0, mem = 0.0, wgs = 0.0, pwgs = 0.0, ph[kK6SpanPhases] = {}, sp = 0.0;
                 int m = 0;
                 g_k6_last_records[b].clear();
+                g_k6_spans[b].clear();
                 for (const K6Launch &L : g_k6_launches) {
                     if ((int)L.bracketed != b) continue;
                     g_k6_last_records[b].assign(h.begin() + L.off, h.begin() + L.off + (size_t)kK6SpanWords * 2 * L.n_slabs);
@@ -233,7 +236,11 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
                             pwgs += 1.0;
                         }
                     }
-                    if (hi > lo) { sp += (double)(hi - lo) / khz; ++m; }
+                    if (hi > lo) {
+                        sp += (double)(hi - lo) / khz;
+                        ++m;
+                        g_k6_spans[b].emplace_back(L.index, (double)(hi - lo) / khz * 1e3);
+                    }
                 }
                 K6Stats &st = g_k6_stats[b];
                 st.span_ms = sp;
@@ -282,6 +289,19 @@ extern "C" int erl_k6_timing_last_records(int bracketed, unsigned long long *out
     const auto &r = g_k6_last_records[bracketed ? 1 : 0];
     const int n = std::min((int)(r.size() / kK6SpanWords), max_workgroups);
     if (out && n > 0) memcpy(out, r.data(), (size_t)n * kK6SpanWords * sizeof(unsigned long long));
+    return n;
+}
+
+// every sampled launch of the group drained by the last erl_k6_timing_read2: its number since erl_k6_timing_enable (so a caller that
+// knows its loop's length knows where in the loop the launch sat) and its span; returns the number of launches copied
+extern "C" int erl_k6_timing_spans(int bracketed, long long *launch_index, double *span_us, int max_launches)
+{
+    const auto &v = g_k6_spans[bracketed ? 1 : 0];
+    const int n = std::min((int)v.size(), max_launches);
+    for (int i = 0; i < n; ++i) {
+        if (launch_index) launch_index[i] = v[i].first;
+        if (span_us) span_us[i] = v[i].second;
+    }
     return n;
 }
 

@@ -509,6 +509,7 @@ static int k6_wg_map_for_launch(Ppo2Args g, int n_slabs, bool vec, bool pre, hip
     WgMapChoice &c = g_wg_map[dev];
     if (c.map >= 0) return c.map;
     if (2 * n_slabs < 256) return 0;
+    if (getenv("ERL_K6_NO_TUNE")) return 0;            // (diagnostics: no measurement, map 0)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
     constexpr int kLegs = 2, kReps = 4;

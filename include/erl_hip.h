@@ -652,6 +652,10 @@ ERL_API int erl_k6_timing_null_bracket_us(void *stream, int reps, double *median
  * entry / exit on the shader clock, three words of phase stamps, HW_REG_HW_ID | HW_REG_XCC_ID << 32 = where the workgroup ran); actor
  * workgroups first.  Returns the number of workgroups copied (<= max_workgroups). */
 ERL_API int erl_k6_timing_last_records(int bracketed, unsigned long long *out, int max_workgroups);
+/* every sampled launch of the group the last erl_k6_timing_read2 drained: launch_index[i] = the launch's number since
+ * erl_k6_timing_enable (a caller that knows its update loop's length knows where in the loop the launch sat: the first launch of a loop
+ * finds the instruction caches cold), span_us[i] = its span.  Returns the number of launches copied (<= max_launches). */
+ERL_API int erl_k6_timing_spans(int bracketed, long long *launch_index, double *span_us, int max_launches);
 /* The same hook for the other kernels of the hot path (ABI 17): after erl_kernel_span_enable(n), every n-th launch of a tagged kernel
  * leaves one {entry, exit} record per workgroup on the device's constant-rate clock (plain stores; 2 M workgroup records between
  * enables); erl_kernel_span_read(tag) waits for the device and returns the summed first-workgroup-in to last-workgroup-out spans

@@ -1,7 +1,7 @@
 // What clock does THIS box give a kernel?  (round 5: the pool's boxes run the PPO minibatch kernel at different speeds; the chip
 // clocks to its power budget -- MI355X_MICROARCH.md, "DVFS give-back" -- so the question is asked of the hardware, per kind of work.)
 //
-//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/clock_probe tools/clock_probe.hip && tools/bin/clock_probe
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/clock_probe tools/clock_probe.hip -lhsa-runtime64 && tools/bin/clock_probe
 //
 // Every workgroup (one per CU, 4 waves = one per SIMD, like the minibatch kernel) runs a fixed instruction count of ONE kind of work
 // and stamps s_memtime (shader clock) and s_memrealtime (constant 100 MHz) around it; the ratio is the clock the body ran at, the
@@ -9,10 +9,13 @@
 // accumulators (the minibatch kernel's matrix instruction), fp32 MFMA 32x32x2, plain fp32 FMA, an MFMA + 5 VALU mix (the minibatch
 // kernel's forward layers), and LDS reads.  Output: one JSON line.
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -181,54 +184,107 @@ void run_k6like(int khz, int iters, int reps)
     CHECK(hipFree(sink));
 }
 
-// dependent-load latency by working-set size: ONE lane chases a random cycle through a buffer of 128-byte nodes -- 2 MiB sits in an XCD's
-// L2, 64 MiB in the memory-side cache (MALL) if the box has it working, 1 GiB is HBM.  The single-instruction bodies above agree on every
-// box of the pool; the minibatch kernel does not, and it is the one that lives on re-fetched weights, gathered rows and 110 KB of code.
-__global__ void chase(const unsigned *next, int hops, unsigned long long *out)
+// instruction fetch: a workgroup's waves walk 56 KB of straight-line VALU code (one dependent fp32 op per 4 bytes, ~4 cycles each: 56 KB
+// in ~27 us -- the minibatch kernel's rate: ~55 KB per network in ~33 us), one workgroup per CU (155 KB of LDS asked for), 256 workgroups.
+//   single     every workgroup walks block A
+//   dual_map0  workgroups with blockIdx.y == 0 walk block A, the others block B: both blocks on every XCD (the minibatch kernel's old map)
+//   dual_map1  linear id % 8 < 4 walks A, the rest B: one block per XCD (its map 1)
+//   single_112KB  every workgroup walks A, then B (twice the work: compare with 2 x single)
+// Instruction caches are 64 KB and shared by neighbouring CUs: a box where dual_map0 is slower than single / dual_map1 is a box that pays
+// for two code paths per instruction cache -- with no MFMA, no LDS traffic and no memory traffic in the picture.
+#define CODE_BLOCK(ins) asm volatile(".rept 14336\n" ins " %0, %0, %0\n.endr" : "+v"(x))
+template <int MODE>
+__global__ __launch_bounds__(256) void code_walk(float *sink, unsigned long long *rec)
 {
-    unsigned i = 0;
-    for (int k = 0; k < 1000; ++k) i = next[(size_t)i * 32];          // warm the first lines
+    extern __shared__ float lds_pad[];
+    float x = (float)threadIdx.x;
+    const int L = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+    const bool a = MODE == 0 ? true : MODE == 1 ? blockIdx.y == 0 : (L & 7) < 4;
     const unsigned long long w0 = wall_clock64();
-    for (int k = 0; k < hops; ++k) i = next[(size_t)i * 32];
+    if (MODE == 3) { CODE_BLOCK("v_add_f32"); CODE_BLOCK("v_mul_f32"); }      // every workgroup walks both: 112 KB through each instruction cache
+    else if (a) CODE_BLOCK("v_add_f32");
+    else CODE_BLOCK("v_mul_f32");
     const unsigned long long w1 = wall_clock64();
-    out[0] = w1 - w0;
-    out[1] = i;
+    if (threadIdx.x == 0) { rec[2 * L] = w0; rec[2 * L + 1] = w1; }
+    if (x == 12345.678f) { lds_pad[threadIdx.x] = x; sink[0] = lds_pad[0]; }
 }
 
-void run_chase(int khz)
+template <int MODE>
+void run_code_walk(const char *name, int khz, bool last)
 {
-    const size_t sizes[3] = {(size_t)2 << 20, (size_t)64 << 20, (size_t)1 << 30};
-    const char *names[3] = {"2MiB", "64MiB", "1GiB"};
-    printf("\"dependent_load_ns\": {");
-    for (int s = 0; s < 3; ++s) {
-        const size_t nodes = sizes[s] / 128;
-        std::vector<unsigned> perm(nodes);
-        for (size_t i = 0; i < nodes; ++i) perm[i] = (unsigned)i;
-        unsigned long long x = 88172645463325252ull;
-        for (size_t i = nodes - 1; i > 0; --i) {                       // Sattolo: one cycle through all nodes
-            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-            const size_t j = x % i;
-            std::swap(perm[i], perm[j]);
-        }
-        std::vector<unsigned> buf(nodes * 32, 0u);
-        for (size_t i = 0; i < nodes; ++i) buf[i * 32] = perm[i];
-        unsigned *d;
-        unsigned long long *o, h[2];
-        CHECK(hipMalloc(&d, sizes[s]));
-        CHECK(hipMalloc(&o, 16));
-        CHECK(hipMemcpy(d, buf.data(), sizes[s], hipMemcpyHostToDevice));
-        const int hops = 20000;
-        double best = 1e30;
-        for (int r = 0; r < 3; ++r) {
-            hipLaunchKernelGGL(chase, dim3(1), dim3(1), 0, 0, d, hops, o);
-            CHECK(hipDeviceSynchronize());
-            CHECK(hipMemcpy(h, o, 16, hipMemcpyDeviceToHost));
-            best = std::min(best, (double)h[0] / khz * 1e6 / hops);
-        }
-        printf("\"%s\": %.0f%s", names[s], best, s < 2 ? ", " : "}, ");
-        CHECK(hipFree(d));
-        CHECK(hipFree(o));
-    }
+    const int lds = 155 * 1024, grid = 128;
+    CHECK(hipFuncSetAttribute((const void *)code_walk<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    float *sink;
+    unsigned long long *rec;
+    CHECK(hipMalloc(&sink, 4));
+    CHECK(hipMalloc(&rec, 2 * 256 * sizeof(unsigned long long)));
+    std::vector<unsigned long long> h(512);
+    auto one = [&](double &span_us, double &wg_us) {
+        hipLaunchKernelGGL(code_walk<MODE>, dim3(grid, 2), dim3(256), lds, 0, sink, rec);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h.data(), rec, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long lo = ~0ull, hi = 0;
+        double sum = 0;
+        for (int w = 0; w < 256; ++w) { lo = std::min(lo, h[2 * w]); hi = std::max(hi, h[2 * w + 1]); sum += (double)(h[2 * w + 1] - h[2 * w]); }
+        span_us = (double)(hi - lo) / khz * 1e3;
+        wg_us = sum / 256 / khz * 1e3;
+    };
+    double first_span, first_wg, span = 0, wg = 0;
+    one(first_span, first_wg);
+    for (int r = 0; r < 3; ++r) { double s_, w_; one(s_, w_); }
+    // back to back on the stream (no host round trip between launches), HIP events around 20
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(code_walk<MODE>, dim3(grid, 2), dim3(256), lds, 0, sink, rec);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    for (int r = 0; r < 5; ++r) { double s_, w_; one(s_, w_); span += s_ / 5; wg += w_ / 5; }
+    printf("\"%s\": {\"first_launch_span_us\": %.1f, \"span_us\": %.1f, \"workgroup_us\": %.1f, \"back_to_back_us\": %.1f}%s", name, first_span, span, wg,
+           ms * 1e3 / 20, last ? "}, " : ", ");
+    CHECK(hipFree(sink));
+    CHECK(hipFree(rec));
+}
+
+// where the loader put this process's kernel code: a kernel reports its program counter, ROCr says which pool owns that address (a GPU's
+// local memory or the host's), how large the allocation is and whether it is fine-grained (uncached in the GPU's L2)
+__global__ void where_am_i(unsigned long long *out)
+{
+    unsigned long long pc;
+    asm volatile("s_getpc_b64 %0" : "=s"(pc));
+    out[0] = pc;
+}
+
+void run_code_memory()
+{
+    unsigned long long *o, pc = 0;
+    CHECK(hipMalloc(&o, 8));
+    hipLaunchKernelGGL(where_am_i, dim3(1), dim3(1), 0, 0, o);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(&pc, o, 8, hipMemcpyDeviceToHost));
+    CHECK(hipFree(o));
+    hsa_amd_pointer_info_t info;
+    memset(&info, 0, sizeof(info));
+    info.size = sizeof(info);
+    (void)hsa_init();
+    const hsa_status_t st = hsa_amd_pointer_info((const void *)pc, &info, nullptr, nullptr, nullptr);
+    hsa_device_type_t dt = (hsa_device_type_t)-1;
+    if (st == HSA_STATUS_SUCCESS && info.type != HSA_EXT_POINTER_TYPE_UNKNOWN) (void)hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &dt);
+    printf("\"code_memory\": {\"pc\": \"0x%llx\", \"hsa_status\": %d, \"pointer_type\": %d, \"allocation_bytes\": %zu, \"owner\": \"%s\", \"global_flags\": %u, "
+           "\"note\": \"global_flags: 1 kernarg, 2 fine-grained, 4 coarse-grained, 8 extended-scope fine-grained\"}, ",
+           pc, (int)st, (int)info.type, info.sizeInBytes, dt == HSA_DEVICE_TYPE_GPU ? "gpu" : dt == HSA_DEVICE_TYPE_CPU ? "cpu" : "unknown", info.global_flags);
+}
+
+void run_code_walks(int khz)
+{
+    printf("\"code_walk_56KB\": {");
+    run_code_walk<0>("single", khz, false);
+    run_code_walk<1>("dual_map0", khz, false);
+    run_code_walk<2>("dual_map1", khz, false);
+    run_code_walk<3>("single_112KB", khz, true);
 }
 
 template <int KIND>
@@ -273,7 +329,8 @@ int main()
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"wall_clock_khz\": %d, \"attr_clock_khz\": %d, \"attr_memory_clock_khz\": %d, ",
            prop.name, prop.gcnArchName, cus, khz, sclk, mclk);
     // ~100-200 us per launch, 24 launches each: long enough for the power manager to settle on the body's clock
-    run_chase(khz);
+    run_code_memory();
+    run_code_walks(khz);
     run_k6like(khz, 120, 24);
     run<0>("mfma_bf16_32x32x16", 16, 400, 24, khz, false);
     run<1>("mfma_f32_32x32x2", 16, 200, 24, khz, false);

@@ -27,7 +27,7 @@ b = json.load(open("$O/box.json"))
 for k, v in b["k6_standalone"].items():
     ww = v.get("workgroups") or {}
     print("box", k, v.get("us_back_to_back_events"), v.get("us_span_unbracketed"), v.get("workgroup_us"), v.get("shader_mhz"), ww.get("dur_us"), ww.get("dur_us_mean_by_xcc"), ww.get("workgroups_in_a_second_round"))
-print(b["clock_probe"].get("k6_like_forward_mix"), b["clock_probe"].get("dependent_load_ns"), b.get("hbm_copy_GBps"))
+print(b["clock_probe"].get("k6_like_forward_mix"), b["clock_probe"].get("code_walk_56KB"), b.get("hbm_copy_GBps"))
 import os
 if os.path.exists("$O/k6_only_net.jsonl"):
     for ln in open("$O/k6_only_net.jsonl"):

@@ -5,6 +5,7 @@ TAG=${1:-w}
 O=$GRAFT_REPO_ROOT/gpurun_out/r05_wgmap_$TAG; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 export ERL_QUIET=1
+tools/bin/clock_probe > $O/clock_probe.json 2> $O/clock_probe.err
 python tools/k6_wg_map_ab.py 4 > $O/ab.jsonl 2> $O/ab.err
 for rep in 0 1; do
   python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep --no-smi --repeats 3 > $O/c4_auto_$rep.json 2> $O/c4_auto_$rep.err
@@ -18,6 +19,10 @@ if [ -z "$2" ]; then
 fi
 python - <<PY
 import json, glob
+try:
+    cp = json.load(open("$O/clock_probe.json")); print("code_walk", cp.get("code_walk_56KB")); print("k6like", cp.get("k6_like_forward_mix"))
+except Exception as e:
+    print("clock_probe:", e)
 for ln in open("$O/ab.jsonl"):
     r = json.loads(ln); print("ab map", r["wg_map"], "loop_ms", r["loop_ms_40_minibatches"], "span", r.get("us_span"), "wg", r.get("workgroup_us"), r.get("dur_us"), "mhz", r.get("shader_mhz"), "sum", r["params_checksum"], r.get("dur_us_mean_by_xcc"))
 for f in sorted(glob.glob("$O/c4_*.json")):
