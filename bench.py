@@ -822,7 +822,7 @@ def main():
                      # where the kernel's workgroups run (include/erl_hip.h erl_ppo_wg_map_info): the device's first full-chip launch
                      # measured both maps (us_map0 / us_map1, back to back) and kept one -- map 1 on the boxes where two code paths
                      # per instruction cache cost 7-9 us per launch (DESIGN.md "K6 in round 5"), map 0 elsewhere
-                     "workgroup_map": _hip.ppo_wg_map_info(),
+                     "workgroup_map": _hip.ppo_wg_map_info(wide=wide),
                      "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src,
                      # this box against the box the committed rocprofv3 summary was collected on (same sources): avg_launch_us / kernel_us_rocprof
                      "box_ratio": box_ratio,

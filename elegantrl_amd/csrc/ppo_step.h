@@ -4,6 +4,7 @@
 //                     set in the 512-entry register file (S <= 64, net [128,128], A <= 8: BASELINE configs 4 / 5)
 // Both write the same gradient slabs (one per 128 samples and network) and the same objective partial sums.
 #pragma once
+#include <functional>
 #include "mlp_chain.h"
 #include "ppo_objective.h"
 
@@ -270,5 +271,9 @@ bool erl_ppo_w4_supported(int S, int h1, int h2, int A);
 int erl_ppo_w4_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);
 // ppo_step_s3.hip
 bool erl_ppo_s3_supported(int S, int h1, int h2, int A);
+// host side of the workgroup map (k6_wg_map above; ppo_step.hip): one decision per device and kernel family (0: the (128 | 64, h2) kernels of
+// ppo_step_s3_impl.h, 1: the (256, h2[, h3]) kernels of ppo_step_wd_impl.h); `launch(map)` enqueues the kernel once under a map and
+// returns an ERL_* code
+int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std::function<int(int)> &launch);
 int erl_ppo_s3_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);
 int erl_ppo_s3_launch_pre(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);      // ppo_step_s3_pre.hip: W2 images given

@@ -459,7 +459,8 @@ struct WgMapChoice {
     int map = -1;                 // -1: not measured yet
     double us[2] = {0.0, 0.0};    // per launch, back to back, each map (0 when the map was never measured)
 };
-WgMapChoice g_wg_map[kWgMapDevices];
+constexpr int kWgMapFamilies = 2;
+WgMapChoice g_wg_map[kWgMapFamilies][kWgMapDevices];
 int k6_wg_map_env()
 {
     const char *e = getenv("ERL_K6_WG_MAP");
@@ -496,17 +497,18 @@ extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
 
 extern "C" int erl_ppo_num_slabs(int64_t B) { return B >= 1 && B < (1LL << 37) ? (int)erl_cdiv(B, PB) : -1; }
 
-// Which workgroup map this launch runs under.  Not forced and not measured yet on this device: launch the kernel with the CALL'S OWN
-// arguments under both maps, alternating (1 + 4 launches per leg, 2 legs per map, HIP events on the call's stream; the kernel writes
-// nothing but the gradient slabs, which the real launch that follows rewrites) and keep map 1 when it is at least 3 % faster.  Only a
-// launch that fills the chip (>= 256 workgroups) decides; a capturing stream or a failed event leaves the decision to a later call.
-static int k6_wg_map_for_launch(Ppo2Args g, int n_slabs, bool vec, bool pre, hipStream_t st)
+// Which workgroup map this launch runs under.  Not forced and not measured yet on this device for this kernel family: launch the kernel
+// with the CALL'S OWN arguments under both maps, alternating (1 + 4 launches per leg, 2 legs per map, HIP events on the call's stream; the
+// kernel writes nothing but the gradient slabs and its scratch, which the real launch that follows rewrites) and keep map 1 when it is
+// at least 3 % faster.  Only a launch that fills the chip (>= 256 workgroups) decides; a capturing stream or a failed event leaves the
+// decision to a later call.
+int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std::function<int(int)> &launch)
 {
     const int forced = k6_wg_map_env();
     if (forced >= 0) return forced;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kWgMapDevices) return 0;
-    WgMapChoice &c = g_wg_map[dev];
+    if (family < 0 || family >= kWgMapFamilies || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kWgMapDevices) return 0;
+    WgMapChoice &c = g_wg_map[family][dev];
     if (c.map >= 0) return c.map;
     if (2 * n_slabs < 256) return 0;
     if (getenv("ERL_K6_NO_TUNE")) return 0;            // (diagnostics: no measurement, map 0)
@@ -516,12 +518,10 @@ static int k6_wg_map_for_launch(Ppo2Args g, int n_slabs, bool vec, bool pre, hip
     hipEvent_t ev[2 * kLegs][2] = {};
     bool ok = true;
     for (auto &e : ev) ok = ok && hipEventCreate(&e[0]) == hipSuccess && hipEventCreate(&e[1]) == hipSuccess;
-    g.span = nullptr;
     for (int leg = 0; ok && leg < 2 * kLegs; ++leg) {
-        g.wg_map = leg & 1;
         for (int k = 0; ok && k <= kReps; ++k) {
             if (k == 1) ok = hipEventRecord(ev[leg][0], st) == hipSuccess;
-            ok = ok && (pre ? erl_ppo_s3_launch_pre(g, n_slabs, vec, st) : erl_ppo_s3_launch(g, n_slabs, vec, st)) == ERL_OK;
+            ok = ok && launch(leg & 1) == ERL_OK;
         }
         ok = ok && hipEventRecord(ev[leg][1], st) == hipSuccess;
     }
@@ -540,11 +540,13 @@ static int k6_wg_map_for_launch(Ppo2Args g, int n_slabs, bool vec, bool pre, hip
 
 extern "C" int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map1)
 {
-    ERL_REQUIRE(device >= 0 && device < kWgMapDevices, "erl_ppo_wg_map_info: device %d", device);
+    const int family = (device >> 8) & 0xff;              // ERL_PPO_WG_FAMILY_WIDE
+    device &= 0xff;
+    ERL_REQUIRE(device >= 0 && device < kWgMapDevices && family < kWgMapFamilies, "erl_ppo_wg_map_info: device %d family %d", device, family);
     const int forced = k6_wg_map_env();
-    if (map) *map = forced >= 0 ? forced : g_wg_map[device].map;
-    if (us_map0) *us_map0 = g_wg_map[device].us[0];
-    if (us_map1) *us_map1 = g_wg_map[device].us[1];
+    if (map) *map = forced >= 0 ? forced : g_wg_map[family][device].map;
+    if (us_map0) *us_map0 = g_wg_map[family][device].us[0];
+    if (us_map1) *us_map1 = g_wg_map[family][device].us[1];
     return ERL_OK;
 }
 
@@ -603,7 +605,12 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     const bool split = erl_ppo_arith_for_call(S, h1, h2, A, arith_call) == ERL_PPO_ARITH_SPLIT;
     const bool pre = g.w2img[0] && g.w2img[1] && g.w1img[0] && g.w1img[1];
     g.span = nullptr;
-    if (split) g.wg_map = k6_wg_map_for_launch(g, n_slabs, vec, pre, st);       // (the first full-chip launch on a device measures both maps)
+    if (split)                                                                   // (the first full-chip launch on a device measures both maps)
+        g.wg_map = erl_k6_wg_map_for_launch(0, n_slabs, st, [&](int m) {
+            Ppo2Args t = g;
+            t.wg_map = m;
+            return pre ? erl_ppo_s3_launch_pre(t, n_slabs, vec, st) : erl_ppo_s3_launch(t, n_slabs, vec, st);
+        });
     g.span = erl_k6_timing_begin(st, n_slabs);
     int rc;
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else

@@ -109,9 +109,14 @@ int erl_ppo_wd_step(const float *actor_params, const float *critic_params, const
     if (rc) return rc;
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states);
+    auto go = [&](const PpoWdArgs &x) {
+        if (h2 == 128) return S > 32 ? erl_ppo_wd_launch_24(x, n_slabs, vec, st) : erl_ppo_wd_launch_14(x, n_slabs, vec, st);
+        return S > 32 ? erl_ppo_wd_launch_22(x, n_slabs, vec, st) : erl_ppo_wd_launch_12(x, n_slabs, vec, st);
+    };
+    g.span = nullptr;           // (one network per XCD or both on every XCD: ppo_step.h k6_wg_map; these kernels are 125 KB per network)
+    g.wg_map = erl_k6_wg_map_for_launch(1, n_slabs, st, [&](int m) { PpoWdArgs t = a; t.g.wg_map = m; return go(t); });
     g.span = erl_k6_timing_begin(st, n_slabs);
-    if (h2 == 128) rc = S > 32 ? erl_ppo_wd_launch_24(a, n_slabs, vec, st) : erl_ppo_wd_launch_14(a, n_slabs, vec, st);
-    else rc = S > 32 ? erl_ppo_wd_launch_22(a, n_slabs, vec, st) : erl_ppo_wd_launch_12(a, n_slabs, vec, st);
+    rc = go(a);
     erl_k6_timing_end(st);
     return rc;
 }
@@ -232,9 +237,14 @@ int erl_ppo_wd3_step(const float *actor_params, const float *critic_params, cons
     a.scratch = scratch;
     auto al = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = (S % 4 == 0) && al(actor_params) && al(critic_params) && al(states);
+    auto go = [&](const PpoWdArgs &x) {
+        if (h3 == 128) return S > 32 ? erl_ppo_wd3_launch_24(x, n_slabs, vec, st) : erl_ppo_wd3_launch_14(x, n_slabs, vec, st);
+        return S > 32 ? erl_ppo_wd3_launch_22(x, n_slabs, vec, st) : erl_ppo_wd3_launch_12(x, n_slabs, vec, st);
+    };
+    g.span = nullptr;
+    g.wg_map = erl_k6_wg_map_for_launch(1, n_slabs, st, [&](int m) { PpoWdArgs t = a; t.g.wg_map = m; return go(t); });
     g.span = erl_k6_timing_begin(st, n_slabs);
-    if (h3 == 128) rc = S > 32 ? erl_ppo_wd3_launch_24(a, n_slabs, vec, st) : erl_ppo_wd3_launch_14(a, n_slabs, vec, st);
-    else rc = S > 32 ? erl_ppo_wd3_launch_22(a, n_slabs, vec, st) : erl_ppo_wd3_launch_12(a, n_slabs, vec, st);
+    rc = go(a);
     erl_k6_timing_end(st);
     if (rc) return rc;
     return erl_grad_reduce_f32(slabs, n_slabs, stride, flat_grad, stream);

@@ -465,7 +465,7 @@ __device__ __forceinline__ uint32_t wd_gather_off(int i, uint32_t lane16)
 }
 
 template <bool ACTOR, int KX, int N2, int N3, bool VEC>     // KX: input tiles of 32 (1: S <= 32, 2: S <= 64)
-__device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
+__device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem, const int slab_ix)
 {
     const Ppo2Args &g = args.g;
     constexpr int N1 = 8, h1 = 32 * N1, h2 = 32 * N2, h3 = 32 * N3;
@@ -515,7 +515,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     float *s_red = s_nn + 64;
     float *s_b3h = s_red + 16;                                  // the third hidden layer's bias (128)
     constexpr int ld3 = lds_ld(128);
-    float *scr0 = args.scratch + ((size_t)blockIdx.x * 2 + net) * wd_scratch_floats(NL, N3);
+    float *scr0 = args.scratch + ((size_t)slab_ix * 2 + net) * wd_scratch_floats(NL, N3);
     // register tile T (0..7: GELU'(z1); 8..: H2), quad r of this thread: wave-uniform base + the thread's 16 bytes
     auto scr_tile = [&](int T, int r) -> float4 & { return reinterpret_cast<float4 *>(scr0 + (size_t)(4 * T + r) * QNT * 4)[tid]; };
     u8 *scrI = reinterpret_cast<u8 *>(scr0 + (8 + NL) * 16 * QNT);      // H1 quarter images
@@ -532,7 +532,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     // ---- prologue: the sample id; the W1 image by LDS-DMA; biases, W3, normalisation constants (every load unconditional: see
     //      ppo_step_s3_impl.h)
     PROF(0);
-    const int64_t bidx = (int64_t)blockIdx.x * PB + col;
+    const int64_t bidx = (int64_t)slab_ix * PB + col;
     const bool valid = bidx < g.B;
     const int64_t id = g.ids[valid ? bidx : 0];
     const AdvNorm advn = adv_norm_consts(ACTOR ? g.adv_stats : nullptr);
@@ -871,7 +871,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     PROF_NV(9);
     // ---- dZ1 = (W2^T dZ2) * GELU'(z1), quarter by quarter (3, 2 resident; 1, 0 streamed back), each contracted with the input
     //      (dW1, db1) as soon as it is staged
-    float *slab = g.slabs + (size_t)blockIdx.x * g.stride + (ACTOR ? 0 : g.Pa);
+    float *slab = g.slabs + (size_t)slab_ix * g.stride + (ACTOR ? 0 : g.Pa);
     float *RC = RW3;
     Parts dZ2p[2 * N2], dZ1q[4];
     // the gate tiles requested a phase ago are IN their registers as far as the compiler is concerned (called right after a
@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void ppo_block_wd(const PpoWdArgs &args, u8 *smem)
     const float t0 = wg_sum(loss0, s_red);
     const float t1 = wg_sum(loss1, s_red + 8);
     if (tid == 0) {
-        float *logs = g.slabs + (size_t)blockIdx.x * g.stride + g.Pa + g.Pc;
+        float *logs = g.slabs + (size_t)slab_ix * g.stride + g.Pa + g.Pc;
         if (ACTOR) {
             float ent = 0.f;
             for (int a = 0; a < OUT; ++a) ent += 1.4189385332046727418f + logf(expf(std_log[a]));
@@ -1181,8 +1181,9 @@ __global__ __launch_bounds__(QNT) void ppo_step_wd_kernel(PpoWdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_wd[];
     const SpanT t_span = span_enter(a.g);
-    if (blockIdx.y == 0) ppo_block_wd<true, KX, N2, N3, VEC>(a, smem_wd);
-    else ppo_block_wd<false, KX, N2, N3, VEC>(a, smem_wd);
+    const K6Wg wg = k6_wg_map(a.g);
+    if (wg.actor) ppo_block_wd<true, KX, N2, N3, VEC>(a, smem_wd, wg.slab);
+    else ppo_block_wd<false, KX, N2, N3, VEC>(a, smem_wd, wg.slab);
     span_exit(a.g, t_span);
 }
 

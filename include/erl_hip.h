@@ -295,7 +295,9 @@ ERL_API int erl_ppo_arith_in_use(int S, int h1, int h2, int A);   /* ERL_PPO_ARI
  * XCD, map 1 = the actor's on XCDs 0-3 and the critic's on 4-7 (one code path per instruction cache).  Results are bit-identical; which is
  * faster depends on the box (DESIGN.md "K6 in round 5"), so the first full-chip launch on a device measures both (back to back, the
  * call's own arguments, ~0.5 ms once per device and process) and the device keeps the winner.  ERL_K6_WG_MAP=0|1 forces a map.
- * *map = the map in use on `device` (-1: not decided yet), *us_map0 / *us_map1 = the per-launch times the decision saw (0: none). */
+ * *map = the map in use on `device` (-1: not decided yet), *us_map0 / *us_map1 = the per-launch times the decision saw (0: none).
+ * The (256, h2[, h3]) kernels decide for themselves (their code is 125 KB per network): device | ERL_PPO_WG_FAMILY_WIDE asks for theirs. */
+#define ERL_PPO_WG_FAMILY_WIDE 0x100
 ERL_API int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map1);
 ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
 ERL_API int erl_ppo_num_slabs(int64_t B);
