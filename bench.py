@@ -820,7 +820,7 @@ def main():
                                    "phase_cycles": {k: round(v) for k, v in k6_clocks_br["phase_cycles"].items()} or None},
                      "event_bracket_us": round(k6_event_s * 1e6, 2), "event_bracket_null_us": round(null_bracket_us, 2),
                      # where the kernel's workgroups run (include/erl_hip.h erl_ppo_wg_map_info): the device's first full-chip launch
-                     # measured both maps (us_map0 / us_map1, back to back) and kept one -- map 1 on the boxes where two code paths
+                     # measured map 0 against map 2 (us_map0 / us_map2, back to back) and kept one -- map 2 on the boxes where two code paths
                      # per instruction cache cost 7-9 us per launch (DESIGN.md "K6 in round 5"), map 0 elsewhere
                      "workgroup_map": _hip.ppo_wg_map_info(wide=wide),
                      "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src,

@@ -362,14 +362,14 @@ def k6_wg_summary(recs):
 
 def ppo_wg_map_info(device: int = None, wide: bool = False) -> dict:
     """the minibatch kernel's workgroup map on `device` (default: the current one; wide: of the (256, h2[, h3]) kernels): {'map': 0 | 1 | None (not decided yet), 'forced': the
-    ERL_K6_WG_MAP override or None, 'us_map0', 'us_map1': the per-launch times the device's one-off measurement saw (None: never measured)}"""
+    ERL_K6_WG_MAP override or None, 'us_map0', 'us_map2': the per-launch times the device's one-off measurement saw (None: never measured)}"""
     import torch as th
     dev = th.cuda.current_device() if device is None else int(device)
     m, u0, u1 = c_int(-1), c_double(0), c_double(0)
     check(lib().erl_ppo_wg_map_info(dev | (0x100 if wide else 0), ctypes.byref(m), ctypes.byref(u0), ctypes.byref(u1)), "erl_ppo_wg_map_info")
     env = os.environ.get("ERL_K6_WG_MAP", "")
-    return {"map": None if m.value < 0 else m.value, "forced": int(env) if env in ("0", "1") else None,
-            "us_map0": round(u0.value, 2) if u0.value else None, "us_map1": round(u1.value, 2) if u1.value else None}
+    return {"map": None if m.value < 0 else m.value, "forced": int(env) if env in ("0", "1", "2") else None,
+            "us_map0": round(u0.value, 2) if u0.value else None, "us_map2": round(u1.value, 2) if u1.value else None}
 
 
 def k6_null_bracket_us(reps: int = 200) -> float:

@@ -28,7 +28,7 @@ struct Ppo2Args {
     const int64_t *next_ids;   // the NEXT minibatch's ids (update loops; nullptr: none / unknown): -DERL_K6_EXP & 4 lets the critic's workgroups,
                                // which finish ~5k cycles before the actor's, pull that minibatch's rows towards their XCD's L2
     int exp_net;          // -DERL_K6_EXP & 16 builds only (diagnostics): 0 = every workgroup runs the ACTOR's code path, 1 = the critic's, else by blockIdx.y
-    int wg_map;           // ppo_step_s3_kernel's workgroup -> (network, slab) map: 0 = (blockIdx.y, blockIdx.x); 1 = by XCD (k6_wg_map below)
+    int wg_map;           // the minibatch kernels' workgroup -> (network, slab) map: 0 = (blockIdx.y, blockIdx.x); 1 = by XCD, 2 = by shader engine (k6_wg_map below)
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -119,8 +119,13 @@ struct K6Wg {
 __device__ __forceinline__ K6Wg k6_wg_map(const Ppo2Args &g)
 {
     if (g.wg_map == 0) return K6Wg{blockIdx.y == 0, (int)blockIdx.x};
-    const int n = (int)gridDim.x, L = (int)(blockIdx.x + gridDim.x * blockIdx.y), full = n & ~3;
-    if (L < 2 * full) return K6Wg{(L & 7) < 4, 4 * (L >> 3) + (L & 3)};
+    // maps 1 and 2: groups of 2 * W consecutive linear ids, the first W of a group to the actor, the rest to the critic, slab = W * group +
+    // id % W.  W = 4 (map 1): a group is one round over the 8 XCDs -- XCDs 0-3 the actor's.  W = 16 (map 2): a group is one round over the
+    // 8 XCDs x 4 shader engines (engine = (id / 8) % 4 by the same records) -- engines 0-1 of EVERY XCD the actor's, 2-3 the critic's: an
+    // instruction cache (shared by neighbouring CUs of one engine) still holds one path, and every XCD keeps 16 + 16 workgroups.
+    const int W = g.wg_map == 2 ? 16 : 4;
+    const int n = (int)gridDim.x, L = (int)(blockIdx.x + gridDim.x * blockIdx.y), full = n / W * W;
+    if (L < 2 * full) return K6Wg{L % (2 * W) < W, W * (L / (2 * W)) + L % W};
     const int r = n - full, l = L - 2 * full;                 // 2 r workgroups left for slabs full .. n - 1
     return K6Wg{l < r, full + (l < r ? l : l - r)};
 }

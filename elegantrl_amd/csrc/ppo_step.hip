@@ -451,20 +451,22 @@ int k6_form()     // 0 = automatic, 8 = always the 8-wave 16x16x4 kernel (A/B me
     static const int form = [] { const char *e = getenv("ERL_K6_FORM"); return e ? atoi(e) : 0; }();
     return form;
 }
-// the minibatch kernel's workgroup map (ppo_step.h, k6_wg_map).  ERL_K6_WG_MAP=0 / 1 (read per launch: A/B runs flip it inside one process)
-// forces a map; otherwise the FIRST full-chip launch of the split-arithmetic kernel on a device measures both (k6_tune_wg_map below) and the
-// device keeps the faster one: map 1 costs ~1.2 us of 36 on most boxes of the pool and saves 7-9 us of 47-55 on the rest.
+// the minibatch kernels' workgroup map (ppo_step.h, k6_wg_map).  ERL_K6_WG_MAP=0 / 1 / 2 (read per launch: A/B runs flip it inside one
+// process) forces a map; otherwise the FIRST full-chip launch of a kernel family on a device measures map 0 against map 2
+// (erl_k6_wg_map_for_launch below) and the device keeps the faster one: map 2 saves 9-12 us of 47-55 on about one box in four of the pool
+// and is even with map 0 on the rest (DESIGN.md "K6 in round 5").
 constexpr int kWgMapDevices = 64;
+constexpr int kWgMapAlt = 2;          // the map measured against map 0 (k6_wg_map: one network per pair of shader engines)
 struct WgMapChoice {
     int map = -1;                 // -1: not measured yet
-    double us[2] = {0.0, 0.0};    // per launch, back to back, each map (0 when the map was never measured)
+    double us[2] = {0.0, 0.0};    // per launch, back to back: [0] map 0, [1] map kWgMapAlt (0 when never measured)
 };
 constexpr int kWgMapFamilies = 2;
 WgMapChoice g_wg_map[kWgMapFamilies][kWgMapDevices];
 int k6_wg_map_env()
 {
     const char *e = getenv("ERL_K6_WG_MAP");
-    return e && (*e == '0' || *e == '1') ? *e - '0' : -1;
+    return e && (*e == '0' || *e == '1' || *e == '2') ? *e - '0' : -1;
 }
 }  // namespace
 
@@ -499,8 +501,8 @@ extern "C" int erl_ppo_num_slabs(int64_t B) { return B >= 1 && B < (1LL << 37) ?
 
 // Which workgroup map this launch runs under.  Not forced and not measured yet on this device for this kernel family: launch the kernel
 // with the CALL'S OWN arguments under both maps, alternating (1 + 4 launches per leg, 2 legs per map, HIP events on the call's stream; the
-// kernel writes nothing but the gradient slabs and its scratch, which the real launch that follows rewrites) and keep map 1 when it is
-// at least 3 % faster.  Only a launch that fills the chip (>= 256 workgroups) decides; a capturing stream or a failed event leaves the
+// kernel writes nothing but the gradient slabs and its scratch, which the real launch that follows rewrites) and keep map 2 when it is
+// at least 3 % faster (map 1 and map 2 recover the same boxes; map 2 costs the others nothing, map 1 ~1.2 us: map 2 is the candidate).  Only a launch that fills the chip (>= 256 workgroups) decides; a capturing stream or a failed event leaves the
 // decision to a later call.
 int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std::function<int(int)> &launch)
 {
@@ -521,7 +523,7 @@ int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std:
     for (int leg = 0; ok && leg < 2 * kLegs; ++leg) {
         for (int k = 0; ok && k <= kReps; ++k) {
             if (k == 1) ok = hipEventRecord(ev[leg][0], st) == hipSuccess;
-            ok = ok && launch(leg & 1) == ERL_OK;
+            ok = ok && launch((leg & 1) ? kWgMapAlt : 0) == ERL_OK;
         }
         ok = ok && hipEventRecord(ev[leg][1], st) == hipSuccess;
     }
@@ -534,11 +536,11 @@ int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std:
     for (auto &e : ev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
     if (!ok) { (void)hipGetLastError(); return 0; }
     c.us[0] = us[0]; c.us[1] = us[1];
-    c.map = us[1] < 0.97 * us[0] ? 1 : 0;
+    c.map = us[1] < 0.97 * us[0] ? kWgMapAlt : 0;
     return c.map;
 }
 
-extern "C" int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map1)
+extern "C" int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map2)
 {
     const int family = (device >> 8) & 0xff;              // ERL_PPO_WG_FAMILY_WIDE
     device &= 0xff;
@@ -546,7 +548,7 @@ extern "C" int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double
     const int forced = k6_wg_map_env();
     if (map) *map = forced >= 0 ? forced : g_wg_map[family][device].map;
     if (us_map0) *us_map0 = g_wg_map[family][device].us[0];
-    if (us_map1) *us_map1 = g_wg_map[family][device].us[1];
+    if (us_map2) *us_map2 = g_wg_map[family][device].us[1];
     return ERL_OK;
 }
 

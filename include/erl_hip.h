@@ -291,14 +291,17 @@ ERL_API int erl_rollout_pendulum_f32(const float *actor_params, const float *cri
 #define ERL_PPO_MODE(objective, arith) ((objective) | ((arith) << 8))
 ERL_API int erl_ppo_set_arith(int arith);
 ERL_API int erl_ppo_arith_in_use(int S, int h1, int h2, int A);   /* ERL_PPO_ARITH_F32 or _SPLIT for this shape under the current setting */
-/* Where the split-arithmetic minibatch kernel's workgroups run (csrc/ppo_step.h, k6_wg_map): map 0 = both networks' workgroups on every
- * XCD, map 1 = the actor's on XCDs 0-3 and the critic's on 4-7 (one code path per instruction cache).  Results are bit-identical; which is
- * faster depends on the box (DESIGN.md "K6 in round 5"), so the first full-chip launch on a device measures both (back to back, the
- * call's own arguments, ~0.5 ms once per device and process) and the device keeps the winner.  ERL_K6_WG_MAP=0|1 forces a map.
- * *map = the map in use on `device` (-1: not decided yet), *us_map0 / *us_map1 = the per-launch times the decision saw (0: none).
+/* Where the split-arithmetic minibatch kernels' workgroups run (csrc/ppo_step.h, k6_wg_map).  Workgroups go to the 8 XCDs round-robin by
+ * linear id and, inside an XCD, to its 4 shader engines round-robin: map 0 (network = blockIdx.y) puts both networks' workgroups -- two
+ * ~55 KB code paths -- behind every 64 KB instruction cache; map 1 = the actor's workgroups on XCDs 0-3, the critic's on 4-7; map 2 = the
+ * actor's on shader engines 0-1 of every XCD, the critic's on engines 2-3 (one code path per instruction cache, every XCD still 16 + 16).
+ * Results are bit-identical; which is faster depends on the box (about one in four of the pool has a slow instruction-cache miss path:
+ * DESIGN.md "K6 in round 5"), so the first full-chip launch on a device measures map 0 against map 2 (back to back, the call's own
+ * arguments, ~0.5 ms once per device and process) and the device keeps map 2 if it is 3 % faster.  ERL_K6_WG_MAP=0|1|2 forces a map.
+ * *map = the map in use on `device` (-1: not decided yet), *us_map0 / *us_map2 = the per-launch times the decision saw (0: none).
  * The (256, h2[, h3]) kernels decide for themselves (their code is 125 KB per network): device | ERL_PPO_WG_FAMILY_WIDE asks for theirs. */
 #define ERL_PPO_WG_FAMILY_WIDE 0x100
-ERL_API int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map1);
+ERL_API int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map2);
 ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
 ERL_API int erl_ppo_num_slabs(int64_t B);
 ERL_API int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg,

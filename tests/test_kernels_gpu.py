@@ -593,7 +593,7 @@ def test_ppo_step_split_arith(ops, dev, S, h1, h2, A, B):
         assert es <= max(2.0 * e32, 1e-6), f"{name}: split arithmetic error {es:.3e} against the fp32 kernel's {e32:.3e}"
 
 
-@pytest.mark.parametrize("B", [1, 200, 128 * 4, 128 * 5 + 17, 128 * 7, 128 * 11 + 1, 16384])
+@pytest.mark.parametrize("B", [1, 200, 128 * 4, 128 * 5 + 17, 128 * 7, 128 * 11 + 1, 128 * 16, 128 * 35 + 3, 16384])
 def test_ppo_step_workgroup_maps_agree(ops, dev, B, monkeypatch):
     """the split-arithmetic minibatch kernel under both workgroup maps (csrc/ppo_step.h k6_wg_map: network = blockIdx.y against one
     network per XCD, with the halves fallback for a slab count that is no multiple of 4): which workgroup computes a slab must not show in
@@ -607,7 +607,7 @@ def test_ppo_step_workgroup_maps_agree(ops, dev, B, monkeypatch):
     got = {}
     prev = ops.ppo_set_arith("split")
     try:
-        for wg_map in ("0", "1"):
+        for wg_map in ("0", "1", "2"):
             monkeypatch.setenv("ERL_K6_WG_MAP", wg_map)           # read per launch
             slabs = th.full((n_slabs, stride), float("nan"), device=dev)
             ops.ppo_step(cu(flat_params(actor), dev), cu(flat_params(critic), dev), cu(actor.state_avg, dev), cu(actor.state_std, dev),
@@ -618,7 +618,7 @@ def test_ppo_step_workgroup_maps_agree(ops, dev, B, monkeypatch):
             assert _hip.ppo_wg_map_info()["forced"] == int(wg_map) and _hip.ppo_wg_map_info()["map"] == int(wg_map)
     finally:
         ops.ppo_set_arith(prev)
-    assert np.array_equal(got["0"].view(np.uint32), got["1"].view(np.uint32))
+    assert np.array_equal(got["0"].view(np.uint32), got["1"].view(np.uint32)) and np.array_equal(got["0"].view(np.uint32), got["2"].view(np.uint32))
 
 
 def test_ppo_step_workgroup_map_is_measured_once(ops, dev, monkeypatch):
@@ -641,9 +641,9 @@ def test_ppo_step_workgroup_map_is_measured_once(ops, dev, monkeypatch):
         th.cuda.synchronize()
         info = _hip.ppo_wg_map_info()
         print("workgroup map on this box:", info)
-        assert info["forced"] is None and info["map"] in (0, 1)
-        assert info["us_map0"] and info["us_map1"] and 10.0 < info["us_map0"] < 500.0 and 10.0 < info["us_map1"] < 500.0
-        assert info["map"] == (1 if info["us_map1"] < 0.97 * info["us_map0"] else 0)
+        assert info["forced"] is None and info["map"] in (0, 2)
+        assert info["us_map0"] and info["us_map2"] and 10.0 < info["us_map0"] < 500.0 and 10.0 < info["us_map2"] < 500.0
+        assert info["map"] == (2 if info["us_map2"] < 0.97 * info["us_map0"] else 0)
         monkeypatch.setenv("ERL_K6_WG_MAP", "0")
         b = th.full((n_slabs, stride), float("nan"), device=dev)
         ops.ppo_step(*args(b))

@@ -80,7 +80,7 @@ def test_wide_step_against_fp64(ops, dev, S, h1, h2, A, B):
     assert eo.max() <= 2e-6, f"objectives: {eo}"
 
 
-@pytest.mark.parametrize("B", [200, 128 * 5 + 17, 128 * 11 + 1, 16384])
+@pytest.mark.parametrize("B", [200, 128 * 5 + 17, 128 * 11 + 1, 128 * 35 + 3, 16384])
 def test_wide_step_workgroup_maps_agree(ops, dev, B, monkeypatch):
     """the (256, h2) and (256, 128, h3) kernels under both workgroup maps (csrc/ppo_step.h k6_wg_map; ERL_K6_WG_MAP is read per launch): the
     same summed gradient row bit for bit, incl. slab counts that are no multiple of 4 and the full-size launch (which, unforced, is the one
@@ -92,20 +92,21 @@ def test_wide_step_workgroup_maps_agree(ops, dev, B, monkeypatch):
     buf, ids = buf_ids[:6], buf_ids[6]
     actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
     got, got3 = {}, {}
-    for wg_map in ("0", "1"):
+    for wg_map in ("0", "1", "2"):
         monkeypatch.setenv("ERL_K6_WG_MAP", wg_map)
         got[wg_map] = wide_step(ops, dev, S, h1, h2, A, B, buf, ids, actor, critic, H, N)[0]
         got3[wg_map] = wide3_step(ops, dev, 17, 64, 5, B, H, N, 3 + B)[0]
         assert np.isfinite(got[wg_map]).all() and np.isfinite(got3[wg_map]).all()
         assert _hip.ppo_wg_map_info(wide=True)["map"] == int(wg_map)
     assert np.array_equal(got["0"], got["1"]) and np.array_equal(got3["0"], got3["1"])
+    assert np.array_equal(got["0"], got["2"]) and np.array_equal(got3["0"], got3["2"])
     monkeypatch.delenv("ERL_K6_WG_MAP")
     auto = wide_step(ops, dev, S, h1, h2, A, B, buf, ids, actor, critic, H, N)[0]
     assert np.array_equal(auto, got["0"])
     info = _hip.ppo_wg_map_info(wide=True)
     if B == 16384:
         print("wide kernels' workgroup map on this box:", info)
-        assert info["map"] in (0, 1) and info["us_map0"] and info["us_map1"]
+        assert info["map"] in (0, 2) and info["us_map0"] and info["us_map2"]
 
 
 @pytest.mark.parametrize("S,h2,A", [(24, 128, 4), (8, 64, 2)])

@@ -189,6 +189,7 @@ void run_k6like(int khz, int iters, int reps)
 //   single     every workgroup walks block A
 //   dual_map0  workgroups with blockIdx.y == 0 walk block A, the others block B: both blocks on every XCD (the minibatch kernel's old map)
 //   dual_map1  linear id % 8 < 4 walks A, the rest B: one block per XCD (its map 1)
+//   dual_map2  linear id % 32 < 16 walks A, the rest B: one block per pair of shader engines, both blocks on every XCD (its map 2)
 //   single_112KB  every workgroup walks A, then B (twice the work: compare with 2 x single)
 // Instruction caches are 64 KB and shared by neighbouring CUs: a box where dual_map0 is slower than single / dual_map1 is a box that pays
 // for two code paths per instruction cache -- with no MFMA, no LDS traffic and no memory traffic in the picture.
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void code_walk(float *sink, unsigned long long
     extern __shared__ float lds_pad[];
     float x = (float)threadIdx.x;
     const int L = (int)(blockIdx.x + gridDim.x * blockIdx.y);
-    const bool a = MODE == 0 ? true : MODE == 1 ? blockIdx.y == 0 : (L & 7) < 4;
+    const bool a = MODE == 0 ? true : MODE == 1 ? blockIdx.y == 0 : MODE == 4 ? (L & 31) < 16 : (L & 7) < 4;
     const unsigned long long w0 = wall_clock64();
     if (MODE == 3) { CODE_BLOCK("v_add_f32"); CODE_BLOCK("v_mul_f32"); }      // every workgroup walks both: 112 KB through each instruction cache
     else if (a) CODE_BLOCK("v_add_f32");
@@ -284,6 +285,7 @@ void run_code_walks(int khz)
     run_code_walk<0>("single", khz, false);
     run_code_walk<1>("dual_map0", khz, false);
     run_code_walk<2>("dual_map1", khz, false);
+    run_code_walk<4>("dual_map2", khz, false);
     run_code_walk<3>("single_112KB", khz, true);
 }
 

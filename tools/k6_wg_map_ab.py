@@ -18,6 +18,7 @@ from elegantrl_amd import _hip, ops  # noqa: E402
 dev = th.device("cuda:0")
 N, S, A, H, B, h1, h2 = 4096, 64, 8, 32, 16384, 128, 128
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+MAPS = (0, 1, 2)
 g = th.Generator(device=dev).manual_seed(0)
 sa, sc = ops.MlpSpec(S, h1, h2, A, True), ops.MlpSpec(S, h1, h2, 1, False)
 flat0 = th.randn(sa.count + sc.count, device=dev, generator=g) * 0.05
@@ -55,13 +56,13 @@ def one_pass(wg_map: int, timed: bool):
     return out
 
 
-for m in (0, 1):
+for m in MAPS:
     one_pass(m, False)                                       # warm
 for p in range(passes):
-    for m in (0, 1):
+    for m in MAPS:
         print(json.dumps(one_pass(m, True)), flush=True)
 # the same loop with NO launch sampled: does a launch that leaves per-workgroup records run as long as one that does not?  (half of the
 # launches of a timed pass above are sampled; on the pool's slow boxes the bench's sampled launches came out ~9 us above the loop's mean)
 for p in range(2):
-    for m in (0, 1):
+    for m in MAPS:
         print(json.dumps(dict(one_pass(m, False), sampled=False)), flush=True)

@@ -9,12 +9,12 @@ tools/bin/clock_probe > $O/clock_probe.json 2> $O/clock_probe.err
 python tools/k6_wg_map_ab.py 4 > $O/ab.jsonl 2> $O/ab.err
 for rep in 0 1; do
   python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep --no-smi --repeats 3 > $O/c4_auto_$rep.json 2> $O/c4_auto_$rep.err
-  for m in 0 1; do
+  for m in 0 1 2; do
     ERL_K6_WG_MAP=$m python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep --no-smi --repeats 3 > $O/c4_map${m}_$rep.json 2> /dev/null
   done
 done
 if [ -z "$2" ]; then
-  ERL_K6_WG_MAP=1 timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py tests/test_oracle_golden.py -m gpu -q -x > $O/pytest_map1.log 2>&1; echo "map1: $(tail -1 $O/pytest_map1.log)"
+  for m in 1 2; do ERL_K6_WG_MAP=$m timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py tests/test_oracle_golden.py tests/test_ppo_wide_gpu.py -m gpu -q -x > $O/pytest_map$m.log 2>&1; echo "map$m: $(tail -1 $O/pytest_map$m.log)"; done
   timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -s -k "workgroup_map" > $O/pytest_auto.log 2>&1; echo "auto: $(tail -1 $O/pytest_auto.log)"; grep "workgroup map on this box" $O/pytest_auto.log
 fi
 python - <<PY
