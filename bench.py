@@ -638,7 +638,8 @@ def main():
     # the loop runs it (a bracket perturbs what it brackets: the bracketed group is reported next to it)
     k6_clocks, k6_clocks_br = _hip.k6_timing_clocks(False), _hip.k6_timing_clocks(True)
     k6_wgs = _hip.k6_wg_summary(_hip.k6_timing_last_records(False))      # where / when the last sampled launch's workgroups ran
-    k6_spans = _hip.k6_timing_spans(False)                                # (launch number since enable, span) of the unbracketed sampled launches
+    # (launch number since enable, span) of every sampled launch, bracketed or not (a bracket does not change the span inside it)
+    k6_spans = _hip.k6_timing_spans(False) + _hip.k6_timing_spans(True)
     smi = smi_snapshot() if rank == 0 and not opt.no_smi else None
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")

@@ -230,6 +230,7 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
         int rc = erl_adv_stats_fold_f32(adv_partials, n_partials, H, N, adv_stats, stream);
         if (rc) return rc;
     }
+    erl_k6_touch_next_launch();       // the loop's first launch finds the kernel's code in no cache (ppo_step.h, k6_code_touch)
     for (int k = 0; k < update_times; ++k) {
         float *g = grads + (size_t)k * stride;
         int rc = erl_ppo_step_images_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions,

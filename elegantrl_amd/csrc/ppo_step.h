@@ -29,6 +29,12 @@ struct Ppo2Args {
                                // which finish ~5k cycles before the actor's, pull that minibatch's rows towards their XCD's L2
     int exp_net;          // -DERL_K6_EXP & 16 builds only (diagnostics): 0 = every workgroup runs the ACTOR's code path, 1 = the critic's, else by blockIdx.y
     int wg_map;           // the minibatch kernels' workgroup -> (network, slab) map: 0 = (blockIdx.y, blockIdx.x); 1 = by XCD, 2 = by shader engine (k6_wg_map below)
+    // the update loop's FIRST launch on a device whose instruction caches miss slowly (the workgroup-map measurement chose map 2): every
+    // workgroup first pulls the kernel's own code into its XCD's L2 with data loads (k6_code_touch below; 0 bytes: off).  pc_out: a one-off
+    // launch that only reports the kernel's program counter (how the host learns where the code lives; nullptr otherwise)
+    const unsigned char *code_touch = nullptr;
+    unsigned code_touch_bytes = 0;
+    unsigned long long *pc_out = nullptr;
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -276,6 +282,37 @@ bool erl_ppo_w4_supported(int S, int h1, int h2, int A);
 int erl_ppo_w4_launch(const Ppo2Args &g, int n_slabs, bool vec, hipStream_t stream);
 // ppo_step_s3.hip
 bool erl_ppo_s3_supported(int S, int h1, int h2, int A);
+// The first launch of an update loop finds the kernel's code in neither the instruction caches nor the L2s (the rollout ran in between).
+// On most boxes that costs 2 us; on the boxes with a slow instruction-cache miss path it costs 60 us (97 us for a 37 us kernel), because
+// every cache pulls its ~58 KB line by line from HBM.  With code_touch set, every workgroup starts by reading a slice of the code range as
+// DATA (16 bytes per lane; the 32 workgroups of an XCD cover 128 KB): the range arrives in each XCD's L2 in one HBM round trip and the
+// instruction fetches that follow hit there.  Returns true when the launch was the one-off program-counter report (the caller returns).
+__device__ __forceinline__ bool k6_code_touch(const Ppo2Args &g)
+{
+    if (g.pc_out) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            unsigned long long pc;
+            asm volatile("s_getpc_b64 %0" : "=s"(pc));
+            *g.pc_out = pc;
+        }
+        return true;
+    }
+    if (g.code_touch_bytes) {
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+        const size_t off = ((size_t)(L >> 3) * blockDim.x + threadIdx.x) * 16;          // L % 8 = the XCD, L / 8 = the workgroup's rank on it
+        if (off + 16 <= g.code_touch_bytes) {
+            const unsigned char *p = g.code_touch + off;
+            uint4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        }
+    }
+    return false;
+}
+// host side of it (ppo_step.hip): is the NEXT launch on this device the first of an update loop on a slow-fetch device (consumes the
+// request), and the code range of a kernel whose program counter is known (the loader's allocation around it, through ROCr)
+bool erl_k6_code_touch_wanted(int family);
+bool erl_k6_code_range(unsigned long long pc, size_t want_bytes, const unsigned char **base, unsigned *bytes);
+
 // host side of the workgroup map (k6_wg_map above; ppo_step.hip): one decision per device and kernel family (0: the (128 | 64, h2) kernels of
 // ppo_step_s3_impl.h, 1: the (256, h2[, h3]) kernels of ppo_step_wd_impl.h); `launch(map)` enqueues the kernel once under a map and
 // returns an ERL_* code

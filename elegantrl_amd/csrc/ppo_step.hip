@@ -26,6 +26,9 @@
 // instantiation is compile-time (tile counts are template parameters, out-of-range loads are clamped + selected instead
 // of branched).
 #include <stdlib.h>
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include "ppo_step.h"
 #include "ppo_step_wd.h"
@@ -540,6 +543,48 @@ int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std:
     return c.map;
 }
 
+// ---- code touch (ppo_step.h, k6_code_touch) ----------------------------------------------------------------------------------------
+// comm.cpp announces the first launch of an update loop; the launch that follows consumes the request if the device is one whose
+// instruction fetch is slow: the workgroup-map measurement chose map 2 there (ERL_K6_CODE_TOUCH=1 / 0 forces it on / off).
+static bool g_touch_request[kWgMapDevices] = {};
+void erl_k6_touch_next_launch()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kWgMapDevices) g_touch_request[dev] = true;
+}
+bool erl_k6_code_touch_wanted(int family)
+{
+    int dev = 0;
+    if (family < 0 || family >= kWgMapFamilies || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kWgMapDevices || !g_touch_request[dev]) return false;
+    g_touch_request[dev] = false;
+    const char *e = getenv("ERL_K6_CODE_TOUCH");
+    if (e && (*e == '0' || *e == '1')) return *e == '1';
+    return k6_wg_map_env() < 0 && g_wg_map[family][dev].map == kWgMapAlt;
+}
+// the loader's allocation around a kernel's program counter (ROCr, resolved at run time: libhsa-runtime64 is in the process under HIP):
+// [max(allocation base, pc - 512 rounded down to 256), min(allocation end, + want_bytes)), a multiple of 16 bytes
+bool erl_k6_code_range(unsigned long long pc, size_t want_bytes, const unsigned char **base, unsigned *bytes)
+{
+    using Fn = hsa_status_t (*)(const void *, hsa_amd_pointer_info_t *, void *(*)(size_t), uint32_t *, hsa_agent_t **);
+    static const Fn fn = (Fn)dlsym(RTLD_DEFAULT, "hsa_amd_pointer_info");
+    *base = nullptr;
+    *bytes = 0;
+    if (!fn || !pc) return false;
+    hsa_amd_pointer_info_t info;
+    memset(&info, 0, sizeof(info));
+    info.size = sizeof(info);
+    if (fn((const void *)pc, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN || !info.agentBaseAddress) return false;
+    const uintptr_t lo = (uintptr_t)info.agentBaseAddress, hi = lo + info.sizeInBytes;
+    uintptr_t b = ((uintptr_t)pc - 512) & ~(uintptr_t)255;
+    if (b < lo) b = lo;
+    uintptr_t e = b + want_bytes;
+    if (e > hi) e = hi;
+    if ((uintptr_t)pc < lo || (uintptr_t)pc >= hi || e <= b + 16) return false;
+    *base = (const unsigned char *)b;
+    *bytes = (unsigned)((e - b) & ~(uintptr_t)15);
+    return true;
+}
+
 extern "C" int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map2)
 {
     const int family = (device >> 8) & 0xff;              // ERL_PPO_WG_FAMILY_WIDE
@@ -613,6 +658,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
             t.wg_map = m;
             return pre ? erl_ppo_s3_launch_pre(t, n_slabs, vec, st) : erl_ppo_s3_launch(t, n_slabs, vec, st);
         });
+    if (split && erl_k6_code_touch_wanted(0)) g.code_touch_bytes = 1;          // (a request: launch_s3 resolves the range of its instantiation)
     g.span = erl_k6_timing_begin(st, n_slabs);
     int rc;
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else

@@ -978,6 +978,7 @@ __global__ __launch_bounds__(QNT) void ppo_step_s3_kernel(Ppo2Args g)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_s3[];
     const SpanT t_span = span_enter(g);
+    if (k6_code_touch(g)) return;
     SpanStamps sps{reinterpret_cast<uint32_t *>(smem_s3 + kS3LdsBytes - 32)};
     const K6Wg wg = k6_wg_map(g);
 #if ERL_K6_EXP & 16
@@ -1001,6 +1002,34 @@ int launch_s3(const Ppo2Args &g, int n_slabs, hipStream_t stream)
                                 "hipFuncSetAttribute(ppo_step_s3_kernel)");
         if (rc) return rc;
         attr_set = true;
+    }
+    if (g.code_touch_bytes) {
+        // a code-touch request (ppo_step.h k6_code_touch): where THIS instantiation's code lives on this device -- asked of the kernel
+        // itself once (a one-workgroup launch that reports its program counter; one stream sync per instantiation, device and process)
+        struct Range { bool tried = false; const unsigned char *base = nullptr; unsigned bytes = 0; };
+        static Range ranges[64];
+        int dev = 0;
+        Ppo2Args t = g;
+        t.code_touch = nullptr; t.code_touch_bytes = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            Range &r = ranges[dev];
+            if (!r.tried) {
+                r.tried = true;
+                unsigned long long *d_pc = nullptr, pc = 0;
+                if (hipMalloc((void **)&d_pc, sizeof(pc)) == hipSuccess) {
+                    Ppo2Args q = g;
+                    q.code_touch_bytes = 0; q.span = nullptr; q.pc_out = d_pc;
+                    hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(1, 1), dim3(QNT), kS3LdsBytes, stream, q);
+                    if (hipMemcpyAsync(&pc, d_pc, sizeof(pc), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess && pc)
+                        (void)erl_k6_code_range(pc, (size_t)128 << 10, &r.base, &r.bytes);
+                    (void)hipFree(d_pc);
+                }
+                (void)hipGetLastError();
+            }
+            t.code_touch = r.base; t.code_touch_bytes = r.base ? r.bytes : 0;
+        }
+        hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(n_slabs, 2), dim3(QNT), kS3LdsBytes, stream, t);
+        return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");
     }
     hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(n_slabs, 2), dim3(QNT), kS3LdsBytes, stream, g);
     return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");

@@ -57,6 +57,8 @@ inline size_t s3_image1_bytes(int h1, int S) { return (size_t)h1 * 6 * s3_image_
 // ppo_step.hip / grad_tail.hip: the entry points of the update loop (comm.cpp) that carry the images along
 // the arithmetic a call gets: its mode word's arith bits (ERL_PPO_MODE), else the process-wide default (ppo_step.hip)
 int erl_ppo_arith_for_call(int S, int h1, int h2, int A, int arith_call);
+// the next minibatch-kernel launch on the current device is the first of an update loop (ppo_step.hip: code touch on slow-fetch devices)
+void erl_k6_touch_next_launch();
 int erl_ppo_step_images_f32(const float *actor_params, const float *critic_params, const float *act_avg, const float *act_std,
                             const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
                             const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,

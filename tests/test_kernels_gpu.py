@@ -654,6 +654,41 @@ def test_ppo_step_workgroup_map_is_measured_once(ops, dev, monkeypatch):
         ops.ppo_set_arith(prev)
 
 
+def test_update_loop_code_touch_changes_nothing(ops, dev, monkeypatch):
+    """the update loop's first minibatch-kernel launch may start by pulling the kernel's own code into the XCDs' L2s with data loads
+    (csrc/ppo_step.h k6_code_touch: devices with a slow instruction-cache miss path; ERL_K6_CODE_TOUCH=1 forces it): a full-chip loop with
+    the touch forced on leaves the same weights, moments and gradient rows as one with it forced off, under every workgroup map"""
+    S, h1, h2, A, H, N, B, T = 64, 128, 128, 8, 9, 4000, 16384, 3
+    rng = np.random.default_rng(99)
+    buf = ppo_case(rng, H, N, S, A, B)[:6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
+    ids = cu(rng.integers(0, H * N, (T, B)), dev)
+    P0 = cu(np.concatenate([flat_params(actor), flat_params(critic)]), dev)
+    norm = [cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(critic.state_avg, dev), cu(critic.state_std, dev)]
+    tb = [cu(x, dev) for x in buf]
+    out = {}
+    prev = ops.ppo_set_arith("split")
+    try:
+        for touch, wg_map in (("0", "0"), ("1", "0"), ("1", "2"), ("1", "1")):
+            monkeypatch.setenv("ERL_K6_CODE_TOUCH", touch)
+            monkeypatch.setenv("ERL_K6_WG_MAP", wg_map)
+            P, M1, M2 = P0.clone(), th.zeros_like(P0), th.zeros_like(P0)
+            slabs, rows = th.full((n_slabs, stride), float("nan"), device=dev), th.full((T, stride), float("nan"), device=dev)
+            for rep in range(2):                                  # two loops: the second one's first launch touches with the range known
+                ops.ppo_update(P, M1, M2, *norm, S, h1, h2, A, *tb, ids, 0.25, 0.001, slabs, rows, 1 + T * rep, 1e-3, 3.0)
+            th.cuda.synchronize()
+            _hip.check_async_faults()
+            out[(touch, wg_map)] = [x.cpu().numpy().view(np.uint32) for x in (P, M1, M2, rows)]
+            assert np.isfinite(out[(touch, wg_map)][0].view(np.float32)).all()
+    finally:
+        ops.ppo_set_arith(prev)
+    ref = out[("0", "0")]
+    for key, got in out.items():
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), key
+
+
 def test_ppo_step_split_arith_at_benchmark_size(ops, dev):
     """BASELINE configs[3] at full size (4096 envs x 32 steps, minibatch 16384, obs 64, act 8, net [128,128]): the split-arithmetic
     kernel and the fp32-MFMA kernel on the same minibatch, both against the fp64 restatement -- 128 gradient slabs per network
