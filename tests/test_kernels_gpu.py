@@ -643,7 +643,8 @@ def test_ppo_step_workgroup_map_is_measured_once(ops, dev, monkeypatch):
         print("workgroup map on this box:", info)
         assert info["forced"] is None and info["map"] in (0, 2)
         assert info["us_map0"] and info["us_map2"] and 10.0 < info["us_map0"] < 500.0 and 10.0 < info["us_map2"] < 500.0
-        assert info["map"] == (2 if info["us_map2"] < 0.97 * info["us_map0"] else 0)
+        if abs(info["us_map2"] - 0.97 * info["us_map0"]) > 0.02:            # (the reported times are rounded to 0.01 us)
+            assert info["map"] == (2 if info["us_map2"] < 0.97 * info["us_map0"] else 0)
         monkeypatch.setenv("ERL_K6_WG_MAP", "0")
         b = th.full((n_slabs, stride), float("nan"), device=dev)
         ops.ppo_step(*args(b))
