@@ -782,6 +782,10 @@ def main():
     if (breakdown["boundaries_and_rest_per_minibatch_us"] or 0.0) < 0.0:
         log(f"WARNING: the sampled minibatch-kernel launches ({ppo_s * 1e6:.1f} us) ran longer than the update loop leaves for a launch "
             f"({breakdown['k6_us_upper_bound_by_difference']} us incl. its boundaries): on this box the sampled launches are not representative")
+    wg_info = _hip.ppo_wg_map_info(wide=wide)
+    if wg_info.get("us_map0") and wg_info.get("us_map2") and wg_info["us_map0"] > 1.15 * wg_info["us_map2"]:
+        log(f"NOTE: this box's instruction caches miss slowly (minibatch kernel back to back: {wg_info['us_map0']} us with both networks' code paths behind "
+            f"every instruction cache, {wg_info['us_map2']} us with one): the library chose workgroup map {wg_info['map']} and the code touch (DESIGN.md, K6 in round 5)")
     line = {
         "metric": cfg["metric"], "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
@@ -823,7 +827,11 @@ def main():
                      # where the kernel's workgroups run (include/erl_hip.h erl_ppo_wg_map_info): the device's first full-chip launch
                      # measured map 0 against map 2 (us_map0 / us_map2, back to back) and kept one -- map 2 on the boxes where two code paths
                      # per instruction cache cost 7-9 us per launch (DESIGN.md "K6 in round 5"), map 0 elsewhere
-                     "workgroup_map": _hip.ppo_wg_map_info(wide=wide),
+                     "workgroup_map": wg_info,
+                     # what that measurement says about the box: two ~58 KB code paths per instruction cache (map 0) cost > 15 % against one
+                     # (map 2) only where the instruction caches' miss path is slow (~1 box in 4-20 of the pool)
+                     "instruction_fetch": (None if not (wg_info.get("us_map0") and wg_info.get("us_map2")) else
+                                           "slow" if wg_info["us_map0"] > 1.15 * wg_info["us_map2"] else "normal"),
                      "kernel_us_rocprof": k6_rocprof_us, "kernel_us_rocprof_source": k6_rocprof_src,
                      # this box against the box the committed rocprofv3 summary was collected on (same sources): avg_launch_us / kernel_us_rocprof
                      "box_ratio": box_ratio,
