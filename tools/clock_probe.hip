@@ -210,6 +210,62 @@ __global__ __launch_bounds__(256) void code_walk(float *sink, unsigned long long
     if (x == 12345.678f) { lds_pad[threadIdx.x] = x; sink[0] = lds_pad[0]; }
 }
 
+// the instruction caches' capacity: ONE block of KB kilobytes walked by every workgroup, back to back -- microseconds per KB stay flat while
+// the block fits and rise where it does not (visibly so only on a box whose instruction-cache miss path is slow)
+#define STR2(x) #x
+#define STR(x) STR2(x)
+template <int KB>
+__global__ __launch_bounds__(256) void code_size_walk(float *sink)
+{
+    extern __shared__ float lds_pad[];
+    float x = (float)threadIdx.x;
+    static_assert(KB == 40 || KB == 48 || KB == 56 || KB == 60 || KB == 64 || KB == 68 || KB == 72 || KB == 80 || KB == 96, "sizes");
+    if (KB == 40) asm volatile(".rept 10240\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 48) asm volatile(".rept 12288\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 56) asm volatile(".rept 14336\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 60) asm volatile(".rept 15360\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 64) asm volatile(".rept 16384\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 68) asm volatile(".rept 17408\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 72) asm volatile(".rept 18432\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 80) asm volatile(".rept 20480\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (KB == 96) asm volatile(".rept 24576\n v_add_f32 %0, %0, %0\n.endr" : "+v"(x));
+    if (x == 12345.678f) { lds_pad[threadIdx.x] = x; sink[0] = lds_pad[0]; }
+}
+
+template <int KB>
+double run_code_size(float *sink)
+{
+    const int lds = 155 * 1024;
+    CHECK(hipFuncSetAttribute((const void *)code_size_walk<KB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(code_size_walk<KB>, dim3(128, 2), dim3(256), lds, 0, sink);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(code_size_walk<KB>, dim3(128, 2), dim3(256), lds, 0, sink);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3 / 20;
+}
+
+void run_code_sizes()
+{
+    float *sink;
+    CHECK(hipMalloc(&sink, 4));
+    printf("\"code_walk_us_by_KB\": {\"40\": %.1f, ", run_code_size<40>(sink));
+    printf("\"48\": %.1f, ", run_code_size<48>(sink));
+    printf("\"56\": %.1f, ", run_code_size<56>(sink));
+    printf("\"60\": %.1f, ", run_code_size<60>(sink));
+    printf("\"64\": %.1f, ", run_code_size<64>(sink));
+    printf("\"68\": %.1f, ", run_code_size<68>(sink));
+    printf("\"72\": %.1f, ", run_code_size<72>(sink));
+    printf("\"80\": %.1f, ", run_code_size<80>(sink));
+    printf("\"96\": %.1f}, ", run_code_size<96>(sink));
+    CHECK(hipFree(sink));
+}
+
 template <int MODE>
 void run_code_walk(const char *name, int khz, bool last)
 {
@@ -333,6 +389,7 @@ int main()
     // ~100-200 us per launch, 24 launches each: long enough for the power manager to settle on the body's clock
     run_code_memory();
     run_code_walks(khz);
+    run_code_sizes();
     run_k6like(khz, 120, 24);
     run<0>("mfma_bf16_32x32x16", 16, 400, 24, khz, false);
     run<1>("mfma_f32_32x32x2", 16, 200, 24, khz, false);
