@@ -150,6 +150,7 @@ def gae_sweep(ops, dev):
     KERNEL's (18 algorithmic bytes per element / kernel_us)."""
     from elegantrl_amd import _hip
     out = []
+    flush = None
     for H, N in [(32, 4096), (128, 4096), (200, 4096), (1024, 4096), (2048, 4096), (4096, 4096), (32, 32768)]:   # SURVEY 8d sizes (+ 4096 x 4096)
         g = th.Generator(device=dev).manual_seed(0)
         r, v = th.randn((H, N), device=dev, generator=g), th.randn((H, N), device=dev, generator=g)
@@ -171,11 +172,27 @@ def gae_sweep(ops, dev):
         th.cuda.synchronize()
         kernel_us, n_k = _hip.kernel_span_read(_hip.SPAN_GAE)
         _hip.kernel_span_enable(False)
+        # COLD: the back-to-back calls above re-read the same inputs, and 84 MB of them (2048 x 4096) fit the 256 MB Infinity Cache -- that
+        # figure is the kernel on warm inputs.  Here a 640 MB buffer is rewritten between calls, so every call finds its inputs in HBM only,
+        # as the scan does in a training loop behind a rollout's writes (`--config cd` measures exactly that, in the loop).
+        if flush is None:
+            flush = th.zeros(640 << 20, dtype=th.uint8, device=dev)
+        _hip.kernel_span_enable(True)
+        for _ in range(8):
+            flush.add_(1)
+            run()
+        th.cuda.synchronize()
+        cold_us, n_c = _hip.kernel_span_read(_hip.SPAN_GAE)
+        _hip.kernel_span_enable(False)
         call_s = e0.elapsed_time(e1) * 1e-3 / iters
         sec = kernel_us * 1e-6 if kernel_us else call_s
         gbps = 18.0 * H * N / sec / 1e9
-        out.append({"H": H, "N": N, "bytes": 18 * H * N, "kernel_us": round(kernel_us, 2) if kernel_us else None, "call_us": round(call_s * 1e6, 2),
+        out.append({"H": H, "N": N, "bytes": 18 * H * N, "kernel_us": round(kernel_us, 2) if kernel_us else None,
+                    "cold_kernel_us": round(cold_us, 2) if cold_us else None, "call_us": round(call_s * 1e6, 2),
                     "us": round(sec * 1e6, 2), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                    "cold_GBps": round(18.0 * H * N / cold_us / 1e3, 1) if cold_us else None,
+                    "cold_frac": round(18.0 * H * N / cold_us / 1e3 / HBM_PEAK_GBPS, 4) if cold_us else None,
+                    "inputs": "kernel_us / frac: warm (the same inputs again and again: Infinity Cache); cold_*: a 640 MB buffer rewritten between calls",
                     "call_GBps": round(18.0 * H * N / call_s / 1e9, 1)})
     return out
 
@@ -302,6 +319,22 @@ def emit(line: dict):
         sys.stdout.flush()
     else:
         os.write(_JSON_FD, data)
+
+
+def self_launch(n: int):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment): start the N ranks ourselves, exactly as the
+    driver's documented form does -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <the same arguments>` -- on a free port, and hand its stdout (rank 0's ONE JSON line) and exit code through.  The reference's
+    analog is train_agent_multiprocessing_multi_gpu starting its Learner / Worker processes itself (elegantrl/train/run.py:165-202)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
 
 def quiet_gc():
@@ -539,6 +572,8 @@ def main():
                          "c3 = SAC on a 1e6-transition ring, c5 = Ant-shaped 8192 envs, cw = the reference demo's (256,128) network, "
                          "cd = the reference's default horizon / batch shape (2048 x 4096 rollout, 128 minibatches of 128)")
     opt = ap.parse_args()
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(opt.gpus)
     claim_stdout()
     if opt.cpu_baseline_only:
         emit(cpu_baseline(opt.cpu_iters, opt.config))

@@ -286,7 +286,8 @@ def kernel_span_enable(every_nth) -> None:
 
 
 def kernel_span_read(tag: int):
-    """(mean span in microseconds or None, number of launches) of the tagged kernel since the hook was enabled / last read"""
+    """(mean span in microseconds or None, number of launches) of the tagged kernel's sampled launches since the hook was ENABLED (the
+    records are not cleared by a read: enable again to start a new window; launches on another device than the enabling one leave none)"""
     us, n = ctypes.c_double(0), c_int(0)
     check(lib().erl_kernel_span_read(int(tag), ctypes.byref(us), ctypes.byref(n)), "erl_kernel_span_read")
     return (us.value / n.value if n.value else None), n.value

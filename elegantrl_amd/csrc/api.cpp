@@ -105,6 +105,7 @@ static hipEvent_t g_k6_open = nullptr;
 constexpr int kK6SpanWords = 8, kK6SpanPhases = 7;   // = kSpanWords, kSpanPhases of ppo_step.h: one record per WORKGROUP
 constexpr size_t kK6PoolWords = (size_t)4 << 20;     // 32 MiB of records: 2048 sampled launches of 256 workgroups
 static unsigned long long *g_k6_pool = nullptr;      // device
+static int g_k6_pool_dev = -1;                       // ... the one that was current when the hook was enabled: launches elsewhere are not sampled
 static size_t g_k6_pool_used = 0;
 struct K6Launch {
     size_t off;          // first word of the launch's records in the pool
@@ -126,6 +127,14 @@ static std::vector<unsigned long long> g_k6_last_records[2];    // raw per-workg
 
 static void k6_span_reset()
 {
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (g_k6_pool && dev != g_k6_pool_dev) {
+        (void)hipFree(g_k6_pool);
+        g_k6_pool = nullptr;
+        g_k6_pool_used = 0;
+    }
+    g_k6_pool_dev = dev;
     if (!g_k6_pool && hipMalloc((void **)&g_k6_pool, kK6PoolWords * sizeof(unsigned long long)) != hipSuccess) {
         g_k6_pool = nullptr;
         (void)hipGetLastError();
@@ -143,6 +152,8 @@ static void k6_span_reset()
 unsigned long long *erl_k6_timing_begin(hipStream_t stream, int n_slabs)
 {
     if (!g_k6_timing) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != g_k6_pool_dev) return nullptr;    // (the record pool is one device's memory)
     const long k = g_k6_launch++ % g_k6_timing;
     g_k6_skip = k != 0;
     const bool free_sample = g_k6_timing >= 2 && k == g_k6_timing / 2;
@@ -203,8 +214,8 @@ extern "C" int erl_k6_timing_read2(double *event_ms, double *span_ms, int *launc
     double span = 0.0;
     g_k6_stats[0] = g_k6_stats[1] = K6Stats{};
     if (g_k6_pool && !g_k6_launches.empty()) {
-        int dev = 0, khz = 0;
-        (void)hipGetDevice(&dev);
+        int khz = 0;
+        const int dev = g_k6_pool_dev;                                   // the clock of the device the records were written on
         (void)hipDeviceSynchronize();
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
         std::vector<unsigned long long> h(g_k6_pool_used);
@@ -320,10 +331,13 @@ struct SpanLaunch {
 static std::vector<SpanLaunch> g_span_launches;
 static long g_span_count[kSpanTags] = {};
 static int g_span_every = 0;                                     // 0 = off, n = every n-th launch of a tag is sampled
+static int g_span_dev = -1;                                      // the device the pool lives on: launches on another device leave no record
 
 unsigned long long *erl_span_slot(int tag, int64_t n_workgroups)
 {
     if (!g_span_every || !g_span_pool || tag < 0 || tag >= kSpanTags || n_workgroups < 1) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != g_span_dev) return nullptr;      // (the pool is one device's memory)
     if (g_span_count[tag]++ % g_span_every) return nullptr;
     const size_t words = 2 * (size_t)n_workgroups;
     if (g_span_pool_used + words > kSpanPoolWords) return nullptr;
@@ -337,11 +351,19 @@ extern "C" void erl_kernel_span_enable(int every_nth)
     g_span_every = every_nth > 0 ? every_nth : 0;
     for (long &c : g_span_count) c = 0;
     if (!g_span_every) return;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (g_span_pool && dev != g_span_dev) {                      // enabled again from another device: the pool moves with it
+        (void)hipFree(g_span_pool);
+        g_span_pool = nullptr;
+        g_span_pool_used = 0;
+    }
     if (!g_span_pool && hipMalloc((void **)&g_span_pool, kSpanPoolWords * sizeof(unsigned long long)) != hipSuccess) {
         g_span_pool = nullptr;
         (void)hipGetLastError();
         return;
     }
+    g_span_dev = dev;
     (void)hipDeviceSynchronize();
     (void)hipMemset(g_span_pool, 0, (g_span_pool_used ? g_span_pool_used : kSpanPoolWords) * sizeof(unsigned long long));
     g_span_pool_used = 0;
@@ -358,9 +380,8 @@ extern "C" int erl_kernel_span_read(int tag, double *total_us, int *launches)
     if (g_span_pool && g_span_pool_used) {
         int rc = erl_hip_status(hipDeviceSynchronize(), "hipDeviceSynchronize");
         if (rc) return rc;
-        int dev = 0, khz = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g_span_dev) != hipSuccess || khz <= 0) khz = 100000;
         std::vector<unsigned long long> h;
         for (const SpanLaunch &L : g_span_launches) {
             if (L.tag != tag) continue;

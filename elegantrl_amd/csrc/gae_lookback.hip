@@ -25,6 +25,8 @@
 // whose table exceeds that buffer, or calls on a second stream, use the caller's workspace with a memset instead.
 #include "erl_common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int LB_MAX_WAVES = 16;
@@ -45,6 +47,7 @@ struct LbArgs {
     double *partials;          // [gridDim.x][3]
     uint32_t *fault;           // host-mapped counter of look-back spin timeouts (erl_async_fault_count); may be NULL
     uint32_t spin_limit;       // polls per granule before a predecessor is declared lost
+    uint32_t publish_delay;    // ERL_GAE_LB_DELAY=n (tests): every second slab sleeps n x 128 x 64 clocks before it publishes anything
     uint32_t publish_nonce;    // == nonce; ERL_GAE_LB_FAULT=1 (tests) publishes under a foreign nonce so readers time out
     unsigned long long *span;  // measurement hook (erl_common.h: erl_span_*); nullptr = off
 };
@@ -184,6 +187,8 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
         const uint32_t tagbase = g.publish_nonce << 2;
         unsigned long long *mine = g.slots + (size_t)kk * N + n0;
         const bool has_reader = kk + 1 < g.K;
+        if (g.publish_delay && (kk & 1))
+            for (uint32_t i = 0; i < g.publish_delay * 128u; ++i) __builtin_amdgcn_s_sleep(127);
         if (live && has_reader) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -194,24 +199,57 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
             float accA[4] = {0.f, 0.f, 0.f, 0.f}, accP[4] = {1.f, 1.f, 1.f, 1.f};
             uint32_t open = 0xFu;   // envs whose carry still depends on later slabs
             // The walk over the later slabs' granules, latest first.  Round 5: the lane's four granules of a slab are ONE 32-byte line
-            // segment and the granules of several slabs do not depend on each other, so a round fetches LB_BATCH slabs x 4 envs with
+            // segment and the granules of several slabs do not depend on each other, so a round fetches LB_BATCH (2 or 4) slabs x 4 envs with
             // two 16-byte agent-scope loads per slab, all in flight together, and consumes them in order while they are valid (round
             // 4 issued one 8-byte load per env and slab and waited for each: up to 4 (K - 1) dependent round trips -- at 200 x 4096,
             // K = 7, the scan's 9.4 us were mostly this chain).  A granule carries its own validity (the launch's nonce), so reading
             // ahead is safe: what is not published yet is simply fetched again.
-            constexpr int LB_BATCH = 2;
+            constexpr int LB_BATCH = L >= 8 ? 2 : 4;      // (the L = 8 / 16 instantiations sit at their register budgets: 128 / 256)
             int j = kk - 1;
             uint32_t spins = 0;
             while (j >= 0 && open) {
                 unsigned long long gr[LB_BATCH][4];
+                {
+                    // ALL loads of the round and the wait for them in ONE asm statement: the compiler's waitcnt pass does not see
+                    // inline-asm loads, so with the wait in a statement of its own nothing kept a register copy (or a spill) from being
+                    // scheduled between the loads and the wait and reading a destination before its data had landed (round 5's form;
+                    // its wait also sat inside the per-slab loop, which serialised the two slabs' fetches).  Each 16-byte load covers
+                    // two granules that their writer publishes with ONE 8-byte store each (`__hip_atomic_store`, a single
+                    // global_store_dwordx2): a naturally aligned 16-byte segment of one 32-byte sector is read in one piece, and a
+                    // granule is only trusted once its own nonce matches, so a granule is either seen whole or seen stale and fetched
+                    // again (stressed by tests/test_kernels_gpu.py::test_gae_lookback_with_delayed_publishers).
+                    const unsigned long long *src[LB_BATCH];
 #pragma unroll
-                for (int b = 0; b < LB_BATCH; ++b) {
-                    const unsigned long long *src = g.slots + (size_t)(j - b >= 0 ? j - b : 0) * N + n0;
-                    u64x2 lo, hi;
-                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1"
-                                 : "=&v"(lo), "=&v"(hi) : "v"(src) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
-                    gr[b][0] = lo.x; gr[b][1] = lo.y; gr[b][2] = hi.x; gr[b][3] = hi.y;
+                    for (int b = 0; b < LB_BATCH; ++b) src[b] = g.slots + (size_t)(j - b >= 0 ? j - b : 0) * N + n0;
+                    u64x2 q[2 * LB_BATCH];
+                    if constexpr (LB_BATCH == 2) {
+                        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                                     "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %2, %5, off sc1\n\t"
+                                     "global_load_dwordx4 %3, %5, off offset:16 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+                                     : "v"(src[0]), "v"(src[1])
+                                     : "memory");
+                    } else {
+                        static_assert(LB_BATCH == 2 || LB_BATCH == 4, "the asm fetches two or four slabs");
+                        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                                     "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %2, %9, off sc1\n\t"
+                                     "global_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %4, %10, off sc1\n\t"
+                                     "global_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %6, %11, off sc1\n\t"
+                                     "global_load_dwordx4 %7, %11, off offset:16 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3])
+                                     : "memory");
+                    }
+#pragma unroll
+                    for (int b = 0; b < LB_BATCH; ++b) {
+                        gr[b][0] = q[2 * b].x; gr[b][1] = q[2 * b].y; gr[b][2] = q[2 * b + 1].x; gr[b][3] = q[2 * b + 1].y;
+                    }
                 }
                 int consumed = 0;
 #pragma unroll
@@ -366,6 +404,7 @@ struct LbTable {
 };
 static LbTable g_lb_table[kLbMaxTables];
 static int g_lb_tables = 0;
+static std::mutex g_lb_mutex;      // table lookup / creation / nonce hand-out (agents on several devices or streams launch from their own threads)
 
 // Enqueues [memset +] kernel.  workspace layout (fallback path): [ticket: 256 B][slots: K*N*8 B][partials: nblk*24 B].
 // Returns the number of statistics partials (blocks) through *nparts and their location through *partials.
@@ -401,6 +440,7 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     // fast path: the library-owned table (no clearing); fallback: the caller's workspace, cleared by a memset
     LbTable *tab = nullptr;
     int dev = -1;
+    std::lock_guard<std::mutex> lock(g_lb_mutex);
     if (!getenv("ERL_GAE_LB_NO_TABLE") && hipGetDevice(&dev) == hipSuccess && dev >= 0 && 256 + slot_bytes <= kLbTableBytes) {
         for (int i = 0; i < g_lb_tables && !tab; ++i)
             if (g_lb_table[i].dev == dev && g_lb_table[i].stream == stream) tab = &g_lb_table[i];
@@ -435,6 +475,7 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
         int rc = erl_hip_status(hipMemsetAsync(ws, 0, 256 + (K > 1 ? slot_bytes : 0), stream), "hipMemsetAsync(lookback slots)");
         if (rc) return rc;
     }
+    g.publish_delay = (uint32_t)env_int("ERL_GAE_LB_DELAY", 0);
     g.publish_nonce = env_int("ERL_GAE_LB_FAULT", 0) ? (g.nonce ^ 0x15555555u) & 0x3fffffffu : g.nonce;
     const dim3 grid((unsigned)(K * G)), block(W * 64);
 #define LB_LAUNCH(LL)                                                                                  \

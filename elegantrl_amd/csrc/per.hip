@@ -35,7 +35,7 @@ __device__ __forceinline__ bool per_item(const PerItems &it, int64_t i, int64_t 
         const int64_t q64 = it.ids1[i];
         q = (int)q64;
         const float t = fminf(fmaxf(it.td[i], 1e-8f), 10.f);            // td_error.clamp(1e-8, 10).pow(per_alpha)   (:168)
-        p = powf(t, it.alpha);
+        p = it.alpha == 1.f ? t : powf(t, it.alpha);                    // (alpha = 1: the priorities as given, exactly)
         return row >= 0 && row < it.max_size && q64 >= 0 && q64 < it.Q;
     } else {
         const int64_t r = i / it.Q;

@@ -34,6 +34,7 @@
 #include "ppo_step_wd.h"
 #include "s3_image.h"
 #include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -503,7 +504,7 @@ extern "C" int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A)
 extern "C" int erl_ppo_num_slabs(int64_t B) { return B >= 1 && B < (1LL << 37) ? (int)erl_cdiv(B, PB) : -1; }
 
 // Which workgroup map this launch runs under.  Not forced and not measured yet on this device for this kernel family: launch the kernel
-// with the CALL'S OWN arguments under both maps, alternating (1 + 4 launches per leg, 2 legs per map, HIP events on the call's stream; the
+// with the CALL'S OWN arguments under both maps, alternating (1 + 4 launches per leg, 3 legs per map, HIP events on the call's stream; the
 // kernel writes nothing but the gradient slabs and its scratch, which the real launch that follows rewrites) and keep map 2 when it is
 // at least 3 % faster (map 1 and map 2 recover the same boxes; map 2 costs the others nothing, map 1 ~1.2 us: map 2 is the candidate).  Only a launch that fills the chip (>= 256 workgroups) decides; a capturing stream or a failed event leaves the
 // decision to a later call.
@@ -513,13 +514,15 @@ int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std:
     if (forced >= 0) return forced;
     int dev = 0;
     if (family < 0 || family >= kWgMapFamilies || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kWgMapDevices) return 0;
+    static std::mutex mu;                              // agents of several devices may step from their own threads
+    std::lock_guard<std::mutex> lock(mu);
     WgMapChoice &c = g_wg_map[family][dev];
     if (c.map >= 0) return c.map;
     if (2 * n_slabs < 256) return 0;
     if (getenv("ERL_K6_NO_TUNE")) return 0;            // (diagnostics: no measurement, map 0)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
-    constexpr int kLegs = 2, kReps = 4;
+    constexpr int kLegs = 3, kReps = 4;                 // three alternations; map 2 must win EVERY one of them by 3 % (round 6: was one pooled comparison of two)
     hipEvent_t ev[2 * kLegs][2] = {};
     bool ok = true;
     for (auto &e : ev) ok = ok && hipEventCreate(&e[0]) == hipSuccess && hipEventCreate(&e[1]) == hipSuccess;
@@ -530,16 +533,19 @@ int erl_k6_wg_map_for_launch(int family, int n_slabs, hipStream_t st, const std:
         }
         ok = ok && hipEventRecord(ev[leg][1], st) == hipSuccess;
     }
-    double us[2] = {0.0, 0.0};
+    double us[2] = {0.0, 0.0}, leg_us[2 * kLegs] = {};
     for (int leg = 0; ok && leg < 2 * kLegs; ++leg) {
         float ms = 0.f;
         ok = hipEventSynchronize(ev[leg][1]) == hipSuccess && hipEventElapsedTime(&ms, ev[leg][0], ev[leg][1]) == hipSuccess;
-        us[leg & 1] += (double)ms * 1e3 / (kLegs * kReps);
+        leg_us[leg] = (double)ms * 1e3 / kReps;
+        us[leg & 1] += leg_us[leg] / kLegs;
     }
     for (auto &e : ev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
     if (!ok) { (void)hipGetLastError(); return 0; }
+    bool alt_wins = true;
+    for (int i = 0; i < kLegs; ++i) alt_wins = alt_wins && leg_us[2 * i + 1] < 0.97 * leg_us[2 * i];
     c.us[0] = us[0]; c.us[1] = us[1];
-    c.map = us[1] < 0.97 * us[0] ? kWgMapAlt : 0;
+    c.map = alt_wins ? kWgMapAlt : 0;
     return c.map;
 }
 

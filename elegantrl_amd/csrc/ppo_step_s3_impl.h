@@ -289,13 +289,13 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
                 asm volatile("" : "+v"(v0[i]), "+v"(v1[i]));
             } else if (s == 1) {
                 sh[i] = pk_bf16(v0[i], v1[i]);
-                v0[i] -= bf_lo(sh[i]);
-                v1[i] -= bf_hi(sh[i]);
+                v0[i] = sub_bf_lo(v0[i], sh[i]);
+                v1[i] = sub_bf_hi(v1[i], sh[i]);
                 asm volatile("" : "+v"(sh[i]), "+v"(v0[i]), "+v"(v1[i]));
             } else if (s == 2) {
                 sm[i] = pk_bf16(v0[i], v1[i]);
-                v0[i] -= bf_lo(sm[i]);
-                v1[i] -= bf_hi(sm[i]);
+                v0[i] = sub_bf_lo(v0[i], sm[i]);
+                v1[i] = sub_bf_hi(v1[i], sm[i]);
                 asm volatile("" : "+v"(sm[i]), "+v"(v0[i]), "+v"(v1[i]));
             } else if (s == 3) {
                 uint32_t l = pk_bf16(v0[i], v1[i]);

@@ -26,14 +26,45 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b)      // v_cvt_pk_b
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
+// The residual x - (one half of the packed pair p), the step between two levels of a split.  ERL_SPLIT_DOT2 (default 1; round 6):
+// ONE instruction, v_dot2_f32_bf16 D = A.lo B.lo + A.hi B.hi + C with B = {-1, 0} / {0, -1} from a scalar register, instead of
+// unpack (v_lshlrev_b32 / v_and_b32) + v_sub_f32: 4 vector instructions less per pair of a three-way split (11 -> 7; in the minibatch
+// kernels ~900 of 6 300 per lane, 7 KB of code per network path).  The same bits: p's half is x rounded to 8 significant bits, so the
+// difference is exactly representable, and -1 * half + 0 * other + x has nothing to round whatever the instruction's internal order
+// (tools/dot2_split_probe.hip compares the two forms bitwise over 8 M pairs of every class -- normal, tiny, denormal, already bf16 --
+// on the device: profiles/r06_dot2_split_probe.json; 0 disables).
+#ifndef ERL_SPLIT_DOT2
+#define ERL_SPLIT_DOT2 1
+#endif
+__device__ __forceinline__ float sub_bf_lo(float x, uint32_t p)
+{
+#if ERL_SPLIT_DOT2
+    float r;
+    asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r) : "v"(p), "s"(0x0000bf80u), "v"(x));
+    return r;
+#else
+    return x - bf_lo(p);
+#endif
+}
+__device__ __forceinline__ float sub_bf_hi(float x, uint32_t p)
+{
+#if ERL_SPLIT_DOT2
+    float r;
+    asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r) : "v"(p), "s"(0xbf800000u), "v"(x));
+    return r;
+#else
+    return x - bf_hi(p);
+#endif
+}
+
 // (x0, x1) -> three packed bf16 pairs with h + m + l == x exactly (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|, the last residual has
 // <= 8 significant bits left)
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l)
 {
     h = pk_bf16(x0, x1);
-    const float r0 = x0 - bf_lo(h), r1 = x1 - bf_hi(h);
+    const float r0 = sub_bf_lo(x0, h), r1 = sub_bf_hi(x1, h);
     m = pk_bf16(r0, r1);
-    const float q0 = r0 - bf_lo(m), q1 = r1 - bf_hi(m);
+    const float q0 = sub_bf_lo(r0, m), q1 = sub_bf_hi(r1, m);
     l = pk_bf16(q0, q1);
 }
 

@@ -12,7 +12,12 @@
  *  - every tensor is caller-allocated, caller-owned device memory (torch tensors in practice).  The library
  *    itself owns only: a last-error string, an RCCL communicator behind erl_comm_* handles, and one 8 MiB look-back table
  *    per (device, stream) that launches the single-pass GAE scan (allocated on first use, at most 16; see ERL_GAE_ALGO_LOOKBACK).
- *  - all work is enqueued on `stream`; nothing synchronises the host.
+ *  - all work is enqueued on `stream`; nothing synchronises the host -- with ONE exception per device and process: the first
+ *    minibatch-kernel launch that fills the chip (>= 256 workgroups; erl_ppo_step_f32 / erl_ppo_update*_f32 / erl_mlpn_ppo_step_f32)
+ *    measures the kernel under two workgroup maps (30 extra launches between HIP events, ~1 ms, hipEventSynchronize) and, on a device
+ *    that chose map 2, resolves the kernel's code range once (one small hipMalloc / hipStreamSynchronize / hipFree).  Results are
+ *    bit-identical under every map.  ERL_K6_WG_MAP=0|1|2 or ERL_K6_NO_TUNE=1 in the environment skips the measurement; agents make
+ *    that first launch in their warm-up, not in a timed or captured region (a capturing stream defers it).
  *  - layout at the seam is the reference's: time-major (H, N, .) row-major contiguous, fp32 values,
  *    1-byte flags (torch.bool), int64 indices.
  *  - return value: 0 = ok; ERL_EINVAL (-1) = bad argument; -(1000 + hipError_t) = HIP runtime error.

@@ -627,6 +627,52 @@ def make_cum_rewards():
     print("wrote", path)
 
 
+def make_per_update():
+    """Row f2, the half of the reference's prioritised replay that DOES run: SumTree.update_ids (elegantrl/train/replay_buffer.py:249-258),
+    driven the way the reference drives it -- ReplayBuffer(if_use_per=True).update appends rows at priority 10 (:107-115), then
+    td_error_update_for_per's formula prob = td_error.clamp(1e-8, 10).pow(per_alpha) (:168) goes into update_ids for every sequence's
+    tree.  Only power-of-two buffer lengths: there the reference's 0-based heap (root 0, leaves at buf_len - 1 + row) is the heap of
+    csrc/per.hip shifted by one node (root 1, leaves at L + row).  The reference's propagation loop runs `depth - 2` times (:254), i.e. it
+    recomputes the tree levels 1 .. depth - 2 below the root and never the root itself; the fixture stores its whole tensor after every
+    step and the tests compare exactly the levels it touched (`levels_updated`).  important_sampling asserts (tests/test_per.py) and is
+    not part of the fixture."""
+    sys.path.insert(0, REF)
+    from elegantrl.train.config import Config
+    from elegantrl.train.replay_buffer import ReplayBuffer
+
+    th.manual_seed(51)
+    g = {}
+    # (no append wraps: the reference's PER branch raises on a wrapping append -- th.arange(self.p, p) with p already reduced, :109 --
+    # recorded by tests/test_per.py::test_reference_per_append_raises_on_wrap)
+    cases = [(8, 2, [3, 4]), (1024, 3, [400, 500, 124]), (4096, 1, [4000, 96])]
+    g["cases"] = np.array([(m, q, len(a)) for m, q, a in cases], dtype=np.int64)
+    for ci, (max_size, Q, adds) in enumerate(cases):
+        args = Config()
+        args.per_alpha, args.per_beta = 0.6, 0.4
+        buf = ReplayBuffer(max_size=max_size, state_dim=3, action_dim=2, gpu_id=-1, num_seqs=Q, if_use_per=True, args=args)
+        depth = buf.sum_trees[0].depth
+        g[f"c{ci}_depth"] = np.array([depth, depth - 2])          # levels_updated = depth - 2 (counted up from the leaves' parents)
+        for k, add in enumerate(adds):
+            p0 = buf.p
+            items = (th.randn(add, Q, 3), th.randn(add, Q, 2), th.randn(add, Q), th.rand(add, Q) > 0.1, th.rand(add, Q) > 0.1)
+            buf.update(items)
+            g[f"c{ci}_s{k}_append"] = np.array([p0, add, buf.p, buf.cur_size, int(buf.if_full)], dtype=np.int64)
+            g[f"c{ci}_s{k}_tree_after_append"] = np.stack([np32(t.tree) for t in buf.sum_trees])
+            # a td-error update on DISTINCT rows of every sequence (repeats are resolved by a rule of ours, oracle/per_numpy.py D7)
+            n = min(buf.cur_size, 64 if max_size > 8 else 3)
+            ids0 = th.stack([th.randperm(buf.cur_size)[:n] for _ in range(Q)])            # (Q, n) rows
+            td = th.rand(Q, n) * 12.0
+            td[:, 0] = 0.0                                                                  # the clamp's lower edge
+            prob = td.clamp(1e-8, 10).pow(buf.per_alpha)                                     # replay_buffer.py:168
+            for q in range(Q):
+                buf.sum_trees[q].update_ids(ids0[q], prob[q])
+            g[f"c{ci}_s{k}_ids0"], g[f"c{ci}_s{k}_td"], g[f"c{ci}_s{k}_prob"] = ids0.numpy(), np32(td), np32(prob)
+            g[f"c{ci}_s{k}_tree_after_td"] = np.stack([np32(t.tree) for t in buf.sum_trees])
+    path = os.path.join(OUT, "per_update.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, {k: v.shape for k, v in g.items() if "tree_after_td" in k})
+
+
 def make_evaluator():
     """the reference's Evaluator (elegantrl/train/evaluator.py:12-155) driven with a toy single env and a toy vectorised env
     (tests/helpers.py) through a fixed schedule of evaluate_and_save calls: the files it leaves in cwd and recorder.npy."""
@@ -691,3 +737,4 @@ if __name__ == "__main__":
     make_evaluator()
     make_sac_mod("small", N=4, S=11, A=3, rows=40, net_dims=(64, 32), batch_size=64, n_updates=4, seed=23)
     make_state_norm()
+    make_per_update()

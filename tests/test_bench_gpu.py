@@ -87,3 +87,20 @@ def test_bench_falls_back_when_the_p2p_probe_child_dies():
     assert a["p2p_probe"] != "ok" and ("exited with 7" in a["p2p_probe"] or "another rank" in a["p2p_probe"]), a
     assert a["p2p_selftest"].startswith("not run") and a["rccl_selftest"] == "not tried" and a["selected"] == "torch.distributed", a
     assert line["n_gpus"] == 4 and line["value"] > 0 and a["stats_exchange"] == "torch.distributed"
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """plain `python bench.py --gpus 2` -- no torchrun around it, no WORLD_SIZE in the environment: bench.py starts the two ranks itself
+    (`self_launch`), rank 0's single line comes through with n_gpus = 2, the exchange route it chose, what RCCL saw, every rank's own time"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "cr", "--steps", "2", "--warmup", "1", "--no-gae-sweep", "--no-smi"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(env, ERL_DIST_BACKEND="gloo"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["name"] == "cr" and line["value"] > 0
+    a = line["allreduce"]
+    assert "ranks_seen_by_rccl" in a and a["selected"] and a["calls_per_step"] == 4
+    pr = line["extra"]["per_rank_ms_per_step"]
+    assert 0 < pr["min"] <= pr["max"]

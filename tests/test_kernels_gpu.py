@@ -184,6 +184,47 @@ def test_gae_lookback_timeout_is_reported_not_silent(ops, dev, monkeypatch):
     _hip.check_async_faults()
 
 
+@pytest.mark.parametrize("L,W,delay", [(4, 8, 1), (4, 8, 6), (2, 4, 3), (8, 16, 2), (16, 8, 2)])
+def test_gae_lookback_with_delayed_publishers(ops, dev, L, W, delay, monkeypatch):
+    """the look-back walk reads four granules of two (L >= 8) or four slabs per round with 16-byte loads, all issued and waited for in ONE
+    asm statement (round 6; ADVICE r05: the wait was a statement of its own), and trusts a granule only when its own nonce matches.
+    ERL_GAE_LB_DELAY makes every second slab sleep `delay` x 128 x 64 clocks before it publishes anything, so readers poll stale tables
+    for long and meet aggregates and inclusive values in every mix: long undone chains, results within 1e-5 of oracle/gae_scan.c, no
+    timeout, five launches each (nonces advance)."""
+    from elegantrl_amd import _hip
+    monkeypatch.setenv("ERL_GAE_LB_L", str(L))
+    monkeypatch.setenv("ERL_GAE_LB_W", str(W))
+    monkeypatch.setenv("ERL_GAE_LB_DELAY", str(delay))
+    H, N = 1500, 1028
+    r, u, m, v, nv = gae_inputs(H, N, seed=L * 1000 + W * 10 + delay, p_done=0.0003, p_trunc=0.0003)
+    adv_o, ret_o, _, _ = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=True)
+    tm, tv, tnv = cu(m, dev), cu(v, dev), cu(nv, dev)
+    for _ in range(5):
+        adv, ret = ops.gae_scan(cu(r, dev), cu(u, dev), tm, tv, tnv, 0.99, 0.95, algo="lookback")
+        rel_close(adv.cpu().numpy(), adv_o, 1e-5)
+        rel_close(ret.cpu().numpy(), ret_o, 1e-5)
+    th.cuda.synchronize()
+    _hip.check_async_faults()
+
+
+def test_gae_auto_short_horizon_many_envs_is_within_1e5_of_the_exact_kernel(ops, dev):
+    """AUTO sends H < 64 with more than 8192 envs to the ONE-slab look-back form (no granules; 5.3 against 18.9 us at 32 x 32768) and keeps
+    the bit-exact lane-per-env kernel up to 8192 envs: the former within 1e-5 of the latter and of oracle/gae_scan.c, the latter bitwise."""
+    for H, N, exact in [(32, 32768, False), (32, 8192, True), (48, 16384, False)]:
+        r, u, m, v, nv = gae_inputs(H, N, seed=H + N)
+        adv_o, ret_o, _, _ = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=True)
+        t = lambda: (cu(r, dev), cu(u, dev), cu(m, dev), cu(v, dev), cu(nv, dev))   # noqa: E731
+        adv_a, ret_a = ops.gae_scan(*t(), 0.99, 0.95)
+        adv_e, ret_e = ops.gae_scan(*t(), 0.99, 0.95, algo="exact")
+        np.testing.assert_array_equal(adv_e.cpu().numpy(), adv_o)
+        if exact:
+            np.testing.assert_array_equal(adv_a.cpu().numpy(), adv_o)
+            np.testing.assert_array_equal(ret_a.cpu().numpy(), ret_o)
+        else:
+            rel_close(adv_a.cpu().numpy(), adv_e.cpu().numpy(), 1e-5)
+            rel_close(ret_a.cpu().numpy(), ret_o, 1e-5)
+
+
 def test_cum_rewards_reference_golden_bitwise(ops, dev):
     """erl_cum_rewards_f32 against the returns the reference's AgentBase.get_cumulative_rewards produced (4 appends through
     ReplayBuffer.update_cum_rewards, one of them the p < add_size branch): bit-exact."""

@@ -1,5 +1,8 @@
-"""Row f2: prioritised replay.  The reference's SumTree does not run (its own assert fires), so the target is the corrected
-restatement oracle/per_numpy.py: its properties are checked on the CPU, the device trees (csrc/per.hip) against it bit for bit."""
+"""Row f2: prioritised replay.  The reference's SumTree SAMPLING does not run (its own assert fires), so the target there is the corrected
+restatement oracle/per_numpy.py: its properties are checked on the CPU, the device trees (csrc/per.hip) against it bit for bit.  The
+UPDATE half does run in the reference (SumTree.update_ids, replay_buffer.py:249-258): tests/golden/per_update.npz holds the reference's own
+tree tensors (oracle/make_golden.py::make_per_update) and both the restatement and the device trees are compared with them bitwise on
+every level the reference recomputes (round 6: f2 "update half pinned")."""
 import numpy as np
 import pytest
 import torch as th
@@ -24,6 +27,94 @@ def test_reference_sumtree_asserts_which_is_why_parity_is_unpinned():
         tree.update_ids(th.arange(buf_len), prob=th.rand(buf_len) + 0.1)
         with pytest.raises(AssertionError):
             tree.important_sampling(batch_size=16, beg=-buf_len, end=-1, per_beta=0.4)
+
+
+def test_reference_per_append_raises_on_wrap():
+    """why tests/golden/per_update.npz has no wrapping append: the reference's PER branch of ReplayBuffer.update builds
+    th.arange(self.p, p) AFTER p was reduced modulo max_size (replay_buffer.py:92,109) and raises (authoring container only)."""
+    import os
+    import sys
+    ref = os.environ.get("ERL_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        pytest.skip("reference not mounted")
+    sys.path.insert(0, ref)
+    try:
+        from elegantrl.train.replay_buffer import ReplayBuffer
+    finally:
+        sys.path.remove(ref)
+    buf = ReplayBuffer(max_size=8, state_dim=3, action_dim=2, gpu_id=-1, num_seqs=2, if_use_per=True)
+    mk = lambda add: (th.randn(add, 2, 3), th.randn(add, 2, 2), th.randn(add, 2), th.rand(add, 2) > 0.1, th.rand(add, 2) > 0.1)   # noqa: E731
+    buf.update(mk(6))
+    with pytest.raises(RuntimeError):
+        buf.update(mk(5))
+
+
+def _golden_per_steps():
+    """(max_size, Q, depth_levels_updated, [(p0, add, ids0 (Q, n), td (Q, n), prob (Q, n), tree_after_append (Q, 2 m - 1), tree_after_td)])"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "per_update.npz"))
+    for ci, (max_size, Q, n_steps) in enumerate(g["cases"]):
+        steps = [(int(g[f"c{ci}_s{k}_append"][0]), int(g[f"c{ci}_s{k}_append"][1]), g[f"c{ci}_s{k}_ids0"], g[f"c{ci}_s{k}_td"],
+                  g[f"c{ci}_s{k}_prob"], g[f"c{ci}_s{k}_tree_after_append"], g[f"c{ci}_s{k}_tree_after_td"]) for k in range(int(n_steps))]
+        yield int(max_size), int(Q), int(g[f"c{ci}_depth"][1]), steps
+
+
+def _assert_levels_equal(ours_sum, ref_tree, max_size, levels_updated):
+    """ours: (Q, 2 L) heap with root 1, leaves at L + row; the reference's: (Q, 2 m - 1) heap with root 0, leaves at m - 1 + row, m = L a
+    power of two: node i of theirs is node i + 1 of ours.  The reference recomputes `levels_updated` levels above the leaves (never its
+    root): those, and the leaves, must agree bit for bit."""
+    L = max_size
+    assert ours_sum.shape[1] == 2 * L and ref_tree.shape[1] == 2 * L - 1
+    leaf_level = L.bit_length() - 1
+    np.testing.assert_array_equal(ours_sum[:, L:], ref_tree[:, L - 1:])
+    for level in range(leaf_level - 1, leaf_level - 1 - levels_updated, -1):
+        assert level >= 1
+        np.testing.assert_array_equal(ours_sum[:, 1 << level:1 << (level + 1)], ref_tree[:, (1 << level) - 1:(1 << (level + 1)) - 1])
+    assert (ref_tree[:, 0] == 0).all()           # the reference never reaches its root (depth - 2 iterations): what its sampler then trips over
+
+
+def test_oracle_tree_update_matches_the_reference_sumtree_bitwise():
+    """oracle/per_numpy.py against the reference's own SumTree tensors: appends at priority 10, then td-error updates (distinct rows)."""
+    for max_size, Q, levels, steps in _golden_per_steps():
+        t = PerTrees(max_size, Q)
+        assert t.L == max_size
+        for p0, add, ids0, td, prob, tree_append, tree_td in steps:
+            t.add_rows(p0, add)
+            _assert_levels_equal(t.sum, tree_append, max_size, levels)
+            # the priority formula (:168): numpy's powf against torch's -- one ulp at most; the tree arithmetic continues from the reference's
+            ours = np.power(np.clip(td, np.float32(1e-8), np.float32(10.0)), np.float32(0.6)).astype(np.float32)
+            np.testing.assert_allclose(ours, prob, rtol=5e-7)           # (two libms' powf: a few ulp at 1e-8^0.6)
+            n = ids0.shape[1]
+            t.set(ids0.reshape(-1), np.repeat(np.arange(Q), n), prob.reshape(-1))
+            _assert_levels_equal(t.sum, tree_td, max_size, levels)
+
+
+@pytest.mark.gpu
+def test_device_tree_update_matches_the_reference_sumtree_bitwise():
+    """csrc/per.hip (erl_per_add_rows_f32 / erl_per_update_f32) against the reference's own SumTree tensors, level by level, bitwise.  The
+    device computes clamp(td)^alpha itself (powf: within a few ulp of torch's, asserted); where a leaf differs by that ulp the comparison of
+    the upper levels would fail for that reason alone, so a second pair of trees is updated with alpha = 1 and td = the reference's prob
+    (exact: clamp(prob) = prob, x^1 = x), which isolates the tree arithmetic: bitwise on every level the reference recomputes."""
+    from elegantrl_amd import ops
+    dev = th.device("cuda:0")
+    for max_size, Q, levels, steps in _golden_per_steps():
+        t, t1 = ops.PerTrees(max_size, Q, dev), ops.PerTrees(max_size, Q, dev)
+        for p0, add, ids0, td, prob, tree_append, tree_td in steps:
+            n = ids0.shape[1]
+            i0 = th.from_numpy(ids0.reshape(-1).astype(np.int64)).to(dev)
+            i1 = th.from_numpy(np.repeat(np.arange(Q), n).astype(np.int64)).to(dev)
+            for trees in (t, t1):
+                trees.add_rows(p0, add)
+                _assert_levels_equal(trees.sum.view(Q, -1).cpu().numpy(), tree_append, max_size, levels)
+            t.update(i0, i1, th.from_numpy(td.reshape(-1)).to(dev), 0.6)
+            got = t.sum.view(Q, -1).cpu().numpy()
+            np.testing.assert_allclose(got[:, max_size:], tree_td[:, max_size - 1:], rtol=5e-7)          # leaves: the device's own powf
+            t1.update(i0, i1, th.from_numpy(prob.reshape(-1)).to(dev), 1.0)                              # the reference's priorities as they are
+            _assert_levels_equal(t1.sum.view(Q, -1).cpu().numpy(), tree_td, max_size, levels)
+            if np.array_equal(got[:, max_size:], tree_td[:, max_size - 1:]):
+                _assert_levels_equal(got, tree_td, max_size, levels)
+            # keep the two device trees on the reference's leaves for the next step
+            t.update(i0, i1, th.from_numpy(prob.reshape(-1)).to(dev), 1.0)
 
 
 def test_oracle_trees_are_consistent_and_sampling_is_proportional():

@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 from elegantrl_amd import _hip, ops  # noqa: E402
 
 dev = th.device("cuda:0")
+FLUSH = th.zeros(640 << 20, dtype=th.uint8, device=dev)
 
 
 def measure(H, N, algo, L=None, W=None):
@@ -37,13 +38,25 @@ def measure(H, N, algo, L=None, W=None):
         run()
     us, n = _hip.kernel_span_read(_hip.SPAN_GAE)
     _hip.kernel_span_enable(False)
+    # cold: a 640 MB buffer rewritten between calls (the warm figure re-reads inputs that fit the 256 MB Infinity Cache)
+    _hip.kernel_span_enable(True)
+    for _ in range(10):
+        FLUSH.add_(1)
+        run()
+    th.cuda.synchronize()
+    cold, n = _hip.kernel_span_read(_hip.SPAN_GAE)
+    _hip.kernel_span_enable(False)
     _hip.check_async_faults()
     print(json.dumps({"H": H, "N": N, "algo": algo, "L": L, "W": W, "kernel_us": round(us, 2), "GBps": round(18.0 * H * N / us / 1e3, 1),
-                      "frac": round(18.0 * H * N / us / 1e3 / 8000.0, 4)}), flush=True)
+                      "frac": round(18.0 * H * N / us / 1e3 / 8000.0, 4), "cold_kernel_us": round(cold, 2),
+                      "cold_frac": round(18.0 * H * N / cold / 1e3 / 8000.0, 4)}), flush=True)
 
 
 combos = [(None, None), (2, 8), (2, 16), (4, 4), (4, 8), (4, 16), (8, 4), (8, 8), (8, 16), (16, 4), (16, 8)]
-for H, N in [(32, 4096), (128, 4096), (200, 4096), (32, 32768), (512, 4096)]:
+sizes = [(32, 4096), (128, 4096), (200, 4096), (32, 32768), (512, 4096), (1024, 4096), (2048, 4096)]
+if len(sys.argv) > 1:
+    sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
+for H, N in sizes:
     measure(H, N, "exact")
     for L, W in combos:
         measure(H, N, "lookback", L, W)
