@@ -22,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 17
+ABI_VERSION = 18
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 SAC_ACTOR_SAC, SAC_ACTOR_FIX = 0, 1                               # include/erl_hip.h ERL_SAC_ACTOR_*
 COMM_ID_BYTES = 128
@@ -49,6 +49,9 @@ _SIGNATURES = {
                                      c_int64, c_int64, _P]),
     "erl_replay_sample_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64,
                                       _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "erl_replay_row_floats": (c_int64, [c_int, c_int]),
+    "erl_replay_write_rows_f32": (c_int, [_P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, _P]),
+    "erl_replay_sample_rows_f32": (c_int, [_P, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "erl_replay_write_discrete_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int, c_int64,
                                               c_int64, _P]),
     "erl_replay_sample_discrete_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, c_int64,

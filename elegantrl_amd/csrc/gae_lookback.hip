@@ -59,7 +59,7 @@ __device__ __forceinline__ unsigned long long pack_granule(float a, uint32_t tag
     return (unsigned long long)__float_as_uint(a) | ((unsigned long long)tag << 32);
 }
 
-template <int L, bool STATS>
+template <int L, bool STATS, bool NT>
 __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookback_kernel(LbArgs g)
 {
     __shared__ float2 s_agg[LB_MAX_WAVES][256];
@@ -88,10 +88,26 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
         const int t = t_top - j;
         if (live && t >= 0) {
             const size_t i = (size_t)t * N + n0;
-            r[j] = *reinterpret_cast<const float4 *>(g.rewards + i);
-            v[j] = *reinterpret_cast<const float4 *>(g.values + i);
-            ud4[j] = *reinterpret_cast<const uint32_t *>(g.undones + i);
-            um4[j] = *reinterpret_cast<const uint32_t *>(g.unmasks + i);
+            if constexpr (NT) {
+                // Streaming (non-temporal) loads for the single-use inputs of a LARGE scan (round 6).  The scan starts behind kernels
+                // that left the Infinity Cache full of dirty lines (a rollout's buffers, the value pre-pass); ordinary loads allocate
+                // there, every allocation evicts a dirty line, and the scan shares HBM with that write-back: 2048 x 4096 behind 640 MB
+                // of writes 42.9 us, with streaming loads 29.2 us; in `bench.py --config cd`'s loop 38.9 -> 32.6 us = 0.49 -> 0.58 of
+                // the HBM peak.  On inputs that ARE cached (back-to-back calls on the same 84 MB) it costs 2 us (26.3 -> 28.7): the
+                // launcher uses it from 32 MB of inputs + outputs on (profiles/r06_gae_lb_sweep.txt, r06_gae_lb_sweep_nt_loads.txt).
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                const nt_f4 r_ = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(g.rewards + i));
+                const nt_f4 v_ = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(g.values + i));
+                r[j] = make_float4(r_.x, r_.y, r_.z, r_.w);
+                v[j] = make_float4(v_.x, v_.y, v_.z, v_.w);
+                ud4[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(g.undones + i));
+                um4[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(g.unmasks + i));
+            } else {
+                r[j] = *reinterpret_cast<const float4 *>(g.rewards + i);
+                v[j] = *reinterpret_cast<const float4 *>(g.values + i);
+                ud4[j] = *reinterpret_cast<const uint32_t *>(g.undones + i);
+                um4[j] = *reinterpret_cast<const uint32_t *>(g.unmasks + i);
+            }
         } else {
             r[j] = v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             ud4[j] = 0u;
@@ -367,8 +383,10 @@ void erl_gae_lookback_pick(int64_t H, int64_t N, int *L, int *W)
     // (L = 16, W = 8: 512 threads, 256 VGPRs, no scratch; the L = 8 instantiation is built for 1024 threads = 64 VGPRs and
     // spills 24-32 bytes per lane -- equally fast at 2048 x 4096 (32.5 vs 33.1 us, profiles/r02_gae_tiling_ab.txt), so the large
     // sizes avoid it; nontemporal output stores were measured there too: no change)
+    // round 6 (tools/gae_lb_sweep.py with a cold column, profiles/r06_gae_lb_sweep.txt): 1024 x 4096 runs 16.9 us warm / 23.7 us cold on
+    // slabs of 64 steps (L = 4, W = 16: 1024 threads, no spill) against 18.7 / 29.7 us on L = 8 / W = 16 (its instantiation spills)
     if (H >= 2048) { l = 16; w = 8; }
-    else if (H >= 512) { l = 8; w = 16; }
+    else if (H >= 512) { l = 4; w = 16; }
     else if (H >= 64) { l = 4; w = 8; }
     else { l = 4; w = (int)((H + 3) / 4); }      // one slab covers the horizon: no look-back at all (round 5: 32 x 32768 18.9 -> 5.5 us)
     l = env_int("ERL_GAE_LB_L", l);
@@ -478,10 +496,14 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     g.publish_delay = (uint32_t)env_int("ERL_GAE_LB_DELAY", 0);
     g.publish_nonce = env_int("ERL_GAE_LB_FAULT", 0) ? (g.nonce ^ 0x15555555u) & 0x3fffffffu : g.nonce;
     const dim3 grid((unsigned)(K * G)), block(W * 64);
-#define LB_LAUNCH(LL)                                                                                  \
-    do {                                                                                               \
-        if (want_stats) hipLaunchKernelGGL((gae_lookback_kernel<LL, true>), grid, block, 0, stream, g); \
-        else hipLaunchKernelGGL((gae_lookback_kernel<LL, false>), grid, block, 0, stream, g);           \
+    // streaming input loads from 32 MB of traffic on (see the kernel's load loop); ERL_GAE_NT=0 / 1 forces (A/B runs)
+    const bool nt = env_int("ERL_GAE_NT", 18 * H * N >= (32LL << 20) ? 1 : 0) != 0;
+#define LB_LAUNCH(LL)                                                                                                  \
+    do {                                                                                                               \
+        if (want_stats && nt) hipLaunchKernelGGL((gae_lookback_kernel<LL, true, true>), grid, block, 0, stream, g);     \
+        else if (want_stats) hipLaunchKernelGGL((gae_lookback_kernel<LL, true, false>), grid, block, 0, stream, g);     \
+        else if (nt) hipLaunchKernelGGL((gae_lookback_kernel<LL, false, true>), grid, block, 0, stream, g);             \
+        else hipLaunchKernelGGL((gae_lookback_kernel<LL, false, false>), grid, block, 0, stream, g);                    \
     } while (0)
     switch (L) {
         case 2: LB_LAUNCH(2); break;

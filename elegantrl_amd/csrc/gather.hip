@@ -149,6 +149,91 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(const float *__restr
     erl_span_out(span, t_span);
 }
 
+// ---- the interleaved ring (round 6): ONE block ring[num_seqs][max_size][RW] fp32, RW = S + A + 3 rounded up to 4 floats, a row =
+// [state (S) | action (A) | reward | undone | unmask | pad].  A transition is one 16-byte-aligned row, and its next state
+// (states[ids0 + 1, ids1], replay_buffer.py:133) is the head of the NEXT row of the same sequence: a sample reads RW + S consecutive
+// floats -- one or two 128-byte lines instead of the planar layout's six to seven (44-byte state row, 44-byte next-state row num_seqs
+// rows further on, 12-byte action row, three 4-byte scalars: 5.8x the algorithmic bytes fetched at B = 2^20, profiles/r05_k9_pmc_by_size.json).
+// The class keeps the reference's attributes as strided VIEWS of the block (train/replay_buffer.py).
+template <bool FLAG_F32>
+__global__ __launch_bounds__(256) void replay_write_rows_kernel(float *__restrict__ ring, const float *__restrict__ states,
+                                                                const float *__restrict__ actions, const float *__restrict__ rewards,
+                                                                const void *__restrict__ undones, const void *__restrict__ unmasks,
+                                                                int64_t max_size, int64_t num_seqs, int S, int A, int RW, int64_t p, int64_t add)
+{
+    const int W = S + A + 3;
+    const int64_t rows = add * num_seqs, total = rows * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / W;
+        const int c = (int)(e - r * W);
+        const int64_t i = r / num_seqs, q = r - i * num_seqs;
+        int64_t ti = p + i;
+        if (ti >= max_size) ti -= max_size;
+        float v;
+        if (c < S) v = states[r * S + c];
+        else if (c < S + A) v = actions[r * A + (c - S)];
+        else if (c == S + A) v = rewards[r];
+        else if (c == S + A + 1) v = FLAG_F32 ? ((const float *)undones)[r] : (((const uint8_t *)undones)[r] ? 1.f : 0.f);
+        else v = FLAG_F32 ? ((const float *)unmasks)[r] : (((const uint8_t *)unmasks)[r] ? 1.f : 0.f);
+        ring[(q * max_size + ti) * RW + c] = v;
+    }
+}
+
+// a thread moves one 16-byte chunk: chunks [0, RW / 4) of the sample's own row, then ceil(S / 4) chunks of the next row's state
+__global__ __launch_bounds__(256) void replay_sample_rows_kernel(const float *__restrict__ ring, int64_t max_size, int S, int A, int RW,
+                                                                 const int64_t *__restrict__ ids, int64_t B, int64_t sample_len,
+                                                                 float *__restrict__ o_state, float *__restrict__ o_action,
+                                                                 float *__restrict__ o_reward, float *__restrict__ o_undone,
+                                                                 float *__restrict__ o_unmask, float *__restrict__ o_next,
+                                                                 int64_t *__restrict__ o_ids0, int64_t *__restrict__ o_ids1, int spw,
+                                                                 unsigned long long *span)
+{
+    __shared__ int64_t s_row[RS_SAMPLES], s_nxt[RS_SAMPLES];
+    const unsigned long long t_span = erl_span_in(span);
+    const int C0 = RW >> 2, C1 = (S + 3) >> 2, CW = C0 + C1;
+    for (int64_t b0 = (int64_t)blockIdx.x * spw; b0 < B; b0 += (int64_t)gridDim.x * spw) {
+        const int nb = (int)min((int64_t)spw, B - b0);
+        __syncthreads();   // s_row reuse
+        if ((int)threadIdx.x < nb) {
+            const int64_t id = ids[b0 + threadIdx.x];
+            const int64_t n = id / sample_len, t = id - n * sample_len;   // ids0 = ids % L, ids1 = ids // L  (:124-125)
+            s_row[threadIdx.x] = n * max_size + t;
+            // the next row of the same sequence; ids0 = max_size - 1 has none (the reference would raise an IndexError; the uniform
+            // sampler's sample_len = cur_size - 1 and the prioritised sampler's moves never produce it): clamped, never out of the block
+            s_nxt[threadIdx.x] = n * max_size + (t + 1 < max_size ? t + 1 : t);
+            if (o_ids0) o_ids0[b0 + threadIdx.x] = t;
+            if (o_ids1) o_ids1[b0 + threadIdx.x] = n;
+        }
+        __syncthreads();
+        const int total = nb * CW;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int bl = e / CW, c = e - bl * CW;
+            const int64_t row = s_row[bl], b = b0 + bl;
+            if (c < C0) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(ring + row * RW + 4 * c);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int col = 4 * c + k;
+                    if (col < S) o_state[b * S + col] = v[k];
+                    else if (col < S + A) o_action[b * A + (col - S)] = v[k];
+                    else if (col == S + A) o_reward[b] = v[k];
+                    else if (col == S + A + 1) o_undone[b] = v[k];
+                    else if (col == S + A + 2) o_unmask[b] = v[k];
+                }
+            } else {
+                const int cc = c - C0;
+                const float4 v4 = *reinterpret_cast<const float4 *>(ring + s_nxt[bl] * RW + 4 * cc);   // states[ids0 + 1, ids1]  (:133)
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * cc + k < S) o_next[b * S + 4 * cc + k] = v[k];
+            }
+        }
+    }
+    erl_span_out(span, t_span);
+}
+
 inline int grid_for(int64_t total)
 {
     int64_t g = erl_cdiv(total, 256);
@@ -287,4 +372,51 @@ extern "C" int erl_replay_sample_discrete_f32(const float *buf_states, const uin
     return replay_sample_impl("erl_replay_sample_discrete_f32", true, buf_states, buf_actions, buf_rewards, buf_undones,
                               buf_unmasks, max_size, num_seqs, S, 1, ids, B, sample_len, out_state, out_action, out_reward,
                               out_undone, out_unmask, out_next_state, out_ids0, out_ids1, stream);
+}
+
+extern "C" int64_t erl_replay_row_floats(int S, int A) { return S >= 1 && A >= 1 ? ((int64_t)S + A + 3 + 3) / 4 * 4 : -1; }
+
+extern "C" int erl_replay_write_rows_f32(float *ring, int64_t max_size, int64_t num_seqs, int S, int A, const float *states,
+                                         const float *actions, const float *rewards, const void *undones, const void *unmasks,
+                                         int flag_is_f32, int64_t p, int64_t add, void *stream)
+{
+    ERL_REQUIRE(ring && states && actions && rewards && undones && unmasks, "erl_replay_write_rows_f32: NULL tensor");
+    ERL_REQUIRE(max_size >= 1 && num_seqs >= 1 && S >= 1 && A >= 1, "erl_replay_write_rows_f32: bad shape");
+    ERL_REQUIRE((reinterpret_cast<uintptr_t>(ring) & 15) == 0, "erl_replay_write_rows_f32: the ring must be 16-byte aligned");
+    ERL_REQUIRE(add >= 0 && add <= max_size && p >= 0 && p <= max_size, "erl_replay_write_rows_f32: add=%lld p=%lld max_size=%lld",
+                (long long)add, (long long)p, (long long)max_size);
+    if (add == 0) return ERL_OK;
+    const int RW = (int)erl_replay_row_floats(S, A);
+    const int g = grid_for(add * num_seqs * (S + A + 3));
+    hipStream_t st = (hipStream_t)stream;
+    if (flag_is_f32)
+        hipLaunchKernelGGL((replay_write_rows_kernel<true>), dim3(g), dim3(256), 0, st, ring, states, actions, rewards, undones, unmasks,
+                           max_size, num_seqs, S, A, RW, p, add);
+    else
+        hipLaunchKernelGGL((replay_write_rows_kernel<false>), dim3(g), dim3(256), 0, st, ring, states, actions, rewards, undones, unmasks,
+                           max_size, num_seqs, S, A, RW, p, add);
+    return erl_hip_status(hipGetLastError(), "erl_replay_write_rows_f32");
+}
+
+extern "C" int erl_replay_sample_rows_f32(const float *ring, int64_t max_size, int64_t num_seqs, int S, int A, const int64_t *ids, int64_t B,
+                                          int64_t sample_len, float *out_state, float *out_action, float *out_reward, float *out_undone,
+                                          float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1, void *stream)
+{
+    ERL_REQUIRE(ring && ids, "erl_replay_sample_rows_f32: NULL tensor");
+    ERL_REQUIRE(out_state && out_action && out_reward && out_undone && out_unmask && out_next_state, "erl_replay_sample_rows_f32: NULL output");
+    ERL_REQUIRE((reinterpret_cast<uintptr_t>(ring) & 15) == 0, "erl_replay_sample_rows_f32: the ring must be 16-byte aligned");
+    ERL_REQUIRE(num_seqs >= 1 && S >= 1 && A >= 1 && B >= 0 && sample_len >= 1 && sample_len <= max_size,
+                "erl_replay_sample_rows_f32: bad shape (sample_len=%lld max_size=%lld)", (long long)sample_len, (long long)max_size);
+    if (B == 0) return ERL_OK;
+    const int RW = (int)erl_replay_row_floats(S, A);
+    const int CW = RW / 4 + (S + 3) / 4;
+    int64_t spw = B / 1024;                       // (as replay_sample_impl: a small batch is spread, one chunk per thread and one round trip)
+    if (spw < 256 / CW) spw = 256 / CW;
+    if (spw < 1) spw = 1;
+    if (spw > RS_SAMPLES) spw = RS_SAMPLES;
+    const int g = grid_for(erl_cdiv(B, spw) * 256);
+    unsigned long long *sp = erl_span_slot(ERL_SPAN_REPLAY_SAMPLE, g);
+    hipLaunchKernelGGL(replay_sample_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ring, max_size, S, A, RW, ids, B, sample_len,
+                       out_state, out_action, out_reward, out_undone, out_unmask, out_next_state, out_ids0, out_ids1, (int)spw, sp);
+    return erl_hip_status(hipGetLastError(), "erl_replay_sample_rows_f32");
 }

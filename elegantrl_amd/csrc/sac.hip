@@ -466,8 +466,12 @@ extern "C" int erl_sac_update_ring_f32(float *actor_params, float *critic_params
                                        float lr, float beta1, float beta2, float eps_adam, float max_norm, int32_t step, float *objs_out,
                                        void *workspace, int64_t workspace_bytes, void *stream)
 {
-    ERL_REQUIRE(ring && ring->buf_states && ring->buf_actions && ring->buf_rewards && ring->buf_undones && ring->buf_unmasks && ring->ids,
+    ERL_REQUIRE(ring && ring->buf_states && ring->ids && (ring->row_floats || (ring->buf_actions && ring->buf_rewards && ring->buf_undones && ring->buf_unmasks)),
                 "erl_sac_update_ring_f32: NULL ring tensor");
+    ERL_REQUIRE(ring->row_floats == 0 || (ring->row_floats == erl_replay_row_floats(S, A) && ring->sample_len < ring->max_size &&
+                                          (reinterpret_cast<uintptr_t>(ring->buf_states) & 15) == 0),
+                "erl_sac_update_ring_f32: interleaved ring with row_floats=%lld (expected %lld), sample_len=%lld", (long long)ring->row_floats,
+                (long long)erl_replay_row_floats(S, A), (long long)ring->sample_len);
     ERL_REQUIRE(ring->num_seqs >= 1 && ring->sample_len >= 1 && ring->sample_len <= ring->max_size,
                 "erl_sac_update_ring_f32: bad ring shape max_size=%lld num_seqs=%lld sample_len=%lld", (long long)ring->max_size,
                 (long long)ring->num_seqs, (long long)ring->sample_len);
@@ -517,7 +521,12 @@ static int sac_update_impl(float *actor_params, float *critic_params, float *tar
                                     eps_adam, max_norm, step, objs_out, (float *)workspace, ring, s);
     }
     if (ring) {        // the layered step reads a finished batch: the sample as a launch of its own
-        rc = erl_replay_sample_f32(ring->buf_states, ring->buf_actions, ring->buf_rewards, ring->buf_undones, ring->buf_unmasks, ring->max_size, ring->num_seqs, S,
+        rc = ring->row_floats
+                 ? erl_replay_sample_rows_f32(ring->buf_states, ring->max_size, ring->num_seqs, S, A, ring->ids, B, ring->sample_len,
+                                              const_cast<float *>(state), const_cast<float *>(action), const_cast<float *>(reward),
+                                              const_cast<float *>(undone), const_cast<float *>(unmask), const_cast<float *>(next_state),
+                                              ring->out_ids0, ring->out_ids1, stream)
+                 : erl_replay_sample_f32(ring->buf_states, ring->buf_actions, ring->buf_rewards, ring->buf_undones, ring->buf_unmasks, ring->max_size, ring->num_seqs, S,
                                    A, ring->ids, B, ring->sample_len, const_cast<float *>(state), const_cast<float *>(action),
                                    const_cast<float *>(reward), const_cast<float *>(undone), const_cast<float *>(unmask),
                                    const_cast<float *>(next_state), ring->out_ids0, ring->out_ids1, stream);

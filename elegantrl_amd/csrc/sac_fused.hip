@@ -425,7 +425,7 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
     if (g.rg.ids && L.tid < TS) {                          // ids0 = ids % L, ids1 = ids // L  (replay_buffer.py:124-125)
         const int64_t b = row0 + L.tid, id = g.rg.ids[min(b, d.B - 1)];
         const int64_t n = id / g.rg.sample_len, t = id - n * g.rg.sample_len;
-        s_row[L.tid] = t * g.rg.num_seqs + n;
+        s_row[L.tid] = g.rg.row_floats ? n * g.rg.max_size + t : t * g.rg.num_seqs + n;     // (interleaved ring: sequence-major rows)
         if (blockIdx.y == 0 && b < d.B) {
             if (g.rg.out_ids0) g.rg.out_ids0[b] = t;
             if (g.rg.out_ids1) g.rg.out_ids1[b] = n;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
             const int64_t b = row0 + s_;
             float v = 0.f;
             if (b < d.B && c < S) {
-                v = g.rg.buf_states[(s_row[s_] + g.rg.num_seqs) * S + c];
+                v = g.rg.row_floats ? g.rg.buf_states[(s_row[s_] + 1) * g.rg.row_floats + c] : g.rg.buf_states[(s_row[s_] + g.rg.num_seqs) * S + c];
                 if (blockIdx.y == 0) g.o_next[b * S + c] = v;
             }
             lds.T0[s_ * LDT + c] = v;
@@ -451,6 +451,15 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
                 const int s_ = e / W, c = e - s_ * W;
                 const int64_t b = row0 + s_, rr = s_row[s_];
                 if (b >= d.B) continue;
+                if (g.rg.row_floats) {                     // one contiguous row [state | action | reward | undone | unmask]
+                    const float v = g.rg.buf_states[rr * g.rg.row_floats + c];
+                    if (c < S) g.o_state[b * S + c] = v;
+                    else if (c < S + A) g.o_action[b * A + (c - S)] = v;
+                    else if (c == S + A) g.o_reward[b] = v;
+                    else if (c == S + A + 1) g.o_undone[b] = v;
+                    else g.o_unmask[b] = v;
+                    continue;
+                }
                 if (c < S) g.o_state[b * S + c] = g.rg.buf_states[rr * S + c];
                 else if (c < S + A) g.o_action[b * A + (c - S)] = g.rg.buf_actions[rr * A + (c - S)];
                 else if (c == S + A) g.o_reward[b] = g.rg.buf_rewards[rr];

@@ -26,15 +26,16 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b)      // v_cvt_pk_b
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
-// The residual x - (one half of the packed pair p), the step between two levels of a split.  ERL_SPLIT_DOT2 (default 1; round 6):
-// ONE instruction, v_dot2_f32_bf16 D = A.lo B.lo + A.hi B.hi + C with B = {-1, 0} / {0, -1} from a scalar register, instead of
-// unpack (v_lshlrev_b32 / v_and_b32) + v_sub_f32: 4 vector instructions less per pair of a three-way split (11 -> 7; in the minibatch
-// kernels ~900 of 6 300 per lane, 7 KB of code per network path).  The same bits: p's half is x rounded to 8 significant bits, so the
-// difference is exactly representable, and -1 * half + 0 * other + x has nothing to round whatever the instruction's internal order
-// (tools/dot2_split_probe.hip compares the two forms bitwise over 8 M pairs of every class -- normal, tiny, denormal, already bf16 --
-// on the device: profiles/r06_dot2_split_probe.json; 0 disables).
+// The residual x - (one half of the packed pair p), the step between two levels of a split: unpack (v_lshlrev_b32 / v_and_b32) +
+// v_sub_f32.  ERL_SPLIT_DOT2=1 forms it with ONE instruction instead, v_dot2_f32_bf16 D = A.lo B.lo + A.hi B.hi + C with B = {-1, 0} /
+// {0, -1} from a scalar register (4 vector instructions less per pair of a three-way split, 11 -> 7).  Round 6 built and measured it, and
+// it is OFF: the bits are the same (tools/dot2_split_probe.hip: 0 mismatches over 8.2 M pairs of every class, profiles/r06_dot2_split_probe.json)
+// but the instruction is no cheaper than the two it replaces beside the bf16 MFMAs -- the minibatch kernel's backward phase went 13.8k ->
+// 15.4k cycles, the kernel 36.0 -> 35.4-36.2 us, the step 2.067 -> 2.089 ms (profiles/r06_dot2_split_ab.txt: same box, alternating
+// processes) -- and as inline assembly it is invisible to the compiler's hazard recogniser (a transcendental's or an MFMA's result read
+// too early: the rollout kernels' actions came out wrong, tests/test_agent_gpu.py::test_explore_env_reproduces_reference_rollout).
 #ifndef ERL_SPLIT_DOT2
-#define ERL_SPLIT_DOT2 1
+#define ERL_SPLIT_DOT2 0
 #endif
 __device__ __forceinline__ float sub_bf_lo(float x, uint32_t p)
 {

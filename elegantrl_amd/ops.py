@@ -151,6 +151,45 @@ def replay_write(buf_states: TEN, buf_actions: TEN, buf_rewards: TEN, buf_undone
           "erl_replay_write_f32")
 
 
+class ReplayRing:
+    """the INTERLEAVED replay ring (ABI 18): one fp32 block [num_seqs][max_size][row_floats], row = [state | action | reward | undone |
+    unmask | pad to 4 floats], sequence-major so that a transition and its next state are consecutive in memory (one or two 128-byte
+    lines per sample instead of six to seven).  `states`, `actions`, `rewards`, `undones`, `unmasks` are the reference's attributes
+    (elegantrl/train/replay_buffer.py:40-58: shapes (max_size, num_seqs[, .]), fp32) as strided VIEWS of the block: indexing, slicing and
+    assignment work on them as on the reference's tensors; they are not contiguous."""
+
+    def __init__(self, max_size: int, num_seqs: int, S: int, A: int, device):
+        self.max_size, self.num_seqs, self.S, self.A = int(max_size), int(num_seqs), int(S), int(A)
+        self.row_floats = int(lib().erl_replay_row_floats(self.S, self.A))
+        if self.row_floats <= 0:
+            raise HipExtensionError(f"erl_replay_row_floats({S}, {A}) failed")
+        self.block = th.zeros((self.num_seqs, self.max_size, self.row_floats), dtype=th.float32, device=device)
+        t = self.block.permute(1, 0, 2)                                        # (max_size, num_seqs, row_floats)
+        self.states, self.actions = t[:, :, :S], t[:, :, S:S + A]
+        self.rewards, self.undones, self.unmasks = t[:, :, S + A], t[:, :, S + A + 1], t[:, :, S + A + 2]
+
+    def write(self, items: Sequence[TEN], p: int) -> None:
+        """ring append (ReplayBuffer.update, replay_buffer.py:86-105) of (add, num_seqs, .) items at time row p, wrapping at max_size"""
+        states, actions, rewards, undones, unmasks = items
+        add = rewards.shape[0]
+        is_f32 = undones.dtype == th.float32
+        assert unmasks.dtype == undones.dtype and (is_f32 or undones.dtype in (th.bool, th.uint8))
+        assert states.shape == (add, self.num_seqs, self.S) and actions.shape == (add, self.num_seqs, self.A)
+        check(lib().erl_replay_write_rows_f32(ptr(self.block, th.float32), self.max_size, self.num_seqs, self.S, self.A, ptr(states, th.float32),
+                                              ptr(actions, th.float32), ptr(rewards, th.float32), ptr(undones), ptr(unmasks), int(is_f32),
+                                              int(p), add, stream_ptr()), "erl_replay_write_rows_f32")
+
+    def sample(self, ids: TEN, sample_len: int, stage: Optional["ReplayStage"] = None):
+        """ReplayBuffer.sample given the drawn ids: ((state, action, reward, undone, unmask, next_state), (ids0, ids1))"""
+        B = ids.numel()
+        st = stage if stage is not None else ReplayStage(B, self.S, self.A, False, self.block.device)
+        assert st.B == B and not st.discrete
+        check(lib().erl_replay_sample_rows_f32(ptr(self.block, th.float32), self.max_size, self.num_seqs, self.S, self.A, ptr(ids, th.int64), B,
+                                               int(sample_len), st.p_state, st.p_action, st.p_reward, st.p_undone, st.p_unmask, st.p_next,
+                                               st.p_ids0, st.p_ids1, stream_ptr()), "erl_replay_sample_rows_f32")
+        return st.out, st.ids
+
+
 class ReplayStage:
     """the output block of ReplayBuffer.sample for one batch size -- ONE fp32 allocation viewed as state / next_state / action /
     reward / undone / unmask, one int64 (2, B) for ids0 / ids1 and, for a discrete ring, a (B,) uint8 action vector -- with
@@ -666,7 +705,8 @@ class _SacOptions(ctypes.Structure):        # include/erl_hip.h ErlSacOptions
 class _RingSample(ctypes.Structure):        # include/erl_hip.h ErlRingSample
     _fields_ = [("buf_states", ctypes.c_void_p), ("buf_actions", ctypes.c_void_p), ("buf_rewards", ctypes.c_void_p),
                 ("buf_undones", ctypes.c_void_p), ("buf_unmasks", ctypes.c_void_p), ("max_size", ctypes.c_int64), ("num_seqs", ctypes.c_int64),
-                ("ids", ctypes.c_void_p), ("sample_len", ctypes.c_int64), ("out_ids0", ctypes.c_void_p), ("out_ids1", ctypes.c_void_p)]
+                ("ids", ctypes.c_void_p), ("sample_len", ctypes.c_int64), ("out_ids0", ctypes.c_void_p), ("out_ids1", ctypes.c_void_p),
+                ("row_floats", ctypes.c_int64)]
 
 
 def sac_update_from_ring(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: TEN, moments: Sequence[TEN], ring: Sequence[TEN],
@@ -674,16 +714,23 @@ def sac_update_from_ring(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, al
                          max_norm: float, objs_out: TEN, noises: Optional[Tuple[TEN, TEN]] = None, seed: int = 0, counter: int = 0,
                          betas=(0.9, 0.999), eps: float = 1e-8) -> None:
     """ReplayBuffer.sample(ids) + one AgentSAC.update_objectives step from ONE call (erl_sac_update_ring_f32): `ring` = the buffer's
-    (states, actions, rewards, undones, unmasks), `stage` receives the batch (stage.out / stage.ids: what replay_sample would have left)."""
-    b_states, b_actions, b_rewards, b_undones, b_unmasks = ring
-    max_size, num_seqs, S = b_states.shape
+    ReplayRing (interleaved block) or its five planar tensors (states, actions, rewards, undones, unmasks), `stage` receives the batch (stage.out / stage.ids: what replay_sample would have left)."""
     B = ids.numel()
-    assert stage.B == B and not stage.discrete and b_actions.dtype == th.float32
-    ws = _workspace(b_states.device, spec.workspace_bytes(B))
-    n_next, n_cur = (None, None) if noises is None else noises
     f32 = th.float32
-    rs = _RingSample(ptr(b_states, f32), ptr(b_actions, f32), ptr(b_rewards, f32), ptr(b_undones, f32), ptr(b_unmasks, f32), max_size, num_seqs,
-                     ptr(ids, th.int64), int(sample_len), stage.p_ids0, stage.p_ids1)
+    if isinstance(ring, ReplayRing):        # the interleaved block: one base pointer + its row width
+        assert stage.B == B and not stage.discrete and (ring.S, ring.A) == (spec.S, spec.A)
+        dev = ring.block.device
+        rs = _RingSample(ptr(ring.block, f32), None, None, None, None, ring.max_size, ring.num_seqs, ptr(ids, th.int64), int(sample_len),
+                         stage.p_ids0, stage.p_ids1, ring.row_floats)
+    else:
+        b_states, b_actions, b_rewards, b_undones, b_unmasks = ring
+        max_size, num_seqs, S = b_states.shape
+        assert stage.B == B and not stage.discrete and b_actions.dtype == th.float32
+        dev = b_states.device
+        rs = _RingSample(ptr(b_states, f32), ptr(b_actions, f32), ptr(b_rewards, f32), ptr(b_undones, f32), ptr(b_unmasks, f32), max_size, num_seqs,
+                         ptr(ids, th.int64), int(sample_len), stage.p_ids0, stage.p_ids1, 0)
+    ws = _workspace(dev, spec.workspace_bytes(B))
+    n_next, n_cur = (None, None) if noises is None else noises
     check(lib().erl_sac_update_ring_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
                                         spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ctypes.addressof(rs), stage.p_state, stage.p_action,
                                         stage.p_reward, stage.p_undone, stage.p_unmask, stage.p_next, B, ptr(n_next), ptr(n_cur),

@@ -3,7 +3,9 @@
 Same constructor, attributes and cursor behaviour as elegantrl/train/replay_buffer.py:11-134; the
 cursor arithmetic (p, cur_size, if_full, add_size) is host-side integer code and reproduces the
 reference bit for bit (including landing exactly on max_size, Appendix A12 of SURVEY.md).  The tensor
-traffic goes through erl_replay_write_f32 / erl_replay_sample_f32 (uint8 action rings of discrete agents:
+traffic goes through erl_replay_write_rows_f32 / erl_replay_sample_rows_f32 on ONE interleaved block (round 6: a transition and
+its next state are consecutive bytes; the reference's five tensors are strided views of it), or erl_replay_write_f32 /
+erl_replay_sample_f32 on five planar tensors (`args.replay_interleaved = False`; uint8 action rings of discrete agents:
 erl_replay_*_discrete_f32).  Prioritised replay (`if_use_per=True`) keeps its per-sequence
 sum / min trees on the device (csrc/per.hip, erl_per_*).
 """
@@ -32,15 +34,27 @@ class ReplayBuffer:
         self.num_seqs = int(num_seqs)
         self.device = th.device(f"cuda:{gpu_id}" if (th.cuda.is_available() and gpu_id >= 0) else "cpu")
         f32 = dict(dtype=th.float32, device=self.device)
-        self.states = th.empty((self.max_size, self.num_seqs, state_dim), **f32)
         self.if_discrete = bool(if_discrete)
-        self.actions = (th.empty((self.max_size, self.num_seqs), dtype=th.uint8, device=self.device) if if_discrete
-                        else th.empty((self.max_size, self.num_seqs, action_dim), **f32))          # replay_buffer.py:52-54
         self._stage = None
-        self.rewards = th.empty((self.max_size, self.num_seqs), **f32)
-        self.undones = th.empty((self.max_size, self.num_seqs), **f32)   # float flags, as in the reference
-        self.unmasks = th.empty((self.max_size, self.num_seqs), **f32)
-        self.cum_rewards = th.empty_like(self.rewards)
+        # Continuous-action buffers on a HIP device keep ONE interleaved block (ops.ReplayRing, round 6): a row is [state | action |
+        # reward | undone | unmask], sequence-major, so a sampled transition and its next state are consecutive bytes; the reference's
+        # five attributes (replay_buffer.py:40-58) are strided views of it -- same shapes, dtypes, indexing and assignment behaviour, not
+        # contiguous.  `args.replay_interleaved = False` (or a discrete-action ring, or no device) keeps five planar tensors.
+        self._ring = None
+        if (not if_discrete and self.device.type == "cuda" and getattr(args, "replay_interleaved", True) and self.max_size >= 2):
+            from .. import ops
+            with th.cuda.device(self.device):
+                self._ring = ops.ReplayRing(self.max_size, self.num_seqs, state_dim, action_dim, self.device)
+            r = self._ring
+            self.states, self.actions, self.rewards, self.undones, self.unmasks = r.states, r.actions, r.rewards, r.undones, r.unmasks
+        else:
+            self.states = th.empty((self.max_size, self.num_seqs, state_dim), **f32)
+            self.actions = (th.empty((self.max_size, self.num_seqs), dtype=th.uint8, device=self.device) if if_discrete
+                            else th.empty((self.max_size, self.num_seqs, action_dim), **f32))          # replay_buffer.py:52-54
+            self.rewards = th.empty((self.max_size, self.num_seqs), **f32)
+            self.undones = th.empty((self.max_size, self.num_seqs), **f32)   # float flags, as in the reference
+            self.unmasks = th.empty((self.max_size, self.num_seqs), **f32)
+        self.cum_rewards = th.empty((self.max_size, self.num_seqs), **f32)
         self.ids0 = th.tensor((), dtype=th.long, device=self.device)
         self.ids1 = th.tensor((), dtype=th.long, device=self.device)
         # prioritised replay (replay_buffer.py:64-76): the reference keeps one CPU SumTree per sequence; here the trees of all
@@ -72,9 +86,11 @@ class ReplayBuffer:
         from .. import ops
         states, actions, rewards, undones, unmasks = items
         start = self._advance(rewards.shape[0])
-        ops.replay_write(self.states, self.actions, self.rewards, self.undones, self.unmasks,
-                         (states.contiguous(), actions.contiguous(), rewards.contiguous(), undones.contiguous(),
-                          unmasks.contiguous()), start)
+        items = (states.contiguous(), actions.contiguous(), rewards.contiguous(), undones.contiguous(), unmasks.contiguous())
+        if self._ring is not None:
+            self._ring.write(items, start)
+        else:
+            ops.replay_write(self.states, self.actions, self.rewards, self.undones, self.unmasks, items, start)
         if self.if_use_per:                          # new rows enter with the maximum priority (replay_buffer.py:107-115)
             self.sum_trees.add_rows(start, self.add_size, 10.0)
 
@@ -96,8 +112,11 @@ class ReplayBuffer:
                 self._stage = ops.ReplayStage(B, self.states.shape[2], 1 if self.if_discrete else self.actions.shape[2],
                                               self.if_discrete, self.device)
             stage = self._stage
-        out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
-                                                        ids, sample_len, stage=stage)
+        if self._ring is not None:
+            out, (self.ids0, self.ids1) = self._ring.sample(ids, sample_len, stage=stage)
+        else:
+            out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
+                                                            ids, sample_len, stage=stage)
         return out
 
     def ring_for_fused_sample(self, batch_size: int):
@@ -109,7 +128,8 @@ class ReplayBuffer:
             return None
         if self._stage is None or self._stage.B != batch_size:
             self._stage = ops.ReplayStage(batch_size, self.states.shape[2], self.actions.shape[2], False, self.device)
-        return (self.states, self.actions, self.rewards, self.undones, self.unmasks), self.cur_size - 1, self._stage
+        arrays = self._ring if self._ring is not None else (self.states, self.actions, self.rewards, self.undones, self.unmasks)
+        return arrays, self.cur_size - 1, self._stage
 
     @_hip.on_device
     def sample_for_per(self, batch_size: int, uniform: Optional[TEN] = None):
@@ -127,8 +147,11 @@ class ReplayBuffer:
             uniform = th.rand((self.num_seqs, sub), dtype=th.float32, device=self.device)
         # full ring: the newest row (p - 1) is followed in memory by the oldest one -- never drawn (oracle/per_numpy.py D6)
         is_indices, is_weights = self.sum_trees.sample(uniform, self.cur_size, self.per_beta, cursor=self.p if self.if_full else -1)
-        out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
-                                                        is_indices, self.cur_size)     # ids0 = fmod, ids1 = div (:155-156)
+        if self._ring is not None:                                                      # ids0 = fmod, ids1 = div (:155-156)
+            out, (self.ids0, self.ids1) = self._ring.sample(is_indices, self.cur_size)
+        else:
+            out, (self.ids0, self.ids1) = ops.replay_sample(self.states, self.actions, self.rewards, self.undones, self.unmasks,
+                                                            is_indices, self.cur_size)
         return (*out, is_weights, is_indices)
 
     @_hip.on_device
@@ -145,7 +168,7 @@ class ReplayBuffer:
         if if_save:
             for item, name in named:
                 if self.cur_size == self.p:
-                    buf_item = item[:self.cur_size]
+                    buf_item = item[:self.cur_size].contiguous()     # (a view of the interleaved block would drag the whole block into the file)
                 else:
                     buf_item = th.vstack((item[self.p:self.cur_size], item[0:self.p]))
                 path = f"{cwd}/replay_buffer_{name}.pth"

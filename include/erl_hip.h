@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 17
+#define ERL_ABI_VERSION 18
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -163,6 +163,23 @@ ERL_API int erl_replay_sample_discrete_f32(const float *buf_states, const uint8_
                                    float *out_state, uint8_t *out_action, float *out_reward, float *out_undone,
                                    float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1,
                                    void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8 / K9 on the INTERLEAVED ring (ABI 18).  The reference keeps five planar tensors (max_size, num_seqs, .)
+ * (elegantrl/train/replay_buffer.py:40-58); a random transition then touches six to seven 128-byte lines for 232 algorithmic bytes.
+ * Here the ring is ONE block ring[num_seqs][max_size][RW] fp32, RW = erl_replay_row_floats(S, A) = S + A + 3 rounded up to 4 floats,
+ * row = [state (S) | action (A) | reward | undone | unmask | pad], sequence-major so that states[ids0 + 1, ids1] (:133) is the head of the
+ * next row: one sample reads RW + S consecutive floats.  Same arguments and results as erl_replay_write_f32 / erl_replay_sample_f32
+ * otherwise (indices bit-exact, rows bit-exact copies); the Python class exposes the reference's attributes as strided views of the block.
+ * sample_len <= max_size; an id that decodes to ids0 = max_size - 1 (no following row: the reference raises) gets its own row as next state.
+ * ------------------------------------------------------------------------------------------- */
+ERL_API int64_t erl_replay_row_floats(int S, int A);
+ERL_API int erl_replay_write_rows_f32(float *ring, int64_t max_size, int64_t num_seqs, int S, int A, const float *states,
+                              const float *actions, const float *rewards, const void *undones, const void *unmasks,
+                              int flag_is_f32, int64_t p, int64_t add, void *stream);
+ERL_API int erl_replay_sample_rows_f32(const float *ring, int64_t max_size, int64_t num_seqs, int S, int A, const int64_t *ids, int64_t B,
+                               int64_t sample_len, float *out_state, float *out_action, float *out_reward, float *out_undone,
+                               float *out_unmask, float *out_next_state, int64_t *out_ids0, int64_t *out_ids1, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Prioritised experience replay: the per-sequence SumTree of replay_buffer.py:226-299 as device-resident
@@ -554,6 +571,8 @@ typedef struct ErlRingSample {
     const int64_t *ids;
     int64_t sample_len;
     int64_t *out_ids0, *out_ids1;
+    int64_t row_floats;     /* ABI 18: 0 = the five planar arrays above; > 0 = the interleaved ring (erl_replay_row_floats): buf_states is
+                             * the block's base, the other four pointers are ignored */
 } ErlRingSample;
 
 /* AgentModSAC (elegantrl/agents/AgentSAC.py:89-165) on the same step: ErlSacOptions names what differs from AgentSAC (ABI 17).

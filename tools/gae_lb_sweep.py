@@ -46,10 +46,20 @@ def measure(H, N, algo, L=None, W=None):
     th.cuda.synchronize()
     cold, n = _hip.kernel_span_read(_hip.SPAN_GAE)
     _hip.kernel_span_enable(False)
+    # cold behind READS: the same buffer summed instead of rewritten -- the caches are full of CLEAN lines, nothing is written back while
+    # the scan runs (behind writes the scan shares HBM with up to 256 MB of the writer's dirty lines leaving the Infinity Cache)
+    _hip.kernel_span_enable(True)
+    for _ in range(10):
+        FLUSH.view(th.int32).sum()
+        run()
+    th.cuda.synchronize()
+    cold_r, n = _hip.kernel_span_read(_hip.SPAN_GAE)
+    _hip.kernel_span_enable(False)
     _hip.check_async_faults()
     print(json.dumps({"H": H, "N": N, "algo": algo, "L": L, "W": W, "kernel_us": round(us, 2), "GBps": round(18.0 * H * N / us / 1e3, 1),
                       "frac": round(18.0 * H * N / us / 1e3 / 8000.0, 4), "cold_kernel_us": round(cold, 2),
-                      "cold_frac": round(18.0 * H * N / cold / 1e3 / 8000.0, 4)}), flush=True)
+                      "cold_frac": round(18.0 * H * N / cold / 1e3 / 8000.0, 4), "cold_behind_reads_us": round(cold_r, 2),
+                      "cold_behind_reads_frac": round(18.0 * H * N / cold_r / 1e3 / 8000.0, 4)}), flush=True)
 
 
 combos = [(None, None), (2, 8), (2, 16), (4, 4), (4, 8), (4, 16), (8, 4), (8, 8), (8, 16), (16, 4), (16, 8)]
