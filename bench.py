@@ -221,7 +221,7 @@ def kernel_source_sha16(kernel: str):
 
 
 C3_PMC_FILE = os.path.join("profiles", "r05_c3_pmc.json")            # tools/c3_pmc_workload.py under rocprofv3 --pmc (critic_tile_kernel, replay_sample_kernel)
-K9_PMC_FILE = os.path.join("profiles", "r05_k9_pmc_by_size.json")    # ... replay_sample_kernel per (num_seqs, B) case: FETCH_SIZE / WRITE_SIZE bytes
+K9_PMC_FILE = os.path.join("profiles", "r06_k9_pmc_by_size.json")    # ... replay_sample_kernel per (num_seqs, B) case: FETCH_SIZE / WRITE_SIZE bytes
 WIDE_PMC_FILE = os.path.join("profiles", "r04_wide_pmc_traffic_S8_h128.json")     # tools/wide_pmc_workload.py, WD_S=8 WD_A=2 WD_ONLY=128 (cw's shape)
 
 
@@ -435,7 +435,7 @@ def bench_sac(opt):
                     th.rand((max_size // 2 + 7, N), device=dev, generator=g) < 0.995))
     assert buf.if_full and buf.cur_size == max_size
     t_k9 = EventTimer()
-    ops.replay_sample = t_k9.wrap(ops.replay_sample)
+    buf.sample = t_k9.wrap(buf.sample)        # (the class's sample: the interleaved ring's row kernel since round 6)
 
     def step():
         buf.update(agent.explore_env(env, H))
@@ -477,11 +477,11 @@ def bench_sac(opt):
         for bsz in (256, 4096, 1 << 20):
             idx = th.randint((ring.cur_size - 1) * seqs, (bsz,), device=dev, generator=g)
             for _ in range(3):
-                ops.replay_sample(ring.states, ring.actions, ring.rewards, ring.undones, ring.unmasks, idx, ring.cur_size - 1)
+                ring.sample(bsz, ids=idx, reuse=True)
             th.cuda.synchronize()
             _hip.kernel_span_enable(True)
             for _ in range(20):
-                ops.replay_sample(ring.states, ring.actions, ring.rewards, ring.undones, ring.unmasks, idx, ring.cur_size - 1)
+                ring.sample(bsz, ids=idx, reuse=True)
             us, _n = _hip.kernel_span_read(_hip.SPAN_REPLAY_SAMPLE)
             _hip.kernel_span_enable(False)
             by = (2 * (2 * S + A + 3) * 4 + 8) * bsz
@@ -503,12 +503,13 @@ def bench_sac(opt):
         pass
     # the kernel's capability away from the launch floor: one sample call of 2^20 transitions on the same ring
     big = th.randint((max_size - 1) * N, (1 << 20,), device=dev, generator=g)
+    t_k9.enabled = False
     for _ in range(3):
-        ops.replay_sample(buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks, big, max_size - 1)
+        buf.sample(1 << 20, ids=big, reuse=True)
     e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        ops.replay_sample(buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks, big, max_size - 1)
+        buf.sample(1 << 20, ids=big, reuse=True)
     e1.record()
     th.cuda.synchronize()
     big_s = e0.elapsed_time(e1) * 1e-4
@@ -531,7 +532,8 @@ def bench_sac(opt):
                       "note": "fp32 MFMA 16x16x4; a 16-sample tile x decoder per workgroup streams the decoder's whole 256 x 256 layer (forward and "
                               "transposed) through ONE CU: bound by that CU's ~12 B/clk from L2, not by the matrix pipe or HBM (DESIGN.md section 4, SAC)"}
                      if crit_us else None),
-        "roofline_sample": {"kernel": "replay_sample_kernel", "bound": "hbm", "achieved": round(bytes_per / k9_s / 1e9, 2), "peak": HBM_PEAK_GBPS,
+        "roofline_sample": {"kernel": "replay_sample_rows_kernel (the interleaved ring, round 6: one row [state | action | reward | undone | unmask] per transition, "
+                                      "its next state the head of the following row)", "bound": "hbm", "achieved": round(bytes_per / k9_s / 1e9, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(bytes_per / k9_s / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                      "bytes_per_launch": bytes_per, "avg_launch_us": round(k9_s * 1e6, 2), "launches_timed": len(t_k9.pairs),
                      "in_loop": not sample_in_step,

@@ -64,8 +64,10 @@ extern "C" int erl_async_fault_count(int reset)
         "peer-to-peer gradient exchange: %u wait(s) for a peer's slice timed out (a rank is missing or stalled); the optimiser steps "
         "from that exchange on were SKIPPED (parameters and moments untouched). ",
         "clip + Adam grid wait: %u workgroup(s) gave up waiting for the rest of the launch (device shared with another process?); "
-        "those parameter updates were SKIPPED. "};
-    char msg[512] = "";
+        "those parameter updates were SKIPPED. ",
+        "SAC critic training pass: %u wait(s) for another workgroup's share of q timed out; the affected samples' q, and the critic "
+        "gradient of that step, are NaN. "};
+    char msg[768] = "";
     uint64_t total = 0;
     for (int s = 0; s < ERL_FAULT_SOURCES; ++s) {
         const uint32_t n = __atomic_load_n(g_fault_host + s, __ATOMIC_ACQUIRE);

@@ -12,7 +12,7 @@
 void erl_set_error(const char *fmt, ...);
 // pinned host-mapped counters that device code bumps for faults an asynchronous launch cannot return; one word per source
 // (api.cpp), read through erl_async_fault_count.  NULL when pinned memory is unavailable.
-enum ErlFaultSource { ERL_FAULT_GAE_LOOKBACK = 0, ERL_FAULT_P2P_EXCHANGE = 1, ERL_FAULT_ADAM_GRID_WAIT = 2, ERL_FAULT_SOURCES = 3 };
+enum ErlFaultSource { ERL_FAULT_GAE_LOOKBACK = 0, ERL_FAULT_P2P_EXCHANGE = 1, ERL_FAULT_ADAM_GRID_WAIT = 2, ERL_FAULT_SAC_Q_EXCHANGE = 3, ERL_FAULT_SOURCES = 4 };
 uint32_t *erl_fault_word(int source);
 
 // ---- one-shot peer-to-peer exchange (p2p.hip owns the IPC-mapped stages, grad_tail.hip the kernels) ----------------------

@@ -43,6 +43,7 @@ constexpr int TS = 16;                 // samples per tile
 constexpr int LDT = 260;               // LDS image row stride (floats): 16-byte aligned rows, consecutive samples 4 banks apart
 constexpr int FMAXW = 256;             // widest hidden layer
 constexpr int FMAXE = 8;
+constexpr int kQxSplit = 4;             // feature slices per decoder in the split critic training pass (= kCritSplit)
 constexpr float kLogSqrt2PiF2 = 0.91893853320467274178f;
 
 struct FusedDims {
@@ -74,6 +75,8 @@ __device__ long long g_fprof[8][32];
 struct LaneId {
     int tid, wave, lane, l15, q;
 };
+// a 16-byte write-through store: visible to the other XCDs once acknowledged (s_waitcnt vmcnt(0)), no fence, no whole-L2 write-back
+__device__ __forceinline__ void st4_sc1(float *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ LaneId lane_id()
 {
     LaneId L;
@@ -198,9 +201,11 @@ __device__ __forceinline__ void layer_fwd_mma(FwdW<KT_, NU> &w, const float *__r
 
 // the epilogue of a hidden layer: optional exact-erf GELU, the LDS image for the next layer, optional copies in memory
 // (H: what the next layer's weight gradient contracts with; G: GELU' for a backward pass in another kernel)
+// (`ldg`: the rows of gH / gG are ldg floats apart -- a feature slice stored into the full-width matrix; 0: ldg = N)
 __device__ __forceinline__ void emit_hidden(const f32x4 (&z)[2], int N, bool gelu, float *Tout, f32x4 (&gk)[2], float *gH, float *gG, int64_t row,
-                                            bool valid, const LaneId &L)
+                                            bool valid, const LaneId &L, int ldg = 0)
 {
+    if (ldg == 0) ldg = N;
     const int NT = (N + 15) >> 4;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -217,8 +222,8 @@ __device__ __forceinline__ void emit_hidden(const f32x4 (&z)[2], int N, bool gel
         }
         *reinterpret_cast<float4 *>(Tout + L.l15 * LDT + f) = make_float4(h[0], h[1], h[2], h[3]);
         if (valid && f < N) {                                     // hidden widths are multiples of 16: whole float4s
-            if (gH) *reinterpret_cast<float4 *>(gH + row * N + f) = make_float4(h[0], h[1], h[2], h[3]);
-            if (gG) *reinterpret_cast<float4 *>(gG + row * N + f) = make_float4(g[0], g[1], g[2], g[3]);
+            if (gH) *reinterpret_cast<float4 *>(gH + row * ldg + f) = make_float4(h[0], h[1], h[2], h[3]);
+            if (gG) *reinterpret_cast<float4 *>(gG + row * ldg + f) = make_float4(g[0], g[1], g[2], g[3]);
         }
     }
 }
@@ -566,19 +571,44 @@ struct CriticArgs {
     int split;
     int qt_split;                            // MODE 1: qt holds [E][qt_split][B] partial target values
     unsigned long long *span;                // measurement hook (erl_common.h: erl_span_*; set for the training pass); nullptr = off
+    // MODE 1 with split > 1 (round 6).  The training pass's backward needs the FULL q of its own forward, so the `split` workgroups of a
+    // (tile, decoder) exchange their shares of q inside the launch: each publishes {share, nonce} as ONE 8-byte agent-scope granule per
+    // sample in qx[E * split][B] (library-owned, never cleared: the per-launch nonce invalidates older contents) and reads the others'
+    // -- a bounded wait among workgroups that are all resident (tiles * E * split <= 256, three fit a CU) -- then every one of them adds
+    // the shares in slice order (the same bits everywhere) and carries on with its own 64 hidden features: dZ1 and its slice of the
+    // decoder's weight-gradient operands go straight to their places in the full-width matrices (h1_full), the share of dEnc = W1^T dZ1
+    // goes to dEncP[E * split](B, h0) and the LAST of the four to arrive (arrive[tile * E + e], re-armed by it) adds the shares in slice
+    // order into dEncE.  A workgroup streams 64 KB of the decoder (forward) + 64 KB (transposed) instead of 256 + 256 KB through one CU.
+    int h1_full;                             // the decoder's hidden width when d.h1 is a slice's (0: d.h1)
+    unsigned long long *qx;
+    uint32_t nonce, spin_limit;
+    float *dEncP;
+    unsigned *arrive;
+    uint32_t *fault;
 };
 
+// (the training pass on decoder SLICES -- MODE 1, C1 = 0: 64 features -- is compiled for two workgroups per CU: its 256 workgroups wait for
+// each other's shares of q, so they must all be resident while the policy-gradient sample runs next to them on the side stream; at one
+// workgroup per CU -- 149 registers -- the late ones kept their partners spinning: 34.8 us a launch against the unsplit 28.2)
 template <int MODE, int C0, int C1>
-__global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
+__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 && C1 == 0) ? 4 : 2))) void critic_tile_kernel(CriticArgs g)
 {
     __shared__ TileLds lds;
     __shared__ float dql[TS];
     const unsigned long long t_span = MODE == 1 ? erl_span_in(g.span) : 0ull;
     const LaneId L = lane_id();
     const FusedDims &d = g.d;
-    const int ey = blockIdx.y, e = ey / g.split, E = d.E;
+    // MODE 1 with slices: the `split` workgroups of a (tile, decoder) are CONSECUTIVE in dispatch order (they wait for each other: they
+    // should become resident together), i.e. the slice is the fastest index of the linear workgroup id
+    int bx = blockIdx.x, ey = blockIdx.y;
+    if (MODE == 1 && g.split > 1) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, sl = lin % g.split, rest = lin / g.split;
+        bx = rest % gridDim.x;
+        ey = (rest / gridDim.x) * g.split + sl;
+    }
+    const int e = ey / g.split, E = d.E;
     const int64_t fo = (int64_t)(ey - e * g.split) * d.h1;          // first hidden feature of this workgroup's slice
-    const int64_t B = d.B, row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
+    const int64_t B = d.B, row0 = (int64_t)bx * TS, row = row0 + L.l15;
     const bool valid = row < B;
     const float *Pd = g.P + d.cdec0 + (int64_t)e * d.dec;
     const bool first = ey == 0;
@@ -590,26 +620,55 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
     layer_small_load<false, true>(Pd + d.dWo + fo, d.h1, 1, 0, 0, L, wo);
     clear_images(lds.T0, lds.T1, L);
     lds_barrier();
+    if (MODE == 1) FPROF(1, 0);
     load_rows(g.Xs, d.S, g.Xa, d.A, row0, B, lds.T0, (MODE == 1 && first) ? g.xa : nullptr, L);
     lds_barrier();
+    if (MODE == 1) FPROF(1, 1);
     f32x4 z[2], gk[2], gk1[2];
     layer_fwd_mma<4, WClass<C0>::NU, false>(we, g.P + d.cbe, d.S + d.A, d.h0, lds.T0, L, z);            // shared encoder: raw linear
     emit_hidden(z, d.h0, false, lds.T1, gk, (MODE == 1 && first) ? g.enc : nullptr, nullptr, row, valid, L);
     lds_barrier();
+    if (MODE == 1) FPROF(1, 2);
     layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w1, Pd + d.db1 + fo, d.h0, d.h1, lds.T1, L, z);
     // the backward pass's weights are requested now (the forward layer's registers are free): they land under the output layer,
     // the loss and the gate
     BwdW<WClass<C1>::KT, WClass<C0>::NU> wb;
     SmallW wa;
-    emit_hidden(z, d.h1, true, lds.T0, gk1, MODE == 1 ? g.H1e + (size_t)e * B * d.h1 : nullptr, nullptr, row, valid, L);
+    const int h1f = g.h1_full ? g.h1_full : d.h1;
+    emit_hidden(z, d.h1, true, lds.T0, gk1, MODE == 1 ? g.H1e + (size_t)e * B * h1f + fo : nullptr, nullptr, row, valid, L, h1f);
     if (MODE != 0) layer_bwd_load<WClass<C1>::KT, WClass<C0>::NU>(Pd + d.dW1 + fo * d.h0, d.h1, d.h0, L, wb);
     if (MODE == 2) layer_small_load<true, false>(g.P + d.cWe, d.h0, d.A, d.S + d.A, d.S, L, wa);
     lds_barrier();
+    if (MODE == 1) FPROF(1, 3);
     layer_small_mma<false, true>(wo, fo == 0 ? Pd + d.dbo : nullptr, d.h1, 1, lds.T0, lds.part, lds.Yl, L);
+    if (MODE == 1) FPROF(1, 4);
     if (MODE == 0) {
         if (L.tid < TS && row0 + L.tid < B) g.q[(size_t)ey * B + row0 + L.tid] = lds.Yl[L.tid * 16];
         return;
     }
+    if (MODE == 1 && g.split > 1) {
+        // ---- the slices' shares of q meet here (CriticArgs::qx): publish, then read all `split` of them in slice order
+        if (L.tid < TS && row0 + L.tid < B) {
+            const int64_t b = row0 + L.tid;
+            __hip_atomic_store(g.qx + (size_t)ey * B + b, (unsigned long long)__float_as_uint(lds.Yl[L.tid * 16]) | ((unsigned long long)g.nonce << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float qv = 0.f;
+            for (int j = 0; j < g.split; ++j) {
+                const unsigned long long *src = g.qx + (size_t)(e * g.split + j) * B + b;
+                unsigned long long gr = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t spins = 0; (uint32_t)(gr >> 32) != g.nonce && spins < g.spin_limit; ++spins) {
+                    __builtin_amdgcn_s_sleep(1);
+                    gr = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const bool ready = (uint32_t)(gr >> 32) == g.nonce;
+                // bounded: a share that never arrives poisons this sample's q with NaN AND is counted in the host-visible fault word
+                if (!ready && g.fault) __hip_atomic_fetch_add(g.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                qv += ready ? __uint_as_float((uint32_t)gr) : __uint_as_float(0x7FC00000u);
+            }
+            lds.Yl[L.tid * 16] = qv;
+        }
+    }
+    if (MODE == 1) FPROF(1, 5);
     // ---- the target's q of the next state, E values per sample: thread (sample, k) adds the qt_split partial values the target pass left
     __shared__ float qtl[TS * FMAXE];
     if (MODE == 1) {
@@ -631,7 +690,8 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
         float dqv = 0.f;
         if (b < B) {
             const float qv = lds.Yl[L.tid * 16];
-            g.q[(size_t)ey * B + b] = qv;
+            if (MODE != 1 || g.split <= 1) g.q[(size_t)ey * B + b] = qv;
+            else if (fo == 0) g.q[(size_t)e * B + b] = qv;             // (the full q: every slice holds the same bits, slice 0 stores them)
             if (MODE == 1) {
                 // q_label = reward + undone * gamma * (min_e q_target - next_logprob * alpha)      (AgentSAC.py:52-55)
                 float m = qtl[L.tid * FMAXE];
@@ -642,7 +702,7 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
                 // td = mean_e (q - label)^2 * unmask; obj = mean_b (td w): dq = 2 (q - label) unmask w / (E B)   (:57-62)
                 const float w = g.is_weight ? g.is_weight[b] : 1.f;
                 dqv = 2.f * (qv - lab) * g.unmask[b] * w / ((float)E * (float)B);
-                g.dq[(size_t)e * B + b] = dqv;
+                if (fo == 0) g.dq[(size_t)e * B + b] = dqv;
             } else {
                 dqv = -1.0f / ((float)E * (float)B);               // L = -(mean_b mean_e q - alpha mean_b logprob)   (:82-84)
             }
@@ -672,6 +732,7 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
         }
     }
     lds_barrier();
+    if (MODE == 1) FPROF(1, 6);
     // ---- dZ1 = (Wo^T dq) * GELU'(z1): the wave's own tiles (it still holds their GELU')
     {
         const int NT = (d.h1 + 15) >> 4;
@@ -686,10 +747,11 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
             for (int r = 0; r < 4; ++r) v[r] = (f + r < d.h1) ? Pd[d.dWo + fo + f + r] * dqs * gk1[u][r] : 0.f;
             *reinterpret_cast<float4 *>(lds.T1 + L.l15 * LDT + f) = make_float4(v[0], v[1], v[2], v[3]);
             if (MODE == 1 && valid && f < d.h1)
-                *reinterpret_cast<float4 *>(g.dZ1e + ((size_t)e * B + row) * d.h1 + f) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(g.dZ1e + ((size_t)e * B + row) * h1f + fo + f) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     lds_barrier();
+    if (MODE == 1) FPROF(1, 7);
     // ---- dEnc = W1^T dZ1 (the encoder is a raw linear layer: no gate)
     f32x4 dx[2];
     layer_bwd_mma<WClass<C1>::KT, WClass<C0>::NU>(wb, d.h1, d.h0, lds.T1, L, dx);
@@ -701,14 +763,59 @@ __global__ __launch_bounds__(FT) void critic_tile_kernel(CriticArgs g)
             if (it >= NT) continue;
             const int f = 16 * it + 4 * L.q;
             if (MODE == 1) {
-                if (valid && f < d.h0)
-                    *reinterpret_cast<float4 *>(g.dEncE + ((size_t)e * B + row) * d.h0 + f) = make_float4(dx[u][0], dx[u][1], dx[u][2], dx[u][3]);
+                if (valid && f < d.h0) {
+                    if (g.split > 1) {                           // this slice's share: a 16-byte write-through (`sc1`) store, past the per-XCD L2
+                        st4_sc1(g.dEncP + ((size_t)ey * B + row) * d.h0 + f, f32x4{dx[u][0], dx[u][1], dx[u][2], dx[u][3]});
+                    } else {
+                        *reinterpret_cast<float4 *>(g.dEncE + ((size_t)e * B + row) * d.h0 + f) = make_float4(dx[u][0], dx[u][1], dx[u][2], dx[u][3]);
+                    }
+                }
             } else {
                 *reinterpret_cast<float4 *>(lds.T0 + L.l15 * LDT + f) = make_float4(dx[u][0], dx[u][1], dx[u][2], dx[u][3]);
             }
         }
     }
+    if (MODE == 1) FPROF(1, 8);
     if (MODE == 1) {
+        if (g.split > 1) {
+            // the last of the (tile, decoder)'s workgroups to arrive adds the shares of dEnc in slice order (actor_fwd_kernel's idiom)
+            __shared__ int s_last1;
+            // (16-byte `sc1` stores and loads spelled out: float-by-float agent-scope atomics cost 32 dependent round trips in the last
+            // workgroup -- 45 us a launch --, release / acquire FENCES a whole-L2 write-back and invalidate per wave -- 70 us)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (L.tid == 0) {
+                unsigned *cnt = g.arrive + (size_t)bx * E + e;
+                const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last1 = old == (unsigned)g.split - 1u;
+                if (s_last1) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
+            }
+            __syncthreads();
+            if (s_last1) {
+                const int NT = (d.h0 + 15) >> 4;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int it = L.wave + FWV * u;
+                    const int f = 16 * it + 4 * L.q;
+                    if (it >= NT || !valid || f >= d.h0) continue;
+                    static_assert(kQxSplit == 4, "the asm below fetches four shares");
+                    const float *p0 = g.dEncP + ((size_t)(e * kQxSplit) * B + row) * d.h0 + f;
+                    const size_t sl = (size_t)B * d.h0;
+                    f32x4 s0, s1, s2, s3;
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                                 "global_load_dwordx4 %1, %5, off sc1\n\t"
+                                 "global_load_dwordx4 %2, %6, off sc1\n\t"
+                                 "global_load_dwordx4 %3, %7, off sc1\n\t"
+                                 "s_waitcnt vmcnt(0)"
+                                 : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+                                 : "v"(p0), "v"(p0 + sl), "v"(p0 + 2 * sl), "v"(p0 + 3 * sl)
+                                 : "memory");
+                    const f32x4 acc = ((s0 + s1) + s2) + s3;                   // slice order
+                    *reinterpret_cast<float4 *>(g.dEncE + ((size_t)e * B + row) * d.h0 + f) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+        }
+        FPROF(1, 9);
         erl_span_out(g.span, t_span);
         return;
     }
@@ -849,7 +956,8 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
 // v_mfma_f32_32x32x2_f32 with both operands straight from memory (16 row pairs in flight), the four partial tiles meet in LDS and
 // are added in wave order.  The bias gradient rides the A operand of the tile column 0.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DW_MAXP = 12;
+constexpr int DW_MAXP = 1 + 2 * FMAXE;      // the critic's table: the shared encoder + two layers per decoder (round 6: was 12 -- eight critics
+                                           // wrote five problems past the table on the host: found by tests/test_sac.py's E = 8 case)
 struct DwProb {
     const float *dZ; int64_t sZ; int nZ; int M;     // (B, M) row-major, nZ matrices sZ floats apart summed in order
     const float *X; int N;                          // (B, N) row-major
@@ -945,6 +1053,7 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
 
 int dw_add(DwArgs &a, const float *dZ, int64_t sZ, int nZ, int M, const float *X, int N, float *dW, float *db)
 {
+    if (a.np >= DW_MAXP) { a.np = DW_MAXP + 1; return -1; }          // (dw_launch refuses a table that overflowed)
     DwProb &p = a.p[a.np];
     p.dZ = dZ; p.sZ = sZ; p.nZ = nZ; p.M = M; p.X = X; p.N = N; p.dW = dW; p.db = db;
     p.tiles_n = (N + 31) / 32;
@@ -955,6 +1064,7 @@ int dw_add(DwArgs &a, const float *dZ, int64_t sZ, int nZ, int M, const float *X
 
 int dw_launch(const DwArgs &a, hipStream_t s)
 {
+    ERL_REQUIRE(a.np >= 1 && a.np <= DW_MAXP, "erl_sac_update_f32(fused): weight-gradient table of %d problems", a.np);
     const DwProb &last = a.p[a.np - 1];
     ERL_REQUIRE(!a.norm_parts || last.tile0 + last.ntiles <= kDwMaxParts, "erl_sac_update_f32(fused): %d weight-gradient tiles, table of %d",
                 last.tile0 + last.ntiles, kDwMaxParts);
@@ -995,6 +1105,9 @@ struct SacSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     unsigned *arrive = nullptr;           // [256] arrival counters of the split actor forward (zero between launches), owned by this slot
+    unsigned *arrive1 = nullptr;          // [256] ... of the split critic training pass (its dEnc shares)
+    unsigned long long *qx = nullptr;     // [FMAXE * kQxSplit * 4096] granules {share of q, nonce}: the split critic training pass's q exchange
+    uint32_t nonce = 0;
 };
 SacSide g_sac_side[16];
 
@@ -1017,8 +1130,16 @@ SacSide *sac_side_stream(hipStream_t owner)
             return nullptr;
         }
         void *cnt = nullptr;
-        if (hipMalloc(&cnt, 256 * sizeof(unsigned)) == hipSuccess && hipMemset(cnt, 0, 256 * sizeof(unsigned)) == hipSuccess) q.arrive = (unsigned *)cnt;
-        else (void)hipGetLastError();          // (no counters: the actor's forward stays unsplit)
+        if (hipMalloc(&cnt, 512 * sizeof(unsigned)) == hipSuccess && hipMemset(cnt, 0, 512 * sizeof(unsigned)) == hipSuccess) {
+            q.arrive = (unsigned *)cnt;
+            q.arrive1 = q.arrive + 256;
+        } else {
+            (void)hipGetLastError();          // (no counters: the actor's forward and the critic's training pass stay unsplit)
+        }
+        void *qx = nullptr;
+        const size_t qx_bytes = (size_t)FMAXE * kQxSplit * 4096 * sizeof(unsigned long long);
+        if (hipMalloc(&qx, qx_bytes) == hipSuccess && hipMemset(qx, 0, qx_bytes) == hipSuccess) q.qx = (unsigned long long *)qx;
+        else (void)hipGetLastError();
         q.device = dev;
         q.owner = owner;
         return &q;
@@ -1322,6 +1443,7 @@ int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, 
     f += r((int64_t)kCritSplit * E * B) + 2 * r((int64_t)E * B) + r(B);  // qt (also q_pg; up to kCritSplit partial values each), qc, dq | label
     f += r(B * (S + A)) + r(B * h0);                                    // xa, enc
     f += 2 * r((int64_t)E * B * h1) + r((int64_t)E * B * h0);           // H1e, dZ1e | dEncE
+    f += r((int64_t)kCritSplit * E * B * h0);                           // dEncP: the slices' shares of dEnc (split training pass)
     f += r(B * 2 * A) * 2 + 2 * r(B * h0) + 2 * r(B * h1);              // Y, dY | H0, G0 | H1, G1
     f += r((int64_t)kCritSplit * E * B * A) + r(B * h1) + r(B * h0);     // dAct | dZ2, dZ1 (actor)
     f += r(Pa) + r(Pc) + r((int64_t)kCritSplit * E * tiles) + r(tiles) + 64;   // gradients, partial sums, alpha0
@@ -1385,6 +1507,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     float *act_pg = take(B * A);                        // (its own buffer: the policy-gradient sample runs next to the critic update)
     double *nparts_c = reinterpret_cast<double *>(take(2 * kDwMaxParts)), *nparts_a = reinterpret_cast<double *>(take(2 * kDwMaxParts));
     float *ypart = take((int64_t)kCritSplit * B * 2 * A);      // the slices' shares of the actor's head output (launch (1))
+    float *dEncP = take((int64_t)kCritSplit * E * B * h0);     // the slices' shares of dEnc (launch (3))
     float *q_pg = qt;                                   // reused once its first contents are consumed
     const dim3 tgrid(tiles), cgrid(tiles, E), blk(FT);
     int rc;
@@ -1457,14 +1580,28 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
 #define LAUNCH_CRITIC2(K0, K1) LAUNCH_CRITIC(2, K0, K1)
     FUSED_KT_DISPATCH_D(dsl, LAUNCH_CRITIC0)
     // ---- (3) critic training pass: labels, loss gradient, backward to the encoder output                      (:53-62)
-    cg = cgrid;
-    ca.d = d; ca.split = 1; ca.qt_split = split;
+    // (round 6: split like (2) and (7); its workgroups exchange q inside the launch -- CriticArgs::qx; ERL_SAC_TRAIN_SPLIT=1 selects it)
+    // OFF by default: measured at config 3 (B = 256, 4 critics, profiles/r06_sac_train_split_ab.txt) the split launch is 33.2 us against the
+    // unsplit 28.9 -- workgroup (0, 0) itself runs 28.7k cycles instead of 40.8k (tools/sac_fused_profile.py: the decoder's forward 6.7k
+    // instead of 18.2k, its backward 2.6k instead of 7.4k) but pays 3.4k for the q exchange and 7.1k for the dEnc shares, and 256 mutually
+    // waiting workgroups start later and finish more raggedly than 64 independent ones.  ERL_SAC_TRAIN_SPLIT=1 turns it on (read per call).
+    const char *ts_env = getenv("ERL_SAC_TRAIN_SPLIT");
+    const bool tsplit_on = ts_env && atoi(ts_env) == 1;
+    const int tsplit = (split > 1 && tsplit_on && side && side->arrive1 && side->qx && B <= 4096 && kCritSplit == kQxSplit) ? split : 1;
+    cg = tsplit > 1 ? dim3(tiles, E * tsplit) : cgrid;
+    ca.d = tsplit > 1 ? dsl : d; ca.split = tsplit; ca.qt_split = split; ca.h1_full = h1;
+    if (tsplit > 1) {
+        if (++side->nonce == 0) side->nonce = 1;
+        static const uint32_t lim = [] { const char *e = getenv("ERL_SAC_QX_SPIN"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1u << 22; }();
+        ca.qx = side->qx; ca.nonce = side->nonce; ca.spin_limit = lim; ca.dEncP = dEncP; ca.arrive = side->arrive1;
+        ca.fault = erl_fault_word(ERL_FAULT_SAC_Q_EXCHANGE);
+    }
     ca.P = critic_params; ca.Xs = state; ca.Xa = action; ca.q = qc;
     ca.qt = qt; ca.reward = reward; ca.undone = undone; ca.unmask = unmask; ca.lp_next = lp_next; ca.is_weight = is_weight; ca.alpha0 = alpha0;
     ca.gamma = gamma; ca.label = label; ca.dq = dq; ca.xa = xa; ca.enc = enc; ca.H1e = H1e; ca.dZ1e = dZ1e; ca.dEncE = dEncE;
     ca.span = erl_span_slot(ERL_SPAN_SAC_CRITIC_TRAIN, (int64_t)cg.x * cg.y);
-    FUSED_KT_DISPATCH(LAUNCH_CRITIC1)
-    ca.span = nullptr;
+    FUSED_KT_DISPATCH_D(ca.d, LAUNCH_CRITIC1)
+    ca.span = nullptr; ca.h1_full = 0;
     // ---- (4) every critic weight / bias gradient in one launch
     {
         DwArgs dw{};

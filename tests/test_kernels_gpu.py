@@ -425,6 +425,117 @@ def test_replay_large_random_vs_oracle(ops, dev):
             np.testing.assert_array_equal(t.cpu().numpy(), x)
 
 
+def test_interleaved_ring_against_reference_golden(ops, dev):
+    """K8 / K9 on the interleaved block (ops.ReplayRing: [seq][time][state | action | reward | undone | unmask | pad]) against the
+    reference's own ReplayBuffer run: the ring's contents THROUGH THE STRIDED VIEWS, the index split and every sampled row bit for bit;
+    the planar kernels on the same inputs leave the same bits."""
+    g = load("replay_ring.npz")
+    max_size, S, A, num_seqs = [int(x) for x in g["dims"]]
+    ring = ops.ReplayRing(max_size, num_seqs, S, A, dev)
+    assert ring.row_floats == (S + A + 3 + 3) // 4 * 4 and ring.block.shape == (num_seqs, max_size, ring.row_floats)
+    assert ring.states.shape == (max_size, num_seqs, S) and ring.actions.shape == (max_size, num_seqs, A) and ring.rewards.shape == (max_size, num_seqs)
+    assert ring.states.data_ptr() == ring.block.data_ptr() and not ring.states.is_contiguous()
+    ref = O.Ring(max_size, S, A, num_seqs)
+    for k, add in enumerate(g["adds"]):
+        items_np = tuple(g[f"in{k}_{n}"] for n in ("states", "actions", "rewards", "undones", "unmasks"))
+        ring.write([cu(x, dev) for x in items_np], ref.p)
+        ref.update(items_np)
+        for t, n in zip((ring.states, ring.actions, ring.rewards, ring.undones, ring.unmasks), ("states", "actions", "rewards", "undones", "unmasks")):
+            np.testing.assert_array_equal(t.cpu().numpy(), g[f"buf{k}_{n}"])
+        out, (i0, i1) = ring.sample(cu(g[f"ids{k}"], dev), ref.cur_size - 1)
+        np.testing.assert_array_equal(i0.cpu().numpy(), g[f"ids0_{k}"])
+        np.testing.assert_array_equal(i1.cpu().numpy(), g[f"ids1_{k}"])
+        for t, n in zip(out, ("state", "action", "reward", "undone", "unmask", "next_state")):
+            np.testing.assert_array_equal(t.cpu().numpy(), g[f"out{k}_{n}"])
+            assert t.dtype == th.float32
+    assert (ring.block[:, :, S + A + 3:] == 0).all()                      # the pad columns are never written
+
+
+@pytest.mark.parametrize("S,A,num_seqs,max_size", [(11, 3, 4, 1000), (3, 1, 1, 257), (64, 8, 3, 300), (17, 6, 2, 64)])
+def test_interleaved_ring_large_random_vs_oracle(ops, dev, S, A, num_seqs, max_size):
+    """several row widths (S + A + 3 = 17, 7, 75, 26 floats: with and without pad), wraps, bool and float flags, batches from one
+    workgroup's worth to many: writes and samples of the interleaved ring against oracle/ppo_numpy.Ring, bit for bit"""
+    rng = np.random.default_rng(S * 100 + A)
+    ref = O.Ring(max_size, S, A, num_seqs)
+    ring = ops.ReplayRing(max_size, num_seqs, S, A, dev)
+    for k, add in enumerate((max_size // 3, max_size // 2 + 1, max_size // 5, 1, max_size - 1, max_size)):
+        flags_f32 = k % 2 == 0
+        ud, um = rng.random((add, num_seqs)) > 0.1, rng.random((add, num_seqs)) > 0.1
+        items = (rng.standard_normal((add, num_seqs, S), dtype=np.float32), rng.standard_normal((add, num_seqs, A), dtype=np.float32),
+                 rng.standard_normal((add, num_seqs), dtype=np.float32), ud.astype(np.float32), um.astype(np.float32))
+        dev_items = [cu(x, dev) for x in items]
+        if not flags_f32:
+            dev_items[3], dev_items[4] = cu(ud, dev), cu(um, dev)        # torch.bool, as the rollout produces them
+        ring.write(dev_items, ref.p)
+        ref.update(items)
+        np.testing.assert_array_equal(ring.states.cpu().numpy(), ref.states)
+        np.testing.assert_array_equal(ring.actions.cpu().numpy(), ref.actions)
+        np.testing.assert_array_equal(ring.undones.cpu().numpy(), ref.undones)
+        for B in (7, 256, 5000):
+            ids = rng.integers(0, (ref.cur_size - 1) * num_seqs, size=B).astype(np.int64)
+            ids[0], ids[-1] = 0, (ref.cur_size - 1) * num_seqs - 1
+            out, (i0, i1) = ring.sample(cu(ids, dev), ref.cur_size - 1)
+            want, (r0, r1) = ref.sample(ids)
+            np.testing.assert_array_equal(i0.cpu().numpy(), r0)
+            np.testing.assert_array_equal(i1.cpu().numpy(), r1)
+            for t, x in zip(out, want):
+                np.testing.assert_array_equal(t.cpu().numpy(), x)
+
+
+def test_replay_buffer_views_of_the_interleaved_ring_behave_like_the_reference_tensors(dev, tmp_path):
+    """the class keeps the reference's attributes (elegantrl/train/replay_buffer.py:40-58) as strided views of the block: shapes, dtypes,
+    slicing, advanced indexing and ASSIGNMENT work as on the reference's planar tensors; `args.replay_interleaved = False` keeps planar
+    tensors and both layouts sample the same bits; save -> load round-trips across layouts (files hold contiguous rows, not the block)."""
+    from elegantrl_amd.train import Config, ReplayBuffer
+    max_size, S, A, Q = 50, 11, 3, 4
+    planar_args = Config()
+    planar_args.replay_interleaved = False
+    a = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=Q)
+    b = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=Q, args=planar_args)
+    assert a._ring is not None and b._ring is None and b.states.is_contiguous()
+    for buf in (a, b):
+        assert buf.states.shape == (max_size, Q, S) and buf.actions.shape == (max_size, Q, A)
+        assert buf.rewards.shape == buf.undones.shape == buf.unmasks.shape == buf.cum_rewards.shape == (max_size, Q)
+        assert all(t.dtype == th.float32 for t in (buf.states, buf.actions, buf.rewards, buf.undones, buf.unmasks))
+    g = th.Generator(device=dev).manual_seed(4)
+    for add in (20, 25, 17):                                              # the third one wraps
+        items = (th.randn((add, Q, S), device=dev, generator=g), th.randn((add, Q, A), device=dev, generator=g),
+                 th.randn((add, Q), device=dev, generator=g), th.rand((add, Q), device=dev, generator=g) > 0.1,
+                 th.rand((add, Q), device=dev, generator=g) > 0.1)
+        a.update(items)
+        b.update(items)
+        assert (a.p, a.cur_size, a.if_full) == (b.p, b.cur_size, b.if_full)
+        for x, y in zip((a.states, a.actions, a.rewards, a.undones, a.unmasks), (b.states, b.actions, b.rewards, b.undones, b.unmasks)):
+            n = a.cur_size
+            assert th.equal(x[:n], y[:n])
+        ids = th.randint((a.cur_size - 1) * Q, (64,), device=dev, generator=g)
+        for x, y in zip(a.sample(64, ids=ids), b.sample(64, ids=ids)):
+            assert th.equal(x, y)
+        assert th.equal(a.ids0, b.ids0) and th.equal(a.ids1, b.ids1)
+    # assignment through a view lands in the block (what run.py-style code that writes buffer.rewards[...] relies on)
+    a.rewards[3:5] = 7.0
+    a.states[0, 1] = th.arange(S, device=dev, dtype=th.float32)
+    assert (a._ring.block[:, 3:5, S + A] == 7.0).all() and th.equal(a._ring.block[1, 0, :S], th.arange(S, device=dev, dtype=th.float32))
+    b.rewards[3:5] = 7.0
+    b.states[0, 1] = th.arange(S, device=dev, dtype=th.float32)
+    # save from the interleaved buffer, load into a planar one and back: unrolled order, contiguous files
+    a.save_or_load_history(str(tmp_path), if_save=True)
+    st = th.load(str(tmp_path / "replay_buffer_states.pth"))
+    assert st.is_contiguous() and st.shape == (a.cur_size, Q, S) and st.untyped_storage().nbytes() == st.numel() * 4
+    c = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=Q, args=planar_args)
+    c.save_or_load_history(str(tmp_path), if_save=False)
+    d = ReplayBuffer(max_size=max_size, state_dim=S, action_dim=A, gpu_id=0, num_seqs=Q)
+    d.save_or_load_history(str(tmp_path), if_save=False)
+    assert c.cur_size == d.cur_size == a.cur_size
+    for x, y in zip((c.states, c.actions, c.rewards, c.undones), (d.states, d.actions, d.rewards, d.undones)):
+        assert th.equal(x[:c.cur_size], y[:c.cur_size])
+    # update_cum_rewards reads slices of the views
+    a.update_cum_rewards(lambda rewards, undones: rewards * 2 + undones)
+    b.update_cum_rewards(lambda rewards, undones: rewards * 2 + undones)
+    p1 = a.p if a.p >= a.add_size else a.max_size
+    assert th.equal(a.cum_rewards[p1 - a.add_size:p1], b.cum_rewards[p1 - b.add_size:p1])
+
+
 @pytest.mark.parametrize("num_seqs,max_size", [(1, 1_000_000), (64, 15_625)])
 def test_replay_full_size_config3(ops, dev, num_seqs, max_size):
     """BASELINE config 3 ring (1e6 transitions, Hopper-shaped S=11, A=3): size-independent properties.
@@ -457,6 +568,16 @@ def test_replay_full_size_config3(ops, dev, num_seqs, max_size):
     assert th.equal(bs[700:p], before[700:p])
     assert th.equal(bu[p:], items[3][:300].float()) and th.equal(bm[:700], items[4][300:].float())
     assert th.equal(br[:700], items[2][300:])
+    # the same ring as ONE interleaved block: filled through the views, sampled by the row kernel -- the same bits as the planar sample
+    ring = ops.ReplayRing(max_size, num_seqs, S, A, dev)
+    ring.states.copy_(bs); ring.actions.copy_(ba); ring.rewards.copy_(br); ring.undones.copy_(bu); ring.unmasks.copy_(bm)   # noqa: E702
+    out_p, _ = ops.replay_sample(bs, ba, br, bu, bm, ids, sample_len)
+    out_r, (j0, j1) = ring.sample(ids, sample_len)
+    assert th.equal(j0, i0) and th.equal(j1, i1)
+    for x, y in zip(out_r, out_p):
+        assert th.equal(x, y)
+    ring.write(items, p)                                                  # (a wrapped append on top of what the planar write left)
+    assert th.equal(ring.states, bs) and th.equal(ring.undones, bu) and th.equal(ring.rewards, br)
 
 
 # ------------------------------------------------------------------------------------------------

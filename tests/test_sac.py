@@ -424,6 +424,50 @@ def test_sac_update_matches_torch_restatement_on_other_shapes(S, A, hidden, E, B
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,E", [(256, 4), (100, 2), (64, 8)])
+def test_sac_split_training_pass_agrees_with_the_unsplit_one(B, E, monkeypatch):
+    """round 6: the critic's training pass splits every 256-wide decoder over four workgroups that exchange their shares of q INSIDE the
+    launch (CriticArgs::qx) and add their shares of dEnc by last-arriver (ERL_SAC_TRAIN_SPLIT=0: one workgroup per tile and decoder, as
+    before).  Same inputs, three steps each: objectives, critic / target / actor weights and the returned td errors agree to summation
+    order (the shares of q and dEnc are added in slice order instead of feature order), repeated launches of the split form are
+    bit-identical to each other (fixed orders everywhere), no exchange wait timed out."""
+    from elegantrl_amd import _hip, ops
+    dev = th.device("cuda:0")
+    S, A, hidden = 11, 3, (256, 256)
+    spec = ops.SacSpec(S, A, hidden, E)
+    g = th.Generator(device=dev).manual_seed(B + E)
+    init = [0.05 * th.randn(n, device=dev, generator=g) for n in (spec.actor_count, spec.critic_count, spec.critic_count)]
+    batches = [((th.randn((B, S), device=dev, generator=g), th.randn((B, A), device=dev, generator=g).tanh(), th.randn(B, device=dev, generator=g),
+                 (th.rand(B, device=dev, generator=g) > 0.1).float(), (th.rand(B, device=dev, generator=g) > 0.1).float(),
+                 th.randn((B, S), device=dev, generator=g)), th.randn((B, A), device=dev, generator=g), th.randn((B, A), device=dev, generator=g))
+               for _ in range(3)]
+
+    def run(train_split):
+        monkeypatch.setenv("ERL_SAC_TRAIN_SPLIT", "1" if train_split else "0")
+        pa, pc, pt = [x.clone() for x in init]
+        alpha = th.full((1,), -1.0, device=dev)
+        mom = [th.zeros_like(pa), th.zeros_like(pa), th.zeros_like(pc), th.zeros_like(pc), th.zeros(1, device=dev), th.zeros(1, device=dev)]
+        objs, td, out = th.zeros(2, device=dev), th.zeros(B, device=dev), []
+        for step, (batch, e_next, e_cur) in enumerate(batches, 1):
+            ops.sac_update(spec, pa, pc, pt, alpha, mom, list(batch), step, gamma=0.97, target_entropy=-float(A), tau=5e-3, lr=1e-3, max_norm=3.0,
+                           objs_out=objs, noises=(e_next, e_cur), td_error_out=td)
+            out.append((objs.clone(), td.clone()))
+        th.cuda.synchronize()
+        _hip.check_async_faults()
+        return pa, pc, pt, out
+
+    a, b, a2 = run(True), run(False), run(True)
+    for x, y in zip(a[:3], a2[:3]):
+        assert th.equal(x, y)                                   # the split form is deterministic
+    for (oa, ta), (ob, tb) in zip(a[3], b[3]):
+        np.testing.assert_allclose(oa.cpu().numpy(), ob.cpu().numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(ta.cpu().numpy(), tb.cpu().numpy(), rtol=2e-4, atol=1e-6)
+    for x, y in zip(a[:3], b[:3]):
+        d = (x - y).abs().cpu().numpy()
+        assert (d <= 2e-5).mean() >= 0.995 and d.max() <= 6.6e-3      # (Adam's step for a gradient at the fp32 noise floor: see above)
+
+
+@pytest.mark.gpu
 def test_sac_update_with_importance_weights_and_td_errors():
     """prioritised replay through the SAC step (AgentSAC.py:58-62): obj_critic = mean(td_error * is_weight), td_error comes back
     per sample; against oracle/sac_torch.py with the same weights."""
@@ -649,9 +693,10 @@ def test_sac_update_net_with_the_sample_inside_the_step_is_bit_identical(net):
     from elegantrl_amd.train import Config, ReplayBuffer
     N, S, A, H = 16, 11, 3, 40
 
-    def run(in_step):
+    def run(in_step, interleaved=True):
         args = Config(AgentSAC, SynVecEnv, {"env_name": "SynVecEnv", "num_envs": N, "max_step": 50, "state_dim": S, "action_dim": A, "if_discrete": False})
         args.net_dims, args.horizon_len, args.batch_size, args.sample_in_step, args.random_seed = list(net), H, 256, in_step, 3
+        args.replay_interleaved = interleaved
         args.repeat_times = 32.0                            # update_times = int(cur_size * repeat_times / batch_size): 5, then 10
         th.manual_seed(5)
         agent = AgentSAC(args.net_dims, S, A, gpu_id=0, args=args)
@@ -675,3 +720,12 @@ def test_sac_update_net_with_the_sample_inside_the_step_is_bit_identical(net):
     for x, y in zip(ba._stage.out, bb._stage.out):          # the last staged batch
         assert th.equal(x, y)
     assert a._step == b._step == 15
+    # ... and the same again from five PLANAR ring tensors (args.replay_interleaved = False: the reference's layout) -- the in-step gather
+    # reads either layout (ErlRingSample.row_floats), the bits do not depend on it
+    c, bc, oc = run(True, interleaved=False)
+    assert ba._ring is not None and bc._ring is None and oc == oa
+    for name in ("_actor_flat", "_critic_flat", "_target_flat", "alpha_log"):
+        assert th.equal(getattr(a, name), getattr(c, name)), name
+    assert th.equal(ba.ids0, bc.ids0) and th.equal(ba.ids1, bc.ids1)
+    for x, y in zip(ba._stage.out, bc._stage.out):
+        assert th.equal(x, y)

@@ -3,7 +3,7 @@
 algorithmic and FETCH_SIZE bytes" for the replay gather):
     C3_PART=step  a few fused SAC update steps at config 3's shapes (B = 256, net [256, 256], 4 critics, S = 11, A = 3): critic_tile_kernel<MODE, ..>,
                   actor_fwd_kernel, dw_table_kernel, ... -- summarise with PMC_KEEP_TEMPLATE=1 to keep the three critic passes apart
-    C3_PART=k9    replay_sample_kernel alone, CASES x 5 launches in a fixed order: (num_seqs, B) in [(64, 256), (64, 4096), (64, 2^20),
+    C3_PART=k9    replay_sample_rows_kernel (C3_RING=planar: replay_sample_kernel) alone, CASES x 5 launches in a fixed order: (num_seqs, B) in [(64, 256), (64, 4096), (64, 2^20),
                   (1, 256), (1, 4096), (1, 2^20)] on a 1e6-transition ring -- summarise with PMC_CASES=replay_sample_kernel:5:<names>
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -o p -- python tools/c3_pmc_workload.py"""
 import os
@@ -26,7 +26,9 @@ K9_CASES = [(64, 256), (64, 4096), (64, 1 << 20), (1, 256), (1, 4096), (1, 1 << 
 
 def ring(num_seqs):
     rows = 1_000_000 // num_seqs
-    buf = ReplayBuffer(max_size=rows, state_dim=S, action_dim=A, gpu_id=0, num_seqs=num_seqs)
+    a = Config()
+    a.replay_interleaved = os.environ.get("C3_RING", "interleaved") != "planar"     # C3_RING=planar: the reference's five tensors (round 5's layout)
+    buf = ReplayBuffer(max_size=rows, state_dim=S, action_dim=A, gpu_id=0, num_seqs=num_seqs, args=a)
     n = rows - 1
     buf.update((th.randn((n, num_seqs, S), device=dev, generator=g), th.randn((n, num_seqs, A), device=dev, generator=g).tanh(),
                 th.randn((n, num_seqs), device=dev, generator=g), th.rand((n, num_seqs), device=dev, generator=g) < 0.99,
@@ -41,7 +43,7 @@ if part == "k9":
         r = rings[seqs]
         idx = th.randint((r.cur_size - 1) * seqs, (B,), device=dev, generator=g)
         for _ in range(5):
-            ops.replay_sample(r.states, r.actions, r.rewards, r.undones, r.unmasks, idx, r.cur_size - 1)
+            r.sample(B, ids=idx, reuse=True)
         th.cuda.synchronize()
     print("cases:", ",".join(f"seqs{s}_B{b}" for s, b in K9_CASES))
 else:

@@ -35,7 +35,10 @@ lib.erl_debug_sac_fused_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.erl_debug_sac_fused_profile.restype = ctypes.c_int
 assert lib.erl_debug_sac_fused_profile(buf, 256) == 0
 NAMES = {0: ["weight loads issued + image clear", "state rows -> LDS", "L1 mma (K = S)", "L1 epilogue + barrier", "L2 mma (256 x 256)",
-             "L2 epilogue + barrier", "head (reduction split)", "tanh / log-prob (16 threads)"]}
+             "L2 epilogue + barrier", "head (reduction split)", "tanh / log-prob (16 threads)"],
+         1: ["state | action rows -> LDS", "encoder mma + epilogue", "decoder forward mma + GELU (+ backward weights requested)", "output layer (reduction split)",
+             "q exchange among the slices (split only)", "labels, dq", "dZ1", "dEnc = W1^T dZ1", "dEnc shares: publish, arrive, last one adds (split only)"]}
+print("ERL_SAC_TRAIN_SPLIT =", os.environ.get("ERL_SAC_TRAIN_SPLIT", "(default: split)"))
 for slot, names in NAMES.items():
     st = [buf[slot * 32 + i] for i in range(len(names) + 1)]
     print(f"slot {slot}: total {st[-1] - st[0]} cycles (s_memtime = 100 MHz ticks x 1? reported raw)")
