@@ -207,8 +207,8 @@ KERNEL_SOURCES = {
     "ppo_step_wd_kernel": ["ppo_step_wd_impl.h", "ppo_step_wd.hip", "ppo_step_wd.h", "ppo_step_s3_impl.h", "split_bf16.h", "s3_image.h",
                            "ppo_step_w4_impl.h", "ppo_step.h", "mlp_chain.h", "mlp_tiles.h", "ppo_objective.h"],
 }
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
-KTIME_FILE = os.path.join("profiles", "r05_kernel_times.json")     # tools/kstats_summarise.py over rocprofv3 --kernel-trace --stats of this command
+PMC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
+KTIME_FILE = os.path.join("profiles", "r06_kernel_times.json")     # tools/kstats_summarise.py over rocprofv3 --kernel-trace --stats of this command
 
 
 def kernel_source_sha16(kernel: str):
@@ -220,7 +220,7 @@ def kernel_source_sha16(kernel: str):
     return h.hexdigest()[:16]
 
 
-C3_PMC_FILE = os.path.join("profiles", "r05_c3_pmc.json")            # tools/c3_pmc_workload.py under rocprofv3 --pmc (critic_tile_kernel, replay_sample_kernel)
+C3_PMC_FILE = os.path.join("profiles", "r06_c3_pmc.json")            # tools/c3_pmc_workload.py under rocprofv3 --pmc (critic_tile_kernel, replay_sample_kernel)
 K9_PMC_FILE = os.path.join("profiles", "r06_k9_pmc_by_size.json")    # ... replay_sample_kernel per (num_seqs, B) case: FETCH_SIZE / WRITE_SIZE bytes
 WIDE_PMC_FILE = os.path.join("profiles", "r04_wide_pmc_traffic_S8_h128.json")     # tools/wide_pmc_workload.py, WD_S=8 WD_A=2 WD_ONLY=128 (cw's shape)
 
@@ -557,6 +557,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gae-sweep", action="store_true")
+    ap.add_argument("--gc-after-warmup", action="store_true", help="gc.collect() + gc.freeze() and the null-bracket measurement between the warm-up and "
+                                                                     "the timed region (rounds 3-5) instead of before the warm-up with the collector off for the region")
+    ap.add_argument("--gae-sweep-after", action="store_true", help="run the GAE size sweep after the timed region (rounds 1-5) instead of before the warm-up")
     ap.add_argument("--no-smi", action="store_true", help="skip the rocm-smi / amd-smi snapshot after the timed region (`clocks.smi`)")
     ap.add_argument("--cpu-iters", type=int, default=12)   # ~10-15 s of host work on 16 cores
     ap.add_argument("--k6-sample", type=int, default=17,
@@ -640,13 +643,37 @@ def main():
     def flush():
         return pend.pop().result() if pend else None
 
+    # The GAE size sweep (part of the line: `roofline_gae.sweep`) runs BEFORE the warm-up since round 6 (`--gae-sweep-after` restores the old
+    # order): it is ~0.2 s of HBM-bound GPU work, and a process that starts its timed region 11 ms after its first launch measures the
+    # clocks' ramp, not the loop -- round 5's driver lines read 2.25 ms per step in the primary region next to 2.09-2.10 in the five regions
+    # that followed it in the same process (`extra.repeated_regions_ms_per_step`; update_net fell from 2.15 to 1.90 ms ACROSS the region).
+    # The timed region itself is unchanged: W warm-up steps, barrier + synchronize, exactly K steps, barrier + synchronize.
+    sweep_early = None
+    if not opt.no_gae_sweep and opt.config == "c4" and not opt.gae_sweep_after:
+        log("GAE size sweep (before the warm-up)")
+        sweep_early = gae_sweep(ops, dev)
+        th.cuda.synchronize()
+        th.cuda.empty_cache()
+    # Round 6: nothing slow sits between the warm-up and the timed region any more.  The interpreter's full collection (gc.collect: 40-65 ms
+    # with the GPU idle) and the 200 empty launches of the null-bracket measurement used to run AFTER the warm-up: the chip dropped its clocks
+    # during that pause and the timed region measured them coming back (update_net 2.14 -> 1.88 ms across the 20 steps of the primary
+    # region, 2.07 ms in every region after it: profiles/r06_bench_region_order.txt).  Now: collect + freeze and the null bracket first,
+    # then the W warm-up steps, then -- with the collector switched off for the region, as timeit does -- barrier + synchronize and the K
+    # timed steps.  `--gc-after-warmup` restores the old order.
+    import gc
+    if not opt.gc_after_warmup:
+        quiet_gc()
+        null_bracket_us = _hip.k6_null_bracket_us(200)   # what an event bracket adds to its content on this box (empty launch)
     log(f"rank {rank}/{world}: agent + env ready, warm-up x{opt.warmup}")
     for _ in range(opt.warmup):
         step()
     flush()
     th.cuda.synchronize()
-    quiet_gc()
-    null_bracket_us = _hip.k6_null_bracket_us(200)       # what an event bracket adds to its content on this box (empty launch)
+    if opt.gc_after_warmup:
+        quiet_gc()
+        null_bracket_us = _hip.k6_null_bracket_us(200)
+    else:
+        gc.disable()
     log("timed region")
     t_gae.enabled = t_explore.enabled = t_update.enabled = True
     # every n-th K6 launch is timed twice: a HIP-event bracket on its stream and the kernel's own span on the device clock
@@ -660,6 +687,7 @@ def main():
     objs = flush() or objs
     th.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0                  # this rank's own time to its last kernel (before the closing barrier)
+    gc.enable()
     parallel.barrier()
     elapsed = parallel.all_reduce_max_float(time.perf_counter() - t0, device=dev)
     rank_ms_max = parallel.all_reduce_max_float(own_elapsed, device=dev) / opt.steps * 1e3
@@ -831,7 +859,8 @@ def main():
                    "envs_per_gpu": N_ENVS, "horizon": HORIZON, "batch": BATCH, "update_times": UPDATE_TIMES,
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "last_state": "private copy (reference behaviour)" if agent.snapshot_last_state else "aliases the env's live state buffer",
-                   "interpreter": "gc.collect() + gc.freeze() after the warm-up (as elegantrl_amd.train.run does)",
+                   "interpreter": ("gc.collect() + gc.freeze() after the warm-up (as elegantrl_amd.train.run does)" if opt.gc_after_warmup else
+                                   "gc.collect() + gc.freeze() before the warm-up, collector off for the timed region (nothing slow between warm-up and region)"),
                    "logs": ("update_net's three logged objectives are read one rollout late (update_net(lazy=True), as elegantrl_amd.train.run does): "
                             "no host sync between an update and the next rollout's launch; every kernel of the K steps and the last read are inside the timed region"
                             if lazy else "read at once (one host sync per iteration)"),
@@ -927,8 +956,10 @@ def main():
         line.setdefault("extra", {})["per_rank_ms_per_step"] = {"min": round(rank_ms_min, 3), "max": round(rank_ms_max, 3),
                                                                  "note": "every rank's own time to its last kernel, before the closing barrier"}
     if not opt.no_gae_sweep and opt.config == "c4":
-        log("GAE size sweep")
-        sweep = gae_sweep(ops, dev)
+        if sweep_early is None:
+            log("GAE size sweep")
+        sweep = sweep_early if sweep_early is not None else gae_sweep(ops, dev)
+        line["roofline_gae"]["sweep_ran"] = "before the warm-up" if sweep_early is not None else "after the timed region"
         line["roofline_gae"]["sweep"] = sweep
         big = next(x for x in sweep if (x["H"], x["N"]) == (2048, 4096))
         gae_tr, gae_tr_src = pmc_traffic("gae_lookback_kernel")
