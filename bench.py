@@ -780,7 +780,7 @@ def main():
     ppo_s = k6_span_s if k6_span_s == k6_span_s else max(k6_event_s - null_bracket_us * 1e-6, 1e-9)
     # where in the update loop a sampled launch sat: the loop's FIRST launch follows the rollout and the GAE scan and finds the instruction
     # caches (and the XCDs' L2s) without the kernel's code -- +3 us on most boxes of the pool, +50 us on the ones with slow instruction
-    # fetch (DESIGN.md "K6 in round 5").  avg_launch_us weights the two groups as the loop does (1 : update_times - 1), whatever the
+    # fetch (DESIGN.md section 4 "Instruction fetch and the workgroup map"; profiles/HISTORY.md "K6 in round 5").  avg_launch_us weights the two groups as the loop does (1 : update_times - 1), whatever the
     # sampling period made of them.
     k6_first = [us for k, us in k6_spans if k % UPDATE_TIMES == 0]
     k6_rest = [us for k, us in k6_spans if k % UPDATE_TIMES != 0]
@@ -850,7 +850,7 @@ def main():
     wg_info = _hip.ppo_wg_map_info(wide=wide)
     if wg_info.get("us_map0") and wg_info.get("us_map2") and wg_info["us_map0"] > 1.15 * wg_info["us_map2"]:
         log(f"NOTE: this box's instruction caches miss slowly (minibatch kernel back to back: {wg_info['us_map0']} us with both networks' code paths behind "
-            f"every instruction cache, {wg_info['us_map2']} us with one): the library chose workgroup map {wg_info['map']} and the code touch (DESIGN.md, K6 in round 5)")
+            f"every instruction cache, {wg_info['us_map2']} us with one): the library chose workgroup map {wg_info['map']} and the code touch ("Instruction fetch and the workgroup map")")
     line = {
         "metric": cfg["metric"], "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
@@ -892,7 +892,7 @@ def main():
                      "event_bracket_us": round(k6_event_s * 1e6, 2), "event_bracket_null_us": round(null_bracket_us, 2),
                      # where the kernel's workgroups run (include/erl_hip.h erl_ppo_wg_map_info): the device's first full-chip launch
                      # measured map 0 against map 2 (us_map0 / us_map2, back to back) and kept one -- map 2 on the boxes where two code paths
-                     # per instruction cache cost 7-9 us per launch (DESIGN.md "K6 in round 5"), map 0 elsewhere
+                     # per instruction cache cost 7-9 us per launch (DESIGN.md section 4 "Instruction fetch and the workgroup map"; profiles/HISTORY.md "K6 in round 5"), map 0 elsewhere
                      "workgroup_map": wg_info,
                      # what that measurement says about the box: two ~58 KB code paths per instruction cache (map 0) cost > 15 % against one
                      # (map 2) only where the instruction caches' miss path is slow (~1 box in 4-20 of the pool)

@@ -244,7 +244,7 @@ class AgentPPO(AgentBase):
 
     def _describe_kernel_path(self) -> str:
         """which kernels this agent's shapes get, and why (the limits are compile-time: include/erl_hip.h ERL_MAX_*; the layered
-        path costs 2.2-2.4x per minibatch, DESIGN.md section 4 "Generic-shape path")"""
+        path costs 2.2-2.4x per minibatch, DESIGN.md section 4 "Other kernels"; profiles/HISTORY.md "Generic-shape path")"""
         S, A, dims = self.state_dim, self.action_dim, list(self.net_dims)
         if self._fused:
             from .. import ops

@@ -318,7 +318,7 @@ ERL_API int erl_ppo_arith_in_use(int S, int h1, int h2, int A);   /* ERL_PPO_ARI
  * ~55 KB code paths -- behind every 64 KB instruction cache; map 1 = the actor's workgroups on XCDs 0-3, the critic's on 4-7; map 2 = the
  * actor's on shader engines 0-1 of every XCD, the critic's on engines 2-3 (one code path per instruction cache, every XCD still 16 + 16).
  * Results are bit-identical; which is faster depends on the box (about one in four of the pool has a slow instruction-cache miss path:
- * DESIGN.md "K6 in round 5"), so the first full-chip launch on a device measures map 0 against map 2 (back to back, the call's own
+ * DESIGN.md section 4 "Instruction fetch and the workgroup map"; profiles/HISTORY.md "K6 in round 5"), so the first full-chip launch on a device measures map 0 against map 2 (back to back, the call's own
  * arguments, ~0.5 ms once per device and process) and the device keeps map 2 if it is 3 % faster.  ERL_K6_WG_MAP=0|1|2 forces a map.
  * *map = the map in use on `device` (-1: not decided yet), *us_map0 / *us_map2 = the per-launch times the decision saw (0: none).
  * The (256, h2[, h3]) kernels decide for themselves (their code is 125 KB per network): device | ERL_PPO_WG_FAMILY_WIDE asks for theirs. */

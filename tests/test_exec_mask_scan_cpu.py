@@ -1,4 +1,4 @@
-"""The hipcc hazard of DESIGN.md's wide-net section, as a build-time check: no register save (v_accvgpr_write / scratch_store) of an outer
+"""The hipcc hazard of profiles/HISTORY.md's wide-net section, as a build-time check: no register save (v_accvgpr_write / scratch_store) of an outer
 value under a reduced EXEC mask in the (256, h2) minibatch kernels' assembly (tools/exec_mask_scan.py).  Compiles two of the eight
 translation units to assembly (hipcc cross-compiles without a GPU; ~20 s each)."""
 import os
