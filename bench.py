@@ -850,7 +850,7 @@ def main():
     wg_info = _hip.ppo_wg_map_info(wide=wide)
     if wg_info.get("us_map0") and wg_info.get("us_map2") and wg_info["us_map0"] > 1.15 * wg_info["us_map2"]:
         log(f"NOTE: this box's instruction caches miss slowly (minibatch kernel back to back: {wg_info['us_map0']} us with both networks' code paths behind "
-            f"every instruction cache, {wg_info['us_map2']} us with one): the library chose workgroup map {wg_info['map']} and the code touch ("Instruction fetch and the workgroup map")")
+            f"every instruction cache, {wg_info['us_map2']} us with one): the library chose workgroup map {wg_info['map']} and the code touch (DESIGN.md section 4, 'Instruction fetch and the workgroup map')")
     line = {
         "metric": cfg["metric"], "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(elapsed / opt.steps * 1e3, 3),
