@@ -240,7 +240,10 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
 // single-launch tails counted arrivals on ONE device counter (199 same-address atomics, an acquire fence per workgroup, then another
 // pass over the table): 16.0 us back to back against this kernel's ~9.  The grid (ceil(stride / 256) workgroups of 1024 threads: 199 at
 // config 4) must be resident at once: the host checks it against the device's capacity; the wait is bounded all the same, and a
-// timeout SKIPS the update and reports through erl_async_fault_count (the policy of every bounded wait of this library).
+// timeout SKIPS the update and reports through erl_async_fault_count (the policy of every bounded wait of this library).  The skip is
+// decided PER WORKGROUP: a workgroup that saw every partial norm applies clip + Adam to its 256 elements, one whose wait expired does not,
+// so after a fault the parameters and moments are PARTIALLY stepped -- the host must treat the fault as fatal for this optimiser state
+// (restore a checkpoint), not carry on; AgentPPO raises at its next host sync.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr unsigned long long kTailBlank = 0x7ff8dead0000beefull;      // quiet NaN with a payload: never the result of a sum of squares
 struct FusedTail {
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(1024) void tail_fused_kernel(const float *slabs, in
             break;
         }
     }
-    if (timed_out) {                                   // incomplete norm: the update is SKIPPED (and reported), never applied
+    if (timed_out) {                                   // incomplete norm: THIS workgroup's elements are not updated (and the fault is reported)
         if (threadIdx.x == 0 && ft.fault) __hip_atomic_fetch_add(ft.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         erl_span_out(span, t_span);
         return;

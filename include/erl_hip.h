@@ -412,7 +412,8 @@ ERL_API int erl_reduce_clip_adam_grid_f32(const float *slabs, int n_slabs, int64
  * launch's parity and are their own flags (an unwritten entry holds a sentinel NaN); every workgroup polls them -- no arrival counter,
  * no fence, no second pass --, sums them in erl_clip_adam_partials_f32's order and applies clip + Adam to the 256 elements it has just
  * reduced, from registers.  Needs erl_tail_fused_ok(stride): rows up to 131 072 floats, every workgroup of the launch resident at once.
- * The wait is bounded; a timeout SKIPS the update and reports through erl_async_fault_count.  Single process only (a data-parallel
+ * The wait is bounded; a workgroup whose wait times out SKIPS its 256 elements' update and reports through erl_async_fault_count -- the
+ * others may already have stepped theirs: after such a fault the optimiser state is partially updated and must be restored, not used.  Single process only (a data-parallel
  * rank's exchange keeps the two launches).  erl_ppo_update_f32 uses it under ERL_FUSED_TAIL=3. */
 ERL_API int erl_tail_fused_ok(int64_t stride);
 ERL_API int erl_reduce_clip_adam_fused_f32(const float *slabs, int n_slabs, int64_t stride, float *flat_grad, float *params,
