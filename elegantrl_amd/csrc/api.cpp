@@ -144,6 +144,7 @@ static void k6_span_reset()
     }
     if (g_k6_pool_used) (void)hipMemset(g_k6_pool, 0, g_k6_pool_used * sizeof(unsigned long long));
     else (void)hipMemset(g_k6_pool, 0, kK6PoolWords * sizeof(unsigned long long));
+    (void)hipDeviceSynchronize();                        // (sampled launches on non-blocking streams are not ordered behind that memset)
     g_k6_pool_used = 0;
     g_k6_launches.clear();
 }
@@ -368,6 +369,7 @@ extern "C" void erl_kernel_span_enable(int every_nth)
     g_span_dev = dev;
     (void)hipDeviceSynchronize();
     (void)hipMemset(g_span_pool, 0, (g_span_pool_used ? g_span_pool_used : kSpanPoolWords) * sizeof(unsigned long long));
+    (void)hipDeviceSynchronize();
     g_span_pool_used = 0;
     g_span_launches.clear();
 }

@@ -465,7 +465,10 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
         if (!tab && g_lb_tables < kLbMaxTables) {
             void *p = nullptr;
             if (hipMalloc(&p, kLbTableBytes) == hipSuccess) {
-                if (hipMemset(p, 0, kLbTableBytes) == hipSuccess) {
+                // zeroed ON THE LAUNCH STREAM: torch's side streams are non-blocking, i.e. not ordered behind the legacy stream a plain
+                // hipMemset runs on -- the scan could start while its ticket counter and granules were still being cleared (round 6: an
+                // intermittent memory fault in tests/test_kernels_gpu.py::test_gae_lookback_tables_are_per_stream; latent since round 5)
+                if (hipMemsetAsync(p, 0, kLbTableBytes, stream) == hipSuccess) {
                     LbTable &t = g_lb_table[g_lb_tables++];
                     t.ptr = (char *)p; t.dev = dev; t.stream = stream;
                     tab = &t;

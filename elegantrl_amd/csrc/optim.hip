@@ -353,6 +353,7 @@ static int ra_arrivals(const char *what, int64_t nblk, hipStream_t st, RaScratch
         int rc = erl_hip_status(hipMalloc(&ptr, bytes), "hipMalloc(arrival scratch)");
         if (rc) return rc;
         if ((rc = erl_hip_status(hipMemset(ptr, 0, bytes), "hipMemset(arrival scratch)"))) return rc;
+        if ((rc = erl_hip_status(hipDeviceSynchronize(), "hipDeviceSynchronize(arrival scratch)"))) return rc;    // (once: a non-blocking stream is not ordered behind that memset)
         sc.ptr = (char *)ptr;
         sc.base = 0;
     }

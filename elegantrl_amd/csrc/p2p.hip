@@ -64,6 +64,7 @@ int erl_p2p_create(int rank, int world, int64_t max_count, void **out, uint8_t *
     void *pw = nullptr;
     if (!rc) rc = erl_hip_status(hipMalloc(&pw, 256), "hipMalloc(poison word)");
     if (!rc) rc = erl_hip_status(hipMemset(pw, 0, 256), "hipMemset(poison word)");
+    if (!rc) rc = erl_hip_status(hipDeviceSynchronize(), "hipDeviceSynchronize");     // (non-blocking streams are not ordered behind that memset)
     if (rc) {
         if (p) (void)hipFree(p);
         if (pw) (void)hipFree(pw);
@@ -144,6 +145,7 @@ void erl_p2p_clear_poison_all()
             (void)hipMemset(c->poison, 0, 4);
             // ... and the words the peers raised in MY table (theirs are cleared by their own report)
             if (c->local) (void)hipMemset(c->local + (size_t)c->world * c->nblk_max * sizeof(uint32_t), 0, (size_t)c->world * sizeof(uint32_t));
+            (void)hipDeviceSynchronize();
         }
     if (cur >= 0) (void)hipSetDevice(cur);
 }

@@ -1140,6 +1140,7 @@ SacSide *sac_side_stream(hipStream_t owner)
         const size_t qx_bytes = (size_t)FMAXE * kQxSplit * 4096 * sizeof(unsigned long long);
         if (hipMalloc(&qx, qx_bytes) == hipSuccess && hipMemset(qx, 0, qx_bytes) == hipSuccess) q.qx = (unsigned long long *)qx;
         else (void)hipGetLastError();
+        (void)hipDeviceSynchronize();             // (once per slot: the caller's stream may be non-blocking, i.e. not ordered behind those memsets)
         q.device = dev;
         q.owner = owner;
         return &q;
