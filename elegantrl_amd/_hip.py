@@ -134,6 +134,8 @@ _SIGNATURES = {
                                        c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P, _P]),
     "erl_sac_update_ring_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int, _P] + [_P] * 6 + [c_int64, _P, _P, c_uint64,
                                         c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
+    "erl_sac_update_ring_loop_f32": (c_int, [_P] * 10 + [c_int, c_int, POINTER(c_int), c_int, c_int, _P, _P, c_int64] + [_P] * 6 + [c_int64, c_uint64,
+                                             c_uint64] + [c_float] * 8 + [c_int32, _P, _P, c_int64, _P]),
     "erl_sac_explore_action_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P,
                                            c_int64, _P]),
     "erl_sac_explore_action_opt_f32": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int, _P, c_int64, _P, c_uint64, c_uint64, _P, _P, _P,

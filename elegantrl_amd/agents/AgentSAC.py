@@ -158,6 +158,9 @@ class AgentSAC(AgentBase):
         self.fused_rollout = bool(getattr(args, "fused_rollout", True))
         # update_net hands the replay ring + the drawn ids to the step instead of sampling first (False: sample, then step)
         self.sample_in_step = bool(getattr(args, "sample_in_step", os.environ.get("ERL_SAC_SAMPLE_IN_STEP", "1") != "0"))
+        # round 6: with the sample inside the step, update_net's whole loop is ONE C call (erl_sac_update_ring_loop_f32): bit-identical to the
+        # per-step calls; `args.update_loop_in_c = False` / ERL_SAC_LOOP_IN_C=0 keeps one call per step
+        self.update_loop_in_c = bool(getattr(args, "update_loop_in_c", os.environ.get("ERL_SAC_LOOP_IN_C", "1") != "0"))
         self._last_state_token = None
         self._spec = ops.SacSpec(state_dim, action_dim, net_dims, self.num_ensembles, actor_variant=self._actor_variant)
         dev, f32 = self.device, th.float32
@@ -341,12 +344,27 @@ class AgentSAC(AgentBase):
         if not self.if_use_per and self.sample_ids_ahead:
             # the sample ids of ALL the steps in one th.randint (the reference draws batch_size of them per step, replay_buffer.py:121-122:
             # same distribution, same generator, one launch instead of `update_times`; nothing is written to the buffer inside this loop)
-            id_rows = th.randint((buffer.cur_size - 1) * buffer.num_seqs, size=(update_times, self.batch_size), requires_grad=False,
-                                 device=self.device).unbind(0)
+            id_all = th.randint((buffer.cur_size - 1) * buffer.num_seqs, size=(update_times, self.batch_size), requires_grad=False,
+                                device=self.device)
+            id_rows = id_all.unbind(0)
         # the sample rides in the step's first launch (erl_sac_update_ring_f32) where the buffer is the library's continuous-action ring and
         # nothing needs ids0 / ids1 before the step
         ring = (id_rows is not None and self.sample_in_step and not self.lambda_fit_cum_r and not self._actor_variant
                 and getattr(buffer, "ring_for_fused_sample", None) and buffer.ring_for_fused_sample(self.batch_size))
+        if ring and self.update_loop_in_c:
+            # the whole loop from ONE C call (erl_sac_update_ring_loop_f32, round 6): step t = what _update_from_ring(id_rows[t]) enqueues
+            from .. import ops
+            arrays, sample_len, stage = ring
+            ops.sac_update_ring_loop(self._spec, self._actor_flat, self._critic_flat, self._target_flat, self.alpha_log,
+                                     (self.act_optimizer.exp_avg, self.act_optimizer.exp_avg_sq, self.cri_optimizer.exp_avg,
+                                      self.cri_optimizer.exp_avg_sq, self.alpha_optim.exp_avg, self.alpha_optim.exp_avg_sq),
+                                     arrays, id_all, sample_len, stage, self._step + 1, gamma=float(self.gamma),
+                                     target_entropy=float(self.target_entropy), tau=float(self.soft_update_tau), lr=float(self.learning_rate),
+                                     max_norm=float(self.clip_grad_norm), objs_all=objs, seed=self.rng_seed + 1, counter0=self._step + 1)
+            self._step += update_times
+            buffer.ids0, buffer.ids1 = stage.ids
+            self.act_optimizer.step_count = self.cri_optimizer.step_count = self.alpha_optim.step_count = self._step
+            update_times = 0                              # (nothing left for the Python loop)
         for t in range(update_times):
             if self.if_use_per:
                 self._per_step(buffer, objs[t], update_t=t)

@@ -481,6 +481,31 @@ extern "C" int erl_sac_update_ring_f32(float *actor_params, float *critic_params
                            nullptr, stream);
 }
 
+// AgentBase.update_net's loop (elegantrl/agents/AgentBase.py:172-189) for the ring form: n_steps x erl_sac_update_ring_f32 from ONE call --
+// step t samples with ids_all[t], counts as optimiser step step0 + t, keys its noise with counter0 + t and logs into objs_all[2 t ..].
+// The interpreter is off the launch path: at config 3 a step is ~12 launches + 3 event operations, and the per-step Python / ctypes
+// work (~35 us) had become longer than what the GPU waits between launches.
+extern "C" int erl_sac_update_ring_loop_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
+                                            float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
+                                            const int *hidden, int n_hidden, int E, const ErlRingSample *ring, const int64_t *ids_all,
+                                            int64_t n_steps, float *state, float *action, float *reward, float *undone, float *unmask,
+                                            float *next_state, int64_t B, uint64_t seed, uint64_t counter0, float gamma, float target_entropy,
+                                            float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm, int32_t step0,
+                                            float *objs_all, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    ERL_REQUIRE(ring && ids_all && objs_all && n_steps >= 0 && B >= 1, "erl_sac_update_ring_loop_f32: bad argument");
+    for (int64_t t = 0; t < n_steps; ++t) {
+        ErlRingSample r = *ring;
+        r.ids = ids_all + t * B;
+        const int rc = erl_sac_update_ring_f32(actor_params, critic_params, target_params, alpha_log, actor_m, actor_v, critic_m, critic_v, alpha_m,
+                                               alpha_v, S, A, hidden, n_hidden, E, &r, state, action, reward, undone, unmask, next_state, B, nullptr,
+                                               nullptr, seed, counter0 + (uint64_t)t, gamma, target_entropy, tau, lr, beta1, beta2, eps_adam,
+                                               max_norm, step0 + (int32_t)t, objs_all + 2 * t, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+    }
+    return ERL_OK;
+}
+
 static int sac_update_impl(float *actor_params, float *critic_params, float *target_params, float *alpha_log, float *actor_m,
                            float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v, int S, int A,
                            const int *hidden, int n_hidden, int E, const float *state, const float *action,

@@ -396,6 +396,8 @@ struct ActorFwdArgs {
     // the batch out for the launches behind it (state, action, reward, undone, unmask, next_state, ids0, ids1) -- under the weight loads
     // this kernel waits for anyway
     ErlRingSample rg;
+    int rg_self;                   // 1: X = the ring's STATE rows of the drawn transitions themselves (not their next states), nothing copied out:
+                                   // the policy-gradient sample's forward pass, which then does not depend on launch (1)'s staging (round 6)
     float *o_state, *o_action, *o_reward, *o_undone, *o_unmask, *o_next;
     const float *noise;            // (B, A) or NULL: Philox keyed by (seed, counter, row, a)
     uint64_t seed, counter;
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
         const int64_t b = row0 + L.tid, id = g.rg.ids[min(b, d.B - 1)];
         const int64_t n = id / g.rg.sample_len, t = id - n * g.rg.sample_len;
         s_row[L.tid] = g.rg.row_floats ? n * g.rg.max_size + t : t * g.rg.num_seqs + n;     // (interleaved ring: sequence-major rows)
-        if (blockIdx.y == 0 && b < d.B) {
+        if (blockIdx.y == 0 && b < d.B && !g.rg_self) {
             if (g.rg.out_ids0) g.rg.out_ids0[b] = t;
             if (g.rg.out_ids1) g.rg.out_ids1[b] = n;
         }
@@ -445,12 +447,13 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
             const int64_t b = row0 + s_;
             float v = 0.f;
             if (b < d.B && c < S) {
-                v = g.rg.row_floats ? g.rg.buf_states[(s_row[s_] + 1) * g.rg.row_floats + c] : g.rg.buf_states[(s_row[s_] + g.rg.num_seqs) * S + c];
-                if (blockIdx.y == 0) g.o_next[b * S + c] = v;
+                const int64_t nx = g.rg_self ? 0 : 1;           // the next state: the following row of the same sequence
+                v = g.rg.row_floats ? g.rg.buf_states[(s_row[s_] + nx) * g.rg.row_floats + c] : g.rg.buf_states[(s_row[s_] + nx * g.rg.num_seqs) * S + c];
+                if (blockIdx.y == 0 && !g.rg_self) g.o_next[b * S + c] = v;
             }
             lds.T0[s_ * LDT + c] = v;
         }
-        if (blockIdx.y == 0) {
+        if (blockIdx.y == 0 && !g.rg_self) {
             const int W = S + A + 3;
             for (int e = L.tid; e < TS * W; e += FT) {
                 const int s_ = e / W, c = e - s_ * W;
@@ -1103,7 +1106,7 @@ struct SacSide {
     int device = -1;
     hipStream_t owner = nullptr;          // the caller's stream this side stream serves
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, mid = nullptr;
     unsigned *arrive = nullptr;           // [256] arrival counters of the split actor forward (zero between launches), owned by this slot
     unsigned *arrive1 = nullptr;          // [256] ... of the split critic training pass (its dEnc shares)
     unsigned long long *qx = nullptr;     // [FMAXE * kQxSplit * 4096] granules {share of q, nonce}: the split critic training pass's q exchange
@@ -1124,7 +1127,8 @@ SacSide *sac_side_stream(hipStream_t owner)
         if (q.stream) continue;
         if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q.mid, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             q.stream = nullptr;
             return nullptr;
@@ -1526,6 +1530,20 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     hipStream_t sa = s;                                 // the stream the actor-forward launches go to
 #define LAUNCH_ACTOR_FWD(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), tgrid, blk, 0, sa, af)
     SacSide *side = sac_side_stream(s);
+    // The policy-gradient sample (6) runs on a side stream.  Round 6 forks it BEFORE launch (1) -- it reads the actor and the drawn
+    // transitions' state rows (from the ring itself when the sample rides in launch (1): ActorFwdArgs::rg_self), nothing launch (1)
+    // writes -- so that it overlaps launches (1) and (2) and is gone by the time the critic's training pass (3) starts: that pass's 256
+    // workgroups wait for each other (CriticArgs::qx) and need the chip to themselves.  Only the temperature step behind it waits for
+    // launch (1), which parks the old temperature (event `mid`).  ERL_SAC_FORK=2: fork after launch (1) as in rounds 4-5; 0: no fork.
+    const char *fk_env = getenv("ERL_SAC_FORK");
+    const bool do_fork = side && !(fk_env && atoi(fk_env) == 0);
+    const bool fork_early = do_fork && !(fk_env && atoi(fk_env) == 2);
+    SacJoin joiner{side, s};
+    if (fork_early) {
+        if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
+        if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
+        joiner.armed = true;
+    }
     static const bool split_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 0); }();
     static const bool asplit_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 2); }();      // (2: the critic passes only)
     if (split_on && asplit_on && side && side->arrive && h1 == 64 * kCritSplit && tiles * kCritSplit <= 256) {
@@ -1543,8 +1561,10 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     // ---- (6) policy-gradient sample (actor on state, kept for the backward pass) and temperature step              (:72-79)
     // FORKED here onto the side stream: they read the actor, `state` and alpha_log only -- the temperature BEFORE its update
     // is already parked in alpha0 by launch (1) -- and run next to the critic update (2)-(5); joined before (7).
-    SacJoin joiner{side, s};
-    if (side) {
+    if (fork_early) {
+        if ((rc = erl_hip_status(hipEventRecord(side->mid, s), "hipEventRecord(mid)"))) return rc;     // launch (1) is enqueued
+        sa = side->stream;
+    } else if (do_fork) {
         if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
         if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
         sa = side->stream;
@@ -1554,15 +1574,21 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
         ActorFwdArgs af2 = af;
         af2.X = state; af2.noise = eps_cur; af2.counter = 2 * counter + 1; af2.act_t = act_pg; af2.lp = lp_cur; af2.eps_out = eps_used; af2.Y = Y;
         af2.H0 = H0; af2.G0 = G0; af2.H1 = H1; af2.G1 = G1; af2.alpha0 = nullptr;
-        af2.rg = ErlRingSample{};                        // (`state` was staged by launch (1), which the fork waits for)
+        af2.rg = ErlRingSample{};                        // (`state`: the caller's batch, or staged by launch (1), which a late fork waits for)
+        if (fork_early && ring) {                        // launch (1) is still staging `state`: read the same rows from the ring
+            af2.rg = *ring;
+            af2.rg.out_ids0 = af2.rg.out_ids1 = nullptr;
+            af2.rg_self = 1;
+        }
         ActorFwdArgs keep = af;
         af = af2;
         FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
         af = keep;
+        if (fork_early && (rc = erl_hip_status(hipStreamWaitEvent(sa, side->mid, 0), "hipStreamWaitEvent(mid)"))) return rc;   // alpha0 is parked
         const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
         hipLaunchKernelGGL(alpha_step_fused_kernel, dim3(1), dim3(256), 0, sa, lp_cur, B, target_entropy, alpha_log, alpha_m, alpha_v, beta1, beta2,
                            eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
-        if (side && (rc = erl_hip_status(hipEventRecord(side->join, sa), "hipEventRecord(join)"))) return rc;
+        if (do_fork && (rc = erl_hip_status(hipEventRecord(side->join, sa), "hipEventRecord(join)"))) return rc;
         sa = s;
     }
     // ---- (2) target ensemble on (next_state, next_action)                                                     (:52)
@@ -1587,7 +1613,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     // instead of 18.2k, its backward 2.6k instead of 7.4k) but pays 3.4k for the q exchange and 7.1k for the dEnc shares, and 256 mutually
     // waiting workgroups start later and finish more raggedly than 64 independent ones.  ERL_SAC_TRAIN_SPLIT=1 turns it on (read per call).
     const char *ts_env = getenv("ERL_SAC_TRAIN_SPLIT");
-    const bool tsplit_on = ts_env && atoi(ts_env) == 1;
+    const bool tsplit_on = ts_env ? atoi(ts_env) == 1 : fork_early;
     const int tsplit = (split > 1 && tsplit_on && side && side->arrive1 && side->qx && B <= 4096 && kCritSplit == kQxSplit) ? split : 1;
     cg = tsplit > 1 ? dim3(tiles, E * tsplit) : cgrid;
     ca.d = tsplit > 1 ? dsl : d; ca.split = tsplit; ca.qt_split = split; ca.h1_full = h1;
@@ -1621,7 +1647,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
             return rc;
     }
     // ---- (7) TARGET ensemble on (state, action_pg): q and d(mean q)/d(action); finishes the critic objective    (:82-83)
-    if (side && (rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
+    if (do_fork && (rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
     joiner.armed = false;
     cg = dim3(tiles, E * split);
     ca.d = dsl; ca.split = split; ca.qt_split = 1;

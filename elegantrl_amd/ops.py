@@ -739,6 +739,34 @@ def sac_update_from_ring(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, al
           "erl_sac_update_ring_f32")
 
 
+def sac_update_ring_loop(spec: SacSpec, actor: TEN, critic: TEN, target: TEN, alpha_log: TEN, moments: Sequence[TEN], ring, ids_all: TEN,
+                         sample_len: int, stage: ReplayStage, step0: int, *, gamma: float, target_entropy: float, tau: float, lr: float,
+                         max_norm: float, objs_all: TEN, seed: int = 0, counter0: int = 0, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """`ids_all.shape[0]` steps of sac_update_from_ring from ONE C call (erl_sac_update_ring_loop_f32): step t uses ids_all[t], optimiser
+    step step0 + t, noise counter counter0 + t, and writes objs_all[t]; `stage` ends up holding the last step's batch and ids0 / ids1."""
+    T, B = ids_all.shape
+    f32 = th.float32
+    assert ids_all.is_contiguous() and objs_all.shape == (T, 2) and objs_all.is_contiguous() and stage.B == B and not stage.discrete
+    if isinstance(ring, ReplayRing):
+        assert (ring.S, ring.A) == (spec.S, spec.A)
+        dev = ring.block.device
+        rs = _RingSample(ptr(ring.block, f32), None, None, None, None, ring.max_size, ring.num_seqs, None, int(sample_len), stage.p_ids0,
+                         stage.p_ids1, ring.row_floats)
+    else:
+        b_states, b_actions, b_rewards, b_undones, b_unmasks = ring
+        max_size, num_seqs, S = b_states.shape
+        dev = b_states.device
+        rs = _RingSample(ptr(b_states, f32), ptr(b_actions, f32), ptr(b_rewards, f32), ptr(b_undones, f32), ptr(b_unmasks, f32), max_size, num_seqs,
+                         None, int(sample_len), stage.p_ids0, stage.p_ids1, 0)
+    ws = _workspace(dev, spec.workspace_bytes(B))
+    check(lib().erl_sac_update_ring_loop_f32(ptr(actor, f32), ptr(critic, f32), ptr(target, f32), ptr(alpha_log, f32), *[ptr(m, f32) for m in moments],
+                                             spec.S, spec.A, spec._c, len(spec.hidden), spec.E, ctypes.addressof(rs), ptr(ids_all, th.int64), T,
+                                             stage.p_state, stage.p_action, stage.p_reward, stage.p_undone, stage.p_unmask, stage.p_next, B,
+                                             seed & (2 ** 64 - 1), counter0 & (2 ** 64 - 1), gamma, target_entropy, tau, lr, betas[0], betas[1], eps,
+                                             max_norm, int(step0), ptr(objs_all, f32), ptr(ws), ws.numel(), stream_ptr()),
+          "erl_sac_update_ring_loop_f32")
+
+
 def sac_explore_action(spec: SacSpec, actor: TEN, state: TEN, *, noise: Optional[TEN] = None, seed: int = 0, counter: int = 0,
                        out: Optional[TEN] = None, out_state: Optional[TEN] = None) -> TEN:
     """`out` (N, A): the action's destination (e.g. the rollout's row); `out_state` (N, S): a copy of `state` from the same launch."""

@@ -646,6 +646,15 @@ ERL_API int erl_sac_update_ring_f32(float *actor_params, float *critic_params, f
                             const float *eps_next, const float *eps_cur, uint64_t seed, uint64_t counter, float gamma,
                             float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
                             int32_t step, float *objs_out, void *workspace, int64_t workspace_bytes, void *stream);
+/* n_steps of the above from one call (AgentBase.update_net's loop, AgentBase.py:172-189): step t samples with ids_all[t B .. (t + 1) B),
+ * is optimiser step step0 + t, keys its Philox noise with counter0 + t and writes its two objectives to objs_all[2 t], [2 t + 1].  ABI 18. */
+ERL_API int erl_sac_update_ring_loop_f32(float *actor_params, float *critic_params, float *target_params, float *alpha_log,
+                                 float *actor_m, float *actor_v, float *critic_m, float *critic_v, float *alpha_m, float *alpha_v,
+                                 int S, int A, const int *hidden, int n_hidden, int E, const ErlRingSample *ring,
+                                 const int64_t *ids_all, int64_t n_steps, float *state, float *action, float *reward, float *undone,
+                                 float *unmask, float *next_state, int64_t B, uint64_t seed, uint64_t counter0, float gamma,
+                                 float target_entropy, float tau, float lr, float beta1, float beta2, float eps_adam, float max_norm,
+                                 int32_t step0, float *objs_all, void *workspace, int64_t workspace_bytes, void *stream);
 ERL_API int erl_sac_explore_action_f32(const float *actor_params, int S, int A, const int *hidden, int n_hidden,
                                const float *state, int64_t N, const float *noise, uint64_t seed, uint64_t counter,
                                float *action_out, float *state_out, void *workspace, int64_t workspace_bytes, void *stream);

@@ -720,6 +720,21 @@ def test_sac_update_net_with_the_sample_inside_the_step_is_bit_identical(net):
     for x, y in zip(ba._stage.out, bb._stage.out):          # the last staged batch
         assert th.equal(x, y)
     assert a._step == b._step == 15
+    # ... and the same with the whole loop from ONE C call against one call per step (args.update_loop_in_c; the default above is the loop)
+    def run_per_step():
+        import os
+        os.environ["ERL_SAC_LOOP_IN_C"] = "0"
+        try:
+            return run(True)
+        finally:
+            del os.environ["ERL_SAC_LOOP_IN_C"]
+    e, be, oe = run_per_step()
+    assert a.update_loop_in_c and not e.update_loop_in_c and oe == oa and e._step == 15
+    for name in ("_actor_flat", "_critic_flat", "_target_flat", "alpha_log"):
+        assert th.equal(getattr(a, name), getattr(e, name)), name
+    assert th.equal(ba.ids0, be.ids0) and th.equal(ba.ids1, be.ids1)
+    for x, y in zip(ba._stage.out, be._stage.out):
+        assert th.equal(x, y)
     # ... and the same again from five PLANAR ring tensors (args.replay_interleaved = False: the reference's layout) -- the in-step gather
     # reads either layout (ErlRingSample.row_floats), the bits do not depend on it
     c, bc, oc = run(True, interleaved=False)
