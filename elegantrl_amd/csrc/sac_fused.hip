@@ -590,11 +590,16 @@ struct CriticArgs {
     uint32_t *fault;
 };
 
-// (the training pass on decoder SLICES -- MODE 1, C1 = 0: 64 features -- is compiled for two workgroups per CU: its 256 workgroups wait for
-// each other's shares of q, so they must all be resident while the policy-gradient sample runs next to them on the side stream; at one
-// workgroup per CU -- 149 registers -- the late ones kept their partners spinning: 34.8 us a launch against the unsplit 28.2)
+// (ERL_SAC_TRAIN_WPE=4 compiles the training pass on decoder SLICES -- MODE 1, C1 = 0 -- for two workgroups per CU: 128 registers, 52 bytes
+// of scratch.  That was needed while the policy-gradient sample's kernels ran next to it -- its 256 workgroups wait for each other's
+// shares of q and the late ones kept their partners spinning: 33-35 us a launch; since that sample is forked before launch (1) the pass
+// has the chip to itself and the uncapped build -- 149 registers, one workgroup per CU, no scratch -- is the faster one: 20.7 against
+// 22.0 us, 139.7 against 142.5 us per update, profiles/r06_sac_train_split_ab.txt)
 template <int MODE, int C0, int C1>
-__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 && C1 == 0) ? 4 : 2))) void critic_tile_kernel(CriticArgs g)
+#ifndef ERL_SAC_TRAIN_WPE
+#define ERL_SAC_TRAIN_WPE 2
+#endif
+__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 && C1 == 0) ? ERL_SAC_TRAIN_WPE : 2))) void critic_tile_kernel(CriticArgs g)
 {
     __shared__ TileLds lds;
     __shared__ float dql[TS];
