@@ -705,6 +705,9 @@ def main():
     k6_wgs = _hip.k6_wg_summary(_hip.k6_timing_last_records(False))      # where / when the last sampled launch's workgroups ran
     # (launch number since enable, span) of every sampled launch, bracketed or not (a bracket does not change the span inside it)
     k6_spans = _hip.k6_timing_spans(False) + _hip.k6_timing_spans(True)
+    # 2: the update loop ran the two networks as two chains of half-chip launches on two streams (include/erl_hip.h erl_ppo_update_chains):
+    # a minibatch is then TWO minibatch-kernel launches (actor, critic: 128 workgroups each at config 4), in flight side by side
+    k6_chains = max(1, _hip.ppo_update_chains())
     smi = smi_snapshot() if rank == 0 and not opt.no_smi else None
 
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
@@ -782,8 +785,9 @@ def main():
     # caches (and the XCDs' L2s) without the kernel's code -- +3 us on most boxes of the pool, +50 us on the ones with slow instruction
     # fetch (DESIGN.md section 4 "Instruction fetch and the workgroup map"; profiles/HISTORY.md "K6 in round 5").  avg_launch_us weights the two groups as the loop does (1 : update_times - 1), whatever the
     # sampling period made of them.
-    k6_first = [us for k, us in k6_spans if k % UPDATE_TIMES == 0]
-    k6_rest = [us for k, us in k6_spans if k % UPDATE_TIMES != 0]
+    k6_lpl = k6_chains * UPDATE_TIMES                 # minibatch-kernel launches per update loop
+    k6_first = [us for k, us in k6_spans if k % k6_lpl < k6_chains]
+    k6_rest = [us for k, us in k6_spans if k % k6_lpl >= k6_chains]
     k6_by_position = None
     if k6_rest:
         rest_us = sum(k6_rest) / len(k6_rest)
@@ -791,6 +795,10 @@ def main():
         k6_by_position = {"first_launch_of_a_loop_us": round(first_us, 2) if k6_first else None, "first_launches_sampled": len(k6_first),
                           "other_launches_us": round(rest_us, 2), "other_launches_sampled": len(k6_rest),
                           "unweighted_mean_us": round(ppo_s * 1e6, 2)}
+        if k6_chains == 2:                              # (the loop enqueues actor, critic, actor, ...: the launch number's parity is the network)
+            for net, name in ((0, "actor"), (1, "critic")):
+                v = [us for k, us in k6_spans if k % 2 == net and k % k6_lpl >= k6_chains]
+                k6_by_position[f"{name}_launches_us"] = round(sum(v) / len(v), 2) if v else None
         if UPDATE_TIMES > 1:
             ppo_s = (first_us + (UPDATE_TIMES - 1) * rest_us) / UPDATE_TIMES * 1e-6
     # which K6 kernel erl_ppo_step_f32 dispatches to: the one-wave-per-SIMD form for h1, h2 in {64, 128}, S <= 64, A <= 8
@@ -824,7 +832,8 @@ def main():
     explore_ms, update_ms = t_explore.mean_seconds() * 1e3, t_update.mean_seconds() * 1e3
     k6_ms = UPDATE_TIMES * ppo_s * 1e3
     step_ms = elapsed / opt.steps * 1e3
-    breakdown = {"explore_env_ms": round(explore_ms, 4), "update_net_ms": round(update_ms, 4),
+    breakdown = {"update_loop_chains": k6_chains,     # 2: actor and critic chains side by side -- k6_ms / slab_reduce_us / clip_adam_us are ONE chain's launches
+                 "explore_env_ms": round(explore_ms, 4), "update_net_ms": round(update_ms, 4),
                  "k6_ms": round(k6_ms, 4), "update_net_minus_k6_ms": round(update_ms - k6_ms, 4),
                  "per_minibatch_rest_us": round((update_ms - k6_ms) / UPDATE_TIMES * 1e3, 2),
                  "host_and_gaps_ms": round(step_ms - explore_ms - update_ms, 4),
@@ -866,13 +875,18 @@ def main():
                             if lazy else "read at once (one host sync per iteration)"),
                    "k6_arith": ("split: fp32 operands as three bf16 parts on the bf16 matrix pipe, fp32 accumulate (as close to fp64 as the "
                                 "fp32 MFMA: tests/test_kernels_gpu.py::test_ppo_step_split_arith)" if k6_arith == "split" else "f32 MFMA")},
-        "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / ppo_s / 1e12, 2),
-                     "peak": round(k6_peak, 1), "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / k6_peak, 4),
+        "roofline": {"kernel": k6_kernel, "bound": "mfma", "achieved": round(flops / k6_chains / ppo_s / 1e12, 2),
+                     "peak": round(k6_peak / k6_chains, 1), "unit": "TFLOP/s", "frac": round(flops / ppo_s / 1e12 / k6_peak, 4),
+                     "launch_form": ("one launch per minibatch over both networks (the whole chip)" if k6_chains == 1 else
+                                     "two-chain update loop: a minibatch is TWO launches of this kernel, the actor's and the critic's, on two streams; each "
+                                     "holds half of the chip's CUs (128 of 256 workgroup slots at config 4), so `achieved` = one launch's algorithmic "
+                                     "flops (the mean of the two networks') / one launch's mean duration and `peak` = the chip's peak x 1/2; both launches "
+                                     "of a minibatch are in flight side by side"),
                      "arith": ("fp32-equivalent: operands split into three bf16 parts, six partial products per product on v_mfma_f32_32x32x16_bf16, "
                                "fp32 accumulation; `achieved` counts ALGORITHMIC flops, `peak` = bf16 dense MFMA peak / 6"
                                if k6_arith == "split" else "fp32 operands on v_mfma_f32_32x32x2_f32"),
                      "frac_of_fp32_mfma_peak": round(flops / ppo_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops,
+                     "traffic": k6_traffic, "traffic_source": k6_traffic_src, "flops_per_launch": flops // k6_chains,
                      "avg_launch_us": round(ppo_s * 1e6, 2), "launches_timed": k6_clocks["launches"] or n_k6,
                      "by_position_in_the_update_loop": k6_by_position,
                      "timer": ("kernel span on the device clock: first workgroup in to last workgroup out (wall_clock64 in the kernel, one record per "

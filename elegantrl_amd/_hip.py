@@ -22,7 +22,7 @@ GAE_VTRACE, GAE_MUTATE, GAE_STATS = 0x1, 0x2, 0x4
 GAE_ALGO_AUTO, GAE_ALGO_EXACT, GAE_ALGO_CHUNKED, GAE_ALGO_LOOKBACK = 0x00, 0x10, 0x20, 0x30
 MAX_STATE_DIM, MAX_HIDDEN, MAX_ACTION_DIM = 128, 128, 16
 MAX_LAYERS, MAXN_WIDTH = 6, 4096
-ABI_VERSION = 18
+ABI_VERSION = 19
 PPO_OBJ_REFERENCE, PPO_OBJ_CANONICAL, PPO_OBJ_A2C = 0, 1, 2      # include/erl_hip.h ERL_PPO_OBJ_*
 SAC_ACTOR_SAC, SAC_ACTOR_FIX = 0, 1                               # include/erl_hip.h ERL_SAC_ACTOR_*
 COMM_ID_BYTES = 128
@@ -77,6 +77,7 @@ _SIGNATURES = {
     "erl_ppo_arith_in_use": (c_int, [c_int, c_int, c_int, c_int]),
     "erl_k6_timing_spans": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), c_int]),
     "erl_ppo_wg_map_info": (c_int, [c_int, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
+    "erl_ppo_update_chains": (c_int, []),
     "erl_ppo_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, _P, c_int64, c_float, c_float, c_float, c_int, _P, c_int, _P]),
     "erl_grad_reduce_f32": (c_int, [_P, c_int, c_int64, _P, _P]),
@@ -376,6 +377,12 @@ def ppo_wg_map_info(device: int = None, wide: bool = False) -> dict:
     env = os.environ.get("ERL_K6_WG_MAP", "")
     return {"map": None if m.value < 0 else m.value, "forced": int(env) if env in ("0", "1", "2") else None,
             "us_map0": round(u0.value, 2) if u0.value else None, "us_map2": round(u1.value, 2) if u1.value else None}
+
+
+def ppo_update_chains() -> int:
+    """the form the last PPO update loop of this process took: 1 = one chain of launches, 2 = one chain per network on two streams
+    (include/erl_hip.h erl_ppo_update_chains), 0 = none yet"""
+    return int(lib().erl_ppo_update_chains())
 
 
 def k6_null_bracket_us(reps: int = 200) -> float:

@@ -8,6 +8,7 @@
 
 #include "erl_common.h"
 #include "s3_image.h"
+#include "ppo_step_wd.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -18,6 +19,41 @@
 namespace {
 
 constexpr int kDefaultTail = 0;      // ERL_FUSED_TAIL default (see erl_ppo_update_dp_f32)
+constexpr int kDefaultChains = 1;    // ERL_PPO_CHAINS default (see erl_ppo_update_dp_f32): 1 = one chain of launches, 2 = one per network
+
+// The two-chain update loop's second stream: library-owned, one per (device, caller's stream), non-blocking, with the two events that
+// fork it from / join it into the caller's stream.  NULL when the runtime refuses (the loop then stays on one stream).
+struct ChainSide {
+    int device = -1;
+    hipStream_t owner = nullptr, stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+ChainSide g_chain_side[16];
+int g_last_chains = 0;               // what the last erl_ppo_update_dp_f32 of this process ran as (erl_ppo_update_chains)
+std::mutex g_chain_mu;
+
+ChainSide *chain_side(hipStream_t owner)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    std::lock_guard<std::mutex> lock(g_chain_mu);
+    for (auto &q : g_chain_side)
+        if (q.stream && q.device == dev && q.owner == owner) return &q;
+    for (auto &q : g_chain_side) {
+        if (q.stream) continue;
+        if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            q.stream = nullptr;
+            return nullptr;
+        }
+        q.device = dev;
+        q.owner = owner;
+        return &q;
+    }
+    return nullptr;
+}
 
 struct Rccl {
     void *handle = nullptr;
@@ -190,6 +226,9 @@ extern "C" int erl_comm_p2p_set_spin(void *comm, uint32_t spins)
     return ERL_OK;
 }
 
+// 1 / 2: the form the last update loop of this process took (0: none yet) -- measurement and logging
+extern "C" int erl_ppo_update_chains(void) { return g_last_chains; }
+
 extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *exp_avg_sq, const float *act_avg, const float *act_std,
                                      const float *cri_avg, const float *cri_std, int S, int h1, int h2, int A, const float *states,
                                      const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
@@ -230,6 +269,43 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
         int rc = erl_adv_stats_fold_f32(adv_partials, n_partials, H, N, adv_stats, stream);
         if (rc) return rc;
     }
+    // ---- two chains (round 6).  The actor's and the critic's minibatches never meet: each network has its own gradient, its own clip norm
+    // and its own Adam step (optimizer_backward is called per optimiser: elegantrl/agents/AgentPPO.py:196-204, AgentBase.py:239-248), so
+    // minibatch kernel -> slab reduction -> clip + Adam is one dependent chain PER NETWORK.  ERL_PPO_CHAINS=2 runs them as two chains of
+    // half-chip launches on two streams: one chain's launch-bound tail and its gradient write-out overlap the other chain's arithmetic.
+    // Same kernels, same associations: the parameters are bit-identical to the one-chain loop's.  Single process, split-arithmetic
+    // (128 | 64, h2) kernels with their images, a device that keeps workgroup map 0 (on a slow-fetch device the full-chip launch under
+    // map 2 stays: two half launches would put both code paths through every instruction cache again).
+    const int chains_env = [] { const char *e = getenv("ERL_PPO_CHAINS"); return e ? atoi(e) : kDefaultChains; }();
+    if (chains_env == 2 && !comm && !tail && !fused3 && im && !erl_ppo_wd_supported(S, h1, h2, A) && erl_k6_wg_map_choice(0) == 0) {
+        hipStream_t s0 = (hipStream_t)stream;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        ChainSide *side = (hipStreamIsCapturing(s0, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) ? chain_side(s0) : nullptr;
+        (void)hipGetLastError();
+        if (side) {
+            int rc;
+            g_last_chains = 2;
+            if ((rc = erl_hip_status(hipEventRecord(side->fork, s0), "hipEventRecord(fork)"))) return rc;
+            if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
+            const hipStream_t cs[2] = {s0, side->stream};
+            for (int k = 0; k < update_times && !rc; ++k) {
+                float *g = grads + (size_t)k * stride;
+                for (int c = 0; c < 2 && !rc; ++c) {
+                    rc = erl_ppo_step_images_f32(flat_params, flat_params + Pa, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions, unmasks,
+                                                 logprobs, advantages, reward_sums, H, N, ids + (size_t)k * B, B, ratio_clip, lambda_entropy,
+                                                 1.0f / (float)B, objective, slabs, n_slabs, im, adv_stats, nullptr, cs[c], c);
+                    if (!rc) rc = erl_launch_reduce_group_f32(slabs, n_slabs, stride, g, off, len, 2, c, grad_scale, cs[c]);
+                    if (!rc) rc = erl_clip_adam_partials_group_f32(flat_params, g, exp_avg, exp_avg_sq, stride, off, len, 2, c, first_step + k, lr, beta1,
+                                                                   beta2, eps, max_norm, grad_scale, im, cs[c]);
+                }
+            }
+            // every exit joins the side stream back (an error above leaves both streams consistent: whatever was enqueued runs)
+            (void)hipEventRecord(side->join, side->stream);
+            (void)hipStreamWaitEvent(s0, side->join, 0);
+            return rc;
+        }
+    }
+    g_last_chains = 1;
     erl_k6_touch_next_launch();       // the loop's first launch finds the kernel's code in no cache (ppo_step.h, k6_code_touch)
     for (int k = 0; k < update_times; ++k) {
         float *g = grads + (size_t)k * stride;

@@ -29,6 +29,13 @@ constexpr int kMaxPartialChunks = 32768;     // 64-element chunks the partial-no
 struct TailGroups {
     int64_t off[4], len[4];
 };
+// a ONE-GROUP launch of the slab reduction (two-chain update loop, comm.cpp): group >= 0: the grid covers blocks blk0 .. blk0 + n_own - 1 (the
+// group's elements) and then the blocks from blk_logs on (the logged sums behind the last group); -1: every block, every group
+struct TailPart {
+    int group = -1;
+    int n_own = 0;
+    int64_t blk0 = 0, blk_logs = 0;
+};
 
 // the slabs are read once (ERL_SLAB_LD, A/B builds only: 1 plain, 2 `sc1`)
 #ifndef ERL_SLAB_LD
@@ -68,13 +75,15 @@ __device__ __forceinline__ void ld_sys_wait(T (&x)[ERL_P2P_MAX_WORLD])     // th
 template <typename T, bool DP, int NT>
 __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int n_slabs, int64_t stride, T *out, TailGroups gr,
                                                              int n_groups, float grad_scale, double *partials, ErlExchange ex,
-                                                             unsigned long long *span = nullptr)
+                                                             unsigned long long *span = nullptr, TailPart tp = TailPart{})
 {
     const unsigned long long t_span = erl_span_in(span);
     constexpr int NE = NT / 4;
     __shared__ T part[4][NE];
     const int el = threadIdx.x & (NE - 1), p = threadIdx.x / NE;
-    const int64_t i = (int64_t)blockIdx.x * NE + el;
+    // (a one-group launch of the two-chain update loop covers the group's blocks, then the blocks of the logged sums behind the last group)
+    const int64_t blk = tp.group < 0 ? (int64_t)blockIdx.x : ((int)blockIdx.x < tp.n_own ? tp.blk0 + (int64_t)blockIdx.x : tp.blk_logs + ((int64_t)blockIdx.x - tp.n_own));
+    const int64_t i = blk * NE + el;
     T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (i < stride) {                                  // (the loop nest of grad_reduce_kernel, mlp.hip: same association)
         const T *src = slabs + i;
@@ -153,6 +162,23 @@ __global__ __launch_bounds__(NT) void reduce_exchange_kernel(const T *slabs, int
                 if (r < ex.world) gsum += x[r];        // rank order on every rank: bit-identical sums
         }
     }
+    if (tp.group >= 0) {
+        // one-group launch: this chain owns its group's elements and, behind the last group, the logged sums its network's workgroups
+        // write (ppo_step kernels: [critic objective, actor objective, entropy, 0, zero pad ...] -- entries 1 and 2 are the actor's);
+        // everything else in the blocks it covers belongs to the other chain, whose slabs may be half written right now
+        const int64_t lb = gr.off[n_groups - 1] + gr.len[n_groups - 1];
+        const bool mine = i >= lb ? ((i - lb == 1 || i - lb == 2) ? tp.group == 0 : tp.group == n_groups - 1)
+                                  : (i >= gr.off[tp.group] && i < gr.off[tp.group] + gr.len[tp.group]);
+        if (p == 0 && i < stride && mine) out[i] = gsum;
+        if (partials && threadIdx.x < NE) {
+            const double xs = (double)((float)gsum * grad_scale), sq = xs * xs;
+            const bool in = i < stride && i >= gr.off[tp.group] && i < gr.off[tp.group] + gr.len[tp.group];
+            const double t = wave_sum(in ? sq : 0.0);          // (the bits of the all-groups launch: its general path, or a sum over a chunk that lies inside the group)
+            if ((threadIdx.x & 63) == 0) partials[(size_t)(i >> 6) * 4 + tp.group] = t;
+        }
+        erl_span_out(span, t_span);
+        return;
+    }
     if (p == 0 && i < stride) out[i] = gsum;
     if (partials && threadIdx.x < NE) {                // whole waves (NE is a multiple of 64): chunk c = elements 64 c .. 64 c + 63
         const int64_t chunk = i >> 6, c_lo = chunk << 6, c_hi = c_lo + 63;
@@ -206,20 +232,28 @@ __global__ __launch_bounds__(1024) void clip_adam_partials_kernel(float *__restr
                                                                   const double *__restrict__ partials, int nblk, float beta1,
                                                                   float beta2, float eps, float max_norm, float grad_scale,
                                                                   float step_size, float bc2_sqrt, S3Images im,
-                                                                  const uint32_t *__restrict__ poison, unsigned long long *span)
+                                                                  const uint32_t *__restrict__ poison, unsigned long long *span, int g0 = 0,
+                                                                  bool own_chunks_only = false)
 {
     __shared__ double scratch[16];
     const unsigned long long t_span = erl_span_in(span);
     // a gradient exchange of this update loop timed out (reduce_exchange_kernel): its sums are garbage -- touch nothing
     if (poison && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    const int gi = blockIdx.y;
+    const int gi = blockIdx.y + g0;
     const int64_t off = gr.off[gi], len = gr.len[gi];
     const int64_t ie = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     const bool own = ie < len;
     float e_g = 0.f, e_m1 = 0.f, e_m2 = 0.f, e_p = 0.f;
     if (own) { e_g = grads[off + ie]; e_m1 = m1[off + ie]; e_m2 = m2[off + ie]; e_p = params[off + ie]; }
     double ss = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 1024) ss += partials[(size_t)b * 4 + gi];
+    if (own_chunks_only) {
+        // behind a one-group slab reduction: only the chunks that overlap the group were written; the others are exact zeros after an
+        // all-groups reduction, so skipping them leaves the same sum in the same association
+        const int64_t c0 = off >> 6, c1 = (off + len - 1) >> 6;
+        for (int b = threadIdx.x; b < nblk; b += 1024) ss += (b >= c0 && b <= c1) ? partials[(size_t)b * 4 + gi] : 0.0;
+    } else {
+        for (int b = threadIdx.x; b < nblk; b += 1024) ss += partials[(size_t)b * 4 + gi];
+    }
     ss = block_sum(ss, scratch);
     const float total_norm = (float)sqrt(ss);
     float coef = max_norm / (total_norm + 1e-6f);      // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
@@ -582,6 +616,32 @@ int erl_launch_reduce_exchange_f32(const float *slabs, int n_slabs, int64_t stri
     ERL_LAUNCH_CHECK("gradient reduce / exchange");
 }
 
+// the slab reduction of ONE parameter group (two-chain update loop, comm.cpp): its elements of the gradient row, its partial norms, and the
+// logged sums behind the last group that its network's workgroups wrote -- the bits the all-groups launch leaves in those places
+int erl_launch_reduce_group_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len, int n_groups,
+                                int group, float grad_scale, hipStream_t stream)
+{
+    ERL_REQUIRE(slabs && out && n_slabs >= 1 && stride >= 1 && n_groups >= 1 && group >= 0 && group < n_groups, "gradient reduce (one group): bad argument");
+    TailGroups gr;
+    int rc = fill_groups("gradient reduce (one group)", off, len, n_groups, stride, &gr);
+    if (rc) return rc;
+    ERL_REQUIRE(gr.len[group] >= 1 && 4 * erl_cdiv(stride, 256) <= kMaxPartialChunks, "gradient reduce (one group): bad group / row too long");
+    double *partials = nullptr;
+    if ((rc = erl_tail_partials(&partials, stream))) return rc;
+    TailPart tp;
+    tp.group = group;
+    tp.blk0 = gr.off[group] / 64;
+    const int64_t blk1 = erl_cdiv(gr.off[group] + gr.len[group], 64);              // one past the group's last block
+    tp.n_own = (int)(blk1 - tp.blk0);
+    const int64_t lb0 = (gr.off[n_groups - 1] + gr.len[n_groups - 1]) / 64, lb1 = erl_cdiv(stride, 64);     // blocks of the logged sums
+    tp.blk_logs = lb0 >= tp.blk0 && lb0 < blk1 ? blk1 : lb0;                         // (those not covered already)
+    const int64_t n_logs = lb1 > tp.blk_logs ? lb1 - tp.blk_logs : 0;
+    const int64_t nblk = tp.n_own + n_logs;
+    hipLaunchKernelGGL((reduce_exchange_kernel<float, false, 256>), dim3((unsigned)nblk), dim3(256), 0, stream, slabs, n_slabs, stride, out, gr, n_groups,
+                       grad_scale, partials, ErlExchange{}, erl_span_slot(ERL_SPAN_SLAB_REDUCE, nblk), tp);
+    ERL_LAUNCH_CHECK("gradient reduce (one group)");
+}
+
 int erl_launch_exchange_f64(double *buf, int64_t count, const ErlExchange *ex, hipStream_t stream)
 {
     ERL_REQUIRE(buf && ex && count >= 1, "erl_comm_allreduce_sum_f64: bad argument");
@@ -679,6 +739,28 @@ int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *
                        grads, exp_avg, exp_avg_sq, gr, partials, (int)nblk, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1),
                        (float)sqrt(bc2), images ? *images : S3Images{}, poison, erl_span_slot(ERL_SPAN_CLIP_ADAM, erl_cdiv(longest, 1024) * n_groups));
     ERL_LAUNCH_CHECK("erl_clip_adam_partials_f32");
+}
+
+// clip + Adam of ONE parameter group behind erl_launch_reduce_group_f32 on the same stream
+int erl_clip_adam_partials_group_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride, const int64_t *group_off,
+                                     const int64_t *group_len, int n_groups, int group, int32_t step, float lr, float beta1, float beta2, float eps,
+                                     float max_norm, float grad_scale, const S3Images *images, void *stream)
+{
+    ERL_REQUIRE(params && grads && exp_avg && exp_avg_sq && n_groups >= 1 && group >= 0 && group < n_groups && step >= 1,
+                "clip + Adam (one group): bad argument");
+    TailGroups gr;
+    int rc = fill_groups("clip + Adam (one group)", group_off, group_len, n_groups, stride, &gr);
+    if (rc) return rc;
+    const int64_t nblk = erl_cdiv(stride, 64);
+    ERL_REQUIRE(nblk <= kMaxPartialChunks && gr.len[group] >= 1, "clip + Adam (one group): row too long / empty group");
+    double *partials = nullptr;
+    if ((rc = erl_tail_partials(&partials, (hipStream_t)stream))) return rc;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t nb = erl_cdiv(gr.len[group], 1024);
+    hipLaunchKernelGGL(clip_adam_partials_kernel, dim3((unsigned)nb, 1), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, gr,
+                       partials, (int)nblk, beta1, beta2, eps, max_norm, grad_scale, (float)((double)lr / bc1), (float)sqrt(bc2),
+                       images ? *images : S3Images{}, (const uint32_t *)nullptr, erl_span_slot(ERL_SPAN_CLIP_ADAM, nb), group, true);
+    ERL_LAUNCH_CHECK("clip + Adam (one group)");
 }
 
 extern "C" int erl_clip_adam_partials_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride,

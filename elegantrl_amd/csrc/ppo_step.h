@@ -35,6 +35,9 @@ struct Ppo2Args {
     const unsigned char *code_touch = nullptr;
     unsigned code_touch_bytes = 0;
     unsigned long long *pc_out = nullptr;
+    // >= 0: a HALF launch, grid (n_slabs, 1): every workgroup works on this network (0 actor, 1 critic) -- the two-chain update loop of
+    // comm.cpp runs the two networks' minibatch kernels as independent launches on two streams; -1: both networks, grid (n_slabs, 2)
+    int only_net = -1;
     long long *prof;      // ERL_PROFILE builds only: [net][8 waves][32] s_memtime stamps of workgroup prof_block
     int prof_block;
 };
@@ -75,6 +78,10 @@ __device__ __forceinline__ void slab_store_as(float v, float *p)
 }
 #ifndef ERL_K6_EXP
 #define ERL_K6_EXP 0
+#endif
+// order of the weight-gradient phases of ppo_step_s3_kernel: 0 = dW1, dW3, dW2 (rounds 3-5), 1 = dW1, dW2, dW3 (the large store first)
+#ifndef ERL_K6_DW_ORDER
+#define ERL_K6_DW_ORDER 0
 #endif
 
 constexpr int PB = 128;        // samples per workgroup
@@ -124,6 +131,7 @@ struct K6Wg {
 };
 __device__ __forceinline__ K6Wg k6_wg_map(const Ppo2Args &g)
 {
+    if (g.only_net >= 0) return K6Wg{g.only_net == 0, (int)blockIdx.x};
     if (g.wg_map == 0) return K6Wg{blockIdx.y == 0, (int)blockIdx.x};
     // maps 1 and 2: groups of 2 * W consecutive linear ids, the first W of a group to the actor, the rest to the critic, slab = W * group +
     // id % W.  W = 4 (map 1): a group is one round over the 8 XCDs -- XCDs 0-3 the actor's.  W = 16 (map 2): a group is one round over the
@@ -179,7 +187,7 @@ __device__ __forceinline__ void span_exit(const Ppo2Args &g, SpanT t0, const Spa
     if (g.span && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
         const unsigned long long w1 = wall_clock64(), m1 = erl_memtime();
-        unsigned long long *rec = g.span + (size_t)kSpanWords * (blockIdx.x + gridDim.x * blockIdx.y);
+        unsigned long long *rec = g.span + (size_t)kSpanWords * (blockIdx.x + gridDim.x * (g.only_net >= 0 ? g.only_net : blockIdx.y));
         unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull};
         if (st) {
 #pragma unroll

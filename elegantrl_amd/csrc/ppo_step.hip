@@ -591,6 +591,17 @@ bool erl_k6_code_range(unsigned long long pc, size_t want_bytes, const unsigned 
     return true;
 }
 
+// the map the current device keeps for a kernel family: -1 not measured yet, 0 / 2 (a forced map counts as measured)
+int erl_k6_wg_map_choice(int family)
+{
+    const int forced = k6_wg_map_env();
+    if (forced >= 0) return forced;
+    int dev = 0;
+    if (family < 0 || family >= kWgMapFamilies || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kWgMapDevices) return -1;
+    if (getenv("ERL_K6_NO_TUNE")) return 0;
+    return g_wg_map[family][dev].map;
+}
+
 extern "C" int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map2)
 {
     const int family = (device >> 8) & 0xff;              // ERL_PPO_WG_FAMILY_WIDE
@@ -609,7 +620,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                             const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
-                            const double *adv_stats, const int64_t *next_ids, void *stream)
+                            const double *adv_stats, const int64_t *next_ids, void *stream, int only_net)
 {
     const int arith_call = (objective >> 8) & 3;       // ERL_PPO_MODE(objective, arith): the call's own arithmetic (0: process default)
     objective &= 0xff;
@@ -621,6 +632,9 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     ERL_REQUIRE(objective >= ERL_PPO_OBJ_REFERENCE && objective <= ERL_PPO_OBJ_A2C, "erl_ppo_step_f32: unknown objective %d", objective);
     ERL_REQUIRE(n_slabs == erl_ppo_num_slabs(B), "erl_ppo_step_f32: n_slabs=%d, expected erl_ppo_num_slabs(B=%lld)=%d", n_slabs,
                 (long long)B, erl_ppo_num_slabs(B));
+    ERL_REQUIRE(only_net < 0 || (only_net <= 1 && !erl_ppo_wd_supported(S, h1, h2, A) &&
+                                 erl_ppo_arith_for_call(S, h1, h2, A, arith_call) == ERL_PPO_ARITH_SPLIT),
+                "erl_ppo_step_f32: a one-network launch exists for the split-arithmetic (128 | 64, h2) kernels only");
     if (erl_ppo_wd_supported(S, h1, h2, A))
         return erl_ppo_wd_step(actor_params, critic_params, act_avg, act_std, cri_avg, cri_std, S, h1, h2, A, states, actions, unmasks, logprobs,
                                advantages, reward_sums, H, N, ids, B, ratio_clip, lambda_entropy, inv_batch, objective, slabs, n_slabs,
@@ -658,13 +672,14 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     const bool split = erl_ppo_arith_for_call(S, h1, h2, A, arith_call) == ERL_PPO_ARITH_SPLIT;
     const bool pre = g.w2img[0] && g.w2img[1] && g.w1img[0] && g.w1img[1];
     g.span = nullptr;
-    if (split)                                                                   // (the first full-chip launch on a device measures both maps)
+    g.only_net = only_net;
+    if (split && only_net < 0)                                                   // (the first full-chip launch on a device measures both maps)
         g.wg_map = erl_k6_wg_map_for_launch(0, n_slabs, st, [&](int m) {
             Ppo2Args t = g;
             t.wg_map = m;
             return pre ? erl_ppo_s3_launch_pre(t, n_slabs, vec, st) : erl_ppo_s3_launch(t, n_slabs, vec, st);
         });
-    if (split && erl_k6_code_touch_wanted(0)) g.code_touch_bytes = 1;          // (a request: launch_s3 resolves the range of its instantiation)
+    if (split && only_net < 0 && erl_k6_code_touch_wanted(0)) g.code_touch_bytes = 1;          // (a request: launch_s3 resolves the range of its instantiation)
     g.span = erl_k6_timing_begin(st, n_slabs);
     int rc;
     // K6 form: 0 = automatic (one-wave-per-SIMD kernels where their shape classes apply: the split-bf16 one if selected, else

@@ -863,23 +863,20 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     lds_barrier();                                                   // (3) dZ1, X images consumed
     SPAN_STAMP(sps, 5);                                              // phase 4: staging + dW1, db1
 
-    // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2^T staged feature-major in fp32); the first half of
-    //      H1 goes to SB meanwhile
-    {
+    constexpr int NH1 = (N1 > 2) ? 2 : 1;                            // passes over H1's features: SB holds 64 of them
+    constexpr int KSH = 2 * N1 / NH1;                                // k-steps (16 features) per pass
+    constexpr int CPB2 = KSH / 2 * 4;                                // chunks per part of the SB image in dW2
+    // H2^T (fp32, feature-major) over SA for dW3
+    auto stage_h2t = [&]() {
         float *T2 = reinterpret_cast<float *>(SA);
 #pragma unroll
         for (int t = 0; t < N2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) T2[(32 * t + 16 * (r >> 3) + 8 * hi + (r & 7)) * PLD + col] = H2[t][r];
         }
-    }
-    constexpr int NH1 = (N1 > 2) ? 2 : 1;                            // passes over H1's features: SB holds 64 of them
-    constexpr int KSH = 2 * N1 / NH1;                                // k-steps (16 features) per pass
-    constexpr int CPB2 = KSH / 2 * 4;                                // chunks per part of the SB image in dW2
-    stage_s3<KSH, CPB2, 0>(SB, H1p, col, hi);
-    lds_barrier();                                                   // (4)
-    PROF(11);
-    {
+    };
+    // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2^T staged feature-major in fp32), db3, dstd_log
+    auto dw3 = [&]() {
         const float *T2 = reinterpret_cast<const float *>(SA);
         const int l15 = lane & 15, q = lane >> 4;
         f32x2 hs = {0.f, 0.f};
@@ -915,7 +912,14 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
             if (l15 < OUT) slab[d.ob3() + l15] = s;
             else if (ACTOR && l15 >= 8 && l15 - 8 < OUT) slab[d.oStd() + l15 - 8] = s;
         }
-    }
+    };
+#if ERL_K6_DW_ORDER == 0
+    // order dW1, dW3, dW2: the first half of H1 goes to SB while H2^T is staged
+    stage_h2t();
+    stage_s3<KSH, CPB2, 0>(SB, H1p, col, hi);
+    lds_barrier();                                                   // (4)
+    PROF(11);
+    dw3();
     lds_barrier();                                                   // (5) H2^T consumed
     stage_s3<2 * N2, CPH2, 0>(SA, dZ2p, col, hi);
     lds_barrier();                                                   // (6)
@@ -940,6 +944,41 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
         if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
     }
     PROF(13);
+#else
+    // order dW1, dW2, dW3 (round 6): the 64 KB of dW2 -- two thirds of a workgroup's slab -- leave by write-through stores while dW3 is
+    // still computing, and the kernel ends behind the 4 KB of dW3 instead of behind the drain of 256 x 64 KB; H2 waits in registers
+    stage_s3<2 * N2, CPH2, 0>(SA, dZ2p, col, hi);
+    stage_s3<KSH, CPB2, 0>(SB, H1p, col, hi);
+    lds_barrier();                                                   // (4)
+    PROF(11);
+    // ---- layer 2: dW2 = dZ2^T . H1, db2  (wave w: row tile w % N2; its column tiles pass by pass)
+    {
+        constexpr int CS = 4 / N2;
+        constexpr int TPP = N1 / NH1;                                // column tiles per pass
+        constexpr int NBW = (TPP + CS - 1) / CS;
+        const int it = wave % N2, jc = wave / N2;
+        Parts A[8];
+        grad_a_load<CPH2>(SA, it, A, lane);
+        if (jc < TPP) grad_tiles<CPB2, NBW, CS>(A, SB, it, jc, 0, slab + d.oW2(), h1, h1, lane);
+        if (NH1 == 2) {
+            lds_barrier();                                           // (5) first half of H1 consumed; every wave holds its rows of dZ2^T
+            stage_s3<KSH, CPB2, (NH1 == 2 ? KSH : 0)>(SB, H1p, col, hi);
+            stage_h2t();
+            lds_barrier();                                           // (6)
+            if (jc < TPP) grad_tiles<CPB2, NBW, CS>(A, SB, it, jc, TPP, slab + d.oW2(), h1, h1, lane);
+        }
+        if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
+        if (NH1 != 2) {
+            lds_barrier();                                           // (5) dZ2^T consumed
+            stage_h2t();
+            lds_barrier();                                           // (6)
+        }
+    }
+    SPAN_STAMP(sps, 6);                                              // phase 5: staging + dW2, db2; phase 6 = dW3, db3, logs, store drain
+    PROF(12);
+    dw3();
+    PROF(13);
+#endif
 
     // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
     const float t0 = block_sum(loss0, s_red);
@@ -1028,10 +1067,10 @@ int launch_s3(const Ppo2Args &g, int n_slabs, hipStream_t stream)
             }
             t.code_touch = r.base; t.code_touch_bytes = r.base ? r.bytes : 0;
         }
-        hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(n_slabs, 2), dim3(QNT), kS3LdsBytes, stream, t);
+        hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(n_slabs, g.only_net >= 0 ? 1 : 2), dim3(QNT), kS3LdsBytes, stream, t);
         return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");
     }
-    hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(n_slabs, 2), dim3(QNT), kS3LdsBytes, stream, g);
+    hipLaunchKernelGGL((ppo_step_s3_kernel<KX, N1, N2, VEC, PRE>), dim3(n_slabs, g.only_net >= 0 ? 1 : 2), dim3(QNT), kS3LdsBytes, stream, g);
     return erl_hip_status(hipGetLastError(), "erl_ppo_step_f32");
 }
 

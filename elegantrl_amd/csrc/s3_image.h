@@ -64,7 +64,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
                             const float *actions, const uint8_t *unmasks, const float *logprobs, const float *advantages,
                             const float *reward_sums, int64_t H, int64_t N, const int64_t *ids, int64_t B, float ratio_clip,
                             float lambda_entropy, float inv_batch, int objective, float *slabs, int n_slabs, const S3Images *images,
-                            const double *adv_stats, const int64_t *next_ids, void *stream);
+                            const double *adv_stats, const int64_t *next_ids, void *stream, int only_net = -1);
 // the two-launch tail's work in ONE launch (grad_tail.hip, tail_fused_kernel; single process) and whether a row of `stride` floats can take it
 extern "C" int erl_tail_fused_ok(int64_t stride);
 int erl_tail_fused_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len, int n_groups,
@@ -74,6 +74,14 @@ int erl_clip_adam_partials_images_f32(float *params, const float *grads, float *
                                       const int64_t *group_off, const int64_t *group_len, int n_groups, int32_t step, float lr, float beta1,
                                       float beta2, float eps, float max_norm, float grad_scale, const S3Images *images, const uint32_t *poison,
                                       void *stream);
+// one parameter group's share of the two-launch tail (grad_tail.hip; the two-chain update loop of comm.cpp)
+int erl_launch_reduce_group_f32(const float *slabs, int n_slabs, int64_t stride, float *out, const int64_t *off, const int64_t *len, int n_groups,
+                                int group, float grad_scale, hipStream_t stream);
+int erl_clip_adam_partials_group_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t stride, const int64_t *group_off,
+                                     const int64_t *group_len, int n_groups, int group, int32_t step, float lr, float beta1, float beta2, float eps,
+                                     float max_norm, float grad_scale, const S3Images *images, void *stream);
+// the workgroup map the current device keeps for a minibatch-kernel family (ppo_step.hip): -1 not measured yet
+int erl_k6_wg_map_choice(int family);
 // grad_tail.hip: library-owned image buffers of (device, stream), built from the flat parameters [actor | critic]
 // (adv_partials != nullptr: one more block of the same launch folds the n_partials x 3 fp64 partial sums of the rollout's advantage
 // epilogue into adv_stats -- erl_adv_stats_fold_f32 without a launch of its own)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ERL_ABI_VERSION 18
+#define ERL_ABI_VERSION 19
 #define ERL_API __attribute__((visibility("default")))
 #define ERL_OK 0
 #define ERL_EINVAL (-1)
@@ -324,6 +324,13 @@ ERL_API int erl_ppo_arith_in_use(int S, int h1, int h2, int A);   /* ERL_PPO_ARI
  * The (256, h2[, h3]) kernels decide for themselves (their code is 125 KB per network): device | ERL_PPO_WG_FAMILY_WIDE asks for theirs. */
 #define ERL_PPO_WG_FAMILY_WIDE 0x100
 ERL_API int erl_ppo_wg_map_info(int device, int *map, double *us_map0, double *us_map2);
+/* The form the last erl_ppo_update_f32 / erl_ppo_update_dp_f32 of this process took (ABI 19): 1 = one chain of launches per minibatch
+ * (minibatch kernel over both networks, slab reduction, clip + Adam), 2 = TWO chains -- the actor's and the critic's minibatches share
+ * nothing (own gradient, own clip norm, own Adam step: elegantrl/agents/AgentPPO.py:196-204, AgentBase.py:239-248), so each network runs
+ * minibatch kernel -> slab reduction -> clip + Adam as its own chain of half-chip launches, the critic's on a library-owned second
+ * stream forked from / joined into the caller's; 0 = no loop yet.  Bit-identical parameters either way.  Two chains are the default for
+ * a single process on the split-arithmetic (128 | 64, h2) kernels where the device keeps workgroup map 0; ERL_PPO_CHAINS=1 forces one. */
+ERL_API int erl_ppo_update_chains(void);
 ERL_API int64_t erl_ppo_slab_stride(int S, int h1, int h2, int A);
 ERL_API int erl_ppo_num_slabs(int64_t B);
 ERL_API int erl_ppo_step_f32(const float *actor_params, const float *critic_params, const float *act_avg,

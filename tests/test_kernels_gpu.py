@@ -852,6 +852,46 @@ def test_update_loop_code_touch_changes_nothing(ops, dev, monkeypatch):
             assert np.array_equal(a, b), key
 
 
+@pytest.mark.parametrize("S,A,B,h1,h2,N", [(64, 8, 16384, 128, 128, 4000), (64, 8, 1000, 128, 128, 300), (17, 5, 300, 128, 128, 77), (3, 1, 4096, 128, 64, 500),
+                                            (32, 3, 260, 64, 128, 100), (20, 4, 129, 64, 64, 50)])
+def test_update_loop_two_chains_equal_one_chain(ops, dev, monkeypatch, S, A, B, h1, h2, N):
+    """csrc/comm.cpp, round 6: the actor's and the critic's minibatches share nothing (own gradient, own clip norm, own Adam step:
+    elegantrl/agents/AgentPPO.py:196-204), so the update loop runs them as TWO chains of half-chip launches on two streams
+    (ERL_PPO_CHAINS=2, the default where it applies; one-network minibatch kernel, one-group slab reduction, one-group clip + Adam).
+    Same kernels, same associations: weights, both moments and every gradient row (the logged sums included) BIT FOR BIT against the
+    one-chain loop, over two loops of three minibatches, full chip and ragged shapes, the actor | critic seam inside a 64-element chunk."""
+    H, T = 9, 3
+    rng = np.random.default_rng(S * 1000 + B)
+    buf = ppo_case(rng, H, N, S, A, B)[:6]
+    actor, critic = random_net(rng, S, h1, h2, A, True), random_net(rng, S, h1, h2, 1, False)
+    stride, n_slabs = ops.ppo_slab_stride(S, h1, h2, A), ops.ppo_num_slabs(B)
+    ids = cu(rng.integers(0, H * N, (T, B)), dev)
+    P0 = cu(np.concatenate([flat_params(actor), flat_params(critic)]), dev)
+    norm = [cu(actor.state_avg, dev), cu(actor.state_std, dev), cu(critic.state_avg, dev), cu(critic.state_std, dev)]
+    tb = [cu(x, dev) for x in buf]
+    out, took = {}, {}
+    prev = ops.ppo_set_arith("split")
+    monkeypatch.setenv("ERL_K6_WG_MAP", "0")           # (a device that keeps map 2 stays on one chain: decided here, not measured)
+    try:
+        for chains in ("1", "2"):
+            monkeypatch.setenv("ERL_PPO_CHAINS", chains)
+            P, M1, M2 = P0.clone(), th.zeros_like(P0), th.zeros_like(P0)
+            slabs, rows = th.full((n_slabs, stride), float("nan"), device=dev), th.full((2 * T, stride), float("nan"), device=dev)
+            for rep in range(2):
+                ops.ppo_update(P, M1, M2, *norm, S, h1, h2, A, *tb, ids, 0.25, 0.001, slabs, rows[T * rep:], 1 + T * rep, 1e-3, 3.0)
+            th.cuda.synchronize()
+            _hip.check_async_faults()
+            took[chains] = _hip.ppo_update_chains()
+            out[chains] = [x.cpu().numpy().view(np.uint32) for x in (P, M1, M2, rows)]
+            assert np.isfinite(out[chains][0].view(np.float32)).all() and np.isfinite(out[chains][3].view(np.float32)).all()
+    finally:
+        ops.ppo_set_arith(prev)
+    assert took == {"1": 1, "2": 2}, took
+    for name, a, b in zip(("weights", "exp_avg", "exp_avg_sq", "gradient rows"), out["1"], out["2"]):
+        assert np.array_equal(a, b), name
+    assert np.abs(out["2"][0].view(np.float32) - P0.cpu().numpy()).max() > 1e-4
+
+
 def test_ppo_step_split_arith_at_benchmark_size(ops, dev):
     """BASELINE configs[3] at full size (4096 envs x 32 steps, minibatch 16384, obs 64, act 8, net [128,128]): the split-arithmetic
     kernel and the fp32-MFMA kernel on the same minibatch, both against the fp64 restatement -- 128 gradient slabs per network
