@@ -106,14 +106,22 @@ constexpr size_t kRfLdsBytes = (size_t)RF_FLOATS * sizeof(float);
 // they fit (192 bytes per step); longer horizons read them back from the rollout buffers
 constexpr int kRfGaeLdsSteps = 128;
 constexpr size_t rf_gae_lds_bytes(int H) { return ((size_t)H * 3 + 1) * 16 * sizeof(float); }
-static_assert(kRfLdsBytes + rf_gae_lds_bytes(kRfGaeLdsSteps) <= 160 * 1024, "LDS budget of the rollout kernel with the epilogue's tile");
+constexpr size_t kRfRsExtraBytes = 4096;      // role split: one 4 KB tile of W2 small parts behind the layout
+static_assert(kRfLdsBytes + kRfRsExtraBytes + rf_gae_lds_bytes(kRfGaeLdsSteps) <= 160 * 1024, "LDS budget of the rollout kernel with the epilogue's tile");
+static_assert(128 * RF_W1LD >= 12 * 4096 && RB_TBYTES >= 3 * 4096, "role split: homes of the W2 small-part tiles");
 
 // NS_ / N1_ / N2_: k-tiles of the state / hidden layers as compile-time constants for the tuned shapes (0 = read them from
 // the arguments): with them the step body is straight-line code between barriers, which lets the scheduler interleave the
 // LDS operand reads, the divisions of the normalisation and the GELUs with the MFMA chains.
-template <int ENV, bool VEC, int NS_, int N1_, int N2_>
+// RS_ (round 6, "role split"): waves 0..3 run the ACTOR (two 16-row tiles of every layer each) and step the environment, waves 4..7 run
+// the CRITIC on the same state a half step later -- layer 1 while the actor's waves finish the policy head and step the env, layer 2 while
+// they write the new state tile, the value sum at the start of the next step -- so that the critic's ~3k cycles per step leave the step's
+// dependent chain (tools/r06_gpu_f.sh: the chain without the critic's layers is 10.7k cycles of 13.6k).  Every dot product, GELU and sum
+// keeps its operands and its order: the buffers stay bit-identical to the per-step path.  Needs h1 = 128 and h2 in {64, 128} at compile time.
+template <int ENV, bool VEC, int NS_, int N1_, int N2_, bool RS_ = false>
 __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
 {
+    static_assert(!RS_ || (N1_ == 8 && (N2_ == 4 || N2_ == 8) && NS_ >= 1), "role split: compile-time shapes");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *XS = smem + RF_O_XS, *NRM = smem + RF_O_NRM, *PSA = smem + RF_O_PSA;
     u8 *XA = reinterpret_cast<u8 *>(smem + RF_O_XA), *XC = reinterpret_cast<u8 *>(smem + RF_O_XC);
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     float *PSC = smem + RF_O_PSC, *EPS = smem + RF_O_EPS, *RED = smem + RF_O_RED;
     float *WST = smem + RF_O_WST, *WAT = smem + RF_O_WAT, *BIA = smem + RF_O_BIA;
     u8 *W1C = reinterpret_cast<u8 *>(smem + RF_O_W1C);
-    float *GAE = smem + RF_FLOATS;            // [H][3][16] + [16] (only with g.gae_lds)
+    float *GAE = smem + RF_FLOATS + (RS_ ? 1024 : 0);     // [H][3][16] + [16] (only with g.gae_lds); role split: behind the last W2 small-part tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const Dims da{g.S, g.h1, g.h2, g.A}, dc{g.S, g.h1, g.h2, 1};
@@ -182,6 +190,54 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     // (and of W1: rows clamped like the step kernel's loads, columns >= S zero), split into their bf16 parts once
     // (the critic's W1 waits in LDS in its split form: 256 registers hold the three weight blocks below, not four)
     Parts w1a[2], w2a[4], w2c[4];
+    constexpr int TP2 = RS_ ? N2_ / 4 : 1;                 // (role split) layer-2 tiles per wave; layer 1: two
+    // (role split) this wave's rows of ITS network's W1 / W2, split once: W1 and the two large parts of W2 in registers (112), the small
+    // part of W2 in LDS (16 bytes per lane and k-step, lane-contiguous: [tile][k-step][lane]) -- with all three parts of two layer-2 tiles
+    // in registers (144) the step loop spilled 33 registers
+    Parts W1[2][2];
+    u32x4 W2h[TP2][4], W2m[TP2][4];
+    const u8 *w2l_at[TP2];
+    float4 w3r[TP2];                                       //              ... and its k-slices of the output layer (fp32)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);              // (scalar: role branches are scalar branches)
+    const int role = RS_ ? wave_u >> 2 : 0, rw = wave_u & 3;   // (role split) 0: actor, 1: critic; rank among the network's four waves
+    const u8 *w1c_at = nullptr;
+    float4 w3a = zero4(), w3c = zero4();
+    const int kt = min(wave, n2 - 1);                      // this wave's k-tile of the output layers
+    if constexpr (RS_) {
+        const float *P = role ? g.Pc : g.Pa;
+        const Dims &d = role ? dc : da;
+        const int outs = role ? 1 : A;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float *r1 = P + d.oW1() + (size_t)(16 * (2 * rw + j) + l15) * S;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                if (ks < ks_s) W1[j][ks] = rb_load_w<VEC>(r1, ks, q, S);
+        }
+#pragma unroll
+        for (int j = 0; j < TP2; ++j) {
+            const int tile = TP2 * rw + j;
+            const float *r2 = P + d.oW2() + (size_t)(16 * tile + l15) * d.h1;
+            // the small parts' home: the actor's eight tiles and the critic's first four where the all-waves mapping keeps the critic's W1,
+            // the critic's tiles 4..6 in the second H1 tile (one H1 tile serves both networks here: T1A), tile 7 behind the layout
+            u8 *home = role == 0 ? W1C + 4096 * tile : tile < 4 ? W1C + 4096 * (8 + tile) : tile < 7 ? T1C + 4096 * (tile - 4)
+                                                                                                     : reinterpret_cast<u8 *>(smem + RF_FLOATS);
+            w2l_at[j] = home + 16 * lane;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const Parts p = rb_load_w<VEC>(r2, ks, q, d.h1);
+                W2h[j][ks] = p.h;
+                W2m[j][ks] = p.m;
+                *reinterpret_cast<u32x4 *>(home + 1024 * ks + 16 * lane) = p.l;
+            }
+            w3r[j] = load4<VEC>(P + d.oW3() + (size_t)min(l15, outs - 1) * d.h2, 16 * tile + 4 * q, d.h2);
+            if (l15 >= outs) w3r[j] = zero4();
+        }
+        // output-layer partials of tiles nobody owns (h2 = 64: tiles 4..7) stay zero for the whole rollout
+        for (int e = tid; e < 8 * 64 * 4; e += 512) PSA[e] = 0.f;
+        if (tid < 128) PSC[tid] = 0.f;
+        if (role == 0) __builtin_amdgcn_s_setprio(2);      // the actor's waves carry the step's dependent chain
+    } else {
     {
         const int i = tid >> 2, c = tid & 3;                 // row i, columns 16 c .. 16 c + 15
         const float *rc1 = g.Pc + dc.oW1() + (size_t)min(i, dc.h1 - 1) * S;
@@ -194,7 +250,7 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             *reinterpret_cast<u32x4 *>(dst + 256) = p.l;
         }
     }
-    const u8 *w1c_at = W1C + (16 * wave + l15) * RF_W1LD + 16 * q;
+    w1c_at = W1C + (16 * wave + l15) * RF_W1LD + 16 * q;
     {
         const float *ra1 = g.Pa + da.oW1() + (size_t)min(16 * wave + l15, da.h1 - 1) * S;
         const float *ra2 = g.Pa + da.oW2() + (size_t)min(16 * wave + l15, da.h2 - 1) * da.h1;
@@ -213,11 +269,11 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             }
         }
     }
-    const int kt = min(wave, n2 - 1);                      // this wave's k-tile of the output layers
-    float4 w3a = load4<VEC>(g.Pa + da.oW3() + (size_t)min(l15, A - 1) * da.h2, 16 * kt + 4 * q, da.h2);
+    w3a = load4<VEC>(g.Pa + da.oW3() + (size_t)min(l15, A - 1) * da.h2, 16 * kt + 4 * q, da.h2);
     if (l15 >= A || !on2) w3a = zero4();
-    float4 w3c = load4<VEC>(g.Pc + dc.oW3(), 16 * kt + 4 * q, dc.h2);
+    w3c = load4<VEC>(g.Pc + dc.oW3(), 16 * kt + 4 * q, dc.h2);
     if (l15 >= 1 || !on2) w3c = zero4();
+    }
     {   // the biases wait in LDS (a ds_read_b128 per layer and network per step; 16 registers less across the MFMA chains)
         const int which = tid >> 7, k = tid & 127;
         const float *src = (which & 2 ? g.Pc : g.Pa) + (which & 2 ? (which & 1 ? dc.ob2() : dc.ob1()) : (which & 1 ? da.ob2() : da.ob1()));
@@ -251,10 +307,89 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     draw(0);
     __syncthreads();
 
+    // ---- (role split) a network's layers on this wave's tiles.  Operands and order of every sum are those of the all-waves mapping:
+    // rb_mma6 over the k-steps in order, rb_sum + bias, GELU, the output layer's partial of ONE 16-feature tile from four fp32 MFMAs;
+    // the tiles' partials are summed in tile order by whoever finishes the head (below)
+    auto rs_layer1 = [&](const u8 *X, u8 *T1, const float *b1) {
+        RbAcc c0, c1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < ks_s) {
+                const Parts b = rb_tile_get(X, RB_XLD, l15, ks, q);
+                rb_mma6(W1[0][ks], b, c0);
+                rb_mma6(W1[1][ks], b, c1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f0 = 16 * (2 * rw + j) + 4 * q;
+            const float4 bv = *reinterpret_cast<const float4 *>(b1 + f0);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            float h[4], gd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(j ? c1 : c0, r) + bb[r], h[r], gd);
+            rb_tile_put(T1, RB_TLD, l15, f0, h[0], h[1], h[2], h[3]);
+        }
+    };
+    auto rs_layer2 = [&](const u8 *T1, const float *b2, auto critic_c) {
+        constexpr bool critic = decltype(critic_c)::value;
+        RbAcc c[TP2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const Parts b = rb_tile_get(T1, RB_TLD, l15, ks, q);
+#pragma unroll
+            for (int j = 0; j < TP2; ++j) {
+                Parts a;
+                a.h = W2h[j][ks];
+                a.m = W2m[j][ks];
+                a.l = *reinterpret_cast<const u32x4 *>(w2l_at[j] + 1024 * ks);
+                rb_mma6(a, b, c[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TP2; ++j) {
+            const int tile = TP2 * rw + j;
+            const float4 bv = *reinterpret_cast<const float4 *>(b2 + 16 * tile + 4 * q);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            float h[4], gd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(c[j], r) + bb[r], h[r], gd);
+            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+            part = mfma16(w3r[j].x, h[0], part);
+            part = mfma16(w3r[j].y, h[1], part);
+            part = mfma16(w3r[j].z, h[2], part);
+            part = mfma16(w3r[j].w, h[3], part);
+            if (critic) { if (q == 0) PSC[tile * 16 + l15] = part[0]; }
+            else *reinterpret_cast<float4 *>(PSA + (tile * 64 + lane) * 4) = make_float4(part[0], part[1], part[2], part[3]);
+        }
+    };
+    // the value of the state whose critic partials are in PSC: the tiles' partials in tile order + b3 (wave 7)
+    auto value_out = [&](int tv, bool boot) {
+        float p[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) p[w] = PSC[w * 16 + l15];
+        const float v = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + b3c;
+        if (valid && q == 0) {
+            if (boot) { if (g.o_next_value) g.o_next_value[row] = v; }
+            else if (g.o_values) g.o_values[(size_t)tv * N + row] = v;
+        }
+        if (g.gae_lds && q == 0) GAE[boot ? H * 48 + l15 : (tv * 3 + 1) * 16 + l15] = v;
+    };
+
     // one step; LAST = the extra pass after the horizon that only evaluates the critic on the final state (bootstrap value).
     // Compile-time so that the H regular steps carry no `last` branches between their MFMA groups.
     auto step = [&](int t, auto last_c) {
         constexpr bool last = decltype(last_c)::value;
+        if constexpr (RS_ && last) {
+            // (role split) the pass after the horizon: the last step's value, then the critic alone on the final state
+            if (wave == 7 && t > 0) value_out(t - 1, false);
+            if (role == 1) rs_layer1(XC, T1A, BIA + 256);
+            lds_barrier();
+            if (role == 1) rs_layer2(T1A, BIA + 256 + 128, std::true_type{});
+            lds_barrier();
+            if (wave == 7) value_out(0, true);
+            return;
+        }
         // ================= phase 0: state tile -> registers; states[t]; layer 1 of both networks =================
         RFPROF(0);
         if (wave == 7 && !last && valid) {   // states[t] = state (AgentPPO.py:115)
@@ -276,17 +411,25 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                 }
             }
         }
+        if constexpr (RS_) {
+            // (role split) wave 7 finishes the PREVIOUS step's value from the partials the critic's waves left before barrier (4);
+            // the actor's waves run layer 1
+            if (wave == 7 && t > 0) value_out(t - 1, false);
+            if (role == 0) rs_layer1(XA, T1A, BIA);
+        } else
         {
             RbAcc ca, cc;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks < ks_s) {
                     if (!last) rb_mma6(w1a[ks], rb_tile_get(XA, RB_XLD, l15, ks, q), ca);
+#ifndef ERL_RF_NO_CRITIC      // (timing experiment: what the critic's layers cost the step's dependent chain; values are garbage without them)
                     Parts w1c;
                     w1c.h = *reinterpret_cast<const u32x4 *>(w1c_at + 64 * ks);
                     w1c.m = *reinterpret_cast<const u32x4 *>(w1c_at + 64 * ks + 128);
                     w1c.l = *reinterpret_cast<const u32x4 *>(w1c_at + 64 * ks + 256);
                     rb_mma6(w1c, rb_tile_get(XC, RB_XLD, l15, ks, q), cc);
+#endif
                 }
             }
             if (on1) {
@@ -298,11 +441,13 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
                     for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(ca, r) + bb[r], h[r], gd);
                     rb_tile_put(T1A, RB_TLD, l15, 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
                 }
+#ifndef ERL_RF_NO_CRITIC
                 const float4 b1c = *reinterpret_cast<const float4 *>(b1_at + 256);
                 const float bc[4] = {b1c.x, b1c.y, b1c.z, b1c.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(cc, r) + bc[r], h[r], gd);
                 rb_tile_put(T1C, RB_TLD, l15, 16 * wave + 4 * q, h[0], h[1], h[2], h[3]);
+#endif
             }
         }
         RFPROF(1);
@@ -312,6 +457,11 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         // ================= phase 1: layer 2 + the output-layer partials of this wave's k-slice =================
         // (a wave whose 16 rows of W2 lie beyond h2 -- waves 4..7 of the Pendulum demo's [128, 64] -- holds zero operands: it skips the
         // chain and leaves its zero partials; the four waves with rows then have the SIMDs' matrix pipes to themselves.  Scalar branch.)
+        if constexpr (RS_) {
+            // (role split) the actor's layer 2 + output partials; the critic's waves draw the next step's N(0,1) meanwhile
+            if (role == 0) rs_layer2(T1A, BIA + 128, std::false_type{});
+            else draw(t + 1);
+        } else
         if (__builtin_amdgcn_readfirstlane(wave) < n2)
         {
             RbAcc ca, cc;
@@ -319,7 +469,9 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks < ks_1) {
                     if (!last) rb_mma6(w2a[ks], rb_tile_get(T1A, RB_TLD, l15, ks, q), ca);
+#ifndef ERL_RF_NO_CRITIC
                     rb_mma6(w2c[ks], rb_tile_get(T1C, RB_TLD, l15, ks, q), cc);
+#endif
                 }
             }
             float h[4], gd;
@@ -338,8 +490,10 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             }
             const float4 b2c = *reinterpret_cast<const float4 *>(b2_at + 256);
             const float bc[4] = {b2c.x, b2c.y, b2c.z, b2c.w};
+#ifndef ERL_RF_NO_CRITIC
 #pragma unroll
             for (int r = 0; r < 4; ++r) gelu_and_grad_fast(rb_sum(cc, r) + bc[r], h[r], gd);
+#endif
             f32x4 pc = {0.f, 0.f, 0.f, 0.f};
             pc = mfma16(w3c.x, h[0], pc);
             pc = mfma16(w3c.y, h[1], pc);
@@ -356,19 +510,14 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         RFPROF(4);
 
         // ================= phase 2: value (wave 7); policy head + environment step (waves < nt); next draws (waves 4..7) ====
-        if (wave == 7) {
-            float p[8];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) p[w] = PSC[w * 16 + l15];
-            const float v = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + b3c;
-            if (valid && q == 0) {
-                if (last) { if (g.o_next_value) g.o_next_value[row] = v; }
-                else if (g.o_values) g.o_values[(size_t)t * N + row] = v;
-            }
-            if (g.gae_lds && q == 0) GAE[last ? H * 48 + l15 : (t * 3 + 1) * 16 + l15] = v;
+        if constexpr (!RS_) {
+            if (wave == 7) value_out(t, last);
+            if (last) return;
+            draw(t + 1);
+        } else {
+            // (role split) the critic's layer 1 on the state of THIS step (XC is rewritten after barrier (3)), beside the policy head and the env step
+            if (role == 1) rs_layer1(XC, T1A, BIA + 256);
         }
-        if (last) return;
-        draw(t + 1);
         float out[4] = {0.f, 0.f, 0.f, 0.f}, a2 = 0.f, pend_cost = 0.f;
         const int j0 = 16 * wave + 4 * q;
         if (wave < nt) {
@@ -476,8 +625,11 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
         RFPROF(5);
         // (3) the env's cross-wave reductions (SynVecEnv: S features over nt waves).  Pendulum is stepped by wave 0 alone, which goes straight
         // on: nothing it reads below was written by another wave since barrier (2), and what it writes is read after barrier (4)
-        if (ENV == ENV_SYN) lds_barrier();
+        if (ENV == ENV_SYN || RS_) lds_barrier();
         RFPROF(6);
+        if constexpr (RS_) {
+            if (role == 1) rs_layer2(T1A, BIA + 256 + 128, std::true_type{});      // (role split) the critic's layer 2 beside the flags / new state tile
+        }
         if (wave < nt) {
             if (ENV == ENV_SYN) {
                 float sq = 0.f, mx = 0.f;
@@ -661,27 +813,32 @@ int rf_launch(RfArgs &g, int env_kind, hipStream_t stream)
     const bool vec = (g.S % 4 == 0) && al(g.Pa) && al(g.Pc) && al(g.o_states);
     const dim3 grid((unsigned)erl_cdiv(g.N, 16)), block(512);
     g.gae_lds = (g.o_adv && g.H <= kRfGaeLdsSteps) ? 1 : 0;
-    const size_t lds_bytes = kRfLdsBytes + (g.gae_lds ? rf_gae_lds_bytes(g.H) : 0);
-    static bool attr[6] = {false, false, false, false, false, false};
+    const size_t lds_bytes = kRfLdsBytes + kRfRsExtraBytes + (g.gae_lds ? rf_gae_lds_bytes(g.H) : 0);
+    static bool attr[8] = {false, false, false, false, false, false, false, false};
+    // role split (the critic off the step's dependent chain; see the kernel): the default for the tuned shapes, ERL_RF_ROLE_SPLIT=0 keeps
+    // every wave on both networks (read per launch: A/B in one process)
+    const bool rs = [] { const char *e = getenv("ERL_RF_ROLE_SPLIT"); return !e || atoi(e) != 0; }();
 #define RF_LAUNCH(E, V, A_, B_, C_, SLOT)                                                                                  \
     do {                                                                                                                   \
         if (!attr[SLOT]) {                                                                                                 \
-            int rc = erl_hip_status(hipFuncSetAttribute((const void *)rollout_fused_kernel<E, V, A_, B_, C_>,              \
+            int rc = erl_hip_status(hipFuncSetAttribute((const void *)rollout_fused_kernel<E, V, A_, B_, C_, (SLOT >= 6)>,  \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize,                         \
-                                                        (int)(kRfLdsBytes + rf_gae_lds_bytes(kRfGaeLdsSteps))),             \
+                                                        (int)(kRfLdsBytes + kRfRsExtraBytes + rf_gae_lds_bytes(kRfGaeLdsSteps))), \
                                     "hipFuncSetAttribute(rollout_fused_kernel)");                                          \
             if (rc) return rc;                                                                                             \
             attr[SLOT] = true;                                                                                             \
         }                                                                                                                  \
-        hipLaunchKernelGGL((rollout_fused_kernel<E, V, A_, B_, C_>), grid, block, lds_bytes, stream, g);                 \
+        hipLaunchKernelGGL((rollout_fused_kernel<E, V, A_, B_, C_, (SLOT >= 6)>), grid, block, lds_bytes, stream, g);    \
     } while (0)
     const int ns = (g.S + 15) / 16;
     if (env_kind == ENV_SYN) {
-        if (vec && ns == 4 && g.h1 == 128 && g.h2 == 128) RF_LAUNCH(ENV_SYN, true, 4, 8, 8, 0);      // configs 4 / 5
+        if (vec && ns == 4 && g.h1 == 128 && g.h2 == 128 && rs) RF_LAUNCH(ENV_SYN, true, 4, 8, 8, 6);  // configs 4 / 5
+        else if (vec && ns == 4 && g.h1 == 128 && g.h2 == 128) RF_LAUNCH(ENV_SYN, true, 4, 8, 8, 0);
         else if (vec) RF_LAUNCH(ENV_SYN, true, 0, 0, 0, 1);
         else RF_LAUNCH(ENV_SYN, false, 0, 0, 0, 2);
     } else {
-        if (g.h1 == 128 && g.h2 == 64) RF_LAUNCH(ENV_PENDULUM, false, 1, 8, 4, 3);                    // config 2
+        if (g.h1 == 128 && g.h2 == 64 && rs) RF_LAUNCH(ENV_PENDULUM, false, 1, 8, 4, 7);              // config 2
+        else if (g.h1 == 128 && g.h2 == 64) RF_LAUNCH(ENV_PENDULUM, false, 1, 8, 4, 3);
         else RF_LAUNCH(ENV_PENDULUM, false, 0, 0, 0, 4);
     }
 #undef RF_LAUNCH

@@ -10,7 +10,7 @@ import torch as th
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elegantrl_amd import _hip  # noqa: E402
 
-_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "liberl_hip_prof.so")
+_hip.LIB_PATH = os.environ.get("ERL_HIP_PROF_LIB") or os.path.join(os.path.dirname(_hip.LIB_PATH), "liberl_hip_prof.so")
 from elegantrl_amd.agents import AgentPPO  # noqa: E402
 from elegantrl_amd.envs import PendulumVecEnv, SynVecEnv  # noqa: E402
 from elegantrl_amd.train import Config  # noqa: E402
