@@ -95,8 +95,8 @@ constexpr int RF_O_PSC = RF_O_PSA + 8 * 64 * 4;         // [8][16]        critic
 constexpr int RF_O_EPS = RF_O_PSC + 8 * 16;             // [2][16][16]    N(0,1) draws of step t (t & 1) and t + 1, produced a step ahead
 constexpr int RF_O_RED = RF_O_EPS + 2 * 16 * 16;        // [8][16][2]     env reductions
 constexpr int RF_O_BIA = RF_O_RED + 8 * 16 * 2;         // [4][128]       b1 | b2 of the actor, b1 | b2 of the critic (zero beyond h)
-constexpr int RF_O_HEAD = RF_O_BIA + 4 * 128;           // [2][16]        action_std_log | b3 of the actor (index clamped to A - 1)
-constexpr int RF_O_WST = RF_O_HEAD + 32;                // [64][RF_WLD]   Ws^T: WST[j][k] = Ws[k][j]
+constexpr int RF_O_HEAD = RF_O_BIA + 4 * 128;           // [3][16]        action_std_log | b3 of the actor (index clamped to A - 1) | exp(action_std_log)
+constexpr int RF_O_WST = RF_O_HEAD + 48;                // [64][RF_WLD]   Ws^T: WST[j][k] = Ws[k][j]
 constexpr int RF_O_WAT = RF_O_WST + 64 * RF_WLD;        // [64][16]       Wa^T
 constexpr int RF_O_W1C = RF_O_WAT + 64 * 16;            // [128][RF_W1LD bytes]  critic W1, split: [row][3 parts][64 bf16] + 16 bytes (A operands of layer 1)
 constexpr int RF_W1LD = 3 * 128 + 16;                   //                rows 100 dwords apart: the 16 rows of a ds_read_b128 lane group on 16 distinct 4-bank groups
@@ -284,6 +284,9 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
     const float *b1_at = BIA + 16 * min(wave, n1 - 1) + 4 * q, *b2_at = BIA + 128 + 16 * kt + 4 * q;
     float *HEAD = smem + RF_O_HEAD;
     if (tid < 32) HEAD[tid] = g.Pa[(tid < 16 ? da.oStd() : da.ob3()) + min(tid & 15, A - 1)];
+    // the policy's standard deviation is constant over a rollout: expf once per launch instead of four times per step in every env wave
+    // (the same function of the same input: the same bits)
+    if (tid >= 32 && tid < 48) HEAD[tid] = expf(g.Pa[da.oStd() + min(tid & 15, A - 1)]);
     const float b3c = g.Pc[dc.ob3()];
 
     // ---- the environment's per-lane constants
@@ -531,11 +534,13 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
             }
             // every env wave finishes the policy head for its own lanes (same fixed-order sum, same draws: bit-identical in
             // all of them), so tanh(action) reaches the env's MFMA B operand -- k = 4 q + r -- without an LDS round trip
-            float Y[4], sl[4], b3a[4];
+            float Y[4], sl[4], b3a[4], sd[4];
             {
                 const float4 s4 = *reinterpret_cast<const float4 *>(HEAD + 4 * q), b4 = *reinterpret_cast<const float4 *>(HEAD + 16 + 4 * q);
+                const float4 d4 = *reinterpret_cast<const float4 *>(HEAD + 32 + 4 * q);
                 sl[0] = s4.x; sl[1] = s4.y; sl[2] = s4.z; sl[3] = s4.w;
                 b3a[0] = b4.x; b3a[1] = b4.y; b3a[2] = b4.z; b3a[3] = b4.w;
+                sd[0] = d4.x; sd[1] = d4.y; sd[2] = d4.z; sd[3] = d4.w;
             }
             {
                 float4 p[8];
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(512) void rollout_fused_kernel(RfArgs g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool on = 4 * q + r < A;
-                const float sdv = expf(sl[r]), var = sdv * sdv;
+                const float sdv = sd[r], var = sdv * sdv;
                 act[r] = Y[r] + sdv * eps[r];
                 const float diff = act[r] - Y[r];
                 const float term = -(diff * diff) / (2.f * var) - sl[r] - kLogSqrt2PiF;
