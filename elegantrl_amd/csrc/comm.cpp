@@ -260,7 +260,10 @@ extern "C" int erl_ppo_update_dp_f32(float *flat_params, float *exp_avg, float *
     ERL_REQUIRE(!adv_partials || (adv_stats && n_partials >= 1), "erl_ppo_update_dp_f32: adv_partials needs adv_stats and n_partials");
     bool folded = adv_partials == nullptr;
     if (!tail && erl_ppo_arith_for_call(S, h1, h2, A, (objective >> 8) & 3) == ERL_PPO_ARITH_SPLIT) {
-        int rc = erl_s3_images_build(flat_params, S, h1, h2, A, &images, adv_partials, n_partials, H, N, adv_stats, (hipStream_t)stream);
+        // (the (128 | 64, h2) kernels also get the per-sample records: s3_image.h)
+        const S3AuxSrc ax{actions, logprobs, advantages, reward_sums, unmasks, A, H * N};
+        int rc = erl_s3_images_build(flat_params, S, h1, h2, A, &images, adv_partials, n_partials, H, N, adv_stats, (hipStream_t)stream,
+                                     erl_ppo_wd_supported(S, h1, h2, A) ? nullptr : &ax);
         if (rc) return rc;
         im = &images;
         folded = true;

@@ -414,11 +414,25 @@ __global__ __launch_bounds__(1024) void tail_fused_kernel(const float *slabs, in
 // W2 and W1 images of both networks from the flat parameters [actor | critic]: one thread per image element (W1's pad columns: 0)
 __global__ __launch_bounds__(256) void s3_image_build_kernel(const float *__restrict__ params, int64_t Pa, S3Images im,
                                                              const double *__restrict__ adv_partials, int n_partials, int H, int N,
-                                                             double *__restrict__ adv_stats)
+                                                             double *__restrict__ adv_stats, S3AuxSrc ax, float *__restrict__ aux)
 {
+    if (blockIdx.y == 3) {          // the per-sample records (s3_image.h): one thread per buffer row, exact copies
+        const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (aux && r < ax.rows) {
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = j < ax.A ? ax.actions[r * ax.A + j] : 0.f;
+            float4 *dst = reinterpret_cast<float4 *>(aux + r * kS3AuxFloats);
+            dst[0] = make_float4(a[0], a[1], a[2], a[3]);
+            dst[1] = make_float4(a[4], a[5], a[6], a[7]);
+            dst[2] = make_float4(ax.logprobs[r], ax.advantages[r], ax.reward_sums[r], ax.unmasks[r] ? 1.f : 0.f);
+            dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     if (blockIdx.y == 2) {          // the advantage statistics' fold rides this launch (one block)
         __shared__ double scratch[4];
-        if (blockIdx.x == 0) erl_adv_stats_fold_block(adv_partials, n_partials, H, N, adv_stats, scratch);
+        if (blockIdx.x == 0 && adv_partials) erl_adv_stats_fold_block(adv_partials, n_partials, H, N, adv_stats, scratch);
         return;
     }
     const int gi = blockIdx.y;
@@ -789,12 +803,15 @@ struct S3Slot {
     hipStream_t stream = nullptr;
     unsigned char *buf = nullptr;
     size_t bytes = 0;
+    float *aux = nullptr;         // per-sample records (s3_image.h), grown on demand
+    size_t aux_bytes = 0;
 };
 S3Slot g_s3_slots[16];
+constexpr size_t kS3AuxMaxBytes = (size_t)256 << 20;     // beyond it (H x N > 4 Mi rows) the minibatch kernels keep gathering from the buffers
 }  // namespace
 
 int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, const double *adv_partials, int n_partials,
-                        int64_t H, int64_t N, double *adv_stats, hipStream_t stream)
+                        int64_t H, int64_t N, double *adv_stats, hipStream_t stream, const S3AuxSrc *aux_src)
 {
     int dev = 0;
     int rc = erl_hip_status(hipGetDevice(&dev), "hipGetDevice");
@@ -830,7 +847,28 @@ int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, 
         out->net[gi].K1 = s3_image_k1(S);
     }
     const int64_t elems = (int64_t)h1 * h2 + (int64_t)h1 * s3_image_k1(S);
-    hipLaunchKernelGGL(s3_image_build_kernel, dim3((unsigned)erl_cdiv(elems, 256), adv_partials ? 3 : 2), dim3(256), 0, stream, flat_params, Pa, *out,
-                       adv_partials, n_partials, (int)H, (int)N, adv_stats);
+    // the per-sample records ride the same launch (ERL_K6_AUX=0: none -- A/B runs; read per call)
+    out->aux = nullptr;
+    S3AuxSrc ax{};
+    const bool aux_on = [] { const char *e = getenv("ERL_K6_AUX"); return !e || atoi(e) != 0; }();
+    if (aux_on && aux_src && aux_src->actions && aux_src->logprobs && aux_src->advantages && aux_src->reward_sums && aux_src->unmasks &&
+        aux_src->A >= 1 && aux_src->A <= 8 && aux_src->rows >= 1 && (size_t)aux_src->rows * kS3AuxFloats * sizeof(float) <= kS3AuxMaxBytes) {
+        const size_t want = (size_t)aux_src->rows * kS3AuxFloats * sizeof(float);
+        if (slot->aux_bytes < want) {
+            if (slot->aux) {
+                if ((rc = erl_hip_status(hipStreamSynchronize(slot->stream), "hipStreamSynchronize"))) return rc;
+                if ((rc = erl_hip_status(hipFree(slot->aux), "hipFree"))) return rc;
+                slot->aux = nullptr;
+                slot->aux_bytes = 0;
+            }
+            if ((rc = erl_hip_status(hipMalloc((void **)&slot->aux, want), "hipMalloc(per-sample records)"))) return rc;
+            slot->aux_bytes = want;
+        }
+        ax = *aux_src;
+        out->aux = slot->aux;
+    }
+    const int64_t gx_w = erl_cdiv(elems, 256), gx_a = out->aux ? erl_cdiv(ax.rows, 256) : 0, gx = gx_a > gx_w ? gx_a : gx_w;
+    hipLaunchKernelGGL(s3_image_build_kernel, dim3((unsigned)gx, out->aux ? 4 : (adv_partials ? 3 : 2)), dim3(256), 0, stream, flat_params, Pa, *out,
+                       adv_partials, n_partials, (int)H, (int)N, adv_stats, ax, slot->aux);
     ERL_LAUNCH_CHECK("erl_s3_images_build");
 }

@@ -24,6 +24,7 @@ struct Ppo2Args {
     const double *adv_stats;         // nullptr: `advantages` are normalised already; else the raw sums of erl_gae_scan_f32 / the rollout epilogue
     const unsigned char *w2img[2];   // split-arithmetic kernel: pre-split W2 images (s3_image.h) or nullptr
     const unsigned char *w1img[2];   // ... and W1 images (columns padded to 32 / 64); both or neither
+    const float *aux = nullptr;      // per-sample records [H N][16] (s3_image.h S3Images::aux; built by the update loop) or nullptr: gather from the buffers
     unsigned long long *span;   // measurement hook (api.cpp, erl_k6_timing_*): this launch's records, kSpanWords u64 per workgroup (see span_enter); nullptr = off
     const int64_t *next_ids;   // the NEXT minibatch's ids (update loops; nullptr: none / unknown): -DERL_K6_EXP & 4 lets the critic's workgroups,
                                // which finish ~5k cycles before the actor's, pull that minibatch's rows towards their XCD's L2

@@ -661,6 +661,7 @@ int erl_ppo_step_images_f32(const float *actor_params, const float *critic_param
     g.w2img[1] = images ? images->net[1].img : nullptr;
     g.w1img[0] = images ? images->net[0].img1 : nullptr;
     g.w1img[1] = images ? images->net[1].img1 : nullptr;
+    g.aux = images ? images->aux : nullptr;
     g.prof = g_ppo_prof;
     g.prof_block = g_ppo_prof_block;
     // 16-byte vector path: every row / parameter block / normalisation vector must be 16-byte aligned

@@ -26,6 +26,7 @@
 #pragma once
 #include "ppo_step_w4_impl.h"
 #include "split_bf16.h"
+#include "s3_image.h"
 #include <type_traits>
 
 namespace {
@@ -551,25 +552,42 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
             XR[ks][1] = load4<VEC>(xrow, 16 * ks + 8 * hi + 4, S);
         }
     }
-    const uint8_t um_raw = g.unmasks[row];
-    float um_k = (valid && um_raw) ? 1.f : 0.f;
-    float xa_k = ACTOR ? g.logprobs[row] : g.reward_sums[row];
-    float xb_k = ACTOR ? g.advantages[row] : 0.f;
-    const float &um = um_k, &xa = xa_k, &xb = xb_k;
+    float um_k, xa_k, xb_k;
     float act_pre[4] = {0.f, 0.f, 0.f, 0.f}, sl_pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ACTOR) {
-        const bool act4 = (OUT & 3) == 0 && (reinterpret_cast<uintptr_t>(g.actions) & 15) == 0;      // uniform
-        if (act4) {
-            const float4 v = *reinterpret_cast<const float4 *>(g.actions + row * OUT + min(4 * hi, OUT - 4));
+    if (g.aux) {
+        // the sample's scalars from its 64-byte record (s3_image.h: [a_0 .. a_7 | logprob, raw advantage, reward_sum, unmask | pad], exact copies
+        // made once per update loop): one line per sample and two loads per lane instead of four gathers from four arrays (uniform branch)
+        const float4 *rec = reinterpret_cast<const float4 *>(g.aux + row * kS3AuxFloats);
+        const float4 sc4 = rec[2];
+        um_k = (valid && sc4.w != 0.f) ? 1.f : 0.f;
+        xa_k = ACTOR ? sc4.x : sc4.z;
+        xb_k = ACTOR ? sc4.y : 0.f;
+        if (ACTOR) {
+            const float4 v = rec[hi];
             act_pre[0] = v.x; act_pre[1] = v.y; act_pre[2] = v.z; act_pre[3] = v.w;
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ac = min(4 * hi + j, OUT - 1);
-            if (!act4) act_pre[j] = g.actions[row * OUT + ac];
-            sl_pre[j] = std_log[ac];
+            for (int j = 0; j < 4; ++j) sl_pre[j] = std_log[min(4 * hi + j, OUT - 1)];
+        }
+    } else {
+        const uint8_t um_raw = g.unmasks[row];
+        um_k = (valid && um_raw) ? 1.f : 0.f;
+        xa_k = ACTOR ? g.logprobs[row] : g.reward_sums[row];
+        xb_k = ACTOR ? g.advantages[row] : 0.f;
+        if (ACTOR) {
+            const bool act4 = (OUT & 3) == 0 && (reinterpret_cast<uintptr_t>(g.actions) & 15) == 0;      // uniform
+            if (act4) {
+                const float4 v = *reinterpret_cast<const float4 *>(g.actions + row * OUT + min(4 * hi, OUT - 4));
+                act_pre[0] = v.x; act_pre[1] = v.y; act_pre[2] = v.z; act_pre[3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ac = min(4 * hi + j, OUT - 1);
+                if (!act4) act_pre[j] = g.actions[row * OUT + ac];
+                sl_pre[j] = std_log[ac];
+            }
         }
     }
+    const float &um = um_k, &xa = xa_k, &xb = xb_k;
     PROF_NV(17);                                            // (row loads issued)
     // ---- the W2 image.  Without FAST: requested here, last (the memory pipe returns W1 and the rows first), by the compiler's own
     // LDS-DMA intrinsic.  hipcc orders EVERY later LDS access behind an intrinsic LDS-DMA (it cannot tell the bytes apart): the

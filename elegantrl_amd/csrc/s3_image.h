@@ -17,7 +17,20 @@ struct S3Image {
 };
 struct S3Images {
     S3Image net[2];         // actor, critic (= parameter groups 0, 1 of the update loop)
+    // round 6: the per-sample values of a minibatch row as ONE 64-byte record per buffer row, [a_0 .. a_7 | logprob, advantage (raw),
+    // reward_sum, unmask (0 / 1) | pad], built with the images once per update loop: a minibatch kernel's lane fetches its sample's
+    // scalars with one or two 16-byte loads from ONE line instead of four gathers from four arrays (the address processing of those
+    // gathers was a third of the actor workgroups' prologue); nullptr: none
+    const float *aux = nullptr;
 };
+// what the records are built from (the rollout buffers of the update loop; rows = H * N)
+struct S3AuxSrc {
+    const float *actions, *logprobs, *advantages, *reward_sums;
+    const uint8_t *unmasks;
+    int A;
+    int64_t rows;
+};
+constexpr int kS3AuxFloats = 16;
 
 // chunk swizzle of an image with CP = K / 8 chunks per part (the formulas of swz<> in ppo_step_s3_impl.h)
 __host__ __device__ inline int s3_swz(int CP, int r)
@@ -86,4 +99,4 @@ int erl_k6_wg_map_choice(int family);
 // (adv_partials != nullptr: one more block of the same launch folds the n_partials x 3 fp64 partial sums of the rollout's advantage
 // epilogue into adv_stats -- erl_adv_stats_fold_f32 without a launch of its own)
 int erl_s3_images_build(const float *flat_params, int S, int h1, int h2, int A, S3Images *out, const double *adv_partials, int n_partials,
-                        int64_t H, int64_t N, double *adv_stats, hipStream_t stream);
+                        int64_t H, int64_t N, double *adv_stats, hipStream_t stream, const S3AuxSrc *aux_src = nullptr);
