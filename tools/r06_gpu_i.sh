@@ -1,0 +1,30 @@
+#!/bin/bash
+# own-row normalisation before barrier (0a) (ERL_K6_ROWPRE): kernel / agent tests on the new build, then rp0 / main alternating on one box (c4, c2), phase profiles
+O=$GRAFT_REPO_ROOT/gpurun_out/r06_i; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+export ERL_QUIET=1
+L=$GRAFT_REPO_ROOT/elegantrl_amd/lib
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py -m gpu -q -x -k "ppo or agent or golden or step or update" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -4 $O/pytest.log
+for cfg in c4 c2; do
+  for rep in 0 1 2; do
+    for a in rp0 main; do
+      lib=$L/liberl_hip.so; [ $a = rp0 ] && lib=$L/liberl_hip_rp0.so
+      ERL_HIP_LIB=$lib timeout 300 python bench.py --config $cfg --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep --no-smi --repeats 3 > $O/${cfg}_${a}_$rep.json 2> $O/${cfg}_${a}_$rep.err
+    done
+  done
+done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/c*_*_?.json")):
+    try:
+        d = json.loads(open(f).readline()); r = d["roofline"]; b = d["breakdown"]
+        print(f.split('/')[-1], d["value"], d["ms_per_step"], d["extra"]["repeated_regions_ms_per_step"], "k6", r["avg_launch_us"], "update_ms", b["update_net_ms"], "phases", r.get("phase_cycles"))
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
+for a in profrp0 prof; do
+  ERL_HIP_PROF_LIB=$L/liberl_hip_$a.so K6_LOOP=1 python tools/ppo_phase_profile.py > $O/phase_$a.txt 2>&1
+  grep "prologue detail" $O/phase_$a.txt | cut -c1-330
+  grep -A14 "actor: total" $O/phase_$a.txt | cut -c1-120
+done
