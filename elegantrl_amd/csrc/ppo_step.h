@@ -75,14 +75,16 @@ template <int POLICY>
 __device__ __forceinline__ void slab_store_as(float v, float *p)
 {
     if (POLICY == 1) *p = v;
+    else if (POLICY == 2) { }                       // (diagnostics, -DERL_K6_EXP & 32: the store left out -- is the kernel's end the drain of its stores?)
     else slab_store(v, p);
 }
 #ifndef ERL_K6_EXP
 #define ERL_K6_EXP 0
 #endif
-// order of the weight-gradient phases of ppo_step_s3_kernel: 0 = dW1, dW3, dW2 (rounds 3-5), 1 = dW1, dW2, dW3 (the large store first)
+// order of the weight-gradient phases of ppo_step_s3_kernel: 0 = dW1, dW3, dW2 (rounds 3-5), 1 = dW1, dW2, dW3 (the large store first),
+// 2 = dW1, dW2, dW3 with the next phase's operand images staged under the current phase's MFMAs (round 6, default)
 #ifndef ERL_K6_DW_ORDER
-#define ERL_K6_DW_ORDER 0
+#define ERL_K6_DW_ORDER 2
 #endif
 
 constexpr int PB = 128;        // samples per workgroup

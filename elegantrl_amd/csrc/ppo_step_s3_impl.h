@@ -223,6 +223,9 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
         prev = acc;
         prev1 = acc1;
     }
+#if defined(ERL_PROFILE) && defined(ERL_PROFILE_FINE)
+    side(NC);                                            // (fine phase stamps: the MFMA loop is over)
+#endif
     // the last tile has no MFMAs to ride behind: unfenced, so that all 16 elements' chains interleave (two dependent chains
     // alone stall on each other: tools/split_mfma_probe.hip, part E)
 #pragma unroll
@@ -242,9 +245,9 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
 // 4 sigma(u) .. + 3 (sigma swaps 1 and 2), and receives rows .. + 0..3 of column 32 To + phi(lane & 31): the result rows are in
 // the gate's order.
 // ---------------------------------------------------------------------------------------------------------
-template <int NK, int NO, int CP>
+template <int NK, int NO, int CP, typename Side = NoSide>
 __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f32x16 (&dzH)[NK / 2], const f32x16 (&gate)[NO],
-                                       Parts (&outP)[2 * NO], int lane)
+                                       Parts (&outP)[2 * NO], int lane, const Side &side = Side())
 {
     constexpr int ROWB = 48 * CP, PBY = 16 * CP, NC = NO * NK;
     constexpr int EP = 16 / NK;
@@ -326,6 +329,9 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
             };
             acc = mfma_bf(a.m, b.m, acc);
             __builtin_amdgcn_sched_barrier(0);
+#if defined(ERL_PROFILE) && defined(ERL_PROFILE_FINE)
+            side(c);
+#endif
             fill(0);
             acc1 = mfma_bf(a.l, b.h, acc1);
             __builtin_amdgcn_sched_barrier(0);
@@ -343,6 +349,9 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
         prev = acc;
         prev1 = acc1;
     }
+#if defined(ERL_PROFILE) && defined(ERL_PROFILE_FINE)
+    side(NC);
+#endif
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
 #pragma unroll
@@ -401,10 +410,16 @@ __device__ __forceinline__ void grad_bias(const Parts (&A)[8], float *__restrict
 }
 
 // dW tiles (it, jt0 + CS k) = A . B^T, B read from the sample-major image SB (CPB chunks per part) one k-step ahead
-template <int CPB, int NBW, int CS, int POLICY = 0, int POLICY_LAST = POLICY>
+// `side(c, s)`: LDS stores of the NEXT phase's operand images ride behind MFMA s (0..4) of k-step c (0 .. 8 NBW - 1): the vector-memory /
+// LDS ports idle beside the weight gradients' MFMAs, and a staging round of its own costs 1-2k cycles with the matrix pipe idle (round 6)
+struct NoSide2 {
+    __device__ __forceinline__ void operator()(int, int) const {}
+};
+template <int CPB, int NBW, int CS, int POLICY = 0, int POLICY_LAST = POLICY, typename Side = NoSide2>
 __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, int it, int jc, int jt_store0, float *__restrict__ dW, int ldw,
-                                           int cols_real, int lane)
+                                           int cols_real, int lane, const Side &side = Side())
 {
+    constexpr bool SIDE = !std::is_same<Side, NoSide2>::value;
     const TrOperand<CPB> tb(SB, lane);
     const int l31 = lane & 31, hi = lane >> 5;
     u32x2 rq[2][6];
@@ -429,7 +444,33 @@ __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, in
             // lets the two operand buffers share registers and sinks the reads behind the fifth MFMA, one MFMA (32 cycles) before
             // their use -- every k-step then waited for the LDS (round 3: 50-52 cycles per MFMA in dW1 / dW2, floor 32)
             __builtin_amdgcn_sched_barrier(0);
-            mma6(A[ks], parts_of(rq[c & 1]), acc);
+            if constexpr (SIDE) {
+                const Parts &a = A[ks];
+                const Parts b = parts_of(rq[c & 1]);
+                acc = mfma_bf(a.m, b.m, acc);                 // (mma6's order: the same bits)
+                __builtin_amdgcn_sched_barrier(0);
+                side(c, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma_bf(a.l, b.h, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                side(c, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma_bf(a.h, b.l, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                side(c, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma_bf(a.m, b.h, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                side(c, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma_bf(a.h, b.m, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                side(c, 4);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma_bf(a.h, b.h, acc);
+            } else {
+                mma6(A[ks], parts_of(rq[c & 1]), acc);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // a finished tile is stored behind the NEXT tile's first k-step: its last MFMA has long retired, no wait at the seam
             if (ks == 0 && k > 0) {
@@ -729,7 +770,17 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
         }
         stage_s3<2 * KX, CP1, 0>(SB, Xs, col, hi);
     }
+#if defined(ERL_PROFILE) && defined(ERL_PROFILE_FINE)
+    {
+        // fine stamps: the second layer's tile boundaries (slots 21..23) and the end of its MFMA loop (24)
+        auto fine = [&](int c) {
+            if (c > 0 && c % (2 * N1) == 0) { if (c / (2 * N1) == 1) PROF_NV(21); else if (c / (2 * N1) == 2) PROF_NV(22); else if (c / (2 * N1) == 3) PROF_NV(23); else PROF_NV(24); }
+        };
+        fwd_s3<2 * N1, N2, CP2>(IMG2, s_b2, H1p, H1, H2, G2, m, hi, fine);
+    }
+#else
     fwd_s3<2 * N1, N2, CP2>(IMG2, s_b2, H1p, H1, H2, G2, m, hi);       // splits H1 into H1p on the way
+#endif
     SPAN_STAMP(sps, 3);                                              // phase 2: second layer forward
     PROF(4);
 
@@ -849,7 +900,17 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
         }
     }
     Parts dZ1p[2 * N1];
+#if defined(ERL_PROFILE) && defined(ERL_PROFILE_FINE)
+    {
+        PROF(29);                                                    // (dZ2 is formed)
+        auto fine = [&](int c) {
+            if (c > 0 && c % (2 * N2) == 0) { if (c / (2 * N2) == 1) PROF_NV(25); else if (c / (2 * N2) == 2) PROF_NV(26); else if (c / (2 * N2) == 3) PROF_NV(27); else PROF_NV(28); }
+        };
+        bwd_s3<2 * N2, N1, CP2>(IMG2, dZ2p, G2, G1, dZ1p, lane, fine);
+    }
+#else
     bwd_s3<2 * N2, N1, CP2>(IMG2, dZ2p, G2, G1, dZ1p, lane);         // splits dZ2 into dZ2p on the way; dZ1 leaves split
+#endif
     PROF(7);
     lds_barrier();                                                   // (1) every wave is done with the weight images and W3
     SPAN_STAMP(sps, 4);                                              // phase 3: output layer, objective, backward (dZ2, dZ1)
@@ -866,6 +927,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     }
     lds_barrier();                                                   // (2)
     PROF(9);
+#if ERL_K6_DW_ORDER != 2
     {
         // wave w owns row tile it = w % N1; the CS = 4 / N1 waves of a row tile split the KX column tiles
         constexpr int CS = 4 / N1, NBW = (KX + CS - 1) / CS;
@@ -880,6 +942,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     PROF(10);
     lds_barrier();                                                   // (3) dZ1, X images consumed
     SPAN_STAMP(sps, 5);                                              // phase 4: staging + dW1, db1
+#endif
 
     constexpr int NH1 = (N1 > 2) ? 2 : 1;                            // passes over H1's features: SB holds 64 of them
     constexpr int KSH = 2 * N1 / NH1;                                // k-steps (16 features) per pass
@@ -962,6 +1025,78 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
         if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
     }
     PROF(13);
+#elif ERL_K6_DW_ORDER == 2
+    // order dW1, dW2, dW3 with the operand images of the NEXT phase staged UNDER the current phase's MFMAs (round 6).  SA is read only by a
+    // phase's first instructions (a wave's 96-register A operand) and by dW3: once every wave holds its rows of dZ1^T (barrier 2b) the dZ2
+    // image is written over it behind dW1's MFMAs, and once every wave holds its rows of dZ2^T (barrier 4) H2^T behind the first pass of dW2.
+    // Seven barriers instead of eight; the staging rounds (5)-(6) and half of (3)-(4) of the other orders are gone.
+    {
+        constexpr int CS1 = 4 / N1, NBW1 = (KX + CS1 - 1) / CS1;
+        const int it = wave % N1, jc = wave / N1;
+        Parts A[8];
+        grad_a_load<CP2>(SA, it, A, lane);
+        lds_barrier();                                               // (2b) every wave holds its rows of dZ1^T: SA is free
+        PROF(10);
+        constexpr int NP = 6 * N2;                                   // the dZ2 image of this lane's sample: 2 N2 k-steps x 3 parts of 16 bytes
+        constexpr int PPK = (NP + 8 * NBW1 - 1) / (8 * NBW1);        // pieces per k-step
+        static_assert(PPK <= 5, "dZ2 image pieces per k-step of dW1");
+        u8 *zb = SA + col * (48 * CPH2);
+        const int zsw = swz<CPH2>(col);
+        auto piece = [&](int i) {
+            const int ks = i / 3, pl = i % 3;
+            u8 *dst = zb + 16 * ((2 * ks + hi) ^ zsw) + pl * (16 * CPH2);
+            *reinterpret_cast<u32x4 *>(dst) = pl == 0 ? dZ2p[ks].h : pl == 1 ? dZ2p[ks].m : dZ2p[ks].l;
+        };
+        if (jc < KX) {
+            auto side = [&](int c, int sl) {
+                if (sl < PPK && PPK * c + sl < NP) piece(PPK * c + sl);
+            };
+            grad_tiles<CP1, NBW1, CS1, 0, 0>(A, SB, it, jc, 0, slab + d.oW1(), S, S, lane, side);
+            if (jc == 0) grad_bias(A, slab + d.ob1(), it, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) piece(i);
+        }
+    }
+    PROF(11);
+    lds_barrier();                                                   // (3) the X image is consumed, the dZ2 image complete
+    SPAN_STAMP(sps, 5);                                              // phase 4: staging + dW1, db1 (+ the dZ2 image)
+    {
+        constexpr int CS = 4 / N2;
+        constexpr int TPP = N1 / NH1;                                // column tiles per pass
+        constexpr int NBW = (TPP + CS - 1) / CS;
+        static_assert(TPP >= CS, "every wave owns a column tile of dW2");
+        const int it = wave % N2, jc = wave / N2;
+        Parts A[8];
+        grad_a_load<CPH2>(SA, it, A, lane);
+        stage_s3<KSH, CPB2, 0>(SB, H1p, col, hi);
+        lds_barrier();                                               // (4) every wave holds its rows of dZ2^T: SA is free; first half of H1 in SB
+        PROF(12);
+        constexpr int NP = 16 * N2;                                  // H2^T (fp32, feature-major), one 4-byte store per element
+        constexpr int PPK = (NP + 8 * NBW - 1) / (8 * NBW);
+        static_assert(PPK <= 5, "H2^T elements per k-step of dW2");
+        float *T2 = reinterpret_cast<float *>(SA);
+        auto side = [&](int c, int sl) {
+            const int i = PPK * c + sl;
+            if (sl < PPK && i < NP) {
+                const int t = i >> 4, r = i & 15;
+                T2[(32 * t + 16 * (r >> 3) + 8 * hi + (r & 7)) * PLD + col] = H2[t][r];
+            }
+        };
+        constexpr int PW2 = (ERL_K6_EXP & 32) ? 2 : 0;               // (diagnostics: dW2 not stored)
+        grad_tiles<CPB2, NBW, CS, PW2, PW2>(A, SB, it, jc, 0, slab + d.oW2(), h1, h1, lane, side);
+        if (NH1 == 2) {
+            lds_barrier();                                           // (5) first half of H1 consumed; H2^T written
+            stage_s3<KSH, CPB2, (NH1 == 2 ? KSH : 0)>(SB, H1p, col, hi);
+            lds_barrier();                                           // (6)
+            grad_tiles<CPB2, NBW, CS, PW2, PW2>(A, SB, it, jc, TPP, slab + d.oW2(), h1, h1, lane);
+        }
+        if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
+        if (NH1 != 2) lds_barrier();                                 // (5) H2^T written
+    }
+    SPAN_STAMP(sps, 6);                                              // phase 5: dW2, db2 (+ H2^T); phase 6 = dW3, db3, logs, store drain
+    PROF(13);
+    dw3();
 #else
     // order dW1, dW2, dW3 (round 6): the 64 KB of dW2 -- two thirds of a workgroup's slab -- leave by write-through stores while dW3 is
     // still computing, and the kernel ends behind the 4 KB of dW3 instead of behind the drain of 256 x 64 KB; H2 waits in registers

@@ -84,6 +84,12 @@ def main():
         for net, nm in enumerate(("actor", "critic")):
             w = full[net, :4].double()
             print(f"--- {nm}: prologue detail (cycles since entry): " + ", ".join(f"{names[k]} {float((w[:, k] - w[:, 0]).mean()):.0f}" for k in (16, 17, 18, 19, 1, 2, 20, 3)))
+    if int(full[0, 0, 21]) != 0:                      # -DERL_PROFILE_FINE builds: tile boundaries inside the second layer and the backward
+        fn = {3: "(L2 fwd starts)", 21: "L2 tile 1 starts", 22: "L2 tile 2 starts", 23: "L2 tile 3 starts", 24: "L2 MFMA loop over", 4: "(L2 fwd ends)",
+              6: "(backward starts)", 29: "dZ2 formed", 25: "bwd tile 1 starts", 26: "bwd tile 2 starts", 27: "bwd tile 3 starts", 28: "bwd MFMA loop over", 7: "(backward ends)"}
+        for net, nm in enumerate(("actor", "critic")):
+            w = full[net, :4].double()
+            print(f"--- {nm}: fine stamps (cycles since entry): " + ", ".join(f"{v} {float((w[:, k] - w[:, 0]).mean()):.0f}" for k, v in fn.items()))
     p = full[:, :, :NP]
     p = p[:, (p[0, :, 0] != 0)]                        # the 4-wave form stamps waves 0..3 only
     print(f"{p.shape[1]} waves per workgroup")

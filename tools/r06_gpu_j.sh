@@ -1,0 +1,32 @@
+#!/bin/bash
+# (a) slab reduction with 64 loads in flight (ERL_REDUCE_DEEP; main vs rd0), (b) K6 weight-gradient phases with the next phase's operand
+# images staged under the MFMAs (ERL_K6_DW_ORDER=2; main vs dwo2): tests on both libraries, then alternating bench runs on one box, phase profiles
+O=$GRAFT_REPO_ROOT/gpurun_out/r06_j; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+export ERL_QUIET=1
+L=$GRAFT_REPO_ROOT/elegantrl_amd/lib
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py -m gpu -q -x -k "ppo or agent or golden or step or update or reduce or tail or adam" > $O/pytest_main.log 2>&1; echo "pytest main rc=$?" >> $O/pytest_main.log
+tail -3 $O/pytest_main.log
+ERL_HIP_LIB=$L/liberl_hip_dwo2.so timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py -m gpu -q -x -k "ppo or agent or golden or step or update" > $O/pytest_dwo2.log 2>&1; echo "pytest dwo2 rc=$?" >> $O/pytest_dwo2.log
+tail -3 $O/pytest_dwo2.log
+for cfg in c4 c2; do
+  for rep in 0 1 2; do
+    for a in rd0 main dwo2; do
+      lib=$L/liberl_hip.so; [ $a != main ] && lib=$L/liberl_hip_$a.so
+      ERL_HIP_LIB=$lib timeout 300 python bench.py --config $cfg --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep --no-smi --repeats 3 > $O/${cfg}_${a}_$rep.json 2> $O/${cfg}_${a}_$rep.err
+    done
+  done
+done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/c*_*_?.json")):
+    try:
+        d = json.loads(open(f).readline()); r = d["roofline"]; b = d["breakdown"]
+        print(f.split('/')[-1], d["value"], d["ms_per_step"], d["extra"]["repeated_regions_ms_per_step"], "k6", r["avg_launch_us"], "update_ms", b["update_net_ms"], {k: v for k, v in b.items() if "us" in k}, "phases", r.get("phase_cycles"))
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
+for a in prof profdwo2; do
+  ERL_HIP_PROF_LIB=$L/liberl_hip_$a.so K6_LOOP=1 python tools/ppo_phase_profile.py > $O/phase_$a.txt 2>&1
+  grep -A14 "actor: total" $O/phase_$a.txt | cut -c1-120
+done
