@@ -149,6 +149,30 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the same split of k-step ks's four pairs spread over ALL SIX gaps, independent pairs side by side (round 6: one pair per gap was a
+    // chain of eleven dependent instructions behind each of four MFMAs and nothing behind the other two; second layer -0.3k cycles at
+    // [128,128], -0.37k at [128,64].  The GELU cut the same way -- four elements over two k-steps, twelve pieces -- measured +0.24k and is
+    // not kept: profiles/r06_k6_slice_ab.txt)
+    float ja[4], jb[4];
+    auto jit6 = [&](int ks, int gp) {
+        if (ks < NK) {
+            const f32x16 &t = inH[ks >> 1];
+            const int o = 8 * (ks & 1);
+            Parts &q = inP[ks];
+            auto P0 = [&](int j) { uint32_t h = pk_bf16(t[o + 2 * j], t[o + 2 * j + 1]); asm volatile("" : "+v"(h)); q.h[j] = h; };
+            auto P1 = [&](int j) { ja[j] = sub_bf_lo(t[o + 2 * j], q.h[j]); jb[j] = sub_bf_hi(t[o + 2 * j + 1], q.h[j]); asm volatile("" : "+v"(ja[j]), "+v"(jb[j])); };
+            auto P2 = [&](int j) { uint32_t mm = pk_bf16(ja[j], jb[j]); asm volatile("" : "+v"(mm)); q.m[j] = mm; };
+            auto P3 = [&](int j) { ja[j] = sub_bf_lo(ja[j], q.m[j]); jb[j] = sub_bf_hi(jb[j], q.m[j]); asm volatile("" : "+v"(ja[j]), "+v"(jb[j])); };
+            auto P4 = [&](int j) { uint32_t l = pk_bf16(ja[j], jb[j]); asm volatile("" : "+v"(l)); q.l[j] = l; };
+            if (gp == 0) { P0(0); P0(1); P0(2); P0(3); }
+            else if (gp == 1) { P1(0); P1(1); }
+            else if (gp == 2) { P1(2); P1(3); }
+            else if (gp == 3) { P2(0); P2(1); P2(2); P2(3); P3(0); }
+            else if (gp == 4) { P3(1); P3(2); }
+            else { P3(3); P4(0); P4(1); P4(2); P4(3); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll
     for (int s = 0; s < 4; ++s) jit(0, s);
     issue(0, aq[0]);
@@ -197,6 +221,7 @@ __device__ __forceinline__ void fwd_s3(const u8 *img, const float *bias, Parts (
             const Parts &a = aq[c & 1], &b = inP[ks];
             auto fill = [&](int s) {
                 if (To > 0) stage(To - 1, ks, s);
+                else if constexpr ((ERL_K6_SLICE & 1) != 0) jit6(ks + 1, s);
                 else jit(ks + 1, s);
             };
             acc = mfma_bf(a.m, b.m, acc);
@@ -278,6 +303,26 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    float ja[4], jb[4];
+    auto jit6 = [&](int ks, int gp) {                         // (fwd_s3's: the four pairs of a k-step spread over the gaps, side by side)
+        if (ks < NK) {
+            const f32x16 &t = dzH[ks >> 1];
+            const int o = 8 * (ks & 1);
+            Parts &q = dzP[ks];
+            auto P0 = [&](int j) { uint32_t h = pk_bf16(t[o + 2 * j], t[o + 2 * j + 1]); asm volatile("" : "+v"(h)); q.h[j] = h; };
+            auto P1 = [&](int j) { ja[j] = sub_bf_lo(t[o + 2 * j], q.h[j]); jb[j] = sub_bf_hi(t[o + 2 * j + 1], q.h[j]); asm volatile("" : "+v"(ja[j]), "+v"(jb[j])); };
+            auto P2 = [&](int j) { uint32_t mm = pk_bf16(ja[j], jb[j]); asm volatile("" : "+v"(mm)); q.m[j] = mm; };
+            auto P3 = [&](int j) { ja[j] = sub_bf_lo(ja[j], q.m[j]); jb[j] = sub_bf_hi(jb[j], q.m[j]); asm volatile("" : "+v"(ja[j]), "+v"(jb[j])); };
+            auto P4 = [&](int j) { uint32_t l = pk_bf16(ja[j], jb[j]); asm volatile("" : "+v"(l)); q.l[j] = l; };
+            // (this loop has five gaps: the last two MFMAs of a k-step are back to back)
+            if (gp == 0) { P0(0); P0(1); P0(2); P0(3); P1(0); }
+            else if (gp == 1) { P1(1); P1(2); }
+            else if (gp == 2) { P1(3); P2(0); P2(1); P2(2); P2(3); }
+            else if (gp == 3) { P3(0); P3(1); }
+            else { P3(2); P3(3); P4(0); P4(1); P4(2); P4(3); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     f32x16 prev, prev1;
     float v0[NPR], v1[NPR];
     uint32_t sh[NPR], sm[NPR];
@@ -325,6 +370,7 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
             const Parts &b = dzP[ks];
             auto fill = [&](int s) {
                 if (To > 0) gstage(To - 1, ks, s);
+                else if constexpr ((ERL_K6_SLICE & 1) != 0) jit6(ks + 1, s);
                 else jit(ks + 1, s);
             };
             acc = mfma_bf(a.m, b.m, acc);
@@ -343,6 +389,12 @@ __device__ __forceinline__ void bwd_s3(const u8 *img, Parts (&dzP)[NK], const f3
             __builtin_amdgcn_sched_barrier(0);
             fill(3);
             acc = mfma_bf(a.h, b.m, acc);
+            if constexpr ((ERL_K6_SLICE & 1) != 0) {
+                if (To == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    jit6(ks + 1, 4);
+                }
+            }
             acc1 = mfma_bf(a.h, b.h, acc1);
             __builtin_amdgcn_sched_barrier(0);
         }
