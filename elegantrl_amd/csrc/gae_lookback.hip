@@ -365,6 +365,166 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
     erl_span_out(g.span, t_span);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// TALL form (round 6): 64 <= H <= 256.  The look-back form cuts such a horizon into slabs of 32 steps and pays ~2 us per publish -> fetch hop
+// between workgroups (200 x 4096: 7 slabs, 8.7 us for 14.7 MB); one slab per 256 envs would leave 16 workgroups to move it.  Here ONE
+// workgroup owns the whole horizon of 32 envs: 256 threads = 32 time chunks x 8 lanes x 4 envs, a thread holds L = ceil(H / 32) steps of its
+// four envs in registers (16-byte loads, 128 contiguous bytes per row and array), folds them into the chunk's affine map, the 32 maps of an
+// env meet in LDS (a thread composes the later chunks' maps in time order, at most 31 of them), pass 2 replays from registers.  No tickets,
+// no granules, no wait: every byte is read once and all loads of the workgroup are in flight together; N / 32 workgroups (128 at N = 4096).
+// Same arithmetic per step and the same composition rule as the look-back kernel (tolerance class: time-parallel, <= 1e-5 max(1, |ref|)).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int TALL_CHUNKS = 32, TALL_LANES = 8;
+template <int L, bool STATS, bool NT>
+__global__ __launch_bounds__(TALL_CHUNKS * TALL_LANES) void gae_tall_kernel(LbArgs g)
+{
+    __shared__ float2 s_agg[TALL_CHUNKS][TALL_LANES * 4];
+    __shared__ double s_red[3][TALL_CHUNKS * TALL_LANES / 64];
+
+    const unsigned long long t_span = erl_span_in(g.span);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = threadIdx.x / TALL_LANES, el = threadIdx.x % TALL_LANES;      // chunk 0 is the latest in time
+    const int n0 = blockIdx.x * (TALL_LANES * 4) + el * 4;
+    const bool live = n0 < g.N;
+    const int t_top = g.H - c * L - 1;                                 // this thread's latest step; steps t_top - j
+    const size_t N = (size_t)g.N;
+    const float gl = g.gamma * g.lam;
+
+    float4 r[L], v[L];
+    uint32_t ud4[L], um4[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int t = t_top - j;
+        if (live && t >= 0) {
+            const size_t i = (size_t)t * N + n0;
+            if constexpr (NT) {       // streaming loads for a large scan's single-use inputs (see gae_lookback_kernel)
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                const nt_f4 r_ = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(g.rewards + i));
+                const nt_f4 v_ = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(g.values + i));
+                r[j] = make_float4(r_.x, r_.y, r_.z, r_.w);
+                v[j] = make_float4(v_.x, v_.y, v_.z, v_.w);
+                ud4[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(g.undones + i));
+                um4[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(g.unmasks + i));
+            } else {
+                r[j] = *reinterpret_cast<const float4 *>(g.rewards + i);
+                v[j] = *reinterpret_cast<const float4 *>(g.values + i);
+                ud4[j] = *reinterpret_cast<const uint32_t *>(g.undones + i);
+                um4[j] = *reinterpret_cast<const uint32_t *>(g.unmasks + i);
+            }
+        } else {
+            r[j] = v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ud4[j] = 0u;
+            um4[j] = 0x01010101u;
+        }
+    }
+    float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);                      // value following the chunk's latest step
+    if (live && t_top >= 0) {
+        if (t_top + 1 == g.H) { if (g.vtrace) vn = *reinterpret_cast<const float4 *>(g.next_value + n0); }
+        else vn = *reinterpret_cast<const float4 *>(g.values + (size_t)(t_top + 1) * N + n0);
+    }
+
+    // ---- pass 1: chunk -> affine map (A, P); r[j] <- delta, cmask bit <- "chain continues"  (gae_lookback_kernel's, step for step)
+    float A[4] = {0.f, 0.f, 0.f, 0.f}, P[4] = {1.f, 1.f, 1.f, 1.f};
+    float vnext[4] = {vn.x, vn.y, vn.z, vn.w};
+    uint32_t cmask[(L * 4 + 31) / 32];
+#pragma unroll
+    for (int q = 0; q < (L * 4 + 31) / 32; ++q) cmask[q] = 0u;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const float ro[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        float dl[4];
+        bool fix = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bool ud = ((ud4[j] >> (8 * e)) & 0xFFu) != 0u;
+            const bool um = ((um4[j] >> (8 * e)) & 0xFFu) != 0u;
+            float rr = ro[e];
+            if (!um) {  // truncated: bootstrap with V(s_t) and cut the chain (AgentPPO.py:211-214)
+                rr += vv[e];
+                ud = false;
+                fix = true;
+            }
+            const float m = ud ? g.gamma : 0.f, cc = ud ? gl : 0.f;
+            dl[e] = (rr + m * vnext[e]) - vv[e];
+            A[e] = dl[e] + cc * A[e];
+            P[e] = cc * P[e];
+            vnext[e] = vv[e];
+            if (ud) cmask[(j * 4 + e) >> 5] |= 1u << ((j * 4 + e) & 31);
+        }
+        if (fix && g.mutate && live && t_top - j >= 0) {   // rare (truncations): write the fix-up back like the reference does to its caller
+            const size_t i = (size_t)(t_top - j) * N + n0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (((um4[j] >> (8 * e)) & 0xFFu) == 0u) {
+                    g.rewards[i + e] = ro[e] + vv[e];
+                    g.undones[i + e] = 0;
+                }
+        }
+        r[j] = make_float4(dl[0], dl[1], dl[2], dl[3]);   // pass 2 only needs delta
+    }
+
+    // ---- the chunks' maps meet in LDS; this thread's incoming value = the later chunks 0 .. c-1 composed in time order on a zero carry
+    {
+        float4 *dst = reinterpret_cast<float4 *>(&s_agg[c][el * 4]);
+        dst[0] = make_float4(A[0], P[0], A[1], P[1]);
+        dst[1] = make_float4(A[2], P[2], A[3], P[3]);
+    }
+    __syncthreads();
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < c; ++u) {
+        const float4 *src = reinterpret_cast<const float4 *>(&s_agg[u][el * 4]);
+        const float4 x = src[0], y = src[1];
+        const float a_[4] = {x.x, x.z, y.x, y.z}, p_[4] = {x.y, x.w, y.y, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = a_[e] + p_[e] * a[e];
+    }
+
+    // ---- pass 2: replay from registers
+    double s_all = 0, s_sub = 0, q_sub = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int t = t_top - j;
+        const float dd[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool cont = (cmask[(j * 4 + e) >> 5] >> ((j * 4 + e) & 31)) & 1u;
+            a[e] = dd[e] + (cont ? gl : 0.f) * a[e];
+            o[e] = a[e];
+        }
+        if (live && t >= 0) {
+            const size_t i = (size_t)t * N + n0;
+            *reinterpret_cast<float4 *>(g.adv + i) = make_float4(o[0], o[1], o[2], o[3]);
+            if (g.ret)
+                *reinterpret_cast<float4 *>(g.ret + i) = make_float4(o[0] + vv[0], o[1] + vv[1], o[2] + vv[2], o[3] + vv[3]);
+            if (STATS) {
+                s_all += ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
+                if ((t & 3) == 0) {   // n0 is a multiple of 4: env n0 is the only [::4] column of this lane
+                    s_sub += o[0];
+                    q_sub += (double)o[0] * o[0];
+                }
+            }
+        }
+    }
+    if (STATS) {
+        const double w0 = wave_sum(s_all), w1 = wave_sum(s_sub), w2 = wave_sum(q_sub);
+        if (lane == 0) {
+            s_red[0][w] = w0;
+            s_red[1][w] = w1;
+            s_red[2][w] = w2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double sum = 0;
+            for (int u = 0; u < TALL_CHUNKS * TALL_LANES / 64; ++u) sum += s_red[threadIdx.x][u];
+            g.partials[(size_t)blockIdx.x * 3 + threadIdx.x] = sum;
+        }
+    }
+    erl_span_out(g.span, t_span);
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *s = getenv(name);
@@ -431,6 +591,38 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
                             bool vtrace, bool mutate, bool want_stats, void *workspace, int64_t workspace_bytes,
                             double **partials, int *nparts, hipStream_t stream)
 {
+    // 64 <= H <= 256: one workgroup per 32 envs holds the whole horizon (gae_tall_kernel; at 512 x 4096 it only draws with the slabs: 13.1 vs
+    // 13.0 us, profiles/r06_gae_tall_sweep.txt); ERL_GAE_TALL=0, or a forced look-back tiling, keeps slabs
+    if (H >= 64 && H <= 8 * TALL_CHUNKS && env_int("ERL_GAE_TALL", 1) && !getenv("ERL_GAE_LB_L") && !getenv("ERL_GAE_LB_W") &&
+        !env_int("ERL_GAE_LB_FAULT", 0) && !env_int("ERL_GAE_LB_DELAY", 0)) {
+        const int64_t nb = erl_cdiv(N, TALL_LANES * 4);
+        ERL_REQUIRE(nb < (1LL << 30), "erl_gae_scan_f32: grid too large");
+        ERL_REQUIRE(256 + nb * 24 <= workspace_bytes, "erl_gae_scan_f32: workspace too small for the one-workgroup scan");
+        LbArgs g{};
+        g.rewards = rewards; g.undones = undones; g.unmasks = unmasks; g.values = values; g.next_value = next_value;
+        g.adv = adv; g.ret = ret;
+        g.H = (int)H; g.N = (int)N; g.G = (int)nb; g.K = 1;
+        g.gamma = gamma; g.lam = lam; g.vtrace = vtrace; g.mutate = mutate;
+        g.partials = (double *)((char *)workspace + 256);
+        g.span = erl_span_slot(ERL_SPAN_GAE, nb);
+        *partials = g.partials;
+        *nparts = (int)nb;
+        const int Lt = (int)erl_cdiv(H, TALL_CHUNKS);
+        const dim3 grid((unsigned)nb), block(TALL_CHUNKS * TALL_LANES);
+        const bool nt = env_int("ERL_GAE_NT", 18 * H * N >= (32LL << 20) ? 1 : 0) != 0;
+#define TALL_LAUNCH(LL)                                                                                         \
+    do {                                                                                                        \
+        if (want_stats && nt) hipLaunchKernelGGL((gae_tall_kernel<LL, true, true>), grid, block, 0, stream, g);  \
+        else if (want_stats) hipLaunchKernelGGL((gae_tall_kernel<LL, true, false>), grid, block, 0, stream, g);  \
+        else if (nt) hipLaunchKernelGGL((gae_tall_kernel<LL, false, true>), grid, block, 0, stream, g);          \
+        else hipLaunchKernelGGL((gae_tall_kernel<LL, false, false>), grid, block, 0, stream, g);                 \
+    } while (0)
+        if (Lt <= 2) TALL_LAUNCH(2);
+        else if (Lt <= 4) TALL_LAUNCH(4);
+        else TALL_LAUNCH(8);
+#undef TALL_LAUNCH
+        return erl_hip_status(hipGetLastError(), "gae_tall_kernel launch");
+    }
     int L, W;
     erl_gae_lookback_pick(H, N, &L, &W);
     const int64_t T = (int64_t)L * W;

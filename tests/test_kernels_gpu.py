@@ -114,6 +114,33 @@ def test_gae_lookback_within_1e5(ops, dev, H, N, vtrace):
     np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("H,N", [(64, 36), (100, 44), (255, 260), (256, 4100), (129, 32), (200, 4096)])
+def test_gae_one_workgroup_per_32_envs_against_c_oracle(ops, dev, H, N, monkeypatch):
+    """64 <= H <= 256 (round 6: gae_tall_kernel -- a workgroup holds the whole horizon of 32 envs, 32 time chunks composed in LDS): ragged env
+    groups, horizons that do not fill the last chunk, long undone chains so that the carry crosses every chunk, the statistics partials, the
+    in-place truncation fix-up; and the slab form (ERL_GAE_TALL=0) on the same inputs, which must agree within the same bar."""
+    r, u, m, v, nv = gae_inputs(H, N, seed=H * 3 + N, p_done=0.002, p_trunc=0.002)
+    adv_o, ret_o, r_o, u_o = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=True)
+    for tall in ("1", "0"):
+        monkeypatch.setenv("ERL_GAE_TALL", tall)
+        tr, tu = cu(r, dev), cu(u, dev)
+        stats = th.zeros(8, dtype=th.float64, device=dev)
+        adv, ret = ops.gae_scan(tr, tu, cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, use_v_trace=True, algo="lookback", stats=stats)
+        adv_np = adv.cpu().numpy()
+        rel_close(adv_np, adv_o, 1e-5)
+        rel_close(ret.cpu().numpy(), ret_o, 1e-5)
+        np.testing.assert_array_equal(tu.cpu().numpy(), u_o)
+        np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
+        s_, sub = stats.cpu().numpy(), adv_np[::4, ::4].astype(np.float64)
+        np.testing.assert_allclose(s_[0], adv_np.astype(np.float64).sum(), rtol=1e-9, atol=1e-6)
+        assert s_[1] == H * N and s_[4] == sub.size
+        np.testing.assert_allclose(s_[2], sub.sum(), rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(s_[3], (sub * sub).sum(), rtol=1e-9)
+    th.cuda.synchronize()
+    from elegantrl_amd import _hip
+    _hip.check_async_faults()
+
+
 @pytest.mark.parametrize("H,N", [(2048, 4096), (200, 4096), (32, 32768)], ids=["baseline-2048x4096", "config2-200x4096", "32x32768"])
 @pytest.mark.parametrize("vtrace", [True, False])
 def test_gae_lookback_at_baseline_sizes_against_c_oracle(ops, dev, H, N, vtrace):
