@@ -1149,6 +1149,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     SPAN_STAMP(sps, 6);                                              // phase 5: dW2, db2 (+ H2^T); phase 6 = dW3, db3, logs, store drain
     PROF(13);
     dw3();
+    PROF_NV(14);
 #else
     // order dW1, dW2, dW3 (round 6): the 64 KB of dW2 -- two thirds of a workgroup's slab -- leave by write-through stores while dW3 is
     // still computing, and the kernel ends behind the 4 KB of dW3 instead of behind the drain of 256 x 64 KB; H2 waits in registers
@@ -1201,6 +1202,9 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
             for (int64_t e = g.Pa + g.Pc + 4; e < g.stride; ++e) logs[e - (g.Pa + g.Pc)] = 0.f;
         }
     }
+#if ERL_K6_DW_ORDER == 2
+    PROF_NV(15);
+#endif
 #if ERL_K6_EXP & 4
     // (experiment) the critic's workgroups finish ~5k cycles before the actor's: pull the NEXT minibatch's rows of this slab towards this
     // XCD's L2 (the actor's workgroup of the same slab index sits on the same XCD: 128 % 8 == 0), where the next launch's prologue finds them

@@ -90,14 +90,19 @@ def main():
         for net, nm in enumerate(("actor", "critic")):
             w = full[net, :4].double()
             print(f"--- {nm}: fine stamps (cycles since entry): " + ", ".join(f"{v} {float((w[:, k] - w[:, 0]).mean()):.0f}" for k, v in fn.items()))
-    p = full[:, :, :NP]
+    names, NPk = NAMES, NP
+    if int(full[0, 0, 15]) != 0:                      # weight-gradient order 2 (round 6 default): the stamps 9..15 bracket other work
+        names = NAMES[:9] + ["A operand of dW1 (dZ1^T rows) + barrier2b", "dW1 + db1 (the dZ2 image rides)", "barrier3 + A operand of dW2 + stage H1 half + barrier4",
+                             "dW2 + db2 (H2^T rides; barriers 5, 6)", "dW3 + db3", "loss reduce + logs"]
+        NPk = 16
+    p = full[:, :, :NPk]
     p = p[:, (p[0, :, 0] != 0)]                        # the 4-wave form stamps waves 0..3 only
     print(f"{p.shape[1]} waves per workgroup")
     for net, name in enumerate(("actor", "critic")):
         d = (p[net, :, 1:] - p[net, :, :-1]).double()
-        tot = (p[net, :, NP - 1] - p[net, :, 0]).double()
+        tot = (p[net, :, NPk - 1] - p[net, :, 0]).double()
         print(f"--- {name}: total cycles per wave min/mean/max = {tot.min():.0f} / {tot.mean():.0f} / {tot.max():.0f}")
-        for i, nm in enumerate(NAMES[:NP - 1]):
+        for i, nm in enumerate(names[:NPk - 1]):
             print(f"  {nm:36s} mean {d[:, i].mean():9.0f}  min {d[:, i].min():9.0f}  max {d[:, i].max():9.0f}  ({100 * d[:, i].mean() / tot.mean():5.1f} %)")
 
 

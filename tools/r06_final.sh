@@ -29,6 +29,8 @@ PMC_KEEP_TEMPLATE=1 python tools/pmc_summarise.py $O/r06_c3_pmc_by_pass.json $(f
 python tools/pmc_summarise.py $O/r06_c3_pmc.json $(find $O/pmc_c3_* -name "*counter_collection.csv") > $O/pmc_c3.txt 2>&1
 python tools/kstats_summarise.py $O/r06_kernel_times.json $O/c4_kernel_stats.csv "python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep --no-smi --repeats 0" > $O/kernel_times.txt 2>&1
 rm -rf $O/prof_c4 $O/prof_cd $O/prof_c3 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_c3_*
+ERL_HIP_PROF_LIB=$GRAFT_REPO_ROOT/elegantrl_amd/lib/liberl_hip_prof.so K6_LOOP=1 python tools/ppo_phase_profile.py > $O/k6_phase_c4.txt 2>&1
+ERL_HIP_PROF_LIB=$GRAFT_REPO_ROOT/elegantrl_amd/lib/liberl_hip_prof.so K6_LOOP=1 K6_SHAPE=3,128,64,1 python tools/ppo_phase_profile.py > $O/k6_phase_c2.txt 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -3 $O/pytest_gpu.log
 python - <<PY
