@@ -78,6 +78,9 @@ __device__ __forceinline__ void slab_store_as(float v, float *p)
     else if (POLICY == 2) { }                       // (diagnostics, -DERL_K6_EXP & 32: the store left out -- is the kernel's end the drain of its stores?)
     else slab_store(v, p);
 }
+#ifndef ERL_K6_EARLY_LOGS
+#define ERL_K6_EARLY_LOGS 1      // s3: the logged sums' wave parts formed at the objective, not behind four barriers at the kernel's end (round 6)
+#endif
 #ifndef ERL_K6_SLICE
 #define ERL_K6_SLICE 1           // s3 forward / backward: a k-step's operand split spread over all of its MFMA gaps, independent pairs side by side (round 6)
 #endif

@@ -1099,15 +1099,35 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
             u8 *dst = zb + 16 * ((2 * ks + hi) ^ zsw) + pl * (16 * CPH2);
             *reinterpret_cast<u32x4 *>(dst) = pl == 0 ? dZ2p[ks].h : pl == 1 ? dZ2p[ks].m : dZ2p[ks].l;
         };
+        // the logged sums' per-wave parts (block_sum's first half: the wave butterfly, one hop per k-step, behind MFMA 3 or 4; its scratch is
+        // free until the kernel's end): the four parts are added at the end in block_sum's order -- the same bits -- without its two butterflies
+        // and four barriers there, where every cycle is on the critical path (round 6: -1.9k cycles at the end)
+        float lw0 = loss0, lw1 = loss1;
+        auto logs_hop = [&](int hop) {
+            if (hop < 6) {
+                lw0 += __shfl_xor(lw0, 32 >> hop, 64);
+                lw1 += __shfl_xor(lw1, 32 >> hop, 64);
+            } else if (hop == 6 && lane == 0) {
+                s_red[wave] = lw0;
+                s_red[QNW + wave] = lw1;
+            }
+        };
         if (jc < KX) {
             auto side = [&](int c, int sl) {
                 if (sl < PPK && PPK * c + sl < NP) piece(PPK * c + sl);
+                if constexpr (ERL_K6_EARLY_LOGS) {
+                    if (sl == (PPK < 4 ? 3 : 4) && c < 7) logs_hop(c);
+                }
             };
             grad_tiles<CP1, NBW1, CS1, 0, 0>(A, SB, it, jc, 0, slab + d.oW1(), S, S, lane, side);
             if (jc == 0) grad_bias(A, slab + d.ob1(), it, lane);
         } else {
 #pragma unroll
             for (int i = 0; i < NP; ++i) piece(i);
+            if constexpr (ERL_K6_EARLY_LOGS) {
+#pragma unroll
+                for (int hop = 0; hop < 7; ++hop) logs_hop(hop);
+            }
         }
     }
     PROF(11);
@@ -1187,8 +1207,17 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
 #endif
 
     // ---- objective partial sums (scaled by 1/B so that the slab reduction yields the means)
-    const float t0 = block_sum(loss0, s_red);
-    const float t1 = block_sum(loss1, s_red);
+    float t0, t1;
+    if constexpr (ERL_K6_EARLY_LOGS && ERL_K6_DW_ORDER == 2) {
+        t0 = 0.f; t1 = 0.f;
+        if (tid == 0) {                                   // (visible since barrier (1))
+#pragma unroll
+            for (int w = 0; w < QNW; ++w) { t0 += s_red[w]; t1 += s_red[QNW + w]; }
+        }
+    } else {
+        t0 = block_sum(loss0, s_red);
+        t1 = block_sum(loss1, s_red);
+    }
     if (tid == 0) {
         float *logs = g.slabs + (size_t)slab_ix * g.stride + g.Pa + g.Pc;
         if (ACTOR) {
