@@ -75,7 +75,7 @@ template <int POLICY>
 __device__ __forceinline__ void slab_store_as(float v, float *p)
 {
     if (POLICY == 1) *p = v;
-    else if (POLICY == 2) { }                       // (diagnostics, -DERL_K6_EXP & 32: the store left out -- is the kernel's end the drain of its stores?)
+    else if (POLICY == 2) slab_store(v, p);         // (diagnostics, -DERL_K6_EXP & 32: the caller guards it with a condition that is never true at run time)
     else slab_store(v, p);
 }
 #ifndef ERL_K6_EARLY_LOGS

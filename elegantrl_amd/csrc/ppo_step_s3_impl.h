@@ -478,7 +478,7 @@ __device__ __forceinline__ void grad_tiles(const Parts (&A)[8], const u8 *SB, in
     tb.issue(jc, 0, rq[0]);
     auto store = [&](const f32x16 &t, int k, auto pol) {
         const int i = 32 * (jt_store0 + jc + CS * k) + l31;
-        if (i < cols_real) {
+        if (i < cols_real && (decltype(pol)::value != 2 || reinterpret_cast<uintptr_t>(dW) == 1)) {      // (policy 2, diagnostics: computed, never stored)
             float *o = dW + (size_t)(32 * it + 4 * hi) * ldw + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) slab_store_as<decltype(pol)::value>(t[r], o + (size_t)((r & 3) + 8 * (r >> 2)) * ldw);
@@ -1009,20 +1009,37 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
         }
     };
     // ---- output layer: dW3 (16 x h2) = dY^T . H2 on 16x16x4 fp32 MFMA (H2^T staged feature-major in fp32), db3, dstd_log
-    auto dw3 = [&]() {
+    // its operands -- the wave's rows of dY^T and of H2^T, 8 + 8 NR3 reads of 16 bytes -- are all requested up front by dw3_load(), so that the
+    // phase at the kernel's end does not wait for the LDS every eight MFMAs (round 6: -0.2k cycles; requested one phase earlier, in front
+    // of db2's MFMAs, they cost dW2's phase what they saved here: profiles/r06_k6_dw3_preload_ab.txt)
+    constexpr int NR3 = (2 * N2 + QNW - 1) / QNW;
+    float4 d3a[PB / 16], d3b[NR3][PB / 16];
+    auto dw3_load = [&]() {
         const float *T2 = reinterpret_cast<const float *>(SA);
+        const int l15 = lane & 15, q = lane >> 4;
+        const float *a = RC + l15 * PLD + 4 * q;
+#pragma unroll
+        for (int j = 0; j < PB / 16; ++j) d3a[j] = *reinterpret_cast<const float4 *>(a + 16 * j);
+#pragma unroll
+        for (int rep = 0; rep < NR3; ++rep) {
+            const int it = min(wave + QNW * rep, 2 * N2 - 1);
+            const float *b = T2 + (16 * it + l15) * PLD + 4 * q;
+#pragma unroll
+            for (int j = 0; j < PB / 16; ++j) d3b[rep][j] = *reinterpret_cast<const float4 *>(b + 16 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto dw3 = [&]() {
         const int l15 = lane & 15, q = lane >> 4;
         f32x2 hs = {0.f, 0.f};
 #pragma unroll
-        for (int rep = 0; rep < (2 * N2 + QNW - 1) / QNW; ++rep) {
+        for (int rep = 0; rep < NR3; ++rep) {
             const int it = wave + QNW * rep;                            // 16-column tile of dW3 (wave-uniform)
             if (it >= 2 * N2) break;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float *a = RC + l15 * PLD + 4 * q;
-            const float *b = T2 + (16 * it + l15) * PLD + 4 * q;
 #pragma unroll
             for (int j = 0; j < PB / 16; ++j) {
-                const float4 av = *reinterpret_cast<const float4 *>(a + 16 * j), bv = *reinterpret_cast<const float4 *>(b + 16 * j);
+                const float4 av = d3a[j], bv = d3b[rep][j];
                 acc = mfma16(av.x, bv.x, acc);
                 acc = mfma16(av.y, bv.y, acc);
                 acc = mfma16(av.z, bv.z, acc);
@@ -1052,6 +1069,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     stage_s3<KSH, CPB2, 0>(SB, H1p, col, hi);
     lds_barrier();                                                   // (4)
     PROF(11);
+    dw3_load();
     dw3();
     lds_barrier();                                                   // (5) H2^T consumed
     stage_s3<2 * N2, CPH2, 0>(SA, dZ2p, col, hi);
@@ -1163,11 +1181,12 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
             lds_barrier();                                           // (6)
             grad_tiles<CPB2, NBW, CS, PW2, PW2>(A, SB, it, jc, TPP, slab + d.oW2(), h1, h1, lane);
         }
-        if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
         if (NH1 != 2) lds_barrier();                                 // (5) H2^T written
+        if (jc == 0) grad_bias(A, slab + d.ob2(), it, lane);
     }
     SPAN_STAMP(sps, 6);                                              // phase 5: dW2, db2 (+ H2^T); phase 6 = dW3, db3, logs, store drain
     PROF(13);
+    dw3_load();
     dw3();
     PROF_NV(14);
 #else
@@ -1202,6 +1221,7 @@ __device__ __forceinline__ void ppo_block_s3(const Ppo2Args &g, u8 *smem, SpanSt
     }
     SPAN_STAMP(sps, 6);                                              // phase 5: staging + dW2, db2; phase 6 = dW3, db3, logs, store drain
     PROF(12);
+    dw3_load();
     dw3();
     PROF(13);
 #endif

@@ -1,5 +1,5 @@
 #!/bin/bash
-# K6: the logged sums' wave parts at the objective instead of two block_sums at the kernel's end (ERL_K6_EARLY_LOGS): tests, el0 / main alternating
+# K6 A/B of one compile-time switch: the named variant library against main, alternating (tests on main first)
 O=$GRAFT_REPO_ROOT/gpurun_out/r06_o; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 export ERL_QUIET=1
@@ -8,7 +8,7 @@ timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py -
 tail -3 $O/pytest_main.log
 for cfg in c4 c2; do
   for rep in 0 1 2; do
-    for a in el0 main; do
+    for a in d3p0 main; do
       lib=$L/liberl_hip.so; [ $a != main ] && lib=$L/liberl_hip_$a.so
       ERL_HIP_LIB=$lib timeout 300 python bench.py --config $cfg --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gae-sweep --no-smi --repeats 3 > $O/${cfg}_${a}_$rep.json 2> $O/${cfg}_${a}_$rep.err
     done
