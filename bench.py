@@ -928,7 +928,7 @@ def main():
                    "note": "shader_mhz_in_k6 = sum over workgroups of (s_memtime exit - entry) / (constant-rate clock exit - entry) x its rate, on the "
                            "sampled minibatch-kernel launches of the timed region; smi = rocm-smi / amd-smi right after the region"},
         "breakdown": breakdown,
-        "roofline_gae": ({"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
+        "roofline_gae": ({"kernel": f"{'gae_exact_kernel' if HORIZON < 64 else 'gae_tall_kernel' if HORIZON <= 256 else 'gae_lookback_kernel'} (in-loop {HORIZON}x{N_ENVS})",
                           "bound": "hbm",
                           "achieved": round(18.0 * HORIZON * N_ENVS / gae_k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": round(18.0 * HORIZON * N_ENVS / gae_k_s / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,

@@ -69,9 +69,10 @@ ERL_API int erl_device_info(int *num_cu, int *lds_bytes_per_block);
 #define ERL_GAE_ALGO_AUTO 0x00
 #define ERL_GAE_ALGO_EXACT 0x10    /* one thread per env, reference op order, bit-exact vs the oracle */
 #define ERL_GAE_ALGO_CHUNKED 0x20  /* time-parallel two-pass affine scan (within 1e-5) */
-#define ERL_GAE_ALGO_LOOKBACK 0x30 /* time-parallel single-pass scan, decoupled look-back (within 1e-5); its granule table
-                                      lives in a library-owned buffer (nonce-tagged, never cleared) when it fits, else in
-                                      `workspace` behind a memset */
+#define ERL_GAE_ALGO_LOOKBACK 0x30 /* time-parallel single-pass scan (within 1e-5).  64 <= H <= 256: one workgroup per 32 envs
+                                      holds the whole horizon, its 32 time chunks meet in LDS (no table, no waits); otherwise
+                                      decoupled look-back over slabs, whose granule table lives in a library-owned buffer
+                                      (nonce-tagged, never cleared) when it fits, else in `workspace` behind a memset */
 #define ERL_GAE_ALGO_MASK 0xF0
 ERL_API int64_t erl_gae_workspace_bytes(int64_t H, int64_t N);
 ERL_API int erl_gae_scan_f32(float *rewards, uint8_t *undones, const uint8_t *unmasks, const float *values,
