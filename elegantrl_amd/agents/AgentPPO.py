@@ -187,6 +187,10 @@ class AgentPPO(AgentBase):
         # args.fused_gae = False / ERL_FUSED_GAE=0 keeps them in update_net (A/B runs, parity tests)
         import os as _os
         self.fused_gae = bool(getattr(args, "fused_gae", _os.environ.get("ERL_FUSED_GAE", "1") != "0"))
+        # left to itself the epilogue serves horizons up to 128 steps (its inputs wait in LDS); beyond, a 16-env workgroup walking its
+        # steps back from memory costs more than the scan kernels do (200 x 4096: explore_env +33 us against +25 us in update_net:
+        # profiles/r06_c2_fused_gae_ab.txt), so longer horizons take them unless args.fused_gae / ERL_FUSED_GAE says otherwise
+        self._fused_gae_explicit = hasattr(args, "fused_gae") or "ERL_FUSED_GAE" in _os.environ
         self._last_state_token = None
         self.ppo_arith = str(getattr(args, "ppo_arith", "auto"))
         assert self.ppo_arith in ("auto", "f32", "split"), f"args.ppo_arith = {self.ppo_arith!r}"
@@ -352,7 +356,8 @@ class AgentPPO(AgentBase):
         hn = H * N
         pitch = (hn + 255) // 256 * 256                    # every plane starts on a 256-byte boundary whatever H * N is
         # planes: logprobs | rewards | values [| raw advantages | reward sums: the fused rollout's epilogue]
-        planes = th.empty((5 if getattr(self, "fused_gae", False) else 3, pitch), dtype=th.float32, device=dev)
+        fused_gae = bool(getattr(self, "fused_gae", False)) and (getattr(self, "_fused_gae_explicit", True) or H <= 128)
+        planes = th.empty((5 if fused_gae else 3, pitch), dtype=th.float32, device=dev)
         logprobs, rewards = planes[0, :hn].view(H, N), planes[1, :hn].view(H, N)
         flags = th.empty((2, pitch), dtype=th.bool, device=dev)
         terminals, truncates = flags[0, :hn].view(H, N), flags[1, :hn].view(H, N)
@@ -389,14 +394,14 @@ class AgentPPO(AgentBase):
             noise = None if noise is None else noise.contiguous()
             epilogue, adv_raw, ret, stats = None, None, None, None
             last_out = th.empty((N, S), dtype=th.float32, device=dev) if self.snapshot_last_state else None
-            if self.fused_gae:
+            if fused_gae:
                 adv_raw, ret = planes[3, :hn].view(H, N), planes[4, :hn].view(H, N)
                 # [8 doubles: the folded sums | 3 per 16-env workgroup: the epilogue's partial sums]
                 n_parts = int(_hip.lib().erl_rollout_gae_partials(N))
                 sums = th.empty(8 + 3 * n_parts, dtype=th.float64, device=dev)
                 stats, gae_parts = sums[:8], sums[8:]
-            if last_out is not None or self.fused_gae:
-                epilogue = (last_out, adv_raw, ret, None, gae_parts if self.fused_gae else None, float(self.gamma),
+            if last_out is not None or fused_gae:
+                epilogue = (last_out, adv_raw, ret, None, gae_parts if fused_gae else None, float(self.gamma),
                             float(self.lambda_gae_adv), bool(self.if_use_v_trace))
             env.fused_rollout(self, H, noise, (states, actions, logprobs, rewards, undones, unmasks), values, next_value,
                               **({} if epilogue is None else {"epilogue": epilogue}))
@@ -409,7 +414,7 @@ class AgentPPO(AgentBase):
                 self._last_state_token = (last_out, last_out._version, env, getattr(env, "state_epoch", None), (id(env.state), env.state._version))
             self._rollout_cache = dict(states=states, values=values, next_value=next_value, last_state=self.last_state,
                                        key=self._value_cache_key(states, self.last_state))
-            if self.fused_gae:
+            if fused_gae:
                 self._rollout_cache.update(adv=adv_raw, ret=ret, stats=stats, parts=gae_parts, n_parts=n_parts, rewards=rewards,
                                            undones=undones, unmasks=unmasks, adv_key=self._adv_cache_key(rewards, undones, unmasks))
             return states, actions, logprobs, rewards, undones, unmasks

@@ -44,6 +44,7 @@ CASES = [
     ("syn", 8192, 64, 8, (128, 128), 1000, 8, 1.0),        # config-5 env count: two workgroup rounds per CU
     ("pendulum", 4096, 3, 1, (128, 64), 16, 40, 0.25),     # config 2 (Pendulum, net [128, 64]), truncation resets
     ("pendulum", 100, 3, 1, (64, 64), 200, 10, 1.0),
+    ("pendulum", 64, 3, 1, (128, 64), 50, 130, 1.0),       # horizon > 128: the epilogue reads its inputs back from the buffers (args.fused_gae forced on)
 ]
 
 
@@ -149,6 +150,7 @@ def test_rollout_epilogue_is_the_exact_gae_scan(kind, N, S, A, net, max_step, H,
     from elegantrl_amd import ops
     agent, env, _ = _make(kind, N, S, A, net, max_step, True, scale)
     agent.if_use_v_trace = vtrace
+    agent._fused_gae_explicit = True                       # (as args.fused_gae = True: beyond 128 steps the default leaves get_advantages to the scan kernels)
     for it in range(2):
         items = agent._explore_vec_env(env, H)
         states, actions, logprobs, rewards, undones, unmasks = items
@@ -168,6 +170,19 @@ def test_rollout_epilogue_is_the_exact_gae_scan(kind, N, S, A, net, max_step, H,
         assert folded[5:].abs().sum().item() == 0
         if max_step < H:
             assert (~unmasks).any()
+
+
+def test_the_epilogue_is_left_out_beyond_128_steps_unless_asked_for():
+    """default: horizons above 128 steps leave get_advantages to the scan kernels (cheaper there: profiles/r06_c2_fused_gae_ab.txt);
+    args.fused_gae = True keeps the epilogue at any horizon."""
+    agent, env, _ = _make("pendulum", 64, 3, 1, (128, 64), 50, True)
+    agent._explore_vec_env(env, 130)
+    assert agent._rollout_cache is not None and "adv" not in agent._rollout_cache
+    agent._explore_vec_env(env, 128)
+    assert "adv" in agent._rollout_cache
+    agent._fused_gae_explicit = True
+    agent._explore_vec_env(env, 130)
+    assert "adv" in agent._rollout_cache
 
 
 def test_update_net_with_the_rollout_epilogue_matches_the_separate_launches():
