@@ -409,16 +409,15 @@ struct ActorFwdArgs {
 };
 
 template <int C0, int C1>
-__global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
+__device__ __forceinline__ void actor_fwd_body(const ActorFwdArgs &g, TileLds &lds, const int bx, const int by)
 {
-    __shared__ TileLds lds;
     const LaneId L = lane_id();
     const FusedDims &d = g.d;
-    const int64_t row0 = (int64_t)blockIdx.x * TS, row = row0 + L.l15;
+    const int64_t row0 = (int64_t)bx * TS, row = row0 + L.l15;
     const bool valid = row < d.B;
-    const int64_t fo = (int64_t)blockIdx.y * d.h1;                   // first second-layer feature of this workgroup's slice (0 unsplit)
+    const int64_t fo = (int64_t)by * d.h1;                   // first second-layer feature of this workgroup's slice (0 unsplit)
     const int h1f = g.split > 1 ? g.h1_full : d.h1;
-    if (g.alpha0 && blockIdx.x == 0 && blockIdx.y == 0 && L.tid == 0) g.alpha0[0] = g.alpha_log[0];
+    if (g.alpha0 && bx == 0 && by == 0 && L.tid == 0) g.alpha0[0] = g.alpha_log[0];
     FPROF(0, 0);
     // every weight this wave will use, requested before anything else
     FwdW<4, WClass<C0>::NU> w1;
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
         const int64_t b = row0 + L.tid, id = g.rg.ids[min(b, d.B - 1)];
         const int64_t n = id / g.rg.sample_len, t = id - n * g.rg.sample_len;
         s_row[L.tid] = g.rg.row_floats ? n * g.rg.max_size + t : t * g.rg.num_seqs + n;     // (interleaved ring: sequence-major rows)
-        if (blockIdx.y == 0 && b < d.B && !g.rg_self) {
+        if (by == 0 && b < d.B && !g.rg_self) {
             if (g.rg.out_ids0) g.rg.out_ids0[b] = t;
             if (g.rg.out_ids1) g.rg.out_ids1[b] = n;
         }
@@ -449,11 +448,11 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
             if (b < d.B && c < S) {
                 const int64_t nx = g.rg_self ? 0 : 1;           // the next state: the following row of the same sequence
                 v = g.rg.row_floats ? g.rg.buf_states[(s_row[s_] + nx) * g.rg.row_floats + c] : g.rg.buf_states[(s_row[s_] + nx * g.rg.num_seqs) * S + c];
-                if (blockIdx.y == 0 && !g.rg_self) g.o_next[b * S + c] = v;
+                if (by == 0 && !g.rg_self) g.o_next[b * S + c] = v;
             }
             lds.T0[s_ * LDT + c] = v;
         }
-        if (blockIdx.y == 0 && !g.rg_self) {
+        if (by == 0 && !g.rg_self) {
             const int W = S + A + 3;
             for (int e = L.tid; e < TS * W; e += FT) {
                 const int s_ = e / W, c = e - s_ * W;
@@ -476,19 +475,19 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
             }
         }
     } else {
-        load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, blockIdx.y == 0 ? g.Xcopy : nullptr, L);
+        load_rows(g.X, d.S, nullptr, 0, row0, d.B, lds.T0, by == 0 ? g.Xcopy : nullptr, L);
     }
     lds_barrier();
     FPROF(0, 2);
     f32x4 z[2], gk[2];
     layer_fwd_mma<4, WClass<C0>::NU, false>(w1, g.P + d.ab1, d.S, d.h0, lds.T0, L, z);
     FPROF(0, 3);
-    emit_hidden(z, d.h0, true, lds.T1, gk, g.H0, g.G0, row, valid, L);
+    emit_hidden(z, d.h0, true, lds.T1, gk, by == 0 ? g.H0 : nullptr, by == 0 ? g.G0 : nullptr, row, valid, L);     // (every slice forms the whole first layer; slice 0 keeps it)
     lds_barrier();
     FPROF(0, 4);
     layer_fwd_mma<WClass<C0>::KT, WClass<C1>::NU, true>(w2, g.P + d.ab2 + fo, d.h0, d.h1, lds.T1, L, z);
     FPROF(0, 5);
-    emit_hidden(z, d.h1, true, lds.T0, gk, g.H1, g.G1, row, valid, L);
+    emit_hidden(z, d.h1, true, lds.T0, gk, g.H1 ? g.H1 + fo : nullptr, g.G1 ? g.G1 + fo : nullptr, row, valid, L, h1f);   // (a slice keeps its columns of the full-width matrices)
     lds_barrier();
     FPROF(0, 6);
     layer_small_mma<false, true>(wh, fo == 0 ? g.P + d.abh : nullptr, d.h1, 2 * d.A, lds.T0, lds.part, lds.Yl, L);
@@ -501,14 +500,14 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
         if (L.tid < TS * 16) {
             const int s_ = L.tid >> 4, f = L.tid & 15;
             if (f < A2 && row0 + s_ < d.B)
-                __hip_atomic_store(g.Ypart + ((size_t)blockIdx.y * d.B + row0 + s_) * A2 + f, lds.Yl[s_ * 16 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g.Ypart + ((size_t)by * d.B + row0 + s_) * A2 + f, lds.Yl[s_ * 16 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (L.tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(g.arrive + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned old = __hip_atomic_fetch_add(g.arrive + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned)g.split - 1u;
-            if (s_last) __hip_atomic_store(g.arrive + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
+            if (s_last) __hip_atomic_store(g.arrive + bx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
         }
         __syncthreads();
         if (!s_last) return;
@@ -545,6 +544,25 @@ __global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
         }
     }
     FPROF(0, 8);
+}
+
+template <int C0, int C1>
+__global__ __launch_bounds__(FT) void actor_fwd_kernel(ActorFwdArgs g)
+{
+    __shared__ TileLds lds;
+    actor_fwd_body<C0, C1>(g, lds, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Launch (1) -- the actor on the next state, its second layer split over `ay` workgroups per tile -- and the policy-gradient sample's forward
+// (unsplit: its activations are kept for the backward pass) as ONE launch: rows y < ay of the grid run the first, row ay the second.  The
+// two share nothing (the sample's forward reads its state rows from the ring itself), so this replaces the side stream that carried the
+// second one next to launches (1)-(2): one queue instead of two for most of the step (round 6; ERL_SAC_PAIR=0 keeps the side stream).
+template <int C0, int C1A, int C1B>
+__global__ __launch_bounds__(FT) void actor_fwd_pair_kernel(ActorFwdArgs ga, ActorFwdArgs gb, int ay)
+{
+    __shared__ TileLds lds;
+    if ((int)blockIdx.y < ay) actor_fwd_body<C0, C1A>(ga, lds, (int)blockIdx.x, (int)blockIdx.y);
+    else actor_fwd_body<C0, C1B>(gb, lds, (int)blockIdx.x, (int)blockIdx.y - ay);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -979,8 +997,36 @@ struct DwArgs {
     float *clamp_alpha_log;     // not NULL: workgroup 0 also clamps the temperature's logarithm to [-16, 2] (see erl_sac_update_fused)
     double *norm_parts;         // not NULL: [workgroups] the fp64 sum of squares of what each workgroup stores (its dW tile, its db rows): the
                                 // squared gradient norm in pieces, so that clip + Adam needs no pass over the gradient and no grid-wide wait
+    // not NULL (al_lp): workgroup 0 first takes the temperature's Adam step (alpha_step_block: obj_alpha, AgentSAC.py:76-79) -- the critic's
+    // table carries it in the one-stream form of the step (round 6): nothing between launch (1) and the actor's backward reads alpha_log
+    const float *al_lp;
+    int64_t al_n;
+    float *al_alpha_log, *al_m1, *al_m2;
+    float al_target_entropy, al_beta1, al_beta2, al_eps, al_max_norm, al_step_size, al_bc2_sqrt;
 };
 constexpr int kDwMaxParts = 1024;      // workgroups of one dw_table launch at the widest supported network (8 decoders of 256 x 256: 592)
+
+// obj_alpha = mean(alpha_log * (target_entropy - logprob)): g = target_entropy - mean(logprob); clip + Adam on one element (the arithmetic of
+// alpha_step_kernel, sac.hip).  One 256-thread workgroup; every thread of it must call.
+__device__ __forceinline__ void alpha_step_block(const float *__restrict__ lp, int64_t n, float target_entropy, float *__restrict__ alpha_log,
+                                                 float *__restrict__ m1, float *__restrict__ m2, float beta1, float beta2, float eps, float max_norm,
+                                                 float step_size, float bc2_sqrt)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += lp[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x != 0) return;
+    const float gr = t * (-1.0f / (float)n) + target_entropy;
+    const float total_norm = (float)sqrt((double)gr * (double)gr);
+    float coef = max_norm / (total_norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    float e_m1 = m1[0], e_m2 = m2[0], e_p = alpha_log[0];
+    erl_adam_update(erl_mul_rn(gr, erl_mul_rn(1.0f, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);   // the library's one Adam
+    m1[0] = e_m1;
+    m2[0] = e_m2;
+    alpha_log[0] = e_p;
+}
 
 __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
 {
@@ -990,6 +1036,9 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     if (g.clamp_alpha_log && blockIdx.x == 0 && tid == 0)        // after alpha was read (AgentSAC.py:80-81): the actor's backward has run
         g.clamp_alpha_log[0] = fminf(fmaxf(g.clamp_alpha_log[0], -16.f), 2.f);
+    if (g.al_lp && blockIdx.x == 0)                              // (workgroup-uniform: every thread of workgroup 0 takes part in the sum)
+        alpha_step_block(g.al_lp, g.al_n, g.al_target_entropy, g.al_alpha_log, g.al_m1, g.al_m2, g.al_beta1, g.al_beta2, g.al_eps, g.al_max_norm,
+                         g.al_step_size, g.al_bc2_sqrt);
     int pi = 0;
     for (int k = 1; k < g.np; ++k)
         if ((int)blockIdx.x >= g.p[k].tile0) pi = k;
@@ -1084,22 +1133,7 @@ __global__ __launch_bounds__(256) void alpha_step_fused_kernel(const float *__re
                                                                float *__restrict__ m1, float *__restrict__ m2, float beta1, float beta2, float eps,
                                                                float max_norm, float step_size, float bc2_sqrt)
 {
-    // obj_alpha = mean(alpha_log * (target_entropy - logprob)): g = target_entropy - mean(logprob); clip + Adam on one element
-    // (the arithmetic of alpha_step_kernel, sac.hip)
-    __shared__ float red[4];
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += lp[i];
-    const float t = block_sum(s, red);
-    if (threadIdx.x != 0) return;
-    const float gr = t * (-1.0f / (float)n) + target_entropy;
-    const float total_norm = (float)sqrt((double)gr * (double)gr);
-    float coef = max_norm / (total_norm + 1e-6f);
-    coef = coef > 1.f ? 1.f : coef;
-    float e_m1 = m1[0], e_m2 = m2[0], e_p = alpha_log[0];
-    erl_adam_update(erl_mul_rn(gr, erl_mul_rn(1.0f, coef)), e_m1, e_m2, e_p, beta1, beta2, eps, step_size, bc2_sqrt);   // the library's one Adam
-    m1[0] = e_m1;
-    m2[0] = e_m2;
-    alpha_log[0] = e_p;
+    alpha_step_block(lp, n, target_entropy, alpha_log, m1, m2, beta1, beta2, eps, max_norm, step_size, bc2_sqrt);
 }
 
 int wclass(int width) { return width <= 64 ? 0 : (width <= 128 ? 1 : 2); }
@@ -1458,7 +1492,7 @@ int64_t erl_sac_fused_ws_floats(int S, int A, int h0, int h1, int E, int64_t B, 
     f += r((int64_t)kCritSplit * E * B * A) + r(B * h1) + r(B * h0);     // dAct | dZ2, dZ1 (actor)
     f += r(Pa) + r(Pc) + r((int64_t)kCritSplit * E * tiles) + r(tiles) + 64;   // gradients, partial sums, alpha0
     f += 2 * 2 * kDwMaxParts;                                           // the squared-norm pieces of the two dw_table launches (doubles)
-    f += r((int64_t)kCritSplit * B * 2 * A);                            // the slices' shares of the actor's head output
+    f += 2 * r((int64_t)kCritSplit * B * 2 * A);                        // the slices' shares of the actor's head output (launch (1): both passes)
     return f;
 }
 
@@ -1517,6 +1551,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     float *act_pg = take(B * A);                        // (its own buffer: the policy-gradient sample runs next to the critic update)
     double *nparts_c = reinterpret_cast<double *>(take(2 * kDwMaxParts)), *nparts_a = reinterpret_cast<double *>(take(2 * kDwMaxParts));
     float *ypart = take((int64_t)kCritSplit * B * 2 * A);      // the slices' shares of the actor's head output (launch (1))
+    float *ypart2 = take((int64_t)kCritSplit * B * 2 * A);     // ... of the policy-gradient sample's forward when it is split too
     float *dEncP = take((int64_t)kCritSplit * E * B * h0);     // the slices' shares of dEnc (launch (3))
     float *q_pg = qt;                                   // reused once its first contents are consumed
     const dim3 tgrid(tiles), cgrid(tiles, E), blk(FT);
@@ -1542,23 +1577,56 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     // launch (1), which parks the old temperature (event `mid`).  ERL_SAC_FORK=2: fork after launch (1) as in rounds 4-5; 0: no fork.
     const char *fk_env = getenv("ERL_SAC_FORK");
     const bool do_fork = side && !(fk_env && atoi(fk_env) == 0);
-    const bool fork_early = do_fork && !(fk_env && atoi(fk_env) == 2);
+    static const bool split_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 0); }();
+    static const bool asplit_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 2); }();      // (2: the critic passes only)
+    const bool a_split = split_on && asplit_on && side && side->arrive && h1 == 64 * kCritSplit && tiles * kCritSplit <= 256;
+    // round 6: launch (1) and the policy-gradient sample's forward as ONE launch (actor_fwd_pair_kernel; the [256, 256] actor with launch (1)
+    // split); only the temperature step is left for the side stream, forked behind that launch
+    const char *pr_env = getenv("ERL_SAC_PAIR");
+    const bool pair = do_fork && a_split && !(pr_env && atoi(pr_env) == 0) && wclass(h0) == 2 && wclass(h1) == 2 && wclass(h1 / kCritSplit) == 0 &&
+                      (int64_t)tiles * (kCritSplit + 1) <= 65535;
+    const bool fork_early = do_fork && !pair && !(fk_env && atoi(fk_env) == 2);
+    // ERL_SAC_PAIR: 4 (default) as 3 with the sample's forward split over kCritSplit workgroups per tile like launch (1); 3: the temperature step rides the critic's weight-gradient launch (4) -- no side stream at all, nine launches on one
+    // queue: the events that forked / joined the side stream cost ~20 us of gaps per step (profiles/r06_sac_pair_ab.txt); 2: a launch of its own on
+    // the caller's stream; 1: on the side stream; 0: rounds 4-6's side stream for the sample's forward too
+    const int pair_mode = !pair ? 0 : (pr_env ? atoi(pr_env) : 4);
+    const bool side_on = do_fork && !(pair && pair_mode >= 2);
+    const bool alpha_in_dw = pair && pair_mode >= 3;
     SacJoin joiner{side, s};
     if (fork_early) {
         if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
         if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
         joiner.armed = true;
     }
-    static const bool split_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 0); }();
-    static const bool asplit_on = [] { const char *e = getenv("ERL_SAC_SPLIT"); return !(e && atoi(e) == 2); }();      // (2: the critic passes only)
-    if (split_on && asplit_on && side && side->arrive && h1 == 64 * kCritSplit && tiles * kCritSplit <= 256) {
+    auto pg_args = [&](bool from_ring) {                 // the policy-gradient sample's forward: the actor on `state`, everything kept for the backward pass
+        ActorFwdArgs af2 = af;
+        af2.X = state; af2.noise = eps_cur; af2.counter = 2 * counter + 1; af2.act_t = act_pg; af2.lp = lp_cur; af2.eps_out = eps_used; af2.Y = Y;
+        af2.H0 = H0; af2.G0 = G0; af2.H1 = H1; af2.G1 = G1; af2.alpha0 = nullptr;
+        af2.rg = ErlRingSample{};                        // (`state`: the caller's batch, or staged by launch (1), which a late fork waits for)
+        if (from_ring && ring) {                         // launch (1) is still staging `state`: read the same rows from the ring
+            af2.rg = *ring;
+            af2.rg.out_ids0 = af2.rg.out_ids1 = nullptr;
+            af2.rg_self = 1;
+        }
+        return af2;
+    };
+    if (a_split) {
         // (nothing of this pass is kept for a backward pass: a 256-wide second layer is split over kCritSplit workgroups per tile, the last
         // of them to arrive finishes the head -- ActorFwdArgs::split)
         ActorFwdArgs sp = af;
         sp.split = kCritSplit; sp.h1_full = h1; sp.d.h1 = h1 / kCritSplit; sp.Ypart = ypart; sp.arrive = side->arrive;
         const dim3 sgrid(tiles, kCritSplit);
 #define LAUNCH_ACTOR_SPLIT(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), sgrid, blk, 0, sa, sp)
-        FUSED_KT_DISPATCH_D(sp.d, LAUNCH_ACTOR_SPLIT)
+        if (pair && pair_mode >= 4) {                    // the sample's forward split over kCritSplit workgroups per tile like launch (1): its own counters and shares
+            ActorFwdArgs sp2 = pg_args(true);
+            sp2.split = kCritSplit; sp2.h1_full = h1; sp2.d.h1 = h1 / kCritSplit; sp2.Ypart = ypart2; sp2.arrive = side->arrive + 128;
+            hipLaunchKernelGGL((actor_fwd_pair_kernel<2, 0, 0>), dim3(tiles, 2 * kCritSplit), blk, 0, sa, sp, sp2, (int)kCritSplit);
+        } else if (pair) {
+            const ActorFwdArgs af2 = pg_args(true);
+            hipLaunchKernelGGL((actor_fwd_pair_kernel<2, 0, 2>), dim3(tiles, kCritSplit + 1), blk, 0, sa, sp, af2, (int)kCritSplit);
+        } else {
+            FUSED_KT_DISPATCH_D(sp.d, LAUNCH_ACTOR_SPLIT)
+        }
 #undef LAUNCH_ACTOR_SPLIT
     } else {
         FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
@@ -1569,31 +1637,26 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     if (fork_early) {
         if ((rc = erl_hip_status(hipEventRecord(side->mid, s), "hipEventRecord(mid)"))) return rc;     // launch (1) is enqueued
         sa = side->stream;
-    } else if (do_fork) {
+    } else if (side_on) {
         if ((rc = erl_hip_status(hipEventRecord(side->fork, s), "hipEventRecord(fork)"))) return rc;
         if ((rc = erl_hip_status(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
         sa = side->stream;
         joiner.armed = true;
     }
     {
-        ActorFwdArgs af2 = af;
-        af2.X = state; af2.noise = eps_cur; af2.counter = 2 * counter + 1; af2.act_t = act_pg; af2.lp = lp_cur; af2.eps_out = eps_used; af2.Y = Y;
-        af2.H0 = H0; af2.G0 = G0; af2.H1 = H1; af2.G1 = G1; af2.alpha0 = nullptr;
-        af2.rg = ErlRingSample{};                        // (`state`: the caller's batch, or staged by launch (1), which a late fork waits for)
-        if (fork_early && ring) {                        // launch (1) is still staging `state`: read the same rows from the ring
-            af2.rg = *ring;
-            af2.rg.out_ids0 = af2.rg.out_ids1 = nullptr;
-            af2.rg_self = 1;
+        if (!pair) {
+            const ActorFwdArgs af2 = pg_args(fork_early);
+            ActorFwdArgs keep = af;
+            af = af2;
+            FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
+            af = keep;
         }
-        ActorFwdArgs keep = af;
-        af = af2;
-        FUSED_KT_DISPATCH(LAUNCH_ACTOR_FWD)
-        af = keep;
         if (fork_early && (rc = erl_hip_status(hipStreamWaitEvent(sa, side->mid, 0), "hipStreamWaitEvent(mid)"))) return rc;   // alpha0 is parked
         const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-        hipLaunchKernelGGL(alpha_step_fused_kernel, dim3(1), dim3(256), 0, sa, lp_cur, B, target_entropy, alpha_log, alpha_m, alpha_v, beta1, beta2,
-                           eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
-        if (do_fork && (rc = erl_hip_status(hipEventRecord(side->join, sa), "hipEventRecord(join)"))) return rc;
+        if (!alpha_in_dw)
+            hipLaunchKernelGGL(alpha_step_fused_kernel, dim3(1), dim3(256), 0, sa, lp_cur, B, target_entropy, alpha_log, alpha_m, alpha_v, beta1, beta2,
+                               eps_adam, max_norm, (float)((double)lr / bc1), (float)sqrt(bc2));
+        if (side_on && (rc = erl_hip_status(hipEventRecord(side->join, sa), "hipEventRecord(join)"))) return rc;
         sa = s;
     }
     // ---- (2) target ensemble on (next_state, next_action)                                                     (:52)
@@ -1618,7 +1681,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
     // instead of 18.2k, its backward 2.6k instead of 7.4k) but pays 3.4k for the q exchange and 7.1k for the dEnc shares, and 256 mutually
     // waiting workgroups start later and finish more raggedly than 64 independent ones.  ERL_SAC_TRAIN_SPLIT=1 turns it on (read per call).
     const char *ts_env = getenv("ERL_SAC_TRAIN_SPLIT");
-    const bool tsplit_on = ts_env ? atoi(ts_env) == 1 : fork_early;
+    const bool tsplit_on = ts_env ? atoi(ts_env) == 1 : (fork_early || pair);
     const int tsplit = (split > 1 && tsplit_on && side && side->arrive1 && side->qx && B <= 4096 && kCritSplit == kQxSplit) ? split : 1;
     cg = tsplit > 1 ? dim3(tiles, E * tsplit) : cgrid;
     ca.d = tsplit > 1 ? dsl : d; ca.split = tsplit; ca.qt_split = split; ca.h1_full = h1;
@@ -1645,6 +1708,12 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
             dw_add(dw, dq + (size_t)e * B, 0, 1, 1, H1e + (size_t)e * B * h1, h1, G + d.dWo, G + d.dbo);
         }
         dw.norm_parts = nparts_c;
+        if (alpha_in_dw) {
+            const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+            dw.al_lp = lp_cur; dw.al_n = B; dw.al_target_entropy = target_entropy; dw.al_alpha_log = alpha_log; dw.al_m1 = alpha_m; dw.al_m2 = alpha_v;
+            dw.al_beta1 = beta1; dw.al_beta2 = beta2; dw.al_eps = eps_adam; dw.al_max_norm = max_norm; dw.al_step_size = (float)((double)lr / bc1);
+            dw.al_bc2_sqrt = (float)sqrt(bc2);
+        }
         if ((rc = dw_launch(dw, s))) return rc;
         // ---- (5) clip + Adam on the critic from the launch's squared-norm pieces, soft target update in the same launch  (:69-70)
         if ((rc = erl_clip_adam_parts_soft_f32(critic_params, g_critic, critic_m, critic_v, Pc, nparts_c, dw.p[dw.np - 1].tile0 + dw.p[dw.np - 1].ntiles,
@@ -1652,7 +1721,7 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
             return rc;
     }
     // ---- (7) TARGET ensemble on (state, action_pg): q and d(mean q)/d(action); finishes the critic objective    (:82-83)
-    if (do_fork && (rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
+    if (side_on && (rc = erl_hip_status(hipStreamWaitEvent(s, side->join, 0), "hipStreamWaitEvent(join)"))) return rc;
     joiner.armed = false;
     cg = dim3(tiles, E * split);
     ca.d = dsl; ca.split = split; ca.qt_split = 1;
