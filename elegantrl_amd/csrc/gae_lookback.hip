@@ -374,17 +374,24 @@ __global__ __launch_bounds__(L >= 16 ? 512 : LB_MAX_WAVES * 64) void gae_lookbac
 // no granules, no wait: every byte is read once and all loads of the workgroup are in flight together; N / 32 workgroups (128 at N = 4096).
 // Same arithmetic per step and the same composition rule as the look-back kernel (tolerance class: time-parallel, <= 1e-5 max(1, |ref|)).
 // ---------------------------------------------------------------------------------------------------------------------------------
+// NARROW form (round 6): 64 time chunks x 4 lanes x 4 envs = one workgroup per SIXTEEN envs (rows of 64 contiguous bytes per array), half
+// the steps per thread.  Measured (tools/gae_tall_envs_ab.py, profiles/r06_gae_tall_envs_ab.txt): at N = 4096 it does NOT pay although it
+// doubles the workgroups to one per CU (200 x 4096: 4.3 us warm / 7.7 cold against 4.4 / 7.2; 128 x 4096: 3.2 / 5.9 against 2.9 / 4.8 --
+// the kernel is a fixed ~3 us of launch + one memory round trip + compose + store there, not CU bandwidth); below 128 workgroups it does
+// (200 x 2048: 3.5 / 6.1 against 4.4 / 6.6; 200 x 1000: 3.5 / 5.3 against 4.3 / 6.8).  Chosen when N / 32 < 128; ERL_GAE_TALL_ENVS = 32 | 16
+// forces.
 constexpr int TALL_CHUNKS = 32, TALL_LANES = 8;
-template <int L, bool STATS, bool NT>
-__global__ __launch_bounds__(TALL_CHUNKS * TALL_LANES) void gae_tall_kernel(LbArgs g)
+template <int L, bool STATS, bool NT, int TCH = 32, int TLN = 8>
+__global__ __launch_bounds__(TCH * TLN) void gae_tall_kernel(LbArgs g)
 {
-    __shared__ float2 s_agg[TALL_CHUNKS][TALL_LANES * 4];
-    __shared__ double s_red[3][TALL_CHUNKS * TALL_LANES / 64];
+    static_assert(TCH * TLN == 256, "one workgroup = 256 threads");
+    __shared__ float2 s_agg[TCH][TLN * 4];
+    __shared__ double s_red[3][TCH * TLN / 64];
 
     const unsigned long long t_span = erl_span_in(g.span);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = threadIdx.x / TALL_LANES, el = threadIdx.x % TALL_LANES;      // chunk 0 is the latest in time
-    const int n0 = blockIdx.x * (TALL_LANES * 4) + el * 4;
+    const int c = threadIdx.x / TLN, el = threadIdx.x % TLN;      // chunk 0 is the latest in time
+    const int n0 = blockIdx.x * (TLN * 4) + el * 4;
     const bool live = n0 < g.N;
     const int t_top = g.H - c * L - 1;                                 // this thread's latest step; steps t_top - j
     const size_t N = (size_t)g.N;
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(TALL_CHUNKS * TALL_LANES) void gae_tall_kernel(LbAr
         __syncthreads();
         if (threadIdx.x < 3) {
             double sum = 0;
-            for (int u = 0; u < TALL_CHUNKS * TALL_LANES / 64; ++u) sum += s_red[threadIdx.x][u];
+            for (int u = 0; u < TCH * TLN / 64; ++u) sum += s_red[threadIdx.x][u];
             g.partials[(size_t)blockIdx.x * 3 + threadIdx.x] = sum;
         }
     }
@@ -595,7 +602,11 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
     // 13.0 us, profiles/r06_gae_tall_sweep.txt); ERL_GAE_TALL=0, or a forced look-back tiling, keeps slabs
     if (H >= 64 && H <= 8 * TALL_CHUNKS && env_int("ERL_GAE_TALL", 1) && !getenv("ERL_GAE_LB_L") && !getenv("ERL_GAE_LB_W") &&
         !env_int("ERL_GAE_LB_FAULT", 0) && !env_int("ERL_GAE_LB_DELAY", 0)) {
-        const int64_t nb = erl_cdiv(N, TALL_LANES * 4);
+        // 32 envs per workgroup; 16 below 128 workgroups (measured: see the NARROW form's note)
+        int tall_envs = env_int("ERL_GAE_TALL_ENVS", erl_cdiv(N, 32) < 128 ? 16 : 32);
+        if (tall_envs != 16) tall_envs = 32;
+        const int chunks = tall_envs == 16 ? 64 : TALL_CHUNKS;
+        const int64_t nb = erl_cdiv(N, tall_envs);
         ERL_REQUIRE(nb < (1LL << 30), "erl_gae_scan_f32: grid too large");
         ERL_REQUIRE(256 + nb * 24 <= workspace_bytes, "erl_gae_scan_f32: workspace too small for the one-workgroup scan");
         LbArgs g{};
@@ -607,19 +618,22 @@ int erl_gae_lookback_launch(float *rewards, uint8_t *undones, const uint8_t *unm
         g.span = erl_span_slot(ERL_SPAN_GAE, nb);
         *partials = g.partials;
         *nparts = (int)nb;
-        const int Lt = (int)erl_cdiv(H, TALL_CHUNKS);
+        const int Lt = (int)erl_cdiv(H, chunks);
         const dim3 grid((unsigned)nb), block(TALL_CHUNKS * TALL_LANES);
         const bool nt = env_int("ERL_GAE_NT", 18 * H * N >= (32LL << 20) ? 1 : 0) != 0;
-#define TALL_LAUNCH(LL)                                                                                         \
-    do {                                                                                                        \
-        if (want_stats && nt) hipLaunchKernelGGL((gae_tall_kernel<LL, true, true>), grid, block, 0, stream, g);  \
-        else if (want_stats) hipLaunchKernelGGL((gae_tall_kernel<LL, true, false>), grid, block, 0, stream, g);  \
-        else if (nt) hipLaunchKernelGGL((gae_tall_kernel<LL, false, true>), grid, block, 0, stream, g);          \
-        else hipLaunchKernelGGL((gae_tall_kernel<LL, false, false>), grid, block, 0, stream, g);                 \
+#define TALL_LAUNCH(LL, CH, LN)                                                                                          \
+    do {                                                                                                                 \
+        if (want_stats && nt) hipLaunchKernelGGL((gae_tall_kernel<LL, true, true, CH, LN>), grid, block, 0, stream, g);  \
+        else if (want_stats) hipLaunchKernelGGL((gae_tall_kernel<LL, true, false, CH, LN>), grid, block, 0, stream, g);  \
+        else if (nt) hipLaunchKernelGGL((gae_tall_kernel<LL, false, true, CH, LN>), grid, block, 0, stream, g);          \
+        else hipLaunchKernelGGL((gae_tall_kernel<LL, false, false, CH, LN>), grid, block, 0, stream, g);                 \
     } while (0)
-        if (Lt <= 2) TALL_LAUNCH(2);
-        else if (Lt <= 4) TALL_LAUNCH(4);
-        else TALL_LAUNCH(8);
+        if (tall_envs == 16) {
+            if (Lt <= 2) TALL_LAUNCH(2, 64, 4);
+            else TALL_LAUNCH(4, 64, 4);
+        } else if (Lt <= 2) TALL_LAUNCH(2, 32, 8);
+        else if (Lt <= 4) TALL_LAUNCH(4, 32, 8);
+        else TALL_LAUNCH(8, 32, 8);
 #undef TALL_LAUNCH
         return erl_hip_status(hipGetLastError(), "gae_tall_kernel launch");
     }

@@ -114,15 +114,20 @@ def test_gae_lookback_within_1e5(ops, dev, H, N, vtrace):
     np.testing.assert_allclose(tr.cpu().numpy(), r_o, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("H,N", [(64, 36), (100, 44), (255, 260), (256, 4100), (129, 32), (200, 4096)])
+@pytest.mark.parametrize("H,N", [(64, 36), (100, 44), (255, 260), (256, 4100), (129, 32), (200, 4096), (130, 8200)])
 def test_gae_one_workgroup_per_32_envs_against_c_oracle(ops, dev, H, N, monkeypatch):
-    """64 <= H <= 256 (round 6: gae_tall_kernel -- a workgroup holds the whole horizon of 32 envs, 32 time chunks composed in LDS): ragged env
-    groups, horizons that do not fill the last chunk, long undone chains so that the carry crosses every chunk, the statistics partials, the
-    in-place truncation fix-up; and the slab form (ERL_GAE_TALL=0) on the same inputs, which must agree within the same bar."""
+    """64 <= H <= 256 (round 6: gae_tall_kernel -- a workgroup holds the whole horizon of 32 envs, 32 time chunks composed in LDS; or of
+    16 envs, 64 chunks, when 32 would leave CUs without a workgroup): ragged env groups, horizons that do not fill the last chunk, long
+    undone chains so that the carry crosses every chunk, the statistics partials, the in-place truncation fix-up; both widths forced
+    (ERL_GAE_TALL_ENVS), the library's own choice, and the slab form (ERL_GAE_TALL=0) on the same inputs, all within the same bar."""
     r, u, m, v, nv = gae_inputs(H, N, seed=H * 3 + N, p_done=0.002, p_trunc=0.002)
     adv_o, ret_o, r_o, u_o = c_oracle.gae(r, u, m, v, nv, 0.99, 0.95, use_v_trace=True)
-    for tall in ("1", "0"):
+    for tall, envs in (("1", "32"), ("1", "16"), ("1", None), ("0", None)):
         monkeypatch.setenv("ERL_GAE_TALL", tall)
+        if envs is None:
+            monkeypatch.delenv("ERL_GAE_TALL_ENVS", raising=False)
+        else:
+            monkeypatch.setenv("ERL_GAE_TALL_ENVS", envs)
         tr, tu = cu(r, dev), cu(u, dev)
         stats = th.zeros(8, dtype=th.float64, device=dev)
         adv, ret = ops.gae_scan(tr, tu, cu(m, dev), cu(v, dev), cu(nv, dev), 0.99, 0.95, use_v_trace=True, algo="lookback", stats=stats)
