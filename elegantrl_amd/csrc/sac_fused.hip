@@ -1003,6 +1003,7 @@ struct DwArgs {
     int64_t al_n;
     float *al_alpha_log, *al_m1, *al_m2;
     float al_target_entropy, al_beta1, al_beta2, al_eps, al_max_norm, al_step_size, al_bc2_sqrt;
+    int alpha_wg;               // the workgroup that carries the temperature's duties: 0 (with its tile), or the extra one behind the last tile
 };
 constexpr int kDwMaxParts = 1024;      // workgroups of one dw_table launch at the widest supported network (8 decoders of 256 x 256: 592)
 
@@ -1028,17 +1029,22 @@ __device__ __forceinline__ void alpha_step_block(const float *__restrict__ lp, i
     alpha_log[0] = e_p;
 }
 
+template <int U, int KC>
 __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
 {
     __shared__ float red[4][32 * 33];
     __shared__ float bsum[4][32];
     __shared__ double nscratch[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    if (g.clamp_alpha_log && blockIdx.x == 0 && tid == 0)        // after alpha was read (AgentSAC.py:80-81): the actor's backward has run
+    // the temperature's duties: workgroup 0's first duty (default), or a workgroup of their own behind the last tile (ERL_SAC_DW=2: the serial
+    // prefix -- a sum over the batch, then a dependent Adam round trip -- leaves workgroup 0; measured even, the launch is not held by it)
+    const int wg_alpha = g.alpha_wg;                              // 0, or the extra workgroup's index
+    if (g.clamp_alpha_log && (int)blockIdx.x == wg_alpha && tid == 0)        // after alpha was read (AgentSAC.py:80-81): the actor's backward has run
         g.clamp_alpha_log[0] = fminf(fmaxf(g.clamp_alpha_log[0], -16.f), 2.f);
-    if (g.al_lp && blockIdx.x == 0)                              // (workgroup-uniform: every thread of workgroup 0 takes part in the sum)
+    if (g.al_lp && (int)blockIdx.x == wg_alpha)                  // (workgroup-uniform: every thread of that workgroup takes part in the sum)
         alpha_step_block(g.al_lp, g.al_n, g.al_target_entropy, g.al_alpha_log, g.al_m1, g.al_m2, g.al_beta1, g.al_beta2, g.al_eps, g.al_max_norm,
                          g.al_step_size, g.al_bc2_sqrt);
+    if (wg_alpha && (int)blockIdx.x == wg_alpha) return;         // (the extra workgroup owns no tile and no squared-norm piece)
     int pi = 0;
     for (int k = 1; k < g.np; ++k)
         if ((int)blockIdx.x >= g.p[k].tile0) pi = k;
@@ -1051,10 +1057,13 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
     const int64_t b0 = per * wave, b1 = min(B, b0 + per);
     f32x16 acc = {0};
     float bs = 0.f;
-    constexpr int U = 16;
     const int mc = min(m, p.M - 1), nc = min(n, p.N - 1);
     const int64_t rmax = B - 1;
-    for (int64_t b = b0; b < b1; b += 2 * U) {       // (uniform trip count; loads clamped + selected: 32 in flight per lane)
+    // U row pairs per round trip; the nZ - 1 further matrices of a summed A operand (the encoder's gradient: one dEnc per decoder) are
+    // requested KC at a time in the same round trip (round 6, last session: one more round trip per further matrix made the encoder's
+    // tiles -- six round trips at four decoders against two -- the launch's stragglers).  Same loads, same order of every sum and of the
+    // MFMAs in every instantiation: the same bits.
+    for (int64_t b = b0; b < b1; b += 2 * U) {       // (uniform trip count; loads clamped + selected: 2 U .. (2 + KC) U in flight per lane)
         float a[U], x[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1062,13 +1071,22 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
             a[u] = p.dZ[rc * p.M + mc];
             x[u] = p.X[rc * p.N + nc];
         }
-        for (int k = 1; k < p.nZ; ++k) {             // A = the sum of nZ matrices, added in order (the encoder gradient: sum over decoders)
-            float t[U];
+        for (int k = 1; k < p.nZ; k += KC) {          // A = the sum of nZ matrices, added in order (the encoder gradient: sum over decoders)
+            float t[KC][U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) t[u] = p.dZ[(size_t)k * p.sZ + min(b + 2 * u + hi, rmax) * p.M + mc];
+            for (int c = 0; c < KC; ++c) {
+                const int kk = min(k + c, p.nZ - 1);
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[c][u] = p.dZ[(size_t)kk * p.sZ + min(b + 2 * u + hi, rmax) * p.M + mc];
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < U; ++u) a[u] += t[u];
+            for (int c = 0; c < KC; ++c) {
+                if (k + c < p.nZ) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) a[u] += t[c][u];
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);           // (all loads issued; masks afterwards: see ldw4_raw)
 #pragma unroll
@@ -1125,7 +1143,23 @@ int dw_launch(const DwArgs &a, hipStream_t s)
     const DwProb &last = a.p[a.np - 1];
     ERL_REQUIRE(!a.norm_parts || last.tile0 + last.ntiles <= kDwMaxParts, "erl_sac_update_f32(fused): %d weight-gradient tiles, table of %d",
                 last.tile0 + last.ntiles, kDwMaxParts);
-    hipLaunchKernelGGL(dw_table_kernel, dim3(last.tile0 + last.ntiles), dim3(256), 0, s, a);
+    // ERL_SAC_DW (read at every launch: the forms are compared inside one process by the tests; all leave the same bits):
+    //   0 (default) a summed operand's matrices requested in ONE round trip, three at a time (dw_table_kernel<16, 3>): config 3 118.7 -> 117.1 us
+    //     per update, the launch 9.45 -> 8.66 us on average (profiles/r06_sac_dw_ab.txt)
+    //   1 round 6's earlier form: one round trip per further matrix (<16, 1>)
+    //   2 as 0, and the temperature's duties in a workgroup of their own behind the last tile instead of in front of workgroup 0's tile: measured even
+    //   3 as 1 with that workgroup
+    //   4 as 0 with a wave's whole quarter of a 256-sample batch in one round trip (<32, 3>: 325 registers, one wave per SIMD): measured slower
+    const char *form_env = getenv("ERL_SAC_DW");
+    const int form = form_env ? atoi(form_env) : 0;
+    DwArgs b = a;
+    const int ntiles = last.tile0 + last.ntiles;
+    const bool own_wg = (form == 2 || form == 3) && (b.al_lp || b.clamp_alpha_log);
+    b.alpha_wg = own_wg ? ntiles : 0;
+    const dim3 grid(ntiles + (own_wg ? 1 : 0));
+    if (form == 1 || form == 3) hipLaunchKernelGGL((dw_table_kernel<16, 1>), grid, dim3(256), 0, s, b);
+    else if (form == 4) hipLaunchKernelGGL((dw_table_kernel<32, 3>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((dw_table_kernel<16, 3>), grid, dim3(256), 0, s, b);
     return erl_hip_status(hipGetLastError(), "erl_sac_update_f32(fused: dw_table)");
 }
 

@@ -468,6 +468,44 @@ def test_sac_split_training_pass_agrees_with_the_unsplit_one(B, E, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,E,hidden", [(256, 4, (256, 256)), (100, 2, (256, 256)), (64, 8, (256, 256)), (130, 5, (64, 48))])
+def test_sac_weight_gradient_table_forms_are_bit_identical(B, E, hidden, monkeypatch):
+    """dw_table_kernel (csrc/sac_fused.hip), ERL_SAC_DW: 0 (default) requests a summed operand's matrices (the encoder's gradient: one dEnc
+    per decoder) in one round trip; 1 is the earlier form (one round trip per further matrix); 2 / 3 the same two with the temperature's
+    Adam step / clamp in a workgroup of their own behind the last tile; 4 a deeper instantiation.  Same loads, same order of every sum:
+    weights, moments, temperature and objectives must be the SAME BITS after three steps."""
+    from elegantrl_amd import _hip, ops
+    dev = th.device("cuda:0")
+    S, A = 11, 3
+    spec = ops.SacSpec(S, A, hidden, E)
+    g = th.Generator(device=dev).manual_seed(7 * B + E)
+    init = [0.05 * th.randn(n, device=dev, generator=g) for n in (spec.actor_count, spec.critic_count, spec.critic_count)]
+    batches = [((th.randn((B, S), device=dev, generator=g), th.randn((B, A), device=dev, generator=g).tanh(), th.randn(B, device=dev, generator=g),
+                 (th.rand(B, device=dev, generator=g) > 0.1).float(), (th.rand(B, device=dev, generator=g) > 0.1).float(),
+                 th.randn((B, S), device=dev, generator=g)), th.randn((B, A), device=dev, generator=g), th.randn((B, A), device=dev, generator=g))
+               for _ in range(3)]
+
+    def run(form):
+        monkeypatch.setenv("ERL_SAC_DW", form)
+        pa, pc, pt = [x.clone() for x in init]
+        alpha = th.full((1,), 1.9, device=dev)                   # (close to the clamp's upper edge: the clamp has work to do)
+        mom = [th.zeros_like(pa), th.zeros_like(pa), th.zeros_like(pc), th.zeros_like(pc), th.zeros(1, device=dev), th.zeros(1, device=dev)]
+        objs, out = th.zeros(2, device=dev), []
+        for step, (batch, e_next, e_cur) in enumerate(batches, 1):
+            ops.sac_update(spec, pa, pc, pt, alpha, mom, list(batch), step, gamma=0.97, target_entropy=-float(A), tau=5e-3, lr=1e-3, max_norm=3.0,
+                           objs_out=objs, noises=(e_next, e_cur))
+            out.append(objs.clone())
+        th.cuda.synchronize()
+        _hip.check_async_faults()
+        return [pa, pc, pt, alpha] + mom + out
+
+    ref = run("1")
+    for form in ("0", "2", "3", "4"):
+        for x, y in zip(ref, run(form)):
+            assert th.equal(x, y), f"ERL_SAC_DW={form}"
+
+
+@pytest.mark.gpu
 def test_sac_update_with_importance_weights_and_td_errors():
     """prioritised replay through the SAC step (AgentSAC.py:58-62): obj_critic = mean(td_error * is_weight), td_error comes back
     per sample; against oracle/sac_torch.py with the same weights."""
