@@ -1003,6 +1003,7 @@ struct DwArgs {
     int64_t al_n;
     float *al_alpha_log, *al_m1, *al_m2;
     float al_target_entropy, al_beta1, al_beta2, al_eps, al_max_norm, al_step_size, al_bc2_sqrt;
+    int xcd_tiles;              // not 0: the launch's tile count, and workgroups take their tiles in the XCD-contiguous order (dw_table_kernel)
     int alpha_wg;               // the workgroup that carries the temperature's duties: 0 (with its tile), or the extra one behind the last tile
 };
 constexpr int kDwMaxParts = 1024;      // workgroups of one dw_table launch at the widest supported network (8 decoders of 256 x 256: 592)
@@ -1039,17 +1040,26 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
     // the temperature's duties: workgroup 0's first duty (default), or a workgroup of their own behind the last tile (ERL_SAC_DW=2: the serial
     // prefix -- a sum over the batch, then a dependent Adam round trip -- leaves workgroup 0; measured even, the launch is not held by it)
     const int wg_alpha = g.alpha_wg;                              // 0, or the extra workgroup's index
-    if (g.clamp_alpha_log && (int)blockIdx.x == wg_alpha && tid == 0)        // after alpha was read (AgentSAC.py:80-81): the actor's backward has run
+    // which tile: blockIdx.x itself, or (g.xcd_tiles: the launch's tile count) the XCD-contiguous order -- consecutive workgroups go to
+    // consecutive XCDs, so workgroup b takes tile (b % 8) * (tiles / 8) + b / 8 (remainders spread over the first XCDs): the tiles one
+    // XCD's L2 serves are then neighbours in (problem, tm, tn) order and share their dZ row blocks and X column blocks, instead of every XCD
+    // fetching every block of every problem over the fabric.  Everything below (the squared-norm piece too) is indexed by the TILE: same bits.
+    int bid = blockIdx.x;
+    if (g.xcd_tiles && bid < g.xcd_tiles) {
+        const int x = bid & 7, i = bid >> 3, fl = g.xcd_tiles >> 3, rem = g.xcd_tiles & 7;
+        bid = x * fl + min(x, rem) + i;
+    }
+    if (g.clamp_alpha_log && bid == wg_alpha && tid == 0)        // after alpha was read (AgentSAC.py:80-81): the actor's backward has run
         g.clamp_alpha_log[0] = fminf(fmaxf(g.clamp_alpha_log[0], -16.f), 2.f);
-    if (g.al_lp && (int)blockIdx.x == wg_alpha)                  // (workgroup-uniform: every thread of that workgroup takes part in the sum)
+    if (g.al_lp && bid == wg_alpha)                              // (workgroup-uniform: every thread of that workgroup takes part in the sum)
         alpha_step_block(g.al_lp, g.al_n, g.al_target_entropy, g.al_alpha_log, g.al_m1, g.al_m2, g.al_beta1, g.al_beta2, g.al_eps, g.al_max_norm,
                          g.al_step_size, g.al_bc2_sqrt);
-    if (wg_alpha && (int)blockIdx.x == wg_alpha) return;         // (the extra workgroup owns no tile and no squared-norm piece)
+    if (wg_alpha && bid == wg_alpha) return;                     // (the extra workgroup owns no tile and no squared-norm piece)
     int pi = 0;
     for (int k = 1; k < g.np; ++k)
-        if ((int)blockIdx.x >= g.p[k].tile0) pi = k;
+        if (bid >= g.p[k].tile0) pi = k;
     const DwProb &p = g.p[pi];
-    const int t = blockIdx.x - p.tile0, tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int t = bid - p.tile0, tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
     const int m = 32 * tm + l31, n = 32 * tn + l31;
     const bool mok = m < p.M, nok = n < p.N;
     const int64_t B = g.B;
@@ -1122,7 +1132,7 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwArgs g)
     }
     if (g.norm_parts) {                 // (fixed association: thread-strided, wave butterfly, waves in order)
         sq = block_sum(sq, nscratch);
-        if (tid == 0) g.norm_parts[blockIdx.x] = sq;
+        if (tid == 0) g.norm_parts[bid] = sq;
     }
 }
 
@@ -1149,6 +1159,7 @@ int dw_launch(const DwArgs &a, hipStream_t s)
     //   1 round 6's earlier form: one round trip per further matrix (<16, 1>)
     //   2 as 0, and the temperature's duties in a workgroup of their own behind the last tile instead of in front of workgroup 0's tile: measured even
     //   3 as 1 with that workgroup
+    //   5 as 0 with the tiles handed out in XCD-contiguous order; 6 as 1 with it
     //   4 as 0 with a wave's whole quarter of a 256-sample batch in one round trip (<32, 3>: 325 registers, one wave per SIMD): measured slower
     const char *form_env = getenv("ERL_SAC_DW");
     const int form = form_env ? atoi(form_env) : 0;
@@ -1156,8 +1167,9 @@ int dw_launch(const DwArgs &a, hipStream_t s)
     const int ntiles = last.tile0 + last.ntiles;
     const bool own_wg = (form == 2 || form == 3) && (b.al_lp || b.clamp_alpha_log);
     b.alpha_wg = own_wg ? ntiles : 0;
+    b.xcd_tiles = (form == 5 || form == 6) ? ntiles : 0;
     const dim3 grid(ntiles + (own_wg ? 1 : 0));
-    if (form == 1 || form == 3) hipLaunchKernelGGL((dw_table_kernel<16, 1>), grid, dim3(256), 0, s, b);
+    if (form == 1 || form == 3 || form == 6) hipLaunchKernelGGL((dw_table_kernel<16, 1>), grid, dim3(256), 0, s, b);
     else if (form == 4) hipLaunchKernelGGL((dw_table_kernel<32, 3>), grid, dim3(256), 0, s, b);
     else hipLaunchKernelGGL((dw_table_kernel<16, 3>), grid, dim3(256), 0, s, b);
     return erl_hip_status(hipGetLastError(), "erl_sac_update_f32(fused: dw_table)");

@@ -472,7 +472,8 @@ def test_sac_split_training_pass_agrees_with_the_unsplit_one(B, E, monkeypatch):
 def test_sac_weight_gradient_table_forms_are_bit_identical(B, E, hidden, monkeypatch):
     """dw_table_kernel (csrc/sac_fused.hip), ERL_SAC_DW: 0 (default) requests a summed operand's matrices (the encoder's gradient: one dEnc
     per decoder) in one round trip; 1 is the earlier form (one round trip per further matrix); 2 / 3 the same two with the temperature's
-    Adam step / clamp in a workgroup of their own behind the last tile; 4 a deeper instantiation.  Same loads, same order of every sum:
+    Adam step / clamp in a workgroup of their own behind the last tile; 4 a deeper instantiation; 5 / 6 = 0 / 1 with the tiles handed out in
+    XCD-contiguous order.  Same loads, same order of every sum:
     weights, moments, temperature and objectives must be the SAME BITS after three steps."""
     from elegantrl_amd import _hip, ops
     dev = th.device("cuda:0")
@@ -500,7 +501,7 @@ def test_sac_weight_gradient_table_forms_are_bit_identical(B, E, hidden, monkeyp
         return [pa, pc, pt, alpha] + mom + out
 
     ref = run("1")
-    for form in ("0", "2", "3", "4"):
+    for form in ("0", "2", "3", "4", "5", "6"):
         for x, y in zip(ref, run(form)):
             assert th.equal(x, y), f"ERL_SAC_DW={form}"
 
