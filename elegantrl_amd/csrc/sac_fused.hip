@@ -516,9 +516,16 @@ __device__ __forceinline__ void actor_fwd_body(const ActorFwdArgs &g, TileLds &l
             const int s_ = L.tid >> 4, f = L.tid & 15;
             float y = 0.f;
             if (f < A2 && row0 + s_ < d.B) {
-                y = __hip_atomic_load(g.Ypart + ((size_t)0 * d.B + row0 + s_) * A2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int k = 1; k < g.split; ++k)
-                    y += __hip_atomic_load(g.Ypart + ((size_t)k * d.B + row0 + s_) * A2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (all shares requested together -- one round trip instead of one per slice -- and added in slice order: the same bits)
+                static_assert(kQxSplit == 4, "four shares are fetched at once (kCritSplit below is the same 4)");
+                float yk[kQxSplit];
+#pragma unroll
+                for (int k = 0; k < kQxSplit; ++k)
+                    yk[k] = __hip_atomic_load(g.Ypart + ((size_t)min(k, g.split - 1) * d.B + row0 + s_) * A2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                y = yk[0];
+#pragma unroll
+                for (int k = 1; k < kQxSplit; ++k)
+                    if (k < g.split) y += yk[k];
             }
             lds.Yl[s_ * 16 + f] = y;
         }
@@ -644,6 +651,33 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 &
     layer_fwd_load<4, WClass<C0>::NU, false>(g.P + d.cWe, d.S + d.A, d.h0, L, we);
     layer_fwd_load<WClass<C0>::KT, WClass<C1>::NU, true>(Pd + d.dW1 + fo * d.h0, d.h0, d.h1, L, w1);
     layer_small_load<false, true>(Pd + d.dWo + fo, d.h1, 1, 0, 0, L, wo);
+    // (round 6, last session) what the epilogue reads of EARLIER launches' results -- the target's partial q values, the label's inputs, the
+    // training pass's q for the td errors -- is requested here, behind the weights, instead of where it is used: there each was a round
+    // trip of its own on the tile's critical path ("labels, dq": 10 % of the training pass in tools/sac_fused_profile.py's stamps).  Clamped
+    // addresses, values selected where they are used; the same arithmetic in the same order.
+    float pq[kQxSplit] = {0.f, 0.f, 0.f, 0.f}, p_rew = 0.f, p_und = 0.f, p_lpn = 0.f, p_unm = 0.f, p_w = 1.f, p_al0 = 0.f;
+    float p_qe[FMAXE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, p_lab = 0.f;
+    if (MODE == 1) {
+        if (L.tid < TS * FMAXE) {
+            const int s_ = L.tid / FMAXE, k = min(L.tid - s_ * FMAXE, E - 1);
+            const int64_t b = min(row0 + s_, B - 1);
+#pragma unroll
+            for (int j = 0; j < kQxSplit; ++j) pq[j] = g.qt[((size_t)k * g.qt_split + min(j, g.qt_split - 1)) * B + b];
+        }
+        if (L.tid < TS) {
+            const int64_t b = min(row0 + L.tid, B - 1);
+            p_rew = g.reward[b]; p_und = g.undone[b]; p_lpn = g.lp_next[b]; p_unm = g.unmask[b]; p_al0 = g.alpha0[0];
+            if (g.is_weight) p_w = g.is_weight[b];
+        }
+    }
+    if (MODE == 2 && first && L.wave == 1 && L.lane < TS) {
+        const int64_t b = min(row0 + L.lane, B - 1);
+        p_lab = g.label_in[b]; p_unm = g.unmask[b];
+        if (g.is_weight) p_w = g.is_weight[b];
+#pragma unroll
+        for (int k = 0; k < FMAXE; ++k) p_qe[k] = g.qc[(size_t)min(k, E - 1) * B + b];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     clear_images(lds.T0, lds.T1, L);
     lds_barrier();
     if (MODE == 1) FPROF(1, 0);
@@ -679,9 +713,17 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 &
             __hip_atomic_store(g.qx + (size_t)ey * B + b, (unsigned long long)__float_as_uint(lds.Yl[L.tid * 16]) | ((unsigned long long)g.nonce << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float qv = 0.f;
-            for (int j = 0; j < g.split; ++j) {
+            // (the first look at every share goes out together: one round trip when the slices finish together, not one per slice; a share
+            // that is not there yet is polled on its own, and the shares are added in slice order either way: the same bits)
+            unsigned long long gr4[kQxSplit];
+#pragma unroll
+            for (int j = 0; j < kQxSplit; ++j)
+                gr4[j] = __hip_atomic_load(g.qx + (size_t)(e * g.split + min(j, g.split - 1)) * B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < kQxSplit; ++j) {
+                if (j >= g.split) continue;
                 const unsigned long long *src = g.qx + (size_t)(e * g.split + j) * B + b;
-                unsigned long long gr = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long gr = gr4[j];
                 for (uint32_t spins = 0; (uint32_t)(gr >> 32) != g.nonce && spins < g.spin_limit; ++spins) {
                     __builtin_amdgcn_s_sleep(1);
                     gr = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -702,9 +744,11 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 &
             const int s_ = L.tid / FMAXE, k = L.tid - s_ * FMAXE;
             const int64_t b = row0 + s_;
             float qk = 0.f;
-            if (k < E && b < B) {
-                qk = g.qt[(size_t)k * g.qt_split * B + b];
-                for (int j = 1; j < g.qt_split; ++j) qk += g.qt[((size_t)k * g.qt_split + j) * B + b];
+            if (k < E && b < B) {                       // (requested at the kernel's start, added in slice order)
+                qk = pq[0];
+#pragma unroll
+                for (int j = 1; j < kQxSplit; ++j)
+                    if (j < g.qt_split) qk += pq[j];
             }
             qtl[L.tid] = qk;
         }
@@ -722,12 +766,12 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 &
                 // q_label = reward + undone * gamma * (min_e q_target - next_logprob * alpha)      (AgentSAC.py:52-55)
                 float m = qtl[L.tid * FMAXE];
                 for (int k = 1; k < E; ++k) m = fminf(m, qtl[L.tid * FMAXE + k]);
-                const float alpha = expf(g.alpha0[0]);
-                const float lab = g.reward[b] + (g.undone[b] * g.gamma) * (m - g.lp_next[b] * alpha);
+                const float alpha = expf(p_al0);
+                const float lab = p_rew + (p_und * g.gamma) * (m - p_lpn * alpha);
                 if (first) g.label[b] = lab;
                 // td = mean_e (q - label)^2 * unmask; obj = mean_b (td w): dq = 2 (q - label) unmask w / (E B)   (:57-62)
-                const float w = g.is_weight ? g.is_weight[b] : 1.f;
-                dqv = 2.f * (qv - lab) * g.unmask[b] * w / ((float)E * (float)B);
+                const float w = g.is_weight ? p_w : 1.f;
+                dqv = 2.f * (qv - lab) * p_unm * w / ((float)E * (float)B);
                 if (fo == 0) g.dq[(size_t)e * B + b] = dqv;
             } else {
                 dqv = -1.0f / ((float)E * (float)B);               // L = -(mean_b mean_e q - alpha mean_b logprob)   (:82-84)
@@ -743,15 +787,17 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu((MODE == 1 &
             const int64_t b = row0 + L.lane;                       // that every decoder's q of the training pass is in memory
             float td = 0.f;
             if (L.lane < TS && b < B) {
-                const float lab = g.label_in[b];
+                const float lab = p_lab;                    // (every decoder's q and the label requested at the kernel's start; the squares added in decoder order)
                 float s2 = 0.f;
-                for (int k = 0; k < E; ++k) {
-                    const float diff = g.qc[(size_t)k * B + b] - lab;
+#pragma unroll
+                for (int k = 0; k < FMAXE; ++k) {
+                    if (k >= E) continue;
+                    const float diff = p_qe[k] - lab;
                     s2 += diff * diff;
                 }
-                td = (s2 / (float)E) * g.unmask[b];
+                td = (s2 / (float)E) * p_unm;
                 if (g.td_out) g.td_out[b] = td;
-                td *= g.is_weight ? g.is_weight[b] : 1.f;
+                td *= g.is_weight ? p_w : 1.f;
             }
             td = wave_sum(td);
             if (L.lane == 0) g.tdpart[blockIdx.x] = td;
@@ -893,7 +939,14 @@ __global__ __launch_bounds__(FT) void actor_bwd_kernel(ActorBwdArgs g)
         const float sq = block_sum(sqp, lds.red);
         if (L.tid == 0) {
             float std_ = 0.f;
-            for (int t = 0; t < g.ntiles; ++t) std_ += g.tdpart[t];
+            for (int t0 = 0; t0 < g.ntiles; t0 += 16) {      // (sixteen entries per round trip instead of one; added in tile order)
+                float tv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tv[u] = g.tdpart[min(t0 + u, g.ntiles - 1)];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (t0 + u < g.ntiles) std_ += tv[u];
+            }
             g.objs_out[0] = std_ / (float)B;
             g.objs_out[1] = sq / ((float)E * (float)B) - expf(g.alpha_log[0]) * (tl / (float)B);
         }
