@@ -430,7 +430,13 @@ __device__ __forceinline__ void actor_fwd_body(const ActorFwdArgs &g, TileLds &l
     __shared__ int64_t s_row[TS];
     if (g.rg.ids && L.tid < TS) {                          // ids0 = ids % L, ids1 = ids // L  (replay_buffer.py:124-125)
         const int64_t b = row0 + L.tid, id = g.rg.ids[min(b, d.B - 1)];
-        const int64_t n = id / g.rg.sample_len, t = id - n * g.rg.sample_len;
+        int64_t n, t;                                       // (a 64-bit divide is ~10x the instructions of a 32-bit one, on the tile's critical path)
+        if ((uint64_t)id <= 0x7fffffffull && (uint64_t)g.rg.sample_len <= 0x7fffffffull) {
+            const uint32_t i32 = (uint32_t)id, l32 = (uint32_t)g.rg.sample_len, n32 = i32 / l32;
+            n = n32; t = i32 - n32 * l32;
+        } else {
+            n = id / g.rg.sample_len; t = id - n * g.rg.sample_len;
+        }
         s_row[L.tid] = g.rg.row_floats ? n * g.rg.max_size + t : t * g.rg.num_seqs + n;     // (interleaved ring: sequence-major rows)
         if (by == 0 && b < d.B && !g.rg_self) {
             if (g.rg.out_ids0) g.rg.out_ids0[b] = t;
