@@ -391,6 +391,15 @@ struct ActorFwdArgs {
     int split, h1_full;
     float *Ypart;
     unsigned *arrive;
+    // OWNER form of the meeting (round 6, last session; yx != NULL): every slice publishes its share as 8-byte {share, nonce} granules in
+    // yx[split][B][2 A] (library-owned, never cleared: the per-launch nonce invalidates older contents) and LEAVES -- no wait for the stores'
+    // acknowledgement, no arrival counter; the tile's LAST slice in dispatch order (by = split - 1: its partners were dispatched before it
+    // and wait for nothing, so it cannot wait for a workgroup that is not running or finished) polls the others' granules, adds the
+    // shares in slice order and samples.  One round trip after the slowest slice instead of three (acknowledge, count, fetch).  Bounded
+    // spin; a share that never arrives poisons the tile's actions with NaN and is counted in the host-visible fault word.
+    unsigned long long *yx;
+    uint32_t nonce, spin_limit;
+    uint32_t *fault;
     // ReplayBuffer.sample inside this launch (elegantrl/train/replay_buffer.py:120-134; the gather of csrc/gather.hip replay_sample_kernel):
     // rg.ids != NULL makes X the ring's NEXT-state rows of the drawn transitions, read in place, and the tile's slice-0 workgroup also copies
     // the batch out for the launches behind it (state, action, reward, undone, unmask, next_state, ids0, ids1) -- under the weight loads
@@ -503,6 +512,49 @@ __device__ __forceinline__ void actor_fwd_body(const ActorFwdArgs &g, TileLds &l
         // shares in slice order -- the sum every order of arrival gives -- into Yl and carries on as the unsplit kernel does
         __shared__ int s_last;
         const int A2 = 2 * d.A;
+        if (g.yx) {
+            static_assert(kQxSplit == 4, "four shares are polled at once");
+            const int s_ = L.tid >> 4, f = L.tid & 15;
+            const bool mine = L.tid < TS * 16 && f < A2 && row0 + s_ < d.B;
+            const int owner = g.split - 1;
+            if (by != owner) {
+                if (mine)
+                    __hip_atomic_store(g.yx + ((size_t)by * d.B + row0 + s_) * A2 + f,
+                                       (unsigned long long)__float_as_uint(lds.Yl[s_ * 16 + f]) | ((unsigned long long)g.nonce << 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (L.tid < TS * 16) {
+                float y = 0.f;
+                if (mine) {
+                    unsigned long long gr4[kQxSplit];
+#pragma unroll
+                    for (int k = 0; k < kQxSplit; ++k)
+                        gr4[k] = __hip_atomic_load(g.yx + ((size_t)min(k, max(owner - 1, 0)) * d.B + row0 + s_) * A2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < kQxSplit; ++k) {
+                        if (k >= g.split) continue;
+                        float sh;
+                        if (k == owner) {
+                            sh = lds.Yl[s_ * 16 + f];                   // (my own share: the bits the granule would carry)
+                        } else {
+                            const unsigned long long *src = g.yx + ((size_t)k * d.B + row0 + s_) * A2 + f;
+                            unsigned long long gr = gr4[k];
+                            for (uint32_t spins = 0; (uint32_t)(gr >> 32) != g.nonce && spins < g.spin_limit; ++spins) {
+                                __builtin_amdgcn_s_sleep(1);
+                                gr = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            const bool ready = (uint32_t)(gr >> 32) == g.nonce;
+                            if (!ready && g.fault) __hip_atomic_fetch_add(g.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            sh = ready ? __uint_as_float((uint32_t)gr) : __uint_as_float(0x7FC00000u);
+                        }
+                        y = k == 0 ? sh : y + sh;                        // slice order: ((s0 + s1) + s2) + s3
+                    }
+                }
+                lds.Yl[s_ * 16 + f] = y;
+            }
+            lds_barrier();
+        } else {
         if (L.tid < TS * 16) {
             const int s_ = L.tid >> 4, f = L.tid & 15;
             if (f < A2 && row0 + s_ < d.B)
@@ -536,6 +588,7 @@ __device__ __forceinline__ void actor_fwd_body(const ActorFwdArgs &g, TileLds &l
             lds.Yl[s_ * 16 + f] = y;
         }
         lds_barrier();
+        }   // (last-arriver form)
     }
     if (L.tid < TS) {
         const int64_t b = row0 + L.tid;
@@ -1255,7 +1308,10 @@ struct SacSide {
     unsigned *arrive1 = nullptr;          // [256] ... of the split critic training pass (its dEnc shares)
     unsigned long long *qx = nullptr;     // [FMAXE * kQxSplit * 4096] granules {share of q, nonce}: the split critic training pass's q exchange
     uint32_t nonce = 0;
+    unsigned long long *yx = nullptr;     // [2 passes][kQxSplit][4096][16] granules {share of the actor's head output, nonce} (ActorFwdArgs::yx)
+    uint32_t nonce_y = 0;
 };
+constexpr size_t kYxPass = (size_t)kQxSplit * 4096 * 16;      // granules of one pass
 SacSide g_sac_side[16];
 
 // one side stream + event pair per (device, caller stream): two agents on different streams of one device never record each
@@ -1287,6 +1343,10 @@ SacSide *sac_side_stream(hipStream_t owner)
         void *qx = nullptr;
         const size_t qx_bytes = (size_t)FMAXE * kQxSplit * 4096 * sizeof(unsigned long long);
         if (hipMalloc(&qx, qx_bytes) == hipSuccess && hipMemset(qx, 0, qx_bytes) == hipSuccess) q.qx = (unsigned long long *)qx;
+        else (void)hipGetLastError();
+        void *yx = nullptr;
+        if (hipMalloc(&yx, 2 * kYxPass * sizeof(unsigned long long)) == hipSuccess && hipMemset(yx, 0, 2 * kYxPass * sizeof(unsigned long long)) == hipSuccess)
+            q.yx = (unsigned long long *)yx;
         else (void)hipGetLastError();
         (void)hipDeviceSynchronize();             // (once per slot: the caller's stream may be non-blocking, i.e. not ordered behind those memsets)
         q.device = dev;
@@ -1720,11 +1780,20 @@ int erl_sac_update_fused(float *actor_params, float *critic_params, float *targe
         // of them to arrive finishes the head -- ActorFwdArgs::split)
         ActorFwdArgs sp = af;
         sp.split = kCritSplit; sp.h1_full = h1; sp.d.h1 = h1 / kCritSplit; sp.Ypart = ypart; sp.arrive = side->arrive;
+        // ERL_SAC_YX=0 keeps the last-arriver meeting of the head's shares (read at every call: the tests compare the two forms in one process)
+        const char *yx_env = getenv("ERL_SAC_YX");
+        const bool yx_on = side->yx && !(yx_env && atoi(yx_env) == 0) && B <= 4096 && 2 * A <= 16;
+        if (yx_on) {
+            static const uint32_t ylim = [] { const char *e = getenv("ERL_SAC_QX_SPIN"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1u << 22; }();
+            if (++side->nonce_y == 0) side->nonce_y = 1;
+            sp.yx = side->yx; sp.nonce = side->nonce_y; sp.spin_limit = ylim; sp.fault = erl_fault_word(ERL_FAULT_SAC_Q_EXCHANGE);
+        }
         const dim3 sgrid(tiles, kCritSplit);
 #define LAUNCH_ACTOR_SPLIT(K0, K1) hipLaunchKernelGGL((actor_fwd_kernel<K0, K1>), sgrid, blk, 0, sa, sp)
         if (pair && pair_mode >= 4) {                    // the sample's forward split over kCritSplit workgroups per tile like launch (1): its own counters and shares
             ActorFwdArgs sp2 = pg_args(true);
             sp2.split = kCritSplit; sp2.h1_full = h1; sp2.d.h1 = h1 / kCritSplit; sp2.Ypart = ypart2; sp2.arrive = side->arrive + 128;
+            if (yx_on) { sp2.yx = side->yx + kYxPass; sp2.nonce = sp.nonce; sp2.spin_limit = sp.spin_limit; sp2.fault = sp.fault; }
             hipLaunchKernelGGL((actor_fwd_pair_kernel<2, 0, 0>), dim3(tiles, 2 * kCritSplit), blk, 0, sa, sp, sp2, (int)kCritSplit);
         } else if (pair) {
             const ActorFwdArgs af2 = pg_args(true);

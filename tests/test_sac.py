@@ -507,6 +507,45 @@ def test_sac_weight_gradient_table_forms_are_bit_identical(B, E, hidden, monkeyp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,E", [(256, 4), (100, 2), (4096, 2), (37, 1)])
+def test_sac_head_share_meeting_forms_are_bit_identical(B, E, monkeypatch):
+    """The split actor forward's slices meet either by last arriver (shares to memory, acknowledged, an arrival counter, the last one fetches:
+    ERL_SAC_YX=0) or by owner (round 6: {share, nonce} granules, the tile's last-dispatched slice polls and adds in slice order: the default).
+    Same sums in the same order: actions, log-probs and everything downstream -- weights, moments, temperature, objectives -- are the SAME BITS
+    after three steps; no wait timed out (B = 4096: 2048 workgroups, far more than are resident at once)."""
+    from elegantrl_amd import _hip, ops
+    dev = th.device("cuda:0")
+    S, A, hidden = 11, 3, (256, 256)
+    spec = ops.SacSpec(S, A, hidden, E)
+    g = th.Generator(device=dev).manual_seed(11 * B + E)
+    init = [0.05 * th.randn(n, device=dev, generator=g) for n in (spec.actor_count, spec.critic_count, spec.critic_count)]
+    batches = [((th.randn((B, S), device=dev, generator=g), th.randn((B, A), device=dev, generator=g).tanh(), th.randn(B, device=dev, generator=g),
+                 (th.rand(B, device=dev, generator=g) > 0.1).float(), (th.rand(B, device=dev, generator=g) > 0.1).float(),
+                 th.randn((B, S), device=dev, generator=g)), th.randn((B, A), device=dev, generator=g), th.randn((B, A), device=dev, generator=g))
+               for _ in range(3)]
+
+    def run(form):
+        monkeypatch.setenv("ERL_SAC_YX", form)
+        pa, pc, pt = [x.clone() for x in init]
+        alpha = th.full((1,), -1.0, device=dev)
+        mom = [th.zeros_like(pa), th.zeros_like(pa), th.zeros_like(pc), th.zeros_like(pc), th.zeros(1, device=dev), th.zeros(1, device=dev)]
+        objs, out = th.zeros(2, device=dev), []
+        for step, (batch, e_next, e_cur) in enumerate(batches, 1):
+            ops.sac_update(spec, pa, pc, pt, alpha, mom, list(batch), step, gamma=0.97, target_entropy=-float(A), tau=5e-3, lr=1e-3, max_norm=3.0,
+                           objs_out=objs, noises=(e_next, e_cur))
+            out.append(objs.clone())
+        th.cuda.synchronize()
+        _hip.check_async_faults()
+        return [pa, pc, pt, alpha] + mom + out
+
+    ref = run("0")
+    for x, y in zip(ref, run("1")):
+        assert th.equal(x, y)
+    for x, y in zip(ref, run("1")):                               # (twice: the nonce moves on, older granules are never mistaken for new ones)
+        assert th.equal(x, y)
+
+
+@pytest.mark.gpu
 def test_sac_update_with_importance_weights_and_td_errors():
     """prioritised replay through the SAC step (AgentSAC.py:58-62): obj_critic = mean(td_error * is_weight), td_error comes back
     per sample; against oracle/sac_torch.py with the same weights."""
